@@ -1,0 +1,142 @@
+/*
+ * mprime.h — C ABI of the MI355X-native hot path of multiPrime's core step
+ * (degenerate-primer candidate enumeration + mismatch-tolerant coverage scoring).
+ *
+ * The reference (joybio/multiPrime, scripts/multiPrime-core_V20.py, "V20" below) has no
+ * FFI: everything is Python.  This header is the boundary a maintainer would bind with
+ * ctypes from that script: every O(N_sequences) loop of V20 becomes
+ * one call here, the O(1)-per-window control flow stays in Python.
+ *
+ * Two libraries export exactly these symbols:
+ *   multiprime_amd/csrc/libmprime_hip.so   hand-written HIP for gfx950 (the product)
+ *   oracle/_build/libmprime_oracle.so      plain-C restatement of V20 (test infrastructure only)
+ *
+ * Conventions: plain pointers and sizes, caller owns every buffer, the library owns only
+ * the opaque context.  Every function returns MP_OK (0) or a negative MP_ERR_* code and
+ * never throws; mp_last_error() gives a message.  One context per host thread / GPU.
+ *
+ * Encodings
+ *   symbol code   4-bit IUPAC base-set mask: A=1 C=2 G=4 T=8, R=A|G ... ; '-' (and anything
+ *                 V20:453 maps to '-', N included) = 0.
+ *   window words  one (window,row) k-mer = three uint32: b0,b1 = low/high bit of the base
+ *                 index (A=0,C=1,G=2,T=3; 0 where gap), g = gap flag; bit j = window position
+ *                 j (0 = 5' end), k <= MP_MAX_K.  g bit 31 (MP_WIN_SKIP) marks a slot that is
+ *                 not part of the evaluated universe (its window holds an IUPAC code and was
+ *                 handed to the host as an exception, or the row does not exist).
+ *   candidate     k symbol codes (one uint8 each), 5'->3'.
+ *   strict mask   bit j set = a mismatch at 0-based position j disqualifies (V20:1091-1101
+ *                 get_Y; entries outside [0,k) are dropped by the host, as they can never
+ *                 equal a mismatch index).
+ */
+#ifndef MPRIME_H
+#define MPRIME_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MP_MAX_K 28
+#define MP_WIN_SKIP 0x80000000u
+
+#define MP_OK 0
+#define MP_ERR_ARG (-1)          /* bad argument / call order */
+#define MP_ERR_DEVICE (-2)       /* HIP runtime error (message has hipGetErrorString) */
+#define MP_ERR_NOMEM (-3)
+#define MP_ERR_CAPACITY (-4)     /* a caller-sized buffer was too small; message says what is needed */
+#define MP_ERR_SHORT_WINDOW (-5) /* a ragged row leaves fewer than k residues (V20:683-687 falls through
+                                    with a short k-mer there; behaviour of the reference is undefined) */
+
+typedef struct mp_ctx mp_ctx;
+
+/* lifetime ------------------------------------------------------------------------------- */
+int mp_create(int device_ordinal, mp_ctx **out);
+void mp_destroy(mp_ctx *ctx);
+const char *mp_last_error(const mp_ctx *ctx);
+/* "hip" or "oracle" */
+const char *mp_backend_name(void);
+/* Launch every kernel of this context on `hip_stream` (a hipStream_t; NULL = the default
+ * stream).  bench.py passes torch's current stream so that torch.cuda events and RCCL
+ * collectives order with the kernels. */
+int mp_set_stream(mp_ctx *ctx, void *hip_stream);
+
+/* (1) alignment -> device ----------------------------------------------------------------- */
+/* Replaces the per-character work of parse_seq (V20:441-455): `bytes` holds, back to back,
+ * the residue characters of each record (the host has already joined a record's lines and
+ * dropped '>' / '#' lines); row r is bytes[row_off[r] .. row_off[r+1]).  Per character:
+ * upper-case, keep ACGTRYMKSWHBVD, everything else becomes '-' (V20:453).  Rows may be
+ * ragged (unaligned input such as test_data/test.fa). */
+int mp_load_msa(mp_ctx *ctx, const uint8_t *bytes, const int64_t *row_off, int32_t n_rows);
+
+/* Replaces the row scans of seq_attribute (V20:622-627): lead_gap[r] = len - len(lstrip('-')),
+ * rstrip_len[r] = len(rstrip('-')), row_len[r] = len.  Any pointer may be NULL. */
+int mp_row_attributes(mp_ctx *ctx, int32_t *lead_gap, int32_t *rstrip_len, int32_t *row_len);
+
+/* (2) window k-mers ------------------------------------------------------------------------ */
+/* Replaces the slice + edge-gap repair of get_primers (V20:666-687) for every
+ * (window p0+w, row), w in [0,n_windows): the k-mer of row r at window w is stored as window
+ * words.  A k-mer that contains an IUPAC code (before or after repair) is not stored (its slot
+ * gets MP_WIN_SKIP) but appended to the exception list, to be expanded by the host
+ * (degenerate_seq, V20:368-380) and handed back through mp_set_extra_rows.
+ * `v` = --variation: a k-mer with more than v gaps is a "gap row" (V20:689). */
+int mp_build_windows(mp_ctx *ctx, int32_t p0, int32_t n_windows, int32_t k, int32_t v,
+                     int32_t *n_exceptions);
+
+/* Exception list of the last mp_build_windows, sorted by (window, row): ex_codes holds k symbol
+ * codes per exception.  `cap` = capacity of the three arrays in exceptions. */
+int mp_get_exceptions(mp_ctx *ctx, int32_t cap, int32_t *ex_window, int32_t *ex_row, uint8_t *ex_codes);
+
+/* Concrete expansions of exception k-mers with <= v gaps, as extra rows of the evaluated
+ * universe: window[i] ascending (relative to p0), words[3*i..3*i+2] = b0,b1,g. */
+int mp_set_extra_rows(mp_ctx *ctx, int32_t n_extra, const int32_t *window, const uint32_t *words);
+
+/* Parity/debug: window words of rows [row0,row0+n) of window w: out[0..n)=b0, [n..2n)=b1, [2n..3n)=g */
+int mp_get_window_words(mp_ctx *ctx, int32_t w, int32_t row0, int32_t n, uint32_t *out);
+
+/* (3) per-window k-mer histogram ----------------------------------------------------------- */
+/* Replaces the dictionary building of get_primers (V20:689-711: cover / gap_sequence counts
+ * and, through first_row, their first-seen order).  For every window: the distinct window
+ * words over all non-SKIP rows with their multiplicity and the smallest row holding them.
+ * cap_entries bounds the total number of entries over all windows (MP_ERR_CAPACITY if
+ * exceeded; *n_entries then holds the number needed).  want_labels != 0 additionally keeps,
+ * per (window,row), the index of the row's entry inside its window (-1 for SKIP rows) so the
+ * host can rebuild the id lists (non_gap_seq_id / gap_seq_id, V20:698,707). */
+int mp_window_unique(mp_ctx *ctx, int64_t cap_entries, int32_t want_labels, int64_t *n_entries);
+
+/* Entries of window w are [win_off[w], win_off[w+1]); order inside a window is unspecified.
+ * words: b0 at [0,n), b1 at [n,2n), g at [2n,3n) with n = total entries. */
+int mp_get_unique(mp_ctx *ctx, int64_t *win_off, uint32_t *words, int32_t *count, int32_t *first_row);
+int mp_get_labels(mp_ctx *ctx, int32_t w, int32_t *labels);
+
+/* (4) candidate x sequence coverage evaluation ---------------------------------------------- */
+/* Replaces mis_primer_check + Y_distance (V20:1103-1130, 229-233), evaluated per sequence
+ * instead of per distinct k-mer.  For candidate c (window cand_window[c], ascending) and
+ * every row of the universe (non-SKIP rows with <= v gaps, plus the extra rows of that window):
+ *   D = { j : symbol_j not in candidate_j }           ('-' is in no candidate symbol)
+ *   out[3c+0] += |D| == 0                             perfect coverage  (V20:853, :954-956)
+ *   out[3c+1] += 0 < |D| <= v and D & strictF == 0    F_mis_cover       (V20:1123)
+ *   out[3c+2] += 0 < |D| <= v and D & strictR == 0    R_mis_cover       (V20:1127)
+ * One call = one batched launch over all candidates. */
+int mp_eval_candidates(mp_ctx *ctx, int32_t n_cand, const int32_t *cand_window, const uint8_t *cand_codes,
+                       uint32_t strictF, uint32_t strictR, int64_t *out);
+
+/* Device-resident form used by bench.py and the multi-GPU path: upload stages the candidate
+ * tables once; launch enqueues the evaluation on the context's stream and leaves the
+ * [n_cand][3] int64 counters in `device_out` (device memory owned by the caller, e.g. a torch
+ * tensor that is then all-reduced over RCCL).  The oracle treats device_out as host memory. */
+int mp_eval_upload(mp_ctx *ctx, int32_t n_cand, const int32_t *cand_window, const uint8_t *cand_codes,
+                   uint32_t strictF, uint32_t strictR);
+int mp_eval_launch(mp_ctx *ctx, int64_t *device_out);
+
+/* HIP-event timing of the evaluation kernel itself (recorded on the context's stream around
+ * every mp_eval_launch since the last reset): total milliseconds and number of launches. */
+int mp_eval_timing(mp_ctx *ctx, int32_t reset, double *total_ms, int32_t *n_launches);
+
+/* Memory the context holds on the device, in bytes (window words, planes, tables). */
+int mp_device_bytes(mp_ctx *ctx, int64_t *bytes);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MPRIME_H */

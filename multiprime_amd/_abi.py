@@ -1,0 +1,211 @@
+"""ctypes binding of include/mprime.h.
+
+The product loads `csrc/libmprime_hip.so` (hand-written HIP for gfx950) and fails loudly
+when it is missing or cannot create a context on the GPU: there is no CPU fallback.
+`Library(path)` accepts any library exporting the same C ABI; the test-suite uses that to
+drive the host logic with the CPU oracle — the product never does.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+import numpy as np
+
+MP_MAX_K = 28
+MP_WIN_SKIP = 0x80000000
+MP_ERR_CAPACITY = -4
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+HIP_LIB = os.path.join(HERE, "csrc", "libmprime_hip.so")
+
+# every symbol include/mprime.h declares: (name, restype, argtypes)
+_p = C.c_void_p
+SYMBOLS = [
+    ("mp_create", C.c_int, [C.c_int, C.POINTER(_p)]),
+    ("mp_destroy", None, [_p]),
+    ("mp_last_error", C.c_char_p, [_p]),
+    ("mp_backend_name", C.c_char_p, []),
+    ("mp_set_stream", C.c_int, [_p, _p]),
+    ("mp_load_msa", C.c_int, [_p, _p, _p, C.c_int32]),
+    ("mp_row_attributes", C.c_int, [_p, _p, _p, _p]),
+    ("mp_build_windows", C.c_int, [_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.POINTER(C.c_int32)]),
+    ("mp_get_exceptions", C.c_int, [_p, C.c_int32, _p, _p, _p]),
+    ("mp_set_extra_rows", C.c_int, [_p, C.c_int32, _p, _p]),
+    ("mp_get_window_words", C.c_int, [_p, C.c_int32, C.c_int32, C.c_int32, _p]),
+    ("mp_window_unique", C.c_int, [_p, C.c_int64, C.c_int32, C.POINTER(C.c_int64)]),
+    ("mp_get_unique", C.c_int, [_p, _p, _p, _p, _p]),
+    ("mp_get_labels", C.c_int, [_p, C.c_int32, _p]),
+    ("mp_eval_candidates", C.c_int, [_p, C.c_int32, _p, _p, C.c_uint32, C.c_uint32, _p]),
+    ("mp_eval_upload", C.c_int, [_p, C.c_int32, _p, _p, C.c_uint32, C.c_uint32]),
+    ("mp_eval_launch", C.c_int, [_p, _p]),
+    ("mp_eval_timing", C.c_int, [_p, C.c_int32, C.POINTER(C.c_double), C.POINTER(C.c_int32)]),
+    ("mp_device_bytes", C.c_int, [_p, C.POINTER(C.c_int64)]),
+]
+
+
+class MprimeError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__(f"mprime error {code}: {msg}")
+        self.code = code
+
+
+class Library:
+    """A shared library exporting the mprime C ABI."""
+
+    def __init__(self, path: str = HIP_LIB):
+        if not os.path.exists(path):
+            raise MprimeError(-2, f"{path} is missing — build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                                  "(hipcc --offload-arch=gfx950); there is no CPU fallback")
+        self.path = path
+        self.dll = C.CDLL(path)
+        for name, res, args in SYMBOLS:
+            fn = getattr(self.dll, name)     # AttributeError = ABI symbol missing
+            fn.restype = res
+            fn.argtypes = args
+        self.backend = self.dll.mp_backend_name().decode()
+
+    def context(self, device: int = 0) -> "Context":
+        return Context(self, device)
+
+
+def _ptr(a):
+    return a.ctypes.data_as(C.c_void_p) if a is not None else None
+
+
+class Context:
+    """One opaque mp_ctx (one GPU)."""
+
+    def __init__(self, lib: Library, device: int = 0):
+        self.lib = lib
+        self.d = lib.dll
+        h = C.c_void_p()
+        rc = self.d.mp_create(device, C.byref(h))
+        if rc != 0:
+            msg = self.d.mp_last_error(h).decode() if h else "mp_create failed (no usable GPU?)"
+            raise MprimeError(rc, msg)
+        self.h = h
+        self.n_rows = 0
+        self.n_win = 0
+        self.k = 0
+
+    def close(self):
+        if self.h:
+            self.d.mp_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _ck(self, rc):
+        if rc != 0:
+            raise MprimeError(rc, self.d.mp_last_error(self.h).decode())
+
+    def set_stream(self, stream_handle: int):
+        self._ck(self.d.mp_set_stream(self.h, C.c_void_p(stream_handle)))
+
+    # (1)
+    def load_msa(self, data: np.ndarray, row_off: np.ndarray):
+        data = np.ascontiguousarray(data, dtype=np.uint8)
+        row_off = np.ascontiguousarray(row_off, dtype=np.int64)
+        self.n_rows = len(row_off) - 1
+        self._ck(self.d.mp_load_msa(self.h, _ptr(data), _ptr(row_off), self.n_rows))
+
+    def row_attributes(self):
+        lead = np.empty(self.n_rows, np.int32)
+        rstrip = np.empty(self.n_rows, np.int32)
+        rlen = np.empty(self.n_rows, np.int32)
+        self._ck(self.d.mp_row_attributes(self.h, _ptr(lead), _ptr(rstrip), _ptr(rlen)))
+        return lead, rstrip, rlen
+
+    # (2)
+    def build_windows(self, p0: int, n_windows: int, k: int, v: int) -> int:
+        n_ex = C.c_int32(0)
+        self._ck(self.d.mp_build_windows(self.h, p0, n_windows, k, v, C.byref(n_ex)))
+        self.n_win, self.k = n_windows, k
+        return n_ex.value
+
+    def get_exceptions(self, n_ex: int):
+        w = np.empty(max(n_ex, 1), np.int32)
+        r = np.empty(max(n_ex, 1), np.int32)
+        codes = np.empty((max(n_ex, 1), self.k), np.uint8)
+        self._ck(self.d.mp_get_exceptions(self.h, max(n_ex, 1), _ptr(w), _ptr(r), _ptr(codes)))
+        return w[:n_ex], r[:n_ex], codes[:n_ex]
+
+    def set_extra_rows(self, window: np.ndarray, words: np.ndarray):
+        window = np.ascontiguousarray(window, dtype=np.int32)
+        words = np.ascontiguousarray(words, dtype=np.uint32).reshape(-1, 3)
+        self._ck(self.d.mp_set_extra_rows(self.h, len(window), _ptr(window), _ptr(words)))
+
+    def get_window_words(self, w: int, row0: int = 0, n: int | None = None) -> np.ndarray:
+        n = self.n_rows - row0 if n is None else n
+        out = np.empty((3, n), np.uint32)
+        self._ck(self.d.mp_get_window_words(self.h, w, row0, n, _ptr(out)))
+        return out
+
+    # (3)
+    def window_unique(self, want_labels: bool = False, cap_entries: int | None = None):
+        """Returns (win_off[W+1], words[3][n], count[n], first_row[n]) with the entries of
+        every window sorted by first_row (the ABI leaves the order unspecified), and the
+        permutation needed to translate device labels."""
+        cap = cap_entries or max(1 << 16, min(self.n_rows * self.n_win, 1 << 24))
+        n = C.c_int64(0)
+        rc = self.d.mp_window_unique(self.h, cap, int(want_labels), C.byref(n))
+        if rc == MP_ERR_CAPACITY:
+            cap = int(n.value)
+            rc = self.d.mp_window_unique(self.h, cap, int(want_labels), C.byref(n))
+        self._ck(rc)
+        n = int(n.value)
+        off = np.empty(self.n_win + 1, np.int64)
+        words = np.empty((3, max(n, 1)), np.uint32)
+        count = np.empty(max(n, 1), np.int32)
+        first = np.empty(max(n, 1), np.int32)
+        # the C side packs words as [3][n]; allocate exactly so the strides agree
+        wbuf = np.empty(3 * max(n, 1), np.uint32)
+        self._ck(self.d.mp_get_unique(self.h, _ptr(off), _ptr(wbuf), _ptr(count), _ptr(first)))
+        words = wbuf[:3 * n].reshape(3, n) if n else np.zeros((3, 0), np.uint32)
+        count, first = count[:n], first[:n]
+        win_of = np.repeat(np.arange(self.n_win), np.diff(off))
+        order = np.lexsort((first, win_of))
+        self._label_rank = np.empty(n, np.int64)          # device index -> index within window, first-seen order
+        self._label_rank[order] = np.arange(n) - off[win_of[order]]
+        self._off = off
+        return off, words[:, order], count[order], first[order]
+
+    def get_labels(self, w: int) -> np.ndarray:
+        lab = np.empty(self.n_rows, np.int32)
+        self._ck(self.d.mp_get_labels(self.h, w, _ptr(lab)))
+        out = np.full(self.n_rows, -1, np.int64)
+        ok = lab >= 0
+        out[ok] = self._label_rank[self._off[w] + lab[ok]]
+        return out
+
+    # (4)
+    def eval_candidates(self, cand_window, cand_codes, strictF: int, strictR: int) -> np.ndarray:
+        cand_window = np.ascontiguousarray(cand_window, dtype=np.int32)
+        cand_codes = np.ascontiguousarray(cand_codes, dtype=np.uint8).reshape(len(cand_window), self.k)
+        out = np.zeros((len(cand_window), 3), np.int64)
+        self._ck(self.d.mp_eval_candidates(self.h, len(cand_window), _ptr(cand_window), _ptr(cand_codes),
+                                           strictF, strictR, _ptr(out)))
+        return out
+
+    def eval_upload(self, cand_window, cand_codes, strictF: int, strictR: int):
+        cand_window = np.ascontiguousarray(cand_window, dtype=np.int32)
+        cand_codes = np.ascontiguousarray(cand_codes, dtype=np.uint8).reshape(len(cand_window), self.k)
+        self._ck(self.d.mp_eval_upload(self.h, len(cand_window), _ptr(cand_window), _ptr(cand_codes), strictF, strictR))
+
+    def eval_launch(self, out_ptr: int):
+        self._ck(self.d.mp_eval_launch(self.h, C.c_void_p(out_ptr)))
+
+    def eval_timing(self, reset: bool = False):
+        ms, n = C.c_double(0), C.c_int32(0)
+        self._ck(self.d.mp_eval_timing(self.h, int(reset), C.byref(ms), C.byref(n)))
+        return ms.value, n.value
+
+    def device_bytes(self) -> int:
+        b = C.c_int64(0)
+        self._ck(self.d.mp_device_bytes(self.h, C.byref(b)))
+        return b.value

@@ -1,0 +1,104 @@
+"""Per-window string filters of the core step (host side): GC content, low-complexity
+repeats, hairpin, and the 3'-end self-dimer test (V20:387-416, 457-521).
+
+They run once per surviving window on one primer of <= `degeneracy` expansions — O(1) per
+window, which is why they stay on the host.
+"""
+from __future__ import annotations
+
+import re
+from statistics import mean
+
+from .iupac import expand, revcomp
+from .thermo import delta_g, penalty_points
+
+
+def _repeat_patterns():
+    """The ACGT members of the reference's `di_nucleotides` set (V20:196-207): XXXX, (XY)x4 with
+    X != Y, (XYZ)x3 with X != Y and Y != Z (the reference's `i != j != k` is a chained
+    comparison, so X == Z is allowed).  Members containing '#' can never match a primer."""
+    pats = set()
+    for a in "ACGT":
+        pats.add(a * 4)
+        for b in "ACGT":
+            if a != b:
+                pats.add((a + b) * 4)
+            for c in "ACGT":
+                if a != b and b != c:
+                    pats.add((a + b + c) * 3)
+    return pats
+
+
+_REPEATS = re.compile("|".join(sorted(_repeat_patterns())))
+
+
+def gc_fraction(primer: str) -> float:
+    """GC_fraction (V20:401-407): mean over expansions of the 3-decimal GC fraction, 2 decimals.
+    statistics.mean is exact (rational arithmetic), as in the reference."""
+    n = len(primer)
+    vals = [round((s.count("G") + s.count("C")) / n, 3) for s in expand(primer)]
+    return round(mean(vals), 2)
+
+
+def has_repeat(primer: str) -> bool:
+    """di_nucleotide (V20:410-416)."""
+    return any(_REPEATS.search(s) for s in expand(primer))
+
+
+def has_hairpin(primer: str, distance: int) -> bool:
+    """hairpin_check (V20:387-398): a 5-mer whose reverse complement occurs at least `distance`
+    bases downstream."""
+    for n in range(0, len(primer) - 5 - 5 - distance + 1):
+        stems = [revcomp(s) for s in expand(primer[n:n + 5])]
+        for tail in expand(primer[n + 5 + distance:]):
+            for stem in stems:
+                if stem in tail:
+                    return True
+    return False
+
+
+def three_prime_ends(primer: str, num: int = 5, length: int = 14) -> list[str]:
+    """current_end (V20:457-464): expansions of the 3' suffixes of length num .. num+length-1
+    (a suffix longer than the primer is the whole primer again, as Python slicing gives)."""
+    ends = []
+    for i in range(num, num + length):
+        s = primer[-i:]
+        if s:
+            ends.extend(expand(s))
+    return ends
+
+
+def self_dimer(primer: str) -> bool:
+    """dimer_check (V20:487-503): does any 3' end (longest first) find its reverse complement
+    inside an expansion of the primer with Loss >= 3, or dG < -5 with a flush 3' end?"""
+    ends = sorted(three_prime_ends(primer), key=len, reverse=True)
+    members = expand(primer)
+    seen = {}
+    for end in ends:
+        rc = revcomp(end)
+        for p in members:
+            idx = p.find(rc)
+            if idx < 0:
+                continue
+            d2 = len(p) - len(end) - idx
+            loss = penalty_points(len(end), end.count("G") + end.count("C"), 0, d2)
+            if end not in seen:
+                seen[end] = delta_g(end)
+            if loss >= 3 or (seen[end] < -5 and d2 == 0):
+                return True
+    return False
+
+
+def pre_filter(primer: str, gc_range, distance: int):
+    """primer_pre_filter (V20:507-521): the TSV's "Information" column — the GC fraction when
+    the primer is clean, else the '|'-joined reasons."""
+    lo, hi = gc_range
+    info = []
+    gc = gc_fraction(primer)
+    if not float(lo) <= gc <= float(hi):
+        info.append("GC_out_of_range (" + str(gc) + ")")
+    if has_repeat(primer):
+        info.append("di_nucleotide")
+    if has_hairpin(primer, distance):
+        info.append("hairpin")
+    return gc if not info else "|".join(info)

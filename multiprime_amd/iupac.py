@@ -1,0 +1,89 @@
+"""IUPAC symbol tables shared by the host logic and the kernels' encodings.
+
+A symbol is a 4-bit base-set mask (A=1, C=2, G=4, T=8; '-' = 0).  The reference encodes
+the same sets as floating-point "scores" whose sums identify unions (V20:109-110,
+`score_table` / `trans_score_table`); SURVEY §0-6 / Appendix A-9 show the two are
+equivalent, so the host works on masks and only the *order* of an expansion follows the
+reference's `degenerate_base` lists (V20:105-107).
+"""
+from __future__ import annotations
+
+from itertools import product
+
+import numpy as np
+
+BASES = "ACGT"
+MASK = {"-": 0, "A": 1, "C": 2, "G": 4, "T": 8, "R": 5, "Y": 10, "M": 3, "K": 12, "S": 6, "W": 9,
+        "H": 11, "B": 14, "V": 7, "D": 13, "N": 15}
+SYMBOL = {m: s for s, m in MASK.items()}
+# order in which the reference enumerates the members of a degenerate symbol (V20:105-107)
+MEMBERS = {"-": "-", "A": "A", "G": "G", "C": "C", "T": "T", "R": "AG", "Y": "CT", "M": "AC", "K": "GT",
+           "S": "GC", "W": "AT", "H": "ATC", "B": "GTC", "V": "GAC", "D": "GAT", "N": "ATGC"}
+SET_SIZE = {s: max(1, bin(m).count("1")) for s, m in MASK.items()}     # floor(score) in V20:211,215
+_COMP = str.maketrans("ATGCRYMKSWHBVDN", "TACGYRKMSWDVBHN")             # V20:218
+
+MASK_LUT = np.zeros(256, np.uint8)
+for _s, _m in MASK.items():
+    MASK_LUT[ord(_s)] = _m
+SYMBOL_LUT = np.frombuffer("".join(SYMBOL[m] for m in range(16)).encode(), dtype=np.uint8)
+
+
+def expand(seq: str) -> list[str]:
+    """All concrete members of a degenerate string, in the reference's order
+    (itertools.product over per-position member lists, last position fastest; V20:368-380)."""
+    return ["".join(t) for t in product(*(MEMBERS[c] for c in seq))]
+
+
+def degeneracy(seq) -> int:
+    """score_trans (V20:210-211): product of set sizes."""
+    d = 1
+    for c in seq:
+        d *= SET_SIZE[c]
+    return d
+
+
+def n_degenerate(seq) -> int:
+    """dege_number (V20:214-215): number of positions holding more than one base."""
+    return sum(SET_SIZE[c] > 1 for c in seq)
+
+
+def revcomp(seq: str) -> str:
+    return seq.translate(_COMP)[::-1]
+
+
+def codes_of(seq: str) -> np.ndarray:
+    return MASK_LUT[np.frombuffer(seq.encode(), dtype=np.uint8)]
+
+
+def words_of_kmers(chars: np.ndarray) -> np.ndarray:
+    """(n,k) ASCII matrix of concrete k-mers over ACGT- -> (n,3) uint32 window words (mprime.h)."""
+    n, k = chars.shape
+    idx = np.zeros((n, k), np.uint32)
+    idx[chars == ord("C")] = 1
+    idx[chars == ord("G")] = 2
+    idx[chars == ord("T")] = 3
+    gap = (chars == ord("-")).astype(np.uint32)
+    sh = np.arange(k, dtype=np.uint32)[None, :]
+    out = np.empty((n, 3), np.uint32)
+    out[:, 0] = np.bitwise_or.reduce((idx & 1) << sh, axis=1)
+    out[:, 1] = np.bitwise_or.reduce((idx >> 1) << sh, axis=1)
+    out[:, 2] = np.bitwise_or.reduce(gap << sh, axis=1)
+    return out
+
+
+def kmers_of_words(words: np.ndarray, k: int) -> np.ndarray:
+    """(3,n) uint32 window words -> (n,k) ASCII matrix over ACGT-."""
+    sh = np.arange(k, dtype=np.uint32)[None, :]
+    b0 = (words[0][:, None] >> sh) & 1
+    b1 = (words[1][:, None] >> sh) & 1
+    g = (words[2][:, None] >> sh) & 1
+    lut = np.frombuffer(b"ACGT", dtype=np.uint8)
+    ch = lut[(b0 | (b1 << 1)).astype(np.intp)]
+    return np.where(g == 1, np.uint8(ord("-")), ch).astype(np.uint8)
+
+
+def strings_of(chars: np.ndarray) -> list[str]:
+    n, k = chars.shape
+    if n == 0:
+        return []
+    return [s.decode() for s in np.ascontiguousarray(chars).view(f"S{k}").ravel().tolist()] if k else [""] * n

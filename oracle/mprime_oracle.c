@@ -1,0 +1,454 @@
+/*
+ * mprime_oracle.c — CPU restatement of the O(N) loops of multiPrime-core_V20.py ("V20")
+ * behind the C ABI of include/mprime.h.
+ *
+ * TEST INFRASTRUCTURE ONLY.  Nothing in the product (multiprime_amd/) links, loads or calls
+ * this file; only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg do, as the
+ * checker.  It is deliberately written the way the reference is written — strings of
+ * characters, one sequence at a time, set membership for Y_distance — so that it shares no
+ * arithmetic with the bit-plane HIP kernels it checks.  Parity pin: tests/test_oracle_golden.py
+ * compares every function here against traces recorded from the reference itself
+ * (tests/golden/make_golden.py) on all fixtures.
+ *
+ * Each function cites the V20 lines it follows (V20 = /root/reference/scripts/multiPrime-core_V20.py).
+ */
+#include "../include/mprime.h"
+
+#include <ctype.h>
+#include <stdarg.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+struct mp_ctx {
+    char err[512];
+    int32_t n_rows;
+    char **rows;      /* mapped characters, NUL-terminated */
+    int32_t *len;
+    /* windows */
+    int32_t p0, n_win, k, v;
+    char *kmers;      /* [n_win][n_rows][k] characters; kmers[..][0]==0 marks "not stored" (exception) */
+    uint32_t *words;  /* [n_win][3][n_rows] */
+    int32_t n_ex, cap_ex;
+    int32_t *ex_win, *ex_row;
+    char *ex_kmer;    /* [n_ex][k] */
+    /* extra rows */
+    int32_t n_extra;
+    int32_t *extra_win;
+    uint32_t *extra_words;
+    /* unique */
+    int64_t n_ent;
+    int64_t *win_off;
+    uint32_t *u_b0, *u_b1, *u_g;
+    int32_t *u_count, *u_first;
+    int32_t *labels;  /* [n_win][n_rows] or NULL */
+    /* staged candidates */
+    int32_t n_cand;
+    int32_t *cand_win;
+    uint8_t *cand_codes;
+    uint32_t sF, sR;
+    double eval_ms;
+    int32_t eval_n;
+};
+
+static int fail(mp_ctx *c, int code, const char *fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(c->err, sizeof c->err, fmt, ap);
+    va_end(ap);
+    return code;
+}
+
+const char *mp_backend_name(void) { return "oracle"; }
+const char *mp_last_error(const mp_ctx *c) { return c ? c->err : "null context"; }
+int mp_set_stream(mp_ctx *c, void *s) { (void)c; (void)s; return MP_OK; }
+
+int mp_create(int dev, mp_ctx **out) {
+    (void)dev;
+    if (!out) return MP_ERR_ARG;
+    *out = (mp_ctx *)calloc(1, sizeof(mp_ctx));
+    return *out ? MP_OK : MP_ERR_NOMEM;
+}
+
+static void free_windows(mp_ctx *c) {
+    free(c->kmers); free(c->words); free(c->ex_win); free(c->ex_row); free(c->ex_kmer);
+    free(c->extra_win); free(c->extra_words);
+    free(c->win_off); free(c->u_b0); free(c->u_b1); free(c->u_g); free(c->u_count); free(c->u_first);
+    free(c->labels);
+    c->kmers = NULL; c->words = NULL; c->ex_win = c->ex_row = NULL; c->ex_kmer = NULL;
+    c->extra_win = NULL; c->extra_words = NULL; c->win_off = NULL;
+    c->u_b0 = c->u_b1 = c->u_g = NULL; c->u_count = c->u_first = NULL; c->labels = NULL;
+    c->n_ex = c->cap_ex = c->n_extra = 0; c->n_ent = 0; c->n_win = 0;
+}
+
+static void free_rows(mp_ctx *c) {
+    if (c->rows) for (int32_t r = 0; r < c->n_rows; r++) free(c->rows[r]);
+    free(c->rows); free(c->len);
+    c->rows = NULL; c->len = NULL; c->n_rows = 0;
+}
+
+void mp_destroy(mp_ctx *c) {
+    if (!c) return;
+    free_windows(c); free_rows(c);
+    free(c->cand_win); free(c->cand_codes);
+    free(c);
+}
+
+/* V20:453  sequence = re.sub("[^ACGTRYMKSWHBVD]", "-", i.strip().upper()) */
+static char map_char(unsigned char ch) {
+    int u = toupper(ch);
+    return (u && strchr("ACGTRYMKSWHBVD", u)) ? (char)u : '-';
+}
+
+int mp_load_msa(mp_ctx *c, const uint8_t *bytes, const int64_t *off, int32_t n_rows) {
+    if (!c || !bytes || !off || n_rows <= 0) return c ? fail(c, MP_ERR_ARG, "mp_load_msa: bad arguments") : MP_ERR_ARG;
+    free_windows(c); free_rows(c);
+    c->rows = (char **)calloc((size_t)n_rows, sizeof(char *));
+    c->len = (int32_t *)calloc((size_t)n_rows, sizeof(int32_t));
+    if (!c->rows || !c->len) return fail(c, MP_ERR_NOMEM, "out of memory");
+    c->n_rows = n_rows;
+    for (int32_t r = 0; r < n_rows; r++) {
+        int64_t n = off[r + 1] - off[r];
+        if (n < 0 || n > 0x7fffffff) return fail(c, MP_ERR_ARG, "row %d has bad length", r);
+        c->rows[r] = (char *)malloc((size_t)n + 1);
+        if (!c->rows[r]) return fail(c, MP_ERR_NOMEM, "out of memory");
+        for (int64_t i = 0; i < n; i++) c->rows[r][i] = map_char(bytes[off[r] + i]);
+        c->rows[r][n] = 0;
+        c->len[r] = (int32_t)n;
+    }
+    return MP_OK;
+}
+
+/* V20:625-627  start = len - len(lstrip("-")), stop = len(rstrip("-")) */
+int mp_row_attributes(mp_ctx *c, int32_t *lead, int32_t *rstrip, int32_t *rowlen) {
+    if (!c || !c->rows) return c ? fail(c, MP_ERR_ARG, "no alignment loaded") : MP_ERR_ARG;
+    for (int32_t r = 0; r < c->n_rows; r++) {
+        const char *s = c->rows[r];
+        int32_t n = c->len[r], a = 0, b = n;
+        while (a < n && s[a] == '-') a++;
+        while (b > 0 && s[b - 1] == '-') b--;
+        if (lead) lead[r] = a;
+        if (rstrip) rstrip[r] = b;
+        if (rowlen) rowlen[r] = n;
+    }
+    return MP_OK;
+}
+
+/* ungapped characters of s[a:b) into dst, returns their number (V20:674 / :680 .replace("-", "")) */
+static int32_t ungapped(const char *s, int32_t a, int32_t b, char *dst) {
+    int32_t n = 0;
+    for (int32_t i = a; i < b; i++) if (s[i] != '-') dst[n++] = s[i];
+    return n;
+}
+
+/* V20:666-687: the k-mer of one sequence at window position p, with edge-gap repair.
+ * Returns the length of the result (== k unless the row is too short, V20:683-687). */
+static int32_t window_kmer(const char *s, int32_t len, int32_t p, int32_t k, char *buf, char *scratch) {
+    int32_t m = len - p;
+    if (m < 0) m = 0;
+    if (m > k) m = k;
+    memcpy(buf, s + (p < len ? p : len), (size_t)m);   /* V20:666 slice (upper() is a no-op after :453) */
+    int32_t n = m;
+    int all_gap = (m == k);
+    for (int32_t i = 0; i < m && all_gap; i++) if (buf[i] != '-') all_gap = 0;
+    int32_t left_end = p < len ? p : len;              /* s[0:p] */
+    if (!all_gap) {                                      /* V20:668-670 */
+        if (n > 0 && buf[0] == '-') {                    /* V20:671 */
+            int32_t run = 0;
+            while (run < n && buf[run] == '-') run++;    /* :672-673 */
+            int32_t nl = ungapped(s, 0, left_end, scratch);          /* :674 */
+            if (nl >= run)                               /* :675 */
+                memcpy(buf, scratch + nl - run, (size_t)run);        /* :676 left_seq[-run:] + sequence_narrow */
+        }
+        if (n > 0 && buf[n - 1] == '-') {                /* V20:677 */
+            int32_t run = 0;
+            while (run < n && buf[n - 1 - run] == '-') run++;        /* :678-679 */
+            int32_t a = p + k < len ? p + k : len;
+            int32_t nr = ungapped(s, a, len, scratch);   /* :680 */
+            if (nr >= run) memcpy(buf + n - run, scratch, (size_t)run);   /* :681-682 */
+        }
+    }
+    if (n < k) {                                         /* V20:683 */
+        int32_t need = k - n;
+        int32_t nl = ungapped(s, 0, left_end, scratch);  /* :685 */
+        if (nl >= need) {                                /* :686-687 */
+            memmove(buf + need, buf, (size_t)n);
+            memcpy(buf, scratch + nl - need, (size_t)need);
+            n = k;
+        }
+    }
+    return n;
+}
+
+static int base_index(char ch) { return ch == 'A' ? 0 : ch == 'C' ? 1 : ch == 'G' ? 2 : ch == 'T' ? 3 : -1; }
+
+static uint8_t iupac_code(char ch) {
+    switch (ch) {
+    case 'A': return 1; case 'C': return 2; case 'G': return 4; case 'T': return 8;
+    case 'R': return 1 | 4; case 'Y': return 2 | 8; case 'M': return 1 | 2; case 'K': return 4 | 8;
+    case 'S': return 4 | 2; case 'W': return 1 | 8; case 'H': return 1 | 8 | 2; case 'B': return 4 | 8 | 2;
+    case 'V': return 4 | 1 | 2; case 'D': return 4 | 1 | 8; case 'N': return 15;
+    default: return 0;
+    }
+}
+
+int mp_build_windows(mp_ctx *c, int32_t p0, int32_t n_win, int32_t k, int32_t v, int32_t *n_exc) {
+    if (!c || !c->rows) return c ? fail(c, MP_ERR_ARG, "no alignment loaded") : MP_ERR_ARG;
+    if (k < 2 || k > MP_MAX_K || n_win <= 0 || p0 < 0 || v < 0) return fail(c, MP_ERR_ARG, "bad window arguments (k=%d)", k);
+    free_windows(c);
+    int32_t N = c->n_rows, maxlen = 0;
+    for (int32_t r = 0; r < N; r++) if (c->len[r] > maxlen) maxlen = c->len[r];
+    c->p0 = p0; c->n_win = n_win; c->k = k; c->v = v;
+    c->kmers = (char *)calloc((size_t)n_win * N * k, 1);
+    c->words = (uint32_t *)calloc((size_t)n_win * 3 * N, sizeof(uint32_t));
+    char *scratch = (char *)malloc((size_t)maxlen + 1);
+    char buf[2 * MP_MAX_K + 4];
+    if (!c->kmers || !c->words || !scratch) { free(scratch); return fail(c, MP_ERR_NOMEM, "out of memory"); }
+    for (int32_t w = 0; w < n_win; w++) {
+        for (int32_t r = 0; r < N; r++) {
+            int32_t n = window_kmer(c->rows[r], c->len[r], p0 + w, k, buf, scratch);
+            if (n < k) { free(scratch); return fail(c, MP_ERR_SHORT_WINDOW, "row %d has fewer than %d residues at window %d", r, k, p0 + w); }
+            uint32_t b0 = 0, b1 = 0, g = 0;
+            int iupac = 0;
+            for (int32_t j = 0; j < k; j++) {
+                int bi = base_index(buf[j]);
+                if (buf[j] == '-') g |= 1u << j;
+                else if (bi < 0) iupac = 1;
+                else { b0 |= (uint32_t)(bi & 1) << j; b1 |= (uint32_t)(bi >> 1) << j; }
+            }
+            uint32_t *W = c->words + (size_t)w * 3 * N;
+            if (iupac) {
+                if (c->n_ex == c->cap_ex) {
+                    c->cap_ex = c->cap_ex ? 2 * c->cap_ex : 1024;
+                    c->ex_win = (int32_t *)realloc(c->ex_win, sizeof(int32_t) * c->cap_ex);
+                    c->ex_row = (int32_t *)realloc(c->ex_row, sizeof(int32_t) * c->cap_ex);
+                    c->ex_kmer = (char *)realloc(c->ex_kmer, (size_t)c->cap_ex * k);
+                }
+                c->ex_win[c->n_ex] = w; c->ex_row[c->n_ex] = r;
+                memcpy(c->ex_kmer + (size_t)c->n_ex * k, buf, (size_t)k);
+                c->n_ex++;
+                W[r] = 0; W[N + r] = 0; W[2 * N + r] = MP_WIN_SKIP | ((1u << k) - 1);
+            } else {
+                memcpy(c->kmers + ((size_t)w * N + r) * k, buf, (size_t)k);
+                W[r] = b0; W[N + r] = b1; W[2 * N + r] = g;
+            }
+        }
+    }
+    free(scratch);
+    if (n_exc) *n_exc = c->n_ex;
+    return MP_OK;
+}
+
+int mp_get_exceptions(mp_ctx *c, int32_t cap, int32_t *ew, int32_t *er, uint8_t *codes) {
+    if (!c || !c->words) return c ? fail(c, MP_ERR_ARG, "no windows built") : MP_ERR_ARG;
+    if (cap < c->n_ex) return fail(c, MP_ERR_CAPACITY, "exception buffer too small: need %d", c->n_ex);
+    for (int32_t i = 0; i < c->n_ex; i++) {
+        ew[i] = c->ex_win[i]; er[i] = c->ex_row[i];
+        for (int32_t j = 0; j < c->k; j++) codes[(size_t)i * c->k + j] = iupac_code(c->ex_kmer[(size_t)i * c->k + j]);
+    }
+    return MP_OK;
+}
+
+int mp_set_extra_rows(mp_ctx *c, int32_t n, const int32_t *win, const uint32_t *words) {
+    if (!c || !c->words) return c ? fail(c, MP_ERR_ARG, "no windows built") : MP_ERR_ARG;
+    free(c->extra_win); free(c->extra_words);
+    c->extra_win = NULL; c->extra_words = NULL; c->n_extra = 0;
+    if (n <= 0) return MP_OK;
+    for (int32_t i = 0; i < n; i++) {
+        if (win[i] < 0 || win[i] >= c->n_win || (i && win[i] < win[i - 1])) return fail(c, MP_ERR_ARG, "extra rows must be sorted by window");
+    }
+    c->extra_win = (int32_t *)malloc(sizeof(int32_t) * n);
+    c->extra_words = (uint32_t *)malloc(sizeof(uint32_t) * 3 * n);
+    memcpy(c->extra_win, win, sizeof(int32_t) * n);
+    memcpy(c->extra_words, words, sizeof(uint32_t) * 3 * n);
+    c->n_extra = n;
+    return MP_OK;
+}
+
+int mp_get_window_words(mp_ctx *c, int32_t w, int32_t row0, int32_t n, uint32_t *out) {
+    if (!c || !c->words) return c ? fail(c, MP_ERR_ARG, "no windows built") : MP_ERR_ARG;
+    if (w < 0 || w >= c->n_win || row0 < 0 || n < 0 || row0 + n > c->n_rows) return fail(c, MP_ERR_ARG, "bad range");
+    const uint32_t *W = c->words + (size_t)w * 3 * c->n_rows;
+    for (int p = 0; p < 3; p++) memcpy(out + (size_t)p * n, W + (size_t)p * c->n_rows + row0, sizeof(uint32_t) * n);
+    return MP_OK;
+}
+
+/* ---- per-window histogram: V20:689-711 (cover[i] += 1 / gap_sequence[sequence] += 1) -------- */
+typedef struct { uint32_t b0, b1, g; int32_t row; } keyrow;
+
+static int cmp_keyrow(const void *a, const void *b) {
+    const keyrow *x = (const keyrow *)a, *y = (const keyrow *)b;
+    if (x->g != y->g) return x->g < y->g ? -1 : 1;
+    if (x->b1 != y->b1) return x->b1 < y->b1 ? -1 : 1;
+    if (x->b0 != y->b0) return x->b0 < y->b0 ? -1 : 1;
+    return x->row < y->row ? -1 : x->row > y->row;
+}
+
+typedef struct { uint32_t b0, b1, g; int32_t count, first; } uent;
+
+static int cmp_first(const void *a, const void *b) {
+    const uent *x = (const uent *)a, *y = (const uent *)b;
+    return x->first < y->first ? -1 : x->first > y->first;
+}
+
+int mp_window_unique(mp_ctx *c, int64_t cap, int32_t want_labels, int64_t *n_entries) {
+    if (!c || !c->words) return c ? fail(c, MP_ERR_ARG, "no windows built") : MP_ERR_ARG;
+    int32_t N = c->n_rows, W = c->n_win;
+    free(c->win_off); free(c->u_b0); free(c->u_b1); free(c->u_g); free(c->u_count); free(c->u_first); free(c->labels);
+    c->labels = NULL;
+    keyrow *kr = (keyrow *)malloc(sizeof(keyrow) * (size_t)N);
+    uent *ue = (uent *)malloc(sizeof(uent) * (size_t)N);
+    int64_t capn = 1024, n = 0;
+    uent *all = (uent *)malloc(sizeof(uent) * (size_t)capn);
+    c->win_off = (int64_t *)calloc((size_t)W + 1, sizeof(int64_t));
+    if (want_labels) c->labels = (int32_t *)malloc(sizeof(int32_t) * (size_t)W * N);
+    int32_t *slot_of_sorted = (int32_t *)malloc(sizeof(int32_t) * (size_t)N);
+    for (int32_t w = 0; w < W; w++) {
+        const uint32_t *Wd = c->words + (size_t)w * 3 * N;
+        int32_t m = 0;
+        for (int32_t r = 0; r < N; r++) {
+            if (c->labels) c->labels[(size_t)w * N + r] = -1;
+            if (Wd[2 * N + r] & MP_WIN_SKIP) continue;
+            kr[m].b0 = Wd[r]; kr[m].b1 = Wd[N + r]; kr[m].g = Wd[2 * N + r]; kr[m].row = r; m++;
+        }
+        qsort(kr, (size_t)m, sizeof(keyrow), cmp_keyrow);
+        int32_t u = 0;
+        for (int32_t i = 0; i < m; i++) {
+            if (i == 0 || kr[i].b0 != kr[i - 1].b0 || kr[i].b1 != kr[i - 1].b1 || kr[i].g != kr[i - 1].g) {
+                ue[u].b0 = kr[i].b0; ue[u].b1 = kr[i].b1; ue[u].g = kr[i].g; ue[u].count = 0; ue[u].first = kr[i].row; u++;
+            }
+            ue[u - 1].count++;
+        }
+        qsort(ue, (size_t)u, sizeof(uent), cmp_first);   /* first-seen order = dict insertion order */
+        if (c->labels) {
+            /* label = index of the row's entry in first-seen order */
+            for (int32_t e = 0; e < u; e++) slot_of_sorted[e] = 0;
+            for (int32_t i = 0; i < m; i++) {
+                /* binary search entry by key among ue (sorted by first): linear is fine for an oracle */
+                for (int32_t e = 0; e < u; e++)
+                    if (ue[e].b0 == kr[i].b0 && ue[e].b1 == kr[i].b1 && ue[e].g == kr[i].g) { c->labels[(size_t)w * N + kr[i].row] = e; break; }
+            }
+        }
+        if (n + u > capn) { while (n + u > capn) capn *= 2; all = (uent *)realloc(all, sizeof(uent) * (size_t)capn); }
+        memcpy(all + n, ue, sizeof(uent) * (size_t)u);
+        n += u;
+        c->win_off[w + 1] = n;
+    }
+    free(kr); free(ue); free(slot_of_sorted);
+    if (n_entries) *n_entries = n;
+    if (n > cap) { free(all); c->n_ent = 0; return fail(c, MP_ERR_CAPACITY, "unique table needs %lld entries", (long long)n); }
+    c->n_ent = n;
+    c->u_b0 = (uint32_t *)malloc(sizeof(uint32_t) * (size_t)(n + 1)); c->u_b1 = (uint32_t *)malloc(sizeof(uint32_t) * (size_t)(n + 1));
+    c->u_g = (uint32_t *)malloc(sizeof(uint32_t) * (size_t)(n + 1));
+    c->u_count = (int32_t *)malloc(sizeof(int32_t) * (size_t)(n + 1)); c->u_first = (int32_t *)malloc(sizeof(int32_t) * (size_t)(n + 1));
+    for (int64_t i = 0; i < n; i++) {
+        c->u_b0[i] = all[i].b0; c->u_b1[i] = all[i].b1; c->u_g[i] = all[i].g; c->u_count[i] = all[i].count; c->u_first[i] = all[i].first;
+    }
+    free(all);
+    return MP_OK;
+}
+
+int mp_get_unique(mp_ctx *c, int64_t *win_off, uint32_t *words, int32_t *count, int32_t *first_row) {
+    if (!c || !c->win_off) return c ? fail(c, MP_ERR_ARG, "mp_window_unique has not run") : MP_ERR_ARG;
+    int64_t n = c->n_ent;
+    memcpy(win_off, c->win_off, sizeof(int64_t) * ((size_t)c->n_win + 1));
+    memcpy(words, c->u_b0, sizeof(uint32_t) * (size_t)n);
+    memcpy(words + n, c->u_b1, sizeof(uint32_t) * (size_t)n);
+    memcpy(words + 2 * n, c->u_g, sizeof(uint32_t) * (size_t)n);
+    memcpy(count, c->u_count, sizeof(int32_t) * (size_t)n);
+    memcpy(first_row, c->u_first, sizeof(int32_t) * (size_t)n);
+    return MP_OK;
+}
+
+int mp_get_labels(mp_ctx *c, int32_t w, int32_t *labels) {
+    if (!c || !c->labels) return c ? fail(c, MP_ERR_ARG, "labels were not requested") : MP_ERR_ARG;
+    if (w < 0 || w >= c->n_win) return fail(c, MP_ERR_ARG, "bad window");
+    memcpy(labels, c->labels + (size_t)w * c->n_rows, sizeof(int32_t) * (size_t)c->n_rows);
+    return MP_OK;
+}
+
+/* ---- candidate x sequence evaluation: V20:1103-1130 + Y_distance V20:229-233 --------------- */
+/* Y_distance: position j is a mismatch iff the concrete symbol is not in the IUPAC set of the
+ * primer symbol; '-' is in no set (verified exhaustively against score_table). */
+static void eval_one(const uint8_t *cand, int32_t k, int32_t v, uint32_t sF, uint32_t sR,
+                     const char *kmer, int64_t *out) {
+    int32_t nd = 0, gaps = 0;
+    uint32_t D = 0;
+    for (int32_t j = 0; j < k; j++) {
+        if (kmer[j] == '-') gaps++;
+        int bi = base_index(kmer[j]);
+        int in_set = bi >= 0 && (cand[j] >> bi & 1);
+        if (!in_set) { nd++; D |= 1u << j; }              /* m_dist, V20:231 */
+    }
+    if (gaps > v) return;                                  /* not in `cover` (V20:689) */
+    if (nd == 0) { out[0]++; return; }                     /* in optimal_primer_set, V20:1105-1106 */
+    if (nd > v) return;                                    /* V20:1114 */
+    if (!(D & sF)) out[1]++;                               /* V20:1120-1123 */
+    if (!(D & sR)) out[2]++;                               /* V20:1124-1127 */
+}
+
+static void words_to_kmer(uint32_t b0, uint32_t b1, uint32_t g, int32_t k, char *kmer) {
+    for (int32_t j = 0; j < k; j++)
+        kmer[j] = (g >> j & 1) ? '-' : "ACGT"[(b0 >> j & 1) | (b1 >> j & 1) << 1];
+}
+
+static int eval_all(mp_ctx *c, int32_t n_cand, const int32_t *cw, const uint8_t *codes, uint32_t sF, uint32_t sR, int64_t *out) {
+    int32_t N = c->n_rows, k = c->k;
+    char km[MP_MAX_K + 1];
+    int32_t e0 = 0;
+    for (int32_t i = 0; i < n_cand; i++) {
+        int32_t w = cw[i];
+        if (w < 0 || w >= c->n_win || (i && w < cw[i - 1])) return fail(c, MP_ERR_ARG, "candidate windows must be ascending and in range");
+        int64_t *o = out + 3 * (size_t)i;
+        o[0] = o[1] = o[2] = 0;
+        for (int32_t r = 0; r < N; r++) {
+            const char *kmer = c->kmers + ((size_t)w * N + r) * k;
+            if (!kmer[0]) continue;                       /* exception slot */
+            eval_one(codes + (size_t)i * k, k, c->v, sF, sR, kmer, o);
+        }
+        while (e0 < c->n_extra && c->extra_win[e0] < w) e0++;
+        for (int32_t e = e0; e < c->n_extra && c->extra_win[e] == w; e++) {
+            words_to_kmer(c->extra_words[3 * e], c->extra_words[3 * e + 1], c->extra_words[3 * e + 2], k, km);
+            eval_one(codes + (size_t)i * k, k, c->v, sF, sR, km, o);
+        }
+    }
+    return MP_OK;
+}
+
+int mp_eval_candidates(mp_ctx *c, int32_t n_cand, const int32_t *cw, const uint8_t *codes,
+                       uint32_t sF, uint32_t sR, int64_t *out) {
+    if (!c || !c->words) return c ? fail(c, MP_ERR_ARG, "no windows built") : MP_ERR_ARG;
+    if (n_cand < 0 || (n_cand && (!cw || !codes || !out))) return fail(c, MP_ERR_ARG, "bad arguments");
+    return eval_all(c, n_cand, cw, codes, sF, sR, out);
+}
+
+int mp_eval_upload(mp_ctx *c, int32_t n_cand, const int32_t *cw, const uint8_t *codes, uint32_t sF, uint32_t sR) {
+    if (!c || !c->words) return c ? fail(c, MP_ERR_ARG, "no windows built") : MP_ERR_ARG;
+    free(c->cand_win); free(c->cand_codes);
+    c->cand_win = (int32_t *)malloc(sizeof(int32_t) * (size_t)(n_cand + 1));
+    c->cand_codes = (uint8_t *)malloc((size_t)(n_cand + 1) * c->k);
+    memcpy(c->cand_win, cw, sizeof(int32_t) * (size_t)n_cand);
+    memcpy(c->cand_codes, codes, (size_t)n_cand * c->k);
+    c->n_cand = n_cand; c->sF = sF; c->sR = sR;
+    return MP_OK;
+}
+
+int mp_eval_launch(mp_ctx *c, int64_t *out) {
+    if (!c || !c->cand_win) return c ? fail(c, MP_ERR_ARG, "mp_eval_upload has not run") : MP_ERR_ARG;
+    c->eval_n++;
+    return eval_all(c, c->n_cand, c->cand_win, c->cand_codes, c->sF, c->sR, out);
+}
+
+int mp_eval_timing(mp_ctx *c, int32_t reset, double *ms, int32_t *n) {
+    if (!c) return MP_ERR_ARG;
+    if (ms) *ms = c->eval_ms;
+    if (n) *n = c->eval_n;
+    if (reset) { c->eval_ms = 0; c->eval_n = 0; }
+    return MP_OK;
+}
+
+int mp_device_bytes(mp_ctx *c, int64_t *bytes) {
+    if (!c || !bytes) return MP_ERR_ARG;
+    *bytes = 0;
+    return MP_OK;
+}
