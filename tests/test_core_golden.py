@@ -1,0 +1,75 @@
+"""Host logic (multiprime_amd.core) driven through the C ABI, against the reference's own
+outputs recorded in tests/golden/ (TSV byte for byte, JSON side files semantically).
+
+On CPU the ABI is served by the oracle library (test infrastructure); the `gpu` variant at the
+bottom runs the same comparison through the HIP library on a real MI355X.
+"""
+import json
+import os
+
+import pytest
+
+from conftest import GOLDEN, golden_input, load_gz_json
+from multiprime_amd.core import NN_degenerate
+
+FAST = ["syn_iupac", "syn_v2", "syn_ragged", "syn_v3_k27", "ivc_v0", "ivc_v1", "ivc_v2",
+        "msa1000_k18_d64", "msa1000_k20_d64", "msa1000_k22_d64", "msa1000_k18_d10"]
+FULL = FAST + ["cluster0_v1", "cluster0_v2", "testfa"]
+
+
+def canon_noncov(d):
+    return {str(k): [{km: sorted(ids) for km, ids in sorted(side.items())} for side in v] for k, v in d.items()}
+
+
+def canon_gap(d):
+    return {str(k): {km: list(ids) for km, ids in sorted(v.items())} for k, v in d.items()}
+
+
+def run_fixture(name, lib, tmp_path, **kw):
+    meta = load_gz_json(name + ".trace.json.gz")["meta"]
+    fl = meta["flags"]
+    inp = tmp_path / (name + ".fa")
+    inp.write_bytes(golden_input(meta["input"]))
+    out = tmp_path / (name + ".out")
+    app = NN_degenerate(seq_file=str(inp), primer_length=fl["l"], coverage=fl["f"], number_of_dege_bases=fl["n"],
+                        score_of_dege_bases=fl["d"], raw_entropy_threshold=fl["e"], product_len=fl["s"],
+                        position=fl["c"], variation=fl["v"], distance=fl["a"], GC=fl["g"], nproc=1,
+                        outfile=str(out), library=lib, **kw)
+    assert (int(app.start_position), int(app.stop_position)) == (meta["start"], meta["stop"])
+    assert app.total_sequence_number == meta["n_seq"]
+    app.run()
+    return app, out
+
+
+def check_outputs(name, out):
+    with open(os.path.join(GOLDEN, name + ".tsv"), "rb") as f:
+        want = f.read()
+    assert out.read_bytes() == want, "TSV differs from the reference's"
+    got_nc = canon_noncov(json.load(open(str(out) + ".non_coverage_seq_id_json")))
+    assert got_nc == load_gz_json(name + ".noncov.json.gz")
+    got_gap = canon_gap(json.load(open(str(out) + ".gap_seq_id_json")))
+    assert got_gap == load_gz_json(name + ".gap.json.gz")
+
+
+@pytest.mark.parametrize("name", FULL)
+def test_host_logic_matches_reference(name, oracle_lib, tmp_path):
+    _, out = run_fixture(name, oracle_lib, tmp_path)
+    check_outputs(name, out)
+
+
+def test_region_too_short_exits_like_reference(oracle_lib, tmp_path, capsys):
+    inp = tmp_path / "short.fa"
+    inp.write_bytes(b">a\nACGTACGTACGTACGTACGTACGTACGT\n>b\nACGTACGTACGTACGTACGTACGTACGT\n")
+    with pytest.raises(SystemExit) as e:
+        NN_degenerate(seq_file=str(inp), primer_length=18, coverage=0.8, product_len=100, position="1,2,-1",
+                      variation=1, GC="0.2,0.7", outfile=str(tmp_path / "o"), library=oracle_lib)
+    assert e.value.code == 1                                   # V20:635-638
+    assert "Non candidate primers" in capsys.readouterr().out
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", FULL)
+def test_hip_path_matches_reference(name, hip_lib, tmp_path):
+    assert hip_lib.backend == "hip"
+    _, out = run_fixture(name, hip_lib, tmp_path)
+    check_outputs(name, out)

@@ -1,0 +1,67 @@
+"""Pins the CPU oracle (oracle/mprime_oracle.c) to the reference: every intermediate the C ABI
+produces is compared with what multiPrime-core_V20.py computed internally on the same input
+(traces recorded by tests/golden/make_golden.py): the per-window `cover` and `gap_sequence`
+dictionaries in insertion order, cover_number, and the result of every mis_primer_check call.
+"""
+import numpy as np
+import pytest
+
+from conftest import golden_input, load_gz_json
+from multiprime_amd import iupac
+from multiprime_amd.core import NN_degenerate
+
+NAMES = ["syn_iupac", "syn_v2", "syn_ragged", "syn_v3_k27", "ivc_v1", "msa1000_k18_d64", "msa1000_k22_d64",
+         "cluster0_v2"]
+
+
+def open_fixture(name, lib, tmp_path):
+    tr = load_gz_json(name + ".trace.json.gz")
+    fl = tr["meta"]["flags"]
+    inp = tmp_path / (name + ".fa")
+    inp.write_bytes(golden_input(tr["meta"]["input"]))
+    app = NN_degenerate(seq_file=str(inp), primer_length=fl["l"], coverage=fl["f"], number_of_dege_bases=fl["n"],
+                        score_of_dege_bases=fl["d"], raw_entropy_threshold=fl["e"], product_len=fl["s"],
+                        position=fl["c"], variation=fl["v"], distance=fl["a"], GC=fl["g"], nproc=1,
+                        outfile=str(tmp_path / "out"), library=lib, write_json=False)
+    return app, tr
+
+
+def check_against_trace(app, tr):
+    k = app.primer_length
+    off, strs, count, first, gaps, exc = app._device_tables()
+    p0 = int(app.start_position)
+    cand_w, cand_p, want = [], [], []
+    n_tables = 0
+    for pos, rec in sorted(tr["windows"].items(), key=lambda kv: int(kv[0])):
+        if "cover" not in rec:
+            continue
+        w = int(pos) - p0
+        win = app._tables_of(w, off, strs, count, first, gaps, exc)
+        assert list(win.cover.items()) == [tuple(x) for x in rec["cover"]], f"cover dict at {pos}"
+        assert list(win.gap.items()) == [tuple(x) for x in rec["gap"]], f"gap_sequence at {pos}"
+        assert win.cover_number == rec["cover_number"] and win.gap_number == rec["gap_number"]
+        n_tables += 1
+        for primer, F, R, perfect, _ in rec["mis"]:
+            cand_w.append(w)
+            cand_p.append(primer)
+            want.append((perfect, F, R))
+    assert n_tables > 0
+    order = np.argsort(np.asarray(cand_w), kind="stable")
+    codes = iupac.MASK_LUT[np.frombuffer("".join(cand_p).encode(), np.uint8)].reshape(len(cand_p), k)
+    got = app.ctx.eval_candidates(np.asarray(cand_w, np.int32)[order], codes[order], app._sF, app._sR)
+    assert got.tolist() == [list(want[i]) for i in order]
+    return len(cand_w)
+
+
+@pytest.mark.parametrize("name", NAMES)
+def test_oracle_matches_reference_internals(name, oracle_lib, tmp_path):
+    app, tr = open_fixture(name, oracle_lib, tmp_path)
+    n = check_against_trace(app, tr)
+    assert n == tr["meta"]["n_mis_calls"]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", NAMES)
+def test_hip_matches_reference_internals(name, hip_lib, tmp_path):
+    app, tr = open_fixture(name, hip_lib, tmp_path)
+    check_against_trace(app, tr)
