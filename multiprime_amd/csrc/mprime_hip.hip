@@ -1,0 +1,1048 @@
+// mprime_hip.hip — hand-written HIP kernels (gfx950 / MI355X, wave64) and the C ABI of
+// include/mprime.h for the hot path of multiPrime's core step.
+//
+// Data layout in HBM:
+//   planes  [n_chunks][4][Npad] u32   one-hot base-set bit planes (A,C,G,T membership) of 32
+//                                     alignment columns per word, sequences along the fastest
+//                                     axis, so a wave reads 64 consecutive sequences per load
+//   cum     [n_chunks+1][Npad] u32    residues (non-gap symbols) left of each 32-column chunk
+//   ung     [N][ustride] u32          gap-free residue codes, 8 nibbles per word, row-major
+//                                     (only touched by the edge-gap repair path)
+//   win     [W][3][Npad] u32          the k-mer of every (window, sequence) after repair:
+//                                     b0,b1 (2-bit base) and g (gap flag) words, k bits each
+//   uniq    per-window histogram entries (words, count, first row), labels [W][Npad]
+//
+// Kernels: pack_kernel, row_scan_kernel, ungap_kernel (mp_load_msa), build_windows_kernel
+// (V20:666-687), unique_kernel (V20:689-711, LDS hash table per window), eval_kernel
+// (V20:1103-1130 + 229-233; the candidate x sequence evaluation the benchmark measures).
+// No MFMA: this is bit-mask work bounded by HBM / integer ALU.  gfx950 only.
+
+#include "../../include/mprime.h"
+
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <numeric>
+#include <vector>
+
+namespace {
+
+constexpr int kBlock = 256;
+constexpr uint32_t kEmpty = 0xFFFFFFFFu;
+constexpr int kHashSlots = 4096;          // LDS hash table slots per window (unique_kernel)
+constexpr int kHashLimit = 3584;          // load limit before the window is handed to the global-table path
+constexpr int kEvalCC = 8;                // candidates evaluated per block pass
+
+struct ExRec { int32_t win, row; uint64_t lo, hi; };          // exception k-mer, 16+12 nibbles
+struct EvalItem { int32_t win, cand0; };                        // one block's work: window + first padded candidate
+
+// ----------------------------------------------------------------------------------------------
+// (1) alignment -> planes
+// ----------------------------------------------------------------------------------------------
+__constant__ uint8_t c_code_lut[256];
+
+// V20:453: upper-case, keep ACGTRYMKSWHBVD (as 4-bit base sets), everything else (N included) -> '-' = 0
+static void host_code_lut(uint8_t *lut) {
+    memset(lut, 0, 256);
+    const char *sym = "ACGTRYMKSWHBVD";
+    const uint8_t code[] = {1, 2, 4, 8, 5, 10, 3, 12, 6, 9, 11, 14, 7, 13};
+    for (int i = 0; sym[i]; i++) {
+        lut[(uint8_t)sym[i]] = code[i];
+        lut[(uint8_t)(sym[i] + 32)] = code[i];
+    }
+}
+
+// thread = (row, 32-column chunk); lanes run along rows so that the plane stores coalesce
+__global__ __launch_bounds__(kBlock) void pack_kernel(const uint8_t *__restrict__ bytes, const int64_t *__restrict__ row_off,
+                                                      int n_rows, int n_pad, int n_chunks, uint32_t *__restrict__ planes) {
+    int r = blockIdx.x * kBlock + threadIdx.x;
+    int c = blockIdx.y;
+    if (r >= n_pad) return;
+    uint32_t mA = 0, mC = 0, mG = 0, mT = 0;
+    if (r < n_rows) {
+        int64_t o = row_off[r];
+        int64_t len = row_off[r + 1] - o;
+        int64_t col0 = (int64_t)c * 32;
+        const uint8_t *p = bytes + o + col0;
+        int n = (int)(len - col0 < 32 ? (len - col0 < 0 ? 0 : len - col0) : 32);
+        for (int j = 0; j < n; j++) {
+            uint32_t code = c_code_lut[p[j]];
+            mA |= (code & 1u) << j;
+            mC |= ((code >> 1) & 1u) << j;
+            mG |= ((code >> 2) & 1u) << j;
+            mT |= ((code >> 3) & 1u) << j;
+        }
+    }
+    size_t base = ((size_t)c * 4) * n_pad + r;
+    planes[base] = mA;
+    planes[base + n_pad] = mC;
+    planes[base + 2 * (size_t)n_pad] = mG;
+    planes[base + 3 * (size_t)n_pad] = mT;
+}
+
+// thread = row: prefix count of residues per chunk, leading-gap length and right-stripped length
+// (V20:625-627)
+__global__ __launch_bounds__(kBlock) void row_scan_kernel(const uint32_t *__restrict__ planes, const int64_t *__restrict__ row_off,
+                                                          int n_rows, int n_pad, int n_chunks, uint32_t *__restrict__ cum,
+                                                          int32_t *__restrict__ lead, int32_t *__restrict__ rstrip,
+                                                          int32_t *__restrict__ rlen) {
+    int r = blockIdx.x * kBlock + threadIdx.x;
+    if (r >= n_pad) return;
+    uint32_t run = 0;
+    int first = -1, last = 0;
+    for (int c = 0; c < n_chunks; c++) {
+        size_t base = ((size_t)c * 4) * n_pad + r;
+        uint32_t ng = planes[base] | planes[base + n_pad] | planes[base + 2 * (size_t)n_pad] | planes[base + 3 * (size_t)n_pad];
+        cum[(size_t)c * n_pad + r] = run;
+        run += __popc(ng);
+        if (ng) {
+            if (first < 0) first = c * 32 + (__ffs(ng) - 1);
+            last = c * 32 + 32 - __clz(ng);
+        }
+    }
+    cum[(size_t)n_chunks * n_pad + r] = run;
+    if (r < n_rows) {
+        int len = (int)(row_off[r + 1] - row_off[r]);
+        lead[r] = first < 0 ? len : first;
+        rstrip[r] = last;
+        rlen[r] = len;
+    }
+}
+
+// thread = (row, chunk): append this chunk's residues to the row's gap-free code string
+__global__ __launch_bounds__(kBlock) void ungap_kernel(const uint32_t *__restrict__ planes, const uint32_t *__restrict__ cum,
+                                                       int n_rows, int n_pad, int ustride, uint32_t *__restrict__ ung) {
+    int r = blockIdx.x * kBlock + threadIdx.x;
+    int c = blockIdx.y;
+    if (r >= n_rows) return;
+    size_t base = ((size_t)c * 4) * n_pad + r;
+    uint32_t mA = planes[base], mC = planes[base + n_pad], mG = planes[base + 2 * (size_t)n_pad], mT = planes[base + 3 * (size_t)n_pad];
+    uint32_t ng = mA | mC | mG | mT;
+    if (!ng) return;
+    uint32_t pos = cum[(size_t)c * n_pad + r];
+    uint32_t *dst = ung + (size_t)r * ustride;
+    uint32_t word = 0;
+    uint32_t widx = pos >> 3;
+    while (ng) {
+        int j = __ffs(ng) - 1;
+        ng &= ng - 1;
+        uint32_t code = ((mA >> j) & 1u) | (((mC >> j) & 1u) << 1) | (((mG >> j) & 1u) << 2) | (((mT >> j) & 1u) << 3);
+        if ((pos >> 3) != widx) {
+            atomicOr(dst + widx, word);
+            word = 0;
+            widx = pos >> 3;
+        }
+        word |= code << ((pos & 7) * 4);
+        pos++;
+    }
+    atomicOr(dst + widx, word);
+}
+
+// ----------------------------------------------------------------------------------------------
+// (2) window k-mers with edge-gap repair (V20:666-687)
+// ----------------------------------------------------------------------------------------------
+struct Nib {          // up to 32 symbol codes, one nibble each
+    uint64_t lo, hi;
+    __device__ uint32_t get(int j) const { return (uint32_t)((j < 16 ? lo >> (4 * j) : hi >> (4 * (j - 16))) & 15u); }
+    __device__ void set(int j, uint32_t v) {
+        if (j < 16) lo = (lo & ~(15ull << (4 * j))) | ((uint64_t)v << (4 * j));
+        else hi = (hi & ~(15ull << (4 * (j - 16)))) | ((uint64_t)v << (4 * (j - 16)));
+    }
+    __device__ void shift_up(int n) {      // move every nibble n positions towards the 3' end
+        int s = 4 * n;
+        if (s == 0) return;
+        if (s >= 64) { hi = lo << (s - 64); lo = 0; }
+        else { hi = (hi << s) | (lo >> (64 - s)); lo <<= s; }
+    }
+};
+
+__device__ inline uint32_t ung_get(const uint32_t *__restrict__ ung_row, uint32_t t) {
+    return (ung_row[t >> 3] >> ((t & 7) * 4)) & 15u;
+}
+
+// The general path: rows whose window starts or ends in a gap, holds an IUPAC code, or runs past
+// the end of a ragged row.  Follows get_primers line by line.  Returns 0 = store words,
+// 1 = exception (IUPAC code present, `buf` returned), 2 = fewer than k residues (V20:683-687).
+__device__ int repair_window(uint32_t wA, uint32_t wC, uint32_t wG, uint32_t wT, int k, int p, int len,
+                             uint32_t c_left, uint32_t total, const uint32_t *__restrict__ ung_row,
+                             uint32_t &b0, uint32_t &b1, uint32_t &g, Nib &buf) {
+    uint32_t kmask = (k == 32) ? 0xFFFFFFFFu : ((1u << k) - 1u);
+    int m = len - p;
+    m = m < 0 ? 0 : (m > k ? k : m);
+    uint32_t ng = (wA | wC | wG | wT) & kmask;
+    buf.lo = buf.hi = 0;
+    for (int j = 0; j < m; j++) {
+        uint32_t code = ((wA >> j) & 1u) | (((wC >> j) & 1u) << 1) | (((wG >> j) & 1u) << 2) | (((wT >> j) & 1u) << 3);
+        buf.set(j, code);
+    }
+    int n = m;
+    bool all_gap = (m == k) && ng == 0;                       // V20:668
+    if (!all_gap && n > 0) {
+        if (buf.get(0) == 0) {                                // V20:671 sequence.startswith("-")
+            int run = 0;
+            while (run < n && buf.get(run) == 0) run++;
+            if (c_left >= (uint32_t)run)                      // V20:675
+                for (int t = 0; t < run; t++) buf.set(t, ung_get(ung_row, c_left - run + t));
+        }
+        if (buf.get(n - 1) == 0) {                            // V20:677 sequence.endswith("-")
+            int run = 0;
+            while (run < n && buf.get(n - 1 - run) == 0) run++;
+            uint32_t c_after = c_left + __popc(ng);          // residues in s[0 : p+k]
+            if (total - c_after >= (uint32_t)run)             // V20:681
+                for (int t = 0; t < run; t++) buf.set(n - run + t, ung_get(ung_row, c_after + t));
+        }
+    }
+    if (n < k) {                                              // V20:683
+        int need = k - n;
+        if (c_left < (uint32_t)need) return 2;
+        buf.shift_up(need);
+        for (int t = 0; t < need; t++) buf.set(t, ung_get(ung_row, c_left - need + t));
+        n = k;
+    }
+    b0 = b1 = g = 0;
+    bool iupac = false;
+    for (int j = 0; j < k; j++) {
+        uint32_t code = buf.get(j);
+        if (code == 0) g |= 1u << j;
+        else if (code & (code - 1)) iupac = true;
+        else {
+            uint32_t bi = __ffs(code) - 1;
+            b0 |= (bi & 1u) << j;
+            b1 |= (bi >> 1) << j;
+        }
+    }
+    return iupac ? 1 : 0;
+}
+
+// thread = row, block = 256 rows x a tile of consecutive windows; the 32-column plane words slide
+// in registers, so every plane word is read once per tile.
+__global__ __launch_bounds__(kBlock) void build_windows_kernel(
+    const uint32_t *__restrict__ planes, const uint32_t *__restrict__ cum, const uint32_t *__restrict__ ung,
+    const int32_t *__restrict__ rlen, int n_rows, int n_pad, int n_chunks, int ustride, int p0, int n_win, int tile,
+    int k, uint32_t *__restrict__ win, ExRec *__restrict__ ex, int ex_cap, int *__restrict__ ex_count,
+    int *__restrict__ err) {
+    int r = blockIdx.x * kBlock + threadIdx.x;
+    if (r >= n_pad) return;
+    int w0 = blockIdx.y * tile;
+    int w1 = w0 + tile < n_win ? w0 + tile : n_win;
+    const uint32_t kmask = (1u << k) - 1u;
+    const size_t np = (size_t)n_pad;
+    if (r >= n_rows) {                       // padding rows never take part
+        for (int w = w0; w < w1; w++) {
+            size_t o = (size_t)w * 3 * np + r;
+            win[o] = 0; win[o + np] = 0; win[o + 2 * np] = MP_WIN_SKIP | kmask;
+        }
+        return;
+    }
+    const int len = rlen[r];
+    const uint32_t total = cum[(size_t)n_chunks * np + r];
+    const uint32_t *ung_row = ung + (size_t)r * ustride;
+    int cur = -1;
+    uint32_t loA = 0, loC = 0, loG = 0, loT = 0, hiA = 0, hiC = 0, hiG = 0, hiT = 0;
+    for (int w = w0; w < w1; w++) {
+        int p = p0 + w;
+        int c = p >> 5, o = p & 31;
+        if (c != cur) {
+            size_t base = ((size_t)c * 4) * np + r;
+            if (c == cur + 1 && cur >= 0) { loA = hiA; loC = hiC; loG = hiG; loT = hiT; }
+            else { loA = planes[base]; loC = planes[base + np]; loG = planes[base + 2 * np]; loT = planes[base + 3 * np]; }
+            size_t nb = base + 4 * np;           // chunk c+1 exists: n_chunks is padded by two
+            hiA = planes[nb]; hiC = planes[nb + np]; hiG = planes[nb + 2 * np]; hiT = planes[nb + 3 * np];
+            cur = c;
+        }
+        uint32_t wA = __funnelshift_r(loA, hiA, o) & kmask;
+        uint32_t wC = __funnelshift_r(loC, hiC, o) & kmask;
+        uint32_t wG = __funnelshift_r(loG, hiG, o) & kmask;
+        uint32_t wT = __funnelshift_r(loT, hiT, o) & kmask;
+        uint32_t o1 = wA | wC, a1 = wA & wC, o2 = wG | wT, a2 = wG & wT;
+        uint32_t ng = o1 | o2;
+        uint32_t multi = a1 | a2 | (o1 & o2);
+        uint32_t gw = ~ng & kmask;
+        uint32_t b0, b1, g;
+        bool fast = (p + k <= len) && multi == 0 && (gw == kmask || ((gw & 1u) == 0 && (gw >> (k - 1)) == 0));
+        size_t dst = (size_t)w * 3 * np + r;
+        if (fast) {
+            b0 = wC | wT; b1 = wG | wT; g = gw;
+        } else {
+            uint32_t ng_lo = loA | loC | loG | loT;
+            uint32_t c_left = cum[(size_t)c * np + r] + __popc(ng_lo & ((1u << o) - 1u));
+            Nib buf;
+            int rc = repair_window(wA, wC, wG, wT, k, p, len, c_left, total, ung_row, b0, b1, g, buf);
+            if (rc == 1) {
+                int idx = atomicAdd(ex_count, 1);
+                if (idx < ex_cap) { ex[idx].win = w; ex[idx].row = r; ex[idx].lo = buf.lo; ex[idx].hi = buf.hi; }
+                b0 = 0; b1 = 0; g = MP_WIN_SKIP | kmask;
+            } else if (rc == 2) {
+                atomicMax(err, 1);
+                err[1] = w; err[2] = r;
+                b0 = 0; b1 = 0; g = MP_WIN_SKIP | kmask;
+            }
+        }
+        win[dst] = b0; win[dst + np] = b1; win[dst + 2 * np] = g;
+    }
+}
+
+// ----------------------------------------------------------------------------------------------
+// (3) per-window k-mer histogram (V20:689-711)
+// ----------------------------------------------------------------------------------------------
+__device__ inline uint32_t hash3(uint32_t a, uint32_t b, uint32_t c) {
+    uint32_t h = a * 0x9E3779B1u;
+    h = (h ^ (h >> 15)) + b * 0x85EBCA77u;
+    h = (h ^ (h >> 13)) + c * 0xC2B2AE3Du;
+    return h ^ (h >> 16);
+}
+
+struct UniqueOut {
+    uint32_t *b0, *b1, *g;
+    int32_t *count, *first;
+    long long cap;
+    unsigned long long *total;   // entries allocated so far (may exceed cap: caller checks)
+    int64_t *win_base;           // [W]
+    int32_t *win_count;          // [W]
+    int32_t *labels;             // [W][Npad] or nullptr
+    int32_t *overflow;           // [W] set to 1 when the table did not fit
+};
+
+// One block per window.  Rows stream through in lanes; equal keys inside a wave are folded with
+// ballots first (conserved windows put the same k-mer in almost every lane), then one lane per
+// distinct key updates the table.  A slot stores the row of a representative; key comparison
+// reads the representative's window words back (immutable, L2-resident).
+// TABLE_IN_LDS = false: same algorithm on a global-memory table (windows with more distinct k-mers
+// than the LDS table holds).
+template <bool TABLE_IN_LDS>
+__global__ __launch_bounds__(kBlock) void unique_kernel(const uint32_t *__restrict__ win, int n_rows, int n_pad,
+                                                        const int32_t *__restrict__ win_list, int slots, int limit,
+                                                        uint32_t *__restrict__ gtable, UniqueOut out) {
+    __shared__ uint32_t s_rep[TABLE_IN_LDS ? kHashSlots : 1];
+    __shared__ uint32_t s_cnt[TABLE_IN_LDS ? kHashSlots : 1];
+    __shared__ uint32_t s_min[TABLE_IN_LDS ? kHashSlots : 1];
+    __shared__ int s_used, s_over, s_nout;
+    __shared__ unsigned long long s_base;
+    const int w = win_list ? win_list[blockIdx.x] : blockIdx.x;
+    uint32_t *rep, *cnt, *mn;
+    if (TABLE_IN_LDS) { rep = s_rep; cnt = s_cnt; mn = s_min; }
+    else { rep = gtable + (size_t)blockIdx.x * 3 * slots; cnt = rep + slots; mn = cnt + slots; }
+    const uint32_t mask = slots - 1;
+    for (int i = threadIdx.x; i < slots; i += kBlock) { rep[i] = kEmpty; cnt[i] = 0; mn[i] = kEmpty; }
+    if (threadIdx.x == 0) { s_used = 0; s_over = 0; s_nout = 0; }
+    __syncthreads();
+    const size_t np = (size_t)n_pad;
+    const uint32_t *W0 = win + (size_t)w * 3 * np, *W1 = W0 + np, *W2 = W1 + np;
+    const int lane = threadIdx.x & 63;
+    for (int base = 0; base < n_pad; base += kBlock) {
+        int r = base + threadIdx.x;
+        uint32_t b0 = 0, b1 = 0, g = MP_WIN_SKIP;
+        if (r < n_rows) { b0 = W0[r]; b1 = W1[r]; g = W2[r]; }
+        bool todo = !(g & MP_WIN_SKIP);
+        unsigned long long pending = __ballot(todo);
+        while (pending) {
+            int lead = __ffsll((long long)pending) - 1;
+            uint32_t k0 = __shfl(b0, lead), k1 = __shfl(b1, lead), k2 = __shfl(g, lead);
+            bool same = todo && b0 == k0 && b1 == k1 && g == k2;
+            unsigned long long grp = __ballot(same);
+            if (lane == lead) {
+                uint32_t c = (uint32_t)__popcll(grp);
+                uint32_t h = hash3(b0, b1, g) & mask;
+                for (int probe = 0; probe < slots; probe++) {
+                    uint32_t old = atomicCAS(&rep[h], kEmpty, (uint32_t)r);
+                    bool hit = old == kEmpty;
+                    if (hit) {
+                        if (atomicAdd(&s_used, 1) + 1 > limit) s_over = 1;
+                    } else {
+                        hit = W0[old] == b0 && W1[old] == b1 && W2[old] == g;
+                    }
+                    if (hit) { atomicAdd(&cnt[h], c); atomicMin(&mn[h], (uint32_t)r); break; }
+                    h = (h + 1) & mask;
+                }
+            }
+            todo = todo && !same;
+            pending &= ~grp;
+        }
+        if (s_over) break;       // benign race: every thread re-checks after the barrier below
+    }
+    __syncthreads();
+    if (s_over) {
+        if (threadIdx.x == 0) { out.overflow[w] = 1; out.win_count[w] = 0; out.win_base[w] = 0; }
+        return;
+    }
+    // compaction: one reservation in the global entry list per window (s_used = distinct k-mers),
+    // then every occupied slot takes a dense index inside the window's segment
+    if (threadIdx.x == 0) {
+        s_base = atomicAdd(out.total, (unsigned long long)s_used);
+        out.win_base[w] = (int64_t)s_base;
+        out.win_count[w] = s_used;
+        out.overflow[w] = 0;
+    }
+    __syncthreads();
+    const unsigned long long base = s_base;
+    for (int i = threadIdx.x; i < slots; i += kBlock) {
+        uint32_t rr = rep[i];
+        if (rr == kEmpty) continue;
+        int idx = atomicAdd(&s_nout, 1);
+        unsigned long long e = base + idx;
+        if ((long long)e < out.cap) {
+            out.b0[e] = W0[rr]; out.b1[e] = W1[rr]; out.g[e] = W2[rr];
+            out.count[e] = (int32_t)cnt[i];
+            out.first[e] = (int32_t)mn[i];
+        }
+        cnt[i] = (uint32_t)idx;            // count consumed: reuse the word as the slot's dense index
+    }
+    __syncthreads();
+    if (!out.labels) return;
+    for (int base_r = 0; base_r < n_pad; base_r += kBlock) {
+        int r = base_r + threadIdx.x;
+        if (r >= n_rows) continue;
+        uint32_t b0 = W0[r], b1 = W1[r], g = W2[r];
+        int32_t lab = -1;
+        if (!(g & MP_WIN_SKIP)) {
+            uint32_t h = hash3(b0, b1, g) & mask;
+            for (int probe = 0; probe < slots; probe++) {
+                uint32_t rr = rep[h];
+                if (rr == kEmpty) break;
+                if (W0[rr] == b0 && W1[rr] == b1 && W2[rr] == g) { lab = (int32_t)cnt[h]; break; }
+                h = (h + 1) & mask;
+            }
+        }
+        out.labels[(size_t)w * np + r] = lab;
+    }
+}
+
+// ----------------------------------------------------------------------------------------------
+// (4) candidate x sequence evaluation (V20:1103-1130, Y_distance V20:229-233)
+// ----------------------------------------------------------------------------------------------
+// A candidate is held as four k-bit words nX = positions whose symbol does NOT contain base X.
+// For a sequence k-mer (b0,b1,g) the mismatch word is  g | select(nA,nC,nG,nT by (b1,b0))  — three
+// v_bfi_b32 and one v_or_b32 — and |D| = popcount.  The strict-position tests are two ANDs.
+__device__ inline uint32_t bfi(uint32_t s, uint32_t a, uint32_t b) { return (s & a) | (~s & b); }
+
+template <int CC>
+__device__ inline void eval_row(uint32_t b0, uint32_t b1, uint32_t g, uint32_t kmask, int v, uint32_t sF, uint32_t sR,
+                                const uint32_t (&nA)[CC], const uint32_t (&nC)[CC], const uint32_t (&nG)[CC],
+                                const uint32_t (&nT)[CC], uint32_t (&a0)[CC], uint32_t (&aF)[CC], uint32_t (&aR)[CC]) {
+    uint32_t gk = g & kmask;
+    // rows outside the universe (SKIP slots and k-mers with more than v gaps, V20:689) get an
+    // all-ones mismatch word: 32 mismatches, counted nowhere
+    if ((int)__popc(gk) > v) gk = 0xFFFFFFFFu;
+#pragma unroll
+    for (int c = 0; c < CC; c++) {
+        uint32_t mm = bfi(b1, bfi(b0, nT[c], nG[c]), bfi(b0, nC[c], nA[c])) | gk;
+        int d = __popc(mm);
+        a0[c] += (d == 0);
+        bool near = (d <= v) && (d != 0);
+        aF[c] += near && !(mm & sF);
+        aR[c] += near && !(mm & sR);
+    }
+}
+
+template <int CC>
+__global__ __launch_bounds__(kBlock) void eval_kernel(const uint32_t *__restrict__ win, int n_pad,
+                                                      const EvalItem *__restrict__ items,
+                                                      const uint4 *__restrict__ cand_n,       // [padded cand] nA,nC,nG,nT
+                                                      const int32_t *__restrict__ cand_out,  // [padded cand] index into out or -1
+                                                      const int32_t *__restrict__ extra_off, const uint32_t *__restrict__ extra_words,
+                                                      uint32_t sF, uint32_t sR, int v, uint32_t kmask, int rows_per_split,
+                                                      unsigned long long *__restrict__ out) {
+    __shared__ uint32_t s_acc[3 * CC];
+    const EvalItem it = items[blockIdx.x];
+    uint32_t nA[CC], nC[CC], nG[CC], nT[CC], a0[CC], aF[CC], aR[CC];
+#pragma unroll
+    for (int c = 0; c < CC; c++) {
+        uint4 q = cand_n[it.cand0 + c];
+        nA[c] = q.x; nC[c] = q.y; nG[c] = q.z; nT[c] = q.w;
+        a0[c] = aF[c] = aR[c] = 0;
+    }
+    if (threadIdx.x < 3 * CC) s_acc[threadIdx.x] = 0;
+    const size_t np = (size_t)n_pad;
+    const uint32_t *W0 = win + (size_t)it.win * 3 * np, *W1 = W0 + np, *W2 = W1 + np;
+    const int r0 = blockIdx.y * rows_per_split;
+    const int r1 = r0 + rows_per_split < n_pad ? r0 + rows_per_split : n_pad;
+    // 4 consecutive sequences per lane: three 16-byte loads per iteration (n_pad % 4 == 0)
+    for (int r = r0 + threadIdx.x * 4; r < r1; r += kBlock * 4) {
+        uint4 x0 = *reinterpret_cast<const uint4 *>(W0 + r);
+        uint4 x1 = *reinterpret_cast<const uint4 *>(W1 + r);
+        uint4 x2 = *reinterpret_cast<const uint4 *>(W2 + r);
+        eval_row<CC>(x0.x, x1.x, x2.x, kmask, v, sF, sR, nA, nC, nG, nT, a0, aF, aR);
+        eval_row<CC>(x0.y, x1.y, x2.y, kmask, v, sF, sR, nA, nC, nG, nT, a0, aF, aR);
+        eval_row<CC>(x0.z, x1.z, x2.z, kmask, v, sF, sR, nA, nC, nG, nT, a0, aF, aR);
+        eval_row<CC>(x0.w, x1.w, x2.w, kmask, v, sF, sR, nA, nC, nG, nT, a0, aF, aR);
+    }
+    if (blockIdx.y == 0 && extra_off) {      // host-expanded IUPAC rows of this window
+        for (int e = extra_off[it.win] + threadIdx.x; e < extra_off[it.win + 1]; e += kBlock)
+            eval_row<CC>(extra_words[3 * e], extra_words[3 * e + 1], extra_words[3 * e + 2], kmask, v, sF, sR,
+                         nA, nC, nG, nT, a0, aF, aR);
+    }
+    __syncthreads();
+    // wave reduction, then one LDS add per wave and one global atomic per counter per block
+#pragma unroll
+    for (int c = 0; c < CC; c++) {
+        uint32_t x = a0[c], y = aF[c], z = aR[c];
+#pragma unroll
+        for (int s = 32; s >= 1; s >>= 1) {
+            x += __shfl_xor(x, s);
+            y += __shfl_xor(y, s);
+            z += __shfl_xor(z, s);
+        }
+        if ((threadIdx.x & 63) == 0) {
+            atomicAdd(&s_acc[3 * c], x);
+            atomicAdd(&s_acc[3 * c + 1], y);
+            atomicAdd(&s_acc[3 * c + 2], z);
+        }
+    }
+    __syncthreads();
+    if (threadIdx.x < 3 * CC) {
+        int oc = cand_out[it.cand0 + threadIdx.x / 3];
+        uint32_t val = s_acc[threadIdx.x];
+        if (oc >= 0 && val) atomicAdd(&out[(size_t)oc * 3 + threadIdx.x % 3], (unsigned long long)val);
+    }
+}
+
+}  // namespace
+
+// ================================================================================================
+// host side of the C ABI
+// ================================================================================================
+struct mp_ctx {
+    char err[512] = {0};
+    int dev = 0;
+    hipStream_t stream = nullptr;
+    int64_t bytes = 0;
+    // alignment
+    int n_rows = 0, n_pad = 0, n_chunks = 0, max_len = 0, ustride = 0;
+    uint32_t *planes = nullptr, *cum = nullptr, *ung = nullptr;
+    int32_t *lead = nullptr, *rstrip = nullptr, *rlen = nullptr;
+    // windows
+    int p0 = 0, n_win = 0, k = 0, v = 0;
+    uint32_t *win = nullptr;
+    ExRec *ex = nullptr;
+    int ex_cap = 0;
+    int *ex_count = nullptr, *err_flag = nullptr;
+    std::vector<ExRec> ex_host;
+    int32_t *extra_off = nullptr;
+    uint32_t *extra_words = nullptr;
+    int n_extra = 0;
+    // unique
+    long long u_cap = 0, u_n = 0;
+    uint32_t *u_b0 = nullptr, *u_b1 = nullptr, *u_g = nullptr;
+    int32_t *u_count = nullptr, *u_first = nullptr, *labels = nullptr, *u_over = nullptr, *u_wcount = nullptr;
+    int64_t *u_wbase = nullptr;
+    unsigned long long *u_total = nullptr;
+    std::vector<int64_t> h_wbase;
+    std::vector<int32_t> h_wcount;
+    // eval staging
+    int n_cand = 0, n_items = 0, n_padded = 0;
+    EvalItem *items = nullptr;
+    uint4 *cand_n = nullptr;
+    int32_t *cand_out = nullptr;
+    uint32_t sF = 0, sR = 0;
+    unsigned long long *tmp_out = nullptr;
+    int tmp_out_n = 0;
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> ev_busy, ev_free;
+    double ev_ms = 0;
+    int ev_n = 0;
+};
+
+namespace {
+
+int fail(mp_ctx *c, int code, const char *fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(c->err, sizeof c->err, fmt, ap);
+    va_end(ap);
+    return code;
+}
+
+#define HIPCK(c, call)                                                                                   \
+    do {                                                                                                 \
+        hipError_t e_ = (call);                                                                          \
+        if (e_ != hipSuccess) return fail((c), MP_ERR_DEVICE, "%s: %s", #call, hipGetErrorString(e_));  \
+    } while (0)
+
+template <typename T>
+int dev_alloc(mp_ctx *c, T **p, size_t n) {
+    *p = nullptr;
+    if (n == 0) n = 1;
+    hipError_t e = hipMalloc((void **)p, n * sizeof(T));
+    if (e != hipSuccess) return fail(c, MP_ERR_NOMEM, "hipMalloc(%zu bytes): %s", n * sizeof(T), hipGetErrorString(e));
+    c->bytes += (int64_t)(n * sizeof(T));
+    return MP_OK;
+}
+
+template <typename T>
+void dev_free(mp_ctx *c, T **p, size_t n) {
+    if (*p) {
+        (void)hipFree(*p);
+        c->bytes -= (int64_t)((n ? n : 1) * sizeof(T));
+        *p = nullptr;
+    }
+}
+
+void free_eval(mp_ctx *c) {
+    dev_free(c, &c->items, (size_t)c->n_items);
+    dev_free(c, &c->cand_n, (size_t)c->n_padded);
+    dev_free(c, &c->cand_out, (size_t)c->n_padded);
+    c->n_items = c->n_padded = c->n_cand = 0;
+}
+
+void free_unique(mp_ctx *c) {
+    size_t cap = (size_t)c->u_cap, W = (size_t)c->n_win;
+    dev_free(c, &c->u_b0, cap); dev_free(c, &c->u_b1, cap); dev_free(c, &c->u_g, cap);
+    dev_free(c, &c->u_count, cap); dev_free(c, &c->u_first, cap);
+    dev_free(c, &c->labels, W * c->n_pad);
+    dev_free(c, &c->u_over, W); dev_free(c, &c->u_wcount, W); dev_free(c, &c->u_wbase, W);
+    dev_free(c, &c->u_total, 1);
+    c->u_cap = c->u_n = 0;
+    c->h_wbase.clear(); c->h_wcount.clear();
+}
+
+void free_windows(mp_ctx *c) {
+    free_eval(c);
+    free_unique(c);
+    dev_free(c, &c->win, (size_t)c->n_win * 3 * c->n_pad);
+    dev_free(c, &c->ex, (size_t)c->ex_cap);
+    dev_free(c, &c->ex_count, 1);
+    dev_free(c, &c->err_flag, 4);
+    dev_free(c, &c->extra_off, (size_t)c->n_win + 1);
+    dev_free(c, &c->extra_words, (size_t)3 * c->n_extra);
+    c->ex_cap = 0; c->n_extra = 0; c->n_win = 0;
+    c->ex_host.clear();
+}
+
+void free_msa(mp_ctx *c) {
+    free_windows(c);
+    size_t np = (size_t)c->n_pad;
+    dev_free(c, &c->planes, (size_t)c->n_chunks * 4 * np);
+    dev_free(c, &c->cum, ((size_t)c->n_chunks + 1) * np);
+    dev_free(c, &c->ung, (size_t)c->n_rows * c->ustride);
+    dev_free(c, &c->lead, np); dev_free(c, &c->rstrip, np); dev_free(c, &c->rlen, np);
+    c->n_rows = c->n_pad = c->n_chunks = 0;
+}
+
+}  // namespace
+
+extern "C" {
+
+const char *mp_backend_name(void) { return "hip"; }
+const char *mp_last_error(const mp_ctx *c) { return c ? c->err : "mp_create failed: no usable HIP device"; }
+
+int mp_create(int device, mp_ctx **out) {
+    if (!out) return MP_ERR_ARG;
+    *out = nullptr;
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || n <= 0 || device < 0 || device >= n) return MP_ERR_DEVICE;
+    if (hipSetDevice(device) != hipSuccess) return MP_ERR_DEVICE;
+    mp_ctx *c = new mp_ctx();
+    c->dev = device;
+    uint8_t lut[256];
+    host_code_lut(lut);
+    if (hipMemcpyToSymbol(HIP_SYMBOL(c_code_lut), lut, 256) != hipSuccess) { delete c; return MP_ERR_DEVICE; }
+    *out = c;
+    return MP_OK;
+}
+
+void mp_destroy(mp_ctx *c) {
+    if (!c) return;
+    (void)hipSetDevice(c->dev);
+    (void)hipDeviceSynchronize();
+    free_msa(c);
+    dev_free(c, &c->tmp_out, (size_t)c->tmp_out_n);
+    for (auto &p : c->ev_busy) { (void)hipEventDestroy(p.first); (void)hipEventDestroy(p.second); }
+    for (auto &p : c->ev_free) { (void)hipEventDestroy(p.first); (void)hipEventDestroy(p.second); }
+    delete c;
+}
+
+int mp_set_stream(mp_ctx *c, void *s) {
+    if (!c) return MP_ERR_ARG;
+    c->stream = (hipStream_t)s;
+    return MP_OK;
+}
+
+int mp_device_bytes(mp_ctx *c, int64_t *b) {
+    if (!c || !b) return MP_ERR_ARG;
+    *b = c->bytes;
+    return MP_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+int mp_load_msa(mp_ctx *c, const uint8_t *bytes, const int64_t *row_off, int32_t n_rows) {
+    if (!c) return MP_ERR_ARG;
+    if (!bytes || !row_off || n_rows <= 0) return fail(c, MP_ERR_ARG, "mp_load_msa: bad arguments");
+    HIPCK(c, hipSetDevice(c->dev));
+    free_msa(c);
+    int64_t max_len = 0;
+    for (int r = 0; r < n_rows; r++) {
+        int64_t l = row_off[r + 1] - row_off[r];
+        if (l < 0 || l > 0x3fffffff) return fail(c, MP_ERR_ARG, "row %d has bad length", r);
+        max_len = std::max(max_len, l);
+    }
+    c->n_rows = n_rows;
+    c->n_pad = (n_rows + kBlock - 1) / kBlock * kBlock;
+    c->max_len = (int)max_len;
+    c->n_chunks = (int)((max_len + 31) / 32) + 2;
+    c->ustride = (int)(max_len / 8) + 2;
+    size_t np = (size_t)c->n_pad;
+    int64_t total = row_off[n_rows] - row_off[0];
+    uint8_t *d_bytes = nullptr;
+    int64_t *d_off = nullptr;
+    int rc;
+    if ((rc = dev_alloc(c, &d_bytes, (size_t)total + 64))) return rc;
+    if ((rc = dev_alloc(c, &d_off, (size_t)n_rows + 1))) return rc;
+    if ((rc = dev_alloc(c, &c->planes, (size_t)c->n_chunks * 4 * np))) return rc;
+    if ((rc = dev_alloc(c, &c->cum, ((size_t)c->n_chunks + 1) * np))) return rc;
+    if ((rc = dev_alloc(c, &c->ung, (size_t)n_rows * c->ustride))) return rc;
+    if ((rc = dev_alloc(c, &c->lead, np))) return rc;
+    if ((rc = dev_alloc(c, &c->rstrip, np))) return rc;
+    if ((rc = dev_alloc(c, &c->rlen, np))) return rc;
+    std::vector<int64_t> off0(n_rows + 1);
+    for (int r = 0; r <= n_rows; r++) off0[r] = row_off[r] - row_off[0];
+    HIPCK(c, hipMemcpyAsync(d_bytes, bytes + row_off[0], (size_t)total, hipMemcpyHostToDevice, c->stream));
+    HIPCK(c, hipMemcpyAsync(d_off, off0.data(), sizeof(int64_t) * (n_rows + 1), hipMemcpyHostToDevice, c->stream));
+    HIPCK(c, hipMemsetAsync(c->ung, 0, sizeof(uint32_t) * (size_t)n_rows * c->ustride, c->stream));
+    HIPCK(c, hipMemsetAsync(c->rlen, 0, sizeof(int32_t) * np, c->stream));
+    dim3 grid((unsigned)(c->n_pad / kBlock), (unsigned)c->n_chunks);
+    hipLaunchKernelGGL(pack_kernel, grid, dim3(kBlock), 0, c->stream, d_bytes, d_off, n_rows, c->n_pad, c->n_chunks, c->planes);
+    hipLaunchKernelGGL(row_scan_kernel, dim3(c->n_pad / kBlock), dim3(kBlock), 0, c->stream, c->planes, d_off, n_rows,
+                       c->n_pad, c->n_chunks, c->cum, c->lead, c->rstrip, c->rlen);
+    hipLaunchKernelGGL(ungap_kernel, grid, dim3(kBlock), 0, c->stream, c->planes, c->cum, n_rows, c->n_pad, c->ustride, c->ung);
+    HIPCK(c, hipGetLastError());
+    HIPCK(c, hipStreamSynchronize(c->stream));
+    dev_free(c, &d_bytes, (size_t)total + 64);
+    dev_free(c, &d_off, (size_t)n_rows + 1);
+    return MP_OK;
+}
+
+int mp_row_attributes(mp_ctx *c, int32_t *lead, int32_t *rstrip, int32_t *rowlen) {
+    if (!c) return MP_ERR_ARG;
+    if (!c->planes) return fail(c, MP_ERR_ARG, "no alignment loaded");
+    HIPCK(c, hipSetDevice(c->dev));
+    size_t n = sizeof(int32_t) * (size_t)c->n_rows;
+    if (lead) HIPCK(c, hipMemcpyAsync(lead, c->lead, n, hipMemcpyDeviceToHost, c->stream));
+    if (rstrip) HIPCK(c, hipMemcpyAsync(rstrip, c->rstrip, n, hipMemcpyDeviceToHost, c->stream));
+    if (rowlen) HIPCK(c, hipMemcpyAsync(rowlen, c->rlen, n, hipMemcpyDeviceToHost, c->stream));
+    HIPCK(c, hipStreamSynchronize(c->stream));
+    return MP_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+int mp_build_windows(mp_ctx *c, int32_t p0, int32_t n_win, int32_t k, int32_t v, int32_t *n_exc) {
+    if (!c) return MP_ERR_ARG;
+    if (!c->planes) return fail(c, MP_ERR_ARG, "no alignment loaded");
+    if (k < 2 || k > MP_MAX_K || n_win <= 0 || p0 < 0 || v < 0 || v >= k)
+        return fail(c, MP_ERR_ARG, "bad window arguments (k=%d v=%d n_windows=%d)", k, v, n_win);
+    if (p0 + n_win > c->max_len) return fail(c, MP_ERR_ARG, "windows run past the longest row");
+    HIPCK(c, hipSetDevice(c->dev));
+    free_windows(c);
+    c->p0 = p0; c->n_win = n_win; c->k = k; c->v = v;
+    size_t np = (size_t)c->n_pad;
+    int rc;
+    if ((rc = dev_alloc(c, &c->win, (size_t)n_win * 3 * np))) return rc;
+    if ((rc = dev_alloc(c, &c->ex_count, 1))) return rc;
+    if ((rc = dev_alloc(c, &c->err_flag, 4))) return rc;
+    if ((rc = dev_alloc(c, &c->extra_off, (size_t)n_win + 1))) return rc;
+    HIPCK(c, hipMemsetAsync(c->extra_off, 0, sizeof(int32_t) * ((size_t)n_win + 1), c->stream));
+    int cap = 1 << 16;
+    const int tile = 64;
+    for (int attempt = 0; attempt < 2; attempt++) {
+        if ((rc = dev_alloc(c, &c->ex, (size_t)cap))) return rc;
+        c->ex_cap = cap;
+        HIPCK(c, hipMemsetAsync(c->ex_count, 0, sizeof(int), c->stream));
+        HIPCK(c, hipMemsetAsync(c->err_flag, 0, 4 * sizeof(int), c->stream));
+        dim3 grid((unsigned)(c->n_pad / kBlock), (unsigned)((n_win + tile - 1) / tile));
+        hipLaunchKernelGGL(build_windows_kernel, grid, dim3(kBlock), 0, c->stream, c->planes, c->cum, c->ung, c->rlen,
+                           c->n_rows, c->n_pad, c->n_chunks, c->ustride, p0, n_win, tile, k, c->win, c->ex, cap,
+                           c->ex_count, c->err_flag);
+        HIPCK(c, hipGetLastError());
+        int cnt = 0, errv[4] = {0, 0, 0, 0};
+        HIPCK(c, hipMemcpyAsync(&cnt, c->ex_count, sizeof(int), hipMemcpyDeviceToHost, c->stream));
+        HIPCK(c, hipMemcpyAsync(errv, c->err_flag, 4 * sizeof(int), hipMemcpyDeviceToHost, c->stream));
+        HIPCK(c, hipStreamSynchronize(c->stream));
+        if (errv[0])
+            return fail(c, MP_ERR_SHORT_WINDOW, "row %d has fewer than %d residues at window %d", errv[2], k, p0 + errv[1]);
+        if (cnt <= cap) {
+            c->ex_host.resize((size_t)cnt);
+            if (cnt) HIPCK(c, hipMemcpy(c->ex_host.data(), c->ex, sizeof(ExRec) * (size_t)cnt, hipMemcpyDeviceToHost));
+            std::sort(c->ex_host.begin(), c->ex_host.end(),
+                      [](const ExRec &a, const ExRec &b) { return a.win != b.win ? a.win < b.win : a.row < b.row; });
+            if (n_exc) *n_exc = cnt;
+            return MP_OK;
+        }
+        dev_free(c, &c->ex, (size_t)cap);
+        cap = cnt;
+    }
+    return fail(c, MP_ERR_DEVICE, "exception list did not converge");
+}
+
+int mp_get_exceptions(mp_ctx *c, int32_t cap, int32_t *ew, int32_t *er, uint8_t *codes) {
+    if (!c) return MP_ERR_ARG;
+    if (!c->win) return fail(c, MP_ERR_ARG, "no windows built");
+    int n = (int)c->ex_host.size();
+    if (cap < n) return fail(c, MP_ERR_CAPACITY, "exception buffer too small: need %d", n);
+    for (int i = 0; i < n; i++) {
+        const ExRec &e = c->ex_host[(size_t)i];
+        ew[i] = e.win; er[i] = e.row;
+        for (int j = 0; j < c->k; j++)
+            codes[(size_t)i * c->k + j] = (uint8_t)((j < 16 ? e.lo >> (4 * j) : e.hi >> (4 * (j - 16))) & 15u);
+    }
+    return MP_OK;
+}
+
+int mp_set_extra_rows(mp_ctx *c, int32_t n, const int32_t *win, const uint32_t *words) {
+    if (!c) return MP_ERR_ARG;
+    if (!c->win) return fail(c, MP_ERR_ARG, "no windows built");
+    HIPCK(c, hipSetDevice(c->dev));
+    dev_free(c, &c->extra_words, (size_t)3 * c->n_extra);
+    c->n_extra = 0;
+    std::vector<int32_t> off((size_t)c->n_win + 1, 0);
+    for (int i = 0; i < n; i++) {
+        if (win[i] < 0 || win[i] >= c->n_win || (i && win[i] < win[i - 1]))
+            return fail(c, MP_ERR_ARG, "extra rows must be sorted by window and in range");
+        off[(size_t)win[i] + 1]++;
+    }
+    for (int w = 0; w < c->n_win; w++) off[(size_t)w + 1] += off[(size_t)w];
+    HIPCK(c, hipMemcpy(c->extra_off, off.data(), sizeof(int32_t) * off.size(), hipMemcpyHostToDevice));
+    if (n > 0) {
+        int rc;
+        if ((rc = dev_alloc(c, &c->extra_words, (size_t)3 * n))) return rc;
+        c->n_extra = n;
+        HIPCK(c, hipMemcpy(c->extra_words, words, sizeof(uint32_t) * 3 * (size_t)n, hipMemcpyHostToDevice));
+    }
+    return MP_OK;
+}
+
+int mp_get_window_words(mp_ctx *c, int32_t w, int32_t row0, int32_t n, uint32_t *out) {
+    if (!c) return MP_ERR_ARG;
+    if (!c->win) return fail(c, MP_ERR_ARG, "no windows built");
+    if (w < 0 || w >= c->n_win || row0 < 0 || n < 0 || row0 + n > c->n_rows) return fail(c, MP_ERR_ARG, "bad range");
+    HIPCK(c, hipSetDevice(c->dev));
+    size_t np = (size_t)c->n_pad;
+    for (int p = 0; p < 3; p++)
+        HIPCK(c, hipMemcpyAsync(out + (size_t)p * n, c->win + ((size_t)w * 3 + p) * np + row0, sizeof(uint32_t) * (size_t)n,
+                                hipMemcpyDeviceToHost, c->stream));
+    HIPCK(c, hipStreamSynchronize(c->stream));
+    return MP_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+int mp_window_unique(mp_ctx *c, int64_t cap, int32_t want_labels, int64_t *n_entries) {
+    if (!c) return MP_ERR_ARG;
+    if (!c->win) return fail(c, MP_ERR_ARG, "no windows built");
+    if (cap <= 0) return fail(c, MP_ERR_ARG, "cap_entries must be positive");
+    HIPCK(c, hipSetDevice(c->dev));
+    free_unique(c);
+    size_t W = (size_t)c->n_win, np = (size_t)c->n_pad;
+    int rc;
+    c->u_cap = cap;
+    if ((rc = dev_alloc(c, &c->u_b0, (size_t)cap))) return rc;
+    if ((rc = dev_alloc(c, &c->u_b1, (size_t)cap))) return rc;
+    if ((rc = dev_alloc(c, &c->u_g, (size_t)cap))) return rc;
+    if ((rc = dev_alloc(c, &c->u_count, (size_t)cap))) return rc;
+    if ((rc = dev_alloc(c, &c->u_first, (size_t)cap))) return rc;
+    if ((rc = dev_alloc(c, &c->u_over, W))) return rc;
+    if ((rc = dev_alloc(c, &c->u_wcount, W))) return rc;
+    if ((rc = dev_alloc(c, &c->u_wbase, W))) return rc;
+    if ((rc = dev_alloc(c, &c->u_total, 1))) return rc;
+    if (want_labels && (rc = dev_alloc(c, &c->labels, W * np))) return rc;
+    HIPCK(c, hipMemsetAsync(c->u_total, 0, sizeof(unsigned long long), c->stream));
+    UniqueOut uo{c->u_b0, c->u_b1, c->u_g, c->u_count, c->u_first, (long long)cap, c->u_total,
+                 c->u_wbase, c->u_wcount, c->labels, c->u_over};
+    hipLaunchKernelGGL(unique_kernel<true>, dim3((unsigned)W), dim3(kBlock), 0, c->stream, c->win, c->n_rows, c->n_pad,
+                       (const int32_t *)nullptr, kHashSlots, kHashLimit, (uint32_t *)nullptr, uo);
+    HIPCK(c, hipGetLastError());
+    std::vector<int32_t> over(W);
+    HIPCK(c, hipMemcpyAsync(over.data(), c->u_over, sizeof(int32_t) * W, hipMemcpyDeviceToHost, c->stream));
+    HIPCK(c, hipStreamSynchronize(c->stream));
+    std::vector<int32_t> big;
+    for (size_t w = 0; w < W; w++) if (over[w]) big.push_back((int32_t)w);
+    if (!big.empty()) {
+        // windows with more distinct k-mers than the LDS table holds: same kernel on a global table
+        int slots = 1;
+        while (slots < 2 * c->n_rows + 64) slots <<= 1;
+        const size_t batch = 64;
+        uint32_t *gtable = nullptr;
+        int32_t *d_list = nullptr;
+        if ((rc = dev_alloc(c, &gtable, batch * 3 * (size_t)slots))) return rc;
+        if ((rc = dev_alloc(c, &d_list, batch))) return rc;
+        for (size_t i = 0; i < big.size(); i += batch) {
+            size_t nb = std::min(batch, big.size() - i);
+            HIPCK(c, hipMemcpy(d_list, big.data() + i, sizeof(int32_t) * nb, hipMemcpyHostToDevice));
+            hipLaunchKernelGGL(unique_kernel<false>, dim3((unsigned)nb), dim3(kBlock), 0, c->stream, c->win, c->n_rows,
+                               c->n_pad, (const int32_t *)d_list, slots, slots - 32, gtable, uo);
+            HIPCK(c, hipGetLastError());
+            HIPCK(c, hipStreamSynchronize(c->stream));
+        }
+        dev_free(c, &gtable, batch * 3 * (size_t)slots);
+        dev_free(c, &d_list, batch);
+    }
+    unsigned long long total = 0;
+    c->h_wbase.resize(W); c->h_wcount.resize(W);
+    HIPCK(c, hipMemcpy(&total, c->u_total, sizeof(total), hipMemcpyDeviceToHost));
+    HIPCK(c, hipMemcpy(c->h_wbase.data(), c->u_wbase, sizeof(int64_t) * W, hipMemcpyDeviceToHost));
+    HIPCK(c, hipMemcpy(c->h_wcount.data(), c->u_wcount, sizeof(int32_t) * W, hipMemcpyDeviceToHost));
+    if (n_entries) *n_entries = (int64_t)total;
+    if ((long long)total > cap) { c->u_n = 0; return fail(c, MP_ERR_CAPACITY, "unique table needs %llu entries", total); }
+    c->u_n = (long long)total;
+    return MP_OK;
+}
+
+int mp_get_unique(mp_ctx *c, int64_t *win_off, uint32_t *words, int32_t *count, int32_t *first_row) {
+    if (!c) return MP_ERR_ARG;
+    if (c->h_wbase.empty()) return fail(c, MP_ERR_ARG, "mp_window_unique has not run");
+    HIPCK(c, hipSetDevice(c->dev));
+    size_t n = (size_t)c->u_n, W = (size_t)c->n_win;
+    std::vector<uint32_t> b0(n + 1), b1(n + 1), g(n + 1);
+    std::vector<int32_t> cn(n + 1), fr(n + 1);
+    if (n) {
+        HIPCK(c, hipMemcpy(b0.data(), c->u_b0, 4 * n, hipMemcpyDeviceToHost));
+        HIPCK(c, hipMemcpy(b1.data(), c->u_b1, 4 * n, hipMemcpyDeviceToHost));
+        HIPCK(c, hipMemcpy(g.data(), c->u_g, 4 * n, hipMemcpyDeviceToHost));
+        HIPCK(c, hipMemcpy(cn.data(), c->u_count, 4 * n, hipMemcpyDeviceToHost));
+        HIPCK(c, hipMemcpy(fr.data(), c->u_first, 4 * n, hipMemcpyDeviceToHost));
+    }
+    // the kernel reserved each window's segment with one atomic; lay the segments out in window order
+    int64_t o = 0;
+    for (size_t w = 0; w < W; w++) {
+        win_off[w] = o;
+        size_t src = (size_t)c->h_wbase[w], m = (size_t)c->h_wcount[w];
+        for (size_t i = 0; i < m; i++) {
+            words[(size_t)o + i] = b0[src + i];
+            words[n + (size_t)o + i] = b1[src + i];
+            words[2 * n + (size_t)o + i] = g[src + i];
+            count[(size_t)o + i] = cn[src + i];
+            first_row[(size_t)o + i] = fr[src + i];
+        }
+        o += (int64_t)m;
+    }
+    win_off[W] = o;
+    return MP_OK;
+}
+
+int mp_get_labels(mp_ctx *c, int32_t w, int32_t *labels) {
+    if (!c) return MP_ERR_ARG;
+    if (!c->labels) return fail(c, MP_ERR_ARG, "labels were not requested");
+    if (w < 0 || w >= c->n_win) return fail(c, MP_ERR_ARG, "bad window");
+    HIPCK(c, hipSetDevice(c->dev));
+    HIPCK(c, hipMemcpy(labels, c->labels + (size_t)w * c->n_pad, sizeof(int32_t) * (size_t)c->n_rows, hipMemcpyDeviceToHost));
+    return MP_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+int mp_eval_upload(mp_ctx *c, int32_t n_cand, const int32_t *cw, const uint8_t *codes, uint32_t sF, uint32_t sR) {
+    if (!c) return MP_ERR_ARG;
+    if (!c->win) return fail(c, MP_ERR_ARG, "no windows built");
+    if (n_cand < 0 || (n_cand && (!cw || !codes))) return fail(c, MP_ERR_ARG, "bad arguments");
+    HIPCK(c, hipSetDevice(c->dev));
+    free_eval(c);
+    const int k = c->k;
+    const uint32_t kmask = (1u << k) - 1u;
+    std::vector<EvalItem> items;
+    std::vector<uint4> cn;
+    std::vector<int32_t> co;
+    int i = 0;
+    while (i < n_cand) {
+        int w = cw[i];
+        if (w < 0 || w >= c->n_win || (i && w < cw[i - 1])) return fail(c, MP_ERR_ARG, "candidate windows must be ascending and in range");
+        int j = i;
+        while (j < n_cand && cw[j] == w) j++;
+        for (int b = i; b < j; b += kEvalCC) {
+            items.push_back(EvalItem{w, (int32_t)cn.size()});
+            for (int t = 0; t < kEvalCC; t++) {
+                int ci = b + t;
+                if (ci < j) {
+                    uint32_t nA = 0, nC = 0, nG = 0, nT = 0;
+                    for (int p = 0; p < k; p++) {
+                        uint8_t m = codes[(size_t)ci * k + p];
+                        if (!(m & 1)) nA |= 1u << p;
+                        if (!(m & 2)) nC |= 1u << p;
+                        if (!(m & 4)) nG |= 1u << p;
+                        if (!(m & 8)) nT |= 1u << p;
+                    }
+                    cn.push_back(uint4{nA, nC, nG, nT});
+                    co.push_back(ci);
+                } else {
+                    cn.push_back(uint4{kmask, kmask, kmask, kmask});
+                    co.push_back(-1);
+                }
+            }
+        }
+        i = j;
+    }
+    c->n_cand = n_cand; c->sF = sF; c->sR = sR;
+    c->n_items = (int)items.size();
+    c->n_padded = (int)cn.size();
+    if (c->n_items == 0) return MP_OK;
+    int rc;
+    if ((rc = dev_alloc(c, &c->items, items.size()))) return rc;
+    if ((rc = dev_alloc(c, &c->cand_n, cn.size()))) return rc;
+    if ((rc = dev_alloc(c, &c->cand_out, co.size()))) return rc;
+    HIPCK(c, hipMemcpy(c->items, items.data(), sizeof(EvalItem) * items.size(), hipMemcpyHostToDevice));
+    HIPCK(c, hipMemcpy(c->cand_n, cn.data(), sizeof(uint4) * cn.size(), hipMemcpyHostToDevice));
+    HIPCK(c, hipMemcpy(c->cand_out, co.data(), sizeof(int32_t) * co.size(), hipMemcpyHostToDevice));
+    return MP_OK;
+}
+
+int mp_eval_launch(mp_ctx *c, int64_t *device_out) {
+    if (!c) return MP_ERR_ARG;
+    if (!c->win) return fail(c, MP_ERR_ARG, "no windows built");
+    if (!device_out) return fail(c, MP_ERR_ARG, "null output");
+    HIPCK(c, hipSetDevice(c->dev));
+    if (c->n_cand == 0) return MP_OK;
+    HIPCK(c, hipMemsetAsync(device_out, 0, sizeof(int64_t) * 3 * (size_t)c->n_cand, c->stream));
+    // enough blocks to fill 256 CUs several times over, each with at least 1024 sequences
+    int max_split = (c->n_pad + 1023) / 1024;
+    int want = (4096 + c->n_items - 1) / c->n_items;
+    int split = std::max(1, std::min(max_split, want));
+    int rows = ((c->n_pad + split - 1) / split + 1023) / 1024 * 1024;
+    split = (c->n_pad + rows - 1) / rows;
+    std::pair<hipEvent_t, hipEvent_t> ev;
+    if (!c->ev_free.empty()) { ev = c->ev_free.back(); c->ev_free.pop_back(); }
+    else { HIPCK(c, hipEventCreate(&ev.first)); HIPCK(c, hipEventCreate(&ev.second)); }
+    HIPCK(c, hipEventRecord(ev.first, c->stream));
+    hipLaunchKernelGGL(eval_kernel<kEvalCC>, dim3((unsigned)c->n_items, (unsigned)split), dim3(kBlock), 0, c->stream, c->win,
+                       c->n_pad, c->items, c->cand_n, c->cand_out, c->n_extra ? c->extra_off : (const int32_t *)nullptr,
+                       c->extra_words, c->sF, c->sR, c->v, (1u << c->k) - 1u, rows, (unsigned long long *)device_out);
+    HIPCK(c, hipEventRecord(ev.second, c->stream));
+    c->ev_busy.push_back(ev);
+    HIPCK(c, hipGetLastError());
+    return MP_OK;
+}
+
+int mp_eval_timing(mp_ctx *c, int32_t reset, double *total_ms, int32_t *n_launches) {
+    if (!c) return MP_ERR_ARG;
+    HIPCK(c, hipSetDevice(c->dev));
+    for (auto &p : c->ev_busy) {
+        HIPCK(c, hipEventSynchronize(p.second));
+        float ms = 0;
+        HIPCK(c, hipEventElapsedTime(&ms, p.first, p.second));
+        c->ev_ms += ms;
+        c->ev_n++;
+        c->ev_free.push_back(p);
+    }
+    c->ev_busy.clear();
+    if (total_ms) *total_ms = c->ev_ms;
+    if (n_launches) *n_launches = c->ev_n;
+    if (reset) { c->ev_ms = 0; c->ev_n = 0; }
+    return MP_OK;
+}
+
+int mp_eval_candidates(mp_ctx *c, int32_t n_cand, const int32_t *cw, const uint8_t *codes, uint32_t sF, uint32_t sR,
+                       int64_t *out) {
+    if (!c) return MP_ERR_ARG;
+    int rc = mp_eval_upload(c, n_cand, cw, codes, sF, sR);
+    if (rc) return rc;
+    if (n_cand == 0) return MP_OK;
+    if (!out) return fail(c, MP_ERR_ARG, "null output");
+    if (c->tmp_out_n < 3 * n_cand) {
+        dev_free(c, &c->tmp_out, (size_t)c->tmp_out_n);
+        c->tmp_out_n = 0;
+        if ((rc = dev_alloc(c, &c->tmp_out, (size_t)3 * n_cand))) return rc;
+        c->tmp_out_n = 3 * n_cand;
+    }
+    if ((rc = mp_eval_launch(c, (int64_t *)c->tmp_out))) return rc;
+    HIPCK(c, hipMemcpyAsync(out, c->tmp_out, sizeof(int64_t) * 3 * (size_t)n_cand, hipMemcpyDeviceToHost, c->stream));
+    HIPCK(c, hipStreamSynchronize(c->stream));
+    return MP_OK;
+}
+
+}  // extern "C"

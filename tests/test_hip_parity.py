@@ -1,0 +1,178 @@
+"""GPU parity tests proper: the hand-written HIP kernels against the CPU oracle through the same
+C ABI, on seeded inputs — bit-exact (all outputs are integers / bit masks) — plus
+size-independent properties at the benchmark's full size."""
+import numpy as np
+import pytest
+
+from multiprime_amd import iupac
+from multiprime_amd.synth import synth_block
+
+pytestmark = pytest.mark.gpu
+
+
+def fuzz_msa(seed, n, L, ragged=False, p_gap=0.02, p_iupac=0.004, edge=0.3):
+    rows = synth_block(0, n, L, seed, p_gap=p_gap, edge_frac=edge, p_iupac=p_iupac, block_rows=4096)
+    rng = np.random.default_rng(seed + 1000)
+    junk = np.frombuffer(b"RYMKSWHBVDNnacgtx*?.", dtype=np.uint8)
+    hit = rng.random(rows.shape) < p_iupac
+    rows = np.where(hit, junk[rng.integers(0, len(junk), rows.shape)], rows).astype(np.uint8)
+    if n > 6:
+        rows[3, :] = ord("-")                       # an all-gap row
+        rows[4, : L // 2] = ord("-")                # long leading run
+        rows[5, L // 3:] = ord("-")                 # long trailing run
+    lens = np.full(n, L, np.int64)
+    if ragged:
+        lens = rng.integers(L // 2, L + 1, size=n)
+        lens[0] = L
+        if n > 8:
+            lens[7] = 0                             # an empty record
+    off = np.zeros(n + 1, np.int64)
+    np.cumsum(lens, out=off[1:])
+    data = np.concatenate([rows[i, : lens[i]] for i in range(n)]) if n else np.zeros(0, np.uint8)
+    return data, off, int(lens.max())
+
+
+def both(hip_lib, oracle_lib, data, off):
+    ctxs = []
+    for lib in (hip_lib, oracle_lib):
+        c = lib.context(0)
+        c.load_msa(data, off)
+        ctxs.append(c)
+    return ctxs
+
+
+def random_candidates(rng, W, k, per_window):
+    cw = np.repeat(np.arange(W, dtype=np.int32), per_window)
+    codes = rng.integers(1, 16, size=(len(cw), k)).astype(np.uint8)
+    one_hot = np.array([1, 2, 4, 8], np.uint8)[rng.integers(0, 4, size=codes.shape)]
+    concrete = rng.random(codes.shape) < 0.8
+    return cw, np.where(concrete, one_hot, codes).astype(np.uint8)
+
+
+CASES = [
+    # seed, n, L, ragged, k, v, p0
+    (1, 300, 200, False, 18, 1, 5),
+    (2, 257, 150, False, 22, 2, 0),
+    (3, 64, 400, True, 16, 1, 0),
+    (4, 1000, 120, False, 20, 0, 3),
+    (5, 33, 300, True, 28, 3, 10),
+    (6, 700, 90, False, 8, 1, 0),
+]
+
+
+@pytest.mark.parametrize("seed,n,L,ragged,k,v,p0", CASES)
+def test_every_abi_output_matches_oracle(hip_lib, oracle_lib, seed, n, L, ragged, k, v, p0):
+    data, off, maxlen = fuzz_msa(seed, n, L, ragged)
+    h, o = both(hip_lib, oracle_lib, data, off)
+    for a, b in zip(h.row_attributes(), o.row_attributes()):
+        assert a.tolist() == b.tolist()
+    W = maxlen - k - p0
+    if ragged:
+        W = int(np.sort(np.diff(off))[n // 4]) - k - p0       # stay where most rows still have residues
+    try:
+        ne_h = h.build_windows(p0, W, k, v)
+    except Exception as e:                                    # a short-window error must be raised by both
+        with pytest.raises(type(e)):
+            o.build_windows(p0, W, k, v)
+        return
+    ne_o = o.build_windows(p0, W, k, v)
+    assert ne_h == ne_o
+    eh, eo = h.get_exceptions(ne_h), o.get_exceptions(ne_o)
+    for a, b in zip(eh, eo):
+        assert a.tolist() == b.tolist()
+    for w in range(0, W, max(1, W // 40)):
+        assert h.get_window_words(w).tolist() == o.get_window_words(w).tolist(), f"window words {w}"
+    # host-side expansion of the exceptions, exactly as the product does it
+    ew, er, ec = eh
+    raw = iupac.strings_of(iupac.SYMBOL_LUT[ec]) if ne_h else []
+    xw, xk = [], []
+    for w_, s in zip(ew.tolist(), raw):
+        if s.count("-") <= v and iupac.degeneracy(s) <= 64:
+            for e in iupac.expand(s):
+                xw.append(w_)
+                xk.append(e)
+    if xw:
+        words = iupac.words_of_kmers(np.frombuffer("".join(xk).encode(), np.uint8).reshape(len(xk), k))
+        h.set_extra_rows(np.asarray(xw, np.int32), words)
+        o.set_extra_rows(np.asarray(xw, np.int32), words)
+    uh, uo = h.window_unique(want_labels=True), o.window_unique(want_labels=True)
+    for a, b in zip(uh, uo):
+        assert a.tolist() == b.tolist()
+    for w in range(0, W, max(1, W // 25)):
+        assert h.get_labels(w).tolist() == o.get_labels(w).tolist(), f"labels {w}"
+    rng = np.random.default_rng(seed)
+    cw, codes = random_candidates(rng, W, k, 3)
+    # make a share of the candidates near-matches of real k-mers so that all three counters move
+    sF = int(rng.integers(0, 1 << k)) & 0b1110
+    sR = (0b111 << (k - 3)) & ((1 << k) - 1)
+    rh = h.eval_candidates(cw, codes, sF, sR)
+    ro = o.eval_candidates(cw, codes, sF, sR)
+    assert rh.tolist() == ro.tolist()
+    words0 = o.get_window_words(W // 2)
+    ok = (words0[2] & 0x80000000) == 0
+    if ok.any():
+        kmers = iupac.kmers_of_words(words0[:, ok][:, :40], k)
+        cand = iupac.MASK_LUT[kmers]
+        cand[cand == 0] = 15
+        cw2 = np.full(len(cand), W // 2, np.int32)
+        assert h.eval_candidates(cw2, cand, sF, sR).tolist() == o.eval_candidates(cw2, cand, sF, sR).tolist()
+
+
+def test_many_distinct_kmers_take_the_global_table_path(hip_lib, oracle_lib):
+    # random (non-homologous) rows: every window holds ~n distinct k-mers, far more than the LDS table
+    rng = np.random.default_rng(9)
+    n, L, k = 6000, 64, 18
+    rows = np.frombuffer(b"ACGT", np.uint8)[rng.integers(0, 4, size=(n, L))]
+    data, off = rows.reshape(-1), np.arange(n + 1, dtype=np.int64) * L
+    h, o = both(hip_lib, oracle_lib, data, off)
+    h.build_windows(0, 8, k, 1)
+    o.build_windows(0, 8, k, 1)
+    uh, uo = h.window_unique(want_labels=True), o.window_unique(want_labels=True)
+    assert np.diff(uh[0]).min() > 4096
+    for a, b in zip(uh, uo):
+        assert a.tolist() == b.tolist()
+    assert h.get_labels(3).tolist() == o.get_labels(3).tolist()
+
+
+def test_full_size_properties(hip_lib):
+    """At the benchmark's size (131072 x 1000, k=18) the oracle is too slow; check properties
+    that do not depend on size: an all-N candidate covers exactly the universe; the histogram
+    counts add up to the same universe; evaluation is additive over row shards; a k-mer that
+    occurs c times is perfectly covered c times by itself."""
+    n, L, k, v = 131072, 1000, 18, 1
+    rows = synth_block(0, n, L, 20250303)
+    data, off = rows.reshape(-1), np.arange(n + 1, dtype=np.int64) * L
+    ctx = hip_lib.context(0)
+    ctx.load_msa(data, off)
+    W = 900
+    n_ex = ctx.build_windows(20, W, k, v)
+    assert 0 < n_ex < n
+    uoff, words, count, first = ctx.window_unique()
+    gaps = np.array([bin(int(x) & ((1 << k) - 1)).count("1") for x in words[2]])
+    win_of = np.repeat(np.arange(W), np.diff(uoff))
+    universe = np.bincount(win_of, weights=np.where(gaps <= v, count, 0), minlength=W).astype(np.int64)
+    cw = np.arange(W, dtype=np.int32)
+    alln = np.full((W, k), 15, np.uint8)
+    ev = ctx.eval_candidates(cw, alln, 0, 0)
+    # gap symbols mismatch every candidate symbol, so "perfect" under all-N = rows without gaps and
+    # perfect + F_mis = the whole universe (strict masks empty)
+    assert (ev[:, 0] + ev[:, 1] == universe).all()
+    assert (ev[:, 1] == ev[:, 2]).all()
+    # the most frequent k-mer of each window covers itself `count` times
+    top = np.array([uoff[w] + np.argmax(np.where(gaps[uoff[w]:uoff[w + 1]] == 0, count[uoff[w]:uoff[w + 1]], -1))
+                    for w in range(W)])
+    cand = iupac.MASK_LUT[iupac.kmers_of_words(words[:, top], k)]
+    ev2 = ctx.eval_candidates(cw, cand, 0, 0)
+    assert (ev2[:, 0] == count[top]).all()
+    # additivity over row shards (what the multi-GPU all-reduce relies on)
+    half = n // 2
+    parts = []
+    for a, b in ((0, half), (half, n)):
+        c2 = hip_lib.context(0)
+        c2.load_msa(rows[a:b].reshape(-1), np.arange(b - a + 1, dtype=np.int64) * L)
+        c2.build_windows(20, W, k, v)
+        parts.append(c2.eval_candidates(cw, cand, 0b1100, 0b11 << 14))
+        c2.close()
+    whole = ctx.eval_candidates(cw, cand, 0b1100, 0b11 << 14)
+    assert (parts[0] + parts[1] == whole).all()
+    ctx.close()
