@@ -157,6 +157,8 @@ class NN_degenerate(object):
         first = first.astype(np.int64) + row_base
         if self.comm is not None:
             off, words, count, first, exc = self.comm.merge_tables(off, words, count, first, exc, W)
+            if self.write_json:
+                self.comm.gather_labels(self.ctx, W)
         t0 = time.time()
         chars = iupac.kmers_of_words(words, k)
         strs = iupac.strings_of(chars)
@@ -390,9 +392,7 @@ class NN_degenerate(object):
     def _rows_by_entry(self, win):
         """Rows (ascending) of every device histogram entry of the window, from the per-row labels."""
         a, b = win.dev_entries
-        if self.comm is not None:
-            return self.comm.rows_by_entry(self.ctx, win.w, b - a)
-        lab = self.ctx.get_labels(win.w)
+        lab = self.comm.labels(win.w) if self.comm is not None else self.ctx.get_labels(win.w)
         order = np.argsort(lab, kind="stable")
         cnt = np.bincount(lab[lab >= 0], minlength=b - a)
         edge = np.concatenate(([0], np.cumsum(cnt))) + int((lab < 0).sum())

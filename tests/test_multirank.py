@@ -1,0 +1,45 @@
+"""The N>1 path on CPU: world_size 2 and 3 over gloo, rows sharded across ranks, the CPU oracle
+standing in for the GPU behind the same C ABI.  Results must be identical to the single-process
+run, i.e. to the reference's own outputs."""
+import json
+import os
+import sys
+
+import pytest
+import torch.multiprocessing as mp
+
+from conftest import GOLDEN, REPO, golden_input, load_gz_json
+
+
+def _worker(rank, world, port, name, inp, out, oracle_so):
+    sys.path.insert(0, REPO)
+    import torch.distributed as dist
+    from multiprime_amd._abi import Library
+    from multiprime_amd.core import NN_degenerate
+    from multiprime_amd.dist import RowShards
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        import gzip
+        meta = json.loads(gzip.open(os.path.join(GOLDEN, name + ".trace.json.gz")).read())["meta"]
+        fl = meta["flags"]
+        app = NN_degenerate(seq_file=inp, primer_length=fl["l"], coverage=fl["f"], number_of_dege_bases=fl["n"],
+                            score_of_dege_bases=fl["d"], raw_entropy_threshold=fl["e"], product_len=fl["s"],
+                            position=fl["c"], variation=fl["v"], distance=fl["a"], GC=fl["g"], nproc=1,
+                            outfile=out, library=Library(oracle_so), comm=RowShards())
+        app.run()
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("name,world", [("syn_iupac", 2), ("syn_ragged", 3), ("ivc_v1", 2), ("msa1000_k18_d64", 2)])
+def test_sharded_run_matches_reference(name, world, oracle_lib, tmp_path):
+    from test_core_golden import check_outputs
+    meta = load_gz_json(name + ".trace.json.gz")["meta"]
+    inp = tmp_path / (name + ".fa")
+    inp.write_bytes(golden_input(meta["input"]))
+    out = tmp_path / (name + ".out")
+    port = 29500 + (os.getpid() % 2000)
+    mp.spawn(_worker, args=(world, port, name, str(inp), str(out), oracle_lib.path), nprocs=world, join=True)
+    check_outputs(name, out)
