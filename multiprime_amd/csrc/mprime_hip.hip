@@ -8,8 +8,9 @@
 //   cum     [n_chunks+1][Npad] u32    residues (non-gap symbols) left of each 32-column chunk
 //   ung     [N][ustride] u32          gap-free residue codes, 8 nibbles per word, row-major
 //                                     (only touched by the edge-gap repair path)
-//   win     [W][3][Npad] u32          the k-mer of every (window, sequence) after repair:
-//                                     b0,b1 (2-bit base) and g (gap flag) words, k bits each
+//   win     the k-mer of every (window, sequence) after repair, 3 bits per symbol:
+//             k <= 21: [W][Npad] u64       b0 | b1 << k | g << 2k, bit 63 = not in the universe
+//             k >= 22: [W][3][Npad] u32    b0,b1 (2-bit base) and g (gap flag) words
 //   uniq    per-window histogram entries (words, count, first row), labels [W][Npad]
 //
 // Kernels: pack_kernel, row_scan_kernel, ungap_kernel (mp_load_msa), build_windows_kernel
@@ -24,6 +25,7 @@
 #include <algorithm>
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <numeric>
 #include <vector>
@@ -217,12 +219,76 @@ __device__ int repair_window(uint32_t wA, uint32_t wC, uint32_t wG, uint32_t wT,
     return iupac ? 1 : 0;
 }
 
+// ----------------------------------------------------------------------------------------------
+// window words in HBM: one packed u64 per (window, sequence) when 3k <= 63, else three u32 planes
+// ----------------------------------------------------------------------------------------------
+template <bool P64>
+struct WinView;
+
+template <>
+struct WinView<false> {
+    const uint32_t *W0, *W1, *W2;
+    __device__ WinView(const void *base, int w, size_t np, int, uint32_t)
+        : W0((const uint32_t *)base + (size_t)w * 3 * np), W1(W0 + np), W2(W1 + np) {}
+    __device__ inline void load(int r, uint32_t &b0, uint32_t &b1, uint32_t &g) const { b0 = W0[r]; b1 = W1[r]; g = W2[r]; }
+    struct Raw4 { uint4 a, b, c; };
+    __device__ inline Raw4 load4(int r) const {
+        Raw4 q;
+        q.a = *reinterpret_cast<const uint4 *>(W0 + r);
+        q.b = *reinterpret_cast<const uint4 *>(W1 + r);
+        q.c = *reinterpret_cast<const uint4 *>(W2 + r);
+        return q;
+    }
+    __device__ inline void unpack(const Raw4 &q, int i, uint32_t &b0, uint32_t &b1, uint32_t &g) const {
+        b0 = i == 0 ? q.a.x : i == 1 ? q.a.y : i == 2 ? q.a.z : q.a.w;
+        b1 = i == 0 ? q.b.x : i == 1 ? q.b.y : i == 2 ? q.b.z : q.b.w;
+        g = i == 0 ? q.c.x : i == 1 ? q.c.y : i == 2 ? q.c.z : q.c.w;
+    }
+    __device__ static inline void store(void *base, int w, size_t np, int r, uint32_t b0, uint32_t b1, uint32_t g, int, uint32_t) {
+        uint32_t *W = (uint32_t *)base + (size_t)w * 3 * np + r;
+        W[0] = b0; W[np] = b1; W[2 * np] = g;
+    }
+};
+
+template <>
+struct WinView<true> {
+    const uint64_t *Wp;
+    int k;
+    uint32_t kmask;
+    __device__ WinView(const void *base, int w, size_t np, int k_, uint32_t kmask_)
+        : Wp((const uint64_t *)base + (size_t)w * np), k(k_), kmask(kmask_) {}
+    __device__ inline void split(uint64_t x, uint32_t &b0, uint32_t &b1, uint32_t &g) const {
+        b0 = (uint32_t)x & kmask;
+        b1 = (uint32_t)(x >> k) & kmask;
+        g = ((uint32_t)(x >> (2 * k)) & kmask) | ((uint32_t)(x >> 32) & MP_WIN_SKIP);
+    }
+    __device__ inline void load(int r, uint32_t &b0, uint32_t &b1, uint32_t &g) const { split(Wp[r], b0, b1, g); }
+    struct Raw4 { uint4 a, b; };
+    __device__ inline Raw4 load4(int r) const {
+        Raw4 q;
+        q.a = *reinterpret_cast<const uint4 *>(Wp + r);
+        q.b = *reinterpret_cast<const uint4 *>(Wp + r + 2);
+        return q;
+    }
+    __device__ inline void unpack(const Raw4 &q, int i, uint32_t &b0, uint32_t &b1, uint32_t &g) const {
+        uint32_t lo = i == 0 ? q.a.x : i == 1 ? q.a.z : i == 2 ? q.b.x : q.b.z;
+        uint32_t hi = i == 0 ? q.a.y : i == 1 ? q.a.w : i == 2 ? q.b.y : q.b.w;
+        split(((uint64_t)hi << 32) | lo, b0, b1, g);
+    }
+    __device__ static inline void store(void *base, int w, size_t np, int r, uint32_t b0, uint32_t b1, uint32_t g, int k, uint32_t kmask) {
+        uint64_t x = (uint64_t)b0 | ((uint64_t)b1 << k) | ((uint64_t)(g & kmask) << (2 * k)) |
+                     ((uint64_t)(g & MP_WIN_SKIP) << 32);
+        ((uint64_t *)base)[(size_t)w * np + r] = x;
+    }
+};
+
 // thread = row, block = 256 rows x a tile of consecutive windows; the 32-column plane words slide
 // in registers, so every plane word is read once per tile.
+template <bool P64>
 __global__ __launch_bounds__(kBlock) void build_windows_kernel(
     const uint32_t *__restrict__ planes, const uint32_t *__restrict__ cum, const uint32_t *__restrict__ ung,
     const int32_t *__restrict__ rlen, int n_rows, int n_pad, int n_chunks, int ustride, int p0, int n_win, int tile,
-    int k, uint32_t *__restrict__ win, ExRec *__restrict__ ex, int ex_cap, int *__restrict__ ex_count,
+    int k, void *__restrict__ win, ExRec *__restrict__ ex, int ex_cap, int *__restrict__ ex_count,
     int *__restrict__ err) {
     int r = blockIdx.x * kBlock + threadIdx.x;
     if (r >= n_pad) return;
@@ -231,10 +297,7 @@ __global__ __launch_bounds__(kBlock) void build_windows_kernel(
     const uint32_t kmask = (1u << k) - 1u;
     const size_t np = (size_t)n_pad;
     if (r >= n_rows) {                       // padding rows never take part
-        for (int w = w0; w < w1; w++) {
-            size_t o = (size_t)w * 3 * np + r;
-            win[o] = 0; win[o + np] = 0; win[o + 2 * np] = MP_WIN_SKIP | kmask;
-        }
+        for (int w = w0; w < w1; w++) WinView<P64>::store(win, w, np, r, 0, 0, MP_WIN_SKIP | kmask, k, kmask);
         return;
     }
     const int len = rlen[r];
@@ -263,7 +326,6 @@ __global__ __launch_bounds__(kBlock) void build_windows_kernel(
         uint32_t gw = ~ng & kmask;
         uint32_t b0, b1, g;
         bool fast = (p + k <= len) && multi == 0 && (gw == kmask || ((gw & 1u) == 0 && (gw >> (k - 1)) == 0));
-        size_t dst = (size_t)w * 3 * np + r;
         if (fast) {
             b0 = wC | wT; b1 = wG | wT; g = gw;
         } else {
@@ -281,7 +343,7 @@ __global__ __launch_bounds__(kBlock) void build_windows_kernel(
                 b0 = 0; b1 = 0; g = MP_WIN_SKIP | kmask;
             }
         }
-        win[dst] = b0; win[dst + np] = b1; win[dst + 2 * np] = g;
+        WinView<P64>::store(win, w, np, r, b0, b1, g, k, kmask);
     }
 }
 
@@ -312,8 +374,8 @@ struct UniqueOut {
 // reads the representative's window words back (immutable, L2-resident).
 // TABLE_IN_LDS = false: same algorithm on a global-memory table (windows with more distinct k-mers
 // than the LDS table holds).
-template <bool TABLE_IN_LDS>
-__global__ __launch_bounds__(kBlock) void unique_kernel(const uint32_t *__restrict__ win, int n_rows, int n_pad,
+template <bool TABLE_IN_LDS, bool P64>
+__global__ __launch_bounds__(kBlock) void unique_kernel(const void *__restrict__ win, int k, int n_rows, int n_pad,
                                                         const int32_t *__restrict__ win_list, int slots, int limit,
                                                         uint32_t *__restrict__ gtable, UniqueOut out) {
     __shared__ uint32_t s_rep[TABLE_IN_LDS ? kHashSlots : 1];
@@ -330,12 +392,12 @@ __global__ __launch_bounds__(kBlock) void unique_kernel(const uint32_t *__restri
     if (threadIdx.x == 0) { s_used = 0; s_over = 0; s_nout = 0; }
     __syncthreads();
     const size_t np = (size_t)n_pad;
-    const uint32_t *W0 = win + (size_t)w * 3 * np, *W1 = W0 + np, *W2 = W1 + np;
+    const WinView<P64> V(win, w, np, k, (1u << k) - 1u);
     const int lane = threadIdx.x & 63;
     for (int base = 0; base < n_pad; base += kBlock) {
         int r = base + threadIdx.x;
         uint32_t b0 = 0, b1 = 0, g = MP_WIN_SKIP;
-        if (r < n_rows) { b0 = W0[r]; b1 = W1[r]; g = W2[r]; }
+        if (r < n_rows) V.load(r, b0, b1, g);
         bool todo = !(g & MP_WIN_SKIP);
         unsigned long long pending = __ballot(todo);
         while (pending) {
@@ -352,7 +414,9 @@ __global__ __launch_bounds__(kBlock) void unique_kernel(const uint32_t *__restri
                     if (hit) {
                         if (atomicAdd(&s_used, 1) + 1 > limit) s_over = 1;
                     } else {
-                        hit = W0[old] == b0 && W1[old] == b1 && W2[old] == g;
+                        uint32_t o0, o1, o2;
+                        V.load((int)old, o0, o1, o2);
+                        hit = o0 == b0 && o1 == b1 && o2 == g;
                     }
                     if (hit) { atomicAdd(&cnt[h], c); atomicMin(&mn[h], (uint32_t)r); break; }
                     h = (h + 1) & mask;
@@ -384,7 +448,9 @@ __global__ __launch_bounds__(kBlock) void unique_kernel(const uint32_t *__restri
         int idx = atomicAdd(&s_nout, 1);
         unsigned long long e = base + idx;
         if ((long long)e < out.cap) {
-            out.b0[e] = W0[rr]; out.b1[e] = W1[rr]; out.g[e] = W2[rr];
+            uint32_t o0, o1, o2;
+            V.load((int)rr, o0, o1, o2);
+            out.b0[e] = o0; out.b1[e] = o1; out.g[e] = o2;
             out.count[e] = (int32_t)cnt[i];
             out.first[e] = (int32_t)mn[i];
         }
@@ -395,14 +461,17 @@ __global__ __launch_bounds__(kBlock) void unique_kernel(const uint32_t *__restri
     for (int base_r = 0; base_r < n_pad; base_r += kBlock) {
         int r = base_r + threadIdx.x;
         if (r >= n_rows) continue;
-        uint32_t b0 = W0[r], b1 = W1[r], g = W2[r];
+        uint32_t b0, b1, g;
+        V.load(r, b0, b1, g);
         int32_t lab = -1;
         if (!(g & MP_WIN_SKIP)) {
             uint32_t h = hash3(b0, b1, g) & mask;
             for (int probe = 0; probe < slots; probe++) {
                 uint32_t rr = rep[h];
                 if (rr == kEmpty) break;
-                if (W0[rr] == b0 && W1[rr] == b1 && W2[rr] == g) { lab = (int32_t)cnt[h]; break; }
+                uint32_t o0, o1, o2;
+                V.load((int)rr, o0, o1, o2);
+                if (o0 == b0 && o1 == b1 && o2 == g) { lab = (int32_t)cnt[h]; break; }
                 h = (h + 1) & mask;
             }
         }
@@ -415,89 +484,185 @@ __global__ __launch_bounds__(kBlock) void unique_kernel(const uint32_t *__restri
 // ----------------------------------------------------------------------------------------------
 // A candidate is held as four k-bit words nX = positions whose symbol does NOT contain base X.
 // For a sequence k-mer (b0,b1,g) the mismatch word is  g | select(nA,nC,nG,nT by (b1,b0))  — three
-// v_bfi_b32 and one v_or_b32 — and |D| = popcount.  The strict-position tests are two ANDs.
+// v_bfi_b32 and one v_or_b32.  With D = set bits of mm:
+//   perfect = (mm == 0)
+//   F_raw   = |D| <= v  and  mm & strictF == 0      (R_raw likewise)
+// F_raw includes the perfect rows, so the kernel counts F_raw and subtracts `perfect` once per
+// block (F_mis = F_raw - perfect), which saves the |D| != 0 test per evaluation.
+// VMODE 1 (v == 1, the pipeline default): |D| <= 1  <=>  mm & (mm-1) == 0, so
+//   F_raw <=> mm & ((mm-1) | strictF) == 0  — one v_add, one v_bitop3, one compare, no popcount.
 __device__ inline uint32_t bfi(uint32_t s, uint32_t a, uint32_t b) { return (s & a) | (~s & b); }
 
-template <int CC>
-__device__ inline void eval_row(uint32_t b0, uint32_t b1, uint32_t g, uint32_t kmask, int v, uint32_t sF, uint32_t sR,
+struct EvalArgs {
+    const void *win;
+    int n_pad, k;
+    const EvalItem *items;
+    const uint4 *cand_n;        // [padded cand] nA,nC,nG,nT
+    const int32_t *cand_out;    // [padded cand] index into out or -1
+    const int32_t *extra_off;   // [W+1] or nullptr
+    const uint32_t *extra_words;
+    uint32_t sF, sR;
+    int v;
+    uint32_t kmask;
+    int rows_per_split;
+    unsigned long long *out;
+};
+
+// COUNT 0: per-lane VGPR accumulators (v_cmp + v_addc); COUNT 1: wave ballots counted on the
+// scalar unit (v_cmp -> s_bcnt1_i32_b64 -> s_add), accumulators live in SGPRs.
+template <int CC, int COUNT>
+struct EvalAcc {
+    uint32_t p[CC], f[CC], r[CC];
+    __device__ inline void clear() {
+#pragma unroll
+        for (int c = 0; c < CC; c++) p[c] = f[c] = r[c] = 0;
+    }
+    __device__ inline void add(int c, bool pp, bool ff, bool rr) {
+        if (COUNT == 0) {
+            p[c] += pp; f[c] += ff; r[c] += rr;
+        } else {
+            p[c] += (uint32_t)__popcll(__ballot(pp));
+            f[c] += (uint32_t)__popcll(__ballot(ff));
+            r[c] += (uint32_t)__popcll(__ballot(rr));
+        }
+    }
+};
+
+// FORM 0: bfi select, operand placement left to the compiler (candidate words end up in SGPRs and
+//         the one-SGPR-per-VALU constant-bus rule splits every v_bfi_b32 in two);
+// FORM 1: candidate words pinned in VGPRs: three v_bfi_b32 + one v_or_b32 per evaluation;
+// FORM 2: per-row one-hot words eqX (4 ops per row, shared by the candidates) and a chain of four
+//         v_and_or_b32 with the candidate words as the single SGPR operand.
+template <int CC, int VMODE, int COUNT, int FORM>
+__device__ inline void eval_row(uint32_t b0, uint32_t b1, uint32_t g, const EvalArgs &A,
                                 const uint32_t (&nA)[CC], const uint32_t (&nC)[CC], const uint32_t (&nG)[CC],
-                                const uint32_t (&nT)[CC], uint32_t (&a0)[CC], uint32_t (&aF)[CC], uint32_t (&aR)[CC]) {
-    uint32_t gk = g & kmask;
+                                const uint32_t (&nT)[CC], EvalAcc<CC, COUNT> &acc) {
+    uint32_t gk = g & A.kmask;
     // rows outside the universe (SKIP slots and k-mers with more than v gaps, V20:689) get an
     // all-ones mismatch word: 32 mismatches, counted nowhere
-    if ((int)__popc(gk) > v) gk = 0xFFFFFFFFu;
+    if ((int)__popc(gk) > A.v) gk = 0xFFFFFFFFu;
+    uint32_t eA = 0, eC = 0, eG = 0, eT = 0;
+    if (FORM == 2) { eA = ~(b0 | b1 | gk); eC = b0 & ~b1; eG = b1 & ~b0; eT = b0 & b1; }
 #pragma unroll
     for (int c = 0; c < CC; c++) {
-        uint32_t mm = bfi(b1, bfi(b0, nT[c], nG[c]), bfi(b0, nC[c], nA[c])) | gk;
-        int d = __popc(mm);
-        a0[c] += (d == 0);
-        bool near = (d <= v) && (d != 0);
-        aF[c] += near && !(mm & sF);
-        aR[c] += near && !(mm & sR);
+        uint32_t mm;
+        if (FORM == 2) mm = (eT & nT[c]) | ((eG & nG[c]) | ((eC & nC[c]) | ((eA & nA[c]) | gk)));
+        else mm = bfi(b1, bfi(b0, nT[c], nG[c]), bfi(b0, nC[c], nA[c])) | gk;
+        bool pp = mm == 0, ff, rr;
+        if (VMODE == 0) {
+            ff = rr = pp;
+        } else if (VMODE == 1) {
+            uint32_t t;
+            if (FORM == 0) t = mm - 1u;
+            else asm("v_add_u32_e32 %0, -1, %1" : "=v"(t) : "v"(mm));   // no carry-out: keeps `mm == 0` a plain v_cmp
+            ff = (mm & (t | A.sF)) == 0;
+            rr = (mm & (t | A.sR)) == 0;
+        } else {
+            bool le = (int)__popc(mm) <= A.v;
+            ff = le && (mm & A.sF) == 0;
+            rr = le && (mm & A.sR) == 0;
+        }
+        acc.add(c, pp, ff, rr);
     }
 }
 
-template <int CC>
-__global__ __launch_bounds__(kBlock) void eval_kernel(const uint32_t *__restrict__ win, int n_pad,
-                                                      const EvalItem *__restrict__ items,
-                                                      const uint4 *__restrict__ cand_n,       // [padded cand] nA,nC,nG,nT
-                                                      const int32_t *__restrict__ cand_out,  // [padded cand] index into out or -1
-                                                      const int32_t *__restrict__ extra_off, const uint32_t *__restrict__ extra_words,
-                                                      uint32_t sF, uint32_t sR, int v, uint32_t kmask, int rows_per_split,
-                                                      unsigned long long *__restrict__ out) {
+template <int CC, int VMODE, int COUNT, bool PREFETCH, int FORM, bool P64>
+__global__ __launch_bounds__(kBlock) void eval_kernel(const EvalArgs A) {
     __shared__ uint32_t s_acc[3 * CC];
-    const EvalItem it = items[blockIdx.x];
-    uint32_t nA[CC], nC[CC], nG[CC], nT[CC], a0[CC], aF[CC], aR[CC];
+    const EvalItem it = A.items[blockIdx.x];
+    uint32_t nA[CC], nC[CC], nG[CC], nT[CC];
+    EvalAcc<CC, COUNT> acc;
+    acc.clear();
 #pragma unroll
     for (int c = 0; c < CC; c++) {
-        uint4 q = cand_n[it.cand0 + c];
+        uint4 q = A.cand_n[it.cand0 + c];
         nA[c] = q.x; nC[c] = q.y; nG[c] = q.z; nT[c] = q.w;
-        a0[c] = aF[c] = aR[c] = 0;
+        if (FORM == 1) {
+            asm volatile("" : "+v"(nA[c]));
+            asm volatile("" : "+v"(nC[c]));
+            asm volatile("" : "+v"(nG[c]));
+            asm volatile("" : "+v"(nT[c]));
+        }
     }
     if (threadIdx.x < 3 * CC) s_acc[threadIdx.x] = 0;
-    const size_t np = (size_t)n_pad;
-    const uint32_t *W0 = win + (size_t)it.win * 3 * np, *W1 = W0 + np, *W2 = W1 + np;
-    const int r0 = blockIdx.y * rows_per_split;
-    const int r1 = r0 + rows_per_split < n_pad ? r0 + rows_per_split : n_pad;
-    // 4 consecutive sequences per lane: three 16-byte loads per iteration (n_pad % 4 == 0)
-    for (int r = r0 + threadIdx.x * 4; r < r1; r += kBlock * 4) {
-        uint4 x0 = *reinterpret_cast<const uint4 *>(W0 + r);
-        uint4 x1 = *reinterpret_cast<const uint4 *>(W1 + r);
-        uint4 x2 = *reinterpret_cast<const uint4 *>(W2 + r);
-        eval_row<CC>(x0.x, x1.x, x2.x, kmask, v, sF, sR, nA, nC, nG, nT, a0, aF, aR);
-        eval_row<CC>(x0.y, x1.y, x2.y, kmask, v, sF, sR, nA, nC, nG, nT, a0, aF, aR);
-        eval_row<CC>(x0.z, x1.z, x2.z, kmask, v, sF, sR, nA, nC, nG, nT, a0, aF, aR);
-        eval_row<CC>(x0.w, x1.w, x2.w, kmask, v, sF, sR, nA, nC, nG, nT, a0, aF, aR);
+    const size_t np = (size_t)A.n_pad;
+    const WinView<P64> V(A.win, it.win, np, A.k, A.kmask);
+    typedef typename WinView<P64>::Raw4 Raw4;
+    const int r0 = blockIdx.y * A.rows_per_split;
+    const int r1 = r0 + A.rows_per_split < A.n_pad ? r0 + A.rows_per_split : A.n_pad;
+    // 4 consecutive sequences per lane and iteration, 16-byte loads (n_pad % 4 == 0)
+    int r = r0 + threadIdx.x * 4;
+    Raw4 cur;
+    if (PREFETCH && r < r1) cur = V.load4(r);
+#pragma unroll 1
+    while (r < r1) {
+        const int rn = r + kBlock * 4;
+        Raw4 now;
+        if (PREFETCH) {
+            now = cur;
+            if (rn < r1) cur = V.load4(rn);          // next group in flight while this one computes
+        } else {
+            now = V.load4(r);
+        }
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            uint32_t b0, b1, g;
+            V.unpack(now, i, b0, b1, g);
+            eval_row<CC, VMODE, COUNT, FORM>(b0, b1, g, A, nA, nC, nG, nT, acc);
+        }
+        r = rn;
     }
-    if (blockIdx.y == 0 && extra_off) {      // host-expanded IUPAC rows of this window
-        for (int e = extra_off[it.win] + threadIdx.x; e < extra_off[it.win + 1]; e += kBlock)
-            eval_row<CC>(extra_words[3 * e], extra_words[3 * e + 1], extra_words[3 * e + 2], kmask, v, sF, sR,
-                         nA, nC, nG, nT, a0, aF, aR);
+    if (blockIdx.y == 0 && A.extra_off) {      // host-expanded IUPAC rows of this window
+        const int e0 = A.extra_off[it.win], e1 = A.extra_off[it.win + 1];
+        for (int eb = e0; eb < e1; eb += kBlock) {   // uniform trip count: COUNT 1 ballots need every lane
+            int e = eb + threadIdx.x;
+            uint32_t b0 = 0, b1 = 0, g = 0xFFFFFFFFu;
+            if (e < e1) { b0 = A.extra_words[3 * e]; b1 = A.extra_words[3 * e + 1]; g = A.extra_words[3 * e + 2]; }
+            eval_row<CC, VMODE, COUNT, FORM>(b0, b1, g, A, nA, nC, nG, nT, acc);
+        }
     }
     __syncthreads();
-    // wave reduction, then one LDS add per wave and one global atomic per counter per block
 #pragma unroll
     for (int c = 0; c < CC; c++) {
-        uint32_t x = a0[c], y = aF[c], z = aR[c];
+        uint32_t x = acc.p[c], y = acc.f[c], z = acc.r[c];
+        if (COUNT == 0) {
 #pragma unroll
-        for (int s = 32; s >= 1; s >>= 1) {
-            x += __shfl_xor(x, s);
-            y += __shfl_xor(y, s);
-            z += __shfl_xor(z, s);
+            for (int s = 32; s >= 1; s >>= 1) {
+                x += __shfl_xor(x, s);
+                y += __shfl_xor(y, s);
+                z += __shfl_xor(z, s);
+            }
         }
         if ((threadIdx.x & 63) == 0) {
             atomicAdd(&s_acc[3 * c], x);
-            atomicAdd(&s_acc[3 * c + 1], y);
-            atomicAdd(&s_acc[3 * c + 2], z);
+            atomicAdd(&s_acc[3 * c + 1], y - x);      // F_mis = F_raw - perfect
+            atomicAdd(&s_acc[3 * c + 2], z - x);
         }
     }
     __syncthreads();
     if (threadIdx.x < 3 * CC) {
-        int oc = cand_out[it.cand0 + threadIdx.x / 3];
+        int oc = A.cand_out[it.cand0 + threadIdx.x / 3];
         uint32_t val = s_acc[threadIdx.x];
-        if (oc >= 0 && val) atomicAdd(&out[(size_t)oc * 3 + threadIdx.x % 3], (unsigned long long)val);
+        if (oc >= 0 && val) atomicAdd(&A.out[(size_t)oc * 3 + threadIdx.x % 3], (unsigned long long)val);
     }
 }
+
+typedef void (*EvalFn)(const EvalArgs);
+struct EvalVariant { const char *name; EvalFn fn[2][3]; };     // fn[P64][VMODE]
+#define EVAL_VARIANT(name, COUNT, PREFETCH, FORM)                                                         \
+    { name, { { eval_kernel<kEvalCC, 0, COUNT, PREFETCH, FORM, false>, eval_kernel<kEvalCC, 1, COUNT, PREFETCH, FORM, false>, \
+                eval_kernel<kEvalCC, 2, COUNT, PREFETCH, FORM, false> },                                   \
+              { eval_kernel<kEvalCC, 0, COUNT, PREFETCH, FORM, true>, eval_kernel<kEvalCC, 1, COUNT, PREFETCH, FORM, true>,   \
+                eval_kernel<kEvalCC, 2, COUNT, PREFETCH, FORM, true> } } }
+// variant 0 is the default; the others exist to be measured (tools/variant_bench.py, MP_EVAL_VARIANT)
+const EvalVariant kEvalVariants[] = {
+    EVAL_VARIANT("ballot+prefetch/onehot", 1, true, 2),      // default: fastest measured (profiles/r01_variants.txt)
+    EVAL_VARIANT("ballot+prefetch/bfi-vgpr", 1, true, 1),
+    EVAL_VARIANT("ballot+prefetch/bfi-sgpr", 1, true, 0),
+    EVAL_VARIANT("lane-acc+prefetch/onehot", 0, true, 2),
+    EVAL_VARIANT("ballot/onehot", 1, false, 2),
+};
+constexpr int kNumEvalVariants = (int)(sizeof(kEvalVariants) / sizeof(kEvalVariants[0]));
 
 }  // namespace
 
@@ -515,7 +680,9 @@ struct mp_ctx {
     int32_t *lead = nullptr, *rstrip = nullptr, *rlen = nullptr;
     // windows
     int p0 = 0, n_win = 0, k = 0, v = 0;
-    uint32_t *win = nullptr;
+    void *win = nullptr;
+    bool p64 = false;
+    size_t win_bytes = 0;
     ExRec *ex = nullptr;
     int ex_cap = 0;
     int *ex_count = nullptr, *err_flag = nullptr;
@@ -542,6 +709,7 @@ struct mp_ctx {
     std::vector<std::pair<hipEvent_t, hipEvent_t>> ev_busy, ev_free;
     double ev_ms = 0;
     int ev_n = 0;
+    int eval_variant = 0;
 };
 
 namespace {
@@ -600,7 +768,7 @@ void free_unique(mp_ctx *c) {
 void free_windows(mp_ctx *c) {
     free_eval(c);
     free_unique(c);
-    dev_free(c, &c->win, (size_t)c->n_win * 3 * c->n_pad);
+    if (c->win) { (void)hipFree(c->win); c->bytes -= (int64_t)c->win_bytes; c->win = nullptr; c->win_bytes = 0; }
     dev_free(c, &c->ex, (size_t)c->ex_cap);
     dev_free(c, &c->ex_count, 1);
     dev_free(c, &c->err_flag, 4);
@@ -737,7 +905,15 @@ int mp_build_windows(mp_ctx *c, int32_t p0, int32_t n_win, int32_t k, int32_t v,
     c->p0 = p0; c->n_win = n_win; c->k = k; c->v = v;
     size_t np = (size_t)c->n_pad;
     int rc;
-    if ((rc = dev_alloc(c, &c->win, (size_t)n_win * 3 * np))) return rc;
+    // one packed u64 per (window, sequence) when 3k bits + the flag fit, else three u32 planes
+    c->p64 = 3 * k <= 63 && !getenv("MP_WIN_NO_PACK");
+    {
+        uint8_t *wp = nullptr;
+        size_t nb = (size_t)n_win * np * (c->p64 ? 8 : 12);
+        if ((rc = dev_alloc(c, &wp, nb))) return rc;
+        c->win = wp;
+        c->win_bytes = nb;
+    }
     if ((rc = dev_alloc(c, &c->ex_count, 1))) return rc;
     if ((rc = dev_alloc(c, &c->err_flag, 4))) return rc;
     if ((rc = dev_alloc(c, &c->extra_off, (size_t)n_win + 1))) return rc;
@@ -750,9 +926,14 @@ int mp_build_windows(mp_ctx *c, int32_t p0, int32_t n_win, int32_t k, int32_t v,
         HIPCK(c, hipMemsetAsync(c->ex_count, 0, sizeof(int), c->stream));
         HIPCK(c, hipMemsetAsync(c->err_flag, 0, 4 * sizeof(int), c->stream));
         dim3 grid((unsigned)(c->n_pad / kBlock), (unsigned)((n_win + tile - 1) / tile));
-        hipLaunchKernelGGL(build_windows_kernel, grid, dim3(kBlock), 0, c->stream, c->planes, c->cum, c->ung, c->rlen,
-                           c->n_rows, c->n_pad, c->n_chunks, c->ustride, p0, n_win, tile, k, c->win, c->ex, cap,
-                           c->ex_count, c->err_flag);
+        if (c->p64)
+            hipLaunchKernelGGL(build_windows_kernel<true>, grid, dim3(kBlock), 0, c->stream, c->planes, c->cum, c->ung, c->rlen,
+                               c->n_rows, c->n_pad, c->n_chunks, c->ustride, p0, n_win, tile, k, c->win, c->ex, cap,
+                               c->ex_count, c->err_flag);
+        else
+            hipLaunchKernelGGL(build_windows_kernel<false>, grid, dim3(kBlock), 0, c->stream, c->planes, c->cum, c->ung, c->rlen,
+                               c->n_rows, c->n_pad, c->n_chunks, c->ustride, p0, n_win, tile, k, c->win, c->ex, cap,
+                               c->ex_count, c->err_flag);
         HIPCK(c, hipGetLastError());
         int cnt = 0, errv[4] = {0, 0, 0, 0};
         HIPCK(c, hipMemcpyAsync(&cnt, c->ex_count, sizeof(int), hipMemcpyDeviceToHost, c->stream));
@@ -817,8 +998,23 @@ int mp_get_window_words(mp_ctx *c, int32_t w, int32_t row0, int32_t n, uint32_t 
     if (w < 0 || w >= c->n_win || row0 < 0 || n < 0 || row0 + n > c->n_rows) return fail(c, MP_ERR_ARG, "bad range");
     HIPCK(c, hipSetDevice(c->dev));
     size_t np = (size_t)c->n_pad;
+    if (c->p64) {
+        std::vector<uint64_t> tmp((size_t)n + 1);
+        HIPCK(c, hipMemcpyAsync(tmp.data(), (const uint64_t *)c->win + (size_t)w * np + row0, sizeof(uint64_t) * (size_t)n,
+                                hipMemcpyDeviceToHost, c->stream));
+        HIPCK(c, hipStreamSynchronize(c->stream));
+        const uint32_t kmask = (1u << c->k) - 1u;
+        for (int i = 0; i < n; i++) {
+            uint64_t x = tmp[(size_t)i];
+            out[i] = (uint32_t)x & kmask;
+            out[(size_t)n + i] = (uint32_t)(x >> c->k) & kmask;
+            out[2 * (size_t)n + i] = ((uint32_t)(x >> (2 * c->k)) & kmask) | ((uint32_t)(x >> 32) & MP_WIN_SKIP);
+        }
+        return MP_OK;
+    }
+    const uint32_t *W = (const uint32_t *)c->win;
     for (int p = 0; p < 3; p++)
-        HIPCK(c, hipMemcpyAsync(out + (size_t)p * n, c->win + ((size_t)w * 3 + p) * np + row0, sizeof(uint32_t) * (size_t)n,
+        HIPCK(c, hipMemcpyAsync(out + (size_t)p * n, W + ((size_t)w * 3 + p) * np + row0, sizeof(uint32_t) * (size_t)n,
                                 hipMemcpyDeviceToHost, c->stream));
     HIPCK(c, hipStreamSynchronize(c->stream));
     return MP_OK;
@@ -847,8 +1043,12 @@ int mp_window_unique(mp_ctx *c, int64_t cap, int32_t want_labels, int64_t *n_ent
     HIPCK(c, hipMemsetAsync(c->u_total, 0, sizeof(unsigned long long), c->stream));
     UniqueOut uo{c->u_b0, c->u_b1, c->u_g, c->u_count, c->u_first, (long long)cap, c->u_total,
                  c->u_wbase, c->u_wcount, c->labels, c->u_over};
-    hipLaunchKernelGGL(unique_kernel<true>, dim3((unsigned)W), dim3(kBlock), 0, c->stream, c->win, c->n_rows, c->n_pad,
-                       (const int32_t *)nullptr, kHashSlots, kHashLimit, (uint32_t *)nullptr, uo);
+    if (c->p64)
+        hipLaunchKernelGGL((unique_kernel<true, true>), dim3((unsigned)W), dim3(kBlock), 0, c->stream, (const void *)c->win, c->k,
+                           c->n_rows, c->n_pad, (const int32_t *)nullptr, kHashSlots, kHashLimit, (uint32_t *)nullptr, uo);
+    else
+        hipLaunchKernelGGL((unique_kernel<true, false>), dim3((unsigned)W), dim3(kBlock), 0, c->stream, (const void *)c->win, c->k,
+                           c->n_rows, c->n_pad, (const int32_t *)nullptr, kHashSlots, kHashLimit, (uint32_t *)nullptr, uo);
     HIPCK(c, hipGetLastError());
     std::vector<int32_t> over(W);
     HIPCK(c, hipMemcpyAsync(over.data(), c->u_over, sizeof(int32_t) * W, hipMemcpyDeviceToHost, c->stream));
@@ -867,8 +1067,12 @@ int mp_window_unique(mp_ctx *c, int64_t cap, int32_t want_labels, int64_t *n_ent
         for (size_t i = 0; i < big.size(); i += batch) {
             size_t nb = std::min(batch, big.size() - i);
             HIPCK(c, hipMemcpy(d_list, big.data() + i, sizeof(int32_t) * nb, hipMemcpyHostToDevice));
-            hipLaunchKernelGGL(unique_kernel<false>, dim3((unsigned)nb), dim3(kBlock), 0, c->stream, c->win, c->n_rows,
-                               c->n_pad, (const int32_t *)d_list, slots, slots - 32, gtable, uo);
+            if (c->p64)
+                hipLaunchKernelGGL((unique_kernel<false, true>), dim3((unsigned)nb), dim3(kBlock), 0, c->stream, (const void *)c->win,
+                                   c->k, c->n_rows, c->n_pad, (const int32_t *)d_list, slots, slots - 32, gtable, uo);
+            else
+                hipLaunchKernelGGL((unique_kernel<false, false>), dim3((unsigned)nb), dim3(kBlock), 0, c->stream, (const void *)c->win,
+                                   c->k, c->n_rows, c->n_pad, (const int32_t *)d_list, slots, slots - 32, gtable, uo);
             HIPCK(c, hipGetLastError());
             HIPCK(c, hipStreamSynchronize(c->stream));
         }
@@ -999,9 +1203,15 @@ int mp_eval_launch(mp_ctx *c, int64_t *device_out) {
     if (!c->ev_free.empty()) { ev = c->ev_free.back(); c->ev_free.pop_back(); }
     else { HIPCK(c, hipEventCreate(&ev.first)); HIPCK(c, hipEventCreate(&ev.second)); }
     HIPCK(c, hipEventRecord(ev.first, c->stream));
-    hipLaunchKernelGGL(eval_kernel<kEvalCC>, dim3((unsigned)c->n_items, (unsigned)split), dim3(kBlock), 0, c->stream, c->win,
-                       c->n_pad, c->items, c->cand_n, c->cand_out, c->n_extra ? c->extra_off : (const int32_t *)nullptr,
-                       c->extra_words, c->sF, c->sR, c->v, (1u << c->k) - 1u, rows, (unsigned long long *)device_out);
+    EvalArgs ea{c->win, c->n_pad, c->k, c->items, c->cand_n, c->cand_out, c->n_extra ? c->extra_off : (const int32_t *)nullptr,
+                c->extra_words, c->sF, c->sR, c->v, (1u << c->k) - 1u, rows, (unsigned long long *)device_out};
+    int variant = c->eval_variant;
+    if (const char *e = getenv("MP_EVAL_VARIANT")) variant = atoi(e);
+    if (variant < 0 || variant >= kNumEvalVariants) variant = 0;
+    // the predicate specialisation is chosen by --variation: 0, 1 (pipeline default) or general
+    const int vmode = c->v == 0 ? 0 : (c->v == 1 ? 1 : 2);
+    hipLaunchKernelGGL(kEvalVariants[variant].fn[c->p64 ? 1 : 0][getenv("MP_EVAL_GENERIC_V") ? 2 : vmode], dim3((unsigned)c->n_items, (unsigned)split),
+                       dim3(kBlock), 0, c->stream, ea);
     HIPCK(c, hipEventRecord(ev.second, c->stream));
     c->ev_busy.push_back(ev);
     HIPCK(c, hipGetLastError());
