@@ -133,6 +133,40 @@ int mp_eval_launch(mp_ctx *ctx, int64_t *device_out);
  * every mp_eval_launch since the last reset): total milliseconds and number of launches. */
 int mp_eval_timing(mp_ctx *ctx, int32_t reset, double *total_ms, int32_t *n_launches);
 
+/* (5) 3'-end dimer scan — SURVEY §8a rows D and M ------------------------------------------- */
+/* Replaces the search loops of Dimer.dimer_check (scripts/finDimer_V4.py:191-224) and of
+ * dimer_examination (scripts/get_Maxprimerset_V1.3.py:193-215).  Primers are given as symbol
+ * codes (IUPAC allowed, no gaps), primer p = codes[off[p] .. off[p+1]), length <= MP_DIMER_MAX_LEN.
+ *
+ * For a primer x and an "end" length l, every expansion e of x's 3' suffix of length l (in the
+ * reference's expansion order, last position fastest) is searched as RC(e) in every expansion p
+ * of the other primer y (same order); only the FIRST occurrence idx in p counts (str.find).  With
+ * d2 = len(p) - l - idx and GC = #G+#C in e the pair is a dimer hit when
+ *     loss_hit[l][GC][d2] != 0                  (Loss = Penalty_points(l,GC,0,d2) >= threshold)
+ *  or d2 == 0 and deltaG(e) < dg_limit          (deltaG < -5 after rounding to 2 decimals)
+ * The Loss decision table and the deltaG constants are supplied by the caller, computed with the
+ * reference's own libm expressions, so that no device-side log10 / multiply can change a call:
+ *   loss_hit  [MP_DIMER_MAX_LEN+1][MP_DIMER_MAX_LEN+1][64] bytes
+ *   dg_params [16] stack terms indexed [next][this] (finDimer_V4.py:176-178), then [32] initiation
+ *             terms indexed [first][last][ends with "TA"] (:179-183), then [MP_DIMER_MAX_LEN+1] the Na+ term
+ *             times the length (:185), then [1] the symmetry correction (:186-187); deltaG is the
+ *             left-to-right double sum of those.
+ *   dg_limit  the smallest double whose 2-decimal rounding is not below -5.
+ *
+ * mode 0 (finDimer): unordered pairs i <= j, ends of i only, end lengths min(t, len_i) for
+ *   t = 18 .. 5 (finDimer_V4.py:162-169), longest first, then expansion of the end, then
+ *   expansion of j; the first passing combination is the pair's hit and the scan of the pair stops
+ *   (at most one hit per pair).  hits[6h..] = {i, j, l, end expansion index, j expansion index, idx}.
+ * mode 1 (Maxprimerset): ordered pairs (x, y) with x < n_new or y < n_new (the new primers are
+ *   listed first; pairs among the old ones were verified when they were added), end lengths
+ *   len_x-1 .. 5 (get_Maxprimerset_V1.3.py:149-154); same hit record, one per pair.
+ * hits has room for cap_hits records; *n_hits returns the number found (may exceed cap_hits,
+ * in which case only the first cap_hits written are valid).  Order of records is unspecified. */
+#define MP_DIMER_MAX_LEN 32
+int mp_dimer_scan(mp_ctx *ctx, int32_t n_primers, const uint8_t *codes, const int32_t *off, int32_t mode,
+                  int32_t n_new, const uint8_t *loss_hit, const double *dg_params, double dg_limit,
+                  int64_t cap_hits, int32_t *hits, int64_t *n_hits);
+
 /* Memory the context holds on the device, in bytes (window words, planes, tables). */
 int mp_device_bytes(mp_ctx *ctx, int64_t *bytes);
 

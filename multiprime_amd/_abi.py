@@ -40,6 +40,8 @@ SYMBOLS = [
     ("mp_eval_upload", C.c_int, [_p, C.c_int32, _p, _p, C.c_uint32, C.c_uint32]),
     ("mp_eval_launch", C.c_int, [_p, _p]),
     ("mp_eval_timing", C.c_int, [_p, C.c_int32, C.POINTER(C.c_double), C.POINTER(C.c_int32)]),
+    ("mp_dimer_scan", C.c_int, [_p, C.c_int32, _p, _p, C.c_int32, C.c_int32, _p, _p, C.c_double, C.c_int64, _p,
+                                C.POINTER(C.c_int64)]),
     ("mp_device_bytes", C.c_int, [_p, C.POINTER(C.c_int64)]),
 ]
 
@@ -204,6 +206,24 @@ class Context:
         ms, n = C.c_double(0), C.c_int32(0)
         self._ck(self.d.mp_eval_timing(self.h, int(reset), C.byref(ms), C.byref(n)))
         return ms.value, n.value
+
+    # (5)
+    def dimer_scan(self, codes: np.ndarray, off: np.ndarray, mode: int, n_new: int, loss_hit: np.ndarray,
+                   dg_params: np.ndarray, dg_limit: float, cap: int = 1 << 16) -> np.ndarray:
+        """Hit records [n][6] = (x, y, end length, end expansion, y expansion, idx), sorted."""
+        codes = np.ascontiguousarray(codes, dtype=np.uint8)
+        off = np.ascontiguousarray(off, dtype=np.int32)
+        loss_hit = np.ascontiguousarray(loss_hit, dtype=np.uint8)
+        dg_params = np.ascontiguousarray(dg_params, dtype=np.float64)
+        while True:
+            hits = np.empty((max(cap, 1), 6), np.int32)
+            n = C.c_int64(0)
+            self._ck(self.d.mp_dimer_scan(self.h, len(off) - 1, _ptr(codes), _ptr(off), mode, n_new, _ptr(loss_hit),
+                                          _ptr(dg_params), dg_limit, cap, _ptr(hits), C.byref(n)))
+            if n.value <= cap:
+                h = hits[: n.value]
+                return h[np.lexsort((h[:, 1], h[:, 0]))] if len(h) else h
+            cap = int(n.value)
 
     def device_bytes(self) -> int:
         b = C.c_int64(0)

@@ -452,3 +452,118 @@ int mp_device_bytes(mp_ctx *c, int64_t *bytes) {
     *bytes = 0;
     return MP_OK;
 }
+
+/* =================================================================================================
+ * (5) 3'-end dimer scan: restatement of Dimer.dimer_check (finDimer_V4.py:191-224, "FD" below) and
+ * dimer_examination (get_Maxprimerset_V1.3.py:193-215, "MS"), on character strings.
+ * ================================================================================================= */
+static const char *iupac_members(uint8_t code) {
+    /* FD:46-48 degenerate_base / MS:70-72 degenerate_pair: member order of each symbol */
+    switch (code) {
+    case 1: return "A"; case 2: return "C"; case 4: return "G"; case 8: return "T";
+    case 5: return "AG"; case 10: return "CT"; case 3: return "AC"; case 12: return "GT";
+    case 6: return "GC"; case 9: return "AT"; case 11: return "ATC"; case 14: return "GTC";
+    case 7: return "GAC"; case 13: return "GAT"; case 15: return "ATGC";
+    default: return NULL;
+    }
+}
+
+/* expansion number `idx` of codes[0..n) in itertools.product order (last position fastest), FD:146-158 */
+static void expand_at(const uint8_t *codes, int n, long long idx, char *out) {
+    for (int p = n - 1; p >= 0; p--) {
+        const char *m = iupac_members(codes[p]);
+        int sz = (int)strlen(m);
+        out[p] = m[idx % sz];
+        idx /= sz;
+    }
+    out[n] = 0;
+}
+
+static long long n_expansions(const uint8_t *codes, int n) {
+    long long d = 1;
+    for (int p = 0; p < n; p++) {
+        const char *m = iupac_members(codes[p]);
+        if (!m) return -1;
+        d *= (long long)strlen(m);
+        if (d > (1LL << 24)) return -2;
+    }
+    return d;
+}
+
+static char comp_char(char c) { return c == 'A' ? 'T' : c == 'T' ? 'A' : c == 'C' ? 'G' : 'C'; }
+
+/* deltaG of a concrete end, FD:171-189, as the left-to-right sum of the caller's constants */
+static double end_delta_g(const char *e, int l, const double *dg) {
+    double g = 0;
+    for (int n = 0; n + 1 < l; n++) g += dg[base_index(e[n + 1]) * 4 + base_index(e[n])];           /* FD:176-178 */
+    int ta = l >= 2 && e[l - 2] == 'T' && e[l - 1] == 'A';                                            /* FD:179-180 */
+    g += dg[16 + (base_index(e[0]) * 4 + base_index(e[l - 1])) * 2 + ta];                            /* FD:181-183 */
+    g -= dg[48 + l];                                                                                   /* FD:185 */
+    int sym = (l % 2 == 0);                                                                            /* FD:115-125 */
+    for (int t = 0; sym && t < l / 2; t++) if (e[t] != comp_char(e[l / 2 + t])) sym = 0;
+    if (sym) g += dg[48 + MP_DIMER_MAX_LEN + 1];                                                      /* FD:186-187 */
+    return g;
+}
+
+/* one (x, y) pair; returns 1 and fills rec on the first passing combination */
+static int dimer_pair(const uint8_t *cx, int lx, const uint8_t *cy, int ly, int l_hi, int l_lo,
+                      const uint8_t *loss_hit, const double *dg, double dg_limit, int32_t *rec) {
+    char e[MP_DIMER_MAX_LEN + 1], rc[MP_DIMER_MAX_LEN + 1], p[MP_DIMER_MAX_LEN + 1];
+    long long dy = n_expansions(cy, ly);
+    for (int l = l_hi; l >= l_lo; l--) {                       /* ends sorted by length, longest first (FD:193) */
+        if (l <= 0 || l > lx) continue;
+        const uint8_t *suffix = cx + (lx - l);                 /* primer[-l:] */
+        long long de = n_expansions(suffix, l);
+        for (long long ei = 0; ei < de; ei++) {
+            expand_at(suffix, l, ei, e);
+            for (int t = 0; t < l; t++) rc[t] = comp_char(e[l - 1 - t]);      /* reversecomplement(end) */
+            rc[l] = 0;
+            int gc = 0;
+            for (int t = 0; t < l; t++) gc += e[t] == 'G' || e[t] == 'C';
+            for (long long pi = 0; pi < dy; pi++) {            /* for p in degenerate_seq(ps), FD:197 */
+                expand_at(cy, ly, pi, p);
+                const char *f = strstr(p, rc);                 /* p.find(...): first occurrence, FD:198 */
+                if (!f) continue;
+                int idx = (int)(f - p);
+                int d2 = ly - l - idx;                         /* FD:203 */
+                int hit = loss_hit[((size_t)l * (MP_DIMER_MAX_LEN + 1) + gc) * 64 + d2];      /* Loss >= threshold */
+                if (!hit && d2 == 0) hit = end_delta_g(e, l, dg) < dg_limit;                  /* delta_G < -5 and d1 == d2 */
+                if (hit) {
+                    rec[2] = l; rec[3] = (int32_t)ei; rec[4] = (int32_t)pi; rec[5] = idx;
+                    return 1;
+                }
+            }
+        }
+    }
+    return 0;
+}
+
+int mp_dimer_scan(mp_ctx *c, int32_t n, const uint8_t *codes, const int32_t *off, int32_t mode, int32_t n_new,
+                  const uint8_t *loss_hit, const double *dg, double dg_limit, int64_t cap, int32_t *hits, int64_t *n_hits) {
+    if (!c) return MP_ERR_ARG;
+    if (n < 0 || !codes || !off || !loss_hit || !dg || !n_hits || (mode != 0 && mode != 1)) return fail(c, MP_ERR_ARG, "mp_dimer_scan: bad arguments");
+    for (int32_t i = 0; i < n; i++) {
+        int len = off[i + 1] - off[i];
+        if (len < 1 || len > MP_DIMER_MAX_LEN) return fail(c, MP_ERR_ARG, "primer %d has length %d (1..%d supported)", i, len, MP_DIMER_MAX_LEN);
+        long long d = n_expansions(codes + off[i], len);
+        if (d < 0) return fail(c, MP_ERR_ARG, d == -1 ? "primer %d holds a gap / unknown symbol" : "primer %d has too many expansions", i);
+    }
+    int64_t nh = 0;
+    for (int32_t x = 0; x < n; x++) {
+        int lx = off[x + 1] - off[x];
+        for (int32_t y = (mode == 0 ? x : 0); y < n; y++) {
+            if (mode == 1 && x >= n_new && y >= n_new) continue;
+            int ly = off[y + 1] - off[y];
+            int32_t rec[6] = {x, y, 0, 0, 0, 0};
+            int l_hi, l_lo;
+            if (mode == 0) { l_hi = lx < 18 ? lx : 18; l_lo = lx < 5 ? lx : 5; }     /* FD:162-169: primer[-i:], i = 5..18 */
+            else { l_hi = lx - 1; l_lo = 5; }                                          /* MS:149-154: range(5, len) */
+            if (dimer_pair(codes + off[x], lx, codes + off[y], ly, l_hi, l_lo, loss_hit, dg, dg_limit, rec)) {
+                if (nh < cap && hits) memcpy(hits + 6 * nh, rec, sizeof rec);
+                nh++;
+            }
+        }
+    }
+    *n_hits = nh;
+    return MP_OK;
+}

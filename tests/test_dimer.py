@@ -1,0 +1,126 @@
+"""SURVEY §8a rows D (finDimer.py) and M (get_Maxprimerset.py): host logic + mp_dimer_scan against
+outputs recorded from the unmodified reference scripts (tests/golden/make_golden_dimer.py).
+finDimer's row order is the arrival order of a process pool, so hit lines compare as sorted lists;
+every field (Delta G, Loss as printed doubles) must be identical."""
+import contextlib
+import gzip
+import io
+import json
+import os
+import types
+
+import numpy as np
+import pytest
+
+from conftest import GOLDEN
+from multiprime_amd import dimer, iupac, maxset
+
+
+@pytest.fixture(scope="module")
+def gold():
+    return json.loads(gzip.open(os.path.join(GOLDEN, "dimer_maxset.json.gz")).read())
+
+
+FD = [("findimer_cluster0", "cluster0_candidates.fa", 3.96), ("findimer_cluster0_t3", "cluster0_candidates.fa", 3.0),
+      ("findimer_syn_a", "findimer_syn_a.fa", 3.96), ("findimer_syn_a_t3", "findimer_syn_a.fa", 3.0),
+      ("findimer_syn_b", "findimer_syn_b.fa", 3.96), ("findimer_syn_b_t3", "findimer_syn_b.fa", 3.0)]
+MS = ["maxset_shipped", "maxset_fake1", "maxset_fake2", "maxset_fake3"]
+
+
+def test_dg_limit_is_the_rounding_boundary():
+    import math
+    lim = dimer.dg_limit()
+    assert round(lim, 2) >= -5 and round(math.nextafter(lim, -math.inf), 2) < -5
+
+
+def check_findimer(lib, gold, name, inp, thr, tmp_path):
+    fa = tmp_path / inp
+    fa.write_bytes(gzip.open(os.path.join(GOLDEN, "inputs", inp + ".gz")).read())
+    out = tmp_path / "dimer.tsv"
+    dimer.Dimer(primer_file=str(fa), outfile=str(out), threshold=thr, library=lib).run()
+    lines = out.read_text().splitlines()
+    num = open(str(out) + ".dimer_num").read().splitlines()
+    want = gold[name]
+    assert lines[0] == want["header"] and sorted(lines[1:]) == want["hits"]
+    assert num[0] == want["dimer_num_header"] and sorted(num[1:]) == want["dimer_num"]
+
+
+def check_maxset(lib, gold, name, method, tmp_path):
+    want = gold[f"{name}_{method}"]
+    if name == "maxset_shipped":
+        text = gzip.open(os.path.join(GOLDEN, "inputs", "candidate_primers_sets.txt.gz")).read().decode()
+    else:
+        text = "".join("\t".join(r) + "\n" for r in gold[name + "_rows"])
+    inp = tmp_path / "cand.txt"
+    inp.write_text(text)
+    out = tmp_path / "final.xls"
+    opts = types.SimpleNamespace(input=str(inp), step=5, method=method, out=str(out), device=0)
+    buf, rc = io.StringIO(), 0
+    with contextlib.redirect_stdout(buf):
+        try:
+            maxset.run(opts, library=lib)
+        except SystemExit as e:
+            rc = e.code
+    nxt = str(out).rstrip(".xls") + ".next.xls"          # the reference strips characters, not the suffix
+    assert rc == want["returncode"]
+    assert buf.getvalue().splitlines() == want["stdout"]
+    assert (out.read_text() if out.exists() else None) == want["out"]
+    assert (open(nxt).read() if os.path.exists(nxt) else None) == want["next"]
+    assert (tmp_path / "sort.cand.txt").read_text() == want["sort"]
+
+
+@pytest.mark.parametrize("name,inp,thr", FD)
+def test_findimer_matches_reference(name, inp, thr, oracle_lib, gold, tmp_path):
+    check_findimer(oracle_lib, gold, name, inp, thr, tmp_path)
+
+
+@pytest.mark.parametrize("name", MS)
+@pytest.mark.parametrize("method", ["T", "F"])
+def test_maxprimerset_matches_reference(name, method, oracle_lib, gold, tmp_path):
+    check_maxset(oracle_lib, gold, name, method, tmp_path)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name,inp,thr", FD)
+def test_findimer_hip_matches_reference(name, inp, thr, hip_lib, gold, tmp_path):
+    check_findimer(hip_lib, gold, name, inp, thr, tmp_path)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", MS)
+@pytest.mark.parametrize("method", ["T", "F"])
+def test_maxprimerset_hip_matches_reference(name, method, hip_lib, gold, tmp_path):
+    check_maxset(hip_lib, gold, name, method, tmp_path)
+
+
+def random_primers(seed, n, p_deg):
+    rng = np.random.default_rng(seed)
+    out = []
+    for _ in range(n):
+        L = int(rng.integers(4, 33))
+        s = [("ACGT"[int(rng.integers(0, 4))]) for _ in range(L)]
+        for p in range(L):
+            if rng.random() < p_deg:
+                s[p] = "RYMKSWHBVDN"[int(rng.integers(0, 11))]
+        out.append("".join(s))
+    for _ in range(n // 2):                               # plant complementary 3' ends
+        i, j = int(rng.integers(0, n)), int(rng.integers(0, n))
+        e = iupac.expand(out[i][-int(rng.integers(5, 10)):])[0]
+        t = iupac.revcomp(e)
+        if len(out[j]) >= len(t):
+            pos = len(out[j]) - len(t) - int(rng.integers(0, 3))
+            if pos >= 0:
+                out[j] = out[j][:pos] + t + out[j][pos + len(t):]
+    return out
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("seed,n,p_deg,mode", [(1, 400, 0.03, 0), (2, 150, 0.12, 0), (3, 300, 0.0, 1), (4, 64, 0.2, 0),
+                                               (5, 500, 0.0, 0)])
+def test_dimer_scan_hip_equals_oracle(hip_lib, oracle_lib, seed, n, p_deg, mode):
+    seqs = random_primers(seed, n, p_deg)
+    codes, off = dimer.encode_primers(seqs)
+    args = (codes, off, mode, n // 5, dimer.cached_loss_table(3.0 if mode else 3.96), dimer.dg_params(), dimer.dg_limit())
+    h = hip_lib.context(0).dimer_scan(*args)
+    o = oracle_lib.context(0).dimer_scan(*args)
+    assert len(o) > 0 and h.tolist() == o.tolist()
