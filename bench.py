@@ -145,6 +145,21 @@ def main():
     elapsed = time.perf_counter() - t0
     kern_ms, kern_n = ctx.eval_timing(reset=True)
 
+    # measured device-copy bandwidth (SURVEY §8d asks for it next to the spec peak): 1 GiB d2d, read + write
+    copy_gbs = None
+    if rank == 0:
+        src = torch.empty(1 << 28, dtype=torch.float32, device=dev)
+        dst = torch.empty_like(src)
+        dst.copy_(src)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(5):
+            dst.copy_(src)
+        e1.record()
+        torch.cuda.synchronize()
+        copy_gbs = 5 * 2 * src.numel() * 4 / (e0.elapsed_time(e1) * 1e-3) / 1e9
+        del src, dst
+
     tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
     ev = torch.tensor([evals_local], dtype=torch.int64, device=dev)
     if world > 1:
@@ -182,7 +197,7 @@ def main():
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "algorithmic_bytes": alg_bytes,
                          "kernel": "eval_kernel<8,v1,ballot,prefetch,onehot,packed64>", "kernel_ms": per_launch_ms, "launches_timed": kern_n,
                          "algorithmic_bytes_per_eval": 3 * k / 8.0},
-            "setup_s": setup_s, "device_bytes": ctx.device_bytes(), "counter_checksum": checksum,
+            "measured_copy_GBs": copy_gbs, "setup_s": setup_s, "device_bytes": ctx.device_bytes(), "counter_checksum": checksum,
         }
         if world == 1 and not a.no_cpu:
             res["cpu_baseline"] = cpu_baseline(rows[: a.cpu_rows], L, p0, W, k, v, cw, codes, sF, sR, C)

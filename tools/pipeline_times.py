@@ -1,0 +1,38 @@
+#!/usr/bin/env python3
+"""End-to-end wall time of the drop-in core step on the committed fixtures, on the GPU box
+(whole program: parse, pack, windows, histograms, host control flow, evaluation, filters, files).
+The reference's wall time on the same input/flags (1 core, authoring container) is in the
+golden trace's meta."""
+import gzip
+import json
+import os
+import sys
+import tempfile
+import time
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, REPO)
+from multiprime_amd.core import NN_degenerate  # noqa: E402
+
+G = os.path.join(REPO, "tests", "golden")
+for name in sys.argv[1:] or ["msa1000_k18_d64", "msa1000_k20_d64", "msa1000_k22_d64", "cluster0_v1", "cluster0_v2", "ivc_v1", "testfa"]:
+    meta = json.loads(gzip.open(os.path.join(G, name + ".trace.json.gz")).read())["meta"]
+    fl = meta["flags"]
+    with tempfile.TemporaryDirectory() as td:
+        inp = os.path.join(td, "in.fa")
+        open(inp, "wb").write(gzip.open(os.path.join(G, "inputs", meta["input"] + ".gz")).read())
+        best = None
+        for rep in range(2):
+            t0 = time.time()
+            app = NN_degenerate(seq_file=inp, primer_length=fl["l"], coverage=fl["f"], number_of_dege_bases=fl["n"],
+                                score_of_dege_bases=fl["d"], raw_entropy_threshold=fl["e"], product_len=fl["s"],
+                                position=fl["c"], variation=fl["v"], distance=fl["a"], GC=fl["g"], nproc=1,
+                                outfile=os.path.join(td, "out.tsv"))
+            app.run()
+            dt = time.time() - t0
+            best = dt if best is None else min(best, dt)
+        same = open(os.path.join(td, "out.tsv"), "rb").read() == open(os.path.join(G, name + ".tsv"), "rb").read()
+        st = {k: round(v, 3) for k, v in app.stats.items() if isinstance(v, float)}
+        print(json.dumps({"fixture": name, "n_seq": meta["n_seq"], "windows": meta["n_windows"], "wall_s": round(best, 3),
+                          "reference_wall_s": meta["reference_wall_s"], "speedup": round(meta["reference_wall_s"] / best, 1),
+                          "tsv_identical": same, "n_candidates": app.stats.get("n_candidates"), "phases": st}), flush=True)
