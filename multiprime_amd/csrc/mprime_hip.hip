@@ -143,6 +143,28 @@ __global__ __launch_bounds__(kBlock) void ungap_kernel(const uint32_t *__restric
     atomicOr(dst + widx, word);
 }
 
+// Column planes for the bit-sliced evaluation: cols[col][3][Npad/64] u64, bit r%64 of word r/64 =
+// sequence r; planes b0, b1 (2-bit base, 0 where gap) and g (gap / beyond the row's end).  IUPAC
+// symbols produce arbitrary b0/b1 here: windows that touch one are always routed to the
+// general path (patch list), never to the bit-sliced pass.
+__global__ __launch_bounds__(kBlock) void colplane_kernel(const uint32_t *__restrict__ planes, int n_pad, int n_chunks,
+                                                          unsigned long long *__restrict__ cols) {
+    const int r = blockIdx.x * kBlock + threadIdx.x;     // n_pad is a multiple of kBlock: every lane is live
+    const int c = blockIdx.y;
+    const size_t np = (size_t)n_pad, nw = np / 64;
+    const size_t base = ((size_t)c * 4) * np + r;
+    const uint32_t mA = planes[base], mC = planes[base + np], mG = planes[base + 2 * np], mT = planes[base + 3 * np];
+    const uint32_t b0 = mC | mT, b1 = mG | mT, ng = mA | mC | mG | mT;
+    const int lane = threadIdx.x & 63;
+    for (int j = 0; j < 32; j++) {
+        unsigned long long x0 = __ballot((b0 >> j) & 1u), x1 = __ballot((b1 >> j) & 1u), xg = __ballot(!((ng >> j) & 1u));
+        if (lane == 0) {
+            unsigned long long *dst = cols + ((size_t)(c * 32 + j) * 3) * nw + (size_t)(r >> 6);
+            dst[0] = x0; dst[nw] = x1; dst[2 * nw] = xg;
+        }
+    }
+}
+
 // ----------------------------------------------------------------------------------------------
 // (2) window k-mers with edge-gap repair (V20:666-687)
 // ----------------------------------------------------------------------------------------------
@@ -284,12 +306,26 @@ struct WinView<true> {
 
 // thread = row, block = 256 rows x a tile of consecutive windows; the 32-column plane words slide
 // in registers, so every plane word is read once per tile.
+// Rows whose k-mer is NOT the plain column slice (edge-gap repair, IUPAC, ragged end) are flagged per
+// (window, 64-row word) in `excl` and collected, per window, in a compact patch list of window words:
+// the bit-sliced evaluation skips them, the row-per-lane evaluation handles exactly them.
+// pass 0 writes the window words, the flags and the per-window patch counts; pass 1 (same
+// computation) fills the patch list once the host has turned the counts into offsets.
+struct PatchOut {
+    int pass;
+    unsigned long long *excl;     // [W][Npad/64]
+    int32_t *count;               // [W]
+    const int32_t *off;           // [W+1]   (pass 1)
+    int32_t *cursor;              // [W]     (pass 1)
+    uint32_t *words;              // [n][3]  (pass 1)
+};
+
 template <bool P64>
 __global__ __launch_bounds__(kBlock) void build_windows_kernel(
     const uint32_t *__restrict__ planes, const uint32_t *__restrict__ cum, const uint32_t *__restrict__ ung,
     const int32_t *__restrict__ rlen, int n_rows, int n_pad, int n_chunks, int ustride, int p0, int n_win, int tile,
     int k, void *__restrict__ win, ExRec *__restrict__ ex, int ex_cap, int *__restrict__ ex_count,
-    int *__restrict__ err) {
+    int *__restrict__ err, PatchOut po) {
     int r = blockIdx.x * kBlock + threadIdx.x;
     if (r >= n_pad) return;
     int w0 = blockIdx.y * tile;
@@ -297,7 +333,8 @@ __global__ __launch_bounds__(kBlock) void build_windows_kernel(
     const uint32_t kmask = (1u << k) - 1u;
     const size_t np = (size_t)n_pad;
     if (r >= n_rows) {                       // padding rows never take part
-        for (int w = w0; w < w1; w++) WinView<P64>::store(win, w, np, r, 0, 0, MP_WIN_SKIP | kmask, k, kmask);
+        if (po.pass == 0)
+            for (int w = w0; w < w1; w++) WinView<P64>::store(win, w, np, r, 0, 0, MP_WIN_SKIP | kmask, k, kmask);
         return;
     }
     const int len = rlen[r];
@@ -334,8 +371,10 @@ __global__ __launch_bounds__(kBlock) void build_windows_kernel(
             Nib buf;
             int rc = repair_window(wA, wC, wG, wT, k, p, len, c_left, total, ung_row, b0, b1, g, buf);
             if (rc == 1) {
-                int idx = atomicAdd(ex_count, 1);
-                if (idx < ex_cap) { ex[idx].win = w; ex[idx].row = r; ex[idx].lo = buf.lo; ex[idx].hi = buf.hi; }
+                if (po.pass == 0) {
+                    int idx = atomicAdd(ex_count, 1);
+                    if (idx < ex_cap) { ex[idx].win = w; ex[idx].row = r; ex[idx].lo = buf.lo; ex[idx].hi = buf.hi; }
+                }
                 b0 = 0; b1 = 0; g = MP_WIN_SKIP | kmask;
             } else if (rc == 2) {
                 atomicMax(err, 1);
@@ -343,7 +382,30 @@ __global__ __launch_bounds__(kBlock) void build_windows_kernel(
                 b0 = 0; b1 = 0; g = MP_WIN_SKIP | kmask;
             }
         }
-        WinView<P64>::store(win, w, np, r, b0, b1, g, k, kmask);
+        {
+            // flags and patch list; the lanes of a wave that are still here are all real rows
+            const unsigned long long live = __ballot(true);
+            const unsigned long long flg = __ballot(!fast);
+            const bool keep = !fast && !(g & MP_WIN_SKIP);
+            const unsigned long long kp = __ballot(keep);
+            const int lane = threadIdx.x & 63;
+            const int leader = __ffsll((long long)live) - 1;
+            if (po.pass == 0) {
+                if (lane == leader) {
+                    po.excl[(size_t)w * (np / 64) + (size_t)(r >> 6)] = flg;
+                    if (kp) atomicAdd(&po.count[w], (int)__popcll(kp));
+                }
+            } else if (kp) {
+                int base = 0;
+                if (lane == leader) base = atomicAdd(&po.cursor[w], (int)__popcll(kp));
+                base = __shfl(base, leader);
+                if (keep) {
+                    int slot = po.off[w] + base + (int)__popcll(kp & ((1ull << lane) - 1ull));
+                    po.words[3 * (size_t)slot] = b0; po.words[3 * (size_t)slot + 1] = b1; po.words[3 * (size_t)slot + 2] = g;
+                }
+            }
+        }
+        if (po.pass == 0) WinView<P64>::store(win, w, np, r, b0, b1, g, k, kmask);
     }
 }
 
@@ -647,6 +709,263 @@ __global__ __launch_bounds__(kBlock) void eval_kernel(const EvalArgs A) {
     }
 }
 
+
+// ----------------------------------------------------------------------------------------------
+// (4b) bit-sliced evaluation: 64 sequences per register word
+// ----------------------------------------------------------------------------------------------
+// For the sequences whose k-mer at window w is the plain column slice (everything the patch list
+// does not hold) the symbol at window position j is column p0+w+j of the alignment, so the
+// evaluation can run on the COLUMN planes: a thread owns G words of 64 sequences; for every
+// position it loads the three plane words once, and for every candidate the mismatch word of 64
+// sequences is ONE v_bitop3 of (g,b1,b0) whose truth table is fixed by the candidate's symbol
+// (a wave-uniform 16-way dispatch).  Mismatch counts are bit-sliced saturating counters
+// (t1 = ">= 1", t2 = ">= 2", t3 = ">= 3": LV = v+1 levels), the strict-position sets are two more
+// words, and the three coverage counters are popcounts at the end.  ~2.5 VALU per evaluation
+// instead of ~13, and the inputs (N*L*3/8 bytes) stay in L2 / Infinity Cache.
+struct EvalBitsArgs {
+    const unsigned long long *cols;    // [n_cols][3][nw]
+    const unsigned long long *excl;    // [W][nw]
+    int nw, p0, k, v;
+    const EvalItem *items;
+    const uint32_t *cand_symT;         // [item][32] u32: nibble c of word j = symbol of candidate c at position j
+    const int32_t *cand_out;
+    uint32_t sF, sR;
+    unsigned long long *out;
+    int ny, ny_pad;                    // row slices per item; ny_pad = ny rounded up to a multiple of 8 (XCDs)
+};
+
+// truth table of v_bitop3_b32 D = f(S0,S1,S2): bit (S0<<2 | S1<<1 | S2) of the immediate
+constexpr int bs_lut_mismatch(int sym) {      // inputs (g, b1, b0): gap, or base not in the symbol's set
+    int t = 0;
+    for (int idx = 0; idx < 8; idx++) {
+        int g = idx >> 2, base = idx & 3;
+        if (g || !((sym >> base) & 1)) t |= 1 << idx;
+    }
+    return t;
+}
+constexpr int kLutOrAnd = 0xF8;               // S0 | (S1 & S2)
+constexpr int kLutAndNotNot = 0x10;           // S0 & ~S1 & ~S2
+
+template <int SYM, int GW>
+__device__ inline void bs_mismatch(const uint32_t (&b0)[GW], const uint32_t (&b1)[GW], const uint32_t (&g)[GW], uint32_t (&m)[GW]) {
+    constexpr int lut = bs_lut_mismatch(SYM);
+#pragma unroll
+    for (int i = 0; i < GW; i++) m[i] = __builtin_amdgcn_bitop3_b32(g[i], b1[i], b0[i], lut);
+}
+
+// CP candidates per pass over the k positions (8 / CP passes), GW 32-bit words (32 sequences each)
+// per thread, LV = v + 1 saturating counter levels.
+template <int CP, int LV, int GW, bool PREFETCH>
+__global__ __launch_bounds__(kBlock) void eval_bits_kernel(const EvalBitsArgs A) {
+    constexpr int CC = 8;
+    __shared__ uint32_t s_acc[3 * CC];
+    // XCD-aware block mapping: workgroup b runs on XCD b % 8 (observed dispatch order), so all blocks of
+    // one row slice land on the same XCD and consecutive windows re-read their 17 shared columns from
+    // that XCD's L2 (a slice of the planes is 1/ny of N*L*3/8 bytes)
+    const int slice = blockIdx.x % A.ny_pad, item = blockIdx.x / A.ny_pad;
+    if (slice >= A.ny) return;
+    const EvalItem it = A.items[item];
+    if (threadIdx.x < 3 * CC) s_acc[threadIdx.x] = 0;
+    const size_t nw32 = (size_t)A.nw * 2;             // 32-bit words per plane row
+    const int word0 = (slice * kBlock + threadIdx.x) * GW;
+    const bool live = word0 < (int)nw32;              // nw32 % GW == 0 (n_pad % 256 == 0, GW <= 8)
+    const uint32_t *cols = reinterpret_cast<const uint32_t *>(A.cols);
+    uint32_t accP[CC], accF[CC], accR[CC];
+#pragma unroll
+    for (int c = 0; c < CC; c++) accP[c] = accF[c] = accR[c] = 0;
+    if (live) {
+        uint32_t valid[GW];
+        bool have_valid = false;
+#pragma unroll 1
+        for (int pass = 0; pass < CC / CP; pass++) {
+            uint32_t t1[CP][GW], t2[CP][GW], t3[CP][GW], sf[CP][GW], sr[CP][GW];
+            uint32_t g1[GW], g2[GW], g3[GW];
+#pragma unroll
+            for (int i = 0; i < GW; i++) {
+                g1[i] = g2[i] = g3[i] = 0;
+#pragma unroll
+                for (int c = 0; c < CP; c++) t1[c][i] = t2[c][i] = t3[c][i] = sf[c][i] = sr[c][i] = 0;
+            }
+            uint32_t n0[GW], n1[GW], ng[GW];               // next position's planes, in flight during this one
+            if (PREFETCH) {
+                const uint32_t *P = cols + ((size_t)(A.p0 + it.win) * 3) * nw32 + word0;
+#pragma unroll
+                for (int i = 0; i < GW; i++) { n0[i] = P[i]; n1[i] = P[nw32 + i]; ng[i] = P[2 * nw32 + i]; }
+            }
+#pragma unroll 1
+            for (int j = 0; j < A.k; j++) {
+                uint32_t b0[GW], b1[GW], g[GW];
+                if (PREFETCH) {
+#pragma unroll
+                    for (int i = 0; i < GW; i++) { b0[i] = n0[i]; b1[i] = n1[i]; g[i] = ng[i]; }
+                    if (j + 1 < A.k) {
+                        const uint32_t *P = cols + ((size_t)(A.p0 + it.win + j + 1) * 3) * nw32 + word0;
+#pragma unroll
+                        for (int i = 0; i < GW; i++) { n0[i] = P[i]; n1[i] = P[nw32 + i]; ng[i] = P[2 * nw32 + i]; }
+                    }
+                } else {
+                    const uint32_t *P = cols + ((size_t)(A.p0 + it.win + j) * 3) * nw32 + word0;
+#pragma unroll
+                    for (int i = 0; i < GW; i++) { b0[i] = P[i]; b1[i] = P[nw32 + i]; g[i] = P[2 * nw32 + i]; }
+                }
+                if (!have_valid) {
+#pragma unroll
+                    for (int i = 0; i < GW; i++) {            // gaps per k-mer, saturating (V20:689 needs "> v")
+                        if (LV >= 3) g3[i] = __builtin_amdgcn_bitop3_b32(g3[i], g2[i], g[i], kLutOrAnd);
+                        if (LV >= 2) g2[i] = __builtin_amdgcn_bitop3_b32(g2[i], g1[i], g[i], kLutOrAnd);
+                        g1[i] |= g[i];
+                    }
+                }
+                const uint32_t sw = __builtin_amdgcn_readfirstlane(A.cand_symT[(size_t)item * 32 + j]) >> (4 * CP * pass);
+                // the mismatch word of every possible candidate symbol at this position (15 x GW v_bitop3,
+                // shared by all candidates); a candidate then picks its word by a wave-uniform register index
+                uint32_t tab[16][GW];
+#pragma unroll
+                for (int i = 0; i < GW; i++) tab[0][i] = 0xFFFFFFFFu;
+                bs_mismatch<1, GW>(b0, b1, g, tab[1]); bs_mismatch<2, GW>(b0, b1, g, tab[2]); bs_mismatch<3, GW>(b0, b1, g, tab[3]);
+                bs_mismatch<4, GW>(b0, b1, g, tab[4]); bs_mismatch<5, GW>(b0, b1, g, tab[5]); bs_mismatch<6, GW>(b0, b1, g, tab[6]);
+                bs_mismatch<7, GW>(b0, b1, g, tab[7]); bs_mismatch<8, GW>(b0, b1, g, tab[8]); bs_mismatch<9, GW>(b0, b1, g, tab[9]);
+                bs_mismatch<10, GW>(b0, b1, g, tab[10]); bs_mismatch<11, GW>(b0, b1, g, tab[11]); bs_mismatch<12, GW>(b0, b1, g, tab[12]);
+                bs_mismatch<13, GW>(b0, b1, g, tab[13]); bs_mismatch<14, GW>(b0, b1, g, tab[14]); bs_mismatch<15, GW>(b0, b1, g, tab[15]);
+                uint32_t m[CP][GW];
+#pragma unroll
+                for (int c = 0; c < CP; c++) {
+                    const uint32_t sy = (sw >> (4 * c)) & 15u;
+#pragma unroll
+                    for (int i = 0; i < GW; i++) m[c][i] = tab[sy][i];
+#pragma unroll
+                    for (int i = 0; i < GW; i++) {
+                        if (LV >= 3) t3[c][i] = __builtin_amdgcn_bitop3_b32(t3[c][i], t2[c][i], m[c][i], kLutOrAnd);
+                        if (LV >= 2) t2[c][i] = __builtin_amdgcn_bitop3_b32(t2[c][i], t1[c][i], m[c][i], kLutOrAnd);
+                        t1[c][i] |= m[c][i];
+                    }
+                }
+                if (__builtin_amdgcn_readfirstlane((A.sF >> j) & 1u)) {
+#pragma unroll
+                    for (int c = 0; c < CP; c++)
+#pragma unroll
+                        for (int i = 0; i < GW; i++) sf[c][i] |= m[c][i];
+                }
+                if (__builtin_amdgcn_readfirstlane((A.sR >> j) & 1u)) {
+#pragma unroll
+                    for (int c = 0; c < CP; c++)
+#pragma unroll
+                        for (int i = 0; i < GW; i++) sr[c][i] |= m[c][i];
+                }
+            }
+            if (!have_valid) {
+                const uint32_t *E = reinterpret_cast<const uint32_t *>(A.excl) + (size_t)it.win * nw32 + word0;
+#pragma unroll
+                for (int i = 0; i < GW; i++) {
+                    const uint32_t gapbad = LV == 1 ? g1[i] : (LV == 2 ? g2[i] : g3[i]);
+                    valid[i] = ~(E[i] | gapbad);
+                }
+                have_valid = true;
+            }
+#pragma unroll
+            for (int c = 0; c < CP; c++) {
+                uint32_t p = 0, f = 0, r = 0;
+#pragma unroll
+                for (int i = 0; i < GW; i++) {
+                    const uint32_t far = LV == 1 ? t1[c][i] : (LV == 2 ? t2[c][i] : t3[c][i]);
+                    p += __popc(valid[i] & ~t1[c][i]);
+                    f += __popc(__builtin_amdgcn_bitop3_b32(valid[i], far, sf[c][i], kLutAndNotNot));
+                    r += __popc(__builtin_amdgcn_bitop3_b32(valid[i], far, sr[c][i], kLutAndNotNot));
+                }
+                // static index into the accumulators: the pass loop is not unrolled, so select by pass
+#pragma unroll
+                for (int q = 0; q < CC / CP; q++)
+                    if (pass == q) { accP[q * CP + c] += p; accF[q * CP + c] += f; accR[q * CP + c] += r; }
+            }
+        }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int c = 0; c < CC; c++) {
+        uint32_t x = accP[c], y = accF[c], z = accR[c];
+#pragma unroll
+        for (int sft = 32; sft >= 1; sft >>= 1) {
+            x += __shfl_xor(x, sft);
+            y += __shfl_xor(y, sft);
+            z += __shfl_xor(z, sft);
+        }
+        if ((threadIdx.x & 63) == 0) {
+            atomicAdd(&s_acc[3 * c], x);
+            atomicAdd(&s_acc[3 * c + 1], y - x);      // F_mis = F_raw - perfect
+            atomicAdd(&s_acc[3 * c + 2], z - x);
+        }
+    }
+    __syncthreads();
+    if (threadIdx.x < 3 * CC) {
+        int oc = A.cand_out[it.cand0 + threadIdx.x / 3];
+        uint32_t val = s_acc[threadIdx.x];
+        if (oc >= 0 && val) atomicAdd(&A.out[(size_t)oc * 3 + threadIdx.x % 3], (unsigned long long)val);
+    }
+}
+
+// Row-per-lane evaluation of two compact per-window lists of window words: the patch list (rows with
+// edge-gap repair / ragged ends, built on the device) and the host-expanded IUPAC rows.
+struct EvalListArgs {
+    const EvalItem *items;
+    const uint4 *cand_n;
+    const int32_t *cand_out;
+    const int32_t *off_a;
+    const uint32_t *words_a;
+    const int32_t *off_b;       // may be nullptr
+    const uint32_t *words_b;
+    uint32_t sF, sR;
+    int v;
+    uint32_t kmask;
+    unsigned long long *out;
+};
+
+template <int CC, int VMODE>
+__global__ __launch_bounds__(kBlock) void eval_list_kernel(const EvalListArgs L) {
+    __shared__ uint32_t s_acc[3 * CC];
+    const EvalItem it = L.items[blockIdx.x];
+    uint32_t nA[CC], nC[CC], nG[CC], nT[CC];
+    EvalAcc<CC, 1> acc;
+    acc.clear();
+#pragma unroll
+    for (int c = 0; c < CC; c++) {
+        uint4 q = L.cand_n[it.cand0 + c];
+        nA[c] = q.x; nC[c] = q.y; nG[c] = q.z; nT[c] = q.w;
+    }
+    if (threadIdx.x < 3 * CC) s_acc[threadIdx.x] = 0;
+    EvalArgs A;
+    A.sF = L.sF; A.sR = L.sR; A.v = L.v; A.kmask = L.kmask;
+    for (int which = 0; which < 2; which++) {
+        const int32_t *off = which ? L.off_b : L.off_a;
+        const uint32_t *words = which ? L.words_b : L.words_a;
+        if (!off) continue;
+        const int e0 = off[it.win], e1 = off[it.win + 1];
+        for (int eb = e0 + blockIdx.y * kBlock; eb < e1; eb += gridDim.y * kBlock) {     // uniform per wave
+            int e = eb + threadIdx.x;
+            uint32_t b0 = 0, b1 = 0, g = 0xFFFFFFFFu;
+            if (e < e1) { b0 = words[3 * (size_t)e]; b1 = words[3 * (size_t)e + 1]; g = words[3 * (size_t)e + 2]; }
+            eval_row<CC, VMODE, 1, 2>(b0, b1, g, A, nA, nC, nG, nT, acc);
+        }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int c = 0; c < CC; c++) {
+        if ((threadIdx.x & 63) == 0) {
+            atomicAdd(&s_acc[3 * c], acc.p[c]);
+            atomicAdd(&s_acc[3 * c + 1], acc.f[c] - acc.p[c]);
+            atomicAdd(&s_acc[3 * c + 2], acc.r[c] - acc.p[c]);
+        }
+    }
+    __syncthreads();
+    if (threadIdx.x < 3 * CC) {
+        int oc = L.cand_out[it.cand0 + threadIdx.x / 3];
+        uint32_t val = s_acc[threadIdx.x];
+        if (oc >= 0 && val) atomicAdd(&L.out[(size_t)oc * 3 + threadIdx.x % 3], (unsigned long long)val);
+    }
+}
+
+typedef void (*EvalBitsFn)(const EvalBitsArgs);
+typedef void (*EvalListFn)(const EvalListArgs);
+
 typedef void (*EvalFn)(const EvalArgs);
 struct EvalVariant { const char *name; EvalFn fn[2][3]; };     // fn[P64][VMODE]
 #define EVAL_VARIANT(name, COUNT, PREFETCH, FORM)                                                         \
@@ -784,10 +1103,15 @@ struct mp_ctx {
     // alignment
     int n_rows = 0, n_pad = 0, n_chunks = 0, max_len = 0, ustride = 0;
     uint32_t *planes = nullptr, *cum = nullptr, *ung = nullptr;
+    unsigned long long *cols = nullptr;      // [n_chunks*32][3][n_pad/64]
     int32_t *lead = nullptr, *rstrip = nullptr, *rlen = nullptr;
     // windows
     int p0 = 0, n_win = 0, k = 0, v = 0;
     void *win = nullptr;
+    unsigned long long *excl = nullptr;      // [W][n_pad/64]
+    int32_t *patch_count = nullptr, *patch_off = nullptr, *patch_cursor = nullptr;
+    uint32_t *patch_words = nullptr;
+    int n_patch = 0, max_patch = 0;
     bool p64 = false;
     size_t win_bytes = 0;
     ExRec *ex = nullptr;
@@ -809,6 +1133,7 @@ struct mp_ctx {
     int n_cand = 0, n_items = 0, n_padded = 0;
     EvalItem *items = nullptr;
     uint4 *cand_n = nullptr;
+    uint32_t *cand_symT = nullptr;
     int32_t *cand_out = nullptr;
     uint32_t sF = 0, sR = 0;
     unsigned long long *tmp_out = nullptr;
@@ -858,6 +1183,7 @@ void free_eval(mp_ctx *c) {
     dev_free(c, &c->items, (size_t)c->n_items);
     dev_free(c, &c->cand_n, (size_t)c->n_padded);
     dev_free(c, &c->cand_out, (size_t)c->n_padded);
+    dev_free(c, &c->cand_symT, (size_t)c->n_items * 32);
     c->n_items = c->n_padded = c->n_cand = 0;
 }
 
@@ -876,6 +1202,12 @@ void free_windows(mp_ctx *c) {
     free_eval(c);
     free_unique(c);
     if (c->win) { (void)hipFree(c->win); c->bytes -= (int64_t)c->win_bytes; c->win = nullptr; c->win_bytes = 0; }
+    dev_free(c, &c->excl, (size_t)c->n_win * (c->n_pad / 64));
+    dev_free(c, &c->patch_count, (size_t)c->n_win);
+    dev_free(c, &c->patch_off, (size_t)c->n_win + 1);
+    dev_free(c, &c->patch_cursor, (size_t)c->n_win);
+    dev_free(c, &c->patch_words, (size_t)3 * c->n_patch);
+    c->n_patch = c->max_patch = 0;
     dev_free(c, &c->ex, (size_t)c->ex_cap);
     dev_free(c, &c->ex_count, 1);
     dev_free(c, &c->err_flag, 4);
@@ -889,6 +1221,7 @@ void free_msa(mp_ctx *c) {
     free_windows(c);
     size_t np = (size_t)c->n_pad;
     dev_free(c, &c->planes, (size_t)c->n_chunks * 4 * np);
+    dev_free(c, &c->cols, (size_t)c->n_chunks * 32 * 3 * (np / 64));
     dev_free(c, &c->cum, ((size_t)c->n_chunks + 1) * np);
     dev_free(c, &c->ung, (size_t)c->n_rows * c->ustride);
     dev_free(c, &c->lead, np); dev_free(c, &c->rstrip, np); dev_free(c, &c->rlen, np);
@@ -978,6 +1311,7 @@ int mp_load_msa(mp_ctx *c, const uint8_t *bytes, const int64_t *row_off, int32_t
     if ((rc = dev_alloc(c, &d_bytes, (size_t)total + 64))) return rc;
     if ((rc = dev_alloc(c, &d_off, (size_t)n_rows + 1))) return rc;
     if ((rc = dev_alloc(c, &c->planes, (size_t)c->n_chunks * 4 * np))) return rc;
+    if ((rc = dev_alloc(c, &c->cols, (size_t)c->n_chunks * 32 * 3 * (np / 64)))) return rc;
     if ((rc = dev_alloc(c, &c->cum, ((size_t)c->n_chunks + 1) * np))) return rc;
     if ((rc = dev_alloc(c, &c->ung, (size_t)n_rows * c->ustride))) return rc;
     if ((rc = dev_alloc(c, &c->lead, np))) return rc;
@@ -994,6 +1328,7 @@ int mp_load_msa(mp_ctx *c, const uint8_t *bytes, const int64_t *row_off, int32_t
     hipLaunchKernelGGL(row_scan_kernel, dim3(c->n_pad / kBlock), dim3(kBlock), 0, c->stream, c->planes, d_off, n_rows,
                        c->n_pad, c->n_chunks, c->cum, c->lead, c->rstrip, c->rlen);
     hipLaunchKernelGGL(ungap_kernel, grid, dim3(kBlock), 0, c->stream, c->planes, c->cum, n_rows, c->n_pad, c->ustride, c->ung);
+    hipLaunchKernelGGL(colplane_kernel, grid, dim3(kBlock), 0, c->stream, c->planes, c->n_pad, c->n_chunks, c->cols);
     HIPCK(c, hipGetLastError());
     HIPCK(c, hipStreamSynchronize(c->stream));
     dev_free(c, &d_bytes, (size_t)total + 64);
@@ -1038,22 +1373,32 @@ int mp_build_windows(mp_ctx *c, int32_t p0, int32_t n_win, int32_t k, int32_t v,
     if ((rc = dev_alloc(c, &c->err_flag, 4))) return rc;
     if ((rc = dev_alloc(c, &c->extra_off, (size_t)n_win + 1))) return rc;
     HIPCK(c, hipMemsetAsync(c->extra_off, 0, sizeof(int32_t) * ((size_t)n_win + 1), c->stream));
+    const size_t nw = np / 64;
+    if ((rc = dev_alloc(c, &c->excl, (size_t)n_win * nw))) return rc;
+    if ((rc = dev_alloc(c, &c->patch_count, (size_t)n_win))) return rc;
+    if ((rc = dev_alloc(c, &c->patch_off, (size_t)n_win + 1))) return rc;
+    if ((rc = dev_alloc(c, &c->patch_cursor, (size_t)n_win))) return rc;
     int cap = 1 << 16;
     const int tile = 64;
+    const dim3 grid((unsigned)(c->n_pad / kBlock), (unsigned)((n_win + tile - 1) / tile));
+    auto launch = [&](const PatchOut &po, int ex_cap) {
+        if (c->p64)
+            hipLaunchKernelGGL(build_windows_kernel<true>, grid, dim3(kBlock), 0, c->stream, c->planes, c->cum, c->ung, c->rlen,
+                               c->n_rows, c->n_pad, c->n_chunks, c->ustride, p0, n_win, tile, k, c->win, c->ex, ex_cap,
+                               c->ex_count, c->err_flag, po);
+        else
+            hipLaunchKernelGGL(build_windows_kernel<false>, grid, dim3(kBlock), 0, c->stream, c->planes, c->cum, c->ung, c->rlen,
+                               c->n_rows, c->n_pad, c->n_chunks, c->ustride, p0, n_win, tile, k, c->win, c->ex, ex_cap,
+                               c->ex_count, c->err_flag, po);
+    };
     for (int attempt = 0; attempt < 2; attempt++) {
         if ((rc = dev_alloc(c, &c->ex, (size_t)cap))) return rc;
         c->ex_cap = cap;
         HIPCK(c, hipMemsetAsync(c->ex_count, 0, sizeof(int), c->stream));
         HIPCK(c, hipMemsetAsync(c->err_flag, 0, 4 * sizeof(int), c->stream));
-        dim3 grid((unsigned)(c->n_pad / kBlock), (unsigned)((n_win + tile - 1) / tile));
-        if (c->p64)
-            hipLaunchKernelGGL(build_windows_kernel<true>, grid, dim3(kBlock), 0, c->stream, c->planes, c->cum, c->ung, c->rlen,
-                               c->n_rows, c->n_pad, c->n_chunks, c->ustride, p0, n_win, tile, k, c->win, c->ex, cap,
-                               c->ex_count, c->err_flag);
-        else
-            hipLaunchKernelGGL(build_windows_kernel<false>, grid, dim3(kBlock), 0, c->stream, c->planes, c->cum, c->ung, c->rlen,
-                               c->n_rows, c->n_pad, c->n_chunks, c->ustride, p0, n_win, tile, k, c->win, c->ex, cap,
-                               c->ex_count, c->err_flag);
+        HIPCK(c, hipMemsetAsync(c->excl, 0, sizeof(unsigned long long) * (size_t)n_win * nw, c->stream));
+        HIPCK(c, hipMemsetAsync(c->patch_count, 0, sizeof(int32_t) * (size_t)n_win, c->stream));
+        launch(PatchOut{0, c->excl, c->patch_count, nullptr, nullptr, nullptr}, cap);
         HIPCK(c, hipGetLastError());
         int cnt = 0, errv[4] = {0, 0, 0, 0};
         HIPCK(c, hipMemcpyAsync(&cnt, c->ex_count, sizeof(int), hipMemcpyDeviceToHost, c->stream));
@@ -1067,6 +1412,27 @@ int mp_build_windows(mp_ctx *c, int32_t p0, int32_t n_win, int32_t k, int32_t v,
             std::sort(c->ex_host.begin(), c->ex_host.end(),
                       [](const ExRec &a, const ExRec &b) { return a.win != b.win ? a.win < b.win : a.row < b.row; });
             if (n_exc) *n_exc = cnt;
+            // patch list: counts -> offsets on the host, then the fill pass
+            std::vector<int32_t> pc((size_t)n_win), po((size_t)n_win + 1, 0);
+            HIPCK(c, hipMemcpy(pc.data(), c->patch_count, sizeof(int32_t) * (size_t)n_win, hipMemcpyDeviceToHost));
+            long long tot = 0;
+            c->max_patch = 0;
+            for (int w = 0; w < n_win; w++) {
+                po[(size_t)w] = (int32_t)tot;
+                tot += pc[(size_t)w];
+                c->max_patch = std::max(c->max_patch, (int)pc[(size_t)w]);
+            }
+            if (tot > 0x7fffffffLL / 4) return fail(c, MP_ERR_NOMEM, "patch list too large (%lld rows)", tot);
+            po[(size_t)n_win] = (int32_t)tot;
+            c->n_patch = (int)tot;
+            HIPCK(c, hipMemcpy(c->patch_off, po.data(), sizeof(int32_t) * po.size(), hipMemcpyHostToDevice));
+            if (tot) {
+                if ((rc = dev_alloc(c, &c->patch_words, (size_t)3 * (size_t)tot))) return rc;
+                HIPCK(c, hipMemsetAsync(c->patch_cursor, 0, sizeof(int32_t) * (size_t)n_win, c->stream));
+                launch(PatchOut{1, c->excl, c->patch_count, c->patch_off, c->patch_cursor, c->patch_words}, 0);
+                HIPCK(c, hipGetLastError());
+                HIPCK(c, hipStreamSynchronize(c->stream));
+            }
             return MP_OK;
         }
         dev_free(c, &c->ex, (size_t)cap);
@@ -1263,6 +1629,7 @@ int mp_eval_upload(mp_ctx *c, int32_t n_cand, const int32_t *cw, const uint8_t *
     std::vector<EvalItem> items;
     std::vector<uint4> cn;
     std::vector<int32_t> co;
+    std::vector<uint32_t> symT;
     int i = 0;
     while (i < n_cand) {
         int w = cw[i];
@@ -1271,6 +1638,7 @@ int mp_eval_upload(mp_ctx *c, int32_t n_cand, const int32_t *cw, const uint8_t *
         while (j < n_cand && cw[j] == w) j++;
         for (int b = i; b < j; b += kEvalCC) {
             items.push_back(EvalItem{w, (int32_t)cn.size()});
+            symT.resize(items.size() * 32, 0u);
             for (int t = 0; t < kEvalCC; t++) {
                 int ci = b + t;
                 if (ci < j) {
@@ -1284,6 +1652,8 @@ int mp_eval_upload(mp_ctx *c, int32_t n_cand, const int32_t *cw, const uint8_t *
                     }
                     cn.push_back(uint4{nA, nC, nG, nT});
                     co.push_back(ci);
+                    for (int p = 0; p < k; p++)
+                        symT[(items.size() - 1) * 32 + (size_t)p] |= (uint32_t)(codes[(size_t)ci * k + p] & 15u) << (4 * t);
                 } else {
                     cn.push_back(uint4{kmask, kmask, kmask, kmask});
                     co.push_back(-1);
@@ -1300,6 +1670,8 @@ int mp_eval_upload(mp_ctx *c, int32_t n_cand, const int32_t *cw, const uint8_t *
     if ((rc = dev_alloc(c, &c->items, items.size()))) return rc;
     if ((rc = dev_alloc(c, &c->cand_n, cn.size()))) return rc;
     if ((rc = dev_alloc(c, &c->cand_out, co.size()))) return rc;
+    if ((rc = dev_alloc(c, &c->cand_symT, symT.size()))) return rc;
+    HIPCK(c, hipMemcpy(c->cand_symT, symT.data(), sizeof(uint32_t) * symT.size(), hipMemcpyHostToDevice));
     HIPCK(c, hipMemcpy(c->items, items.data(), sizeof(EvalItem) * items.size(), hipMemcpyHostToDevice));
     HIPCK(c, hipMemcpy(c->cand_n, cn.data(), sizeof(uint4) * cn.size(), hipMemcpyHostToDevice));
     HIPCK(c, hipMemcpy(c->cand_out, co.data(), sizeof(int32_t) * co.size(), hipMemcpyHostToDevice));
@@ -1323,15 +1695,43 @@ int mp_eval_launch(mp_ctx *c, int64_t *device_out) {
     if (!c->ev_free.empty()) { ev = c->ev_free.back(); c->ev_free.pop_back(); }
     else { HIPCK(c, hipEventCreate(&ev.first)); HIPCK(c, hipEventCreate(&ev.second)); }
     HIPCK(c, hipEventRecord(ev.first, c->stream));
+    const char *mode_env = getenv("MP_EVAL_MODE");
+    const bool bits = c->v <= 2 && !(mode_env && !strcmp(mode_env, "rows"));
+    const int vmode = c->v == 0 ? 0 : (c->v == 1 ? 1 : 2);     // predicate specialisation of the row-per-lane code
+    if (bits) {
+        // bit-sliced pass over the column planes + row-per-lane pass over the patch / IUPAC lists
+        // kernel shape (MP_EVAL_BITS): 0 = 8 candidates x 2 words (64 sequences) per thread (default),
+        // 1 = the same with the next position's planes prefetched, 2 = 8 x 1 word
+        int shape = 0;
+        if (const char *e = getenv("MP_EVAL_BITS")) { shape = atoi(e); if (shape < 0 || shape > 2) shape = 0; }
+        static const int shape_gw[3] = {2, 2, 1};
+        const int nw = c->n_pad / 64;
+        const int GW = shape_gw[shape];
+        const int ny = std::max(1, (2 * nw / GW + kBlock - 1) / kBlock);
+        const int ny_pad = (ny + 7) / 8 * 8;
+        EvalBitsArgs ba{c->cols, c->excl, nw, c->p0, c->k, c->v, c->items, c->cand_symT, c->cand_out, c->sF, c->sR,
+                        (unsigned long long *)device_out, ny, ny_pad};
+#define BITS_ROW(LV) {eval_bits_kernel<8, LV, 2, false>, eval_bits_kernel<8, LV, 2, true>, eval_bits_kernel<8, LV, 1, false>}
+        static const EvalBitsFn bfn[3][3] = {BITS_ROW(1), BITS_ROW(2), BITS_ROW(3)};
+#undef BITS_ROW
+        hipLaunchKernelGGL(bfn[c->v][shape], dim3((unsigned)((size_t)c->n_items * ny_pad)), dim3(kBlock), 0, c->stream, ba);
+        if (c->n_patch || c->n_extra) {
+            EvalListArgs la{c->items, c->cand_n, c->cand_out, c->n_patch ? c->patch_off : (const int32_t *)nullptr, c->patch_words,
+                            c->n_extra ? c->extra_off : (const int32_t *)nullptr, c->extra_words, c->sF, c->sR, c->v,
+                            (1u << c->k) - 1u, (unsigned long long *)device_out};
+            static const EvalListFn lfn[3] = {eval_list_kernel<kEvalCC, 0>, eval_list_kernel<kEvalCC, 1>, eval_list_kernel<kEvalCC, 2>};
+            int ly = std::max(1, std::min(64, (c->max_patch + 2047) / 2048));
+            hipLaunchKernelGGL(lfn[vmode], dim3((unsigned)c->n_items, (unsigned)ly), dim3(kBlock), 0, c->stream, la);
+        }
+    } else {
     EvalArgs ea{c->win, c->n_pad, c->k, c->items, c->cand_n, c->cand_out, c->n_extra ? c->extra_off : (const int32_t *)nullptr,
                 c->extra_words, c->sF, c->sR, c->v, (1u << c->k) - 1u, rows, (unsigned long long *)device_out};
     int variant = c->eval_variant;
     if (const char *e = getenv("MP_EVAL_VARIANT")) variant = atoi(e);
     if (variant < 0 || variant >= kNumEvalVariants) variant = 0;
-    // the predicate specialisation is chosen by --variation: 0, 1 (pipeline default) or general
-    const int vmode = c->v == 0 ? 0 : (c->v == 1 ? 1 : 2);
     hipLaunchKernelGGL(kEvalVariants[variant].fn[c->p64 ? 1 : 0][getenv("MP_EVAL_GENERIC_V") ? 2 : vmode], dim3((unsigned)c->n_items, (unsigned)split),
                        dim3(kBlock), 0, c->stream, ea);
+    }
     HIPCK(c, hipEventRecord(ev.second, c->stream));
     c->ev_busy.push_back(ev);
     HIPCK(c, hipGetLastError());

@@ -6,7 +6,7 @@ TAG=${1:-r1}
 ARGS=${2:-"--steps 20 --warmup 3 --no-cpu"}
 ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$ROOT/gpurun_out/prof_$TAG
-mkdir -p $OUT
+mkdir -p $OUT $OUT/trace
 cd /tmp && export TMPDIR=/tmp
 timeout 300 rocprofv3 --kernel-trace --stats -d $OUT/trace -o bench -- python $ROOT/bench.py $ARGS > $OUT/trace_bench.json 2> $OUT/trace.err
 timeout 300 rocprofv3 --pmc FETCH_SIZE -d $OUT/pmc_fetch -o bench -- python $ROOT/bench.py --steps 5 --warmup 1 --no-cpu > $OUT/pmc_fetch_bench.json 2> $OUT/pmc_fetch.err
