@@ -62,6 +62,7 @@ FIXTURES = {
     "syn_v2": ("@syn_v2", dict(DEF, l=20, v=2, d=64, s=100, c="2,3,-1")),
     "syn_ragged": ("@syn_ragged", dict(DEF, l=16, v=1, s=80)),
     "syn_v3_k27": ("@syn_v2", dict(DEF, l=27, v=3, d=32, s=100, c="1,-2", n=6)),
+    "syn_edge": ("@syn_edge", dict(DEF, l=15, v=1, s=50, d=16, f=0.7)),
 }
 
 
@@ -94,6 +95,24 @@ def make_synthetic(name):
             for j in range(0, len(s), 70):          # multi-line records
                 parts.append(s[j:j + 70] + b"\n")
         parts.insert(6, b"# a comment line the parser must skip\n")
+        data = b"".join(parts)
+    elif name == "@syn_edge":
+        # record-level quirks of parse_seq: a repeated id concatenates (ragged, longer row), CRLF line ends,
+        # blank lines, '#' comments, an all-gap row, '*' / '.' / digits, multi-line records of uneven width
+        rows = synth_block(0, 40, 180, 14, p_gap=0.02, edge_frac=0.4, p_iupac=3e-3, block_rows=64)
+        rows[5, :] = ord("-")
+        rows[6, 20:60] = ord("N")
+        rows[7, 30:33] = np.frombuffer(b"*.7", dtype=np.uint8)
+        parts = []
+        for i in range(rows.shape[0]):
+            s = rows[i].tobytes()
+            parts.append(b">e%02d desc\r\n" % i)
+            w = 50 + 7 * (i % 4)
+            for j in range(0, len(s), w):
+                parts.append(s[j:j + w] + (b"\r\n" if i % 2 else b"\n"))
+            if i == 9:
+                parts.append(b"\n# comment\n\n")
+        parts.append(b">e03 again\n" + rows[3, :25].tobytes() + b"\n")      # same id twice: appended to e03
         data = b"".join(parts)
     else:
         raise KeyError(name)

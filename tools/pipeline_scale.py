@@ -1,0 +1,40 @@
+#!/usr/bin/env python3
+"""Whole drop-in core step on a large synthetic alignment (default 131072 x 1000, the bench shard)
+on the GPU box: writes the FASTA, runs scripts/multiPrime-core.py's code path with --no-json and
+prints the per-phase timings.  There is no reference output at this size (the Python reference would
+need ~1 h); the run checks the internal host/device perfect-coverage invariant on every candidate."""
+import argparse
+import json
+import os
+import sys
+import tempfile
+import time
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, REPO)
+from multiprime_amd.core import NN_degenerate  # noqa: E402
+from multiprime_amd.synth import synth_block, to_fasta  # noqa: E402
+
+ap = argparse.ArgumentParser()
+ap.add_argument("--rows", type=int, default=131072)
+ap.add_argument("--cols", type=int, default=1000)
+ap.add_argument("--k", type=int, default=18)
+a = ap.parse_args()
+with tempfile.TemporaryDirectory() as td:
+    t0 = time.time()
+    rows = synth_block(0, a.rows, a.cols, 20250303)
+    fa = os.path.join(td, "syn.fa")
+    with open(fa, "wb") as f:
+        f.write(to_fasta(rows))
+    t_gen = time.time() - t0
+    t0 = time.time()
+    app = NN_degenerate(seq_file=fa, primer_length=a.k, coverage=0.8, number_of_dege_bases=4, score_of_dege_bases=10,
+                        raw_entropy_threshold=3.6, product_len=150, position="2,3,-1", variation=1, distance=4, GC="0.2,0.7",
+                        nproc=1, outfile=os.path.join(td, "out.tsv"), write_json=False)
+    app.run()
+    wall = time.time() - t0
+    n_out = sum(1 for _ in open(os.path.join(td, "out.tsv"))) - 1
+    print(json.dumps({"rows": a.rows, "cols": a.cols, "k": a.k, "generate_s": round(t_gen, 2), "wall_s": round(wall, 2),
+                      "windows": app.n_windows, "rows_out": n_out, "n_candidates": app.stats.get("n_candidates"),
+                      "phases": {k: round(v, 3) for k, v in app.stats.items() if isinstance(v, float)},
+                      "device_bytes": app.ctx.device_bytes()}))
