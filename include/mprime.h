@@ -167,6 +167,23 @@ int mp_dimer_scan(mp_ctx *ctx, int32_t n_primers, const uint8_t *codes, const in
                   int32_t n_new, const uint8_t *loss_hit, const double *dg_params, double dg_limit,
                   int64_t cap_hits, int32_t *hits, int64_t *n_hits);
 
+/* mode-0 style search for an explicit list of ORDERED primer pairs (x -> y): ends of x (lengths
+ * min(t, len_x), t = 18..5) against the expansions of y, any passing combination sets flags[p] = 1.
+ * Replaces the loops of Primers_filter.dimer_check (scripts/get_multiPrime_V8.py:419-438), which
+ * is the union of the four ordered pairs (F,F), (F,R), (R,F), (R,R); its `Loss > 3.6` and its
+ * one-term initiation in deltaG (:405-413) come in through loss_hit / dg_params. */
+int mp_dimer_pairs(mp_ctx *ctx, int32_t n_primers, const uint8_t *codes, const int32_t *off, int64_t n_pairs,
+                   const int32_t *pairs, const uint8_t *loss_hit, const double *dg_params, double dg_limit,
+                   uint8_t *flags);
+
+/* (6) coverage of primer pairs from per-window sequence bitsets — SURVEY §8f-1 -------------- */
+/* Replaces the id-list unions of Primers_filter.primer_pairs (get_multiPrime_V8.py:560-569): set a
+ * of `sets_a` holds the sequences a forward window does not cover (gap rows U F non-covered), set b
+ * of `sets_b` the same for a reverse window; out[p] = popcount(sets_a[pairs[2p]] | sets_b[pairs[2p+1]]).
+ * Each set is n_words 64-bit words. */
+int mp_pair_coverage(mp_ctx *ctx, int32_t n_sets, int32_t n_words, const uint64_t *sets_a, const uint64_t *sets_b,
+                     int64_t n_pairs, const int32_t *pairs, int32_t *out);
+
 /* Memory the context holds on the device, in bytes (window words, planes, tables). */
 int mp_device_bytes(mp_ctx *ctx, int64_t *bytes);
 

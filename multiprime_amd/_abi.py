@@ -42,6 +42,8 @@ SYMBOLS = [
     ("mp_eval_timing", C.c_int, [_p, C.c_int32, C.POINTER(C.c_double), C.POINTER(C.c_int32)]),
     ("mp_dimer_scan", C.c_int, [_p, C.c_int32, _p, _p, C.c_int32, C.c_int32, _p, _p, C.c_double, C.c_int64, _p,
                                 C.POINTER(C.c_int64)]),
+    ("mp_dimer_pairs", C.c_int, [_p, C.c_int32, _p, _p, C.c_int64, _p, _p, _p, C.c_double, _p]),
+    ("mp_pair_coverage", C.c_int, [_p, C.c_int32, C.c_int32, _p, _p, C.c_int64, _p, _p]),
     ("mp_device_bytes", C.c_int, [_p, C.POINTER(C.c_int64)]),
 ]
 
@@ -224,6 +226,28 @@ class Context:
                 h = hits[: n.value]
                 return h[np.lexsort((h[:, 1], h[:, 0]))] if len(h) else h
             cap = int(n.value)
+
+    def dimer_pairs(self, codes, off, pairs, loss_hit, dg_params, dg_limit: float) -> np.ndarray:
+        """flags[p] = 1 if the ordered pair (pairs[p,0] -> pairs[p,1]) forms a 3'-end dimer."""
+        codes = np.ascontiguousarray(codes, dtype=np.uint8)
+        off = np.ascontiguousarray(off, dtype=np.int32)
+        pairs = np.ascontiguousarray(pairs, dtype=np.int32).reshape(-1, 2)
+        loss_hit = np.ascontiguousarray(loss_hit, dtype=np.uint8)
+        dg_params = np.ascontiguousarray(dg_params, dtype=np.float64)
+        flags = np.zeros(max(len(pairs), 1), np.uint8)
+        self._ck(self.d.mp_dimer_pairs(self.h, len(off) - 1, _ptr(codes), _ptr(off), len(pairs), _ptr(pairs), _ptr(loss_hit),
+                                       _ptr(dg_params), dg_limit, _ptr(flags)))
+        return flags[: len(pairs)]
+
+    def pair_coverage(self, sets_a, sets_b, pairs) -> np.ndarray:
+        """popcount(sets_a[i] | sets_b[j]) for every (i, j) in pairs; sets are rows of uint64 words."""
+        sets_a = np.ascontiguousarray(sets_a, dtype=np.uint64)
+        sets_b = np.ascontiguousarray(sets_b, dtype=np.uint64)
+        pairs = np.ascontiguousarray(pairs, dtype=np.int32).reshape(-1, 2)
+        out = np.zeros(max(len(pairs), 1), np.int32)
+        self._ck(self.d.mp_pair_coverage(self.h, sets_a.shape[0], sets_a.shape[1], _ptr(sets_a), _ptr(sets_b), len(pairs),
+                                         _ptr(pairs), _ptr(out)))
+        return out[: len(pairs)]
 
     def device_bytes(self) -> int:
         b = C.c_int64(0)

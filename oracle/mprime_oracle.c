@@ -567,3 +567,44 @@ int mp_dimer_scan(mp_ctx *c, int32_t n, const uint8_t *codes, const int32_t *off
     *n_hits = nh;
     return MP_OK;
 }
+
+/* Primers_filter.dimer_check (get_multiPrime_V8.py:419-438), one ordered pair x -> y at a time */
+int mp_dimer_pairs(mp_ctx *c, int32_t n, const uint8_t *codes, const int32_t *off, int64_t n_pairs, const int32_t *pairs,
+                   const uint8_t *loss_hit, const double *dg, double dg_limit, uint8_t *flags) {
+    if (!c) return MP_ERR_ARG;
+    if (n < 0 || !codes || !off || !loss_hit || !dg || n_pairs < 0 || (n_pairs && (!pairs || !flags)))
+        return fail(c, MP_ERR_ARG, "mp_dimer_pairs: bad arguments");
+    for (int32_t i = 0; i < n; i++) {
+        int len = off[i + 1] - off[i];
+        if (len < 1 || len > MP_DIMER_MAX_LEN || n_expansions(codes + off[i], len) < 0)
+            return fail(c, MP_ERR_ARG, "primer %d is not usable (length %d)", i, len);
+    }
+    for (int64_t p = 0; p < n_pairs; p++) {
+        int32_t x = pairs[2 * p], y = pairs[2 * p + 1];
+        if (x < 0 || x >= n || y < 0 || y >= n) return fail(c, MP_ERR_ARG, "pair %lld out of range", (long long)p);
+        int lx = off[x + 1] - off[x], ly = off[y + 1] - off[y];
+        int32_t rec[6];
+        flags[p] = (uint8_t)dimer_pair(codes + off[x], lx, codes + off[y], ly, lx < 18 ? lx : 18, lx < 5 ? lx : 5,
+                                       loss_hit, dg, dg_limit, rec);
+    }
+    return MP_OK;
+}
+
+/* len(set(un_cover_list)) of get_multiPrime_V8.py:560-569 on bitsets */
+int mp_pair_coverage(mp_ctx *c, int32_t n_sets, int32_t n_words, const uint64_t *a, const uint64_t *b, int64_t n_pairs,
+                     const int32_t *pairs, int32_t *out) {
+    if (!c) return MP_ERR_ARG;
+    if (n_sets < 0 || n_words < 0 || n_pairs < 0 || (n_pairs && (!a || !b || !pairs || !out)))
+        return fail(c, MP_ERR_ARG, "mp_pair_coverage: bad arguments");
+    for (int64_t p = 0; p < n_pairs; p++) {
+        int32_t i = pairs[2 * p], j = pairs[2 * p + 1];
+        if (i < 0 || i >= n_sets || j < 0 || j >= n_sets) return fail(c, MP_ERR_ARG, "pair %lld out of range", (long long)p);
+        int32_t cnt = 0;
+        for (int32_t w = 0; w < n_words; w++) {
+            uint64_t x = a[(size_t)i * n_words + w] | b[(size_t)j * n_words + w];
+            while (x) { x &= x - 1; cnt++; }
+        }
+        out[p] = cnt;
+    }
+    return MP_OK;
+}

@@ -1,0 +1,81 @@
+"""the pairing stage (get_multiPrime.py) against outputs recorded from the unmodified
+reference script (tests/golden/make_golden_pairing.py).  Its input files are regenerated with this
+build's core (byte-identical TSV / identical JSON by tests/test_core_golden.py)."""
+import contextlib
+import gzip
+import hashlib
+import io
+import json
+import os
+
+import pytest
+
+from conftest import GOLDEN, golden_input, load_gz_json
+from multiprime_amd.core import NN_degenerate
+from multiprime_amd.pairing import Primers_filter
+
+ARG = {"-f": ("fraction", float), "-s": ("size", str), "-e": ("position", int), "-d": ("distance", int), "-a": ("adaptor", str),
+       "-m": ("rep_seq_number", int), "-t": ("diff_Tm", int)}
+DEFAULTS = dict(fraction=0.6, size="250,500", position=4, distance=4, diff_Tm=4, rep_seq_number=0,
+                adaptor="TCTTTCCCTACACGACGCTCTTCCGATCT,TCTTTCCCTACACGACGCTCTTCCGATCT")
+
+
+@pytest.fixture(scope="module")
+def gold():
+    return json.loads(gzip.open(os.path.join(GOLDEN, "pairing.json.gz")).read())
+
+
+@pytest.fixture(scope="module")
+def core_outputs(oracle_lib, tmp_path_factory):
+    made = {}
+
+    def get(name):
+        if name not in made:
+            d = tmp_path_factory.mktemp(name)
+            meta = load_gz_json(name + ".trace.json.gz")["meta"]
+            fl = meta["flags"]
+            inp = d / "in.fa"
+            inp.write_bytes(golden_input(meta["input"]))
+            out = d / (name + ".top.primer.out")
+            NN_degenerate(seq_file=str(inp), primer_length=fl["l"], coverage=fl["f"], number_of_dege_bases=fl["n"],
+                          score_of_dege_bases=fl["d"], raw_entropy_threshold=fl["e"], product_len=fl["s"], position=fl["c"],
+                          variation=fl["v"], distance=fl["a"], GC=fl["g"], nproc=1, outfile=str(out), library=oracle_lib).run()
+            ref = d / "ref.tfa"
+            ref.write_text("".join(f">s{i}\nACGT\n" for i in range(meta["n_seq"])))
+            made[name] = (str(out), str(ref))
+        return made[name]
+    return get
+
+
+def run_pairing(lib, gold, core_outputs, fixture, flagset, tmp_path):
+    want = gold["results"][fixture][flagset]
+    kw = dict(DEFAULTS)
+    fl = gold["flags"][flagset]
+    for k, v in zip(fl[::2], fl[1::2]):
+        if k in ARG:
+            kw[ARG[k][0]] = ARG[k][1](v)
+    core_out, ref = core_outputs(fixture)
+    out = tmp_path / (fixture + ".candidate.primers.txt")
+    buf = io.StringIO()
+    with contextlib.redirect_stdout(buf):
+        Primers_filter(ref_file=ref, primer_file=core_out, outfile=str(out), nproc=1, library=lib, **kw).run()
+    lines = buf.getvalue().splitlines()
+    for ext, path in (("txt", str(out)), ("xls", str(out).strip(".txt") + ".xls"), ("fa", str(out).strip(".txt") + ".fa")):
+        got = open(path).read().replace(str(out), "<OUT>") if os.path.exists(path) else None
+        assert got == want[ext], ext
+    assert len(lines) == want["stdout_lines"]
+    assert hashlib.sha256("\n".join(lines).encode()).hexdigest() == want["stdout_sha256"]
+
+
+CASES = [(f, s) for f in ("ivc_v1", "msa1000_k18_d64", "cluster0_v1") for s in ("yaml", "default", "noadaptor_t2", "tight")]
+
+
+@pytest.mark.parametrize("fixture,flagset", CASES)
+def test_pairing_matches_reference(fixture, flagset, oracle_lib, gold, core_outputs, tmp_path):
+    run_pairing(oracle_lib, gold, core_outputs, fixture, flagset, tmp_path)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("fixture,flagset", CASES)
+def test_pairing_hip_matches_reference(fixture, flagset, hip_lib, gold, core_outputs, tmp_path):
+    run_pairing(hip_lib, gold, core_outputs, fixture, flagset, tmp_path)
