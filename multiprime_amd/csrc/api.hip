@@ -1,0 +1,103 @@
+// api.hip — part of libmprime_hip.so: hand-written HIP (gfx950 / MI355X, wave64) behind the C ABI of
+// include/mprime.h.  Context lifetime and bookkeeping.
+#include "common.hpp"
+
+namespace mp {
+
+void free_eval(mp_ctx *c) {
+    dev_free(c, &c->items, (size_t)c->n_items);
+    dev_free(c, &c->cand_n, (size_t)c->n_padded);
+    dev_free(c, &c->cand_out, (size_t)c->n_padded);
+    dev_free(c, &c->cand_symT, (size_t)c->n_items * 32);
+    c->n_items = c->n_padded = c->n_cand = 0;
+}
+
+void free_unique(mp_ctx *c) {
+    size_t cap = (size_t)c->u_cap, W = (size_t)c->n_win;
+    dev_free(c, &c->u_b0, cap); dev_free(c, &c->u_b1, cap); dev_free(c, &c->u_g, cap);
+    dev_free(c, &c->u_count, cap); dev_free(c, &c->u_first, cap);
+    dev_free(c, &c->labels, W * c->n_pad);
+    dev_free(c, &c->u_over, W); dev_free(c, &c->u_wcount, W); dev_free(c, &c->u_wbase, W);
+    dev_free(c, &c->u_total, 1);
+    c->u_cap = c->u_n = 0;
+    c->h_wbase.clear(); c->h_wcount.clear();
+}
+
+void free_windows(mp_ctx *c) {
+    free_eval(c);
+    free_unique(c);
+    if (c->win) { (void)hipFree(c->win); c->bytes -= (int64_t)c->win_bytes; c->win = nullptr; c->win_bytes = 0; }
+    dev_free(c, &c->excl, (size_t)c->n_win * (c->n_pad / 64));
+    dev_free(c, &c->patch_count, (size_t)c->n_win);
+    dev_free(c, &c->patch_off, (size_t)c->n_win + 1);
+    dev_free(c, &c->patch_cursor, (size_t)c->n_win);
+    dev_free(c, &c->patch_words, (size_t)3 * c->n_patch);
+    c->n_patch = c->max_patch = 0;
+    dev_free(c, &c->ex, (size_t)c->ex_cap);
+    dev_free(c, &c->ex_count, 1);
+    dev_free(c, &c->err_flag, 4);
+    dev_free(c, &c->extra_off, (size_t)c->n_win + 1);
+    dev_free(c, &c->extra_words, (size_t)3 * c->n_extra);
+    c->ex_cap = 0; c->n_extra = 0; c->n_win = 0;
+    c->ex_host.clear();
+}
+
+void free_msa(mp_ctx *c) {
+    free_windows(c);
+    size_t np = (size_t)c->n_pad;
+    dev_free(c, &c->planes, (size_t)c->n_chunks * 4 * np);
+    dev_free(c, &c->cols, (size_t)c->n_chunks * 32 * 3 * (np / 64));
+    dev_free(c, &c->cum, ((size_t)c->n_chunks + 1) * np);
+    dev_free(c, &c->ung, (size_t)c->n_rows * c->ustride);
+    dev_free(c, &c->lead, np); dev_free(c, &c->rstrip, np); dev_free(c, &c->rlen, np);
+    c->n_rows = c->n_pad = c->n_chunks = 0;
+}
+
+
+}  // namespace mp
+
+using namespace mp;
+
+extern "C" {
+
+const char *mp_backend_name(void) { return "hip"; }
+const char *mp_last_error(const mp_ctx *c) { return c ? c->err : "mp_create failed: no usable HIP device"; }
+
+int mp_create(int device, mp_ctx **out) {
+    if (!out) return MP_ERR_ARG;
+    *out = nullptr;
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || n <= 0 || device < 0 || device >= n) return MP_ERR_DEVICE;
+    if (hipSetDevice(device) != hipSuccess) return MP_ERR_DEVICE;
+    mp_ctx *c = new mp_ctx();
+    c->dev = device;
+    if (pack_init() != MP_OK || dimer_init() != MP_OK) { delete c; return MP_ERR_DEVICE; }
+    *out = c;
+    return MP_OK;
+}
+
+void mp_destroy(mp_ctx *c) {
+    if (!c) return;
+    (void)hipSetDevice(c->dev);
+    (void)hipDeviceSynchronize();
+    free_msa(c);
+    dev_free(c, &c->tmp_out, (size_t)c->tmp_out_n);
+    for (auto &p : c->ev_busy) { (void)hipEventDestroy(p.first); (void)hipEventDestroy(p.second); }
+    for (auto &p : c->ev_free) { (void)hipEventDestroy(p.first); (void)hipEventDestroy(p.second); }
+    delete c;
+}
+
+int mp_set_stream(mp_ctx *c, void *s) {
+    if (!c) return MP_ERR_ARG;
+    c->stream = (hipStream_t)s;
+    return MP_OK;
+}
+
+int mp_device_bytes(mp_ctx *c, int64_t *b) {
+    if (!c || !b) return MP_ERR_ARG;
+    *b = c->bytes;
+    return MP_OK;
+}
+
+
+}  // extern "C"

@@ -1,0 +1,224 @@
+// common.hpp — shared declarations of libmprime_hip.so (hand-written HIP for gfx950 / MI355X behind
+// the C ABI of include/mprime.h).
+//
+// Data layout in HBM:
+//   planes  [n_chunks][4][Npad] u32   base-set bit planes (A,C,G,T membership) of 32 alignment columns
+//                                     per word, sequences along the fastest axis (coalesced per wave)
+//   cols    [L][3][Npad/64] u64       column planes b0,b1,g — one bit per sequence — for the bit-sliced evaluation
+//   cum     [n_chunks+1][Npad] u32    residues (non-gap symbols) left of each 32-column chunk
+//   ung     [N][ustride] u32          gap-free residue codes, 8 nibbles per word (edge-gap repair only)
+//   win     the k-mer of every (window, sequence) after repair, 3 bits per symbol:
+//             k <= 21: [W][Npad] u64       b0 | b1 << k | g << 2k, bit 63 = not in the universe
+//             k >= 22: [W][3][Npad] u32    b0,b1 (2-bit base) and g (gap flag) words
+//   excl / patch list, histogram entries, labels: see windows.hip / unique.hip
+// Translation units: pack.hip (mp_load_msa), windows.hip (mp_build_windows), unique.hip (histograms),
+// eval.hip (candidate x sequence evaluation), dimer.hip (3'-end dimer scan, pair coverage), api.hip.
+// No MFMA anywhere: this is bit-mask work bounded by integer ALU / HBM.  gfx950 only.
+#pragma once
+
+#include "../../include/mprime.h"
+
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cstdarg>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <numeric>
+#include <vector>
+
+namespace mp {
+
+constexpr int kBlock = 256;
+constexpr uint32_t kEmpty = 0xFFFFFFFFu;
+constexpr int kHashSlots = 4096;          // LDS hash table slots per window (unique_kernel)
+constexpr int kHashLimit = 3584;          // load limit before the window is handed to the global-table path
+constexpr int kEvalCC = 8;                // candidates evaluated per block pass
+
+struct ExRec { int32_t win, row; uint64_t lo, hi; };          // exception k-mer, 16+12 nibbles
+struct EvalItem { int32_t win, cand0; };                        // one block's work: window + first padded candidate
+
+
+struct Nib {          // up to 32 symbol codes, one nibble each
+    uint64_t lo, hi;
+    __device__ uint32_t get(int j) const { return (uint32_t)((j < 16 ? lo >> (4 * j) : hi >> (4 * (j - 16))) & 15u); }
+    __device__ void set(int j, uint32_t v) {
+        if (j < 16) lo = (lo & ~(15ull << (4 * j))) | ((uint64_t)v << (4 * j));
+        else hi = (hi & ~(15ull << (4 * (j - 16)))) | ((uint64_t)v << (4 * (j - 16)));
+    }
+    __device__ void shift_up(int n) {      // move every nibble n positions towards the 3' end
+        int s = 4 * n;
+        if (s == 0) return;
+        if (s >= 64) { hi = lo << (s - 64); lo = 0; }
+        else { hi = (hi << s) | (lo >> (64 - s)); lo <<= s; }
+    }
+};
+
+// ----------------------------------------------------------------------------------------------
+// window words in HBM: one packed u64 per (window, sequence) when 3k <= 63, else three u32 planes
+// ----------------------------------------------------------------------------------------------
+template <bool P64>
+struct WinView;
+
+template <>
+struct WinView<false> {
+    const uint32_t *W0, *W1, *W2;
+    __device__ WinView(const void *base, int w, size_t np, int, uint32_t)
+        : W0((const uint32_t *)base + (size_t)w * 3 * np), W1(W0 + np), W2(W1 + np) {}
+    __device__ inline void load(int r, uint32_t &b0, uint32_t &b1, uint32_t &g) const { b0 = W0[r]; b1 = W1[r]; g = W2[r]; }
+    struct Raw4 { uint4 a, b, c; };
+    __device__ inline Raw4 load4(int r) const {
+        Raw4 q;
+        q.a = *reinterpret_cast<const uint4 *>(W0 + r);
+        q.b = *reinterpret_cast<const uint4 *>(W1 + r);
+        q.c = *reinterpret_cast<const uint4 *>(W2 + r);
+        return q;
+    }
+    __device__ inline void unpack(const Raw4 &q, int i, uint32_t &b0, uint32_t &b1, uint32_t &g) const {
+        b0 = i == 0 ? q.a.x : i == 1 ? q.a.y : i == 2 ? q.a.z : q.a.w;
+        b1 = i == 0 ? q.b.x : i == 1 ? q.b.y : i == 2 ? q.b.z : q.b.w;
+        g = i == 0 ? q.c.x : i == 1 ? q.c.y : i == 2 ? q.c.z : q.c.w;
+    }
+    __device__ static inline void store(void *base, int w, size_t np, int r, uint32_t b0, uint32_t b1, uint32_t g, int, uint32_t) {
+        uint32_t *W = (uint32_t *)base + (size_t)w * 3 * np + r;
+        W[0] = b0; W[np] = b1; W[2 * np] = g;
+    }
+};
+
+template <>
+struct WinView<true> {
+    const uint64_t *Wp;
+    int k;
+    uint32_t kmask;
+    __device__ WinView(const void *base, int w, size_t np, int k_, uint32_t kmask_)
+        : Wp((const uint64_t *)base + (size_t)w * np), k(k_), kmask(kmask_) {}
+    __device__ inline void split(uint64_t x, uint32_t &b0, uint32_t &b1, uint32_t &g) const {
+        b0 = (uint32_t)x & kmask;
+        b1 = (uint32_t)(x >> k) & kmask;
+        g = ((uint32_t)(x >> (2 * k)) & kmask) | ((uint32_t)(x >> 32) & MP_WIN_SKIP);
+    }
+    __device__ inline void load(int r, uint32_t &b0, uint32_t &b1, uint32_t &g) const { split(Wp[r], b0, b1, g); }
+    struct Raw4 { uint4 a, b; };
+    __device__ inline Raw4 load4(int r) const {
+        Raw4 q;
+        q.a = *reinterpret_cast<const uint4 *>(Wp + r);
+        q.b = *reinterpret_cast<const uint4 *>(Wp + r + 2);
+        return q;
+    }
+    __device__ inline void unpack(const Raw4 &q, int i, uint32_t &b0, uint32_t &b1, uint32_t &g) const {
+        uint32_t lo = i == 0 ? q.a.x : i == 1 ? q.a.z : i == 2 ? q.b.x : q.b.z;
+        uint32_t hi = i == 0 ? q.a.y : i == 1 ? q.a.w : i == 2 ? q.b.y : q.b.w;
+        split(((uint64_t)hi << 32) | lo, b0, b1, g);
+    }
+    __device__ static inline void store(void *base, int w, size_t np, int r, uint32_t b0, uint32_t b1, uint32_t g, int k, uint32_t kmask) {
+        uint64_t x = (uint64_t)b0 | ((uint64_t)b1 << k) | ((uint64_t)(g & kmask) << (2 * k)) |
+                     ((uint64_t)(g & MP_WIN_SKIP) << 32);
+        ((uint64_t *)base)[(size_t)w * np + r] = x;
+    }
+};
+
+// thread = row, block = 256 rows x a tile of consecutive windows; the 32-column plane words slide
+// in registers, so every plane word is read once per tile.
+
+}  // namespace mp
+
+// ================================================================================================
+// the opaque context
+// ================================================================================================
+struct mp_ctx {
+    char err[512] = {0};
+    int dev = 0;
+    hipStream_t stream = nullptr;
+    int64_t bytes = 0;
+    // alignment
+    int n_rows = 0, n_pad = 0, n_chunks = 0, max_len = 0, ustride = 0;
+    uint32_t *planes = nullptr, *cum = nullptr, *ung = nullptr;
+    unsigned long long *cols = nullptr;      // [n_chunks*32][3][n_pad/64]
+    int32_t *lead = nullptr, *rstrip = nullptr, *rlen = nullptr;
+    // windows
+    int p0 = 0, n_win = 0, k = 0, v = 0;
+    void *win = nullptr;
+    unsigned long long *excl = nullptr;      // [W][n_pad/64]
+    int32_t *patch_count = nullptr, *patch_off = nullptr, *patch_cursor = nullptr;
+    uint32_t *patch_words = nullptr;
+    int n_patch = 0, max_patch = 0;
+    bool p64 = false;
+    size_t win_bytes = 0;
+    mp::ExRec *ex = nullptr;
+    int ex_cap = 0;
+    int *ex_count = nullptr, *err_flag = nullptr;
+    std::vector<mp::ExRec> ex_host;
+    int32_t *extra_off = nullptr;
+    uint32_t *extra_words = nullptr;
+    int n_extra = 0;
+    // unique
+    long long u_cap = 0, u_n = 0;
+    uint32_t *u_b0 = nullptr, *u_b1 = nullptr, *u_g = nullptr;
+    int32_t *u_count = nullptr, *u_first = nullptr, *labels = nullptr, *u_over = nullptr, *u_wcount = nullptr;
+    int64_t *u_wbase = nullptr;
+    unsigned long long *u_total = nullptr;
+    std::vector<int64_t> h_wbase;
+    std::vector<int32_t> h_wcount;
+    // eval staging
+    int n_cand = 0, n_items = 0, n_padded = 0;
+    mp::EvalItem *items = nullptr;
+    uint4 *cand_n = nullptr;
+    uint32_t *cand_symT = nullptr;
+    int32_t *cand_out = nullptr;
+    uint32_t sF = 0, sR = 0;
+    unsigned long long *tmp_out = nullptr;
+    int tmp_out_n = 0;
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> ev_busy, ev_free;
+    double ev_ms = 0;
+    int ev_n = 0;
+    int eval_variant = 0;
+};
+
+namespace mp {
+
+
+inline int fail(mp_ctx *c, int code, const char *fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(c->err, sizeof c->err, fmt, ap);
+    va_end(ap);
+    return code;
+}
+
+#define HIPCK(c, call)                                                                                   \
+    do {                                                                                                 \
+        hipError_t e_ = (call);                                                                          \
+        if (e_ != hipSuccess) return fail((c), MP_ERR_DEVICE, "%s: %s", #call, hipGetErrorString(e_));  \
+    } while (0)
+
+template <typename T>
+int dev_alloc(mp_ctx *c, T **p, size_t n) {
+    *p = nullptr;
+    if (n == 0) n = 1;
+    hipError_t e = hipMalloc((void **)p, n * sizeof(T));
+    if (e != hipSuccess) return fail(c, MP_ERR_NOMEM, "hipMalloc(%zu bytes): %s", n * sizeof(T), hipGetErrorString(e));
+    c->bytes += (int64_t)(n * sizeof(T));
+    return MP_OK;
+}
+
+template <typename T>
+void dev_free(mp_ctx *c, T **p, size_t n) {
+    if (*p) {
+        (void)hipFree(*p);
+        c->bytes -= (int64_t)((n ? n : 1) * sizeof(T));
+        *p = nullptr;
+    }
+}
+
+
+// release the device arrays of one stage (and of every stage that depends on it); api.hip
+void free_eval(mp_ctx *c);
+void free_unique(mp_ctx *c);
+void free_windows(mp_ctx *c);
+void free_msa(mp_ctx *c);
+// per-translation-unit device constants (called by mp_create on the context's device)
+int pack_init();
+int dimer_init();
+
+}  // namespace mp

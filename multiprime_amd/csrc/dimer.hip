@@ -1,0 +1,312 @@
+// dimer.hip — part of libmprime_hip.so: hand-written HIP (gfx950 / MI355X, wave64) behind the C ABI of
+// include/mprime.h.  3'-end dimer scans (finDimer, get_Maxprimerset, get_multiPrime) and pair coverage from sequence bitsets.
+#include "common.hpp"
+
+using namespace mp;
+
+namespace {
+
+// ----------------------------------------------------------------------------------------------
+// (5) 3'-end dimer scan (finDimer_V4.py:191-224 "FD", get_Maxprimerset_V1.3.py:193-215 "MS")
+// ----------------------------------------------------------------------------------------------
+// thread = one (x, y) primer pair.  Primers are <= 32 symbols: the symbol codes sit in a 2 x u64
+// nibble buffer, a concrete expansion is a 2-bit-packed u64, "RC(end) occurs in p at idx" is one
+// shift-mask-compare per offset, GC content one popcount.  The two floating-point decisions come
+// in as an exact byte table (Loss >= threshold) and as double constants that are only ADDED, in
+// the reference's order, with __dadd_rn (no contraction, no multiply): the same doubles as CPython.
+__constant__ uint8_t c_msize[16];
+__constant__ uint8_t c_member[16][4];
+
+struct DimerArgs {
+    const uint8_t *codes;
+    const int32_t *off;
+    int n, mode, n_new;
+    const uint8_t *loss_hit;
+    const double *dg;
+    double dg_limit;
+    long long cap;
+    int32_t *hits;
+    unsigned long long *n_hits;
+};
+
+__device__ inline uint32_t dm_degeneracy(const Nib &c, int start, int len) {
+    uint32_t d = 1;
+    for (int p = 0; p < len; p++) d *= c_msize[c.get(start + p)];
+    return d;
+}
+
+// expansion number idx (itertools.product order, last position fastest) as 2 bits per base, position 0 lowest
+__device__ inline uint64_t dm_expand(const Nib &c, int start, int len, uint32_t idx) {
+    uint64_t x = 0;
+    for (int p = len - 1; p >= 0; p--) {
+        uint32_t code = c.get(start + p);
+        uint32_t sz = c_msize[code];
+        uint32_t ch = idx % sz;
+        idx /= sz;
+        x |= (uint64_t)c_member[code][ch] << (2 * p);
+    }
+    return x;
+}
+
+__device__ inline double dm_delta_g(uint64_t e, int l, const double *__restrict__ dg) {
+    double g = 0.0;
+    uint32_t prev = (uint32_t)e & 3u;
+    for (int t = 1; t < l; t++) {
+        uint32_t cur = (uint32_t)(e >> (2 * t)) & 3u;
+        g = __dadd_rn(g, dg[cur * 4 + prev]);                        // FD:176-178
+        prev = cur;
+    }
+    uint32_t first = (uint32_t)e & 3u, last = (uint32_t)(e >> (2 * (l - 1))) & 3u;
+    int ta = l >= 2 && ((uint32_t)(e >> (2 * (l - 2))) & 3u) == 3u && last == 0u;    // end[-2:] == "TA", FD:179
+    g = __dadd_rn(g, dg[16 + (first * 4 + last) * 2 + ta]);          // FD:181-183
+    g = __dadd_rn(g, -dg[48 + l]);                                   // FD:185
+    bool sym = (l & 1) == 0;                                         // FD:115-125
+    for (int t = 0; sym && t < l / 2; t++)
+        sym = ((uint32_t)(e >> (2 * t)) & 3u) == (3u - ((uint32_t)(e >> (2 * (l / 2 + t))) & 3u));
+    if (sym) g = __dadd_rn(g, dg[48 + MP_DIMER_MAX_LEN + 1]);        // FD:186-187
+    return g;
+}
+
+// one ordered pair x -> y: first passing (end length, end expansion, y expansion); returns true on a hit
+__device__ inline bool dimer_pair_scan(const uint8_t *__restrict__ codes, const int32_t *__restrict__ off, int x, int y,
+                                       int mode, const uint8_t *__restrict__ loss_hit, const double *__restrict__ dg,
+                                       double dg_limit, int32_t (&rec)[4]) {
+    const int lx = off[x + 1] - off[x], ly = off[y + 1] - off[y];
+    Nib cx, cy;
+    cx.lo = cx.hi = cy.lo = cy.hi = 0;
+    for (int p = 0; p < lx; p++) cx.set(p, codes[off[x] + p]);
+    for (int p = 0; p < ly; p++) cy.set(p, codes[off[y] + p]);
+    const uint32_t dy = dm_degeneracy(cy, 0, ly);
+    int l_hi, l_lo;
+    if (mode == 0) { l_hi = lx < 18 ? lx : 18; l_lo = lx < 5 ? lx : 5; }         // FD:162-169
+    else { l_hi = lx - 1; l_lo = 5; }                                             // MS:149-154
+    for (int l = l_hi; l >= l_lo; l--) {
+        if (l <= 0 || l > ly) continue;                                           // cannot occur in a shorter primer
+        const uint32_t de = dm_degeneracy(cx, lx - l, l);
+        const uint64_t mask = l == 32 ? ~0ull : ((1ull << (2 * l)) - 1ull);
+        for (uint32_t ei = 0; ei < de; ei++) {
+            const uint64_t e = dm_expand(cx, lx - l, l, ei);
+            uint64_t rc = 0;                                                      // reverse complement: 3 - base, reversed
+            for (int t = 0; t < l; t++) rc |= (uint64_t)(3u - ((uint32_t)(e >> (2 * (l - 1 - t))) & 3u)) << (2 * t);
+            const int gc = __popcll((e ^ (e >> 1)) & 0x5555555555555555ull & mask);   // C = 01, G = 10
+            for (uint32_t pi = 0; pi < dy; pi++) {
+                const uint64_t p = dm_expand(cy, 0, ly, pi);
+                int idx = -1;
+                for (int s0 = 0; s0 + l <= ly; s0++)
+                    if (((p >> (2 * s0)) & mask) == rc) { idx = s0; break; }      // str.find: first occurrence
+                if (idx < 0) continue;
+                const int d2 = ly - l - idx;
+                bool hit = loss_hit[((size_t)l * (MP_DIMER_MAX_LEN + 1) + gc) * 64 + d2] != 0;
+                if (!hit && d2 == 0) hit = dm_delta_g(e, l, dg) < dg_limit;
+                if (hit) { rec[0] = l; rec[1] = (int32_t)ei; rec[2] = (int32_t)pi; rec[3] = idx; return true; }
+            }
+        }
+    }
+    return false;
+}
+
+__global__ __launch_bounds__(kBlock) void dimer_kernel(const DimerArgs A) {
+    const int x = blockIdx.x;
+    const int y = blockIdx.y * kBlock + threadIdx.x;
+    if (y >= A.n) return;
+    if (A.mode == 0 ? (y < x) : (x >= A.n_new && y >= A.n_new)) return;
+    int32_t rec[4];
+    if (dimer_pair_scan(A.codes, A.off, x, y, A.mode, A.loss_hit, A.dg, A.dg_limit, rec)) {
+        unsigned long long h = atomicAdd(A.n_hits, 1ull);
+        if ((long long)h < A.cap) {
+            int32_t *r = A.hits + 6 * h;
+            r[0] = x; r[1] = y; r[2] = rec[0]; r[3] = rec[1]; r[4] = rec[2]; r[5] = rec[3];
+        }
+    }
+}
+
+// explicit ordered pairs (get_multiPrime_V8.py:419-438): one thread per pair, any passing combination
+__global__ __launch_bounds__(kBlock) void dimer_pairs_kernel(const uint8_t *__restrict__ codes, const int32_t *__restrict__ off,
+                                                             long long n_pairs, const int32_t *__restrict__ pairs,
+                                                             const uint8_t *__restrict__ loss_hit, const double *__restrict__ dg,
+                                                             double dg_limit, uint8_t *__restrict__ flags) {
+    const long long p = (long long)blockIdx.x * kBlock + threadIdx.x;
+    if (p >= n_pairs) return;
+    int32_t rec[4];
+    flags[p] = dimer_pair_scan(codes, off, pairs[2 * p], pairs[2 * p + 1], 0, loss_hit, dg, dg_limit, rec) ? 1 : 0;
+}
+
+// popcount(A[i] | B[j]) per pair: one wave per pair, lanes stride over the set's words (get_multiPrime_V8.py:560-569)
+__global__ __launch_bounds__(kBlock) void pair_coverage_kernel(const unsigned long long *__restrict__ a,
+                                                               const unsigned long long *__restrict__ b, int n_words,
+                                                               long long n_pairs, const int32_t *__restrict__ pairs,
+                                                               int32_t *__restrict__ out) {
+    const long long p = (long long)blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6);
+    if (p >= n_pairs) return;
+    const int lane = threadIdx.x & 63;
+    const unsigned long long *A = a + (size_t)pairs[2 * p] * n_words, *B = b + (size_t)pairs[2 * p + 1] * n_words;
+    int cnt = 0;
+    for (int w = lane; w < n_words; w += 64) cnt += __popcll(A[w] | B[w]);
+#pragma unroll
+    for (int s = 32; s >= 1; s >>= 1) cnt += __shfl_xor(cnt, s);
+    if (lane == 0) out[p] = cnt;
+}
+
+
+}  // namespace
+
+namespace mp {
+int dimer_init() {
+    // member order of every IUPAC symbol as the reference lists it (V20:105-107, FD:46-48), bases as A0 C1 G2 T3
+    static const char *members[16] = {"", "A", "C", "AC", "G", "AG", "GC", "GAC", "T", "AT", "CT", "ATC", "GT", "GAT", "GTC", "ATGC"};
+    uint8_t msize[16], member[16][4];
+    for (int m = 0; m < 16; m++) {
+        msize[m] = (uint8_t)strlen(members[m]);
+        for (int t = 0; t < 4; t++) {
+            char ch = t < msize[m] ? members[m][t] : 'A';
+            member[m][t] = ch == 'A' ? 0 : ch == 'C' ? 1 : ch == 'G' ? 2 : 3;
+        }
+    }
+    if (hipMemcpyToSymbol(HIP_SYMBOL(c_msize), msize, 16) != hipSuccess) return MP_ERR_DEVICE;
+    if (hipMemcpyToSymbol(HIP_SYMBOL(c_member), member, 64) != hipSuccess) return MP_ERR_DEVICE;
+    return MP_OK;
+}
+}  // namespace mp
+
+namespace {
+static int check_primers(mp_ctx *c, int32_t n, const uint8_t *codes, const int32_t *off) {
+    static const int msize[16] = {0, 1, 1, 2, 1, 2, 2, 3, 1, 2, 2, 3, 2, 3, 3, 4};
+    for (int32_t i = 0; i < n; i++) {
+        int len = off[i + 1] - off[i];
+        if (len < 1 || len > MP_DIMER_MAX_LEN) return fail(c, MP_ERR_ARG, "primer %d has length %d (1..%d supported)", i, len, MP_DIMER_MAX_LEN);
+        long long d = 1;
+        for (int p = 0; p < len; p++) {
+            uint8_t m = codes[off[i] + p];
+            if (m == 0 || m > 15) return fail(c, MP_ERR_ARG, "primer %d holds a gap / unknown symbol", i);
+            d *= msize[m];
+            if (d > (1LL << 24)) return fail(c, MP_ERR_ARG, "primer %d has too many expansions", i);
+        }
+    }
+    return MP_OK;
+}
+}  // namespace
+
+extern "C" {
+
+int mp_dimer_scan(mp_ctx *c, int32_t n, const uint8_t *codes, const int32_t *off, int32_t mode, int32_t n_new,
+                  const uint8_t *loss_hit, const double *dg, double dg_limit, int64_t cap, int32_t *hits, int64_t *n_hits) {
+    if (!c) return MP_ERR_ARG;
+    if (n < 0 || !codes || !off || !loss_hit || !dg || !n_hits || cap < 0 || (cap && !hits) || (mode != 0 && mode != 1))
+        return fail(c, MP_ERR_ARG, "mp_dimer_scan: bad arguments");
+    HIPCK(c, hipSetDevice(c->dev));
+    *n_hits = 0;
+    if (n == 0) return MP_OK;
+    static const int msize[16] = {0, 1, 1, 2, 1, 2, 2, 3, 1, 2, 2, 3, 2, 3, 3, 4};
+    for (int32_t i = 0; i < n; i++) {
+        int len = off[i + 1] - off[i];
+        if (len < 1 || len > MP_DIMER_MAX_LEN) return fail(c, MP_ERR_ARG, "primer %d has length %d (1..%d supported)", i, len, MP_DIMER_MAX_LEN);
+        long long d = 1;
+        for (int p = 0; p < len; p++) {
+            uint8_t m = codes[off[i] + p];
+            if (m == 0 || m > 15) return fail(c, MP_ERR_ARG, "primer %d holds a gap / unknown symbol", i);
+            d *= msize[m];
+            if (d > (1LL << 24)) return fail(c, MP_ERR_ARG, "primer %d has too many expansions", i);
+        }
+    }
+    const size_t total = (size_t)off[n], tbl = (size_t)(MP_DIMER_MAX_LEN + 1) * (MP_DIMER_MAX_LEN + 1) * 64;
+    const size_t ndg = 16 + 32 + MP_DIMER_MAX_LEN + 1 + 1;
+    uint8_t *d_codes = nullptr, *d_loss = nullptr;
+    int32_t *d_off = nullptr, *d_hits = nullptr;
+    double *d_dg = nullptr;
+    unsigned long long *d_n = nullptr;
+    int rc;
+    if ((rc = dev_alloc(c, &d_codes, total))) return rc;
+    if ((rc = dev_alloc(c, &d_off, (size_t)n + 1))) return rc;
+    if ((rc = dev_alloc(c, &d_loss, tbl))) return rc;
+    if ((rc = dev_alloc(c, &d_dg, ndg))) return rc;
+    if ((rc = dev_alloc(c, &d_hits, (size_t)cap * 6))) return rc;
+    if ((rc = dev_alloc(c, &d_n, 1))) return rc;
+    HIPCK(c, hipMemcpyAsync(d_codes, codes, total, hipMemcpyHostToDevice, c->stream));
+    HIPCK(c, hipMemcpyAsync(d_off, off, sizeof(int32_t) * ((size_t)n + 1), hipMemcpyHostToDevice, c->stream));
+    HIPCK(c, hipMemcpyAsync(d_loss, loss_hit, tbl, hipMemcpyHostToDevice, c->stream));
+    HIPCK(c, hipMemcpyAsync(d_dg, dg, sizeof(double) * ndg, hipMemcpyHostToDevice, c->stream));
+    HIPCK(c, hipMemsetAsync(d_n, 0, sizeof(unsigned long long), c->stream));
+    DimerArgs da{d_codes, d_off, n, mode, n_new, d_loss, d_dg, dg_limit, (long long)cap, d_hits, d_n};
+    hipLaunchKernelGGL(dimer_kernel, dim3((unsigned)n, (unsigned)((n + kBlock - 1) / kBlock)), dim3(kBlock), 0, c->stream, da);
+    HIPCK(c, hipGetLastError());
+    unsigned long long nh = 0;
+    HIPCK(c, hipMemcpyAsync(&nh, d_n, sizeof(nh), hipMemcpyDeviceToHost, c->stream));
+    HIPCK(c, hipStreamSynchronize(c->stream));
+    size_t ncopy = (size_t)std::min<unsigned long long>(nh, (unsigned long long)cap);
+    if (ncopy) HIPCK(c, hipMemcpy(hits, d_hits, sizeof(int32_t) * 6 * ncopy, hipMemcpyDeviceToHost));
+    *n_hits = (int64_t)nh;
+    dev_free(c, &d_codes, total); dev_free(c, &d_off, (size_t)n + 1); dev_free(c, &d_loss, tbl);
+    dev_free(c, &d_dg, ndg); dev_free(c, &d_hits, (size_t)cap * 6); dev_free(c, &d_n, 1);
+    return MP_OK;
+}
+
+
+int mp_dimer_pairs(mp_ctx *c, int32_t n, const uint8_t *codes, const int32_t *off, int64_t n_pairs, const int32_t *pairs,
+                   const uint8_t *loss_hit, const double *dg, double dg_limit, uint8_t *flags) {
+    if (!c) return MP_ERR_ARG;
+    if (n < 0 || !codes || !off || !loss_hit || !dg || n_pairs < 0 || (n_pairs && (!pairs || !flags)))
+        return fail(c, MP_ERR_ARG, "mp_dimer_pairs: bad arguments");
+    HIPCK(c, hipSetDevice(c->dev));
+    if (n_pairs == 0) return MP_OK;
+    int rc;
+    if ((rc = check_primers(c, n, codes, off))) return rc;
+    for (int64_t p = 0; p < 2 * n_pairs; p++)
+        if (pairs[p] < 0 || pairs[p] >= n) return fail(c, MP_ERR_ARG, "pair %lld out of range", (long long)(p / 2));
+    const size_t total = (size_t)off[n], tbl = (size_t)(MP_DIMER_MAX_LEN + 1) * (MP_DIMER_MAX_LEN + 1) * 64;
+    const size_t ndg = 16 + 32 + MP_DIMER_MAX_LEN + 1 + 1;
+    uint8_t *d_codes = nullptr, *d_loss = nullptr, *d_flags = nullptr;
+    int32_t *d_off = nullptr, *d_pairs = nullptr;
+    double *d_dg = nullptr;
+    if ((rc = dev_alloc(c, &d_codes, total))) return rc;
+    if ((rc = dev_alloc(c, &d_off, (size_t)n + 1))) return rc;
+    if ((rc = dev_alloc(c, &d_loss, tbl))) return rc;
+    if ((rc = dev_alloc(c, &d_dg, ndg))) return rc;
+    if ((rc = dev_alloc(c, &d_pairs, (size_t)2 * n_pairs))) return rc;
+    if ((rc = dev_alloc(c, &d_flags, (size_t)n_pairs))) return rc;
+    HIPCK(c, hipMemcpyAsync(d_codes, codes, total, hipMemcpyHostToDevice, c->stream));
+    HIPCK(c, hipMemcpyAsync(d_off, off, sizeof(int32_t) * ((size_t)n + 1), hipMemcpyHostToDevice, c->stream));
+    HIPCK(c, hipMemcpyAsync(d_loss, loss_hit, tbl, hipMemcpyHostToDevice, c->stream));
+    HIPCK(c, hipMemcpyAsync(d_dg, dg, sizeof(double) * ndg, hipMemcpyHostToDevice, c->stream));
+    HIPCK(c, hipMemcpyAsync(d_pairs, pairs, sizeof(int32_t) * 2 * (size_t)n_pairs, hipMemcpyHostToDevice, c->stream));
+    hipLaunchKernelGGL(dimer_pairs_kernel, dim3((unsigned)((n_pairs + kBlock - 1) / kBlock)), dim3(kBlock), 0, c->stream, d_codes,
+                       d_off, (long long)n_pairs, d_pairs, d_loss, d_dg, dg_limit, d_flags);
+    HIPCK(c, hipGetLastError());
+    HIPCK(c, hipMemcpyAsync(flags, d_flags, (size_t)n_pairs, hipMemcpyDeviceToHost, c->stream));
+    HIPCK(c, hipStreamSynchronize(c->stream));
+    dev_free(c, &d_codes, total); dev_free(c, &d_off, (size_t)n + 1); dev_free(c, &d_loss, tbl); dev_free(c, &d_dg, ndg);
+    dev_free(c, &d_pairs, (size_t)2 * n_pairs); dev_free(c, &d_flags, (size_t)n_pairs);
+    return MP_OK;
+}
+
+int mp_pair_coverage(mp_ctx *c, int32_t n_sets, int32_t n_words, const uint64_t *a, const uint64_t *b, int64_t n_pairs,
+                     const int32_t *pairs, int32_t *out) {
+    if (!c) return MP_ERR_ARG;
+    if (n_sets < 0 || n_words < 0 || n_pairs < 0 || (n_pairs && (!a || !b || !pairs || !out)))
+        return fail(c, MP_ERR_ARG, "mp_pair_coverage: bad arguments");
+    HIPCK(c, hipSetDevice(c->dev));
+    if (n_pairs == 0) return MP_OK;
+    for (int64_t p = 0; p < 2 * n_pairs; p++)
+        if (pairs[p] < 0 || pairs[p] >= n_sets) return fail(c, MP_ERR_ARG, "pair %lld out of range", (long long)(p / 2));
+    const size_t nset = (size_t)n_sets * (size_t)n_words;
+    unsigned long long *d_a = nullptr, *d_b = nullptr;
+    int32_t *d_pairs = nullptr, *d_out = nullptr;
+    int rc;
+    if ((rc = dev_alloc(c, &d_a, nset))) return rc;
+    if ((rc = dev_alloc(c, &d_b, nset))) return rc;
+    if ((rc = dev_alloc(c, &d_pairs, (size_t)2 * n_pairs))) return rc;
+    if ((rc = dev_alloc(c, &d_out, (size_t)n_pairs))) return rc;
+    HIPCK(c, hipMemcpyAsync(d_a, a, sizeof(uint64_t) * nset, hipMemcpyHostToDevice, c->stream));
+    HIPCK(c, hipMemcpyAsync(d_b, b, sizeof(uint64_t) * nset, hipMemcpyHostToDevice, c->stream));
+    HIPCK(c, hipMemcpyAsync(d_pairs, pairs, sizeof(int32_t) * 2 * (size_t)n_pairs, hipMemcpyHostToDevice, c->stream));
+    const long long per_block = kBlock / 64;
+    hipLaunchKernelGGL(pair_coverage_kernel, dim3((unsigned)((n_pairs + per_block - 1) / per_block)), dim3(kBlock), 0, c->stream,
+                       d_a, d_b, n_words, (long long)n_pairs, d_pairs, d_out);
+    HIPCK(c, hipGetLastError());
+    HIPCK(c, hipMemcpyAsync(out, d_out, sizeof(int32_t) * (size_t)n_pairs, hipMemcpyDeviceToHost, c->stream));
+    HIPCK(c, hipStreamSynchronize(c->stream));
+    dev_free(c, &d_a, nset); dev_free(c, &d_b, nset); dev_free(c, &d_pairs, (size_t)2 * n_pairs); dev_free(c, &d_out, (size_t)n_pairs);
+    return MP_OK;
+}
+
+
+}  // extern "C"

@@ -1,0 +1,208 @@
+// pack.hip — part of libmprime_hip.so: hand-written HIP (gfx950 / MI355X, wave64) behind the C ABI of
+// include/mprime.h.  Alignment -> bit planes: pack, row scan, gap-free strings, column planes (mp_load_msa).
+#include "common.hpp"
+
+using namespace mp;
+
+namespace {
+
+// ----------------------------------------------------------------------------------------------
+// (1) alignment -> planes
+// ----------------------------------------------------------------------------------------------
+__constant__ uint8_t c_code_lut[256];
+
+// V20:453: upper-case, keep ACGTRYMKSWHBVD (as 4-bit base sets), everything else (N included) -> '-' = 0
+static void host_code_lut(uint8_t *lut) {
+    memset(lut, 0, 256);
+    const char *sym = "ACGTRYMKSWHBVD";
+    const uint8_t code[] = {1, 2, 4, 8, 5, 10, 3, 12, 6, 9, 11, 14, 7, 13};
+    for (int i = 0; sym[i]; i++) {
+        lut[(uint8_t)sym[i]] = code[i];
+        lut[(uint8_t)(sym[i] + 32)] = code[i];
+    }
+}
+
+// thread = (row, 32-column chunk); lanes run along rows so that the plane stores coalesce
+__global__ __launch_bounds__(kBlock) void pack_kernel(const uint8_t *__restrict__ bytes, const int64_t *__restrict__ row_off,
+                                                      int n_rows, int n_pad, int n_chunks, uint32_t *__restrict__ planes) {
+    int r = blockIdx.x * kBlock + threadIdx.x;
+    int c = blockIdx.y;
+    if (r >= n_pad) return;
+    uint32_t mA = 0, mC = 0, mG = 0, mT = 0;
+    if (r < n_rows) {
+        int64_t o = row_off[r];
+        int64_t len = row_off[r + 1] - o;
+        int64_t col0 = (int64_t)c * 32;
+        const uint8_t *p = bytes + o + col0;
+        int n = (int)(len - col0 < 32 ? (len - col0 < 0 ? 0 : len - col0) : 32);
+        for (int j = 0; j < n; j++) {
+            uint32_t code = c_code_lut[p[j]];
+            mA |= (code & 1u) << j;
+            mC |= ((code >> 1) & 1u) << j;
+            mG |= ((code >> 2) & 1u) << j;
+            mT |= ((code >> 3) & 1u) << j;
+        }
+    }
+    size_t base = ((size_t)c * 4) * n_pad + r;
+    planes[base] = mA;
+    planes[base + n_pad] = mC;
+    planes[base + 2 * (size_t)n_pad] = mG;
+    planes[base + 3 * (size_t)n_pad] = mT;
+}
+
+// thread = row: prefix count of residues per chunk, leading-gap length and right-stripped length
+// (V20:625-627)
+__global__ __launch_bounds__(kBlock) void row_scan_kernel(const uint32_t *__restrict__ planes, const int64_t *__restrict__ row_off,
+                                                          int n_rows, int n_pad, int n_chunks, uint32_t *__restrict__ cum,
+                                                          int32_t *__restrict__ lead, int32_t *__restrict__ rstrip,
+                                                          int32_t *__restrict__ rlen) {
+    int r = blockIdx.x * kBlock + threadIdx.x;
+    if (r >= n_pad) return;
+    uint32_t run = 0;
+    int first = -1, last = 0;
+    for (int c = 0; c < n_chunks; c++) {
+        size_t base = ((size_t)c * 4) * n_pad + r;
+        uint32_t ng = planes[base] | planes[base + n_pad] | planes[base + 2 * (size_t)n_pad] | planes[base + 3 * (size_t)n_pad];
+        cum[(size_t)c * n_pad + r] = run;
+        run += __popc(ng);
+        if (ng) {
+            if (first < 0) first = c * 32 + (__ffs(ng) - 1);
+            last = c * 32 + 32 - __clz(ng);
+        }
+    }
+    cum[(size_t)n_chunks * n_pad + r] = run;
+    if (r < n_rows) {
+        int len = (int)(row_off[r + 1] - row_off[r]);
+        lead[r] = first < 0 ? len : first;
+        rstrip[r] = last;
+        rlen[r] = len;
+    }
+}
+
+// thread = (row, chunk): append this chunk's residues to the row's gap-free code string
+__global__ __launch_bounds__(kBlock) void ungap_kernel(const uint32_t *__restrict__ planes, const uint32_t *__restrict__ cum,
+                                                       int n_rows, int n_pad, int ustride, uint32_t *__restrict__ ung) {
+    int r = blockIdx.x * kBlock + threadIdx.x;
+    int c = blockIdx.y;
+    if (r >= n_rows) return;
+    size_t base = ((size_t)c * 4) * n_pad + r;
+    uint32_t mA = planes[base], mC = planes[base + n_pad], mG = planes[base + 2 * (size_t)n_pad], mT = planes[base + 3 * (size_t)n_pad];
+    uint32_t ng = mA | mC | mG | mT;
+    if (!ng) return;
+    uint32_t pos = cum[(size_t)c * n_pad + r];
+    uint32_t *dst = ung + (size_t)r * ustride;
+    uint32_t word = 0;
+    uint32_t widx = pos >> 3;
+    while (ng) {
+        int j = __ffs(ng) - 1;
+        ng &= ng - 1;
+        uint32_t code = ((mA >> j) & 1u) | (((mC >> j) & 1u) << 1) | (((mG >> j) & 1u) << 2) | (((mT >> j) & 1u) << 3);
+        if ((pos >> 3) != widx) {
+            atomicOr(dst + widx, word);
+            word = 0;
+            widx = pos >> 3;
+        }
+        word |= code << ((pos & 7) * 4);
+        pos++;
+    }
+    atomicOr(dst + widx, word);
+}
+
+// Column planes for the bit-sliced evaluation: cols[col][3][Npad/64] u64, bit r%64 of word r/64 =
+// sequence r; planes b0, b1 (2-bit base, 0 where gap) and g (gap / beyond the row's end).  IUPAC
+// symbols produce arbitrary b0/b1 here: windows that touch one are always routed to the
+// general path (patch list), never to the bit-sliced pass.
+__global__ __launch_bounds__(kBlock) void colplane_kernel(const uint32_t *__restrict__ planes, int n_pad, int n_chunks,
+                                                          unsigned long long *__restrict__ cols) {
+    const int r = blockIdx.x * kBlock + threadIdx.x;     // n_pad is a multiple of kBlock: every lane is live
+    const int c = blockIdx.y;
+    const size_t np = (size_t)n_pad, nw = np / 64;
+    const size_t base = ((size_t)c * 4) * np + r;
+    const uint32_t mA = planes[base], mC = planes[base + np], mG = planes[base + 2 * np], mT = planes[base + 3 * np];
+    const uint32_t b0 = mC | mT, b1 = mG | mT, ng = mA | mC | mG | mT;
+    const int lane = threadIdx.x & 63;
+    for (int j = 0; j < 32; j++) {
+        unsigned long long x0 = __ballot((b0 >> j) & 1u), x1 = __ballot((b1 >> j) & 1u), xg = __ballot(!((ng >> j) & 1u));
+        if (lane == 0) {
+            unsigned long long *dst = cols + ((size_t)(c * 32 + j) * 3) * nw + (size_t)(r >> 6);
+            dst[0] = x0; dst[nw] = x1; dst[2 * nw] = xg;
+        }
+    }
+}
+
+
+}  // namespace
+
+namespace mp {
+int pack_init() {
+    uint8_t lut[256];
+    host_code_lut(lut);
+    return hipMemcpyToSymbol(HIP_SYMBOL(c_code_lut), lut, 256) == hipSuccess ? MP_OK : MP_ERR_DEVICE;
+}
+}  // namespace mp
+
+extern "C" {
+
+int mp_load_msa(mp_ctx *c, const uint8_t *bytes, const int64_t *row_off, int32_t n_rows) {
+    if (!c) return MP_ERR_ARG;
+    if (!bytes || !row_off || n_rows <= 0) return fail(c, MP_ERR_ARG, "mp_load_msa: bad arguments");
+    HIPCK(c, hipSetDevice(c->dev));
+    free_msa(c);
+    int64_t max_len = 0;
+    for (int r = 0; r < n_rows; r++) {
+        int64_t l = row_off[r + 1] - row_off[r];
+        if (l < 0 || l > 0x3fffffff) return fail(c, MP_ERR_ARG, "row %d has bad length", r);
+        max_len = std::max(max_len, l);
+    }
+    c->n_rows = n_rows;
+    c->n_pad = (n_rows + kBlock - 1) / kBlock * kBlock;
+    c->max_len = (int)max_len;
+    c->n_chunks = (int)((max_len + 31) / 32) + 2;
+    c->ustride = (int)(max_len / 8) + 2;
+    size_t np = (size_t)c->n_pad;
+    int64_t total = row_off[n_rows] - row_off[0];
+    uint8_t *d_bytes = nullptr;
+    int64_t *d_off = nullptr;
+    int rc;
+    if ((rc = dev_alloc(c, &d_bytes, (size_t)total + 64))) return rc;
+    if ((rc = dev_alloc(c, &d_off, (size_t)n_rows + 1))) return rc;
+    if ((rc = dev_alloc(c, &c->planes, (size_t)c->n_chunks * 4 * np))) return rc;
+    if ((rc = dev_alloc(c, &c->cols, (size_t)c->n_chunks * 32 * 3 * (np / 64)))) return rc;
+    if ((rc = dev_alloc(c, &c->cum, ((size_t)c->n_chunks + 1) * np))) return rc;
+    if ((rc = dev_alloc(c, &c->ung, (size_t)n_rows * c->ustride))) return rc;
+    if ((rc = dev_alloc(c, &c->lead, np))) return rc;
+    if ((rc = dev_alloc(c, &c->rstrip, np))) return rc;
+    if ((rc = dev_alloc(c, &c->rlen, np))) return rc;
+    std::vector<int64_t> off0(n_rows + 1);
+    for (int r = 0; r <= n_rows; r++) off0[r] = row_off[r] - row_off[0];
+    HIPCK(c, hipMemcpyAsync(d_bytes, bytes + row_off[0], (size_t)total, hipMemcpyHostToDevice, c->stream));
+    HIPCK(c, hipMemcpyAsync(d_off, off0.data(), sizeof(int64_t) * (n_rows + 1), hipMemcpyHostToDevice, c->stream));
+    HIPCK(c, hipMemsetAsync(c->ung, 0, sizeof(uint32_t) * (size_t)n_rows * c->ustride, c->stream));
+    HIPCK(c, hipMemsetAsync(c->rlen, 0, sizeof(int32_t) * np, c->stream));
+    dim3 grid((unsigned)(c->n_pad / kBlock), (unsigned)c->n_chunks);
+    hipLaunchKernelGGL(pack_kernel, grid, dim3(kBlock), 0, c->stream, d_bytes, d_off, n_rows, c->n_pad, c->n_chunks, c->planes);
+    hipLaunchKernelGGL(row_scan_kernel, dim3(c->n_pad / kBlock), dim3(kBlock), 0, c->stream, c->planes, d_off, n_rows,
+                       c->n_pad, c->n_chunks, c->cum, c->lead, c->rstrip, c->rlen);
+    hipLaunchKernelGGL(ungap_kernel, grid, dim3(kBlock), 0, c->stream, c->planes, c->cum, n_rows, c->n_pad, c->ustride, c->ung);
+    hipLaunchKernelGGL(colplane_kernel, grid, dim3(kBlock), 0, c->stream, c->planes, c->n_pad, c->n_chunks, c->cols);
+    HIPCK(c, hipGetLastError());
+    HIPCK(c, hipStreamSynchronize(c->stream));
+    dev_free(c, &d_bytes, (size_t)total + 64);
+    dev_free(c, &d_off, (size_t)n_rows + 1);
+    return MP_OK;
+}
+
+int mp_row_attributes(mp_ctx *c, int32_t *lead, int32_t *rstrip, int32_t *rowlen) {
+    if (!c) return MP_ERR_ARG;
+    if (!c->planes) return fail(c, MP_ERR_ARG, "no alignment loaded");
+    HIPCK(c, hipSetDevice(c->dev));
+    size_t n = sizeof(int32_t) * (size_t)c->n_rows;
+    if (lead) HIPCK(c, hipMemcpyAsync(lead, c->lead, n, hipMemcpyDeviceToHost, c->stream));
+    if (rstrip) HIPCK(c, hipMemcpyAsync(rstrip, c->rstrip, n, hipMemcpyDeviceToHost, c->stream));
+    if (rowlen) HIPCK(c, hipMemcpyAsync(rowlen, c->rlen, n, hipMemcpyDeviceToHost, c->stream));
+    HIPCK(c, hipStreamSynchronize(c->stream));
+    return MP_OK;
+}
+
+
+}  // extern "C"

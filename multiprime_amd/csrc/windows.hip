@@ -1,0 +1,336 @@
+// windows.hip — part of libmprime_hip.so: hand-written HIP (gfx950 / MI355X, wave64) behind the C ABI of
+// include/mprime.h.  The k-mer of every (window, sequence) with edge-gap repair, exception and patch lists (mp_build_windows).
+#include "common.hpp"
+
+using namespace mp;
+
+namespace {
+
+// ----------------------------------------------------------------------------------------------
+// (2) window k-mers with edge-gap repair (V20:666-687)
+// ----------------------------------------------------------------------------------------------
+__device__ inline uint32_t ung_get(const uint32_t *__restrict__ ung_row, uint32_t t) {
+    return (ung_row[t >> 3] >> ((t & 7) * 4)) & 15u;
+}
+
+// The general path: rows whose window starts or ends in a gap, holds an IUPAC code, or runs past
+// the end of a ragged row.  Follows get_primers line by line.  Returns 0 = store words,
+// 1 = exception (IUPAC code present, `buf` returned), 2 = fewer than k residues (V20:683-687).
+__device__ int repair_window(uint32_t wA, uint32_t wC, uint32_t wG, uint32_t wT, int k, int p, int len,
+                             uint32_t c_left, uint32_t total, const uint32_t *__restrict__ ung_row,
+                             uint32_t &b0, uint32_t &b1, uint32_t &g, Nib &buf) {
+    uint32_t kmask = (k == 32) ? 0xFFFFFFFFu : ((1u << k) - 1u);
+    int m = len - p;
+    m = m < 0 ? 0 : (m > k ? k : m);
+    uint32_t ng = (wA | wC | wG | wT) & kmask;
+    buf.lo = buf.hi = 0;
+    for (int j = 0; j < m; j++) {
+        uint32_t code = ((wA >> j) & 1u) | (((wC >> j) & 1u) << 1) | (((wG >> j) & 1u) << 2) | (((wT >> j) & 1u) << 3);
+        buf.set(j, code);
+    }
+    int n = m;
+    bool all_gap = (m == k) && ng == 0;                       // V20:668
+    if (!all_gap && n > 0) {
+        if (buf.get(0) == 0) {                                // V20:671 sequence.startswith("-")
+            int run = 0;
+            while (run < n && buf.get(run) == 0) run++;
+            if (c_left >= (uint32_t)run)                      // V20:675
+                for (int t = 0; t < run; t++) buf.set(t, ung_get(ung_row, c_left - run + t));
+        }
+        if (buf.get(n - 1) == 0) {                            // V20:677 sequence.endswith("-")
+            int run = 0;
+            while (run < n && buf.get(n - 1 - run) == 0) run++;
+            uint32_t c_after = c_left + __popc(ng);          // residues in s[0 : p+k]
+            if (total - c_after >= (uint32_t)run)             // V20:681
+                for (int t = 0; t < run; t++) buf.set(n - run + t, ung_get(ung_row, c_after + t));
+        }
+    }
+    if (n < k) {                                              // V20:683
+        int need = k - n;
+        if (c_left < (uint32_t)need) return 2;
+        buf.shift_up(need);
+        for (int t = 0; t < need; t++) buf.set(t, ung_get(ung_row, c_left - need + t));
+        n = k;
+    }
+    b0 = b1 = g = 0;
+    bool iupac = false;
+    for (int j = 0; j < k; j++) {
+        uint32_t code = buf.get(j);
+        if (code == 0) g |= 1u << j;
+        else if (code & (code - 1)) iupac = true;
+        else {
+            uint32_t bi = __ffs(code) - 1;
+            b0 |= (bi & 1u) << j;
+            b1 |= (bi >> 1) << j;
+        }
+    }
+    return iupac ? 1 : 0;
+}
+
+// Rows whose k-mer is NOT the plain column slice (edge-gap repair, IUPAC, ragged end) are flagged per
+// (window, 64-row word) in `excl` and collected, per window, in a compact patch list of window words:
+// the bit-sliced evaluation skips them, the row-per-lane evaluation handles exactly them.
+// pass 0 writes the window words, the flags and the per-window patch counts; pass 1 (same
+// computation) fills the patch list once the host has turned the counts into offsets.
+struct PatchOut {
+    int pass;
+    unsigned long long *excl;     // [W][Npad/64]
+    int32_t *count;               // [W]
+    const int32_t *off;           // [W+1]   (pass 1)
+    int32_t *cursor;              // [W]     (pass 1)
+    uint32_t *words;              // [n][3]  (pass 1)
+};
+
+template <bool P64>
+__global__ __launch_bounds__(kBlock) void build_windows_kernel(
+    const uint32_t *__restrict__ planes, const uint32_t *__restrict__ cum, const uint32_t *__restrict__ ung,
+    const int32_t *__restrict__ rlen, int n_rows, int n_pad, int n_chunks, int ustride, int p0, int n_win, int tile,
+    int k, void *__restrict__ win, ExRec *__restrict__ ex, int ex_cap, int *__restrict__ ex_count,
+    int *__restrict__ err, PatchOut po) {
+    int r = blockIdx.x * kBlock + threadIdx.x;
+    if (r >= n_pad) return;
+    int w0 = blockIdx.y * tile;
+    int w1 = w0 + tile < n_win ? w0 + tile : n_win;
+    const uint32_t kmask = (1u << k) - 1u;
+    const size_t np = (size_t)n_pad;
+    if (r >= n_rows) {                       // padding rows never take part
+        if (po.pass == 0)
+            for (int w = w0; w < w1; w++) WinView<P64>::store(win, w, np, r, 0, 0, MP_WIN_SKIP | kmask, k, kmask);
+        return;
+    }
+    const int len = rlen[r];
+    const uint32_t total = cum[(size_t)n_chunks * np + r];
+    const uint32_t *ung_row = ung + (size_t)r * ustride;
+    int cur = -1;
+    uint32_t loA = 0, loC = 0, loG = 0, loT = 0, hiA = 0, hiC = 0, hiG = 0, hiT = 0;
+    for (int w = w0; w < w1; w++) {
+        int p = p0 + w;
+        int c = p >> 5, o = p & 31;
+        if (c != cur) {
+            size_t base = ((size_t)c * 4) * np + r;
+            if (c == cur + 1 && cur >= 0) { loA = hiA; loC = hiC; loG = hiG; loT = hiT; }
+            else { loA = planes[base]; loC = planes[base + np]; loG = planes[base + 2 * np]; loT = planes[base + 3 * np]; }
+            size_t nb = base + 4 * np;           // chunk c+1 exists: n_chunks is padded by two
+            hiA = planes[nb]; hiC = planes[nb + np]; hiG = planes[nb + 2 * np]; hiT = planes[nb + 3 * np];
+            cur = c;
+        }
+        uint32_t wA = __funnelshift_r(loA, hiA, o) & kmask;
+        uint32_t wC = __funnelshift_r(loC, hiC, o) & kmask;
+        uint32_t wG = __funnelshift_r(loG, hiG, o) & kmask;
+        uint32_t wT = __funnelshift_r(loT, hiT, o) & kmask;
+        uint32_t o1 = wA | wC, a1 = wA & wC, o2 = wG | wT, a2 = wG & wT;
+        uint32_t ng = o1 | o2;
+        uint32_t multi = a1 | a2 | (o1 & o2);
+        uint32_t gw = ~ng & kmask;
+        uint32_t b0, b1, g;
+        bool fast = (p + k <= len) && multi == 0 && (gw == kmask || ((gw & 1u) == 0 && (gw >> (k - 1)) == 0));
+        if (fast) {
+            b0 = wC | wT; b1 = wG | wT; g = gw;
+        } else {
+            uint32_t ng_lo = loA | loC | loG | loT;
+            uint32_t c_left = cum[(size_t)c * np + r] + __popc(ng_lo & ((1u << o) - 1u));
+            Nib buf;
+            int rc = repair_window(wA, wC, wG, wT, k, p, len, c_left, total, ung_row, b0, b1, g, buf);
+            if (rc == 1) {
+                if (po.pass == 0) {
+                    int idx = atomicAdd(ex_count, 1);
+                    if (idx < ex_cap) { ex[idx].win = w; ex[idx].row = r; ex[idx].lo = buf.lo; ex[idx].hi = buf.hi; }
+                }
+                b0 = 0; b1 = 0; g = MP_WIN_SKIP | kmask;
+            } else if (rc == 2) {
+                atomicMax(err, 1);
+                err[1] = w; err[2] = r;
+                b0 = 0; b1 = 0; g = MP_WIN_SKIP | kmask;
+            }
+        }
+        {
+            // flags and patch list; the lanes of a wave that are still here are all real rows
+            const unsigned long long live = __ballot(true);
+            const unsigned long long flg = __ballot(!fast);
+            const bool keep = !fast && !(g & MP_WIN_SKIP);
+            const unsigned long long kp = __ballot(keep);
+            const int lane = threadIdx.x & 63;
+            const int leader = __ffsll((long long)live) - 1;
+            if (po.pass == 0) {
+                if (lane == leader) {
+                    po.excl[(size_t)w * (np / 64) + (size_t)(r >> 6)] = flg;
+                    if (kp) atomicAdd(&po.count[w], (int)__popcll(kp));
+                }
+            } else if (kp) {
+                int base = 0;
+                if (lane == leader) base = atomicAdd(&po.cursor[w], (int)__popcll(kp));
+                base = __shfl(base, leader);
+                if (keep) {
+                    int slot = po.off[w] + base + (int)__popcll(kp & ((1ull << lane) - 1ull));
+                    po.words[3 * (size_t)slot] = b0; po.words[3 * (size_t)slot + 1] = b1; po.words[3 * (size_t)slot + 2] = g;
+                }
+            }
+        }
+        if (po.pass == 0) WinView<P64>::store(win, w, np, r, b0, b1, g, k, kmask);
+    }
+}
+
+
+}  // namespace
+
+extern "C" {
+
+int mp_build_windows(mp_ctx *c, int32_t p0, int32_t n_win, int32_t k, int32_t v, int32_t *n_exc) {
+    if (!c) return MP_ERR_ARG;
+    if (!c->planes) return fail(c, MP_ERR_ARG, "no alignment loaded");
+    if (k < 2 || k > MP_MAX_K || n_win <= 0 || p0 < 0 || v < 0 || v >= k)
+        return fail(c, MP_ERR_ARG, "bad window arguments (k=%d v=%d n_windows=%d)", k, v, n_win);
+    if (p0 + n_win > c->max_len) return fail(c, MP_ERR_ARG, "windows run past the longest row");
+    HIPCK(c, hipSetDevice(c->dev));
+    free_windows(c);
+    c->p0 = p0; c->n_win = n_win; c->k = k; c->v = v;
+    size_t np = (size_t)c->n_pad;
+    int rc;
+    // one packed u64 per (window, sequence) when 3k bits + the flag fit, else three u32 planes
+    c->p64 = 3 * k <= 63 && !getenv("MP_WIN_NO_PACK");
+    {
+        uint8_t *wp = nullptr;
+        size_t nb = (size_t)n_win * np * (c->p64 ? 8 : 12);
+        if ((rc = dev_alloc(c, &wp, nb))) return rc;
+        c->win = wp;
+        c->win_bytes = nb;
+    }
+    if ((rc = dev_alloc(c, &c->ex_count, 1))) return rc;
+    if ((rc = dev_alloc(c, &c->err_flag, 4))) return rc;
+    if ((rc = dev_alloc(c, &c->extra_off, (size_t)n_win + 1))) return rc;
+    HIPCK(c, hipMemsetAsync(c->extra_off, 0, sizeof(int32_t) * ((size_t)n_win + 1), c->stream));
+    const size_t nw = np / 64;
+    if ((rc = dev_alloc(c, &c->excl, (size_t)n_win * nw))) return rc;
+    if ((rc = dev_alloc(c, &c->patch_count, (size_t)n_win))) return rc;
+    if ((rc = dev_alloc(c, &c->patch_off, (size_t)n_win + 1))) return rc;
+    if ((rc = dev_alloc(c, &c->patch_cursor, (size_t)n_win))) return rc;
+    int cap = 1 << 16;
+    const int tile = 64;
+    const dim3 grid((unsigned)(c->n_pad / kBlock), (unsigned)((n_win + tile - 1) / tile));
+    auto launch = [&](const PatchOut &po, int ex_cap) {
+        if (c->p64)
+            hipLaunchKernelGGL(build_windows_kernel<true>, grid, dim3(kBlock), 0, c->stream, c->planes, c->cum, c->ung, c->rlen,
+                               c->n_rows, c->n_pad, c->n_chunks, c->ustride, p0, n_win, tile, k, c->win, c->ex, ex_cap,
+                               c->ex_count, c->err_flag, po);
+        else
+            hipLaunchKernelGGL(build_windows_kernel<false>, grid, dim3(kBlock), 0, c->stream, c->planes, c->cum, c->ung, c->rlen,
+                               c->n_rows, c->n_pad, c->n_chunks, c->ustride, p0, n_win, tile, k, c->win, c->ex, ex_cap,
+                               c->ex_count, c->err_flag, po);
+    };
+    for (int attempt = 0; attempt < 2; attempt++) {
+        if ((rc = dev_alloc(c, &c->ex, (size_t)cap))) return rc;
+        c->ex_cap = cap;
+        HIPCK(c, hipMemsetAsync(c->ex_count, 0, sizeof(int), c->stream));
+        HIPCK(c, hipMemsetAsync(c->err_flag, 0, 4 * sizeof(int), c->stream));
+        HIPCK(c, hipMemsetAsync(c->excl, 0, sizeof(unsigned long long) * (size_t)n_win * nw, c->stream));
+        HIPCK(c, hipMemsetAsync(c->patch_count, 0, sizeof(int32_t) * (size_t)n_win, c->stream));
+        launch(PatchOut{0, c->excl, c->patch_count, nullptr, nullptr, nullptr}, cap);
+        HIPCK(c, hipGetLastError());
+        int cnt = 0, errv[4] = {0, 0, 0, 0};
+        HIPCK(c, hipMemcpyAsync(&cnt, c->ex_count, sizeof(int), hipMemcpyDeviceToHost, c->stream));
+        HIPCK(c, hipMemcpyAsync(errv, c->err_flag, 4 * sizeof(int), hipMemcpyDeviceToHost, c->stream));
+        HIPCK(c, hipStreamSynchronize(c->stream));
+        if (errv[0])
+            return fail(c, MP_ERR_SHORT_WINDOW, "row %d has fewer than %d residues at window %d", errv[2], k, p0 + errv[1]);
+        if (cnt <= cap) {
+            c->ex_host.resize((size_t)cnt);
+            if (cnt) HIPCK(c, hipMemcpy(c->ex_host.data(), c->ex, sizeof(ExRec) * (size_t)cnt, hipMemcpyDeviceToHost));
+            std::sort(c->ex_host.begin(), c->ex_host.end(),
+                      [](const ExRec &a, const ExRec &b) { return a.win != b.win ? a.win < b.win : a.row < b.row; });
+            if (n_exc) *n_exc = cnt;
+            // patch list: counts -> offsets on the host, then the fill pass
+            std::vector<int32_t> pc((size_t)n_win), po((size_t)n_win + 1, 0);
+            HIPCK(c, hipMemcpy(pc.data(), c->patch_count, sizeof(int32_t) * (size_t)n_win, hipMemcpyDeviceToHost));
+            long long tot = 0;
+            c->max_patch = 0;
+            for (int w = 0; w < n_win; w++) {
+                po[(size_t)w] = (int32_t)tot;
+                tot += pc[(size_t)w];
+                c->max_patch = std::max(c->max_patch, (int)pc[(size_t)w]);
+            }
+            if (tot > 0x7fffffffLL / 4) return fail(c, MP_ERR_NOMEM, "patch list too large (%lld rows)", tot);
+            po[(size_t)n_win] = (int32_t)tot;
+            c->n_patch = (int)tot;
+            HIPCK(c, hipMemcpy(c->patch_off, po.data(), sizeof(int32_t) * po.size(), hipMemcpyHostToDevice));
+            if (tot) {
+                if ((rc = dev_alloc(c, &c->patch_words, (size_t)3 * (size_t)tot))) return rc;
+                HIPCK(c, hipMemsetAsync(c->patch_cursor, 0, sizeof(int32_t) * (size_t)n_win, c->stream));
+                launch(PatchOut{1, c->excl, c->patch_count, c->patch_off, c->patch_cursor, c->patch_words}, 0);
+                HIPCK(c, hipGetLastError());
+                HIPCK(c, hipStreamSynchronize(c->stream));
+            }
+            return MP_OK;
+        }
+        dev_free(c, &c->ex, (size_t)cap);
+        cap = cnt;
+    }
+    return fail(c, MP_ERR_DEVICE, "exception list did not converge");
+}
+
+int mp_get_exceptions(mp_ctx *c, int32_t cap, int32_t *ew, int32_t *er, uint8_t *codes) {
+    if (!c) return MP_ERR_ARG;
+    if (!c->win) return fail(c, MP_ERR_ARG, "no windows built");
+    int n = (int)c->ex_host.size();
+    if (cap < n) return fail(c, MP_ERR_CAPACITY, "exception buffer too small: need %d", n);
+    for (int i = 0; i < n; i++) {
+        const ExRec &e = c->ex_host[(size_t)i];
+        ew[i] = e.win; er[i] = e.row;
+        for (int j = 0; j < c->k; j++)
+            codes[(size_t)i * c->k + j] = (uint8_t)((j < 16 ? e.lo >> (4 * j) : e.hi >> (4 * (j - 16))) & 15u);
+    }
+    return MP_OK;
+}
+
+int mp_set_extra_rows(mp_ctx *c, int32_t n, const int32_t *win, const uint32_t *words) {
+    if (!c) return MP_ERR_ARG;
+    if (!c->win) return fail(c, MP_ERR_ARG, "no windows built");
+    HIPCK(c, hipSetDevice(c->dev));
+    dev_free(c, &c->extra_words, (size_t)3 * c->n_extra);
+    c->n_extra = 0;
+    std::vector<int32_t> off((size_t)c->n_win + 1, 0);
+    for (int i = 0; i < n; i++) {
+        if (win[i] < 0 || win[i] >= c->n_win || (i && win[i] < win[i - 1]))
+            return fail(c, MP_ERR_ARG, "extra rows must be sorted by window and in range");
+        off[(size_t)win[i] + 1]++;
+    }
+    for (int w = 0; w < c->n_win; w++) off[(size_t)w + 1] += off[(size_t)w];
+    HIPCK(c, hipMemcpy(c->extra_off, off.data(), sizeof(int32_t) * off.size(), hipMemcpyHostToDevice));
+    if (n > 0) {
+        int rc;
+        if ((rc = dev_alloc(c, &c->extra_words, (size_t)3 * n))) return rc;
+        c->n_extra = n;
+        HIPCK(c, hipMemcpy(c->extra_words, words, sizeof(uint32_t) * 3 * (size_t)n, hipMemcpyHostToDevice));
+    }
+    return MP_OK;
+}
+
+int mp_get_window_words(mp_ctx *c, int32_t w, int32_t row0, int32_t n, uint32_t *out) {
+    if (!c) return MP_ERR_ARG;
+    if (!c->win) return fail(c, MP_ERR_ARG, "no windows built");
+    if (w < 0 || w >= c->n_win || row0 < 0 || n < 0 || row0 + n > c->n_rows) return fail(c, MP_ERR_ARG, "bad range");
+    HIPCK(c, hipSetDevice(c->dev));
+    size_t np = (size_t)c->n_pad;
+    if (c->p64) {
+        std::vector<uint64_t> tmp((size_t)n + 1);
+        HIPCK(c, hipMemcpyAsync(tmp.data(), (const uint64_t *)c->win + (size_t)w * np + row0, sizeof(uint64_t) * (size_t)n,
+                                hipMemcpyDeviceToHost, c->stream));
+        HIPCK(c, hipStreamSynchronize(c->stream));
+        const uint32_t kmask = (1u << c->k) - 1u;
+        for (int i = 0; i < n; i++) {
+            uint64_t x = tmp[(size_t)i];
+            out[i] = (uint32_t)x & kmask;
+            out[(size_t)n + i] = (uint32_t)(x >> c->k) & kmask;
+            out[2 * (size_t)n + i] = ((uint32_t)(x >> (2 * c->k)) & kmask) | ((uint32_t)(x >> 32) & MP_WIN_SKIP);
+        }
+        return MP_OK;
+    }
+    const uint32_t *W = (const uint32_t *)c->win;
+    for (int p = 0; p < 3; p++)
+        HIPCK(c, hipMemcpyAsync(out + (size_t)p * n, W + ((size_t)w * 3 + p) * np + row0, sizeof(uint32_t) * (size_t)n,
+                                hipMemcpyDeviceToHost, c->stream));
+    HIPCK(c, hipStreamSynchronize(c->stream));
+    return MP_OK;
+}
+
+
+}  // extern "C"
