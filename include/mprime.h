@@ -121,6 +121,17 @@ int mp_get_labels(mp_ctx *ctx, int32_t w, int32_t *labels);
 int mp_eval_candidates(mp_ctx *ctx, int32_t n_cand, const int32_t *cand_window, const uint8_t *cand_codes,
                        uint32_t strictF, uint32_t strictR, int64_t *out);
 
+/* (4c) per-sequence coverage masks ----------------------------------------------------------- */
+/* The bitset form of the two JSON side files (V20:1172-1177) for one candidate per entry: for
+ * candidate c (window cand_window[c], ascending) bit r of not_f[c] (resp. not_r[c]) is set iff row r
+ * would appear in gap_seq_id (more than v gaps, V20:689-698) or in the F (resp. R) dict of
+ * non_coverage_seq_id (in `cover`, not perfectly matched, and not F- (resp. R-) admissible,
+ * V20:1107-1127).  Rows whose window went to the exception list (IUPAC) get 0: the host owns them.
+ * Each mask is (n_rows + 63) / 64 words.  This is what the pairing stage needs and it
+ * scales as bits, not id strings. */
+int mp_eval_masks(mp_ctx *ctx, int32_t n_cand, const int32_t *cand_window, const uint8_t *cand_codes,
+                  uint32_t strictF, uint32_t strictR, uint64_t *not_f, uint64_t *not_r);
+
 /* Device-resident form used by bench.py and the multi-GPU path: upload stages the candidate
  * tables once; launch enqueues the evaluation on the context's stream and leaves the
  * [n_cand][3] int64 counters in `device_out` (device memory owned by the caller, e.g. a torch

@@ -37,6 +37,7 @@ SYMBOLS = [
     ("mp_get_unique", C.c_int, [_p, _p, _p, _p, _p]),
     ("mp_get_labels", C.c_int, [_p, C.c_int32, _p]),
     ("mp_eval_candidates", C.c_int, [_p, C.c_int32, _p, _p, C.c_uint32, C.c_uint32, _p]),
+    ("mp_eval_masks", C.c_int, [_p, C.c_int32, _p, _p, C.c_uint32, C.c_uint32, _p, _p]),
     ("mp_eval_upload", C.c_int, [_p, C.c_int32, _p, _p, C.c_uint32, C.c_uint32]),
     ("mp_eval_launch", C.c_int, [_p, _p]),
     ("mp_eval_timing", C.c_int, [_p, C.c_int32, C.POINTER(C.c_double), C.POINTER(C.c_int32)]),
@@ -195,6 +196,17 @@ class Context:
         self._ck(self.d.mp_eval_candidates(self.h, len(cand_window), _ptr(cand_window), _ptr(cand_codes),
                                            strictF, strictR, _ptr(out)))
         return out
+
+    def eval_masks(self, cand_window, cand_codes, strictF: int, strictR: int):
+        """(not_f, not_r): uint64 [n_cand][(n_rows+63)//64] — sequences a forward / reverse primer does not reach."""
+        cand_window = np.ascontiguousarray(cand_window, dtype=np.int32)
+        cand_codes = np.ascontiguousarray(cand_codes, dtype=np.uint8).reshape(len(cand_window), self.k)
+        nw = (self.n_rows + 63) // 64
+        nf = np.zeros((max(len(cand_window), 1), nw), np.uint64)
+        nr = np.zeros((max(len(cand_window), 1), nw), np.uint64)
+        self._ck(self.d.mp_eval_masks(self.h, len(cand_window), _ptr(cand_window), _ptr(cand_codes), strictF, strictR,
+                                      _ptr(nf), _ptr(nr)))
+        return nf[: len(cand_window)], nr[: len(cand_window)]
 
     def eval_upload(self, cand_window, cand_codes, strictF: int, strictR: int):
         cand_window = np.ascontiguousarray(cand_window, dtype=np.int32)

@@ -35,6 +35,9 @@ def parse_args(argv=None):
     p.add_argument("-o", "--out", type=str, required=True, metavar="<file>", help="output file")
     p.add_argument("--device", type=int, default=0, help="GPU ordinal (default 0)")
     p.add_argument("--no-json", action="store_true", help="do not write the two *_seq_id_json side files")
+    p.add_argument("--bitsets", action="store_true",
+                   help="also write <out>.coverage_bitsets.npz: per window, one bit per sequence the primer does not "
+                        "reach (the bitset form of the JSON files; scripts/get_multiPrime.py reads it when the JSON is absent)")
     p.add_argument("--stats", action="store_true", help="print per-phase timings to stderr")
     return p.parse_args(argv)
 
@@ -47,7 +50,7 @@ def main(argv=None):
                         number_of_dege_bases=args.dnum, score_of_dege_bases=args.degeneracy,
                         raw_entropy_threshold=args.entropy, product_len=args.size, position=args.coordinate,
                         variation=args.variation, distance=args.away, GC=args.gc, nproc=args.proc, outfile=args.out,
-                        device=args.device, write_json=not args.no_json)
+                        device=args.device, write_json=not args.no_json, write_bitsets=args.bitsets)
     app.run()
     e2 = time.time()
     if args.stats:

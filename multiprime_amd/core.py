@@ -76,7 +76,7 @@ class NN_degenerate(object):
     def __init__(self, seq_file, primer_length=18, coverage=0.8, number_of_dege_bases=18, score_of_dege_bases=1000,
                  product_len=250, position="2,-1", variation=2, raw_entropy_threshold=3.6, distance=4, GC="0.4,0.6",
                  nproc=10, outfile="", *, library: Library | None = None, device: int = 0, comm=None,
-                 write_json: bool = True):
+                 write_json: bool = True, write_bitsets: bool = False):
         self.primer_length = int(primer_length)
         self.coverage = coverage
         self.number_of_dege_bases = number_of_dege_bases
@@ -90,6 +90,7 @@ class NN_degenerate(object):
         self.raw_entropy_threshold = raw_entropy_threshold
         self.outfile = outfile
         self.write_json = write_json
+        self.write_bitsets = write_bitsets      # {out}.coverage_bitsets.npz: the bitset form of the two JSON files
         self.comm = comm                        # multiprime_amd.dist.RowShards or None
         k = self.primer_length
         if not 2 <= k <= 28:
@@ -429,6 +430,7 @@ class NN_degenerate(object):
         tables = self._device_tables()
         rows_out, non_cov_out, gap_out = [], {}, {}
         n_cand = 0
+        exc = {}
         if tables is not None:
             off, strs, count, first, gaps, exc = tables
             t0 = time.time()
@@ -480,6 +482,10 @@ class NN_degenerate(object):
                 if self.write_json:
                     non_cov_out[win.pos], gap_out[win.pos] = self._side_files(win, primer, strs)
             self.stats["finish_s"] = time.time() - t0
+            if self.write_bitsets:
+                t0 = time.time()
+                self._write_bitsets(rows_out, exc)
+                self.stats["bitsets_s"] = time.time() - t0
         if self.comm is None or self.comm.rank == 0:
             self._write(rows_out, non_cov_out, gap_out)
         self.stats["run_s"] = time.time() - t_run
@@ -513,6 +519,58 @@ class NN_degenerate(object):
                 gap_keys.setdefault(e)
         gids = self._ids_by_kmer(win, strs, rows_by_entry, set(gap_keys), True)
         return non_cov, {g: gids[g] for g in gap_keys}
+
+    def _write_bitsets(self, rows_out, exc):
+        """Per output window, which sequences a forward / reverse primer there does NOT reach — exactly
+        the union the pairing stage takes of gap_seq_id and non_coverage_seq_id (get_multiPrime_V8.py:
+        560-567) — as bits, one per sequence, from one mp_eval_masks launch.  O(W x N / 8) bytes."""
+        k, v = self.primer_length, self.variation
+        p0 = int(self.start_position)
+        n_out = len(rows_out)
+        wins = np.asarray([int(r[0]) - p0 for r in rows_out], np.int32)
+        if n_out:
+            codes = iupac.MASK_LUT[np.frombuffer("".join(r[3] for r in rows_out).encode(), np.uint8)].reshape(n_out, k)
+            nf, nr = self.ctx.eval_masks(wins, codes, self._sF, self._sR)
+        else:
+            nf = nr = np.zeros((0, 1), np.uint64)
+        n_local = self.ctx.n_rows
+        bits = [np.unpackbits(m.view(np.uint8), axis=1, bitorder="little")[:, :n_local].astype(bool) for m in (nf, nr)]
+        if self.comm is not None:
+            bits = [np.concatenate(self.comm._gather_objects(b), axis=1) for b in bits]
+        # rows whose window held an IUPAC code: every expansion must be reached (V20:701-707 puts the id
+        # under each expansion's k-mer), gap-type ones are in gap_seq_id
+        for i, row in enumerate(rows_out):
+            lst = exc.get(int(wins[i]))
+            if not lst:
+                continue
+            pc = iupac.codes_of(row[3])
+            for r_glob, raw in lst:
+                if raw.count("-") > v:
+                    bits[0][i, r_glob] = bits[1][i, r_glob] = True
+                    continue
+                bad_f = bad_r = False
+                for e in iupac.expand(raw):
+                    D, nd = 0, 0
+                    for j, ch in enumerate(e):
+                        if ch == "-" or not (pc[j] >> _B2I[ch]) & 1:
+                            D |= 1 << j
+                            nd += 1
+                    if nd == 0:
+                        continue
+                    bad_f |= nd > v or bool(D & self._sF)
+                    bad_r |= nd > v or bool(D & self._sR)
+                bits[0][i, r_glob], bits[1][i, r_glob] = bad_f, bad_r
+        if self.comm is not None and self.comm.rank != 0:
+            return
+        n_total = bits[0].shape[1] if n_out else self.total_sequence_number
+        nw = (n_total + 63) // 64
+        packed = []
+        for b in bits:
+            pad = np.zeros((n_out, nw * 64), bool)
+            pad[:, :b.shape[1]] = b
+            packed.append(np.packbits(pad, axis=1, bitorder="little").view(np.uint64).reshape(n_out, nw))
+        np.savez_compressed(self.outfile + ".coverage_bitsets.npz", positions=np.asarray([int(r[0]) for r in rows_out], np.int64),
+                            not_f=packed[0], not_r=packed[1], n_seq=np.int64(n_total), ids=np.asarray(self.seq_ids))
 
     def _write(self, rows_out, non_cov_out, gap_out):
         with open(self.outfile, "w") as fo:                                        # V20:1148-1170

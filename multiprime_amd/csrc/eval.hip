@@ -428,6 +428,39 @@ __global__ __launch_bounds__(kBlock) void eval_list_kernel(const EvalListArgs L)
     }
 }
 
+
+// Per-sequence coverage masks (mp_eval_masks): thread = sequence, the wave's 64 "not covered" bits
+// go out as one 64-bit word per candidate straight from the ballot (blocks are 64-row aligned), so
+// there are no atomics; works on the window words, i.e. after edge-gap repair, for any v.
+template <int CC, bool P64>
+__global__ __launch_bounds__(kBlock) void mask_rows_kernel(const EvalArgs A, int n_rows, unsigned long long *__restrict__ not_f,
+                                                           unsigned long long *__restrict__ not_r) {
+    const EvalItem it = A.items[blockIdx.x];
+    const int r = blockIdx.y * kBlock + threadIdx.x;             // n_pad is a multiple of kBlock
+    const size_t nw = (size_t)A.n_pad / 64;
+    const WinView<P64> V(A.win, it.win, (size_t)A.n_pad, A.k, A.kmask);
+    uint32_t b0, b1, g;
+    V.load(r, b0, b1, g);
+    const bool skip = (g & MP_WIN_SKIP) || r >= n_rows;
+    const uint32_t gk = g & A.kmask;
+    const bool gap_row = (int)__popc(gk) > A.v;
+#pragma unroll
+    for (int c = 0; c < CC; c++) {
+        const uint4 q = A.cand_n[it.cand0 + c];
+        const uint32_t mm = bfi(b1, bfi(b0, q.w, q.z), bfi(b0, q.y, q.x)) | gk;
+        const int d = __popc(mm);
+        const bool near = d <= A.v;
+        const bool bad_f = !skip && (gap_row || !(near && (d == 0 || !(mm & A.sF))));
+        const bool bad_r = !skip && (gap_row || !(near && (d == 0 || !(mm & A.sR))));
+        const unsigned long long wf = __ballot(bad_f), wr = __ballot(bad_r);
+        const int oc = A.cand_out[it.cand0 + c];
+        if ((threadIdx.x & 63) == 0 && oc >= 0) {
+            not_f[(size_t)oc * nw + (size_t)(r >> 6)] = wf;
+            not_r[(size_t)oc * nw + (size_t)(r >> 6)] = wr;
+        }
+    }
+}
+
 typedef void (*EvalBitsFn)(const EvalBitsArgs);
 typedef void (*EvalListFn)(const EvalListArgs);
 
@@ -611,5 +644,31 @@ int mp_eval_candidates(mp_ctx *c, int32_t n_cand, const int32_t *cw, const uint8
     return MP_OK;
 }
 
+
+int mp_eval_masks(mp_ctx *c, int32_t n_cand, const int32_t *cw, const uint8_t *codes, uint32_t sF, uint32_t sR,
+                  uint64_t *not_f, uint64_t *not_r) {
+    if (!c) return MP_ERR_ARG;
+    int rc = mp_eval_upload(c, n_cand, cw, codes, sF, sR);
+    if (rc) return rc;
+    if (n_cand == 0) return MP_OK;
+    if (!not_f || !not_r) return fail(c, MP_ERR_ARG, "null output");
+    const size_t nw = (size_t)c->n_pad / 64, nwo = ((size_t)c->n_rows + 63) / 64;
+    unsigned long long *d_f = nullptr, *d_r = nullptr;
+    if ((rc = dev_alloc(c, &d_f, (size_t)n_cand * nw))) return rc;
+    if ((rc = dev_alloc(c, &d_r, (size_t)n_cand * nw))) return rc;
+    EvalArgs ea{c->win, c->n_pad, c->k, c->items, c->cand_n, c->cand_out, nullptr, nullptr, c->sF, c->sR, c->v,
+                (1u << c->k) - 1u, 0, nullptr};
+    const dim3 grid((unsigned)c->n_items, (unsigned)(c->n_pad / kBlock));
+    if (c->p64) hipLaunchKernelGGL((mask_rows_kernel<kEvalCC, true>), grid, dim3(kBlock), 0, c->stream, ea, c->n_rows, d_f, d_r);
+    else hipLaunchKernelGGL((mask_rows_kernel<kEvalCC, false>), grid, dim3(kBlock), 0, c->stream, ea, c->n_rows, d_f, d_r);
+    HIPCK(c, hipGetLastError());
+    // rows are padded to a multiple of 256 on the device: copy the (n_rows+63)/64 meaningful words of each mask
+    HIPCK(c, hipMemcpy2DAsync(not_f, nwo * 8, d_f, nw * 8, nwo * 8, (size_t)n_cand, hipMemcpyDeviceToHost, c->stream));
+    HIPCK(c, hipMemcpy2DAsync(not_r, nwo * 8, d_r, nw * 8, nwo * 8, (size_t)n_cand, hipMemcpyDeviceToHost, c->stream));
+    HIPCK(c, hipStreamSynchronize(c->stream));
+    dev_free(c, &d_f, (size_t)n_cand * nw);
+    dev_free(c, &d_r, (size_t)n_cand * nw);
+    return MP_OK;
+}
 
 }  // extern "C"

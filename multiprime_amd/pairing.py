@@ -100,10 +100,20 @@ class Primers_filter(object):
                     continue
                 i = line.strip().split("\t")
                 primer_dict[int(i[0])] = [i[3], round(int(i[6]) / self.number, 2), int(i[7]), int(i[8]), round(float(i[9]), 2)]
-        with open(self.primer_file + ".gap_seq_id_json") as g:
-            gap_dict = json.load(g)
-        with open(self.primer_file + ".non_coverage_seq_id_json") as n:
-            non_cover_dict = json.load(n)
+        # the core step's coverage side data: the two JSON files of the reference format, or — when they were not
+        # written (deep alignments) — the bitset file of `multiPrime-core.py --bitsets`
+        self.bitset_file = None
+        gap_json, non_json = self.primer_file + ".gap_seq_id_json", self.primer_file + ".non_coverage_seq_id_json"
+        if os.path.exists(gap_json) and os.path.exists(non_json):
+            with open(gap_json) as g:
+                gap_dict = json.load(g)
+            with open(non_json) as n:
+                non_cover_dict = json.load(n)
+        elif os.path.exists(self.primer_file + ".coverage_bitsets.npz"):
+            self.bitset_file = self.primer_file + ".coverage_bitsets.npz"
+            gap_dict, non_cover_dict = None, None
+        else:
+            raise FileNotFoundError(gap_json)           # what the reference raises
         return primer_dict, gap_dict, non_cover_dict
 
     # ---- per-window string filters ---------------------------------------------------------------
@@ -171,6 +181,11 @@ class Primers_filter(object):
     def _bitsets(self, cand):
         """Per candidate window: the sequences a forward / reverse primer there does NOT reach —
         gap rows U F (resp. R) non-covered ids (GM:560-567) — as bitsets over the ids seen."""
+        if self.bitset_file is not None:
+            z = np.load(self.bitset_file)
+            where = {int(p): i for i, p in enumerate(z["positions"].tolist())}
+            sel = np.asarray([where[int(p)] for p in cand], np.int64)
+            return [np.ascontiguousarray(z["not_f"][sel]), np.ascontiguousarray(z["not_r"][sel])]
         index = {}
         rows_f, rows_r = [], []
         for pos in cand:

@@ -608,3 +608,35 @@ int mp_pair_coverage(mp_ctx *c, int32_t n_sets, int32_t n_words, const uint64_t 
     }
     return MP_OK;
 }
+
+/* bitset form of gap_seq_id / non_coverage_seq_id for one candidate per entry (V20:689-698, 1107-1127) */
+int mp_eval_masks(mp_ctx *c, int32_t n_cand, const int32_t *cw, const uint8_t *codes, uint32_t sF, uint32_t sR,
+                  uint64_t *not_f, uint64_t *not_r) {
+    if (!c || !c->words) return c ? fail(c, MP_ERR_ARG, "no windows built") : MP_ERR_ARG;
+    if (n_cand < 0 || (n_cand && (!cw || !codes || !not_f || !not_r))) return fail(c, MP_ERR_ARG, "bad arguments");
+    int32_t N = c->n_rows, k = c->k;
+    size_t nw = ((size_t)N + 63) / 64;
+    for (int32_t i = 0; i < n_cand; i++) {
+        int32_t w = cw[i];
+        if (w < 0 || w >= c->n_win || (i && w < cw[i - 1])) return fail(c, MP_ERR_ARG, "candidate windows must be ascending and in range");
+        uint64_t *F = not_f + (size_t)i * nw, *R = not_r + (size_t)i * nw;
+        memset(F, 0, nw * 8); memset(R, 0, nw * 8);
+        for (int32_t r = 0; r < N; r++) {
+            const char *kmer = c->kmers + ((size_t)w * N + r) * k;
+            if (!kmer[0]) continue;                                   /* exception slot: the host owns it */
+            int64_t o[3] = {0, 0, 0};
+            int gaps = 0;
+            for (int32_t j = 0; j < k; j++) gaps += kmer[j] == '-';
+            int bf, br;
+            if (gaps > c->v) bf = br = 1;                             /* gap row -> gap_seq_id */
+            else {
+                eval_one(codes + (size_t)i * k, k, c->v, sF, sR, kmer, o);
+                bf = !(o[0] || o[1]);                                  /* not perfect and not F-admissible -> F_non_cover */
+                br = !(o[0] || o[2]);
+            }
+            if (bf) F[r >> 6] |= 1ull << (r & 63);
+            if (br) R[r >> 6] |= 1ull << (r & 63);
+        }
+    }
+    return MP_OK;
+}

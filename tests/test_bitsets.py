@@ -1,0 +1,74 @@
+"""mp_eval_masks / `--bitsets`: the per-window coverage bitsets must say exactly what the reference's two
+JSON side files say (which sequences a forward / reverse primer at that window does not reach), and
+the pairing stage fed with the bitset file instead of the JSON must give the reference's output."""
+import contextlib
+import gzip
+import io
+import json
+import os
+
+import numpy as np
+import pytest
+
+from conftest import GOLDEN, golden_input, load_gz_json
+from multiprime_amd.core import NN_degenerate
+from multiprime_amd.pairing import Primers_filter
+
+NAMES = ["syn_iupac", "syn_edge", "syn_v2", "syn_ragged", "ivc_v1", "msa1000_k18_d64"]
+
+
+def run_core(name, lib, tmp_path, write_json):
+    meta = load_gz_json(name + ".trace.json.gz")["meta"]
+    fl = meta["flags"]
+    inp = tmp_path / "in.fa"
+    inp.write_bytes(golden_input(meta["input"]))
+    out = tmp_path / (name + ".top.primer.out")
+    app = NN_degenerate(seq_file=str(inp), primer_length=fl["l"], coverage=fl["f"], number_of_dege_bases=fl["n"],
+                        score_of_dege_bases=fl["d"], raw_entropy_threshold=fl["e"], product_len=fl["s"], position=fl["c"],
+                        variation=fl["v"], distance=fl["a"], GC=fl["g"], nproc=1, outfile=str(out), library=lib,
+                        write_json=write_json, write_bitsets=True)
+    app.run()
+    return app, out, meta
+
+
+def check_bitsets(name, lib, tmp_path):
+    app, out, meta = run_core(name, lib, tmp_path, write_json=False)
+    z = np.load(str(out) + ".coverage_bitsets.npz")
+    ids = z["ids"].tolist()
+    assert int(z["n_seq"]) == meta["n_seq"] == len(ids)
+    noncov, gap = load_gz_json(name + ".noncov.json.gz"), load_gz_json(name + ".gap.json.gz")
+    assert [str(p) for p in z["positions"].tolist()] == sorted(noncov, key=int)
+    for i, pos in enumerate(z["positions"].tolist()):
+        g = {x for lst in gap[str(pos)].values() for x in lst}
+        for side, arr in ((0, z["not_f"]), (1, z["not_r"])):
+            want = g | {x for lst in noncov[str(pos)][side].values() for x in lst}
+            bits = np.unpackbits(arr[i].view(np.uint8), bitorder="little")[: len(ids)]
+            got = {ids[r] for r in np.nonzero(bits)[0]}
+            assert got == want, (pos, side)
+
+
+@pytest.mark.parametrize("name", NAMES)
+def test_bitsets_equal_json_side_files(name, oracle_lib, tmp_path):
+    check_bitsets(name, oracle_lib, tmp_path)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", NAMES + ["cluster0_v1"])
+def test_bitsets_hip_equal_json_side_files(name, hip_lib, tmp_path):
+    check_bitsets(name, hip_lib, tmp_path)
+
+
+def test_pairing_from_bitsets_matches_reference(oracle_lib, tmp_path):
+    gold = json.loads(gzip.open(os.path.join(GOLDEN, "pairing.json.gz")).read())
+    app, out, meta = run_core("ivc_v1", oracle_lib, tmp_path, write_json=False)
+    assert not os.path.exists(str(out) + ".gap_seq_id_json")
+    ref = tmp_path / "ref.tfa"
+    ref.write_text("".join(f">s{i}\nACGT\n" for i in range(meta["n_seq"])))
+    res = tmp_path / "ivc_v1.candidate.primers.txt"
+    with contextlib.redirect_stdout(io.StringIO()):
+        Primers_filter(ref_file=str(ref), primer_file=str(out), outfile=str(res), nproc=1, library=oracle_lib, fraction=0.7,
+                       size="150,1200", position=4, distance=4, diff_Tm=4, rep_seq_number=0,
+                       adaptor="TCTTTCCCTACACGACGCTCTTCCGATCT,TGGAGTTCAGACGTGTGCTCTTCCGATCT").run()
+    want = gold["results"]["ivc_v1"]["yaml"]
+    assert res.read_text().replace(str(res), "<OUT>") == want["txt"]
+    assert open(str(res).strip(".txt") + ".xls").read() == want["xls"]

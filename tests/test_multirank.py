@@ -27,7 +27,7 @@ def _worker(rank, world, port, name, inp, out, oracle_so):
         app = NN_degenerate(seq_file=inp, primer_length=fl["l"], coverage=fl["f"], number_of_dege_bases=fl["n"],
                             score_of_dege_bases=fl["d"], raw_entropy_threshold=fl["e"], product_len=fl["s"],
                             position=fl["c"], variation=fl["v"], distance=fl["a"], GC=fl["g"], nproc=1,
-                            outfile=out, library=Library(oracle_so), comm=RowShards())
+                            outfile=out, library=Library(oracle_so), comm=RowShards(), write_bitsets=True)
         app.run()
     finally:
         dist.destroy_process_group()
@@ -43,3 +43,14 @@ def test_sharded_run_matches_reference(name, world, oracle_lib, tmp_path):
     port = 29500 + (os.getpid() % 2000)
     mp.spawn(_worker, args=(world, port, name, str(inp), str(out), oracle_lib.path), nprocs=world, join=True)
     check_outputs(name, out)
+    # the sharded coverage bitsets (gathered bit by bit across ranks) agree with the reference's JSON files
+    import numpy as np
+    z = np.load(str(out) + ".coverage_bitsets.npz")
+    ids = z["ids"].tolist()
+    noncov, gap = load_gz_json(name + ".noncov.json.gz"), load_gz_json(name + ".gap.json.gz")
+    for i, pos in enumerate(z["positions"].tolist()):
+        g = {x for lst in gap[str(pos)].values() for x in lst}
+        for side, arr in ((0, z["not_f"]), (1, z["not_r"])):
+            want = g | {x for lst in noncov[str(pos)][side].values() for x in lst}
+            bits = np.unpackbits(arr[i].view(np.uint8), bitorder="little")[: len(ids)]
+            assert {ids[r] for r in np.nonzero(bits)[0]} == want, (pos, side)
