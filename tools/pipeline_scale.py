@@ -30,10 +30,24 @@ with tempfile.TemporaryDirectory() as td:
     t0 = time.time()
     app = NN_degenerate(seq_file=fa, primer_length=a.k, coverage=0.8, number_of_dege_bases=4, score_of_dege_bases=10,
                         raw_entropy_threshold=3.6, product_len=150, position="2,3,-1", variation=1, distance=4, GC="0.2,0.7",
-                        nproc=1, outfile=os.path.join(td, "out.tsv"), write_json=False)
+                        nproc=1, outfile=os.path.join(td, "out.tsv"), write_json=False, write_bitsets=True)
     app.run()
     wall = time.time() - t0
     n_out = sum(1 for _ in open(os.path.join(td, "out.tsv"))) - 1
+    # pairing stage straight from the coverage bitsets (no JSON exists at this depth)
+    import contextlib
+    import io
+    from multiprime_amd.pairing import Primers_filter
+    t0 = time.time()
+    with contextlib.redirect_stdout(io.StringIO()):
+        pf = Primers_filter(ref_file=fa, primer_file=os.path.join(td, "out.tsv"), outfile=os.path.join(td, "syn.candidate.primers.txt"),
+                            adaptor="TCTTTCCCTACACGACGCTCTTCCGATCT,TGGAGTTCAGACGTGTGCTCTTCCGATCT", rep_seq_number=0, distance=4,
+                            size="150,600", position=4, fraction=0.7, diff_Tm=4)
+        pf.run()
+    pair_wall = time.time() - t0
+    n_pairs = sum(1 for _ in open(os.path.join(td, "syn.candidate.primers.xls"))) - 1
+    print(json.dumps({"pairing_wall_s": round(pair_wall, 2), "pairs": n_pairs, "bitset_file_bytes": os.path.getsize(os.path.join(td, "out.tsv.coverage_bitsets.npz")),
+                      "pairing_stats": {k: (round(v, 3) if isinstance(v, float) else v) for k, v in pf.stats.items()}}))
     print(json.dumps({"rows": a.rows, "cols": a.cols, "k": a.k, "generate_s": round(t_gen, 2), "wall_s": round(wall, 2),
                       "windows": app.n_windows, "rows_out": n_out, "n_candidates": app.stats.get("n_candidates"),
                       "phases": {k: round(v, 3) for k, v in app.stats.items() if isinstance(v, float)},
