@@ -54,3 +54,36 @@ def test_sharded_run_matches_reference(name, world, oracle_lib, tmp_path):
             want = g | {x for lst in noncov[str(pos)][side].values() for x in lst}
             bits = np.unpackbits(arr[i].view(np.uint8), bitorder="little")[: len(ids)]
             assert {ids[r] for r in np.nonzero(bits)[0]} == want, (pos, side)
+
+
+@pytest.mark.gpu
+def test_rccl_path_single_rank(tmp_path):
+    """The device branch of RowShards (candidate counters in a torch CUDA tensor, mp_eval_launch on torch's
+    stream, all-reduce over RCCL) with a world of one GPU: the multi-GPU code path the driver's 8-GPU run
+    takes, minus the other ranks."""
+    import torch
+    import torch.distributed as dist
+    from multiprime_amd._abi import Library
+    from multiprime_amd.core import NN_degenerate
+    from multiprime_amd.dist import RowShards
+    from test_core_golden import check_outputs
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(29600 + os.getpid() % 1000)
+    torch.cuda.set_device(0)
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    try:
+        for name in ("syn_iupac", "msa1000_k18_d64"):
+            meta = load_gz_json(name + ".trace.json.gz")["meta"]
+            fl = meta["flags"]
+            inp = tmp_path / (name + ".fa")
+            inp.write_bytes(golden_input(meta["input"]))
+            out = tmp_path / (name + ".out")
+            comm = RowShards()
+            assert comm.on_gpu
+            NN_degenerate(seq_file=str(inp), primer_length=fl["l"], coverage=fl["f"], number_of_dege_bases=fl["n"],
+                          score_of_dege_bases=fl["d"], raw_entropy_threshold=fl["e"], product_len=fl["s"], position=fl["c"],
+                          variation=fl["v"], distance=fl["a"], GC=fl["g"], nproc=1, outfile=str(out), library=Library(),
+                          comm=comm).run()
+            check_outputs(name, out)
+    finally:
+        dist.destroy_process_group()
