@@ -43,6 +43,37 @@ HEADERS = ["Position", "Entropy of cover (bit)", "Entropy of total (bit)", "Opti
            "Mis-R-coverage", "Tm", "Information"]
 
 
+from json.encoder import encode_basestring_ascii as _q
+
+
+def _dump_side_file(obj, fh, depth_list):
+    """json.dump(obj, fh, indent=4) for {pos: {kmer: [ids]}} (depth_list False) or {pos: [{kmer: [ids]}, {...}]}
+    (True), byte for byte, without the pure-Python encoder that `indent` forces (it was 25 % of the run)."""
+    def ids_block(ids, ind):
+        if not ids:
+            return "[]"
+        pad = " " * (ind + 4)
+        return "[\n" + ",\n".join(pad + _q(x) for x in ids) + "\n" + " " * ind + "]"
+
+    def kmer_block(d, ind):
+        if not d:
+            return "{}"
+        pad = " " * (ind + 4)
+        return "{\n" + ",\n".join(pad + _q(k) + ": " + ids_block(v, ind + 4) for k, v in d.items()) + "\n" + " " * ind + "}"
+
+    if not obj:
+        fh.write("{}")
+        return
+    parts = []
+    for pos, val in obj.items():
+        if depth_list:
+            body = "[\n" + ",\n".join(" " * 8 + kmer_block(d, 8) for d in val) + "\n" + " " * 4 + "]" if val else "[]"
+        else:
+            body = kmer_block(val, 4)
+        parts.append(" " * 4 + _q(str(pos)) + ": " + body)
+    fh.write("{\n" + ",\n".join(parts) + "\n}")
+
+
 def _desc_stable(values):
     """np.argsort(x)[::-1] with the stable tie order of the author's numpy (SURVEY A-14)."""
     return sorted(range(len(values)), key=lambda i: values[i])[::-1]
@@ -261,26 +292,18 @@ class NN_degenerate(object):
 
     @staticmethod
     def _viterbi(freq, NN):
-        """get_optimal_primer_by_viterbi (V20:579-593): max-sum path, ties to the lowest index."""
+        """get_optimal_primer_by_viterbi (V20:579-593): max-sum path over base frequencies and
+        nearest-neighbour counts; ties go to the lowest base index (numpy argmax takes the first)."""
         k = freq.shape[1]
-        score = [int(freq[a, 0]) for a in range(4)]
+        score = freq[:, 0].copy()
         back = []
         for t in range(1, k):
-            new, arg = [], []
-            for b in range(4):
-                best_a, best_v = 0, None
-                for a in range(4):
-                    val = score[a] + int(NN[t - 1, a, b]) + int(freq[b, t])
-                    if best_v is None or val > best_v:
-                        best_a, best_v = a, val
-                new.append(best_v)
-                arg.append(best_a)
-            score = new
-            back.append(arg)
-        last = max(range(4), key=lambda b: (score[b], -b))
-        path = [last]
+            M = score[:, None] + NN[t - 1] + freq[:, t][None, :]        # M[a][b]: best score ending in a, then b
+            back.append(M.argmax(axis=0))
+            score = M.max(axis=0)
+        path = [int(score.argmax())]
         for arg in reversed(back):
-            path.append(arg[path[-1]])
+            path.append(int(arg[path[-1]]))
         return path[::-1]
 
     # -- refinement ----------------------------------------------------------------------------
@@ -376,6 +399,18 @@ class NN_degenerate(object):
                 break
             nn_cov = cv
 
+    def _self_dimers(self, primers):
+        """dimer_check (V20:487-503) for a list of primers: one mp_dimer_pairs launch."""
+        if not primers:
+            return []
+        from .dimer import cached_loss_table, dg_limit, dg_params, encode_primers
+        uniq = list(dict.fromkeys(primers))
+        codes, off = encode_primers(uniq)
+        pairs = np.repeat(np.arange(len(uniq), dtype=np.int32), 2).reshape(-1, 2)
+        flags = self.ctx.dimer_pairs(codes, off, pairs, cached_loss_table(3.0), dg_params(), dg_limit())
+        hit = dict(zip(uniq, (bool(x) for x in flags)))
+        return [hit[p] for p in primers]
+
     def _replay(self, seed, ev, cn):
         """The stopping rules of coverage_stast (V20:881-906) on the batched evaluations."""
         i = 0
@@ -457,6 +492,7 @@ class NN_degenerate(object):
             self.stats["eval_s"] = time.time() - t0
             self.stats["n_candidates"] = n_cand
             t0 = time.time()
+            chosen_of = {}
             for win in windows:
                 for s in win.seeds:
                     self._replay(s, ev, win.cover_number)
@@ -470,8 +506,15 @@ class NN_degenerate(object):
                     chosen = nm if (nm[2] + nm[3]) > (mm[2] + mm[3]) else mm       # V20:816
                 else:
                     chosen = win.seeds[0].final
+                chosen_of[win.w] = chosen
+            # the 3'-end self-dimer test of every window's primer (dimer_check, V20:487-503) in ONE launch:
+            # it is the ordered pair (x -> x) of the dimer scan with Loss >= 3 and the two-term deltaG
+            order = [win for win in windows]
+            dimer_flag = self._self_dimers([chosen_of[win.w][0] for win in order])
+            for win, is_dimer in zip(order, dimer_flag):
+                chosen = chosen_of[win.w]
                 primer, cov, f_mis, r_mis, _ = chosen
-                if filters.self_dimer(primer):                                     # V20:749
+                if is_dimer:                                                       # V20:749
                     continue
                 members = iupac.expand(primer)
                 nonsense = sum(1 for e in members if e not in win.cover and e != win.present)   # V20:846
@@ -578,7 +621,7 @@ class NN_degenerate(object):
             for row in rows_out:
                 fo.write("\t".join(map(str, row)) + "\n")
         if self.write_json:
-            with open(self.outfile + ".non_coverage_seq_id_json", "w") as fj:      # V20:1172-1173
-                json.dump(non_cov_out, fj, indent=4)
+            with open(self.outfile + ".non_coverage_seq_id_json", "w") as fj:      # V20:1172-1173 json.dump(.., indent=4)
+                _dump_side_file(non_cov_out, fj, True)
             with open(self.outfile + ".gap_seq_id_json", "w") as fg:               # V20:1175-1176
-                json.dump(gap_out, fg, indent=4)
+                _dump_side_file(gap_out, fg, False)
