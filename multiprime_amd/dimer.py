@@ -28,11 +28,13 @@ HEADERS = ["Primer_ID", "Primer seq", "Primer end", "Delta G", "Primer end lengt
 
 def loss_table(threshold: float) -> np.ndarray:
     """loss_hit[l][GC][d2] = Penalty_points(l, GC, 0, d2) >= threshold  (FD:90-92, 207)."""
+    # 2**l * 2**GC is the integer 2**(l+GC): the value depends on (l + GC, d2) only
+    by_sum = np.array([[thermo.penalty_points(sm, 0, 0, d2) >= threshold for d2 in range(64)] for sm in range(2 * MAX_LEN + 1)],
+                      np.uint8)
     t = np.zeros((MAX_LEN + 1, MAX_LEN + 1, 64), np.uint8)
     for l in range(1, MAX_LEN + 1):
         for gc in range(0, l + 1):
-            for d2 in range(64):
-                t[l, gc, d2] = thermo.penalty_points(l, gc, 0, d2) >= threshold
+            t[l, gc] = by_sum[l + gc]
     return t
 
 

@@ -33,11 +33,12 @@ HEADERS = ["Primer_F_seq", "Primer_R_seq", "Product length:Tm:coverage_percentag
 
 def _loss_table_strict(threshold: float) -> np.ndarray:
     """loss_hit[l][GC][d2] = Penalty_points(l, GC, 0, d2) > threshold  (GM:431-435: strictly greater)."""
+    by_sum = np.array([[thermo.penalty_points(sm, 0, 0, d2) > threshold for d2 in range(64)] for sm in range(2 * MAX_LEN + 1)],
+                      np.uint8)               # 2**l * 2**GC == 2**(l+GC): only the sum matters
     t = np.zeros((MAX_LEN + 1, MAX_LEN + 1, 64), np.uint8)
     for l in range(1, MAX_LEN + 1):
         for gc in range(0, l + 1):
-            for d2 in range(64):
-                t[l, gc, d2] = thermo.penalty_points(l, gc, 0, d2) > threshold
+            t[l, gc] = by_sum[l + gc]
     return t
 
 
