@@ -195,6 +195,20 @@ int mp_dimer_pairs(mp_ctx *ctx, int32_t n_primers, const uint8_t *codes, const i
 int mp_pair_coverage(mp_ctx *ctx, int32_t n_sets, int32_t n_words, const uint64_t *sets_a, const uint64_t *sets_b,
                      int64_t n_pairs, const int32_t *pairs, int32_t *out);
 
+/* (7) exact in-silico PCR — SURVEY §8f-2 ---------------------------------------------------- */
+/* Replaces the search of Product.get_PCR_PRODUCT (scripts/extract_PCR_product_V1.py:189-216, "PCR") for
+ * every (primer pair, sequence).  `bytes`/`row_off` hold the sequence lines of the reference FASTA as they
+ * stand in the file (no upper-casing: the reference's re.search is case sensitive, so only upper-case
+ * A/C/G/T can match a primer expansion).  Primer 2p is the forward, 2p+1 the reverse primer of pair p
+ * (symbol codes, IUPAC allowed, <= MP_DIMER_MAX_LEN).  For each pair and sequence, in the reference's order:
+ * the first forward expansion iF that occurs in the sequence AND for which a reverse expansion matches
+ * inside its "Product" — the text from the first occurrence p1 of that expansion up to its next
+ * non-overlapping occurrence (str.split) or the end of the line; inside it the first reverse expansion iR
+ * (in expansion order) whose reverse complement occurs, at its first position q.  The amplicon is
+ * sequence[p1 : q + len(R)].  out[(p * n_rows + r) * 4 ..] = {iF, p1, iR, q}, iF = -1 when there is none. */
+int mp_pcr_scan(mp_ctx *ctx, const uint8_t *bytes, const int64_t *row_off, int32_t n_rows, int32_t n_pairs,
+                const uint8_t *codes, const int32_t *off, int32_t *out);
+
 /* Memory the context holds on the device, in bytes (window words, planes, tables). */
 int mp_device_bytes(mp_ctx *ctx, int64_t *bytes);
 

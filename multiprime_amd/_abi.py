@@ -45,6 +45,7 @@ SYMBOLS = [
                                 C.POINTER(C.c_int64)]),
     ("mp_dimer_pairs", C.c_int, [_p, C.c_int32, _p, _p, C.c_int64, _p, _p, _p, C.c_double, _p]),
     ("mp_pair_coverage", C.c_int, [_p, C.c_int32, C.c_int32, _p, _p, C.c_int64, _p, _p]),
+    ("mp_pcr_scan", C.c_int, [_p, _p, _p, C.c_int32, C.c_int32, _p, _p, _p]),
     ("mp_device_bytes", C.c_int, [_p, C.POINTER(C.c_int64)]),
 ]
 
@@ -260,6 +261,17 @@ class Context:
         self._ck(self.d.mp_pair_coverage(self.h, sets_a.shape[0], sets_a.shape[1], _ptr(sets_a), _ptr(sets_b), len(pairs),
                                          _ptr(pairs), _ptr(out)))
         return out[: len(pairs)]
+
+    def pcr_scan(self, data, row_off, codes, off) -> np.ndarray:
+        """[n_pairs][n_rows][4] = (forward expansion, amplicon start, reverse expansion, position of RC(reverse)); -1 = none."""
+        data = np.ascontiguousarray(data, dtype=np.uint8)
+        row_off = np.ascontiguousarray(row_off, dtype=np.int64)
+        codes = np.ascontiguousarray(codes, dtype=np.uint8)
+        off = np.ascontiguousarray(off, dtype=np.int32)
+        n_rows, n_pairs = len(row_off) - 1, (len(off) - 1) // 2
+        out = np.full((max(n_pairs, 1), max(n_rows, 1), 4), -1, np.int32)
+        self._ck(self.d.mp_pcr_scan(self.h, _ptr(data), _ptr(row_off), n_rows, n_pairs, _ptr(codes), _ptr(off), _ptr(out)))
+        return out[:n_pairs, :n_rows]
 
     def device_bytes(self) -> int:
         b = C.c_int64(0)

@@ -148,6 +148,61 @@ __global__ __launch_bounds__(kBlock) void pair_coverage_kernel(const unsigned lo
 }
 
 
+// ----------------------------------------------------------------------------------------------
+// (7) exact in-silico PCR (extract_PCR_product_V1.py:189-216)
+// ----------------------------------------------------------------------------------------------
+// thread = (primer pair, sequence).  The sequence is scanned with a rolling 2-bit window (newest base
+// in the top position, so window position j sits at bits 2j like dm_expand's packing); any character
+// other than upper-case A/C/G/T resets the window — the reference's regex search is case sensitive.
+__device__ inline int pcr_base(uint8_t ch) { return ch == 'A' ? 0 : ch == 'C' ? 1 : ch == 'G' ? 2 : ch == 'T' ? 3 : -1; }
+
+// first occurrence of the k-base pattern `pat` in s[from, to) (entirely inside), or -1
+__device__ inline int pcr_find(const uint8_t *__restrict__ s, int from, int to, uint64_t pat, int k) {
+    const uint64_t mask = k == 32 ? ~0ull : ((1ull << (2 * k)) - 1ull);
+    uint64_t win = 0;
+    int valid = 0;
+    for (int pos = from; pos < to; pos++) {
+        const int b = pcr_base(s[pos]);
+        if (b < 0) { valid = 0; win = 0; continue; }
+        win = (win >> 2) | ((uint64_t)b << (2 * (k - 1)));
+        if (++valid >= k && (win & mask) == pat) return pos - k + 1;
+    }
+    return -1;
+}
+
+__global__ __launch_bounds__(kBlock) void pcr_kernel(const uint8_t *__restrict__ bytes, const int64_t *__restrict__ row_off,
+                                                     int n_rows, const uint8_t *__restrict__ codes,
+                                                     const int32_t *__restrict__ off, int32_t *__restrict__ out) {
+    const int row = blockIdx.x * kBlock + threadIdx.x, p = blockIdx.y;
+    if (row >= n_rows) return;
+    const uint8_t *s = bytes + row_off[row];
+    const int len = (int)(row_off[row + 1] - row_off[row]);
+    const int lf = off[2 * p + 1] - off[2 * p], lr = off[2 * p + 2] - off[2 * p + 1];
+    Nib cf, cr;
+    cf.lo = cf.hi = cr.lo = cr.hi = 0;
+    for (int j = 0; j < lf; j++) cf.set(j, codes[off[2 * p] + j]);
+    for (int j = 0; j < lr; j++) cr.set(j, codes[off[2 * p + 1] + j]);
+    const uint32_t df = dm_degeneracy(cf, 0, lf), dr = dm_degeneracy(cr, 0, lr);
+    int32_t res[4] = {-1, -1, -1, -1};
+    for (uint32_t fi = 0; fi < df && res[0] < 0; fi++) {                   // for sequence in Fseq
+        const uint64_t f = dm_expand(cf, 0, lf, fi);
+        const int p1 = pcr_find(s, 0, len, f, lf);                         // re.search(sequence, i)
+        if (p1 < 0) continue;
+        const int p2 = pcr_find(s, p1 + lf, len, f, lf);                   // next non-overlapping occurrence (str.split)
+        const int end = p2 < 0 ? len : p2;                                 // Product = sequence + line[1]
+        for (uint32_t ri = 0; ri < dr; ri++) {                             // for sequence2 in Rseq
+            const uint64_t e = dm_expand(cr, 0, lr, ri);
+            uint64_t rc = 0;
+            for (int t = 0; t < lr; t++) rc |= (uint64_t)(3u - ((uint32_t)(e >> (2 * (lr - 1 - t))) & 3u)) << (2 * t);
+            const int q = pcr_find(s, p1, end, rc, lr);                    // re.search(RC(sequence2), Product)
+            if (q >= 0) { res[0] = (int32_t)fi; res[1] = p1; res[2] = (int32_t)ri; res[3] = q; break; }
+        }
+    }
+    int32_t *o = out + ((size_t)p * n_rows + row) * 4;
+    o[0] = res[0]; o[1] = res[1]; o[2] = res[2]; o[3] = res[3];
+}
+
+
 }  // namespace
 
 namespace mp {
@@ -308,5 +363,40 @@ int mp_pair_coverage(mp_ctx *c, int32_t n_sets, int32_t n_words, const uint64_t 
     return MP_OK;
 }
 
+
+int mp_pcr_scan(mp_ctx *c, const uint8_t *bytes, const int64_t *row_off, int32_t n_rows, int32_t n_pairs,
+                const uint8_t *codes, const int32_t *off, int32_t *out) {
+    if (!c) return MP_ERR_ARG;
+    if (n_rows < 0 || n_pairs < 0 || (n_rows && (!bytes || !row_off)) || (n_pairs && (!codes || !off)) || (n_rows && n_pairs && !out))
+        return fail(c, MP_ERR_ARG, "mp_pcr_scan: bad arguments");
+    HIPCK(c, hipSetDevice(c->dev));
+    if (n_rows == 0 || n_pairs == 0) return MP_OK;
+    int rc;
+    if ((rc = check_primers(c, 2 * n_pairs, codes, off))) return rc;
+    const size_t total = (size_t)(row_off[n_rows] - row_off[0]), ncodes = (size_t)off[2 * n_pairs];
+    const size_t nout = (size_t)n_pairs * (size_t)n_rows * 4;
+    uint8_t *d_bytes = nullptr, *d_codes = nullptr;
+    int64_t *d_roff = nullptr;
+    int32_t *d_off = nullptr, *d_out = nullptr;
+    if ((rc = dev_alloc(c, &d_bytes, total + 16))) return rc;
+    if ((rc = dev_alloc(c, &d_roff, (size_t)n_rows + 1))) return rc;
+    if ((rc = dev_alloc(c, &d_codes, ncodes))) return rc;
+    if ((rc = dev_alloc(c, &d_off, (size_t)2 * n_pairs + 1))) return rc;
+    if ((rc = dev_alloc(c, &d_out, nout))) return rc;
+    std::vector<int64_t> roff((size_t)n_rows + 1);
+    for (int32_t r = 0; r <= n_rows; r++) roff[(size_t)r] = row_off[r] - row_off[0];
+    HIPCK(c, hipMemcpyAsync(d_bytes, bytes + row_off[0], total, hipMemcpyHostToDevice, c->stream));
+    HIPCK(c, hipMemcpyAsync(d_roff, roff.data(), sizeof(int64_t) * roff.size(), hipMemcpyHostToDevice, c->stream));
+    HIPCK(c, hipMemcpyAsync(d_codes, codes, ncodes, hipMemcpyHostToDevice, c->stream));
+    HIPCK(c, hipMemcpyAsync(d_off, off, sizeof(int32_t) * ((size_t)2 * n_pairs + 1), hipMemcpyHostToDevice, c->stream));
+    hipLaunchKernelGGL(pcr_kernel, dim3((unsigned)((n_rows + kBlock - 1) / kBlock), (unsigned)n_pairs), dim3(kBlock), 0, c->stream,
+                       d_bytes, d_roff, n_rows, d_codes, d_off, d_out);
+    HIPCK(c, hipGetLastError());
+    HIPCK(c, hipMemcpyAsync(out, d_out, sizeof(int32_t) * nout, hipMemcpyDeviceToHost, c->stream));
+    HIPCK(c, hipStreamSynchronize(c->stream));
+    dev_free(c, &d_bytes, total + 16); dev_free(c, &d_roff, (size_t)n_rows + 1); dev_free(c, &d_codes, ncodes);
+    dev_free(c, &d_off, (size_t)2 * n_pairs + 1); dev_free(c, &d_out, nout);
+    return MP_OK;
+}
 
 }  // extern "C"

@@ -640,3 +640,51 @@ int mp_eval_masks(mp_ctx *c, int32_t n_cand, const int32_t *cw, const uint8_t *c
     }
     return MP_OK;
 }
+
+/* =================================================================================================
+ * (7) exact in-silico PCR: Product.get_PCR_PRODUCT (extract_PCR_product_V1.py:189-216, "PCR"), on strings
+ * ================================================================================================= */
+static const char *find_str(const char *hay, int hay_len, const char *needle, int n_len) {
+    for (int i = 0; i + n_len <= hay_len; i++)
+        if (!memcmp(hay + i, needle, (size_t)n_len)) return hay + i;
+    return NULL;
+}
+
+int mp_pcr_scan(mp_ctx *c, const uint8_t *bytes, const int64_t *row_off, int32_t n_rows, int32_t n_pairs,
+                const uint8_t *codes, const int32_t *off, int32_t *out) {
+    if (!c) return MP_ERR_ARG;
+    if (n_rows < 0 || n_pairs < 0 || (n_rows && (!bytes || !row_off)) || (n_pairs && (!codes || !off)) || (n_rows && n_pairs && !out))
+        return fail(c, MP_ERR_ARG, "mp_pcr_scan: bad arguments");
+    for (int32_t i = 0; i < 2 * n_pairs; i++) {
+        int len = off[i + 1] - off[i];
+        if (len < 1 || len > MP_DIMER_MAX_LEN || n_expansions(codes + off[i], len) < 0)
+            return fail(c, MP_ERR_ARG, "primer %d is not usable (length %d)", i, len);
+    }
+    char f[MP_DIMER_MAX_LEN + 1], r[MP_DIMER_MAX_LEN + 1], rc[MP_DIMER_MAX_LEN + 1];
+    for (int32_t p = 0; p < n_pairs; p++) {
+        const uint8_t *cf = codes + off[2 * p], *cr = codes + off[2 * p + 1];
+        int lf = off[2 * p + 1] - off[2 * p], lr = off[2 * p + 2] - off[2 * p + 1];
+        long long df = n_expansions(cf, lf), dr = n_expansions(cr, lr);
+        for (int32_t row = 0; row < n_rows; row++) {
+            const char *s = (const char *)bytes + row_off[row];
+            int len = (int)(row_off[row + 1] - row_off[row]);
+            int32_t *o = out + ((size_t)p * n_rows + row) * 4;
+            o[0] = o[1] = o[2] = o[3] = -1;
+            for (long long fi = 0; fi < df && o[0] < 0; fi++) {            /* for sequence in Fseq, PCR:198 */
+                expand_at(cf, lf, fi, f);
+                const char *a = find_str(s, len, f, lf);                   /* re.search(sequence, i), PCR:199 */
+                if (!a) continue;
+                int p1 = (int)(a - s);
+                const char *b = find_str(a + lf, len - p1 - lf, f, lf);    /* i.split(sequence): next occurrence */
+                int end = b ? (int)(b - s) : len;                          /* Product = sequence + line[1], PCR:200-201 */
+                for (long long ri = 0; ri < dr; ri++) {                    /* for sequence2 in Rseq, PCR:202 */
+                    expand_at(cr, lr, ri, r);
+                    for (int t = 0; t < lr; t++) rc[t] = comp_char(r[lr - 1 - t]);
+                    const char *q = find_str(a, end - p1, rc, lr);         /* re.search(RC(sequence2), Product) */
+                    if (q) { o[0] = (int32_t)fi; o[1] = p1; o[2] = (int32_t)ri; o[3] = (int)(q - s); break; }
+                }
+            }
+        }
+    }
+    return MP_OK;
+}
