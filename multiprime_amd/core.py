@@ -577,9 +577,28 @@ class NN_degenerate(object):
         else:
             nf = nr = np.zeros((0, 1), np.uint64)
         n_local = self.ctx.n_rows
-        bits = [np.unpackbits(m.view(np.uint8), axis=1, bitorder="little")[:, :n_local].astype(bool) for m in (nf, nr)]
         if self.comm is not None:
+            # row shards are not multiples of 64: concatenate bit by bit across ranks, then re-pack
+            bits = [np.unpackbits(m.view(np.uint8), axis=1, bitorder="little")[:, :n_local].astype(bool) for m in (nf, nr)]
             bits = [np.concatenate(self.comm._gather_objects(b), axis=1) for b in bits]
+            n_total = bits[0].shape[1] if n_out else self.total_sequence_number
+            nw = (n_total + 63) // 64
+            packed = []
+            for b in bits:
+                pad = np.zeros((n_out, nw * 64), bool)
+                pad[:, :b.shape[1]] = b
+                packed.append(np.packbits(pad, axis=1, bitorder="little").view(np.uint64).reshape(n_out, nw))
+        else:
+            n_total = n_local
+            packed = [np.array(nf, np.uint64), np.array(nr, np.uint64)]
+
+        def put(which, i, row, value):
+            word, bit = row >> 6, np.uint64(1) << np.uint64(row & 63)
+            if value:
+                packed[which][i, word] |= bit
+            else:
+                packed[which][i, word] &= ~bit
+
         # rows whose window held an IUPAC code: every expansion must be reached (V20:701-707 puts the id
         # under each expansion's k-mer), gap-type ones are in gap_seq_id
         for i, row in enumerate(rows_out):
@@ -589,7 +608,8 @@ class NN_degenerate(object):
             pc = iupac.codes_of(row[3])
             for r_glob, raw in lst:
                 if raw.count("-") > v:
-                    bits[0][i, r_glob] = bits[1][i, r_glob] = True
+                    put(0, i, r_glob, True)
+                    put(1, i, r_glob, True)
                     continue
                 bad_f = bad_r = False
                 for e in iupac.expand(raw):
@@ -602,17 +622,11 @@ class NN_degenerate(object):
                         continue
                     bad_f |= nd > v or bool(D & self._sF)
                     bad_r |= nd > v or bool(D & self._sR)
-                bits[0][i, r_glob], bits[1][i, r_glob] = bad_f, bad_r
+                put(0, i, r_glob, bad_f)
+                put(1, i, r_glob, bad_r)
         if self.comm is not None and self.comm.rank != 0:
             return
-        n_total = bits[0].shape[1] if n_out else self.total_sequence_number
-        nw = (n_total + 63) // 64
-        packed = []
-        for b in bits:
-            pad = np.zeros((n_out, nw * 64), bool)
-            pad[:, :b.shape[1]] = b
-            packed.append(np.packbits(pad, axis=1, bitorder="little").view(np.uint64).reshape(n_out, nw))
-        np.savez_compressed(self.outfile + ".coverage_bitsets.npz", positions=np.asarray([int(r[0]) for r in rows_out], np.int64),
+        np.savez(self.outfile + ".coverage_bitsets.npz", positions=np.asarray([int(r[0]) for r in rows_out], np.int64),
                             not_f=packed[0], not_r=packed[1], n_seq=np.int64(n_total), ids=np.asarray(self.seq_ids))
 
     def _write(self, rows_out, non_cov_out, gap_out):
