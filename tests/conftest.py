@@ -46,5 +46,8 @@ def oracle_lib():
 
 @pytest.fixture(scope="session")
 def hip_lib():
+    """The product library (hand-written HIP).  Rebuilt with hipcc when sources are newer than the .so."""
+    import __graft_entry__ as g
+    g.build()
     from multiprime_amd._abi import Library
     return Library()

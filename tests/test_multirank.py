@@ -11,7 +11,7 @@ import torch.multiprocessing as mp
 from conftest import GOLDEN, REPO, golden_input, load_gz_json
 
 
-def _worker(rank, world, port, name, inp, out, oracle_so):
+def _worker(rank, world, port, name, inp, out, lib_path):
     sys.path.insert(0, REPO)
     import torch.distributed as dist
     from multiprime_amd._abi import Library
@@ -27,7 +27,7 @@ def _worker(rank, world, port, name, inp, out, oracle_so):
         app = NN_degenerate(seq_file=inp, primer_length=fl["l"], coverage=fl["f"], number_of_dege_bases=fl["n"],
                             score_of_dege_bases=fl["d"], raw_entropy_threshold=fl["e"], product_len=fl["s"],
                             position=fl["c"], variation=fl["v"], distance=fl["a"], GC=fl["g"], nproc=1,
-                            outfile=out, library=Library(oracle_so), comm=RowShards(), write_bitsets=True)
+                            outfile=out, library=Library(lib_path), comm=RowShards(), write_bitsets=True)
         app.run()
     finally:
         dist.destroy_process_group()
@@ -87,3 +87,18 @@ def test_rccl_path_single_rank(tmp_path):
             check_outputs(name, out)
     finally:
         dist.destroy_process_group()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name,world", [("syn_iupac", 2), ("msa1000_k18_d64", 2)])
+def test_sharded_hip_contexts_match_reference(name, world, hip_lib, tmp_path):
+    """Two ranks, each with its own HIP context on the one GPU of the box (gloo carries the collectives): row
+    offsets, histogram merging and counter all-reduce on top of the real kernels."""
+    from test_core_golden import check_outputs
+    meta = load_gz_json(name + ".trace.json.gz")["meta"]
+    inp = tmp_path / (name + ".fa")
+    inp.write_bytes(golden_input(meta["input"]))
+    out = tmp_path / (name + ".out")
+    port = 29700 + (os.getpid() % 2000)
+    mp.spawn(_worker, args=(world, port, name, str(inp), str(out), hip_lib.path), nprocs=world, join=True)
+    check_outputs(name, out)
