@@ -28,6 +28,22 @@ sys.path.insert(0, REPO)
 HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec (MI355X_MICROARCH.md); ~6300 GB/s achievable
 
 
+KERNELS = {
+    "chain": "eval_chain_kernel (bit-sliced one-hot column planes, nested refinement chains) + eval_list_kernel (patch rows)",
+    "table": "eval_bits_kernel (bit-sliced one-hot column planes, symbol table per position) + eval_list_kernel (patch rows)",
+    "rows": "eval_kernel (row-per-lane window words)",
+}
+
+
+def eval_mode():
+    """Which evaluation kernels the library's environment switches select (defaults: the nested-chain kernel)."""
+    if os.environ.get("MP_EVAL_MODE") == "rows":
+        return "rows"
+    if os.environ.get("MP_EVAL_BITS", "0") in ("1", "2") or os.environ.get("MP_EVAL_GROUP") == "plain":
+        return "table"
+    return "chain"
+
+
 def make_candidates(root_codes, p0, W, k, C, seed):
     """C candidates per window: the root k-mer of the window, then progressively more degenerate
     versions (one more random base at one more random position each), seeded per window — the
@@ -173,7 +189,7 @@ def main():
         traffic = None
         try:     # measured in a separate PMC pass of this same command; reported only on an exact config match
             for e in json.load(open(os.path.join(REPO, "profiles", "hbm_traffic.json")))["entries"]:
-                if (e["rows"], e["cols"], e["k"], e["v"], e["cands"], e.get("mode")) == (a.rows, L, k, v, C, os.environ.get("MP_EVAL_MODE", "bits")):
+                if (e["rows"], e["cols"], e["k"], e["v"], e["cands"], e.get("mode")) == (a.rows, L, k, v, C, eval_mode()):
                     traffic = e["traffic_bytes"]
                     break
         except (OSError, KeyError, ValueError):
@@ -196,7 +212,7 @@ def main():
                        "parallelism": f"row shards x{world}, RCCL all-reduce of [{n_cand}x3] int64 counters"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "algorithmic_bytes": alg_bytes,
-                         "kernel": "eval_bits_kernel<8,2,2> (bit-sliced column planes) + eval_list_kernel<8,1> (patch rows); timed region = counter memset + both launches", "kernel_ms": per_launch_ms, "launches_timed": kern_n,
+                         "kernel": KERNELS[eval_mode()] + "; timed region = counter memset + all launches", "eval_mode": eval_mode(), "kernel_ms": per_launch_ms, "launches_timed": kern_n,
                          "algorithmic_bytes_per_eval": 3 * k / 8.0},
             "measured_copy_GBs": copy_gbs, "setup_s": setup_s, "device_bytes": ctx.device_bytes(), "counter_checksum": checksum,
         }

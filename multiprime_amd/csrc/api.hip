@@ -9,6 +9,11 @@ void free_eval(mp_ctx *c) {
     dev_free(c, &c->cand_n, (size_t)c->n_padded);
     dev_free(c, &c->cand_out, (size_t)c->n_padded);
     dev_free(c, &c->cand_symT, (size_t)c->n_items * 32);
+    dev_free(c, &c->cand_diff, (size_t)c->n_items);
+    dev_free(c, &c->chain_items, (size_t)c->n_chain);
+    if (c->n_chain) dev_free(c, &c->chain_events, (size_t)c->n_events + 1);
+    dev_free(c, &c->table_ids, (size_t)c->n_table);
+    c->n_chain = c->n_table = c->n_events = 0;
     c->n_items = c->n_padded = c->n_cand = 0;
 }
 
@@ -46,7 +51,7 @@ void free_msa(mp_ctx *c) {
     free_windows(c);
     size_t np = (size_t)c->n_pad;
     dev_free(c, &c->planes, (size_t)c->n_chunks * 4 * np);
-    dev_free(c, &c->cols, (size_t)c->n_chunks * 32 * 3 * (np / 64));
+    dev_free(c, &c->cols, (size_t)c->n_chunks * 32 * 4 * (np / 64));
     dev_free(c, &c->cum, ((size_t)c->n_chunks + 1) * np);
     dev_free(c, &c->ung, (size_t)c->n_rows * c->ustride);
     dev_free(c, &c->lead, np); dev_free(c, &c->rstrip, np); dev_free(c, &c->rlen, np);

@@ -4,7 +4,7 @@
 // Data layout in HBM:
 //   planes  [n_chunks][4][Npad] u32   base-set bit planes (A,C,G,T membership) of 32 alignment columns
 //                                     per word, sequences along the fastest axis (coalesced per wave)
-//   cols    [L][3][Npad/64] u64       column planes b0,b1,g — one bit per sequence — for the bit-sliced evaluation
+//   cols    [L][4][Npad/64] u64       column planes A,C,G,T (one-hot, gap = none) — one bit per sequence — for the bit-sliced evaluation
 //   cum     [n_chunks+1][Npad] u32    residues (non-gap symbols) left of each 32-column chunk
 //   ung     [N][ustride] u32          gap-free residue codes, 8 nibbles per word (edge-gap repair only)
 //   win     the k-mer of every (window, sequence) after repair, 3 bits per symbol:
@@ -37,8 +37,14 @@ constexpr int kHashLimit = 3584;          // load limit before the window is han
 constexpr int kEvalCC = 8;                // candidates evaluated per block pass
 
 struct ExRec { int32_t win, row; uint64_t lo, hi; };          // exception k-mer, 16+12 nibbles
-struct EvalItem { int32_t win, cand0; };                        // one block's work: window + first padded candidate
-
+struct EvalItem { int32_t win, cand0; };                       // one block's work: window + first padded candidate
+// One nested run of candidates for eval_chain_kernel: 8 output slots from cand0, n_steps of them used,
+// n_ev events (position | lost base << 8 | step << 16) from ev0.
+struct ChainItem {
+    int32_t win, cand0, n_steps, ev0, n_ev;
+    uint32_t sym[4];                   // nibble j = symbol of the first (most degenerate) candidate at position j
+    uint32_t pos1, pos2, pos4;         // positions where that symbol has one / two / more bases
+};
 
 struct Nib {          // up to 32 symbol codes, one nibble each
     uint64_t lo, hi;
@@ -134,7 +140,7 @@ struct mp_ctx {
     // alignment
     int n_rows = 0, n_pad = 0, n_chunks = 0, max_len = 0, ustride = 0;
     uint32_t *planes = nullptr, *cum = nullptr, *ung = nullptr;
-    unsigned long long *cols = nullptr;      // [n_chunks*32][3][n_pad/64]
+    unsigned long long *cols = nullptr;      // [n_chunks*32][4][n_pad/64]
     int32_t *lead = nullptr, *rstrip = nullptr, *rlen = nullptr;
     // windows
     int p0 = 0, n_win = 0, k = 0, v = 0;
@@ -164,7 +170,10 @@ struct mp_ctx {
     int n_cand = 0, n_items = 0, n_padded = 0;
     mp::EvalItem *items = nullptr;
     uint4 *cand_n = nullptr;
-    uint32_t *cand_symT = nullptr;
+    uint32_t *cand_symT = nullptr, *cand_diff = nullptr, *chain_events = nullptr;
+    mp::ChainItem *chain_items = nullptr;
+    int32_t *table_ids = nullptr;
+    int n_chain = 0, n_table = 0, n_events = 0;
     int32_t *cand_out = nullptr;
     uint32_t sF = 0, sR = 0;
     unsigned long long *tmp_out = nullptr;

@@ -175,201 +175,10 @@ __global__ __launch_bounds__(kBlock) void eval_kernel(const EvalArgs A) {
 }
 
 
-// ----------------------------------------------------------------------------------------------
-// (4b) bit-sliced evaluation: 64 sequences per register word
-// ----------------------------------------------------------------------------------------------
-// For the sequences whose k-mer at window w is the plain column slice (everything the patch list
-// does not hold) the symbol at window position j is column p0+w+j of the alignment, so the
-// evaluation can run on the COLUMN planes: a thread owns G words of 64 sequences; for every
-// position it loads the three plane words once, and for every candidate the mismatch word of 64
-// sequences is ONE v_bitop3 of (g,b1,b0) whose truth table is fixed by the candidate's symbol
-// (a wave-uniform 16-way dispatch).  Mismatch counts are bit-sliced saturating counters
-// (t1 = ">= 1", t2 = ">= 2", t3 = ">= 3": LV = v+1 levels), the strict-position sets are two more
-// words, and the three coverage counters are popcounts at the end.  ~2.5 VALU per evaluation
-// instead of ~13, and the inputs (N*L*3/8 bytes) stay in L2 / Infinity Cache.
-struct EvalBitsArgs {
-    const unsigned long long *cols;    // [n_cols][3][nw]
-    const unsigned long long *excl;    // [W][nw]
-    int nw, p0, k, v;
-    const EvalItem *items;
-    const uint32_t *cand_symT;         // [item][32] u32: nibble c of word j = symbol of candidate c at position j
-    const int32_t *cand_out;
-    uint32_t sF, sR;
-    unsigned long long *out;
-    int ny, ny_pad;                    // row slices per item; ny_pad = ny rounded up to a multiple of 8 (XCDs)
-};
-
-// truth table of v_bitop3_b32 D = f(S0,S1,S2): bit (S0<<2 | S1<<1 | S2) of the immediate
-constexpr int bs_lut_mismatch(int sym) {      // inputs (g, b1, b0): gap, or base not in the symbol's set
-    int t = 0;
-    for (int idx = 0; idx < 8; idx++) {
-        int g = idx >> 2, base = idx & 3;
-        if (g || !((sym >> base) & 1)) t |= 1 << idx;
-    }
-    return t;
-}
-constexpr int kLutOrAnd = 0xF8;               // S0 | (S1 & S2)
-constexpr int kLutAndNotNot = 0x10;           // S0 & ~S1 & ~S2
-
-template <int SYM, int GW>
-__device__ inline void bs_mismatch(const uint32_t (&b0)[GW], const uint32_t (&b1)[GW], const uint32_t (&g)[GW], uint32_t (&m)[GW]) {
-    constexpr int lut = bs_lut_mismatch(SYM);
-#pragma unroll
-    for (int i = 0; i < GW; i++) m[i] = __builtin_amdgcn_bitop3_b32(g[i], b1[i], b0[i], lut);
-}
-
-// CP candidates per pass over the k positions (8 / CP passes), GW 32-bit words (32 sequences each)
-// per thread, LV = v + 1 saturating counter levels.
-template <int CP, int LV, int GW, bool PREFETCH>
-__global__ __launch_bounds__(kBlock) void eval_bits_kernel(const EvalBitsArgs A) {
-    constexpr int CC = 8;
-    __shared__ uint32_t s_acc[3 * CC];
-    // XCD-aware block mapping: workgroup b runs on XCD b % 8 (observed dispatch order), so all blocks of
-    // one row slice land on the same XCD and consecutive windows re-read their 17 shared columns from
-    // that XCD's L2 (a slice of the planes is 1/ny of N*L*3/8 bytes)
-    const int slice = blockIdx.x % A.ny_pad, item = blockIdx.x / A.ny_pad;
-    if (slice >= A.ny) return;
-    const EvalItem it = A.items[item];
-    if (threadIdx.x < 3 * CC) s_acc[threadIdx.x] = 0;
-    const size_t nw32 = (size_t)A.nw * 2;             // 32-bit words per plane row
-    const int word0 = (slice * kBlock + threadIdx.x) * GW;
-    const bool live = word0 < (int)nw32;              // nw32 % GW == 0 (n_pad % 256 == 0, GW <= 8)
-    const uint32_t *cols = reinterpret_cast<const uint32_t *>(A.cols);
-    uint32_t accP[CC], accF[CC], accR[CC];
-#pragma unroll
-    for (int c = 0; c < CC; c++) accP[c] = accF[c] = accR[c] = 0;
-    if (live) {
-        uint32_t valid[GW];
-        bool have_valid = false;
-#pragma unroll 1
-        for (int pass = 0; pass < CC / CP; pass++) {
-            uint32_t t1[CP][GW], t2[CP][GW], t3[CP][GW], sf[CP][GW], sr[CP][GW];
-            uint32_t g1[GW], g2[GW], g3[GW];
-#pragma unroll
-            for (int i = 0; i < GW; i++) {
-                g1[i] = g2[i] = g3[i] = 0;
-#pragma unroll
-                for (int c = 0; c < CP; c++) t1[c][i] = t2[c][i] = t3[c][i] = sf[c][i] = sr[c][i] = 0;
-            }
-            uint32_t n0[GW], n1[GW], ng[GW];               // next position's planes, in flight during this one
-            if (PREFETCH) {
-                const uint32_t *P = cols + ((size_t)(A.p0 + it.win) * 3) * nw32 + word0;
-#pragma unroll
-                for (int i = 0; i < GW; i++) { n0[i] = P[i]; n1[i] = P[nw32 + i]; ng[i] = P[2 * nw32 + i]; }
-            }
-#pragma unroll 1
-            for (int j = 0; j < A.k; j++) {
-                uint32_t b0[GW], b1[GW], g[GW];
-                if (PREFETCH) {
-#pragma unroll
-                    for (int i = 0; i < GW; i++) { b0[i] = n0[i]; b1[i] = n1[i]; g[i] = ng[i]; }
-                    if (j + 1 < A.k) {
-                        const uint32_t *P = cols + ((size_t)(A.p0 + it.win + j + 1) * 3) * nw32 + word0;
-#pragma unroll
-                        for (int i = 0; i < GW; i++) { n0[i] = P[i]; n1[i] = P[nw32 + i]; ng[i] = P[2 * nw32 + i]; }
-                    }
-                } else {
-                    const uint32_t *P = cols + ((size_t)(A.p0 + it.win + j) * 3) * nw32 + word0;
-#pragma unroll
-                    for (int i = 0; i < GW; i++) { b0[i] = P[i]; b1[i] = P[nw32 + i]; g[i] = P[2 * nw32 + i]; }
-                }
-                if (!have_valid) {
-#pragma unroll
-                    for (int i = 0; i < GW; i++) {            // gaps per k-mer, saturating (V20:689 needs "> v")
-                        if (LV >= 3) g3[i] = __builtin_amdgcn_bitop3_b32(g3[i], g2[i], g[i], kLutOrAnd);
-                        if (LV >= 2) g2[i] = __builtin_amdgcn_bitop3_b32(g2[i], g1[i], g[i], kLutOrAnd);
-                        g1[i] |= g[i];
-                    }
-                }
-                const uint32_t sw = __builtin_amdgcn_readfirstlane(A.cand_symT[(size_t)item * 32 + j]) >> (4 * CP * pass);
-                // the mismatch word of every possible candidate symbol at this position (15 x GW v_bitop3,
-                // shared by all candidates); a candidate then picks its word by a wave-uniform register index
-                uint32_t tab[16][GW];
-#pragma unroll
-                for (int i = 0; i < GW; i++) tab[0][i] = 0xFFFFFFFFu;
-                bs_mismatch<1, GW>(b0, b1, g, tab[1]); bs_mismatch<2, GW>(b0, b1, g, tab[2]); bs_mismatch<3, GW>(b0, b1, g, tab[3]);
-                bs_mismatch<4, GW>(b0, b1, g, tab[4]); bs_mismatch<5, GW>(b0, b1, g, tab[5]); bs_mismatch<6, GW>(b0, b1, g, tab[6]);
-                bs_mismatch<7, GW>(b0, b1, g, tab[7]); bs_mismatch<8, GW>(b0, b1, g, tab[8]); bs_mismatch<9, GW>(b0, b1, g, tab[9]);
-                bs_mismatch<10, GW>(b0, b1, g, tab[10]); bs_mismatch<11, GW>(b0, b1, g, tab[11]); bs_mismatch<12, GW>(b0, b1, g, tab[12]);
-                bs_mismatch<13, GW>(b0, b1, g, tab[13]); bs_mismatch<14, GW>(b0, b1, g, tab[14]); bs_mismatch<15, GW>(b0, b1, g, tab[15]);
-                uint32_t m[CP][GW];
-#pragma unroll
-                for (int c = 0; c < CP; c++) {
-                    const uint32_t sy = (sw >> (4 * c)) & 15u;
-#pragma unroll
-                    for (int i = 0; i < GW; i++) m[c][i] = tab[sy][i];
-#pragma unroll
-                    for (int i = 0; i < GW; i++) {
-                        if (LV >= 3) t3[c][i] = __builtin_amdgcn_bitop3_b32(t3[c][i], t2[c][i], m[c][i], kLutOrAnd);
-                        if (LV >= 2) t2[c][i] = __builtin_amdgcn_bitop3_b32(t2[c][i], t1[c][i], m[c][i], kLutOrAnd);
-                        t1[c][i] |= m[c][i];
-                    }
-                }
-                if (__builtin_amdgcn_readfirstlane((A.sF >> j) & 1u)) {
-#pragma unroll
-                    for (int c = 0; c < CP; c++)
-#pragma unroll
-                        for (int i = 0; i < GW; i++) sf[c][i] |= m[c][i];
-                }
-                if (__builtin_amdgcn_readfirstlane((A.sR >> j) & 1u)) {
-#pragma unroll
-                    for (int c = 0; c < CP; c++)
-#pragma unroll
-                        for (int i = 0; i < GW; i++) sr[c][i] |= m[c][i];
-                }
-            }
-            if (!have_valid) {
-                const uint32_t *E = reinterpret_cast<const uint32_t *>(A.excl) + (size_t)it.win * nw32 + word0;
-#pragma unroll
-                for (int i = 0; i < GW; i++) {
-                    const uint32_t gapbad = LV == 1 ? g1[i] : (LV == 2 ? g2[i] : g3[i]);
-                    valid[i] = ~(E[i] | gapbad);
-                }
-                have_valid = true;
-            }
-#pragma unroll
-            for (int c = 0; c < CP; c++) {
-                uint32_t p = 0, f = 0, r = 0;
-#pragma unroll
-                for (int i = 0; i < GW; i++) {
-                    const uint32_t far = LV == 1 ? t1[c][i] : (LV == 2 ? t2[c][i] : t3[c][i]);
-                    p += __popc(valid[i] & ~t1[c][i]);
-                    f += __popc(__builtin_amdgcn_bitop3_b32(valid[i], far, sf[c][i], kLutAndNotNot));
-                    r += __popc(__builtin_amdgcn_bitop3_b32(valid[i], far, sr[c][i], kLutAndNotNot));
-                }
-                // static index into the accumulators: the pass loop is not unrolled, so select by pass
-#pragma unroll
-                for (int q = 0; q < CC / CP; q++)
-                    if (pass == q) { accP[q * CP + c] += p; accF[q * CP + c] += f; accR[q * CP + c] += r; }
-            }
-        }
-    }
-    __syncthreads();
-#pragma unroll
-    for (int c = 0; c < CC; c++) {
-        uint32_t x = accP[c], y = accF[c], z = accR[c];
-#pragma unroll
-        for (int sft = 32; sft >= 1; sft >>= 1) {
-            x += __shfl_xor(x, sft);
-            y += __shfl_xor(y, sft);
-            z += __shfl_xor(z, sft);
-        }
-        if ((threadIdx.x & 63) == 0) {
-            atomicAdd(&s_acc[3 * c], x);
-            atomicAdd(&s_acc[3 * c + 1], y - x);      // F_mis = F_raw - perfect
-            atomicAdd(&s_acc[3 * c + 2], z - x);
-        }
-    }
-    __syncthreads();
-    if (threadIdx.x < 3 * CC) {
-        int oc = A.cand_out[it.cand0 + threadIdx.x / 3];
-        uint32_t val = s_acc[threadIdx.x];
-        if (oc >= 0 && val) atomicAdd(&A.out[(size_t)oc * 3 + threadIdx.x % 3], (unsigned long long)val);
-    }
-}
-
 // Row-per-lane evaluation of two compact per-window lists of window words: the patch list (rows with
-// edge-gap repair / ragged ends, built on the device) and the host-expanded IUPAC rows.
+// edge-gap repair / ragged ends, built on the device) and the host-expanded IUPAC rows.  It rides in the
+// same launch as a bit-sliced kernel: the first n_blocks workgroups of that launch do this (item = b / ny,
+// part y = b % ny of the item's lists), concurrently with the column-plane work of the others.
 struct EvalListArgs {
     const EvalItem *items;
     const uint4 *cand_n;
@@ -382,12 +191,13 @@ struct EvalListArgs {
     int v;
     uint32_t kmask;
     unsigned long long *out;
+    int ny, n_blocks;           // parts per item; ny * n_items rounded up to a multiple of 8 (0: no list work)
+    int n_items;
 };
 
 template <int CC, int VMODE>
-__global__ __launch_bounds__(kBlock) void eval_list_kernel(const EvalListArgs L) {
-    __shared__ uint32_t s_acc[3 * CC];
-    const EvalItem it = L.items[blockIdx.x];
+__device__ __forceinline__ void eval_list_block(const EvalListArgs &L, int item, int y, uint32_t *s_acc) {
+    const EvalItem it = L.items[item];
     uint32_t nA[CC], nC[CC], nG[CC], nT[CC];
     EvalAcc<CC, 1> acc;
     acc.clear();
@@ -404,7 +214,7 @@ __global__ __launch_bounds__(kBlock) void eval_list_kernel(const EvalListArgs L)
         const uint32_t *words = which ? L.words_b : L.words_a;
         if (!off) continue;
         const int e0 = off[it.win], e1 = off[it.win + 1];
-        for (int eb = e0 + blockIdx.y * kBlock; eb < e1; eb += gridDim.y * kBlock) {     // uniform per wave
+        for (int eb = e0 + y * kBlock; eb < e1; eb += L.ny * kBlock) {     // uniform per wave
             int e = eb + threadIdx.x;
             uint32_t b0 = 0, b1 = 0, g = 0xFFFFFFFFu;
             if (e < e1) { b0 = words[3 * (size_t)e]; b1 = words[3 * (size_t)e + 1]; g = words[3 * (size_t)e + 2]; }
@@ -428,6 +238,474 @@ __global__ __launch_bounds__(kBlock) void eval_list_kernel(const EvalListArgs L)
     }
 }
 
+// ----------------------------------------------------------------------------------------------
+// (4b) bit-sliced evaluation: 32 sequences per register word
+// ----------------------------------------------------------------------------------------------
+// For the sequences whose k-mer at window w is the plain column slice (everything `excl` does not
+// flag) the symbol at window position j is column p0+w+j of the alignment, so the evaluation runs
+// on the one-hot COLUMN planes (A, C, G, T; a gap sets none): "sequence matches symbol s at position
+// j" is the OR of the planes of s's bases — for a concrete symbol just one loaded word, no ALU work.
+// Mismatch counts are bit-sliced saturating counters (t1 = ">= 1", t2 = ">= 2", t3 = ">= 3": LV =
+// v+1 levels), the strict-position sets two more words, the three coverage counters popcounts at
+// the end.  Rows with more than v gaps never count (V20:689): build_windows folded them into `excl`.
+// Two kernels share this scheme:
+//   eval_chain_kernel — the candidates of an item form a NESTED chain (a refinement chain): one pass
+//       over the k positions for the most degenerate candidate, then one bit plane per refinement step;
+//   eval_bits_kernel  — any 8 candidates: per position the match word of every possible symbol (11
+//       VALU per word, shared by the candidates), each candidate picks its word by register index.
+// The inputs (N*L/2 bytes of planes) stay in L2 / Infinity Cache across the windows of a launch.
+// truth table of v_bitop3_b32 D = f(S0,S1,S2): bit (S0<<2 | S1<<1 | S2) of the immediate
+template <typename F>
+constexpr int make_lut(F f) {
+    int t = 0;
+    for (int i = 0; i < 8; i++)
+        if (f((i >> 2) & 1, (i >> 1) & 1, i & 1)) t |= 1 << i;
+    return t;
+}
+constexpr int kLutOrAnd = make_lut([](int a, int b, int c) { return a | (b & c); });            // S0 | (S1 & S2)
+constexpr int kLutOrAndNot = make_lut([](int a, int b, int c) { return a | (b & (c ^ 1)); });   // S0 | (S1 & ~S2)
+constexpr int kLutOrNot = make_lut([](int a, int b, int) { return a | (b ^ 1); });              // S0 | ~S1
+constexpr int kLutOrNotAnd = make_lut([](int a, int b, int c) { return a | ((b ^ 1) & c); });   // S0 | (~S1 & S2)
+constexpr int kLutAndNotNot = make_lut([](int a, int b, int c) { return a & (b ^ 1) & (c ^ 1); });   // S0 & ~S1 & ~S2
+constexpr int kLutOr3 = make_lut([](int a, int b, int c) { return a | b | c; });
+constexpr int kLutAndOr = make_lut([](int a, int b, int c) { return (a & b) | c; });            // (S0 & S1) | S2
+static_assert(kLutOrAnd == 0xF8 && kLutAndNotNot == 0x10, "v_bitop3 truth tables");
+
+// add one "mismatch where NOT m" plane to saturating counters
+template <int LV>
+__device__ __forceinline__ void count_unmatched(uint32_t &t1, uint32_t &t2, uint32_t &t3, uint32_t m) {
+    if (LV >= 3) t3 = __builtin_amdgcn_bitop3_b32(t3, t2, m, kLutOrAndNot);
+    if (LV >= 2) t2 = __builtin_amdgcn_bitop3_b32(t2, t1, m, kLutOrAndNot);
+    t1 = __builtin_amdgcn_bitop3_b32(t1, m, m, kLutOrNot);
+}
+// add one "mismatch where d" plane
+template <int LV>
+__device__ __forceinline__ void count_plane(uint32_t &t1, uint32_t &t2, uint32_t &t3, uint32_t d) {
+    if (LV >= 3) t3 = __builtin_amdgcn_bitop3_b32(t3, t2, d, kLutOrAnd);
+    if (LV >= 2) t2 = __builtin_amdgcn_bitop3_b32(t2, t1, d, kLutOrAnd);
+    t1 |= d;
+}
+
+struct BlockMap { int ny, ny_pad, n_items, per_band; };       // see map_block
+
+struct EvalBitsArgs {
+    const unsigned long long *cols;    // [n_cols][4][nw]
+    const unsigned long long *excl;    // [W][nw]
+    int nw, p0, k, v;
+    const EvalItem *items;
+    const uint32_t *cand_symT;         // [item][32] u32: nibble c of word j = symbol of candidate c at position j
+    const int32_t *cand_out;
+    uint32_t sF, sR;
+    unsigned long long *out;
+    BlockMap map;                      // row slices per item (ny; ny_pad = rounded up to 1, 2, 4 or a multiple of 8), items
+    const uint32_t *diff_mask;         // [item] positions where the item's candidates do not all carry the same symbol
+    const int32_t *item_ids;           // items this launch covers (null: all of them)
+    EvalListArgs list;                 // patch / IUPAC rows riding in the first list.n_blocks workgroups
+};
+
+// Sum over the 64 lanes of a wave with DPP adds only (no LDS); the total ends up in lane 63.  All lanes active.
+__device__ __forceinline__ uint32_t wave_sum_lane63(uint32_t x) {
+    x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0xB1, 0xF, 0xF, true);     // quad_perm [1,0,3,2]
+    x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x4E, 0xF, 0xF, true);     // quad_perm [2,3,0,1]
+    x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x141, 0xF, 0xF, true);    // row_half_mirror
+    x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x140, 0xF, 0xF, true);    // row_mirror: every lane = its row's sum
+    x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x142, 0xA, 0xF, false);   // row_bcast15 into rows 1 and 3
+    x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x143, 0xC, 0xF, false);   // row_bcast31 into rows 2 and 3
+    return x;
+}
+
+// Block totals of the 8 x 3 per-thread popcounts without LDS round trips: two 16-bit counts per word (a wave's
+// sum is at most 64 * 32 * GW), six DPP adds per word leave the wave total in lane 63, which parks it in LDS for
+// the final 24 threads; those add the block's share to the global counters (F_mis = F_raw - perfect).
+template <int GW>
+__device__ __forceinline__ void block_commit(const uint32_t (&accP)[8], const uint32_t (&accF)[8], const uint32_t (&accR)[8],
+                                             uint32_t (&s_part)[kBlock / 64][12], const int32_t *cand_out, unsigned long long *out) {
+    constexpr int CC = 8;
+    static_assert(64 * 32 * GW < 65536, "packed wave sums must fit 16 bits");
+    uint32_t vals[3 * CC];
+#pragma unroll
+    for (int c = 0; c < CC; c++) { vals[3 * c] = accP[c]; vals[3 * c + 1] = accF[c]; vals[3 * c + 2] = accR[c]; }
+    uint32_t tot[3 * CC / 2];
+#pragma unroll
+    for (int q = 0; q < 3 * CC / 2; q++) tot[q] = wave_sum_lane63(vals[2 * q] | (vals[2 * q + 1] << 16));
+    if ((threadIdx.x & 63) == 63) {
+#pragma unroll
+        for (int q = 0; q < 3 * CC / 2; q++) s_part[threadIdx.x >> 6][q] = tot[q];
+    }
+    __syncthreads();
+    if (threadIdx.x < 3 * CC) {
+        const int c = threadIdx.x / 3, r = threadIdx.x % 3;
+        uint32_t mine = 0, perfect = 0;
+#pragma unroll
+        for (int w = 0; w < kBlock / 64; w++) {
+            mine += (s_part[w][threadIdx.x >> 1] >> (16 * (threadIdx.x & 1))) & 0xFFFFu;
+            perfect += (s_part[w][(3 * c) >> 1] >> (16 * ((3 * c) & 1))) & 0xFFFFu;
+        }
+        const uint32_t val = r ? mine - perfect : mine;
+        const int oc = cand_out[c];
+        if (oc >= 0 && val) atomicAdd(&out[(size_t)oc * 3 + r], (unsigned long long)val);
+    }
+}
+
+// XCD-aware block mapping shared by both kernels: workgroup b runs on XCD b % 8 (observed dispatch order) and every
+// XCD has its own L2, so the (item, row slice) grid is laid out to let consecutive windows re-read their k-1 shared
+// columns from ONE L2.  With 8 or more slices (ny_pad a multiple of 8) slice = b % ny_pad: an XCD owns slices.  With
+// fewer (ny_pad = 1, 2, 4) an XCD owns one slice and one of 8 / ny_pad contiguous BANDS of items — otherwise two
+// XCDs would walk the same slice with interleaved windows and each pull every column from HBM.
+__device__ __forceinline__ bool map_block(const BlockMap &M, unsigned b, int &slice, int &idx) {
+    if (M.ny_pad >= 8) {
+        slice = (int)(b % (unsigned)M.ny_pad);
+        idx = (int)(b / (unsigned)M.ny_pad);
+    } else {
+        const int xcd = (int)(b & 7u);
+        slice = xcd % M.ny_pad;
+        idx = (xcd / M.ny_pad) * M.per_band + (int)(b >> 3);
+        if ((int)(b >> 3) >= M.per_band) return false;
+    }
+    return slice < M.ny && idx < M.n_items;
+}
+
+// GW 32-bit words (32 sequences each) per thread, LV = v + 1 saturating counter levels.
+// CHAIN: positions where all 8 candidates carry the same symbol (not in diff_mask, from the host) update ONE
+// shared set of counters (c1..) with one match word; only the positions where they differ run the symbol
+// table, the register-indexed select and the per-candidate updates.  The two counter sets add up exactly at the
+// end (saturating sums: >=1: a1|b1, >=2: a2|b2|a1&b1, ...).
+template <int LV, int GW, bool CHAIN, int D>
+__global__ __launch_bounds__(kBlock) void eval_bits_kernel(const EvalBitsArgs A) {
+    constexpr int CC = 8;
+    __shared__ uint32_t s_part[kBlock / 64][3 * CC / 2];
+    if ((int)blockIdx.x < A.list.n_blocks) {
+        if ((int)blockIdx.x < A.list.ny * A.list.n_items)
+            eval_list_block<CC, LV - 1>(A.list, blockIdx.x / A.list.ny, blockIdx.x % A.list.ny, &s_part[0][0]);
+        return;
+    }
+    int slice, idx;
+    if (!map_block(A.map, blockIdx.x - A.list.n_blocks, slice, idx)) return;
+    const int item = A.item_ids ? A.item_ids[idx] : idx;
+    const EvalItem it = A.items[item];
+    const size_t nw32 = (size_t)A.nw * 2;             // 32-bit words per plane row
+    const int word0 = (slice * kBlock + threadIdx.x) * GW;
+    const bool live = word0 < (int)nw32;              // nw32 % GW == 0 (n_pad % 256 == 0, GW <= 8)
+    const uint32_t *cols = reinterpret_cast<const uint32_t *>(A.cols);
+    const uint32_t kbits = (1u << A.k) - 1u;           // k <= MP_MAX_K = 28
+    const uint32_t diff = CHAIN ? (__builtin_amdgcn_readfirstlane(A.diff_mask[item]) & kbits) : kbits;
+    const uint32_t same = kbits & ~diff;
+    uint32_t accP[CC], accF[CC], accR[CC];
+#pragma unroll
+    for (int c = 0; c < CC; c++) accP[c] = accF[c] = accR[c] = 0;
+    if (live) {
+        uint32_t t1[CC][GW], t2[CC][GW], t3[CC][GW], sf[CC][GW], sr[CC][GW];
+        uint32_t c1[GW], c2[GW], c3[GW], csf[GW], csr[GW];      // counters of the positions all candidates share
+#pragma unroll
+        for (int i = 0; i < GW; i++) {
+            c1[i] = c2[i] = c3[i] = csf[i] = csr[i] = 0;
+#pragma unroll
+            for (int c = 0; c < CC; c++) t1[c][i] = t2[c][i] = t3[c][i] = sf[c][i] = sr[c][i] = 0;
+        }
+        const uint32_t *Pw = cols + ((size_t)(A.p0 + it.win) * 4) * nw32 + word0;
+        const uint32_t *symrow = A.cand_symT + (size_t)item * 32;
+        // (1) positions where all candidates of the item carry the same symbol: one match word for all of them,
+        // branch-free (the symbol's base masks are wave-uniform)
+        if (CHAIN) {
+            uint32_t rem = same;
+#pragma unroll 1
+            while (rem) {
+                int js[D]; bool has[D];
+                uint32_t pl[D][4][GW], sws[D];
+#pragma unroll
+                for (int u = 0; u < D; u++) {           // D positions of loads in flight before the first is consumed
+                    has[u] = rem != 0u;
+                    js[u] = has[u] ? __builtin_ctz(rem) : js[0];
+                    rem &= rem - 1u;
+                    const uint32_t *P = Pw + (size_t)js[u] * 4 * nw32;
+#pragma unroll
+                    for (int b = 0; b < 4; b++)
+#pragma unroll
+                        for (int i = 0; i < GW; i++) pl[u][b][i] = P[b * nw32 + i];
+                    sws[u] = symrow[js[u]];
+                }
+#pragma unroll
+                for (int u = 0; u < D; u++) {
+                    if (!has[u]) break;
+                    const uint32_t sy = __builtin_amdgcn_readfirstlane(sws[u]) & 15u;
+                    const uint32_t kA = (sy & 1u) ? 0xFFFFFFFFu : 0u, kC = (sy & 2u) ? 0xFFFFFFFFu : 0u;
+                    const uint32_t kG = (sy & 4u) ? 0xFFFFFFFFu : 0u, kT = (sy & 8u) ? 0xFFFFFFFFu : 0u;
+                    const uint32_t fF = ((A.sF >> js[u]) & 1u) ? 0xFFFFFFFFu : 0u, fR = ((A.sR >> js[u]) & 1u) ? 0xFFFFFFFFu : 0u;
+#pragma unroll
+                    for (int i = 0; i < GW; i++) {
+                        uint32_t m = pl[u][0][i] & kA;
+                        m = __builtin_amdgcn_bitop3_b32(pl[u][1][i], kC, m, kLutAndOr);
+                        m = __builtin_amdgcn_bitop3_b32(pl[u][2][i], kG, m, kLutAndOr);
+                        m = __builtin_amdgcn_bitop3_b32(pl[u][3][i], kT, m, kLutAndOr);
+                        count_unmatched<LV>(c1[i], c2[i], c3[i], m);
+                        csf[i] = __builtin_amdgcn_bitop3_b32(csf[i], m, fF, kLutOrNotAnd);
+                        csr[i] = __builtin_amdgcn_bitop3_b32(csr[i], m, fR, kLutOrNotAnd);
+                    }
+                }
+            }
+        }
+        // (2) the other positions: the match word of every possible symbol (11 x GW VALU, shared by all
+        // candidates); a candidate then picks its word by a wave-uniform register index
+        {
+            uint32_t rem = diff;
+#pragma unroll 1
+            while (rem) {
+                int js[D]; bool has[D];
+                uint32_t pl[D][4][GW], sws[D];
+#pragma unroll
+                for (int u = 0; u < D; u++) {
+                    has[u] = rem != 0u;
+                    js[u] = has[u] ? __builtin_ctz(rem) : js[0];
+                    rem &= rem - 1u;
+                    const uint32_t *P = Pw + (size_t)js[u] * 4 * nw32;
+#pragma unroll
+                    for (int b = 0; b < 4; b++)
+#pragma unroll
+                        for (int i = 0; i < GW; i++) pl[u][b][i] = P[b * nw32 + i];
+                    sws[u] = symrow[js[u]];
+                }
+#pragma unroll
+                for (int u = 0; u < D; u++) {
+                    if (!has[u]) break;
+                    const uint32_t sw = __builtin_amdgcn_readfirstlane(sws[u]);
+                    const bool jF = (A.sF >> js[u]) & 1u, jR = (A.sR >> js[u]) & 1u;
+                    uint32_t tab[16][GW];
+#pragma unroll
+                    for (int i = 0; i < GW; i++) {
+                        const uint32_t a = pl[u][0][i], cc = pl[u][1][i], g = pl[u][2][i], t = pl[u][3][i];
+                        tab[0][i] = 0u;
+                        tab[1][i] = a; tab[2][i] = cc; tab[4][i] = g; tab[8][i] = t;
+                        tab[3][i] = a | cc; tab[5][i] = a | g; tab[9][i] = a | t;
+                        tab[6][i] = cc | g; tab[10][i] = cc | t; tab[12][i] = g | t;
+                        tab[7][i] = __builtin_amdgcn_bitop3_b32(a, cc, g, kLutOr3);
+                        tab[11][i] = __builtin_amdgcn_bitop3_b32(a, cc, t, kLutOr3);
+                        tab[13][i] = __builtin_amdgcn_bitop3_b32(a, g, t, kLutOr3);
+                        tab[14][i] = __builtin_amdgcn_bitop3_b32(cc, g, t, kLutOr3);
+                        tab[15][i] = tab[3][i] | tab[12][i];
+                    }
+                    uint32_t m[CC][GW];
+#pragma unroll
+                    for (int c = 0; c < CC; c++) {
+                        const uint32_t sy = (sw >> (4 * c)) & 15u;
+#pragma unroll
+                        for (int i = 0; i < GW; i++) m[c][i] = tab[sy][i];
+#pragma unroll
+                        for (int i = 0; i < GW; i++) count_unmatched<LV>(t1[c][i], t2[c][i], t3[c][i], m[c][i]);
+                    }
+                    if (jF) {
+#pragma unroll
+                        for (int c = 0; c < CC; c++)
+#pragma unroll
+                            for (int i = 0; i < GW; i++) sf[c][i] = __builtin_amdgcn_bitop3_b32(sf[c][i], m[c][i], m[c][i], kLutOrNot);
+                    }
+                    if (jR) {
+#pragma unroll
+                        for (int c = 0; c < CC; c++)
+#pragma unroll
+                            for (int i = 0; i < GW; i++) sr[c][i] = __builtin_amdgcn_bitop3_b32(sr[c][i], m[c][i], m[c][i], kLutOrNot);
+                    }
+                }
+            }
+        }
+        const uint32_t *E = reinterpret_cast<const uint32_t *>(A.excl) + (size_t)it.win * nw32 + word0;
+#pragma unroll
+        for (int i = 0; i < GW; i++) {
+            const uint32_t valid = ~E[i];
+#pragma unroll
+            for (int c = 0; c < CC; c++) {
+                // exact saturating sum of the shared and the per-candidate counters
+                const uint32_t a1 = t1[c][i] | c1[i];
+                uint32_t far = a1;
+                if (LV >= 2) far = t2[c][i] | c2[i] | (t1[c][i] & c1[i]);
+                if (LV >= 3) far = t3[c][i] | c3[i] | (t2[c][i] & c1[i]) | (t1[c][i] & c2[i]);
+                const uint32_t bf = sf[c][i] | csf[i], br = sr[c][i] | csr[i];
+                accP[c] += __popc(valid & ~a1);
+                accF[c] += __popc(__builtin_amdgcn_bitop3_b32(valid, far, bf, kLutAndNotNot));
+                accR[c] += __popc(__builtin_amdgcn_bitop3_b32(valid, far, br, kLutAndNotNot));
+            }
+        }
+    }
+    block_commit<GW>(accP, accF, accR, s_part, A.cand_out + it.cand0, A.out);
+}
+
+// ----------------------------------------------------------------------------------------------
+// (4c) bit-sliced evaluation of a NESTED chain: the candidates of the item, ordered from the most degenerate
+// one down, each accept a subset of what the previous one accepts (a refinement chain read backwards).  Then
+// the mismatch counters of candidate s are those of candidate s-1 plus, for every position whose symbol lost
+// bases in between, one bit plane d = "the sequence's base is one of the lost ones" — for one lost base that is
+// the base's column plane as loaded.  Counters only ever grow, so saturating bit-sliced counters stay exact.
+// Work per 32 sequences at v = 1: k positions once (1 load + 2-4 VALU each, for the first candidate) + 1 load and
+// 2-4 VALU per event + 6 VALU per candidate, against 4 loads and ~45 VALU per position in the symbol-table kernel.
+// ----------------------------------------------------------------------------------------------
+struct EvalChainArgs {
+    const unsigned long long *cols;    // [n_cols][4][nw]
+    const unsigned long long *excl;    // [W][nw]
+    int nw, p0, k, v;
+    const ChainItem *items;
+    const uint32_t *events;            // position | lost base (one-hot) << 8 | step << 16, ascending by step
+    const int32_t *cand_out;
+    uint32_t sF, sR;
+    unsigned long long *out;
+    BlockMap map;
+    EvalListArgs list;                 // patch / IUPAC rows riding in the first list.n_blocks workgroups
+};
+
+// One pass of the first candidate over the positions in `rem` whose symbol has NB bases (NB = 4: three or four,
+// all planes loaded and masked).  D positions of loads are requested before the first one is consumed; no other
+// load sits in between, so each position waits for exactly its own words.
+template <int LV, int GW, int D, int NB>
+__device__ __forceinline__ void chain_first_pass(uint32_t rem, const uint32_t *Pw, size_t nw32, unsigned long long sy_lo,
+                                                 unsigned long long sy_hi, uint32_t sF, uint32_t sR, uint32_t (&t1)[GW],
+                                                 uint32_t (&t2)[GW], uint32_t (&t3)[GW], uint32_t (&sf)[GW], uint32_t (&sr)[GW]) {
+#pragma unroll 1
+    while (rem) {
+        int js[D]; bool has[D];
+        uint32_t ld[D][NB][GW], sys[D];
+#pragma unroll
+        for (int u = 0; u < D; u++) {
+            has[u] = rem != 0u;
+            js[u] = has[u] ? __builtin_ctz(rem) : js[0];
+            rem &= rem - 1u;
+            const int j = js[u];
+            const uint32_t sy = (uint32_t)((j < 16 ? sy_lo : sy_hi) >> (4 * (j & 15))) & 15u;
+            sys[u] = sy;
+            const uint32_t *P = Pw + (size_t)j * 4 * nw32;
+            if (NB == 4) {
+#pragma unroll
+                for (int b = 0; b < 4; b++)
+#pragma unroll
+                    for (int i = 0; i < GW; i++) ld[u][b][i] = P[b * nw32 + i];
+            } else {
+                const uint32_t second = sy & (sy - 1u);
+                const size_t b0 = (size_t)__builtin_ctz(sy | 16u), b1 = (size_t)__builtin_ctz(second | 16u);
+#pragma unroll
+                for (int i = 0; i < GW; i++) {
+                    ld[u][0][i] = P[b0 * nw32 + i];
+                    if (NB == 2) ld[u][1][i] = P[b1 * nw32 + i];
+                }
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < D; u++) {
+            if (!has[u]) break;
+            const int j = js[u];
+            uint32_t m[GW];
+            if (NB == 4) {
+                const uint32_t sy = sys[u];
+                const uint32_t kA = (sy & 1u) ? 0xFFFFFFFFu : 0u, kC = (sy & 2u) ? 0xFFFFFFFFu : 0u;
+                const uint32_t kG = (sy & 4u) ? 0xFFFFFFFFu : 0u, kT = (sy & 8u) ? 0xFFFFFFFFu : 0u;
+#pragma unroll
+                for (int i = 0; i < GW; i++) {
+                    m[i] = ld[u][0][i] & kA;
+                    m[i] = __builtin_amdgcn_bitop3_b32(ld[u][1][i], kC, m[i], kLutAndOr);
+                    m[i] = __builtin_amdgcn_bitop3_b32(ld[u][2][i], kG, m[i], kLutAndOr);
+                    m[i] = __builtin_amdgcn_bitop3_b32(ld[u][3][i], kT, m[i], kLutAndOr);
+                }
+            } else {
+#pragma unroll
+                for (int i = 0; i < GW; i++) m[i] = NB == 2 ? (ld[u][0][i] | ld[u][1][i]) : ld[u][0][i];
+            }
+#pragma unroll
+            for (int i = 0; i < GW; i++) count_unmatched<LV>(t1[i], t2[i], t3[i], m[i]);
+            if (((sF | sR) >> j) & 1u) {
+                const uint32_t fF = ((sF >> j) & 1u) ? 0xFFFFFFFFu : 0u, fR = ((sR >> j) & 1u) ? 0xFFFFFFFFu : 0u;
+#pragma unroll
+                for (int i = 0; i < GW; i++) {
+                    sf[i] = __builtin_amdgcn_bitop3_b32(sf[i], m[i], fF, kLutOrNotAnd);
+                    sr[i] = __builtin_amdgcn_bitop3_b32(sr[i], m[i], fR, kLutOrNotAnd);
+                }
+            }
+        }
+    }
+}
+
+template <int LV, int GW, int D>
+__global__ __launch_bounds__(kBlock) void eval_chain_kernel(const EvalChainArgs A) {
+    constexpr int CC = 8;
+    __shared__ uint32_t s_part[kBlock / 64][3 * CC / 2];
+    if ((int)blockIdx.x < A.list.n_blocks) {
+        if ((int)blockIdx.x < A.list.ny * A.list.n_items)
+            eval_list_block<CC, LV - 1>(A.list, blockIdx.x / A.list.ny, blockIdx.x % A.list.ny, &s_part[0][0]);
+        return;
+    }
+    int slice, item;
+    if (!map_block(A.map, blockIdx.x - A.list.n_blocks, slice, item)) return;
+    const ChainItem it = A.items[item];
+    const size_t nw32 = (size_t)A.nw * 2;
+    const int word0 = (slice * kBlock + threadIdx.x) * GW;
+    const bool live = word0 < (int)nw32;
+    const uint32_t *cols = reinterpret_cast<const uint32_t *>(A.cols);
+    uint32_t accP[CC], accF[CC], accR[CC];
+#pragma unroll
+    for (int c = 0; c < CC; c++) accP[c] = accF[c] = accR[c] = 0;
+    if (live) {
+        uint32_t t1[GW], t2[GW], t3[GW], sf[GW], sr[GW];
+#pragma unroll
+        for (int i = 0; i < GW; i++) t1[i] = t2[i] = t3[i] = sf[i] = sr[i] = 0;
+        const uint32_t *Pw = cols + ((size_t)(A.p0 + it.win) * 4) * nw32 + word0;
+        const unsigned long long sy_lo = it.sym[0] | ((unsigned long long)it.sym[1] << 32);
+        const unsigned long long sy_hi = it.sym[2] | ((unsigned long long)it.sym[3] << 32);
+        // (1) the first candidate over all k positions, grouped by the number of bases of its symbol there
+        chain_first_pass<LV, GW, D, 1>(it.pos1, Pw, nw32, sy_lo, sy_hi, A.sF, A.sR, t1, t2, t3, sf, sr);
+        chain_first_pass<LV, GW, (D + 1) / 2, 2>(it.pos2, Pw, nw32, sy_lo, sy_hi, A.sF, A.sR, t1, t2, t3, sf, sr);
+        chain_first_pass<LV, GW, (D + 3) / 4, 4>(it.pos4, Pw, nw32, sy_lo, sy_hi, A.sF, A.sR, t1, t2, t3, sf, sr);
+        uint32_t valid[GW];
+        {
+            const uint32_t *E = reinterpret_cast<const uint32_t *>(A.excl) + (size_t)it.win * nw32 + word0;
+#pragma unroll
+            for (int i = 0; i < GW; i++) valid[i] = ~E[i];
+        }
+        // (2) walk down the chain: apply the events of step s, then count candidate s
+        const uint32_t *ev = A.events + it.ev0;
+        int e = 0;
+        uint32_t evw = it.n_ev ? ev[0] : (1u << 8);
+        uint32_t cur[GW];
+        {
+            const uint32_t *P = Pw + ((size_t)(evw & 255u) * 4 + (size_t)__builtin_ctz(((evw >> 8) & 15u) | 16u)) * nw32;
+#pragma unroll
+            for (int i = 0; i < GW; i++) cur[i] = P[i];
+        }
+#pragma unroll
+        for (int s = 0; s < CC; s++) {
+            if (s >= it.n_steps) break;
+            if (s > 0) {
+#pragma unroll 1
+                while (e < it.n_ev && (int)(evw >> 16) == s) {
+                    e++;
+                    const uint32_t evn = e < it.n_ev ? ev[e] : evw;          // the plane of the next event is on its way
+                    uint32_t nxt[GW];
+                    {
+                        const uint32_t *P = Pw + ((size_t)(evn & 255u) * 4 + (size_t)__builtin_ctz(((evn >> 8) & 15u) | 16u)) * nw32;
+#pragma unroll
+                        for (int i = 0; i < GW; i++) nxt[i] = P[i];
+                    }
+                    const uint32_t j = evw & 255u;
+#pragma unroll
+                    for (int i = 0; i < GW; i++) count_plane<LV>(t1[i], t2[i], t3[i], cur[i]);
+                    if (((A.sF | A.sR) >> j) & 1u) {
+                        const uint32_t fF = ((A.sF >> j) & 1u) ? 0xFFFFFFFFu : 0u, fR = ((A.sR >> j) & 1u) ? 0xFFFFFFFFu : 0u;
+#pragma unroll
+                        for (int i = 0; i < GW; i++) {
+                            sf[i] = __builtin_amdgcn_bitop3_b32(sf[i], cur[i], fF, kLutOrAnd);
+                            sr[i] = __builtin_amdgcn_bitop3_b32(sr[i], cur[i], fR, kLutOrAnd);
+                        }
+                    }
+#pragma unroll
+                    for (int i = 0; i < GW; i++) cur[i] = nxt[i];
+                    evw = evn;
+                }
+            }
+#pragma unroll
+            for (int i = 0; i < GW; i++) {
+                const uint32_t far = LV == 1 ? t1[i] : (LV == 2 ? t2[i] : t3[i]);
+                accP[s] += __popc(valid[i] & ~t1[i]);
+                accF[s] += __popc(__builtin_amdgcn_bitop3_b32(valid[i], far, sf[i], kLutAndNotNot));
+                accR[s] += __popc(__builtin_amdgcn_bitop3_b32(valid[i], far, sr[i], kLutAndNotNot));
+            }
+        }
+    }
+    block_commit<GW>(accP, accF, accR, s_part, A.cand_out + it.cand0, A.out);
+}
 
 // Per-sequence coverage masks (mp_eval_masks): thread = sequence, the wave's 64 "not covered" bits
 // go out as one 64-bit word per candidate straight from the ballot (blocks are 64-row aligned), so
@@ -462,7 +740,7 @@ __global__ __launch_bounds__(kBlock) void mask_rows_kernel(const EvalArgs A, int
 }
 
 typedef void (*EvalBitsFn)(const EvalBitsArgs);
-typedef void (*EvalListFn)(const EvalListArgs);
+typedef void (*EvalChainFn)(const EvalChainArgs);
 
 typedef void (*EvalFn)(const EvalArgs);
 struct EvalVariant { const char *name; EvalFn fn[2][3]; };     // fn[P64][VMODE]
@@ -497,36 +775,116 @@ int mp_eval_upload(mp_ctx *c, int32_t n_cand, const int32_t *cw, const uint8_t *
     const uint32_t kmask = (1u << k) - 1u;
     std::vector<EvalItem> items;
     std::vector<uint4> cn;
-    std::vector<int32_t> co;
-    std::vector<uint32_t> symT;
+    std::vector<int32_t> co, table_ids;
+    std::vector<uint32_t> symT, diffm, events;
+    std::vector<ChainItem> chains;
+    // grouping policy (MP_EVAL_GROUP): "plain" = 8 consecutive candidates per item, symbol-table kernel; "nested" =
+    // always split into nested runs; default = whichever the per-window cost model (VALU per 32 sequences) prefers
+    const char *genv = getenv("MP_EVAL_GROUP");
+    const int policy = genv ? (!strcmp(genv, "plain") ? 1 : (!strcmp(genv, "nested") ? 2 : 0)) : 0;
+    struct Run { int b, e; bool asc; int n_ev; };
+    auto sym_at = [&](int ci, int p) { return (uint32_t)(codes[(size_t)ci * k + p] & 15u); };
+    auto diff_of = [&](int b, int e) {
+        uint32_t dm = 0;
+        for (int p = 0; p < k; p++)
+            for (int ci = b + 1; ci < e; ci++)
+                if (sym_at(ci, p) != sym_at(b, p)) dm |= 1u << p;
+        return dm;
+    };
+    // one item = up to 8 slots; `order` lists its candidates (for a nested run: most degenerate first)
+    auto emit = [&](int w, const std::vector<int> &order, bool nested) {
+        const int n = (int)order.size();
+        const int item = (int)items.size();
+        items.push_back(EvalItem{w, (int32_t)cn.size()});
+        symT.resize(items.size() * 32, 0u);
+        uint32_t dm = 0;
+        for (int p = 0; p < k; p++)
+            for (int t = 1; t < n; t++)
+                if (sym_at(order[t], p) != sym_at(order[0], p)) dm |= 1u << p;
+        diffm.push_back(dm);
+        if (nested) {
+            ChainItem ch{w, (int32_t)cn.size(), n, (int32_t)events.size(), 0, {0u, 0u, 0u, 0u}, 0u, 0u, 0u};
+            for (int p = 0; p < k; p++) {
+                const uint32_t sy = sym_at(order[0], p);
+                ch.sym[p >> 3] |= sy << (4 * (p & 7));
+                const int nb = __builtin_popcount(sy);
+                (nb == 1 ? ch.pos1 : (nb == 2 ? ch.pos2 : ch.pos4)) |= 1u << p;
+            }
+            for (int t = 1; t < n; t++)
+                for (int p = 0; p < k; p++) {
+                    const uint32_t lost = sym_at(order[t - 1], p) & ~sym_at(order[t], p);
+                    for (uint32_t bit = 1; bit < 16; bit <<= 1)      // one event per lost base: its column plane IS the increment
+                        if (lost & bit) events.push_back((uint32_t)p | (bit << 8) | ((uint32_t)t << 16));
+                }
+            ch.n_ev = (int32_t)events.size() - ch.ev0;
+            chains.push_back(ch);
+        } else {
+            table_ids.push_back(item);
+        }
+        for (int t = 0; t < kEvalCC; t++) {
+            const int ci = t < n ? order[t] : order[n - 1];      // an unused slot repeats the last candidate, reports nowhere
+            uint32_t nA = 0, nC = 0, nG = 0, nT = 0;
+            for (int p = 0; p < k; p++) {
+                const uint32_t m = sym_at(ci, p);
+                if (!(m & 1)) nA |= 1u << p;
+                if (!(m & 2)) nC |= 1u << p;
+                if (!(m & 4)) nG |= 1u << p;
+                if (!(m & 8)) nT |= 1u << p;
+                symT[(size_t)item * 32 + (size_t)p] |= m << (4 * t);
+            }
+            if (t < n) { cn.push_back(uint4{nA, nC, nG, nT}); co.push_back(ci); }
+            else { cn.push_back(uint4{kmask, kmask, kmask, kmask}); co.push_back(-1); }
+        }
+    };
     int i = 0;
+    std::vector<Run> runs;
+    std::vector<int> order;
     while (i < n_cand) {
         int w = cw[i];
         if (w < 0 || w >= c->n_win || (i && w < cw[i - 1])) return fail(c, MP_ERR_ARG, "candidate windows must be ascending and in range");
         int j = i;
         while (j < n_cand && cw[j] == w) j++;
-        for (int b = i; b < j; b += kEvalCC) {
-            items.push_back(EvalItem{w, (int32_t)cn.size()});
-            symT.resize(items.size() * 32, 0u);
-            for (int t = 0; t < kEvalCC; t++) {
-                int ci = b + t;
-                if (ci < j) {
-                    uint32_t nA = 0, nC = 0, nG = 0, nT = 0;
-                    for (int p = 0; p < k; p++) {
-                        uint8_t m = codes[(size_t)ci * k + p];
-                        if (!(m & 1)) nA |= 1u << p;
-                        if (!(m & 2)) nC |= 1u << p;
-                        if (!(m & 4)) nG |= 1u << p;
-                        if (!(m & 8)) nT |= 1u << p;
-                    }
-                    cn.push_back(uint4{nA, nC, nG, nT});
-                    co.push_back(ci);
-                    for (int p = 0; p < k; p++)
-                        symT[(items.size() - 1) * 32 + (size_t)p] |= (uint32_t)(codes[(size_t)ci * k + p] & 15u) << (4 * t);
-                } else {
-                    cn.push_back(uint4{kmask, kmask, kmask, kmask});
-                    co.push_back(-1);
+        // maximal runs of consecutive candidates that are nested in one direction (a refinement chain, either way round)
+        runs.clear();
+        long cost_nested = 0, cost_plain = 0;
+        bool has_empty = false;                     // a candidate with an empty symbol (matches nothing): symbol-table kernel only
+        for (int b = i; b < j;) {
+            int e = b + 1, dir = 3, n_ev = 0;
+            while (e < j && e - b < kEvalCC) {
+                int rel = 3, changed = 0;
+                for (int p = 0; p < k; p++) {
+                    const uint32_t x = sym_at(e - 1, p), y = sym_at(e, p);
+                    if (x & ~y) rel &= ~1;           // not "previous within next"
+                    if (y & ~x) rel &= ~2;           // not "next within previous"
+                    changed += x != y;
                 }
+                if (!(dir & rel)) break;
+                dir &= rel; n_ev += changed; e++;
+            }
+            for (int ci = b; ci < e; ci++)
+                for (int p = 0; p < k; p++)
+                    if (!sym_at(ci, p)) has_empty = true;
+            runs.push_back(Run{b, e, (dir & 2) == 0, n_ev});
+            cost_nested += 4L * k + 4L * n_ev + 6L * (e - b) + 40;
+            b = e;
+        }
+        for (int b = i; b < j; b += kEvalCC) {
+            const int nd = __builtin_popcount(diff_of(b, std::min(j, b + kEvalCC)));
+            cost_plain += 45L * nd + 8L * (k - nd) + 136 + 40;
+        }
+        const bool use_nested = !has_empty && (policy == 2 || (policy == 0 && cost_nested <= cost_plain));
+        if (use_nested) {
+            for (const Run &r : runs) {
+                order.clear();
+                if (r.asc) for (int ci = r.e - 1; ci >= r.b; ci--) order.push_back(ci);
+                else for (int ci = r.b; ci < r.e; ci++) order.push_back(ci);
+                emit(w, order, true);
+            }
+        } else {
+            for (int b = i; b < j; b += kEvalCC) {
+                order.clear();
+                for (int ci = b; ci < j && ci < b + kEvalCC; ci++) order.push_back(ci);
+                emit(w, order, false);
             }
         }
         i = j;
@@ -541,6 +899,19 @@ int mp_eval_upload(mp_ctx *c, int32_t n_cand, const int32_t *cw, const uint8_t *
     if ((rc = dev_alloc(c, &c->cand_out, co.size()))) return rc;
     if ((rc = dev_alloc(c, &c->cand_symT, symT.size()))) return rc;
     HIPCK(c, hipMemcpy(c->cand_symT, symT.data(), sizeof(uint32_t) * symT.size(), hipMemcpyHostToDevice));
+    if ((rc = dev_alloc(c, &c->cand_diff, diffm.size()))) return rc;
+    HIPCK(c, hipMemcpy(c->cand_diff, diffm.data(), sizeof(uint32_t) * diffm.size(), hipMemcpyHostToDevice));
+    c->n_chain = (int)chains.size(); c->n_table = (int)table_ids.size(); c->n_events = (int)events.size();
+    if (c->n_chain) {
+        if ((rc = dev_alloc(c, &c->chain_items, chains.size()))) return rc;
+        HIPCK(c, hipMemcpy(c->chain_items, chains.data(), sizeof(ChainItem) * chains.size(), hipMemcpyHostToDevice));
+        if ((rc = dev_alloc(c, &c->chain_events, events.size() + 1))) return rc;      // + 1: never a null pointer
+        if (!events.empty()) HIPCK(c, hipMemcpy(c->chain_events, events.data(), sizeof(uint32_t) * events.size(), hipMemcpyHostToDevice));
+    }
+    if (c->n_table) {
+        if ((rc = dev_alloc(c, &c->table_ids, table_ids.size()))) return rc;
+        HIPCK(c, hipMemcpy(c->table_ids, table_ids.data(), sizeof(int32_t) * table_ids.size(), hipMemcpyHostToDevice));
+    }
     HIPCK(c, hipMemcpy(c->items, items.data(), sizeof(EvalItem) * items.size(), hipMemcpyHostToDevice));
     HIPCK(c, hipMemcpy(c->cand_n, cn.data(), sizeof(uint4) * cn.size(), hipMemcpyHostToDevice));
     HIPCK(c, hipMemcpy(c->cand_out, co.data(), sizeof(int32_t) * co.size(), hipMemcpyHostToDevice));
@@ -569,28 +940,64 @@ int mp_eval_launch(mp_ctx *c, int64_t *device_out) {
     const int vmode = c->v == 0 ? 0 : (c->v == 1 ? 1 : 2);     // predicate specialisation of the row-per-lane code
     if (bits) {
         // bit-sliced pass over the column planes + row-per-lane pass over the patch / IUPAC lists
-        // kernel shape (MP_EVAL_BITS): 0 = 8 candidates x 2 words (64 sequences) per thread (default),
-        // 1 = the same with the next position's planes prefetched, 2 = 8 x 1 word
+        // MP_EVAL_BITS: 0 (default) = nested-chain kernel on the nested items + symbol-table kernel (with the shared-
+        // position shortcut) on the others; 1 = symbol-table kernel on every item, no shortcut; 2 = the same with it
         int shape = 0;
         if (const char *e = getenv("MP_EVAL_BITS")) { shape = atoi(e); if (shape < 0 || shape > 2) shape = 0; }
-        static const int shape_gw[3] = {2, 2, 1};
         const int nw = c->n_pad / 64;
-        const int GW = shape_gw[shape];
-        const int ny = std::max(1, (2 * nw / GW + kBlock - 1) / kBlock);
-        const int ny_pad = (ny + 7) / 8 * 8;
-        EvalBitsArgs ba{c->cols, c->excl, nw, c->p0, c->k, c->v, c->items, c->cand_symT, c->cand_out, c->sF, c->sR,
-                        (unsigned long long *)device_out, ny, ny_pad};
-#define BITS_ROW(LV) {eval_bits_kernel<8, LV, 2, false>, eval_bits_kernel<8, LV, 2, true>, eval_bits_kernel<8, LV, 1, false>}
-        static const EvalBitsFn bfn[3][3] = {BITS_ROW(1), BITS_ROW(2), BITS_ROW(3)};
-#undef BITS_ROW
-        hipLaunchKernelGGL(bfn[c->v][shape], dim3((unsigned)((size_t)c->n_items * ny_pad)), dim3(kBlock), 0, c->stream, ba);
+        auto block_map = [&](int GW, int n_items, unsigned &grid) {
+            BlockMap m;
+            m.ny = std::max(1, (2 * nw / GW + kBlock - 1) / kBlock);
+            m.ny_pad = m.ny > 4 ? (m.ny + 7) / 8 * 8 : (m.ny > 2 ? 4 : m.ny);
+            m.n_items = n_items;
+            const int bands = m.ny_pad >= 8 ? 1 : 8 / m.ny_pad;
+            m.per_band = (n_items + bands - 1) / bands;
+            grid = m.ny_pad >= 8 ? (unsigned)((size_t)n_items * m.ny_pad) : (unsigned)(8 * (size_t)m.per_band);
+            return m;
+        };
+        // the patch / IUPAC rows ride in the first bit-sliced launch
+        EvalListArgs la{c->items, c->cand_n, c->cand_out, c->n_patch ? c->patch_off : (const int32_t *)nullptr, c->patch_words,
+                        c->n_extra ? c->extra_off : (const int32_t *)nullptr, c->extra_words, c->sF, c->sR, c->v,
+                        (1u << c->k) - 1u, (unsigned long long *)device_out, 0, 0, c->n_items};
         if (c->n_patch || c->n_extra) {
-            EvalListArgs la{c->items, c->cand_n, c->cand_out, c->n_patch ? c->patch_off : (const int32_t *)nullptr, c->patch_words,
-                            c->n_extra ? c->extra_off : (const int32_t *)nullptr, c->extra_words, c->sF, c->sR, c->v,
-                            (1u << c->k) - 1u, (unsigned long long *)device_out};
-            static const EvalListFn lfn[3] = {eval_list_kernel<kEvalCC, 0>, eval_list_kernel<kEvalCC, 1>, eval_list_kernel<kEvalCC, 2>};
-            int ly = std::max(1, std::min(64, (c->max_patch + 2047) / 2048));
-            hipLaunchKernelGGL(lfn[vmode], dim3((unsigned)c->n_items, (unsigned)ly), dim3(kBlock), 0, c->stream, la);
+            la.ny = std::max(1, std::min(64, (c->max_patch + 2047) / 2048));
+            la.n_blocks = (la.ny * c->n_items + 7) / 8 * 8;
+        }
+        EvalListArgs no_list = la;
+        no_list.ny = no_list.n_blocks = 0;
+        bool list_done = la.n_blocks == 0;
+        static const EvalBitsFn tfn[3][2] = {{eval_bits_kernel<1, 2, true, 1>, eval_bits_kernel<1, 2, false, 1>},
+                                             {eval_bits_kernel<2, 2, true, 1>, eval_bits_kernel<2, 2, false, 1>},
+                                             {eval_bits_kernel<3, 2, true, 1>, eval_bits_kernel<3, 2, false, 1>}};
+        if (shape == 0 && c->n_chain) {
+            // words per thread x positions in flight: the more sequences a block covers, the further its fixed costs
+            // (24 popcount totals, item and event fetches) are spread — 8 x 2 from 32768 sequences up (half a block of
+            // threads at that size), 4 x 3 from 16384, else 2 x 6 / 1 x 6.  MP_EVAL_CHAIN overrides (tools/variant_bench.py).
+            const int nw32 = 2 * nw;
+            int cshape = nw32 >= 4 * kBlock ? 6 : (nw32 >= 2 * kBlock ? 3 : (nw32 >= kBlock ? 0 : 5));
+            if (const char *e = getenv("MP_EVAL_CHAIN")) { cshape = atoi(e); if (cshape < 0 || cshape > 9) cshape = 0; }
+            static const int cgw[10] = {2, 2, 2, 4, 4, 1, 8, 8, 8, 16};
+#define CHAIN_ROW(LV) {eval_chain_kernel<LV, 2, 6>, eval_chain_kernel<LV, 2, 3>, eval_chain_kernel<LV, 2, 9>, eval_chain_kernel<LV, 4, 3>, \
+                       eval_chain_kernel<LV, 4, 6>, eval_chain_kernel<LV, 1, 6>, eval_chain_kernel<LV, 8, 2>, eval_chain_kernel<LV, 8, 4>, \
+                       eval_chain_kernel<LV, 8, 1>, eval_chain_kernel<LV, 16, 1>}
+            static const EvalChainFn cfn[3][10] = {CHAIN_ROW(1), CHAIN_ROW(2), CHAIN_ROW(3)};
+#undef CHAIN_ROW
+            unsigned grid;
+            const BlockMap bm = block_map(cgw[cshape], c->n_chain, grid);
+            EvalChainArgs ca{c->cols, c->excl, nw, c->p0, c->k, c->v, c->chain_items, c->chain_events, c->cand_out, c->sF, c->sR,
+                             (unsigned long long *)device_out, bm, list_done ? no_list : la};
+            hipLaunchKernelGGL(cfn[c->v][cshape], dim3(grid + (unsigned)ca.list.n_blocks), dim3(kBlock), 0, c->stream, ca);
+            list_done = true;
+        }
+        const int n_tab = shape == 0 ? c->n_table : c->n_items;
+        if (n_tab) {
+            unsigned grid;
+            const BlockMap bm = block_map(2, n_tab, grid);
+            EvalBitsArgs ba{c->cols, c->excl, nw, c->p0, c->k, c->v, c->items, c->cand_symT, c->cand_out, c->sF, c->sR,
+                            (unsigned long long *)device_out, bm, c->cand_diff, shape == 0 ? c->table_ids : (const int32_t *)nullptr,
+                            list_done ? no_list : la};
+            hipLaunchKernelGGL(tfn[c->v][shape == 1 ? 1 : 0], dim3(grid + (unsigned)ba.list.n_blocks), dim3(kBlock), 0, c->stream, ba);
+            list_done = true;
         }
     } else {
     EvalArgs ea{c->win, c->n_pad, c->k, c->items, c->cand_n, c->cand_out, c->n_extra ? c->extra_off : (const int32_t *)nullptr,

@@ -108,10 +108,11 @@ __global__ __launch_bounds__(kBlock) void ungap_kernel(const uint32_t *__restric
     atomicOr(dst + widx, word);
 }
 
-// Column planes for the bit-sliced evaluation: cols[col][3][Npad/64] u64, bit r%64 of word r/64 =
-// sequence r; planes b0, b1 (2-bit base, 0 where gap) and g (gap / beyond the row's end).  IUPAC
-// symbols produce arbitrary b0/b1 here: windows that touch one are always routed to the
-// general path (patch list), never to the bit-sliced pass.
+// Column planes for the bit-sliced evaluation: cols[col][4][Npad/64] u64, bit r%64 of word r/64 =
+// sequence r; one plane per base (A, C, G, T), all four clear where the sequence has a gap or has
+// ended.  A concrete candidate symbol then needs ONE plane per position ("matches" = that plane), a
+// degenerate one the OR of its bases' planes.  IUPAC residues set several planes: windows that touch
+// one are always routed to the general path (patch list), never to the bit-sliced pass.
 __global__ __launch_bounds__(kBlock) void colplane_kernel(const uint32_t *__restrict__ planes, int n_pad, int n_chunks,
                                                           unsigned long long *__restrict__ cols) {
     const int r = blockIdx.x * kBlock + threadIdx.x;     // n_pad is a multiple of kBlock: every lane is live
@@ -119,13 +120,13 @@ __global__ __launch_bounds__(kBlock) void colplane_kernel(const uint32_t *__rest
     const size_t np = (size_t)n_pad, nw = np / 64;
     const size_t base = ((size_t)c * 4) * np + r;
     const uint32_t mA = planes[base], mC = planes[base + np], mG = planes[base + 2 * np], mT = planes[base + 3 * np];
-    const uint32_t b0 = mC | mT, b1 = mG | mT, ng = mA | mC | mG | mT;
     const int lane = threadIdx.x & 63;
     for (int j = 0; j < 32; j++) {
-        unsigned long long x0 = __ballot((b0 >> j) & 1u), x1 = __ballot((b1 >> j) & 1u), xg = __ballot(!((ng >> j) & 1u));
+        unsigned long long xA = __ballot((mA >> j) & 1u), xC = __ballot((mC >> j) & 1u);
+        unsigned long long xG = __ballot((mG >> j) & 1u), xT = __ballot((mT >> j) & 1u);
         if (lane == 0) {
-            unsigned long long *dst = cols + ((size_t)(c * 32 + j) * 3) * nw + (size_t)(r >> 6);
-            dst[0] = x0; dst[nw] = x1; dst[2 * nw] = xg;
+            unsigned long long *dst = cols + ((size_t)(c * 32 + j) * 4) * nw + (size_t)(r >> 6);
+            dst[0] = xA; dst[nw] = xC; dst[2 * nw] = xG; dst[3 * nw] = xT;
         }
     }
 }
@@ -167,7 +168,7 @@ int mp_load_msa(mp_ctx *c, const uint8_t *bytes, const int64_t *row_off, int32_t
     if ((rc = dev_alloc(c, &d_bytes, (size_t)total + 64))) return rc;
     if ((rc = dev_alloc(c, &d_off, (size_t)n_rows + 1))) return rc;
     if ((rc = dev_alloc(c, &c->planes, (size_t)c->n_chunks * 4 * np))) return rc;
-    if ((rc = dev_alloc(c, &c->cols, (size_t)c->n_chunks * 32 * 3 * (np / 64)))) return rc;
+    if ((rc = dev_alloc(c, &c->cols, (size_t)c->n_chunks * 32 * 4 * (np / 64)))) return rc;
     if ((rc = dev_alloc(c, &c->cum, ((size_t)c->n_chunks + 1) * np))) return rc;
     if ((rc = dev_alloc(c, &c->ung, (size_t)n_rows * c->ustride))) return rc;
     if ((rc = dev_alloc(c, &c->lead, np))) return rc;

@@ -69,7 +69,9 @@ __device__ int repair_window(uint32_t wA, uint32_t wC, uint32_t wG, uint32_t wT,
 
 // Rows whose k-mer is NOT the plain column slice (edge-gap repair, IUPAC, ragged end) are flagged per
 // (window, 64-row word) in `excl` and collected, per window, in a compact patch list of window words:
-// the bit-sliced evaluation skips them, the row-per-lane evaluation handles exactly them.
+// the bit-sliced evaluation skips them, the row-per-lane evaluation handles exactly them.  `excl` also
+// carries the plain rows with more than v gaps in the window (outside every count, V20:689) and the
+// padding rows, so the bit-sliced kernels need no gap bookkeeping of their own.
 // pass 0 writes the window words, the flags and the per-window patch counts; pass 1 (same
 // computation) fills the patch list once the host has turned the counts into offsets.
 struct PatchOut {
@@ -85,7 +87,7 @@ template <bool P64>
 __global__ __launch_bounds__(kBlock) void build_windows_kernel(
     const uint32_t *__restrict__ planes, const uint32_t *__restrict__ cum, const uint32_t *__restrict__ ung,
     const int32_t *__restrict__ rlen, int n_rows, int n_pad, int n_chunks, int ustride, int p0, int n_win, int tile,
-    int k, void *__restrict__ win, ExRec *__restrict__ ex, int ex_cap, int *__restrict__ ex_count,
+    int k, int v, void *__restrict__ win, ExRec *__restrict__ ex, int ex_cap, int *__restrict__ ex_count,
     int *__restrict__ err, PatchOut po) {
     int r = blockIdx.x * kBlock + threadIdx.x;
     if (r >= n_pad) return;
@@ -93,9 +95,13 @@ __global__ __launch_bounds__(kBlock) void build_windows_kernel(
     int w1 = w0 + tile < n_win ? w0 + tile : n_win;
     const uint32_t kmask = (1u << k) - 1u;
     const size_t np = (size_t)n_pad;
+    const unsigned long long real = __ballot(r < n_rows);
     if (r >= n_rows) {                       // padding rows never take part
         if (po.pass == 0)
-            for (int w = w0; w < w1; w++) WinView<P64>::store(win, w, np, r, 0, 0, MP_WIN_SKIP | kmask, k, kmask);
+            for (int w = w0; w < w1; w++) {
+                WinView<P64>::store(win, w, np, r, 0, 0, MP_WIN_SKIP | kmask, k, kmask);
+                if (real == 0ull && (threadIdx.x & 63) == 0) po.excl[(size_t)w * (np / 64) + (size_t)(r >> 6)] = ~0ull;
+            }
         return;
     }
     const int len = rlen[r];
@@ -146,7 +152,7 @@ __global__ __launch_bounds__(kBlock) void build_windows_kernel(
         {
             // flags and patch list; the lanes of a wave that are still here are all real rows
             const unsigned long long live = __ballot(true);
-            const unsigned long long flg = __ballot(!fast);
+            const unsigned long long flg = __ballot(!fast || __popc(g & kmask) > v) | ~real;
             const bool keep = !fast && !(g & MP_WIN_SKIP);
             const unsigned long long kp = __ballot(keep);
             const int lane = threadIdx.x & 63;
@@ -210,11 +216,11 @@ int mp_build_windows(mp_ctx *c, int32_t p0, int32_t n_win, int32_t k, int32_t v,
     auto launch = [&](const PatchOut &po, int ex_cap) {
         if (c->p64)
             hipLaunchKernelGGL(build_windows_kernel<true>, grid, dim3(kBlock), 0, c->stream, c->planes, c->cum, c->ung, c->rlen,
-                               c->n_rows, c->n_pad, c->n_chunks, c->ustride, p0, n_win, tile, k, c->win, c->ex, ex_cap,
+                               c->n_rows, c->n_pad, c->n_chunks, c->ustride, p0, n_win, tile, k, v, c->win, c->ex, ex_cap,
                                c->ex_count, c->err_flag, po);
         else
             hipLaunchKernelGGL(build_windows_kernel<false>, grid, dim3(kBlock), 0, c->stream, c->planes, c->cum, c->ung, c->rlen,
-                               c->n_rows, c->n_pad, c->n_chunks, c->ustride, p0, n_win, tile, k, c->win, c->ex, ex_cap,
+                               c->n_rows, c->n_pad, c->n_chunks, c->ustride, p0, n_win, tile, k, v, c->win, c->ex, ex_cap,
                                c->ex_count, c->err_flag, po);
     };
     for (int attempt = 0; attempt < 2; attempt++) {

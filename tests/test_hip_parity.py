@@ -176,3 +176,74 @@ def test_full_size_properties(hip_lib):
     whole = ctx.eval_candidates(cw, cand, 0b1100, 0b11 << 14)
     assert (parts[0] + parts[1] == whole).all()
     ctx.close()
+
+
+def chain_candidates(rng, root, W, k, kind):
+    """Structured candidate lists per window: refinement chains (each member adds bases to the previous one),
+    in either order, several chains back to back, duplicates, unrelated candidates, empty symbols."""
+    cw, codes = [], []
+    for w in range(W):
+        seed = np.array([1, 2, 4, 8], np.uint8)[rng.integers(0, 4, size=k)] if rng.random() < 0.3 else root[w: w + k].copy()
+        members = []
+        n_chains = 1 if kind in ("up", "down") else int(rng.integers(1, 4))
+        for _ in range(n_chains):
+            cur = seed.copy() if rng.random() < 0.7 else np.array([1, 2, 4, 8], np.uint8)[rng.integers(0, 4, size=k)]
+            chain = [cur.copy()]
+            for _ in range(int(rng.integers(0, 12))):
+                if rng.random() < 0.15:
+                    chain.append(cur.copy())                        # a repeated member
+                    continue
+                for _ in range(int(rng.integers(1, 3))):            # one or two positions widen in one step
+                    cur[rng.integers(0, k)] |= np.uint8(1 << rng.integers(0, 4))
+                chain.append(cur.copy())
+            if kind == "down" or (kind == "mixed" and rng.random() < 0.5):
+                chain.reverse()
+            members += chain
+        if kind == "mixed":
+            for _ in range(int(rng.integers(0, 4))):                # unrelated candidates in between
+                members.insert(int(rng.integers(0, len(members) + 1)), rng.integers(1, 16, size=k).astype(np.uint8))
+            if rng.random() < 0.2:
+                members[int(rng.integers(0, len(members)))][rng.integers(0, k)] = 0        # a symbol that matches nothing
+        cw += [w] * len(members)
+        codes += members
+    return np.asarray(cw, np.int32), np.asarray(codes, np.uint8)
+
+
+@pytest.mark.parametrize("n,v,kind", [(300, 1, "up"), (300, 2, "down"), (700, 0, "mixed"), (9000, 1, "mixed"),
+                                      (40000, 2, "mixed"), (40000, 1, "up"), (5000, 3, "mixed")])
+def test_candidate_grouping_paths_match_oracle(hip_lib, oracle_lib, monkeypatch, n, v, kind):
+    """mp_eval_candidates groups a window's candidates into nested runs (chain kernel) or plain groups of 8
+    (symbol-table kernel): every policy and kernel shape must give the oracle's counters."""
+    L, k, p0 = 120, 18, 4
+    data, off, _ = fuzz_msa(77 + n + v, n, L, ragged=False, p_gap=0.03, p_iupac=0.002)
+    W = L - p0 - k - 3
+    rng = np.random.default_rng(n * 7 + v)
+    root = np.array([1, 2, 4, 8], np.uint8)[rng.integers(0, 4, size=L)]
+    cw, codes = chain_candidates(rng, root, W, k, kind)
+    sF = sum(1 << y for y in (2, 3) if y < k)
+    sR = sum(1 << y for y in (2, k - 3, k - 2))
+    hip, ora = both(hip_lib, oracle_lib, data, off)
+    for c in (hip, ora):
+        n_ex = c.build_windows(p0, W, k, v)
+        if n_ex:
+            ew, er, ec = c.get_exceptions(n_ex)
+            raw = iupac.strings_of(iupac.SYMBOL_LUT[ec])
+            xw, xk = [], []
+            for w_, s in zip(ew.tolist(), raw):
+                if s.count("-") <= v:
+                    for e in iupac.expand(s):
+                        xw.append(w_)
+                        xk.append(e)
+            if xw:
+                chars = np.frombuffer("".join(xk).encode(), np.uint8).reshape(len(xk), k)
+                c.set_extra_rows(np.asarray(xw, np.int32), iupac.words_of_kmers(chars))
+    want = ora.eval_candidates(cw, codes, sF, sR)
+    settings = [{}, {"MP_EVAL_GROUP": "plain"}, {"MP_EVAL_GROUP": "nested"}, {"MP_EVAL_BITS": "1"}, {"MP_EVAL_BITS": "2"},
+                {"MP_EVAL_CHAIN": "0"}, {"MP_EVAL_CHAIN": "3"}, {"MP_EVAL_CHAIN": "5"}, {"MP_EVAL_CHAIN": "7"},
+                {"MP_EVAL_MODE": "rows"}]
+    for env in settings:
+        with monkeypatch.context() as m:
+            for key, val in env.items():
+                m.setenv(key, val)
+            got = hip.eval_candidates(cw, codes, sF, sR)
+        assert np.array_equal(got, want), f"counters differ with {env or 'defaults'}"

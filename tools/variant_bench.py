@@ -22,8 +22,12 @@ def main():
     ap.add_argument("--v", type=int, default=1)
     ap.add_argument("--cands", type=int, default=8)
     ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--variants", type=int, nargs="*", default=list(range(5)))
+    ap.add_argument("--variants", nargs="*", default=["0", "1", "2", "3", "4"],
+                    help="rows mode: MP_EVAL_VARIANT numbers; bits mode: bN = MP_EVAL_BITS=N (symbol-table kernel), "
+                         "cN = nested-chain kernel shape MP_EVAL_CHAIN=N")
     ap.add_argument("--generic-v", action="store_true")
+    ap.add_argument("--mode", choices=["rows", "bits"], default="rows",
+                    help="rows: MP_EVAL_VARIANT of the row-per-lane kernel; bits: MP_EVAL_BITS shapes of the bit-sliced kernel")
     a = ap.parse_args()
     import torch
     from multiprime_amd._abi import Library
@@ -47,7 +51,14 @@ def main():
     if a.generic_v:
         os.environ["MP_EVAL_GENERIC_V"] = "1"
     for var in a.variants:
-        os.environ["MP_EVAL_VARIANT"] = str(var)
+        os.environ["MP_EVAL_MODE"] = a.mode
+        if a.mode == "rows":
+            os.environ["MP_EVAL_VARIANT"] = var
+        elif var.startswith("c"):
+            os.environ["MP_EVAL_BITS"] = "0"
+            os.environ["MP_EVAL_CHAIN"] = var[1:]
+        else:
+            os.environ["MP_EVAL_BITS"] = var[1:]
         for _ in range(3):
             ctx.eval_launch(out.data_ptr())
         ctx.eval_timing(reset=True)
@@ -59,7 +70,7 @@ def main():
             ref = res
         same = bool((res == ref).all())
         per = ms / n
-        print(json.dumps({"variant": var, "ms": round(per, 4), "evals_per_s": evals / per * 1e3, "identical": same,
+        print(json.dumps({"mode": a.mode, "variant": var, "ms": round(per, 4), "evals_per_s": evals / per * 1e3, "identical": same,
                           "checksum": res.sum(axis=0).tolist(), "C": C, "rows": a.rows, "v": v, "generic_v": a.generic_v}), flush=True)
 
 
