@@ -83,7 +83,7 @@ def expand_exceptions(ctx, n_ex, k, v):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--steps", type=int, default=40)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--rows", type=int, default=131072, help="sequences per GPU (weak scaling)")
     ap.add_argument("--cols", type=int, default=1000)
@@ -115,6 +115,9 @@ def main():
         dist.init_process_group("nccl", device_id=dev)
 
     k, v, C, L = a.k, a.v, a.cands, a.cols
+    # the library brackets every n-th mp_eval_launch with a HIP-event pair on its stream (live kernel time for the
+    # roofline); a pair idles the stream for ~6 us, so the bench samples one launch in four
+    os.environ.setdefault("MP_EVAL_TIMING_EVERY", "4")
     t_setup = time.time()
     lib = Library()                                   # the HIP library or an error: no fallback
     ctx = lib.context(local)
@@ -139,13 +142,32 @@ def main():
     ctx.eval_upload(cw, codes, sF, sR)
     setup_s = time.time() - t_setup
 
+    # N > 1: every step all-reduces its own counters, on RCCL's stream, double-buffered — the reduction of step i
+    # overlaps the evaluation of step i+1 (two batches in flight, as the sharded pipeline does between batches);
+    # every reduction is complete before the closing synchronize of the timed region
+    outs = [out, torch.zeros_like(out)]
+    works = [None, None]
+    n_steps_done = [0]
+
     def step():
-        ctx.eval_launch(out.data_ptr())
+        b = n_steps_done[0] & 1
+        n_steps_done[0] += 1
+        if works[b] is not None:
+            works[b].wait()                          # current stream waits for the reduction that last used this buffer
+            works[b] = None
+        ctx.eval_launch(outs[b].data_ptr())
         if world > 1:
-            dist.all_reduce(out, op=dist.ReduceOp.SUM)
+            works[b] = dist.all_reduce(outs[b], op=dist.ReduceOp.SUM, async_op=True)
+
+    def drain():
+        for b in (0, 1):
+            if works[b] is not None:
+                works[b].wait()
+                works[b] = None
 
     for _ in range(a.warmup):
         step()
+    drain()
     ctx.eval_timing(reset=True)
     torch.cuda.synchronize()
     if world > 1:
@@ -154,6 +176,7 @@ def main():
     t0 = time.perf_counter()
     for _ in range(a.steps):
         step()
+    drain()
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
@@ -183,7 +206,7 @@ def main():
         dist.all_reduce(ev, op=dist.ReduceOp.SUM)
     elapsed = float(tt.item())
     evals_total = int(ev.item())
-    checksum = out.sum(dim=0).tolist()
+    checksum = outs[(n_steps_done[0] - 1) & 1].sum(dim=0).tolist()
 
     if rank == 0:
         traffic = None
@@ -209,10 +232,10 @@ def main():
                                    f"k={k}, v={v}, {C} candidates/window, {W} windows, strict -c 2,3,-1",
                        "rows_per_gpu": a.rows, "cols": L, "k": k, "variation": v, "candidates_per_window": C,
                        "windows": W, "evals_per_step_per_gpu": evals_local, "iupac_extra_rows": n_extra,
-                       "parallelism": f"row shards x{world}, RCCL all-reduce of [{n_cand}x3] int64 counters"},
+                       "parallelism": f"row shards x{world}, RCCL all-reduce of [{n_cand}x3] int64 counters per step, overlapped with the next step"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "algorithmic_bytes": alg_bytes,
-                         "kernel": KERNELS[eval_mode()] + "; timed region = counter memset + all launches", "eval_mode": eval_mode(), "kernel_ms": per_launch_ms, "launches_timed": kern_n,
+                         "kernel": KERNELS[eval_mode()] + "; timed region = counter memset + all launches", "eval_mode": eval_mode(), "kernel_ms": per_launch_ms, "launches_timed": kern_n, "timed_every": int(os.environ["MP_EVAL_TIMING_EVERY"]),
                          "algorithmic_bytes_per_eval": 3 * k / 8.0},
             "measured_copy_GBs": copy_gbs, "setup_s": setup_s, "device_bytes": ctx.device_bytes(), "counter_checksum": checksum,
         }

@@ -140,8 +140,10 @@ int mp_eval_upload(mp_ctx *ctx, int32_t n_cand, const int32_t *cand_window, cons
                    uint32_t strictF, uint32_t strictR);
 int mp_eval_launch(mp_ctx *ctx, int64_t *device_out);
 
-/* HIP-event timing of the evaluation kernel itself (recorded on the context's stream around
- * every mp_eval_launch since the last reset): total milliseconds and number of launches. */
+/* HIP-event timing of the evaluation kernels themselves (recorded on the context's stream around
+ * mp_eval_launch since the last reset): total milliseconds and number of launches timed.  Every
+ * launch is timed unless the environment says MP_EVAL_TIMING_EVERY=n (every n-th launch counted
+ * from the reset, 0 = none): an event pair idles the stream for a few microseconds. */
 int mp_eval_timing(mp_ctx *ctx, int32_t reset, double *total_ms, int32_t *n_launches);
 
 /* (5) 3'-end dimer scan — SURVEY §8a rows D and M ------------------------------------------- */

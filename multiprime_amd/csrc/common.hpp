@@ -174,6 +174,7 @@ struct mp_ctx {
     mp::ChainItem *chain_items = nullptr;
     int32_t *table_ids = nullptr;
     int n_chain = 0, n_table = 0, n_events = 0;
+    unsigned launch_seq = 0;                 // launches since the last timing reset
     int32_t *cand_out = nullptr;
     uint32_t sF = 0, sR = 0;
     unsigned long long *tmp_out = nullptr;

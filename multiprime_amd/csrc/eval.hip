@@ -931,10 +931,17 @@ int mp_eval_launch(mp_ctx *c, int64_t *device_out) {
     int split = std::max(1, std::min(max_split, want));
     int rows = ((c->n_pad + split - 1) / split + 1023) / 1024 * 1024;
     split = (c->n_pad + rows - 1) / rows;
+    // HIP-event timing of the launch (mp_eval_timing).  An event pair idles the stream for ~6 us, so
+    // MP_EVAL_TIMING_EVERY=n times every n-th launch only, counted from the last timing reset (0: none); default: all.
+    int every = 1;
+    if (const char *e = getenv("MP_EVAL_TIMING_EVERY")) every = std::max(0, atoi(e));
+    const bool timed = every > 0 && (c->launch_seq++ % (unsigned)every) == 0;
     std::pair<hipEvent_t, hipEvent_t> ev;
-    if (!c->ev_free.empty()) { ev = c->ev_free.back(); c->ev_free.pop_back(); }
-    else { HIPCK(c, hipEventCreate(&ev.first)); HIPCK(c, hipEventCreate(&ev.second)); }
-    HIPCK(c, hipEventRecord(ev.first, c->stream));
+    if (timed) {
+        if (!c->ev_free.empty()) { ev = c->ev_free.back(); c->ev_free.pop_back(); }
+        else { HIPCK(c, hipEventCreate(&ev.first)); HIPCK(c, hipEventCreate(&ev.second)); }
+        HIPCK(c, hipEventRecord(ev.first, c->stream));
+    }
     const char *mode_env = getenv("MP_EVAL_MODE");
     const bool bits = c->v <= 2 && !(mode_env && !strcmp(mode_env, "rows"));
     const int vmode = c->v == 0 ? 0 : (c->v == 1 ? 1 : 2);     // predicate specialisation of the row-per-lane code
@@ -1008,8 +1015,10 @@ int mp_eval_launch(mp_ctx *c, int64_t *device_out) {
     hipLaunchKernelGGL(kEvalVariants[variant].fn[c->p64 ? 1 : 0][getenv("MP_EVAL_GENERIC_V") ? 2 : vmode], dim3((unsigned)c->n_items, (unsigned)split),
                        dim3(kBlock), 0, c->stream, ea);
     }
-    HIPCK(c, hipEventRecord(ev.second, c->stream));
-    c->ev_busy.push_back(ev);
+    if (timed) {
+        HIPCK(c, hipEventRecord(ev.second, c->stream));
+        c->ev_busy.push_back(ev);
+    }
     HIPCK(c, hipGetLastError());
     return MP_OK;
 }
@@ -1028,7 +1037,7 @@ int mp_eval_timing(mp_ctx *c, int32_t reset, double *total_ms, int32_t *n_launch
     c->ev_busy.clear();
     if (total_ms) *total_ms = c->ev_ms;
     if (n_launches) *n_launches = c->ev_n;
-    if (reset) { c->ev_ms = 0; c->ev_n = 0; }
+    if (reset) { c->ev_ms = 0; c->ev_n = 0; c->launch_seq = 0; }      // the first launch after a reset is a timed one
     return MP_OK;
 }
 
