@@ -109,6 +109,17 @@ int mp_window_unique(mp_ctx *ctx, int64_t cap_entries, int32_t want_labels, int6
 int mp_get_unique(mp_ctx *ctx, int64_t *win_off, uint32_t *words, int32_t *count, int32_t *first_row);
 int mp_get_labels(mp_ctx *ctx, int32_t w, int32_t *labels);
 
+/* (3b) per-window base and nearest-neighbour counts ------------------------------------------ */
+/* Replaces state_matrix (V20:541-554) and di_matrix / trans_matrix (V20:556-577), which the
+ * reference builds as pandas frames of one row per sequence: over the window's universe — one
+ * row per sequence whose k-mer has <= v gaps, plus the extra rows of mp_set_extra_rows —
+ *   freq[w][b][j]  = rows whose symbol at position j is base b (A,C,G,T = 0..3; the '-' row is
+ *                    dropped, V20:551-552)
+ *   nn[w][j][a][b] = rows with base a at position j and base b at j+1 (pairs touching '-' are
+ *                    not counted, V20:569-575)
+ * Host arrays, int64: freq [n_windows][4][k], nn [n_windows][k-1][4][4]. */
+int mp_window_stats(mp_ctx *ctx, int64_t *freq, int64_t *nn);
+
 /* (4) candidate x sequence coverage evaluation ---------------------------------------------- */
 /* Replaces mis_primer_check + Y_distance (V20:1103-1130, 229-233), evaluated per sequence
  * instead of per distinct k-mer.  For candidate c (window cand_window[c], ascending) and

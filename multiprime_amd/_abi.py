@@ -33,6 +33,7 @@ SYMBOLS = [
     ("mp_get_exceptions", C.c_int, [_p, C.c_int32, _p, _p, _p]),
     ("mp_set_extra_rows", C.c_int, [_p, C.c_int32, _p, _p]),
     ("mp_get_window_words", C.c_int, [_p, C.c_int32, C.c_int32, C.c_int32, _p]),
+    ("mp_window_stats", C.c_int, [_p, _p, _p]),
     ("mp_window_unique", C.c_int, [_p, C.c_int64, C.c_int32, C.POINTER(C.c_int64)]),
     ("mp_get_unique", C.c_int, [_p, _p, _p, _p, _p]),
     ("mp_get_labels", C.c_int, [_p, C.c_int32, _p]),
@@ -190,6 +191,14 @@ class Context:
         return out
 
     # (4)
+    def window_stats(self):
+        """(freq [W][4][k], nn [W][k-1][4][4]) int64: per-window base counts and nearest-neighbour pair counts
+        over the universe (state_matrix / trans_matrix, V20:541-577)."""
+        freq = np.zeros((self.n_win, 4, self.k), np.int64)
+        nn = np.zeros((self.n_win, self.k - 1, 4, 4), np.int64)
+        self._ck(self.d.mp_window_stats(self.h, _ptr(freq), _ptr(nn)))
+        return freq, nn
+
     def eval_candidates(self, cand_window, cand_codes, strictF: int, strictR: int) -> np.ndarray:
         cand_window = np.ascontiguousarray(cand_window, dtype=np.int32)
         cand_codes = np.ascontiguousarray(cand_codes, dtype=np.uint8).reshape(len(cand_window), self.k)

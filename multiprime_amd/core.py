@@ -26,6 +26,7 @@ import math
 import sys
 import time
 from collections import defaultdict
+from itertools import compress, islice
 from statistics import mean
 
 import numpy as np
@@ -98,7 +99,7 @@ class _Seed:
 
 class _Window:
     __slots__ = ("w", "pos", "cover", "cover_number", "gap", "gap_number", "cbit", "tbit", "seeds",
-                 "present", "dev_entries", "exc")
+                 "present", "dev_entries", "exc", "cnt", "gapfree")
 
 
 class NN_degenerate(object):
@@ -184,6 +185,12 @@ class NN_degenerate(object):
                 self.ctx.set_extra_rows(np.asarray(extra_w, np.int32), iupac.words_of_kmers(chars))
         self.stats["build_windows_s"] = time.time() - t0
         t0 = time.time()
+        # state_matrix / trans_matrix of every window (V20:541-577) straight from the column planes; shards add up
+        self._freq, self._nn = self.ctx.window_stats()
+        if self.comm is not None:
+            self._freq, self._nn = self.comm.sum_int64(self._freq), self.comm.sum_int64(self._nn)
+        self.stats["stats_s"] = time.time() - t0
+        t0 = time.time()
         off, words, count, first = self.ctx.window_unique(want_labels=self.write_json)
         self.stats["unique_s"] = time.time() - t0
         first = first.astype(np.int64) + row_base
@@ -207,11 +214,21 @@ class NN_degenerate(object):
         win.w, win.pos = w, int(self.start_position) + w
         win.exc = exc.get(w)
         win.dev_entries = (a, b)
+        win.cnt = win.gapfree = None
         if not win.exc:
-            cover, gap = {}, {}
-            for i in range(a, b):
-                (gap if gaps[i] > v else cover)[strs[i]] = int(count[i])
-            win.cover, win.gap = cover, gap
+            # the entries of a window are distinct and already in first-seen order: two dict(zip()) calls
+            is_gap = gaps[a:b] > v
+            cnt = count[a:b]
+            if is_gap.any():
+                keep = ~is_gap
+                win.cnt = cnt[keep]
+                win.cover = dict(zip(compress(strs[a:b], keep.tolist()), win.cnt.tolist()))
+                win.gap = dict(zip(compress(strs[a:b], is_gap.tolist()), cnt[is_gap].tolist()))
+                win.gapfree = gaps[a:b][keep] == 0
+            else:
+                win.cnt = cnt
+                win.cover, win.gap = dict(zip(strs[a:b], cnt.tolist())), {}
+                win.gapfree = gaps[a:b] == 0
         else:
             items = [(int(first[i]), 0, strs[i], int(count[i]), gaps[i] > v) for i in range(a, b)]
             for row, s in win.exc:
@@ -236,12 +253,21 @@ class NN_degenerate(object):
     def _entropy(self, win):
         """entropy (V20:602-614), same summation order."""
         cn, gn = win.cover_number, win.gap_number
-        cbit = 0
-        tbit = 0
         tot = cn + gn
-        for c in win.cover.values():
-            cbit += (c / cn) * math.log((c / cn), 2)
-            tbit += (c / tot) * math.log((c / tot), 2)
+        if win.cnt is not None and len(win.cnt) > 64:
+            # deep windows: one math.log per DISTINCT count (same libm call, same operands as the loop below), then a
+            # strictly left-to-right float64 accumulation (ufunc.accumulate) in dict order — the same sums bit for bit
+            uniq, inv = np.unique(win.cnt, return_inverse=True)
+            tc = np.array([(c / cn) * math.log((c / cn), 2) for c in uniq.tolist()], np.float64)
+            tt = np.array([(c / tot) * math.log((c / tot), 2) for c in uniq.tolist()], np.float64)
+            cbit = float(np.add.accumulate(tc[inv])[-1])
+            tbit = float(np.add.accumulate(tt[inv])[-1])
+        else:
+            cbit = 0
+            tbit = 0
+            for c in win.cover.values():
+                cbit += (c / cn) * math.log((c / cn), 2)
+                tbit += (c / tot) * math.log((c / tot), 2)
         for g in win.gap.values():
             tbit += (g / tot) * math.log((g / tot), 2)
         return round(-cbit, 2), round(-tbit, 2)
@@ -257,27 +283,24 @@ class NN_degenerate(object):
         win.cbit, win.tbit = self._entropy(win)
         if win.tbit > self.entropy_threshold:
             return False
-        keys = list(win.cover.keys())
-        counts = np.fromiter(win.cover.values(), dtype=np.int64, count=len(keys))
-        idx = _IDX_LUT[np.frombuffer("".join(keys).encode(), np.uint8)].reshape(len(keys), k)
-        # state_matrix (V20:541-554): per-column symbol counts over all expansions, '-' dropped
-        freq = np.zeros((4, k), np.int64)
-        for b in range(4):
-            freq[b] = ((idx == b) * counts[:, None]).sum(axis=0)
+        # state_matrix (V20:541-554): per-column base counts over all rows of the window ('-' dropped) and
+        # trans_matrix (V20:556-577): NN[j][a][b] over ACGT pairs only — counted on the device (mp_window_stats)
+        freq = self._freq[win.w]
         if (freq.sum(axis=1) > 0).sum() < 4:         # fewer than 4 distinct bases (V20:736)
             return False
         if (freq.sum(axis=0) == 0).any():            # an all-gap column (V20:738)
             return False
-        # trans_matrix (V20:556-577): NN[j][a][b] over ACGT pairs only
-        pair = idx[:, :-1] * 5 + idx[:, 1:] + (np.arange(k - 1) * 25)[None, :]
-        flat = np.bincount(pair.ravel(), weights=np.repeat(counts, k - 1), minlength=(k - 1) * 25)
-        NN = flat.astype(np.int64).reshape(k - 1, 5, 5)[:, :4, :4].copy()
+        NN = self._nn[win.w].copy()                  # refinement merges rows / columns in place
         nm = self._viterbi(freq, NN)
         mm = None
-        best = 0
-        for s, c in win.cover.items():               # get_optimal_primer_by_MM (V20:595-600)
-            if c > best and "-" not in s:
-                best, mm = c, s
+        if win.cnt is not None:                      # get_optimal_primer_by_MM (V20:595-600): first of the most frequent
+            if win.gapfree.any():
+                mm = next(islice(win.cover, int(np.argmax(np.where(win.gapfree, win.cnt, 0))), None))
+        else:
+            best = 0
+            for s, c in win.cover.items():
+                if c > best and "-" not in s:
+                    best, mm = c, s
         seeds = [_Seed(nm)]
         if mm is not None:
             mm_idx = [_B2I[c] for c in mm]

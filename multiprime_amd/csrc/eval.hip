@@ -707,6 +707,127 @@ __global__ __launch_bounds__(kBlock) void eval_chain_kernel(const EvalChainArgs 
     block_commit<GW>(accP, accF, accR, s_part, A.cand_out + it.cand0, A.out);
 }
 
+// ----------------------------------------------------------------------------------------------
+// (4d) per-window base and nearest-neighbour counts (mp_window_stats; state_matrix / trans_matrix,
+// V20:541-577).  Same universe, same planes: freq[w][b][j] = popcount(valid_w & plane[col w+j][b]),
+// nn[w][j][a][b] = popcount(valid_w & plane[col w+j][a] & plane[col w+j+1][b]) over the plain rows, plus
+// a row-per-lane pass over the patch / IUPAC lists.  20 counters per position: a thread sums its GW words,
+// packs two 16-bit counts per register, six DPP adds give the wave total, lane 63 adds it to the block's
+// LDS table, the block adds its k x 20 totals to the global counters.
+// ----------------------------------------------------------------------------------------------
+struct StatsArgs {
+    const unsigned long long *cols;    // [n_cols][4][nw]
+    const unsigned long long *excl;    // [W][nw]
+    int nw, p0, k, v;
+    BlockMap map;                      // items = windows
+    unsigned long long *freq;          // [W][4][k]
+    unsigned long long *nn;            // [W][k-1][16]
+    const int32_t *off_a;              // patch list (may be nullptr)
+    const uint32_t *words_a;
+    const int32_t *off_b;              // IUPAC expansion rows (may be nullptr)
+    const uint32_t *words_b;
+    int n_win;
+};
+
+__device__ __forceinline__ void stats_flush(const StatsArgs &A, int win, const uint32_t (*s_cnt)[20]) {
+    for (int t = threadIdx.x; t < A.k * 20; t += kBlock) {
+        const int j = t / 20, q = t % 20;
+        const uint32_t val = s_cnt[j][q];
+        if (!val) continue;
+        if (q < 4) atomicAdd(&A.freq[((size_t)win * 4 + q) * A.k + j], (unsigned long long)val);
+        else if (j + 1 < A.k) atomicAdd(&A.nn[((size_t)win * (A.k - 1) + j) * 16 + (q - 4)], (unsigned long long)val);
+    }
+}
+
+template <int GW>
+__global__ __launch_bounds__(kBlock) void window_stats_kernel(const StatsArgs A) {
+    __shared__ uint32_t s_cnt[MP_MAX_K][20];           // [position][4 base counts, then 16 pair counts (j, j+1)]
+    int slice, win;
+    if (!map_block(A.map, blockIdx.x, slice, win)) return;
+    for (int t = threadIdx.x; t < MP_MAX_K * 20; t += kBlock) (&s_cnt[0][0])[t] = 0;
+    __syncthreads();
+    const size_t nw32 = (size_t)A.nw * 2;
+    const int word0 = (slice * kBlock + threadIdx.x) * GW;
+    const bool live = word0 < (int)nw32;
+    const uint32_t *Pw = reinterpret_cast<const uint32_t *>(A.cols) + ((size_t)(A.p0 + win) * 4) * nw32 + word0;
+    uint32_t valid[GW], cur[4][GW], nxt[4][GW];
+#pragma unroll
+    for (int i = 0; i < GW; i++) {
+        valid[i] = live ? ~(reinterpret_cast<const uint32_t *>(A.excl) + (size_t)win * nw32 + word0)[i] : 0u;
+#pragma unroll
+        for (int b = 0; b < 4; b++) cur[b][i] = live ? (valid[i] & Pw[b * nw32 + i]) : 0u;
+    }
+#pragma unroll 1
+    for (int j = 0; j < A.k; j++) {
+        const bool more = j + 1 < A.k;
+#pragma unroll
+        for (int b = 0; b < 4; b++)
+#pragma unroll
+            for (int i = 0; i < GW; i++) nxt[b][i] = (live && more) ? (valid[i] & Pw[((size_t)(j + 1) * 4 + b) * nw32 + i]) : 0u;
+        uint32_t cnt[20];
+#pragma unroll
+        for (int b = 0; b < 4; b++) {
+            cnt[b] = 0;
+#pragma unroll
+            for (int i = 0; i < GW; i++) cnt[b] += __popc(cur[b][i]);
+        }
+#pragma unroll
+        for (int a = 0; a < 4; a++)
+#pragma unroll
+            for (int b = 0; b < 4; b++) {
+                cnt[4 + a * 4 + b] = 0;
+#pragma unroll
+                for (int i = 0; i < GW; i++) cnt[4 + a * 4 + b] += __popc(cur[a][i] & nxt[b][i]);
+            }
+        static_assert(64 * 32 * GW < 65536, "packed wave sums must fit 16 bits");
+        uint32_t tot[10];
+#pragma unroll
+        for (int q = 0; q < 10; q++) tot[q] = wave_sum_lane63(cnt[2 * q] | (cnt[2 * q + 1] << 16));
+        if ((threadIdx.x & 63) == 63) {
+#pragma unroll
+            for (int q = 0; q < 10; q++) {
+                if (tot[q] & 0xFFFFu) atomicAdd(&s_cnt[j][2 * q], tot[q] & 0xFFFFu);
+                if (tot[q] >> 16) atomicAdd(&s_cnt[j][2 * q + 1], tot[q] >> 16);
+            }
+        }
+#pragma unroll
+        for (int b = 0; b < 4; b++)
+#pragma unroll
+            for (int i = 0; i < GW; i++) cur[b][i] = nxt[b][i];
+    }
+    __syncthreads();
+    stats_flush(A, win, s_cnt);
+}
+
+// the patch rows and the IUPAC expansion rows of one window, a row per lane
+__global__ __launch_bounds__(kBlock) void window_stats_list_kernel(const StatsArgs A) {
+    __shared__ uint32_t s_cnt[MP_MAX_K][20];
+    const int win = blockIdx.x;
+    for (int t = threadIdx.x; t < MP_MAX_K * 20; t += kBlock) (&s_cnt[0][0])[t] = 0;
+    __syncthreads();
+    const uint32_t kmask = (1u << A.k) - 1u;
+    for (int which = 0; which < 2; which++) {
+        const int32_t *off = which ? A.off_b : A.off_a;
+        const uint32_t *words = which ? A.words_b : A.words_a;
+        if (!off) continue;
+        for (int e = off[win] + threadIdx.x; e < off[win + 1]; e += kBlock) {
+            const uint32_t b0 = words[3 * (size_t)e], b1 = words[3 * (size_t)e + 1], g = words[3 * (size_t)e + 2];
+            if ((g & MP_WIN_SKIP) || __popc(g & kmask) > A.v) continue;
+            for (int j = 0; j < A.k; j++) {
+                if ((g >> j) & 1u) continue;
+                const uint32_t a = ((b0 >> j) & 1u) | (((b1 >> j) & 1u) << 1);
+                atomicAdd(&s_cnt[j][a], 1u);
+                if (j + 1 < A.k && !((g >> (j + 1)) & 1u)) {
+                    const uint32_t b = ((b0 >> (j + 1)) & 1u) | (((b1 >> (j + 1)) & 1u) << 1);
+                    atomicAdd(&s_cnt[j][4 + a * 4 + b], 1u);
+                }
+            }
+        }
+    }
+    __syncthreads();
+    stats_flush(A, win, s_cnt);
+}
+
 // Per-sequence coverage masks (mp_eval_masks): thread = sequence, the wave's 64 "not covered" bits
 // go out as one 64-bit word per candidate straight from the ballot (blocks are 64-row aligned), so
 // there are no atomics; works on the window words, i.e. after edge-gap repair, for any v.
@@ -1038,6 +1159,42 @@ int mp_eval_timing(mp_ctx *c, int32_t reset, double *total_ms, int32_t *n_launch
     if (total_ms) *total_ms = c->ev_ms;
     if (n_launches) *n_launches = c->ev_n;
     if (reset) { c->ev_ms = 0; c->ev_n = 0; c->launch_seq = 0; }      // the first launch after a reset is a timed one
+    return MP_OK;
+}
+
+int mp_window_stats(mp_ctx *c, int64_t *freq, int64_t *nn) {
+    if (!c) return MP_ERR_ARG;
+    if (!c->win) return fail(c, MP_ERR_ARG, "no windows built");
+    if (!freq || !nn) return fail(c, MP_ERR_ARG, "null output");
+    HIPCK(c, hipSetDevice(c->dev));
+    const size_t W = (size_t)c->n_win, k = (size_t)c->k;
+    const size_t n_f = W * 4 * k, n_t = W * (k - 1) * 16;
+    unsigned long long *d = nullptr;
+    int rc;
+    if ((rc = dev_alloc(c, &d, n_f + n_t))) return rc;
+    HIPCK(c, hipMemsetAsync(d, 0, sizeof(unsigned long long) * (n_f + n_t), c->stream));
+    const int nw = c->n_pad / 64;
+    const int GW = 2 * nw >= 4 * kBlock ? 4 : (2 * nw >= 2 * kBlock ? 2 : 1);
+    BlockMap m;
+    m.ny = std::max(1, (2 * nw / GW + kBlock - 1) / kBlock);
+    m.ny_pad = m.ny > 4 ? (m.ny + 7) / 8 * 8 : (m.ny > 2 ? 4 : m.ny);
+    m.n_items = c->n_win;
+    const int bands = m.ny_pad >= 8 ? 1 : 8 / m.ny_pad;
+    m.per_band = (c->n_win + bands - 1) / bands;
+    const unsigned grid = m.ny_pad >= 8 ? (unsigned)((size_t)c->n_win * m.ny_pad) : (unsigned)(8 * (size_t)m.per_band);
+    StatsArgs sa{c->cols, c->excl, nw, c->p0, c->k, c->v, m, d, d + n_f,
+                 c->n_patch ? c->patch_off : (const int32_t *)nullptr, c->patch_words,
+                 c->n_extra ? c->extra_off : (const int32_t *)nullptr, c->extra_words, c->n_win};
+    if (GW == 4) hipLaunchKernelGGL(window_stats_kernel<4>, dim3(grid), dim3(kBlock), 0, c->stream, sa);
+    else if (GW == 2) hipLaunchKernelGGL(window_stats_kernel<2>, dim3(grid), dim3(kBlock), 0, c->stream, sa);
+    else hipLaunchKernelGGL(window_stats_kernel<1>, dim3(grid), dim3(kBlock), 0, c->stream, sa);
+    if (c->n_patch || c->n_extra)
+        hipLaunchKernelGGL(window_stats_list_kernel, dim3((unsigned)c->n_win), dim3(kBlock), 0, c->stream, sa);
+    HIPCK(c, hipGetLastError());
+    HIPCK(c, hipMemcpyAsync(freq, d, sizeof(int64_t) * n_f, hipMemcpyDeviceToHost, c->stream));
+    HIPCK(c, hipMemcpyAsync(nn, d + n_f, sizeof(int64_t) * n_t, hipMemcpyDeviceToHost, c->stream));
+    HIPCK(c, hipStreamSynchronize(c->stream));
+    dev_free(c, &d, n_f + n_t);
     return MP_OK;
 }
 

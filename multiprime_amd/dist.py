@@ -115,6 +115,14 @@ class RowShards:
         return self.global_labels[w]
 
     # -- evaluation ----------------------------------------------------------------------------
+    def sum_int64(self, a):
+        """Element-wise sum over the ranks of an int64 array every rank holds (per-window statistics)."""
+        t = torch.from_numpy(np.ascontiguousarray(a, dtype=np.int64))
+        if self.on_gpu:
+            t = t.to(torch.device("cuda", torch.cuda.current_device()))
+        dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group)
+        return t.cpu().numpy()
+
     def eval_allreduce(self, ctx, cand_window, cand_codes, sF, sR):
         """Local evaluation + the single all-reduce of the counter block."""
         n = len(cand_window)

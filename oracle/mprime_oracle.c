@@ -370,6 +370,48 @@ int mp_get_labels(mp_ctx *c, int32_t w, int32_t *labels) {
 /* ---- candidate x sequence evaluation: V20:1103-1130 + Y_distance V20:229-233 --------------- */
 /* Y_distance: position j is a mismatch iff the concrete symbol is not in the IUPAC set of the
  * primer symbol; '-' is in no set (verified exhaustively against score_table). */
+/* state_matrix (V20:541-554) + trans_matrix (V20:556-577) of every window: one row per universe k-mer */
+static void stats_one(const char *kmer, int32_t k, int32_t v, int64_t *freq, int64_t *nn) {
+    int32_t gaps = 0;
+    for (int32_t j = 0; j < k; j++) gaps += kmer[j] == '-';
+    if (gaps > v) return;                                  /* a gap row: not in `cover` (V20:689) */
+    for (int32_t j = 0; j < k; j++) {
+        int a = base_index(kmer[j]);
+        if (a < 0) continue;                               /* the '-' row is dropped (V20:551-552) */
+        freq[(size_t)a * k + j]++;
+        if (j + 1 < k) {
+            int b = base_index(kmer[j + 1]);
+            if (b >= 0) nn[((size_t)j * 4 + a) * 4 + b]++;  /* pairs touching '-' do not count (V20:569-575) */
+        }
+    }
+}
+
+int mp_window_stats(mp_ctx *c, int64_t *freq, int64_t *nn) {
+    if (!c || !c->words) return c ? fail(c, MP_ERR_ARG, "no windows built") : MP_ERR_ARG;
+    if (!freq || !nn) return fail(c, MP_ERR_ARG, "null output");
+    int32_t N = c->n_rows, k = c->k;
+    char km[MP_MAX_K + 1];
+    memset(freq, 0, sizeof(int64_t) * (size_t)c->n_win * 4 * k);
+    memset(nn, 0, sizeof(int64_t) * (size_t)c->n_win * (k - 1) * 16);
+    int32_t e = 0;
+    for (int32_t w = 0; w < c->n_win; w++) {
+        int64_t *f = freq + (size_t)w * 4 * k, *t = nn + (size_t)w * (k - 1) * 16;
+        for (int32_t r = 0; r < N; r++) {
+            const char *kmer = c->kmers + ((size_t)w * N + r) * k;
+            if (!kmer[0]) continue;                        /* exception slot: its expansions are extra rows */
+            stats_one(kmer, k, c->v, f, t);
+        }
+        while (e < c->n_extra && c->extra_win[e] < w) e++;
+        for (; e < c->n_extra && c->extra_win[e] == w; e++) {
+            km[k] = 0;
+            for (int32_t j = 0; j < k; j++)
+                km[j] = (c->extra_words[3 * e + 2] >> j & 1) ? '-' : "ACGT"[(c->extra_words[3 * e] >> j & 1) | (c->extra_words[3 * e + 1] >> j & 1) << 1];
+            stats_one(km, k, c->v, f, t);
+        }
+    }
+    return MP_OK;
+}
+
 static void eval_one(const uint8_t *cand, int32_t k, int32_t v, uint32_t sF, uint32_t sR,
                      const char *kmer, int64_t *out) {
     int32_t nd = 0, gaps = 0;

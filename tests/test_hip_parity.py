@@ -95,6 +95,8 @@ def test_every_abi_output_matches_oracle(hip_lib, oracle_lib, seed, n, L, ragged
         words = iupac.words_of_kmers(np.frombuffer("".join(xk).encode(), np.uint8).reshape(len(xk), k))
         h.set_extra_rows(np.asarray(xw, np.int32), words)
         o.set_extra_rows(np.asarray(xw, np.int32), words)
+    for a, b in zip(h.window_stats(), o.window_stats()):       # state_matrix / trans_matrix sums
+        assert np.array_equal(a, b)
     uh, uo = h.window_unique(want_labels=True), o.window_unique(want_labels=True)
     for a, b in zip(uh, uo):
         assert a.tolist() == b.tolist()
