@@ -93,6 +93,7 @@ def main():
     ap.add_argument("--seed", type=int, default=20250303)
     ap.add_argument("--cpu-rows", type=int, default=49152, help="rows of the shard timed on the CPU oracle")
     ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--bucket", type=int, default=4, help="steps whose counters share one all-reduce (N > 1)")
     a = ap.parse_args()
 
     import torch
@@ -133,7 +134,6 @@ def main():
     sF = sum(1 << y for y in f_set if 0 <= y < k)
     sR = sum(1 << y for y in r_set if 0 <= y < k)
     n_cand = len(cw)
-    out = torch.zeros((n_cand, 3), dtype=torch.int64, device=dev)
     # universe size per window (sequences with <= v gaps, plus expansions): an all-N candidate
     # matches every non-gap symbol, so perfect + F_mis under empty strict masks counts it
     alln = ctx.eval_candidates(np.arange(W, dtype=np.int32), np.full((W, k), 15, np.uint8), 0, 0)
@@ -142,28 +142,18 @@ def main():
     ctx.eval_upload(cw, codes, sF, sR)
     setup_s = time.time() - t_setup
 
-    # N > 1: every step all-reduces its own counters, on RCCL's stream, double-buffered — the reduction of step i
-    # overlaps the evaluation of step i+1 (two batches in flight, as the sharded pipeline does between batches);
-    # every reduction is complete before the closing synchronize of the timed region
-    outs = [out, torch.zeros_like(out)]
-    works = [None, None]
-    n_steps_done = [0]
+    # N > 1: the counters of every step are all-reduced over RCCL, bucketed and overlapped (dist.StepBuckets):
+    # `--bucket` consecutive steps write into one [bucket][n_cand][3] buffer that is reduced with ONE collective
+    # (xGMI rings are latency-bound at 180 KB per step), on RCCL's stream, while the next bucket's steps evaluate
+    # into the other buffer.  Every step's counters are reduced; all reductions complete inside the timed region.
+    from multiprime_amd.dist import StepBuckets
+    sb = StepBuckets(n_cand, a.bucket, dev, world)
 
     def step():
-        b = n_steps_done[0] & 1
-        n_steps_done[0] += 1
-        if works[b] is not None:
-            works[b].wait()                          # current stream waits for the reduction that last used this buffer
-            works[b] = None
-        ctx.eval_launch(outs[b].data_ptr())
-        if world > 1:
-            works[b] = dist.all_reduce(outs[b], op=dist.ReduceOp.SUM, async_op=True)
+        ctx.eval_launch(sb.begin_step().data_ptr())
+        sb.end_step()
 
-    def drain():
-        for b in (0, 1):
-            if works[b] is not None:
-                works[b].wait()
-                works[b] = None
+    drain = sb.drain
 
     for _ in range(a.warmup):
         step()
@@ -206,7 +196,7 @@ def main():
         dist.all_reduce(ev, op=dist.ReduceOp.SUM)
     elapsed = float(tt.item())
     evals_total = int(ev.item())
-    checksum = outs[(n_steps_done[0] - 1) & 1].sum(dim=0).tolist()
+    checksum = sb.block_of(a.steps - 1).sum(dim=0).tolist()
 
     if rank == 0:
         traffic = None
@@ -232,7 +222,7 @@ def main():
                                    f"k={k}, v={v}, {C} candidates/window, {W} windows, strict -c 2,3,-1",
                        "rows_per_gpu": a.rows, "cols": L, "k": k, "variation": v, "candidates_per_window": C,
                        "windows": W, "evals_per_step_per_gpu": evals_local, "iupac_extra_rows": n_extra,
-                       "parallelism": f"row shards x{world}, RCCL all-reduce of [{n_cand}x3] int64 counters per step, overlapped with the next step"},
+                       "parallelism": f"row shards x{world}, RCCL all-reduce of every step's [{n_cand}x3] int64 counters, {sb.B} steps per collective, overlapped with the next bucket"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "algorithmic_bytes": alg_bytes,
                          "kernel": KERNELS[eval_mode()] + "; timed region = counter memset + all launches", "eval_mode": eval_mode(), "kernel_ms": per_launch_ms, "launches_timed": kern_n, "timed_every": int(os.environ["MP_EVAL_TIMING_EVERY"]),

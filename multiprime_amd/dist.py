@@ -137,3 +137,50 @@ class RowShards:
         out = torch.from_numpy(ctx.eval_candidates(cand_window, cand_codes, sF, sR))
         dist.all_reduce(out, op=dist.ReduceOp.SUM, group=self.group)
         return out.numpy()
+
+
+class StepBuckets:
+    """Bucketed, double-buffered all-reduce of per-step counter blocks (bench.py, batch pipelines).
+
+    `bucket` consecutive steps write into one [bucket][n][3] int64 buffer that is reduced with ONE collective
+    (xGMI rings are latency-bound at a few hundred KB), asynchronously on the backend's stream, while the next
+    bucket's steps fill the other buffer.  Every step's block is reduced; `drain()` completes everything."""
+
+    def __init__(self, n, bucket, device, world=1, group=None):
+        self.B = max(1, int(bucket))
+        self.world, self.group = world, group
+        self.buf = torch.zeros((2, self.B, n, 3), dtype=torch.int64, device=device)
+        self.works = [None, None]
+        self.i = 0
+
+    def begin_step(self):
+        """The [n][3] block this step writes; waits (stream-side) for the reduction that last used its buffer."""
+        b, slot = (self.i // self.B) & 1, self.i % self.B
+        if slot == 0 and self.works[b] is not None:
+            self.works[b].wait()
+            self.works[b] = None
+        return self.buf[b, slot]
+
+    def end_step(self):
+        b, slot = (self.i // self.B) & 1, self.i % self.B
+        self.i += 1
+        if slot == self.B - 1:
+            self._flush(b, self.B)
+
+    def _flush(self, b, n_slots):
+        if self.world > 1 and n_slots:
+            self.works[b] = dist.all_reduce(self.buf[b, :n_slots], op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+
+    def drain(self):
+        """Reduce the last, partial bucket and wait for everything in flight; the step counter restarts at 0."""
+        if self.i % self.B:
+            self._flush((self.i // self.B) & 1, self.i % self.B)
+        for b in (0, 1):
+            if self.works[b] is not None:
+                self.works[b].wait()
+                self.works[b] = None
+        self.n_done, self.i = self.i, 0
+
+    def block_of(self, step):
+        """Reduced block of `step` (one of the last 2 * bucket steps before the last drain)."""
+        return self.buf[(step // self.B) & 1, step % self.B]

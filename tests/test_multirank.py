@@ -102,3 +102,40 @@ def test_sharded_hip_contexts_match_reference(name, world, hip_lib, tmp_path):
     port = 29700 + (os.getpid() % 2000)
     mp.spawn(_worker, args=(world, port, name, str(inp), str(out), hip_lib.path), nprocs=world, join=True)
     check_outputs(name, out)
+
+
+def _bucket_worker(rank, world, port, steps, bucket, q):
+    sys.path.insert(0, REPO)
+    import torch
+    import torch.distributed as dist
+    from multiprime_amd.dist import StepBuckets
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        ok = True
+        sb = StepBuckets(5, bucket, torch.device("cpu"), world)
+        for round_ in range(2):                               # drain() must leave the object reusable
+            for i in range(steps):
+                blk = sb.begin_step()
+                blk.copy_(torch.full((5, 3), (rank + 1) * 1000 + i + 100 * round_, dtype=torch.int64))   # "the kernel"
+                sb.end_step()
+            sb.drain()
+            for i in range(max(0, steps - bucket), steps):    # at least the last bucket's worth is still in the buffers
+                want = sum((r + 1) * 1000 + i + 100 * round_ for r in range(world))
+                ok = ok and bool((sb.block_of(i) == want).all())
+        if rank == 0:
+            q.put(ok)
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,steps,bucket", [(2, 9, 4), (2, 8, 4), (3, 5, 1), (2, 3, 8)])
+def test_bucketed_overlapped_allreduce_reduces_every_step(world, steps, bucket):
+    """bench.py's N > 1 exchange (dist.StepBuckets): several steps per collective, two buffers in flight, partial
+    last bucket — every step's block must come out as the sum over the ranks."""
+    ctx = mp.get_context("spawn")
+    q = ctx.SimpleQueue()
+    port = 31500 + (os.getpid() % 2000)
+    mp.spawn(_bucket_worker, args=(world, port, steps, bucket, q), nprocs=world, join=True)
+    assert q.get() is True
