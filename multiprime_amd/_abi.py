@@ -176,7 +176,7 @@ class Context:
         words = wbuf[:3 * n].reshape(3, n) if n else np.zeros((3, 0), np.uint32)
         count, first = count[:n], first[:n]
         win_of = np.repeat(np.arange(self.n_win), np.diff(off))
-        order = np.lexsort((first, win_of))
+        order = np.argsort((win_of.astype(np.int64) << 32) | first.astype(np.int64))     # (window, first row): all distinct
         self._label_rank = np.empty(n, np.int64)          # device index -> index within window, first-seen order
         self._label_rank[order] = np.arange(n) - off[win_of[order]]
         self._off = off

@@ -97,6 +97,62 @@ class _Seed:
         self.final = None    # (primer, cov, F_mis, R_mis) after replay
 
 
+def _merge_seen(dev, first, gapfree, items):
+    """Insertion-ordered dict of a window after the exception k-mers joined it.
+
+    `dev`: {k-mer: count} of the device entries in first-seen order, `first` their first rows (ascending), `items`:
+    (row, j, key) in ascending (row, j), one sequence each.  A key takes the position of its earliest sighting — a
+    plain row never shares its row with an exception — and counts add up (V20:689-711 run row by row would give
+    exactly this dict).  Returns (dict, counts array, gap-free flags or None)."""
+    if not items:
+        return dev, np.fromiter(dev.values(), np.int64, len(dev)), gapfree
+    first_of = None
+    placed = {}                                                  # key -> [row, j, count]: new keys and keys that move up
+    for row, j, e in items:
+        if e in placed:
+            placed[e][2] += 1
+        elif e in dev:
+            if first_of is None:
+                first_of = dict(zip(dev, first.tolist()))
+            if first_of[e] > row:                                # seen here before any plain row carried it: it moves up
+                placed[e] = [row, j, dev[e] + 1]
+            else:
+                dev[e] += 1
+        else:
+            placed[e] = [row, j, 1]
+    if not placed:
+        return dev, np.fromiter(dev.values(), np.int64, len(dev)), gapfree
+    keys = list(dev)
+    vals = list(dev.values())
+    flags = gapfree.tolist() if gapfree is not None else None
+    rows = first
+    moved = [e for e in placed if e in dev]
+    if moved:
+        drop = set(moved)
+        keep = [e not in drop for e in keys]
+        keys = list(compress(keys, keep))
+        vals = list(compress(vals, keep))
+        if flags is not None:
+            flags = list(compress(flags, keep))
+        rows = first[np.asarray(keep, bool)]
+    pos = np.searchsorted(rows, [p[0] for p in placed.values()]).tolist()      # placed is in ascending (row, j)
+    out_k, out_v, out_f, prev = [], [], [], 0
+    for at, (e, (_, _, c)) in zip(pos, placed.items()):
+        out_k += keys[prev:at]
+        out_v += vals[prev:at]
+        out_k.append(e)
+        out_v.append(c)
+        if flags is not None:
+            out_f += flags[prev:at]
+            out_f.append("-" not in e)
+        prev = at
+    out_k += keys[prev:]
+    out_v += vals[prev:]
+    if flags is not None:
+        out_f += flags[prev:]
+    return dict(zip(out_k, out_v)), np.asarray(out_v, np.int64), (np.asarray(out_f, bool) if flags is not None else None)
+
+
 class _Window:
     __slots__ = ("w", "pos", "cover", "cover_number", "gap", "gap_number", "cbit", "tbit", "seeds",
                  "present", "dev_entries", "exc", "cnt", "gapfree")
@@ -214,35 +270,31 @@ class NN_degenerate(object):
         win.w, win.pos = w, int(self.start_position) + w
         win.exc = exc.get(w)
         win.dev_entries = (a, b)
-        win.cnt = win.gapfree = None
-        if not win.exc:
-            # the entries of a window are distinct and already in first-seen order: two dict(zip()) calls
-            is_gap = gaps[a:b] > v
-            cnt = count[a:b]
-            if is_gap.any():
-                keep = ~is_gap
-                win.cnt = cnt[keep]
-                win.cover = dict(zip(compress(strs[a:b], keep.tolist()), win.cnt.tolist()))
-                win.gap = dict(zip(compress(strs[a:b], is_gap.tolist()), cnt[is_gap].tolist()))
-                win.gapfree = gaps[a:b][keep] == 0
-            else:
-                win.cnt = cnt
-                win.cover, win.gap = dict(zip(strs[a:b], cnt.tolist())), {}
-                win.gapfree = gaps[a:b] == 0
+        # the device entries of a window are distinct and already in first-seen order: two dict(zip()) calls
+        is_gap = gaps[a:b] > v
+        cnt = count[a:b]
+        if is_gap.any():
+            keep = ~is_gap
+            win.cnt = cnt[keep]
+            win.cover = dict(zip(compress(strs[a:b], keep.tolist()), win.cnt.tolist()))
+            win.gap = dict(zip(compress(strs[a:b], is_gap.tolist()), cnt[is_gap].tolist()))
+            win.gapfree = gaps[a:b][keep] == 0
+            first_c, first_g = first[a:b][keep], first[a:b][is_gap]
         else:
-            items = [(int(first[i]), 0, strs[i], int(count[i]), gaps[i] > v) for i in range(a, b)]
-            for row, s in win.exc:
+            win.cnt = cnt
+            win.cover, win.gap = dict(zip(strs[a:b], cnt.tolist())), {}
+            win.gapfree = gaps[a:b] == 0
+            first_c, first_g = first[a:b], first[a:b][:0]
+        if win.exc:
+            # IUPAC k-mers (host-expanded, V20:368-380) join at the row they were seen in: (row, expansion index)
+            exp_items, gap_items = [], []
+            for row, s in win.exc:                               # ascending rows
                 if s.count("-") > v:
-                    items.append((row, 0, s, 1, True))           # gap_sequence is keyed by the raw string
+                    gap_items.append((row, 0, s))                # gap_sequence is keyed by the raw string
                 else:
-                    for j, e in enumerate(iupac.expand(s)):
-                        items.append((row, j, e, 1, False))
-            items.sort(key=lambda t: (t[0], t[1]))
-            cover, gap = {}, {}
-            for _, _, s, c, is_gap in items:
-                d = gap if is_gap else cover
-                d[s] = d.get(s, 0) + c
-            win.cover, win.gap = cover, gap
+                    exp_items.extend((row, j, e) for j, e in enumerate(iupac.expand(s)))
+            win.cover, win.cnt, win.gapfree = _merge_seen(win.cover, first_c, win.gapfree, exp_items)
+            win.gap, _, _ = _merge_seen(win.gap, first_g, None, gap_items)
         win.gap_number = sum(win.gap.values())
         n_exc_cover = sum(1 for _, s in win.exc if s.count("-") <= v) if win.exc else 0
         n_exp = sum(len(iupac.expand(s)) for _, s in win.exc if s.count("-") <= v) if win.exc else 0

@@ -71,19 +71,27 @@ def words_of_kmers(chars: np.ndarray) -> np.ndarray:
     return out
 
 
+_WORD_LUT = np.frombuffer(b"ACGT----", dtype=np.uint8)      # index = b0 | b1 << 1 | gap << 2
+
+
 def kmers_of_words(words: np.ndarray, k: int) -> np.ndarray:
     """(3,n) uint32 window words -> (n,k) ASCII matrix over ACGT-."""
-    sh = np.arange(k, dtype=np.uint32)[None, :]
-    b0 = (words[0][:, None] >> sh) & 1
-    b1 = (words[1][:, None] >> sh) & 1
-    g = (words[2][:, None] >> sh) & 1
-    lut = np.frombuffer(b"ACGT", dtype=np.uint8)
-    ch = lut[(b0 | (b1 << 1)).astype(np.intp)]
-    return np.where(g == 1, np.uint8(ord("-")), ch).astype(np.uint8)
+    n = words.shape[1]
+    if n == 0:
+        return np.zeros((0, k), np.uint8)
+    bits = [np.unpackbits(np.ascontiguousarray(words[i]).astype("<u4", copy=False).view(np.uint8).reshape(n, 4),
+                          axis=1, bitorder="little")[:, :k] for i in range(3)]
+    idx = bits[1] << 1
+    idx |= bits[0]
+    idx |= bits[2] << 2
+    return _WORD_LUT[idx]
 
 
 def strings_of(chars: np.ndarray) -> list[str]:
     n, k = chars.shape
     if n == 0:
         return []
-    return [s.decode() for s in np.ascontiguousarray(chars).view(f"S{k}").ravel().tolist()] if k else [""] * n
+    if not k:
+        return [""] * n
+    buf = np.ascontiguousarray(chars).tobytes().decode("ascii")      # one decode, then n slices
+    return [buf[i:i + k] for i in range(0, n * k, k)]
