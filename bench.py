@@ -91,7 +91,7 @@ def main():
     ap.add_argument("--v", type=int, default=1)
     ap.add_argument("--cands", type=int, default=8, help="candidates per window")
     ap.add_argument("--seed", type=int, default=20250303)
-    ap.add_argument("--cpu-rows", type=int, default=49152, help="rows of the shard timed on the CPU oracle")
+    ap.add_argument("--cpu-rows", type=int, default=131072, help="rows of the shard timed on the CPU oracle (~13 s for the whole shard)")
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--bucket", type=int, default=4, help="steps whose counters share one all-reduce (N > 1)")
     a = ap.parse_args()
