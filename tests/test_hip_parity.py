@@ -249,3 +249,31 @@ def test_candidate_grouping_paths_match_oracle(hip_lib, oracle_lib, monkeypatch,
                 m.setenv(key, val)
             got = hip.eval_candidates(cw, codes, sF, sR)
         assert np.array_equal(got, want), f"counters differ with {env or 'defaults'}"
+
+
+@pytest.mark.parametrize("n,k,v", [(1, 5, 0), (63, 2, 1), (64, 16, 2), (65, 17, 1), (257, 27, 2), (2049, 28, 1),
+                                   (33000, 28, 2), (8200, 3, 0), (16500, 21, 1)])
+def test_kernel_shapes_and_extreme_k(hip_lib, oracle_lib, monkeypatch, n, k, v):
+    """Row counts around the word / block boundaries and the smallest and largest k, chains of every kind."""
+    v = min(v, k - 1)
+    L, p0 = 4 * k + 40, 1                              # the half-gap fuzz rows keep more than k residues
+    data, off, _ = fuzz_msa(1000 + n + k, n, L, ragged=False, p_gap=0.02, p_iupac=0.003, edge=0.2)
+    W = min(L - p0 - k - 1, 60)
+    rng = np.random.default_rng(n + 31 * k)
+    root = np.array([1, 2, 4, 8], np.uint8)[rng.integers(0, 4, size=L)]
+    hip, ora = both(hip_lib, oracle_lib, data, off)
+    n_ex = hip.build_windows(p0, W, k, v)
+    assert ora.build_windows(p0, W, k, v) == n_ex
+    for a, b in zip(hip.window_stats(), ora.window_stats()):
+        assert np.array_equal(a, b)
+    sF = sum(1 << y for y in (0, 2) if y < k)
+    sR = sum(1 << y for y in (k - 1, k - 3) if 0 <= y < k)
+    for kind in ("up", "down", "mixed"):
+        cw, codes = chain_candidates(rng, root, W, k, kind)
+        want = ora.eval_candidates(cw, codes, sF, sR)
+        for env in ({}, {"MP_EVAL_GROUP": "plain"}, {"MP_EVAL_CHAIN": "0"}, {"MP_EVAL_CHAIN": "6"}):
+            with monkeypatch.context() as m:
+                for key, val in env.items():
+                    m.setenv(key, val)
+                got = hip.eval_candidates(cw, codes, sF, sR)
+            assert np.array_equal(got, want), f"{kind} counters differ with {env or 'defaults'}"
