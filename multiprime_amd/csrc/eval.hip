@@ -1,5 +1,10 @@
 // eval.hip — part of libmprime_hip.so: hand-written HIP (gfx950 / MI355X, wave64) behind the C ABI of
-// include/mprime.h.  Candidate x sequence coverage evaluation: bit-sliced kernel, list kernel, row-per-lane kernel (mp_eval_*).
+// include/mprime.h.  Candidate x sequence coverage evaluation (mp_eval_*) and per-window statistics (mp_window_stats):
+//   (4)  row-per-lane evaluation on the window words — eval_kernel (v > 2, MP_EVAL_MODE=rows), eval_list_block (patch rows)
+//   (4b) bit-sliced evaluation on the one-hot column planes, any 8 candidates — eval_bits_kernel
+//   (4c) bit-sliced evaluation of nested refinement chains — eval_chain_kernel (the benchmarked kernel)
+//   (4d) state_matrix / trans_matrix counts — window_stats_kernel, window_stats_list_kernel
+//   per-sequence coverage masks — mask_rows_kernel
 #include "common.hpp"
 
 using namespace mp;
