@@ -556,6 +556,7 @@ class NN_degenerate(object):
                     cand_s.extend(s.chain)
                 windows.append(win)
             self.stats["plan_s"] = time.time() - t0
+            self.stats["windows_planned"] = len(windows)      # passed the gap / entropy / composition gates (V20:713-740)
             n_cand = len(cand_w)
             t0 = time.time()
             if n_cand:

@@ -49,6 +49,6 @@ with tempfile.TemporaryDirectory() as td:
     print(json.dumps({"pairing_wall_s": round(pair_wall, 2), "pairs": n_pairs, "bitset_file_bytes": os.path.getsize(os.path.join(td, "out.tsv.coverage_bitsets.npz")),
                       "pairing_stats": {k: (round(v, 3) if isinstance(v, float) else v) for k, v in pf.stats.items()}}))
     print(json.dumps({"rows": a.rows, "cols": a.cols, "k": a.k, "generate_s": round(t_gen, 2), "wall_s": round(wall, 2),
-                      "windows": app.n_windows, "rows_out": n_out, "n_candidates": app.stats.get("n_candidates"),
+                      "windows": app.n_windows, "windows_past_the_gates": app.stats.get("windows_planned"), "rows_out": n_out, "n_candidates": app.stats.get("n_candidates"),
                       "phases": {k: round(v, 3) for k, v in app.stats.items() if isinstance(v, float)},
                       "device_bytes": app.ctx.device_bytes()}))
