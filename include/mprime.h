@@ -62,6 +62,12 @@ const char *mp_backend_name(void);
 int mp_set_stream(mp_ctx *ctx, void *hip_stream);
 
 /* (1) alignment -> device ----------------------------------------------------------------- */
+/* Row shards: the alignment is at least n_columns wide even if no row of this context's share is
+ * that long (the window range comes from quantiles over ALL rows, V20:617-640).  Call before
+ * mp_load_msa; windows may then start anywhere below max(longest local row, n_columns), and a row
+ * that ends before a window is an ordinary ragged row. */
+int mp_reserve_columns(mp_ctx *ctx, int32_t n_columns);
+
 /* Replaces the per-character work of parse_seq (V20:441-455): `bytes` holds, back to back,
  * the residue characters of each record (the host has already joined a record's lines and
  * dropped '>' / '#' lines); row r is bytes[row_off[r] .. row_off[r+1]).  Per character:

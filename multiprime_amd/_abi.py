@@ -27,6 +27,7 @@ SYMBOLS = [
     ("mp_last_error", C.c_char_p, [_p]),
     ("mp_backend_name", C.c_char_p, []),
     ("mp_set_stream", C.c_int, [_p, _p]),
+    ("mp_reserve_columns", C.c_int, [_p, C.c_int32]),
     ("mp_load_msa", C.c_int, [_p, _p, _p, C.c_int32]),
     ("mp_row_attributes", C.c_int, [_p, _p, _p, _p]),
     ("mp_build_windows", C.c_int, [_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.POINTER(C.c_int32)]),
@@ -115,6 +116,10 @@ class Context:
         self._ck(self.d.mp_set_stream(self.h, C.c_void_p(stream_handle)))
 
     # (1)
+    def reserve_columns(self, n_columns: int):
+        """Row shards: the alignment is at least this wide even if no local row is (call before load_msa)."""
+        self._ck(self.d.mp_reserve_columns(self.h, int(n_columns)))
+
     def load_msa(self, data: np.ndarray, row_off: np.ndarray):
         data = np.ascontiguousarray(data, dtype=np.uint8)
         row_off = np.ascontiguousarray(row_off, dtype=np.int64)

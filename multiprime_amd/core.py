@@ -195,6 +195,7 @@ class NN_degenerate(object):
         self.seq_ids = ids
         self.total_sequence_number = len(ids)
         if comm is not None:
+            self.ctx.reserve_columns(int(np.diff(row_off).max()))      # windows span the whole alignment, not this shard's rows
             data, row_off = comm.take_shard(data, row_off)
         self.ctx.load_msa(data, row_off)
         lead, rstrip, _ = self.ctx.row_attributes()

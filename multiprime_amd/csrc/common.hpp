@@ -139,6 +139,7 @@ struct mp_ctx {
     int64_t bytes = 0;
     // alignment
     int n_rows = 0, n_pad = 0, n_chunks = 0, max_len = 0, ustride = 0;
+    int reserve_cols = 0;                    // mp_reserve_columns: minimum alignment width (row shards)
     uint32_t *planes = nullptr, *cum = nullptr, *ung = nullptr;
     unsigned long long *cols = nullptr;      // [n_chunks*32][4][n_pad/64]
     int32_t *lead = nullptr, *rstrip = nullptr, *rlen = nullptr;

@@ -144,6 +144,13 @@ int pack_init() {
 
 extern "C" {
 
+int mp_reserve_columns(mp_ctx *c, int32_t n_columns) {
+    if (!c) return MP_ERR_ARG;
+    if (n_columns < 0 || n_columns > 0x3fffffff) return fail(c, MP_ERR_ARG, "mp_reserve_columns: bad width %d", n_columns);
+    c->reserve_cols = n_columns;
+    return MP_OK;
+}
+
 int mp_load_msa(mp_ctx *c, const uint8_t *bytes, const int64_t *row_off, int32_t n_rows) {
     if (!c) return MP_ERR_ARG;
     if (!bytes || !row_off || n_rows <= 0) return fail(c, MP_ERR_ARG, "mp_load_msa: bad arguments");
@@ -157,6 +164,7 @@ int mp_load_msa(mp_ctx *c, const uint8_t *bytes, const int64_t *row_off, int32_t
     }
     c->n_rows = n_rows;
     c->n_pad = (n_rows + kBlock - 1) / kBlock * kBlock;
+    max_len = std::max<int64_t>(max_len, c->reserve_cols);      // row shards: the alignment is wider than the local rows
     c->max_len = (int)max_len;
     c->n_chunks = (int)((max_len + 31) / 32) + 2;
     c->ustride = (int)(max_len / 8) + 2;

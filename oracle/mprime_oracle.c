@@ -22,7 +22,7 @@
 
 struct mp_ctx {
     char err[512];
-    int32_t n_rows;
+    int32_t n_rows, reserve_cols;
     char **rows;      /* mapped characters, NUL-terminated */
     int32_t *len;
     /* windows */
@@ -98,6 +98,13 @@ void mp_destroy(mp_ctx *c) {
 static char map_char(unsigned char ch) {
     int u = toupper(ch);
     return (u && strchr("ACGTRYMKSWHBVD", u)) ? (char)u : '-';
+}
+
+int mp_reserve_columns(mp_ctx *c, int32_t n_columns) {
+    if (!c) return MP_ERR_ARG;
+    if (n_columns < 0 || n_columns > 0x3fffffff) return fail(c, MP_ERR_ARG, "mp_reserve_columns: bad width %d", n_columns);
+    c->reserve_cols = n_columns;
+    return MP_OK;
 }
 
 int mp_load_msa(mp_ctx *c, const uint8_t *bytes, const int64_t *off, int32_t n_rows) {
@@ -194,10 +201,12 @@ static uint8_t iupac_code(char ch) {
 
 int mp_build_windows(mp_ctx *c, int32_t p0, int32_t n_win, int32_t k, int32_t v, int32_t *n_exc) {
     if (!c || !c->rows) return c ? fail(c, MP_ERR_ARG, "no alignment loaded") : MP_ERR_ARG;
-    if (k < 2 || k > MP_MAX_K || n_win <= 0 || p0 < 0 || v < 0) return fail(c, MP_ERR_ARG, "bad window arguments (k=%d)", k);
-    free_windows(c);
+    if (k < 2 || k > MP_MAX_K || n_win <= 0 || p0 < 0 || v < 0 || v >= k)
+        return fail(c, MP_ERR_ARG, "bad window arguments (k=%d v=%d n_windows=%d)", k, v, n_win);
     int32_t N = c->n_rows, maxlen = 0;
     for (int32_t r = 0; r < N; r++) if (c->len[r] > maxlen) maxlen = c->len[r];
+    if (p0 + n_win > (maxlen > c->reserve_cols ? maxlen : c->reserve_cols)) return fail(c, MP_ERR_ARG, "windows run past the longest row");
+    free_windows(c);
     c->p0 = p0; c->n_win = n_win; c->k = k; c->v = v;
     c->kmers = (char *)calloc((size_t)n_win * N * k, 1);
     c->words = (uint32_t *)calloc((size_t)n_win * 3 * N, sizeof(uint32_t));

@@ -63,3 +63,38 @@ def test_product_never_reaches_into_the_oracle():
                 txt = open(os.path.join(root, f)).read()
                 for needle in ("libmprime_oracle", "import oracle", "from oracle", "oracle/_build"):
                     assert needle not in txt, (f, needle)
+
+
+def _calls_in_wrong_order(lib):
+    """Every entry point that needs earlier state must refuse with a negative code and a message, not crash."""
+    import numpy as np
+    from multiprime_amd._abi import MprimeError
+    ctx = lib.context(0)
+    for call in (lambda: ctx.build_windows(0, 4, 8, 1), lambda: ctx.row_attributes()):
+        with pytest.raises(MprimeError, match="no alignment loaded"):
+            call()
+    data = np.frombuffer(b"ACGTACGTACGTACGTACGTACGTAC" * 3, np.uint8)
+    ctx.load_msa(data, np.array([0, 26, 52, 78], np.int64))
+    ctx.n_win, ctx.k = 4, 8                                     # what build_windows would have set on the wrapper
+    for call in (lambda: ctx.window_stats(), lambda: ctx.window_unique(),
+                 lambda: ctx.eval_candidates(np.zeros(1, np.int32), np.ones((1, 8), np.uint8), 0, 0)):
+        with pytest.raises(MprimeError, match="no windows built"):
+            call()
+    with pytest.raises(MprimeError):
+        ctx.build_windows(0, 4, 40, 1)                          # k > MP_MAX_K
+    with pytest.raises(MprimeError):
+        ctx.build_windows(0, 400, 8, 1)                         # windows past the longest row
+    assert ctx.build_windows(0, 4, 8, 1) == 0
+    with pytest.raises(MprimeError, match="ascending"):
+        ctx.eval_candidates(np.array([2, 1], np.int32), np.ones((2, 8), np.uint8), 0, 0)
+    freq, nn = ctx.window_stats()
+    assert freq.sum() == 4 * 3 * 8 and nn.sum() == 4 * 3 * 7    # 4 windows x 3 sequences x k (k - 1) symbols
+
+
+def test_oracle_refuses_calls_in_the_wrong_order(oracle_lib):
+    _calls_in_wrong_order(oracle_lib)
+
+
+@pytest.mark.gpu
+def test_hip_refuses_calls_in_the_wrong_order(hip_lib):
+    _calls_in_wrong_order(hip_lib)

@@ -90,7 +90,7 @@ def test_rccl_path_single_rank(tmp_path):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("name,world", [("syn_iupac", 2), ("msa1000_k18_d64", 2)])
+@pytest.mark.parametrize("name,world", [("syn_iupac", 2), ("msa1000_k18_d64", 2), ("syn_ragged", 3)])
 def test_sharded_hip_contexts_match_reference(name, world, hip_lib, tmp_path):
     """Two ranks, each with its own HIP context on the one GPU of the box (gloo carries the collectives): row
     offsets, histogram merging and counter all-reduce on top of the real kernels."""
