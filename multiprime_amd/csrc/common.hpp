@@ -38,6 +38,8 @@ constexpr int kEvalCC = 8;                // candidates evaluated per block pass
 
 struct ExRec { int32_t win, row; uint64_t lo, hi; };          // exception k-mer, 16+12 nibbles
 struct EvalItem { int32_t win, cand0; };                       // one block's work: window + first padded candidate
+// Patch planes of one window: k x 4 plane rows of npw words from pplanes[poff], npw validity words from pvalid[voff]
+struct PatchWin { int32_t poff, voff, npw; };
 // One nested run of candidates for eval_chain_kernel: 8 output slots from cand0, n_steps of them used,
 // n_ev events (position | lost base << 8 | step << 16) from ev0.
 struct ChainItem {
@@ -159,6 +161,14 @@ struct mp_ctx {
     int32_t *extra_off = nullptr;
     uint32_t *extra_words = nullptr;
     int n_extra = 0;
+    // patch planes: the patch rows and the IUPAC expansion rows of every window as one-hot planes of their own
+    // (position-major, like `cols` but per window), so the bit-sliced kernels cover them too; built on demand
+    std::vector<int32_t> h_patch_off, h_extra_off;       // host copies of the two per-window offset tables
+    uint32_t *pplanes = nullptr, *pvalid = nullptr;
+    mp::PatchWin *pwin = nullptr;                        // [W]
+    size_t pp_words = 0, pv_words = 0;
+    int max_npw = 0;                                     // widest window, in 32-row words
+    bool pp_dirty = true;
     // unique
     long long u_cap = 0, u_n = 0;
     uint32_t *u_b0 = nullptr, *u_b1 = nullptr, *u_g = nullptr;

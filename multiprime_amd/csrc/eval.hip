@@ -1,9 +1,9 @@
 // eval.hip — part of libmprime_hip.so: hand-written HIP (gfx950 / MI355X, wave64) behind the C ABI of
 // include/mprime.h.  Candidate x sequence coverage evaluation (mp_eval_*) and per-window statistics (mp_window_stats):
-//   (4)  row-per-lane evaluation on the window words — eval_kernel (v > 2, MP_EVAL_MODE=rows), eval_list_block (patch rows)
+//   (4)  row-per-lane evaluation on the window words — eval_kernel (v > 2, MP_EVAL_MODE=rows); patch planes for the rest
 //   (4b) bit-sliced evaluation on the one-hot column planes, any 8 candidates — eval_bits_kernel
 //   (4c) bit-sliced evaluation of nested refinement chains — eval_chain_kernel (the benchmarked kernel)
-//   (4d) state_matrix / trans_matrix counts — window_stats_kernel, window_stats_list_kernel
+//   (4d) state_matrix / trans_matrix counts — window_stats_kernel
 //   per-sequence coverage masks — mask_rows_kernel
 #include "common.hpp"
 
@@ -180,66 +180,89 @@ __global__ __launch_bounds__(kBlock) void eval_kernel(const EvalArgs A) {
 }
 
 
-// Row-per-lane evaluation of two compact per-window lists of window words: the patch list (rows with
-// edge-gap repair / ragged ends, built on the device) and the host-expanded IUPAC rows.  It rides in the
-// same launch as a bit-sliced kernel: the first n_blocks workgroups of that launch do this (item = b / ny,
-// part y = b % ny of the item's lists), concurrently with the column-plane work of the others.
-struct EvalListArgs {
-    const EvalItem *items;
-    const uint4 *cand_n;
-    const int32_t *cand_out;
-    const int32_t *off_a;
-    const uint32_t *words_a;
-    const int32_t *off_b;       // may be nullptr
-    const uint32_t *words_b;
-    uint32_t sF, sR;
-    int v;
-    uint32_t kmask;
-    unsigned long long *out;
-    int ny, n_blocks;           // parts per item; ny * n_items rounded up to a multiple of 8 (0: no list work)
-    int n_items;
+// ----------------------------------------------------------------------------------------------
+// Patch planes: the rows `excl` takes out of the column-plane pass — k-mers with edge-gap repair or a ragged end
+// (device-built patch list) and the host-expanded IUPAC rows — get one-hot planes of their own, per window and
+// position: pplanes[poff + (j * 4 + base) * npw + word], 32 rows per word, npw a multiple of 8 words, zero padded.
+// A bit-sliced workgroup then either covers a slice of the alignment's columns or the patch planes of its item's
+// window (`WordTile`); the kernels do not care which.
+// ----------------------------------------------------------------------------------------------
+struct PatchArgs {
+    const uint32_t *pplanes;
+    const uint32_t *pvalid;
+    const PatchWin *pwin;      // [W]
+    int per_item;              // patch units per item (0: no patch rows anywhere); a unit = one WAVE in the evaluation kernels
+                               // (4 items' patch planes per workgroup: they are a few hundred rows each), one workgroup in window_stats
+    int n_blocks;              // workgroups holding the units, rounded up to a multiple of 8; they come first in the grid
 };
 
-template <int CC, int VMODE>
-__device__ __forceinline__ void eval_list_block(const EvalListArgs &L, int item, int y, uint32_t *s_acc) {
-    const EvalItem it = L.items[item];
-    uint32_t nA[CC], nC[CC], nG[CC], nT[CC];
-    EvalAcc<CC, 1> acc;
-    acc.clear();
-#pragma unroll
-    for (int c = 0; c < CC; c++) {
-        uint4 q = L.cand_n[it.cand0 + c];
-        nA[c] = q.x; nC[c] = q.y; nG[c] = q.z; nT[c] = q.w;
-    }
-    if (threadIdx.x < 3 * CC) s_acc[threadIdx.x] = 0;
-    EvalArgs A;
-    A.sF = L.sF; A.sR = L.sR; A.v = L.v; A.kmask = L.kmask;
-    for (int which = 0; which < 2; which++) {
-        const int32_t *off = which ? L.off_b : L.off_a;
-        const uint32_t *words = which ? L.words_b : L.words_a;
-        if (!off) continue;
-        const int e0 = off[it.win], e1 = off[it.win + 1];
-        for (int eb = e0 + y * kBlock; eb < e1; eb += L.ny * kBlock) {     // uniform per wave
-            int e = eb + threadIdx.x;
-            uint32_t b0 = 0, b1 = 0, g = 0xFFFFFFFFu;
-            if (e < e1) { b0 = words[3 * (size_t)e]; b1 = words[3 * (size_t)e + 1]; g = words[3 * (size_t)e + 2]; }
-            eval_row<CC, VMODE, 1, 2>(b0, b1, g, A, nA, nC, nG, nT, acc);
+struct WordTile {
+    const uint32_t *planes;    // plane (j, base) of the tile's first word: planes + (j * 4 + base) * stride
+    const uint32_t *mask;      // validity words: valid = mask[i] ^ mask_flip
+    uint32_t stride, mask_flip;
+    bool live;
+};
+
+// words [word0, word0 + GW) of the column planes of window `win` (valid = not excluded) ...
+__device__ __forceinline__ WordTile column_tile(const unsigned long long *cols, const unsigned long long *excl, int nw, int p0,
+                                                int win, int word0) {
+    const size_t nw32 = (size_t)nw * 2;
+    WordTile t;
+    t.planes = reinterpret_cast<const uint32_t *>(cols) + ((size_t)(p0 + win) * 4) * nw32 + word0;
+    t.mask = reinterpret_cast<const uint32_t *>(excl) + (size_t)win * nw32 + word0;
+    t.stride = (uint32_t)nw32;
+    t.mask_flip = 0xFFFFFFFFu;
+    t.live = word0 < (int)nw32;                        // nw32 % GW == 0 (n_pad % 256 == 0, GW <= 8)
+    return t;
+}
+// ... or of the window's patch planes
+__device__ __forceinline__ WordTile patch_tile(const PatchArgs &P, int win, int word0) {
+    const PatchWin pw = P.pwin[win];
+    WordTile t;
+    t.planes = P.pplanes + pw.poff + word0;
+    t.mask = P.pvalid + pw.voff + word0;
+    t.stride = (uint32_t)pw.npw;
+    t.mask_flip = 0u;
+    t.live = word0 < pw.npw;                           // npw % 8 == 0
+    return t;
+}
+
+// one block per window: 64 rows per wave pass, one ballot per (position, base)
+__global__ __launch_bounds__(kBlock) void patch_planes_kernel(const int32_t *__restrict__ off_a, const uint32_t *__restrict__ words_a,
+                                                              const int32_t *__restrict__ off_b, const uint32_t *__restrict__ words_b,
+                                                              const PatchWin *__restrict__ pwin, int k, int v,
+                                                              uint32_t *__restrict__ pplanes, uint32_t *__restrict__ pvalid) {
+    const int win = blockIdx.x;
+    const PatchWin pw = pwin[win];
+    const int na = off_a ? off_a[win + 1] - off_a[win] : 0, nb = off_b ? off_b[win + 1] - off_b[win] : 0;
+    const uint32_t kmask = (1u << k) - 1u;
+    const int lane = threadIdx.x & 63;
+    for (int r0 = (threadIdx.x >> 6) * 64; r0 < na + nb; r0 += kBlock) {          // uniform per wave
+        const int e = r0 + lane;
+        uint32_t b0 = 0, b1 = 0, g = 0xFFFFFFFFu;
+        if (e < na) {
+            const size_t q = 3 * ((size_t)off_a[win] + e);
+            b0 = words_a[q]; b1 = words_a[q + 1]; g = words_a[q + 2];
+        } else if (e < na + nb) {
+            const size_t q = 3 * ((size_t)off_b[win] + (e - na));
+            b0 = words_b[q]; b1 = words_b[q + 1]; g = words_b[q + 2];
         }
-    }
-    __syncthreads();
+        const bool ok = e < na + nb && !(g & MP_WIN_SKIP) && __popc(g & kmask) <= v;
+        const unsigned long long okb = __ballot(ok);
+        const int w0 = r0 >> 5;                                                    // r0 % 64 == 0; npw is even
+        if (lane == 0) { pvalid[pw.voff + w0] = (uint32_t)okb; pvalid[pw.voff + w0 + 1] = (uint32_t)(okb >> 32); }
+        for (int j = 0; j < k; j++) {
+            const bool base_here = ok && !((g >> j) & 1u);
+            const uint32_t code = ((b0 >> j) & 1u) | (((b1 >> j) & 1u) << 1);
 #pragma unroll
-    for (int c = 0; c < CC; c++) {
-        if ((threadIdx.x & 63) == 0) {
-            atomicAdd(&s_acc[3 * c], acc.p[c]);
-            atomicAdd(&s_acc[3 * c + 1], acc.f[c] - acc.p[c]);
-            atomicAdd(&s_acc[3 * c + 2], acc.r[c] - acc.p[c]);
+            for (uint32_t b = 0; b < 4; b++) {
+                const unsigned long long bal = __ballot(base_here && code == b);
+                if (lane == 0) {
+                    uint32_t *dst = pplanes + pw.poff + ((size_t)j * 4 + b) * pw.npw + w0;
+                    dst[0] = (uint32_t)bal; dst[1] = (uint32_t)(bal >> 32);
+                }
+            }
         }
-    }
-    __syncthreads();
-    if (threadIdx.x < 3 * CC) {
-        int oc = L.cand_out[it.cand0 + threadIdx.x / 3];
-        uint32_t val = s_acc[threadIdx.x];
-        if (oc >= 0 && val) atomicAdd(&L.out[(size_t)oc * 3 + threadIdx.x % 3], (unsigned long long)val);
     }
 }
 
@@ -305,7 +328,7 @@ struct EvalBitsArgs {
     BlockMap map;                      // row slices per item (ny; ny_pad = rounded up to 1, 2, 4 or a multiple of 8), items
     const uint32_t *diff_mask;         // [item] positions where the item's candidates do not all carry the same symbol
     const int32_t *item_ids;           // items this launch covers (null: all of them)
-    EvalListArgs list;                 // patch / IUPAC rows riding in the first list.n_blocks workgroups
+    PatchArgs patch;                   // patch / IUPAC rows: the first patch.n_blocks workgroups run on their planes
 };
 
 // Sum over the 64 lanes of a wave with DPP adds only (no LDS); the total ends up in lane 63.  All lanes active.
@@ -352,6 +375,35 @@ __device__ __forceinline__ void block_commit(const uint32_t (&accP)[8], const ui
     }
 }
 
+// The same for ONE wave (a patch unit): lane 63's totals go through the wave's own LDS row, lanes 0..23 add them.
+template <int GW>
+__device__ __forceinline__ void wave_commit(const uint32_t (&accP)[8], const uint32_t (&accF)[8], const uint32_t (&accR)[8],
+                                            uint32_t (&s_part)[kBlock / 64][12], const int32_t *cand_out, unsigned long long *out) {
+    constexpr int CC = 8;
+    uint32_t vals[3 * CC];
+#pragma unroll
+    for (int c = 0; c < CC; c++) { vals[3 * c] = accP[c]; vals[3 * c + 1] = accF[c]; vals[3 * c + 2] = accR[c]; }
+    uint32_t tot[3 * CC / 2];
+#pragma unroll
+    for (int q = 0; q < 3 * CC / 2; q++) tot[q] = wave_sum_lane63(vals[2 * q] | (vals[2 * q + 1] << 16));
+    const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    if (lane == 63) {
+#pragma unroll
+        for (int q = 0; q < 3 * CC / 2; q++) s_part[wv][q] = tot[q];
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    if (lane < 3 * CC) {
+        const int c = lane / 3, r = lane % 3;
+        const uint32_t mine = (s_part[wv][lane >> 1] >> (16 * (lane & 1))) & 0xFFFFu;
+        const uint32_t perfect = (s_part[wv][(3 * c) >> 1] >> (16 * ((3 * c) & 1))) & 0xFFFFu;
+        const uint32_t val = r ? mine - perfect : mine;
+        const int oc = cand_out[c];
+        if (oc >= 0 && val) atomicAdd(&out[(size_t)oc * 3 + r], (unsigned long long)val);
+    }
+}
+
 // XCD-aware block mapping shared by both kernels: workgroup b runs on XCD b % 8 (observed dispatch order) and every
 // XCD has its own L2, so the (item, row slice) grid is laid out to let consecutive windows re-read their k-1 shared
 // columns from ONE L2.  With 8 or more slices (ny_pad a multiple of 8) slice = b % ny_pad: an XCD owns slices.  With
@@ -379,19 +431,24 @@ template <int LV, int GW, bool CHAIN, int D>
 __global__ __launch_bounds__(kBlock) void eval_bits_kernel(const EvalBitsArgs A) {
     constexpr int CC = 8;
     __shared__ uint32_t s_part[kBlock / 64][3 * CC / 2];
-    if ((int)blockIdx.x < A.list.n_blocks) {
-        if ((int)blockIdx.x < A.list.ny * A.list.n_items)
-            eval_list_block<CC, LV - 1>(A.list, blockIdx.x / A.list.ny, blockIdx.x % A.list.ny, &s_part[0][0]);
-        return;
+    const bool on_patch = (int)blockIdx.x < A.patch.n_blocks;
+    int slice, idx, word0;
+    if (on_patch) {                                    // a wave per patch unit: everything below is wave-uniform
+        const int unit = __builtin_amdgcn_readfirstlane((int)(blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6)));
+        idx = unit / A.patch.per_item;
+        slice = unit % A.patch.per_item;
+        if (idx >= A.map.n_items) return;
+        word0 = (slice * 64 + (int)(threadIdx.x & 63)) * GW;
+    } else {
+        if (!map_block(A.map, blockIdx.x - A.patch.n_blocks, slice, idx)) return;
+        word0 = (slice * kBlock + threadIdx.x) * GW;
     }
-    int slice, idx;
-    if (!map_block(A.map, blockIdx.x - A.list.n_blocks, slice, idx)) return;
     const int item = A.item_ids ? A.item_ids[idx] : idx;
     const EvalItem it = A.items[item];
-    const size_t nw32 = (size_t)A.nw * 2;             // 32-bit words per plane row
-    const int word0 = (slice * kBlock + threadIdx.x) * GW;
-    const bool live = word0 < (int)nw32;              // nw32 % GW == 0 (n_pad % 256 == 0, GW <= 8)
-    const uint32_t *cols = reinterpret_cast<const uint32_t *>(A.cols);
+    const WordTile T = on_patch ? patch_tile(A.patch, it.win, word0) : column_tile(A.cols, A.excl, A.nw, A.p0, it.win, word0);
+    if (on_patch && slice * 64 * GW >= (int)T.stride) return;               // nothing of this window's patch planes left for the wave
+    const size_t nw32 = T.stride;                     // 32-bit words per plane row of the tile
+    const bool live = T.live;
     const uint32_t kbits = (1u << A.k) - 1u;           // k <= MP_MAX_K = 28
     const uint32_t diff = CHAIN ? (__builtin_amdgcn_readfirstlane(A.diff_mask[item]) & kbits) : kbits;
     const uint32_t same = kbits & ~diff;
@@ -407,7 +464,7 @@ __global__ __launch_bounds__(kBlock) void eval_bits_kernel(const EvalBitsArgs A)
 #pragma unroll
             for (int c = 0; c < CC; c++) t1[c][i] = t2[c][i] = t3[c][i] = sf[c][i] = sr[c][i] = 0;
         }
-        const uint32_t *Pw = cols + ((size_t)(A.p0 + it.win) * 4) * nw32 + word0;
+        const uint32_t *Pw = T.planes;
         const uint32_t *symrow = A.cand_symT + (size_t)item * 32;
         // (1) positions where all candidates of the item carry the same symbol: one match word for all of them,
         // branch-free (the symbol's base masks are wave-uniform)
@@ -512,10 +569,9 @@ __global__ __launch_bounds__(kBlock) void eval_bits_kernel(const EvalBitsArgs A)
                 }
             }
         }
-        const uint32_t *E = reinterpret_cast<const uint32_t *>(A.excl) + (size_t)it.win * nw32 + word0;
 #pragma unroll
         for (int i = 0; i < GW; i++) {
-            const uint32_t valid = ~E[i];
+            const uint32_t valid = T.mask[i] ^ T.mask_flip;
 #pragma unroll
             for (int c = 0; c < CC; c++) {
                 // exact saturating sum of the shared and the per-candidate counters
@@ -530,7 +586,8 @@ __global__ __launch_bounds__(kBlock) void eval_bits_kernel(const EvalBitsArgs A)
             }
         }
     }
-    block_commit<GW>(accP, accF, accR, s_part, A.cand_out + it.cand0, A.out);
+    if (on_patch) wave_commit<GW>(accP, accF, accR, s_part, A.cand_out + it.cand0, A.out);
+    else block_commit<GW>(accP, accF, accR, s_part, A.cand_out + it.cand0, A.out);
 }
 
 // ----------------------------------------------------------------------------------------------
@@ -552,7 +609,7 @@ struct EvalChainArgs {
     uint32_t sF, sR;
     unsigned long long *out;
     BlockMap map;
-    EvalListArgs list;                 // patch / IUPAC rows riding in the first list.n_blocks workgroups
+    PatchArgs patch;                   // patch / IUPAC rows: the first patch.n_blocks workgroups run on their planes
 };
 
 // One pass of the first candidate over the positions in `rem` whose symbol has NB bases (NB = 4: three or four,
@@ -628,18 +685,23 @@ template <int LV, int GW, int D>
 __global__ __launch_bounds__(kBlock) void eval_chain_kernel(const EvalChainArgs A) {
     constexpr int CC = 8;
     __shared__ uint32_t s_part[kBlock / 64][3 * CC / 2];
-    if ((int)blockIdx.x < A.list.n_blocks) {
-        if ((int)blockIdx.x < A.list.ny * A.list.n_items)
-            eval_list_block<CC, LV - 1>(A.list, blockIdx.x / A.list.ny, blockIdx.x % A.list.ny, &s_part[0][0]);
-        return;
+    const bool on_patch = (int)blockIdx.x < A.patch.n_blocks;
+    int slice, item, word0;
+    if (on_patch) {                                    // a wave per patch unit: everything below is wave-uniform
+        const int unit = __builtin_amdgcn_readfirstlane((int)(blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6)));
+        item = unit / A.patch.per_item;
+        slice = unit % A.patch.per_item;
+        if (item >= A.map.n_items) return;
+        word0 = (slice * 64 + (int)(threadIdx.x & 63)) * GW;
+    } else {
+        if (!map_block(A.map, blockIdx.x - A.patch.n_blocks, slice, item)) return;
+        word0 = (slice * kBlock + threadIdx.x) * GW;
     }
-    int slice, item;
-    if (!map_block(A.map, blockIdx.x - A.list.n_blocks, slice, item)) return;
     const ChainItem it = A.items[item];
-    const size_t nw32 = (size_t)A.nw * 2;
-    const int word0 = (slice * kBlock + threadIdx.x) * GW;
-    const bool live = word0 < (int)nw32;
-    const uint32_t *cols = reinterpret_cast<const uint32_t *>(A.cols);
+    const WordTile T = on_patch ? patch_tile(A.patch, it.win, word0) : column_tile(A.cols, A.excl, A.nw, A.p0, it.win, word0);
+    if (on_patch && slice * 64 * GW >= (int)T.stride) return;               // nothing of this window's patch planes left for the wave
+    const size_t nw32 = T.stride;
+    const bool live = T.live;
     uint32_t accP[CC], accF[CC], accR[CC];
 #pragma unroll
     for (int c = 0; c < CC; c++) accP[c] = accF[c] = accR[c] = 0;
@@ -647,7 +709,7 @@ __global__ __launch_bounds__(kBlock) void eval_chain_kernel(const EvalChainArgs 
         uint32_t t1[GW], t2[GW], t3[GW], sf[GW], sr[GW];
 #pragma unroll
         for (int i = 0; i < GW; i++) t1[i] = t2[i] = t3[i] = sf[i] = sr[i] = 0;
-        const uint32_t *Pw = cols + ((size_t)(A.p0 + it.win) * 4) * nw32 + word0;
+        const uint32_t *Pw = T.planes;
         const unsigned long long sy_lo = it.sym[0] | ((unsigned long long)it.sym[1] << 32);
         const unsigned long long sy_hi = it.sym[2] | ((unsigned long long)it.sym[3] << 32);
         // (1) the first candidate over all k positions, grouped by the number of bases of its symbol there
@@ -656,9 +718,8 @@ __global__ __launch_bounds__(kBlock) void eval_chain_kernel(const EvalChainArgs 
         chain_first_pass<LV, GW, (D + 3) / 4, 4>(it.pos4, Pw, nw32, sy_lo, sy_hi, A.sF, A.sR, t1, t2, t3, sf, sr);
         uint32_t valid[GW];
         {
-            const uint32_t *E = reinterpret_cast<const uint32_t *>(A.excl) + (size_t)it.win * nw32 + word0;
 #pragma unroll
-            for (int i = 0; i < GW; i++) valid[i] = ~E[i];
+            for (int i = 0; i < GW; i++) valid[i] = T.mask[i] ^ T.mask_flip;
         }
         // (2) walk down the chain: apply the events of step s, then count candidate s
         const uint32_t *ev = A.events + it.ev0;
@@ -709,14 +770,15 @@ __global__ __launch_bounds__(kBlock) void eval_chain_kernel(const EvalChainArgs 
             }
         }
     }
-    block_commit<GW>(accP, accF, accR, s_part, A.cand_out + it.cand0, A.out);
+    if (on_patch) wave_commit<GW>(accP, accF, accR, s_part, A.cand_out + it.cand0, A.out);
+    else block_commit<GW>(accP, accF, accR, s_part, A.cand_out + it.cand0, A.out);
 }
 
 // ----------------------------------------------------------------------------------------------
 // (4d) per-window base and nearest-neighbour counts (mp_window_stats; state_matrix / trans_matrix,
 // V20:541-577).  Same universe, same planes: freq[w][b][j] = popcount(valid_w & plane[col w+j][b]),
 // nn[w][j][a][b] = popcount(valid_w & plane[col w+j][a] & plane[col w+j+1][b]) over the plain rows, plus
-// a row-per-lane pass over the patch / IUPAC lists.  20 counters per position: a thread sums its GW words,
+// the same pass over the windows' patch planes.  20 counters per position: a thread sums its GW words,
 // packs two 16-bit counts per register, six DPP adds give the wave total, lane 63 adds it to the block's
 // LDS table, the block adds its k x 20 totals to the global counters.
 // ----------------------------------------------------------------------------------------------
@@ -727,11 +789,7 @@ struct StatsArgs {
     BlockMap map;                      // items = windows
     unsigned long long *freq;          // [W][4][k]
     unsigned long long *nn;            // [W][k-1][16]
-    const int32_t *off_a;              // patch list (may be nullptr)
-    const uint32_t *words_a;
-    const int32_t *off_b;              // IUPAC expansion rows (may be nullptr)
-    const uint32_t *words_b;
-    int n_win;
+    PatchArgs patch;
 };
 
 __device__ __forceinline__ void stats_flush(const StatsArgs &A, int win, const uint32_t (*s_cnt)[20]) {
@@ -747,18 +805,27 @@ __device__ __forceinline__ void stats_flush(const StatsArgs &A, int win, const u
 template <int GW>
 __global__ __launch_bounds__(kBlock) void window_stats_kernel(const StatsArgs A) {
     __shared__ uint32_t s_cnt[MP_MAX_K][20];           // [position][4 base counts, then 16 pair counts (j, j+1)]
+    const bool on_patch = (int)blockIdx.x < A.patch.n_blocks;
     int slice, win;
-    if (!map_block(A.map, blockIdx.x, slice, win)) return;
+    if (on_patch) {
+        win = blockIdx.x / A.patch.per_item;
+        slice = blockIdx.x % A.patch.per_item;
+        if (win >= A.map.n_items) return;
+    } else if (!map_block(A.map, blockIdx.x - A.patch.n_blocks, slice, win)) {
+        return;
+    }
+    const int word0 = (slice * kBlock + threadIdx.x) * GW;
+    const WordTile T = on_patch ? patch_tile(A.patch, win, word0) : column_tile(A.cols, A.excl, A.nw, A.p0, win, word0);
+    if (on_patch && (int)(slice * kBlock * GW) >= (int)T.stride) return;
     for (int t = threadIdx.x; t < MP_MAX_K * 20; t += kBlock) (&s_cnt[0][0])[t] = 0;
     __syncthreads();
-    const size_t nw32 = (size_t)A.nw * 2;
-    const int word0 = (slice * kBlock + threadIdx.x) * GW;
-    const bool live = word0 < (int)nw32;
-    const uint32_t *Pw = reinterpret_cast<const uint32_t *>(A.cols) + ((size_t)(A.p0 + win) * 4) * nw32 + word0;
+    const size_t nw32 = T.stride;
+    const bool live = T.live;
+    const uint32_t *Pw = T.planes;
     uint32_t valid[GW], cur[4][GW], nxt[4][GW];
 #pragma unroll
     for (int i = 0; i < GW; i++) {
-        valid[i] = live ? ~(reinterpret_cast<const uint32_t *>(A.excl) + (size_t)win * nw32 + word0)[i] : 0u;
+        valid[i] = live ? (T.mask[i] ^ T.mask_flip) : 0u;
 #pragma unroll
         for (int b = 0; b < 4; b++) cur[b][i] = live ? (valid[i] & Pw[b * nw32 + i]) : 0u;
     }
@@ -799,35 +866,6 @@ __global__ __launch_bounds__(kBlock) void window_stats_kernel(const StatsArgs A)
         for (int b = 0; b < 4; b++)
 #pragma unroll
             for (int i = 0; i < GW; i++) cur[b][i] = nxt[b][i];
-    }
-    __syncthreads();
-    stats_flush(A, win, s_cnt);
-}
-
-// the patch rows and the IUPAC expansion rows of one window, a row per lane
-__global__ __launch_bounds__(kBlock) void window_stats_list_kernel(const StatsArgs A) {
-    __shared__ uint32_t s_cnt[MP_MAX_K][20];
-    const int win = blockIdx.x;
-    for (int t = threadIdx.x; t < MP_MAX_K * 20; t += kBlock) (&s_cnt[0][0])[t] = 0;
-    __syncthreads();
-    const uint32_t kmask = (1u << A.k) - 1u;
-    for (int which = 0; which < 2; which++) {
-        const int32_t *off = which ? A.off_b : A.off_a;
-        const uint32_t *words = which ? A.words_b : A.words_a;
-        if (!off) continue;
-        for (int e = off[win] + threadIdx.x; e < off[win + 1]; e += kBlock) {
-            const uint32_t b0 = words[3 * (size_t)e], b1 = words[3 * (size_t)e + 1], g = words[3 * (size_t)e + 2];
-            if ((g & MP_WIN_SKIP) || __popc(g & kmask) > A.v) continue;
-            for (int j = 0; j < A.k; j++) {
-                if ((g >> j) & 1u) continue;
-                const uint32_t a = ((b0 >> j) & 1u) | (((b1 >> j) & 1u) << 1);
-                atomicAdd(&s_cnt[j][a], 1u);
-                if (j + 1 < A.k && !((g >> (j + 1)) & 1u)) {
-                    const uint32_t b = ((b0 >> (j + 1)) & 1u) | (((b1 >> (j + 1)) & 1u) << 1);
-                    atomicAdd(&s_cnt[j][4 + a * 4 + b], 1u);
-                }
-            }
-        }
     }
     __syncthreads();
     stats_flush(A, win, s_cnt);
@@ -886,6 +924,54 @@ const EvalVariant kEvalVariants[] = {
 constexpr int kNumEvalVariants = (int)(sizeof(kEvalVariants) / sizeof(kEvalVariants[0]));
 
 
+
+// (Re)builds the patch planes after mp_build_windows / mp_set_extra_rows changed the lists they mirror.
+int ensure_patch_planes(mp_ctx *c) {
+    if (!c->pp_dirty) return MP_OK;
+    dev_free(c, &c->pplanes, c->pp_words); dev_free(c, &c->pvalid, c->pv_words); dev_free(c, &c->pwin, (size_t)c->n_win);
+    c->pp_words = c->pv_words = 0;
+    c->max_npw = 0;
+    const size_t W = (size_t)c->n_win;
+    std::vector<PatchWin> pw(W);
+    size_t poff = 0, voff = 0;
+    for (size_t w = 0; w < W; w++) {
+        const int n = (c->h_patch_off[w + 1] - c->h_patch_off[w]) + (c->h_extra_off[w + 1] - c->h_extra_off[w]);
+        const int npw = ((n + 31) / 32 + 7) / 8 * 8;
+        if (poff + (size_t)c->k * 4 * npw > 0x7fffffffu) return fail(c, MP_ERR_NOMEM, "patch planes too large");
+        pw[w] = PatchWin{(int32_t)poff, (int32_t)voff, npw};
+        poff += (size_t)c->k * 4 * npw;
+        voff += (size_t)npw;
+        c->max_npw = std::max(c->max_npw, npw);
+    }
+    int rc;
+    if ((rc = dev_alloc(c, &c->pwin, W))) return rc;
+    HIPCK(c, hipMemcpyAsync(c->pwin, pw.data(), sizeof(PatchWin) * W, hipMemcpyHostToDevice, c->stream));
+    if (poff) {
+        if ((rc = dev_alloc(c, &c->pplanes, poff))) return rc;
+        if ((rc = dev_alloc(c, &c->pvalid, voff))) return rc;
+        c->pp_words = poff; c->pv_words = voff;
+        HIPCK(c, hipMemsetAsync(c->pplanes, 0, sizeof(uint32_t) * poff, c->stream));
+        HIPCK(c, hipMemsetAsync(c->pvalid, 0, sizeof(uint32_t) * voff, c->stream));
+        hipLaunchKernelGGL(patch_planes_kernel, dim3((unsigned)W), dim3(kBlock), 0, c->stream,
+                           c->n_patch ? c->patch_off : (const int32_t *)nullptr, c->patch_words,
+                           c->n_extra ? c->extra_off : (const int32_t *)nullptr, c->extra_words, c->pwin, c->k, c->v, c->pplanes, c->pvalid);
+        HIPCK(c, hipGetLastError());
+    }
+    HIPCK(c, hipStreamSynchronize(c->stream));            // pw is a host temporary
+    c->pp_dirty = false;
+    return MP_OK;
+}
+
+// patch units of a launch over n_items items with GW words per thread and unit_threads threads per unit
+PatchArgs patch_args(const mp_ctx *c, int GW, int n_items, int unit_threads) {
+    PatchArgs pa{c->pplanes, c->pvalid, c->pwin, 0, 0};
+    if (c->max_npw > 0 && n_items > 0) {
+        pa.per_item = (c->max_npw + unit_threads * GW - 1) / (unit_threads * GW);
+        const long long units = (long long)pa.per_item * n_items, per_block = kBlock / unit_threads;
+        pa.n_blocks = (int)(((units + per_block - 1) / per_block + 7) / 8 * 8);
+    }
+    return pa;
+}
 
 }  // namespace
 
@@ -1088,26 +1174,16 @@ int mp_eval_launch(mp_ctx *c, int64_t *device_out) {
             grid = m.ny_pad >= 8 ? (unsigned)((size_t)n_items * m.ny_pad) : (unsigned)(8 * (size_t)m.per_band);
             return m;
         };
-        // the patch / IUPAC rows ride in the first bit-sliced launch
-        EvalListArgs la{c->items, c->cand_n, c->cand_out, c->n_patch ? c->patch_off : (const int32_t *)nullptr, c->patch_words,
-                        c->n_extra ? c->extra_off : (const int32_t *)nullptr, c->extra_words, c->sF, c->sR, c->v,
-                        (1u << c->k) - 1u, (unsigned long long *)device_out, 0, 0, c->n_items};
-        if (c->n_patch || c->n_extra) {
-            la.ny = std::max(1, std::min(64, (c->max_patch + 2047) / 2048));
-            la.n_blocks = (la.ny * c->n_items + 7) / 8 * 8;
-        }
-        EvalListArgs no_list = la;
-        no_list.ny = no_list.n_blocks = 0;
-        bool list_done = la.n_blocks == 0;
+        { int rc = ensure_patch_planes(c); if (rc) return rc; }
         static const EvalBitsFn tfn[3][2] = {{eval_bits_kernel<1, 2, true, 1>, eval_bits_kernel<1, 2, false, 1>},
                                              {eval_bits_kernel<2, 2, true, 1>, eval_bits_kernel<2, 2, false, 1>},
                                              {eval_bits_kernel<3, 2, true, 1>, eval_bits_kernel<3, 2, false, 1>}};
         if (shape == 0 && c->n_chain) {
             // words per thread x positions in flight: the more sequences a block covers, the further its fixed costs
-            // (24 popcount totals, item and event fetches) are spread — 8 x 2 from 32768 sequences up (half a block of
+            // (24 popcount totals, item and event fetches) are spread — 8 x 4 from 32768 sequences up (half a block of
             // threads at that size), 4 x 3 from 16384, else 2 x 6 / 1 x 6.  MP_EVAL_CHAIN overrides (tools/variant_bench.py).
             const int nw32 = 2 * nw;
-            int cshape = nw32 >= 4 * kBlock ? 6 : (nw32 >= 2 * kBlock ? 3 : (nw32 >= kBlock ? 0 : 5));
+            int cshape = nw32 >= 4 * kBlock ? 7 : (nw32 >= 2 * kBlock ? 3 : (nw32 >= kBlock ? 0 : 5));
             if (const char *e = getenv("MP_EVAL_CHAIN")) { cshape = atoi(e); if (cshape < 0 || cshape > 9) cshape = 0; }
             static const int cgw[10] = {2, 2, 2, 4, 4, 1, 8, 8, 8, 16};
 #define CHAIN_ROW(LV) {eval_chain_kernel<LV, 2, 6>, eval_chain_kernel<LV, 2, 3>, eval_chain_kernel<LV, 2, 9>, eval_chain_kernel<LV, 4, 3>, \
@@ -1118,9 +1194,8 @@ int mp_eval_launch(mp_ctx *c, int64_t *device_out) {
             unsigned grid;
             const BlockMap bm = block_map(cgw[cshape], c->n_chain, grid);
             EvalChainArgs ca{c->cols, c->excl, nw, c->p0, c->k, c->v, c->chain_items, c->chain_events, c->cand_out, c->sF, c->sR,
-                             (unsigned long long *)device_out, bm, list_done ? no_list : la};
-            hipLaunchKernelGGL(cfn[c->v][cshape], dim3(grid + (unsigned)ca.list.n_blocks), dim3(kBlock), 0, c->stream, ca);
-            list_done = true;
+                             (unsigned long long *)device_out, bm, patch_args(c, cgw[cshape], c->n_chain, 64)};
+            hipLaunchKernelGGL(cfn[c->v][cshape], dim3(grid + (unsigned)ca.patch.n_blocks), dim3(kBlock), 0, c->stream, ca);
         }
         const int n_tab = shape == 0 ? c->n_table : c->n_items;
         if (n_tab) {
@@ -1128,9 +1203,8 @@ int mp_eval_launch(mp_ctx *c, int64_t *device_out) {
             const BlockMap bm = block_map(2, n_tab, grid);
             EvalBitsArgs ba{c->cols, c->excl, nw, c->p0, c->k, c->v, c->items, c->cand_symT, c->cand_out, c->sF, c->sR,
                             (unsigned long long *)device_out, bm, c->cand_diff, shape == 0 ? c->table_ids : (const int32_t *)nullptr,
-                            list_done ? no_list : la};
-            hipLaunchKernelGGL(tfn[c->v][shape == 1 ? 1 : 0], dim3(grid + (unsigned)ba.list.n_blocks), dim3(kBlock), 0, c->stream, ba);
-            list_done = true;
+                            patch_args(c, 2, n_tab, 64)};
+            hipLaunchKernelGGL(tfn[c->v][shape == 1 ? 1 : 0], dim3(grid + (unsigned)ba.patch.n_blocks), dim3(kBlock), 0, c->stream, ba);
         }
     } else {
     EvalArgs ea{c->win, c->n_pad, c->k, c->items, c->cand_n, c->cand_out, c->n_extra ? c->extra_off : (const int32_t *)nullptr,
@@ -1187,14 +1261,12 @@ int mp_window_stats(mp_ctx *c, int64_t *freq, int64_t *nn) {
     const int bands = m.ny_pad >= 8 ? 1 : 8 / m.ny_pad;
     m.per_band = (c->n_win + bands - 1) / bands;
     const unsigned grid = m.ny_pad >= 8 ? (unsigned)((size_t)c->n_win * m.ny_pad) : (unsigned)(8 * (size_t)m.per_band);
-    StatsArgs sa{c->cols, c->excl, nw, c->p0, c->k, c->v, m, d, d + n_f,
-                 c->n_patch ? c->patch_off : (const int32_t *)nullptr, c->patch_words,
-                 c->n_extra ? c->extra_off : (const int32_t *)nullptr, c->extra_words, c->n_win};
-    if (GW == 4) hipLaunchKernelGGL(window_stats_kernel<4>, dim3(grid), dim3(kBlock), 0, c->stream, sa);
-    else if (GW == 2) hipLaunchKernelGGL(window_stats_kernel<2>, dim3(grid), dim3(kBlock), 0, c->stream, sa);
-    else hipLaunchKernelGGL(window_stats_kernel<1>, dim3(grid), dim3(kBlock), 0, c->stream, sa);
-    if (c->n_patch || c->n_extra)
-        hipLaunchKernelGGL(window_stats_list_kernel, dim3((unsigned)c->n_win), dim3(kBlock), 0, c->stream, sa);
+    if ((rc = ensure_patch_planes(c))) { dev_free(c, &d, n_f + n_t); return rc; }
+    StatsArgs sa{c->cols, c->excl, nw, c->p0, c->k, c->v, m, d, d + n_f, patch_args(c, GW, c->n_win, kBlock)};
+    const dim3 full(grid + (unsigned)sa.patch.n_blocks);
+    if (GW == 4) hipLaunchKernelGGL(window_stats_kernel<4>, full, dim3(kBlock), 0, c->stream, sa);
+    else if (GW == 2) hipLaunchKernelGGL(window_stats_kernel<2>, full, dim3(kBlock), 0, c->stream, sa);
+    else hipLaunchKernelGGL(window_stats_kernel<1>, full, dim3(kBlock), 0, c->stream, sa);
     HIPCK(c, hipGetLastError());
     HIPCK(c, hipMemcpyAsync(freq, d, sizeof(int64_t) * n_f, hipMemcpyDeviceToHost, c->stream));
     HIPCK(c, hipMemcpyAsync(nn, d + n_f, sizeof(int64_t) * n_t, hipMemcpyDeviceToHost, c->stream));
