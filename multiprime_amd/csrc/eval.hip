@@ -1158,7 +1158,7 @@ int mp_eval_launch(mp_ctx *c, int64_t *device_out) {
     const bool bits = c->v <= 2 && !(mode_env && !strcmp(mode_env, "rows"));
     const int vmode = c->v == 0 ? 0 : (c->v == 1 ? 1 : 2);     // predicate specialisation of the row-per-lane code
     if (bits) {
-        // bit-sliced pass over the column planes + row-per-lane pass over the patch / IUPAC lists
+        // bit-sliced pass over the column planes and over the windows' patch planes
         // MP_EVAL_BITS: 0 (default) = nested-chain kernel on the nested items + symbol-table kernel (with the shared-
         // position shortcut) on the others; 1 = symbol-table kernel on every item, no shortcut; 2 = the same with it
         int shape = 0;
