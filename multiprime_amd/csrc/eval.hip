@@ -1,6 +1,6 @@
 // eval.hip — part of libmprime_hip.so: hand-written HIP (gfx950 / MI355X, wave64) behind the C ABI of
 // include/mprime.h.  Candidate x sequence coverage evaluation (mp_eval_*) and per-window statistics (mp_window_stats):
-//   (4)  row-per-lane evaluation on the window words — eval_kernel (v > 2, MP_EVAL_MODE=rows); patch planes for the rest
+//   (4)  row-per-lane evaluation on the window words — eval_kernel (v > 3, MP_EVAL_MODE=rows); patch planes for the rest
 //   (4b) bit-sliced evaluation on the one-hot column planes, any 8 candidates — eval_bits_kernel
 //   (4c) bit-sliced evaluation of nested refinement chains — eval_chain_kernel (the benchmarked kernel)
 //   (4d) state_matrix / trans_matrix counts — window_stats_kernel
@@ -273,7 +273,7 @@ __global__ __launch_bounds__(kBlock) void patch_planes_kernel(const int32_t *__r
 // flag) the symbol at window position j is column p0+w+j of the alignment, so the evaluation runs
 // on the one-hot COLUMN planes (A, C, G, T; a gap sets none): "sequence matches symbol s at position
 // j" is the OR of the planes of s's bases — for a concrete symbol just one loaded word, no ALU work.
-// Mismatch counts are bit-sliced saturating counters (t1 = ">= 1", t2 = ">= 2", t3 = ">= 3": LV =
+// Mismatch counts are bit-sliced saturating counters (t1 = ">= 1", t2 = ">= 2", t3, t4 likewise: LV =
 // v+1 levels), the strict-position sets two more words, the three coverage counters popcounts at
 // the end.  Rows with more than v gaps never count (V20:689): build_windows folded them into `excl`.
 // Two kernels share this scheme:
@@ -301,14 +301,16 @@ static_assert(kLutOrAnd == 0xF8 && kLutAndNotNot == 0x10, "v_bitop3 truth tables
 
 // add one "mismatch where NOT m" plane to saturating counters
 template <int LV>
-__device__ __forceinline__ void count_unmatched(uint32_t &t1, uint32_t &t2, uint32_t &t3, uint32_t m) {
+__device__ __forceinline__ void count_unmatched(uint32_t &t1, uint32_t &t2, uint32_t &t3, uint32_t &t4, uint32_t m) {
+    if (LV >= 4) t4 = __builtin_amdgcn_bitop3_b32(t4, t3, m, kLutOrAndNot);
     if (LV >= 3) t3 = __builtin_amdgcn_bitop3_b32(t3, t2, m, kLutOrAndNot);
     if (LV >= 2) t2 = __builtin_amdgcn_bitop3_b32(t2, t1, m, kLutOrAndNot);
     t1 = __builtin_amdgcn_bitop3_b32(t1, m, m, kLutOrNot);
 }
 // add one "mismatch where d" plane
 template <int LV>
-__device__ __forceinline__ void count_plane(uint32_t &t1, uint32_t &t2, uint32_t &t3, uint32_t d) {
+__device__ __forceinline__ void count_plane(uint32_t &t1, uint32_t &t2, uint32_t &t3, uint32_t &t4, uint32_t d) {
+    if (LV >= 4) t4 = __builtin_amdgcn_bitop3_b32(t4, t3, d, kLutOrAnd);
     if (LV >= 3) t3 = __builtin_amdgcn_bitop3_b32(t3, t2, d, kLutOrAnd);
     if (LV >= 2) t2 = __builtin_amdgcn_bitop3_b32(t2, t1, d, kLutOrAnd);
     t1 |= d;
@@ -456,13 +458,13 @@ __global__ __launch_bounds__(kBlock) void eval_bits_kernel(const EvalBitsArgs A)
 #pragma unroll
     for (int c = 0; c < CC; c++) accP[c] = accF[c] = accR[c] = 0;
     if (live) {
-        uint32_t t1[CC][GW], t2[CC][GW], t3[CC][GW], sf[CC][GW], sr[CC][GW];
-        uint32_t c1[GW], c2[GW], c3[GW], csf[GW], csr[GW];      // counters of the positions all candidates share
+        uint32_t t1[CC][GW], t2[CC][GW], t3[CC][GW], t4[CC][GW], sf[CC][GW], sr[CC][GW];
+        uint32_t c1[GW], c2[GW], c3[GW], c4[GW], csf[GW], csr[GW];      // counters of the positions all candidates share
 #pragma unroll
         for (int i = 0; i < GW; i++) {
-            c1[i] = c2[i] = c3[i] = csf[i] = csr[i] = 0;
+            c1[i] = c2[i] = c3[i] = c4[i] = csf[i] = csr[i] = 0;
 #pragma unroll
-            for (int c = 0; c < CC; c++) t1[c][i] = t2[c][i] = t3[c][i] = sf[c][i] = sr[c][i] = 0;
+            for (int c = 0; c < CC; c++) t1[c][i] = t2[c][i] = t3[c][i] = t4[c][i] = sf[c][i] = sr[c][i] = 0;
         }
         const uint32_t *Pw = T.planes;
         const uint32_t *symrow = A.cand_symT + (size_t)item * 32;
@@ -499,7 +501,7 @@ __global__ __launch_bounds__(kBlock) void eval_bits_kernel(const EvalBitsArgs A)
                         m = __builtin_amdgcn_bitop3_b32(pl[u][1][i], kC, m, kLutAndOr);
                         m = __builtin_amdgcn_bitop3_b32(pl[u][2][i], kG, m, kLutAndOr);
                         m = __builtin_amdgcn_bitop3_b32(pl[u][3][i], kT, m, kLutAndOr);
-                        count_unmatched<LV>(c1[i], c2[i], c3[i], m);
+                        count_unmatched<LV>(c1[i], c2[i], c3[i], c4[i], m);
                         csf[i] = __builtin_amdgcn_bitop3_b32(csf[i], m, fF, kLutOrNotAnd);
                         csr[i] = __builtin_amdgcn_bitop3_b32(csr[i], m, fR, kLutOrNotAnd);
                     }
@@ -552,7 +554,7 @@ __global__ __launch_bounds__(kBlock) void eval_bits_kernel(const EvalBitsArgs A)
 #pragma unroll
                         for (int i = 0; i < GW; i++) m[c][i] = tab[sy][i];
 #pragma unroll
-                        for (int i = 0; i < GW; i++) count_unmatched<LV>(t1[c][i], t2[c][i], t3[c][i], m[c][i]);
+                        for (int i = 0; i < GW; i++) count_unmatched<LV>(t1[c][i], t2[c][i], t3[c][i], t4[c][i], m[c][i]);
                     }
                     if (jF) {
 #pragma unroll
@@ -579,6 +581,7 @@ __global__ __launch_bounds__(kBlock) void eval_bits_kernel(const EvalBitsArgs A)
                 uint32_t far = a1;
                 if (LV >= 2) far = t2[c][i] | c2[i] | (t1[c][i] & c1[i]);
                 if (LV >= 3) far = t3[c][i] | c3[i] | (t2[c][i] & c1[i]) | (t1[c][i] & c2[i]);
+                if (LV >= 4) far = t4[c][i] | c4[i] | (t3[c][i] & c1[i]) | (t2[c][i] & c2[i]) | (t1[c][i] & c3[i]);
                 const uint32_t bf = sf[c][i] | csf[i], br = sr[c][i] | csr[i];
                 accP[c] += __popc(valid & ~a1);
                 accF[c] += __popc(__builtin_amdgcn_bitop3_b32(valid, far, bf, kLutAndNotNot));
@@ -618,7 +621,8 @@ struct EvalChainArgs {
 template <int LV, int GW, int D, int NB>
 __device__ __forceinline__ void chain_first_pass(uint32_t rem, const uint32_t *Pw, size_t nw32, unsigned long long sy_lo,
                                                  unsigned long long sy_hi, uint32_t sF, uint32_t sR, uint32_t (&t1)[GW],
-                                                 uint32_t (&t2)[GW], uint32_t (&t3)[GW], uint32_t (&sf)[GW], uint32_t (&sr)[GW]) {
+                                                 uint32_t (&t2)[GW], uint32_t (&t3)[GW], uint32_t (&t4)[GW], uint32_t (&sf)[GW],
+                                                 uint32_t (&sr)[GW]) {
 #pragma unroll 1
     while (rem) {
         int js[D]; bool has[D];
@@ -668,7 +672,7 @@ __device__ __forceinline__ void chain_first_pass(uint32_t rem, const uint32_t *P
                 for (int i = 0; i < GW; i++) m[i] = NB == 2 ? (ld[u][0][i] | ld[u][1][i]) : ld[u][0][i];
             }
 #pragma unroll
-            for (int i = 0; i < GW; i++) count_unmatched<LV>(t1[i], t2[i], t3[i], m[i]);
+            for (int i = 0; i < GW; i++) count_unmatched<LV>(t1[i], t2[i], t3[i], t4[i], m[i]);
             if (((sF | sR) >> j) & 1u) {
                 const uint32_t fF = ((sF >> j) & 1u) ? 0xFFFFFFFFu : 0u, fR = ((sR >> j) & 1u) ? 0xFFFFFFFFu : 0u;
 #pragma unroll
@@ -706,16 +710,16 @@ __global__ __launch_bounds__(kBlock) void eval_chain_kernel(const EvalChainArgs 
 #pragma unroll
     for (int c = 0; c < CC; c++) accP[c] = accF[c] = accR[c] = 0;
     if (live) {
-        uint32_t t1[GW], t2[GW], t3[GW], sf[GW], sr[GW];
+        uint32_t t1[GW], t2[GW], t3[GW], t4[GW], sf[GW], sr[GW];
 #pragma unroll
-        for (int i = 0; i < GW; i++) t1[i] = t2[i] = t3[i] = sf[i] = sr[i] = 0;
+        for (int i = 0; i < GW; i++) t1[i] = t2[i] = t3[i] = t4[i] = sf[i] = sr[i] = 0;
         const uint32_t *Pw = T.planes;
         const unsigned long long sy_lo = it.sym[0] | ((unsigned long long)it.sym[1] << 32);
         const unsigned long long sy_hi = it.sym[2] | ((unsigned long long)it.sym[3] << 32);
         // (1) the first candidate over all k positions, grouped by the number of bases of its symbol there
-        chain_first_pass<LV, GW, D, 1>(it.pos1, Pw, nw32, sy_lo, sy_hi, A.sF, A.sR, t1, t2, t3, sf, sr);
-        chain_first_pass<LV, GW, (D + 1) / 2, 2>(it.pos2, Pw, nw32, sy_lo, sy_hi, A.sF, A.sR, t1, t2, t3, sf, sr);
-        chain_first_pass<LV, GW, (D + 3) / 4, 4>(it.pos4, Pw, nw32, sy_lo, sy_hi, A.sF, A.sR, t1, t2, t3, sf, sr);
+        chain_first_pass<LV, GW, D, 1>(it.pos1, Pw, nw32, sy_lo, sy_hi, A.sF, A.sR, t1, t2, t3, t4, sf, sr);
+        chain_first_pass<LV, GW, (D + 1) / 2, 2>(it.pos2, Pw, nw32, sy_lo, sy_hi, A.sF, A.sR, t1, t2, t3, t4, sf, sr);
+        chain_first_pass<LV, GW, (D + 3) / 4, 4>(it.pos4, Pw, nw32, sy_lo, sy_hi, A.sF, A.sR, t1, t2, t3, t4, sf, sr);
         uint32_t valid[GW];
         {
 #pragma unroll
@@ -747,7 +751,7 @@ __global__ __launch_bounds__(kBlock) void eval_chain_kernel(const EvalChainArgs 
                     }
                     const uint32_t j = evw & 255u;
 #pragma unroll
-                    for (int i = 0; i < GW; i++) count_plane<LV>(t1[i], t2[i], t3[i], cur[i]);
+                    for (int i = 0; i < GW; i++) count_plane<LV>(t1[i], t2[i], t3[i], t4[i], cur[i]);
                     if (((A.sF | A.sR) >> j) & 1u) {
                         const uint32_t fF = ((A.sF >> j) & 1u) ? 0xFFFFFFFFu : 0u, fR = ((A.sR >> j) & 1u) ? 0xFFFFFFFFu : 0u;
 #pragma unroll
@@ -763,7 +767,7 @@ __global__ __launch_bounds__(kBlock) void eval_chain_kernel(const EvalChainArgs 
             }
 #pragma unroll
             for (int i = 0; i < GW; i++) {
-                const uint32_t far = LV == 1 ? t1[i] : (LV == 2 ? t2[i] : t3[i]);
+                const uint32_t far = LV == 1 ? t1[i] : (LV == 2 ? t2[i] : (LV == 3 ? t3[i] : t4[i]));
                 accP[s] += __popc(valid[i] & ~t1[i]);
                 accF[s] += __popc(__builtin_amdgcn_bitop3_b32(valid[i], far, sf[i], kLutAndNotNot));
                 accR[s] += __popc(__builtin_amdgcn_bitop3_b32(valid[i], far, sr[i], kLutAndNotNot));
@@ -1155,7 +1159,7 @@ int mp_eval_launch(mp_ctx *c, int64_t *device_out) {
         HIPCK(c, hipEventRecord(ev.first, c->stream));
     }
     const char *mode_env = getenv("MP_EVAL_MODE");
-    const bool bits = c->v <= 2 && !(mode_env && !strcmp(mode_env, "rows"));
+    const bool bits = c->v <= 3 && !(mode_env && !strcmp(mode_env, "rows"));
     const int vmode = c->v == 0 ? 0 : (c->v == 1 ? 1 : 2);     // predicate specialisation of the row-per-lane code
     if (bits) {
         // bit-sliced pass over the column planes and over the windows' patch planes
@@ -1175,9 +1179,10 @@ int mp_eval_launch(mp_ctx *c, int64_t *device_out) {
             return m;
         };
         { int rc = ensure_patch_planes(c); if (rc) return rc; }
-        static const EvalBitsFn tfn[3][2] = {{eval_bits_kernel<1, 2, true, 1>, eval_bits_kernel<1, 2, false, 1>},
+        static const EvalBitsFn tfn[4][2] = {{eval_bits_kernel<1, 2, true, 1>, eval_bits_kernel<1, 2, false, 1>},
                                              {eval_bits_kernel<2, 2, true, 1>, eval_bits_kernel<2, 2, false, 1>},
-                                             {eval_bits_kernel<3, 2, true, 1>, eval_bits_kernel<3, 2, false, 1>}};
+                                             {eval_bits_kernel<3, 2, true, 1>, eval_bits_kernel<3, 2, false, 1>},
+                                             {eval_bits_kernel<4, 2, true, 1>, eval_bits_kernel<4, 2, false, 1>}};
         if (shape == 0 && c->n_chain) {
             // words per thread x positions in flight: the more sequences a block covers, the further its fixed costs
             // (24 popcount totals, item and event fetches) are spread — 8 x 4 from 32768 sequences up (half a block of
@@ -1189,7 +1194,7 @@ int mp_eval_launch(mp_ctx *c, int64_t *device_out) {
 #define CHAIN_ROW(LV) {eval_chain_kernel<LV, 2, 6>, eval_chain_kernel<LV, 2, 3>, eval_chain_kernel<LV, 2, 9>, eval_chain_kernel<LV, 4, 3>, \
                        eval_chain_kernel<LV, 4, 6>, eval_chain_kernel<LV, 1, 6>, eval_chain_kernel<LV, 8, 2>, eval_chain_kernel<LV, 8, 4>, \
                        eval_chain_kernel<LV, 8, 1>, eval_chain_kernel<LV, 16, 1>}
-            static const EvalChainFn cfn[3][10] = {CHAIN_ROW(1), CHAIN_ROW(2), CHAIN_ROW(3)};
+            static const EvalChainFn cfn[4][10] = {CHAIN_ROW(1), CHAIN_ROW(2), CHAIN_ROW(3), CHAIN_ROW(4)};
 #undef CHAIN_ROW
             unsigned grid;
             const BlockMap bm = block_map(cgw[cshape], c->n_chain, grid);
