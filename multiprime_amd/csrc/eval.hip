@@ -687,6 +687,7 @@ __device__ __forceinline__ void chain_first_pass(uint32_t rem, const uint32_t *P
 
 template <int LV, int GW, int D>
 __global__ __launch_bounds__(kBlock) void eval_chain_kernel(const EvalChainArgs A) {
+    static_assert(GW <= 8, "plane rows are padded to multiples of 8 words");
     constexpr int CC = 8;
     __shared__ uint32_t s_part[kBlock / 64][3 * CC / 2];
     const bool on_patch = (int)blockIdx.x < A.patch.n_blocks;
@@ -1189,12 +1190,13 @@ int mp_eval_launch(mp_ctx *c, int64_t *device_out) {
             // threads at that size), 4 x 3 from 16384, else 2 x 6 / 1 x 6.  MP_EVAL_CHAIN overrides (tools/variant_bench.py).
             const int nw32 = 2 * nw;
             int cshape = nw32 >= 4 * kBlock ? 7 : (nw32 >= 2 * kBlock ? 3 : (nw32 >= kBlock ? 0 : 5));
-            if (const char *e = getenv("MP_EVAL_CHAIN")) { cshape = atoi(e); if (cshape < 0 || cshape > 9) cshape = 0; }
-            static const int cgw[10] = {2, 2, 2, 4, 4, 1, 8, 8, 8, 16};
+            if (const char *e = getenv("MP_EVAL_CHAIN")) { cshape = atoi(e); if (cshape < 0 || cshape > 8) cshape = 0; }
+            // (plane rows and patch planes are padded to multiples of 8 words: 8 words per thread is the widest legal shape)
+            static const int cgw[9] = {2, 2, 2, 4, 4, 1, 8, 8, 8};
 #define CHAIN_ROW(LV) {eval_chain_kernel<LV, 2, 6>, eval_chain_kernel<LV, 2, 3>, eval_chain_kernel<LV, 2, 9>, eval_chain_kernel<LV, 4, 3>, \
                        eval_chain_kernel<LV, 4, 6>, eval_chain_kernel<LV, 1, 6>, eval_chain_kernel<LV, 8, 2>, eval_chain_kernel<LV, 8, 4>, \
-                       eval_chain_kernel<LV, 8, 1>, eval_chain_kernel<LV, 16, 1>}
-            static const EvalChainFn cfn[4][10] = {CHAIN_ROW(1), CHAIN_ROW(2), CHAIN_ROW(3), CHAIN_ROW(4)};
+                       eval_chain_kernel<LV, 8, 1>}
+            static const EvalChainFn cfn[4][9] = {CHAIN_ROW(1), CHAIN_ROW(2), CHAIN_ROW(3), CHAIN_ROW(4)};
 #undef CHAIN_ROW
             unsigned grid;
             const BlockMap bm = block_map(cgw[cshape], c->n_chain, grid);
