@@ -1,8 +1,8 @@
 #!/usr/bin/env python3
 """Randomised soak of the HIP library against the CPU oracle through the C ABI (GPU box): random alignment shapes,
 k, v, window ranges and candidate lists (chains in either order, unrelated candidates, empty symbols), every
-grouping policy / kernel shape override, for `--seconds`.  Compares exceptions, histograms, window statistics and
-coverage counters bit for bit; prints one JSON line.  Exit code 1 on the first difference (the case is printed)."""
+grouping policy / kernel shape override, for `--seconds`.  Compares exceptions, histograms, window statistics,
+coverage counters and coverage masks bit for bit; prints one JSON line.  Exit code 1 on the first difference (the case is printed)."""
 import argparse
 import json
 import os
@@ -95,6 +95,9 @@ def main():
                 os.environ.update(env)
                 got = ctxs[0].eval_candidates(cw, codes, sF, sR)
                 assert np.array_equal(got, want), ("eval_candidates", env)
+            m = min(len(cw), 40)                                     # per-sequence coverage masks of a few candidates
+            for x, y in zip(ctxs[0].eval_masks(cw[:m], codes[:m], sF, sR), ctxs[1].eval_masks(cw[:m], codes[:m], sF, sR)):
+                assert np.array_equal(x, y), "eval_masks"
             n_cand_total += len(cw)
             n_cases += 1
         except AssertionError as e:
