@@ -227,6 +227,7 @@ class NN_degenerate(object):
         n_ex = self.ctx.build_windows(p0, W, k, v)
         ex_w, ex_r, ex_codes = self.ctx.get_exceptions(n_ex)
         exc = defaultdict(list)                  # window -> [(row, raw string)]
+        self._expansions = {}                    # raw IUPAC k-mer -> its expansions (looked at three times per exception)
         row_base = self.comm.row0 if self.comm is not None else 0
         if n_ex:
             raw = iupac.strings_of(iupac.SYMBOL_LUT[ex_codes])
@@ -234,9 +235,11 @@ class NN_degenerate(object):
             for w_, r_, s in zip(ex_w.tolist(), ex_r.tolist(), raw):
                 exc[w_].append((r_ + row_base, s))
                 if s.count("-") <= v:
-                    for e in iupac.expand(s):
-                        extra_w.append(w_)
-                        extra_k.append(e)
+                    exps = self._expansions.get(s)
+                    if exps is None:
+                        exps = self._expansions[s] = iupac.expand(s)
+                    extra_w.extend([w_] * len(exps))
+                    extra_k.extend(exps)
             if extra_w:
                 chars = np.frombuffer("".join(extra_k).encode(), np.uint8).reshape(len(extra_k), k)
                 self.ctx.set_extra_rows(np.asarray(extra_w, np.int32), iupac.words_of_kmers(chars))
@@ -293,15 +296,22 @@ class NN_degenerate(object):
                 if s.count("-") > v:
                     gap_items.append((row, 0, s))                # gap_sequence is keyed by the raw string
                 else:
-                    exp_items.extend((row, j, e) for j, e in enumerate(iupac.expand(s)))
+                    exp_items.extend((row, j, e) for j, e in enumerate(self._expand(s)))
             win.cover, win.cnt, win.gapfree = _merge_seen(win.cover, first_c, win.gapfree, exp_items)
             win.gap, _, _ = _merge_seen(win.gap, first_g, None, gap_items)
         win.gap_number = sum(win.gap.values())
         n_exc_cover = sum(1 for _, s in win.exc if s.count("-") <= v) if win.exc else 0
-        n_exp = sum(len(iupac.expand(s)) for _, s in win.exc if s.count("-") <= v) if win.exc else 0
+        n_exp = sum(len(self._expand(s)) for _, s in win.exc if s.count("-") <= v) if win.exc else 0
         # cover_number counts sequences (V20:702), cover counts expansions (V20:704)
         win.cover_number = sum(win.cover.values()) - n_exp + n_exc_cover
         return win
+
+    def _expand(self, s):
+        """Expansions of an exception k-mer, memoised per run (other ranks' exceptions arrive unexpanded)."""
+        exps = self._expansions.get(s)
+        if exps is None:
+            exps = self._expansions[s] = iupac.expand(s)
+        return exps
 
     def _entropy(self, win):
         """entropy (V20:602-614), same summation order."""
