@@ -247,7 +247,7 @@ __global__ __launch_bounds__(kBlock) void patch_planes_kernel(const int32_t *__r
             const size_t q = 3 * ((size_t)off_b[win] + (e - na));
             b0 = words_b[q]; b1 = words_b[q + 1]; g = words_b[q + 2];
         }
-        const bool ok = e < na + nb && !(g & MP_WIN_SKIP) && __popc(g & kmask) <= v;
+        const bool ok = e < na + nb && !(g & MP_WIN_SKIP) && (int)__popc(g & kmask) <= v;
         const unsigned long long okb = __ballot(ok);
         const int w0 = r0 >> 5;                                                    // r0 % 64 == 0; npw is even
         if (lane == 0) { pvalid[pw.voff + w0] = (uint32_t)okb; pvalid[pw.voff + w0 + 1] = (uint32_t)(okb >> 32); }

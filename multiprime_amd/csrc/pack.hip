@@ -24,7 +24,7 @@ static void host_code_lut(uint8_t *lut) {
 
 // thread = (row, 32-column chunk); lanes run along rows so that the plane stores coalesce
 __global__ __launch_bounds__(kBlock) void pack_kernel(const uint8_t *__restrict__ bytes, const int64_t *__restrict__ row_off,
-                                                      int n_rows, int n_pad, int n_chunks, uint32_t *__restrict__ planes) {
+                                                      int n_rows, int n_pad, int /*n_chunks*/, uint32_t *__restrict__ planes) {
     int r = blockIdx.x * kBlock + threadIdx.x;
     int c = blockIdx.y;
     if (r >= n_pad) return;
@@ -113,7 +113,7 @@ __global__ __launch_bounds__(kBlock) void ungap_kernel(const uint32_t *__restric
 // ended.  A concrete candidate symbol then needs ONE plane per position ("matches" = that plane), a
 // degenerate one the OR of its bases' planes.  IUPAC residues set several planes: windows that touch
 // one are always routed to the general path (patch list), never to the bit-sliced pass.
-__global__ __launch_bounds__(kBlock) void colplane_kernel(const uint32_t *__restrict__ planes, int n_pad, int n_chunks,
+__global__ __launch_bounds__(kBlock) void colplane_kernel(const uint32_t *__restrict__ planes, int n_pad, int /*n_chunks*/,
                                                           unsigned long long *__restrict__ cols) {
     const int r = blockIdx.x * kBlock + threadIdx.x;     // n_pad is a multiple of kBlock: every lane is live
     const int c = blockIdx.y;

@@ -152,7 +152,7 @@ __global__ __launch_bounds__(kBlock) void build_windows_kernel(
         {
             // flags and patch list; the lanes of a wave that are still here are all real rows
             const unsigned long long live = __ballot(true);
-            const unsigned long long flg = __ballot(!fast || __popc(g & kmask) > v) | ~real;
+            const unsigned long long flg = __ballot(!fast || (int)__popc(g & kmask) > v) | ~real;
             const bool keep = !fast && !(g & MP_WIN_SKIP);
             const unsigned long long kp = __ballot(keep);
             const int lane = threadIdx.x & 63;
