@@ -1,7 +1,8 @@
 """Pins the CPU oracle (oracle/mprime_oracle.c) to the reference: every intermediate the C ABI
 produces is compared with what multiPrime-core_V20.py computed internally on the same input
 (traces recorded by tests/golden/make_golden.py): the per-window `cover` and `gap_sequence`
-dictionaries in insertion order, cover_number, and the result of every mis_primer_check call.
+dictionaries in insertion order, cover_number, the state_matrix / trans_matrix counts (mp_window_stats) and the
+result of every mis_primer_check call.
 """
 import numpy as np
 import pytest
@@ -32,6 +33,7 @@ def check_against_trace(app, tr):
     p0 = int(app.start_position)
     cand_w, cand_p, want = [], [], []
     n_tables = 0
+    n_stats = [0, 0]
     for pos, rec in sorted(tr["windows"].items(), key=lambda kv: int(kv[0])):
         if "cover" not in rec:
             continue
@@ -41,11 +43,20 @@ def check_against_trace(app, tr):
         assert list(win.gap.items()) == [tuple(x) for x in rec["gap"]], f"gap_sequence at {pos}"
         assert win.cover_number == rec["cover_number"] and win.gap_number == rec["gap_number"]
         n_tables += 1
+        if "freq" in rec:                                   # state_matrix as the reference built it (rows it has, V20:541-554)
+            want_f = np.zeros((4, k), np.int64)
+            for name_, row in zip(rec["freq_rows"], rec["freq"]):
+                want_f["ACGT".index(name_)] = row
+            assert np.array_equal(app._freq[w], want_f), f"state_matrix at {pos}"
+            n_stats[0] += 1
+        if rec.get("NN") is not None:                       # trans_matrix (V20:556-577)
+            assert np.array_equal(app._nn[w], np.asarray(rec["NN"], np.int64)), f"trans_matrix at {pos}"
+            n_stats[1] += 1
         for primer, F, R, perfect, _ in rec["mis"]:
             cand_w.append(w)
             cand_p.append(primer)
             want.append((perfect, F, R))
-    assert n_tables > 0
+    assert n_tables > 0 and n_stats[0] > 0 and n_stats[1] > 0      # mp_window_stats was pinned too
     order = np.argsort(np.asarray(cand_w), kind="stable")
     codes = iupac.MASK_LUT[np.frombuffer("".join(cand_p).encode(), np.uint8)].reshape(len(cand_p), k)
     got = app.ctx.eval_candidates(np.asarray(cand_w, np.int32)[order], codes[order], app._sF, app._sR)
