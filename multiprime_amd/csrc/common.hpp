@@ -184,7 +184,7 @@ struct mp_ctx {
     uint32_t *cand_symT = nullptr, *cand_diff = nullptr, *chain_events = nullptr;
     mp::ChainItem *chain_items = nullptr;
     int32_t *table_ids = nullptr;
-    int n_chain = 0, n_table = 0, n_events = 0;
+    int n_chain = 0, n_table = 0, n_events = 0, max_steps = 0;     // max_steps: members of the longest chain item
     unsigned launch_seq = 0;                 // launches since the last timing reset
     int32_t *cand_out = nullptr;
     uint32_t sF = 0, sR = 0;

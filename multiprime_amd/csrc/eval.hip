@@ -779,6 +779,108 @@ __global__ __launch_bounds__(kBlock) void eval_chain_kernel(const EvalChainArgs 
     else block_commit<GW>(accP, accF, accR, s_part, A.cand_out + it.cand0, A.out);
 }
 
+// The same for chains of more than 8 members (up to 64): the members are counted 8 at a time — one group of output
+// slots, one commit — and the counters carry over from group to group, so the first pass runs once per chain instead
+// of once per 8 members.  A separate kernel because the extra loop costs registers (120 instead of 85 VGPRs at 8 words
+// per thread): chains of up to 8 members, the common case, keep the leaner one.
+template <int LV, int GW, int D>
+__global__ __launch_bounds__(kBlock) void eval_chain_long_kernel(const EvalChainArgs A) {
+    static_assert(GW <= 8, "plane rows are padded to multiples of 8 words");
+    constexpr int CC = 8;
+    __shared__ uint32_t s_part[kBlock / 64][3 * CC / 2];
+    const bool on_patch = (int)blockIdx.x < A.patch.n_blocks;
+    int slice, item, word0;
+    if (on_patch) {                                    // a wave per patch unit: everything below is wave-uniform
+        const int unit = __builtin_amdgcn_readfirstlane((int)(blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6)));
+        item = unit / A.patch.per_item;
+        slice = unit % A.patch.per_item;
+        if (item >= A.map.n_items) return;
+        word0 = (slice * 64 + (int)(threadIdx.x & 63)) * GW;
+    } else {
+        if (!map_block(A.map, blockIdx.x - A.patch.n_blocks, slice, item)) return;
+        word0 = (slice * kBlock + threadIdx.x) * GW;
+    }
+    const ChainItem it = A.items[item];
+    const WordTile T = on_patch ? patch_tile(A.patch, it.win, word0) : column_tile(A.cols, A.excl, A.nw, A.p0, it.win, word0);
+    if (on_patch && slice * 64 * GW >= (int)T.stride) return;               // nothing of this window's patch planes left for the wave
+    const size_t nw32 = T.stride;
+    const bool live = T.live;
+    uint32_t t1[GW], t2[GW], t3[GW], t4[GW], sf[GW], sr[GW], valid[GW], cur[GW];
+#pragma unroll
+    for (int i = 0; i < GW; i++) t1[i] = t2[i] = t3[i] = t4[i] = sf[i] = sr[i] = valid[i] = cur[i] = 0;
+    const uint32_t *Pw = T.planes;
+    const uint32_t *ev = A.events + it.ev0;
+    int e = 0;
+    uint32_t evw = it.n_ev ? ev[0] : (1u << 8);
+    if (live) {
+        const unsigned long long sy_lo = it.sym[0] | ((unsigned long long)it.sym[1] << 32);
+        const unsigned long long sy_hi = it.sym[2] | ((unsigned long long)it.sym[3] << 32);
+        // (1) the first candidate over all k positions, grouped by the number of bases of its symbol there
+        chain_first_pass<LV, GW, D, 1>(it.pos1, Pw, nw32, sy_lo, sy_hi, A.sF, A.sR, t1, t2, t3, t4, sf, sr);
+        chain_first_pass<LV, GW, (D + 1) / 2, 2>(it.pos2, Pw, nw32, sy_lo, sy_hi, A.sF, A.sR, t1, t2, t3, t4, sf, sr);
+        chain_first_pass<LV, GW, (D + 3) / 4, 4>(it.pos4, Pw, nw32, sy_lo, sy_hi, A.sF, A.sR, t1, t2, t3, t4, sf, sr);
+#pragma unroll
+        for (int i = 0; i < GW; i++) valid[i] = T.mask[i] ^ T.mask_flip;
+        const uint32_t *P = Pw + ((size_t)(evw & 255u) * 4 + (size_t)__builtin_ctz(((evw >> 8) & 15u) | 16u)) * nw32;
+#pragma unroll
+        for (int i = 0; i < GW; i++) cur[i] = P[i];
+    }
+    // (2) walk down the chain, 8 members (one group of output slots) at a time; the counters carry over between groups
+#pragma unroll 1
+    for (int g0 = 0; g0 < it.n_steps; g0 += CC) {
+        uint32_t accP[CC], accF[CC], accR[CC];
+#pragma unroll
+        for (int c = 0; c < CC; c++) accP[c] = accF[c] = accR[c] = 0;
+        if (live) {
+#pragma unroll
+            for (int s = 0; s < CC; s++) {
+                const int step = g0 + s;
+                if (step >= it.n_steps) break;
+                if (step > 0) {                            // apply the events of this step, then count the member
+#pragma unroll 1
+                    while (e < it.n_ev && (int)(evw >> 16) == step) {
+                        e++;
+                        const uint32_t evn = e < it.n_ev ? ev[e] : evw;          // the plane of the next event is on its way
+                        uint32_t nxt[GW];
+                        {
+                            const uint32_t *P = Pw + ((size_t)(evn & 255u) * 4 + (size_t)__builtin_ctz(((evn >> 8) & 15u) | 16u)) * nw32;
+#pragma unroll
+                            for (int i = 0; i < GW; i++) nxt[i] = P[i];
+                        }
+                        const uint32_t j = evw & 255u;
+#pragma unroll
+                        for (int i = 0; i < GW; i++) count_plane<LV>(t1[i], t2[i], t3[i], t4[i], cur[i]);
+                        if (((A.sF | A.sR) >> j) & 1u) {
+                            const uint32_t fF = ((A.sF >> j) & 1u) ? 0xFFFFFFFFu : 0u, fR = ((A.sR >> j) & 1u) ? 0xFFFFFFFFu : 0u;
+#pragma unroll
+                            for (int i = 0; i < GW; i++) {
+                                sf[i] = __builtin_amdgcn_bitop3_b32(sf[i], cur[i], fF, kLutOrAnd);
+                                sr[i] = __builtin_amdgcn_bitop3_b32(sr[i], cur[i], fR, kLutOrAnd);
+                            }
+                        }
+#pragma unroll
+                        for (int i = 0; i < GW; i++) cur[i] = nxt[i];
+                        evw = evn;
+                    }
+                }
+#pragma unroll
+                for (int i = 0; i < GW; i++) {
+                    const uint32_t far = LV == 1 ? t1[i] : (LV == 2 ? t2[i] : (LV == 3 ? t3[i] : t4[i]));
+                    accP[s] += __popc(valid[i] & ~t1[i]);
+                    accF[s] += __popc(__builtin_amdgcn_bitop3_b32(valid[i], far, sf[i], kLutAndNotNot));
+                    accR[s] += __popc(__builtin_amdgcn_bitop3_b32(valid[i], far, sr[i], kLutAndNotNot));
+                }
+            }
+        }
+        if (on_patch) {
+            wave_commit<GW>(accP, accF, accR, s_part, A.cand_out + it.cand0 + g0, A.out);
+        } else {
+            if (g0) __syncthreads();                       // the previous group's totals have been read out of s_part
+            block_commit<GW>(accP, accF, accR, s_part, A.cand_out + it.cand0 + g0, A.out);
+        }
+    }
+}
+
 // ----------------------------------------------------------------------------------------------
 // (4d) per-window base and nearest-neighbour counts (mp_window_stats; state_matrix / trans_matrix,
 // V20:541-577).  Same universe, same planes: freq[w][b][j] = popcount(valid_w & plane[col w+j][b]),
@@ -1000,6 +1102,7 @@ int mp_eval_upload(mp_ctx *c, int32_t n_cand, const int32_t *cw, const uint8_t *
     const char *genv = getenv("MP_EVAL_GROUP");
     const int policy = genv ? (!strcmp(genv, "plain") ? 1 : (!strcmp(genv, "nested") ? 2 : 0)) : 0;
     struct Run { int b, e; bool asc; int n_ev; };
+    constexpr int kMaxRun = 64;                  // members of one chain item (8 groups of output slots)
     auto sym_at = [&](int ci, int p) { return (uint32_t)(codes[(size_t)ci * k + p] & 15u); };
     auto diff_of = [&](int b, int e) {
         uint32_t dm = 0;
@@ -1009,16 +1112,36 @@ int mp_eval_upload(mp_ctx *c, int32_t n_cand, const int32_t *cw, const uint8_t *
         return dm;
     };
     // one item = up to 8 slots; `order` lists its candidates (for a nested run: most degenerate first)
-    auto emit = [&](int w, const std::vector<int> &order, bool nested) {
-        const int n = (int)order.size();
+    // 8 output slots (one EvalItem) from `order[g0 .. g0+8)`; `order` lists candidates (for a nested run: most degenerate first)
+    auto emit_slots = [&](int w, const std::vector<int> &order, int g0) {
+        const int n = std::min(kEvalCC, (int)order.size() - g0);
         const int item = (int)items.size();
         items.push_back(EvalItem{w, (int32_t)cn.size()});
         symT.resize(items.size() * 32, 0u);
         uint32_t dm = 0;
         for (int p = 0; p < k; p++)
             for (int t = 1; t < n; t++)
-                if (sym_at(order[t], p) != sym_at(order[0], p)) dm |= 1u << p;
+                if (sym_at(order[g0 + t], p) != sym_at(order[g0], p)) dm |= 1u << p;
         diffm.push_back(dm);
+        for (int t = 0; t < kEvalCC; t++) {
+            const int ci = order[g0 + (t < n ? t : n - 1)];      // an unused slot repeats the last candidate, reports nowhere
+            uint32_t nA = 0, nC = 0, nG = 0, nT = 0;
+            for (int p = 0; p < k; p++) {
+                const uint32_t m = sym_at(ci, p);
+                if (!(m & 1)) nA |= 1u << p;
+                if (!(m & 2)) nC |= 1u << p;
+                if (!(m & 4)) nG |= 1u << p;
+                if (!(m & 8)) nT |= 1u << p;
+                symT[(size_t)item * 32 + (size_t)p] |= m << (4 * t);
+            }
+            if (t < n) { cn.push_back(uint4{nA, nC, nG, nT}); co.push_back(ci); }
+            else { cn.push_back(uint4{kmask, kmask, kmask, kmask}); co.push_back(-1); }
+        }
+        return item;
+    };
+    // a nested run of any length up to kMaxRun is ONE chain item over consecutive 8-slot groups: the counters carry over
+    auto emit = [&](int w, const std::vector<int> &order, bool nested) {
+        const int n = (int)order.size();
         if (nested) {
             ChainItem ch{w, (int32_t)cn.size(), n, (int32_t)events.size(), 0, {0u, 0u, 0u, 0u}, 0u, 0u, 0u};
             for (int p = 0; p < k; p++) {
@@ -1035,22 +1158,9 @@ int mp_eval_upload(mp_ctx *c, int32_t n_cand, const int32_t *cw, const uint8_t *
                 }
             ch.n_ev = (int32_t)events.size() - ch.ev0;
             chains.push_back(ch);
+            for (int g0 = 0; g0 < n; g0 += kEvalCC) emit_slots(w, order, g0);
         } else {
-            table_ids.push_back(item);
-        }
-        for (int t = 0; t < kEvalCC; t++) {
-            const int ci = t < n ? order[t] : order[n - 1];      // an unused slot repeats the last candidate, reports nowhere
-            uint32_t nA = 0, nC = 0, nG = 0, nT = 0;
-            for (int p = 0; p < k; p++) {
-                const uint32_t m = sym_at(ci, p);
-                if (!(m & 1)) nA |= 1u << p;
-                if (!(m & 2)) nC |= 1u << p;
-                if (!(m & 4)) nG |= 1u << p;
-                if (!(m & 8)) nT |= 1u << p;
-                symT[(size_t)item * 32 + (size_t)p] |= m << (4 * t);
-            }
-            if (t < n) { cn.push_back(uint4{nA, nC, nG, nT}); co.push_back(ci); }
-            else { cn.push_back(uint4{kmask, kmask, kmask, kmask}); co.push_back(-1); }
+            for (int g0 = 0; g0 < n; g0 += kEvalCC) table_ids.push_back(emit_slots(w, order, g0));
         }
     };
     int i = 0;
@@ -1067,7 +1177,7 @@ int mp_eval_upload(mp_ctx *c, int32_t n_cand, const int32_t *cw, const uint8_t *
         bool has_empty = false;                     // a candidate with an empty symbol (matches nothing): symbol-table kernel only
         for (int b = i; b < j;) {
             int e = b + 1, dir = 3, n_ev = 0;
-            while (e < j && e - b < kEvalCC) {
+            while (e < j && e - b < kMaxRun) {
                 int rel = 3, changed = 0;
                 for (int p = 0; p < k; p++) {
                     const uint32_t x = sym_at(e - 1, p), y = sym_at(e, p);
@@ -1082,7 +1192,7 @@ int mp_eval_upload(mp_ctx *c, int32_t n_cand, const int32_t *cw, const uint8_t *
                 for (int p = 0; p < k; p++)
                     if (!sym_at(ci, p)) has_empty = true;
             runs.push_back(Run{b, e, (dir & 2) == 0, n_ev});
-            cost_nested += 4L * k + 4L * n_ev + 6L * (e - b) + 40;
+            cost_nested += 4L * k + 4L * n_ev + 6L * (e - b) + 40L * ((e - b + kEvalCC - 1) / kEvalCC);
             b = e;
         }
         for (int b = i; b < j; b += kEvalCC) {
@@ -1119,6 +1229,8 @@ int mp_eval_upload(mp_ctx *c, int32_t n_cand, const int32_t *cw, const uint8_t *
     if ((rc = dev_alloc(c, &c->cand_diff, diffm.size()))) return rc;
     HIPCK(c, hipMemcpy(c->cand_diff, diffm.data(), sizeof(uint32_t) * diffm.size(), hipMemcpyHostToDevice));
     c->n_chain = (int)chains.size(); c->n_table = (int)table_ids.size(); c->n_events = (int)events.size();
+    c->max_steps = 0;
+    for (const ChainItem &ch : chains) c->max_steps = std::max(c->max_steps, (int)ch.n_steps);
     if (c->n_chain) {
         if ((rc = dev_alloc(c, &c->chain_items, chains.size()))) return rc;
         HIPCK(c, hipMemcpy(c->chain_items, chains.data(), sizeof(ChainItem) * chains.size(), hipMemcpyHostToDevice));
@@ -1198,11 +1310,17 @@ int mp_eval_launch(mp_ctx *c, int64_t *device_out) {
                        eval_chain_kernel<LV, 8, 1>}
             static const EvalChainFn cfn[4][9] = {CHAIN_ROW(1), CHAIN_ROW(2), CHAIN_ROW(3), CHAIN_ROW(4)};
 #undef CHAIN_ROW
+#define CHAIN_ROW(LV) {eval_chain_long_kernel<LV, 2, 6>, eval_chain_long_kernel<LV, 2, 3>, eval_chain_long_kernel<LV, 2, 9>, \
+                       eval_chain_long_kernel<LV, 4, 3>, eval_chain_long_kernel<LV, 4, 6>, eval_chain_long_kernel<LV, 1, 6>, \
+                       eval_chain_long_kernel<LV, 8, 2>, eval_chain_long_kernel<LV, 8, 4>, eval_chain_long_kernel<LV, 8, 1>}
+            static const EvalChainFn lfn[4][9] = {CHAIN_ROW(1), CHAIN_ROW(2), CHAIN_ROW(3), CHAIN_ROW(4)};
+#undef CHAIN_ROW
             unsigned grid;
             const BlockMap bm = block_map(cgw[cshape], c->n_chain, grid);
             EvalChainArgs ca{c->cols, c->excl, nw, c->p0, c->k, c->v, c->chain_items, c->chain_events, c->cand_out, c->sF, c->sR,
                              (unsigned long long *)device_out, bm, patch_args(c, cgw[cshape], c->n_chain, 64)};
-            hipLaunchKernelGGL(cfn[c->v][cshape], dim3(grid + (unsigned)ca.patch.n_blocks), dim3(kBlock), 0, c->stream, ca);
+            hipLaunchKernelGGL((c->max_steps > kEvalCC ? lfn : cfn)[c->v][cshape], dim3(grid + (unsigned)ca.patch.n_blocks), dim3(kBlock), 0,
+                               c->stream, ca);
         }
         const int n_tab = shape == 0 ? c->n_table : c->n_items;
         if (n_tab) {
