@@ -35,6 +35,7 @@ from . import filters, iupac, msa, thermo
 from ._abi import Library
 
 _B2I = {"A": 0, "C": 1, "G": 2, "T": 3}
+_DROP_ACGT = {ord(c): None for c in "ACGT"}
 _IDX_LUT = np.full(256, 4, np.int64)
 for _c, _i in _B2I.items():
     _IDX_LUT[ord(_c)] = _i
@@ -81,7 +82,11 @@ def _desc_stable(values):
 
 
 def _npos(values):
-    return sum(1 for x in values if x > 0)
+    """Number of positive entries (of a row / column of the 4 x 4 nearest-neighbour counts)."""
+    v = values.tolist() if hasattr(values, "tolist") else values     # plain ints: no numpy scalar per comparison
+    if len(v) == 4:
+        return (v[0] > 0) + (v[1] > 0) + (v[2] > 0) + (v[3] > 0)
+    return sum(1 for x in v if x > 0)
 
 
 class _Seed:
@@ -249,6 +254,7 @@ class NN_degenerate(object):
         self._freq, self._nn = self.ctx.window_stats()
         if self.comm is not None:
             self._freq, self._nn = self.comm.sum_int64(self._freq), self.comm.sum_int64(self._nn)
+        self._nm_all = self._viterbi_all(self._freq, self._nn)
         self.stats["stats_s"] = time.time() - t0
         t0 = time.time()
         off, words, count, first = self.ctx.window_unique(want_labels=self.write_json)
@@ -354,7 +360,7 @@ class NN_degenerate(object):
         if (freq.sum(axis=0) == 0).any():            # an all-gap column (V20:738)
             return False
         NN = self._nn[win.w].copy()                  # refinement merges rows / columns in place
-        nm = self._viterbi(freq, NN)
+        nm = self._nm_all[win.w].tolist()            # get_optimal_primer_by_viterbi, all windows at once (_viterbi_all)
         mm = None
         if win.cnt is not None:                      # get_optimal_primer_by_MM (V20:595-600): first of the most frequent
             if win.gapfree.any():
@@ -377,26 +383,31 @@ class NN_degenerate(object):
         return True
 
     @staticmethod
-    def _viterbi(freq, NN):
-        """get_optimal_primer_by_viterbi (V20:579-593): max-sum path over base frequencies and
-        nearest-neighbour counts; ties go to the lowest base index (numpy argmax takes the first)."""
-        k = freq.shape[1]
-        score = freq[:, 0].copy()
+    def _viterbi_all(freq, nn):
+        """get_optimal_primer_by_viterbi (V20:579-593) for every window at once: max-sum path over base
+        frequencies (freq [W][4][k]) and nearest-neighbour counts (nn [W][k-1][4][4]); ties go to the lowest
+        base index (numpy argmax takes the first).  Returns the base indices [W][k]."""
+        W, _, k = freq.shape
+        score = freq[:, :, 0].copy()                                     # [W][a]
         back = []
         for t in range(1, k):
-            M = score[:, None] + NN[t - 1] + freq[:, t][None, :]        # M[a][b]: best score ending in a, then b
-            back.append(M.argmax(axis=0))
-            score = M.max(axis=0)
-        path = [int(score.argmax())]
+            M = score[:, :, None] + nn[:, t - 1] + freq[:, None, :, t]   # M[w][a][b]: best score ending in a, then b
+            back.append(M.argmax(axis=1))
+            score = M.max(axis=1)
+        rows = np.arange(W)
+        path = [score.argmax(axis=1)]
         for arg in reversed(back):
-            path.append(int(arg[path[-1]]))
-        return path[::-1]
+            path.append(arg[rows, path[-1]])
+        return np.stack(path[::-1], axis=1)
 
     # -- refinement ----------------------------------------------------------------------------
     def _perfect(self, cover, primer_list):
         """Sum of cover[] over the expansions of a primer (V20:954-956)."""
         get = cover.get
-        return sum(get(e, 0) for e in iupac.expand("".join(primer_list)))
+        s = "".join(primer_list)
+        if not s.translate(_DROP_ACGT):                  # a concrete primer is its own only expansion
+            return get(s, 0)
+        return sum(get(e, 0) for e in iupac.expand(s))
 
     def _refine(self, primer, cov, cover, index, nn_cov, NN):
         """refine_by_NN_array (V20:922-1089): add one base next to the weakest nearest-neighbour
@@ -605,7 +616,9 @@ class NN_degenerate(object):
                     continue
                 members = iupac.expand(primer)
                 nonsense = sum(1 for e in members if e not in win.cover and e != win.present)   # V20:846
-                tm_avg = round(mean([thermo.tm(e) for e in members]), 2)         # V20:849-852
+                tms = [thermo.tm(e) for e in members]
+                # statistics.mean is the correctly rounded exact mean; for one or two values plain float arithmetic is too
+                tm_avg = round(tms[0] if len(tms) == 1 else ((tms[0] + tms[1]) / 2 if len(tms) == 2 else mean(tms)), 2)   # V20:849-852
                 info = filters.pre_filter(primer, self.GC, self.distance)          # V20:911
                 rows_out.append([win.pos, win.cbit, win.tbit, primer, iupac.n_degenerate(primer), nonsense, cov,
                                  f_mis, r_mis, tm_avg, info])
