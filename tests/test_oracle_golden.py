@@ -33,7 +33,7 @@ def check_against_trace(app, tr):
     p0 = int(app.start_position)
     cand_w, cand_p, want = [], [], []
     n_tables = 0
-    n_stats = [0, 0]
+    n_stats = [0, 0, 0]
     for pos, rec in sorted(tr["windows"].items(), key=lambda kv: int(kv[0])):
         if "cover" not in rec:
             continue
@@ -52,11 +52,14 @@ def check_against_trace(app, tr):
         if rec.get("NN") is not None:                       # trans_matrix (V20:556-577)
             assert np.array_equal(app._nn[w], np.asarray(rec["NN"], np.int64)), f"trans_matrix at {pos}"
             n_stats[1] += 1
+        if "NM" in rec:                                     # get_optimal_primer_by_viterbi (V20:579-593), batched on the host
+            assert app._nm_all[w].tolist() == rec["NM"], f"Viterbi seed at {pos}"
+            n_stats[2] += 1
         for primer, F, R, perfect, _ in rec["mis"]:
             cand_w.append(w)
             cand_p.append(primer)
             want.append((perfect, F, R))
-    assert n_tables > 0 and n_stats[0] > 0 and n_stats[1] > 0      # mp_window_stats was pinned too
+    assert n_tables > 0 and min(n_stats) > 0                       # mp_window_stats and the Viterbi seeds were pinned too
     order = np.argsort(np.asarray(cand_w), kind="stable")
     codes = iupac.MASK_LUT[np.frombuffer("".join(cand_p).encode(), np.uint8)].reshape(len(cand_p), k)
     got = app.ctx.eval_candidates(np.asarray(cand_w, np.int32)[order], codes[order], app._sF, app._sR)
