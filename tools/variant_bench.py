@@ -1,7 +1,11 @@
 #!/usr/bin/env python3
-"""Times every eval_kernel variant compiled into libmprime_hip.so on the bench workload (same
-shard, windows and candidates as bench.py) and checks that all of them return identical counters.
-Runs on the GPU box:  python tools/variant_bench.py [--rows 131072] [--cands 8] [--variants 0 1 2 ...]"""
+"""A/B of the evaluation kernels compiled into libmprime_hip.so on the bench workload (same shard, windows and
+candidates as bench.py); checks that every variant returns the counters of the first one.  Runs on the GPU box.
+
+  --mode rows   MP_EVAL_VARIANT numbers of the row-per-lane kernel (profiles/r01_variants.txt)
+  --mode bits   bN = symbol-table kernel (MP_EVAL_BITS=N), cN = nested-chain kernel shape (MP_EVAL_CHAIN=N)
+                e.g. --variants b1 b2 c3 c7   (profiles/r01_variants_v4.txt)
+  --rows / --cands / --v   shard depth, candidates per window (a chain of that length), mismatch tolerance"""
 import argparse
 import json
 import os
