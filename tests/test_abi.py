@@ -98,3 +98,16 @@ def test_oracle_refuses_calls_in_the_wrong_order(oracle_lib):
 @pytest.mark.gpu
 def test_hip_refuses_calls_in_the_wrong_order(hip_lib):
     _calls_in_wrong_order(hip_lib)
+
+
+def test_bench_refuses_to_run_without_a_gpu():
+    """bench.py parses, imports and then stops with a message on a box without a GPU (there is no CPU path to time)."""
+    import subprocess
+    import sys
+    from conftest import REPO
+    r = subprocess.run([sys.executable, os.path.join(REPO, "bench.py"), "--steps", "2"], capture_output=True, text=True, timeout=300)
+    if r.returncode == 0:
+        pytest.skip("a GPU is present")
+    assert "needs a GPU" in (r.stderr + r.stdout)
+    r = subprocess.run([sys.executable, os.path.join(REPO, "bench.py"), "--gpus", "2"], capture_output=True, text=True, timeout=300)
+    assert r.returncode != 0 and "WORLD_SIZE" in (r.stderr + r.stdout)
