@@ -111,3 +111,14 @@ def test_bench_refuses_to_run_without_a_gpu():
     assert "needs a GPU" in (r.stderr + r.stdout)
     r = subprocess.run([sys.executable, os.path.join(REPO, "bench.py"), "--gpus", "2"], capture_output=True, text=True, timeout=300)
     assert r.returncode != 0 and "WORLD_SIZE" in (r.stderr + r.stdout)
+
+
+def test_tools_and_scripts_compile():
+    """The GPU-box tools cannot run here; at least they must be valid Python."""
+    import glob
+    import py_compile
+    from conftest import REPO
+    files = glob.glob(os.path.join(REPO, "tools", "*.py")) + glob.glob(os.path.join(REPO, "scripts", "*.py"))
+    assert len(files) >= 12
+    for f in files:
+        py_compile.compile(f, doraise=True)
