@@ -1,0 +1,127 @@
+/*
+ * mprime_host.h — C ABI of the native HOST stage of the core step: everything multiPrime-core_V20.py ("V20") does
+ * per window once the O(N_sequences) loops have been reduced to tables by the device kernels of mprime.h —
+ * the cover / gap_sequence dictionaries in first-seen order (V20:689-711), the gates (V20:713-740), entropy
+ * (V20:602-614), the Viterbi and most-frequent seeds (V20:579-600), the greedy degeneracy refinement
+ * (V20:860-1089) and the replay of its stopping rules on the batched evaluations — plus the FASTA record parser
+ * (parse_seq, V20:441-455).  Plain C++ on the host cores (threads over windows / file chunks), no device calls:
+ * these entry points take and return host arrays, so they work with any library serving mprime.h.
+ *
+ * Exported by multiprime_amd/csrc/libmprime_hip.so only (the product).  Their checker is test infrastructure:
+ * oracle/core_ref.py (the pure-Python restatement that round 1 shipped, pinned to V20's recorded internals) and
+ * the golden traces under tests/golden/.
+ *
+ * Conventions as in mprime.h: 0 or a negative MP_ERR_* code, never throws, caller owns every buffer, the library
+ * owns only the opaque objects.  Symbol codes are 4-bit base-set masks (A=1 C=2 G=4 T=8, '-' = 0).
+ */
+#ifndef MPRIME_HOST_H
+#define MPRIME_HOST_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ------------------------------------------------------------------------------------------------------------
+ * (H1) FASTA records — replaces parse_seq (V20:441-455) minus its per-character mapping (that is mp_load_msa):
+ * lines are split at \n, \r\n or \r (Python's universal newlines); a line starting with '#' is skipped; a line
+ * starting with '>' sets the current id to the first space-delimited token of the stripped line ('>' included);
+ * every other line is stripped of ASCII whitespace at both ends and appended to the current id's record — a
+ * repeated id concatenates (the reference's defaultdict(str)); ids keep first-appearance order.
+ * Sequence data before the first header is an error (the reference raises NameError there).
+ * ------------------------------------------------------------------------------------------------------------ */
+typedef struct mp_fasta mp_fasta;
+int mp_fasta_parse_file(const char *path, int32_t n_threads, mp_fasta **out);
+int mp_fasta_parse_buffer(const uint8_t *bytes, int64_t n_bytes, int32_t n_threads, mp_fasta **out);
+void mp_fasta_destroy(mp_fasta *f);
+const char *mp_fasta_error(const mp_fasta *f);
+/* number of records, total residue bytes, total id bytes */
+int mp_fasta_sizes(const mp_fasta *f, int32_t *n_rows, int64_t *n_residue_bytes, int64_t *n_id_bytes);
+/* residues of all records back to back (row r = data[row_off[r] .. row_off[r+1])) — the input of mp_load_msa;
+ * `data` may be NULL to fetch only the offsets.  The copy runs on n_threads threads. */
+int mp_fasta_rows(const mp_fasta *f, uint8_t *data, int64_t *row_off);
+/* ids back to back, id r = ids[id_off[r] .. id_off[r+1]) (raw bytes of the file) */
+int mp_fasta_ids(const mp_fasta *f, uint8_t *ids, int64_t *id_off);
+
+/* ------------------------------------------------------------------------------------------------------------
+ * (H2) per-window planning
+ * ------------------------------------------------------------------------------------------------------------ */
+typedef struct mp_plan mp_plan;
+
+typedef struct mp_plan_params {
+    int32_t k;                   /* primer length (-l) */
+    int32_t v;                   /* --variation */
+    int32_t n_windows;
+    int32_t n_threads;           /* 0 = one per host core (at most 32; MP_HOST_THREADS overrides) */
+    int64_t total_sequences;     /* total_sequence_number (V20:713) */
+    double coverage;             /* -f */
+    double entropy_threshold;    /* after the length scaling of V20:642-649 */
+    double max_degeneracy;       /* -d, score_of_dege_bases (V20:899-903) */
+    int32_t max_dege_positions;  /* -n, number_of_dege_bases */
+    int32_t keep_tables;         /* != 0: keep every window's ordered tables for mp_plan_window_table */
+} mp_plan_params;
+
+/* window status after planning */
+#define MP_WIN_PLANNED 0
+#define MP_WIN_GAP_GATE 1        /* round(gap_number / total, 2) >= 1 - coverage   (V20:713) */
+#define MP_WIN_NO_COVER 2        /* len(cover) < 1                                  (V20:716) */
+#define MP_WIN_ENTROPY 3         /* tBit > threshold                                (V20:723) */
+#define MP_WIN_FEW_BASES 4       /* fewer than 4 bases in the frequency matrix      (V20:736) */
+#define MP_WIN_GAP_COLUMN 5      /* an all-gap column                               (V20:738) */
+
+/* Builds, for every window, the insertion-ordered cover / gap_sequence tables from
+ *   - histogram entries (any order, duplicates allowed: entries of several row shards are merged by key — counts
+ *     add, the smallest first row wins): e_window[i] in [0, n_windows), e_words = b0 at [0,n), b1 at [n,2n),
+ *     g at [2n,3n) (window words of mprime.h), e_count, e_first (GLOBAL row index of the first sighting);
+ *   - exception k-mers (windows holding an IUPAC code, mp_get_exceptions): window, GLOBAL row, k symbol codes;
+ *     each is expanded in the reference's order (itertools.product over the member lists of V20:105-107, last
+ *     position fastest) unless it has more than v gaps (then it is a gap_sequence key as it stands, V20:689-698);
+ * then applies the gates, computes the entropies, takes the seeds from freq [W][4][k] / nn [W][k-1][4][4]
+ * (mp_window_stats, summed over shards) and derives the whole refinement chain of every seed. */
+int mp_plan_create(const mp_plan_params *params, int64_t n_entries, const int32_t *e_window, const uint32_t *e_words,
+                   const int64_t *e_count, const int64_t *e_first, int64_t n_exc, const int32_t *x_window,
+                   const int64_t *x_row, const uint8_t *x_codes, const int64_t *freq, const int64_t *nn, mp_plan **out);
+void mp_plan_destroy(mp_plan *p);
+const char *mp_plan_error(const mp_plan *p);
+
+/* status[W] (MP_WIN_*), cover_number[W], gap_number[W], cbit[W], tbit[W] (entropies are NaN where the window was
+ * rejected before they were computed); any pointer may be NULL */
+int mp_plan_windows(const mp_plan *p, int32_t *status, int64_t *cover_number, int64_t *gap_number, double *cbit, double *tbit);
+/* number of planned windows and of candidates (all chain members of all seeds, window-ascending) */
+int mp_plan_sizes(const mp_plan *p, int32_t *n_planned, int64_t *n_candidates);
+/* the candidate list for mp_eval_candidates: cand_window[n] ascending, cand_codes[n][k] */
+int mp_plan_candidates(const mp_plan *p, int32_t *cand_window, uint8_t *cand_codes);
+/* seeds of window w: nm[k] / mm[k] base indices (0..3), *has_mm = 0 when there is no gap-free k-mer or MM == NM;
+ * chain lengths (members incl. the seed) of both seeds */
+int mp_plan_seeds(const mp_plan *p, int32_t w, uint8_t *nm, uint8_t *mm, int32_t *has_mm, int32_t *n_chain_nm, int32_t *n_chain_mm);
+
+/* refinement chain of seed `seed` (0 = NM, 1 = MM) of window w: codes[n][k] (member 0 = the seed), the running perfect
+ * coverage cov[n] and stops[n] (1 = a structural break rule of V20:899-904 ends the loop after this member).
+ * *n returns the length; MP_ERR_CAPACITY if cap is too small. */
+int mp_plan_chain(const mp_plan *p, int32_t w, int32_t seed, int32_t cap, uint8_t *codes, int64_t *cov, uint8_t *stops, int32_t *n);
+
+/* Replays coverage_stast's stopping rules (V20:881-906) on ev [n_candidates][3] = {perfect, F_mis, R_mis} of
+ * mp_eval_candidates (summed over shards), picks NM or MM (V20:816) and counts the nonsense expansions
+ * (V20:846).  Fails with MP_ERR_ARG if a candidate's perfect coverage differs from the host's running sum
+ * (the two are the same quantity). */
+int mp_plan_finish(mp_plan *p, const int64_t *ev);
+/* per planned window, ascending: window index, entropies (rounded as the reference prints them), the chosen primer's
+ * symbol codes [n][k], its perfect coverage, F / R mis-coverage (perfect + admissible), nonsense_primer_number,
+ * number of degenerate positions, cover_number */
+int mp_plan_results(const mp_plan *p, int32_t *window, double *cbit, double *tbit, uint8_t *primer_codes, int64_t *cov,
+                    int64_t *f_mis, int64_t *r_mis, int32_t *nonsense, int32_t *n_dege, int64_t *cover_number);
+
+/* Ordered table of window w (needs keep_tables): which = 0 the cover dict, 1 gap_sequence; codes[n][k], counts[n],
+ * first_row[n] in insertion order.  *n returns the size; MP_ERR_CAPACITY if cap is too small. */
+int mp_plan_window_table(const mp_plan *p, int32_t w, int32_t which, int64_t cap, uint8_t *codes, int64_t *counts,
+                         int64_t *first_row, int64_t *n);
+
+/* Expansions of n k-mers of symbol codes (degenerate_seq, V20:368-380) in the reference's order; out_src[i] = index
+ * of the k-mer expansion i comes from.  *n_out returns the number needed; MP_ERR_CAPACITY if cap is too small. */
+int mp_expand_kmers(int32_t k, int64_t n, const uint8_t *codes, int64_t cap, uint8_t *out_codes, int64_t *out_src, int64_t *n_out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MPRIME_HOST_H */

@@ -159,10 +159,10 @@ class Context:
         return out
 
     # (3)
-    def window_unique(self, want_labels: bool = False, cap_entries: int | None = None):
-        """Returns (win_off[W+1], words[3][n], count[n], first_row[n]) with the entries of
-        every window sorted by first_row (the ABI leaves the order unspecified), and the
-        permutation needed to translate device labels."""
+    def window_unique(self, want_labels: bool = False, cap_entries: int | None = None, sort: bool = True):
+        """Returns (win_off[W+1], words[3][n], count[n], first_row[n]).  sort=True: the entries of every window sorted
+        by first_row (the ABI leaves the order unspecified) plus the permutation needed to translate device labels;
+        sort=False: as the library returned them (the native planning stage orders them itself)."""
         cap = cap_entries or max(1 << 16, min(self.n_rows * self.n_win, 1 << 24))
         n = C.c_int64(0)
         rc = self.d.mp_window_unique(self.h, cap, int(want_labels), C.byref(n))
@@ -180,6 +180,10 @@ class Context:
         self._ck(self.d.mp_get_unique(self.h, _ptr(off), _ptr(wbuf), _ptr(count), _ptr(first)))
         words = wbuf[:3 * n].reshape(3, n) if n else np.zeros((3, 0), np.uint32)
         count, first = count[:n], first[:n]
+        self._off = off
+        if not sort:
+            self._label_rank = None
+            return off, words, count, first
         win_of = np.repeat(np.arange(self.n_win), np.diff(off))
         order = np.argsort((win_of.astype(np.int64) << 32) | first.astype(np.int64))     # (window, first row): all distinct
         self._label_rank = np.empty(n, np.int64)          # device index -> index within window, first-seen order

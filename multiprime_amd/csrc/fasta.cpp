@@ -1,0 +1,333 @@
+// fasta.cpp — part of libmprime_hip.so: native FASTA record parser behind include/mprime_host.h (H1).
+// Restates the record semantics of parse_seq (scripts/multiPrime-core_V20.py:441-455) on raw bytes, on several
+// threads: the file is read with parallel pread()s, cut into chunks at line starts, every chunk is scanned for
+// lines (terminators \n, \r\n, \r — Python's universal newlines), and one serial pass joins the chunks: it keeps
+// the ids in first-appearance order and makes a repeated id continue its first record (defaultdict(str)).
+// The per-character mapping of V20:453 is NOT done here — that is device work (pack_kernel, mp_load_msa).
+#include "../../include/mprime.h"
+#include "../../include/mprime_host.h"
+
+#include <fcntl.h>
+#include <sys/stat.h>
+#include <unistd.h>
+
+#include <algorithm>
+#include <cerrno>
+#include <cstdarg>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <thread>
+#include <vector>
+
+namespace {
+
+struct Seg { int64_t off; int32_t len; int32_t row; };          // one stripped sequence line
+struct Event {                                                   // per line that matters, in file order
+    int64_t off;
+    int32_t len;
+    int32_t header;             // 1: id token [off, off+len); 0: sequence line
+    uint64_t hash;              // of the id token
+};
+
+inline bool is_space(uint8_t c) { return c == ' ' || (c >= 9 && c <= 13); }      // bytes.strip()
+
+inline uint64_t hash_bytes(const uint8_t *p, size_t n) {
+    uint64_t h = 0xcbf29ce484222325ULL ^ (n * 0x9E3779B97F4A7C15ULL);
+    size_t i = 0;
+    for (; i + 8 <= n; i += 8) {
+        uint64_t x;
+        memcpy(&x, p + i, 8);
+        h = (h ^ x) * 0x100000001b3ULL;
+        h ^= h >> 29;
+    }
+    for (; i < n; i++) h = (h ^ p[i]) * 0x100000001b3ULL;
+    h ^= h >> 32; h *= 0xff51afd7ed558ccdULL; h ^= h >> 29;
+    return h;
+}
+
+}  // namespace
+
+struct mp_fasta {
+    char err[512] = {0};
+    uint8_t *own = nullptr;           // file contents when parsed from a path
+    const uint8_t *buf = nullptr;
+    int64_t n = 0;
+    int n_threads = 1;
+    std::vector<int64_t> id_off_src;  // per row: offset of the id token in buf
+    std::vector<int32_t> id_len;
+    std::vector<Seg> segs;            // grouped by row, file order inside a row
+    std::vector<int64_t> row_seg;     // [n_rows+1] segment range of each row
+    std::vector<int64_t> row_off;     // [n_rows+1] residue offsets
+    int64_t id_bytes = 0;
+    ~mp_fasta() { free(own); }
+};
+
+namespace {
+
+int ffail(mp_fasta *f, int code, const char *fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(f->err, sizeof f->err, fmt, ap);
+    va_end(ap);
+    return code;
+}
+
+int threads_for(int asked, int64_t bytes) {
+    if (const char *e = getenv("MP_HOST_THREADS")) return std::max(1, atoi(e));     // exact (tests cut tiny inputs into chunks)
+    int n = asked;
+    if (n <= 0) {
+        n = (int)std::thread::hardware_concurrency();
+        if (n <= 0) n = 1;
+        n = std::min(n, 32);
+    }
+    int64_t by_size = bytes / (1 << 20) + 1;              // no point in a thread per few kilobytes
+    if ((int64_t)n > by_size) n = (int)by_size;
+    return std::max(n, 1);
+}
+
+// first line start at or after `pos`
+int64_t line_start_at_or_after(const uint8_t *b, int64_t n, int64_t pos) {
+    if (pos <= 0) return 0;
+    if (pos >= n) return n;
+    uint8_t prev = b[pos - 1];
+    if (prev == '\n') return pos;
+    if (prev == '\r') return b[pos] == '\n' ? pos + 1 : pos;
+    for (int64_t i = pos; i < n; i++) {
+        if (b[i] == '\n') return i + 1;
+        if (b[i] == '\r') return (i + 1 < n && b[i + 1] == '\n') ? i + 2 : i + 1;
+    }
+    return n;
+}
+
+void scan_chunk(const uint8_t *b, int64_t n, int64_t begin, int64_t end, std::vector<Event> &out) {
+    int64_t p = begin;
+    while (p < end) {
+        // the line is [p, q), q = its terminator or the end of the buffer
+        int64_t q = p;
+        {
+            const uint8_t *nl = (const uint8_t *)memchr(b + p, '\n', (size_t)(n - p));
+            int64_t qn = nl ? (int64_t)(nl - b) : n;
+            // a lone \r inside [p, qn) also ends the line (rare: only look when one exists)
+            const uint8_t *cr = (const uint8_t *)memchr(b + p, '\r', (size_t)(qn - p));
+            q = cr ? (int64_t)(cr - b) : qn;
+        }
+        int64_t next = q;
+        if (q < n) next = (b[q] == '\r' && q + 1 < n && b[q + 1] == '\n') ? q + 2 : q + 1;
+        if (q > p && b[p] == '#') { p = next; continue; }
+        int64_t a = p, z = q;
+        while (a < z && is_space(b[a])) a++;
+        while (z > a && is_space(b[z - 1])) z--;
+        if (q > p && b[p] == '>') {
+            // i.strip().split(" ")[0]: the stripped line up to its first blank
+            int64_t t = a;
+            while (t < z && b[t] != ' ') t++;
+            out.push_back(Event{a, (int32_t)(t - a), 1, hash_bytes(b + a, (size_t)(t - a))});
+        } else {
+            out.push_back(Event{a, (int32_t)(z - a), 0, 0});
+        }
+        p = next;
+    }
+}
+
+int parse(mp_fasta *f) {
+    const uint8_t *b = f->buf;
+    const int64_t n = f->n;
+    const int T = f->n_threads;
+    std::vector<int64_t> cut((size_t)T + 1);
+    for (int t = 0; t <= T; t++) cut[(size_t)t] = line_start_at_or_after(b, n, n * t / T);
+    cut[(size_t)T] = n;
+    std::vector<std::vector<Event>> ev((size_t)T);
+    if (T == 1) scan_chunk(b, n, 0, n, ev[0]);
+    else {
+        std::vector<std::thread> th;
+        for (int t = 0; t < T; t++) th.emplace_back([&, t]() { scan_chunk(b, n, cut[(size_t)t], cut[(size_t)t + 1], ev[(size_t)t]); });
+        for (auto &x : th) x.join();
+    }
+    // serial join: ids in first-appearance order, a repeated id continues its first record
+    size_t n_ev = 0;
+    for (auto &e : ev) n_ev += e.size();
+    size_t cap = 16;
+    while (cap < n_ev + 8) cap <<= 1;
+    std::vector<int32_t> table(cap, -1);
+    const size_t mask = cap - 1;
+    std::vector<Seg> raw;
+    raw.reserve(n_ev);
+    std::vector<uint64_t> id_hash;
+    // A record comes into being when its id RECEIVES a line (seq_dict[acc_id] += ..., V20:454) — a header that is
+    // followed by another header creates nothing — and it takes its place in the order at that moment.
+    int32_t cur = -1;
+    bool have_header = false, resolved = false;
+    Event pending{};
+    for (auto &chunk : ev) {
+        for (const Event &e : chunk) {
+            if (e.header) { pending = e; have_header = true; resolved = false; continue; }
+            if (!have_header) return ffail(f, MP_ERR_ARG, "sequence data before the first '>' header");
+            if (!resolved) {
+                size_t h = (size_t)pending.hash & mask;
+                for (;;) {
+                    int32_t r = table[h];
+                    if (r < 0) {
+                        r = (int32_t)f->id_off_src.size();
+                        table[h] = r;
+                        f->id_off_src.push_back(pending.off);
+                        f->id_len.push_back(pending.len);
+                        id_hash.push_back(pending.hash);
+                        cur = r;
+                        break;
+                    }
+                    if (id_hash[(size_t)r] == pending.hash && f->id_len[(size_t)r] == pending.len &&
+                        memcmp(b + f->id_off_src[(size_t)r], b + pending.off, (size_t)pending.len) == 0) { cur = r; break; }
+                    h = (h + 1) & mask;
+                }
+                resolved = true;
+            }
+            if (e.len) raw.push_back(Seg{e.off, e.len, cur});
+        }
+        std::vector<Event>().swap(chunk);
+    }
+    const size_t R = f->id_off_src.size();
+    // group the segments by row (stable: file order inside a row); already grouped when no id repeats out of order
+    f->row_seg.assign(R + 1, 0);
+    for (const Seg &s : raw) f->row_seg[(size_t)s.row + 1]++;
+    for (size_t r = 0; r < R; r++) f->row_seg[r + 1] += f->row_seg[r];
+    bool sorted = true;
+    for (size_t i = 1; i < raw.size(); i++) if (raw[i].row < raw[i - 1].row) { sorted = false; break; }
+    if (sorted) f->segs.swap(raw);
+    else {
+        f->segs.resize(raw.size());
+        std::vector<int64_t> at(f->row_seg.begin(), f->row_seg.end() - 1);
+        for (const Seg &s : raw) f->segs[(size_t)at[(size_t)s.row]++] = s;
+    }
+    f->row_off.assign(R + 1, 0);
+    f->id_bytes = 0;
+    for (size_t r = 0; r < R; r++) {
+        int64_t len = 0;
+        for (int64_t i = f->row_seg[r]; i < f->row_seg[r + 1]; i++) len += f->segs[(size_t)i].len;
+        f->row_off[r + 1] = f->row_off[r] + len;
+        f->id_bytes += f->id_len[r];
+    }
+    if (R > 0x7fffffffULL - 1) return ffail(f, MP_ERR_ARG, "too many records");
+    return MP_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+const char *mp_fasta_error(const mp_fasta *f) { return f ? f->err : "mp_fasta_parse failed"; }
+void mp_fasta_destroy(mp_fasta *f) { delete f; }
+
+int mp_fasta_parse_buffer(const uint8_t *bytes, int64_t n_bytes, int32_t n_threads, mp_fasta **out) {
+    if (!out) return MP_ERR_ARG;
+    *out = nullptr;
+    if (n_bytes < 0 || (n_bytes && !bytes)) return MP_ERR_ARG;
+    mp_fasta *f = new (std::nothrow) mp_fasta();
+    if (!f) return MP_ERR_NOMEM;
+    *out = f;
+    f->own = (uint8_t *)malloc((size_t)n_bytes + 1);
+    if (!f->own) return ffail(f, MP_ERR_NOMEM, "out of memory (%lld bytes)", (long long)n_bytes);
+    if (n_bytes) memcpy(f->own, bytes, (size_t)n_bytes);
+    f->buf = f->own;
+    f->n = n_bytes;
+    f->n_threads = threads_for(n_threads, n_bytes);
+    return parse(f);
+}
+
+int mp_fasta_parse_file(const char *path, int32_t n_threads, mp_fasta **out) {
+    if (!out) return MP_ERR_ARG;
+    *out = nullptr;
+    if (!path) return MP_ERR_ARG;
+    mp_fasta *f = new (std::nothrow) mp_fasta();
+    if (!f) return MP_ERR_NOMEM;
+    *out = f;
+    int fd = open(path, O_RDONLY);
+    if (fd < 0) return ffail(f, MP_ERR_ARG, "%s: %s", path, strerror(errno));
+    struct stat st;
+    if (fstat(fd, &st) != 0) { close(fd); return ffail(f, MP_ERR_ARG, "%s: %s", path, strerror(errno)); }
+    int64_t n = (int64_t)st.st_size;
+    std::vector<uint8_t> piped;
+    if (!S_ISREG(st.st_mode)) {
+        // a pipe / device: read to the end
+        uint8_t tmp[1 << 16];
+        ssize_t got;
+        while ((got = read(fd, tmp, sizeof tmp)) > 0) piped.insert(piped.end(), tmp, tmp + got);
+        n = (int64_t)piped.size();
+    }
+    f->own = (uint8_t *)malloc((size_t)n + 1);
+    if (!f->own) { close(fd); return ffail(f, MP_ERR_NOMEM, "out of memory (%lld bytes)", (long long)n); }
+    f->n_threads = threads_for(n_threads, n);
+    if (!piped.empty()) memcpy(f->own, piped.data(), (size_t)n);
+    else if (S_ISREG(st.st_mode) && n) {
+        const int T = f->n_threads;
+        std::vector<int> bad((size_t)T, 0);
+        auto rd = [&](int t) {
+            int64_t a = n * t / T, z = n * (t + 1) / T;
+            while (a < z) {
+                ssize_t got = pread(fd, f->own + a, (size_t)(z - a), (off_t)a);
+                if (got <= 0) { bad[(size_t)t] = 1; return; }
+                a += got;
+            }
+        };
+        if (T == 1) rd(0);
+        else {
+            std::vector<std::thread> th;
+            for (int t = 0; t < T; t++) th.emplace_back(rd, t);
+            for (auto &x : th) x.join();
+        }
+        for (int x : bad) if (x) { close(fd); return ffail(f, MP_ERR_ARG, "%s: short read", path); }
+    }
+    close(fd);
+    f->buf = f->own;
+    f->n = n;
+    return parse(f);
+}
+
+int mp_fasta_sizes(const mp_fasta *f, int32_t *n_rows, int64_t *n_residue_bytes, int64_t *n_id_bytes) {
+    if (!f) return MP_ERR_ARG;
+    if (n_rows) *n_rows = (int32_t)f->id_off_src.size();
+    if (n_residue_bytes) *n_residue_bytes = f->row_off.empty() ? 0 : f->row_off.back();
+    if (n_id_bytes) *n_id_bytes = f->id_bytes;
+    return MP_OK;
+}
+
+int mp_fasta_rows(const mp_fasta *f, uint8_t *data, int64_t *row_off) {
+    if (!f) return MP_ERR_ARG;
+    const size_t R = f->id_off_src.size();
+    if (row_off) memcpy(row_off, f->row_off.data(), sizeof(int64_t) * (R + 1));
+    if (!data || R == 0) return MP_OK;
+    const int T = std::max(1, std::min<int>(f->n_threads, (int)(f->row_off.back() / (1 << 20) + 1)));
+    auto copy = [&](int t) {
+        size_t r0 = R * (size_t)t / (size_t)T, r1 = R * ((size_t)t + 1) / (size_t)T;
+        for (size_t r = r0; r < r1; r++) {
+            uint8_t *dst = data + f->row_off[r];
+            for (int64_t i = f->row_seg[r]; i < f->row_seg[r + 1]; i++) {
+                const Seg &s = f->segs[(size_t)i];
+                memcpy(dst, f->buf + s.off, (size_t)s.len);
+                dst += s.len;
+            }
+        }
+    };
+    if (T == 1) copy(0);
+    else {
+        std::vector<std::thread> th;
+        for (int t = 0; t < T; t++) th.emplace_back(copy, t);
+        for (auto &x : th) x.join();
+    }
+    return MP_OK;
+}
+
+int mp_fasta_ids(const mp_fasta *f, uint8_t *ids, int64_t *id_off) {
+    if (!f || !id_off) return MP_ERR_ARG;
+    const size_t R = f->id_off_src.size();
+    int64_t o = 0;
+    for (size_t r = 0; r < R; r++) {
+        id_off[r] = o;
+        if (ids) memcpy(ids + o, f->buf + f->id_off_src[r], (size_t)f->id_len[r]);
+        o += f->id_len[r];
+    }
+    id_off[R] = o;
+    return MP_OK;
+}
+
+}  // extern "C"

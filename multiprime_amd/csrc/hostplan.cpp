@@ -1,0 +1,783 @@
+// hostplan.cpp — part of libmprime_hip.so: the native HOST stage of the core step behind include/mprime_host.h (H2).
+// Plain C++17 on the host cores, threads over windows; no device calls.  "V20" = scripts/multiPrime-core_V20.py.
+//
+// What is restated here (each function cites its lines): the insertion-ordered cover / gap_sequence dictionaries of
+// get_primers (V20:689-711) rebuilt from the device histograms and the IUPAC exception list, the gates (V20:713-740),
+// entropy (V20:602-614), get_optimal_primer_by_viterbi / _by_MM (V20:579-600), refine_by_NN_array (V20:922-1089), the
+// structural part of coverage_stast (V20:860-906) and the replay of its stopping rules on the batched evaluations.
+// All floating-point expressions keep the reference's operand order and libm calls (log(x)/log(2), Python's round()).
+#include "../../include/mprime.h"
+#include "../../include/mprime_host.h"
+
+#include <algorithm>
+#include <atomic>
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <limits>
+#include <string>
+#include <thread>
+#include <vector>
+
+namespace {
+
+// ---------------------------------------------------------------------------------------------------------------
+// symbols
+// ---------------------------------------------------------------------------------------------------------------
+struct Key {                    // k symbol codes, one nibble each (position j = nibble j)
+    uint64_t lo = 0, hi = 0;
+    bool operator==(const Key &o) const { return lo == o.lo && hi == o.hi; }
+    uint32_t get(int j) const { return (uint32_t)((j < 16 ? lo >> (4 * j) : hi >> (4 * (j - 16))) & 15u); }
+    void set(int j, uint32_t c) {
+        if (j < 16) lo = (lo & ~(15ull << (4 * j))) | ((uint64_t)c << (4 * j));
+        else hi = (hi & ~(15ull << (4 * (j - 16)))) | ((uint64_t)c << (4 * (j - 16)));
+    }
+};
+
+inline uint64_t mix(uint64_t x) {
+    x ^= x >> 33; x *= 0xff51afd7ed558ccdULL; x ^= x >> 33; x *= 0xc4ceb9fe1a85ec53ULL; x ^= x >> 33;
+    return x;
+}
+inline uint64_t hash_key(const Key &k) { return mix(k.lo ^ mix(k.hi + 0x9E3779B97F4A7C15ULL)); }
+
+// members of a symbol in the reference's enumeration order (degenerate_base, V20:105-107), as base codes
+struct Members { uint8_t n; uint8_t m[4]; };
+constexpr uint8_t A = 1, C = 2, G = 4, T = 8;
+const Members kMembers[16] = {
+    {1, {0, 0, 0, 0}},        // '-'
+    {1, {A, 0, 0, 0}},        // A
+    {1, {C, 0, 0, 0}},        // C
+    {2, {A, C, 0, 0}},        // M = AC
+    {1, {G, 0, 0, 0}},        // G
+    {2, {A, G, 0, 0}},        // R = AG
+    {2, {G, C, 0, 0}},        // S = GC
+    {3, {G, A, C, 0}},        // V = GAC
+    {1, {T, 0, 0, 0}},        // T
+    {2, {A, T, 0, 0}},        // W = AT
+    {2, {C, T, 0, 0}},        // Y = CT
+    {3, {A, T, C, 0}},        // H = ATC
+    {2, {G, T, 0, 0}},        // K = GT
+    {3, {G, A, T, 0}},        // D = GAT
+    {3, {G, T, C, 0}},        // B = GTC
+    {4, {A, T, G, C}},        // N = ATGC
+};
+inline int set_size(uint32_t code) { return code == 0 ? 1 : __builtin_popcount(code); }     // floor(score), V20:211
+
+// itertools.product over the member lists, last position fastest (degenerate_seq, V20:368-380): calls f(Key) for
+// every expansion in that order.  Returns the number of expansions.
+template <typename F>
+int64_t for_each_expansion(const uint8_t *codes, int k, F &&f) {
+    int idx[32] = {0};
+    Key cur;
+    for (int j = 0; j < k; j++) cur.set(j, kMembers[codes[j]].m[0]);
+    int64_t n = 0;
+    for (;;) {
+        f(cur);
+        n++;
+        int j = k - 1;
+        for (; j >= 0; j--) {
+            const Members &mb = kMembers[codes[j]];
+            if (++idx[j] < mb.n) { cur.set(j, mb.m[idx[j]]); break; }
+            idx[j] = 0;
+            cur.set(j, mb.m[0]);
+        }
+        if (j < 0) break;
+    }
+    return n;
+}
+
+inline double expansions_of(const uint8_t *codes, int k) {
+    double d = 1;
+    for (int j = 0; j < k; j++) d *= set_size(codes[j]);
+    return d;
+}
+
+// Python's round(x, 2) on a float: correctly rounded decimal with two places (round-half-even on the exact binary
+// value), then back to the nearest double — what glibc's printf/strtod pair does.
+double py_round2(double x) {
+    if (!std::isfinite(x)) return x;
+    char buf[64];
+    snprintf(buf, sizeof buf, "%.2f", x);
+    return strtod(buf, nullptr);
+}
+
+// math.log(x, 2) of CPython: log(x) / log(2.0), two libm calls and a division
+inline double py_log2(double x) { return std::log(x) / std::log(2.0); }
+
+// ---------------------------------------------------------------------------------------------------------------
+// per-window tables
+// ---------------------------------------------------------------------------------------------------------------
+struct Entry {
+    Key key;
+    int64_t count;
+    int64_t first_row;
+    int32_t first_sub;        // expansion index inside its exception row (0 for plain rows)
+    int32_t ngap;
+};
+
+// open-addressing map Key -> index into a vector<Entry>
+struct KeyMap {
+    std::vector<int32_t> slot;
+    uint32_t mask = 0;
+    void reset(size_t n_expected) {
+        size_t cap = 16;
+        while (cap < 2 * n_expected + 8) cap <<= 1;
+        slot.assign(cap, -1);
+        mask = (uint32_t)(cap - 1);
+    }
+    // returns the index stored for `key`, or -1 after inserting `idx_new`
+    int32_t find_or_insert(const Key &key, const std::vector<Entry> &ents, int32_t idx_new) {
+        uint32_t h = (uint32_t)hash_key(key) & mask;
+        for (;;) {
+            int32_t s = slot[h];
+            if (s < 0) { slot[h] = idx_new; return -1; }
+            if (ents[(size_t)s].key == key) return s;
+            h = (h + 1) & mask;
+        }
+    }
+    int32_t find(const Key &key, const std::vector<Entry> &ents) const {
+        if (slot.empty()) return -1;
+        uint32_t h = (uint32_t)hash_key(key) & mask;
+        for (;;) {
+            int32_t s = slot[h];
+            if (s < 0) return -1;
+            if (ents[(size_t)s].key == key) return s;
+            h = (h + 1) & mask;
+        }
+    }
+};
+
+struct Seed {
+    uint8_t index[32];                       // base index per position
+    std::vector<Key> chain;                  // chain[0] = the seed
+    std::vector<int64_t> cov;                // running perfect coverage (optimal_coverage_init)
+    std::vector<uint8_t> stops;              // a structural break rule ends the loop after this member
+    int64_t first_cand = -1;
+    // after replay
+    int final_i = 0;
+    int64_t F = 0, R = 0;
+};
+
+struct Window {
+    int32_t status = MP_WIN_PLANNED;
+    int64_t cover_number = 0, gap_number = 0;
+    double cbit = std::numeric_limits<double>::quiet_NaN(), tbit = std::numeric_limits<double>::quiet_NaN();
+    std::vector<Entry> cover, gap;           // insertion order
+    KeyMap cover_map;                        // over `cover`
+    int n_seeds = 0;
+    Seed seeds[2];
+    Key present;                             // phantom key the reference inserts for the NM seed (V20:787/800/835)
+    // results
+    Key primer;
+    int64_t cov = 0, f_mis = 0, r_mis = 0;
+    int32_t nonsense = 0, n_dege = 0;
+};
+
+}  // namespace
+
+struct mp_plan {
+    char err[512] = {0};
+    mp_plan_params P{};
+    std::vector<Window> win;
+    std::vector<int32_t> planned;            // window indices, ascending
+    int64_t n_cand = 0;
+    bool finished = false;
+};
+
+namespace {
+
+int pfail(mp_plan *p, int code, const char *fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(p->err, sizeof p->err, fmt, ap);
+    va_end(ap);
+    return code;
+}
+
+struct NNArr {                                // nn[i][a][b], i < k-1
+    int64_t v[31][4][4];
+};
+
+// sum of cover[] over the expansions of a primer (V20:954-956)
+int64_t perfect(const Window &w, const uint8_t *P, int k) {
+    bool concrete = true;
+    for (int j = 0; j < k; j++) concrete &= (P[j] & (P[j] - 1)) == 0;
+    if (concrete) {
+        Key key;
+        for (int j = 0; j < k; j++) key.set(j, P[j]);
+        int32_t s = w.cover_map.find(key, w.cover);
+        return s < 0 ? 0 : w.cover[(size_t)s].count;
+    }
+    int64_t tot = 0;
+    for_each_expansion(P, k, [&](const Key &e) {
+        int32_t s = w.cover_map.find(e, w.cover);
+        if (s >= 0) tot += w.cover[(size_t)s].count;
+    });
+    return tot;
+}
+
+// np.argsort(x)[::-1] with the stable tie order of the author's numpy (SURVEY A-14): ascending stable, reversed
+inline void desc_stable(const int64_t v[4], int order[4]) {
+    int idx[4] = {0, 1, 2, 3};
+    std::stable_sort(idx, idx + 4, [&](int a, int b) { return v[a] < v[b]; });
+    for (int i = 0; i < 4; i++) order[i] = idx[3 - i];
+}
+inline int npos(const int64_t v[4]) { return (v[0] > 0) + (v[1] > 0) + (v[2] > 0) + (v[3] > 0); }
+
+struct Refined {
+    uint8_t P[32];
+    int64_t c2;
+    int64_t cv[31];
+    NNArr nn;
+};
+
+// refine_by_NN_array (V20:922-1089): add one base next to the weakest nearest-neighbour link(s); among the weakest
+// links keep the first one with the largest perfect coverage.
+void refine(const Window &w, int k, const uint8_t *primer, int64_t cov, const uint8_t *index, const int64_t *nn_cov,
+            const NNArr &NN, Refined &best) {
+    const int last = k - 2;
+    int64_t lo = nn_cov[0];
+    for (int i = 1; i <= last; i++) lo = std::min(lo, nn_cov[i]);
+    bool have = false;
+    Refined cur;
+    for (int i = 0; i <= last; i++) {
+        if (nn_cov[i] != lo) continue;
+        cur.nn = NN;
+        memcpy(cur.cv, nn_cov, sizeof(int64_t) * (size_t)(k - 1));
+        memcpy(cur.P, primer, (size_t)k);
+        cur.c2 = cov;
+        const int row = index[i], col = index[i + 1];
+        auto widen = [&](int pos, const int64_t ranking[4], int skip) -> int {
+            int order[4];
+            desc_stable(ranking, order);
+            for (int t = 0; t < 4; t++) {
+                int x = order[t];
+                if (x == skip) continue;
+                cur.P[pos] = (uint8_t)(1u << x);
+                cur.c2 += perfect(w, cur.P, k);                                   // coverage gained (V20:954-956)
+                cur.P[pos] = (uint8_t)(primer[pos] | (1u << x));
+                return x;
+            }
+            return -1;
+        };
+        auto &nn = cur.nn.v;
+        int64_t colv[4] = {nn[0][0][col], nn[0][1][col], nn[0][2][col], nn[0][3][col]};
+        if (i == 0 && npos(colv) > 1) {
+            // position 0 (V20:941-965): fold predecessor x of `col` into the seed's row
+            int x = widen(0, colv, row);
+            if (x >= 0) {
+                for (int b = 0; b < 4; b++) { nn[0][row][b] += nn[0][x][b]; nn[0][x][b] = 0; }
+                cur.cv[0] = nn[0][row][col];
+            }
+        } else if (i == 0 && !(npos(nn[0][row]) > 1)) {
+            // V20:1002-1003
+        } else if (i == last && i != 0) {
+            // last position (V20:1004-1031)
+            int64_t line[4] = {nn[i][row][0], nn[i][row][1], nn[i][row][2], nn[i][row][3]};
+            if (npos(line) > 1) {
+                int x = widen(i + 1, line, col);
+                if (x >= 0) {
+                    for (int a = 0; a < 4; a++) { nn[i][a][col] += nn[i][a][x]; nn[i][a][x] = 0; }
+                    cur.cv[i] = nn[i][row][col];
+                }
+            }
+        } else if (i + 2 <= k - 1) {
+            // inner position i+1, shared by link i and link i+1 (V20:967-1001, 1032-1072)
+            const int nrow = index[i + 1], ncol = index[i + 2];
+            int64_t both[4];
+            for (int b = 0; b < 4; b++) both[b] = std::min(nn[i][row][b], nn[i + 1][b][ncol]);
+            if (npos(both) > 1) {
+                int x = widen(i + 1, both, col);
+                if (x >= 0) {
+                    for (int a = 0; a < 4; a++) { nn[i][a][col] += nn[i][a][x]; nn[i][a][x] = 0; }
+                    for (int b = 0; b < 4; b++) { nn[i + 1][nrow][b] += nn[i + 1][x][b]; nn[i + 1][x][b] = 0; }
+                    cur.cv[i] = nn[i][row][col];
+                    cur.cv[i + 1] = nn[i + 1][nrow][ncol];
+                }
+            }
+        }
+        if (!have || cur.c2 > best.c2) { best = cur; have = true; }
+    }
+}
+
+// everything coverage_stast (V20:860-920) does that does not depend on an evaluation
+int build_chain(const Window &w, Seed &s, int k, const NNArr &NN, double d, int n_max) {
+    uint8_t P[32];
+    Key key;
+    for (int j = 0; j < k; j++) { P[j] = (uint8_t)(1u << s.index[j]); key.set(j, P[j]); }
+    int32_t slot = w.cover_map.find(key, w.cover);
+    int64_t cov = slot < 0 ? 0 : w.cover[(size_t)slot].count;
+    NNArr nn = NN;
+    int64_t nn_cov[31];
+    for (int i = 0; i < k - 1; i++) nn_cov[i] = NN.v[i][s.index[i]][s.index[i + 1]];
+    s.chain.push_back(key);
+    s.cov.push_back(cov);
+    s.stops.push_back(0);
+    Refined r;
+    for (int guard = 0; guard < 4 * 32 + 8; guard++) {
+        refine(w, k, P, cov, s.index, nn_cov, nn, r);
+        memcpy(P, r.P, (size_t)k);
+        cov = r.c2;
+        nn = r.nn;
+        double deg = expansions_of(P, k);
+        int ndeg = 0;
+        for (int j = 0; j < k; j++) ndeg += set_size(P[j]) > 1;
+        bool same = memcmp(r.cv, nn_cov, sizeof(int64_t) * (size_t)(k - 1)) == 0;
+        bool stop = same || 2 * deg > d || 3 * deg / 2 > d || ndeg == n_max;              // V20:899-904
+        Key ck;
+        for (int j = 0; j < k; j++) ck.set(j, P[j]);
+        s.chain.push_back(ck);
+        s.cov.push_back(cov);
+        s.stops.push_back(stop ? 1 : 0);
+        if (stop) return MP_OK;
+        memcpy(nn_cov, r.cv, sizeof(int64_t) * (size_t)(k - 1));
+    }
+    return MP_ERR_ARG;       // a chain that neither saturates nor stops: cannot happen (every step adds a base)
+}
+
+// get_optimal_primer_by_viterbi (V20:579-593): max-sum path over base frequencies and nearest-neighbour counts;
+// ties go to the lowest base index (numpy argmax takes the first)
+void viterbi(const int64_t *freq /*[4][k]*/, const int64_t *nn /*[k-1][4][4]*/, int k, uint8_t *path) {
+    int64_t score[4];
+    uint8_t back[32][4];
+    for (int a = 0; a < 4; a++) score[a] = freq[a * k + 0];
+    for (int t = 1; t < k; t++) {
+        int64_t nxt[4];
+        for (int b = 0; b < 4; b++) {
+            int besta = 0;
+            int64_t bestv = 0;
+            for (int a = 0; a < 4; a++) {
+                int64_t m = score[a] + nn[((t - 1) * 4 + a) * 4 + b] + freq[b * k + t];
+                if (a == 0 || m > bestv) { bestv = m; besta = a; }
+            }
+            nxt[b] = bestv;
+            back[t][b] = (uint8_t)besta;
+        }
+        memcpy(score, nxt, sizeof score);
+    }
+    int cur = 0;
+    for (int a = 1; a < 4; a++) if (score[a] > score[cur]) cur = a;
+    path[k - 1] = (uint8_t)cur;
+    for (int t = k - 1; t >= 1; t--) { cur = back[t][cur]; path[t - 1] = (uint8_t)cur; }
+}
+
+struct Sight {                 // one sighting of a k-mer inside a window, before merging
+    Key key;
+    int64_t count, row;
+    int32_t sub, ngap;
+};
+
+// cover / gap_sequence of one window in the reference's dict insertion order (V20:689-711): a key takes the place of
+// its earliest sighting (row, then expansion index inside that row); counts add up.
+void build_tables(Window &w, std::vector<Sight> &sights, int v, int64_t n_exc_cover, int64_t n_exp) {
+    std::vector<Entry> all;
+    all.reserve(sights.size());
+    KeyMap map;
+    map.reset(sights.size());
+    for (const Sight &s : sights) {
+        int32_t at = map.find_or_insert(s.key, all, (int32_t)all.size());
+        if (at < 0) all.push_back(Entry{s.key, s.count, s.row, s.sub, s.ngap});
+        else {
+            Entry &e = all[(size_t)at];
+            e.count += s.count;
+            if (s.row < e.first_row || (s.row == e.first_row && s.sub < e.first_sub)) { e.first_row = s.row; e.first_sub = s.sub; }
+        }
+    }
+    std::sort(all.begin(), all.end(), [](const Entry &a, const Entry &b) {
+        return a.first_row != b.first_row ? a.first_row < b.first_row : a.first_sub < b.first_sub;
+    });
+    int64_t csum = 0, gsum = 0;
+    for (const Entry &e : all) {
+        if (e.ngap > v) { w.gap.push_back(e); gsum += e.count; }
+        else { w.cover.push_back(e); csum += e.count; }
+    }
+    w.gap_number = gsum;
+    w.cover_number = csum - n_exp + n_exc_cover;      // cover_number counts sequences (V20:702), cover counts expansions
+    w.cover_map.reset(w.cover.size());
+    for (size_t i = 0; i < w.cover.size(); i++) w.cover_map.find_or_insert(w.cover[i].key, w.cover, (int32_t)i);
+}
+
+// entropy (V20:602-614), same summation order
+void entropy(Window &w) {
+    const int64_t cn = w.cover_number, gn = w.gap_number, tot = cn + gn;
+    double cbit = 0, tbit = 0;
+    for (const Entry &e : w.cover) {
+        double pc = (double)e.count / (double)cn, pt = (double)e.count / (double)tot;
+        cbit += pc * py_log2(pc);
+        tbit += pt * py_log2(pt);
+    }
+    for (const Entry &e : w.gap) {
+        double pt = (double)e.count / (double)tot;
+        tbit += pt * py_log2(pt);
+    }
+    w.cbit = py_round2(-cbit);
+    w.tbit = py_round2(-tbit);
+}
+
+int plan_window(mp_plan *p, int wi, std::vector<Sight> &sights, int64_t n_exc_cover, int64_t n_exp, const int64_t *freq,
+                const int64_t *nn) {
+    const mp_plan_params &P = p->P;
+    const int k = P.k;
+    Window &w = p->win[(size_t)wi];
+    build_tables(w, sights, P.v, n_exc_cover, n_exp);
+    // gates (V20:713-740)
+    if (py_round2((double)w.gap_number / (double)P.total_sequences) >= (1 - P.coverage)) { w.status = MP_WIN_GAP_GATE; return MP_OK; }
+    if (w.cover.empty()) { w.status = MP_WIN_NO_COVER; return MP_OK; }
+    entropy(w);
+    if (w.tbit > P.entropy_threshold) { w.status = MP_WIN_ENTROPY; return MP_OK; }
+    int bases = 0;
+    for (int a = 0; a < 4; a++) {
+        int64_t s = 0;
+        for (int j = 0; j < k; j++) s += freq[a * k + j];
+        bases += s > 0;
+    }
+    if (bases < 4) { w.status = MP_WIN_FEW_BASES; return MP_OK; }                     // V20:736
+    for (int j = 0; j < k; j++)
+        if (freq[0 * k + j] + freq[1 * k + j] + freq[2 * k + j] + freq[3 * k + j] == 0) { w.status = MP_WIN_GAP_COLUMN; return MP_OK; }
+    NNArr NN;
+    memset(&NN, 0, sizeof NN);
+    memcpy(NN.v, nn, sizeof(int64_t) * (size_t)(k - 1) * 16);
+    // seeds
+    Seed &nm = w.seeds[0];
+    viterbi(freq, nn, k, nm.index);
+    w.n_seeds = 1;
+    // get_optimal_primer_by_MM (V20:595-600): first of the most frequent gap-free k-mers
+    int64_t best = 0;
+    int best_i = -1;
+    for (size_t i = 0; i < w.cover.size(); i++)
+        if (w.cover[i].ngap == 0 && w.cover[i].count > best) { best = w.cover[i].count; best_i = (int)i; }
+    if (best_i >= 0) {
+        Seed &mm = w.seeds[1];
+        bool same = true;
+        for (int j = 0; j < k; j++) {
+            uint32_t c = w.cover[(size_t)best_i].key.get(j);
+            mm.index[j] = (uint8_t)__builtin_ctz(c);
+            same &= mm.index[j] == nm.index[j];
+        }
+        if (!same) w.n_seeds = 2;
+    }
+    for (int j = 0; j < k; j++) w.present.set(j, 1u << nm.index[j]);
+    for (int s = 0; s < w.n_seeds; s++) {
+        int rc = build_chain(w, w.seeds[s], k, NN, P.max_degeneracy, P.max_dege_positions);
+        if (rc != MP_OK) return pfail(p, rc, "refinement chain of window %d does not terminate", wi);
+    }
+    return MP_OK;
+}
+
+int resolve_threads(int asked, int64_t work_items) {
+    int n = asked;
+    if (const char *e = getenv("MP_HOST_THREADS")) n = atoi(e);
+    if (n <= 0) {
+        n = (int)std::thread::hardware_concurrency();
+        if (n <= 0) n = 1;
+        n = std::min(n, 32);
+    }
+    if ((int64_t)n > work_items) n = (int)std::max<int64_t>(1, work_items);
+    return n;
+}
+
+}  // namespace
+
+extern "C" {
+
+const char *mp_plan_error(const mp_plan *p) { return p ? p->err : "mp_plan_create failed"; }
+
+void mp_plan_destroy(mp_plan *p) { delete p; }
+
+int mp_plan_create(const mp_plan_params *params, int64_t n_entries, const int32_t *e_window, const uint32_t *e_words,
+                   const int64_t *e_count, const int64_t *e_first, int64_t n_exc, const int32_t *x_window,
+                   const int64_t *x_row, const uint8_t *x_codes, const int64_t *freq, const int64_t *nn, mp_plan **out) {
+    if (!out) return MP_ERR_ARG;
+    *out = nullptr;
+    if (!params || !freq || !nn) return MP_ERR_ARG;
+    mp_plan *p = new (std::nothrow) mp_plan();
+    if (!p) return MP_ERR_NOMEM;
+    *out = p;                                  // returned even on failure so that the caller can read the message
+    p->P = *params;
+    const mp_plan_params &P = p->P;
+    const int k = P.k, W = P.n_windows;
+    if (k < 2 || k > 32 || W < 0 || P.v < 0 || P.total_sequences <= 0) return pfail(p, MP_ERR_ARG, "mp_plan_create: bad parameters");
+    if (n_entries < 0 || n_exc < 0 || (n_entries && (!e_window || !e_words || !e_count || !e_first)) ||
+        (n_exc && (!x_window || !x_row || !x_codes)))
+        return pfail(p, MP_ERR_ARG, "mp_plan_create: bad arguments");
+    // counting sort of entries and exceptions by window
+    std::vector<int64_t> eoff((size_t)W + 1, 0), xoff((size_t)W + 1, 0);
+    for (int64_t i = 0; i < n_entries; i++) {
+        if (e_window[i] < 0 || e_window[i] >= W) return pfail(p, MP_ERR_ARG, "entry %lld: window %d out of range", (long long)i, e_window[i]);
+        eoff[(size_t)e_window[i] + 1]++;
+    }
+    for (int64_t i = 0; i < n_exc; i++) {
+        if (x_window[i] < 0 || x_window[i] >= W) return pfail(p, MP_ERR_ARG, "exception %lld: window %d out of range", (long long)i, x_window[i]);
+        xoff[(size_t)x_window[i] + 1]++;
+    }
+    for (int w = 0; w < W; w++) { eoff[(size_t)w + 1] += eoff[(size_t)w]; xoff[(size_t)w + 1] += xoff[(size_t)w]; }
+    std::vector<int64_t> eidx((size_t)n_entries), xidx((size_t)n_exc);
+    {
+        std::vector<int64_t> cur(eoff.begin(), eoff.end() - 1);
+        for (int64_t i = 0; i < n_entries; i++) eidx[(size_t)cur[(size_t)e_window[i]]++] = i;
+        std::vector<int64_t> cux(xoff.begin(), xoff.end() - 1);
+        for (int64_t i = 0; i < n_exc; i++) xidx[(size_t)cux[(size_t)x_window[i]]++] = i;
+    }
+    try {
+        p->win.resize((size_t)W);
+    } catch (...) {
+        return pfail(p, MP_ERR_NOMEM, "mp_plan_create: out of memory");
+    }
+    const uint32_t kmask = k == 32 ? 0xFFFFFFFFu : ((1u << k) - 1u);
+    const double max_exp = 1 << 22;            // expansions of one exception k-mer the host is willing to enumerate
+    std::atomic<int> next{0}, failed{0};       // failed: 0 or the MP_ERR_* code of the first failure
+    const int n_thr = resolve_threads(P.n_threads, W);
+    auto worker = [&]() {
+        std::vector<Sight> sights;
+        for (;;) {
+            int w = next.fetch_add(1);
+            if (w >= W || failed.load()) break;
+            sights.clear();
+            for (int64_t t = eoff[(size_t)w]; t < eoff[(size_t)w + 1]; t++) {
+                const int64_t i = eidx[(size_t)t];
+                const uint32_t b0 = e_words[i], b1 = e_words[(size_t)n_entries + i], g = e_words[2 * (size_t)n_entries + i] & kmask;
+                Sight s;
+                for (int j = 0; j < k; j++)
+                    s.key.set(j, (g >> j) & 1u ? 0u : 1u << (((b0 >> j) & 1u) | (((b1 >> j) & 1u) << 1)));
+                s.count = e_count[i];
+                s.row = e_first[i];
+                s.sub = 0;
+                s.ngap = __builtin_popcount(g);
+                sights.push_back(s);
+            }
+            int64_t n_exc_cover = 0, n_exp = 0;
+            for (int64_t t = xoff[(size_t)w]; t < xoff[(size_t)w + 1]; t++) {
+                const int64_t i = xidx[(size_t)t];
+                const uint8_t *codes = x_codes + (size_t)i * k;
+                int ngap = 0;
+                for (int j = 0; j < k; j++) ngap += codes[j] == 0;
+                if (ngap > P.v) {                      // gap_sequence is keyed by the raw string (V20:691)
+                    Sight s;
+                    for (int j = 0; j < k; j++) s.key.set(j, codes[j]);
+                    s.count = 1; s.row = x_row[i]; s.sub = 0; s.ngap = ngap;
+                    sights.push_back(s);
+                } else {
+                    if (expansions_of(codes, k) > max_exp) {
+                        int zero = 0;
+                        if (failed.compare_exchange_strong(zero, MP_ERR_CAPACITY))
+                            pfail(p, MP_ERR_CAPACITY, "window %d, sequence %lld: an IUPAC k-mer with %.0f expansions (limit %.0f)", w,
+                                  (long long)x_row[i], expansions_of(codes, k), max_exp);
+                        break;
+                    }
+                    int32_t sub = 0;
+                    n_exp += for_each_expansion(codes, k, [&](const Key &e) {
+                        sights.push_back(Sight{e, 1, x_row[i], sub++, ngap});
+                    });
+                    n_exc_cover++;
+                }
+            }
+            if (failed.load()) break;
+            int rc = plan_window(p, w, sights, n_exc_cover, n_exp, freq + (size_t)w * 4 * k, nn + (size_t)w * (k - 1) * 16);
+            if (rc != MP_OK) { int zero = 0; failed.compare_exchange_strong(zero, rc); break; }
+            if (!P.keep_tables && p->win[(size_t)w].status != MP_WIN_PLANNED) {
+                Window &ww = p->win[(size_t)w];
+                std::vector<Entry>().swap(ww.cover);
+                std::vector<Entry>().swap(ww.gap);
+                std::vector<int32_t>().swap(ww.cover_map.slot);
+            }
+        }
+    };
+    if (n_thr <= 1) worker();
+    else {
+        std::vector<std::thread> th;
+        for (int t = 0; t < n_thr; t++) th.emplace_back(worker);
+        for (auto &t : th) t.join();
+    }
+    if (failed.load()) return failed.load();
+    for (int w = 0; w < W; w++) {
+        Window &ww = p->win[(size_t)w];
+        if (ww.status != MP_WIN_PLANNED) continue;
+        p->planned.push_back(w);
+        for (int s = 0; s < ww.n_seeds; s++) {
+            ww.seeds[s].first_cand = p->n_cand;
+            p->n_cand += (int64_t)ww.seeds[s].chain.size();
+        }
+    }
+    return MP_OK;
+}
+
+int mp_plan_windows(const mp_plan *p, int32_t *status, int64_t *cover_number, int64_t *gap_number, double *cbit, double *tbit) {
+    if (!p) return MP_ERR_ARG;
+    for (size_t w = 0; w < p->win.size(); w++) {
+        const Window &x = p->win[w];
+        if (status) status[w] = x.status;
+        if (cover_number) cover_number[w] = x.cover_number;
+        if (gap_number) gap_number[w] = x.gap_number;
+        if (cbit) cbit[w] = x.cbit;
+        if (tbit) tbit[w] = x.tbit;
+    }
+    return MP_OK;
+}
+
+int mp_plan_sizes(const mp_plan *p, int32_t *n_planned, int64_t *n_candidates) {
+    if (!p) return MP_ERR_ARG;
+    if (n_planned) *n_planned = (int32_t)p->planned.size();
+    if (n_candidates) *n_candidates = p->n_cand;
+    return MP_OK;
+}
+
+int mp_plan_candidates(const mp_plan *p, int32_t *cand_window, uint8_t *cand_codes) {
+    if (!p || !cand_window || !cand_codes) return MP_ERR_ARG;
+    const int k = p->P.k;
+    int64_t c = 0;
+    for (int32_t w : p->planned) {
+        const Window &x = p->win[(size_t)w];
+        for (int s = 0; s < x.n_seeds; s++)
+            for (const Key &key : x.seeds[s].chain) {
+                cand_window[c] = w;
+                for (int j = 0; j < k; j++) cand_codes[(size_t)c * k + j] = (uint8_t)key.get(j);
+                c++;
+            }
+    }
+    return MP_OK;
+}
+
+int mp_plan_seeds(const mp_plan *p, int32_t w, uint8_t *nm, uint8_t *mm, int32_t *has_mm, int32_t *n_chain_nm, int32_t *n_chain_mm) {
+    if (!p || w < 0 || (size_t)w >= p->win.size()) return MP_ERR_ARG;
+    const Window &x = p->win[(size_t)w];
+    if (x.status != MP_WIN_PLANNED) return MP_ERR_ARG;
+    const int k = p->P.k;
+    if (nm) memcpy(nm, x.seeds[0].index, (size_t)k);
+    if (mm && x.n_seeds == 2) memcpy(mm, x.seeds[1].index, (size_t)k);
+    if (has_mm) *has_mm = x.n_seeds == 2;
+    if (n_chain_nm) *n_chain_nm = (int32_t)x.seeds[0].chain.size();
+    if (n_chain_mm) *n_chain_mm = x.n_seeds == 2 ? (int32_t)x.seeds[1].chain.size() : 0;
+    return MP_OK;
+}
+
+int mp_plan_chain(const mp_plan *p, int32_t w, int32_t seed, int32_t cap, uint8_t *codes, int64_t *cov, uint8_t *stops, int32_t *n) {
+    if (!p || w < 0 || (size_t)w >= p->win.size() || !n) return MP_ERR_ARG;
+    const Window &x = p->win[(size_t)w];
+    if (x.status != MP_WIN_PLANNED || seed < 0 || seed >= x.n_seeds) return MP_ERR_ARG;
+    const Seed &s = x.seeds[seed];
+    *n = (int32_t)s.chain.size();
+    if (*n > cap) return MP_ERR_CAPACITY;
+    const int k = p->P.k;
+    for (size_t i = 0; i < s.chain.size(); i++) {
+        if (codes) for (int j = 0; j < k; j++) codes[i * k + j] = (uint8_t)s.chain[i].get(j);
+        if (cov) cov[i] = s.cov[i];
+        if (stops) stops[i] = s.stops[i];
+    }
+    return MP_OK;
+}
+
+int mp_plan_finish(mp_plan *p, const int64_t *ev) {
+    if (!p || !ev) return MP_ERR_ARG;
+    const int k = p->P.k;
+    for (int32_t w : p->planned) {
+        Window &x = p->win[(size_t)w];
+        const int64_t cn = x.cover_number;
+        for (int si = 0; si < x.n_seeds; si++) {
+            Seed &s = x.seeds[si];
+            const int64_t base = s.first_cand;
+            // the host's running perfect coverage and the device's count are the same quantity
+            for (size_t j = 0; j < s.chain.size(); j++)
+                if (ev[3 * (base + (int64_t)j)] != s.cov[j])
+                    return pfail(p, MP_ERR_ARG, "perfect-coverage mismatch between the host chain and the evaluation at window %d "
+                                 "(seed %d, member %zu: host %lld, evaluation %lld)", w, si, j, (long long)s.cov[j],
+                                 (long long)ev[3 * (base + (int64_t)j)]);
+            // the stopping rules of coverage_stast (V20:881-906)
+            int i = 0;
+            int64_t F = ev[3 * base + 1], R = ev[3 * base + 2];
+            if (s.cov[0] + F < cn || s.cov[0] + R < cn) {
+                while (s.cov[(size_t)i] + F < cn || s.cov[(size_t)i] + R < cn) {
+                    i++;
+                    F = ev[3 * (base + i) + 1];
+                    R = ev[3 * (base + i) + 2];
+                    if (std::max(F, R) == cn || s.stops[(size_t)i]) break;
+                }
+            }
+            s.final_i = i;
+            s.F = s.cov[(size_t)i] + F;
+            s.R = s.cov[(size_t)i] + R;
+        }
+        const Seed *ch = &x.seeds[0];
+        if (x.n_seeds == 2) {
+            const Seed &nm = x.seeds[0], &mm = x.seeds[1];
+            ch = (nm.F + nm.R) > (mm.F + mm.R) ? &nm : &mm;                              // V20:816: ties go to MM
+        }
+        x.primer = ch->chain[(size_t)ch->final_i];
+        x.cov = ch->cov[(size_t)ch->final_i];
+        x.f_mis = ch->F;
+        x.r_mis = ch->R;
+        uint8_t codes[32];
+        x.n_dege = 0;
+        for (int j = 0; j < k; j++) { codes[j] = (uint8_t)x.primer.get(j); x.n_dege += set_size(codes[j]) > 1; }
+        // nonsense_primer_number (V20:846): expansions that are neither observed k-mers nor the NM seed's phantom key
+        int32_t nonsense = 0;
+        for_each_expansion(codes, k, [&](const Key &e) {
+            if (x.cover_map.find(e, x.cover) < 0 && !(e == x.present)) nonsense++;
+        });
+        x.nonsense = nonsense;
+    }
+    p->finished = true;
+    return MP_OK;
+}
+
+int mp_plan_results(const mp_plan *p, int32_t *window, double *cbit, double *tbit, uint8_t *primer_codes, int64_t *cov,
+                    int64_t *f_mis, int64_t *r_mis, int32_t *nonsense, int32_t *n_dege, int64_t *cover_number) {
+    if (!p) return MP_ERR_ARG;
+    if (!p->finished) return MP_ERR_ARG;
+    const int k = p->P.k;
+    size_t i = 0;
+    for (int32_t w : p->planned) {
+        const Window &x = p->win[(size_t)w];
+        if (window) window[i] = w;
+        if (cbit) cbit[i] = x.cbit;
+        if (tbit) tbit[i] = x.tbit;
+        if (primer_codes) for (int j = 0; j < k; j++) primer_codes[i * k + j] = (uint8_t)x.primer.get(j);
+        if (cov) cov[i] = x.cov;
+        if (f_mis) f_mis[i] = x.f_mis;
+        if (r_mis) r_mis[i] = x.r_mis;
+        if (nonsense) nonsense[i] = x.nonsense;
+        if (n_dege) n_dege[i] = x.n_dege;
+        if (cover_number) cover_number[i] = x.cover_number;
+        i++;
+    }
+    return MP_OK;
+}
+
+int mp_plan_window_table(const mp_plan *p, int32_t w, int32_t which, int64_t cap, uint8_t *codes, int64_t *counts,
+                         int64_t *first_row, int64_t *n) {
+    if (!p || w < 0 || (size_t)w >= p->win.size() || (which != 0 && which != 1) || !n) return MP_ERR_ARG;
+    const Window &x = p->win[(size_t)w];
+    const std::vector<Entry> &t = which == 0 ? x.cover : x.gap;
+    *n = (int64_t)t.size();
+    if ((int64_t)t.size() > cap) return MP_ERR_CAPACITY;
+    const int k = p->P.k;
+    for (size_t i = 0; i < t.size(); i++) {
+        if (codes) for (int j = 0; j < k; j++) codes[i * k + j] = (uint8_t)t[i].key.get(j);
+        if (counts) counts[i] = t[i].count;
+        if (first_row) first_row[i] = t[i].first_row;
+    }
+    return MP_OK;
+}
+
+int mp_expand_kmers(int32_t k, int64_t n, const uint8_t *codes, int64_t cap, uint8_t *out_codes, int64_t *out_src, int64_t *n_out) {
+    if (k < 1 || k > 32 || n < 0 || !n_out || (n && !codes)) return MP_ERR_ARG;
+    double need = 0;
+    for (int64_t i = 0; i < n; i++) {
+        for (int j = 0; j < k; j++) if (codes[(size_t)i * k + j] > 15) return MP_ERR_ARG;
+        need += expansions_of(codes + (size_t)i * k, k);
+    }
+    if (need > 9e15) return MP_ERR_CAPACITY;
+    *n_out = (int64_t)need;
+    if ((int64_t)need > cap) return MP_ERR_CAPACITY;
+    int64_t o = 0;
+    for (int64_t i = 0; i < n; i++)
+        for_each_expansion(codes + (size_t)i * k, k, [&](const Key &e) {
+            if (out_codes) for (int j = 0; j < k; j++) out_codes[(size_t)o * k + j] = (uint8_t)e.get(j);
+            if (out_src) out_src[o] = i;
+            o++;
+        });
+    return MP_OK;
+}
+
+}  // extern "C"

@@ -6,18 +6,17 @@ over xGMI on ROCm, "gloo" in the CPU tests):
 
   * candidate evaluation: each rank evaluates its rows; ONE all-reduce (sum, int64) of the
     [n_candidates x 3] counter block per alignment — a few hundred KB, latency-bound;
-  * per-window histograms: (key, count, first row) lists are all-gathered and merged by key
-    (sum of counts, min of first row) identically on every rank — the two non-additive
-    consumers (entropy, most-frequent seed with first-seen tie-break) need the global table;
-  * row attributes (region quantiles): all-gathered ints.
+  * per-window histograms: (window, key, count, first row) entries are all-gathered as packed int64
+    tensors (RCCL all_gather, no pickling) and merged by key (sum of counts, min of first row) by the
+    native planning stage, identically on every rank — the two non-additive consumers (entropy,
+    most-frequent seed with first-seen tie-break) need the global table;
+  * row attributes (region quantiles) and the IUPAC exception list: all-gathered packed tensors.
 
 The host control flow is replicated on every rank (it is deterministic given the merged
 tables), rank 0 writes the files.  Results are identical for 1/2/4/8 shards: integer sums are
 associative and the merged tables reproduce the single-process insertion order.
 """
 from __future__ import annotations
-
-from collections import defaultdict
 
 import numpy as np
 import torch
@@ -53,66 +52,82 @@ class RowShards:
         self.row0, self.n_local, self.n_total = a, b - a, n
         return data[row_off[a]:row_off[b]], row_off[a:b + 1] - row_off[a]
 
-    def _gather_objects(self, obj):
-        out = [None] * self.world
-        dist.all_gather_object(out, obj, group=self.group)
-        return out
+    # -- variable-length all-gather of packed arrays (RCCL on GPUs, gloo in the CPU tests) -------
+    def _device(self):
+        return torch.device("cuda", torch.cuda.current_device()) if self.on_gpu else torch.device("cpu")
+
+    def gather_var(self, arr, axis=0):
+        """Concatenation over ranks (rank order) of a numpy array whose length along `axis` differs per rank: one
+        all_gather of the lengths, one all_gather of the byte-packed, padded payloads — tensors, no pickling."""
+        arr = np.ascontiguousarray(np.moveaxis(np.asarray(arr), axis, 0))
+        tail, dt = arr.shape[1:], arr.dtype
+        row_bytes = int(np.prod(tail, dtype=np.int64)) * dt.itemsize
+        dev = self._device()
+        n_local = torch.tensor([arr.shape[0]], dtype=torch.int64, device=dev)
+        sizes = [torch.zeros(1, dtype=torch.int64, device=dev) for _ in range(self.world)]
+        dist.all_gather(sizes, n_local, group=self.group)
+        sizes = [int(x.item()) for x in sizes]
+        cap = max(max(sizes) * row_bytes, 1)
+        payload = torch.zeros(cap, dtype=torch.uint8, device=dev)
+        if arr.size:
+            flat = torch.from_numpy(arr.reshape(-1).view(np.uint8).copy())
+            payload[: flat.numel()] = flat.to(dev)
+        parts = [torch.empty(cap, dtype=torch.uint8, device=dev) for _ in range(self.world)]
+        dist.all_gather(parts, payload, group=self.group)
+        out = [p[: n * row_bytes].cpu().numpy().view(dt).reshape((n,) + tail) for p, n in zip(parts, sizes)]
+        return np.moveaxis(np.concatenate(out, axis=0), 0, axis)
 
     def gather_rows(self, arr):
-        return np.concatenate(self._gather_objects(np.asarray(arr)))
+        return self.gather_var(np.asarray(arr))
 
-    # -- histograms ----------------------------------------------------------------------------
-    def merge_tables(self, off, words, count, first, exc, W, labels=None):
-        """All-gather the per-rank (window, key, count, first_row) entries and merge by key."""
-        win_of = np.repeat(np.arange(W, dtype=np.int64), np.diff(off))
-        mine = (win_of, words, count.astype(np.int64), first.astype(np.int64), dict(exc))
-        parts = self._gather_objects(mine)
-        win_all = np.concatenate([p[0] for p in parts])
-        words_all = np.concatenate([p[1] for p in parts], axis=1)
-        count_all = np.concatenate([p[2] for p in parts])
-        first_all = np.concatenate([p[3] for p in parts])
-        key = np.stack([win_all.astype(np.uint64), words_all[0].astype(np.uint64), words_all[1].astype(np.uint64),
-                        words_all[2].astype(np.uint64)], axis=1)
-        uniq, inv = np.unique(key, axis=0, return_inverse=True)
-        inv = inv.reshape(-1)
-        m = len(uniq)
-        cnt = np.bincount(inv, weights=count_all, minlength=m).astype(np.int64)
-        fst = np.full(m, np.iinfo(np.int64).max, np.int64)
-        np.minimum.at(fst, inv, first_all)
-        order = np.lexsort((fst, uniq[:, 0]))
-        rank_of = np.empty(m, np.int64)
-        rank_of[order] = np.arange(m)
-        uw = uniq[order, 0].astype(np.int64)
-        moff = np.zeros(W + 1, np.int64)
-        np.cumsum(np.bincount(uw, minlength=W), out=moff[1:])
-        mwords = np.stack([uniq[order, 1], uniq[order, 2], uniq[order, 3]]).astype(np.uint32)
-        # position of this rank's local entries inside the merged table (for the id lists)
-        lo = sum(len(p[0]) for p in parts[: self.rank])
-        self._local_to_merged = rank_of[inv[lo: lo + len(win_of)]] - moff[win_of]
-        self._local_off = off
-        mexc = defaultdict(list)
-        for p in parts:
-            for w_, lst in p[4].items():
-                mexc[w_].extend(lst)
-        for lst in mexc.values():
-            lst.sort()
-        return moff, mwords, cnt[order], fst[order], mexc
+    def gather_columns(self, arr):
+        """[m][n_local] per rank -> [m][n_total] (columns = rows of the alignment)."""
+        return self.gather_var(arr, axis=1)
 
-    def gather_labels(self, ctx, W):
-        """Per-row histogram labels of every window, translated to merged-table indices and
-        gathered from all ranks: [W][n_total].  O(W x N) — only for the JSON side files."""
-        local = np.empty((W, self.n_local), np.int64)
-        for w in range(W):
-            lab = ctx.get_labels(w)
-            ok = lab >= 0
-            row = np.full(self.n_local, -1, np.int64)
-            row[ok] = self._local_to_merged[self._local_off[w] + lab[ok]]
-            local[w] = row
-        parts = self._gather_objects(local)
-        self.global_labels = np.concatenate(parts, axis=1)
+    def gather_dicts(self, d):
+        """{k-mer string: [rows]} of every rank, rank order (JSON side files only: O(ids), small alignments)."""
+        keys = list(d)
+        lens = np.fromiter((len(d[s]) for s in keys), np.int64, len(keys))
+        rows = np.fromiter((r for s in keys for r in d[s]), np.int64, int(lens.sum()))
+        kb = np.frombuffer("".join(keys).encode("ascii"), np.uint8)
+        klen = len(keys[0]) if keys else 0
+        # per rank: number of keys, then the three packed arrays
+        n_keys = self.gather_var(np.asarray([len(keys), klen], np.int64).reshape(1, 2))
+        all_kb, all_lens, all_rows = self.gather_var(kb), self.gather_var(lens), self.gather_var(rows)
+        out, ko, lo, ro = [], 0, 0, 0
+        for nk, kl in n_keys.tolist():
+            part = {}
+            for i in range(nk):
+                s = all_kb[ko + i * kl: ko + (i + 1) * kl].tobytes().decode("ascii")
+                n = int(all_lens[lo + i])
+                part[s] = all_rows[ro: ro + n].tolist()
+                ro += n
+            ko += nk * kl
+            lo += nk
+            out.append(part)
+        return out
 
-    def labels(self, w):
-        return self.global_labels[w]
+    # -- histograms and exceptions ---------------------------------------------------------------
+    def gather_entries(self, e_window, words, count, first_global):
+        """Every rank's (window, key words, count, first global row) entries, concatenated.  No merge here: the native
+        planning stage merges by key (counts add, the smallest first row wins)."""
+        packed = np.empty((len(e_window), 5), np.int64)
+        packed[:, 0] = e_window
+        packed[:, 1] = np.asarray(words[0], np.int64) | (np.asarray(words[1], np.int64) << 32)
+        packed[:, 2] = np.asarray(words[2], np.int64)
+        packed[:, 3] = count
+        packed[:, 4] = first_global
+        g = self.gather_var(packed)
+        w = np.stack([(g[:, 1] & 0xFFFFFFFF).astype(np.uint32), (g[:, 1] >> 32).astype(np.uint32), g[:, 2].astype(np.uint32)])
+        return g[:, 0].astype(np.int32), w, g[:, 3].copy(), g[:, 4].copy()
+
+    def gather_exceptions(self, ex_w, x_row, ex_codes, k):
+        head = np.empty((len(ex_w), 2), np.int64)
+        head[:, 0] = ex_w
+        head[:, 1] = x_row
+        g = self.gather_var(head)
+        codes = self.gather_var(np.asarray(ex_codes, np.uint8).reshape(len(ex_w), k))
+        return g[:, 0].astype(np.int32), g[:, 1].copy(), codes
 
     # -- evaluation ----------------------------------------------------------------------------
     def sum_int64(self, a):

@@ -1,0 +1,259 @@
+"""ctypes binding of include/mprime_host.h — the native host stage of the core step (C++ inside
+`csrc/libmprime_hip.so`: FASTA record parser, per-window planning).  Pure host code: it loads and runs without a
+GPU, takes and returns numpy arrays, and is always served by the product library (there is no Python fallback;
+the pure-Python restatement lives in oracle/core_ref.py as test infrastructure).
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+import numpy as np
+
+from ._abi import HIP_LIB, MP_ERR_CAPACITY, MprimeError, _ptr
+
+_p = C.c_void_p
+
+
+class PlanParams(C.Structure):
+    _fields_ = [("k", C.c_int32), ("v", C.c_int32), ("n_windows", C.c_int32), ("n_threads", C.c_int32),
+                ("total_sequences", C.c_int64), ("coverage", C.c_double), ("entropy_threshold", C.c_double),
+                ("max_degeneracy", C.c_double), ("max_dege_positions", C.c_int32), ("keep_tables", C.c_int32)]
+
+
+# every symbol include/mprime_host.h declares: (name, restype, argtypes)
+HOST_SYMBOLS = [
+    ("mp_fasta_parse_file", C.c_int, [C.c_char_p, C.c_int32, C.POINTER(_p)]),
+    ("mp_fasta_parse_buffer", C.c_int, [_p, C.c_int64, C.c_int32, C.POINTER(_p)]),
+    ("mp_fasta_destroy", None, [_p]),
+    ("mp_fasta_error", C.c_char_p, [_p]),
+    ("mp_fasta_sizes", C.c_int, [_p, C.POINTER(C.c_int32), C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),
+    ("mp_fasta_rows", C.c_int, [_p, _p, _p]),
+    ("mp_fasta_ids", C.c_int, [_p, _p, _p]),
+    ("mp_plan_create", C.c_int, [C.POINTER(PlanParams), C.c_int64, _p, _p, _p, _p, C.c_int64, _p, _p, _p, _p, _p, C.POINTER(_p)]),
+    ("mp_plan_destroy", None, [_p]),
+    ("mp_plan_error", C.c_char_p, [_p]),
+    ("mp_plan_windows", C.c_int, [_p, _p, _p, _p, _p, _p]),
+    ("mp_plan_sizes", C.c_int, [_p, C.POINTER(C.c_int32), C.POINTER(C.c_int64)]),
+    ("mp_plan_candidates", C.c_int, [_p, _p, _p]),
+    ("mp_plan_seeds", C.c_int, [_p, C.c_int32, _p, _p, C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
+    ("mp_plan_chain", C.c_int, [_p, C.c_int32, C.c_int32, C.c_int32, _p, _p, _p, C.POINTER(C.c_int32)]),
+    ("mp_plan_finish", C.c_int, [_p, _p]),
+    ("mp_plan_results", C.c_int, [_p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p]),
+    ("mp_plan_window_table", C.c_int, [_p, C.c_int32, C.c_int32, C.c_int64, _p, _p, _p, C.POINTER(C.c_int64)]),
+    ("mp_expand_kmers", C.c_int, [C.c_int32, C.c_int64, _p, C.c_int64, _p, _p, C.POINTER(C.c_int64)]),
+]
+
+_dll = None
+
+
+def dll():
+    """The product library's host-stage entry points (loaded once; raises if the library is missing)."""
+    global _dll
+    if _dll is None:
+        if not os.path.exists(HIP_LIB):
+            raise MprimeError(-2, f"{HIP_LIB} is missing — build it with `python -c 'import __graft_entry__ as g; g.build()'`; "
+                                  "the host stage has no Python fallback")
+        d = C.CDLL(HIP_LIB)
+        for name, res, args in HOST_SYMBOLS:
+            fn = getattr(d, name)
+            fn.restype = res
+            fn.argtypes = args
+        _dll = d
+    return _dll
+
+
+class Fasta:
+    """Records of a FASTA / alignment file (parse_seq's record semantics, V20:441-455)."""
+
+    def __init__(self, path: str | None = None, raw: bytes | None = None, n_threads: int = 0):
+        self.d = dll()
+        h = _p()
+        if raw is not None:
+            buf = np.frombuffer(raw, np.uint8)
+            rc = self.d.mp_fasta_parse_buffer(_ptr(buf) if len(buf) else None, len(buf), n_threads, C.byref(h))
+        else:
+            rc = self.d.mp_fasta_parse_file(os.fsencode(path), n_threads, C.byref(h))
+        self.h = h
+        if rc != 0:
+            msg = self.d.mp_fasta_error(h).decode(errors="replace") if h else "mp_fasta_parse failed"
+            self.close()
+            if "before the first" in msg:
+                raise ValueError(msg)
+            if rc == -1:
+                raise OSError(msg)
+            raise MprimeError(rc, msg)
+        n, nb, ni = C.c_int32(0), C.c_int64(0), C.c_int64(0)
+        self.d.mp_fasta_sizes(h, C.byref(n), C.byref(nb), C.byref(ni))
+        self.n_rows, self.n_bytes, self.n_id_bytes = n.value, nb.value, ni.value
+        self._ids = None
+
+    def rows(self):
+        """(data, row_off): the residue bytes of all records back to back — the input of mp_load_msa."""
+        data = np.empty(max(self.n_bytes, 1), np.uint8)
+        off = np.empty(self.n_rows + 1, np.int64)
+        rc = self.d.mp_fasta_rows(self.h, _ptr(data), _ptr(off))
+        if rc != 0:
+            raise MprimeError(rc, "mp_fasta_rows")
+        return data[: self.n_bytes], off
+
+    @property
+    def ids(self):
+        """Sequence ids (first-appearance order), decoded like the reference's text-mode read (UTF-8)."""
+        if self._ids is None:
+            buf = np.empty(max(self.n_id_bytes, 1), np.uint8)
+            off = np.empty(self.n_rows + 1, np.int64)
+            self.d.mp_fasta_ids(self.h, _ptr(buf), _ptr(off))
+            raw = buf[: self.n_id_bytes].tobytes()
+            try:
+                text = raw.decode("ascii")
+                o = off.tolist()
+                self._ids = [text[a:b] for a, b in zip(o[:-1], o[1:])]
+            except UnicodeDecodeError:
+                o = off.tolist()
+                self._ids = [raw[a:b].decode("utf-8", errors="surrogateescape") for a, b in zip(o[:-1], o[1:])]
+        return self._ids
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.d.mp_fasta_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def expand_kmers(codes: np.ndarray):
+    """(expansions [m][k], src [m]): degenerate_seq (V20:368-380) of every k-mer of symbol codes, reference order."""
+    codes = np.ascontiguousarray(codes, dtype=np.uint8)
+    n, k = codes.shape
+    d = dll()
+    need = C.c_int64(0)
+    rc = d.mp_expand_kmers(k, n, _ptr(codes), 0, None, None, C.byref(need))
+    if rc not in (0, MP_ERR_CAPACITY):
+        raise MprimeError(rc, "mp_expand_kmers: bad symbol codes or too many expansions")
+    m = need.value
+    if m > 1 << 28:
+        raise MprimeError(MP_ERR_CAPACITY, f"IUPAC k-mers expand to {m} concrete k-mers")
+    out = np.empty((max(m, 1), k), np.uint8)
+    src = np.empty(max(m, 1), np.int64)
+    rc = d.mp_expand_kmers(k, n, _ptr(codes), m, _ptr(out), _ptr(src), C.byref(need))
+    if rc != 0:
+        raise MprimeError(rc, "mp_expand_kmers")
+    return out[:m], src[:m]
+
+
+class Plan:
+    """Per-window planning of one alignment (mp_plan_*)."""
+
+    def __init__(self, *, k, v, n_windows, total_sequences, coverage, entropy_threshold, max_degeneracy, max_dege_positions,
+                 e_window, e_words, e_count, e_first, x_window, x_row, x_codes, freq, nn, keep_tables=False, n_threads=0):
+        self.d = dll()
+        self.k, self.W = int(k), int(n_windows)
+        P = PlanParams(int(k), int(v), int(n_windows), int(n_threads), int(total_sequences), float(coverage), float(entropy_threshold),
+                       float(max_degeneracy), int(max_dege_positions), int(bool(keep_tables)))
+        e_window = np.ascontiguousarray(e_window, dtype=np.int32)
+        n = len(e_window)
+        e_words = np.ascontiguousarray(e_words, dtype=np.uint32).reshape(3, n)
+        e_count = np.ascontiguousarray(e_count, dtype=np.int64)
+        e_first = np.ascontiguousarray(e_first, dtype=np.int64)
+        x_window = np.ascontiguousarray(x_window, dtype=np.int32)
+        x_row = np.ascontiguousarray(x_row, dtype=np.int64)
+        x_codes = np.ascontiguousarray(x_codes, dtype=np.uint8).reshape(len(x_window), self.k)
+        freq = np.ascontiguousarray(freq, dtype=np.int64)
+        nn = np.ascontiguousarray(nn, dtype=np.int64)
+        assert freq.shape == (self.W, 4, self.k) and nn.shape == (self.W, self.k - 1, 4, 4)
+        h = _p()
+        rc = self.d.mp_plan_create(C.byref(P), n, _ptr(e_window), _ptr(e_words), _ptr(e_count), _ptr(e_first), len(x_window),
+                                   _ptr(x_window), _ptr(x_row), _ptr(x_codes), _ptr(freq), _ptr(nn), C.byref(h))
+        self.h = h
+        if rc != 0:
+            msg = self.d.mp_plan_error(h).decode() if h else "mp_plan_create failed"
+            self.close()
+            raise MprimeError(rc, msg)
+        np_, nc = C.c_int32(0), C.c_int64(0)
+        self.d.mp_plan_sizes(h, C.byref(np_), C.byref(nc))
+        self.n_planned, self.n_candidates = np_.value, nc.value
+
+    def _ck(self, rc):
+        if rc != 0:
+            raise MprimeError(rc, self.d.mp_plan_error(self.h).decode())
+
+    def windows(self):
+        """(status, cover_number, gap_number, cbit, tbit) of every window."""
+        st = np.empty(self.W, np.int32)
+        cn = np.empty(self.W, np.int64)
+        gn = np.empty(self.W, np.int64)
+        cb = np.empty(self.W, np.float64)
+        tb = np.empty(self.W, np.float64)
+        self._ck(self.d.mp_plan_windows(self.h, _ptr(st), _ptr(cn), _ptr(gn), _ptr(cb), _ptr(tb)))
+        return st, cn, gn, cb, tb
+
+    def candidates(self):
+        n = self.n_candidates
+        cw = np.empty(max(n, 1), np.int32)
+        codes = np.empty((max(n, 1), self.k), np.uint8)
+        self._ck(self.d.mp_plan_candidates(self.h, _ptr(cw), _ptr(codes)))
+        return cw[:n], codes[:n]
+
+    def seeds(self, w: int):
+        nm = np.zeros(self.k, np.uint8)
+        mm = np.zeros(self.k, np.uint8)
+        has, a, b = C.c_int32(0), C.c_int32(0), C.c_int32(0)
+        self._ck(self.d.mp_plan_seeds(self.h, int(w), _ptr(nm), _ptr(mm), C.byref(has), C.byref(a), C.byref(b)))
+        return nm, (mm if has.value else None), a.value, b.value
+
+    def chain(self, w: int, seed: int):
+        """(codes [n][k], cov [n], stops [n]) of the refinement chain of seed 0 (NM) / 1 (MM) of window w."""
+        cap = 4 * 32 + 16
+        codes = np.empty((cap, self.k), np.uint8)
+        cov = np.empty(cap, np.int64)
+        stops = np.empty(cap, np.uint8)
+        n = C.c_int32(0)
+        self._ck(self.d.mp_plan_chain(self.h, int(w), int(seed), cap, _ptr(codes), _ptr(cov), _ptr(stops), C.byref(n)))
+        return codes[: n.value], cov[: n.value], stops[: n.value]
+
+    def finish(self, ev: np.ndarray):
+        ev = np.ascontiguousarray(ev, dtype=np.int64).reshape(-1, 3)
+        if len(ev) != self.n_candidates:
+            raise ValueError("one evaluation triple per candidate expected")
+        self._ck(self.d.mp_plan_finish(self.h, _ptr(ev) if len(ev) else _ptr(np.zeros(3, np.int64))))
+
+    def results(self):
+        n = self.n_planned
+        m = max(n, 1)
+        r = {"window": np.empty(m, np.int32), "cbit": np.empty(m, np.float64), "tbit": np.empty(m, np.float64),
+             "codes": np.empty((m, self.k), np.uint8), "cov": np.empty(m, np.int64), "f_mis": np.empty(m, np.int64),
+             "r_mis": np.empty(m, np.int64), "nonsense": np.empty(m, np.int32), "n_dege": np.empty(m, np.int32),
+             "cover_number": np.empty(m, np.int64)}
+        self._ck(self.d.mp_plan_results(self.h, *[_ptr(r[key]) for key in ("window", "cbit", "tbit", "codes", "cov", "f_mis", "r_mis",
+                                                                             "nonsense", "n_dege", "cover_number")]))
+        return {key: val[:n] for key, val in r.items()}
+
+    def window_table(self, w: int, which: int):
+        """(codes [n][k], counts [n], first_row [n]) of the cover (which = 0) or gap_sequence (1) dict of window w, in
+        insertion order."""
+        n = C.c_int64(0)
+        rc = self.d.mp_plan_window_table(self.h, int(w), int(which), 0, None, None, None, C.byref(n))
+        if rc not in (0, MP_ERR_CAPACITY):
+            self._ck(rc)
+        m = n.value
+        codes = np.empty((max(m, 1), self.k), np.uint8)
+        counts = np.empty(max(m, 1), np.int64)
+        first = np.empty(max(m, 1), np.int64)
+        self._ck(self.d.mp_plan_window_table(self.h, int(w), int(which), m, _ptr(codes), _ptr(counts), _ptr(first), C.byref(n)))
+        return codes[:m], counts[:m], first[:m]
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.d.mp_plan_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

@@ -71,6 +71,18 @@ def words_of_kmers(chars: np.ndarray) -> np.ndarray:
     return out
 
 
+def words_of_codes(codes: np.ndarray) -> np.ndarray:
+    """(n,k) concrete symbol codes (A=1 C=2 G=4 T=8, '-'=0) -> (n,3) uint32 window words (mprime.h)."""
+    codes = np.asarray(codes, np.uint8)
+    n, k = codes.shape
+    sh = np.arange(k, dtype=np.uint32)[None, :]
+    out = np.empty((n, 3), np.uint32)
+    out[:, 0] = np.bitwise_or.reduce((((codes & 10) != 0).astype(np.uint32)) << sh, axis=1) if n else 0      # C or T: low index bit
+    out[:, 1] = np.bitwise_or.reduce((((codes & 12) != 0).astype(np.uint32)) << sh, axis=1) if n else 0      # G or T: high index bit
+    out[:, 2] = np.bitwise_or.reduce(((codes == 0).astype(np.uint32)) << sh, axis=1) if n else 0
+    return out
+
+
 _WORD_LUT = np.frombuffer(b"ACGT----", dtype=np.uint8)      # index = b0 | b1 << 1 | gap << 2
 
 

@@ -5,7 +5,8 @@ skipped, a '>' line sets the current id to its first space-delimited token (lead
 included), every other line is stripped and appended to the current id's sequence — so a
 repeated id concatenates, as the reference's defaultdict(str) does.  The per-character
 mapping of V20:453 (upper-case, keep ACGTRYMKSWHBVD, else '-') is NOT done here: it is
-O(bytes) work and runs on the device (mp_load_msa).
+O(bytes) work and runs on the device (mp_load_msa).  The record logic itself is native
+(csrc/fasta.cpp behind include/mprime_host.h); its pure-Python restatement is oracle/core_ref.py::parse_records.
 """
 from __future__ import annotations
 
@@ -13,32 +14,20 @@ import numpy as np
 
 
 def read_records(path: str):
-    """Returns (ids, data, row_off): ids in first-appearance order, `data` the concatenated raw
-    residue bytes of all records, row r = data[row_off[r]:row_off[r+1]]."""
-    with open(path, "rb") as f:
-        raw = f.read()
-    return parse_records(raw)
+    """Returns (ids, data, row_off): ids in first-appearance order, `data` the concatenated raw residue bytes of all
+    records, row r = data[row_off[r]:row_off[r+1]] — parsed by the native host stage (csrc/fasta.cpp)."""
+    from .host import Fasta
+    fa = Fasta(path)
+    data, row_off = fa.rows()
+    return fa.ids, data, row_off
 
 
 def parse_records(raw: bytes):
-    pieces: dict[bytes, list[bytes]] = {}
-    cur = None
-    for line in raw.splitlines():
-        if line.startswith(b"#"):
-            continue
-        if line.startswith(b">"):
-            cur = line.strip().split(b" ")[0]
-        else:
-            if cur is None:
-                raise ValueError("sequence data before the first '>' header")
-            pieces.setdefault(cur, []).append(line.strip())
-    ids = [k.decode("latin-1") for k in pieces]
-    rows = [b"".join(v) for v in pieces.values()]
-    lens = np.fromiter((len(r) for r in rows), dtype=np.int64, count=len(rows))
-    row_off = np.zeros(len(rows) + 1, np.int64)
-    np.cumsum(lens, out=row_off[1:])
-    data = np.frombuffer(b"".join(rows), dtype=np.uint8)
-    return ids, data, row_off
+    """Same from a bytes object."""
+    from .host import Fasta
+    fa = Fasta(raw=raw)
+    data, row_off = fa.rows()
+    return fa.ids, data, row_off
 
 
 def region(lead_gap: np.ndarray, rstrip_len: np.ndarray, coverage: float):

@@ -10,8 +10,8 @@ from conftest import REPO
 from multiprime_amd import _abi
 
 
-def header_symbols():
-    src = open(os.path.join(REPO, "include", "mprime.h")).read()
+def header_symbols(name="mprime.h"):
+    src = open(os.path.join(REPO, "include", name)).read()
     src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
     return sorted(set(re.findall(r"\b(mp_[a-z_]+)\s*\(", src)))
 
@@ -33,6 +33,18 @@ def test_hip_library_exports_abi(built):
         assert hasattr(dll, name), name
     dll.mp_backend_name.restype = ctypes.c_char_p
     assert dll.mp_backend_name() == b"hip"
+
+
+def test_host_stage_binding_and_exports(built):
+    """include/mprime_host.h (native host stage): the ctypes table covers it and the PRODUCT library exports it; the
+    oracle library does not serve it (its checker is oracle/core_ref.py + the golden traces)."""
+    from multiprime_amd import host
+    want = header_symbols("mprime_host.h")
+    assert sorted(n for n, _, _ in host.HOST_SYMBOLS) == want and len(want) >= 20
+    dll = ctypes.CDLL(built.HIP_SO)
+    for name in want:
+        assert hasattr(dll, name), name
+    assert host.dll() is not None                       # loads and resolves on a box without a GPU
 
 
 def test_oracle_library_exports_abi(built):

@@ -1,0 +1,251 @@
+"""The native host stage (include/mprime_host.h: csrc/fasta.cpp, csrc/hostplan.cpp) against its checkers:
+  * the FASTA record parser against the pure-Python restatement of parse_seq's record logic (oracle/core_ref.py),
+    on fuzzed files (CRLF, lone CR, comments, repeated ids, blank lines, no final newline), whole and cut into chunks;
+  * the insertion-ordered cover / gap dictionaries against a row-by-row replay of V20:689-711;
+  * seeds, refinement chains and entropies against the reference's recorded internals (tests/golden traces);
+  * the whole drop-in (native stage) against the round-1 pure-Python host logic on random alignments — TSV bytes
+    and both JSON files.
+All CPU: the C ABI of mprime.h is served by the oracle library here; the host stage itself is the product's code
+(pure host C++ inside libmprime_hip.so, it needs no GPU).
+"""
+import itertools
+import json
+import os
+
+import numpy as np
+import pytest
+
+from conftest import golden_input, load_gz_json
+from multiprime_amd import host, iupac
+from multiprime_amd.core import NN_degenerate
+from multiprime_amd.synth import synth_block, to_fasta
+from oracle import core_ref
+
+
+# ------------------------------------------------------------------------------------------------ FASTA records
+def _fuzz_fasta(rng):
+    nl = [b"\n", b"\r\n", b"\r"][int(rng.integers(0, 3))] if rng.random() < 0.5 else None
+    out = []
+    n_ids = int(rng.integers(1, 12))
+    ids = [b">s%d" % i for i in range(n_ids)]
+    for _ in range(int(rng.integers(1, 60))):
+        t = nl or [b"\n", b"\r\n", b"\r"][int(rng.integers(0, 3))]
+        r = rng.random()
+        if r < 0.25 or not out:
+            tail = [b"", b" desc text", b"\tx", b"  ", b" a b"][int(rng.integers(0, 5))]
+            out.append(ids[int(rng.integers(0, n_ids))] + tail + t)
+        elif r < 0.32:
+            out.append(b"#comment >x" + t)
+        elif r < 0.38:
+            out.append(t)                                             # blank line
+        else:
+            body = bytes(rng.choice(np.frombuffer(b"ACGTacgtNRY-.*x", np.uint8), size=int(rng.integers(0, 40))))
+            pad = [b"", b" ", b"\t", b"  "][int(rng.integers(0, 4))]
+            out.append(pad + body + pad + t)
+    raw = b"".join(out)
+    if rng.random() < 0.3:
+        raw = raw.rstrip(b"\r\n")                                     # no terminator on the last line
+    return raw
+
+
+@pytest.mark.parametrize("threads", [1, 2, 5])
+def test_fasta_parser_matches_python_restatement(threads, monkeypatch):
+    monkeypatch.setenv("MP_HOST_THREADS", str(threads))               # exact: even tiny inputs are cut into chunks
+    rng = np.random.default_rng(threads)
+    for _ in range(300):
+        raw = _fuzz_fasta(rng)
+        want_ids, want_data, want_off = core_ref.parse_records(raw)
+        fa = host.Fasta(raw=raw)
+        data, off = fa.rows()
+        assert fa.ids == want_ids
+        assert off.tolist() == want_off.tolist()
+        assert data.tobytes() == want_data.tobytes()
+
+
+def test_fasta_parser_edge_cases(tmp_path):
+    with pytest.raises(ValueError):
+        host.Fasta(raw=b"ACGT\n>a\nAC\n")                            # data before the first header (V20: NameError)
+    with pytest.raises(ValueError):
+        host.Fasta(raw=b"\n>a\nAC\n")                                # even a blank line
+    fa = host.Fasta(raw=b"")
+    assert fa.n_rows == 0 and fa.ids == []
+    fa = host.Fasta(raw=b">a x\nAC\n>b\n>a\nGT\n>c\n\n")              # repeated id concatenates; >b never receives a line
+    assert fa.ids == [">a", ">c"] and fa.rows()[0].tobytes() == b"ACGT" and fa.rows()[1].tolist() == [0, 4, 4]
+    fa = host.Fasta(raw=">séq\nAC\n".encode("utf-8"))           # non-ASCII id: decoded as the reference's text mode does
+    assert fa.ids == [">séq"]
+    p = tmp_path / "x.fa"
+    p.write_bytes(b">a\nACGT\nAC\n#c\n>b\nTTTT")
+    fa = host.Fasta(str(p))
+    assert fa.ids == [">a", ">b"] and fa.rows()[0].tobytes() == b"ACGTACTTTT"
+    with pytest.raises(OSError):
+        host.Fasta(str(tmp_path / "missing.fa"))
+
+
+def test_fasta_parser_large_file_threads(tmp_path):
+    rows = synth_block(0, 3000, 700, 7)
+    p = tmp_path / "big.fa"
+    p.write_bytes(to_fasta(rows))                                     # ~2 MB: several reader / scanner threads
+    fa = host.Fasta(str(p), n_threads=4)
+    want_ids, want_data, want_off = core_ref.parse_records(p.read_bytes())
+    data, off = fa.rows()
+    assert fa.ids == want_ids and off.tolist() == want_off.tolist() and data.tobytes() == want_data.tobytes()
+
+
+# ------------------------------------------------------------------------------------------------ ordered tables
+def _replay(rows):
+    d = {}
+    for _, keys in sorted(rows.items()):
+        for key in keys:
+            d[key] = d.get(key, 0) + 1
+    return d
+
+
+@pytest.mark.parametrize("seed", range(30))
+def test_tables_equal_row_by_row_replay(seed):
+    """The dictionaries the reference builds by walking the sequences in order (plain rows add their k-mer, IUPAC
+    rows add their expansions, V20:689-711) = what the planning stage derives from the device histogram
+    (k-mer, count, first row — here in shuffled order and split over two 'shards') plus the exception list."""
+    rng = np.random.default_rng(seed)
+    k, v = 6, 1
+    n_rows = int(rng.integers(1, 300))
+    pool = ["".join(rng.choice(list("ACGT-"), p=[.23, .23, .23, .23, .08], size=k)) for _ in range(int(rng.integers(1, 25)))]
+    cover_rows, gap_rows, exc, plain = {}, {}, [], {}
+    for r in range(n_rows):
+        if rng.random() < 0.2:                                         # a row holding IUPAC codes
+            s = list(pool[int(rng.integers(0, len(pool)))])
+            for _ in range(int(rng.integers(1, 3))):
+                s[int(rng.integers(0, k))] = "RYMKSWHBVD"[int(rng.integers(0, 10))]
+            s = "".join(s)
+            exc.append((r, s))
+            if s.count("-") > v:
+                gap_rows[r] = [s]
+            else:
+                cover_rows[r] = iupac.expand(s)
+        else:
+            s = pool[int(rng.integers(0, len(pool)))]
+            plain[r] = s
+            (gap_rows if s.count("-") > v else cover_rows)[r] = [s]
+    want_cover, want_gap = _replay(cover_rows), _replay(gap_rows)
+    # device view: distinct plain k-mers per shard with count and first row, shuffled
+    cut = n_rows // 2
+    ents = []
+    for lo, hi in ((0, cut), (cut, n_rows)):
+        cnt, first = {}, {}
+        for r in range(lo, hi):
+            if r in plain:
+                cnt[plain[r]] = cnt.get(plain[r], 0) + 1
+                first.setdefault(plain[r], r)
+        ents += [(s, cnt[s], first[s]) for s in cnt]
+    rng.shuffle(ents)
+    chars = np.frombuffer("".join(e[0] for e in ents).encode(), np.uint8).reshape(len(ents), k) if ents else np.zeros((0, k), np.uint8)
+    words = iupac.words_of_kmers(chars).T if len(ents) else np.zeros((3, 0), np.uint32)
+    xs = [e for e in exc]
+    rng.shuffle(xs)
+    freq = np.ones((1, 4, k), np.int64)
+    nn = np.ones((1, k - 1, 4, 4), np.int64)
+    plan = host.Plan(k=k, v=v, n_windows=1, total_sequences=n_rows, coverage=0.0, entropy_threshold=100.0, max_degeneracy=8,
+                     max_dege_positions=3, e_window=np.zeros(len(ents), np.int32), e_words=words,
+                     e_count=[e[1] for e in ents], e_first=[e[2] for e in ents], x_window=np.zeros(len(xs), np.int32),
+                     x_row=[x[0] for x in xs], x_codes=iupac.MASK_LUT[np.frombuffer("".join(x[1] for x in xs).encode(), np.uint8)].reshape(len(xs), k),
+                     freq=freq, nn=nn, keep_tables=True)
+    for which, want in ((0, want_cover), (1, want_gap)):
+        codes, counts, _ = plan.window_table(0, which)
+        got = list(zip(iupac.strings_of(iupac.SYMBOL_LUT[codes]), counts.tolist()))
+        assert got == list(want.items())
+    _, cn, gn, _, _ = plan.windows()
+    assert cn[0] == len(cover_rows) and gn[0] == len(gap_rows)
+
+
+def test_expand_kmers_is_itertools_product_order():
+    rng = np.random.default_rng(3)
+    syms = "ACGTRYMKSWHBVDN-"
+    kmers = ["".join(rng.choice(list(syms), size=7)) for _ in range(50)]
+    codes = iupac.MASK_LUT[np.frombuffer("".join(kmers).encode(), np.uint8)].reshape(len(kmers), 7)
+    exp, src = host.expand_kmers(codes)
+    got = iupac.strings_of(iupac.SYMBOL_LUT[exp])
+    want = list(itertools.chain.from_iterable(iupac.expand(s) for s in kmers))
+    assert got == want
+    assert src.tolist() == [i for i, s in enumerate(kmers) for _ in iupac.expand(s)]
+
+
+def test_plan_refuses_an_exponential_iupac_window():
+    k = 18
+    codes = np.full((1, k), 15, np.uint8)                              # NNN...: 4^18 expansions
+    with pytest.raises(Exception) as e:
+        host.Plan(k=k, v=1, n_windows=1, total_sequences=1, coverage=0.8, entropy_threshold=3.6, max_degeneracy=10,
+                  max_dege_positions=4, e_window=[], e_words=np.zeros((3, 0), np.uint32), e_count=[], e_first=[],
+                  x_window=[0], x_row=[0], x_codes=codes, freq=np.ones((1, 4, k), np.int64), nn=np.ones((1, k - 1, 4, 4), np.int64))
+    assert "expansions" in str(e.value)
+
+
+# ------------------------------------------------------------------------------------------------ reference internals
+TRACED = ["syn_iupac", "syn_v2", "syn_ragged", "syn_v3_k27", "syn_edge", "ivc_v1", "msa1000_k18_d64", "msa1000_k22_d64", "cluster0_v2"]
+
+
+@pytest.mark.parametrize("name", TRACED)
+def test_seeds_chains_entropies_match_reference_trace(name, oracle_lib, tmp_path):
+    tr = load_gz_json(name + ".trace.json.gz")
+    fl = tr["meta"]["flags"]
+    inp = tmp_path / (name + ".fa")
+    inp.write_bytes(golden_input(tr["meta"]["input"]))
+    app = NN_degenerate(seq_file=str(inp), primer_length=fl["l"], coverage=fl["f"], number_of_dege_bases=fl["n"],
+                        score_of_dege_bases=fl["d"], raw_entropy_threshold=fl["e"], product_len=fl["s"], position=fl["c"],
+                        variation=fl["v"], distance=fl["a"], GC=fl["g"], nproc=1, outfile=str(tmp_path / "o"), library=oracle_lib,
+                        write_json=False)
+    plan = app._plan()
+    status, _, _, cbit, tbit = plan.windows()
+    p0 = int(app.start_position)
+    sym = iupac.SYMBOL_LUT
+    n_refine = n_seed = n_bits = 0
+    for pos, rec in tr["windows"].items():
+        w = int(pos) - p0
+        if "cBit" in rec:                                              # entropy (V20:602-614) as the reference rounded it
+            assert (cbit[w], tbit[w]) == (rec["cBit"], rec["tBit"]), f"entropy at {pos}"
+            n_bits += 1
+        if "NM" not in rec:
+            continue
+        assert status[w] == 0
+        nm, mm, _, _ = plan.seeds(w)
+        assert nm.tolist() == rec["NM"]
+        if rec.get("MM") is not None and rec["MM"] != rec["NM"]:
+            assert mm is not None and mm.tolist() == rec["MM"], f"most-frequent seed at {pos}"
+        n_seed += 1
+        chains = []
+        for s in range(2 if mm is not None else 1):
+            codes, cov, _ = plan.chain(w, s)
+            chains.append((iupac.strings_of(sym[codes]), cov.tolist()))
+        for before, after, cov_after, *_ in rec["refine"]:             # every refine_by_NN_array call the reference made
+            ok = any(a == before and b == after and c == cov_after
+                     for strs, covs in chains for a, b, c in zip(strs, strs[1:], covs[1:]))
+            assert ok, f"refinement step {before} -> {after} ({cov_after}) at {pos} is not on a native chain"
+            n_refine += 1
+    assert n_seed > 0 and n_bits > 0
+    assert n_refine == sum(len(r["refine"]) for r in tr["windows"].values())
+
+
+# ------------------------------------------------------------------------------------------------ native == python
+def _run(cls, lib, inp, out, k, v, d, f):
+    app = cls(seq_file=str(inp), primer_length=k, coverage=f, number_of_dege_bases=4, score_of_dege_bases=d,
+              raw_entropy_threshold=3.6, product_len=60, position="2,3,-1", variation=v, distance=4, GC="0.2,0.7", nproc=1,
+              outfile=str(out), library=lib)
+    app.run()
+    return app
+
+
+@pytest.mark.parametrize("seed", range(6))
+def test_native_stage_equals_python_restatement_on_random_alignments(seed, oracle_lib, tmp_path):
+    rng = np.random.default_rng(100 + seed)
+    n, L = int(rng.integers(40, 220)), int(rng.integers(140, 260))
+    rows = synth_block(0, n, L, 500 + seed, p_gap=float(rng.choice([0.002, 0.02])), edge_frac=float(rng.choice([0.1, 0.4])),
+                       p_iupac=float(rng.choice([0.0, 5e-4, 3e-3])), block_rows=256)
+    inp = tmp_path / "in.fa"
+    inp.write_bytes(to_fasta(rows))
+    k, v = int(rng.choice([12, 18, 22])), int(rng.integers(0, 3))
+    d, f = int(rng.choice([4, 10, 64])), float(rng.choice([0.6, 0.8]))
+    _run(NN_degenerate, oracle_lib, inp, tmp_path / "native.out", k, v, d, f)
+    _run(core_ref.NN_degenerate, oracle_lib, inp, tmp_path / "python.out", k, v, d, f)
+    for suffix in ("", ".non_coverage_seq_id_json", ".gap_seq_id_json"):
+        a = (tmp_path / ("native.out" + suffix)).read_bytes()
+        b = (tmp_path / ("python.out" + suffix)).read_bytes()
+        assert a == b, f"native host stage differs from the Python restatement in out{suffix}"
+    assert len((tmp_path / "native.out").read_bytes().splitlines()) >= 1

@@ -1,8 +1,9 @@
 """Pins the CPU oracle (oracle/mprime_oracle.c) to the reference: every intermediate the C ABI
 produces is compared with what multiPrime-core_V20.py computed internally on the same input
 (traces recorded by tests/golden/make_golden.py): the per-window `cover` and `gap_sequence`
-dictionaries in insertion order, cover_number, the state_matrix / trans_matrix counts (mp_window_stats) and the
-result of every mis_primer_check call.
+dictionaries in insertion order (device histograms + IUPAC exceptions, ordered by the native planning stage),
+cover_number, the state_matrix / trans_matrix counts (mp_window_stats), the Viterbi seeds and the result of every
+mis_primer_check call.
 """
 import numpy as np
 import pytest
@@ -29,8 +30,10 @@ def open_fixture(name, lib, tmp_path):
 
 def check_against_trace(app, tr):
     k = app.primer_length
-    off, strs, count, first, gaps, exc = app._device_tables()
+    plan = app._plan(keep_tables=True)          # device tables -> native planning stage, every window's tables kept
+    status, cover_number, gap_number, _, _ = plan.windows()
     p0 = int(app.start_position)
+    sym = iupac.SYMBOL_LUT
     cand_w, cand_p, want = [], [], []
     n_tables = 0
     n_stats = [0, 0, 0]
@@ -38,10 +41,11 @@ def check_against_trace(app, tr):
         if "cover" not in rec:
             continue
         w = int(pos) - p0
-        win = app._tables_of(w, off, strs, count, first, gaps, exc)
-        assert list(win.cover.items()) == [tuple(x) for x in rec["cover"]], f"cover dict at {pos}"
-        assert list(win.gap.items()) == [tuple(x) for x in rec["gap"]], f"gap_sequence at {pos}"
-        assert win.cover_number == rec["cover_number"] and win.gap_number == rec["gap_number"]
+        for which, name_ in ((0, "cover"), (1, "gap")):
+            codes, counts, _ = plan.window_table(w, which)
+            got = list(zip(iupac.strings_of(sym[codes]), counts.tolist()))
+            assert got == [tuple(x) for x in rec[name_]], f"{name_} dict at {pos}"
+        assert cover_number[w] == rec["cover_number"] and gap_number[w] == rec["gap_number"]
         n_tables += 1
         if "freq" in rec:                                   # state_matrix as the reference built it (rows it has, V20:541-554)
             want_f = np.zeros((4, k), np.int64)
@@ -52,8 +56,9 @@ def check_against_trace(app, tr):
         if rec.get("NN") is not None:                       # trans_matrix (V20:556-577)
             assert np.array_equal(app._nn[w], np.asarray(rec["NN"], np.int64)), f"trans_matrix at {pos}"
             n_stats[1] += 1
-        if "NM" in rec:                                     # get_optimal_primer_by_viterbi (V20:579-593), batched on the host
-            assert app._nm_all[w].tolist() == rec["NM"], f"Viterbi seed at {pos}"
+        if "NM" in rec:                                     # get_optimal_primer_by_viterbi (V20:579-593), native host stage
+            assert status[w] == 0
+            assert plan.seeds(w)[0].tolist() == rec["NM"], f"Viterbi seed at {pos}"
             n_stats[2] += 1
         for primer, F, R, perfect, _ in rec["mis"]:
             cand_w.append(w)
