@@ -1,23 +1,39 @@
 #!/usr/bin/env python3
 """Benchmark of the hot path: batched candidate x sequence coverage evaluation
-(mp_eval_launch -> eval_kernel) on a synthetic alignment shard per GPU (SURVEY §8d input 4 /
+(mp_eval_launch -> eval_chain_kernel) on a synthetic alignment shard per GPU (SURVEY §8d input 4 /
 BASELINE.json configs[3]: 1M x 1 kb sequences sharded over 8 GPUs = 131072 rows per GPU).
 
 One step = one pass of the evaluation over every window of the shard with C candidates per
 window, plus (N > 1) the RCCL all-reduce of the per-candidate coverage counters.  Inputs are
-resident in HBM (window words built once, untimed); weak scaling: the shard per GPU is fixed.
+resident in HBM (planes built once, untimed); weak scaling: the shard per GPU is fixed.
 
   python bench.py --gpus 1 --steps 20 --warmup 3
   python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
 
-Prints ONE JSON line on rank 0 (contract in the task statement), with `roofline` (algorithmic
-bytes 3k/8 per evaluation over the HIP-event kernel time, vs 8 TB/s) and `cpu_baseline` (the
-plain-C oracle on one host core, bounded sample, N=1 only).
+Prints ONE JSON line on rank 0 (contract in the task statement).  What the line carries beyond the contract:
+
+  roofline      every fraction is <= 1 by construction.  The kernel does not stream a k-mer per evaluation (8 nested
+                candidates share one pass over L2-resident one-hot planes), so HBM cannot bind it; the binding ceilings
+                are integer VALU issue and L2 reads.  `bound` names the largest of
+                  valu_frac = VALU wave-instructions per launch / (kernel time x SIMDs x measured issue rate)
+                  l2_frac   = bytes requested from L2 per launch / (kernel time x measured L2 read bandwidth)
+                  hbm_frac  = measured fabric/HBM bytes per launch (`traffic`) / (kernel time x 8 TB/s)
+                with instruction / request / byte counts from separate rocprofv3 --pmc passes of this same command
+                (profiles/r02_counters.json, written by tools/collect_counters.py — looked up by exact configuration)
+                and ceilings measured on the box by tools/ubench.hip (profiles/r02_ubench.json).  SURVEY §8d's
+                algorithmic figure (3k/8 bytes per evaluation / kernel time / 8 TB/s) is kept as `algorithmic_frac`,
+                labelled: it exceeds 1 and is NOT a roofline fraction.
+  variants      the same kernel library on less friendly candidate sets: unrelated candidates (no nesting), the
+                symbol-table kernel forced on the nested set, C = 1, and one cold launch (caches flushed, no warm-up).
+  cpu_baseline  the plain-C oracle on ALL host cores (threads over row blocks of the whole shard) and on one core
+                (bounded sample); its counters are compared with the GPU's, candidate by candidate —
+                `parity_checked` true, or the run exits non-zero.
 """
 import argparse
 import json
 import os
 import sys
+import threading
 import time
 
 import numpy as np
@@ -26,12 +42,15 @@ REPO = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, REPO)
 
 HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec (MI355X_MICROARCH.md); ~6300 GB/s achievable
+N_SIMD = 1024                  # 256 CUs x 4 SIMDs
+# measured ceilings (tools/ubench.hip on the same GPU pool, profiles/r02_ubench.json); used when that file is absent
+DEFAULT_CEILINGS = {"valu_wave_instr_per_s_per_simd": 8.5e8, "l2_read_GBs": 31559.0, "source": "built-in defaults (profiles/r02_ubench.json missing)"}
 
 
 KERNELS = {
     "chain": "eval_chain_kernel (bit-sliced one-hot column planes, nested refinement chains; patch rows ride in the same launch)",
     "table": "eval_bits_kernel (bit-sliced one-hot column planes, symbol table per position; patch rows ride in the same launch)",
-    "rows": "eval_kernel (row-per-lane window words)",
+    "rows": "eval_kernel (row-per-lane, window words derived from the planes)",
 }
 
 
@@ -44,40 +63,86 @@ def eval_mode():
     return "chain"
 
 
-def make_candidates(root_codes, p0, W, k, C, seed):
-    """C candidates per window: the root k-mer of the window, then progressively more degenerate
-    versions (one more random base at one more random position each), seeded per window — the
-    shape of a refinement chain (SURVEY §8d micro-benchmark)."""
+def make_candidates(root_codes, p0, W, k, C, seed, nested=True):
+    """C candidates per window.  nested: the root k-mer of the window, then progressively more degenerate versions (one
+    more random base at one more random position each), seeded per window — the shape of a refinement chain (SURVEY §8d
+    micro-benchmark).  not nested: C unrelated candidates — the root with ONE random extra base at a random position
+    each, so that no candidate accepts a subset of another's k-mers."""
     rng = np.random.default_rng(seed)
     cw = np.repeat(np.arange(W, dtype=np.int32), C)
     codes = np.empty((W, C, k), np.uint8)
-    cur = np.stack([root_codes[p0 + w: p0 + w + k] for w in range(W)]).astype(np.uint8)
+    root = np.stack([root_codes[p0 + w: p0 + w + k] for w in range(W)]).astype(np.uint8)
+    cur = root
     codes[:, 0] = cur
     for c in range(1, C):
-        pos = rng.integers(0, k, size=W)
+        pos = rng.integers(0, k, size=W) if nested else (rng.integers(0, k, size=W) + c) % k
         add = (1 << rng.integers(0, 4, size=W)).astype(np.uint8)
-        cur = cur.copy()
+        cur = (cur if nested else root).copy()
         cur[np.arange(W), pos] |= add
         codes[:, c] = cur
     return cw, codes.reshape(W * C, k)
 
 
 def expand_exceptions(ctx, n_ex, k, v):
-    from multiprime_amd import iupac
+    """IUPAC windows of the shard -> concrete extra rows (native expansion, reference order)."""
+    from multiprime_amd import host, iupac
     if not n_ex:
         return 0
     ew, er, ec = ctx.get_exceptions(n_ex)
-    raw = iupac.strings_of(iupac.SYMBOL_LUT[ec])
-    xw, xk = [], []
-    for w_, s in zip(ew.tolist(), raw):
-        if s.count("-") <= v:
-            for e in iupac.expand(s):
-                xw.append(w_)
-                xk.append(e)
-    if xw:
-        chars = np.frombuffer("".join(xk).encode(), np.uint8).reshape(len(xk), k)
-        ctx.set_extra_rows(np.asarray(xw, np.int32), iupac.words_of_kmers(chars))
-    return len(xw)
+    sel = (ec == 0).sum(axis=1) <= v
+    if not sel.any():
+        return 0
+    exp, src = host.expand_kmers(ec[sel])
+    ctx.set_extra_rows(ew[sel][src], iupac.words_of_codes(exp))
+    return len(exp)
+
+
+def load_json(name):
+    try:
+        with open(os.path.join(REPO, "profiles", name)) as f:
+            return json.load(f)
+    except (OSError, ValueError):
+        return None
+
+
+def ceilings():
+    ub = load_json("r02_ubench.json")
+    if not ub:
+        return dict(DEFAULT_CEILINGS)
+    try:
+        valu = max(r["wave_instr_per_s_per_simd"] for r in ub["valu"] if r["op"] in ("v_bitop3_b32", "v_add_u32", "v_xor_b32"))
+        l2 = max(r["GBs"] for r in ub["reads"] if r["case"].startswith("l2_"))
+        hbm = max(r["GBs"] for r in ub["reads"] if r["case"].startswith("hbm"))
+        return {"valu_wave_instr_per_s_per_simd": valu, "l2_read_GBs": l2, "hbm_read_GBs_measured": hbm,
+                "source": "profiles/r02_ubench.json (tools/ubench.hip: saturated v_bitop3/v_add issue rate, 8 waves per SIMD; L2-resident dwordx4 reads)"}
+    except (KeyError, ValueError):
+        return dict(DEFAULT_CEILINGS)
+
+
+def counters_for(cfg):
+    """PMC counters per launch of the timed kernel for exactly this configuration, or None."""
+    db = load_json("r02_counters.json")
+    if not db:
+        return None
+    for e in db.get("entries", []):
+        if all(e.get(key) == val for key, val in cfg.items()):
+            return e
+    return None
+
+
+def time_launches(ctx, torch, out_ptr, n, warm):
+    """Median / max / mean HIP-event duration (ms) of n launches of the staged candidate set (every launch timed)."""
+    for _ in range(warm):
+        ctx.eval_launch(out_ptr)
+    torch.cuda.synchronize()
+    ctx.eval_timing(reset=True)
+    for _ in range(n):
+        ctx.eval_launch(out_ptr)
+    torch.cuda.synchronize()
+    ms, cnt = ctx.eval_timing(reset=True)
+    s = np.sort(ctx.eval_timing_samples())
+    return {"mean_ms": ms / max(cnt, 1), "median_ms": float(s[len(s) // 2]) if len(s) else None,
+            "max_ms": float(s[-1]) if len(s) else None, "launches": cnt}
 
 
 def main():
@@ -91,14 +156,15 @@ def main():
     ap.add_argument("--v", type=int, default=1)
     ap.add_argument("--cands", type=int, default=8, help="candidates per window")
     ap.add_argument("--seed", type=int, default=20250303)
-    ap.add_argument("--cpu-rows", type=int, default=131072, help="rows of the shard timed on the CPU oracle (~13 s for the whole shard)")
+    ap.add_argument("--cpu-rows", type=int, default=0, help="rows of the shard the CPU oracle evaluates (0 = the whole shard)")
+    ap.add_argument("--cpu-threads", type=int, default=0, help="host threads of the all-core CPU leg (0 = every core, at most 64)")
     ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--no-variants", action="store_true")
     ap.add_argument("--bucket", type=int, default=4, help="steps whose counters share one all-reduce (N > 1)")
     a = ap.parse_args()
 
     import torch
     import torch.distributed as dist
-    from multiprime_amd import iupac
     from multiprime_amd._abi import Library
     from multiprime_amd.synth import synth_block, synth_root
 
@@ -125,8 +191,8 @@ def main():
 
     k, v, C, L = a.k, a.v, a.cands, a.cols
     # the library brackets every n-th mp_eval_launch with a HIP-event pair on its stream (live kernel time for the
-    # roofline); a pair idles the stream for ~6 us, so the bench samples one launch in four
-    os.environ.setdefault("MP_EVAL_TIMING_EVERY", "4")
+    # roofline); a pair idles the stream for ~6 us, so the timed region samples one launch in four
+    every = int(os.environ.setdefault("MP_EVAL_TIMING_EVERY", "4"))
     t_setup = time.time()
     lib = Library()                                   # the HIP library or an error: no fallback
     ctx = lib.context(local)
@@ -155,35 +221,55 @@ def main():
     # (xGMI rings are latency-bound at 180 KB per step), on RCCL's stream, while the next bucket's steps evaluate
     # into the other buffer.  Every step's counters are reduced; all reductions complete inside the timed region.
     from multiprime_amd.dist import StepBuckets
-    sb = StepBuckets(n_cand, a.bucket, dev, world)
 
-    def step():
-        ctx.eval_launch(sb.begin_step().data_ptr())
-        sb.end_step()
+    def timed_region(bucket):
+        sb = StepBuckets(n_cand, bucket, dev, world)
 
-    drain = sb.drain
+        def step():
+            ctx.eval_launch(sb.begin_step().data_ptr())
+            sb.end_step()
 
-    for _ in range(a.warmup):
-        step()
-    drain()
-    ctx.eval_timing(reset=True)
-    torch.cuda.synchronize()
+        for _ in range(a.warmup):
+            step()
+        sb.drain()
+        ctx.eval_timing(reset=True)
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(a.steps):
+            step()
+        sb.drain()
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        kern_ms, kern_n = ctx.eval_timing(reset=True)
+        samples = np.sort(ctx.eval_timing_samples())
+        tt = torch.tensor([dt], dtype=torch.float64, device=dev)
+        if world > 1:
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        return float(tt.item()), kern_ms, kern_n, samples, sb
+
+    elapsed, kern_ms, kern_n, samples, sb = timed_region(a.bucket)
+    gpu_counters = sb.block_of(a.steps - 1).cpu().numpy().copy()       # [n_cand][3], summed over ranks when N > 1
+    # N > 1: the same K steps with ONE collective per step (the drop-in pipeline reduces once per alignment), for comparison
+    unbucketed = None
+    if world > 1 and a.bucket != 1:
+        e1, *_ = timed_region(1)
+        unbucketed = e1
+
+    ev = torch.tensor([evals_local], dtype=torch.int64, device=dev)
     if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(a.steps):
-        step()
-    drain()
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    elapsed = time.perf_counter() - t0
-    kern_ms, kern_n = ctx.eval_timing(reset=True)
+        dist.all_reduce(ev, op=dist.ReduceOp.SUM)
+    evals_total = int(ev.item())
+    checksum = gpu_counters.sum(axis=0).tolist()
 
     # measured device-copy bandwidth (SURVEY §8d asks for it next to the spec peak): 1 GiB d2d, read + write
     copy_gbs = None
+    variants = None
     if rank == 0:
         src = torch.empty(1 << 28, dtype=torch.float32, device=dev)
         dst = torch.empty_like(src)
@@ -195,29 +281,37 @@ def main():
         e1.record()
         torch.cuda.synchronize()
         copy_gbs = 5 * 2 * src.numel() * 4 / (e0.elapsed_time(e1) * 1e-3) / 1e9
+        if world == 1 and not a.no_variants:
+            variants = run_variants(ctx, torch, dev, src, dst, root_codes, p0, W, k, C, a.seed, sF, sR, universe, cw, codes, n_cand)
         del src, dst
 
-    tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-    ev = torch.tensor([evals_local], dtype=torch.int64, device=dev)
-    if world > 1:
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        dist.all_reduce(ev, op=dist.ReduceOp.SUM)
-    elapsed = float(tt.item())
-    evals_total = int(ev.item())
-    checksum = sb.block_of(a.steps - 1).sum(dim=0).tolist()
-
     if rank == 0:
-        traffic = None
-        try:     # measured in a separate PMC pass of this same command; reported only on an exact config match
-            for e in json.load(open(os.path.join(REPO, "profiles", "hbm_traffic.json")))["entries"]:
-                if (e["rows"], e["cols"], e["k"], e["v"], e["cands"], e.get("mode")) == (a.rows, L, k, v, C, eval_mode()):
-                    traffic = e["traffic_bytes"]
-                    break
-        except (OSError, KeyError, ValueError):
-            pass
         per_launch_ms = kern_ms / max(kern_n, 1)
+        kern_s = per_launch_ms * 1e-3
         alg_bytes = evals_local * 3 * k / 8.0         # 3k/8 bytes per evaluation
-        achieved = alg_bytes / (per_launch_ms * 1e-3) / 1e9
+        ceil = ceilings()
+        cfg = {"rows": a.rows, "cols": L, "k": k, "v": v, "cands": C, "mode": eval_mode()}
+        pmc = counters_for(cfg)
+        fr = {"valu": None, "l2": None, "hbm": None}
+        traffic = None
+        if pmc:
+            if pmc.get("valu_insts"):
+                fr["valu"] = pmc["valu_insts"] / (kern_s * N_SIMD * ceil["valu_wave_instr_per_s_per_simd"])
+            if pmc.get("l2_read_bytes"):
+                fr["l2"] = pmc["l2_read_bytes"] / kern_s / 1e9 / ceil["l2_read_GBs"]
+            if pmc.get("hbm_read_bytes") is not None:
+                traffic = pmc["hbm_read_bytes"] + (pmc.get("hbm_write_bytes") or 0)
+                fr["hbm"] = traffic / kern_s / 1e9 / HBM_PEAK_GBS
+        known = {key: val for key, val in fr.items() if val is not None}
+        bound = max(known, key=known.get) if known else "valu"
+        if bound == "valu" and pmc:
+            achieved, peak, unit = pmc["valu_insts"] / kern_s / 1e9, N_SIMD * ceil["valu_wave_instr_per_s_per_simd"] / 1e9, "G wave-instr/s"
+        elif bound == "l2" and pmc:
+            achieved, peak, unit = pmc["l2_read_bytes"] / kern_s / 1e9, ceil["l2_read_GBs"], "GB/s"
+        elif bound == "hbm" and pmc:
+            achieved, peak, unit = traffic / kern_s / 1e9, HBM_PEAK_GBS, "GB/s"
+        else:
+            achieved, peak, unit = None, None, None
         res = {
             "metric": "candidate x sequence coverage evals/s",
             "value": evals_total * a.steps / elapsed,
@@ -231,41 +325,135 @@ def main():
                        "rows_per_gpu": a.rows, "cols": L, "k": k, "variation": v, "candidates_per_window": C,
                        "windows": W, "evals_per_step_per_gpu": evals_local, "iupac_extra_rows": n_extra,
                        "parallelism": f"row shards x{world}, RCCL all-reduce of every step's [{n_cand}x3] int64 counters, {sb.B} steps per collective, overlapped with the next bucket"},
-            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "algorithmic_bytes": alg_bytes,
-                         "kernel": KERNELS[eval_mode()] + "; timed region = counter memset + kernel", "eval_mode": eval_mode(), "kernel_ms": per_launch_ms, "launches_timed": kern_n, "timed_every": int(os.environ["MP_EVAL_TIMING_EVERY"]),
-                         "algorithmic_bytes_per_eval": 3 * k / 8.0},
+            "roofline": {"bound": bound, "achieved": achieved, "peak": peak, "unit": unit,
+                         "frac": known.get(bound), "traffic": traffic,
+                         "valu_frac": fr["valu"], "l2_frac": fr["l2"], "hbm_frac": fr["hbm"],
+                         "algorithmic_frac": alg_bytes / kern_s / 1e9 / HBM_PEAK_GBS,
+                         "algorithmic_note": "SURVEY 8d figure: 3k/8 bytes per evaluation over the kernel time vs 8 TB/s; exceeds 1 because 8 nested candidates share "
+                                             "one pass over L2-resident planes — NOT a roofline fraction, kept for comparison with round 1",
+                         "algorithmic_bytes": alg_bytes, "algorithmic_bytes_per_eval": 3 * k / 8.0,
+                         "counters": pmc, "ceilings": ceil,
+                         "kernel": KERNELS[eval_mode()] + "; timed region = counter memset + kernel", "eval_mode": eval_mode(),
+                         "kernel_ms": per_launch_ms, "kernel_ms_median": float(samples[len(samples) // 2]) if len(samples) else None,
+                         "kernel_ms_max": float(samples[-1]) if len(samples) else None,
+                         "launches_timed": kern_n, "timed_every": every},
+            "variants": variants,
             "measured_copy_GBs": copy_gbs, "setup_s": setup_s, "device_bytes": ctx.device_bytes(), "counter_checksum": checksum,
         }
+        if unbucketed is not None:
+            res["ms_per_step_one_collective_per_step"] = unbucketed / a.steps * 1e3
         if world == 1 and not a.no_cpu:
-            res["cpu_baseline"] = cpu_baseline(rows[: a.cpu_rows], L, p0, W, k, v, cw, codes, sF, sR, C)
+            n_cpu = a.cpu_rows or a.rows
+            res["cpu_baseline"] = cpu_baseline(rows[:n_cpu], L, p0, W, k, v, cw, codes, sF, sR, C, a.cpu_threads,
+                                               gpu_counters if n_cpu == a.rows else None)
+            res["parity_checked"] = res["cpu_baseline"].get("parity_checked")
         print(json.dumps(res), flush=True)
+        if res.get("parity_checked") is False:
+            raise SystemExit("bench.py: GPU counters differ from the CPU oracle's")
     if world > 1:
         dist.destroy_process_group()
 
 
-def cpu_baseline(rows, L, p0, W, k, v, cw, codes, sF, sR, C):
-    """The oracle (plain-C restatement of the reference, one thread) on a bounded sample of the
-    same workload: the first `cpu_rows` sequences of rank 0's shard, same windows and candidates.
-    This is the only place bench.py touches oracle/."""
+def run_variants(ctx, torch, dev, scratch_a, scratch_b, root_codes, p0, W, k, C, seed, sF, sR, universe, cw, codes, n_cand):
+    """The evaluation library on less friendly inputs (every launch timed with HIP events, 20 launches after 3 warm-ups)."""
+    os.environ["MP_EVAL_TIMING_EVERY"] = "1"
+    total = int(universe.sum())
+    out = {}
+
+    def measure(name, cand_w, cand_codes, c_per_window, note):
+        ctx.eval_upload(cand_w, cand_codes, sF, sR)
+        buf = torch.zeros((len(cand_w), 3), dtype=torch.int64, device=dev)
+        t = time_launches(ctx, torch, buf.data_ptr(), 20, 3)
+        evals = total * c_per_window
+        out[name] = {"evals_per_s": evals / (t["mean_ms"] * 1e-3), "kernel_ms": t["mean_ms"], "kernel_ms_median": t["median_ms"],
+                     "kernel_ms_max": t["max_ms"], "candidates_per_window": c_per_window, "what": note}
+
+    uw, ucodes = make_candidates(root_codes, p0, W, k, C, seed + 1, nested=False)
+    measure("unrelated_candidates", uw, ucodes, C, f"{C} candidates per window that are NOT a refinement chain (root + one extra base each): symbol-table kernel")
+    os.environ["MP_EVAL_GROUP"] = "plain"
+    measure("nested_on_table_kernel", cw, codes, C, "the headline candidates with chain detection off (MP_EVAL_GROUP=plain): symbol-table kernel")
+    del os.environ["MP_EVAL_GROUP"]
+    measure("c1", cw[::C].copy(), codes[::C].copy(), 1, "one candidate per window (the root k-mer)")
+    # cold: one launch of the headline set with L2 / Infinity Cache flushed by a 2 GiB device copy, no warm-up
+    ctx.eval_upload(cw, codes, sF, sR)
+    buf = torch.zeros((n_cand, 3), dtype=torch.int64, device=dev)
+    colds = []
+    for _ in range(3):
+        scratch_b.copy_(scratch_a)
+        torch.cuda.synchronize()
+        ctx.eval_timing(reset=True)
+        ctx.eval_launch(buf.data_ptr())
+        torch.cuda.synchronize()
+        ms, _ = ctx.eval_timing(reset=True)
+        colds.append(ms)
+    out["cold_single_launch"] = {"kernel_ms": colds, "evals_per_s": total * C / (min(colds) * 1e-3),
+                                 "what": "headline candidates, ONE launch right after a 2 GiB device copy (planes come from HBM, not from L2 / Infinity Cache), best of 3 listed"}
+    os.environ["MP_EVAL_TIMING_EVERY"] = "4"
+    return out
+
+
+def cpu_baseline(rows, L, p0, W, k, v, cw, codes, sF, sR, C, n_threads, gpu_counters):
+    """The oracle (plain-C restatement of the reference) on the host cores: all cores over row blocks of the sample
+    (the C call releases the GIL, one oracle context per thread) and one core on a bounded sub-sample.  When the sample is
+    the whole shard its summed counters are compared with the GPU's.  This is the only place bench.py touches oracle/."""
     from multiprime_amd._abi import Library
     so = os.path.join(REPO, "oracle", "_build", "libmprime_oracle.so")
     if not os.path.exists(so):
-        return {"value": None, "unit": "evals/s", "cores": 1, "kind": "port", "sample": "oracle library not built"}
-    ora = Library(so).context(0)
+        return {"value": None, "unit": "evals/s", "cores": 0, "kind": "port", "sample": "oracle library not built", "parity_checked": None}
+    lib = Library(so)
     n = rows.shape[0]
-    ora.load_msa(rows.reshape(-1), np.arange(n + 1, dtype=np.int64) * L)
+    cores = os.cpu_count() or 1
+    T = n_threads or min(cores, 64)
+    T = max(1, min(T, n // 256))
+    bounds = [n * t // T for t in range(T + 1)]
+    results = [None] * T
+    universe = [0] * T
+
+    def work(t):
+        blk = rows[bounds[t]:bounds[t + 1]]
+        ora = lib.context(0)
+        ora.load_msa(blk.reshape(-1), np.arange(blk.shape[0] + 1, dtype=np.int64) * L)
+        n_ex = ora.build_windows(p0, W, k, v)
+        expand_exceptions(ora, n_ex, k, v)
+        alln = ora.eval_candidates(np.arange(W, dtype=np.int32), np.full((W, k), 15, np.uint8), 0, 0)
+        universe[t] = int((alln[:, 0] + alln[:, 1]).sum())
+        t0 = time.perf_counter()
+        results[t] = ora.eval_candidates(cw, codes, sF, sR)
+        return time.perf_counter() - t0
+
+    # all cores: wall time of the evaluation calls only (loading / window building of the oracle contexts is untimed, as on the GPU)
+    spans = [0.0] * T
+    th = [threading.Thread(target=lambda t=t: spans.__setitem__(t, work(t))) for t in range(T)]
+    t0 = time.perf_counter()
+    for x in th:
+        x.start()
+    for x in th:
+        x.join()
+    wall_all = time.perf_counter() - t0
+    evals = sum(universe) * C
+    eval_wall = max(spans)
+    total = np.sum(results, axis=0)
+    parity = None
+    if gpu_counters is not None:
+        parity = bool(np.array_equal(total, gpu_counters))
+    # one core: a bounded sub-sample (first rows), ~1/T of the work above
+    n1 = max(256, min(n, 8192))
+    ora = lib.context(0)
+    ora.load_msa(rows[:n1].reshape(-1), np.arange(n1 + 1, dtype=np.int64) * L)
     n_ex = ora.build_windows(p0, W, k, v)
     expand_exceptions(ora, n_ex, k, v)
     alln = ora.eval_candidates(np.arange(W, dtype=np.int32), np.full((W, k), 15, np.uint8), 0, 0)
-    evals = int((alln[:, 0] + alln[:, 1]).sum()) * C
+    ev1 = int((alln[:, 0] + alln[:, 1]).sum()) * C
     t0 = time.perf_counter()
     ora.eval_candidates(cw, codes, sF, sR)
-    dt = time.perf_counter() - t0
-    return {"value": evals / dt, "unit": "evals/s", "cores": 1, "kind": "port",
-            "sample": f"first {n} sequences of the shard, all {W} windows x {C} candidates, {evals} evals in {dt:.1f} s "
-                      f"(oracle/mprime_oracle.c, 1 thread; the Python reference itself measures 2-3e5 evals/s "
-                      f"inside mis_primer_check, BASELINE.md)"}
+    dt1 = time.perf_counter() - t0
+    return {"value": evals / eval_wall, "unit": "evals/s", "cores": T, "kind": "port", "host_cores": cores,
+            "sample": f"all {n} sequences of the shard, all {W} windows x {C} candidates = {evals} evals on {T} threads in {eval_wall:.2f} s "
+                      f"(oracle/mprime_oracle.c; {wall_all:.1f} s incl. building the oracle's own tables); the Python reference itself "
+                      f"measures 2-3e5 evals/s inside mis_primer_check on one core (BASELINE.md)",
+            "one_core": {"value": ev1 / dt1, "cores": 1, "sample": f"first {n1} sequences, {ev1} evals in {dt1:.2f} s"},
+            "parity_checked": parity,
+            "parity_note": "per candidate, all three counters, GPU == sum of the oracle's row blocks" if parity is not None else "sample is not the whole shard: no comparison"}
 
 
 if __name__ == "__main__":

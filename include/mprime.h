@@ -162,6 +162,9 @@ int mp_eval_launch(mp_ctx *ctx, int64_t *device_out);
  * launch is timed unless the environment says MP_EVAL_TIMING_EVERY=n (every n-th launch counted
  * from the reset, 0 = none): an event pair idles the stream for a few microseconds. */
 int mp_eval_timing(mp_ctx *ctx, int32_t reset, double *total_ms, int32_t *n_launches);
+/* The individual durations (milliseconds) behind the totals of the LAST mp_eval_timing call, at most 4096 since its
+ * reset: *n returns how many there are, the first min(*n, cap) are written (median / maximum for bench.py). */
+int mp_eval_timing_samples(mp_ctx *ctx, int32_t cap, float *ms, int32_t *n);
 
 /* (5) 3'-end dimer scan — SURVEY §8a rows D and M ------------------------------------------- */
 /* Replaces the search loops of Dimer.dimer_check (scripts/finDimer_V4.py:191-224) and of

@@ -43,6 +43,7 @@ SYMBOLS = [
     ("mp_eval_upload", C.c_int, [_p, C.c_int32, _p, _p, C.c_uint32, C.c_uint32]),
     ("mp_eval_launch", C.c_int, [_p, _p]),
     ("mp_eval_timing", C.c_int, [_p, C.c_int32, C.POINTER(C.c_double), C.POINTER(C.c_int32)]),
+    ("mp_eval_timing_samples", C.c_int, [_p, C.c_int32, _p, C.POINTER(C.c_int32)]),
     ("mp_dimer_scan", C.c_int, [_p, C.c_int32, _p, _p, C.c_int32, C.c_int32, _p, _p, C.c_double, C.c_int64, _p,
                                 C.POINTER(C.c_int64)]),
     ("mp_dimer_pairs", C.c_int, [_p, C.c_int32, _p, _p, C.c_int64, _p, _p, _p, C.c_double, _p]),
@@ -239,6 +240,13 @@ class Context:
         ms, n = C.c_double(0), C.c_int32(0)
         self._ck(self.d.mp_eval_timing(self.h, int(reset), C.byref(ms), C.byref(n)))
         return ms.value, n.value
+
+    def eval_timing_samples(self) -> np.ndarray:
+        """Durations (ms) of the timed launches behind the last eval_timing() call."""
+        n = C.c_int32(0)
+        buf = np.zeros(4096, np.float32)
+        self._ck(self.d.mp_eval_timing_samples(self.h, 4096, _ptr(buf), C.byref(n)))
+        return buf[: min(n.value, 4096)].copy()
 
     # (5)
     def dimer_scan(self, codes: np.ndarray, off: np.ndarray, mode: int, n_new: int, loss_hit: np.ndarray,

@@ -24,6 +24,9 @@ void free_unique(mp_ctx *c) {
     dev_free(c, &c->labels, W * c->n_pad);
     dev_free(c, &c->u_over, W); dev_free(c, &c->u_wcount, W); dev_free(c, &c->u_wbase, W);
     dev_free(c, &c->u_total, 1);
+    dev_free(c, &c->g_key, W * (size_t)c->g_slots); dev_free(c, &c->g_cnt, W * (size_t)c->g_slots);
+    dev_free(c, &c->g_min, W * (size_t)c->g_slots); dev_free(c, &c->g_idx, W * (size_t)c->g_slots);
+    c->g_slots = 0;
     c->u_cap = c->u_n = 0;
     c->h_wbase.clear(); c->h_wcount.clear();
 }
@@ -31,7 +34,6 @@ void free_unique(mp_ctx *c) {
 void free_windows(mp_ctx *c) {
     free_eval(c);
     free_unique(c);
-    if (c->win) { (void)hipFree(c->win); c->bytes -= (int64_t)c->win_bytes; c->win = nullptr; c->win_bytes = 0; }
     dev_free(c, &c->excl, (size_t)c->n_win * (c->n_pad / 64));
     dev_free(c, &c->patch_count, (size_t)c->n_win);
     dev_free(c, &c->patch_off, (size_t)c->n_win + 1);
@@ -55,7 +57,7 @@ void free_msa(mp_ctx *c) {
     dev_free(c, &c->planes, (size_t)c->n_chunks * 4 * np);
     dev_free(c, &c->cols, (size_t)c->n_chunks * 32 * 4 * (np / 64));
     dev_free(c, &c->cum, ((size_t)c->n_chunks + 1) * np);
-    dev_free(c, &c->ung, (size_t)c->n_rows * c->ustride);
+    dev_free(c, &c->ung, np * c->ustride);
     dev_free(c, &c->lead, np); dev_free(c, &c->rstrip, np); dev_free(c, &c->rlen, np);
     c->n_rows = c->n_pad = c->n_chunks = 0;
 }

@@ -6,11 +6,11 @@
 //                                     per word, sequences along the fastest axis (coalesced per wave)
 //   cols    [L][4][Npad/64] u64       column planes A,C,G,T (one-hot, gap = none) — one bit per sequence — for the bit-sliced evaluation
 //   cum     [n_chunks+1][Npad] u32    residues (non-gap symbols) left of each 32-column chunk
-//   ung     [N][ustride] u32          gap-free residue codes, 8 nibbles per word (edge-gap repair only)
-//   win     the k-mer of every (window, sequence) after repair, 3 bits per symbol:
-//             k <= 21: [W][Npad] u64       b0 | b1 << k | g << 2k, bit 63 = not in the universe
-//             k >= 22: [W][3][Npad] u32    b0,b1 (2-bit base) and g (gap flag) words
-//   excl / patch list, histogram entries, labels: see windows.hip / unique.hip
+//   ung     [ustride][Npad] u32       gap-free residue codes, 8 nibbles per word, word-major so that a wave's stores and
+//                                     loads of one word index coalesce (edge-gap repair only)
+//   The k-mer of a (window, sequence) pair ("window words" b0,b1,g) is never stored: every consumer derives it from
+//   the planes on the fly (winwords.hpp) — round 1 kept a [W][Npad] u64 array of them (1 GB at the bench shard).
+//   excl / patch list, histogram tables and entries, labels: see windows.hip / unique.hip
 // Translation units: pack.hip (mp_load_msa), windows.hip (mp_build_windows), unique.hip (histograms),
 // eval.hip (candidate x sequence evaluation), dimer.hip (3'-end dimer scan, pair coverage), api.hip.
 // No MFMA anywhere: this is bit-mask work bounded by integer ALU / HBM.  gfx950 only.
@@ -63,72 +63,6 @@ struct Nib {          // up to 32 symbol codes, one nibble each
     }
 };
 
-// ----------------------------------------------------------------------------------------------
-// window words in HBM: one packed u64 per (window, sequence) when 3k <= 63, else three u32 planes
-// ----------------------------------------------------------------------------------------------
-template <bool P64>
-struct WinView;
-
-template <>
-struct WinView<false> {
-    const uint32_t *W0, *W1, *W2;
-    __device__ WinView(const void *base, int w, size_t np, int, uint32_t)
-        : W0((const uint32_t *)base + (size_t)w * 3 * np), W1(W0 + np), W2(W1 + np) {}
-    __device__ inline void load(int r, uint32_t &b0, uint32_t &b1, uint32_t &g) const { b0 = W0[r]; b1 = W1[r]; g = W2[r]; }
-    struct Raw4 { uint4 a, b, c; };
-    __device__ inline Raw4 load4(int r) const {
-        Raw4 q;
-        q.a = *reinterpret_cast<const uint4 *>(W0 + r);
-        q.b = *reinterpret_cast<const uint4 *>(W1 + r);
-        q.c = *reinterpret_cast<const uint4 *>(W2 + r);
-        return q;
-    }
-    __device__ inline void unpack(const Raw4 &q, int i, uint32_t &b0, uint32_t &b1, uint32_t &g) const {
-        b0 = i == 0 ? q.a.x : i == 1 ? q.a.y : i == 2 ? q.a.z : q.a.w;
-        b1 = i == 0 ? q.b.x : i == 1 ? q.b.y : i == 2 ? q.b.z : q.b.w;
-        g = i == 0 ? q.c.x : i == 1 ? q.c.y : i == 2 ? q.c.z : q.c.w;
-    }
-    __device__ static inline void store(void *base, int w, size_t np, int r, uint32_t b0, uint32_t b1, uint32_t g, int, uint32_t) {
-        uint32_t *W = (uint32_t *)base + (size_t)w * 3 * np + r;
-        W[0] = b0; W[np] = b1; W[2 * np] = g;
-    }
-};
-
-template <>
-struct WinView<true> {
-    const uint64_t *Wp;
-    int k;
-    uint32_t kmask;
-    __device__ WinView(const void *base, int w, size_t np, int k_, uint32_t kmask_)
-        : Wp((const uint64_t *)base + (size_t)w * np), k(k_), kmask(kmask_) {}
-    __device__ inline void split(uint64_t x, uint32_t &b0, uint32_t &b1, uint32_t &g) const {
-        b0 = (uint32_t)x & kmask;
-        b1 = (uint32_t)(x >> k) & kmask;
-        g = ((uint32_t)(x >> (2 * k)) & kmask) | ((uint32_t)(x >> 32) & MP_WIN_SKIP);
-    }
-    __device__ inline void load(int r, uint32_t &b0, uint32_t &b1, uint32_t &g) const { split(Wp[r], b0, b1, g); }
-    struct Raw4 { uint4 a, b; };
-    __device__ inline Raw4 load4(int r) const {
-        Raw4 q;
-        q.a = *reinterpret_cast<const uint4 *>(Wp + r);
-        q.b = *reinterpret_cast<const uint4 *>(Wp + r + 2);
-        return q;
-    }
-    __device__ inline void unpack(const Raw4 &q, int i, uint32_t &b0, uint32_t &b1, uint32_t &g) const {
-        uint32_t lo = i == 0 ? q.a.x : i == 1 ? q.a.z : i == 2 ? q.b.x : q.b.z;
-        uint32_t hi = i == 0 ? q.a.y : i == 1 ? q.a.w : i == 2 ? q.b.y : q.b.w;
-        split(((uint64_t)hi << 32) | lo, b0, b1, g);
-    }
-    __device__ static inline void store(void *base, int w, size_t np, int r, uint32_t b0, uint32_t b1, uint32_t g, int k, uint32_t kmask) {
-        uint64_t x = (uint64_t)b0 | ((uint64_t)b1 << k) | ((uint64_t)(g & kmask) << (2 * k)) |
-                     ((uint64_t)(g & MP_WIN_SKIP) << 32);
-        ((uint64_t *)base)[(size_t)w * np + r] = x;
-    }
-};
-
-// thread = row, block = 256 rows x a tile of consecutive windows; the 32-column plane words slide
-// in registers, so every plane word is read once per tile.
-
 }  // namespace mp
 
 // ================================================================================================
@@ -147,13 +81,11 @@ struct mp_ctx {
     int32_t *lead = nullptr, *rstrip = nullptr, *rlen = nullptr;
     // windows
     int p0 = 0, n_win = 0, k = 0, v = 0;
-    void *win = nullptr;
-    unsigned long long *excl = nullptr;      // [W][n_pad/64]
+    unsigned long long *excl = nullptr;      // [W][n_pad/64]; non-null = windows are built
     int32_t *patch_count = nullptr, *patch_off = nullptr, *patch_cursor = nullptr;
     uint32_t *patch_words = nullptr;
     int n_patch = 0, max_patch = 0;
-    bool p64 = false;
-    size_t win_bytes = 0;
+    bool p64 = false;                        // 3k <= 63: histogram keys are one packed u64
     mp::ExRec *ex = nullptr;
     int ex_cap = 0;
     int *ex_count = nullptr, *err_flag = nullptr;
@@ -169,7 +101,11 @@ struct mp_ctx {
     size_t pp_words = 0, pv_words = 0;
     int max_npw = 0;                                     // widest window, in 32-row words
     bool pp_dirty = true;
-    // unique
+    // unique: global hash tables [W][g_slots] (k <= 21) behind the per-workgroup LDS tables
+    unsigned long long *g_key = nullptr;
+    uint32_t *g_cnt = nullptr, *g_min = nullptr;
+    int32_t *g_idx = nullptr;                // dense index of a slot's entry inside its window (labels)
+    int g_slots = 0;
     long long u_cap = 0, u_n = 0;
     uint32_t *u_b0 = nullptr, *u_b1 = nullptr, *u_g = nullptr;
     int32_t *u_count = nullptr, *u_first = nullptr, *labels = nullptr, *u_over = nullptr, *u_wcount = nullptr;
@@ -192,6 +128,7 @@ struct mp_ctx {
     int tmp_out_n = 0;
     std::vector<std::pair<hipEvent_t, hipEvent_t>> ev_busy, ev_free;
     double ev_ms = 0;
+    std::vector<float> ev_samples, ev_last;     // per-launch durations since the last reset / as of the last mp_eval_timing call
     int ev_n = 0;
     int eval_variant = 0;
 };

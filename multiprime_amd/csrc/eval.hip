@@ -6,6 +6,7 @@
 //   (4d) state_matrix / trans_matrix counts — window_stats_kernel
 //   per-sequence coverage masks — mask_rows_kernel
 #include "common.hpp"
+#include "winwords.hpp"
 
 using namespace mp;
 
@@ -26,7 +27,8 @@ namespace {
 __device__ inline uint32_t bfi(uint32_t s, uint32_t a, uint32_t b) { return (s & a) | (~s & b); }
 
 struct EvalArgs {
-    const void *win;
+    MsaArgs M;                  // window words are derived from the planes on the fly (winwords.hpp)
+    int p0;
     int n_pad, k;
     const EvalItem *items;
     const uint4 *cand_n;        // [padded cand] nA,nC,nG,nT
@@ -98,7 +100,15 @@ __device__ inline void eval_row(uint32_t b0, uint32_t b1, uint32_t g, const Eval
     }
 }
 
-template <int CC, int VMODE, int COUNT, bool PREFETCH, int FORM, bool P64>
+struct Raw4 { uint32_t b0[4], b1[4], g[4]; };
+__device__ inline Raw4 load4(const FlyView &V, int r) {
+    Raw4 q;
+#pragma unroll
+    for (int i = 0; i < 4; i++) V.load(r + i, q.b0[i], q.b1[i], q.g[i]);
+    return q;
+}
+
+template <int CC, int VMODE, int COUNT, bool PREFETCH, int FORM>
 __global__ __launch_bounds__(kBlock) void eval_kernel(const EvalArgs A) {
     __shared__ uint32_t s_acc[3 * CC];
     const EvalItem it = A.items[blockIdx.x];
@@ -117,29 +127,26 @@ __global__ __launch_bounds__(kBlock) void eval_kernel(const EvalArgs A) {
         }
     }
     if (threadIdx.x < 3 * CC) s_acc[threadIdx.x] = 0;
-    const size_t np = (size_t)A.n_pad;
-    const WinView<P64> V(A.win, it.win, np, A.k, A.kmask);
-    typedef typename WinView<P64>::Raw4 Raw4;
+    const FlyView V(A.M, A.p0 + it.win, A.k, A.kmask);
     const int r0 = blockIdx.y * A.rows_per_split;
     const int r1 = r0 + A.rows_per_split < A.n_pad ? r0 + A.rows_per_split : A.n_pad;
     // 4 consecutive sequences per lane and iteration, 16-byte loads (n_pad % 4 == 0)
     int r = r0 + threadIdx.x * 4;
     Raw4 cur;
-    if (PREFETCH && r < r1) cur = V.load4(r);
+    if (PREFETCH && r < r1) cur = load4(V, r);
 #pragma unroll 1
     while (r < r1) {
         const int rn = r + kBlock * 4;
         Raw4 now;
         if (PREFETCH) {
             now = cur;
-            if (rn < r1) cur = V.load4(rn);          // next group in flight while this one computes
+            if (rn < r1) cur = load4(V, rn);          // next group in flight while this one computes
         } else {
-            now = V.load4(r);
+            now = load4(V, r);
         }
 #pragma unroll
         for (int i = 0; i < 4; i++) {
-            uint32_t b0, b1, g;
-            V.unpack(now, i, b0, b1, g);
+            const uint32_t b0 = now.b0[i], b1 = now.b1[i], g = now.g[i];
             eval_row<CC, VMODE, COUNT, FORM>(b0, b1, g, A, nA, nC, nG, nT, acc);
         }
         r = rn;
@@ -981,13 +988,13 @@ __global__ __launch_bounds__(kBlock) void window_stats_kernel(const StatsArgs A)
 // Per-sequence coverage masks (mp_eval_masks): thread = sequence, the wave's 64 "not covered" bits
 // go out as one 64-bit word per candidate straight from the ballot (blocks are 64-row aligned), so
 // there are no atomics; works on the window words, i.e. after edge-gap repair, for any v.
-template <int CC, bool P64>
+template <int CC>
 __global__ __launch_bounds__(kBlock) void mask_rows_kernel(const EvalArgs A, int n_rows, unsigned long long *__restrict__ not_f,
                                                            unsigned long long *__restrict__ not_r) {
     const EvalItem it = A.items[blockIdx.x];
     const int r = blockIdx.y * kBlock + threadIdx.x;             // n_pad is a multiple of kBlock
     const size_t nw = (size_t)A.n_pad / 64;
-    const WinView<P64> V(A.win, it.win, (size_t)A.n_pad, A.k, A.kmask);
+    const FlyView V(A.M, A.p0 + it.win, A.k, A.kmask);
     uint32_t b0, b1, g;
     V.load(r, b0, b1, g);
     const bool skip = (g & MP_WIN_SKIP) || r >= n_rows;
@@ -1014,12 +1021,10 @@ typedef void (*EvalBitsFn)(const EvalBitsArgs);
 typedef void (*EvalChainFn)(const EvalChainArgs);
 
 typedef void (*EvalFn)(const EvalArgs);
-struct EvalVariant { const char *name; EvalFn fn[2][3]; };     // fn[P64][VMODE]
+struct EvalVariant { const char *name; EvalFn fn[3]; };     // fn[VMODE]
 #define EVAL_VARIANT(name, COUNT, PREFETCH, FORM)                                                         \
-    { name, { { eval_kernel<kEvalCC, 0, COUNT, PREFETCH, FORM, false>, eval_kernel<kEvalCC, 1, COUNT, PREFETCH, FORM, false>, \
-                eval_kernel<kEvalCC, 2, COUNT, PREFETCH, FORM, false> },                                   \
-              { eval_kernel<kEvalCC, 0, COUNT, PREFETCH, FORM, true>, eval_kernel<kEvalCC, 1, COUNT, PREFETCH, FORM, true>,   \
-                eval_kernel<kEvalCC, 2, COUNT, PREFETCH, FORM, true> } } }
+    { name, { eval_kernel<kEvalCC, 0, COUNT, PREFETCH, FORM>, eval_kernel<kEvalCC, 1, COUNT, PREFETCH, FORM>, \
+              eval_kernel<kEvalCC, 2, COUNT, PREFETCH, FORM> } }
 // variant 0 is the default; the others exist to be measured (tools/variant_bench.py, MP_EVAL_VARIANT)
 const EvalVariant kEvalVariants[] = {
     EVAL_VARIANT("ballot+prefetch/onehot", 1, true, 2),      // default: fastest measured (profiles/r01_variants.txt)
@@ -1086,7 +1091,7 @@ extern "C" {
 
 int mp_eval_upload(mp_ctx *c, int32_t n_cand, const int32_t *cw, const uint8_t *codes, uint32_t sF, uint32_t sR) {
     if (!c) return MP_ERR_ARG;
-    if (!c->win) return fail(c, MP_ERR_ARG, "no windows built");
+    if (!c->excl) return fail(c, MP_ERR_ARG, "no windows built");
     if (n_cand < 0 || (n_cand && (!cw || !codes))) return fail(c, MP_ERR_ARG, "bad arguments");
     HIPCK(c, hipSetDevice(c->dev));
     free_eval(c);
@@ -1249,7 +1254,7 @@ int mp_eval_upload(mp_ctx *c, int32_t n_cand, const int32_t *cw, const uint8_t *
 
 int mp_eval_launch(mp_ctx *c, int64_t *device_out) {
     if (!c) return MP_ERR_ARG;
-    if (!c->win) return fail(c, MP_ERR_ARG, "no windows built");
+    if (!c->excl) return fail(c, MP_ERR_ARG, "no windows built");
     if (!device_out) return fail(c, MP_ERR_ARG, "null output");
     HIPCK(c, hipSetDevice(c->dev));
     if (c->n_cand == 0) return MP_OK;
@@ -1332,12 +1337,12 @@ int mp_eval_launch(mp_ctx *c, int64_t *device_out) {
             hipLaunchKernelGGL(tfn[c->v][shape == 1 ? 1 : 0], dim3(grid + (unsigned)ba.patch.n_blocks), dim3(kBlock), 0, c->stream, ba);
         }
     } else {
-    EvalArgs ea{c->win, c->n_pad, c->k, c->items, c->cand_n, c->cand_out, c->n_extra ? c->extra_off : (const int32_t *)nullptr,
+    EvalArgs ea{msa_args(c), c->p0, c->n_pad, c->k, c->items, c->cand_n, c->cand_out, c->n_extra ? c->extra_off : (const int32_t *)nullptr,
                 c->extra_words, c->sF, c->sR, c->v, (1u << c->k) - 1u, rows, (unsigned long long *)device_out};
     int variant = c->eval_variant;
     if (const char *e = getenv("MP_EVAL_VARIANT")) variant = atoi(e);
     if (variant < 0 || variant >= kNumEvalVariants) variant = 0;
-    hipLaunchKernelGGL(kEvalVariants[variant].fn[c->p64 ? 1 : 0][getenv("MP_EVAL_GENERIC_V") ? 2 : vmode], dim3((unsigned)c->n_items, (unsigned)split),
+    hipLaunchKernelGGL(kEvalVariants[variant].fn[getenv("MP_EVAL_GENERIC_V") ? 2 : vmode], dim3((unsigned)c->n_items, (unsigned)split),
                        dim3(kBlock), 0, c->stream, ea);
     }
     if (timed) {
@@ -1357,18 +1362,27 @@ int mp_eval_timing(mp_ctx *c, int32_t reset, double *total_ms, int32_t *n_launch
         HIPCK(c, hipEventElapsedTime(&ms, p.first, p.second));
         c->ev_ms += ms;
         c->ev_n++;
+        if (c->ev_samples.size() < 4096) c->ev_samples.push_back(ms);
         c->ev_free.push_back(p);
     }
     c->ev_busy.clear();
     if (total_ms) *total_ms = c->ev_ms;
     if (n_launches) *n_launches = c->ev_n;
-    if (reset) { c->ev_ms = 0; c->ev_n = 0; c->launch_seq = 0; }      // the first launch after a reset is a timed one
+    c->ev_last = c->ev_samples;
+    if (reset) { c->ev_ms = 0; c->ev_n = 0; c->launch_seq = 0; c->ev_samples.clear(); }      // the first launch after a reset is a timed one
+    return MP_OK;
+}
+
+int mp_eval_timing_samples(mp_ctx *c, int32_t cap, float *ms, int32_t *n) {
+    if (!c || !n) return MP_ERR_ARG;
+    *n = (int32_t)c->ev_last.size();
+    if (ms) for (int i = 0; i < *n && i < cap; i++) ms[i] = c->ev_last[(size_t)i];
     return MP_OK;
 }
 
 int mp_window_stats(mp_ctx *c, int64_t *freq, int64_t *nn) {
     if (!c) return MP_ERR_ARG;
-    if (!c->win) return fail(c, MP_ERR_ARG, "no windows built");
+    if (!c->excl) return fail(c, MP_ERR_ARG, "no windows built");
     if (!freq || !nn) return fail(c, MP_ERR_ARG, "null output");
     HIPCK(c, hipSetDevice(c->dev));
     const size_t W = (size_t)c->n_win, k = (size_t)c->k;
@@ -1431,11 +1445,10 @@ int mp_eval_masks(mp_ctx *c, int32_t n_cand, const int32_t *cw, const uint8_t *c
     unsigned long long *d_f = nullptr, *d_r = nullptr;
     if ((rc = dev_alloc(c, &d_f, (size_t)n_cand * nw))) return rc;
     if ((rc = dev_alloc(c, &d_r, (size_t)n_cand * nw))) return rc;
-    EvalArgs ea{c->win, c->n_pad, c->k, c->items, c->cand_n, c->cand_out, nullptr, nullptr, c->sF, c->sR, c->v,
+    EvalArgs ea{msa_args(c), c->p0, c->n_pad, c->k, c->items, c->cand_n, c->cand_out, nullptr, nullptr, c->sF, c->sR, c->v,
                 (1u << c->k) - 1u, 0, nullptr};
     const dim3 grid((unsigned)c->n_items, (unsigned)(c->n_pad / kBlock));
-    if (c->p64) hipLaunchKernelGGL((mask_rows_kernel<kEvalCC, true>), grid, dim3(kBlock), 0, c->stream, ea, c->n_rows, d_f, d_r);
-    else hipLaunchKernelGGL((mask_rows_kernel<kEvalCC, false>), grid, dim3(kBlock), 0, c->stream, ea, c->n_rows, d_f, d_r);
+    hipLaunchKernelGGL((mask_rows_kernel<kEvalCC>), grid, dim3(kBlock), 0, c->stream, ea, c->n_rows, d_f, d_r);
     HIPCK(c, hipGetLastError());
     // rows are padded to a multiple of 256 on the device: copy the (n_rows+63)/64 meaningful words of each mask
     HIPCK(c, hipMemcpy2DAsync(not_f, nwo * 8, d_f, nw * 8, nwo * 8, (size_t)n_cand, hipMemcpyDeviceToHost, c->stream));

@@ -50,62 +50,53 @@ __global__ __launch_bounds__(kBlock) void pack_kernel(const uint8_t *__restrict_
     planes[base + 3 * (size_t)n_pad] = mT;
 }
 
-// thread = row: prefix count of residues per chunk, leading-gap length and right-stripped length
-// (V20:625-627)
+// thread = row: prefix count of residues per chunk, leading-gap length and right-stripped length (V20:625-627), and the
+// row's gap-free residue string `ung` (what `.replace("-", "")` gives, V20:673/679): residues are appended in a 64-bit
+// nibble buffer and stored a word at a time into the word-major array, so a wave's stores of one word index coalesce.
+// (Round 1 appended per (row, chunk) with atomicOr into a row-major array: 0.89 ms at 131072 x 1000.)
 __global__ __launch_bounds__(kBlock) void row_scan_kernel(const uint32_t *__restrict__ planes, const int64_t *__restrict__ row_off,
                                                           int n_rows, int n_pad, int n_chunks, uint32_t *__restrict__ cum,
                                                           int32_t *__restrict__ lead, int32_t *__restrict__ rstrip,
-                                                          int32_t *__restrict__ rlen) {
+                                                          int32_t *__restrict__ rlen, uint32_t *__restrict__ ung) {
     int r = blockIdx.x * kBlock + threadIdx.x;
     if (r >= n_pad) return;
+    const size_t np = (size_t)n_pad;
     uint32_t run = 0;
     int first = -1, last = 0;
+    unsigned long long buf = 0;
+    int nb = 0;
+    size_t widx = 0;
     for (int c = 0; c < n_chunks; c++) {
-        size_t base = ((size_t)c * 4) * n_pad + r;
-        uint32_t ng = planes[base] | planes[base + n_pad] | planes[base + 2 * (size_t)n_pad] | planes[base + 3 * (size_t)n_pad];
-        cum[(size_t)c * n_pad + r] = run;
+        size_t base = ((size_t)c * 4) * np + r;
+        const uint32_t mA = planes[base], mC = planes[base + np], mG = planes[base + 2 * np], mT = planes[base + 3 * np];
+        uint32_t ng = mA | mC | mG | mT;
+        cum[(size_t)c * np + r] = run;
         run += __popc(ng);
         if (ng) {
             if (first < 0) first = c * 32 + (__ffs(ng) - 1);
             last = c * 32 + 32 - __clz(ng);
         }
+        while (ng) {
+            const int j = __ffs(ng) - 1;
+            ng &= ng - 1;
+            const unsigned long long code = ((mA >> j) & 1u) | (((mC >> j) & 1u) << 1) | (((mG >> j) & 1u) << 2) | (((mT >> j) & 1u) << 3);
+            buf |= code << (4 * nb);
+            if (++nb == 16) {
+                ung[widx * np + r] = (uint32_t)buf;
+                ung[(widx + 1) * np + r] = (uint32_t)(buf >> 32);
+                widx += 2; buf = 0; nb = 0;
+            }
+        }
     }
-    cum[(size_t)n_chunks * n_pad + r] = run;
+    if (nb > 0) ung[widx * np + r] = (uint32_t)buf;
+    if (nb > 8) ung[(widx + 1) * np + r] = (uint32_t)(buf >> 32);
+    cum[(size_t)n_chunks * np + r] = run;
     if (r < n_rows) {
         int len = (int)(row_off[r + 1] - row_off[r]);
         lead[r] = first < 0 ? len : first;
         rstrip[r] = last;
         rlen[r] = len;
     }
-}
-
-// thread = (row, chunk): append this chunk's residues to the row's gap-free code string
-__global__ __launch_bounds__(kBlock) void ungap_kernel(const uint32_t *__restrict__ planes, const uint32_t *__restrict__ cum,
-                                                       int n_rows, int n_pad, int ustride, uint32_t *__restrict__ ung) {
-    int r = blockIdx.x * kBlock + threadIdx.x;
-    int c = blockIdx.y;
-    if (r >= n_rows) return;
-    size_t base = ((size_t)c * 4) * n_pad + r;
-    uint32_t mA = planes[base], mC = planes[base + n_pad], mG = planes[base + 2 * (size_t)n_pad], mT = planes[base + 3 * (size_t)n_pad];
-    uint32_t ng = mA | mC | mG | mT;
-    if (!ng) return;
-    uint32_t pos = cum[(size_t)c * n_pad + r];
-    uint32_t *dst = ung + (size_t)r * ustride;
-    uint32_t word = 0;
-    uint32_t widx = pos >> 3;
-    while (ng) {
-        int j = __ffs(ng) - 1;
-        ng &= ng - 1;
-        uint32_t code = ((mA >> j) & 1u) | (((mC >> j) & 1u) << 1) | (((mG >> j) & 1u) << 2) | (((mT >> j) & 1u) << 3);
-        if ((pos >> 3) != widx) {
-            atomicOr(dst + widx, word);
-            word = 0;
-            widx = pos >> 3;
-        }
-        word |= code << ((pos & 7) * 4);
-        pos++;
-    }
-    atomicOr(dst + widx, word);
 }
 
 // Column planes for the bit-sliced evaluation: cols[col][4][Npad/64] u64, bit r%64 of word r/64 =
@@ -167,7 +158,7 @@ int mp_load_msa(mp_ctx *c, const uint8_t *bytes, const int64_t *row_off, int32_t
     max_len = std::max<int64_t>(max_len, c->reserve_cols);      // row shards: the alignment is wider than the local rows
     c->max_len = (int)max_len;
     c->n_chunks = (int)((max_len + 31) / 32) + 2;
-    c->ustride = (int)(max_len / 8) + 2;
+    c->ustride = (int)(max_len / 8) + 3;
     size_t np = (size_t)c->n_pad;
     int64_t total = row_off[n_rows] - row_off[0];
     uint8_t *d_bytes = nullptr;
@@ -178,7 +169,7 @@ int mp_load_msa(mp_ctx *c, const uint8_t *bytes, const int64_t *row_off, int32_t
     if ((rc = dev_alloc(c, &c->planes, (size_t)c->n_chunks * 4 * np))) return rc;
     if ((rc = dev_alloc(c, &c->cols, (size_t)c->n_chunks * 32 * 4 * (np / 64)))) return rc;
     if ((rc = dev_alloc(c, &c->cum, ((size_t)c->n_chunks + 1) * np))) return rc;
-    if ((rc = dev_alloc(c, &c->ung, (size_t)n_rows * c->ustride))) return rc;
+    if ((rc = dev_alloc(c, &c->ung, np * c->ustride))) return rc;
     if ((rc = dev_alloc(c, &c->lead, np))) return rc;
     if ((rc = dev_alloc(c, &c->rstrip, np))) return rc;
     if ((rc = dev_alloc(c, &c->rlen, np))) return rc;
@@ -186,13 +177,12 @@ int mp_load_msa(mp_ctx *c, const uint8_t *bytes, const int64_t *row_off, int32_t
     for (int r = 0; r <= n_rows; r++) off0[r] = row_off[r] - row_off[0];
     HIPCK(c, hipMemcpyAsync(d_bytes, bytes + row_off[0], (size_t)total, hipMemcpyHostToDevice, c->stream));
     HIPCK(c, hipMemcpyAsync(d_off, off0.data(), sizeof(int64_t) * (n_rows + 1), hipMemcpyHostToDevice, c->stream));
-    HIPCK(c, hipMemsetAsync(c->ung, 0, sizeof(uint32_t) * (size_t)n_rows * c->ustride, c->stream));
+    HIPCK(c, hipMemsetAsync(c->ung, 0, sizeof(uint32_t) * np * c->ustride, c->stream));
     HIPCK(c, hipMemsetAsync(c->rlen, 0, sizeof(int32_t) * np, c->stream));
     dim3 grid((unsigned)(c->n_pad / kBlock), (unsigned)c->n_chunks);
     hipLaunchKernelGGL(pack_kernel, grid, dim3(kBlock), 0, c->stream, d_bytes, d_off, n_rows, c->n_pad, c->n_chunks, c->planes);
     hipLaunchKernelGGL(row_scan_kernel, dim3(c->n_pad / kBlock), dim3(kBlock), 0, c->stream, c->planes, d_off, n_rows,
-                       c->n_pad, c->n_chunks, c->cum, c->lead, c->rstrip, c->rlen);
-    hipLaunchKernelGGL(ungap_kernel, grid, dim3(kBlock), 0, c->stream, c->planes, c->cum, n_rows, c->n_pad, c->ustride, c->ung);
+                       c->n_pad, c->n_chunks, c->cum, c->lead, c->rstrip, c->rlen, c->ung);
     hipLaunchKernelGGL(colplane_kernel, grid, dim3(kBlock), 0, c->stream, c->planes, c->n_pad, c->n_chunks, c->cols);
     HIPCK(c, hipGetLastError());
     HIPCK(c, hipStreamSynchronize(c->stream));

@@ -1,6 +1,19 @@
 // unique.hip — part of libmprime_hip.so: hand-written HIP (gfx950 / MI355X, wave64) behind the C ABI of
-// include/mprime.h.  Per-window k-mer histograms in an LDS hash table (mp_window_unique).
+// include/mprime.h.  Per-window k-mer histograms (mp_window_unique), straight from the bit planes.
+//
+// k <= 21 (3k bits fit one u64 key) — hist_kernel: a workgroup owns (window, slice of rows).  Every thread derives its
+//   row's k-mer from the eight plane words that cover the window (winwords.hpp; next iteration's words are already in
+//   flight), the wave folds the k-mer of its first lane (conserved windows put the same k-mer in almost every lane) and
+//   the remaining lanes insert theirs in parallel into an LDS table {key, count, first row} with 64-bit ds_cmpst.  The LDS
+//   table is a write-combining front of the window's table in HBM: when it fills up, and at the end of the slice, its
+//   entries are merged into the global table with 64-bit CAS / add / min atomics — no overflow path, any number of
+//   distinct k-mers per slice.  compact_kernel then lays the occupied slots out as per-window entry segments.
+//   (Round 1 stored a [W][Npad] u64 array of window words first and ran ONE workgroup per window over it: 1.5 s at
+//   10^6 rows.)
+// k >= 22 — unique_kernel: one workgroup per window, LDS table of representative rows; keys are compared by
+//   re-deriving the representative's k-mer.  Same algorithm as round 1, minus the stored window words.
 #include "common.hpp"
+#include "winwords.hpp"
 
 using namespace mp;
 
@@ -15,7 +28,208 @@ __device__ inline uint32_t hash3(uint32_t a, uint32_t b, uint32_t c) {
     h = (h ^ (h >> 13)) + c * 0xC2B2AE3Du;
     return h ^ (h >> 16);
 }
+__device__ inline uint32_t hash64(unsigned long long x) {
+    x ^= x >> 31; x *= 0x9E3779B97F4A7C15ULL; x ^= x >> 29; x *= 0xBF58476D1CE4E5B9ULL; x ^= x >> 32;
+    return (uint32_t)x;
+}
 
+constexpr unsigned long long kNoKey = ~0ull;
+constexpr int kLdsSlots = 2048;           // 32 KB of LDS per workgroup -> 4-5 workgroups per CU
+constexpr int kLdsLimit = 1536;           // flush above this; one iteration adds at most kBlock keys
+
+struct HistArgs {
+    MsaArgs M;
+    int p0, k, n_win, rows_per_block, n_slices, win_per_xcd;
+    unsigned long long *g_key;            // [W][g_slots]
+    uint32_t *g_cnt, *g_min;
+    int g_slots;
+    int32_t *g_used;                      // [W] occupied slots
+    int32_t *g_over;                      // [W] 1 = the global table of the window is too small
+};
+
+// merge one (key, count, first row) into the window's global table
+__device__ inline void global_insert(const HistArgs &A, int w, unsigned long long key, uint32_t cnt, uint32_t row) {
+    const uint32_t mask = (uint32_t)A.g_slots - 1u;
+    unsigned long long *K = A.g_key + (size_t)w * A.g_slots;
+    uint32_t h = hash64(key) & mask;
+    for (int probe = 0; probe < A.g_slots; probe++) {
+        unsigned long long old = K[h];
+        if (old == kNoKey) {
+            old = atomicCAS(&K[h], kNoKey, key);
+            if (old == kNoKey) { atomicAdd(&A.g_used[w], 1); old = key; }
+        }
+        if (old == key) {
+            atomicAdd(&A.g_cnt[(size_t)w * A.g_slots + h], cnt);
+            atomicMin(&A.g_min[(size_t)w * A.g_slots + h], row);
+            return;
+        }
+        h = (h + 1) & mask;
+    }
+    A.g_over[w] = 1;
+}
+
+__global__ __launch_bounds__(kBlock) void hist_kernel(const HistArgs A) {
+    __shared__ unsigned long long s_key[kLdsSlots];
+    __shared__ uint32_t s_cnt[kLdsSlots];
+    __shared__ uint32_t s_min[kLdsSlots];
+    __shared__ int s_used;
+    // workgroup b runs on XCD b % 8 and every XCD has its own L2: an XCD owns a band of consecutive windows and walks it
+    // window-fastest, so the workgroups resident on it at any time read the same few 32-column chunks of one row slice
+    const int xcd = blockIdx.x & 7, q = blockIdx.x >> 3;
+    const int wl = q % A.win_per_xcd, slice = q / A.win_per_xcd;
+    const int w = xcd * A.win_per_xcd + wl;
+    if (w >= A.n_win || slice >= A.n_slices) return;
+    const int k = A.k;
+    const uint32_t kmask = (1u << k) - 1u;
+    const int p = A.p0 + w;
+    const size_t np = (size_t)A.M.n_pad;
+    const int r0 = slice * A.rows_per_block;
+    const int r1 = min(r0 + A.rows_per_block, A.M.n_pad);
+    for (int i = threadIdx.x; i < kLdsSlots; i += kBlock) { s_key[i] = kNoKey; s_cnt[i] = 0; s_min[i] = kEmpty; }
+    if (threadIdx.x == 0) s_used = 0;
+    __syncthreads();
+    const int lane = threadIdx.x & 63;
+    const uint32_t *P = A.M.planes + ((size_t)(p >> 5) * 4) * np;
+    auto flush = [&]() {
+        for (int i = threadIdx.x; i < kLdsSlots; i += kBlock) {
+            const unsigned long long key = s_key[i];
+            if (key != kNoKey) global_insert(A, w, key, s_cnt[i], s_min[i]);
+            s_key[i] = kNoKey; s_cnt[i] = 0; s_min[i] = kEmpty;
+        }
+    };
+    uint32_t nx[8];
+    int nlen = 0;
+    {
+        const int r = r0 + threadIdx.x;
+        if (r < r1) {
+#pragma unroll
+            for (int j = 0; j < 8; j++) nx[j] = P[(size_t)j * np + r];
+            nlen = A.M.rlen[r];
+        }
+    }
+    for (int base = r0; base < r1; base += kBlock) {
+        const int r = base + threadIdx.x;
+        uint32_t cw[8];
+#pragma unroll
+        for (int j = 0; j < 8; j++) cw[j] = nx[j];
+        const int len = nlen;
+        {
+            const int rn = r + kBlock;                 // next iteration's plane words: in flight while this one hashes
+            if (rn < r1) {
+#pragma unroll
+                for (int j = 0; j < 8; j++) nx[j] = P[(size_t)j * np + rn];
+                nlen = A.M.rlen[rn];
+            }
+        }
+        bool todo = false;
+        unsigned long long key = kNoKey;
+        if (r < A.M.n_rows) {
+            uint32_t b0, b1, g;
+            bool fast;
+            Nib buf;
+            int rc = words_from_planes(A.M, r, p, k, kmask, len, cw[0], cw[1], cw[2], cw[3], cw[4], cw[5], cw[6], cw[7], b0, b1, g, fast, buf);
+            if (rc == 0) {
+                todo = true;
+                key = (unsigned long long)b0 | ((unsigned long long)b1 << k) | ((unsigned long long)(g & kmask) << (2 * k));
+            }
+        }
+        // fold the first lane's k-mer over the wave, then every other distinct lane inserts its own
+        const unsigned long long pending = __ballot(todo);
+        uint32_t cnt = 1;
+        if (pending) {
+            const int lead = __ffsll((long long)pending) - 1;
+            const unsigned long long k0 = __shfl(key, lead);
+            const unsigned long long grp = __ballot(todo && key == k0);
+            if (lane == lead) cnt = (uint32_t)__popcll(grp);
+            else if (todo && key == k0) todo = false;
+        }
+        if (todo) {
+            uint32_t h = hash64(key) & (kLdsSlots - 1);
+            for (;;) {
+                unsigned long long old = atomicCAS(&s_key[h], kNoKey, key);
+                if (old == kNoKey) { atomicAdd(&s_used, 1); old = key; }
+                if (old == key) { atomicAdd(&s_cnt[h], cnt); atomicMin(&s_min[h], (uint32_t)r); break; }
+                h = (h + 1) & (kLdsSlots - 1);
+            }
+        }
+        __syncthreads();
+        if (s_used > kLdsLimit) {                     // uniform: read after the barrier
+            flush();
+            __syncthreads();
+            if (threadIdx.x == 0) s_used = 0;
+            __syncthreads();
+        }
+    }
+    flush();
+}
+
+struct CompactArgs {
+    const unsigned long long *g_key;
+    const uint32_t *g_cnt, *g_min;
+    int32_t *g_idx;
+    int g_slots, k;
+    const int64_t *win_base;      // [W] first entry of the window's segment
+    int32_t *win_cursor;          // [W]
+    uint32_t *b0, *b1, *g;
+    int32_t *count, *first;
+    long long cap;
+};
+
+// occupied slots -> entries of the window's segment (order inside a window is unspecified)
+__global__ __launch_bounds__(kBlock) void compact_kernel(const CompactArgs A) {
+    const int per_win = A.g_slots / kBlock;                  // g_slots is a multiple of kBlock
+    const int w = blockIdx.x / per_win;
+    const int i = (blockIdx.x % per_win) * kBlock + threadIdx.x;
+    const size_t s = (size_t)w * A.g_slots + i;
+    const unsigned long long key = A.g_key[s];
+    const bool occ = key != kNoKey;
+    const unsigned long long m = __ballot(occ);
+    if (!m) return;
+    const int lane = threadIdx.x & 63;
+    const int leader = __ffsll((long long)m) - 1;
+    int base = 0;
+    if (lane == leader) base = atomicAdd(&A.win_cursor[w], (int)__popcll(m));
+    base = __shfl(base, leader);
+    if (!occ) return;
+    const int idx = base + (int)__popcll(m & ((1ull << lane) - 1ull));
+    A.g_idx[s] = idx;
+    const long long e = A.win_base[w] + idx;
+    if (e < A.cap) {
+        const uint32_t kmask = (1u << A.k) - 1u;
+        A.b0[e] = (uint32_t)key & kmask;
+        A.b1[e] = (uint32_t)(key >> A.k) & kmask;
+        A.g[e] = (uint32_t)(key >> (2 * A.k)) & kmask;
+        A.count[e] = (int32_t)A.g_cnt[s];
+        A.first[e] = (int32_t)A.g_min[s];
+    }
+}
+
+// per-row labels (index of the row's entry inside its window, -1 = not in the histogram): JSON side files only
+__global__ __launch_bounds__(kBlock) void label_kernel(const MsaArgs M, int p0, int k, const unsigned long long *__restrict__ g_key,
+                                                       const int32_t *__restrict__ g_idx, int g_slots, int32_t *__restrict__ labels) {
+    const int per_win = M.n_pad / kBlock;
+    const int w = blockIdx.x / per_win;
+    const int r = (blockIdx.x % per_win) * kBlock + threadIdx.x;
+    if (r >= M.n_rows) return;
+    const uint32_t kmask = (1u << k) - 1u;
+    uint32_t b0, b1, g;
+    FlyView(M, p0 + w, k, kmask).load(r, b0, b1, g);
+    int32_t lab = -1;
+    if (!(g & MP_WIN_SKIP)) {
+        const unsigned long long key = (unsigned long long)b0 | ((unsigned long long)b1 << k) | ((unsigned long long)(g & kmask) << (2 * k));
+        const uint32_t mask = (uint32_t)g_slots - 1u;
+        uint32_t h = hash64(key) & mask;
+        for (int probe = 0; probe < g_slots; probe++) {
+            const unsigned long long o = g_key[(size_t)w * g_slots + h];
+            if (o == key) { lab = g_idx[(size_t)w * g_slots + h]; break; }
+            if (o == kNoKey) break;
+            h = (h + 1) & mask;
+        }
+    }
+    labels[(size_t)w * M.n_pad + r] = lab;
+}
+
+// ---------------------------------------------------------------------------------------------- k >= 22
 struct UniqueOut {
     uint32_t *b0, *b1, *g;
     int32_t *count, *first;
@@ -28,20 +242,19 @@ struct UniqueOut {
 };
 
 // One block per window.  Rows stream through in lanes; equal keys inside a wave are folded with
-// ballots first (conserved windows put the same k-mer in almost every lane), then one lane per
-// distinct key updates the table.  A slot stores the row of a representative; key comparison
-// reads the representative's window words back (immutable, L2-resident).
+// ballots first, then one lane per distinct key updates the table.  A slot stores the row of a representative; key
+// comparison re-derives the representative's window words from the planes.
 // TABLE_IN_LDS = false: same algorithm on a global-memory table (windows with more distinct k-mers
 // than the LDS table holds).
-template <bool TABLE_IN_LDS, bool P64>
-__global__ __launch_bounds__(kBlock) void unique_kernel(const void *__restrict__ win, int k, int n_rows, int n_pad,
-                                                        const int32_t *__restrict__ win_list, int slots, int limit,
-                                                        uint32_t *__restrict__ gtable, UniqueOut out) {
+template <bool TABLE_IN_LDS>
+__global__ __launch_bounds__(kBlock) void unique_kernel(const MsaArgs M, int p0, int k, const int32_t *__restrict__ win_list, int slots,
+                                                        int limit, uint32_t *__restrict__ gtable, UniqueOut out) {
     __shared__ uint32_t s_rep[TABLE_IN_LDS ? kHashSlots : 1];
     __shared__ uint32_t s_cnt[TABLE_IN_LDS ? kHashSlots : 1];
     __shared__ uint32_t s_min[TABLE_IN_LDS ? kHashSlots : 1];
     __shared__ int s_used, s_over, s_nout;
     __shared__ unsigned long long s_base;
+    const int n_rows = M.n_rows, n_pad = M.n_pad;
     const int w = win_list ? win_list[blockIdx.x] : blockIdx.x;
     uint32_t *rep, *cnt, *mn;
     if (TABLE_IN_LDS) { rep = s_rep; cnt = s_cnt; mn = s_min; }
@@ -51,7 +264,7 @@ __global__ __launch_bounds__(kBlock) void unique_kernel(const void *__restrict__
     if (threadIdx.x == 0) { s_used = 0; s_over = 0; s_nout = 0; }
     __syncthreads();
     const size_t np = (size_t)n_pad;
-    const WinView<P64> V(win, w, np, k, (1u << k) - 1u);
+    const FlyView V(M, p0 + w, k, (1u << k) - 1u);
     const int lane = threadIdx.x & 63;
     for (int base = 0; base < n_pad; base += kBlock) {
         int r = base + threadIdx.x;
@@ -138,18 +351,7 @@ __global__ __launch_bounds__(kBlock) void unique_kernel(const void *__restrict__
     }
 }
 
-
-}  // namespace
-
-extern "C" {
-
-int mp_window_unique(mp_ctx *c, int64_t cap, int32_t want_labels, int64_t *n_entries) {
-    if (!c) return MP_ERR_ARG;
-    if (!c->win) return fail(c, MP_ERR_ARG, "no windows built");
-    if (cap <= 0) return fail(c, MP_ERR_ARG, "cap_entries must be positive");
-    HIPCK(c, hipSetDevice(c->dev));
-    free_unique(c);
-    size_t W = (size_t)c->n_win, np = (size_t)c->n_pad;
+int alloc_entries(mp_ctx *c, int64_t cap) {
     int rc;
     c->u_cap = cap;
     if ((rc = dev_alloc(c, &c->u_b0, (size_t)cap))) return rc;
@@ -157,6 +359,85 @@ int mp_window_unique(mp_ctx *c, int64_t cap, int32_t want_labels, int64_t *n_ent
     if ((rc = dev_alloc(c, &c->u_g, (size_t)cap))) return rc;
     if ((rc = dev_alloc(c, &c->u_count, (size_t)cap))) return rc;
     if ((rc = dev_alloc(c, &c->u_first, (size_t)cap))) return rc;
+    return MP_OK;
+}
+
+// k <= 21: LDS-combined global hash tables straight from the planes
+int unique_packed(mp_ctx *c, int64_t cap, int32_t want_labels, int64_t *n_entries) {
+    const size_t W = (size_t)c->n_win, np = (size_t)c->n_pad;
+    int rc;
+    if ((rc = dev_alloc(c, &c->u_over, W))) return rc;
+    if ((rc = dev_alloc(c, &c->u_wcount, W))) return rc;
+    if ((rc = dev_alloc(c, &c->u_wbase, W))) return rc;
+    int32_t *d_cursor = nullptr;
+    // a table holds every distinct k-mer of a window; first try: twice the rows, at most 16384 slots (256 KB per window)
+    int slots = kBlock;
+    while (slots < 2 * c->n_rows + 64 && slots < 16384) slots <<= 1;
+    if (const char *e = getenv("MP_HIST_SLOTS")) { int s = atoi(e); if (s >= kBlock && (s & (s - 1)) == 0) slots = s; }
+    std::vector<int32_t> used(W), over(W);
+    for (int attempt = 0; attempt < 8; attempt++) {
+        const size_t n = W * (size_t)slots;
+        c->g_slots = slots;
+        if ((rc = dev_alloc(c, &c->g_key, n))) return rc;
+        if ((rc = dev_alloc(c, &c->g_cnt, n))) return rc;
+        if ((rc = dev_alloc(c, &c->g_min, n))) return rc;
+        if ((rc = dev_alloc(c, &c->g_idx, n))) return rc;
+        HIPCK(c, hipMemsetAsync(c->g_key, 0xFF, sizeof(unsigned long long) * n, c->stream));
+        HIPCK(c, hipMemsetAsync(c->g_cnt, 0, sizeof(uint32_t) * n, c->stream));
+        HIPCK(c, hipMemsetAsync(c->g_min, 0xFF, sizeof(uint32_t) * n, c->stream));
+        HIPCK(c, hipMemsetAsync(c->u_wcount, 0, sizeof(int32_t) * W, c->stream));
+        HIPCK(c, hipMemsetAsync(c->u_over, 0, sizeof(int32_t) * W, c->stream));
+        HistArgs A{msa_args(c), c->p0, c->k, c->n_win, 0, 0, 0, c->g_key, c->g_cnt, c->g_min, slots, c->u_wcount, c->u_over};
+        // enough workgroups to fill 256 CUs several times over, slices of at least 4096 rows
+        int n_slices = (int)std::max<size_t>(1, std::min<size_t>((np + 4095) / 4096, (8192 + W - 1) / W));
+        if (const char *e = getenv("MP_HIST_SLICES")) n_slices = std::max(1, atoi(e));
+        A.rows_per_block = (int)(((np + n_slices - 1) / n_slices + kBlock - 1) / kBlock * kBlock);
+        A.n_slices = (int)((np + A.rows_per_block - 1) / A.rows_per_block);
+        A.win_per_xcd = (int)((W + 7) / 8);
+        const unsigned blocks = 8u * (unsigned)A.win_per_xcd * (unsigned)A.n_slices;
+        hipLaunchKernelGGL(hist_kernel, dim3(blocks), dim3(kBlock), 0, c->stream, A);
+        HIPCK(c, hipGetLastError());
+        HIPCK(c, hipMemcpyAsync(used.data(), c->u_wcount, sizeof(int32_t) * W, hipMemcpyDeviceToHost, c->stream));
+        HIPCK(c, hipMemcpyAsync(over.data(), c->u_over, sizeof(int32_t) * W, hipMemcpyDeviceToHost, c->stream));
+        HIPCK(c, hipStreamSynchronize(c->stream));
+        bool any_over = false;
+        for (size_t w = 0; w < W; w++) any_over |= over[w] != 0 || used[w] > slots - slots / 8;
+        if (!any_over) break;
+        // a window has (nearly) as many distinct k-mers as slots: start over with tables 8x the size (rare: random input)
+        dev_free(c, &c->g_key, n); dev_free(c, &c->g_cnt, n); dev_free(c, &c->g_min, n); dev_free(c, &c->g_idx, n);
+        if (attempt == 7 || (size_t)slots * 8 > ((size_t)1 << 28)) return fail(c, MP_ERR_NOMEM, "histogram tables do not converge");
+        slots *= 8;
+    }
+    c->h_wbase.resize(W); c->h_wcount.resize(W);
+    int64_t total = 0;
+    for (size_t w = 0; w < W; w++) { c->h_wbase[w] = total; c->h_wcount[w] = used[w]; total += used[w]; }
+    if (n_entries) *n_entries = total;
+    if (total > cap) { c->u_n = 0; return fail(c, MP_ERR_CAPACITY, "unique table needs %lld entries", (long long)total); }
+    if ((rc = alloc_entries(c, std::max<int64_t>(total, 1)))) return rc;
+    if ((rc = dev_alloc(c, &d_cursor, W))) return rc;
+    HIPCK(c, hipMemcpyAsync(c->u_wbase, c->h_wbase.data(), sizeof(int64_t) * W, hipMemcpyHostToDevice, c->stream));
+    HIPCK(c, hipMemsetAsync(d_cursor, 0, sizeof(int32_t) * W, c->stream));
+    CompactArgs CA{c->g_key, c->g_cnt, c->g_min, c->g_idx, c->g_slots, c->k, c->u_wbase, d_cursor,
+                   c->u_b0, c->u_b1, c->u_g, c->u_count, c->u_first, (long long)c->u_cap};
+    hipLaunchKernelGGL(compact_kernel, dim3((unsigned)((size_t)(c->g_slots / kBlock) * W)), dim3(kBlock), 0, c->stream, CA);
+    HIPCK(c, hipGetLastError());
+    if (want_labels) {
+        if ((rc = dev_alloc(c, &c->labels, W * np))) return rc;
+        hipLaunchKernelGGL(label_kernel, dim3((unsigned)((np / kBlock) * W)), dim3(kBlock), 0, c->stream, msa_args(c), c->p0, c->k,
+                           (const unsigned long long *)c->g_key, (const int32_t *)c->g_idx, c->g_slots, c->labels);
+        HIPCK(c, hipGetLastError());
+    }
+    HIPCK(c, hipStreamSynchronize(c->stream));
+    dev_free(c, &d_cursor, W);
+    c->u_n = total;
+    return MP_OK;
+}
+
+// k >= 22: one workgroup per window, representative-row table
+int unique_wide(mp_ctx *c, int64_t cap, int32_t want_labels, int64_t *n_entries) {
+    size_t W = (size_t)c->n_win, np = (size_t)c->n_pad;
+    int rc;
+    if ((rc = alloc_entries(c, cap))) return rc;
     if ((rc = dev_alloc(c, &c->u_over, W))) return rc;
     if ((rc = dev_alloc(c, &c->u_wcount, W))) return rc;
     if ((rc = dev_alloc(c, &c->u_wbase, W))) return rc;
@@ -165,12 +446,9 @@ int mp_window_unique(mp_ctx *c, int64_t cap, int32_t want_labels, int64_t *n_ent
     HIPCK(c, hipMemsetAsync(c->u_total, 0, sizeof(unsigned long long), c->stream));
     UniqueOut uo{c->u_b0, c->u_b1, c->u_g, c->u_count, c->u_first, (long long)cap, c->u_total,
                  c->u_wbase, c->u_wcount, c->labels, c->u_over};
-    if (c->p64)
-        hipLaunchKernelGGL((unique_kernel<true, true>), dim3((unsigned)W), dim3(kBlock), 0, c->stream, (const void *)c->win, c->k,
-                           c->n_rows, c->n_pad, (const int32_t *)nullptr, kHashSlots, kHashLimit, (uint32_t *)nullptr, uo);
-    else
-        hipLaunchKernelGGL((unique_kernel<true, false>), dim3((unsigned)W), dim3(kBlock), 0, c->stream, (const void *)c->win, c->k,
-                           c->n_rows, c->n_pad, (const int32_t *)nullptr, kHashSlots, kHashLimit, (uint32_t *)nullptr, uo);
+    const MsaArgs M = msa_args(c);
+    hipLaunchKernelGGL((unique_kernel<true>), dim3((unsigned)W), dim3(kBlock), 0, c->stream, M, c->p0, c->k, (const int32_t *)nullptr,
+                       kHashSlots, kHashLimit, (uint32_t *)nullptr, uo);
     HIPCK(c, hipGetLastError());
     std::vector<int32_t> over(W);
     HIPCK(c, hipMemcpyAsync(over.data(), c->u_over, sizeof(int32_t) * W, hipMemcpyDeviceToHost, c->stream));
@@ -189,12 +467,8 @@ int mp_window_unique(mp_ctx *c, int64_t cap, int32_t want_labels, int64_t *n_ent
         for (size_t i = 0; i < big.size(); i += batch) {
             size_t nb = std::min(batch, big.size() - i);
             HIPCK(c, hipMemcpy(d_list, big.data() + i, sizeof(int32_t) * nb, hipMemcpyHostToDevice));
-            if (c->p64)
-                hipLaunchKernelGGL((unique_kernel<false, true>), dim3((unsigned)nb), dim3(kBlock), 0, c->stream, (const void *)c->win,
-                                   c->k, c->n_rows, c->n_pad, (const int32_t *)d_list, slots, slots - 32, gtable, uo);
-            else
-                hipLaunchKernelGGL((unique_kernel<false, false>), dim3((unsigned)nb), dim3(kBlock), 0, c->stream, (const void *)c->win,
-                                   c->k, c->n_rows, c->n_pad, (const int32_t *)d_list, slots, slots - 32, gtable, uo);
+            hipLaunchKernelGGL((unique_kernel<false>), dim3((unsigned)nb), dim3(kBlock), 0, c->stream, M, c->p0, c->k,
+                               (const int32_t *)d_list, slots, slots - 32, gtable, uo);
             HIPCK(c, hipGetLastError());
             HIPCK(c, hipStreamSynchronize(c->stream));
         }
@@ -212,11 +486,44 @@ int mp_window_unique(mp_ctx *c, int64_t cap, int32_t want_labels, int64_t *n_ent
     return MP_OK;
 }
 
+}  // namespace
+
+extern "C" {
+
+int mp_window_unique(mp_ctx *c, int64_t cap, int32_t want_labels, int64_t *n_entries) {
+    if (!c) return MP_ERR_ARG;
+    if (!c->excl) return fail(c, MP_ERR_ARG, "no windows built");
+    if (cap <= 0) return fail(c, MP_ERR_ARG, "cap_entries must be positive");
+    HIPCK(c, hipSetDevice(c->dev));
+    free_unique(c);
+    return c->p64 ? unique_packed(c, cap, want_labels, n_entries) : unique_wide(c, cap, want_labels, n_entries);
+}
+
 int mp_get_unique(mp_ctx *c, int64_t *win_off, uint32_t *words, int32_t *count, int32_t *first_row) {
     if (!c) return MP_ERR_ARG;
     if (c->h_wbase.empty()) return fail(c, MP_ERR_ARG, "mp_window_unique has not run");
     HIPCK(c, hipSetDevice(c->dev));
     size_t n = (size_t)c->u_n, W = (size_t)c->n_win;
+    // segments are laid out in window order when every window's base is the running sum (the packed path)
+    bool in_order = true;
+    {
+        int64_t o = 0;
+        for (size_t w = 0; w < W; w++) { if (c->h_wbase[w] != o) { in_order = false; break; } o += c->h_wcount[w]; }
+    }
+    if (in_order) {
+        if (n) {
+            HIPCK(c, hipMemcpyAsync(words, c->u_b0, 4 * n, hipMemcpyDeviceToHost, c->stream));
+            HIPCK(c, hipMemcpyAsync(words + n, c->u_b1, 4 * n, hipMemcpyDeviceToHost, c->stream));
+            HIPCK(c, hipMemcpyAsync(words + 2 * n, c->u_g, 4 * n, hipMemcpyDeviceToHost, c->stream));
+            HIPCK(c, hipMemcpyAsync(count, c->u_count, 4 * n, hipMemcpyDeviceToHost, c->stream));
+            HIPCK(c, hipMemcpyAsync(first_row, c->u_first, 4 * n, hipMemcpyDeviceToHost, c->stream));
+            HIPCK(c, hipStreamSynchronize(c->stream));
+        }
+        int64_t o = 0;
+        for (size_t w = 0; w < W; w++) { win_off[w] = o; o += c->h_wcount[w]; }
+        win_off[W] = o;
+        return MP_OK;
+    }
     std::vector<uint32_t> b0(n + 1), b1(n + 1), g(n + 1);
     std::vector<int32_t> cn(n + 1), fr(n + 1);
     if (n) {

@@ -1,6 +1,7 @@
 // windows.hip — part of libmprime_hip.so: hand-written HIP (gfx950 / MI355X, wave64) behind the C ABI of
-// include/mprime.h.  The k-mer of every (window, sequence) with edge-gap repair, exception and patch lists (mp_build_windows).
+// include/mprime.h.  Window scan: which (window, sequence) k-mers are plain column slices, the patch list of the repaired ones, the IUPAC exception list (mp_build_windows).
 #include "common.hpp"
+#include "winwords.hpp"
 
 using namespace mp;
 
@@ -9,64 +10,6 @@ namespace {
 // ----------------------------------------------------------------------------------------------
 // (2) window k-mers with edge-gap repair (V20:666-687)
 // ----------------------------------------------------------------------------------------------
-__device__ inline uint32_t ung_get(const uint32_t *__restrict__ ung_row, uint32_t t) {
-    return (ung_row[t >> 3] >> ((t & 7) * 4)) & 15u;
-}
-
-// The general path: rows whose window starts or ends in a gap, holds an IUPAC code, or runs past
-// the end of a ragged row.  Follows get_primers line by line.  Returns 0 = store words,
-// 1 = exception (IUPAC code present, `buf` returned), 2 = fewer than k residues (V20:683-687).
-__device__ int repair_window(uint32_t wA, uint32_t wC, uint32_t wG, uint32_t wT, int k, int p, int len,
-                             uint32_t c_left, uint32_t total, const uint32_t *__restrict__ ung_row,
-                             uint32_t &b0, uint32_t &b1, uint32_t &g, Nib &buf) {
-    uint32_t kmask = (k == 32) ? 0xFFFFFFFFu : ((1u << k) - 1u);
-    int m = len - p;
-    m = m < 0 ? 0 : (m > k ? k : m);
-    uint32_t ng = (wA | wC | wG | wT) & kmask;
-    buf.lo = buf.hi = 0;
-    for (int j = 0; j < m; j++) {
-        uint32_t code = ((wA >> j) & 1u) | (((wC >> j) & 1u) << 1) | (((wG >> j) & 1u) << 2) | (((wT >> j) & 1u) << 3);
-        buf.set(j, code);
-    }
-    int n = m;
-    bool all_gap = (m == k) && ng == 0;                       // V20:668
-    if (!all_gap && n > 0) {
-        if (buf.get(0) == 0) {                                // V20:671 sequence.startswith("-")
-            int run = 0;
-            while (run < n && buf.get(run) == 0) run++;
-            if (c_left >= (uint32_t)run)                      // V20:675
-                for (int t = 0; t < run; t++) buf.set(t, ung_get(ung_row, c_left - run + t));
-        }
-        if (buf.get(n - 1) == 0) {                            // V20:677 sequence.endswith("-")
-            int run = 0;
-            while (run < n && buf.get(n - 1 - run) == 0) run++;
-            uint32_t c_after = c_left + __popc(ng);          // residues in s[0 : p+k]
-            if (total - c_after >= (uint32_t)run)             // V20:681
-                for (int t = 0; t < run; t++) buf.set(n - run + t, ung_get(ung_row, c_after + t));
-        }
-    }
-    if (n < k) {                                              // V20:683
-        int need = k - n;
-        if (c_left < (uint32_t)need) return 2;
-        buf.shift_up(need);
-        for (int t = 0; t < need; t++) buf.set(t, ung_get(ung_row, c_left - need + t));
-        n = k;
-    }
-    b0 = b1 = g = 0;
-    bool iupac = false;
-    for (int j = 0; j < k; j++) {
-        uint32_t code = buf.get(j);
-        if (code == 0) g |= 1u << j;
-        else if (code & (code - 1)) iupac = true;
-        else {
-            uint32_t bi = __ffs(code) - 1;
-            b0 |= (bi & 1u) << j;
-            b1 |= (bi >> 1) << j;
-        }
-    }
-    return iupac ? 1 : 0;
-}
-
 // Rows whose k-mer is NOT the plain column slice (edge-gap repair, IUPAC, ragged end) are flagged per
 // (window, 64-row word) in `excl` and collected, per window, in a compact patch list of window words:
 // the bit-sliced evaluation skips them, the row-per-lane evaluation handles exactly them.  `excl` also
@@ -83,35 +26,33 @@ struct PatchOut {
     uint32_t *words;              // [n][3]  (pass 1)
 };
 
-template <bool P64>
-__global__ __launch_bounds__(kBlock) void build_windows_kernel(
-    const uint32_t *__restrict__ planes, const uint32_t *__restrict__ cum, const uint32_t *__restrict__ ung,
-    const int32_t *__restrict__ rlen, int n_rows, int n_pad, int n_chunks, int ustride, int p0, int n_win, int tile,
-    int k, int v, void *__restrict__ win, ExRec *__restrict__ ex, int ex_cap, int *__restrict__ ex_count,
-    int *__restrict__ err, PatchOut po) {
+// thread = row, workgroup = 256 rows x a tile of consecutive windows; the 32-column plane words slide in registers, so
+// every plane word is read once per tile.  Nothing is stored per (window, row) any more: the kernel classifies each
+// k-mer (plain column slice / repaired / IUPAC exception / too short) and writes the 1-bit-per-pair `excl` flags, the
+// patch list of the repaired k-mers and the exception list.
+__global__ __launch_bounds__(kBlock) void scan_windows_kernel(const MsaArgs M, int p0, int n_win, int tile, int k, int v,
+                                                              ExRec *__restrict__ ex, int ex_cap, int *__restrict__ ex_count,
+                                                              int *__restrict__ err, PatchOut po) {
     int r = blockIdx.x * kBlock + threadIdx.x;
-    if (r >= n_pad) return;
+    if (r >= M.n_pad) return;
+    const int n_rows = M.n_rows;
     int w0 = blockIdx.y * tile;
     int w1 = w0 + tile < n_win ? w0 + tile : n_win;
     const uint32_t kmask = (1u << k) - 1u;
-    const size_t np = (size_t)n_pad;
+    const size_t np = (size_t)M.n_pad;
+    const uint32_t *__restrict__ planes = M.planes;
     const unsigned long long real = __ballot(r < n_rows);
     if (r >= n_rows) {                       // padding rows never take part
-        if (po.pass == 0)
-            for (int w = w0; w < w1; w++) {
-                WinView<P64>::store(win, w, np, r, 0, 0, MP_WIN_SKIP | kmask, k, kmask);
-                if (real == 0ull && (threadIdx.x & 63) == 0) po.excl[(size_t)w * (np / 64) + (size_t)(r >> 6)] = ~0ull;
-            }
+        if (po.pass == 0 && real == 0ull && (threadIdx.x & 63) == 0)
+            for (int w = w0; w < w1; w++) po.excl[(size_t)w * (np / 64) + (size_t)(r >> 6)] = ~0ull;
         return;
     }
-    const int len = rlen[r];
-    const uint32_t total = cum[(size_t)n_chunks * np + r];
-    const uint32_t *ung_row = ung + (size_t)r * ustride;
+    const int len = M.rlen[r];
     int cur = -1;
     uint32_t loA = 0, loC = 0, loG = 0, loT = 0, hiA = 0, hiC = 0, hiG = 0, hiT = 0;
     for (int w = w0; w < w1; w++) {
         int p = p0 + w;
-        int c = p >> 5, o = p & 31;
+        int c = p >> 5;
         if (c != cur) {
             size_t base = ((size_t)c * 4) * np + r;
             if (c == cur + 1 && cur >= 0) { loA = hiA; loC = hiC; loG = hiG; loT = hiT; }
@@ -120,34 +61,20 @@ __global__ __launch_bounds__(kBlock) void build_windows_kernel(
             hiA = planes[nb]; hiC = planes[nb + np]; hiG = planes[nb + 2 * np]; hiT = planes[nb + 3 * np];
             cur = c;
         }
-        uint32_t wA = __funnelshift_r(loA, hiA, o) & kmask;
-        uint32_t wC = __funnelshift_r(loC, hiC, o) & kmask;
-        uint32_t wG = __funnelshift_r(loG, hiG, o) & kmask;
-        uint32_t wT = __funnelshift_r(loT, hiT, o) & kmask;
-        uint32_t o1 = wA | wC, a1 = wA & wC, o2 = wG | wT, a2 = wG & wT;
-        uint32_t ng = o1 | o2;
-        uint32_t multi = a1 | a2 | (o1 & o2);
-        uint32_t gw = ~ng & kmask;
         uint32_t b0, b1, g;
-        bool fast = (p + k <= len) && multi == 0 && (gw == kmask || ((gw & 1u) == 0 && (gw >> (k - 1)) == 0));
-        if (fast) {
-            b0 = wC | wT; b1 = wG | wT; g = gw;
-        } else {
-            uint32_t ng_lo = loA | loC | loG | loT;
-            uint32_t c_left = cum[(size_t)c * np + r] + __popc(ng_lo & ((1u << o) - 1u));
-            Nib buf;
-            int rc = repair_window(wA, wC, wG, wT, k, p, len, c_left, total, ung_row, b0, b1, g, buf);
-            if (rc == 1) {
-                if (po.pass == 0) {
-                    int idx = atomicAdd(ex_count, 1);
-                    if (idx < ex_cap) { ex[idx].win = w; ex[idx].row = r; ex[idx].lo = buf.lo; ex[idx].hi = buf.hi; }
-                }
-                b0 = 0; b1 = 0; g = MP_WIN_SKIP | kmask;
-            } else if (rc == 2) {
-                atomicMax(err, 1);
-                err[1] = w; err[2] = r;
-                b0 = 0; b1 = 0; g = MP_WIN_SKIP | kmask;
+        bool fast;
+        Nib buf;
+        int rc = words_from_planes(M, r, p, k, kmask, len, loA, loC, loG, loT, hiA, hiC, hiG, hiT, b0, b1, g, fast, buf);
+        if (rc == 1) {
+            if (po.pass == 0) {
+                int idx = atomicAdd(ex_count, 1);
+                if (idx < ex_cap) { ex[idx].win = w; ex[idx].row = r; ex[idx].lo = buf.lo; ex[idx].hi = buf.hi; }
             }
+            b0 = 0; b1 = 0; g = MP_WIN_SKIP | kmask;
+        } else if (rc == 2) {
+            atomicMax(err, 1);
+            err[1] = w; err[2] = r;
+            b0 = 0; b1 = 0; g = MP_WIN_SKIP | kmask;
         }
         {
             // flags and patch list; the lanes of a wave that are still here are all real rows
@@ -172,8 +99,16 @@ __global__ __launch_bounds__(kBlock) void build_windows_kernel(
                 }
             }
         }
-        if (po.pass == 0) WinView<P64>::store(win, w, np, r, b0, b1, g, k, kmask);
     }
+}
+
+// parity / debug: window words of rows [row0, row0 + n) of one window, derived on the fly
+__global__ __launch_bounds__(kBlock) void window_words_kernel(const MsaArgs M, int p, int k, int row0, int n, uint32_t *__restrict__ out) {
+    int i = blockIdx.x * kBlock + threadIdx.x;
+    if (i >= n) return;
+    uint32_t b0, b1, g;
+    FlyView(M, p, k, (1u << k) - 1u).load(row0 + i, b0, b1, g);
+    out[i] = b0; out[(size_t)n + i] = b1; out[2 * (size_t)n + i] = g;
 }
 
 
@@ -192,15 +127,8 @@ int mp_build_windows(mp_ctx *c, int32_t p0, int32_t n_win, int32_t k, int32_t v,
     c->p0 = p0; c->n_win = n_win; c->k = k; c->v = v;
     size_t np = (size_t)c->n_pad;
     int rc;
-    // one packed u64 per (window, sequence) when 3k bits + the flag fit, else three u32 planes
+    // histogram keys: one packed u64 when 3k bits fit (unique.hip), else three u32 words compared through a representative row
     c->p64 = 3 * k <= 63 && !getenv("MP_WIN_NO_PACK");
-    {
-        uint8_t *wp = nullptr;
-        size_t nb = (size_t)n_win * np * (c->p64 ? 8 : 12);
-        if ((rc = dev_alloc(c, &wp, nb))) return rc;
-        c->win = wp;
-        c->win_bytes = nb;
-    }
     if ((rc = dev_alloc(c, &c->ex_count, 1))) return rc;
     if ((rc = dev_alloc(c, &c->err_flag, 4))) return rc;
     if ((rc = dev_alloc(c, &c->extra_off, (size_t)n_win + 1))) return rc;
@@ -213,15 +141,10 @@ int mp_build_windows(mp_ctx *c, int32_t p0, int32_t n_win, int32_t k, int32_t v,
     int cap = 1 << 16;
     const int tile = 64;
     const dim3 grid((unsigned)(c->n_pad / kBlock), (unsigned)((n_win + tile - 1) / tile));
+    const MsaArgs M = msa_args(c);
     auto launch = [&](const PatchOut &po, int ex_cap) {
-        if (c->p64)
-            hipLaunchKernelGGL(build_windows_kernel<true>, grid, dim3(kBlock), 0, c->stream, c->planes, c->cum, c->ung, c->rlen,
-                               c->n_rows, c->n_pad, c->n_chunks, c->ustride, p0, n_win, tile, k, v, c->win, c->ex, ex_cap,
-                               c->ex_count, c->err_flag, po);
-        else
-            hipLaunchKernelGGL(build_windows_kernel<false>, grid, dim3(kBlock), 0, c->stream, c->planes, c->cum, c->ung, c->rlen,
-                               c->n_rows, c->n_pad, c->n_chunks, c->ustride, p0, n_win, tile, k, v, c->win, c->ex, ex_cap,
-                               c->ex_count, c->err_flag, po);
+        hipLaunchKernelGGL(scan_windows_kernel, grid, dim3(kBlock), 0, c->stream, M, p0, n_win, tile, k, v, c->ex, ex_cap, c->ex_count,
+                           c->err_flag, po);
     };
     for (int attempt = 0; attempt < 2; attempt++) {
         if ((rc = dev_alloc(c, &c->ex, (size_t)cap))) return rc;
@@ -278,7 +201,7 @@ int mp_build_windows(mp_ctx *c, int32_t p0, int32_t n_win, int32_t k, int32_t v,
 
 int mp_get_exceptions(mp_ctx *c, int32_t cap, int32_t *ew, int32_t *er, uint8_t *codes) {
     if (!c) return MP_ERR_ARG;
-    if (!c->win) return fail(c, MP_ERR_ARG, "no windows built");
+    if (!c->excl) return fail(c, MP_ERR_ARG, "no windows built");
     int n = (int)c->ex_host.size();
     if (cap < n) return fail(c, MP_ERR_CAPACITY, "exception buffer too small: need %d", n);
     for (int i = 0; i < n; i++) {
@@ -292,7 +215,7 @@ int mp_get_exceptions(mp_ctx *c, int32_t cap, int32_t *ew, int32_t *er, uint8_t 
 
 int mp_set_extra_rows(mp_ctx *c, int32_t n, const int32_t *win, const uint32_t *words) {
     if (!c) return MP_ERR_ARG;
-    if (!c->win) return fail(c, MP_ERR_ARG, "no windows built");
+    if (!c->excl) return fail(c, MP_ERR_ARG, "no windows built");
     HIPCK(c, hipSetDevice(c->dev));
     dev_free(c, &c->extra_words, (size_t)3 * c->n_extra);
     c->n_extra = 0;
@@ -317,29 +240,19 @@ int mp_set_extra_rows(mp_ctx *c, int32_t n, const int32_t *win, const uint32_t *
 
 int mp_get_window_words(mp_ctx *c, int32_t w, int32_t row0, int32_t n, uint32_t *out) {
     if (!c) return MP_ERR_ARG;
-    if (!c->win) return fail(c, MP_ERR_ARG, "no windows built");
+    if (!c->excl) return fail(c, MP_ERR_ARG, "no windows built");
     if (w < 0 || w >= c->n_win || row0 < 0 || n < 0 || row0 + n > c->n_rows) return fail(c, MP_ERR_ARG, "bad range");
     HIPCK(c, hipSetDevice(c->dev));
-    size_t np = (size_t)c->n_pad;
-    if (c->p64) {
-        std::vector<uint64_t> tmp((size_t)n + 1);
-        HIPCK(c, hipMemcpyAsync(tmp.data(), (const uint64_t *)c->win + (size_t)w * np + row0, sizeof(uint64_t) * (size_t)n,
-                                hipMemcpyDeviceToHost, c->stream));
-        HIPCK(c, hipStreamSynchronize(c->stream));
-        const uint32_t kmask = (1u << c->k) - 1u;
-        for (int i = 0; i < n; i++) {
-            uint64_t x = tmp[(size_t)i];
-            out[i] = (uint32_t)x & kmask;
-            out[(size_t)n + i] = (uint32_t)(x >> c->k) & kmask;
-            out[2 * (size_t)n + i] = ((uint32_t)(x >> (2 * c->k)) & kmask) | ((uint32_t)(x >> 32) & MP_WIN_SKIP);
-        }
-        return MP_OK;
-    }
-    const uint32_t *W = (const uint32_t *)c->win;
-    for (int p = 0; p < 3; p++)
-        HIPCK(c, hipMemcpyAsync(out + (size_t)p * n, W + ((size_t)w * 3 + p) * np + row0, sizeof(uint32_t) * (size_t)n,
-                                hipMemcpyDeviceToHost, c->stream));
-    HIPCK(c, hipStreamSynchronize(c->stream));
+    if (n == 0) return MP_OK;
+    uint32_t *d_out = nullptr;
+    int rc;
+    if ((rc = dev_alloc(c, &d_out, (size_t)3 * n))) return rc;
+    hipLaunchKernelGGL(window_words_kernel, dim3((unsigned)((n + kBlock - 1) / kBlock)), dim3(kBlock), 0, c->stream, msa_args(c),
+                       c->p0 + w, c->k, row0, n, d_out);
+    hipError_t e = hipMemcpyAsync(out, d_out, sizeof(uint32_t) * 3 * (size_t)n, hipMemcpyDeviceToHost, c->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+    dev_free(c, &d_out, (size_t)3 * n);
+    if (e != hipSuccess) return fail(c, MP_ERR_DEVICE, "mp_get_window_words: %s", hipGetErrorString(e));
     return MP_OK;
 }
 

@@ -498,6 +498,13 @@ int mp_eval_timing(mp_ctx *c, int32_t reset, double *ms, int32_t *n) {
     return MP_OK;
 }
 
+int mp_eval_timing_samples(mp_ctx *c, int32_t cap, float *ms, int32_t *n) {
+    (void)cap; (void)ms;
+    if (!c || !n) return MP_ERR_ARG;
+    *n = 0;                      /* the oracle keeps totals only */
+    return MP_OK;
+}
+
 int mp_device_bytes(mp_ctx *c, int64_t *bytes) {
     if (!c || !bytes) return MP_ERR_ARG;
     *bytes = 0;
