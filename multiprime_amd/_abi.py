@@ -15,6 +15,7 @@ import numpy as np
 MP_MAX_K = 28
 MP_WIN_SKIP = 0x80000000
 MP_ERR_CAPACITY = -4
+MP_ERR_SHORT_WINDOW = -5
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 HIP_LIB = os.path.join(HERE, "csrc", "libmprime_hip.so")

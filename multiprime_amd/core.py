@@ -30,7 +30,7 @@ from statistics import mean
 import numpy as np
 
 from . import filters, host, iupac, msa, thermo
-from ._abi import Library
+from ._abi import MP_ERR_SHORT_WINDOW, Library, MprimeError
 
 _B2I = {"A": 0, "C": 1, "G": 2, "T": 3}
 
@@ -147,7 +147,17 @@ class NN_degenerate(object):
         keep = self.write_json if keep_tables is None else keep_tables
         row_base = self.comm.row0 if self.comm is not None else 0
         t0 = time.time()
-        n_ex = self.ctx.build_windows(p0, W, k, v)
+        try:
+            n_ex = self.ctx.build_windows(p0, W, k, v)
+        except MprimeError as e:
+            if e.code != MP_ERR_SHORT_WINDOW:
+                raise
+            # A row with fewer than k residues: V20:683-687 leaves its k-mer short and the reference dies with a ValueError in
+            # Y_distance (V20:230) as soon as an affected window reaches mis_primer_check (tests/golden/short_row.json).
+            # This build refuses the alignment up front: same exit status, a message instead of a traceback.
+            print("Error: {}. The reference fails on such an alignment too (ValueError in Y_distance); remove sequences with "
+                  "fewer than {} residues.".format(str(e).split(": ", 1)[-1], k))
+            sys.exit(1)
         ex_w, ex_r, ex_codes = self.ctx.get_exceptions(n_ex)
         if n_ex:
             # IUPAC k-mers with <= v gaps join the evaluated universe as their concrete expansions (V20:701-707)

@@ -1,4 +1,4 @@
-"""The N>1 path on CPU: world_size 2 and 3 over gloo, rows sharded across ranks, the CPU oracle
+"""The N>1 path on CPU: world_size 2, 3, 4 and 8 over gloo (even and uneven row splits), rows sharded across ranks, the CPU oracle
 standing in for the GPU behind the same C ABI.  Results must be identical to the single-process
 run, i.e. to the reference's own outputs."""
 import json
@@ -33,7 +33,9 @@ def _worker(rank, world, port, name, inp, out, lib_path):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("name,world", [("syn_iupac", 2), ("syn_ragged", 3), ("ivc_v1", 2), ("msa1000_k18_d64", 2)])
+# 1/2/4/8 shards incl. uneven splits: syn_iupac has 60 rows (8 ranks: 7 or 8 rows each), ivc_v1 166 (4 ranks: 41/42)
+@pytest.mark.parametrize("name,world", [("syn_iupac", 2), ("syn_ragged", 3), ("ivc_v1", 2), ("msa1000_k18_d64", 2),
+                                        ("syn_iupac", 8), ("ivc_v1", 4), ("syn_edge", 4), ("msa1000_k18_d64", 8)])
 def test_sharded_run_matches_reference(name, world, oracle_lib, tmp_path):
     from test_core_golden import check_outputs
     meta = load_gz_json(name + ".trace.json.gz")["meta"]

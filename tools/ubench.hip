@@ -158,8 +158,8 @@ int main() {
             best = std::min(best, time_ms(e0, e1));
         }
         const double bytes = (double)blocks * cs.passes * (double)cs.region_bytes;
-        printf("%s  {\"case\": \"%s\", \"region_bytes\": %zu, \"regions\": %d, \"ms\": %.4f, \"GBs\": %.1f}", first ? "" : ",\n",
-               cs.name, cs.region_bytes, cs.n_regions, best, bytes / (best * 1e-3) / 1e9);
+        printf("%s  {\"case\": \"%s\", \"region_bytes\": %zu, \"regions\": %d, \"bytes_per_launch\": %.0f, \"ms\": %.4f, \"GBs\": %.1f}",
+               first ? "" : ",\n", cs.name, cs.region_bytes, cs.n_regions, bytes, best, bytes / (best * 1e-3) / 1e9);
         first = false;
     }
     {   // HBM: 4 GiB read once, every workgroup its own contiguous slice
@@ -176,8 +176,8 @@ int main() {
             CK(hipEventSynchronize(e1));
             best = std::min(best, time_ms(e0, e1));
         }
-        printf(",\n  {\"case\": \"hbm_dwordx4\", \"region_bytes\": %zu, \"regions\": %d, \"ms\": %.4f, \"GBs\": %.1f}", rw * 4, blocks, best,
-               (double)blocks * rw * 4 / (best * 1e-3) / 1e9);
+        printf(",\n  {\"case\": \"hbm_dwordx4\", \"region_bytes\": %zu, \"regions\": %d, \"bytes_per_launch\": %.0f, \"ms\": %.4f, \"GBs\": %.1f}",
+               rw * 4, blocks, (double)blocks * rw * 4, best, (double)blocks * rw * 4 / (best * 1e-3) / 1e9);
     }
     printf("\n ]\n}\n");
     return 0;
