@@ -231,6 +231,24 @@ int mp_pair_coverage(mp_ctx *ctx, int32_t n_sets, int32_t n_words, const uint64_
 int mp_pcr_scan(mp_ctx *ctx, const uint8_t *bytes, const int64_t *row_off, int32_t n_rows, int32_t n_pairs,
                 const uint8_t *codes, const int32_t *off, int32_t *out);
 
+/* (8) k-mismatch primer-site scan — SURVEY §8f-3 ------------------------------------------------ */
+/* Replaces the mapping step of scripts/primer_coverage_validation_by_BWT_V9.py ("BWT": bowtie2 -N m -L 8 -a + samtools
+ * + the MD:Z filter of build_dict, BWT:264-300, 241-262) by an exhaustive ungapped scan.  bowtie2 and samtools are absent
+ * from this image, so the acceptance rule is a restatement, not a recorded behaviour (parity unpinned):
+ * `bytes`/`row_off` hold the reference sequences (upper-cased by the scan; any character outside ACGT mismatches every
+ * base, like bowtie2's N).  Pattern i = pat_codes[pat_off[i] .. pat_off[i+1]) is one CONCRETE primer expansion
+ * (codes 1,2,4,8; length 4..MP_DIMER_MAX_LEN).  For every sequence, start position p and strand s (0: the text reads the
+ * pattern, 1: the text reads its reverse complement — SAM flag 16) the ungapped alignment is a hit when
+ *   - it has at most max_mismatch mismatching positions (bowtie2 end-to-end, default scoring: the minimum score
+ *     -0.6 - 0.6 L with 6 per mismatch admits floor((0.6 + 0.6 L) / 6) mismatches; the host passes that or its override), and
+ *   - the last `term` positions of the alignment IN REFERENCE ORIENTATION all match: build_dict keeps an alignment when
+ *     the trailing match count of its MD:Z string is >= the 3'-term threshold, and applies the same test to the
+ *     reverse-strand file, where the end of the MD string is the primer's 5' end (quirk kept).
+ * hits[4h..] = {sequence, p, pattern, strand}; cap_hits / *n_hits as in mp_dimer_scan; order unspecified. */
+int mp_kmm_scan(mp_ctx *ctx, const uint8_t *bytes, const int64_t *row_off, int32_t n_rows, int32_t n_patterns,
+                const uint8_t *pat_codes, const int32_t *pat_off, int32_t max_mismatch, int32_t term, int64_t cap_hits,
+                int32_t *hits, int64_t *n_hits);
+
 /* Memory the context holds on the device, in bytes (window words, planes, tables). */
 int mp_device_bytes(mp_ctx *ctx, int64_t *bytes);
 

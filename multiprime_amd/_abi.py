@@ -50,6 +50,7 @@ SYMBOLS = [
     ("mp_dimer_pairs", C.c_int, [_p, C.c_int32, _p, _p, C.c_int64, _p, _p, _p, C.c_double, _p]),
     ("mp_pair_coverage", C.c_int, [_p, C.c_int32, C.c_int32, _p, _p, C.c_int64, _p, _p]),
     ("mp_pcr_scan", C.c_int, [_p, _p, _p, C.c_int32, C.c_int32, _p, _p, _p]),
+    ("mp_kmm_scan", C.c_int, [_p, _p, _p, C.c_int32, C.c_int32, _p, _p, C.c_int32, C.c_int32, C.c_int64, _p, C.POINTER(C.c_int64)]),
     ("mp_device_bytes", C.c_int, [_p, C.POINTER(C.c_int64)]),
 ]
 
@@ -299,6 +300,22 @@ class Context:
         out = np.full((max(n_pairs, 1), max(n_rows, 1), 4), -1, np.int32)
         self._ck(self.d.mp_pcr_scan(self.h, _ptr(data), _ptr(row_off), n_rows, n_pairs, _ptr(codes), _ptr(off), _ptr(out)))
         return out[:n_pairs, :n_rows]
+
+    def kmm_scan(self, data, row_off, pat_codes, pat_off, max_mismatch: int, term: int, cap: int = 1 << 20) -> np.ndarray:
+        """Hits [n][4] = (sequence, start, pattern, strand) of the k-mismatch primer-site scan, sorted."""
+        data = np.ascontiguousarray(data, dtype=np.uint8)
+        row_off = np.ascontiguousarray(row_off, dtype=np.int64)
+        pat_codes = np.ascontiguousarray(pat_codes, dtype=np.uint8)
+        pat_off = np.ascontiguousarray(pat_off, dtype=np.int32)
+        while True:
+            hits = np.empty((max(cap, 1), 4), np.int32)
+            n = C.c_int64(0)
+            self._ck(self.d.mp_kmm_scan(self.h, _ptr(data), _ptr(row_off), len(row_off) - 1, len(pat_off) - 1, _ptr(pat_codes),
+                                        _ptr(pat_off), int(max_mismatch), int(term), cap, _ptr(hits), C.byref(n)))
+            if n.value <= cap:
+                h = hits[: n.value]
+                return h[np.lexsort((h[:, 3], h[:, 2], h[:, 1], h[:, 0]))] if len(h) else h
+            cap = int(n.value)
 
     def device_bytes(self) -> int:
         b = C.c_int64(0)

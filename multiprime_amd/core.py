@@ -374,7 +374,7 @@ class NN_degenerate(object):
                 packed.append(np.packbits(pad, axis=1, bitorder="little").view(np.uint64).reshape(n_out, nw))
         else:
             n_total = n_local
-            packed = [np.array(nf, np.uint64), np.array(nr, np.uint64)]
+            packed = [nf, nr]                           # fresh host arrays of this call: patched in place below
 
         def put(which, i, row, value):
             word, bit = row >> 6, np.uint64(1) << np.uint64(row & 63)
@@ -412,8 +412,10 @@ class NN_degenerate(object):
                         put(1, i, r_glob, bad_r)
         if self.comm is not None and self.comm.rank != 0:
             return
+        # ids as the raw bytes of the file + offsets (bitset_ids() decodes them): 10^6 Python strings cost more than the masks
+        ids_bytes, ids_off = self._fasta.ids_raw()
         np.savez(self.outfile + ".coverage_bitsets.npz", positions=np.asarray([int(r[0]) for r in rows_out], np.int64),
-                 not_f=packed[0], not_r=packed[1], n_seq=np.int64(n_total), ids=np.asarray(self.seq_ids))
+                 not_f=packed[0], not_r=packed[1], n_seq=np.int64(n_total), ids_bytes=ids_bytes, ids_off=ids_off)
 
     def _write(self, rows_out, non_cov_out, gap_out):
         with open(self.outfile, "w") as fo:                                        # V20:1148-1170
@@ -425,3 +427,9 @@ class NN_degenerate(object):
                 _dump_side_file(non_cov_out, fj, True)
             with open(self.outfile + ".gap_seq_id_json", "w") as fg:               # V20:1175-1176
                 _dump_side_file(gap_out, fg, False)
+
+
+def bitset_ids(z):
+    """Sequence ids of a `.coverage_bitsets.npz` (np.load result), in bit order."""
+    raw, off = z["ids_bytes"].tobytes(), z["ids_off"].tolist()
+    return [raw[a:b].decode("utf-8", errors="surrogateescape") for a, b in zip(off[:-1], off[1:])]

@@ -39,6 +39,7 @@ void free_windows(mp_ctx *c) {
     dev_free(c, &c->patch_off, (size_t)c->n_win + 1);
     dev_free(c, &c->patch_cursor, (size_t)c->n_win);
     dev_free(c, &c->patch_words, (size_t)3 * c->n_patch);
+    dev_free(c, &c->patch_rows, (size_t)c->n_patch);
     c->n_patch = c->max_patch = 0;
     dev_free(c, &c->ex, (size_t)c->ex_cap);
     dev_free(c, &c->ex_count, 1);

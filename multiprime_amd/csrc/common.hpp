@@ -83,7 +83,8 @@ struct mp_ctx {
     int p0 = 0, n_win = 0, k = 0, v = 0;
     unsigned long long *excl = nullptr;      // [W][n_pad/64]; non-null = windows are built
     int32_t *patch_count = nullptr, *patch_off = nullptr, *patch_cursor = nullptr;
-    uint32_t *patch_words = nullptr;
+    uint32_t *patch_words = nullptr;         // [n_patch][3] window words of the slow pairs (SKIP = exception / too short)
+    int32_t *patch_rows = nullptr;           // [n_patch] their rows, grouped by window like patch_words
     int n_patch = 0, max_patch = 0;
     bool p64 = false;                        // 3k <= 63: histogram keys are one packed u64
     mp::ExRec *ex = nullptr;

@@ -1,0 +1,164 @@
+// scan.hip — part of libmprime_hip.so: hand-written HIP (gfx950 / MI355X, wave64) behind the C ABI of include/mprime.h.
+// (8) k-mismatch primer-site scan over unaligned sequences (mp_kmm_scan) — the GPU replacement of the bowtie2 + samtools
+// mapping step of scripts/primer_coverage_validation_by_BWT_V9.py (BWT:264-300) and of its MD:Z filter (BWT:241-262).
+//
+// Shape: a workgroup owns one segment of one sequence.  It packs the segment once into LDS — 2 bits per base plus a
+// "never matches" bit for everything outside ACGT — and every thread then slides over its start positions: the 32-base
+// window at a position is two LDS words and a funnel shift, and one pattern costs an XOR, a fold of the two bits of each
+// base, a mask, a popcount and two compares.  The pattern table (code word, length mask, trailing-run mask per strand) is
+// wave-uniform and arrives through scalar loads.  HBM traffic is the text once (1 byte per base); the work is integer VALU:
+// ~10 wave-instructions per (64 positions, pattern).
+#include "common.hpp"
+
+using namespace mp;
+
+namespace {
+
+constexpr int kSeg = 8192;                       // start positions per workgroup
+constexpr int kSegWords = kSeg / 32 + 2;         // 64-bit words of 32 bases, with the 32-base overhang
+
+struct KmmPat {
+    unsigned long long word;      // base j of the aligned text at bits 2j (A0 C1 G2 T3)
+    unsigned long long lenmask;   // bit 2j set for j < len
+    unsigned long long termmask;  // bit 2j set for the last `term` positions in reference orientation (all of lenmask if term > len)
+    int32_t len, id, strand, never;   // never: term > len — the trailing match run cannot reach the threshold
+};
+
+__global__ __launch_bounds__(kBlock) void kmm_kernel(const uint8_t *__restrict__ bytes, const int64_t *__restrict__ row_off,
+                                                     const int32_t *__restrict__ blk_row, const int32_t *__restrict__ blk_seg,
+                                                     const KmmPat *__restrict__ pats, int n_pats, int max_mm, long long cap,
+                                                     int32_t *__restrict__ hits, unsigned long long *__restrict__ n_hits) {
+    __shared__ unsigned long long s_b[kSegWords];      // 2-bit codes
+    __shared__ unsigned long long s_n[kSegWords];      // 0b01 at positions that match nothing (non-ACGT, past the end)
+    const int row = blk_row[blockIdx.x], seg = blk_seg[blockIdx.x];
+    const uint8_t *s = bytes + row_off[row];
+    const long long len = row_off[row + 1] - row_off[row];
+    const long long base = (long long)seg * kSeg;
+    // pack: thread t builds word t (32 bases)
+    for (int w = threadIdx.x; w < kSegWords; w += kBlock) {
+        unsigned long long b = 0, n = 0;
+        const long long p0 = base + (long long)w * 32;
+        for (int j = 0; j < 32; j++) {
+            const long long p = p0 + j;
+            unsigned long long code = 0, bad = 1;
+            if (p < len) {
+                uint8_t ch = s[p];
+                if (ch >= 'a' && ch <= 'z') ch -= 32;
+                if (ch == 'A') { code = 0; bad = 0; }
+                else if (ch == 'C') { code = 1; bad = 0; }
+                else if (ch == 'G') { code = 2; bad = 0; }
+                else if (ch == 'T') { code = 3; bad = 0; }
+            }
+            b |= code << (2 * j);
+            n |= bad << (2 * j);
+        }
+        s_b[w] = b;
+        s_n[w] = n;
+    }
+    __syncthreads();
+    const unsigned long long kOdd = 0x5555555555555555ull;
+    for (int q = threadIdx.x; q < kSeg; q += kBlock) {
+        const long long p = base + q;
+        if (p >= len) break;
+        const int w = q >> 5, sh = (q & 31) * 2;
+        unsigned long long win = s_b[w] >> sh, nw = s_n[w] >> sh;
+        if (sh) { win |= s_b[w + 1] << (64 - sh); nw |= s_n[w + 1] << (64 - sh); }
+        for (int i = 0; i < n_pats; i++) {
+            const KmmPat P = pats[i];                   // uniform index: scalar loads
+            const unsigned long long x = win ^ P.word;
+            const unsigned long long mm = (((x | (x >> 1)) & kOdd) | nw) & P.lenmask;
+            if ((int)__popcll(mm) <= max_mm && (mm & P.termmask) == 0 && !P.never && p + P.len <= len) {
+                const unsigned long long idx = atomicAdd(n_hits, 1ull);
+                if ((long long)idx < cap) {
+                    hits[4 * idx] = row; hits[4 * idx + 1] = (int32_t)p; hits[4 * idx + 2] = P.id; hits[4 * idx + 3] = P.strand;
+                }
+            }
+        }
+    }
+}
+
+}  // namespace
+
+extern "C" {
+
+int mp_kmm_scan(mp_ctx *c, const uint8_t *bytes, const int64_t *row_off, int32_t n_rows, int32_t n_pat, const uint8_t *pat_codes,
+                const int32_t *pat_off, int32_t max_mm, int32_t term, int64_t cap, int32_t *hits, int64_t *n_hits) {
+    if (!c) return MP_ERR_ARG;
+    if (n_rows < 0 || n_pat < 0 || !n_hits || cap < 0 || (cap && !hits) || (n_rows && (!bytes || !row_off)) ||
+        (n_pat && (!pat_codes || !pat_off)) || max_mm < 0 || term < 0)
+        return fail(c, MP_ERR_ARG, "mp_kmm_scan: bad arguments");
+    HIPCK(c, hipSetDevice(c->dev));
+    *n_hits = 0;
+    if (n_rows == 0 || n_pat == 0) return MP_OK;
+    std::vector<KmmPat> pats;
+    for (int32_t i = 0; i < n_pat; i++) {
+        const int len = pat_off[i + 1] - pat_off[i];
+        if (len < 4 || len > MP_DIMER_MAX_LEN) return fail(c, MP_ERR_ARG, "pattern %d has length %d (4..%d supported)", i, len, MP_DIMER_MAX_LEN);
+        int b[MP_DIMER_MAX_LEN];
+        for (int j = 0; j < len; j++) {
+            const uint8_t m = pat_codes[pat_off[i] + j];
+            if (m != 1 && m != 2 && m != 4 && m != 8) return fail(c, MP_ERR_ARG, "pattern %d is not a concrete A/C/G/T sequence", i);
+            b[j] = m == 1 ? 0 : m == 2 ? 1 : m == 4 ? 2 : 3;
+        }
+        for (int strand = 0; strand < 2; strand++) {
+            KmmPat P{};
+            for (int j = 0; j < len; j++) {
+                const int code = strand == 0 ? b[j] : 3 - b[len - 1 - j];      // the text reads the pattern / its reverse complement
+                P.word |= (unsigned long long)code << (2 * j);
+                P.lenmask |= 1ull << (2 * j);
+                if (j >= len - term) P.termmask |= 1ull << (2 * j);
+            }
+            P.len = len; P.id = i; P.strand = strand; P.never = term > len;
+            pats.push_back(P);
+        }
+    }
+    std::vector<int32_t> blk_row, blk_seg;
+    for (int32_t r = 0; r < n_rows; r++) {
+        const int64_t len = row_off[r + 1] - row_off[r];
+        if (len < 0 || len > 0x7fffffffLL) return fail(c, MP_ERR_ARG, "sequence %d has bad length", r);
+        for (int64_t sgm = 0; sgm * kSeg < len; sgm++) { blk_row.push_back(r); blk_seg.push_back((int32_t)sgm); }
+    }
+    if (blk_row.empty()) return MP_OK;
+    const size_t total = (size_t)(row_off[n_rows] - row_off[0]), nb = blk_row.size();
+    uint8_t *d_bytes = nullptr;
+    int64_t *d_roff = nullptr;
+    int32_t *d_brow = nullptr, *d_bseg = nullptr, *d_hits = nullptr;
+    KmmPat *d_pats = nullptr;
+    unsigned long long *d_n = nullptr;
+    const size_t hcap = (size_t)std::max<int64_t>(cap, 1) * 4;
+    int rc = MP_OK;
+    auto cleanup = [&]() {
+        dev_free(c, &d_bytes, total + 16); dev_free(c, &d_roff, (size_t)n_rows + 1); dev_free(c, &d_brow, nb); dev_free(c, &d_bseg, nb);
+        dev_free(c, &d_hits, hcap); dev_free(c, &d_pats, pats.size()); dev_free(c, &d_n, 1);
+    };
+    std::vector<int64_t> roff((size_t)n_rows + 1);
+    for (int32_t r = 0; r <= n_rows; r++) roff[(size_t)r] = row_off[r] - row_off[0];
+    hipError_t e = hipSuccess;
+    if ((rc = dev_alloc(c, &d_bytes, total + 16)) || (rc = dev_alloc(c, &d_roff, (size_t)n_rows + 1)) || (rc = dev_alloc(c, &d_brow, nb)) ||
+        (rc = dev_alloc(c, &d_bseg, nb)) || (rc = dev_alloc(c, &d_hits, hcap)) || (rc = dev_alloc(c, &d_pats, pats.size())) ||
+        (rc = dev_alloc(c, &d_n, 1))) { cleanup(); return rc; }
+    if (e == hipSuccess) e = hipMemcpyAsync(d_bytes, bytes + row_off[0], total, hipMemcpyHostToDevice, c->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(d_roff, roff.data(), sizeof(int64_t) * roff.size(), hipMemcpyHostToDevice, c->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(d_brow, blk_row.data(), sizeof(int32_t) * nb, hipMemcpyHostToDevice, c->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(d_bseg, blk_seg.data(), sizeof(int32_t) * nb, hipMemcpyHostToDevice, c->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(d_pats, pats.data(), sizeof(KmmPat) * pats.size(), hipMemcpyHostToDevice, c->stream);
+    if (e == hipSuccess) e = hipMemsetAsync(d_n, 0, sizeof(unsigned long long), c->stream);
+    if (e == hipSuccess) {
+        hipLaunchKernelGGL(kmm_kernel, dim3((unsigned)nb), dim3(kBlock), 0, c->stream, d_bytes, d_roff, d_brow, d_bseg, d_pats,
+                           (int)pats.size(), (int)max_mm, (long long)cap, d_hits, d_n);
+        e = hipGetLastError();
+    }
+    unsigned long long n = 0;
+    if (e == hipSuccess) e = hipMemcpyAsync(&n, d_n, sizeof n, hipMemcpyDeviceToHost, c->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+    if (e == hipSuccess && cap) {
+        const size_t got = (size_t)std::min<unsigned long long>(n, (unsigned long long)cap);
+        if (got) e = hipMemcpy(hits, d_hits, sizeof(int32_t) * 4 * got, hipMemcpyDeviceToHost);
+    }
+    cleanup();
+    if (e != hipSuccess) return fail(c, MP_ERR_DEVICE, "mp_kmm_scan: %s", hipGetErrorString(e));
+    *n_hits = (int64_t)n;
+    return MP_OK;
+}
+
+}  // extern "C"

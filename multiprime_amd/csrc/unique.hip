@@ -45,6 +45,9 @@ struct HistArgs {
     int g_slots;
     int32_t *g_used;                      // [W] occupied slots
     int32_t *g_over;                      // [W] 1 = the global table of the window is too small
+    const int32_t *patch_off;             // [W+1] slow pairs of every window (mp_build_windows): rows and window words
+    const int32_t *patch_rows;
+    const uint32_t *patch_words;
 };
 
 // merge one (key, count, first row) into the window's global table
@@ -125,12 +128,10 @@ __global__ __launch_bounds__(kBlock) void hist_kernel(const HistArgs A) {
         unsigned long long key = kNoKey;
         if (r < A.M.n_rows) {
             uint32_t b0, b1, g;
-            bool fast;
-            Nib buf;
-            int rc = words_from_planes(A.M, r, p, k, kmask, len, cw[0], cw[1], cw[2], cw[3], cw[4], cw[5], cw[6], cw[7], b0, b1, g, fast, buf);
-            if (rc == 0) {
+            // plain column slices only: the repaired / IUPAC / ragged rows of the window come from the patch list below
+            if (fast_words(p, k, kmask, len, cw[0], cw[1], cw[2], cw[3], cw[4], cw[5], cw[6], cw[7], b0, b1, g)) {
                 todo = true;
-                key = (unsigned long long)b0 | ((unsigned long long)b1 << k) | ((unsigned long long)(g & kmask) << (2 * k));
+                key = (unsigned long long)b0 | ((unsigned long long)b1 << k) | ((unsigned long long)g << (2 * k));
             }
         }
         // fold the first lane's k-mer over the wave, then every other distinct lane inserts its own
@@ -158,6 +159,33 @@ __global__ __launch_bounds__(kBlock) void hist_kernel(const HistArgs A) {
             __syncthreads();
             if (threadIdx.x == 0) s_used = 0;
             __syncthreads();
+        }
+    }
+    if (slice == 0 && A.patch_off) {
+        // the window's slow pairs (edge-gap repair, ragged end): their k-mers were derived once by repair_kernel
+        const int e0 = A.patch_off[w], e1 = A.patch_off[w + 1];
+        for (int eb = e0; eb < e1; eb += kBlock) {
+            const int e = eb + threadIdx.x;
+            if (e < e1) {
+                const uint32_t b0 = A.patch_words[3 * (size_t)e], b1 = A.patch_words[3 * (size_t)e + 1], g = A.patch_words[3 * (size_t)e + 2];
+                if (!(g & MP_WIN_SKIP)) {
+                    const unsigned long long key = (unsigned long long)b0 | ((unsigned long long)b1 << k) | ((unsigned long long)(g & kmask) << (2 * k));
+                    uint32_t h = hash64(key) & (kLdsSlots - 1);
+                    for (;;) {
+                        unsigned long long old = atomicCAS(&s_key[h], kNoKey, key);
+                        if (old == kNoKey) { atomicAdd(&s_used, 1); old = key; }
+                        if (old == key) { atomicAdd(&s_cnt[h], 1u); atomicMin(&s_min[h], (uint32_t)A.patch_rows[e]); break; }
+                        h = (h + 1) & (kLdsSlots - 1);
+                    }
+                }
+            }
+            __syncthreads();
+            if (s_used > kLdsLimit) {
+                flush();
+                __syncthreads();
+                if (threadIdx.x == 0) s_used = 0;
+                __syncthreads();
+            }
         }
     }
     flush();
@@ -387,7 +415,8 @@ int unique_packed(mp_ctx *c, int64_t cap, int32_t want_labels, int64_t *n_entrie
         HIPCK(c, hipMemsetAsync(c->g_min, 0xFF, sizeof(uint32_t) * n, c->stream));
         HIPCK(c, hipMemsetAsync(c->u_wcount, 0, sizeof(int32_t) * W, c->stream));
         HIPCK(c, hipMemsetAsync(c->u_over, 0, sizeof(int32_t) * W, c->stream));
-        HistArgs A{msa_args(c), c->p0, c->k, c->n_win, 0, 0, 0, c->g_key, c->g_cnt, c->g_min, slots, c->u_wcount, c->u_over};
+        HistArgs A{msa_args(c), c->p0, c->k, c->n_win, 0, 0, 0, c->g_key, c->g_cnt, c->g_min, slots, c->u_wcount, c->u_over,
+                   c->n_patch ? c->patch_off : (const int32_t *)nullptr, c->patch_rows, c->patch_words};
         // enough workgroups to fill 256 CUs several times over, slices of at least 4096 rows
         int n_slices = (int)std::max<size_t>(1, std::min<size_t>((np + 4095) / 4096, (8192 + W - 1) / W));
         if (const char *e = getenv("MP_HIST_SLICES")) n_slices = std::max(1, atoi(e));

@@ -11,28 +11,29 @@ namespace {
 // (2) window k-mers with edge-gap repair (V20:666-687)
 // ----------------------------------------------------------------------------------------------
 // Rows whose k-mer is NOT the plain column slice (edge-gap repair, IUPAC, ragged end) are flagged per
-// (window, 64-row word) in `excl` and collected, per window, in a compact patch list of window words:
-// the bit-sliced evaluation skips them, the row-per-lane evaluation handles exactly them.  `excl` also
-// carries the plain rows with more than v gaps in the window (outside every count, V20:689) and the
-// padding rows, so the bit-sliced kernels need no gap bookkeeping of their own.
-// pass 0 writes the window words, the flags and the per-window patch counts; pass 1 (same
-// computation) fills the patch list once the host has turned the counts into offsets.
+// (window, 64-row word) in `excl` and collected, per window, in a compact patch list {row, window words}:
+// the bit-sliced kernels skip them in the column planes and meet them again in the patch planes; the histograms take
+// them from the list.  `excl` also carries the plain rows with more than v gaps in the window (outside every count,
+// V20:689) and the padding rows, so the bit-sliced kernels need no gap bookkeeping of their own.
+//
+// Two kernels.  classify_kernel (thread = row, workgroup = 256 rows x a tile of consecutive windows; the 32-column plane
+// words slide in registers, so every plane word is read once per tile) only tells plain slices from the rest — 4 funnel
+// shifts and a dozen logic ops per (window, row), no divergence; pass 0 writes `excl` and counts the slow pairs per
+// window, pass 1 (offsets known) lists them.  repair_kernel then gives every slow pair a lane of its own for the
+// line-by-line restatement of V20:668-687.  (Round 1 and the first round-2 version ran the repair inside the sliding
+// loop: a quarter of the (wave, window) steps had one lane in the repair path and 63 waiting — 1.36 ms per pass at
+// 131072 x 1000; see profiles/r02_bench_eval.txt.)
 struct PatchOut {
     int pass;
     unsigned long long *excl;     // [W][Npad/64]
     int32_t *count;               // [W]
     const int32_t *off;           // [W+1]   (pass 1)
     int32_t *cursor;              // [W]     (pass 1)
-    uint32_t *words;              // [n][3]  (pass 1)
+    int32_t *rows;                // [n]     (pass 1) row of every slow pair, grouped by window
+    int32_t *wins;                // [n]     (pass 1) its window
 };
 
-// thread = row, workgroup = 256 rows x a tile of consecutive windows; the 32-column plane words slide in registers, so
-// every plane word is read once per tile.  Nothing is stored per (window, row) any more: the kernel classifies each
-// k-mer (plain column slice / repaired / IUPAC exception / too short) and writes the 1-bit-per-pair `excl` flags, the
-// patch list of the repaired k-mers and the exception list.
-__global__ __launch_bounds__(kBlock) void scan_windows_kernel(const MsaArgs M, int p0, int n_win, int tile, int k, int v,
-                                                              ExRec *__restrict__ ex, int ex_cap, int *__restrict__ ex_count,
-                                                              int *__restrict__ err, PatchOut po) {
+__global__ __launch_bounds__(kBlock) void classify_kernel(const MsaArgs M, int p0, int n_win, int tile, int k, int v, PatchOut po) {
     int r = blockIdx.x * kBlock + threadIdx.x;
     if (r >= M.n_pad) return;
     const int n_rows = M.n_rows;
@@ -48,6 +49,9 @@ __global__ __launch_bounds__(kBlock) void scan_windows_kernel(const MsaArgs M, i
         return;
     }
     const int len = M.rlen[r];
+    const int lane = threadIdx.x & 63;
+    const unsigned long long live = __ballot(true);          // the lanes of a wave that are still here are all real rows
+    const int leader = __ffsll((long long)live) - 1;
     int cur = -1;
     uint32_t loA = 0, loC = 0, loG = 0, loT = 0, hiA = 0, hiC = 0, hiG = 0, hiT = 0;
     for (int w = w0; w < w1; w++) {
@@ -62,44 +66,52 @@ __global__ __launch_bounds__(kBlock) void scan_windows_kernel(const MsaArgs M, i
             cur = c;
         }
         uint32_t b0, b1, g;
-        bool fast;
-        Nib buf;
-        int rc = words_from_planes(M, r, p, k, kmask, len, loA, loC, loG, loT, hiA, hiC, hiG, hiT, b0, b1, g, fast, buf);
-        if (rc == 1) {
-            if (po.pass == 0) {
-                int idx = atomicAdd(ex_count, 1);
-                if (idx < ex_cap) { ex[idx].win = w; ex[idx].row = r; ex[idx].lo = buf.lo; ex[idx].hi = buf.hi; }
+        const bool fast = fast_words(p, k, kmask, len, loA, loC, loG, loT, hiA, hiC, hiG, hiT, b0, b1, g);
+        const unsigned long long slow = __ballot(!fast);
+        if (po.pass == 0) {
+            const unsigned long long flg = __ballot(!fast || (int)__popc(g) > v) | ~real;
+            if (lane == leader) {
+                po.excl[(size_t)w * (np / 64) + (size_t)(r >> 6)] = flg;
+                if (slow) atomicAdd(&po.count[w], (int)__popcll(slow));
             }
-            b0 = 0; b1 = 0; g = MP_WIN_SKIP | kmask;
-        } else if (rc == 2) {
-            atomicMax(err, 1);
-            err[1] = w; err[2] = r;
-            b0 = 0; b1 = 0; g = MP_WIN_SKIP | kmask;
-        }
-        {
-            // flags and patch list; the lanes of a wave that are still here are all real rows
-            const unsigned long long live = __ballot(true);
-            const unsigned long long flg = __ballot(!fast || (int)__popc(g & kmask) > v) | ~real;
-            const bool keep = !fast && !(g & MP_WIN_SKIP);
-            const unsigned long long kp = __ballot(keep);
-            const int lane = threadIdx.x & 63;
-            const int leader = __ffsll((long long)live) - 1;
-            if (po.pass == 0) {
-                if (lane == leader) {
-                    po.excl[(size_t)w * (np / 64) + (size_t)(r >> 6)] = flg;
-                    if (kp) atomicAdd(&po.count[w], (int)__popcll(kp));
-                }
-            } else if (kp) {
-                int base = 0;
-                if (lane == leader) base = atomicAdd(&po.cursor[w], (int)__popcll(kp));
-                base = __shfl(base, leader);
-                if (keep) {
-                    int slot = po.off[w] + base + (int)__popcll(kp & ((1ull << lane) - 1ull));
-                    po.words[3 * (size_t)slot] = b0; po.words[3 * (size_t)slot + 1] = b1; po.words[3 * (size_t)slot + 2] = g;
-                }
+        } else if (slow) {
+            int base = 0;
+            if (lane == leader) base = atomicAdd(&po.cursor[w], (int)__popcll(slow));
+            base = __shfl(base, leader);
+            if (!fast) {
+                const int slot = po.off[w] + base + (int)__popcll(slow & ((1ull << lane) - 1ull));
+                po.rows[slot] = r;
+                po.wins[slot] = w;
             }
         }
     }
+}
+
+// thread = one slow (window, row) pair: V20:668-687 line by line (winwords.hpp).  Writes the pair's window words (SKIP when the
+// k-mer holds an IUPAC code or the row is too short), appends IUPAC k-mers to the exception list, raises the short-row flag.
+__global__ __launch_bounds__(kBlock) void repair_kernel(const MsaArgs M, int p0, int k, int n, const int32_t *__restrict__ rows,
+                                                        const int32_t *__restrict__ wins, uint32_t *__restrict__ words,
+                                                        ExRec *__restrict__ ex, int *__restrict__ ex_count, int *__restrict__ err) {
+    const int e = blockIdx.x * kBlock + threadIdx.x;
+    if (e >= n) return;
+    const int r = rows[e], w = wins[e], p = p0 + w;
+    const uint32_t kmask = (1u << k) - 1u;
+    const size_t np = (size_t)M.n_pad;
+    const uint32_t *P = M.planes + ((size_t)(p >> 5) * 4) * np + r;
+    uint32_t b0, b1, g;
+    Nib buf;
+    const int rc = slow_words(M, r, p, k, kmask, M.rlen[r], P[0], P[np], P[2 * np], P[3 * np], P[4 * np], P[5 * np], P[6 * np], P[7 * np],
+                              b0, b1, g, buf);
+    if (rc == 1) {
+        const int idx = atomicAdd(ex_count, 1);
+        ex[idx].win = w; ex[idx].row = r; ex[idx].lo = buf.lo; ex[idx].hi = buf.hi;      // capacity = n: cannot overflow
+        b0 = 0; b1 = 0; g = MP_WIN_SKIP | kmask;
+    } else if (rc == 2) {
+        atomicMax(err, 1);
+        err[1] = w; err[2] = r;
+        b0 = 0; b1 = 0; g = MP_WIN_SKIP | kmask;
+    }
+    words[3 * (size_t)e] = b0; words[3 * (size_t)e + 1] = b1; words[3 * (size_t)e + 2] = g;
 }
 
 // parity / debug: window words of rows [row0, row0 + n) of one window, derived on the fly
@@ -138,65 +150,66 @@ int mp_build_windows(mp_ctx *c, int32_t p0, int32_t n_win, int32_t k, int32_t v,
     if ((rc = dev_alloc(c, &c->patch_count, (size_t)n_win))) return rc;
     if ((rc = dev_alloc(c, &c->patch_off, (size_t)n_win + 1))) return rc;
     if ((rc = dev_alloc(c, &c->patch_cursor, (size_t)n_win))) return rc;
-    int cap = 1 << 16;
     const int tile = 64;
     const dim3 grid((unsigned)(c->n_pad / kBlock), (unsigned)((n_win + tile - 1) / tile));
     const MsaArgs M = msa_args(c);
-    auto launch = [&](const PatchOut &po, int ex_cap) {
-        hipLaunchKernelGGL(scan_windows_kernel, grid, dim3(kBlock), 0, c->stream, M, p0, n_win, tile, k, v, c->ex, ex_cap, c->ex_count,
-                           c->err_flag, po);
-    };
-    for (int attempt = 0; attempt < 2; attempt++) {
-        if ((rc = dev_alloc(c, &c->ex, (size_t)cap))) return rc;
-        c->ex_cap = cap;
-        HIPCK(c, hipMemsetAsync(c->ex_count, 0, sizeof(int), c->stream));
-        HIPCK(c, hipMemsetAsync(c->err_flag, 0, 4 * sizeof(int), c->stream));
-        HIPCK(c, hipMemsetAsync(c->excl, 0, sizeof(unsigned long long) * (size_t)n_win * nw, c->stream));
-        HIPCK(c, hipMemsetAsync(c->patch_count, 0, sizeof(int32_t) * (size_t)n_win, c->stream));
-        launch(PatchOut{0, c->excl, c->patch_count, nullptr, nullptr, nullptr}, cap);
-        HIPCK(c, hipGetLastError());
+    HIPCK(c, hipMemsetAsync(c->ex_count, 0, sizeof(int), c->stream));
+    HIPCK(c, hipMemsetAsync(c->err_flag, 0, 4 * sizeof(int), c->stream));
+    HIPCK(c, hipMemsetAsync(c->excl, 0, sizeof(unsigned long long) * (size_t)n_win * nw, c->stream));
+    HIPCK(c, hipMemsetAsync(c->patch_count, 0, sizeof(int32_t) * (size_t)n_win, c->stream));
+    hipLaunchKernelGGL(classify_kernel, grid, dim3(kBlock), 0, c->stream, M, p0, n_win, tile, k, v,
+                       PatchOut{0, c->excl, c->patch_count, nullptr, nullptr, nullptr, nullptr});
+    HIPCK(c, hipGetLastError());
+    // slow pairs per window -> offsets on the host, then the listing pass and the repair
+    std::vector<int32_t> pc((size_t)n_win), po((size_t)n_win + 1, 0);
+    HIPCK(c, hipMemcpyAsync(pc.data(), c->patch_count, sizeof(int32_t) * (size_t)n_win, hipMemcpyDeviceToHost, c->stream));
+    HIPCK(c, hipStreamSynchronize(c->stream));
+    long long tot = 0;
+    c->max_patch = 0;
+    for (int w = 0; w < n_win; w++) {
+        po[(size_t)w] = (int32_t)tot;
+        tot += pc[(size_t)w];
+        c->max_patch = std::max(c->max_patch, (int)pc[(size_t)w]);
+    }
+    if (tot > 0x7fffffffLL / 4) return fail(c, MP_ERR_NOMEM, "patch list too large (%lld rows)", tot);
+    po[(size_t)n_win] = (int32_t)tot;
+    c->n_patch = (int)tot;
+    HIPCK(c, hipMemcpyAsync(c->patch_off, po.data(), sizeof(int32_t) * po.size(), hipMemcpyHostToDevice, c->stream));
+    c->h_patch_off = po;
+    c->h_extra_off.assign((size_t)n_win + 1, 0);
+    c->pp_dirty = true;
+    c->ex_host.clear();
+    if (n_exc) *n_exc = 0;
+    if (tot) {
+        int32_t *d_wins = nullptr;
+        if ((rc = dev_alloc(c, &c->patch_words, (size_t)3 * (size_t)tot))) return rc;
+        if ((rc = dev_alloc(c, &c->patch_rows, (size_t)tot))) return rc;
+        if ((rc = dev_alloc(c, &d_wins, (size_t)tot))) return rc;
+        if ((rc = dev_alloc(c, &c->ex, (size_t)tot))) { dev_free(c, &d_wins, (size_t)tot); return rc; }
+        c->ex_cap = (int)tot;
+        hipError_t e = hipMemsetAsync(c->patch_cursor, 0, sizeof(int32_t) * (size_t)n_win, c->stream);
         int cnt = 0, errv[4] = {0, 0, 0, 0};
-        HIPCK(c, hipMemcpyAsync(&cnt, c->ex_count, sizeof(int), hipMemcpyDeviceToHost, c->stream));
-        HIPCK(c, hipMemcpyAsync(errv, c->err_flag, 4 * sizeof(int), hipMemcpyDeviceToHost, c->stream));
-        HIPCK(c, hipStreamSynchronize(c->stream));
+        if (e == hipSuccess) {
+            hipLaunchKernelGGL(classify_kernel, grid, dim3(kBlock), 0, c->stream, M, p0, n_win, tile, k, v,
+                               PatchOut{1, c->excl, c->patch_count, c->patch_off, c->patch_cursor, c->patch_rows, d_wins});
+            hipLaunchKernelGGL(repair_kernel, dim3((unsigned)((tot + kBlock - 1) / kBlock)), dim3(kBlock), 0, c->stream, M, p0, k, (int)tot,
+                               (const int32_t *)c->patch_rows, (const int32_t *)d_wins, c->patch_words, c->ex, c->ex_count, c->err_flag);
+            e = hipGetLastError();
+        }
+        if (e == hipSuccess) e = hipMemcpyAsync(&cnt, c->ex_count, sizeof(int), hipMemcpyDeviceToHost, c->stream);
+        if (e == hipSuccess) e = hipMemcpyAsync(errv, c->err_flag, 4 * sizeof(int), hipMemcpyDeviceToHost, c->stream);
+        if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+        dev_free(c, &d_wins, (size_t)tot);
+        if (e != hipSuccess) return fail(c, MP_ERR_DEVICE, "mp_build_windows: %s", hipGetErrorString(e));
         if (errv[0])
             return fail(c, MP_ERR_SHORT_WINDOW, "row %d has fewer than %d residues at window %d", errv[2], k, p0 + errv[1]);
-        if (cnt <= cap) {
-            c->ex_host.resize((size_t)cnt);
-            if (cnt) HIPCK(c, hipMemcpy(c->ex_host.data(), c->ex, sizeof(ExRec) * (size_t)cnt, hipMemcpyDeviceToHost));
-            std::sort(c->ex_host.begin(), c->ex_host.end(),
-                      [](const ExRec &a, const ExRec &b) { return a.win != b.win ? a.win < b.win : a.row < b.row; });
-            if (n_exc) *n_exc = cnt;
-            // patch list: counts -> offsets on the host, then the fill pass
-            std::vector<int32_t> pc((size_t)n_win), po((size_t)n_win + 1, 0);
-            HIPCK(c, hipMemcpy(pc.data(), c->patch_count, sizeof(int32_t) * (size_t)n_win, hipMemcpyDeviceToHost));
-            long long tot = 0;
-            c->max_patch = 0;
-            for (int w = 0; w < n_win; w++) {
-                po[(size_t)w] = (int32_t)tot;
-                tot += pc[(size_t)w];
-                c->max_patch = std::max(c->max_patch, (int)pc[(size_t)w]);
-            }
-            if (tot > 0x7fffffffLL / 4) return fail(c, MP_ERR_NOMEM, "patch list too large (%lld rows)", tot);
-            po[(size_t)n_win] = (int32_t)tot;
-            c->n_patch = (int)tot;
-            HIPCK(c, hipMemcpy(c->patch_off, po.data(), sizeof(int32_t) * po.size(), hipMemcpyHostToDevice));
-            c->h_patch_off = po;
-            c->h_extra_off.assign((size_t)n_win + 1, 0);
-            c->pp_dirty = true;
-            if (tot) {
-                if ((rc = dev_alloc(c, &c->patch_words, (size_t)3 * (size_t)tot))) return rc;
-                HIPCK(c, hipMemsetAsync(c->patch_cursor, 0, sizeof(int32_t) * (size_t)n_win, c->stream));
-                launch(PatchOut{1, c->excl, c->patch_count, c->patch_off, c->patch_cursor, c->patch_words}, 0);
-                HIPCK(c, hipGetLastError());
-                HIPCK(c, hipStreamSynchronize(c->stream));
-            }
-            return MP_OK;
-        }
-        dev_free(c, &c->ex, (size_t)cap);
-        cap = cnt;
+        c->ex_host.resize((size_t)cnt);
+        if (cnt) HIPCK(c, hipMemcpy(c->ex_host.data(), c->ex, sizeof(ExRec) * (size_t)cnt, hipMemcpyDeviceToHost));
+        std::sort(c->ex_host.begin(), c->ex_host.end(),
+                  [](const ExRec &a, const ExRec &b) { return a.win != b.win ? a.win < b.win : a.row < b.row; });
+        if (n_exc) *n_exc = cnt;
     }
-    return fail(c, MP_ERR_DEVICE, "exception list did not converge");
+    return MP_OK;
 }
 
 int mp_get_exceptions(mp_ctx *c, int32_t cap, int32_t *ew, int32_t *er, uint8_t *codes) {

@@ -74,13 +74,12 @@ __device__ inline int repair_window(const MsaArgs &M, int r, uint32_t wA, uint32
     return iupac ? 1 : 0;
 }
 
-// Window words of row r at absolute column p from the eight plane words that cover it (chunk c = p >> 5 and c + 1).
-// rc 0: (b0,b1,g) valid; 1: IUPAC exception (`buf` holds the symbol codes); 2: fewer than k residues.
-// `fast` = the k-mer is the plain column slice (no repair, no IUPAC code, inside the row).
-__device__ inline int words_from_planes(const MsaArgs &M, int r, int p, int k, uint32_t kmask, int len, uint32_t loA, uint32_t loC,
-                                        uint32_t loG, uint32_t loT, uint32_t hiA, uint32_t hiC, uint32_t hiG, uint32_t hiT,
-                                        uint32_t &b0, uint32_t &b1, uint32_t &g, bool &fast, Nib &buf) {
-    const int c = p >> 5, o = p & 31;
+// The plain column slice: window words of row r at absolute column p from the eight plane words that cover it (chunk
+// c = p >> 5 and c + 1).  Returns true when the k-mer IS that slice (inside the row, no IUPAC code, no gap at either
+// edge — or all gaps): (b0,b1,g) are then final.  false: the row needs slow_words().
+__device__ inline bool fast_words(int p, int k, uint32_t kmask, int len, uint32_t loA, uint32_t loC, uint32_t loG, uint32_t loT,
+                                  uint32_t hiA, uint32_t hiC, uint32_t hiG, uint32_t hiT, uint32_t &b0, uint32_t &b1, uint32_t &g) {
+    const int o = p & 31;
     const uint32_t wA = __funnelshift_r(loA, hiA, o) & kmask;
     const uint32_t wC = __funnelshift_r(loC, hiC, o) & kmask;
     const uint32_t wG = __funnelshift_r(loG, hiG, o) & kmask;
@@ -89,16 +88,33 @@ __device__ inline int words_from_planes(const MsaArgs &M, int r, int p, int k, u
     const uint32_t ng = o1 | o2;
     const uint32_t multi = a1 | a2 | (o1 & o2);
     const uint32_t gw = ~ng & kmask;
-    fast = (p + k <= len) && multi == 0 && (gw == kmask || ((gw & 1u) == 0 && (gw >> (k - 1)) == 0));
-    if (fast) {
-        b0 = wC | wT; b1 = wG | wT; g = gw;
-        return 0;
-    }
+    b0 = wC | wT; b1 = wG | wT; g = gw;
+    return (p + k <= len) && multi == 0 && (gw == kmask || ((gw & 1u) == 0 && (gw >> (k - 1)) == 0));
+}
+
+// The general path for a row fast_words() turned down (edge-gap repair, IUPAC code, ragged end).
+// rc 0: (b0,b1,g) valid; 1: IUPAC exception (`buf` holds the symbol codes); 2: fewer than k residues.
+__device__ inline int slow_words(const MsaArgs &M, int r, int p, int k, uint32_t kmask, int len, uint32_t loA, uint32_t loC,
+                                 uint32_t loG, uint32_t loT, uint32_t hiA, uint32_t hiC, uint32_t hiG, uint32_t hiT,
+                                 uint32_t &b0, uint32_t &b1, uint32_t &g, Nib &buf) {
+    const int c = p >> 5, o = p & 31;
+    const uint32_t wA = __funnelshift_r(loA, hiA, o) & kmask;
+    const uint32_t wC = __funnelshift_r(loC, hiC, o) & kmask;
+    const uint32_t wG = __funnelshift_r(loG, hiG, o) & kmask;
+    const uint32_t wT = __funnelshift_r(loT, hiT, o) & kmask;
     const size_t np = (size_t)M.n_pad;
     const uint32_t ng_lo = loA | loC | loG | loT;
     const uint32_t c_left = M.cum[(size_t)c * np + r] + __popc(ng_lo & ((1u << o) - 1u));
     const uint32_t total = M.cum[(size_t)M.n_chunks * np + r];
     return repair_window(M, r, wA, wC, wG, wT, k, p, len, c_left, total, b0, b1, g, buf);
+}
+
+__device__ inline int words_from_planes(const MsaArgs &M, int r, int p, int k, uint32_t kmask, int len, uint32_t loA, uint32_t loC,
+                                        uint32_t loG, uint32_t loT, uint32_t hiA, uint32_t hiC, uint32_t hiG, uint32_t hiT,
+                                        uint32_t &b0, uint32_t &b1, uint32_t &g, bool &fast, Nib &buf) {
+    fast = fast_words(p, k, kmask, len, loA, loC, loG, loT, hiA, hiC, hiG, hiT, b0, b1, g);
+    if (fast) return 0;
+    return slow_words(M, r, p, k, kmask, len, loA, loC, loG, loT, hiA, hiC, hiG, hiT, b0, b1, g, buf);
 }
 
 // Window words of (window at absolute column p, row r), derived on the fly; rows past n_rows, IUPAC windows and

@@ -97,6 +97,13 @@ class Fasta:
             raise MprimeError(rc, "mp_fasta_rows")
         return data[: self.n_bytes], off
 
+    def ids_raw(self):
+        """(bytes as a uint8 array, offsets): the ids as they stand in the file, id r = bytes[off[r]:off[r+1]]."""
+        buf = np.empty(max(self.n_id_bytes, 1), np.uint8)
+        off = np.empty(self.n_rows + 1, np.int64)
+        self.d.mp_fasta_ids(self.h, _ptr(buf), _ptr(off))
+        return buf[: self.n_id_bytes], off
+
     @property
     def ids(self):
         """Sequence ids (first-appearance order), decoded like the reference's text-mode read (UTF-8)."""

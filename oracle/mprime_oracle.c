@@ -746,3 +746,50 @@ int mp_pcr_scan(mp_ctx *c, const uint8_t *bytes, const int64_t *row_off, int32_t
     }
     return MP_OK;
 }
+
+/* (8) k-mismatch primer-site scan: the acceptance rule of mprime.h, character by character.  bowtie2 and
+ * samtools are not in this image, so this restatement is NOT pinned to recorded reference output ("parity unpinned"). */
+int mp_kmm_scan(mp_ctx *c, const uint8_t *bytes, const int64_t *row_off, int32_t n_rows, int32_t n_pat, const uint8_t *pat_codes,
+                const int32_t *pat_off, int32_t max_mm, int32_t term, int64_t cap, int32_t *hits, int64_t *n_hits) {
+    if (!c) return MP_ERR_ARG;
+    if (n_rows < 0 || n_pat < 0 || !n_hits || cap < 0 || (cap && !hits) || (n_rows && (!bytes || !row_off)) ||
+        (n_pat && (!pat_codes || !pat_off)) || max_mm < 0 || term < 0)
+        return fail(c, MP_ERR_ARG, "mp_kmm_scan: bad arguments");
+    *n_hits = 0;
+    static const char base_of[9] = {0, 'A', 'C', 0, 'G', 0, 0, 0, 'T'};
+    for (int32_t i = 0; i < n_pat; i++) {
+        int len = pat_off[i + 1] - pat_off[i];
+        if (len < 4 || len > MP_DIMER_MAX_LEN) return fail(c, MP_ERR_ARG, "pattern %d has length %d (4..%d supported)", i, len, MP_DIMER_MAX_LEN);
+        for (int j = 0; j < len; j++) {
+            uint8_t m = pat_codes[pat_off[i] + j];
+            if (m != 1 && m != 2 && m != 4 && m != 8) return fail(c, MP_ERR_ARG, "pattern %d is not a concrete A/C/G/T sequence", i);
+        }
+    }
+    int64_t n = 0;
+    for (int32_t r = 0; r < n_rows; r++) {
+        const uint8_t *s = bytes + row_off[r];
+        int64_t len = row_off[r + 1] - row_off[r];
+        for (int64_t p = 0; p < len; p++) {
+            for (int32_t i = 0; i < n_pat; i++) {
+                int m = pat_off[i + 1] - pat_off[i];
+                if (p + m > len || term > m) continue;
+                for (int strand = 0; strand < 2; strand++) {
+                    int mism = 0, run = 0;                /* run: matches since the last mismatch, left to right */
+                    for (int j = 0; j < m; j++) {
+                        char want = base_of[pat_codes[pat_off[i] + (strand ? m - 1 - j : j)]];
+                        if (strand) want = want == 'A' ? 'T' : want == 'C' ? 'G' : want == 'G' ? 'C' : 'A';
+                        char have = (char)toupper(s[p + j]);
+                        if (have == want) run++;          /* a character outside ACGT equals no base */
+                        else { mism++; run = 0; }
+                    }
+                    if (mism <= max_mm && run >= term) {  /* trailing number of the MD:Z string >= threshold (BWT:253-259) */
+                        if (n < cap) { hits[4 * n] = r; hits[4 * n + 1] = (int32_t)p; hits[4 * n + 2] = i; hits[4 * n + 3] = strand; }
+                        n++;
+                    }
+                }
+            }
+        }
+    }
+    *n_hits = n;
+    return MP_OK;
+}

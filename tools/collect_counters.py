@@ -51,6 +51,7 @@ def main():
     ap.add_argument("--out", default=os.path.join(REPO, "gpurun_out", "r02", "prof_bench"))
     ap.add_argument("--bench-args", default="")
     a = ap.parse_args()
+    a.out = os.path.abspath(a.out)                 # rocprofv3 runs from /tmp
     os.makedirs(a.out, exist_ok=True)
     bench = [sys.executable, os.path.join(REPO, "bench.py"), "--rows", str(a.rows), "--no-cpu", "--no-variants"] + a.bench_args.split()
     # kernel trace of the bench command itself
