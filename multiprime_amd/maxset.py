@@ -106,6 +106,14 @@ class PrimerSetCover:
                         if r < blank_row:
                             print("Non maximum primer set. Try maximal primer set!")
                             sys.exit(1)
+                        if r not in jdict:
+                            # The reference reads jdict[row_pointer] of a cluster it never selected from (a blank cluster, or one
+                            # the search already left: the for-loop's row pointer and the back-tracking one diverge) and dies
+                            # with KeyError, exit status 1, nothing written (tests/golden/maxset_multi.json.gz, seeds 3 and 7).
+                            # Same status here, with a message instead of a traceback.
+                            print("KeyError: {} (the maximum-set search cannot back-track past this cluster; "
+                                  "the reference script fails here too)".format(r), file=sys.stderr)
+                            sys.exit(1)
                         c = jdict[r] + step
                         primer_set = saved_set[r]
                         clique.pop()

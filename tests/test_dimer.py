@@ -25,6 +25,9 @@ FD = [("findimer_cluster0", "cluster0_candidates.fa", 3.96), ("findimer_cluster0
       ("findimer_syn_a", "findimer_syn_a.fa", 3.96), ("findimer_syn_a_t3", "findimer_syn_a.fa", 3.0),
       ("findimer_syn_b", "findimer_syn_b.fa", 3.96), ("findimer_syn_b_t3", "findimer_syn_b.fa", 3.0)]
 MS = ["maxset_shipped", "maxset_fake1", "maxset_fake2", "maxset_fake3"]
+# multi-cluster inputs with planted cross-cluster dimers (tests/golden/make_golden_maxset2.py): pairs are skipped, clusters go
+# to .next.xls (-m T), the maximum-set search back-tracks or dies as the reference does (-m F)
+MS_MULTI = [f"maxset_multi{i}" for i in range(1, 9)]
 
 
 def test_dg_limit_is_the_rounding_boundary():
@@ -46,6 +49,8 @@ def check_findimer(lib, gold, name, inp, thr, tmp_path):
 
 
 def check_maxset(lib, gold, name, method, tmp_path):
+    if name.startswith("maxset_multi"):
+        gold = json.loads(gzip.open(os.path.join(GOLDEN, "maxset_multi.json.gz")).read())
     want = gold[f"{name}_{method}"]
     if name == "maxset_shipped":
         text = gzip.open(os.path.join(GOLDEN, "inputs", "candidate_primers_sets.txt.gz")).read().decode()
@@ -74,7 +79,7 @@ def test_findimer_matches_reference(name, inp, thr, oracle_lib, gold, tmp_path):
     check_findimer(oracle_lib, gold, name, inp, thr, tmp_path)
 
 
-@pytest.mark.parametrize("name", MS)
+@pytest.mark.parametrize("name", MS + MS_MULTI)
 @pytest.mark.parametrize("method", ["T", "F"])
 def test_maxprimerset_matches_reference(name, method, oracle_lib, gold, tmp_path):
     check_maxset(oracle_lib, gold, name, method, tmp_path)
@@ -87,7 +92,7 @@ def test_findimer_hip_matches_reference(name, inp, thr, hip_lib, gold, tmp_path)
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("name", MS)
+@pytest.mark.parametrize("name", MS + MS_MULTI)
 @pytest.mark.parametrize("method", ["T", "F"])
 def test_maxprimerset_hip_matches_reference(name, method, hip_lib, gold, tmp_path):
     check_maxset(hip_lib, gold, name, method, tmp_path)

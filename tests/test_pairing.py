@@ -79,3 +79,41 @@ def test_pairing_matches_reference(fixture, flagset, oracle_lib, gold, core_outp
 @pytest.mark.parametrize("fixture,flagset", CASES)
 def test_pairing_hip_matches_reference(fixture, flagset, hip_lib, gold, core_outputs, tmp_path):
     run_pairing(hip_lib, gold, core_outputs, fixture, flagset, tmp_path)
+
+
+def _known_answer(lib, gold, core_outputs, tmp_path):
+    """SURVEY §8c end-to-end known answer, through this build's own drop-ins only: core (Cluster_0, yaml flags) ->
+    get_multiPrime (yaml flags) -> get_Maxprimerset -s 5 -m T.  The unmodified reference chain gives 2749 candidate pairs, the
+    best being RRTCAGATGCACCYATTG / CCCAKRTCYTCAGCATTT 566:51.59:0.968 484 888:1453, and selects exactly that pair."""
+    import types
+    from multiprime_amd import maxset
+    run_pairing(lib, gold, core_outputs, "cluster0_v1", "yaml", tmp_path)           # candidate file == the reference's, byte for byte
+    cand = tmp_path / "cluster0_v1.candidate.primers.txt"
+    fields = [x for x in cand.read_text().strip().split("\t") if x]
+    assert (len(fields) - 1) // 5 == 2749
+    assert fields[1:6] == ["RRTCAGATGCACCYATTG", "CCCAKRTCYTCAGCATTT", "566:51.59:0.968", "484", "888:1453"]
+    final = tmp_path / "final_maxprimers_set.xls"
+    maxset.run(types.SimpleNamespace(input=str(cand), step=5, method="T", out=str(final), device=0), library=lib)
+    rows = final.read_text().splitlines()
+    assert len(rows) == 2 and rows[1].split("\t")[2:4] == ["RRTCAGATGCACCYATTG", "CCCAKRTCYTCAGCATTT"]
+
+
+def test_end_to_end_known_answer(oracle_lib, gold, core_outputs, tmp_path):
+    _known_answer(oracle_lib, gold, core_outputs, tmp_path)
+
+
+@pytest.mark.gpu
+def test_end_to_end_known_answer_on_gpu(hip_lib, gold, tmp_path_factory, tmp_path):
+    """Every stage on the HIP library: the core step too (the module fixture above builds its inputs with the oracle)."""
+    d = tmp_path_factory.mktemp("e2e_hip")
+    meta = load_gz_json("cluster0_v1.trace.json.gz")["meta"]
+    fl = meta["flags"]
+    inp = d / "in.fa"
+    inp.write_bytes(golden_input(meta["input"]))
+    out = d / "cluster0_v1.top.primer.out"
+    NN_degenerate(seq_file=str(inp), primer_length=fl["l"], coverage=fl["f"], number_of_dege_bases=fl["n"], score_of_dege_bases=fl["d"],
+                  raw_entropy_threshold=fl["e"], product_len=fl["s"], position=fl["c"], variation=fl["v"], distance=fl["a"], GC=fl["g"],
+                  nproc=1, outfile=str(out), library=hip_lib).run()
+    ref = d / "ref.tfa"
+    ref.write_text("".join(f">s{i}\nACGT\n" for i in range(meta["n_seq"])))
+    _known_answer(hip_lib, gold, lambda name: (str(out), str(ref)), tmp_path)
