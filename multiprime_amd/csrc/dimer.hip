@@ -105,6 +105,133 @@ __device__ inline bool dimer_pair_scan(const uint8_t *__restrict__ codes, const 
     return false;
 }
 
+// One (end length, end expansion, y expansion) combination of the ordered pair x -> y; on a hit *idx_out = where RC(end) starts.
+__device__ inline bool dimer_combo(const Nib &cx, const Nib &cy, int lx, int ly, int l, uint32_t ei, uint32_t pi,
+                                   const uint8_t *__restrict__ loss_hit, const double *__restrict__ dg, double dg_limit, int &idx_out) {
+    const uint64_t mask = l == 32 ? ~0ull : ((1ull << (2 * l)) - 1ull);
+    const uint64_t e = dm_expand(cx, lx - l, l, ei);
+    uint64_t rc = 0;                                                      // reverse complement: 3 - base, reversed
+    for (int t = 0; t < l; t++) rc |= (uint64_t)(3u - ((uint32_t)(e >> (2 * (l - 1 - t))) & 3u)) << (2 * t);
+    const uint64_t p = dm_expand(cy, 0, ly, pi);
+    int idx = -1;
+    for (int s0 = 0; s0 + l <= ly; s0++)
+        if (((p >> (2 * s0)) & mask) == rc) { idx = s0; break; }          // str.find: first occurrence
+    if (idx < 0) return false;
+    const int gc = __popcll((e ^ (e >> 1)) & 0x5555555555555555ull & mask);   // C = 01, G = 10
+    const int d2 = ly - l - idx;
+    bool hit = loss_hit[((size_t)l * (MP_DIMER_MAX_LEN + 1) + gc) * 64 + d2] != 0;
+    if (!hit && d2 == 0) hit = dm_delta_g(e, l, dg) < dg_limit;
+    idx_out = idx;
+    return hit;
+}
+
+// The same search with G lanes per pair (G = 16 or 64, a sub-wave): the (end length, end expansion, y expansion) combinations
+// are numbered in the reference's order — longest end first, then expansion of the end, then expansion of y — and taken G at a
+// time, one per lane; the lowest lane with a hit IS the first passing combination.  A pair of plain primers has one
+// combination per end length (14 in finDimer's mode): one step instead of a 14-step serial loop, and a degenerate pair walks
+// its expansions G at a time.  Used when there are too few pairs to fill the chip with one thread each (the self-dimer test
+// of the core step, the pair lists of the pairing stage, get_Maxprimerset's incremental scans).
+template <int G>
+__device__ inline bool dimer_pair_group(const uint8_t *__restrict__ codes, const int32_t *__restrict__ off, int x, int y, int mode,
+                                        const uint8_t *__restrict__ loss_hit, const double *__restrict__ dg, double dg_limit,
+                                        int32_t (&rec)[4]) {
+    const int lane = threadIdx.x & 63, gl = lane & (G - 1), g0 = lane & ~(G - 1);
+    const unsigned long long gmask = (G == 64 ? ~0ull : ((1ull << G) - 1ull)) << g0;
+    const int lx = off[x + 1] - off[x], ly = off[y + 1] - off[y];
+    Nib cx, cy;
+    cx.lo = cx.hi = cy.lo = cy.hi = 0;
+    for (int p = 0; p < lx; p++) cx.set(p, codes[off[x] + p]);
+    for (int p = 0; p < ly; p++) cy.set(p, codes[off[y] + p]);
+    const uint32_t dy = dm_degeneracy(cy, 0, ly);
+    int l_hi, l_lo;
+    if (mode == 0) { l_hi = lx < 18 ? lx : 18; l_lo = lx < 5 ? lx : 5; }         // FD:162-169
+    else { l_hi = lx - 1; l_lo = 5; }                                             // MS:149-154
+    const int n_l = l_hi - l_lo + 1;                                              // <= 28 end lengths, j-th is l_hi - j
+    // combinations per end length, two slots per lane (n_l <= 32 = 2 x 16)
+    unsigned long long cnt[2] = {0, 0};
+    for (int t = 0; t < 2; t++) {
+        const int j = gl + t * G;
+        const int l = l_hi - j;
+        if (j < n_l && l > 0 && l <= ly) cnt[t] = (unsigned long long)dm_degeneracy(cx, lx - l, l) * dy;
+    }
+    unsigned long long total = 0;
+    for (int j = 0; j < n_l; j++) total += __shfl(cnt[j / G], g0 + (j % G));
+    for (unsigned long long t0 = 0; t0 < total; t0 += G) {
+        const unsigned long long id = t0 + gl;
+        bool hit = false;
+        int l = 0, idx = 0;
+        uint32_t ei = 0, pi = 0;
+        unsigned long long acc = 0;
+        bool found = false;
+        for (int j = 0; j < n_l; j++) {                                           // uniform trip count: every lane shuffles
+            const unsigned long long cj = __shfl(cnt[j / G], g0 + (j % G));
+            if (!found && id < acc + cj) {
+                found = true;
+                l = l_hi - j;
+                const unsigned long long rem = id - acc;
+                ei = (uint32_t)(rem / dy);
+                pi = (uint32_t)(rem % dy);
+            }
+            acc += cj;
+        }
+        if (found) hit = dimer_combo(cx, cy, lx, ly, l, ei, pi, loss_hit, dg, dg_limit, idx);
+        const unsigned long long hb = __ballot(hit) & gmask;
+        if (hb) {
+            const int first = __ffsll((long long)hb) - 1;
+            rec[0] = __shfl(l, first); rec[1] = (int32_t)__shfl(ei, first); rec[2] = (int32_t)__shfl(pi, first); rec[3] = __shfl(idx, first);
+            return true;
+        }
+    }
+    return false;
+}
+
+// Tables in LDS (north_star): the Loss decision bytes of the end lengths a launch can meet and the deltaG constants.
+struct DimerTables {
+    const uint8_t *loss;     // indexed like the global table: [(l) * 33 + gc] * 64 + d2, rebased so that l = 5 is the first staged row
+    const double *dg;
+};
+constexpr int kLossRow = (MP_DIMER_MAX_LEN + 1) * 64;                    // bytes per end length
+constexpr int kLossL0 = 5, kLossRows = 27;                               // end lengths 5..31 are staged (57 KB); shorter / 32 read global
+constexpr int kNdg = 16 + 32 + MP_DIMER_MAX_LEN + 1 + 1;
+
+// explicit ordered pairs or an all-pairs scan, G lanes per pair, tables staged in LDS; persistent workgroups stride over the pairs
+template <int G>
+__global__ __launch_bounds__(kBlock) void dimer_group_kernel(const DimerArgs A, long long n_pairs, const int32_t *__restrict__ pairs,
+                                                             uint8_t *__restrict__ flags) {
+    __shared__ uint8_t s_loss[kLossRows * kLossRow];
+    __shared__ double s_dg[kNdg];
+    for (int i = threadIdx.x; i < kLossRows * kLossRow / 16; i += kBlock)
+        reinterpret_cast<uint4 *>(s_loss)[i] = reinterpret_cast<const uint4 *>(A.loss_hit + (size_t)kLossL0 * kLossRow)[i];
+    for (int i = threadIdx.x; i < kNdg; i += kBlock) s_dg[i] = A.dg[i];
+    __syncthreads();
+    // dimer_combo indexes loss_hit[l * 33 * 64 + ...]: hand it a pointer rebased by kLossL0 rows; lengths outside 5..31 are rare
+    // (primers shorter than 5, 32-mers) and take the global table through the wrapper below
+    const int per_block = kBlock / G;
+    const int gl = threadIdx.x & (G - 1);
+    for (long long p = (long long)blockIdx.x * per_block + threadIdx.x / G; p < n_pairs; p += (long long)gridDim.x * per_block) {
+        int x, y;
+        if (pairs) { x = pairs[2 * p]; y = pairs[2 * p + 1]; }
+        else {
+            x = (int)(p / A.n); y = (int)(p % A.n);
+            if (A.mode == 0 ? (y < x) : (x >= A.n_new && y >= A.n_new)) continue;
+        }
+        const int lx = A.off[x + 1] - A.off[x];
+        const bool staged = lx <= 31 && (A.mode != 0 || lx >= 5);          // every end length of this pair lies in 5..31
+        int32_t rec[4];
+        const bool hit = staged ? dimer_pair_group<G>(A.codes, A.off, x, y, A.mode, s_loss - (size_t)kLossL0 * kLossRow, s_dg, A.dg_limit, rec)
+                                : dimer_pair_group<G>(A.codes, A.off, x, y, A.mode, A.loss_hit, A.dg, A.dg_limit, rec);
+        if (gl != 0) continue;
+        if (flags) flags[p] = hit ? 1 : 0;
+        else if (hit) {
+            unsigned long long h = atomicAdd(A.n_hits, 1ull);
+            if ((long long)h < A.cap) {
+                int32_t *r = A.hits + 6 * h;
+                r[0] = x; r[1] = y; r[2] = rec[0]; r[3] = rec[1]; r[4] = rec[2]; r[5] = rec[3];
+            }
+        }
+    }
+}
+
 __global__ __launch_bounds__(kBlock) void dimer_kernel(const DimerArgs A) {
     const int x = blockIdx.x;
     const int y = blockIdx.y * kBlock + threadIdx.x;

@@ -16,10 +16,8 @@ namespace {
 // them from the list.  `excl` also carries the plain rows with more than v gaps in the window (outside every count,
 // V20:689) and the padding rows, so the bit-sliced kernels need no gap bookkeeping of their own.
 //
-// Two kernels.  classify_kernel (thread = row, workgroup = 256 rows x a tile of consecutive windows; the 32-column plane
-// words slide in registers, so every plane word is read once per tile) only tells plain slices from the rest — 4 funnel
-// shifts and a dozen logic ops per (window, row), no divergence; pass 0 writes `excl` and counts the slow pairs per
-// window, pass 1 (offsets known) lists them.  repair_kernel then gives every slow pair a lane of its own for the
+// Two kernels.  classify_kernel only tells plain slices from the rest — bit-parallel over the 32 windows starting in a
+// chunk, no divergence; pass 0 writes `excl` and counts the slow pairs per window, pass 1 (offsets known) lists them.  repair_kernel then gives every slow pair a lane of its own for the
 // line-by-line restatement of V20:668-687.  (Round 1 and the first round-2 version ran the repair inside the sliding
 // loop: a quarter of the (wave, window) steps had one lane in the repair path and 63 waiting — 1.36 ms per pass at
 // 131072 x 1000; see profiles/r02_bench_eval.txt.)
@@ -33,43 +31,59 @@ struct PatchOut {
     int32_t *wins;                // [n]     (pass 1) its window
 };
 
-__global__ __launch_bounds__(kBlock) void classify_kernel(const MsaArgs M, int p0, int n_win, int tile, int k, int v, PatchOut po) {
-    int r = blockIdx.x * kBlock + threadIdx.x;
+// thread = row, workgroup = 256 rows x the (up to) 32 windows that START in one 32-column chunk.  The classification is
+// bit-parallel over those windows: with N = the row's 64-bit "holds a residue" word of chunk c and c+1 and M = its "holds an
+// IUPAC code" word, a sliding OR over k columns (five shift-OR doublings) tells for all 32 start offsets at once whether a
+// window touches an IUPAC code / holds any residue, and two more shifts whether it starts and ends on a residue — bit o of
+// `fast` = the k-mer at offset o is the plain column slice (fast_words() of winwords.hpp, 32 windows per instruction).
+// Only the gap count (> v gaps: outside every count, V20:689) is taken window by window (shift, mask, popcount).
+// Per (wave, window) there remain two ballots that turn lane bits into the row-bit words of `excl` and the slow-pair lists.
+__global__ __launch_bounds__(kBlock) void classify_kernel(const MsaArgs M, int p0, int n_win, int k, int v, PatchOut po) {
+    const int r = blockIdx.x * kBlock + threadIdx.x;
     if (r >= M.n_pad) return;
     const int n_rows = M.n_rows;
-    int w0 = blockIdx.y * tile;
-    int w1 = w0 + tile < n_win ? w0 + tile : n_win;
+    const int c = (p0 >> 5) + blockIdx.y;                    // chunk of the window starts handled here
+    const int o_lo = max(0, p0 - c * 32), o_hi = min(32, p0 + n_win - c * 32);      // start offsets [o_lo, o_hi) are windows
     const uint32_t kmask = (1u << k) - 1u;
     const size_t np = (size_t)M.n_pad;
-    const uint32_t *__restrict__ planes = M.planes;
     const unsigned long long real = __ballot(r < n_rows);
     if (r >= n_rows) {                       // padding rows never take part
         if (po.pass == 0 && real == 0ull && (threadIdx.x & 63) == 0)
-            for (int w = w0; w < w1; w++) po.excl[(size_t)w * (np / 64) + (size_t)(r >> 6)] = ~0ull;
+            for (int o = o_lo; o < o_hi; o++) po.excl[(size_t)(c * 32 + o - p0) * (np / 64) + (size_t)(r >> 6)] = ~0ull;
         return;
     }
-    const int len = M.rlen[r];
     const int lane = threadIdx.x & 63;
     const unsigned long long live = __ballot(true);          // the lanes of a wave that are still here are all real rows
     const int leader = __ffsll((long long)live) - 1;
-    int cur = -1;
-    uint32_t loA = 0, loC = 0, loG = 0, loT = 0, hiA = 0, hiC = 0, hiG = 0, hiT = 0;
-    for (int w = w0; w < w1; w++) {
-        int p = p0 + w;
-        int c = p >> 5;
-        if (c != cur) {
-            size_t base = ((size_t)c * 4) * np + r;
-            if (c == cur + 1 && cur >= 0) { loA = hiA; loC = hiC; loG = hiG; loT = hiT; }
-            else { loA = planes[base]; loC = planes[base + np]; loG = planes[base + 2 * np]; loT = planes[base + 3 * np]; }
-            size_t nb = base + 4 * np;           // chunk c+1 exists: n_chunks is padded by two
-            hiA = planes[nb]; hiC = planes[nb + np]; hiG = planes[nb + 2 * np]; hiT = planes[nb + 3 * np];
-            cur = c;
-        }
-        uint32_t b0, b1, g;
-        const bool fast = fast_words(p, k, kmask, len, loA, loC, loG, loT, hiA, hiC, hiG, hiT, b0, b1, g);
-        const unsigned long long slow = __ballot(!fast);
+    const int len = M.rlen[r];
+    const uint32_t *P = M.planes + ((size_t)c * 4) * np + r;
+    const uint32_t loA = P[0], loC = P[np], loG = P[2 * np], loT = P[3 * np];
+    const uint32_t hiA = P[4 * np], hiC = P[5 * np], hiG = P[6 * np], hiT = P[7 * np];      // chunk c+1 exists: n_chunks is padded by two
+    const uint32_t lo1 = loA | loC, lo2 = loG | loT, hi1 = hiA | hiC, hi2 = hiG | hiT;
+    const unsigned long long N = (unsigned long long)(lo1 | lo2) | ((unsigned long long)(hi1 | hi2) << 32);
+    const unsigned long long Mu = (unsigned long long)((loA & loC) | (loG & loT) | (lo1 & lo2)) |
+                                  ((unsigned long long)((hiA & hiC) | (hiG & hiT) | (hi1 & hi2)) << 32);
+    // sliding OR over k columns: X_t covers t columns, t the largest power of two <= k; cover(o) = X_t(o) | X_t(o + k - t)
+    auto cover = [k](unsigned long long X) {
+        int t = 1;
+        while (2 * t <= k) { X |= X >> t; t *= 2; }
+        return X | (X >> (k - t));
+    };
+    const uint32_t any_iupac = (uint32_t)cover(Mu), any_res = (uint32_t)cover(N);
+    const uint32_t ends_ok = (uint32_t)N & (uint32_t)(N >> (k - 1));
+    const int room = len - k - c * 32;                                             // offsets 0..room lie inside the row
+    const uint32_t inrow = room < 0 ? 0u : (room >= 31 ? 0xFFFFFFFFu : ((2u << room) - 1u));
+    const uint32_t fast = inrow & ~any_iupac & (~any_res | ends_ok);
+    uint32_t flag = ~fast;                                                          // excl: not a plain slice, or more than v gaps
+    if (po.pass == 0)
+        for (int o = o_lo; o < o_hi; o++)
+            if ((int)__popc(~(uint32_t)(N >> o) & kmask) > v) flag |= 1u << o;
+    for (int o = o_lo; o < o_hi; o++) {
+        const int w = c * 32 + o - p0;
+        const bool is_slow = !((fast >> o) & 1u);
+        const unsigned long long slow = __ballot(is_slow);
         if (po.pass == 0) {
-            const unsigned long long flg = __ballot(!fast || (int)__popc(g) > v) | ~real;
+            const unsigned long long flg = __ballot((flag >> o) & 1u) | ~real;
             if (lane == leader) {
                 po.excl[(size_t)w * (np / 64) + (size_t)(r >> 6)] = flg;
                 if (slow) atomicAdd(&po.count[w], (int)__popcll(slow));
@@ -78,7 +92,7 @@ __global__ __launch_bounds__(kBlock) void classify_kernel(const MsaArgs M, int p
             int base = 0;
             if (lane == leader) base = atomicAdd(&po.cursor[w], (int)__popcll(slow));
             base = __shfl(base, leader);
-            if (!fast) {
+            if (is_slow) {
                 const int slot = po.off[w] + base + (int)__popcll(slow & ((1ull << lane) - 1ull));
                 po.rows[slot] = r;
                 po.wins[slot] = w;
@@ -150,14 +164,13 @@ int mp_build_windows(mp_ctx *c, int32_t p0, int32_t n_win, int32_t k, int32_t v,
     if ((rc = dev_alloc(c, &c->patch_count, (size_t)n_win))) return rc;
     if ((rc = dev_alloc(c, &c->patch_off, (size_t)n_win + 1))) return rc;
     if ((rc = dev_alloc(c, &c->patch_cursor, (size_t)n_win))) return rc;
-    const int tile = 64;
-    const dim3 grid((unsigned)(c->n_pad / kBlock), (unsigned)((n_win + tile - 1) / tile));
+    const dim3 grid((unsigned)(c->n_pad / kBlock), (unsigned)(((p0 + n_win - 1) >> 5) - (p0 >> 5) + 1));   // y: chunks holding window starts
     const MsaArgs M = msa_args(c);
     HIPCK(c, hipMemsetAsync(c->ex_count, 0, sizeof(int), c->stream));
     HIPCK(c, hipMemsetAsync(c->err_flag, 0, 4 * sizeof(int), c->stream));
     HIPCK(c, hipMemsetAsync(c->excl, 0, sizeof(unsigned long long) * (size_t)n_win * nw, c->stream));
     HIPCK(c, hipMemsetAsync(c->patch_count, 0, sizeof(int32_t) * (size_t)n_win, c->stream));
-    hipLaunchKernelGGL(classify_kernel, grid, dim3(kBlock), 0, c->stream, M, p0, n_win, tile, k, v,
+    hipLaunchKernelGGL(classify_kernel, grid, dim3(kBlock), 0, c->stream, M, p0, n_win, k, v,
                        PatchOut{0, c->excl, c->patch_count, nullptr, nullptr, nullptr, nullptr});
     HIPCK(c, hipGetLastError());
     // slow pairs per window -> offsets on the host, then the listing pass and the repair
@@ -190,7 +203,7 @@ int mp_build_windows(mp_ctx *c, int32_t p0, int32_t n_win, int32_t k, int32_t v,
         hipError_t e = hipMemsetAsync(c->patch_cursor, 0, sizeof(int32_t) * (size_t)n_win, c->stream);
         int cnt = 0, errv[4] = {0, 0, 0, 0};
         if (e == hipSuccess) {
-            hipLaunchKernelGGL(classify_kernel, grid, dim3(kBlock), 0, c->stream, M, p0, n_win, tile, k, v,
+            hipLaunchKernelGGL(classify_kernel, grid, dim3(kBlock), 0, c->stream, M, p0, n_win, k, v,
                                PatchOut{1, c->excl, c->patch_count, c->patch_off, c->patch_cursor, c->patch_rows, d_wins});
             hipLaunchKernelGGL(repair_kernel, dim3((unsigned)((tot + kBlock - 1) / kBlock)), dim3(kBlock), 0, c->stream, M, p0, k, (int)tot,
                                (const int32_t *)c->patch_rows, (const int32_t *)d_wins, c->patch_words, c->ex, c->ex_count, c->err_flag);
