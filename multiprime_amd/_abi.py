@@ -268,6 +268,17 @@ class Context:
                 return h[np.lexsort((h[:, 1], h[:, 0]))] if len(h) else h
             cap = int(n.value)
 
+    def dimer_any(self, codes, off, mode: int, n_new: int, loss_hit, dg_params, dg_limit: float) -> bool:
+        """True iff the scan has at least one hit (no hit records fetched, no re-scan with a larger buffer)."""
+        codes = np.ascontiguousarray(codes, dtype=np.uint8)
+        off = np.ascontiguousarray(off, dtype=np.int32)
+        loss_hit = np.ascontiguousarray(loss_hit, dtype=np.uint8)
+        dg_params = np.ascontiguousarray(dg_params, dtype=np.float64)
+        n = C.c_int64(0)
+        self._ck(self.d.mp_dimer_scan(self.h, len(off) - 1, _ptr(codes), _ptr(off), mode, n_new, _ptr(loss_hit), _ptr(dg_params),
+                                      dg_limit, 0, None, C.byref(n)))
+        return n.value > 0
+
     def dimer_pairs(self, codes, off, pairs, loss_hit, dg_params, dg_limit: float) -> np.ndarray:
         """flags[p] = 1 if the ordered pair (pairs[p,0] -> pairs[p,1]) forms a 3'-end dimer."""
         codes = np.ascontiguousarray(codes, dtype=np.uint8)

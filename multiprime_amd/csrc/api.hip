@@ -92,6 +92,8 @@ void mp_destroy(mp_ctx *c) {
     (void)hipDeviceSynchronize();
     free_msa(c);
     dev_free(c, &c->tmp_out, (size_t)c->tmp_out_n);
+    dev_free(c, &c->dm_loss, (size_t)(MP_DIMER_MAX_LEN + 1) * (MP_DIMER_MAX_LEN + 1) * 64);
+    dev_free(c, &c->dm_dg, (size_t)(16 + 32 + MP_DIMER_MAX_LEN + 1 + 1));
     for (auto &p : c->ev_busy) { (void)hipEventDestroy(p.first); (void)hipEventDestroy(p.second); }
     for (auto &p : c->ev_free) { (void)hipEventDestroy(p.first); (void)hipEventDestroy(p.second); }
     delete c;

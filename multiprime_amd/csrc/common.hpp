@@ -114,6 +114,11 @@ struct mp_ctx {
     unsigned long long *u_total = nullptr;
     std::vector<int64_t> h_wbase;
     std::vector<int32_t> h_wcount;
+    // dimer tables (Loss decisions, deltaG constants): cached across calls, re-uploaded only when the contents change
+    uint8_t *dm_loss = nullptr;
+    double *dm_dg = nullptr;
+    std::vector<uint8_t> dm_loss_host;
+    std::vector<double> dm_dg_host;
     // eval staging
     int n_cand = 0, n_items = 0, n_padded = 0;
     mp::EvalItem *items = nullptr;

@@ -107,7 +107,7 @@ __device__ inline bool dimer_pair_scan(const uint8_t *__restrict__ codes, const 
 
 // One (end length, end expansion, y expansion) combination of the ordered pair x -> y; on a hit *idx_out = where RC(end) starts.
 __device__ inline bool dimer_combo(const Nib &cx, const Nib &cy, int lx, int ly, int l, uint32_t ei, uint32_t pi,
-                                   const uint8_t *__restrict__ loss_hit, const double *__restrict__ dg, double dg_limit, int &idx_out) {
+                                   const uint8_t *__restrict__ loss_hit, int l0, const double *__restrict__ dg, double dg_limit, int &idx_out) {
     const uint64_t mask = l == 32 ? ~0ull : ((1ull << (2 * l)) - 1ull);
     const uint64_t e = dm_expand(cx, lx - l, l, ei);
     uint64_t rc = 0;                                                      // reverse complement: 3 - base, reversed
@@ -119,7 +119,7 @@ __device__ inline bool dimer_combo(const Nib &cx, const Nib &cy, int lx, int ly,
     if (idx < 0) return false;
     const int gc = __popcll((e ^ (e >> 1)) & 0x5555555555555555ull & mask);   // C = 01, G = 10
     const int d2 = ly - l - idx;
-    bool hit = loss_hit[((size_t)l * (MP_DIMER_MAX_LEN + 1) + gc) * 64 + d2] != 0;
+    bool hit = loss_hit[((size_t)(l - l0) * (MP_DIMER_MAX_LEN + 1) + gc) * 64 + d2] != 0;      // the table starts at end length l0
     if (!hit && d2 == 0) hit = dm_delta_g(e, l, dg) < dg_limit;
     idx_out = idx;
     return hit;
@@ -133,10 +133,10 @@ __device__ inline bool dimer_combo(const Nib &cx, const Nib &cy, int lx, int ly,
 // of the core step, the pair lists of the pairing stage, get_Maxprimerset's incremental scans).
 template <int G>
 __device__ inline bool dimer_pair_group(const uint8_t *__restrict__ codes, const int32_t *__restrict__ off, int x, int y, int mode,
-                                        const uint8_t *__restrict__ loss_hit, const double *__restrict__ dg, double dg_limit,
+                                        const uint8_t *__restrict__ loss_hit, int l0, const double *__restrict__ dg, double dg_limit,
                                         int32_t (&rec)[4]) {
     const int lane = threadIdx.x & 63, gl = lane & (G - 1), g0 = lane & ~(G - 1);
-    const unsigned long long gmask = (G == 64 ? ~0ull : ((1ull << G) - 1ull)) << g0;
+    const unsigned long long gmask = (G == 64 ? ~0ull : ((1ull << (G & 63)) - 1ull)) << g0;
     const int lx = off[x + 1] - off[x], ly = off[y + 1] - off[y];
     Nib cx, cy;
     cx.lo = cx.hi = cy.lo = cy.hi = 0;
@@ -174,7 +174,7 @@ __device__ inline bool dimer_pair_group(const uint8_t *__restrict__ codes, const
             }
             acc += cj;
         }
-        if (found) hit = dimer_combo(cx, cy, lx, ly, l, ei, pi, loss_hit, dg, dg_limit, idx);
+        if (found) hit = dimer_combo(cx, cy, lx, ly, l, ei, pi, loss_hit, l0, dg, dg_limit, idx);
         const unsigned long long hb = __ballot(hit) & gmask;
         if (hb) {
             const int first = __ffsll((long long)hb) - 1;
@@ -186,10 +186,6 @@ __device__ inline bool dimer_pair_group(const uint8_t *__restrict__ codes, const
 }
 
 // Tables in LDS (north_star): the Loss decision bytes of the end lengths a launch can meet and the deltaG constants.
-struct DimerTables {
-    const uint8_t *loss;     // indexed like the global table: [(l) * 33 + gc] * 64 + d2, rebased so that l = 5 is the first staged row
-    const double *dg;
-};
 constexpr int kLossRow = (MP_DIMER_MAX_LEN + 1) * 64;                    // bytes per end length
 constexpr int kLossL0 = 5, kLossRows = 27;                               // end lengths 5..31 are staged (57 KB); shorter / 32 read global
 constexpr int kNdg = 16 + 32 + MP_DIMER_MAX_LEN + 1 + 1;
@@ -204,8 +200,7 @@ __global__ __launch_bounds__(kBlock) void dimer_group_kernel(const DimerArgs A, 
         reinterpret_cast<uint4 *>(s_loss)[i] = reinterpret_cast<const uint4 *>(A.loss_hit + (size_t)kLossL0 * kLossRow)[i];
     for (int i = threadIdx.x; i < kNdg; i += kBlock) s_dg[i] = A.dg[i];
     __syncthreads();
-    // dimer_combo indexes loss_hit[l * 33 * 64 + ...]: hand it a pointer rebased by kLossL0 rows; lengths outside 5..31 are rare
-    // (primers shorter than 5, 32-mers) and take the global table through the wrapper below
+    // pairs whose end lengths all lie in 5..31 use the staged rows; the rare others (primers shorter than 5, 32-mers) the global table
     const int per_block = kBlock / G;
     const int gl = threadIdx.x & (G - 1);
     for (long long p = (long long)blockIdx.x * per_block + threadIdx.x / G; p < n_pairs; p += (long long)gridDim.x * per_block) {
@@ -218,8 +213,8 @@ __global__ __launch_bounds__(kBlock) void dimer_group_kernel(const DimerArgs A, 
         const int lx = A.off[x + 1] - A.off[x];
         const bool staged = lx <= 31 && (A.mode != 0 || lx >= 5);          // every end length of this pair lies in 5..31
         int32_t rec[4];
-        const bool hit = staged ? dimer_pair_group<G>(A.codes, A.off, x, y, A.mode, s_loss - (size_t)kLossL0 * kLossRow, s_dg, A.dg_limit, rec)
-                                : dimer_pair_group<G>(A.codes, A.off, x, y, A.mode, A.loss_hit, A.dg, A.dg_limit, rec);
+        const bool hit = staged ? dimer_pair_group<G>(A.codes, A.off, x, y, A.mode, s_loss, kLossL0, s_dg, A.dg_limit, rec)
+                                : dimer_pair_group<G>(A.codes, A.off, x, y, A.mode, A.loss_hit, 0, A.dg, A.dg_limit, rec);
         if (gl != 0) continue;
         if (flags) flags[p] = hit ? 1 : 0;
         else if (hit) {
@@ -366,6 +361,50 @@ static int check_primers(mp_ctx *c, int32_t n, const uint8_t *codes, const int32
     }
     return MP_OK;
 }
+// The Loss decision table and the deltaG constants live in the context and are uploaded only when their contents change
+// (get_Maxprimerset calls the scan once per candidate pair with the same tables).
+static int ensure_dimer_tables(mp_ctx *c, const uint8_t *loss_hit, const double *dg) {
+    const size_t tbl = (size_t)(MP_DIMER_MAX_LEN + 1) * kLossRow;
+    int rc;
+    if (!c->dm_loss) {
+        if ((rc = dev_alloc(c, &c->dm_loss, tbl))) return rc;
+        if ((rc = dev_alloc(c, &c->dm_dg, (size_t)kNdg))) return rc;
+        c->dm_loss_host.clear();
+    }
+    if (c->dm_loss_host.size() != tbl || memcmp(c->dm_loss_host.data(), loss_hit, tbl) != 0) {
+        HIPCK(c, hipMemcpyAsync(c->dm_loss, loss_hit, tbl, hipMemcpyHostToDevice, c->stream));
+        c->dm_loss_host.assign(loss_hit, loss_hit + tbl);
+    }
+    if (c->dm_dg_host.size() != (size_t)kNdg || memcmp(c->dm_dg_host.data(), dg, sizeof(double) * kNdg) != 0) {
+        HIPCK(c, hipMemcpyAsync(c->dm_dg, dg, sizeof(double) * kNdg, hipMemcpyHostToDevice, c->stream));
+        c->dm_dg_host.assign(dg, dg + kNdg);
+    }
+    return MP_OK;
+}
+
+// device scratch of one call, released on every path
+struct Scratch {
+    mp_ctx *c;
+    std::vector<std::pair<void **, size_t>> bufs;
+    explicit Scratch(mp_ctx *c_) : c(c_) {}
+    template <typename T>
+    int alloc(T **p, size_t n) {
+        int rc = dev_alloc(c, p, n);
+        if (rc == MP_OK) bufs.push_back({(void **)p, (n ? n : 1) * sizeof(T)});
+        return rc;
+    }
+    ~Scratch() {
+        for (auto &b : bufs)
+            if (*b.first) { (void)hipFree(*b.first); c->bytes -= (int64_t)b.second; *b.first = nullptr; }
+    }
+};
+
+// lanes per pair: one thread per pair once there are enough pairs to fill the chip several times over, else a sub-wave
+static int lanes_per_pair(long long n_pairs) {
+    if (const char *e = getenv("MP_DIMER_LANES")) { int g = atoi(e); if (g == 1 || g == 16 || g == 64) return g; }
+    return n_pairs <= 32768 ? 64 : (n_pairs <= 262144 ? 16 : 1);
+}
+
 }  // namespace
 
 extern "C" {
@@ -378,38 +417,30 @@ int mp_dimer_scan(mp_ctx *c, int32_t n, const uint8_t *codes, const int32_t *off
     HIPCK(c, hipSetDevice(c->dev));
     *n_hits = 0;
     if (n == 0) return MP_OK;
-    static const int msize[16] = {0, 1, 1, 2, 1, 2, 2, 3, 1, 2, 2, 3, 2, 3, 3, 4};
-    for (int32_t i = 0; i < n; i++) {
-        int len = off[i + 1] - off[i];
-        if (len < 1 || len > MP_DIMER_MAX_LEN) return fail(c, MP_ERR_ARG, "primer %d has length %d (1..%d supported)", i, len, MP_DIMER_MAX_LEN);
-        long long d = 1;
-        for (int p = 0; p < len; p++) {
-            uint8_t m = codes[off[i] + p];
-            if (m == 0 || m > 15) return fail(c, MP_ERR_ARG, "primer %d holds a gap / unknown symbol", i);
-            d *= msize[m];
-            if (d > (1LL << 24)) return fail(c, MP_ERR_ARG, "primer %d has too many expansions", i);
-        }
-    }
-    const size_t total = (size_t)off[n], tbl = (size_t)(MP_DIMER_MAX_LEN + 1) * (MP_DIMER_MAX_LEN + 1) * 64;
-    const size_t ndg = 16 + 32 + MP_DIMER_MAX_LEN + 1 + 1;
-    uint8_t *d_codes = nullptr, *d_loss = nullptr;
-    int32_t *d_off = nullptr, *d_hits = nullptr;
-    double *d_dg = nullptr;
-    unsigned long long *d_n = nullptr;
     int rc;
-    if ((rc = dev_alloc(c, &d_codes, total))) return rc;
-    if ((rc = dev_alloc(c, &d_off, (size_t)n + 1))) return rc;
-    if ((rc = dev_alloc(c, &d_loss, tbl))) return rc;
-    if ((rc = dev_alloc(c, &d_dg, ndg))) return rc;
-    if ((rc = dev_alloc(c, &d_hits, (size_t)cap * 6))) return rc;
-    if ((rc = dev_alloc(c, &d_n, 1))) return rc;
+    if ((rc = check_primers(c, n, codes, off))) return rc;
+    if ((rc = ensure_dimer_tables(c, loss_hit, dg))) return rc;
+    const size_t total = (size_t)off[n];
+    Scratch sc(c);
+    uint8_t *d_codes = nullptr;
+    int32_t *d_off = nullptr, *d_hits = nullptr;
+    unsigned long long *d_n = nullptr;
+    if ((rc = sc.alloc(&d_codes, total)) || (rc = sc.alloc(&d_off, (size_t)n + 1)) || (rc = sc.alloc(&d_hits, (size_t)cap * 6)) ||
+        (rc = sc.alloc(&d_n, 1))) return rc;
     HIPCK(c, hipMemcpyAsync(d_codes, codes, total, hipMemcpyHostToDevice, c->stream));
     HIPCK(c, hipMemcpyAsync(d_off, off, sizeof(int32_t) * ((size_t)n + 1), hipMemcpyHostToDevice, c->stream));
-    HIPCK(c, hipMemcpyAsync(d_loss, loss_hit, tbl, hipMemcpyHostToDevice, c->stream));
-    HIPCK(c, hipMemcpyAsync(d_dg, dg, sizeof(double) * ndg, hipMemcpyHostToDevice, c->stream));
     HIPCK(c, hipMemsetAsync(d_n, 0, sizeof(unsigned long long), c->stream));
-    DimerArgs da{d_codes, d_off, n, mode, n_new, d_loss, d_dg, dg_limit, (long long)cap, d_hits, d_n};
-    hipLaunchKernelGGL(dimer_kernel, dim3((unsigned)n, (unsigned)((n + kBlock - 1) / kBlock)), dim3(kBlock), 0, c->stream, da);
+    DimerArgs da{d_codes, d_off, n, mode, n_new, c->dm_loss, c->dm_dg, dg_limit, (long long)cap, d_hits, d_n};
+    // pairs the scan really visits: mode 1 only those touching one of the n_new new primers
+    const long long all = (long long)n * n;
+    const long long visited = mode == 0 ? all / 2 + n : (long long)n_new * (2LL * n - n_new);
+    const int G = lanes_per_pair(visited);
+    if (G == 1) hipLaunchKernelGGL(dimer_kernel, dim3((unsigned)n, (unsigned)((n + kBlock - 1) / kBlock)), dim3(kBlock), 0, c->stream, da);
+    else {
+        const unsigned blocks = (unsigned)std::min<long long>((all + kBlock / G - 1) / (kBlock / G), 256 * 16);
+        if (G == 64) hipLaunchKernelGGL(dimer_group_kernel<64>, dim3(blocks), dim3(kBlock), 0, c->stream, da, all, (const int32_t *)nullptr, (uint8_t *)nullptr);
+        else hipLaunchKernelGGL(dimer_group_kernel<16>, dim3(blocks), dim3(kBlock), 0, c->stream, da, all, (const int32_t *)nullptr, (uint8_t *)nullptr);
+    }
     HIPCK(c, hipGetLastError());
     unsigned long long nh = 0;
     HIPCK(c, hipMemcpyAsync(&nh, d_n, sizeof(nh), hipMemcpyDeviceToHost, c->stream));
@@ -417,8 +448,6 @@ int mp_dimer_scan(mp_ctx *c, int32_t n, const uint8_t *codes, const int32_t *off
     size_t ncopy = (size_t)std::min<unsigned long long>(nh, (unsigned long long)cap);
     if (ncopy) HIPCK(c, hipMemcpy(hits, d_hits, sizeof(int32_t) * 6 * ncopy, hipMemcpyDeviceToHost));
     *n_hits = (int64_t)nh;
-    dev_free(c, &d_codes, total); dev_free(c, &d_off, (size_t)n + 1); dev_free(c, &d_loss, tbl);
-    dev_free(c, &d_dg, ndg); dev_free(c, &d_hits, (size_t)cap * 6); dev_free(c, &d_n, 1);
     return MP_OK;
 }
 
@@ -434,29 +463,29 @@ int mp_dimer_pairs(mp_ctx *c, int32_t n, const uint8_t *codes, const int32_t *of
     if ((rc = check_primers(c, n, codes, off))) return rc;
     for (int64_t p = 0; p < 2 * n_pairs; p++)
         if (pairs[p] < 0 || pairs[p] >= n) return fail(c, MP_ERR_ARG, "pair %lld out of range", (long long)(p / 2));
-    const size_t total = (size_t)off[n], tbl = (size_t)(MP_DIMER_MAX_LEN + 1) * (MP_DIMER_MAX_LEN + 1) * 64;
-    const size_t ndg = 16 + 32 + MP_DIMER_MAX_LEN + 1 + 1;
-    uint8_t *d_codes = nullptr, *d_loss = nullptr, *d_flags = nullptr;
+    if ((rc = ensure_dimer_tables(c, loss_hit, dg))) return rc;
+    const size_t total = (size_t)off[n];
+    Scratch sc(c);
+    uint8_t *d_codes = nullptr, *d_flags = nullptr;
     int32_t *d_off = nullptr, *d_pairs = nullptr;
-    double *d_dg = nullptr;
-    if ((rc = dev_alloc(c, &d_codes, total))) return rc;
-    if ((rc = dev_alloc(c, &d_off, (size_t)n + 1))) return rc;
-    if ((rc = dev_alloc(c, &d_loss, tbl))) return rc;
-    if ((rc = dev_alloc(c, &d_dg, ndg))) return rc;
-    if ((rc = dev_alloc(c, &d_pairs, (size_t)2 * n_pairs))) return rc;
-    if ((rc = dev_alloc(c, &d_flags, (size_t)n_pairs))) return rc;
+    if ((rc = sc.alloc(&d_codes, total)) || (rc = sc.alloc(&d_off, (size_t)n + 1)) || (rc = sc.alloc(&d_pairs, (size_t)2 * n_pairs)) ||
+        (rc = sc.alloc(&d_flags, (size_t)n_pairs))) return rc;
     HIPCK(c, hipMemcpyAsync(d_codes, codes, total, hipMemcpyHostToDevice, c->stream));
     HIPCK(c, hipMemcpyAsync(d_off, off, sizeof(int32_t) * ((size_t)n + 1), hipMemcpyHostToDevice, c->stream));
-    HIPCK(c, hipMemcpyAsync(d_loss, loss_hit, tbl, hipMemcpyHostToDevice, c->stream));
-    HIPCK(c, hipMemcpyAsync(d_dg, dg, sizeof(double) * ndg, hipMemcpyHostToDevice, c->stream));
     HIPCK(c, hipMemcpyAsync(d_pairs, pairs, sizeof(int32_t) * 2 * (size_t)n_pairs, hipMemcpyHostToDevice, c->stream));
-    hipLaunchKernelGGL(dimer_pairs_kernel, dim3((unsigned)((n_pairs + kBlock - 1) / kBlock)), dim3(kBlock), 0, c->stream, d_codes,
-                       d_off, (long long)n_pairs, d_pairs, d_loss, d_dg, dg_limit, d_flags);
+    const int G = lanes_per_pair((long long)n_pairs);
+    if (G == 1)
+        hipLaunchKernelGGL(dimer_pairs_kernel, dim3((unsigned)((n_pairs + kBlock - 1) / kBlock)), dim3(kBlock), 0, c->stream, d_codes,
+                           d_off, (long long)n_pairs, d_pairs, c->dm_loss, c->dm_dg, dg_limit, d_flags);
+    else {
+        DimerArgs da{d_codes, d_off, n, 0, 0, c->dm_loss, c->dm_dg, dg_limit, 0, nullptr, nullptr};
+        const unsigned blocks = (unsigned)std::min<long long>((n_pairs + kBlock / G - 1) / (kBlock / G), 256 * 16);
+        if (G == 64) hipLaunchKernelGGL(dimer_group_kernel<64>, dim3(blocks), dim3(kBlock), 0, c->stream, da, (long long)n_pairs, (const int32_t *)d_pairs, d_flags);
+        else hipLaunchKernelGGL(dimer_group_kernel<16>, dim3(blocks), dim3(kBlock), 0, c->stream, da, (long long)n_pairs, (const int32_t *)d_pairs, d_flags);
+    }
     HIPCK(c, hipGetLastError());
     HIPCK(c, hipMemcpyAsync(flags, d_flags, (size_t)n_pairs, hipMemcpyDeviceToHost, c->stream));
     HIPCK(c, hipStreamSynchronize(c->stream));
-    dev_free(c, &d_codes, total); dev_free(c, &d_off, (size_t)n + 1); dev_free(c, &d_loss, tbl); dev_free(c, &d_dg, ndg);
-    dev_free(c, &d_pairs, (size_t)2 * n_pairs); dev_free(c, &d_flags, (size_t)n_pairs);
     return MP_OK;
 }
 

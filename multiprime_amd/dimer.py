@@ -85,7 +85,8 @@ def encode_primers(seqs):
     np.cumsum([len(s) for s in seqs], out=off[1:])
     for s in seqs:
         if not 1 <= len(s) <= MAX_LEN:
-            raise ValueError(f"primer length {len(s)} outside 1..{MAX_LEN}: {s}")
+            # the reference has no length limit; this build packs a primer into 64 bits ("Limits")
+            raise ValueError(f"primer length {len(s)} outside 1..{MAX_LEN} (limit of this build, see INTEGRATION.md): {s}")
     if (codes == 0).any():
         raise ValueError("primers may only hold IUPAC nucleotide codes")
     return codes, off
@@ -167,9 +168,9 @@ class DimerExaminer:
         self.limit = dg_limit()
 
     def any_dimer(self, new: list[str], selected: list[str]) -> bool:
-        new = [s for s in dict.fromkeys(new) if s not in set(selected)]
+        sel = set(selected)
+        new = [s for s in dict.fromkeys(new) if s not in sel]
         if not new:
             return False
         codes, off = encode_primers(new + list(selected))
-        hits = self.ctx.dimer_scan(codes, off, 1, len(new), self.loss, self.dg, self.limit, cap=16)
-        return len(hits) > 0
+        return self.ctx.dimer_any(codes, off, 1, len(new), self.loss, self.dg, self.limit)

@@ -92,7 +92,7 @@ class Product(object):
         flat = [s for n in names for s in self.primers[n]]
         codes, off = encode_primers(flat) if flat else (np.zeros(0, np.uint8), np.zeros(1, np.int32))
         t0 = time.time()
-        hits = self.ctx.pcr_scan(data, row_off, codes, off) if names and bodies else np.zeros((len(names), len(bodies), 4), np.int32)
+        hits = self.ctx.pcr_scan(data, row_off, codes, off) if names and bodies else np.full((len(names), len(bodies), 4), -1, np.int32)   # -1 = no amplicon (0 would read "expansion 0 at position 0")
         self.stats["scan_s"] = time.time() - t0
         product_ids = set()
         for pi, name in enumerate(names):
