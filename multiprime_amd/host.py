@@ -51,10 +51,11 @@ def dll():
     """The product library's host-stage entry points (loaded once; raises if the library is missing)."""
     global _dll
     if _dll is None:
-        if not os.path.exists(HIP_LIB):
+        path = os.environ.get("MP_HOST_LIB", HIP_LIB)       # MP_HOST_LIB: a sanitizer build of hostplan.cpp + fasta.cpp (tools/sanitize_host.sh)
+        if not os.path.exists(path):
             raise MprimeError(-2, f"{HIP_LIB} is missing — build it with `python -c 'import __graft_entry__ as g; g.build()'`; "
                                   "the host stage has no Python fallback")
-        d = C.CDLL(HIP_LIB)
+        d = C.CDLL(path)
         for name, res, args in HOST_SYMBOLS:
             fn = getattr(d, name)
             fn.restype = res

@@ -36,6 +36,9 @@ def kat():
 @pytest.fixture(scope="session")
 def oracle_lib():
     """The CPU oracle behind the same C ABI (test infrastructure; built on demand)."""
+    if os.environ.get("MP_ORACLE_LIB"):                       # tools/sanitize_host.sh: an ASAN/UBSAN build of the oracle
+        from multiprime_amd._abi import Library
+        return Library(os.environ["MP_ORACLE_LIB"])
     so = os.path.join(REPO, "oracle", "_build", "libmprime_oracle.so")
     src = os.path.join(REPO, "oracle", "mprime_oracle.c")
     if not os.path.exists(so) or os.path.getmtime(so) < os.path.getmtime(src):
