@@ -203,32 +203,41 @@ struct CompactArgs {
     long long cap;
 };
 
-// occupied slots -> entries of the window's segment (order inside a window is unspecified)
+// occupied slots -> entries of the window's segment (order inside a window is unspecified).  One workgroup per window
+// walks the window's table with a running count in LDS: no global atomics (a returning atomic per wave on ~1000 hot
+// addresses made the first version 0.7 ms at 131072 x 1000 for 128 MB of reads).
 __global__ __launch_bounds__(kBlock) void compact_kernel(const CompactArgs A) {
-    const int per_win = A.g_slots / kBlock;                  // g_slots is a multiple of kBlock
-    const int w = blockIdx.x / per_win;
-    const int i = (blockIdx.x % per_win) * kBlock + threadIdx.x;
-    const size_t s = (size_t)w * A.g_slots + i;
-    const unsigned long long key = A.g_key[s];
-    const bool occ = key != kNoKey;
-    const unsigned long long m = __ballot(occ);
-    if (!m) return;
-    const int lane = threadIdx.x & 63;
-    const int leader = __ffsll((long long)m) - 1;
-    int base = 0;
-    if (lane == leader) base = atomicAdd(&A.win_cursor[w], (int)__popcll(m));
-    base = __shfl(base, leader);
-    if (!occ) return;
-    const int idx = base + (int)__popcll(m & ((1ull << lane) - 1ull));
-    A.g_idx[s] = idx;
-    const long long e = A.win_base[w] + idx;
-    if (e < A.cap) {
-        const uint32_t kmask = (1u << A.k) - 1u;
-        A.b0[e] = (uint32_t)key & kmask;
-        A.b1[e] = (uint32_t)(key >> A.k) & kmask;
-        A.g[e] = (uint32_t)(key >> (2 * A.k)) & kmask;
-        A.count[e] = (int32_t)A.g_cnt[s];
-        A.first[e] = (int32_t)A.g_min[s];
+    __shared__ int s_wave[kBlock / 64];
+    __shared__ int s_base;
+    const int w = blockIdx.x;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (threadIdx.x == 0) s_base = 0;
+    __syncthreads();
+    const uint32_t kmask = (1u << A.k) - 1u;
+    for (int i0 = 0; i0 < A.g_slots; i0 += kBlock) {
+        const size_t s = (size_t)w * A.g_slots + i0 + threadIdx.x;
+        const unsigned long long key = A.g_key[s];
+        const bool occ = key != kNoKey;
+        const unsigned long long m = __ballot(occ);
+        if (lane == 0) s_wave[wave] = (int)__popcll(m);
+        __syncthreads();
+        int before = s_base;
+        for (int q = 0; q < wave; q++) before += s_wave[q];
+        if (occ) {
+            const int idx = before + (int)__popcll(m & ((1ull << lane) - 1ull));
+            A.g_idx[s] = idx;
+            const long long e = A.win_base[w] + idx;
+            if (e < A.cap) {
+                A.b0[e] = (uint32_t)key & kmask;
+                A.b1[e] = (uint32_t)(key >> A.k) & kmask;
+                A.g[e] = (uint32_t)(key >> (2 * A.k)) & kmask;
+                A.count[e] = (int32_t)A.g_cnt[s];
+                A.first[e] = (int32_t)A.g_min[s];
+            }
+        }
+        __syncthreads();
+        if (threadIdx.x == 0) { int t = 0; for (int q = 0; q < kBlock / 64; q++) t += s_wave[q]; s_base += t; }
+        __syncthreads();
     }
 }
 
@@ -448,7 +457,7 @@ int unique_packed(mp_ctx *c, int64_t cap, int32_t want_labels, int64_t *n_entrie
     HIPCK(c, hipMemsetAsync(d_cursor, 0, sizeof(int32_t) * W, c->stream));
     CompactArgs CA{c->g_key, c->g_cnt, c->g_min, c->g_idx, c->g_slots, c->k, c->u_wbase, d_cursor,
                    c->u_b0, c->u_b1, c->u_g, c->u_count, c->u_first, (long long)c->u_cap};
-    hipLaunchKernelGGL(compact_kernel, dim3((unsigned)((size_t)(c->g_slots / kBlock) * W)), dim3(kBlock), 0, c->stream, CA);
+    hipLaunchKernelGGL(compact_kernel, dim3((unsigned)W), dim3(kBlock), 0, c->stream, CA);
     HIPCK(c, hipGetLastError());
     if (want_labels) {
         if ((rc = dev_alloc(c, &c->labels, W * np))) return rc;

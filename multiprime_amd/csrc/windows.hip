@@ -38,58 +38,60 @@ struct PatchOut {
 // `fast` = the k-mer at offset o is the plain column slice (fast_words() of winwords.hpp, 32 windows per instruction).
 // Only the gap count (> v gaps: outside every count, V20:689) is taken window by window (shift, mask, popcount).
 // Per (wave, window) there remain two ballots that turn lane bits into the row-bit words of `excl` and the slow-pair lists.
-__global__ __launch_bounds__(kBlock) void classify_kernel(const MsaArgs M, int p0, int n_win, int k, int v, PatchOut po) {
-    const int r = blockIdx.x * kBlock + threadIdx.x;
-    if (r >= M.n_pad) return;
+constexpr int kClsBlock = 1024;          // 16 waves = 1024 rows per workgroup: a window's 16 `excl` words leave as one 128-byte store
+
+__global__ __launch_bounds__(kClsBlock) void classify_kernel(const MsaArgs M, int p0, int n_win, int k, int v, PatchOut po) {
+    // ballot words of (window offset, wave): the `excl` array is window-major, so the 32 x 16 words of a workgroup are
+    // transposed through LDS and stored 16 consecutive words at a time (a lone 8-byte store per (wave, window) cost
+    // 0.8 ms per pass at 131072 x 1000: 2 M scattered partial-line writes)
+    __shared__ unsigned long long s_flag[32][kClsBlock / 64];
+    const int r = blockIdx.x * kClsBlock + threadIdx.x;
     const int n_rows = M.n_rows;
     const int c = (p0 >> 5) + blockIdx.y;                    // chunk of the window starts handled here
     const int o_lo = max(0, p0 - c * 32), o_hi = min(32, p0 + n_win - c * 32);      // start offsets [o_lo, o_hi) are windows
     const uint32_t kmask = (1u << k) - 1u;
     const size_t np = (size_t)M.n_pad;
-    const unsigned long long real = __ballot(r < n_rows);
-    if (r >= n_rows) {                       // padding rows never take part
-        if (po.pass == 0 && real == 0ull && (threadIdx.x & 63) == 0)
-            for (int o = o_lo; o < o_hi; o++) po.excl[(size_t)(c * 32 + o - p0) * (np / 64) + (size_t)(r >> 6)] = ~0ull;
-        return;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const bool in_pad = r < M.n_pad, real_row = r < n_rows;
+    uint32_t fast = 0, flag = 0xFFFFFFFFu;                   // rows that do not exist: not plain, flagged
+    if (real_row) {
+        const int len = M.rlen[r];
+        const uint32_t *P = M.planes + ((size_t)c * 4) * np + r;
+        const uint32_t loA = P[0], loC = P[np], loG = P[2 * np], loT = P[3 * np];
+        const uint32_t hiA = P[4 * np], hiC = P[5 * np], hiG = P[6 * np], hiT = P[7 * np];      // chunk c+1 exists: n_chunks is padded by two
+        const uint32_t lo1 = loA | loC, lo2 = loG | loT, hi1 = hiA | hiC, hi2 = hiG | hiT;
+        const unsigned long long N = (unsigned long long)(lo1 | lo2) | ((unsigned long long)(hi1 | hi2) << 32);
+        const unsigned long long Mu = (unsigned long long)((loA & loC) | (loG & loT) | (lo1 & lo2)) |
+                                      ((unsigned long long)((hiA & hiC) | (hiG & hiT) | (hi1 & hi2)) << 32);
+        // sliding OR over k columns: X_t covers t columns, t the largest power of two <= k; cover(o) = X_t(o) | X_t(o + k - t)
+        auto cover = [k](unsigned long long X) {
+            int t = 1;
+            while (2 * t <= k) { X |= X >> t; t *= 2; }
+            return X | (X >> (k - t));
+        };
+        const uint32_t any_iupac = (uint32_t)cover(Mu), any_res = (uint32_t)cover(N);
+        const uint32_t ends_ok = (uint32_t)N & (uint32_t)(N >> (k - 1));
+        const int room = len - k - c * 32;                                             // offsets 0..room lie inside the row
+        const uint32_t inrow = room < 0 ? 0u : (room >= 31 ? 0xFFFFFFFFu : ((2u << room) - 1u));
+        fast = inrow & ~any_iupac & (~any_res | ends_ok);
+        flag = ~fast;                                                                   // excl: not a plain slice, or more than v gaps
+        if (po.pass == 0)
+            for (int o = o_lo; o < o_hi; o++)
+                if ((int)__popc(~(uint32_t)(N >> o) & kmask) > v) flag |= 1u << o;
     }
-    const int lane = threadIdx.x & 63;
-    const unsigned long long live = __ballot(true);          // the lanes of a wave that are still here are all real rows
-    const int leader = __ffsll((long long)live) - 1;
-    const int len = M.rlen[r];
-    const uint32_t *P = M.planes + ((size_t)c * 4) * np + r;
-    const uint32_t loA = P[0], loC = P[np], loG = P[2 * np], loT = P[3 * np];
-    const uint32_t hiA = P[4 * np], hiC = P[5 * np], hiG = P[6 * np], hiT = P[7 * np];      // chunk c+1 exists: n_chunks is padded by two
-    const uint32_t lo1 = loA | loC, lo2 = loG | loT, hi1 = hiA | hiC, hi2 = hiG | hiT;
-    const unsigned long long N = (unsigned long long)(lo1 | lo2) | ((unsigned long long)(hi1 | hi2) << 32);
-    const unsigned long long Mu = (unsigned long long)((loA & loC) | (loG & loT) | (lo1 & lo2)) |
-                                  ((unsigned long long)((hiA & hiC) | (hiG & hiT) | (hi1 & hi2)) << 32);
-    // sliding OR over k columns: X_t covers t columns, t the largest power of two <= k; cover(o) = X_t(o) | X_t(o + k - t)
-    auto cover = [k](unsigned long long X) {
-        int t = 1;
-        while (2 * t <= k) { X |= X >> t; t *= 2; }
-        return X | (X >> (k - t));
-    };
-    const uint32_t any_iupac = (uint32_t)cover(Mu), any_res = (uint32_t)cover(N);
-    const uint32_t ends_ok = (uint32_t)N & (uint32_t)(N >> (k - 1));
-    const int room = len - k - c * 32;                                             // offsets 0..room lie inside the row
-    const uint32_t inrow = room < 0 ? 0u : (room >= 31 ? 0xFFFFFFFFu : ((2u << room) - 1u));
-    const uint32_t fast = inrow & ~any_iupac & (~any_res | ends_ok);
-    uint32_t flag = ~fast;                                                          // excl: not a plain slice, or more than v gaps
-    if (po.pass == 0)
-        for (int o = o_lo; o < o_hi; o++)
-            if ((int)__popc(~(uint32_t)(N >> o) & kmask) > v) flag |= 1u << o;
     for (int o = o_lo; o < o_hi; o++) {
         const int w = c * 32 + o - p0;
-        const bool is_slow = !((fast >> o) & 1u);
+        const bool is_slow = real_row && !((fast >> o) & 1u);
         const unsigned long long slow = __ballot(is_slow);
         if (po.pass == 0) {
-            const unsigned long long flg = __ballot((flag >> o) & 1u) | ~real;
-            if (lane == leader) {
-                po.excl[(size_t)w * (np / 64) + (size_t)(r >> 6)] = flg;
+            const unsigned long long flg = __ballot((flag >> o) & 1u);
+            if (lane == 0) {
+                s_flag[o][wave] = flg;
                 if (slow) atomicAdd(&po.count[w], (int)__popcll(slow));
             }
         } else if (slow) {
             int base = 0;
+            const int leader = __ffsll((long long)slow) - 1;
             if (lane == leader) base = atomicAdd(&po.cursor[w], (int)__popcll(slow));
             base = __shfl(base, leader);
             if (is_slow) {
@@ -99,6 +101,15 @@ __global__ __launch_bounds__(kBlock) void classify_kernel(const MsaArgs M, int p
             }
         }
     }
+    if (po.pass != 0) return;
+    __syncthreads();
+    // 32 windows x 16 row words: thread t stores word (t % 16) of window offset (t / 16) — 16 lanes, 128 contiguous bytes
+    const int o = threadIdx.x >> 4, j = threadIdx.x & 15;
+    if (threadIdx.x < 32 * 16 && o >= o_lo && o < o_hi) {
+        const size_t word = (size_t)blockIdx.x * (kClsBlock / 64) + j;
+        if (word < np / 64) po.excl[(size_t)(c * 32 + o - p0) * (np / 64) + word] = s_flag[o][j];
+    }
+    (void)in_pad;
 }
 
 // thread = one slow (window, row) pair: V20:668-687 line by line (winwords.hpp).  Writes the pair's window words (SKIP when the
@@ -164,13 +175,13 @@ int mp_build_windows(mp_ctx *c, int32_t p0, int32_t n_win, int32_t k, int32_t v,
     if ((rc = dev_alloc(c, &c->patch_count, (size_t)n_win))) return rc;
     if ((rc = dev_alloc(c, &c->patch_off, (size_t)n_win + 1))) return rc;
     if ((rc = dev_alloc(c, &c->patch_cursor, (size_t)n_win))) return rc;
-    const dim3 grid((unsigned)(c->n_pad / kBlock), (unsigned)(((p0 + n_win - 1) >> 5) - (p0 >> 5) + 1));   // y: chunks holding window starts
+    const dim3 grid((unsigned)((c->n_pad + kClsBlock - 1) / kClsBlock), (unsigned)(((p0 + n_win - 1) >> 5) - (p0 >> 5) + 1));   // y: chunks holding window starts
     const MsaArgs M = msa_args(c);
     HIPCK(c, hipMemsetAsync(c->ex_count, 0, sizeof(int), c->stream));
     HIPCK(c, hipMemsetAsync(c->err_flag, 0, 4 * sizeof(int), c->stream));
     HIPCK(c, hipMemsetAsync(c->excl, 0, sizeof(unsigned long long) * (size_t)n_win * nw, c->stream));
     HIPCK(c, hipMemsetAsync(c->patch_count, 0, sizeof(int32_t) * (size_t)n_win, c->stream));
-    hipLaunchKernelGGL(classify_kernel, grid, dim3(kBlock), 0, c->stream, M, p0, n_win, k, v,
+    hipLaunchKernelGGL(classify_kernel, grid, dim3(kClsBlock), 0, c->stream, M, p0, n_win, k, v,
                        PatchOut{0, c->excl, c->patch_count, nullptr, nullptr, nullptr, nullptr});
     HIPCK(c, hipGetLastError());
     // slow pairs per window -> offsets on the host, then the listing pass and the repair
@@ -203,7 +214,7 @@ int mp_build_windows(mp_ctx *c, int32_t p0, int32_t n_win, int32_t k, int32_t v,
         hipError_t e = hipMemsetAsync(c->patch_cursor, 0, sizeof(int32_t) * (size_t)n_win, c->stream);
         int cnt = 0, errv[4] = {0, 0, 0, 0};
         if (e == hipSuccess) {
-            hipLaunchKernelGGL(classify_kernel, grid, dim3(kBlock), 0, c->stream, M, p0, n_win, k, v,
+            hipLaunchKernelGGL(classify_kernel, grid, dim3(kClsBlock), 0, c->stream, M, p0, n_win, k, v,
                                PatchOut{1, c->excl, c->patch_count, c->patch_off, c->patch_cursor, c->patch_rows, d_wins});
             hipLaunchKernelGGL(repair_kernel, dim3((unsigned)((tot + kBlock - 1) / kBlock)), dim3(kBlock), 0, c->stream, M, p0, k, (int)tot,
                                (const int32_t *)c->patch_rows, (const int32_t *)d_wins, c->patch_words, c->ex, c->ex_count, c->err_flag);
