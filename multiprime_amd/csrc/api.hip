@@ -35,9 +35,9 @@ void free_windows(mp_ctx *c) {
     free_eval(c);
     free_unique(c);
     dev_free(c, &c->excl, (size_t)c->n_win * (c->n_pad / 64));
-    dev_free(c, &c->patch_count, (size_t)c->n_win);
+    dev_free(c, &c->patch_count, (size_t)c->n_win * 32);
     dev_free(c, &c->patch_off, (size_t)c->n_win + 1);
-    dev_free(c, &c->patch_cursor, (size_t)c->n_win);
+    dev_free(c, &c->patch_cursor, (size_t)c->n_win * 32);
     dev_free(c, &c->patch_words, (size_t)3 * c->n_patch);
     dev_free(c, &c->patch_rows, (size_t)c->n_patch);
     c->n_patch = c->max_patch = 0;

@@ -43,7 +43,6 @@ struct HistArgs {
     unsigned long long *g_key;            // [W][g_slots]
     uint32_t *g_cnt, *g_min;
     int g_slots;
-    int32_t *g_used;                      // [W] occupied slots
     int32_t *g_over;                      // [W] 1 = the global table of the window is too small
     const int32_t *patch_off;             // [W+1] slow pairs of every window (mp_build_windows): rows and window words
     const int32_t *patch_rows;
@@ -59,7 +58,7 @@ __device__ inline void global_insert(const HistArgs &A, int w, unsigned long lon
         unsigned long long old = K[h];
         if (old == kNoKey) {
             old = atomicCAS(&K[h], kNoKey, key);
-            if (old == kNoKey) { atomicAdd(&A.g_used[w], 1); old = key; }
+            if (old == kNoKey) old = key;                 // claimed (occupied slots are counted afterwards, count_kernel)
         }
         if (old == key) {
             atomicAdd(&A.g_cnt[(size_t)w * A.g_slots + h], cnt);
@@ -202,6 +201,20 @@ struct CompactArgs {
     int32_t *count, *first;
     long long cap;
 };
+
+// occupied slots per window (a counter bumped at every claim would be ~2 x 10^6 atomics on 31 cache lines)
+__global__ __launch_bounds__(kBlock) void count_kernel(const unsigned long long *__restrict__ g_key, int g_slots, int32_t *__restrict__ used) {
+    __shared__ int s_n;
+    const int w = blockIdx.x;
+    if (threadIdx.x == 0) s_n = 0;
+    __syncthreads();
+    int n = 0;
+    for (int i = threadIdx.x; i < g_slots; i += kBlock) n += g_key[(size_t)w * g_slots + i] != kNoKey;
+    for (int sft = 32; sft >= 1; sft >>= 1) n += __shfl_xor(n, sft);
+    if ((threadIdx.x & 63) == 0) atomicAdd(&s_n, n);
+    __syncthreads();
+    if (threadIdx.x == 0) used[w] = s_n;
+}
 
 // occupied slots -> entries of the window's segment (order inside a window is unspecified).  One workgroup per window
 // walks the window's table with a running count in LDS: no global atomics (a returning atomic per wave on ~1000 hot
@@ -424,7 +437,7 @@ int unique_packed(mp_ctx *c, int64_t cap, int32_t want_labels, int64_t *n_entrie
         HIPCK(c, hipMemsetAsync(c->g_min, 0xFF, sizeof(uint32_t) * n, c->stream));
         HIPCK(c, hipMemsetAsync(c->u_wcount, 0, sizeof(int32_t) * W, c->stream));
         HIPCK(c, hipMemsetAsync(c->u_over, 0, sizeof(int32_t) * W, c->stream));
-        HistArgs A{msa_args(c), c->p0, c->k, c->n_win, 0, 0, 0, c->g_key, c->g_cnt, c->g_min, slots, c->u_wcount, c->u_over,
+        HistArgs A{msa_args(c), c->p0, c->k, c->n_win, 0, 0, 0, c->g_key, c->g_cnt, c->g_min, slots, c->u_over,
                    c->n_patch ? c->patch_off : (const int32_t *)nullptr, c->patch_rows, c->patch_words};
         // enough workgroups to fill 256 CUs several times over, slices of at least 4096 rows
         int n_slices = (int)std::max<size_t>(1, std::min<size_t>((np + 4095) / 4096, (8192 + W - 1) / W));
@@ -434,6 +447,7 @@ int unique_packed(mp_ctx *c, int64_t cap, int32_t want_labels, int64_t *n_entrie
         A.win_per_xcd = (int)((W + 7) / 8);
         const unsigned blocks = 8u * (unsigned)A.win_per_xcd * (unsigned)A.n_slices;
         hipLaunchKernelGGL(hist_kernel, dim3(blocks), dim3(kBlock), 0, c->stream, A);
+        hipLaunchKernelGGL(count_kernel, dim3((unsigned)W), dim3(kBlock), 0, c->stream, (const unsigned long long *)c->g_key, slots, c->u_wcount);
         HIPCK(c, hipGetLastError());
         HIPCK(c, hipMemcpyAsync(used.data(), c->u_wcount, sizeof(int32_t) * W, hipMemcpyDeviceToHost, c->stream));
         HIPCK(c, hipMemcpyAsync(over.data(), c->u_over, sizeof(int32_t) * W, hipMemcpyDeviceToHost, c->stream));

@@ -38,6 +38,7 @@ struct PatchOut {
 // `fast` = the k-mer at offset o is the plain column slice (fast_words() of winwords.hpp, 32 windows per instruction).
 // Only the gap count (> v gaps: outside every count, V20:689) is taken window by window (shift, mask, popcount).
 // Per (wave, window) there remain two ballots that turn lane bits into the row-bit words of `excl` and the slow-pair lists.
+constexpr int kCtrStride = 32;            // ints between two windows' global counters: one 128-byte line each
 constexpr int kClsBlock = 1024;          // 16 waves = 1024 rows per workgroup: a window's 16 `excl` words leave as one 128-byte store
 
 __global__ __launch_bounds__(kClsBlock) void classify_kernel(const MsaArgs M, int p0, int n_win, int k, int v, PatchOut po) {
@@ -45,6 +46,9 @@ __global__ __launch_bounds__(kClsBlock) void classify_kernel(const MsaArgs M, in
     // transposed through LDS and stored 16 consecutive words at a time (a lone 8-byte store per (wave, window) cost
     // 0.8 ms per pass at 131072 x 1000: 2 M scattered partial-line writes)
     __shared__ unsigned long long s_flag[32][kClsBlock / 64];
+    __shared__ int s_slow[32], s_base[32];   // slow pairs of this workgroup per window offset / their first slot in the window's list
+    if (threadIdx.x < 32) s_slow[threadIdx.x] = 0;
+    __syncthreads();
     const int r = blockIdx.x * kClsBlock + threadIdx.x;
     const int n_rows = M.n_rows;
     const int c = (p0 >> 5) + blockIdx.y;                    // chunk of the window starts handled here
@@ -79,30 +83,50 @@ __global__ __launch_bounds__(kClsBlock) void classify_kernel(const MsaArgs M, in
             for (int o = o_lo; o < o_hi; o++)
                 if ((int)__popc(~(uint32_t)(N >> o) & kmask) > v) flag |= 1u << o;
     }
-    for (int o = o_lo; o < o_hi; o++) {
-        const int w = c * 32 + o - p0;
+    // The per-window counters are hot: ~5 x 10^5 (wave, window) steps hold a slow pair at 131072 x 1000.  Device-scope
+    // atomics on one cache line serialise (~50 ns each, measured: 0.8 ms per pass with a counter per 4 bytes), so a workgroup
+    // first adds up in LDS, issues ONE global atomic per window, and the global counters sit 128 bytes apart (kCtrStride).
+    int my_pos[32];                          // pass 1: rank of this lane's slow pair inside the workgroup, per window offset
+#pragma unroll
+    for (int o = 0; o < 32; o++) {           // fixed trip count: my_pos stays in registers
+        my_pos[o] = -1;
+        if (o < o_lo || o >= o_hi) continue;
         const bool is_slow = real_row && !((fast >> o) & 1u);
         const unsigned long long slow = __ballot(is_slow);
         if (po.pass == 0) {
             const unsigned long long flg = __ballot((flag >> o) & 1u);
             if (lane == 0) {
                 s_flag[o][wave] = flg;
-                if (slow) atomicAdd(&po.count[w], (int)__popcll(slow));
+                if (slow) atomicAdd(&s_slow[o], (int)__popcll(slow));
             }
-        } else if (slow) {
+        } else {
             int base = 0;
-            const int leader = __ffsll((long long)slow) - 1;
-            if (lane == leader) base = atomicAdd(&po.cursor[w], (int)__popcll(slow));
-            base = __shfl(base, leader);
-            if (is_slow) {
-                const int slot = po.off[w] + base + (int)__popcll(slow & ((1ull << lane) - 1ull));
-                po.rows[slot] = r;
-                po.wins[slot] = w;
+            if (slow) {
+                const int leader = __ffsll((long long)slow) - 1;
+                if (lane == leader) base = atomicAdd(&s_slow[o], (int)__popcll(slow));
+                base = __shfl(base, leader);
             }
+            my_pos[o] = is_slow ? base + (int)__popcll(slow & ((1ull << lane) - 1ull)) : -1;
         }
     }
-    if (po.pass != 0) return;
     __syncthreads();
+    if (threadIdx.x < 32 && threadIdx.x >= o_lo && threadIdx.x < o_hi && s_slow[threadIdx.x]) {
+        const int w = c * 32 + threadIdx.x - p0;
+        if (po.pass == 0) atomicAdd(&po.count[(size_t)w * kCtrStride], s_slow[threadIdx.x]);
+        else s_base[threadIdx.x] = atomicAdd(&po.cursor[(size_t)w * kCtrStride], s_slow[threadIdx.x]);
+    }
+    if (po.pass != 0) {
+        __syncthreads();
+#pragma unroll
+        for (int o = 0; o < 32; o++) {
+            if (my_pos[o] < 0) continue;
+            const int w = c * 32 + o - p0;
+            const int slot = po.off[w] + s_base[o] + my_pos[o];
+            po.rows[slot] = r;
+            po.wins[slot] = w;
+        }
+        return;
+    }
     // 32 windows x 16 row words: thread t stores word (t % 16) of window offset (t / 16) — 16 lanes, 128 contiguous bytes
     const int o = threadIdx.x >> 4, j = threadIdx.x & 15;
     if (threadIdx.x < 32 * 16 && o >= o_lo && o < o_hi) {
@@ -172,22 +196,23 @@ int mp_build_windows(mp_ctx *c, int32_t p0, int32_t n_win, int32_t k, int32_t v,
     HIPCK(c, hipMemsetAsync(c->extra_off, 0, sizeof(int32_t) * ((size_t)n_win + 1), c->stream));
     const size_t nw = np / 64;
     if ((rc = dev_alloc(c, &c->excl, (size_t)n_win * nw))) return rc;
-    if ((rc = dev_alloc(c, &c->patch_count, (size_t)n_win))) return rc;
+    if ((rc = dev_alloc(c, &c->patch_count, (size_t)n_win * kCtrStride))) return rc;
     if ((rc = dev_alloc(c, &c->patch_off, (size_t)n_win + 1))) return rc;
-    if ((rc = dev_alloc(c, &c->patch_cursor, (size_t)n_win))) return rc;
+    if ((rc = dev_alloc(c, &c->patch_cursor, (size_t)n_win * kCtrStride))) return rc;
     const dim3 grid((unsigned)((c->n_pad + kClsBlock - 1) / kClsBlock), (unsigned)(((p0 + n_win - 1) >> 5) - (p0 >> 5) + 1));   // y: chunks holding window starts
     const MsaArgs M = msa_args(c);
     HIPCK(c, hipMemsetAsync(c->ex_count, 0, sizeof(int), c->stream));
     HIPCK(c, hipMemsetAsync(c->err_flag, 0, 4 * sizeof(int), c->stream));
     HIPCK(c, hipMemsetAsync(c->excl, 0, sizeof(unsigned long long) * (size_t)n_win * nw, c->stream));
-    HIPCK(c, hipMemsetAsync(c->patch_count, 0, sizeof(int32_t) * (size_t)n_win, c->stream));
+    HIPCK(c, hipMemsetAsync(c->patch_count, 0, sizeof(int32_t) * (size_t)n_win * kCtrStride, c->stream));
     hipLaunchKernelGGL(classify_kernel, grid, dim3(kClsBlock), 0, c->stream, M, p0, n_win, k, v,
                        PatchOut{0, c->excl, c->patch_count, nullptr, nullptr, nullptr, nullptr});
     HIPCK(c, hipGetLastError());
     // slow pairs per window -> offsets on the host, then the listing pass and the repair
-    std::vector<int32_t> pc((size_t)n_win), po((size_t)n_win + 1, 0);
-    HIPCK(c, hipMemcpyAsync(pc.data(), c->patch_count, sizeof(int32_t) * (size_t)n_win, hipMemcpyDeviceToHost, c->stream));
+    std::vector<int32_t> pc((size_t)n_win), po((size_t)n_win + 1, 0), padded((size_t)n_win * kCtrStride);
+    HIPCK(c, hipMemcpyAsync(padded.data(), c->patch_count, sizeof(int32_t) * padded.size(), hipMemcpyDeviceToHost, c->stream));
     HIPCK(c, hipStreamSynchronize(c->stream));
+    for (int w = 0; w < n_win; w++) pc[(size_t)w] = padded[(size_t)w * kCtrStride];
     long long tot = 0;
     c->max_patch = 0;
     for (int w = 0; w < n_win; w++) {
@@ -211,7 +236,7 @@ int mp_build_windows(mp_ctx *c, int32_t p0, int32_t n_win, int32_t k, int32_t v,
         if ((rc = dev_alloc(c, &d_wins, (size_t)tot))) return rc;
         if ((rc = dev_alloc(c, &c->ex, (size_t)tot))) { dev_free(c, &d_wins, (size_t)tot); return rc; }
         c->ex_cap = (int)tot;
-        hipError_t e = hipMemsetAsync(c->patch_cursor, 0, sizeof(int32_t) * (size_t)n_win, c->stream);
+        hipError_t e = hipMemsetAsync(c->patch_cursor, 0, sizeof(int32_t) * (size_t)n_win * kCtrStride, c->stream);
         int cnt = 0, errv[4] = {0, 0, 0, 0};
         if (e == hipSuccess) {
             hipLaunchKernelGGL(classify_kernel, grid, dim3(kClsBlock), 0, c->stream, M, p0, n_win, k, v,
