@@ -149,6 +149,18 @@ int mp_eval_candidates(mp_ctx *ctx, int32_t n_cand, const int32_t *cand_window, 
 int mp_eval_masks(mp_ctx *ctx, int32_t n_cand, const int32_t *cand_window, const uint8_t *cand_codes,
                   uint32_t strictF, uint32_t strictR, uint64_t *not_f, uint64_t *not_r);
 
+/* (4d) the same masks kept on the device — the hand-off to the pairing stage when core and pairing run in one process:
+ * mp_eval_masks_resident computes them and leaves them in the context ([n_cand][row words]); mp_masks_set_bits applies the
+ * host's verdict on single (mask, row) bits (which[i] = 0: not_f, 1: not_r — the rows whose window held an IUPAC code, which
+ * the masks leave 0); mp_masks_fetch copies them out in mp_eval_masks's layout; mp_pair_coverage_resident returns, for every
+ * pair (i, j), popcount(not_f[i] | not_r[j]) — the sequences a forward primer at window i or a reverse primer at window j
+ * does not reach (get_multiPrime_V8.py:560-569) — without the masks ever leaving HBM. */
+int mp_eval_masks_resident(mp_ctx *ctx, int32_t n_cand, const int32_t *cand_window, const uint8_t *cand_codes,
+                           uint32_t strictF, uint32_t strictR);
+int mp_masks_set_bits(mp_ctx *ctx, int64_t n, const int32_t *mask_index, const int32_t *row, const uint8_t *which, const uint8_t *value);
+int mp_masks_fetch(mp_ctx *ctx, uint64_t *not_f, uint64_t *not_r);
+int mp_pair_coverage_resident(mp_ctx *ctx, int64_t n_pairs, const int32_t *pairs, int32_t *out);
+
 /* Device-resident form used by bench.py and the multi-GPU path: upload stages the candidate
  * tables once; launch enqueues the evaluation on the context's stream and leaves the
  * [n_cand][3] int64 counters in `device_out` (device memory owned by the caller, e.g. a torch

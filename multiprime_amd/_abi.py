@@ -41,6 +41,10 @@ SYMBOLS = [
     ("mp_get_labels", C.c_int, [_p, C.c_int32, _p]),
     ("mp_eval_candidates", C.c_int, [_p, C.c_int32, _p, _p, C.c_uint32, C.c_uint32, _p]),
     ("mp_eval_masks", C.c_int, [_p, C.c_int32, _p, _p, C.c_uint32, C.c_uint32, _p, _p]),
+    ("mp_eval_masks_resident", C.c_int, [_p, C.c_int32, _p, _p, C.c_uint32, C.c_uint32]),
+    ("mp_masks_set_bits", C.c_int, [_p, C.c_int64, _p, _p, _p, _p]),
+    ("mp_masks_fetch", C.c_int, [_p, _p, _p]),
+    ("mp_pair_coverage_resident", C.c_int, [_p, C.c_int64, _p, _p]),
     ("mp_eval_upload", C.c_int, [_p, C.c_int32, _p, _p, C.c_uint32, C.c_uint32]),
     ("mp_eval_launch", C.c_int, [_p, _p]),
     ("mp_eval_timing", C.c_int, [_p, C.c_int32, C.POINTER(C.c_double), C.POINTER(C.c_int32)]),
@@ -229,6 +233,35 @@ class Context:
         self._ck(self.d.mp_eval_masks(self.h, len(cand_window), _ptr(cand_window), _ptr(cand_codes), strictF, strictR,
                                       _ptr(nf), _ptr(nr)))
         return nf[: len(cand_window)], nr[: len(cand_window)]
+
+    def eval_masks_resident(self, cand_window, cand_codes, strictF: int, strictR: int):
+        """The same masks, left in device memory (fetch with masks_fetch, combine with pair_coverage_resident)."""
+        cand_window = np.ascontiguousarray(cand_window, dtype=np.int32)
+        cand_codes = np.ascontiguousarray(cand_codes, dtype=np.uint8).reshape(len(cand_window), self.k)
+        self._ck(self.d.mp_eval_masks_resident(self.h, len(cand_window), _ptr(cand_window), _ptr(cand_codes), strictF, strictR))
+        self.n_masks = len(cand_window)
+
+    def masks_set_bits(self, cand, row, which, value):
+        cand = np.ascontiguousarray(cand, dtype=np.int32)
+        row = np.ascontiguousarray(row, dtype=np.int32)
+        which = np.ascontiguousarray(which, dtype=np.uint8)
+        value = np.ascontiguousarray(value, dtype=np.uint8)
+        self._ck(self.d.mp_masks_set_bits(self.h, len(cand), _ptr(cand), _ptr(row), _ptr(which), _ptr(value)))
+
+    def masks_fetch(self):
+        nw = (self.n_rows + 63) // 64
+        nf = np.zeros((max(self.n_masks, 1), nw), np.uint64)
+        nr = np.zeros((max(self.n_masks, 1), nw), np.uint64)
+        if self.n_masks:
+            self._ck(self.d.mp_masks_fetch(self.h, _ptr(nf), _ptr(nr)))
+        return nf[: self.n_masks], nr[: self.n_masks]
+
+    def pair_coverage_resident(self, pairs) -> np.ndarray:
+        """popcount(not_f[i] | not_r[j]) over the resident masks for every (i, j) in pairs."""
+        pairs = np.ascontiguousarray(pairs, dtype=np.int32).reshape(-1, 2)
+        out = np.zeros(max(len(pairs), 1), np.int32)
+        self._ck(self.d.mp_pair_coverage_resident(self.h, len(pairs), _ptr(pairs), _ptr(out)))
+        return out[: len(pairs)]
 
     def eval_upload(self, cand_window, cand_codes, strictF: int, strictR: int):
         cand_window = np.ascontiguousarray(cand_window, dtype=np.int32)

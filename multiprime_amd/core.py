@@ -73,7 +73,7 @@ class NN_degenerate(object):
     def __init__(self, seq_file, primer_length=18, coverage=0.8, number_of_dege_bases=18, score_of_dege_bases=1000,
                  product_len=250, position="2,-1", variation=2, raw_entropy_threshold=3.6, distance=4, GC="0.4,0.6",
                  nproc=10, outfile="", *, library: Library | None = None, device: int = 0, comm=None,
-                 write_json: bool = True, write_bitsets: bool = False):
+                 write_json: bool = True, write_bitsets: bool = False, keep_bitsets: bool = False):
         self.primer_length = int(primer_length)
         self.coverage = coverage
         self.number_of_dege_bases = number_of_dege_bases
@@ -88,6 +88,8 @@ class NN_degenerate(object):
         self.outfile = outfile
         self.write_json = write_json
         self.write_bitsets = write_bitsets      # {out}.coverage_bitsets.npz: the bitset form of the two JSON files
+        self.keep_bitsets = keep_bitsets        # leave those bitsets on the device for a pairing stage in this process (pairing.Primers_filter(core=...))
+        self.mask_index = {}
         self.comm = comm                        # multiprime_amd.dist.RowShards or None
         k = self.primer_length
         if not 2 <= k <= 28:
@@ -252,9 +254,11 @@ class NN_degenerate(object):
                 if side is not None:
                     non_cov_out[pos], gap_out[pos] = side(wins[i], primer)
             self.stats["finish_s"] = time.time() - t0
-            if self.write_bitsets:
+            if self.write_bitsets or self.keep_bitsets:
                 t0 = time.time()
-                self._write_bitsets(rows_out)
+                self._resident_bitsets(rows_out)
+                if self.write_bitsets:
+                    self._write_bitsets(rows_out)
                 self.stats["bitsets_s"] = time.time() - t0
         if self.comm is None or self.comm.rank == 0:
             self._write(rows_out, non_cov_out, gap_out)
@@ -347,19 +351,63 @@ class NN_degenerate(object):
 
         return build
 
-    def _write_bitsets(self, rows_out):
-        """Per output window, which sequences a forward / reverse primer there does NOT reach — exactly
-        the union the pairing stage takes of gap_seq_id and non_coverage_seq_id (get_multiPrime_V8.py:
-        560-567) — as bits, one per sequence, from one mp_eval_masks launch.  O(W x N / 8) bytes."""
+    def _resident_bitsets(self, rows_out):
+        """Per output window, which sequences a forward / reverse primer there does NOT reach — exactly the union the
+        pairing stage takes of gap_seq_id and non_coverage_seq_id (get_multiPrime_V8.py:560-567) — as bits, one per
+        sequence, computed by one mp_eval_masks_resident launch and LEFT ON THE DEVICE (mask i = output row i);
+        the rows whose window held an IUPAC code are decided here on the host and patched in (mp_masks_set_bits)."""
         k, v = self.primer_length, self.variation
         p0 = int(self.start_position)
         n_out = len(rows_out)
         wins = np.asarray([int(r[0]) - p0 for r in rows_out], np.int32)
-        if n_out:
-            codes = iupac.MASK_LUT[np.frombuffer("".join(r[3] for r in rows_out).encode(), np.uint8)].reshape(n_out, k)
-            nf, nr = self.ctx.eval_masks(wins, codes, self._sF, self._sR)
-        else:
-            nf = nr = np.zeros((0, 1), np.uint64)
+        codes = (iupac.MASK_LUT[np.frombuffer("".join(r[3] for r in rows_out).encode(), np.uint8)].reshape(n_out, k)
+                 if n_out else np.zeros((0, k), np.uint8))
+        t0 = time.time()
+        self.ctx.eval_masks_resident(wins, codes, self._sF, self._sR)
+        self.stats["bitsets_masks_s"] = time.time() - t0
+        self.mask_index = {int(r[0]): i for i, r in enumerate(rows_out)}
+        # rows whose window held an IUPAC code: every expansion must be reached (V20:701-707 puts the id
+        # under each expansion's k-mer), gap-type ones are in gap_seq_id
+        ex_w = self._exc[0]
+        fix = []                                     # (mask, local row, which, value)
+        if len(ex_w) and n_out:
+            touched = np.isin(wins, ex_w)
+            if touched.any():
+                exc = self._exceptions_by_window()
+                row0 = self.comm.row0 if self.comm is not None else 0
+                n_local = self.ctx.n_rows
+                for i in np.nonzero(touched)[0].tolist():
+                    pc = iupac.codes_of(rows_out[i][3])
+                    for r_glob, raw in exc.get(int(wins[i]), ()):
+                        r_loc = r_glob - row0
+                        if not 0 <= r_loc < n_local:
+                            continue
+                        if raw.count("-") > v:
+                            fix.append((i, r_loc, 0, 1))
+                            fix.append((i, r_loc, 1, 1))
+                            continue
+                        bad_f = bad_r = False
+                        for e in iupac.expand(raw):
+                            D, nd = 0, 0
+                            for j, ch in enumerate(e):
+                                if ch == "-" or not (pc[j] >> _B2I[ch]) & 1:
+                                    D |= 1 << j
+                                    nd += 1
+                            if nd == 0:
+                                continue
+                            bad_f |= nd > v or bool(D & self._sF)
+                            bad_r |= nd > v or bool(D & self._sR)
+                        fix.append((i, r_loc, 0, int(bad_f)))
+                        fix.append((i, r_loc, 1, int(bad_r)))
+        if fix:
+            f = np.asarray(fix, np.int64)
+            self.ctx.masks_set_bits(f[:, 0], f[:, 1], f[:, 2], f[:, 3])
+
+    def _write_bitsets(self, rows_out):
+        """{out}.coverage_bitsets.npz: the resident masks fetched (and, with row shards, gathered bit by bit) into a file —
+        the hand-off to a pairing stage in ANOTHER process.  O(W x N / 8) bytes."""
+        n_out = len(rows_out)
+        nf, nr = self.ctx.masks_fetch()
         n_local = self.ctx.n_rows
         if self.comm is not None:
             # row shards are not multiples of 64: concatenate bit by bit across ranks, then re-pack
@@ -374,48 +422,15 @@ class NN_degenerate(object):
                 packed.append(np.packbits(pad, axis=1, bitorder="little").view(np.uint64).reshape(n_out, nw))
         else:
             n_total = n_local
-            packed = [nf, nr]                           # fresh host arrays of this call: patched in place below
-
-        def put(which, i, row, value):
-            word, bit = row >> 6, np.uint64(1) << np.uint64(row & 63)
-            if value:
-                packed[which][i, word] |= bit
-            else:
-                packed[which][i, word] &= ~bit
-
-        # rows whose window held an IUPAC code: every expansion must be reached (V20:701-707 puts the id
-        # under each expansion's k-mer), gap-type ones are in gap_seq_id
-        ex_w = self._exc[0]
-        if len(ex_w) and n_out:
-            touched = np.isin(wins, ex_w)
-            if touched.any():
-                exc = self._exceptions_by_window()
-                for i in np.nonzero(touched)[0].tolist():
-                    pc = iupac.codes_of(rows_out[i][3])
-                    for r_glob, raw in exc.get(int(wins[i]), ()):
-                        if raw.count("-") > v:
-                            put(0, i, r_glob, True)
-                            put(1, i, r_glob, True)
-                            continue
-                        bad_f = bad_r = False
-                        for e in iupac.expand(raw):
-                            D, nd = 0, 0
-                            for j, ch in enumerate(e):
-                                if ch == "-" or not (pc[j] >> _B2I[ch]) & 1:
-                                    D |= 1 << j
-                                    nd += 1
-                            if nd == 0:
-                                continue
-                            bad_f |= nd > v or bool(D & self._sF)
-                            bad_r |= nd > v or bool(D & self._sR)
-                        put(0, i, r_glob, bad_f)
-                        put(1, i, r_glob, bad_r)
+            packed = [nf, nr]
         if self.comm is not None and self.comm.rank != 0:
             return
         # ids as the raw bytes of the file + offsets (bitset_ids() decodes them): 10^6 Python strings cost more than the masks
         ids_bytes, ids_off = self._fasta.ids_raw()
+        t0 = time.time()
         np.savez(self.outfile + ".coverage_bitsets.npz", positions=np.asarray([int(r[0]) for r in rows_out], np.int64),
                  not_f=packed[0], not_r=packed[1], n_seq=np.int64(n_total), ids_bytes=ids_bytes, ids_off=ids_off)
+        self.stats["bitsets_save_s"] = time.time() - t0
 
     def _write(self, rows_out, non_cov_out, gap_out):
         with open(self.outfile, "w") as fo:                                        # V20:1148-1170

@@ -33,6 +33,8 @@ void free_unique(mp_ctx *c) {
 
 void free_windows(mp_ctx *c) {
     free_eval(c);
+    dev_free(c, &c->mask_f, c->mask_words); dev_free(c, &c->mask_r, c->mask_words);
+    c->mask_words = 0; c->n_masks = 0;
     free_unique(c);
     dev_free(c, &c->excl, (size_t)c->n_win * (c->n_pad / 64));
     dev_free(c, &c->patch_count, (size_t)c->n_win * 32);

@@ -119,6 +119,10 @@ struct mp_ctx {
     double *dm_dg = nullptr;
     std::vector<uint8_t> dm_loss_host;
     std::vector<double> dm_dg_host;
+    // device-resident coverage masks of the last mp_eval_masks(_resident): [n_masks][n_pad/64] each
+    unsigned long long *mask_f = nullptr, *mask_r = nullptr;
+    size_t mask_words = 0;
+    int n_masks = 0;
     // eval staging
     int n_cand = 0, n_items = 0, n_padded = 0;
     mp::EvalItem *items = nullptr;

@@ -988,33 +988,92 @@ __global__ __launch_bounds__(kBlock) void window_stats_kernel(const StatsArgs A)
 // Per-sequence coverage masks (mp_eval_masks): thread = sequence, the wave's 64 "not covered" bits
 // go out as one 64-bit word per candidate straight from the ballot (blocks are 64-row aligned), so
 // there are no atomics; works on the window words, i.e. after edge-gap repair, for any v.
+// decision of one (candidate, k-mer) pair for the masks: would the sequence appear in gap_seq_id / the F (R) dict of
+// non_coverage_seq_id (V20:689-698, 1107-1127)?
+__device__ inline void mask_decide(uint32_t b0, uint32_t b1, uint32_t gk, const uint4 q, const EvalArgs &A, bool &bad_f, bool &bad_r) {
+    const bool gap_row = (int)__popc(gk) > A.v;
+    const uint32_t mm = bfi(b1, bfi(b0, q.w, q.z), bfi(b0, q.y, q.x)) | gk;
+    const int d = __popc(mm);
+    const bool near = d <= A.v;
+    bad_f = gap_row || !(near && (d == 0 || !(mm & A.sF)));
+    bad_r = gap_row || !(near && (d == 0 || !(mm & A.sR)));
+}
+
+// thread = row of one item's window, 8 candidates: plain column slices straight from the planes (fast_words, no divergence);
+// the repaired / ragged rows of the window are added by mask_patch_kernel from the patch list, IUPAC rows stay 0 (host).
 template <int CC>
 __global__ __launch_bounds__(kBlock) void mask_rows_kernel(const EvalArgs A, int n_rows, unsigned long long *__restrict__ not_f,
                                                            unsigned long long *__restrict__ not_r) {
     const EvalItem it = A.items[blockIdx.x];
     const int r = blockIdx.y * kBlock + threadIdx.x;             // n_pad is a multiple of kBlock
-    const size_t nw = (size_t)A.n_pad / 64;
-    const FlyView V(A.M, A.p0 + it.win, A.k, A.kmask);
-    uint32_t b0, b1, g;
-    V.load(r, b0, b1, g);
-    const bool skip = (g & MP_WIN_SKIP) || r >= n_rows;
-    const uint32_t gk = g & A.kmask;
-    const bool gap_row = (int)__popc(gk) > A.v;
+    const size_t nw = (size_t)A.n_pad / 64, np = (size_t)A.n_pad;
+    const int p = A.p0 + it.win;
+    uint32_t b0 = 0, b1 = 0, g = 0;
+    bool plain = false;
+    if (r < n_rows) {
+        const uint32_t *P = A.M.planes + ((size_t)(p >> 5) * 4) * np + r;
+        plain = fast_words(p, A.k, A.kmask, A.M.rlen[r], P[0], P[np], P[2 * np], P[3 * np], P[4 * np], P[5 * np], P[6 * np], P[7 * np], b0, b1, g);
+    }
 #pragma unroll
     for (int c = 0; c < CC; c++) {
-        const uint4 q = A.cand_n[it.cand0 + c];
-        const uint32_t mm = bfi(b1, bfi(b0, q.w, q.z), bfi(b0, q.y, q.x)) | gk;
-        const int d = __popc(mm);
-        const bool near = d <= A.v;
-        const bool bad_f = !skip && (gap_row || !(near && (d == 0 || !(mm & A.sF))));
-        const bool bad_r = !skip && (gap_row || !(near && (d == 0 || !(mm & A.sR))));
-        const unsigned long long wf = __ballot(bad_f), wr = __ballot(bad_r);
+        bool bad_f, bad_r;
+        mask_decide(b0, b1, g, A.cand_n[it.cand0 + c], A, bad_f, bad_r);
+        const unsigned long long wf = __ballot(plain && bad_f), wr = __ballot(plain && bad_r);
         const int oc = A.cand_out[it.cand0 + c];
         if ((threadIdx.x & 63) == 0 && oc >= 0) {
             not_f[(size_t)oc * nw + (size_t)(r >> 6)] = wf;
             not_r[(size_t)oc * nw + (size_t)(r >> 6)] = wr;
         }
     }
+}
+
+// one workgroup per item: the window's slow pairs (patch list: rows and window words from repair_kernel)
+template <int CC>
+__global__ __launch_bounds__(kBlock) void mask_patch_kernel(const EvalArgs A, const int32_t *__restrict__ patch_off,
+                                                            const int32_t *__restrict__ patch_rows, const uint32_t *__restrict__ patch_words,
+                                                            unsigned long long *__restrict__ not_f, unsigned long long *__restrict__ not_r) {
+    const EvalItem it = A.items[blockIdx.x];
+    const size_t nw = (size_t)A.n_pad / 64;
+    for (int e = patch_off[it.win] + threadIdx.x; e < patch_off[it.win + 1]; e += kBlock) {
+        const uint32_t b0 = patch_words[3 * (size_t)e], b1 = patch_words[3 * (size_t)e + 1], g = patch_words[3 * (size_t)e + 2];
+        if (g & MP_WIN_SKIP) continue;                            // IUPAC k-mer (the host owns it) or a too-short row
+        const int r = patch_rows[e];
+        for (int c = 0; c < CC; c++) {
+            const int oc = A.cand_out[it.cand0 + c];
+            if (oc < 0) continue;
+            bool bad_f, bad_r;
+            mask_decide(b0, b1, g & A.kmask, A.cand_n[it.cand0 + c], A, bad_f, bad_r);
+            if (bad_f) atomicOr(&not_f[(size_t)oc * nw + (size_t)(r >> 6)], 1ull << (r & 63));
+            if (bad_r) atomicOr(&not_r[(size_t)oc * nw + (size_t)(r >> 6)], 1ull << (r & 63));
+        }
+    }
+}
+
+// fix-ups of single bits (the host's verdict on IUPAC rows): thread = one (mask, row) assignment
+__global__ __launch_bounds__(kBlock) void mask_set_kernel(long long n, const int32_t *__restrict__ cand, const int32_t *__restrict__ row,
+                                                          const uint8_t *__restrict__ which, const uint8_t *__restrict__ value, size_t nw,
+                                                          unsigned long long *__restrict__ not_f, unsigned long long *__restrict__ not_r) {
+    const long long i = (long long)blockIdx.x * kBlock + threadIdx.x;
+    if (i >= n) return;
+    unsigned long long *m = (which[i] ? not_r : not_f) + (size_t)cand[i] * nw + (size_t)(row[i] >> 6);
+    const unsigned long long bit = 1ull << (row[i] & 63);
+    if (value[i]) atomicOr(m, bit);
+    else atomicAnd(m, ~bit);
+}
+
+// popcount(not_f[i] | not_r[j]) over the resident masks: one wave per pair
+__global__ __launch_bounds__(kBlock) void mask_pair_kernel(const unsigned long long *__restrict__ f, const unsigned long long *__restrict__ r2,
+                                                           int n_words, size_t stride, long long n_pairs, const int32_t *__restrict__ pairs,
+                                                           int32_t *__restrict__ out) {
+    const long long p = (long long)blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6);
+    if (p >= n_pairs) return;
+    const int lane = threadIdx.x & 63;
+    const unsigned long long *A = f + (size_t)pairs[2 * p] * stride, *B = r2 + (size_t)pairs[2 * p + 1] * stride;
+    int cnt = 0;
+    for (int w = lane; w < n_words; w += 64) cnt += __popcll(A[w] | B[w]);
+#pragma unroll
+    for (int s = 32; s >= 1; s >>= 1) cnt += __shfl_xor(cnt, s);
+    if (lane == 0) out[p] = cnt;
 }
 
 typedef void (*EvalBitsFn)(const EvalBitsArgs);
@@ -1434,29 +1493,108 @@ int mp_eval_candidates(mp_ctx *c, int32_t n_cand, const int32_t *cw, const uint8
 }
 
 
-int mp_eval_masks(mp_ctx *c, int32_t n_cand, const int32_t *cw, const uint8_t *codes, uint32_t sF, uint32_t sR,
-                  uint64_t *not_f, uint64_t *not_r) {
+int mp_eval_masks_resident(mp_ctx *c, int32_t n_cand, const int32_t *cw, const uint8_t *codes, uint32_t sF, uint32_t sR) {
     if (!c) return MP_ERR_ARG;
     int rc = mp_eval_upload(c, n_cand, cw, codes, sF, sR);
     if (rc) return rc;
+    const size_t nw = (size_t)c->n_pad / 64;
+    dev_free(c, &c->mask_f, c->mask_words); dev_free(c, &c->mask_r, c->mask_words);
+    c->mask_words = 0; c->n_masks = 0;
     if (n_cand == 0) return MP_OK;
-    if (!not_f || !not_r) return fail(c, MP_ERR_ARG, "null output");
-    const size_t nw = (size_t)c->n_pad / 64, nwo = ((size_t)c->n_rows + 63) / 64;
-    unsigned long long *d_f = nullptr, *d_r = nullptr;
-    if ((rc = dev_alloc(c, &d_f, (size_t)n_cand * nw))) return rc;
-    if ((rc = dev_alloc(c, &d_r, (size_t)n_cand * nw))) return rc;
+    if ((rc = dev_alloc(c, &c->mask_f, (size_t)n_cand * nw))) return rc;
+    if ((rc = dev_alloc(c, &c->mask_r, (size_t)n_cand * nw))) return rc;
+    c->mask_words = (size_t)n_cand * nw;
+    c->n_masks = n_cand;
     EvalArgs ea{msa_args(c), c->p0, c->n_pad, c->k, c->items, c->cand_n, c->cand_out, nullptr, nullptr, c->sF, c->sR, c->v,
                 (1u << c->k) - 1u, 0, nullptr};
     const dim3 grid((unsigned)c->n_items, (unsigned)(c->n_pad / kBlock));
-    hipLaunchKernelGGL((mask_rows_kernel<kEvalCC>), grid, dim3(kBlock), 0, c->stream, ea, c->n_rows, d_f, d_r);
+    hipLaunchKernelGGL((mask_rows_kernel<kEvalCC>), grid, dim3(kBlock), 0, c->stream, ea, c->n_rows, c->mask_f, c->mask_r);
+    if (c->n_patch)
+        hipLaunchKernelGGL((mask_patch_kernel<kEvalCC>), dim3((unsigned)c->n_items), dim3(kBlock), 0, c->stream, ea, (const int32_t *)c->patch_off,
+                           (const int32_t *)c->patch_rows, (const uint32_t *)c->patch_words, c->mask_f, c->mask_r);
     HIPCK(c, hipGetLastError());
-    // rows are padded to a multiple of 256 on the device: copy the (n_rows+63)/64 meaningful words of each mask
-    HIPCK(c, hipMemcpy2DAsync(not_f, nwo * 8, d_f, nw * 8, nwo * 8, (size_t)n_cand, hipMemcpyDeviceToHost, c->stream));
-    HIPCK(c, hipMemcpy2DAsync(not_r, nwo * 8, d_r, nw * 8, nwo * 8, (size_t)n_cand, hipMemcpyDeviceToHost, c->stream));
     HIPCK(c, hipStreamSynchronize(c->stream));
-    dev_free(c, &d_f, (size_t)n_cand * nw);
-    dev_free(c, &d_r, (size_t)n_cand * nw);
     return MP_OK;
+}
+
+int mp_masks_set_bits(mp_ctx *c, int64_t n, const int32_t *cand, const int32_t *row, const uint8_t *which, const uint8_t *value) {
+    if (!c) return MP_ERR_ARG;
+    if (n < 0 || (n && (!cand || !row || !which || !value))) return fail(c, MP_ERR_ARG, "mp_masks_set_bits: bad arguments");
+    if (n == 0) return MP_OK;
+    if (!c->mask_f) return fail(c, MP_ERR_ARG, "no resident masks (mp_eval_masks_resident has not run)");
+    for (int64_t i = 0; i < n; i++)
+        if (cand[i] < 0 || cand[i] >= c->n_masks || row[i] < 0 || row[i] >= c->n_rows) return fail(c, MP_ERR_ARG, "assignment %lld out of range", (long long)i);
+    HIPCK(c, hipSetDevice(c->dev));
+    int32_t *d_c = nullptr, *d_r = nullptr;
+    uint8_t *d_w = nullptr, *d_v = nullptr;
+    int rc;
+    if ((rc = dev_alloc(c, &d_c, (size_t)n)) || (rc = dev_alloc(c, &d_r, (size_t)n)) || (rc = dev_alloc(c, &d_w, (size_t)n)) || (rc = dev_alloc(c, &d_v, (size_t)n))) {
+        dev_free(c, &d_c, (size_t)n); dev_free(c, &d_r, (size_t)n); dev_free(c, &d_w, (size_t)n); dev_free(c, &d_v, (size_t)n);
+        return rc;
+    }
+    hipError_t e = hipMemcpyAsync(d_c, cand, sizeof(int32_t) * (size_t)n, hipMemcpyHostToDevice, c->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(d_r, row, sizeof(int32_t) * (size_t)n, hipMemcpyHostToDevice, c->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(d_w, which, (size_t)n, hipMemcpyHostToDevice, c->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(d_v, value, (size_t)n, hipMemcpyHostToDevice, c->stream);
+    if (e == hipSuccess) {
+        hipLaunchKernelGGL(mask_set_kernel, dim3((unsigned)((n + kBlock - 1) / kBlock)), dim3(kBlock), 0, c->stream, (long long)n, (const int32_t *)d_c,
+                           (const int32_t *)d_r, (const uint8_t *)d_w, (const uint8_t *)d_v, (size_t)c->n_pad / 64, c->mask_f, c->mask_r);
+        e = hipGetLastError();
+    }
+    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+    dev_free(c, &d_c, (size_t)n); dev_free(c, &d_r, (size_t)n); dev_free(c, &d_w, (size_t)n); dev_free(c, &d_v, (size_t)n);
+    if (e != hipSuccess) return fail(c, MP_ERR_DEVICE, "mp_masks_set_bits: %s", hipGetErrorString(e));
+    return MP_OK;
+}
+
+int mp_masks_fetch(mp_ctx *c, uint64_t *not_f, uint64_t *not_r) {
+    if (!c) return MP_ERR_ARG;
+    if (!c->mask_f) return fail(c, MP_ERR_ARG, "no resident masks (mp_eval_masks_resident has not run)");
+    if (!not_f || !not_r) return fail(c, MP_ERR_ARG, "null output");
+    HIPCK(c, hipSetDevice(c->dev));
+    // rows are padded to a multiple of 256 on the device: copy the (n_rows+63)/64 meaningful words of each mask
+    const size_t nw = (size_t)c->n_pad / 64, nwo = ((size_t)c->n_rows + 63) / 64;
+    HIPCK(c, hipMemcpy2DAsync(not_f, nwo * 8, c->mask_f, nw * 8, nwo * 8, (size_t)c->n_masks, hipMemcpyDeviceToHost, c->stream));
+    HIPCK(c, hipMemcpy2DAsync(not_r, nwo * 8, c->mask_r, nw * 8, nwo * 8, (size_t)c->n_masks, hipMemcpyDeviceToHost, c->stream));
+    HIPCK(c, hipStreamSynchronize(c->stream));
+    return MP_OK;
+}
+
+int mp_pair_coverage_resident(mp_ctx *c, int64_t n_pairs, const int32_t *pairs, int32_t *out) {
+    if (!c) return MP_ERR_ARG;
+    if (n_pairs < 0 || (n_pairs && (!pairs || !out))) return fail(c, MP_ERR_ARG, "mp_pair_coverage_resident: bad arguments");
+    if (n_pairs == 0) return MP_OK;
+    if (!c->mask_f) return fail(c, MP_ERR_ARG, "no resident masks (mp_eval_masks_resident has not run)");
+    for (int64_t p = 0; p < 2 * n_pairs; p++)
+        if (pairs[p] < 0 || pairs[p] >= c->n_masks) return fail(c, MP_ERR_ARG, "pair %lld out of range", (long long)(p / 2));
+    HIPCK(c, hipSetDevice(c->dev));
+    int32_t *d_pairs = nullptr, *d_out = nullptr;
+    int rc;
+    if ((rc = dev_alloc(c, &d_pairs, (size_t)2 * n_pairs))) return rc;
+    if ((rc = dev_alloc(c, &d_out, (size_t)n_pairs))) { dev_free(c, &d_pairs, (size_t)2 * n_pairs); return rc; }
+    hipError_t e = hipMemcpyAsync(d_pairs, pairs, sizeof(int32_t) * 2 * (size_t)n_pairs, hipMemcpyHostToDevice, c->stream);
+    if (e == hipSuccess) {
+        const long long per_block = kBlock / 64;
+        hipLaunchKernelGGL(mask_pair_kernel, dim3((unsigned)((n_pairs + per_block - 1) / per_block)), dim3(kBlock), 0, c->stream,
+                           (const unsigned long long *)c->mask_f, (const unsigned long long *)c->mask_r, (int)((c->n_rows + 63) / 64),
+                           (size_t)c->n_pad / 64, (long long)n_pairs, (const int32_t *)d_pairs, d_out);
+        e = hipGetLastError();
+    }
+    if (e == hipSuccess) e = hipMemcpyAsync(out, d_out, sizeof(int32_t) * (size_t)n_pairs, hipMemcpyDeviceToHost, c->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+    dev_free(c, &d_pairs, (size_t)2 * n_pairs); dev_free(c, &d_out, (size_t)n_pairs);
+    if (e != hipSuccess) return fail(c, MP_ERR_DEVICE, "mp_pair_coverage_resident: %s", hipGetErrorString(e));
+    return MP_OK;
+}
+
+int mp_eval_masks(mp_ctx *c, int32_t n_cand, const int32_t *cw, const uint8_t *codes, uint32_t sF, uint32_t sR,
+                  uint64_t *not_f, uint64_t *not_r) {
+    if (!c) return MP_ERR_ARG;
+    int rc = mp_eval_masks_resident(c, n_cand, cw, codes, sF, sR);
+    if (rc) return rc;
+    if (n_cand == 0) return MP_OK;
+    if (!not_f || !not_r) return fail(c, MP_ERR_ARG, "null output");
+    return mp_masks_fetch(c, not_f, not_r);
 }
 
 }  // extern "C"

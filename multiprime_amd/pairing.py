@@ -63,7 +63,10 @@ class Primers_filter(object):
 
     def __init__(self, ref_file, primer_file, adaptor, rep_seq_number=500, distance=4, outfile="", diff_Tm=5,
                  size="300,700", position=9, GC="0.4,0.6", nproc=10, fraction=0.6, *, library: Library | None = None,
-                 device: int = 0):
+                 device: int = 0, core=None):
+        # core: the NN_degenerate object of the core step run in THIS process with keep_bitsets=True — its per-window
+        # coverage bitsets are still on the device and the coverage unions are taken there (no JSON, no file, no copy)
+        self.core = core
         self.nproc = nproc
         self.primer_file = primer_file
         self.adaptor = adaptor
@@ -78,8 +81,11 @@ class Primers_filter(object):
         self.number = self.get_number()
         self.position = position
         self.primers, self.gap_id, self.non_cover_id = self.parse_primers()
-        self.lib = library if library is not None else Library()
-        self.ctx = self.lib.context(device)
+        if core is not None:
+            self.lib, self.ctx = core.lib, core.ctx
+        else:
+            self.lib = library if library is not None else Library()
+            self.ctx = self.lib.context(device)
         self.pre_filter_primers = self.pre_filter()
         self.stats = {}
 
@@ -105,7 +111,9 @@ class Primers_filter(object):
         # written (deep alignments) — the bitset file of `multiPrime-core.py --bitsets`
         self.bitset_file = None
         gap_json, non_json = self.primer_file + ".gap_seq_id_json", self.primer_file + ".non_coverage_seq_id_json"
-        if os.path.exists(gap_json) and os.path.exists(non_json):
+        if self.core is not None and self.core.mask_index:
+            gap_dict, non_cover_dict = None, None
+        elif os.path.exists(gap_json) and os.path.exists(non_json):
             with open(gap_json) as g:
                 gap_dict = json.load(g)
             with open(non_json) as n:
@@ -262,8 +270,14 @@ class Primers_filter(object):
         t0 = time.time()
         tm = [self.primers[p][4] for p in cand]
         alive = [ab for ab in real if not dimer[ab] and not abs(tm[ab[0]] - tm[ab[1]]) > self.diff_Tm]
-        sets_f, sets_r = self._bitsets(cand)
-        counts = self.ctx.pair_coverage(sets_f, sets_r, np.asarray(alive, np.int32).reshape(-1, 2)) if alive else []
+        if not alive:
+            counts = []
+        elif self.core is not None and self.core.mask_index:
+            idx = np.asarray([self.core.mask_index[int(p)] for p in cand], np.int32)          # candidate window -> resident mask
+            counts = self.ctx.pair_coverage_resident(idx[np.asarray(alive, np.int32).reshape(-1, 2)])
+        else:
+            sets_f, sets_r = self._bitsets(cand)
+            counts = self.ctx.pair_coverage(sets_f, sets_r, np.asarray(alive, np.int32).reshape(-1, 2))
         non_cover = dict(zip(alive, (int(x) for x in counts)))
         self.stats["coverage_s"] = time.time() - t0
         self.stats["n_combinations"] = len(real)

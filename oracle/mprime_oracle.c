@@ -49,6 +49,9 @@ struct mp_ctx {
     uint32_t sF, sR;
     double eval_ms;
     int32_t eval_n;
+    /* "resident" masks of mp_eval_masks_resident: plain host arrays here */
+    uint64_t *mask_f, *mask_r;
+    int32_t n_masks;
 };
 
 static int fail(mp_ctx *c, int code, const char *fmt, ...) {
@@ -91,6 +94,7 @@ void mp_destroy(mp_ctx *c) {
     if (!c) return;
     free_windows(c); free_rows(c);
     free(c->cand_win); free(c->cand_codes);
+    free(c->mask_f); free(c->mask_r);
     free(c);
 }
 
@@ -695,6 +699,61 @@ int mp_eval_masks(mp_ctx *c, int32_t n_cand, const int32_t *cw, const uint8_t *c
             if (bf) F[r >> 6] |= 1ull << (r & 63);
             if (br) R[r >> 6] |= 1ull << (r & 63);
         }
+    }
+    return MP_OK;
+}
+
+/* (4d) the resident form: the same masks kept in the context, single-bit fix-ups, popcounts of unions */
+int mp_eval_masks_resident(mp_ctx *c, int32_t n_cand, const int32_t *cw, const uint8_t *codes, uint32_t sF, uint32_t sR) {
+    if (!c || !c->words) return c ? fail(c, MP_ERR_ARG, "no windows built") : MP_ERR_ARG;
+    size_t nw = ((size_t)c->n_rows + 63) / 64;
+    free(c->mask_f); free(c->mask_r);
+    c->mask_f = c->mask_r = NULL; c->n_masks = 0;
+    if (n_cand <= 0) return n_cand < 0 ? fail(c, MP_ERR_ARG, "bad arguments") : MP_OK;
+    c->mask_f = (uint64_t *)calloc((size_t)n_cand * nw, 8);
+    c->mask_r = (uint64_t *)calloc((size_t)n_cand * nw, 8);
+    if (!c->mask_f || !c->mask_r) return fail(c, MP_ERR_NOMEM, "out of memory");
+    int rc = mp_eval_masks(c, n_cand, cw, codes, sF, sR, c->mask_f, c->mask_r);
+    if (rc == MP_OK) c->n_masks = n_cand;
+    return rc;
+}
+
+int mp_masks_set_bits(mp_ctx *c, int64_t n, const int32_t *cand, const int32_t *row, const uint8_t *which, const uint8_t *value) {
+    if (!c) return MP_ERR_ARG;
+    if (n < 0 || (n && (!cand || !row || !which || !value))) return fail(c, MP_ERR_ARG, "mp_masks_set_bits: bad arguments");
+    if (n == 0) return MP_OK;
+    if (!c->mask_f) return fail(c, MP_ERR_ARG, "no resident masks (mp_eval_masks_resident has not run)");
+    size_t nw = ((size_t)c->n_rows + 63) / 64;
+    for (int64_t i = 0; i < n; i++) {
+        if (cand[i] < 0 || cand[i] >= c->n_masks || row[i] < 0 || row[i] >= c->n_rows) return fail(c, MP_ERR_ARG, "assignment %lld out of range", (long long)i);
+        uint64_t *m = (which[i] ? c->mask_r : c->mask_f) + (size_t)cand[i] * nw + (size_t)(row[i] >> 6);
+        if (value[i]) *m |= 1ull << (row[i] & 63);
+        else *m &= ~(1ull << (row[i] & 63));
+    }
+    return MP_OK;
+}
+
+int mp_masks_fetch(mp_ctx *c, uint64_t *not_f, uint64_t *not_r) {
+    if (!c) return MP_ERR_ARG;
+    if (!c->mask_f) return fail(c, MP_ERR_ARG, "no resident masks (mp_eval_masks_resident has not run)");
+    if (!not_f || !not_r) return fail(c, MP_ERR_ARG, "null output");
+    size_t n = (size_t)c->n_masks * (((size_t)c->n_rows + 63) / 64);
+    memcpy(not_f, c->mask_f, n * 8); memcpy(not_r, c->mask_r, n * 8);
+    return MP_OK;
+}
+
+int mp_pair_coverage_resident(mp_ctx *c, int64_t n_pairs, const int32_t *pairs, int32_t *out) {
+    if (!c) return MP_ERR_ARG;
+    if (n_pairs < 0 || (n_pairs && (!pairs || !out))) return fail(c, MP_ERR_ARG, "mp_pair_coverage_resident: bad arguments");
+    if (n_pairs == 0) return MP_OK;
+    if (!c->mask_f) return fail(c, MP_ERR_ARG, "no resident masks (mp_eval_masks_resident has not run)");
+    size_t nw = ((size_t)c->n_rows + 63) / 64;
+    for (int64_t p = 0; p < n_pairs; p++) {
+        int32_t i = pairs[2 * p], j = pairs[2 * p + 1];
+        if (i < 0 || i >= c->n_masks || j < 0 || j >= c->n_masks) return fail(c, MP_ERR_ARG, "pair %lld out of range", (long long)p);
+        int cnt = 0;
+        for (size_t w = 0; w < nw; w++) cnt += __builtin_popcountll(c->mask_f[(size_t)i * nw + w] | c->mask_r[(size_t)j * nw + w]);
+        out[p] = cnt;
     }
     return MP_OK;
 }

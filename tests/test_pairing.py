@@ -117,3 +117,46 @@ def test_end_to_end_known_answer_on_gpu(hip_lib, gold, tmp_path_factory, tmp_pat
     ref = d / "ref.tfa"
     ref.write_text("".join(f">s{i}\nACGT\n" for i in range(meta["n_seq"])))
     _known_answer(hip_lib, gold, lambda name: (str(out), str(ref)), tmp_path)
+
+
+def _resident(lib, gold, fixture, flagset, tmp_path):
+    """Core step and pairing stage in ONE process: no JSON, no bitset file — the per-window coverage bitsets stay in the
+    library's memory (mp_eval_masks_resident) and the pair coverages are popcounts taken there (mp_pair_coverage_resident).
+    Output files must equal the ones the reference produced from its JSON side files."""
+    want = gold["results"][fixture][flagset]
+    meta = load_gz_json(fixture + ".trace.json.gz")["meta"]
+    fl = meta["flags"]
+    inp = tmp_path / "in.fa"
+    inp.write_bytes(golden_input(meta["input"]))
+    core_out = tmp_path / (fixture + ".top.primer.out")
+    app = NN_degenerate(seq_file=str(inp), primer_length=fl["l"], coverage=fl["f"], number_of_dege_bases=fl["n"], score_of_dege_bases=fl["d"],
+                        raw_entropy_threshold=fl["e"], product_len=fl["s"], position=fl["c"], variation=fl["v"], distance=fl["a"], GC=fl["g"],
+                        nproc=1, outfile=str(core_out), library=lib, write_json=False, keep_bitsets=True)
+    app.run()
+    assert not os.path.exists(str(core_out) + ".gap_seq_id_json") and not os.path.exists(str(core_out) + ".coverage_bitsets.npz")
+    ref = tmp_path / "ref.tfa"
+    ref.write_text("".join(f">s{i}\nACGT\n" for i in range(meta["n_seq"])))
+    kw = dict(DEFAULTS)
+    fls = gold["flags"][flagset]
+    for k, v in zip(fls[::2], fls[1::2]):
+        if k in ARG:
+            kw[ARG[k][0]] = ARG[k][1](v)
+    out = tmp_path / (fixture + ".candidate.primers.txt")
+    with contextlib.redirect_stdout(io.StringIO()):
+        Primers_filter(ref_file=str(ref), primer_file=str(core_out), outfile=str(out), nproc=1, core=app, **kw).run()
+    for ext, path in (("txt", str(out)), ("xls", str(out).strip(".txt") + ".xls"), ("fa", str(out).strip(".txt") + ".fa")):
+        got = open(path).read().replace(str(out), "<OUT>") if os.path.exists(path) else None
+        assert got == want[ext], ext
+
+
+@pytest.mark.parametrize("fixture,flagset", [("msa1000_k18_d64", "yaml"), ("cluster0_v1", "yaml"), ("ivc_v1", "default")])
+def test_pairing_from_resident_bitsets(fixture, flagset, oracle_lib, gold, tmp_path):
+    _resident(oracle_lib, gold, fixture, flagset, tmp_path)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("fixture,flagset", [("msa1000_k18_d64", "yaml"), ("cluster0_v1", "yaml"), ("syn_iupac", None)])
+def test_pairing_from_resident_bitsets_on_gpu(fixture, flagset, hip_lib, gold, tmp_path):
+    if flagset is None:
+        pytest.skip("no pairing golden for this fixture")
+    _resident(hip_lib, gold, fixture, flagset, tmp_path)

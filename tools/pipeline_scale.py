@@ -19,6 +19,8 @@ ap = argparse.ArgumentParser()
 ap.add_argument("--rows", type=int, default=131072)
 ap.add_argument("--cols", type=int, default=1000)
 ap.add_argument("--k", type=int, default=18)
+ap.add_argument("--file", action="store_true", help="hand the coverage bitsets to the pairing stage through <out>.coverage_bitsets.npz (two "
+                "processes' worth of work) instead of leaving them on the device")
 a = ap.parse_args()
 with tempfile.TemporaryDirectory() as td:
     t0 = time.time()
@@ -30,7 +32,7 @@ with tempfile.TemporaryDirectory() as td:
     t0 = time.time()
     app = NN_degenerate(seq_file=fa, primer_length=a.k, coverage=0.8, number_of_dege_bases=4, score_of_dege_bases=10,
                         raw_entropy_threshold=3.6, product_len=150, position="2,3,-1", variation=1, distance=4, GC="0.2,0.7",
-                        nproc=1, outfile=os.path.join(td, "out.tsv"), write_json=False, write_bitsets=True)
+                        nproc=1, outfile=os.path.join(td, "out.tsv"), write_json=False, write_bitsets=a.file, keep_bitsets=not a.file)
     app.run()
     wall = time.time() - t0
     n_out = sum(1 for _ in open(os.path.join(td, "out.tsv"))) - 1
@@ -42,11 +44,12 @@ with tempfile.TemporaryDirectory() as td:
     with contextlib.redirect_stdout(io.StringIO()):
         pf = Primers_filter(ref_file=fa, primer_file=os.path.join(td, "out.tsv"), outfile=os.path.join(td, "syn.candidate.primers.txt"),
                             adaptor="TCTTTCCCTACACGACGCTCTTCCGATCT,TGGAGTTCAGACGTGTGCTCTTCCGATCT", rep_seq_number=0, distance=4,
-                            size="150,600", position=4, fraction=0.7, diff_Tm=4)
+                            size="150,600", position=4, fraction=0.7, diff_Tm=4, core=None if a.file else app)
         pf.run()
     pair_wall = time.time() - t0
     n_pairs = sum(1 for _ in open(os.path.join(td, "syn.candidate.primers.xls"))) - 1
-    print(json.dumps({"pairing_wall_s": round(pair_wall, 2), "pairs": n_pairs, "bitset_file_bytes": os.path.getsize(os.path.join(td, "out.tsv.coverage_bitsets.npz")),
+    print(json.dumps({"pairing_wall_s": round(pair_wall, 2), "pairs": n_pairs, "hand_off": "file" if a.file else "device-resident bitsets",
+                      "bitset_file_bytes": os.path.getsize(os.path.join(td, "out.tsv.coverage_bitsets.npz")) if a.file else 0,
                       "pairing_stats": {k: (round(v, 3) if isinstance(v, float) else v) for k, v in pf.stats.items()}}))
     print(json.dumps({"rows": a.rows, "cols": a.cols, "k": a.k, "generate_s": round(t_gen, 2), "wall_s": round(wall, 2),
                       "windows": app.n_windows, "windows_past_the_gates": app.stats.get("windows_planned"), "rows_out": n_out, "n_candidates": app.stats.get("n_candidates"),
