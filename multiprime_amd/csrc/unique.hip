@@ -28,14 +28,18 @@ __device__ inline uint32_t hash3(uint32_t a, uint32_t b, uint32_t c) {
     h = (h ^ (h >> 13)) + c * 0xC2B2AE3Du;
     return h ^ (h >> 16);
 }
+// two 32-bit multiplies and three shifts (a 64-bit multiply is four quarter-rate v_mul on gfx950; the first version's
+// splitmix hash was a fifth of the kernel's VALU time)
 __device__ inline uint32_t hash64(unsigned long long x) {
-    x ^= x >> 31; x *= 0x9E3779B97F4A7C15ULL; x ^= x >> 29; x *= 0xBF58476D1CE4E5B9ULL; x ^= x >> 32;
-    return (uint32_t)x;
+    uint32_t h = (uint32_t)x * 0x9E3779B1u + (uint32_t)(x >> 32) * 0x85EBCA77u;
+    h ^= h >> 15; h *= 0xC2B2AE3Du; h ^= h >> 13;
+    return h;
 }
 
 constexpr unsigned long long kNoKey = ~0ull;
 constexpr int kLdsSlots = 2048;           // 32 KB of LDS per workgroup -> 4-5 workgroups per CU
-constexpr int kLdsLimit = 1536;           // flush above this; one iteration adds at most kBlock keys
+constexpr int kCheckEvery = 4;            // iterations between two fill checks (each costs the workgroup a barrier)
+constexpr int kLdsLimit = kLdsSlots - kCheckEvery * kBlock - 128;      // flush above this: the next kCheckEvery iterations add at most that many keys
 
 struct HistArgs {
     MsaArgs M;
@@ -152,13 +156,22 @@ __global__ __launch_bounds__(kBlock) void hist_kernel(const HistArgs A) {
                 h = (h + 1) & (kLdsSlots - 1);
             }
         }
-        __syncthreads();
-        if (s_used > kLdsLimit) {                     // uniform: read after the barrier
-            flush();
+        if (((base - r0) / kBlock) % kCheckEvery == kCheckEvery - 1) {
             __syncthreads();
-            if (threadIdx.x == 0) s_used = 0;
-            __syncthreads();
+            if (s_used > kLdsLimit) {                 // uniform: read after the barrier
+                flush();
+                __syncthreads();
+                if (threadIdx.x == 0) s_used = 0;
+                __syncthreads();
+            }
         }
+    }
+    __syncthreads();
+    if (s_used > kLdsLimit) {
+        flush();
+        __syncthreads();
+        if (threadIdx.x == 0) s_used = 0;
+        __syncthreads();
     }
     if (slice == 0 && A.patch_off) {
         // the window's slow pairs (edge-gap repair, ragged end): their k-mers were derived once by repair_kernel
