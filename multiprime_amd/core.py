@@ -366,42 +366,36 @@ class NN_degenerate(object):
         self.ctx.eval_masks_resident(wins, codes, self._sF, self._sR)
         self.stats["bitsets_masks_s"] = time.time() - t0
         self.mask_index = {int(r[0]): i for i, r in enumerate(rows_out)}
-        # rows whose window held an IUPAC code: every expansion must be reached (V20:701-707 puts the id
-        # under each expansion's k-mer), gap-type ones are in gap_seq_id
-        ex_w = self._exc[0]
-        fix = []                                     # (mask, local row, which, value)
+        # rows whose window held an IUPAC code: every expansion must be reached (V20:701-707 puts the id under each
+        # expansion's k-mer), gap-type ones are in gap_seq_id.  Vectorised over all (exception, expansion) pairs.
+        ex_w, x_row, ex_codes = self._exc
         if len(ex_w) and n_out:
-            touched = np.isin(wins, ex_w)
-            if touched.any():
-                exc = self._exceptions_by_window()
-                row0 = self.comm.row0 if self.comm is not None else 0
-                n_local = self.ctx.n_rows
-                for i in np.nonzero(touched)[0].tolist():
-                    pc = iupac.codes_of(rows_out[i][3])
-                    for r_glob, raw in exc.get(int(wins[i]), ()):
-                        r_loc = r_glob - row0
-                        if not 0 <= r_loc < n_local:
-                            continue
-                        if raw.count("-") > v:
-                            fix.append((i, r_loc, 0, 1))
-                            fix.append((i, r_loc, 1, 1))
-                            continue
-                        bad_f = bad_r = False
-                        for e in iupac.expand(raw):
-                            D, nd = 0, 0
-                            for j, ch in enumerate(e):
-                                if ch == "-" or not (pc[j] >> _B2I[ch]) & 1:
-                                    D |= 1 << j
-                                    nd += 1
-                            if nd == 0:
-                                continue
-                            bad_f |= nd > v or bool(D & self._sF)
-                            bad_r |= nd > v or bool(D & self._sR)
-                        fix.append((i, r_loc, 0, int(bad_f)))
-                        fix.append((i, r_loc, 1, int(bad_r)))
-        if fix:
-            f = np.asarray(fix, np.int64)
-            self.ctx.masks_set_bits(f[:, 0], f[:, 1], f[:, 2], f[:, 3])
+            row0 = self.comm.row0 if self.comm is not None else 0
+            slot_of = np.full(self.n_windows, -1, np.int64)
+            slot_of[wins] = np.arange(n_out)
+            mask_i = slot_of[ex_w]
+            r_loc = x_row - row0
+            sel = (mask_i >= 0) & (r_loc >= 0) & (r_loc < self.ctx.n_rows)
+            if sel.any():
+                mask_i, r_loc, xc = mask_i[sel], r_loc[sel], ex_codes[sel]
+                gap_type = (xc == 0).sum(axis=1) > v
+                n_x = len(mask_i)
+                bad = np.zeros((n_x, 2), bool)
+                bad[gap_type] = True
+                idx = np.nonzero(~gap_type)[0]
+                if len(idx):
+                    exp, src = host.expand_kmers(xc[idx])                       # [m][k] concrete codes, src -> position in idx
+                    miss = (exp & codes[mask_i[idx]][src]) == 0                 # position not in the primer's symbol ('-' = 0 misses)
+                    nd = miss.sum(axis=1)
+                    pos = np.arange(k)
+                    hit_f = (miss & (((self._sF >> pos) & 1) == 1)).any(axis=1)
+                    hit_r = (miss & (((self._sR >> pos) & 1) == 1)).any(axis=1)
+                    bf = (nd > 0) & ((nd > v) | hit_f)
+                    br = (nd > 0) & ((nd > v) | hit_r)
+                    np.logical_or.at(bad[:, 0], idx[src], bf)
+                    np.logical_or.at(bad[:, 1], idx[src], br)
+                self.ctx.masks_set_bits(np.repeat(mask_i, 2), np.repeat(r_loc, 2), np.tile(np.array([0, 1], np.uint8), n_x),
+                                        bad.reshape(-1).astype(np.uint8))
 
     def _write_bitsets(self, rows_out):
         """{out}.coverage_bitsets.npz: the resident masks fetched (and, with row shards, gathered bit by bit) into a file —

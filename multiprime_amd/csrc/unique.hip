@@ -433,9 +433,12 @@ int unique_packed(mp_ctx *c, int64_t cap, int32_t want_labels, int64_t *n_entrie
     if ((rc = dev_alloc(c, &c->u_wcount, W))) return rc;
     if ((rc = dev_alloc(c, &c->u_wbase, W))) return rc;
     int32_t *d_cursor = nullptr;
-    // a table holds every distinct k-mer of a window; first try: twice the rows, at most 16384 slots (256 KB per window)
-    int slots = kBlock;
-    while (slots < 2 * c->n_rows + 64 && slots < 16384) slots <<= 1;
+    // a table holds every distinct k-mer of a window; first try: twice the rows, capped at max(16384, rows / 8) slots —
+    // 24 bytes per slot, 3 GB for 982 windows of 10^6 rows, where the deepest windows hold > 14000 distinct k-mers and the
+    // 16384-slot first try used to be thrown away (0.32 s of a second pass)
+    int slots = kBlock, cap_slots = 16384;
+    while (cap_slots < c->n_rows / 8) cap_slots <<= 1;
+    while (slots < 2 * c->n_rows + 64 && slots < cap_slots) slots <<= 1;
     if (const char *e = getenv("MP_HIST_SLOTS")) { int s = atoi(e); if (s >= kBlock && (s & (s - 1)) == 0) slots = s; }
     std::vector<int32_t> used(W), over(W);
     for (int attempt = 0; attempt < 8; attempt++) {

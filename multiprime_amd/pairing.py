@@ -92,8 +92,14 @@ class Primers_filter(object):
     # ---- input ---------------------------------------------------------------------------------
     def get_number(self):
         """GM:348-357: number of sequences = newlines / 2, capped by --maxseq when that is not 0."""
-        with open(self.Input_file, encoding="utf-8") as f:
-            seq_number = int(f.read().count("\n") / 2)
+        newlines = 0
+        with open(self.Input_file, "rb") as f:                    # same count as the reference's text-mode read, without decoding 1 GB
+            while True:
+                buf = f.read(1 << 24)
+                if not buf:
+                    break
+                newlines += buf.count(b"\n")
+        seq_number = int(newlines / 2)
         if seq_number > self.rep_seq_number != 0:
             return self.rep_seq_number
         return seq_number
