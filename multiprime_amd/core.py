@@ -323,22 +323,17 @@ class NN_degenerate(object):
 
         def build(w, primer):
             codes = iupac.codes_of(primer)
-            cover_keys = iupac.strings_of(sym[plan.window_table(w, 0)[0]])
+            cover_codes = plan.window_table(w, 0)[0]
+            cover_keys = iupac.strings_of(sym[cover_codes])
             gap_raw = iupac.strings_of(sym[plan.window_table(w, 1)[0]])
-            f_keys, r_keys = [], []
-            for q in cover_keys:
-                D = 0
-                nd = 0
-                for j, ch in enumerate(q):
-                    if ch == "-" or not (codes[j] >> _B2I[ch]) & 1:
-                        D |= 1 << j
-                        nd += 1
-                if nd == 0:
-                    continue
-                if nd > v or D & self._sF:
-                    f_keys.append(q)
-                if nd > v or D & self._sR:
-                    r_keys.append(q)
+            # which observed k-mers the primer does not reach (V20:1107-1127), all k-mers of the window at once
+            miss = (cover_codes & codes) == 0                                   # symbol not in the primer's set ('-' = 0 misses)
+            nd = miss.sum(axis=1)
+            pos = np.arange(len(codes))
+            hit_f = (miss & (((self._sF >> pos) & 1) == 1)).any(axis=1)
+            hit_r = (miss & (((self._sR >> pos) & 1) == 1)).any(axis=1)
+            f_keys = [cover_keys[i] for i in np.nonzero((nd > 0) & ((nd > v) | hit_f))[0].tolist()]
+            r_keys = [cover_keys[i] for i in np.nonzero((nd > 0) & ((nd > v) | hit_r))[0].tolist()]
             rows_of = self._rows_by_kmer(w)
             got = ids_by_kmer(w, rows_of, set(f_keys) | set(r_keys), False)
             non_cov = [{q: got[q] for q in f_keys}, {q: got[q] for q in r_keys}]
