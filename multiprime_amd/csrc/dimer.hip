@@ -325,6 +325,119 @@ __global__ __launch_bounds__(kBlock) void pcr_kernel(const uint8_t *__restrict__
 }
 
 
+// ---- block-per-sequence form ---------------------------------------------------------------------------------------
+// One workgroup owns one sequence.  Scan: every forward expansion and every reverse-complemented reverse expansion of
+// every pair is a pattern {2-bit word, length mask}; the sequence is packed segment by segment into LDS (2 bits per base +
+// a "matches nothing" bit for everything that is not an upper-case A/C/G/T: the reference's regex search is case
+// sensitive) and every thread slides over its positions — per (position, pattern): XOR, fold, OR, AND, compare; the
+// pattern table is wave-uniform and arrives through scalar loads.  Occurrences go into an LDS list.  Resolve: one thread
+// per pair walks the reference's order (first forward expansion that occurs and whose Product holds a reverse expansion)
+// on that short list.  A sequence with more occurrences than the list holds falls back to the rolling scan above.
+// Traffic: the text once (1 byte per base); the work is integer VALU, ~6 wave-instructions per (64 positions, pattern).
+constexpr int kPcrSeg = 4096;                        // positions packed per round
+constexpr int kPcrSegWords = kPcrSeg / 32 + 2;
+constexpr int kPcrHits = 3072;                       // occurrences kept per sequence
+
+struct PcrPat { unsigned long long word, lenmask; int32_t len, pad; };
+struct PcrPair { int32_t f0, nf, r0, nr; };         // pattern ranges of a pair: forward expansions, then RC(reverse expansions)
+
+__device__ inline int pcr_first(const uint32_t *__restrict__ s_pos, const uint16_t *__restrict__ s_pat, int n, int pat, int from, int to_excl) {
+    int best = 0x7fffffff;                           // smallest position >= from with position <= to_excl (caller subtracts the length)
+    for (int i = 0; i < n; i++)
+        if ((int)s_pat[i] == pat) { const int q = (int)s_pos[i]; if (q >= from && q <= to_excl && q < best) best = q; }
+    return best == 0x7fffffff ? -1 : best;
+}
+
+__global__ __launch_bounds__(kBlock) void pcr_block_kernel(const uint8_t *__restrict__ bytes, const int64_t *__restrict__ row_off, int n_rows,
+                                                           const PcrPat *__restrict__ pats, int n_pats, const PcrPair *__restrict__ pairs,
+                                                           int n_pairs, const uint8_t *__restrict__ codes, const int32_t *__restrict__ off,
+                                                           int32_t *__restrict__ out) {
+    __shared__ unsigned long long s_b[kPcrSegWords], s_n[kPcrSegWords];
+    __shared__ uint32_t s_pos[kPcrHits];
+    __shared__ uint16_t s_pat[kPcrHits];
+    __shared__ int s_nh;
+    const int row = blockIdx.x;
+    const uint8_t *s = bytes + row_off[row];
+    const int len = (int)(row_off[row + 1] - row_off[row]);
+    if (threadIdx.x == 0) s_nh = 0;
+    const unsigned long long kOdd = 0x5555555555555555ull;
+    for (int base = 0; base < len; base += kPcrSeg) {
+        __syncthreads();
+        for (int w = threadIdx.x; w < kPcrSegWords; w += kBlock) {
+            unsigned long long b = 0, n = 0;
+            const int p0 = base + w * 32;
+            for (int j = 0; j < 32; j++) {
+                const int p = p0 + j;
+                const int c = p < len ? pcr_base(s[p]) : -1;
+                b |= (unsigned long long)(c < 0 ? 0 : c) << (2 * j);
+                n |= (unsigned long long)(c < 0) << (2 * j);
+            }
+            s_b[w] = b; s_n[w] = n;
+        }
+        __syncthreads();
+        for (int q = threadIdx.x; q < kPcrSeg; q += kBlock) {
+            const int p = base + q;
+            if (p >= len) break;
+            const int w = q >> 5, sh = (q & 31) * 2;
+            unsigned long long win = s_b[w] >> sh, nw = s_n[w] >> sh;
+            if (sh) { win |= s_b[w + 1] << (64 - sh); nw |= s_n[w + 1] << (64 - sh); }
+            for (int i = 0; i < n_pats; i++) {
+                const PcrPat P = pats[i];                                  // uniform index: scalar loads
+                const unsigned long long x = win ^ P.word;
+                if (((((x | (x >> 1)) & kOdd) | nw) & P.lenmask) == 0 && p + P.len <= len) {
+                    const int h = atomicAdd(&s_nh, 1);
+                    if (h < kPcrHits) { s_pos[h] = (uint32_t)p; s_pat[h] = (uint16_t)i; }
+                }
+            }
+        }
+    }
+    __syncthreads();
+    const int nh = s_nh;
+    for (int pr = threadIdx.x; pr < n_pairs; pr += kBlock) {
+        int32_t res[4] = {-1, -1, -1, -1};
+        if (nh <= kPcrHits) {
+            const PcrPair Q = pairs[pr];
+            for (int fi = 0; fi < Q.nf && res[0] < 0; fi++) {                                   // for sequence in Fseq
+                const int lf = pats[Q.f0 + fi].len;
+                const int p1 = pcr_first(s_pos, s_pat, nh, Q.f0 + fi, 0, len);                   // re.search(sequence, i)
+                if (p1 < 0) continue;
+                const int p2 = pcr_first(s_pos, s_pat, nh, Q.f0 + fi, p1 + lf, len);             // next non-overlapping occurrence (str.split)
+                const int end = p2 < 0 ? len : p2;                                               // Product = sequence + line[1]
+                for (int ri = 0; ri < Q.nr; ri++) {                                              // for sequence2 in Rseq
+                    const int lr = pats[Q.r0 + ri].len;
+                    const int q = pcr_first(s_pos, s_pat, nh, Q.r0 + ri, p1, end - lr);          // re.search(RC(sequence2), Product)
+                    if (q >= 0) { res[0] = fi; res[1] = p1; res[2] = ri; res[3] = q; break; }
+                }
+            }
+        } else {
+            // too many occurrences for the list (low-complexity sequence): the rolling scan of pcr_kernel for this (pair, sequence)
+            const int lf = off[2 * pr + 1] - off[2 * pr], lr = off[2 * pr + 2] - off[2 * pr + 1];
+            Nib cf, cr;
+            cf.lo = cf.hi = cr.lo = cr.hi = 0;
+            for (int j = 0; j < lf; j++) cf.set(j, codes[off[2 * pr] + j]);
+            for (int j = 0; j < lr; j++) cr.set(j, codes[off[2 * pr + 1] + j]);
+            const uint32_t df = dm_degeneracy(cf, 0, lf), dr = dm_degeneracy(cr, 0, lr);
+            for (uint32_t fi = 0; fi < df && res[0] < 0; fi++) {
+                const uint64_t f = dm_expand(cf, 0, lf, fi);
+                const int p1 = pcr_find(s, 0, len, f, lf);
+                if (p1 < 0) continue;
+                const int p2 = pcr_find(s, p1 + lf, len, f, lf);
+                const int end = p2 < 0 ? len : p2;
+                for (uint32_t ri = 0; ri < dr; ri++) {
+                    const uint64_t e = dm_expand(cr, 0, lr, ri);
+                    uint64_t rc = 0;
+                    for (int t = 0; t < lr; t++) rc |= (uint64_t)(3u - ((uint32_t)(e >> (2 * (lr - 1 - t))) & 3u)) << (2 * t);
+                    const int q = pcr_find(s, p1, end, rc, lr);
+                    if (q >= 0) { res[0] = (int32_t)fi; res[1] = p1; res[2] = (int32_t)ri; res[3] = q; break; }
+                }
+            }
+        }
+        int32_t *o = out + ((size_t)pr * n_rows + row) * 4;
+        o[0] = res[0]; o[1] = res[1]; o[2] = res[2]; o[3] = res[3];
+    }
+}
+
+
 }  // namespace
 
 namespace mp {
@@ -545,13 +658,63 @@ int mp_pcr_scan(mp_ctx *c, const uint8_t *bytes, const int64_t *row_off, int32_t
     HIPCK(c, hipMemcpyAsync(d_roff, roff.data(), sizeof(int64_t) * roff.size(), hipMemcpyHostToDevice, c->stream));
     HIPCK(c, hipMemcpyAsync(d_codes, codes, ncodes, hipMemcpyHostToDevice, c->stream));
     HIPCK(c, hipMemcpyAsync(d_off, off, sizeof(int32_t) * ((size_t)2 * n_pairs + 1), hipMemcpyHostToDevice, c->stream));
-    hipLaunchKernelGGL(pcr_kernel, dim3((unsigned)((n_rows + kBlock - 1) / kBlock), (unsigned)n_pairs), dim3(kBlock), 0, c->stream,
-                       d_bytes, d_roff, n_rows, d_codes, d_off, d_out);
+    // pattern table of the block-per-sequence kernel: every forward expansion and RC(reverse expansion), in expansion order
+    static const char *members[16] = {"", "A", "C", "AC", "G", "AG", "GC", "GAC", "T", "AT", "CT", "ATC", "GT", "GAT", "GTC", "ATGC"};
+    std::vector<PcrPat> pats;
+    std::vector<PcrPair> prs((size_t)n_pairs);
+    bool fits = !getenv("MP_PCR_ROLLING");
+    for (int32_t p = 0; p < n_pairs && fits; p++) {
+        for (int side = 0; side < 2; side++) {
+            const int a0 = off[2 * p + side], L = off[2 * p + side + 1] - a0;
+            long long d = 1;
+            for (int j = 0; j < L; j++) d *= (long long)strlen(members[codes[a0 + j]]);
+            if ((long long)pats.size() + d > 4096) { fits = false; break; }
+            if (side == 0) { prs[(size_t)p].f0 = (int32_t)pats.size(); prs[(size_t)p].nf = (int32_t)d; }
+            else { prs[(size_t)p].r0 = (int32_t)pats.size(); prs[(size_t)p].nr = (int32_t)d; }
+            for (long long e = 0; e < d; e++) {                      // expansion e: last position fastest (itertools.product)
+                int base[MP_DIMER_MAX_LEN];
+                long long idx = e;
+                for (int j = L - 1; j >= 0; j--) {
+                    const char *m = members[codes[a0 + j]];
+                    const int sz = (int)strlen(m);
+                    const char ch = m[idx % sz];
+                    idx /= sz;
+                    base[j] = ch == 'A' ? 0 : ch == 'C' ? 1 : ch == 'G' ? 2 : 3;
+                }
+                PcrPat P{};
+                for (int j = 0; j < L; j++) {
+                    const int code = side == 0 ? base[j] : 3 - base[L - 1 - j];     // the text reads RC(reverse expansion)
+                    P.word |= (unsigned long long)code << (2 * j);
+                    P.lenmask |= 1ull << (2 * j);
+                }
+                P.len = L;
+                pats.push_back(P);
+            }
+        }
+    }
+    PcrPat *d_pats = nullptr;
+    PcrPair *d_prs = nullptr;
+    if (fits) {
+        if ((rc = dev_alloc(c, &d_pats, pats.size())) || (rc = dev_alloc(c, &d_prs, prs.size()))) {
+            dev_free(c, &d_pats, pats.size()); dev_free(c, &d_prs, prs.size());
+            fits = false;
+        }
+    }
+    if (fits) {
+        HIPCK(c, hipMemcpyAsync(d_pats, pats.data(), sizeof(PcrPat) * pats.size(), hipMemcpyHostToDevice, c->stream));
+        HIPCK(c, hipMemcpyAsync(d_prs, prs.data(), sizeof(PcrPair) * prs.size(), hipMemcpyHostToDevice, c->stream));
+        hipLaunchKernelGGL(pcr_block_kernel, dim3((unsigned)n_rows), dim3(kBlock), 0, c->stream, d_bytes, d_roff, n_rows, (const PcrPat *)d_pats,
+                           (int)pats.size(), (const PcrPair *)d_prs, n_pairs, d_codes, d_off, d_out);
+    } else {
+        hipLaunchKernelGGL(pcr_kernel, dim3((unsigned)((n_rows + kBlock - 1) / kBlock), (unsigned)n_pairs), dim3(kBlock), 0, c->stream,
+                           d_bytes, d_roff, n_rows, d_codes, d_off, d_out);
+    }
     HIPCK(c, hipGetLastError());
     HIPCK(c, hipMemcpyAsync(out, d_out, sizeof(int32_t) * nout, hipMemcpyDeviceToHost, c->stream));
     HIPCK(c, hipStreamSynchronize(c->stream));
     dev_free(c, &d_bytes, total + 16); dev_free(c, &d_roff, (size_t)n_rows + 1); dev_free(c, &d_codes, ncodes);
     dev_free(c, &d_off, (size_t)2 * n_pairs + 1); dev_free(c, &d_out, nout);
+    dev_free(c, &d_pats, pats.size()); dev_free(c, &d_prs, prs.size());
     return MP_OK;
 }
 

@@ -65,18 +65,20 @@ def main():
             rows_total += int(sizes[i])
             t0 = time.time()
             top = os.path.join(wd, f"Cluster_{i}.top.primer.out")
-            deep = sizes[i] > 2000                      # the JSON side files are O(windows x sequences): bitsets instead
-            NN_degenerate(seq_file=fa, primer_length=18, coverage=0.7, number_of_dege_bases=4, score_of_dege_bases=10,
+            deep = sizes[i] > 2000                      # the JSON side files are O(windows x sequences): device-resident bitsets instead
+            app = NN_degenerate(seq_file=fa, primer_length=18, coverage=0.7, number_of_dege_bases=4, score_of_dege_bases=10,
                           raw_entropy_threshold=3.6, product_len=150, position="2,3,-1", variation=1, distance=4,
-                          GC="0.2,0.7", nproc=1, outfile=top, device=local, write_json=not deep, write_bitsets=deep).run()
+                          GC="0.2,0.7", nproc=1, outfile=top, device=local, write_json=not deep, keep_bitsets=deep)
+            app.run()
             t["core_s"] += time.time() - t0
             n_primers += sum(1 for _ in open(top)) - 1
             t0 = time.time()
             cand = os.path.join(wd, f"Cluster_{i}.candidate.primers.txt")
             with contextlib.redirect_stdout(io.StringIO()):
                 Primers_filter(ref_file=fa, primer_file=top, outfile=cand, adaptor=ADAPTOR, rep_seq_number=0, distance=4,
-                               size="150,1200", position=4, fraction=0.7, diff_Tm=4).run()
+                               size="150,1200", position=4, fraction=0.7, diff_Tm=4, core=app if deep else None).run()
             t["pairing_s"] += time.time() - t0
+            app.ctx.close()
             if os.path.exists(cand):
                 n_pairs += sum(max(0, len(line.rstrip("\n").split("\t")) - 1) for line in open(cand))
         if world > 1:
