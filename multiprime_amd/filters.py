@@ -9,7 +9,7 @@ from __future__ import annotations
 import re
 from statistics import mean
 
-from .iupac import expand, revcomp
+from .iupac import exact_mean, expand, occurs_in_some_expansion, revcomp
 from .thermo import delta_g, penalty_points
 
 
@@ -37,7 +37,7 @@ def gc_fraction(primer: str) -> float:
     statistics.mean is exact (rational arithmetic), as in the reference."""
     n = len(primer)
     vals = [round((s.count("G") + s.count("C")) / n, 3) for s in expand(primer)]
-    return round(mean(vals), 2)
+    return round(exact_mean(vals), 2)
 
 
 def has_repeat(primer: str) -> bool:
@@ -49,11 +49,10 @@ def has_hairpin(primer: str, distance: int) -> bool:
     """hairpin_check (V20:387-398): a 5-mer whose reverse complement occurs at least `distance`
     bases downstream."""
     for n in range(0, len(primer) - 5 - 5 - distance + 1):
-        stems = [revcomp(s) for s in expand(primer[n:n + 5])]
-        for tail in expand(primer[n + 5 + distance:]):
-            for stem in stems:
-                if stem in tail:
-                    return True
+        tail = primer[n + 5 + distance:]
+        for s in expand(primer[n:n + 5]):
+            if occurs_in_some_expansion(revcomp(s), tail):      # == any(stem in t for t in expand(tail))
+                return True
     return False
 
 

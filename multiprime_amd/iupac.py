@@ -34,6 +34,31 @@ def expand(seq: str) -> list[str]:
     return ["".join(t) for t in product(*(MEMBERS[c] for c in seq))]
 
 
+_CLASS_OF_BASE = {b: "[" + "".join(sym for sym, m in MASK.items() if sym != "-" and m & MASK[b]) + "]" for b in BASES}
+_OCCURS = {}
+
+
+def occurs_in_some_expansion(concrete: str, degenerate: str) -> bool:
+    """any(concrete in e for e in expand(degenerate)) without enumerating the expansions: positions expand independently,
+    so the concrete string occurs in SOME expansion iff at some offset every base lies in the symbol's set — one regex
+    search with a character class per base (compiled once per concrete string)."""
+    pat = _OCCURS.get(concrete)
+    if pat is None:
+        import re
+        pat = _OCCURS[concrete] = re.compile("".join(_CLASS_OF_BASE[b] for b in concrete))
+    return pat.search(degenerate) is not None
+
+
+def exact_mean(vals):
+    """statistics.mean (the correctly rounded exact mean the reference uses) — one or two values need no rationals."""
+    if len(vals) == 1:
+        return vals[0]
+    if len(vals) == 2:
+        return (vals[0] + vals[1]) / 2          # fl(a + b) / 2 == fl((a + b) / 2): halving is exact
+    from statistics import mean
+    return mean(vals)
+
+
 def degeneracy(seq) -> int:
     """score_trans (V20:210-211): product of set sizes."""
     d = 1

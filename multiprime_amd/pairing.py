@@ -138,16 +138,15 @@ class Primers_filter(object):
         meet an exhausted iterator: only the first stem expansion is ever compared."""
         for n in range(0, len(primer) - 5 - 5 - self.distance + 1):
             stem = iupac.revcomp(iupac.expand(primer[n:n + 5])[0])
-            for tail in iupac.expand(primer[n + 5 + self.distance:]):
-                if stem in tail:
-                    return True
+            if iupac.occurs_in_some_expansion(stem, primer[n + 5 + self.distance:]):      # == any(stem in t for t in expand(tail))
+                return True
         return False
 
     @staticmethod
     def GC_fraction(sequence):
         """GM:451-458: mean (not rounded) of the per-expansion GC fractions rounded to 3 decimals."""
         n = len(sequence)
-        return mean([round((s.count("G") + s.count("C")) / n, 3) for s in iupac.expand(sequence)])
+        return iupac.exact_mean([round((s.count("G") + s.count("C")) / n, 3) for s in iupac.expand(sequence)])
 
     @staticmethod
     def di_nucleotide(primer):

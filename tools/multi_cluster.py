@@ -55,6 +55,7 @@ def main():
         cols = rng.integers(600, 1200, size=a.clusters)
         t = {"generate_s": 0.0, "core_s": 0.0, "pairing_s": 0.0}
         n_primers = n_pairs = rows_total = 0
+        phases = {}
         from multiprime_amd.pairing import Primers_filter
         for i in range(rank, a.clusters, world):
             t0 = time.time()
@@ -71,20 +72,28 @@ def main():
                           GC="0.2,0.7", nproc=1, outfile=top, device=local, write_json=not deep, keep_bitsets=deep)
             app.run()
             t["core_s"] += time.time() - t0
+            for key, val in app.stats.items():
+                if isinstance(val, float):
+                    phases["core." + key] = phases.get("core." + key, 0.0) + val
             n_primers += sum(1 for _ in open(top)) - 1
             t0 = time.time()
             cand = os.path.join(wd, f"Cluster_{i}.candidate.primers.txt")
             with contextlib.redirect_stdout(io.StringIO()):
-                Primers_filter(ref_file=fa, primer_file=top, outfile=cand, adaptor=ADAPTOR, rep_seq_number=0, distance=4,
-                               size="150,1200", position=4, fraction=0.7, diff_Tm=4, core=app if deep else None).run()
+                pf = Primers_filter(ref_file=fa, primer_file=top, outfile=cand, adaptor=ADAPTOR, rep_seq_number=0, distance=4,
+                               size="150,1200", position=4, fraction=0.7, diff_Tm=4, core=app if deep else None)
+                pf.run()
             t["pairing_s"] += time.time() - t0
+            for key, val in pf.stats.items():
+                if isinstance(val, float):
+                    phases["pairing." + key] = phases.get("pairing." + key, 0.0) + val
             app.ctx.close()
             if os.path.exists(cand):
                 n_pairs += sum(max(0, len(line.rstrip("\n").split("\t")) - 1) for line in open(cand))
         if world > 1:
             dist.barrier()
         res = {"clusters": a.clusters, "n_gpus": world, "rows_this_rank": rows_total, "primers_this_rank": n_primers,
-               "pairs_this_rank": n_pairs, **{k: round(v, 2) for k, v in t.items()}}
+               "pairs_this_rank": n_pairs, **{k: round(v, 2) for k, v in t.items()},
+               "phase_sums": {k: round(v, 2) for k, v in sorted(phases.items()) if v >= 0.05}}
         if rank == 0:
             t0 = time.time()
             agg = os.path.join(wd, "candidate_primers_sets.txt")
