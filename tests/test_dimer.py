@@ -129,3 +129,23 @@ def test_dimer_scan_hip_equals_oracle(hip_lib, oracle_lib, seed, n, p_deg, mode)
     h = hip_lib.context(0).dimer_scan(*args)
     o = oracle_lib.context(0).dimer_scan(*args)
     assert len(o) > 0 and h.tolist() == o.tolist()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("lanes", ["1", "16", "64"])
+def test_dimer_kernels_agree_for_every_lane_width(hip_lib, oracle_lib, lanes, monkeypatch):
+    """thread-per-pair (dimer_kernel) and sub-wave-per-pair (dimer_group_kernel<16|64>, tables in LDS) against the oracle on the
+    same degenerate primers, both scan modes and an explicit pair list — incl. primers shorter than 5 and 32-mers, which take
+    the un-staged table."""
+    monkeypatch.setenv("MP_DIMER_LANES", lanes)
+    seqs = random_primers(11, 220, 0.08)
+    codes, off = dimer.encode_primers(seqs)
+    hc, oc = hip_lib.context(0), oracle_lib.context(0)
+    for mode, thr in ((0, 3.96), (1, 3.0)):
+        args = (codes, off, mode, 40, dimer.cached_loss_table(thr), dimer.dg_params(), dimer.dg_limit())
+        assert hc.dimer_scan(*args).tolist() == oc.dimer_scan(*args).tolist()
+    rng = np.random.default_rng(5)
+    pairs = rng.integers(0, len(seqs), size=(3000, 2)).astype(np.int32)
+    args = (codes, off, pairs, dimer.cached_loss_table(3.6), dimer.dg_params(), dimer.dg_limit())
+    got, want = hc.dimer_pairs(*args), oc.dimer_pairs(*args)
+    assert want.any() and got.tolist() == want.tolist()

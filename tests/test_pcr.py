@@ -49,3 +49,55 @@ def test_pcr_matches_reference(case, oracle_lib, tmp_path):
 @pytest.mark.parametrize("case", list(CASES))
 def test_pcr_hip_matches_reference(case, hip_lib, tmp_path):
     check(case, hip_lib, tmp_path)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("rolling", [False, True])
+def test_pcr_kernels_equal_oracle_on_random_database(rolling, hip_lib, oracle_lib, monkeypatch):
+    """Both in-silico PCR kernels — block-per-sequence (LDS-packed segments, occurrence list) and the rolling scan it falls
+    back to (also forced for a sequence whose occurrence list overflows) — against the oracle: degenerate primers planted into
+    random sequences incl. lower case, N, repeated forward sites, sequences longer than one 4096-position segment and a
+    low-complexity sequence with thousands of occurrences."""
+    import numpy as np
+    from multiprime_amd import iupac
+    from multiprime_amd.dimer import encode_primers
+    if rolling:
+        monkeypatch.setenv("MP_PCR_ROLLING", "1")
+    rng = np.random.default_rng(3)
+    comp = str.maketrans("ACGT", "TGCA")
+    primers = []
+    for _ in range(12):
+        f = "".join(rng.choice(list("ACGT"), size=int(rng.integers(16, 24))))
+        r = "".join(rng.choice(list("ACGT"), size=int(rng.integers(16, 24))))
+        f = f[:5] + "R" + f[6:] if rng.random() < 0.5 else f
+        r = r[:7] + "Y" + r[8:12] + "N" + r[13:] if rng.random() < 0.5 else r
+        primers += [f, r]
+    seqs = []
+    for i in range(300):
+        n = int(rng.integers(50, 9000))
+        s = list(rng.choice(list("ACGT"), size=n))
+        for _ in range(int(rng.integers(0, 4))):
+            p = int(rng.integers(0, 12))
+            fe = iupac.expand(primers[2 * p])[int(rng.integers(0, 2)) % len(iupac.expand(primers[2 * p]))]
+            re_ = iupac.expand(primers[2 * p + 1])[0].translate(comp)[::-1]
+            a = int(rng.integers(0, max(1, n - 700)))
+            b = a + int(rng.integers(60, 600))
+            if b + len(re_) < n:
+                s[a:a + len(fe)] = fe
+                s[b:b + len(re_)] = re_
+                if rng.random() < 0.3 and b + 100 + len(fe) < n:
+                    s[b + 60:b + 60 + len(fe)] = fe          # a second forward site behind the product
+        if rng.random() < 0.2:
+            j = int(rng.integers(0, n))
+            s[j] = "N" if rng.random() < 0.5 else s[j].lower()
+        seqs.append("".join(s))
+    poly = iupac.expand(primers[0])[0]
+    seqs.append((poly + "A") * 400)                        # thousands of forward sites: the occurrence list overflows
+    data = np.frombuffer("".join(seqs).encode(), np.uint8)
+    off = np.zeros(len(seqs) + 1, np.int64)
+    np.cumsum([len(s) for s in seqs], out=off[1:])
+    codes, poff = encode_primers(primers)
+    got = hip_lib.context(0).pcr_scan(data, off, codes, poff)
+    want = oracle_lib.context(0).pcr_scan(data, off, codes, poff)
+    assert (want[:, :, 0] >= 0).sum() > 50
+    assert got.tolist() == want.tolist()
