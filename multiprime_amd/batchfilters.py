@@ -1,0 +1,129 @@
+"""The per-primer string filters and Tm of the core step (filters.py, thermo.py — V20:282-336, 387-416, 507-521) for ALL output
+primers of an alignment at once, on symbol-code matrices with numpy.
+
+Same results as the scalar functions, value for value (tests/test_batchfilters.py runs both on random degenerate primers;
+the 15 golden TSVs hold the "Tm" and "Information" columns):
+  * Tm: the nearest-neighbour sums are accumulated position by position (one vector add per position: the same left-to-right
+    double additions per expansion as the reference's loop), the closing formula is elementwise IEEE arithmetic, and the final
+    round(x, 2) is Python's, applied per value;
+  * GC fraction: round(g / n, 3) is looked up per GC count, the mean over a primer's expansions is the exact one;
+  * repeats / hairpin: an expansion picks one base per position independently, so "some expansion contains the pattern" is a
+    statement about intersections of the positions' base sets — no expansion is enumerated.
+"""
+from __future__ import annotations
+
+import numpy as np
+
+from . import host, iupac, thermo
+
+_COMP_MASK = np.zeros(16, np.uint8)          # complement of a base set: A<->T, C<->G
+for _m in range(16):
+    _COMP_MASK[_m] = ((_m & 1) << 3) | ((_m & 2) << 1) | ((_m & 4) >> 1) | ((_m & 8) >> 3)
+_POP = np.array([bin(m).count("1") for m in range(16)], np.uint8)
+_BASE_OF_CODE = np.zeros(16, np.int64)       # concrete code 1,2,4,8 -> 0..3
+_BASE_OF_CODE[[1, 2, 4, 8]] = [0, 1, 2, 3]
+_DH = np.asarray(thermo._DH, np.float64)
+_DS = np.asarray(thermo._DS, np.float64)
+_DH_END = np.asarray([thermo._DH_END[b] for b in "ACGT"], np.float64)
+_DS_END = np.asarray([thermo._DS_END[b] for b in "ACGT"], np.float64)
+
+
+def _segments(src, n):
+    """start offsets of every primer's run inside the expansion list (src ascending)."""
+    return np.searchsorted(src, np.arange(n + 1))
+
+
+def tm_of_primers(codes: np.ndarray):
+    """[round(mean(Calc_Tm_v2 over the expansions), 2)] per primer (V20:849-852, 282-336)."""
+    n, k = codes.shape
+    if n == 0:
+        return []
+    exp, src = host.expand_kmers(codes)
+    idx = _BASE_OF_CODE[exp]                                   # [m][k] base indices
+    dh = np.zeros(len(idx), np.float64)
+    ds = np.zeros(len(idx), np.float64)
+    for t in range(1, k):                                      # dh += Htable[cur][prev], left to right (V20:253-256)
+        dh += _DH[idx[:, t], idx[:, t - 1]]
+        ds += _DS[idx[:, t], idx[:, t - 1]]
+    dh += _DH_END[idx[:, 0]] + _DH_END[idx[:, k - 1]]
+    ds += _DS_END[idx[:, 0]] + _DS_END[idx[:, k - 1]]
+    sym = np.zeros(len(idx), bool)
+    if k % 2 == 0:                                             # symmetry (V20:237-246): first half == RC(reversed second half)
+        h = k // 2
+        sym = (idx[:, :h] == 3 - idx[:, h:]).all(axis=1)
+        ds = np.where(sym, ds + thermo._DS_SYMMETRY, ds)
+    dh = dh * 1000
+    ln_c = np.where(sym, thermo._LN_CONC_A, thermo._LN_CONC_B)
+    t_raw = 1 / ((1 / (dh / (ds + ln_c))) + thermo.SALT_CORRECTION) - thermo.KELVIN
+    vals = [round(x, 2) for x in t_raw.tolist()]               # thermo.tm rounds every expansion's Tm
+    seg = _segments(src, n).tolist()
+    return [round(iupac.exact_mean(vals[a:b]), 2) for a, b in zip(seg[:-1], seg[1:])]
+
+
+def gc_of_primers(codes: np.ndarray):
+    """filters.gc_fraction per primer (V20:401-407)."""
+    n, k = codes.shape
+    if n == 0:
+        return []
+    exp, src = host.expand_kmers(codes)
+    r3 = [round(g / k, 3) for g in range(k + 1)]
+    gc = ((exp == 2) | (exp == 4)).sum(axis=1).tolist()
+    vals = [r3[g] for g in gc]
+    seg = _segments(src, n).tolist()
+    return [round(iupac.exact_mean(vals[a:b]), 2) for a, b in zip(seg[:-1], seg[1:])]
+
+
+def repeat_of_primers(codes: np.ndarray) -> np.ndarray:
+    """filters.has_repeat per primer (di_nucleotide, V20:410-416): some expansion holds XXXX, (XY)x4 with X != Y or (XYZ)x3 with
+    X != Y and Y != Z."""
+    n, k = codes.shape
+    M = codes
+    hit = np.zeros(n, bool)
+    for o in range(0, k - 3):
+        hit |= (M[:, o] & M[:, o + 1] & M[:, o + 2] & M[:, o + 3]) != 0
+    for o in range(0, k - 7):
+        a = M[:, o] & M[:, o + 2] & M[:, o + 4] & M[:, o + 6]
+        b = M[:, o + 1] & M[:, o + 3] & M[:, o + 5] & M[:, o + 7]
+        hit |= (a != 0) & (b != 0) & ~((a == b) & (_POP[a] == 1))
+    for o in range(0, k - 8):
+        a = M[:, o] & M[:, o + 3] & M[:, o + 6]
+        b = M[:, o + 1] & M[:, o + 4] & M[:, o + 7]
+        c = M[:, o + 2] & M[:, o + 5] & M[:, o + 8]
+        for y in (1, 2, 4, 8):
+            hit |= ((b & y) != 0) & ((a & ~np.uint8(y) & 15) != 0) & ((c & ~np.uint8(y) & 15) != 0)
+    return hit
+
+
+def hairpin_of_primers(codes: np.ndarray, distance: int) -> np.ndarray:
+    """filters.has_hairpin per primer (V20:387-398): a 5-mer (any of its expansions) whose reverse complement occurs in some
+    expansion of the primer at least `distance` bases downstream."""
+    n, k = codes.shape
+    M = codes
+    CM = _COMP_MASK[M]
+    hit = np.zeros(n, bool)
+    for s in range(0, k - 5 - 5 - distance + 1):
+        for o in range(s + 5 + distance, k - 4):
+            ok = np.ones(n, bool)
+            for j in range(5):                                  # RC(stem)[j] = comp(stem[4 - j]) must lie in the set at o + j
+                ok &= (CM[:, s + 4 - j] & M[:, o + j]) != 0
+            hit |= ok
+    return hit
+
+
+def information_of_primers(codes: np.ndarray, gc_range, distance: int):
+    """filters.pre_filter per primer (primer_pre_filter, V20:507-521): the TSV's "Information" column."""
+    lo, hi = float(gc_range[0]), float(gc_range[1])
+    gcs = gc_of_primers(codes)
+    rep = repeat_of_primers(codes).tolist()
+    hp = hairpin_of_primers(codes, distance).tolist()
+    out = []
+    for gc, r, h in zip(gcs, rep, hp):
+        info = []
+        if not lo <= gc <= hi:
+            info.append("GC_out_of_range (" + str(gc) + ")")
+        if r:
+            info.append("di_nucleotide")
+        if h:
+            info.append("hairpin")
+        out.append(gc if not info else "|".join(info))
+    return out

@@ -25,11 +25,10 @@ import sys
 import time
 from collections import defaultdict
 from json.encoder import encode_basestring_ascii as _q
-from statistics import mean
 
 import numpy as np
 
-from . import filters, host, iupac, msa, thermo
+from . import batchfilters, host, iupac, msa
 from ._abi import MP_ERR_SHORT_WINDOW, Library, MprimeError
 
 _B2I = {"A": 0, "C": 1, "G": 2, "T": 3}
@@ -242,13 +241,16 @@ class NN_degenerate(object):
             cov, f_mis, r_mis = res["cov"].tolist(), res["f_mis"].tolist(), res["r_mis"].tolist()
             nonsense, n_dege = res["nonsense"].tolist(), res["n_dege"].tolist()
             side = self._side_file_builder() if self.write_json else None
+            # Tm (V20:849-852, 282-336) and the "Information" column (primer_pre_filter, V20:507-521, V20:911) of every primer
+            # at once: numpy over the symbol-code matrix, value for value what thermo.tm / filters.pre_filter give per primer
+            keep = [i for i, d in enumerate(dimer_flag) if not d]                 # V20:749
+            kept_codes = res["codes"][keep] if keep else np.zeros((0, k), np.uint8)
+            tm_all = dict(zip(keep, batchfilters.tm_of_primers(kept_codes)))
+            info_all = dict(zip(keep, batchfilters.information_of_primers(kept_codes, self.GC, self.distance)))
             for i, primer in enumerate(primers):
-                if dimer_flag[i]:                                                  # V20:749
+                if dimer_flag[i]:
                     continue
-                tms = [thermo.tm(e) for e in iupac.expand(primer)]
-                # statistics.mean is the correctly rounded exact mean; for one or two values plain float arithmetic is too
-                tm_avg = round(tms[0] if len(tms) == 1 else ((tms[0] + tms[1]) / 2 if len(tms) == 2 else mean(tms)), 2)   # V20:849-852
-                info = filters.pre_filter(primer, self.GC, self.distance)          # V20:911
+                tm_avg, info = tm_all[i], info_all[i]
                 pos = p0 + wins[i]
                 rows_out.append([pos, cbit[i], tbit[i], primer, n_dege[i], nonsense[i], cov[i], f_mis[i], r_mis[i], tm_avg, info])
                 if side is not None:

@@ -1,0 +1,54 @@
+"""multiprime_amd/batchfilters.py (numpy over all output primers) against the scalar restatements of the reference's functions
+(filters.py / thermo.py, pinned to V20's known answers in test_kat.py): Tm, GC fraction, repeats, hairpin, Information —
+value for value on random degenerate primers of several lengths."""
+import numpy as np
+import pytest
+
+from multiprime_amd import batchfilters, filters, iupac, thermo
+
+
+def random_primers(seed, n, k, p_deg):
+    rng = np.random.default_rng(seed)
+    out = []
+    for _ in range(n):
+        s = list(rng.choice(list("ACGT"), size=k))
+        if rng.random() < 0.3:                                   # plant low-complexity stretches and palindromes
+            a = int(rng.integers(0, k - 8))
+            unit = "".join(rng.choice(list("ACGT"), size=int(rng.integers(1, 4))))
+            s[a:a + 9] = list((unit * 9)[:9])[: len(s[a:a + 9])]
+        if rng.random() < 0.3 and k >= 16:
+            a = int(rng.integers(0, k - 15))
+            stem = s[a:a + 5]
+            s[a + 10:a + 15] = list(iupac.revcomp("".join(stem)))
+        deg = 1
+        for j in range(k):
+            if rng.random() < p_deg and deg < 12:
+                sym = "RYMKSWHBVDN"[int(rng.integers(0, 11))]
+                deg *= iupac.SET_SIZE[sym]
+                s[j] = sym
+        out.append("".join(s))
+    if k % 2 == 0:
+        half = "".join(rng.choice(list("ACGT"), size=k // 2))
+        out.append(half + iupac.revcomp(half))                   # a self-complementary primer: the symmetry branch of Tm
+        out.append(half + iupac.revcomp(half[::-1])[::-1])
+    return out
+
+
+@pytest.mark.parametrize("k,seed", [(14, 1), (18, 2), (18, 3), (22, 4), (27, 5)])
+def test_batch_equals_scalar(k, seed):
+    prim = random_primers(seed, 600, k, 0.06)
+    codes = iupac.MASK_LUT[np.frombuffer("".join(prim).encode(), np.uint8)].reshape(len(prim), k)
+    want_tm = []
+    for p in prim:
+        tms = [thermo.tm(e) for e in iupac.expand(p)]
+        want_tm.append(round(iupac.exact_mean(tms), 2))
+    assert batchfilters.tm_of_primers(codes) == want_tm
+    assert batchfilters.gc_of_primers(codes) == [filters.gc_fraction(p) for p in prim]
+    want_rep = [filters.has_repeat(p) for p in prim]
+    assert batchfilters.repeat_of_primers(codes).tolist() == want_rep and any(want_rep) and not all(want_rep)
+    for d in (3, 4):
+        want_hp = [filters.has_hairpin(p, d) for p in prim]
+        assert batchfilters.hairpin_of_primers(codes, d).tolist() == want_hp
+    assert any(filters.has_hairpin(p, 4) for p in prim)
+    got = batchfilters.information_of_primers(codes, ["0.2", "0.7"], 4)
+    assert [str(x) for x in got] == [str(filters.pre_filter(p, ["0.2", "0.7"], 4)) for p in prim]
