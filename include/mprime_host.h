@@ -117,6 +117,21 @@ int mp_plan_results(const mp_plan *p, int32_t *window, double *cbit, double *tbi
 int mp_plan_window_table(const mp_plan *p, int32_t w, int32_t which, int64_t cap, uint8_t *codes, int64_t *counts,
                          int64_t *first_row, int64_t *n);
 
+/* Writes the two JSON side files of the core step (V20:1172-1177) — {out}.non_coverage_seq_id_json = {pos: [{k-mer: [ids]} (F),
+ * {k-mer: [ids]} (R)]} and {out}.gap_seq_id_json = {pos: {expanded gap k-mer: [ids]}} — byte for byte what the reference's
+ * json.dump(obj, fh, indent=4) writes (dict insertion orders, ids in file order, encode_basestring_ascii escapes), for the
+ * n_out output windows out_window[] (ascending) at positions out_pos[] with final primers primer_codes [n_out][k]:
+ * a cover k-mer is listed under F (R) when the primer misses it in 1..v positions one of which is F- (R-) strict, or in more
+ * than v positions (V20:1107-1127).  The plan must have been created with keep_tables.  Sequences come from
+ *   dev_off [W+1] / dev_words (b0 at [0,n_dev), b1, g) — the histogram entries as mp_get_unique returned them,
+ *   labels [n_out][n_rows] — mp_get_labels of each output window (index of the row's entry inside its window, -1 = none),
+ *   the exception list (x_window, x_row, x_codes) and the ids (raw bytes + offsets, decoded as UTF-8 / surrogateescape). */
+int mp_plan_write_side_files(const mp_plan *p, int32_t n_out, const int32_t *out_window, const int64_t *out_pos,
+                             const uint8_t *primer_codes, uint32_t strictF, uint32_t strictR, const int64_t *dev_off,
+                             const uint32_t *dev_words, int64_t n_dev, const int32_t *labels, int32_t n_rows, int64_t n_exc,
+                             const int32_t *x_window, const int64_t *x_row, const uint8_t *x_codes, const uint8_t *ids,
+                             const int64_t *id_off, const char *noncov_path, const char *gap_path);
+
 /* Expansions of n k-mers of symbol codes (degenerate_seq, V20:368-380) in the reference's order; out_src[i] = index
  * of the k-mer expansion i comes from.  *n_out returns the number needed; MP_ERR_CAPACITY if cap is too small. */
 int mp_expand_kmers(int32_t k, int64_t n, const uint8_t *codes, int64_t cap, uint8_t *out_codes, int64_t *out_src, int64_t *n_out);

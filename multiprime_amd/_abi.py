@@ -206,6 +206,14 @@ class Context:
         out[ok] = self._label_rank[self._off[w] + lab[ok]]
         return out
 
+    def get_labels_raw(self, windows) -> np.ndarray:
+        """[len(windows)][n_rows] int32: mp_get_labels of each window as the library returns them (index of the row's entry inside
+        the window's segment of mp_get_unique, -1 = the row is not in the histogram)."""
+        out = np.empty((max(len(windows), 1), self.n_rows), np.int32)
+        for i, w in enumerate(windows):
+            self._ck(self.d.mp_get_labels(self.h, int(w), _ptr(out[i])))
+        return out[: len(windows)]
+
     # (4)
     def window_stats(self):
         """(freq [W][4][k], nn [W][k-1][4][4]) int64: per-window base counts and nearest-neighbour pair counts

@@ -21,6 +21,7 @@ from ~12 dependent rounds to one.
 """
 from __future__ import annotations
 
+import os
 import sys
 import time
 from collections import defaultdict
@@ -175,7 +176,10 @@ class NN_degenerate(object):
         self.stats["stats_s"] = time.time() - t0
         t0 = time.time()
         # per-window histograms; sorted by first row only when the id lists of the JSON files need the labels
-        off, words, count, first = self.ctx.window_unique(want_labels=self.write_json, sort=self.write_json)
+        # (the Python JSON writer of the row-sharded path wants them sorted by first row; the native writer takes them as they come)
+        # MP_JSON_WRITER=python keeps the Python writer in a single process too (tests compare the two byte for byte)
+        self._native_json = self.write_json and self.comm is None and os.environ.get("MP_JSON_WRITER", "native") != "python"
+        off, words, count, first = self.ctx.window_unique(want_labels=self.write_json, sort=self.write_json and not self._native_json)
         self.stats["unique_s"] = time.time() - t0
         t0 = time.time()
         e_window = np.repeat(np.arange(W, dtype=np.int32), np.diff(off))
@@ -240,7 +244,9 @@ class NN_degenerate(object):
             cbit, tbit = res["cbit"].tolist(), res["tbit"].tolist()
             cov, f_mis, r_mis = res["cov"].tolist(), res["f_mis"].tolist(), res["r_mis"].tolist()
             nonsense, n_dege = res["nonsense"].tolist(), res["n_dege"].tolist()
-            side = self._side_file_builder() if self.write_json else None
+            # JSON side files: written natively for a single process (mp_plan_write_side_files); row shards gather id lists per
+            # output window and use the Python writer below
+            side = self._side_file_builder() if self.write_json and not self._native_json else None
             # Tm (V20:849-852, 282-336) and the "Information" column (primer_pre_filter, V20:507-521, V20:911) of every primer
             # at once: numpy over the symbol-code matrix, value for value what thermo.tm / filters.pre_filter give per primer
             keep = [i for i, d in enumerate(dimer_flag) if not d]                 # V20:749
@@ -428,7 +434,19 @@ class NN_degenerate(object):
             fo.write("\t".join(HEADERS) + "\n")
             for row in rows_out:
                 fo.write("\t".join(map(str, row)) + "\n")
-        if self.write_json:
+        if self.write_json and getattr(self, "_native_json", False) and self.plan is not None:
+            k = self.primer_length
+            p0 = int(self.start_position)
+            wins = np.asarray([int(r[0]) - p0 for r in rows_out], np.int32)
+            codes = (iupac.MASK_LUT[np.frombuffer("".join(r[3] for r in rows_out).encode(), np.uint8)].reshape(len(rows_out), k)
+                     if rows_out else np.zeros((0, k), np.uint8))
+            off, words = self._dev_entries
+            ex_w, x_row, ex_codes = self._exc
+            ids_bytes, ids_off = self._fasta.ids_raw()
+            self.plan.write_side_files(wins, [int(r[0]) for r in rows_out], codes, self._sF, self._sR, off, words,
+                                       self.ctx.get_labels_raw(wins), ex_w, x_row, ex_codes, ids_bytes, ids_off,
+                                       self.outfile + ".non_coverage_seq_id_json", self.outfile + ".gap_seq_id_json")
+        elif self.write_json:
             with open(self.outfile + ".non_coverage_seq_id_json", "w") as fj:      # V20:1172-1173 json.dump(.., indent=4)
                 _dump_side_file(non_cov_out, fj, True)
             with open(self.outfile + ".gap_seq_id_json", "w") as fg:               # V20:1175-1176

@@ -19,6 +19,7 @@
 #include <limits>
 #include <string>
 #include <thread>
+#include <unordered_map>
 #include <vector>
 
 namespace {
@@ -781,3 +782,215 @@ int mp_expand_kmers(int32_t k, int64_t n, const uint8_t *codes, int64_t cap, uin
 }
 
 }  // extern "C"
+
+// ---------------------------------------------------------------------------------------------------------------
+// JSON side files (V20:1172-1177): {out}.non_coverage_seq_id_json and {out}.gap_seq_id_json, byte for byte what
+// json.dump(obj, fh, indent=4) writes for the reference's dictionaries
+// ---------------------------------------------------------------------------------------------------------------
+namespace {
+
+struct Out {
+    FILE *f;
+    std::string buf;
+    explicit Out(FILE *f_) : f(f_) { buf.reserve(1 << 20); }
+    void put(const char *s) { buf += s; if (buf.size() > (1 << 20)) flush(); }
+    void put(const std::string &s) { buf += s; if (buf.size() > (1 << 20)) flush(); }
+    void pad(int n) { buf.append((size_t)n, ' '); }
+    void flush() { if (!buf.empty()) { fwrite(buf.data(), 1, buf.size(), f); buf.clear(); } }
+};
+
+// json.encoder.encode_basestring_ascii of a str that was decoded from `n` UTF-8 bytes with errors="surrogateescape"
+std::string json_quote(const uint8_t *s, size_t n) {
+    std::string o = "\"";
+    char tmp[16];
+    auto esc = [&](uint32_t cp) {
+        if (cp >= 0x10000) {                                  // UTF-16 surrogate pair
+            cp -= 0x10000;
+            snprintf(tmp, sizeof tmp, "\\u%04x\\u%04x", 0xd800 | ((cp >> 10) & 0x3ff), 0xdc00 | (cp & 0x3ff));
+        } else snprintf(tmp, sizeof tmp, "\\u%04x", cp);
+        o += tmp;
+    };
+    size_t i = 0;
+    while (i < n) {
+        const uint8_t c = s[i];
+        if (c < 0x80) {
+            switch (c) {
+            case '"': o += "\\\""; break;
+            case '\\': o += "\\\\"; break;
+            case '\n': o += "\\n"; break;
+            case '\r': o += "\\r"; break;
+            case '\t': o += "\\t"; break;
+            case '\b': o += "\\b"; break;
+            case '\f': o += "\\f"; break;
+            default:
+                if (c < 0x20) esc(c);
+                else o += (char)c;
+            }
+            i++;
+            continue;
+        }
+        // decode one UTF-8 sequence; an invalid byte becomes the lone surrogate U+DC00 + byte (surrogateescape)
+        int len = (c >= 0xf0 && c <= 0xf4) ? 4 : (c >= 0xe0 && c < 0xf0) ? 3 : (c >= 0xc2 && c < 0xe0) ? 2 : 0;
+        uint32_t cp = 0;
+        bool ok = len > 0 && i + (size_t)len <= n;
+        if (ok) {
+            cp = len == 2 ? (c & 0x1f) : len == 3 ? (c & 0x0f) : (c & 0x07);
+            for (int t = 1; t < len; t++) {
+                if ((s[i + t] & 0xc0) != 0x80) { ok = false; break; }
+                cp = (cp << 6) | (s[i + t] & 0x3f);
+            }
+            if (ok && ((len == 3 && (cp < 0x800 || (cp >= 0xd800 && cp <= 0xdfff))) || (len == 4 && (cp < 0x10000 || cp > 0x10ffff)))) ok = false;
+        }
+        if (ok) { esc(cp); i += (size_t)len; }
+        else { esc(0xdc00 + c); i++; }
+    }
+    o += '"';
+    return o;
+}
+
+std::string key_string(const Key &k, int n) {
+    static const char *sym = "-ACMGRSVTWYHKDBN";
+    std::string s((size_t)n, '-');
+    for (int j = 0; j < n; j++) s[(size_t)j] = sym[k.get(j)];
+    return s;
+}
+
+struct KeyHash { size_t operator()(const Key &k) const { return (size_t)hash_key(k); } };
+
+}  // namespace
+
+extern "C" int mp_plan_write_side_files(const mp_plan *p, int32_t n_out, const int32_t *out_window, const int64_t *out_pos,
+                                        const uint8_t *primer_codes, uint32_t strictF, uint32_t strictR, const int64_t *dev_off,
+                                        const uint32_t *dev_words, int64_t n_dev, const int32_t *labels, int32_t n_rows, int64_t n_exc,
+                                        const int32_t *x_window, const int64_t *x_row, const uint8_t *x_codes, const uint8_t *ids,
+                                        const int64_t *id_off, const char *noncov_path, const char *gap_path) {
+    if (!p || n_out < 0 || n_rows < 0 || !noncov_path || !gap_path || (n_out && (!out_window || !out_pos || !primer_codes || !dev_off || !labels || !ids || !id_off)))
+        return MP_ERR_ARG;
+    if (!p->P.keep_tables) return MP_ERR_ARG;
+    const int k = p->P.k, v = p->P.v;
+    const uint32_t kmask = k == 32 ? 0xFFFFFFFFu : ((1u << k) - 1u);
+    FILE *fn = fopen(noncov_path, "wb"), *fg = fopen(gap_path, "wb");
+    if (!fn || !fg) { if (fn) fclose(fn); if (fg) fclose(fg); return MP_ERR_ARG; }
+    Out on(fn), og(fg);
+    // exceptions grouped by window, ascending rows
+    std::vector<int64_t> xorder((size_t)n_exc);
+    for (int64_t i = 0; i < n_exc; i++) xorder[(size_t)i] = i;
+    std::sort(xorder.begin(), xorder.end(), [&](int64_t a, int64_t b) {
+        return x_window[a] != x_window[b] ? x_window[a] < x_window[b] : x_row[a] < x_row[b];
+    });
+    std::vector<std::string> idq((size_t)n_rows);                        // quoted ids, made on first use
+    auto quoted_id = [&](int64_t r) -> const std::string & {
+        std::string &q = idq[(size_t)r];
+        if (q.empty()) q = json_quote(ids + id_off[r], (size_t)(id_off[r + 1] - id_off[r]));
+        return q;
+    };
+    auto ids_block = [&](Out &o, const std::vector<int64_t> &rows, int ind) {
+        if (rows.empty()) { o.put("[]"); return; }
+        o.put("[\n");
+        for (size_t i = 0; i < rows.size(); i++) {
+            o.pad(ind + 4);
+            o.put(quoted_id(rows[i]));
+            if (i + 1 < rows.size()) o.put(",\n");
+        }
+        o.put("\n");
+        o.pad(ind);
+        o.put("]");
+    };
+    on.put(n_out ? "{\n" : "{}");
+    og.put(n_out ? "{\n" : "{}");
+    for (int32_t oi = 0; oi < n_out; oi++) {
+        const int32_t w = out_window[oi];
+        if (w < 0 || (size_t)w >= p->win.size()) { fclose(fn); fclose(fg); return MP_ERR_ARG; }
+        const Window &W = p->win[(size_t)w];
+        const uint8_t *pc = primer_codes + (size_t)oi * k;
+        // rows of every device entry of the window (labels index the entries in device order)
+        const int64_t a = dev_off[w], b = dev_off[w + 1];
+        std::vector<std::vector<int64_t>> rows_of_entry((size_t)(b - a));
+        const int32_t *lab = labels + (size_t)oi * n_rows;
+        for (int32_t r = 0; r < n_rows; r++)
+            if (lab[r] >= 0 && lab[r] < b - a) rows_of_entry[(size_t)lab[r]].push_back(r);
+        std::unordered_map<Key, int32_t, KeyHash> entry_of;             // k-mer -> device entry
+        for (int64_t e = a; e < b; e++) {
+            const uint32_t b0 = dev_words[e], b1 = dev_words[(size_t)n_dev + e], g = dev_words[2 * (size_t)n_dev + e] & kmask;
+            Key key;
+            for (int j = 0; j < k; j++) key.set(j, (g >> j) & 1u ? 0u : 1u << (((b0 >> j) & 1u) | (((b1 >> j) & 1u) << 1)));
+            entry_of.emplace(key, (int32_t)(e - a));
+        }
+        // exceptions of this window
+        auto lo = std::lower_bound(xorder.begin(), xorder.end(), w, [&](int64_t i, int32_t ww) { return x_window[i] < ww; });
+        auto hi = std::upper_bound(xorder.begin(), xorder.end(), w, [&](int32_t ww, int64_t i) { return ww < x_window[i]; });
+        // ids of a k-mer: rows of its device entry + the exception rows (of the wanted kind) one of whose expansions it is
+        auto rows_of_key = [&](const Key &key, bool gap_rows) {
+            std::vector<int64_t> rows;
+            auto it = entry_of.find(key);
+            if (it != entry_of.end()) rows = rows_of_entry[(size_t)it->second];
+            bool touched = false;
+            for (auto x = lo; x != hi; ++x) {
+                const uint8_t *codes = x_codes + (size_t)*x * k;
+                int ngap = 0;
+                bool member = true;
+                for (int j = 0; j < k; j++) {
+                    ngap += codes[j] == 0;
+                    const uint32_t kc = key.get(j);
+                    member &= codes[j] == 0 ? kc == 0 : (kc != 0 && (codes[j] & kc) == kc);
+                }
+                if ((ngap > v) != gap_rows || !member) continue;
+                rows.push_back(x_row[*x]);
+                touched = true;
+            }
+            if (touched) std::sort(rows.begin(), rows.end());
+            return rows;
+        };
+        // ---- non_coverage: [ {k-mer: ids} for F, {k-mer: ids} for R ] over the cover dict in insertion order (V20:1107-1127)
+        char num[32];
+        snprintf(num, sizeof num, "%lld", (long long)out_pos[oi]);
+        on.pad(4); on.put("\""); on.put(num); on.put("\": [\n");
+        for (int side = 0; side < 2; side++) {
+            const uint32_t strict = side == 0 ? strictF : strictR;
+            on.pad(8);
+            bool any = false;
+            for (const Entry &e : W.cover) {
+                uint32_t D = 0;
+                int nd = 0;
+                for (int j = 0; j < k; j++) {
+                    const uint32_t c = e.key.get(j);
+                    if (c == 0 || !(pc[j] & c)) { D |= 1u << j; nd++; }
+                }
+                if (nd == 0 || !(nd > v || (D & strict))) continue;
+                on.put(any ? ",\n" : "{\n");
+                any = true;
+                on.pad(12); on.put("\""); on.put(key_string(e.key, k)); on.put("\": ");
+                ids_block(on, rows_of_key(e.key, false), 12);
+            }
+            if (any) { on.put("\n"); on.pad(8); on.put("}"); }
+            else on.put("{}");
+            on.put(side == 0 ? ",\n" : "\n");
+        }
+        on.pad(4); on.put("]");
+        on.put(oi + 1 < n_out ? ",\n" : "\n}");
+        // ---- gap_seq_id: expansions of the gap_sequence keys in insertion order (V20:698)
+        og.pad(4); og.put("\""); og.put(num); og.put("\": ");
+        std::vector<Key> gkeys;
+        std::unordered_map<Key, int32_t, KeyHash> seen;
+        for (const Entry &e : W.gap) {
+            uint8_t codes[32];
+            for (int j = 0; j < k; j++) codes[j] = (uint8_t)e.key.get(j);
+            for_each_expansion(codes, k, [&](const Key &x) { if (seen.emplace(x, 1).second) gkeys.push_back(x); });
+        }
+        if (gkeys.empty()) og.put("{}");
+        else {
+            og.put("{\n");
+            for (size_t i = 0; i < gkeys.size(); i++) {
+                og.pad(8); og.put("\""); og.put(key_string(gkeys[i], k)); og.put("\": ");
+                ids_block(og, rows_of_key(gkeys[i], true), 8);
+                if (i + 1 < gkeys.size()) og.put(",\n");
+            }
+            og.put("\n"); og.pad(4); og.put("}");
+        }
+        og.put(oi + 1 < n_out ? ",\n" : "\n}");
+    }
+    on.flush(); og.flush();
+    const bool bad = ferror(fn) || ferror(fg);
+    fclose(fn); fclose(fg);
+    return bad ? MP_ERR_ARG : MP_OK;
+}

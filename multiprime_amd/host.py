@@ -41,6 +41,8 @@ HOST_SYMBOLS = [
     ("mp_plan_finish", C.c_int, [_p, _p]),
     ("mp_plan_results", C.c_int, [_p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p]),
     ("mp_plan_window_table", C.c_int, [_p, C.c_int32, C.c_int32, C.c_int64, _p, _p, _p, C.POINTER(C.c_int64)]),
+    ("mp_plan_write_side_files", C.c_int, [_p, C.c_int32, _p, _p, _p, C.c_uint32, C.c_uint32, _p, _p, C.c_int64, _p, C.c_int32, C.c_int64,
+                                           _p, _p, _p, _p, _p, C.c_char_p, C.c_char_p]),
     ("mp_expand_kmers", C.c_int, [C.c_int32, C.c_int64, _p, C.c_int64, _p, _p, C.POINTER(C.c_int64)]),
 ]
 
@@ -254,6 +256,27 @@ class Plan:
         first = np.empty(max(m, 1), np.int64)
         self._ck(self.d.mp_plan_window_table(self.h, int(w), int(which), m, _ptr(codes), _ptr(counts), _ptr(first), C.byref(n)))
         return codes[:m], counts[:m], first[:m]
+
+    def write_side_files(self, out_window, out_pos, primer_codes, strictF, strictR, dev_off, dev_words, labels, x_window, x_row,
+                         x_codes, ids_bytes, ids_off, noncov_path, gap_path):
+        """The two JSON side files of the core step, written natively (byte-identical to json.dump(..., indent=4))."""
+        out_window = np.ascontiguousarray(out_window, dtype=np.int32)
+        out_pos = np.ascontiguousarray(out_pos, dtype=np.int64)
+        primer_codes = np.ascontiguousarray(primer_codes, dtype=np.uint8).reshape(len(out_window), self.k)
+        dev_off = np.ascontiguousarray(dev_off, dtype=np.int64)
+        dev_words = np.ascontiguousarray(dev_words, dtype=np.uint32)
+        n_dev = dev_words.shape[1] if dev_words.ndim == 2 else 0
+        labels = np.ascontiguousarray(labels, dtype=np.int32)
+        n_rows = labels.shape[1] if labels.ndim == 2 else 0
+        x_window = np.ascontiguousarray(x_window, dtype=np.int32)
+        x_row = np.ascontiguousarray(x_row, dtype=np.int64)
+        x_codes = np.ascontiguousarray(x_codes, dtype=np.uint8)
+        ids_bytes = np.ascontiguousarray(ids_bytes, dtype=np.uint8)
+        ids_off = np.ascontiguousarray(ids_off, dtype=np.int64)
+        self._ck(self.d.mp_plan_write_side_files(self.h, len(out_window), _ptr(out_window), _ptr(out_pos), _ptr(primer_codes), int(strictF),
+                                                 int(strictR), _ptr(dev_off), _ptr(dev_words), n_dev, _ptr(labels), n_rows, len(x_window),
+                                                 _ptr(x_window), _ptr(x_row), _ptr(x_codes), _ptr(ids_bytes), _ptr(ids_off),
+                                                 os.fsencode(noncov_path), os.fsencode(gap_path)))
 
     def close(self):
         if getattr(self, "h", None):

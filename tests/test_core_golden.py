@@ -73,3 +73,55 @@ def test_hip_path_matches_reference(name, hip_lib, tmp_path):
     assert hip_lib.backend == "hip"
     _, out = run_fixture(name, hip_lib, tmp_path)
     check_outputs(name, out)
+
+
+def _side_bytes(out):
+    return (open(str(out) + ".non_coverage_seq_id_json", "rb").read(), open(str(out) + ".gap_seq_id_json", "rb").read())
+
+
+@pytest.mark.parametrize("name", ["syn_iupac", "syn_ragged", "syn_edge", "ivc_v2", "msa1000_k18_d10", "cluster0_v2"])
+def test_native_json_writer_equals_python_writer(name, oracle_lib, tmp_path, monkeypatch):
+    """mp_plan_write_side_files (single process) and the Python writer of the row-sharded path give the same bytes."""
+    (tmp_path / "n").mkdir()
+    (tmp_path / "p").mkdir()
+    _, out_n = run_fixture(name, oracle_lib, tmp_path / "n")
+    monkeypatch.setenv("MP_JSON_WRITER", "python")
+    _, out_p = run_fixture(name, oracle_lib, tmp_path / "p")
+    assert _side_bytes(out_n) == _side_bytes(out_p)
+
+
+def test_native_json_writer_escapes_ids_like_json_dump(oracle_lib, tmp_path, monkeypatch):
+    """ids with quotes, backslashes, control bytes, non-ASCII UTF-8 (BMP and astral) and invalid UTF-8 (surrogateescape): the
+    native writer's strings are json.dump's (ensure_ascii) and the file reads back to the same dicts."""
+    import random
+    rng = random.Random(5)
+    base = "".join(rng.choice("ACGT") for _ in range(90))
+    ids = [b'plain', b'quo"te', b'back\\slash', b'tab\there', "été".encode(), "中文".encode(),
+           "\U0001f9ec x".encode(), b'bad\xff\xfebytes', b'\x7f del', b'trunc\xe4\xb8', b'over\xc0\xaf', b'sur\xed\xa0\x80']
+    rec = []
+    for i, name in enumerate(ids):
+        s = list(base)
+        for _ in range(i % 5):
+            s[rng.randrange(len(s))] = rng.choice("ACGT")
+        if i % 3 == 1:
+            s[30 + i] = "-"
+        if i % 4 == 2:
+            s[50 + i] = "R"
+        rec.append(b">" + name + b"\n" + "".join(s).encode() + b"\n")
+    outs = []
+    for mode in ("native", "python"):
+        d = tmp_path / mode
+        d.mkdir()
+        (d / "in.fa").write_bytes(b"".join(rec))
+        monkeypatch.setenv("MP_JSON_WRITER", mode)
+        app = NN_degenerate(seq_file=str(d / "in.fa"), primer_length=18, coverage=0.3, number_of_dege_bases=4, score_of_dege_bases=16,
+                            product_len=30, position="1,2,-1", variation=1, GC="0.2,0.8", nproc=1, outfile=str(d / "o"),
+                            library=oracle_lib)
+        app.run()
+        outs.append(_side_bytes(d / "o"))
+        assert len(open(d / "o").read().splitlines()) > 1
+    assert outs[0] == outs[1]
+    nc = json.loads(outs[0][0])
+    seen = {i for sides in nc.values() for side in sides for v in side.values() for i in v}
+    seen |= {i for d in json.loads(outs[0][1]).values() for v in d.values() for i in v}
+    assert any("\udcff" in i for i in seen) and any("\U0001f9ec" in i for i in seen) and any('"' in i for i in seen)
