@@ -33,6 +33,35 @@ def _segments(src, n):
     return np.searchsorted(src, np.arange(n + 1))
 
 
+def _exact_means(vals, seg):
+    """statistics.mean (exact rational sum, one rounding) of vals[seg[i]:seg[i+1]] for every i, without rationals: the doubles
+    are integers times one common power of two, summed per segment in two int64 halves; Python's int / int is correctly
+    rounded, as Fraction -> float is."""
+    vals = np.asarray(vals, np.float64)
+    seg = np.asarray(seg, np.int64)
+    n = len(seg) - 1
+    if n == 0:
+        return []
+    m, e = np.frexp(vals)
+    nz = m != 0
+    emin = int(e[nz].min()) - 53 if nz.any() else 0
+    shift = np.where(nz, e - 53 - emin, 0).astype(np.int64)
+    counts = np.diff(seg)
+    if int(shift.max(initial=0)) > 15 or int(counts.max()) >= 1 << 20 or not np.isfinite(vals).all() or int(counts.min()) < 1:
+        v = vals.tolist()
+        return [iupac.exact_mean(v[a:b]) for a, b in zip(seg[:-1].tolist(), seg[1:].tolist())]
+    mant = np.ldexp(m, 53).astype(np.int64)                     # exact: |mant| < 2^53
+    hi = mant >> 26                                             # floor split, also right for negative values
+    lo = mant - (hi << 26)
+    hs = np.add.reduceat(hi << shift, seg[:-1]).tolist()
+    ls = np.add.reduceat(lo << shift, seg[:-1]).tolist()
+    out = []
+    for h, l, c in zip(hs, ls, counts.tolist()):
+        total = (h << 26) + l
+        out.append(total / (c << -emin) if emin < 0 else (total << emin) / c)
+    return out
+
+
 def tm_of_primers(codes: np.ndarray):
     """[round(mean(Calc_Tm_v2 over the expansions), 2)] per primer (V20:849-852, 282-336)."""
     n, k = codes.shape
@@ -56,8 +85,7 @@ def tm_of_primers(codes: np.ndarray):
     ln_c = np.where(sym, thermo._LN_CONC_A, thermo._LN_CONC_B)
     t_raw = 1 / ((1 / (dh / (ds + ln_c))) + thermo.SALT_CORRECTION) - thermo.KELVIN
     vals = [round(x, 2) for x in t_raw.tolist()]               # thermo.tm rounds every expansion's Tm
-    seg = _segments(src, n).tolist()
-    return [round(iupac.exact_mean(vals[a:b]), 2) for a, b in zip(seg[:-1], seg[1:])]
+    return [round(x, 2) for x in _exact_means(vals, _segments(src, n))]
 
 
 def gc_of_primers(codes: np.ndarray):
@@ -66,11 +94,9 @@ def gc_of_primers(codes: np.ndarray):
     if n == 0:
         return []
     exp, src = host.expand_kmers(codes)
-    r3 = [round(g / k, 3) for g in range(k + 1)]
-    gc = ((exp == 2) | (exp == 4)).sum(axis=1).tolist()
-    vals = [r3[g] for g in gc]
-    seg = _segments(src, n).tolist()
-    return [round(iupac.exact_mean(vals[a:b]), 2) for a, b in zip(seg[:-1], seg[1:])]
+    r3 = np.asarray([round(g / k, 3) for g in range(k + 1)], np.float64)
+    vals = r3[((exp == 2) | (exp == 4)).sum(axis=1)]
+    return [round(x, 2) for x in _exact_means(vals, _segments(src, n))]
 
 
 def repeat_of_primers(codes: np.ndarray) -> np.ndarray:

@@ -52,3 +52,28 @@ def test_batch_equals_scalar(k, seed):
     assert any(filters.has_hairpin(p, 4) for p in prim)
     got = batchfilters.information_of_primers(codes, ["0.2", "0.7"], 4)
     assert [str(x) for x in got] == [str(filters.pre_filter(p, ["0.2", "0.7"], 4)) for p in prim]
+
+
+def test_segmented_exact_means_equal_statistics_mean():
+    """_exact_means (two int64 halves per segment, one int / int division) against statistics.mean on rounded Tm-like values,
+    GC-like values, signed values and values with wide exponent spread (which take the rational fallback)."""
+    import random
+    from statistics import mean
+
+    import numpy as np
+
+    from multiprime_amd.batchfilters import _exact_means
+    rng = random.Random(1)
+    for trial in range(120):
+        counts = [rng.choice([1, 2, 3, 4, 7, 16, 64, 1000]) for _ in range(rng.randrange(1, 30))]
+        seg = np.concatenate([[0], np.cumsum(counts)])
+        kind = trial % 4
+        if kind == 0:
+            vals = [round(rng.uniform(20, 90), 2) for _ in range(seg[-1])]
+        elif kind == 1:
+            vals = [round(rng.randrange(0, 19) / 18, 3) for _ in range(seg[-1])]
+        elif kind == 2:
+            vals = [rng.uniform(-5, 5) for _ in range(seg[-1])]
+        else:
+            vals = [rng.choice([0.0, 1e-9, 3.3, -7.25, 1e6]) for _ in range(seg[-1])]
+        assert _exact_means(vals, seg) == [mean(vals[a:b]) for a, b in zip(seg[:-1], seg[1:])]
