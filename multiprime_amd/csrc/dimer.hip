@@ -67,44 +67,6 @@ __device__ inline double dm_delta_g(uint64_t e, int l, const double *__restrict_
     return g;
 }
 
-// one ordered pair x -> y: first passing (end length, end expansion, y expansion); returns true on a hit
-__device__ inline bool dimer_pair_scan(const uint8_t *__restrict__ codes, const int32_t *__restrict__ off, int x, int y,
-                                       int mode, const uint8_t *__restrict__ loss_hit, const double *__restrict__ dg,
-                                       double dg_limit, int32_t (&rec)[4]) {
-    const int lx = off[x + 1] - off[x], ly = off[y + 1] - off[y];
-    Nib cx, cy;
-    cx.lo = cx.hi = cy.lo = cy.hi = 0;
-    for (int p = 0; p < lx; p++) cx.set(p, codes[off[x] + p]);
-    for (int p = 0; p < ly; p++) cy.set(p, codes[off[y] + p]);
-    const uint32_t dy = dm_degeneracy(cy, 0, ly);
-    int l_hi, l_lo;
-    if (mode == 0) { l_hi = lx < 18 ? lx : 18; l_lo = lx < 5 ? lx : 5; }         // FD:162-169
-    else { l_hi = lx - 1; l_lo = 5; }                                             // MS:149-154
-    for (int l = l_hi; l >= l_lo; l--) {
-        if (l <= 0 || l > ly) continue;                                           // cannot occur in a shorter primer
-        const uint32_t de = dm_degeneracy(cx, lx - l, l);
-        const uint64_t mask = l == 32 ? ~0ull : ((1ull << (2 * l)) - 1ull);
-        for (uint32_t ei = 0; ei < de; ei++) {
-            const uint64_t e = dm_expand(cx, lx - l, l, ei);
-            uint64_t rc = 0;                                                      // reverse complement: 3 - base, reversed
-            for (int t = 0; t < l; t++) rc |= (uint64_t)(3u - ((uint32_t)(e >> (2 * (l - 1 - t))) & 3u)) << (2 * t);
-            const int gc = __popcll((e ^ (e >> 1)) & 0x5555555555555555ull & mask);   // C = 01, G = 10
-            for (uint32_t pi = 0; pi < dy; pi++) {
-                const uint64_t p = dm_expand(cy, 0, ly, pi);
-                int idx = -1;
-                for (int s0 = 0; s0 + l <= ly; s0++)
-                    if (((p >> (2 * s0)) & mask) == rc) { idx = s0; break; }      // str.find: first occurrence
-                if (idx < 0) continue;
-                const int d2 = ly - l - idx;
-                bool hit = loss_hit[((size_t)l * (MP_DIMER_MAX_LEN + 1) + gc) * 64 + d2] != 0;
-                if (!hit && d2 == 0) hit = dm_delta_g(e, l, dg) < dg_limit;
-                if (hit) { rec[0] = l; rec[1] = (int32_t)ei; rec[2] = (int32_t)pi; rec[3] = idx; return true; }
-            }
-        }
-    }
-    return false;
-}
-
 // One (end length, end expansion, y expansion) combination of the ordered pair x -> y; on a hit *idx_out = where RC(end) starts.
 __device__ inline bool dimer_combo(const Nib &cx, const Nib &cy, int lx, int ly, int l, uint32_t ei, uint32_t pi,
                                    const uint8_t *__restrict__ loss_hit, int l0, const double *__restrict__ dg, double dg_limit, int &idx_out) {
@@ -227,30 +189,249 @@ __global__ __launch_bounds__(kBlock) void dimer_group_kernel(const DimerArgs A, 
     }
 }
 
-__global__ __launch_bounds__(kBlock) void dimer_kernel(const DimerArgs A) {
+// ---- one thread per pair, for lists that fill the chip (the all-pairs scans of finDimer / get_Maxprimerset at database scale) ----
+// A primer as the pair test wants it (80 bytes, written once per call by prim_kernel): its symbol codes as nibbles, the base-set
+// planes of the primer itself (y[b] bit i = base b allowed at position i) and of its reverse complement (r[b] bit i = base b
+// allowed at position i of RC(primer)), its first expansion 2 bits per base, the positions holding more than one base, length and
+// number of expansions.
+struct __align__(16) PrimRec {
+    uint32_t nib[4];
+    uint32_t y[4];
+    uint32_t r[4];
+    uint32_t base0[2];
+    uint32_t dmask;
+    int32_t len;
+    uint32_t deg;
+    uint32_t pad[3];
+};
+
+// member order of the symbols (the table dimer_init uploads), 2 bits per member, one byte per symbol code
+constexpr uint64_t member_pack(int half) {
+    const char *members[16] = {"", "A", "C", "AC", "G", "AG", "GC", "GAC", "T", "AT", "CT", "ATC", "GT", "GAT", "GTC", "ATGC"};
+    uint64_t w = 0;
+    for (int m = 0; m < 8; m++)
+        for (int t = 0; t < 4 && members[half * 8 + m][t]; t++) {
+            const char ch = members[half * 8 + m][t];
+            w |= (uint64_t)(ch == 'A' ? 0 : ch == 'C' ? 1 : ch == 'G' ? 2 : 3) << (8 * m + 2 * t);
+        }
+    return w;
+}
+constexpr uint64_t kMemLo = member_pack(0), kMemHi = member_pack(1);
+__device__ inline uint32_t member_of(uint32_t code, uint32_t r) { return (uint32_t)(((code & 8u) ? kMemHi : kMemLo) >> (8 * (code & 7u) + 2 * r)) & 3u; }
+
+__global__ __launch_bounds__(kBlock) void prim_kernel(const uint8_t *__restrict__ codes, const int32_t *__restrict__ off, int n,
+                                                      PrimRec *__restrict__ out) {
+    const int i = blockIdx.x * kBlock + threadIdx.x;
+    if (i >= n) return;
+    const int len = off[i + 1] - off[i];
+    Nib nb;
+    nb.lo = nb.hi = 0;
+    uint32_t y[4] = {0, 0, 0, 0}, r[4] = {0, 0, 0, 0}, deg = 1, dmask = 0;
+    uint64_t base0 = 0;
+    for (int p = 0; p < len; p++) {
+        const uint32_t c = codes[off[i] + p];
+        nb.set(p, c);
+        deg *= (uint32_t)__popc(c);
+        dmask |= (uint32_t)(__popc(c) > 1) << p;
+        base0 |= (uint64_t)member_of(c, 0) << (2 * p);
+#pragma unroll
+        for (int b = 0; b < 4; b++) {
+            y[b] |= ((c >> b) & 1u) << p;
+            r[b] |= ((c >> (3 - b)) & 1u) << (len - 1 - p);            // complement: A <-> T, C <-> G (bit b <-> bit 3 - b), reversed
+        }
+    }
+    PrimRec o;
+    o.nib[0] = (uint32_t)nb.lo; o.nib[1] = (uint32_t)(nb.lo >> 32); o.nib[2] = (uint32_t)nb.hi; o.nib[3] = (uint32_t)(nb.hi >> 32);
+#pragma unroll
+    for (int b = 0; b < 4; b++) { o.y[b] = y[b]; o.r[b] = r[b]; }
+    o.base0[0] = (uint32_t)base0; o.base0[1] = (uint32_t)(base0 >> 32);
+    o.dmask = dmask; o.len = len; o.deg = deg;
+    o.pad[0] = o.pad[1] = o.pad[2] = 0;
+    out[i] = o;
+}
+
+__device__ inline Nib nib_of(const PrimRec &P) {
+    Nib c;
+    c.lo = (uint64_t)P.nib[0] | ((uint64_t)P.nib[1] << 32);
+    c.hi = (uint64_t)P.nib[2] | ((uint64_t)P.nib[3] << 32);
+    return c;
+}
+
+// expansions of positions [start, start + len): only the positions holding several bases are visited
+__device__ inline uint32_t fast_degeneracy(const Nib &c, uint32_t dmask, int start, int len) {
+    uint32_t m = (dmask >> start) & (len >= 32 ? ~0u : ((1u << len) - 1u)), d = 1;
+    while (m) {
+        const int p = __ffs((int)m) - 1;
+        m &= m - 1;
+        d *= (uint32_t)__popc(c.get(start + p));
+    }
+    return d;
+}
+
+// expansion number idx of positions [start, start + len) (itertools.product order: last position fastest), 2 bits per base
+__device__ inline uint64_t fast_expand(const Nib &c, uint64_t base0, uint32_t dmask, int start, int len, uint32_t idx) {
+    uint64_t x = (base0 >> (2 * start)) & (len >= 32 ? ~0ull : ((1ull << (2 * len)) - 1ull));
+    uint32_t m = (dmask >> start) & (len >= 32 ? ~0u : ((1u << len) - 1u));
+    while (m) {
+        const int p = 31 - __clz((int)m);
+        m &= ~(1u << p);
+        const uint32_t code = c.get(start + p);
+        const uint32_t sz = (uint32_t)__popc(code);                                  // 2, 3 or 4
+        const uint32_t q = sz == 3 ? __umulhi(idx, 0xAAAAAAABu) >> 1 : idx >> (sz >> 1);
+        const uint32_t r = idx - q * sz;
+        idx = q;
+        x = (x & ~(3ull << (2 * p))) | ((uint64_t)member_of(code, r) << (2 * p));
+    }
+    return x;
+}
+
+// reverse complement of an l-base string (complement = 3 - base = ~base): bit reversal turns the 2-bit groups around and
+// swaps the two bits inside each, which one mask-shift undoes
+__device__ inline uint64_t fast_rc(uint64_t e, int l) {
+    uint64_t r = __brevll(~e);
+    r = ((r & 0x5555555555555555ull) << 1) | ((r >> 1) & 0x5555555555555555ull);
+    return r >> (64 - 2 * l);
+}
+
+struct PairEnds { int l_hi, l_lo; };
+__device__ inline PairEnds end_lengths(int lx, int mode) {
+    PairEnds e;
+    if (mode == 0) { e.l_hi = lx < 18 ? lx : 18; e.l_lo = lx < 5 ? lx : 5; }      // FD:162-169
+    else { e.l_hi = lx - 1; e.l_lo = 5; }                                         // MS:149-154
+    return e;
+}
+
+// The ordered pair x -> y.  RC(end of length l) is the first l symbols of RC(x), so "some expansion of the end occurs reverse-
+// complemented in some expansion of y at offset s" needs the base sets of RC(x)[0..l) and y[s..s+l) to intersect position by
+// position: M(s) = length of that run, from four AND-ORs of bit planes and a count of trailing ones.  No end longer than
+// max_s M(s) can match in any expansion, and an end can only sit at an offset with M(s) >= the shortest end length: the filter
+// returns max M and the candidate offsets, 0 / nothing for most pairs.
+__device__ inline int pair_filter(const PrimRec &X, const PrimRec &Y, int l_lo, uint32_t &cand) {
+    int max_m = 0;
+    uint32_t cd = 0;
+    const int ly = Y.len;
+    for (int s = 0; s + l_lo <= ly; s++) {
+        const uint32_t m = (X.r[0] & (Y.y[0] >> s)) | (X.r[1] & (Y.y[1] >> s)) | (X.r[2] & (Y.y[2] >> s)) | (X.r[3] & (Y.y[3] >> s));
+        const int run = m == 0xffffffffu ? 32 : __builtin_ctz(~m);
+        max_m = run > max_m ? run : max_m;
+        cd |= (uint32_t)(run >= l_lo) << s;
+    }
+    cand = cd;
+    return max_m;
+}
+
+// The reference's search (longest end first, expansions of the end, expansions of y; first passing combination) over the end
+// lengths the filter left, looking for RC(end) only at the candidate offsets.
+__device__ inline bool pair_search(const PrimRec &X, const PrimRec &Y, PairEnds E, int max_m, uint32_t cand,
+                                   const uint8_t *__restrict__ loss_hit, const double *__restrict__ dg, double dg_limit, int32_t (&rec)[4]) {
+    const int lx = X.len, ly = Y.len;
+    const Nib cx = nib_of(X), cy = nib_of(Y);
+    const uint64_t bx = (uint64_t)X.base0[0] | ((uint64_t)X.base0[1] << 32), by = (uint64_t)Y.base0[0] | ((uint64_t)Y.base0[1] << 32);
+    const uint32_t dy = Y.deg;
+    for (int l = E.l_hi < max_m ? E.l_hi : max_m; l >= E.l_lo; l--) {
+        if (l > ly) continue;
+        const uint64_t mask = l == 32 ? ~0ull : ((1ull << (2 * l)) - 1ull);
+        const uint32_t de = fast_degeneracy(cx, X.dmask, lx - l, l);
+        for (uint32_t ei = 0; ei < de; ei++) {
+            const uint64_t e = fast_expand(cx, bx, X.dmask, lx - l, l, ei);
+            const uint64_t rc = fast_rc(e, l);
+            for (uint32_t pi = 0; pi < dy; pi++) {
+                const uint64_t p = dy == 1 ? by : fast_expand(cy, by, Y.dmask, 0, ly, pi);
+                int idx = -1;
+                for (uint32_t cs = cand; cs; cs &= cs - 1) {                       // str.find: first occurrence
+                    const int s = __ffs((int)cs) - 1;
+                    if (s + l > ly) break;
+                    if (((p >> (2 * s)) & mask) == rc) { idx = s; break; }
+                }
+                if (idx < 0) continue;
+                const int gc = __popcll((e ^ (e >> 1)) & 0x5555555555555555ull & mask);   // C = 01, G = 10
+                const int d2 = ly - l - idx;
+                bool hit = loss_hit[((size_t)l * (MP_DIMER_MAX_LEN + 1) + gc) * 64 + d2] != 0;
+                if (!hit && d2 == 0) hit = dm_delta_g(e, l, dg) < dg_limit;
+                if (hit) { rec[0] = l; rec[1] = (int32_t)ei; rec[2] = (int32_t)pi; rec[3] = idx; return true; }
+            }
+        }
+    }
+    return false;
+}
+
+// All pairs of n primers: workgroup = one primer x (its record is wave-uniform), threads stride over the partners y the mode asks
+// for.  Every partner goes through the bit-plane filter; the few that pass are queued in LDS and searched 256 at a time, so the
+// search runs with full waves instead of one or two lanes of every wave.  Hits are collected in LDS and appended to the output
+// with ONE device atomic per flush (~n atomics on the shared counter per launch instead of one per hit).
+constexpr int kHitBuf = 1024, kQueue = 2 * kBlock;
+__global__ __launch_bounds__(kBlock) void dimer_rows_kernel(const DimerArgs A, const PrimRec *__restrict__ prim) {
+    __shared__ int32_t s_rec[kHitBuf][6];
+    __shared__ int32_t s_qy[kQueue];
+    __shared__ uint32_t s_qc[kQueue];
+    __shared__ uint8_t s_qm[kQueue];
+    __shared__ int s_n, s_q;
+    __shared__ unsigned long long s_base;
     const int x = blockIdx.x;
-    const int y = blockIdx.y * kBlock + threadIdx.x;
-    if (y >= A.n) return;
-    if (A.mode == 0 ? (y < x) : (x >= A.n_new && y >= A.n_new)) return;
-    int32_t rec[4];
-    if (dimer_pair_scan(A.codes, A.off, x, y, A.mode, A.loss_hit, A.dg, A.dg_limit, rec)) {
-        unsigned long long h = atomicAdd(A.n_hits, 1ull);
-        if ((long long)h < A.cap) {
-            int32_t *r = A.hits + 6 * h;
-            r[0] = x; r[1] = y; r[2] = rec[0]; r[3] = rec[1]; r[4] = rec[2]; r[5] = rec[3];
+    const PrimRec X = prim[x];
+    const PairEnds E = end_lengths(X.len, A.mode);
+    int y0, y1;                                                     // partners: FD:206-209 (y >= x), MS:199-204 (pairs touching a new primer)
+    if (A.mode == 0) { y0 = x; y1 = A.n; }
+    else { y0 = 0; y1 = x < A.n_new ? A.n : A.n_new; }
+    if (threadIdx.x == 0) { s_n = 0; s_q = 0; }
+    __syncthreads();
+    if (E.l_hi < E.l_lo || E.l_hi < 1) return;                      // no end length to try (mode 1, primers of <= 5 bases)
+    for (int yb = y0; yb < y1; yb += kBlock) {
+        const int y = yb + threadIdx.x;
+        const bool last = yb + kBlock >= y1;
+        if (y < y1) {
+            uint32_t cand;
+            const int max_m = pair_filter(X, prim[y], E.l_lo, cand);
+            if (max_m >= E.l_lo) {
+                const int at = atomicAdd(&s_q, 1);
+                s_qy[at] = y; s_qc[at] = cand; s_qm[at] = (uint8_t)max_m;
+            }
+        }
+        __syncthreads();
+        const int queued = s_q;
+        if (queued >= kBlock || last) {                             // (queued < 2 * kBlock: at most kBlock - 1 were left, kBlock came)
+            for (int i = threadIdx.x; i < queued; i += kBlock) {
+                const int yq = s_qy[i];
+                int32_t rec[4];
+                if (pair_search(X, prim[yq], E, s_qm[i], s_qc[i], A.loss_hit, A.dg, A.dg_limit, rec)) {
+                    const int at = atomicAdd(&s_n, 1);
+                    int32_t *r = s_rec[at];
+                    r[0] = x; r[1] = yq; r[2] = rec[0]; r[3] = rec[1]; r[4] = rec[2]; r[5] = rec[3];
+                }
+            }
+            __syncthreads();
+            if (threadIdx.x == 0) s_q = 0;
+            const int held = s_n;
+            if (held + kQueue > kHitBuf || last) {                  // the next drain might not fit, or this was the last one
+                if (held) {
+                    if (threadIdx.x == 0) s_base = atomicAdd(A.n_hits, (unsigned long long)held);
+                    __syncthreads();
+                    const unsigned long long base = s_base;
+                    for (int i = threadIdx.x; i < held * 6; i += kBlock) {
+                        const unsigned long long h = base + (unsigned long long)(i / 6);
+                        if ((long long)h < A.cap) A.hits[6 * h + i % 6] = s_rec[i / 6][i % 6];
+                    }
+                    __syncthreads();
+                    if (threadIdx.x == 0) s_n = 0;
+                }
+            }
+            __syncthreads();
         }
     }
 }
 
 // explicit ordered pairs (get_multiPrime_V8.py:419-438): one thread per pair, any passing combination
-__global__ __launch_bounds__(kBlock) void dimer_pairs_kernel(const uint8_t *__restrict__ codes, const int32_t *__restrict__ off,
-                                                             long long n_pairs, const int32_t *__restrict__ pairs,
-                                                             const uint8_t *__restrict__ loss_hit, const double *__restrict__ dg,
-                                                             double dg_limit, uint8_t *__restrict__ flags) {
+__global__ __launch_bounds__(kBlock) void dimer_pairs_kernel(const PrimRec *__restrict__ prim, long long n_pairs,
+                                                             const int32_t *__restrict__ pairs, const uint8_t *__restrict__ loss_hit,
+                                                             const double *__restrict__ dg, double dg_limit, uint8_t *__restrict__ flags) {
     const long long p = (long long)blockIdx.x * kBlock + threadIdx.x;
     if (p >= n_pairs) return;
+    const PrimRec X = prim[pairs[2 * p]], Y = prim[pairs[2 * p + 1]];
+    const PairEnds E = end_lengths(X.len, 0);
+    uint32_t cand;
+    const int max_m = pair_filter(X, Y, E.l_lo, cand);
     int32_t rec[4];
-    flags[p] = dimer_pair_scan(codes, off, pairs[2 * p], pairs[2 * p + 1], 0, loss_hit, dg, dg_limit, rec) ? 1 : 0;
+    flags[p] = max_m >= E.l_lo && pair_search(X, Y, E, max_m, cand, loss_hit, dg, dg_limit, rec) ? 1 : 0;
 }
 
 // popcount(A[i] | B[j]) per pair: one wave per pair, lanes stride over the set's words (get_multiPrime_V8.py:560-569)
@@ -548,8 +729,12 @@ int mp_dimer_scan(mp_ctx *c, int32_t n, const uint8_t *codes, const int32_t *off
     const long long all = (long long)n * n;
     const long long visited = mode == 0 ? all / 2 + n : (long long)n_new * (2LL * n - n_new);
     const int G = lanes_per_pair(visited);
-    if (G == 1) hipLaunchKernelGGL(dimer_kernel, dim3((unsigned)n, (unsigned)((n + kBlock - 1) / kBlock)), dim3(kBlock), 0, c->stream, da);
-    else {
+    PrimRec *d_prim = nullptr;                         // (function scope: Scratch frees through the variable's address)
+    if (G == 1) {
+        if ((rc = sc.alloc(&d_prim, (size_t)n))) return rc;
+        hipLaunchKernelGGL(prim_kernel, dim3((unsigned)((n + kBlock - 1) / kBlock)), dim3(kBlock), 0, c->stream, d_codes, d_off, (int)n, d_prim);
+        hipLaunchKernelGGL(dimer_rows_kernel, dim3((unsigned)n), dim3(kBlock), 0, c->stream, da, (const PrimRec *)d_prim);
+    } else {
         const unsigned blocks = (unsigned)std::min<long long>((all + kBlock / G - 1) / (kBlock / G), 256 * 16);
         if (G == 64) hipLaunchKernelGGL(dimer_group_kernel<64>, dim3(blocks), dim3(kBlock), 0, c->stream, da, all, (const int32_t *)nullptr, (uint8_t *)nullptr);
         else hipLaunchKernelGGL(dimer_group_kernel<16>, dim3(blocks), dim3(kBlock), 0, c->stream, da, all, (const int32_t *)nullptr, (uint8_t *)nullptr);
@@ -587,10 +772,13 @@ int mp_dimer_pairs(mp_ctx *c, int32_t n, const uint8_t *codes, const int32_t *of
     HIPCK(c, hipMemcpyAsync(d_off, off, sizeof(int32_t) * ((size_t)n + 1), hipMemcpyHostToDevice, c->stream));
     HIPCK(c, hipMemcpyAsync(d_pairs, pairs, sizeof(int32_t) * 2 * (size_t)n_pairs, hipMemcpyHostToDevice, c->stream));
     const int G = lanes_per_pair((long long)n_pairs);
-    if (G == 1)
-        hipLaunchKernelGGL(dimer_pairs_kernel, dim3((unsigned)((n_pairs + kBlock - 1) / kBlock)), dim3(kBlock), 0, c->stream, d_codes,
-                           d_off, (long long)n_pairs, d_pairs, c->dm_loss, c->dm_dg, dg_limit, d_flags);
-    else {
+    PrimRec *d_prim = nullptr;                         // (function scope: Scratch frees through the variable's address)
+    if (G == 1) {
+        if ((rc = sc.alloc(&d_prim, (size_t)n))) return rc;
+        hipLaunchKernelGGL(prim_kernel, dim3((unsigned)((n + kBlock - 1) / kBlock)), dim3(kBlock), 0, c->stream, d_codes, d_off, (int)n, d_prim);
+        hipLaunchKernelGGL(dimer_pairs_kernel, dim3((unsigned)((n_pairs + kBlock - 1) / kBlock)), dim3(kBlock), 0, c->stream,
+                           (const PrimRec *)d_prim, (long long)n_pairs, d_pairs, c->dm_loss, c->dm_dg, dg_limit, d_flags);
+    } else {
         DimerArgs da{d_codes, d_off, n, 0, 0, c->dm_loss, c->dm_dg, dg_limit, 0, nullptr, nullptr};
         const unsigned blocks = (unsigned)std::min<long long>((n_pairs + kBlock / G - 1) / (kBlock / G), 256 * 16);
         if (G == 64) hipLaunchKernelGGL(dimer_group_kernel<64>, dim3(blocks), dim3(kBlock), 0, c->stream, da, (long long)n_pairs, (const int32_t *)d_pairs, d_flags);

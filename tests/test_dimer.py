@@ -134,7 +134,7 @@ def test_dimer_scan_hip_equals_oracle(hip_lib, oracle_lib, seed, n, p_deg, mode)
 @pytest.mark.gpu
 @pytest.mark.parametrize("lanes", ["1", "16", "64"])
 def test_dimer_kernels_agree_for_every_lane_width(hip_lib, oracle_lib, lanes, monkeypatch):
-    """thread-per-pair (dimer_kernel) and sub-wave-per-pair (dimer_group_kernel<16|64>, tables in LDS) against the oracle on the
+    """thread-per-pair (dimer_rows_kernel / dimer_pairs_kernel: bit-plane run filter first) and sub-wave-per-pair (dimer_group_kernel<16|64>, tables in LDS) against the oracle on the
     same degenerate primers, both scan modes and an explicit pair list — incl. primers shorter than 5 and 32-mers, which take
     the un-staged table."""
     monkeypatch.setenv("MP_DIMER_LANES", lanes)
@@ -149,3 +149,19 @@ def test_dimer_kernels_agree_for_every_lane_width(hip_lib, oracle_lib, lanes, mo
     args = (codes, off, pairs, dimer.cached_loss_table(3.6), dimer.dg_params(), dimer.dg_limit())
     got, want = hc.dimer_pairs(*args), oc.dimer_pairs(*args)
     assert want.any() and got.tolist() == want.tolist()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("mode", [0, 1])
+def test_dimer_rows_with_more_hits_than_the_lds_buffer(hip_lib, oracle_lib, mode, monkeypatch):
+    """Rows holding thousands of hits (copies of primers that pair with each other) flush the workgroup's LDS hit list several
+    times; a capacity below the number of hits reports the full count and fills what fits."""
+    monkeypatch.setenv("MP_DIMER_LANES", "1")
+    a, b = "ACGTTGCAAGGCTTAACCGGAT", "TTGACCATGGATCCGGTTAAGC"
+    rc_a = a[::-1].translate(str.maketrans("ACGT", "TGCA"))
+    seqs = [a, b, rc_a] * 500 + random_primers(9, 100, 0.1)
+    codes, off = dimer.encode_primers(seqs)
+    args = (codes, off, mode, 700, dimer.cached_loss_table(3.0 if mode else 3.96), dimer.dg_params(), dimer.dg_limit())
+    o = oracle_lib.context(0).dimer_scan(*args, cap=1 << 21)
+    h = hip_lib.context(0).dimer_scan(*args)                     # default capacity 65536: overflows, reports the count, is re-run
+    assert len(o) > 70000 and h.tolist() == o.tolist()
