@@ -43,6 +43,10 @@ int mp_fasta_sizes(const mp_fasta *f, int32_t *n_rows, int64_t *n_residue_bytes,
 int mp_fasta_rows(const mp_fasta *f, uint8_t *data, int64_t *row_off);
 /* ids back to back, id r = ids[id_off[r] .. id_off[r+1]) (raw bytes of the file) */
 int mp_fasta_ids(const mp_fasta *f, uint8_t *ids, int64_t *id_off);
+/* Newlines of a file as Python's text mode counts them (\n, \r\n as one, a lone \r), on n_threads threads (0 = as many as pay
+ * off) — get_multiPrime / get_degePrimer take "newlines / 2" of the whole input as the number of sequences
+ * (get_multiPrime_V8.py:348-357, get_degePrimer_V6.py:260-271): a full pass over files of a gigabyte and more. */
+int mp_file_count_newlines(const char *path, int32_t n_threads, int64_t *count);
 
 /* ------------------------------------------------------------------------------------------------------------
  * (H2) per-window planning

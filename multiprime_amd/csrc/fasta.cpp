@@ -283,6 +283,65 @@ int mp_fasta_parse_file(const char *path, int32_t n_threads, mp_fasta **out) {
     return parse(f);
 }
 
+int mp_file_count_newlines(const char *path, int32_t n_threads, int64_t *count) {
+    if (!path || !count) return MP_ERR_ARG;
+    *count = 0;
+    int fd = open(path, O_RDONLY);
+    if (fd < 0) return MP_ERR_ARG;
+    struct stat st;
+    if (fstat(fd, &st) != 0) { close(fd); return MP_ERR_ARG; }
+    // newlines of Python's text mode: \n, \r\n (one) and a lone \r
+    auto tally = [](const uint8_t *b, int64_t m, bool more, uint8_t next) {      // [0, m) counted; b[m] = next when `more`
+        int64_t c = std::count(b, b + m, (uint8_t)'\n');
+        const uint8_t *p = b, *e = b + m;
+        while ((p = (const uint8_t *)memchr(p, '\r', (size_t)(e - p)))) {
+            const bool last = p + 1 == e;
+            if (last ? !(more && next == '\n') : p[1] != '\n') c++;
+            p++;
+        }
+        return c;
+    };
+    if (!S_ISREG(st.st_mode)) {                                  // a pipe / device: read to the end, one pass
+        std::vector<uint8_t> all;
+        uint8_t tmp[1 << 16];
+        ssize_t got;
+        while ((got = read(fd, tmp, sizeof tmp)) > 0) all.insert(all.end(), tmp, tmp + got);
+        close(fd);
+        *count = tally(all.data(), (int64_t)all.size(), false, 0);
+        return MP_OK;
+    }
+    const int64_t n = (int64_t)st.st_size;
+    const int T = threads_for(n_threads, n);
+    std::vector<int64_t> part((size_t)T, 0);
+    std::vector<int> bad((size_t)T, 0);
+    auto run = [&](int t) {
+        std::vector<uint8_t> tmp((4 << 20) + 1);
+        int64_t a = n * t / T;
+        const int64_t z = n * (t + 1) / T;
+        while (a < z) {
+            const int64_t m = std::min<int64_t>(4 << 20, z - a), want = std::min<int64_t>(m + 1, n - a);   // one byte of lookahead
+            int64_t have = 0;
+            while (have < want) {
+                ssize_t got = pread(fd, tmp.data() + have, (size_t)(want - have), (off_t)(a + have));
+                if (got <= 0) { bad[(size_t)t] = 1; return; }
+                have += got;
+            }
+            part[(size_t)t] += tally(tmp.data(), m, want > m, want > m ? tmp[(size_t)m] : 0);
+            a += m;
+        }
+    };
+    if (T == 1) run(0);
+    else {
+        std::vector<std::thread> th;
+        for (int t = 0; t < T; t++) th.emplace_back(run, t);
+        for (auto &x : th) x.join();
+    }
+    close(fd);
+    for (int x : bad) if (x) return MP_ERR_ARG;
+    for (int64_t c : part) *count += c;
+    return MP_OK;
+}
+
 int mp_fasta_sizes(const mp_fasta *f, int32_t *n_rows, int64_t *n_residue_bytes, int64_t *n_id_bytes) {
     if (!f) return MP_ERR_ARG;
     if (n_rows) *n_rows = (int32_t)f->id_off_src.size();

@@ -21,7 +21,7 @@ import time
 from bisect import bisect_left
 from optparse import OptionParser
 
-from . import iupac
+from . import host, iupac
 from .pairing import Primers_filter as _GM
 
 
@@ -57,8 +57,7 @@ class Primers_filter(object):
 
     def get_number(self):
         """GD:260-271: number of records of the reference FASTA = newlines / 2, capped at -m."""
-        with open(self.Input_file, encoding="utf-8") as f:
-            seq_number = int(f.read().count("\n") / 2)
+        seq_number = int(host.count_newlines(self.Input_file) / 2)
         if seq_number > self.rep_seq_number != 0:
             print(seq_number, self.rep_seq_number)
             return self.rep_seq_number

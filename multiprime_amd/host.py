@@ -30,6 +30,7 @@ HOST_SYMBOLS = [
     ("mp_fasta_sizes", C.c_int, [_p, C.POINTER(C.c_int32), C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),
     ("mp_fasta_rows", C.c_int, [_p, _p, _p]),
     ("mp_fasta_ids", C.c_int, [_p, _p, _p]),
+    ("mp_file_count_newlines", C.c_int, [C.c_char_p, C.c_int32, C.POINTER(C.c_int64)]),
     ("mp_plan_create", C.c_int, [C.POINTER(PlanParams), C.c_int64, _p, _p, _p, _p, C.c_int64, _p, _p, _p, _p, _p, C.POINTER(_p)]),
     ("mp_plan_destroy", None, [_p]),
     ("mp_plan_error", C.c_char_p, [_p]),
@@ -134,6 +135,15 @@ class Fasta:
             self.close()
         except Exception:
             pass
+
+
+def count_newlines(path, n_threads: int = 0) -> int:
+    """str.count("\\n") of the file read in text mode (\\n, \\r\\n, lone \\r), counted natively on several threads."""
+    n = C.c_int64(0)
+    rc = dll().mp_file_count_newlines(os.fsencode(path), n_threads, C.byref(n))
+    if rc != 0:
+        raise OSError(f"cannot read {path}")
+    return n.value
 
 
 def expand_kmers(codes: np.ndarray):

@@ -23,7 +23,7 @@ from statistics import mean
 
 import numpy as np
 
-from . import iupac, thermo
+from . import host, iupac, thermo
 from ._abi import Library
 from .dimer import MAX_LEN, dg_limit, encode_primers
 from .filters import _REPEATS
@@ -92,13 +92,7 @@ class Primers_filter(object):
     # ---- input ---------------------------------------------------------------------------------
     def get_number(self):
         """GM:348-357: number of sequences = newlines / 2, capped by --maxseq when that is not 0."""
-        newlines = 0
-        with open(self.Input_file, "rb") as f:                    # same count as the reference's text-mode read, without decoding 1 GB
-            while True:
-                buf = f.read(1 << 24)
-                if not buf:
-                    break
-                newlines += buf.count(b"\n")
+        newlines = host.count_newlines(self.Input_file)            # the count of the reference's whole-file text read, on several threads
         seq_number = int(newlines / 2)
         if seq_number > self.rep_seq_number != 0:
             return self.rep_seq_number

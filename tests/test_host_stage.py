@@ -249,3 +249,24 @@ def test_native_stage_equals_python_restatement_on_random_alignments(seed, oracl
         b = (tmp_path / ("python.out" + suffix)).read_bytes()
         assert a == b, f"native host stage differs from the Python restatement in out{suffix}"
     assert len((tmp_path / "native.out").read_bytes().splitlines()) >= 1
+
+
+def test_newline_count_equals_text_mode_read(tmp_path, monkeypatch):
+    """mp_file_count_newlines against open(path).read().count("\\n") — \\n, \\r\\n, lone \\r, pairs split across thread chunks
+    and 4 MB blocks, a trailing \\r, an empty file."""
+    import random
+    rng = random.Random(3)
+    cases = [b"", b"\r", b"\n", b"\r\n", b"a\rb\r\nc\n\r", b"\r\r\n\n\r"]
+    cases.append(b"".join(rng.choice([b"ACGT", b"\n", b"\r\n", b"\r", b">id x"]) for _ in range(20000)))
+    big = bytearray(b"A" * ((4 << 20) + 10))
+    big[(4 << 20) - 1:(4 << 20) + 1] = b"\r\n"                       # \r\n across a block boundary
+    big[100:101] = b"\r"
+    cases.append(bytes(big))
+    for threads in ("1", "3", "7"):
+        monkeypatch.setenv("MP_HOST_THREADS", threads)
+        for i, raw in enumerate(cases):
+            p = tmp_path / f"c{i}.txt"
+            p.write_bytes(raw)
+            with open(p, encoding="latin-1") as f:
+                want = f.read().count("\n")
+            assert host.count_newlines(str(p)) == want, (threads, i)
