@@ -79,6 +79,12 @@ int mp_load_msa(mp_ctx *ctx, const uint8_t *bytes, const int64_t *row_off, int32
  * rstrip_len[r] = len(rstrip('-')), row_len[r] = len.  Any pointer may be NULL. */
 int mp_row_attributes(mp_ctx *ctx, int32_t *lead_gap, int32_t *rstrip_len, int32_t *row_len);
 
+/* The same two quantities as histograms: lead_hist[x] = rows whose leading-gap length is x, rstrip_hist[x] = rows whose
+ * right-stripped length is x, 0 <= x < n_bins (n_bins > the longest row, else MP_ERR_CAPACITY).  seq_attribute only takes one
+ * order statistic of each (np.quantile, "higher" / "lower", V20:628-633), which a cumulative sum of the histogram gives
+ * exactly — 8 x n_bins bytes leave the device instead of two values per row, and row shards add their histograms. */
+int mp_row_histograms(mp_ctx *ctx, int32_t n_bins, int64_t *lead_hist, int64_t *rstrip_hist);
+
 /* (2) window k-mers ------------------------------------------------------------------------ */
 /* Replaces the slice + edge-gap repair of get_primers (V20:666-687) for every
  * (window p0+w, row), w in [0,n_windows): the k-mer of row r at window w is stored as window

@@ -31,6 +31,7 @@ SYMBOLS = [
     ("mp_reserve_columns", C.c_int, [_p, C.c_int32]),
     ("mp_load_msa", C.c_int, [_p, _p, _p, C.c_int32]),
     ("mp_row_attributes", C.c_int, [_p, _p, _p, _p]),
+    ("mp_row_histograms", C.c_int, [_p, C.c_int32, _p, _p]),
     ("mp_build_windows", C.c_int, [_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.POINTER(C.c_int32)]),
     ("mp_get_exceptions", C.c_int, [_p, C.c_int32, _p, _p, _p]),
     ("mp_set_extra_rows", C.c_int, [_p, C.c_int32, _p, _p]),
@@ -139,6 +140,13 @@ class Context:
         rlen = np.empty(self.n_rows, np.int32)
         self._ck(self.d.mp_row_attributes(self.h, _ptr(lead), _ptr(rstrip), _ptr(rlen)))
         return lead, rstrip, rlen
+
+    def row_histograms(self, n_bins: int):
+        """(lead_hist, rstrip_hist) int64 [n_bins]: rows per leading-gap length / per right-stripped length."""
+        lead = np.empty(n_bins, np.int64)
+        rstrip = np.empty(n_bins, np.int64)
+        self._ck(self.d.mp_row_histograms(self.h, n_bins, _ptr(lead), _ptr(rstrip)))
+        return lead, rstrip
 
     # (2)
     def build_windows(self, p0: int, n_windows: int, k: int, v: int) -> int:

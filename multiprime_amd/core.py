@@ -111,14 +111,18 @@ class NN_degenerate(object):
             raise ValueError("no sequence records in " + str(seq_file))
         data, row_off = fa.rows()
         self.stats["parse_s"] = time.time() - t0
+        t0 = time.time()
+        width = int(np.diff(row_off).max())                           # longest record (of ALL rows)
         if comm is not None:
-            self.ctx.reserve_columns(int(np.diff(row_off).max()))      # windows span the whole alignment, not this shard's rows
+            self.ctx.reserve_columns(width)                            # windows span the whole alignment, not this shard's rows
             data, row_off = comm.take_shard(data, row_off)
         self.ctx.load_msa(data, row_off)
-        lead, rstrip, _ = self.ctx.row_attributes()
+        # seq_attribute (V20:617-640) takes one order statistic of the rows' leading-gap lengths and one of their right-stripped
+        # lengths: histograms of both leave the device (8 KB instead of 8 bytes per row), shards add theirs
+        lead_h, rstrip_h = self.ctx.row_histograms(width + 1)
         if comm is not None:
-            lead, rstrip = comm.gather_rows(lead), comm.gather_rows(rstrip)
-        start, stop = msa.region(lead, rstrip, self.coverage)
+            lead_h, rstrip_h = comm.sum_int64(lead_h), comm.sum_int64(rstrip_h)
+        start, stop = msa.region_from_histograms(lead_h, rstrip_h, self.coverage)
         if stop - start < int(self.product):     # V20:635-638
             print("Error: max length of PCR product is shorter than the default min Product length with {} "
                   "coverage! Non candidate primers !!!".format(self.coverage))

@@ -8,10 +8,12 @@
 #include "../../include/mprime_host.h"
 
 #include <fcntl.h>
+#include <sys/mman.h>
 #include <sys/stat.h>
 #include <unistd.h>
 
 #include <algorithm>
+#include <chrono>
 #include <cerrno>
 #include <cstdarg>
 #include <cstdio>
@@ -50,7 +52,8 @@ inline uint64_t hash_bytes(const uint8_t *p, size_t n) {
 
 struct mp_fasta {
     char err[512] = {0};
-    uint8_t *own = nullptr;           // file contents when parsed from a path
+    uint8_t *own = nullptr;           // file contents when parsed from a path (big_alloc)
+    size_t own_bytes = 0;
     const uint8_t *buf = nullptr;
     int64_t n = 0;
     int n_threads = 1;
@@ -60,10 +63,24 @@ struct mp_fasta {
     std::vector<int64_t> row_seg;     // [n_rows+1] segment range of each row
     std::vector<int64_t> row_off;     // [n_rows+1] residue offsets
     int64_t id_bytes = 0;
-    ~mp_fasta() { free(own); }
+    ~mp_fasta();
 };
 
 namespace {
+
+// Buffers of file size: anonymous mappings advised to use huge pages — first touch of a gigabyte costs ~500 page faults instead
+// of ~260 000 (the parallel pread()s of a large file spend most of their time in those faults otherwise).
+uint8_t *big_alloc(size_t n, size_t *mapped, bool want_huge) {
+    const size_t huge = (size_t)2 << 20;
+    const size_t len = (n + huge) / huge * huge;
+    void *p = mmap(nullptr, len, PROT_READ | PROT_WRITE, MAP_PRIVATE | MAP_ANONYMOUS, -1, 0);
+    if (p == MAP_FAILED) return nullptr;
+#ifdef MADV_HUGEPAGE
+    if (want_huge && len >= 2 * huge) (void)madvise(p, len, MADV_HUGEPAGE);
+#endif
+    *mapped = len;
+    return (uint8_t *)p;
+}
 
 int ffail(mp_fasta *f, int code, const char *fmt, ...) {
     va_list ap;
@@ -72,6 +89,18 @@ int ffail(mp_fasta *f, int code, const char *fmt, ...) {
     va_end(ap);
     return code;
 }
+
+// MP_HOST_TRACE=1: stage times of the parser on stderr
+struct Trace {
+    bool on = getenv("MP_HOST_TRACE") != nullptr;
+    std::chrono::steady_clock::time_point t = std::chrono::steady_clock::now();
+    void lap(const char *what) {
+        if (!on) return;
+        auto now = std::chrono::steady_clock::now();
+        fprintf(stderr, "[mprime host] %-12s %8.3f ms\n", what, std::chrono::duration<double, std::milli>(now - t).count());
+        t = now;
+    }
+};
 
 int threads_for(int asked, int64_t bytes) {
     if (const char *e = getenv("MP_HOST_THREADS")) return std::max(1, atoi(e));     // exact (tests cut tiny inputs into chunks)
@@ -138,12 +167,14 @@ int parse(mp_fasta *f) {
     for (int t = 0; t <= T; t++) cut[(size_t)t] = line_start_at_or_after(b, n, n * t / T);
     cut[(size_t)T] = n;
     std::vector<std::vector<Event>> ev((size_t)T);
+    Trace tr;
     if (T == 1) scan_chunk(b, n, 0, n, ev[0]);
     else {
         std::vector<std::thread> th;
         for (int t = 0; t < T; t++) th.emplace_back([&, t]() { scan_chunk(b, n, cut[(size_t)t], cut[(size_t)t + 1], ev[(size_t)t]); });
         for (auto &x : th) x.join();
     }
+    tr.lap("scan");
     // serial join: ids in first-appearance order, a repeated id continues its first record
     size_t n_ev = 0;
     for (auto &e : ev) n_ev += e.size();
@@ -160,7 +191,12 @@ int parse(mp_fasta *f) {
     bool have_header = false, resolved = false;
     Event pending{};
     for (auto &chunk : ev) {
-        for (const Event &e : chunk) {
+        const size_t n_chunk = chunk.size();
+        for (size_t ei = 0; ei < n_chunk; ei++) {
+            const Event &e = chunk[ei];
+            // the table slot of a header a few lines ahead is fetched while this line is handled (the probe is the one random
+            // memory access of the loop)
+            if (ei + 8 < n_chunk && chunk[ei + 8].header) __builtin_prefetch(&table[(size_t)chunk[ei + 8].hash & mask]);
             if (e.header) { pending = e; have_header = true; resolved = false; continue; }
             if (!have_header) return ffail(f, MP_ERR_ARG, "sequence data before the first '>' header");
             if (!resolved) {
@@ -186,6 +222,7 @@ int parse(mp_fasta *f) {
         }
         std::vector<Event>().swap(chunk);
     }
+    tr.lap("join");
     const size_t R = f->id_off_src.size();
     // group the segments by row (stable: file order inside a row); already grouped when no id repeats out of order
     f->row_seg.assign(R + 1, 0);
@@ -207,11 +244,16 @@ int parse(mp_fasta *f) {
         f->row_off[r + 1] = f->row_off[r] + len;
         f->id_bytes += f->id_len[r];
     }
+    tr.lap("group");
     if (R > 0x7fffffffULL - 1) return ffail(f, MP_ERR_ARG, "too many records");
     return MP_OK;
 }
 
 }  // namespace
+
+mp_fasta::~mp_fasta() {
+    if (own) munmap(own, own_bytes);
+}
 
 extern "C" {
 
@@ -225,7 +267,7 @@ int mp_fasta_parse_buffer(const uint8_t *bytes, int64_t n_bytes, int32_t n_threa
     mp_fasta *f = new (std::nothrow) mp_fasta();
     if (!f) return MP_ERR_NOMEM;
     *out = f;
-    f->own = (uint8_t *)malloc((size_t)n_bytes + 1);
+    f->own = big_alloc((size_t)n_bytes + 1, &f->own_bytes, false);
     if (!f->own) return ffail(f, MP_ERR_NOMEM, "out of memory (%lld bytes)", (long long)n_bytes);
     if (n_bytes) memcpy(f->own, bytes, (size_t)n_bytes);
     f->buf = f->own;
@@ -254,9 +296,27 @@ int mp_fasta_parse_file(const char *path, int32_t n_threads, mp_fasta **out) {
         while ((got = read(fd, tmp, sizeof tmp)) > 0) piped.insert(piped.end(), tmp, tmp + got);
         n = (int64_t)piped.size();
     }
-    f->own = (uint8_t *)malloc((size_t)n + 1);
+    // A regular file is mapped read-only: no copy and no fresh pages to fault in — the scan threads are the first to touch the
+    // page cache (the file must not shrink while the handle lives).  MP_HOST_READ=pread reads it into private memory instead,
+    // =huge into huge-page memory.
+    const char *mode = getenv("MP_HOST_READ");
+    const bool want_map = (!mode || !strcmp(mode, "mmap")) && S_ISREG(st.st_mode) && n > 0;
+    if (want_map) {
+        void *m = mmap(nullptr, (size_t)n, PROT_READ, MAP_PRIVATE, fd, 0);
+        if (m != MAP_FAILED) {
+            close(fd);
+            f->own = (uint8_t *)m;
+            f->own_bytes = (size_t)n;
+            f->n_threads = threads_for(n_threads, n);
+            f->buf = f->own;
+            f->n = n;
+            return parse(f);
+        }
+    }
+    f->own = big_alloc((size_t)n + 1, &f->own_bytes, mode && !strcmp(mode, "huge"));
     if (!f->own) { close(fd); return ffail(f, MP_ERR_NOMEM, "out of memory (%lld bytes)", (long long)n); }
     f->n_threads = threads_for(n_threads, n);
+    Trace tr;
     if (!piped.empty()) memcpy(f->own, piped.data(), (size_t)n);
     else if (S_ISREG(st.st_mode) && n) {
         const int T = f->n_threads;
@@ -278,6 +338,7 @@ int mp_fasta_parse_file(const char *path, int32_t n_threads, mp_fasta **out) {
         for (int x : bad) if (x) { close(fd); return ffail(f, MP_ERR_ARG, "%s: short read", path); }
     }
     close(fd);
+    tr.lap("read");
     f->buf = f->own;
     f->n = n;
     return parse(f);

@@ -123,6 +123,29 @@ __global__ __launch_bounds__(kBlock) void colplane_kernel(const uint32_t *__rest
 }
 
 
+
+// histograms of two per-row integers: equal values inside a wave are added once (most rows share the value 0 / the alignment
+// width, and a device atomic per row on one address would serialise the launch)
+__global__ __launch_bounds__(kBlock) void row_hist_kernel(const int32_t *__restrict__ lead, const int32_t *__restrict__ rstrip, int n_rows,
+                                                          int n_bins, unsigned long long *__restrict__ hist, int *__restrict__ overflow) {
+    const int r = blockIdx.x * kBlock + threadIdx.x;
+    const bool active = r < n_rows;
+    const int lane = threadIdx.x & 63;
+    for (int which = 0; which < 2; which++) {
+        const int v = active ? (which ? rstrip[r] : lead[r]) : -1;
+        unsigned long long todo = __ballot(active);
+        while (todo) {
+            const int first = __ffsll((long long)todo) - 1;
+            const int v0 = __shfl(v, first);
+            const unsigned long long same = __ballot(active && v == v0);
+            if (lane == first) {
+                if (v0 >= 0 && v0 < n_bins) atomicAdd(&hist[(size_t)which * n_bins + v0], (unsigned long long)__popcll(same));
+                else atomicExch(overflow, 1);
+            }
+            todo &= ~same;
+        }
+    }
+}
 }  // namespace
 
 namespace mp {
@@ -203,5 +226,34 @@ int mp_row_attributes(mp_ctx *c, int32_t *lead, int32_t *rstrip, int32_t *rowlen
     return MP_OK;
 }
 
+int mp_row_histograms(mp_ctx *c, int32_t n_bins, int64_t *lead_hist, int64_t *rstrip_hist) {
+    if (!c) return MP_ERR_ARG;
+    if (!c->planes) return fail(c, MP_ERR_ARG, "no alignment loaded");
+    if (n_bins <= 0 || !lead_hist || !rstrip_hist) return fail(c, MP_ERR_ARG, "mp_row_histograms: bad arguments");
+    HIPCK(c, hipSetDevice(c->dev));
+    unsigned long long *d_hist = nullptr;
+    int *d_over = nullptr;
+    int rc;
+    if ((rc = dev_alloc(c, &d_hist, (size_t)2 * n_bins))) return rc;
+    if ((rc = dev_alloc(c, &d_over, 1))) { dev_free(c, &d_hist, (size_t)2 * n_bins); return rc; }
+    std::vector<unsigned long long> h((size_t)2 * n_bins);
+    int over = 0;
+    hipError_t e = hipMemsetAsync(d_hist, 0, sizeof(unsigned long long) * 2 * (size_t)n_bins, c->stream);
+    if (e == hipSuccess) e = hipMemsetAsync(d_over, 0, sizeof(int), c->stream);
+    if (e == hipSuccess) {
+        hipLaunchKernelGGL(row_hist_kernel, dim3((unsigned)(c->n_pad / kBlock)), dim3(kBlock), 0, c->stream, (const int32_t *)c->lead,
+                           (const int32_t *)c->rstrip, c->n_rows, (int)n_bins, d_hist, d_over);
+        e = hipGetLastError();
+    }
+    if (e == hipSuccess) e = hipMemcpyAsync(h.data(), d_hist, sizeof(unsigned long long) * h.size(), hipMemcpyDeviceToHost, c->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(&over, d_over, sizeof(int), hipMemcpyDeviceToHost, c->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+    dev_free(c, &d_hist, (size_t)2 * n_bins);
+    dev_free(c, &d_over, 1);
+    if (e != hipSuccess) return fail(c, MP_ERR_DEVICE, "mp_row_histograms: %s", hipGetErrorString(e));
+    if (over) return fail(c, MP_ERR_CAPACITY, "mp_row_histograms: a row is longer than %d", n_bins - 1);
+    for (int i = 0; i < n_bins; i++) { lead_hist[i] = (int64_t)h[(size_t)i]; rstrip_hist[i] = (int64_t)h[(size_t)n_bins + i]; }
+    return MP_OK;
+}
 
 }  // extern "C"

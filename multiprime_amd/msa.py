@@ -38,6 +38,19 @@ def region(lead_gap: np.ndarray, rstrip_len: np.ndarray, coverage: float):
     return start, stop
 
 
+def region_from_histograms(lead_hist: np.ndarray, rstrip_hist: np.ndarray, coverage: float):
+    """The same two order statistics from histograms of the two per-row quantities (mp_row_histograms): np.quantile's
+    "higher" / "lower" take sorted[ceil((n - 1) q)] / sorted[floor((n - 1) q)], and sorted[i] is the first value whose
+    cumulative count exceeds i."""
+    n = int(lead_hist.sum())
+    q = np.float64(coverage)
+    hi = int(np.ceil((n - 1) * q))
+    lo = int(np.floor((n - 1) * q))
+    start = np.int64(np.searchsorted(np.cumsum(lead_hist), hi, side="right"))
+    stop = np.int64(np.searchsorted(np.cumsum(rstrip_hist), lo, side="right"))
+    return start, stop
+
+
 def strict_sets(position: str, k: int):
     """get_Y (V20:1091-1101)."""
     f, r = set(), set()

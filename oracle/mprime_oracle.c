@@ -145,6 +145,24 @@ int mp_row_attributes(mp_ctx *c, int32_t *lead, int32_t *rstrip, int32_t *rowlen
     return MP_OK;
 }
 
+/* the same as histograms (np.quantile of seq_attribute takes one order statistic of each, V20:628-633) */
+int mp_row_histograms(mp_ctx *c, int32_t n_bins, int64_t *lead_hist, int64_t *rstrip_hist) {
+    if (!c || !c->rows) return c ? fail(c, MP_ERR_ARG, "no alignment loaded") : MP_ERR_ARG;
+    if (n_bins <= 0 || !lead_hist || !rstrip_hist) return fail(c, MP_ERR_ARG, "mp_row_histograms: bad arguments");
+    memset(lead_hist, 0, sizeof(int64_t) * (size_t)n_bins);
+    memset(rstrip_hist, 0, sizeof(int64_t) * (size_t)n_bins);
+    for (int32_t r = 0; r < c->n_rows; r++) {
+        const char *s = c->rows[r];
+        int32_t n = c->len[r], a = 0, b = n;
+        while (a < n && s[a] == '-') a++;            /* len - len(lstrip("-")) */
+        while (b > 0 && s[b - 1] == '-') b--;        /* len(rstrip("-")) */
+        if (a >= n_bins || b >= n_bins) return fail(c, MP_ERR_CAPACITY, "mp_row_histograms: a row is longer than %d", n_bins - 1);
+        lead_hist[a]++;
+        rstrip_hist[b]++;
+    }
+    return MP_OK;
+}
+
 /* ungapped characters of s[a:b) into dst, returns their number (V20:674 / :680 .replace("-", "")) */
 static int32_t ungapped(const char *s, int32_t a, int32_t b, char *dst) {
     int32_t n = 0;

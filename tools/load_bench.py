@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
-"""Times the way an alignment reaches the device: native FASTA parse, the joined copy + mp_load_msa, and mp_load_msa_segments
-(gather into page-locked staging, pipelined copies) — cold and warm, on a synthetic rows x cols FASTA file.  One JSON line."""
+"""Times the way an alignment reaches the device: library / context start-up, native FASTA parse (MP_HOST_TRACE=1 prints its
+stages), the joined copy, mp_load_msa cold and warm, and the two ways to the primer region (per-row arrays + np.quantile,
+device histograms) on a synthetic rows x cols FASTA file.  One JSON line."""
 import argparse
 import json
 import os
@@ -37,9 +38,8 @@ with tempfile.TemporaryDirectory() as td:
     data, off = timed("rows_copy_s", fa.rows)
     timed("load_msa_cold_s", lambda: ctx.load_msa(data, off))
     timed("load_msa_warm_s", lambda: ctx.load_msa(data, off))
-    timed("load_segments_cold_s", lambda: ctx.load_fasta(fa))
-    timed("load_segments_warm_s", lambda: ctx.load_fasta(fa))
-    timed("load_segments_warm2_s", lambda: ctx.load_fasta(fa))
     lead, rstrip, _ = timed("row_attributes_s", ctx.row_attributes)
-    timed("region_s", lambda: msa.region(lead, rstrip, 0.8))
+    timed("region_quantiles_s", lambda: msa.region(lead, rstrip, 0.8))
+    lh, rh = timed("row_histograms_s", lambda: ctx.row_histograms(a.cols + 1))
+    timed("region_from_histograms_s", lambda: msa.region_from_histograms(lh, rh, 0.8))
 print(json.dumps(res))
