@@ -26,6 +26,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <numeric>
+#include <chrono>
 #include <vector>
 
 namespace mp {
@@ -68,6 +69,21 @@ struct Nib {          // up to 32 symbol codes, one nibble each
 // ================================================================================================
 // the opaque context
 // ================================================================================================
+// MP_TRACE=1: host-side stage times of the library calls on stderr (each lap waits for the stream first)
+struct Lap {
+    bool on = getenv("MP_TRACE") != nullptr;
+    hipStream_t st;
+    std::chrono::steady_clock::time_point t = std::chrono::steady_clock::now();
+    explicit Lap(hipStream_t s) : st(s) {}
+    void operator()(const char *what) {
+        if (!on) return;
+        (void)hipStreamSynchronize(st);
+        auto now = std::chrono::steady_clock::now();
+        fprintf(stderr, "[mprime] %-28s %8.3f ms\n", what, std::chrono::duration<double, std::milli>(now - t).count());
+        t = now;
+    }
+};
+
 struct mp_ctx {
     char err[512] = {0};
     int dev = 0;
@@ -178,7 +194,6 @@ void dev_free(mp_ctx *c, T **p, size_t n) {
         *p = nullptr;
     }
 }
-
 
 // release the device arrays of one stage (and of every stage that depends on it); api.hip
 void free_eval(mp_ctx *c);

@@ -184,7 +184,9 @@ int mp_build_windows(mp_ctx *c, int32_t p0, int32_t n_win, int32_t k, int32_t v,
         return fail(c, MP_ERR_ARG, "bad window arguments (k=%d v=%d n_windows=%d)", k, v, n_win);
     if (p0 + n_win > c->max_len) return fail(c, MP_ERR_ARG, "windows run past the longest row");
     HIPCK(c, hipSetDevice(c->dev));
+    Lap lap(c->stream);
     free_windows(c);
+    lap("build_windows: free");
     c->p0 = p0; c->n_win = n_win; c->k = k; c->v = v;
     size_t np = (size_t)c->n_pad;
     int rc;
@@ -205,13 +207,16 @@ int mp_build_windows(mp_ctx *c, int32_t p0, int32_t n_win, int32_t k, int32_t v,
     HIPCK(c, hipMemsetAsync(c->err_flag, 0, 4 * sizeof(int), c->stream));
     HIPCK(c, hipMemsetAsync(c->excl, 0, sizeof(unsigned long long) * (size_t)n_win * nw, c->stream));
     HIPCK(c, hipMemsetAsync(c->patch_count, 0, sizeof(int32_t) * (size_t)n_win * kCtrStride, c->stream));
+    lap("build_windows: alloc+memset");
     hipLaunchKernelGGL(classify_kernel, grid, dim3(kClsBlock), 0, c->stream, M, p0, n_win, k, v,
                        PatchOut{0, c->excl, c->patch_count, nullptr, nullptr, nullptr, nullptr});
     HIPCK(c, hipGetLastError());
+    lap("build_windows: classify");
     // slow pairs per window -> offsets on the host, then the listing pass and the repair
     std::vector<int32_t> pc((size_t)n_win), po((size_t)n_win + 1, 0), padded((size_t)n_win * kCtrStride);
     HIPCK(c, hipMemcpyAsync(padded.data(), c->patch_count, sizeof(int32_t) * padded.size(), hipMemcpyDeviceToHost, c->stream));
     HIPCK(c, hipStreamSynchronize(c->stream));
+    lap("build_windows: counts d2h");
     for (int w = 0; w < n_win; w++) pc[(size_t)w] = padded[(size_t)w * kCtrStride];
     long long tot = 0;
     c->max_patch = 0;
@@ -229,6 +234,7 @@ int mp_build_windows(mp_ctx *c, int32_t p0, int32_t n_win, int32_t k, int32_t v,
     c->pp_dirty = true;
     c->ex_host.clear();
     if (n_exc) *n_exc = 0;
+    lap("build_windows: counts+offsets");
     if (tot) {
         int32_t *d_wins = nullptr;
         if ((rc = dev_alloc(c, &c->patch_words, (size_t)3 * (size_t)tot))) return rc;
@@ -248,15 +254,18 @@ int mp_build_windows(mp_ctx *c, int32_t p0, int32_t n_win, int32_t k, int32_t v,
         if (e == hipSuccess) e = hipMemcpyAsync(&cnt, c->ex_count, sizeof(int), hipMemcpyDeviceToHost, c->stream);
         if (e == hipSuccess) e = hipMemcpyAsync(errv, c->err_flag, 4 * sizeof(int), hipMemcpyDeviceToHost, c->stream);
         if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+        lap("build_windows: list+repair");
         dev_free(c, &d_wins, (size_t)tot);
         if (e != hipSuccess) return fail(c, MP_ERR_DEVICE, "mp_build_windows: %s", hipGetErrorString(e));
         if (errv[0])
             return fail(c, MP_ERR_SHORT_WINDOW, "row %d has fewer than %d residues at window %d", errv[2], k, p0 + errv[1]);
         c->ex_host.resize((size_t)cnt);
         if (cnt) HIPCK(c, hipMemcpy(c->ex_host.data(), c->ex, sizeof(ExRec) * (size_t)cnt, hipMemcpyDeviceToHost));
+        lap("build_windows: ex d2h");
         std::sort(c->ex_host.begin(), c->ex_host.end(),
                   [](const ExRec &a, const ExRec &b) { return a.win != b.win ? a.win < b.win : a.row < b.row; });
         if (n_exc) *n_exc = cnt;
+        lap("build_windows: exceptions");
     }
     return MP_OK;
 }
