@@ -27,9 +27,11 @@ def main():
     ora = Library(os.path.join(REPO, "oracle", "_build", "libmprime_oracle.so")).context(0)
     rng = np.random.default_rng(a.seed)
     t_end = time.time() + a.seconds
-    n = {"dimer_scan": 0, "dimer_pairs": 0, "pair_coverage": 0, "pcr_scan": 0}
+    n = {"dimer_scan": 0, "dimer_pairs": 0, "pair_coverage": 0, "pcr_scan": 0, "dimer_cases_thread_per_pair": 0}
     while time.time() < t_end:
         seed = int(rng.integers(1 << 30))
+        # every case picks the kernel family of the dimer calls: thread per pair (bit-plane filter + queued search), 16 or 64 lanes
+        os.environ["MP_DIMER_LANES"] = str(rng.choice(["1", "16", "64"]))
         try:
             p_deg = float(rng.choice([0.0, 0.03, 0.1, 0.2]))
             # the oracle expands every primer: keep the all-pairs work of a case around a second of CPU
@@ -41,6 +43,7 @@ def main():
                         dimer.dg_params(), dimer.dg_limit())
                 assert np.array_equal(hip.dimer_scan(*args), ora.dimer_scan(*args)), ("dimer_scan", mode)
                 n["dimer_scan"] += 1
+            n["dimer_cases_thread_per_pair"] += os.environ["MP_DIMER_LANES"] == "1"
             pairs = rng.integers(0, len(seqs), size=(int(rng.integers(1, 400)), 2)).astype(np.int32)
             pargs = (codes, off, pairs, dimer.cached_loss_table(3.6), dimer.dg_params(), dimer.dg_limit())
             assert np.array_equal(hip.dimer_pairs(*pargs), ora.dimer_pairs(*pargs)), "dimer_pairs"
