@@ -50,13 +50,29 @@ def occurs_in_some_expansion(concrete: str, degenerate: str) -> bool:
 
 
 def exact_mean(vals):
-    """statistics.mean (the correctly rounded exact mean the reference uses) — one or two values need no rationals."""
-    if len(vals) == 1:
+    """statistics.mean of floats (the exact rational mean, rounded once — what the reference uses) without Fractions: every
+    double is an integer over a power of two, the sum is kept as one integer over the largest such power, and Python's
+    int / int is correctly rounded like Fraction -> float."""
+    n = len(vals)
+    if n == 1:
         return vals[0]
-    if len(vals) == 2:
+    if n == 2:
         return (vals[0] + vals[1]) / 2          # fl(a + b) / 2 == fl((a + b) / 2): halving is exact
-    from statistics import mean
-    return mean(vals)
+    try:
+        if type(vals[0]) is not float:
+            raise ValueError
+        total, shift = 0, 0                      # sum = total / 2**shift
+        for v in vals:
+            a, b = v.as_integer_ratio()
+            k = b.bit_length() - 1
+            if k > shift:
+                total <<= k - shift
+                shift = k
+            total += a << (shift - k)
+        return total / (n << shift)
+    except (AttributeError, OverflowError, ValueError):      # ints, inf / nan: the library's own path
+        from statistics import mean
+        return mean(vals)
 
 
 def degeneracy(seq) -> int:
