@@ -714,9 +714,12 @@ __global__ __launch_bounds__(kBlock) void eval_chain_kernel(const EvalChainArgs 
     if (on_patch && slice * 64 * GW >= (int)T.stride) return;               // nothing of this window's patch planes left for the wave
     const size_t nw32 = T.stride;
     const bool live = T.live;
-    uint32_t accP[CC], accF[CC], accR[CC];
+    // the three counts of a chain member are written once (when the walk reaches it) and are at most 32 * GW <= 256 per thread:
+    // one register per member (10 bits each) instead of three keeps the kernel at 8 waves per SIMD
+    static_assert(32 * GW < 1024, "three counts per register need 10 bits each");
+    uint32_t acc[CC];
 #pragma unroll
-    for (int c = 0; c < CC; c++) accP[c] = accF[c] = accR[c] = 0;
+    for (int c = 0; c < CC; c++) acc[c] = 0;
     if (live) {
         uint32_t t1[GW], t2[GW], t3[GW], t4[GW], sf[GW], sr[GW];
 #pragma unroll
@@ -773,15 +776,20 @@ __global__ __launch_bounds__(kBlock) void eval_chain_kernel(const EvalChainArgs 
                     evw = evn;
                 }
             }
+            uint32_t nP = 0, nF = 0, nR = 0;
 #pragma unroll
             for (int i = 0; i < GW; i++) {
                 const uint32_t far = LV == 1 ? t1[i] : (LV == 2 ? t2[i] : (LV == 3 ? t3[i] : t4[i]));
-                accP[s] += __popc(valid[i] & ~t1[i]);
-                accF[s] += __popc(__builtin_amdgcn_bitop3_b32(valid[i], far, sf[i], kLutAndNotNot));
-                accR[s] += __popc(__builtin_amdgcn_bitop3_b32(valid[i], far, sr[i], kLutAndNotNot));
+                nP += __popc(valid[i] & ~t1[i]);
+                nF += __popc(__builtin_amdgcn_bitop3_b32(valid[i], far, sf[i], kLutAndNotNot));
+                nR += __popc(__builtin_amdgcn_bitop3_b32(valid[i], far, sr[i], kLutAndNotNot));
             }
+            acc[s] = nP | (nF << 10) | (nR << 20);
         }
     }
+    uint32_t accP[CC], accF[CC], accR[CC];
+#pragma unroll
+    for (int c = 0; c < CC; c++) { accP[c] = acc[c] & 1023u; accF[c] = (acc[c] >> 10) & 1023u; accR[c] = acc[c] >> 20; }
     if (on_patch) wave_commit<GW>(accP, accF, accR, s_part, A.cand_out + it.cand0, A.out);
     else block_commit<GW>(accP, accF, accR, s_part, A.cand_out + it.cand0, A.out);
 }
