@@ -134,3 +134,28 @@ def test_tools_and_scripts_compile():
     assert len(files) >= 12
     for f in files:
         py_compile.compile(f, doraise=True)
+
+
+def test_product_never_reaches_for_the_oracle():
+    """The oracle is test infrastructure: no module of the package and no drop-in script imports it or names its library
+    (only tests/, bench.py's cpu_baseline leg and __graft_entry__.smoke() may)."""
+    import ast
+    import glob
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    files = glob.glob(os.path.join(root, "multiprime_amd", "*.py")) + glob.glob(os.path.join(root, "scripts", "*.py"))
+    assert len(files) > 15
+    for path in files:
+        src = open(path).read()
+        tree = ast.parse(src)
+        for node in ast.walk(tree):
+            names = []
+            if isinstance(node, ast.Import):
+                names = [a.name for a in node.names]
+            elif isinstance(node, ast.ImportFrom):
+                names = [node.module or ""]
+            assert not any(n == "oracle" or n.startswith("oracle.") for n in names), path
+            if isinstance(node, ast.Constant) and isinstance(node.value, str) and node is not ast.get_docstring:
+                assert "libmprime_oracle" not in node.value, path
+    for path in glob.glob(os.path.join(root, "multiprime_amd", "csrc", "*")):
+        if os.path.isfile(path) and path.endswith((".hip", ".cpp", ".hpp")):
+            assert "oracle/" not in open(path).read().replace("oracle/core_ref.py", ""), path
