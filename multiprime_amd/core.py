@@ -194,6 +194,17 @@ class NN_degenerate(object):
             e_window, words, count, e_first = self.comm.gather_entries(e_window, words, count, e_first)
             ex_w, x_row, ex_codes = self.comm.gather_exceptions(ex_w, x_row, ex_codes, k)
         self._exc = (ex_w, x_row, ex_codes)
+        # Row shards without JSON side files split the planning by WINDOWS: every rank holds the merged histograms of all windows
+        # (one all-gather) but plans only its contiguous share of them; the candidates are gathered, evaluated by everyone on their
+        # own rows, and the results of the shares are concatenated (run()).  The JSON writers need every window's ordered table
+        # on rank 0, so with them the planning stays replicated (it is O(windows x sequences) output anyway).
+        self._win_split = self.comm is not None and not self.write_json and not keep
+        if self._win_split:
+            lo, hi = self.comm.window_range(W)
+            sel = (e_window >= lo) & (e_window < hi)
+            e_window, words, count, e_first = e_window[sel], np.ascontiguousarray(words[:, sel]), count[sel], e_first[sel]
+            xs = (ex_w >= lo) & (ex_w < hi)
+            ex_w, x_row, ex_codes = ex_w[xs], x_row[xs], ex_codes[xs]
         plan = host.Plan(k=k, v=v, n_windows=W, total_sequences=self.total_sequence_number, coverage=self.coverage,
                          entropy_threshold=self.entropy_threshold, max_degeneracy=self.score_of_dege_bases,
                          max_dege_positions=self.number_of_dege_bases, e_window=e_window, e_words=words, e_count=count,
@@ -227,7 +238,19 @@ class NN_degenerate(object):
             n_cand = plan.n_candidates
             t0 = time.time()
             cand_w, codes = plan.candidates()
-            if n_cand:
+            if self._win_split:
+                # every rank planned its share of the windows: all candidates (rank order = window order) go to everyone, each
+                # rank counts them on its rows, one all-reduce; a rank replays the stopping rules on its own slice
+                mine = len(cand_w)
+                counts = self.comm.gather_var(np.asarray([mine], np.int64))
+                first = int(counts[: self.comm.rank].sum())
+                all_w, all_codes = self.comm.gather_var(cand_w), self.comm.gather_var(codes)
+                n_cand = len(all_w)
+                ev_all = (self.comm.eval_allreduce(self.ctx, all_w, all_codes, self._sF, self._sR) if n_cand
+                          else np.zeros((0, 3), np.int64))
+                ev = np.ascontiguousarray(ev_all[first:first + mine])
+                self.stats["windows_planned"] = int(self.comm.gather_var(np.asarray([plan.n_planned], np.int64)).sum())
+            elif n_cand:
                 if self.comm is not None:
                     ev = self.comm.eval_allreduce(self.ctx, cand_w, codes, self._sF, self._sR)
                 else:
@@ -239,6 +262,8 @@ class NN_degenerate(object):
             t0 = time.time()
             plan.finish(ev)                      # replay of the stopping rules, NM / MM choice, nonsense counts
             res = plan.results()
+            if self._win_split:
+                res = {key: self.comm.gather_var(val) for key, val in res.items()}       # shares in rank order = window order
             primers = iupac.strings_of(iupac.SYMBOL_LUT[res["codes"]])
             # the 3'-end self-dimer test of every window's primer (dimer_check, V20:487-503) in ONE launch:
             # it is the ordered pair (x -> x) of the dimer scan with Loss >= 3 and the two-term deltaG

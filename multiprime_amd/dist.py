@@ -42,6 +42,11 @@ class RowShards:
         starts = [r * base + min(r, rem) for r in range(self.world + 1)]
         return starts
 
+    def window_range(self, n_windows):
+        """[lo, hi): this rank's contiguous share of the windows (planning is split by windows, core.py)."""
+        starts = self.bounds(n_windows)
+        return starts[self.rank], starts[self.rank + 1]
+
     def take_shard(self, data, row_off):
         n = len(row_off) - 1
         starts = self.bounds(n)

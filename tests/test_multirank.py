@@ -11,7 +11,7 @@ import torch.multiprocessing as mp
 from conftest import GOLDEN, REPO, golden_input, load_gz_json
 
 
-def _worker(rank, world, port, name, inp, out, lib_path):
+def _worker(rank, world, port, name, inp, out, lib_path, write_json=True):
     sys.path.insert(0, REPO)
     import torch.distributed as dist
     from multiprime_amd._abi import Library
@@ -27,8 +27,9 @@ def _worker(rank, world, port, name, inp, out, lib_path):
         app = NN_degenerate(seq_file=inp, primer_length=fl["l"], coverage=fl["f"], number_of_dege_bases=fl["n"],
                             score_of_dege_bases=fl["d"], raw_entropy_threshold=fl["e"], product_len=fl["s"],
                             position=fl["c"], variation=fl["v"], distance=fl["a"], GC=fl["g"], nproc=1,
-                            outfile=out, library=Library(lib_path), comm=RowShards(), write_bitsets=True)
+                            outfile=out, library=Library(lib_path), comm=RowShards(), write_bitsets=True, write_json=write_json)
         app.run()
+        assert app._win_split == (not write_json)
     finally:
         dist.destroy_process_group()
 
@@ -57,6 +58,37 @@ def test_sharded_run_matches_reference(name, world, oracle_lib, tmp_path):
             want = g | {x for lst in noncov[str(pos)][side].values() for x in lst}
             bits = np.unpackbits(arr[i].view(np.uint8), bitorder="little")[: len(ids)]
             assert {ids[r] for r in np.nonzero(bits)[0]} == want, (pos, side)
+
+
+def _check_bitsets(name, out):
+    import numpy as np
+    from multiprime_amd.core import bitset_ids
+    z = np.load(str(out) + ".coverage_bitsets.npz")
+    ids = bitset_ids(z)
+    noncov, gap = load_gz_json(name + ".noncov.json.gz"), load_gz_json(name + ".gap.json.gz")
+    assert len(z["positions"]) == len(noncov)
+    for i, pos in enumerate(z["positions"].tolist()):
+        g = {x for lst in gap[str(pos)].values() for x in lst}
+        for side, arr in ((0, z["not_f"]), (1, z["not_r"])):
+            want = g | {x for lst in noncov[str(pos)][side].values() for x in lst}
+            bits = np.unpackbits(arr[i].view(np.uint8), bitorder="little")[: len(ids)]
+            assert {ids[r] for r in np.nonzero(bits)[0]} == want, (pos, side)
+
+
+# without the JSON side files the planning is split by windows across the ranks (candidates gathered, results concatenated)
+@pytest.mark.parametrize("name,world", [("syn_iupac", 2), ("syn_ragged", 3), ("ivc_v1", 4), ("msa1000_k18_d64", 8), ("syn_edge", 5),
+                                        ("cluster0_v2", 3)])
+def test_sharded_run_with_window_split_planning(name, world, oracle_lib, tmp_path):
+    meta = load_gz_json(name + ".trace.json.gz")["meta"]
+    inp = tmp_path / (name + ".fa")
+    inp.write_bytes(golden_input(meta["input"]))
+    out = tmp_path / (name + ".out")
+    port = 31500 + (os.getpid() % 2000)
+    mp.spawn(_worker, args=(world, port, name, str(inp), str(out), oracle_lib.path, False), nprocs=world, join=True)
+    with open(os.path.join(GOLDEN, name + ".tsv"), "rb") as f:
+        assert out.read_bytes() == f.read(), "TSV differs from the reference's"
+    assert not os.path.exists(str(out) + ".gap_seq_id_json")
+    _check_bitsets(name, out)
 
 
 @pytest.mark.gpu
@@ -88,6 +120,14 @@ def test_rccl_path_single_rank(tmp_path):
                           variation=fl["v"], distance=fl["a"], GC=fl["g"], nproc=1, outfile=str(out), library=Library(),
                           comm=comm).run()
             check_outputs(name, out)
+            # the window-split planning path (no JSON side files): candidates and results travel through RCCL all_gathers
+            out2 = tmp_path / (name + ".nojson.out")
+            app = NN_degenerate(seq_file=str(inp), primer_length=fl["l"], coverage=fl["f"], number_of_dege_bases=fl["n"],
+                                score_of_dege_bases=fl["d"], raw_entropy_threshold=fl["e"], product_len=fl["s"], position=fl["c"],
+                                variation=fl["v"], distance=fl["a"], GC=fl["g"], nproc=1, outfile=str(out2), library=Library(),
+                                comm=RowShards(), write_json=False)
+            app.run()
+            assert app._win_split and out2.read_bytes() == out.read_bytes()
     finally:
         dist.destroy_process_group()
 
