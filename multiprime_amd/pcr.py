@@ -95,30 +95,28 @@ class Product(object):
         hits = self.ctx.pcr_scan(data, row_off, codes, off) if names and bodies else np.full((len(names), len(bodies), 4), -1, np.int32)   # -1 = no amplicon (0 would read "expansion 0 at position 0")
         self.stats["scan_s"] = time.time() - t0
         product_ids = set()
+        stripped = [line.strip() for line in seqs]                                     # what a non-target record prints (PCR:211)
         for pi, name in enumerate(names):
             F, R = self.primers[name]
             r_exp = [iupac.revcomp(x) for x in iupac.expand(R)]
             product_dict, non_targets = {}, {}
             h = hits[pi]
-            for row in range(len(seqs)):
-                i_f, p1, i_r, q = (int(x) for x in h[row])
-                if i_f >= 0:
-                    line = seqs[row]
-                    product_dict[keys[row]] = line[p1:q].strip() + r_exp[i_r]          # PCR:204-205
+            i_f, p1, i_r, q = h[:, 0].tolist(), h[:, 1].tolist(), h[:, 2].tolist(), h[:, 3].tolist()
+            for row, key in enumerate(keys):                                           # dicts: a later line of a record replaces an earlier one
+                if i_f[row] >= 0:
+                    product_dict[key] = seqs[row][p1[row]:q[row]].strip() + r_exp[i_r[row]]   # PCR:204-205
                 else:
-                    non_targets[keys[row]] = seqs[row].strip()
+                    non_targets[key] = stripped[row]
             pcr_product = Path(self.output_file).joinpath(name).with_suffix(".PCR.product.fa")
             pcr_non_product = Path(self.output_file).joinpath(name).with_suffix(".non_PCR.product.fa")
             with open(self.coverage, "a+") as c:                                       # PCR:228-232 (appends)
                 c.write("Number of Product/non_Product, primer-F and primer-R: {}\t{}\t{}\t{}\t{}\n".format(
                     name, len(product_dict), len(non_targets), F, R))
+            product_ids.update(product_dict)
             with open(pcr_product, "w") as p:
-                for k, v in product_dict.items():
-                    product_ids.add(k)
-                    p.write(k + "\n" + v + "\n")
+                p.write("".join([k + "\n" + v + "\n" for k, v in product_dict.items()]))
             with open(pcr_non_product, "w") as p:
-                for k, v in non_targets.items():
-                    p.write(k + "\n" + v + "\n")
+                p.write("".join([k + "\n" + v + "\n" for k, v in non_targets.items()]))
         with open(self.ref_file, encoding="utf-8") as f:
             seq_number = int(f.read().count("\n") / 2)
         with open(self.coverage, "a+") as c:
