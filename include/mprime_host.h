@@ -139,6 +139,9 @@ int mp_plan_write_side_files(const mp_plan *p, int32_t n_out, const int32_t *out
 /* Expansions of n k-mers of symbol codes (degenerate_seq, V20:368-380) in the reference's order; out_src[i] = index
  * of the k-mer expansion i comes from.  *n_out returns the number needed; MP_ERR_CAPACITY if cap is too small. */
 int mp_expand_kmers(int32_t k, int64_t n, const uint8_t *codes, int64_t cap, uint8_t *out_codes, int64_t *out_src, int64_t *n_out);
+/* The same expansions as window words (b0, b1, g of mprime.h, three per expansion) — what mp_set_extra_rows takes. */
+int mp_expand_kmer_words(int32_t k, int64_t n, const uint8_t *codes, int64_t cap, uint32_t *out_words, int64_t *out_src,
+                         int64_t *n_out);
 
 #ifdef __cplusplus
 }

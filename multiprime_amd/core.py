@@ -23,6 +23,7 @@ from __future__ import annotations
 
 import os
 import sys
+import threading
 import time
 from collections import defaultdict
 from json.encoder import encode_basestring_ascii as _q
@@ -103,13 +104,29 @@ class NN_degenerate(object):
 
         t0 = time.time()
         self.lib = library if library is not None else Library()      # raises if the HIP library is absent
-        self.ctx = self.lib.context(device)
-        fa = host.Fasta(seq_file)                                      # native parser (parse_seq's record semantics)
-        self._fasta = fa
-        self.total_sequence_number = fa.n_rows
-        if fa.n_rows == 0:
-            raise ValueError("no sequence records in " + str(seq_file))
-        data, row_off = fa.rows()
+        # the first device call of a process starts the HIP runtime (0.1-0.3 s): it runs beside the FASTA parser (both release the GIL)
+        made = {}
+
+        def make_context():
+            try:
+                made["ctx"] = self.lib.context(device)
+            except BaseException as e:                                 # re-raised below, in the constructor's thread
+                made["error"] = e
+
+        starter = threading.Thread(target=make_context)
+        starter.start()
+        try:
+            fa = host.Fasta(seq_file)                                  # native parser (parse_seq's record semantics)
+            self._fasta = fa
+            self.total_sequence_number = fa.n_rows
+            if fa.n_rows == 0:
+                raise ValueError("no sequence records in " + str(seq_file))
+            data, row_off = fa.rows()
+        finally:
+            starter.join()
+        if "error" in made:
+            raise made["error"]
+        self.ctx = made["ctx"]
         self.stats["parse_s"] = time.time() - t0
         t0 = time.time()
         width = int(np.diff(row_off).max())                           # longest record (of ALL rows)
@@ -169,8 +186,8 @@ class NN_degenerate(object):
             # IUPAC k-mers with <= v gaps join the evaluated universe as their concrete expansions (V20:701-707)
             sel = (ex_codes == 0).sum(axis=1) <= v
             if sel.any():
-                exp, src = host.expand_kmers(ex_codes[sel])
-                self.ctx.set_extra_rows(ex_w[sel][src], iupac.words_of_codes(exp))
+                words, src = host.expand_kmer_words(ex_codes[sel])
+                self.ctx.set_extra_rows(ex_w[sel][src], words)
         self.stats["build_windows_s"] = time.time() - t0
         t0 = time.time()
         # state_matrix / trans_matrix of every window (V20:541-577) straight from the column planes; shards add up

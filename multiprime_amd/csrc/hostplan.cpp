@@ -781,6 +781,35 @@ int mp_expand_kmers(int32_t k, int64_t n, const uint8_t *codes, int64_t cap, uin
     return MP_OK;
 }
 
+int mp_expand_kmer_words(int32_t k, int64_t n, const uint8_t *codes, int64_t cap, uint32_t *out_words, int64_t *out_src, int64_t *n_out) {
+    if (k < 1 || k > 32 || n < 0 || !n_out || (n && !codes)) return MP_ERR_ARG;
+    double need = 0;
+    for (int64_t i = 0; i < n; i++) {
+        for (int j = 0; j < k; j++) if (codes[(size_t)i * k + j] > 15) return MP_ERR_ARG;
+        need += expansions_of(codes + (size_t)i * k, k);
+    }
+    if (need > 9e15) return MP_ERR_CAPACITY;
+    *n_out = (int64_t)need;
+    if ((int64_t)need > cap) return MP_ERR_CAPACITY;
+    int64_t o = 0;
+    for (int64_t i = 0; i < n; i++)
+        for_each_expansion(codes + (size_t)i * k, k, [&](const Key &e) {
+            if (out_words) {
+                uint32_t b0 = 0, b1 = 0, g = 0;                       // window words of mprime.h: base index bits and the gap flag
+                for (int j = 0; j < k; j++) {
+                    const uint32_t c = (uint32_t)e.get(j);
+                    b0 |= (uint32_t)((c & 10u) != 0) << j;            // C or T
+                    b1 |= (uint32_t)((c & 12u) != 0) << j;            // G or T
+                    g |= (uint32_t)(c == 0) << j;
+                }
+                out_words[(size_t)o * 3] = b0; out_words[(size_t)o * 3 + 1] = b1; out_words[(size_t)o * 3 + 2] = g;
+            }
+            if (out_src) out_src[o] = i;
+            o++;
+        });
+    return MP_OK;
+}
+
 }  // extern "C"
 
 // ---------------------------------------------------------------------------------------------------------------

@@ -44,6 +44,7 @@ HOST_SYMBOLS = [
     ("mp_plan_window_table", C.c_int, [_p, C.c_int32, C.c_int32, C.c_int64, _p, _p, _p, C.POINTER(C.c_int64)]),
     ("mp_plan_write_side_files", C.c_int, [_p, C.c_int32, _p, _p, _p, C.c_uint32, C.c_uint32, _p, _p, C.c_int64, _p, C.c_int32, C.c_int64,
                                            _p, _p, _p, _p, _p, C.c_char_p, C.c_char_p]),
+    ("mp_expand_kmer_words", C.c_int, [C.c_int32, C.c_int64, _p, C.c_int64, _p, _p, C.POINTER(C.c_int64)]),
     ("mp_expand_kmers", C.c_int, [C.c_int32, C.c_int64, _p, C.c_int64, _p, _p, C.POINTER(C.c_int64)]),
 ]
 
@@ -164,6 +165,26 @@ def expand_kmers(codes: np.ndarray):
     if rc != 0:
         raise MprimeError(rc, "mp_expand_kmers")
     return out[:m], src[:m]
+
+
+def expand_kmer_words(codes: np.ndarray):
+    """(words [m][3] uint32, src [m]): the expansions of expand_kmers as window words (mp_set_extra_rows)."""
+    codes = np.ascontiguousarray(codes, dtype=np.uint8)
+    n, k = codes.shape
+    d = dll()
+    need = C.c_int64(0)
+    rc = d.mp_expand_kmer_words(k, n, _ptr(codes), 0, None, None, C.byref(need))
+    if rc not in (0, MP_ERR_CAPACITY):
+        raise MprimeError(rc, "mp_expand_kmer_words: bad symbol codes or too many expansions")
+    m = need.value
+    if m > 1 << 28:
+        raise MprimeError(MP_ERR_CAPACITY, f"IUPAC k-mers expand to {m} concrete k-mers")
+    words = np.empty((max(m, 1), 3), np.uint32)
+    src = np.empty(max(m, 1), np.int64)
+    rc = d.mp_expand_kmer_words(k, n, _ptr(codes), m, _ptr(words), _ptr(src), C.byref(need))
+    if rc != 0:
+        raise MprimeError(rc, "mp_expand_kmer_words")
+    return words[:m], src[:m]
 
 
 class Plan:

@@ -270,3 +270,12 @@ def test_newline_count_equals_text_mode_read(tmp_path, monkeypatch):
             with open(p, encoding="latin-1") as f:
                 want = f.read().count("\n")
             assert host.count_newlines(str(p)) == want, (threads, i)
+
+
+def test_expansions_as_window_words_equal_the_code_path():
+    rng = np.random.default_rng(8)
+    codes = np.where(rng.random((400, 18)) < 0.85, rng.choice(np.array([1, 2, 4, 8], np.uint8), size=(400, 18)),
+                     rng.integers(0, 16, size=(400, 18))).astype(np.uint8)
+    exp, src = host.expand_kmers(codes)
+    words, src2 = host.expand_kmer_words(codes)
+    assert np.array_equal(src, src2) and np.array_equal(iupac.words_of_codes(exp), words)
