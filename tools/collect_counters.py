@@ -81,7 +81,7 @@ def main():
         rows = list(db.execute("select name, count(*), avg(duration), min(duration), max(duration) from kernels where name like '%eval_%' group by name order by sum(duration) desc"))
         if rows:
             kern = rows[0][0]
-            entry["kernel"] = kern.split("(")[0]
+            entry["kernel"] = kern.replace("(anonymous namespace)::", "").split("(")[0].replace("void ", "").strip() + " (incl. the patch-plane waves)"
             entry["trace"] = {"dispatches": rows[0][1], "avg_us": rows[0][2] / 1e3, "min_us": rows[0][3] / 1e3, "max_us": rows[0][4] / 1e3,
                               "note": "rocprofv3 --kernel-trace of `bench.py --steps 20 --warmup 3`"}
     raw = {}
