@@ -213,7 +213,8 @@ int mp_eval_timing_samples(mp_ctx *ctx, int32_t cap, float *ms, int32_t *n);
  *   len_x-1 .. 5 (get_Maxprimerset_V1.3.py:149-154); same hit record, one per pair.
  * hits has room for cap_hits records; *n_hits returns the number found (may exceed cap_hits,
  * in which case only the first cap_hits written are valid).  Order of records is unspecified. */
-#define MP_DIMER_MAX_LEN 32
+#define MP_DIMER_MAX_LEN 64      /* primers of the dimer scans (adaptor-tailed primers included) */
+#define MP_PATTERN_MAX_LEN 32    /* primers / patterns of the sequence scans (mp_pcr_scan, mp_kmm_scan): 2 bits per base in 64 */
 int mp_dimer_scan(mp_ctx *ctx, int32_t n_primers, const uint8_t *codes, const int32_t *off, int32_t mode,
                   int32_t n_new, const uint8_t *loss_hit, const double *dg_params, double dg_limit,
                   int64_t cap_hits, int32_t *hits, int64_t *n_hits);
@@ -240,7 +241,7 @@ int mp_pair_coverage(mp_ctx *ctx, int32_t n_sets, int32_t n_words, const uint64_
  * every (primer pair, sequence).  `bytes`/`row_off` hold the sequence lines of the reference FASTA as they
  * stand in the file (no upper-casing: the reference's re.search is case sensitive, so only upper-case
  * A/C/G/T can match a primer expansion).  Primer 2p is the forward, 2p+1 the reverse primer of pair p
- * (symbol codes, IUPAC allowed, <= MP_DIMER_MAX_LEN).  For each pair and sequence, in the reference's order:
+ * (symbol codes, IUPAC allowed, <= MP_PATTERN_MAX_LEN).  For each pair and sequence, in the reference's order:
  * the first forward expansion iF that occurs in the sequence AND for which a reverse expansion matches
  * inside its "Product" — the text from the first occurrence p1 of that expansion up to its next
  * non-overlapping occurrence (str.split) or the end of the line; inside it the first reverse expansion iR
@@ -255,7 +256,7 @@ int mp_pcr_scan(mp_ctx *ctx, const uint8_t *bytes, const int64_t *row_off, int32
  * from this image, so the acceptance rule is a restatement, not a recorded behaviour (parity unpinned):
  * `bytes`/`row_off` hold the reference sequences (upper-cased by the scan; any character outside ACGT mismatches every
  * base, like bowtie2's N).  Pattern i = pat_codes[pat_off[i] .. pat_off[i+1]) is one CONCRETE primer expansion
- * (codes 1,2,4,8; length 4..MP_DIMER_MAX_LEN).  For every sequence, start position p and strand s (0: the text reads the
+ * (codes 1,2,4,8; length 4..MP_PATTERN_MAX_LEN).  For every sequence, start position p and strand s (0: the text reads the
  * pattern, 1: the text reads its reverse complement — SAM flag 16) the ungapped alignment is a hit when
  *   - it has at most max_mismatch mismatching positions (bowtie2 end-to-end, default scoring: the minimum score
  *     -0.6 - 0.6 L with 6 per mismatch admits floor((0.6 + 0.6 L) / 6) mismatches; the host passes that or its override), and

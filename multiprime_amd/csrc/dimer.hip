@@ -48,7 +48,8 @@ __device__ inline uint64_t dm_expand(const Nib &c, int start, int len, uint32_t 
     return x;
 }
 
-__device__ inline double dm_delta_g(uint64_t e, int l, const double *__restrict__ dg) {
+template <typename Str>
+__device__ inline double dm_delta_g(Str e, int l, const double *__restrict__ dg) {
     double g = 0.0;
     uint32_t prev = (uint32_t)e & 3u;
     for (int t = 1; t < l; t++) {
@@ -69,7 +70,8 @@ __device__ inline double dm_delta_g(uint64_t e, int l, const double *__restrict_
 
 // One (end length, end expansion, y expansion) combination of the ordered pair x -> y; on a hit *idx_out = where RC(end) starts.
 __device__ inline bool dimer_combo(const Nib &cx, const Nib &cy, int lx, int ly, int l, uint32_t ei, uint32_t pi,
-                                   const uint8_t *__restrict__ loss_hit, int l0, const double *__restrict__ dg, double dg_limit, int &idx_out) {
+                                   const uint8_t *__restrict__ loss_hit, int l0, int gc_rows, const double *__restrict__ dg, double dg_limit,
+                                   int &idx_out) {
     const uint64_t mask = l == 32 ? ~0ull : ((1ull << (2 * l)) - 1ull);
     const uint64_t e = dm_expand(cx, lx - l, l, ei);
     uint64_t rc = 0;                                                      // reverse complement: 3 - base, reversed
@@ -81,7 +83,7 @@ __device__ inline bool dimer_combo(const Nib &cx, const Nib &cy, int lx, int ly,
     if (idx < 0) return false;
     const int gc = __popcll((e ^ (e >> 1)) & 0x5555555555555555ull & mask);   // C = 01, G = 10
     const int d2 = ly - l - idx;
-    bool hit = loss_hit[((size_t)(l - l0) * (MP_DIMER_MAX_LEN + 1) + gc) * 64 + d2] != 0;      // the table starts at end length l0
+    bool hit = loss_hit[((size_t)(l - l0) * gc_rows + gc) * 64 + d2] != 0;      // the table starts at end length l0, gc_rows rows per length
     if (!hit && d2 == 0) hit = dm_delta_g(e, l, dg) < dg_limit;
     idx_out = idx;
     return hit;
@@ -95,8 +97,8 @@ __device__ inline bool dimer_combo(const Nib &cx, const Nib &cy, int lx, int ly,
 // of the core step, the pair lists of the pairing stage, get_Maxprimerset's incremental scans).
 template <int G>
 __device__ inline bool dimer_pair_group(const uint8_t *__restrict__ codes, const int32_t *__restrict__ off, int x, int y, int mode,
-                                        const uint8_t *__restrict__ loss_hit, int l0, const double *__restrict__ dg, double dg_limit,
-                                        int32_t (&rec)[4]) {
+                                        const uint8_t *__restrict__ loss_hit, int l0, int gc_rows, const double *__restrict__ dg,
+                                        double dg_limit, int32_t (&rec)[4]) {
     const int lane = threadIdx.x & 63, gl = lane & (G - 1), g0 = lane & ~(G - 1);
     const unsigned long long gmask = (G == 64 ? ~0ull : ((1ull << (G & 63)) - 1ull)) << g0;
     const int lx = off[x + 1] - off[x], ly = off[y + 1] - off[y];
@@ -136,7 +138,7 @@ __device__ inline bool dimer_pair_group(const uint8_t *__restrict__ codes, const
             }
             acc += cj;
         }
-        if (found) hit = dimer_combo(cx, cy, lx, ly, l, ei, pi, loss_hit, l0, dg, dg_limit, idx);
+        if (found) hit = dimer_combo(cx, cy, lx, ly, l, ei, pi, loss_hit, l0, gc_rows, dg, dg_limit, idx);
         const unsigned long long hb = __ballot(hit) & gmask;
         if (hb) {
             const int first = __ffsll((long long)hb) - 1;
@@ -148,18 +150,21 @@ __device__ inline bool dimer_pair_group(const uint8_t *__restrict__ codes, const
 }
 
 // Tables in LDS (north_star): the Loss decision bytes of the end lengths a launch can meet and the deltaG constants.
-constexpr int kLossRow = (MP_DIMER_MAX_LEN + 1) * 64;                    // bytes per end length
-constexpr int kLossL0 = 5, kLossRows = 27;                               // end lengths 5..31 are staged (57 KB); shorter / 32 read global
+constexpr int kLossRow = (MP_DIMER_MAX_LEN + 1) * 64;                    // bytes per end length of the caller's table
+constexpr int kLossL0 = 5, kLossRows = 27, kStageGc = 32;                // end lengths 5..31 x GC counts 0..31 are staged (54 KB); others read global
+constexpr int kStageRow = kStageGc * 64;
 constexpr int kNdg = 16 + 32 + MP_DIMER_MAX_LEN + 1 + 1;
 
 // explicit ordered pairs or an all-pairs scan, G lanes per pair, tables staged in LDS; persistent workgroups stride over the pairs
 template <int G>
 __global__ __launch_bounds__(kBlock) void dimer_group_kernel(const DimerArgs A, long long n_pairs, const int32_t *__restrict__ pairs,
                                                              uint8_t *__restrict__ flags) {
-    __shared__ uint8_t s_loss[kLossRows * kLossRow];
+    __shared__ uint8_t s_loss[kLossRows * kStageRow];
     __shared__ double s_dg[kNdg];
-    for (int i = threadIdx.x; i < kLossRows * kLossRow / 16; i += kBlock)
-        reinterpret_cast<uint4 *>(s_loss)[i] = reinterpret_cast<const uint4 *>(A.loss_hit + (size_t)kLossL0 * kLossRow)[i];
+    for (int i = threadIdx.x; i < kLossRows * kStageRow / 16; i += kBlock) {
+        const int l = i / (kStageRow / 16), rest = i % (kStageRow / 16);                       // rest = 16-byte piece of [gc < 32][64]
+        reinterpret_cast<uint4 *>(s_loss)[i] = reinterpret_cast<const uint4 *>(A.loss_hit + (size_t)(kLossL0 + l) * kLossRow)[rest];
+    }
     for (int i = threadIdx.x; i < kNdg; i += kBlock) s_dg[i] = A.dg[i];
     __syncthreads();
     // pairs whose end lengths all lie in 5..31 use the staged rows; the rare others (primers shorter than 5, 32-mers) the global table
@@ -175,8 +180,8 @@ __global__ __launch_bounds__(kBlock) void dimer_group_kernel(const DimerArgs A, 
         const int lx = A.off[x + 1] - A.off[x];
         const bool staged = lx <= 31 && (A.mode != 0 || lx >= 5);          // every end length of this pair lies in 5..31
         int32_t rec[4];
-        const bool hit = staged ? dimer_pair_group<G>(A.codes, A.off, x, y, A.mode, s_loss, kLossL0, s_dg, A.dg_limit, rec)
-                                : dimer_pair_group<G>(A.codes, A.off, x, y, A.mode, A.loss_hit, 0, A.dg, A.dg_limit, rec);
+        const bool hit = staged ? dimer_pair_group<G>(A.codes, A.off, x, y, A.mode, s_loss, kLossL0, kStageGc, s_dg, A.dg_limit, rec)
+                                : dimer_pair_group<G>(A.codes, A.off, x, y, A.mode, A.loss_hit, 0, MP_DIMER_MAX_LEN + 1, A.dg, A.dg_limit, rec);
         if (gl != 0) continue;
         if (flags) flags[p] = hit ? 1 : 0;
         else if (hit) {
@@ -189,20 +194,39 @@ __global__ __launch_bounds__(kBlock) void dimer_group_kernel(const DimerArgs A, 
     }
 }
 
-// ---- one thread per pair, for lists that fill the chip (the all-pairs scans of finDimer / get_Maxprimerset at database scale) ----
-// A primer as the pair test wants it (80 bytes, written once per call by prim_kernel): its symbol codes as nibbles, the base-set
-// planes of the primer itself (y[b] bit i = base b allowed at position i) and of its reverse complement (r[b] bit i = base b
-// allowed at position i of RC(primer)), its first expansion 2 bits per base, the positions holding more than one base, length and
-// number of expansions.
+// ---- one thread per pair, for lists that fill the chip (the all-pairs scans of finDimer / get_Maxprimerset at database scale) and for
+// every list that holds a primer of more than 32 bases (adaptor-tailed primers: 64-bit planes, 128-bit strings) ----
+typedef unsigned __int128 u128;
+template <bool LONG> struct PrimTraits;
+template <> struct PrimTraits<false> {
+    typedef uint32_t plane_t;          // one bit per position
+    typedef uint64_t str_t;            // 2 bits per base
+    static constexpr int kMax = 32, kNibWords = 2;
+};
+template <> struct PrimTraits<true> {
+    typedef uint64_t plane_t;
+    typedef u128 str_t;
+    static constexpr int kMax = 64, kNibWords = 4;
+};
+
+// A primer as the pair test wants it (written once per call by prim_kernel): its symbol codes as nibbles, the base-set planes of the
+// primer itself (y[b] bit i = base b allowed at position i) and of its reverse complement (r[b] bit i = base b allowed at position i
+// of RC(primer)), its first expansion 2 bits per base, the positions holding more than one base, length, number of expansions.
+template <bool LONG>
 struct __align__(16) PrimRec {
-    uint32_t nib[4];
-    uint32_t y[4];
-    uint32_t r[4];
-    uint32_t base0[2];
-    uint32_t dmask;
+    typedef typename PrimTraits<LONG>::plane_t plane_t;
+    uint64_t nib[PrimTraits<LONG>::kNibWords];
+    plane_t y[4];
+    plane_t r[4];
+    uint64_t base0[LONG ? 2 : 1];
+    plane_t dmask;
     int32_t len;
     uint32_t deg;
-    uint32_t pad[3];
+    __device__ uint32_t code(int j) const { return (uint32_t)(nib[j >> 4] >> (4 * (j & 15))) & 15u; }
+    __device__ typename PrimTraits<LONG>::str_t first() const {
+        if constexpr (LONG) return (u128)base0[0] | ((u128)base0[1] << 64);
+        else return base0[0];
+    }
 };
 
 // member order of the symbols (the table dimer_init uploads), 2 bits per member, one byte per symbol code
@@ -219,68 +243,76 @@ constexpr uint64_t member_pack(int half) {
 constexpr uint64_t kMemLo = member_pack(0), kMemHi = member_pack(1);
 __device__ inline uint32_t member_of(uint32_t code, uint32_t r) { return (uint32_t)(((code & 8u) ? kMemHi : kMemLo) >> (8 * (code & 7u) + 2 * r)) & 3u; }
 
+template <bool LONG>
 __global__ __launch_bounds__(kBlock) void prim_kernel(const uint8_t *__restrict__ codes, const int32_t *__restrict__ off, int n,
-                                                      PrimRec *__restrict__ out) {
+                                                      PrimRec<LONG> *__restrict__ out) {
+    typedef typename PrimTraits<LONG>::plane_t plane_t;
     const int i = blockIdx.x * kBlock + threadIdx.x;
     if (i >= n) return;
     const int len = off[i + 1] - off[i];
-    Nib nb;
-    nb.lo = nb.hi = 0;
-    uint32_t y[4] = {0, 0, 0, 0}, r[4] = {0, 0, 0, 0}, deg = 1, dmask = 0;
-    uint64_t base0 = 0;
+    PrimRec<LONG> o;
+#pragma unroll
+    for (int t = 0; t < PrimTraits<LONG>::kNibWords; t++) o.nib[t] = 0;
+#pragma unroll
+    for (int b = 0; b < 4; b++) o.y[b] = o.r[b] = 0;
+    o.base0[0] = 0;
+    if constexpr (LONG) o.base0[1] = 0;
+    plane_t dmask = 0;
+    uint32_t deg = 1;
     for (int p = 0; p < len; p++) {
         const uint32_t c = codes[off[i] + p];
-        nb.set(p, c);
+#pragma unroll
+        for (int t = 0; t < PrimTraits<LONG>::kNibWords; t++)
+            if ((p >> 4) == t) o.nib[t] |= (uint64_t)c << (4 * (p & 15));
         deg *= (uint32_t)__popc(c);
-        dmask |= (uint32_t)(__popc(c) > 1) << p;
-        base0 |= (uint64_t)member_of(c, 0) << (2 * p);
+        dmask |= (plane_t)(__popc(c) > 1) << p;
+        const uint64_t first = member_of(c, 0);
+        if (p < 32) o.base0[0] |= first << (2 * p);
+        else if constexpr (LONG) o.base0[1] |= first << (2 * (p - 32));
 #pragma unroll
         for (int b = 0; b < 4; b++) {
-            y[b] |= ((c >> b) & 1u) << p;
-            r[b] |= ((c >> (3 - b)) & 1u) << (len - 1 - p);            // complement: A <-> T, C <-> G (bit b <-> bit 3 - b), reversed
+            o.y[b] |= (plane_t)((c >> b) & 1u) << p;
+            o.r[b] |= (plane_t)((c >> (3 - b)) & 1u) << (len - 1 - p);      // complement: A <-> T, C <-> G (bit b <-> bit 3 - b), reversed
         }
     }
-    PrimRec o;
-    o.nib[0] = (uint32_t)nb.lo; o.nib[1] = (uint32_t)(nb.lo >> 32); o.nib[2] = (uint32_t)nb.hi; o.nib[3] = (uint32_t)(nb.hi >> 32);
-#pragma unroll
-    for (int b = 0; b < 4; b++) { o.y[b] = y[b]; o.r[b] = r[b]; }
-    o.base0[0] = (uint32_t)base0; o.base0[1] = (uint32_t)(base0 >> 32);
     o.dmask = dmask; o.len = len; o.deg = deg;
-    o.pad[0] = o.pad[1] = o.pad[2] = 0;
     out[i] = o;
 }
 
-__device__ inline Nib nib_of(const PrimRec &P) {
-    Nib c;
-    c.lo = (uint64_t)P.nib[0] | ((uint64_t)P.nib[1] << 32);
-    c.hi = (uint64_t)P.nib[2] | ((uint64_t)P.nib[3] << 32);
-    return c;
-}
+template <typename P> __device__ inline int low_bit(P m) { return sizeof(P) == 8 ? __ffsll((long long)m) - 1 : __ffs((int)m) - 1; }
+template <typename P> __device__ inline int high_bit(P m) { return sizeof(P) == 8 ? 63 - __clzll((long long)m) : 31 - __clz((int)m); }
 
 // expansions of positions [start, start + len): only the positions holding several bases are visited
-__device__ inline uint32_t fast_degeneracy(const Nib &c, uint32_t dmask, int start, int len) {
-    uint32_t m = (dmask >> start) & (len >= 32 ? ~0u : ((1u << len) - 1u)), d = 1;
+template <bool LONG>
+__device__ inline uint32_t fast_degeneracy(const PrimRec<LONG> &R, int start, int len) {
+    typedef typename PrimTraits<LONG>::plane_t plane_t;
+    plane_t m = (R.dmask >> start) & (len >= PrimTraits<LONG>::kMax ? ~(plane_t)0 : (((plane_t)1 << len) - 1));
+    uint32_t d = 1;
     while (m) {
-        const int p = __ffs((int)m) - 1;
+        const int p = low_bit(m);
         m &= m - 1;
-        d *= (uint32_t)__popc(c.get(start + p));
+        d *= (uint32_t)__popc(R.code(start + p));
     }
     return d;
 }
 
 // expansion number idx of positions [start, start + len) (itertools.product order: last position fastest), 2 bits per base
-__device__ inline uint64_t fast_expand(const Nib &c, uint64_t base0, uint32_t dmask, int start, int len, uint32_t idx) {
-    uint64_t x = (base0 >> (2 * start)) & (len >= 32 ? ~0ull : ((1ull << (2 * len)) - 1ull));
-    uint32_t m = (dmask >> start) & (len >= 32 ? ~0u : ((1u << len) - 1u));
+template <bool LONG>
+__device__ inline typename PrimTraits<LONG>::str_t fast_expand(const PrimRec<LONG> &R, int start, int len, uint32_t idx) {
+    typedef typename PrimTraits<LONG>::plane_t plane_t;
+    typedef typename PrimTraits<LONG>::str_t str_t;
+    const bool all = len >= PrimTraits<LONG>::kMax;
+    str_t x = (R.first() >> (2 * start)) & (all ? ~(str_t)0 : (((str_t)1 << (2 * len)) - 1));
+    plane_t m = (R.dmask >> start) & (all ? ~(plane_t)0 : (((plane_t)1 << len) - 1));
     while (m) {
-        const int p = 31 - __clz((int)m);
-        m &= ~(1u << p);
-        const uint32_t code = c.get(start + p);
+        const int p = high_bit(m);
+        m &= ~((plane_t)1 << p);
+        const uint32_t code = R.code(start + p);
         const uint32_t sz = (uint32_t)__popc(code);                                  // 2, 3 or 4
         const uint32_t q = sz == 3 ? __umulhi(idx, 0xAAAAAAABu) >> 1 : idx >> (sz >> 1);
         const uint32_t r = idx - q * sz;
         idx = q;
-        x = (x & ~(3ull << (2 * p))) | ((uint64_t)member_of(code, r) << (2 * p));
+        x = (x & ~((str_t)3 << (2 * p))) | ((str_t)member_of(code, r) << (2 * p));
     }
     return x;
 }
@@ -291,6 +323,18 @@ __device__ inline uint64_t fast_rc(uint64_t e, int l) {
     uint64_t r = __brevll(~e);
     r = ((r & 0x5555555555555555ull) << 1) | ((r >> 1) & 0x5555555555555555ull);
     return r >> (64 - 2 * l);
+}
+__device__ inline u128 fast_rc(u128 e, int l) {
+    const u128 n = ~e;
+    uint64_t hi = __brevll((uint64_t)n), lo = __brevll((uint64_t)(n >> 64));      // reversed halves change places
+    hi = ((hi & 0x5555555555555555ull) << 1) | ((hi >> 1) & 0x5555555555555555ull);
+    lo = ((lo & 0x5555555555555555ull) << 1) | ((lo >> 1) & 0x5555555555555555ull);
+    return (((u128)hi << 64) | lo) >> (128 - 2 * l);
+}
+__device__ inline int gc_count(uint64_t e, uint64_t mask) { return __popcll((e ^ (e >> 1)) & 0x5555555555555555ull & mask); }      // C = 01, G = 10
+__device__ inline int gc_count(u128 e, u128 mask) {
+    const u128 x = (e ^ (e >> 1)) & mask;
+    return __popcll((uint64_t)x & 0x5555555555555555ull) + __popcll((uint64_t)(x >> 64) & 0x5555555555555555ull);
 }
 
 struct PairEnds { int l_hi, l_lo; };
@@ -306,15 +350,17 @@ __device__ inline PairEnds end_lengths(int lx, int mode) {
 // position: M(s) = length of that run, from four AND-ORs of bit planes and a count of trailing ones.  No end longer than
 // max_s M(s) can match in any expansion, and an end can only sit at an offset with M(s) >= the shortest end length: the filter
 // returns max M and the candidate offsets, 0 / nothing for most pairs.
-__device__ inline int pair_filter(const PrimRec &X, const PrimRec &Y, int l_lo, uint32_t &cand) {
+template <bool LONG>
+__device__ inline int pair_filter(const PrimRec<LONG> &X, const PrimRec<LONG> &Y, int l_lo, typename PrimTraits<LONG>::plane_t &cand) {
+    typedef typename PrimTraits<LONG>::plane_t plane_t;
     int max_m = 0;
-    uint32_t cd = 0;
+    plane_t cd = 0;
     const int ly = Y.len;
     for (int s = 0; s + l_lo <= ly; s++) {
-        const uint32_t m = (X.r[0] & (Y.y[0] >> s)) | (X.r[1] & (Y.y[1] >> s)) | (X.r[2] & (Y.y[2] >> s)) | (X.r[3] & (Y.y[3] >> s));
-        const int run = m == 0xffffffffu ? 32 : __builtin_ctz(~m);
+        const plane_t m = (X.r[0] & (Y.y[0] >> s)) | (X.r[1] & (Y.y[1] >> s)) | (X.r[2] & (Y.y[2] >> s)) | (X.r[3] & (Y.y[3] >> s));
+        const int run = m == ~(plane_t)0 ? PrimTraits<LONG>::kMax : low_bit((plane_t)~m);
         max_m = run > max_m ? run : max_m;
-        cd |= (uint32_t)(run >= l_lo) << s;
+        cd |= (plane_t)(run >= l_lo) << s;
     }
     cand = cd;
     return max_m;
@@ -322,29 +368,31 @@ __device__ inline int pair_filter(const PrimRec &X, const PrimRec &Y, int l_lo, 
 
 // The reference's search (longest end first, expansions of the end, expansions of y; first passing combination) over the end
 // lengths the filter left, looking for RC(end) only at the candidate offsets.
-__device__ inline bool pair_search(const PrimRec &X, const PrimRec &Y, PairEnds E, int max_m, uint32_t cand,
+template <bool LONG>
+__device__ inline bool pair_search(const PrimRec<LONG> &X, const PrimRec<LONG> &Y, PairEnds E, int max_m, typename PrimTraits<LONG>::plane_t cand,
                                    const uint8_t *__restrict__ loss_hit, const double *__restrict__ dg, double dg_limit, int32_t (&rec)[4]) {
+    typedef typename PrimTraits<LONG>::plane_t plane_t;
+    typedef typename PrimTraits<LONG>::str_t str_t;
     const int lx = X.len, ly = Y.len;
-    const Nib cx = nib_of(X), cy = nib_of(Y);
-    const uint64_t bx = (uint64_t)X.base0[0] | ((uint64_t)X.base0[1] << 32), by = (uint64_t)Y.base0[0] | ((uint64_t)Y.base0[1] << 32);
+    const str_t by = Y.first();
     const uint32_t dy = Y.deg;
     for (int l = E.l_hi < max_m ? E.l_hi : max_m; l >= E.l_lo; l--) {
         if (l > ly) continue;
-        const uint64_t mask = l == 32 ? ~0ull : ((1ull << (2 * l)) - 1ull);
-        const uint32_t de = fast_degeneracy(cx, X.dmask, lx - l, l);
+        const str_t mask = l >= PrimTraits<LONG>::kMax ? ~(str_t)0 : (((str_t)1 << (2 * l)) - 1);
+        const uint32_t de = fast_degeneracy<LONG>(X, lx - l, l);
         for (uint32_t ei = 0; ei < de; ei++) {
-            const uint64_t e = fast_expand(cx, bx, X.dmask, lx - l, l, ei);
-            const uint64_t rc = fast_rc(e, l);
+            const str_t e = fast_expand<LONG>(X, lx - l, l, ei);
+            const str_t rc = fast_rc(e, l);
             for (uint32_t pi = 0; pi < dy; pi++) {
-                const uint64_t p = dy == 1 ? by : fast_expand(cy, by, Y.dmask, 0, ly, pi);
+                const str_t p = dy == 1 ? by : fast_expand<LONG>(Y, 0, ly, pi);
                 int idx = -1;
-                for (uint32_t cs = cand; cs; cs &= cs - 1) {                       // str.find: first occurrence
-                    const int s = __ffs((int)cs) - 1;
+                for (plane_t cs = cand; cs; cs &= cs - 1) {                        // str.find: first occurrence
+                    const int s = low_bit(cs);
                     if (s + l > ly) break;
                     if (((p >> (2 * s)) & mask) == rc) { idx = s; break; }
                 }
                 if (idx < 0) continue;
-                const int gc = __popcll((e ^ (e >> 1)) & 0x5555555555555555ull & mask);   // C = 01, G = 10
+                const int gc = gc_count(e, mask);
                 const int d2 = ly - l - idx;
                 bool hit = loss_hit[((size_t)l * (MP_DIMER_MAX_LEN + 1) + gc) * 64 + d2] != 0;
                 if (!hit && d2 == 0) hit = dm_delta_g(e, l, dg) < dg_limit;
@@ -360,15 +408,17 @@ __device__ inline bool pair_search(const PrimRec &X, const PrimRec &Y, PairEnds 
 // search runs with full waves instead of one or two lanes of every wave.  Hits are collected in LDS and appended to the output
 // with ONE device atomic per flush (~n atomics on the shared counter per launch instead of one per hit).
 constexpr int kHitBuf = 1024, kQueue = 2 * kBlock;
-__global__ __launch_bounds__(kBlock) void dimer_rows_kernel(const DimerArgs A, const PrimRec *__restrict__ prim) {
+template <bool LONG>
+__global__ __launch_bounds__(kBlock) void dimer_rows_kernel(const DimerArgs A, const PrimRec<LONG> *__restrict__ prim) {
+    typedef typename PrimTraits<LONG>::plane_t plane_t;
     __shared__ int32_t s_rec[kHitBuf][6];
     __shared__ int32_t s_qy[kQueue];
-    __shared__ uint32_t s_qc[kQueue];
+    __shared__ plane_t s_qc[kQueue];
     __shared__ uint8_t s_qm[kQueue];
     __shared__ int s_n, s_q;
     __shared__ unsigned long long s_base;
     const int x = blockIdx.x;
-    const PrimRec X = prim[x];
+    const PrimRec<LONG> X = prim[x];
     const PairEnds E = end_lengths(X.len, A.mode);
     int y0, y1;                                                     // partners: FD:206-209 (y >= x), MS:199-204 (pairs touching a new primer)
     if (A.mode == 0) { y0 = x; y1 = A.n; }
@@ -380,8 +430,8 @@ __global__ __launch_bounds__(kBlock) void dimer_rows_kernel(const DimerArgs A, c
         const int y = yb + threadIdx.x;
         const bool last = yb + kBlock >= y1;
         if (y < y1) {
-            uint32_t cand;
-            const int max_m = pair_filter(X, prim[y], E.l_lo, cand);
+            plane_t cand;
+            const int max_m = pair_filter<LONG>(X, prim[y], E.l_lo, cand);
             if (max_m >= E.l_lo) {
                 const int at = atomicAdd(&s_q, 1);
                 s_qy[at] = y; s_qc[at] = cand; s_qm[at] = (uint8_t)max_m;
@@ -393,7 +443,7 @@ __global__ __launch_bounds__(kBlock) void dimer_rows_kernel(const DimerArgs A, c
             for (int i = threadIdx.x; i < queued; i += kBlock) {
                 const int yq = s_qy[i];
                 int32_t rec[4];
-                if (pair_search(X, prim[yq], E, s_qm[i], s_qc[i], A.loss_hit, A.dg, A.dg_limit, rec)) {
+                if (pair_search<LONG>(X, prim[yq], E, s_qm[i], s_qc[i], A.loss_hit, A.dg, A.dg_limit, rec)) {
                     const int at = atomicAdd(&s_n, 1);
                     int32_t *r = s_rec[at];
                     r[0] = x; r[1] = yq; r[2] = rec[0]; r[3] = rec[1]; r[4] = rec[2]; r[5] = rec[3];
@@ -421,17 +471,18 @@ __global__ __launch_bounds__(kBlock) void dimer_rows_kernel(const DimerArgs A, c
 }
 
 // explicit ordered pairs (get_multiPrime_V8.py:419-438): one thread per pair, any passing combination
-__global__ __launch_bounds__(kBlock) void dimer_pairs_kernel(const PrimRec *__restrict__ prim, long long n_pairs,
+template <bool LONG>
+__global__ __launch_bounds__(kBlock) void dimer_pairs_kernel(const PrimRec<LONG> *__restrict__ prim, long long n_pairs,
                                                              const int32_t *__restrict__ pairs, const uint8_t *__restrict__ loss_hit,
                                                              const double *__restrict__ dg, double dg_limit, uint8_t *__restrict__ flags) {
     const long long p = (long long)blockIdx.x * kBlock + threadIdx.x;
     if (p >= n_pairs) return;
-    const PrimRec X = prim[pairs[2 * p]], Y = prim[pairs[2 * p + 1]];
+    const PrimRec<LONG> X = prim[pairs[2 * p]], Y = prim[pairs[2 * p + 1]];
     const PairEnds E = end_lengths(X.len, 0);
-    uint32_t cand;
-    const int max_m = pair_filter(X, Y, E.l_lo, cand);
+    typename PrimTraits<LONG>::plane_t cand;
+    const int max_m = pair_filter<LONG>(X, Y, E.l_lo, cand);
     int32_t rec[4];
-    flags[p] = max_m >= E.l_lo && pair_search(X, Y, E, max_m, cand, loss_hit, dg, dg_limit, rec) ? 1 : 0;
+    flags[p] = max_m >= E.l_lo && pair_search<LONG>(X, Y, E, max_m, cand, loss_hit, dg, dg_limit, rec) ? 1 : 0;
 }
 
 // popcount(A[i] | B[j]) per pair: one wave per pair, lanes stride over the set's words (get_multiPrime_V8.py:560-569)
@@ -640,11 +691,13 @@ int dimer_init() {
 }  // namespace mp
 
 namespace {
-static int check_primers(mp_ctx *c, int32_t n, const uint8_t *codes, const int32_t *off) {
+static int check_primers(mp_ctx *c, int32_t n, const uint8_t *codes, const int32_t *off, int max_len = MP_DIMER_MAX_LEN, int *longest = nullptr) {
     static const int msize[16] = {0, 1, 1, 2, 1, 2, 2, 3, 1, 2, 2, 3, 2, 3, 3, 4};
+    if (longest) *longest = 0;
     for (int32_t i = 0; i < n; i++) {
         int len = off[i + 1] - off[i];
-        if (len < 1 || len > MP_DIMER_MAX_LEN) return fail(c, MP_ERR_ARG, "primer %d has length %d (1..%d supported)", i, len, MP_DIMER_MAX_LEN);
+        if (len < 1 || len > max_len) return fail(c, MP_ERR_ARG, "primer %d has length %d (1..%d supported)", i, len, max_len);
+        if (longest && len > *longest) *longest = len;
         long long d = 1;
         for (int p = 0; p < len; p++) {
             uint8_t m = codes[off[i] + p];
@@ -694,7 +747,8 @@ struct Scratch {
 };
 
 // lanes per pair: one thread per pair once there are enough pairs to fill the chip several times over, else a sub-wave
-static int lanes_per_pair(long long n_pairs) {
+static int lanes_per_pair(long long n_pairs, int longest) {
+    if (longest > 32) return 1;                         // primers of more than 32 bases: only the thread-per-pair kernels hold them
     if (const char *e = getenv("MP_DIMER_LANES")) { int g = atoi(e); if (g == 1 || g == 16 || g == 64) return g; }
     return n_pairs <= 32768 ? 64 : (n_pairs <= 262144 ? 16 : 1);
 }
@@ -711,8 +765,8 @@ int mp_dimer_scan(mp_ctx *c, int32_t n, const uint8_t *codes, const int32_t *off
     HIPCK(c, hipSetDevice(c->dev));
     *n_hits = 0;
     if (n == 0) return MP_OK;
-    int rc;
-    if ((rc = check_primers(c, n, codes, off))) return rc;
+    int rc, longest = 0;
+    if ((rc = check_primers(c, n, codes, off, MP_DIMER_MAX_LEN, &longest))) return rc;
     if ((rc = ensure_dimer_tables(c, loss_hit, dg))) return rc;
     const size_t total = (size_t)off[n];
     Scratch sc(c);
@@ -728,12 +782,17 @@ int mp_dimer_scan(mp_ctx *c, int32_t n, const uint8_t *codes, const int32_t *off
     // pairs the scan really visits: mode 1 only those touching one of the n_new new primers
     const long long all = (long long)n * n;
     const long long visited = mode == 0 ? all / 2 + n : (long long)n_new * (2LL * n - n_new);
-    const int G = lanes_per_pair(visited);
-    PrimRec *d_prim = nullptr;                         // (function scope: Scratch frees through the variable's address)
-    if (G == 1) {
+    const int G = lanes_per_pair(visited, longest);
+    PrimRec<false> *d_prim = nullptr;                  // (function scope: Scratch frees through the variables' addresses)
+    PrimRec<true> *d_priml = nullptr;
+    if (G == 1 && longest > 32) {
+        if ((rc = sc.alloc(&d_priml, (size_t)n))) return rc;
+        hipLaunchKernelGGL(prim_kernel<true>, dim3((unsigned)((n + kBlock - 1) / kBlock)), dim3(kBlock), 0, c->stream, d_codes, d_off, (int)n, d_priml);
+        hipLaunchKernelGGL(dimer_rows_kernel<true>, dim3((unsigned)n), dim3(kBlock), 0, c->stream, da, (const PrimRec<true> *)d_priml);
+    } else if (G == 1) {
         if ((rc = sc.alloc(&d_prim, (size_t)n))) return rc;
-        hipLaunchKernelGGL(prim_kernel, dim3((unsigned)((n + kBlock - 1) / kBlock)), dim3(kBlock), 0, c->stream, d_codes, d_off, (int)n, d_prim);
-        hipLaunchKernelGGL(dimer_rows_kernel, dim3((unsigned)n), dim3(kBlock), 0, c->stream, da, (const PrimRec *)d_prim);
+        hipLaunchKernelGGL(prim_kernel<false>, dim3((unsigned)((n + kBlock - 1) / kBlock)), dim3(kBlock), 0, c->stream, d_codes, d_off, (int)n, d_prim);
+        hipLaunchKernelGGL(dimer_rows_kernel<false>, dim3((unsigned)n), dim3(kBlock), 0, c->stream, da, (const PrimRec<false> *)d_prim);
     } else {
         const unsigned blocks = (unsigned)std::min<long long>((all + kBlock / G - 1) / (kBlock / G), 256 * 16);
         if (G == 64) hipLaunchKernelGGL(dimer_group_kernel<64>, dim3(blocks), dim3(kBlock), 0, c->stream, da, all, (const int32_t *)nullptr, (uint8_t *)nullptr);
@@ -757,8 +816,8 @@ int mp_dimer_pairs(mp_ctx *c, int32_t n, const uint8_t *codes, const int32_t *of
         return fail(c, MP_ERR_ARG, "mp_dimer_pairs: bad arguments");
     HIPCK(c, hipSetDevice(c->dev));
     if (n_pairs == 0) return MP_OK;
-    int rc;
-    if ((rc = check_primers(c, n, codes, off))) return rc;
+    int rc, longest = 0;
+    if ((rc = check_primers(c, n, codes, off, MP_DIMER_MAX_LEN, &longest))) return rc;
     for (int64_t p = 0; p < 2 * n_pairs; p++)
         if (pairs[p] < 0 || pairs[p] >= n) return fail(c, MP_ERR_ARG, "pair %lld out of range", (long long)(p / 2));
     if ((rc = ensure_dimer_tables(c, loss_hit, dg))) return rc;
@@ -771,13 +830,19 @@ int mp_dimer_pairs(mp_ctx *c, int32_t n, const uint8_t *codes, const int32_t *of
     HIPCK(c, hipMemcpyAsync(d_codes, codes, total, hipMemcpyHostToDevice, c->stream));
     HIPCK(c, hipMemcpyAsync(d_off, off, sizeof(int32_t) * ((size_t)n + 1), hipMemcpyHostToDevice, c->stream));
     HIPCK(c, hipMemcpyAsync(d_pairs, pairs, sizeof(int32_t) * 2 * (size_t)n_pairs, hipMemcpyHostToDevice, c->stream));
-    const int G = lanes_per_pair((long long)n_pairs);
-    PrimRec *d_prim = nullptr;                         // (function scope: Scratch frees through the variable's address)
-    if (G == 1) {
+    const int G = lanes_per_pair((long long)n_pairs, longest);
+    PrimRec<false> *d_prim = nullptr;                  // (function scope: Scratch frees through the variables' addresses)
+    PrimRec<true> *d_priml = nullptr;
+    if (G == 1 && longest > 32) {
+        if ((rc = sc.alloc(&d_priml, (size_t)n))) return rc;
+        hipLaunchKernelGGL(prim_kernel<true>, dim3((unsigned)((n + kBlock - 1) / kBlock)), dim3(kBlock), 0, c->stream, d_codes, d_off, (int)n, d_priml);
+        hipLaunchKernelGGL(dimer_pairs_kernel<true>, dim3((unsigned)((n_pairs + kBlock - 1) / kBlock)), dim3(kBlock), 0, c->stream,
+                           (const PrimRec<true> *)d_priml, (long long)n_pairs, d_pairs, c->dm_loss, c->dm_dg, dg_limit, d_flags);
+    } else if (G == 1) {
         if ((rc = sc.alloc(&d_prim, (size_t)n))) return rc;
-        hipLaunchKernelGGL(prim_kernel, dim3((unsigned)((n + kBlock - 1) / kBlock)), dim3(kBlock), 0, c->stream, d_codes, d_off, (int)n, d_prim);
-        hipLaunchKernelGGL(dimer_pairs_kernel, dim3((unsigned)((n_pairs + kBlock - 1) / kBlock)), dim3(kBlock), 0, c->stream,
-                           (const PrimRec *)d_prim, (long long)n_pairs, d_pairs, c->dm_loss, c->dm_dg, dg_limit, d_flags);
+        hipLaunchKernelGGL(prim_kernel<false>, dim3((unsigned)((n + kBlock - 1) / kBlock)), dim3(kBlock), 0, c->stream, d_codes, d_off, (int)n, d_prim);
+        hipLaunchKernelGGL(dimer_pairs_kernel<false>, dim3((unsigned)((n_pairs + kBlock - 1) / kBlock)), dim3(kBlock), 0, c->stream,
+                           (const PrimRec<false> *)d_prim, (long long)n_pairs, d_pairs, c->dm_loss, c->dm_dg, dg_limit, d_flags);
     } else {
         DimerArgs da{d_codes, d_off, n, 0, 0, c->dm_loss, c->dm_dg, dg_limit, 0, nullptr, nullptr};
         const unsigned blocks = (unsigned)std::min<long long>((n_pairs + kBlock / G - 1) / (kBlock / G), 256 * 16);
@@ -829,7 +894,7 @@ int mp_pcr_scan(mp_ctx *c, const uint8_t *bytes, const int64_t *row_off, int32_t
     HIPCK(c, hipSetDevice(c->dev));
     if (n_rows == 0 || n_pairs == 0) return MP_OK;
     int rc;
-    if ((rc = check_primers(c, 2 * n_pairs, codes, off))) return rc;
+    if ((rc = check_primers(c, 2 * n_pairs, codes, off, MP_PATTERN_MAX_LEN))) return rc;
     const size_t total = (size_t)(row_off[n_rows] - row_off[0]), ncodes = (size_t)off[2 * n_pairs];
     const size_t nout = (size_t)n_pairs * (size_t)n_rows * 4;
     uint8_t *d_bytes = nullptr, *d_codes = nullptr;
@@ -860,7 +925,7 @@ int mp_pcr_scan(mp_ctx *c, const uint8_t *bytes, const int64_t *row_off, int32_t
             if (side == 0) { prs[(size_t)p].f0 = (int32_t)pats.size(); prs[(size_t)p].nf = (int32_t)d; }
             else { prs[(size_t)p].r0 = (int32_t)pats.size(); prs[(size_t)p].nr = (int32_t)d; }
             for (long long e = 0; e < d; e++) {                      // expansion e: last position fastest (itertools.product)
-                int base[MP_DIMER_MAX_LEN];
+                int base[MP_PATTERN_MAX_LEN];
                 long long idx = e;
                 for (int j = L - 1; j >= 0; j--) {
                     const char *m = members[codes[a0 + j]];

@@ -93,8 +93,8 @@ int mp_kmm_scan(mp_ctx *c, const uint8_t *bytes, const int64_t *row_off, int32_t
     std::vector<KmmPat> pats;
     for (int32_t i = 0; i < n_pat; i++) {
         const int len = pat_off[i + 1] - pat_off[i];
-        if (len < 4 || len > MP_DIMER_MAX_LEN) return fail(c, MP_ERR_ARG, "pattern %d has length %d (4..%d supported)", i, len, MP_DIMER_MAX_LEN);
-        int b[MP_DIMER_MAX_LEN];
+        if (len < 4 || len > MP_PATTERN_MAX_LEN) return fail(c, MP_ERR_ARG, "pattern %d has length %d (4..%d supported)", i, len, MP_PATTERN_MAX_LEN);
+        int b[MP_PATTERN_MAX_LEN];
         for (int j = 0; j < len; j++) {
             const uint8_t m = pat_codes[pat_off[i] + j];
             if (m != 1 && m != 2 && m != 4 && m != 8) return fail(c, MP_ERR_ARG, "pattern %d is not a concrete A/C/G/T sequence", i);

@@ -21,7 +21,8 @@ import numpy as np
 from . import iupac, thermo
 from ._abi import Library
 
-MAX_LEN = 32
+MAX_LEN = 64               # MP_DIMER_MAX_LEN: primers of the dimer scans (adaptor-tailed primers included)
+PATTERN_MAX_LEN = 32       # MP_PATTERN_MAX_LEN: primers of the sequence scans (in-silico PCR, validation)
 HEADERS = ["Primer_ID", "Primer seq", "Primer end", "Delta G", "Primer end length", "End (distance 1)", "End (GC)",
            "Dimer-primer_ID", "Dimer-primer seq", "End (distance 2)", "Loss"]
 
@@ -79,14 +80,14 @@ def dg_limit() -> float:
     return hi
 
 
-def encode_primers(seqs):
+def encode_primers(seqs, max_len: int = MAX_LEN):
     codes = np.concatenate([iupac.codes_of(s) for s in seqs]) if seqs else np.zeros(0, np.uint8)
     off = np.zeros(len(seqs) + 1, np.int32)
     np.cumsum([len(s) for s in seqs], out=off[1:])
     for s in seqs:
-        if not 1 <= len(s) <= MAX_LEN:
-            # the reference has no length limit; this build packs a primer into 64 bits ("Limits")
-            raise ValueError(f"primer length {len(s)} outside 1..{MAX_LEN} (limit of this build, see INTEGRATION.md): {s}")
+        if not 1 <= len(s) <= max_len:
+            # the reference has no length limit; this build packs a primer into 128 (dimer scans) / 64 bits ("Limits")
+            raise ValueError(f"primer length {len(s)} outside 1..{max_len} (limit of this build, see INTEGRATION.md): {s}")
     if (codes == 0).any():
         raise ValueError("primers may only hold IUPAC nucleotide codes")
     return codes, off

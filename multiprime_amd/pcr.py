@@ -16,7 +16,7 @@ import numpy as np
 
 from . import iupac
 from ._abi import Library
-from .dimer import encode_primers
+from .dimer import PATTERN_MAX_LEN, encode_primers
 
 
 class Product(object):
@@ -90,7 +90,7 @@ class Product(object):
         data = np.frombuffer(b"".join(bodies), dtype=np.uint8) if bodies else np.zeros(0, np.uint8)
         names = list(self.primers.keys())
         flat = [s for n in names for s in self.primers[n]]
-        codes, off = encode_primers(flat) if flat else (np.zeros(0, np.uint8), np.zeros(1, np.int32))
+        codes, off = encode_primers(flat, PATTERN_MAX_LEN) if flat else (np.zeros(0, np.uint8), np.zeros(1, np.int32))
         t0 = time.time()
         hits = self.ctx.pcr_scan(data, row_off, codes, off) if names and bodies else np.full((len(names), len(bodies), 4), -1, np.int32)   # -1 = no amplicon (0 would read "expansion 0 at position 0")
         self.stats["scan_s"] = time.time() - t0

@@ -792,10 +792,10 @@ int mp_pcr_scan(mp_ctx *c, const uint8_t *bytes, const int64_t *row_off, int32_t
         return fail(c, MP_ERR_ARG, "mp_pcr_scan: bad arguments");
     for (int32_t i = 0; i < 2 * n_pairs; i++) {
         int len = off[i + 1] - off[i];
-        if (len < 1 || len > MP_DIMER_MAX_LEN || n_expansions(codes + off[i], len) < 0)
+        if (len < 1 || len > MP_PATTERN_MAX_LEN || n_expansions(codes + off[i], len) < 0)
             return fail(c, MP_ERR_ARG, "primer %d is not usable (length %d)", i, len);
     }
-    char f[MP_DIMER_MAX_LEN + 1], r[MP_DIMER_MAX_LEN + 1], rc[MP_DIMER_MAX_LEN + 1];
+    char f[MP_PATTERN_MAX_LEN + 1], r[MP_PATTERN_MAX_LEN + 1], rc[MP_PATTERN_MAX_LEN + 1];
     for (int32_t p = 0; p < n_pairs; p++) {
         const uint8_t *cf = codes + off[2 * p], *cr = codes + off[2 * p + 1];
         int lf = off[2 * p + 1] - off[2 * p], lr = off[2 * p + 2] - off[2 * p + 1];
@@ -836,7 +836,7 @@ int mp_kmm_scan(mp_ctx *c, const uint8_t *bytes, const int64_t *row_off, int32_t
     static const char base_of[9] = {0, 'A', 'C', 0, 'G', 0, 0, 0, 'T'};
     for (int32_t i = 0; i < n_pat; i++) {
         int len = pat_off[i + 1] - pat_off[i];
-        if (len < 4 || len > MP_DIMER_MAX_LEN) return fail(c, MP_ERR_ARG, "pattern %d has length %d (4..%d supported)", i, len, MP_DIMER_MAX_LEN);
+        if (len < 4 || len > MP_PATTERN_MAX_LEN) return fail(c, MP_ERR_ARG, "pattern %d has length %d (4..%d supported)", i, len, MP_PATTERN_MAX_LEN);
         for (int j = 0; j < len; j++) {
             uint8_t m = pat_codes[pat_off[i] + j];
             if (m != 1 && m != 2 && m != 4 && m != 8) return fail(c, MP_ERR_ARG, "pattern %d is not a concrete A/C/G/T sequence", i);

@@ -18,13 +18,18 @@ from multiprime_amd import dimer, iupac, maxset
 
 @pytest.fixture(scope="module")
 def gold():
-    return json.loads(gzip.open(os.path.join(GOLDEN, "dimer_maxset.json.gz")).read())
+    g = json.loads(gzip.open(os.path.join(GOLDEN, "dimer_maxset.json.gz")).read())
+    g.update(json.loads(gzip.open(os.path.join(GOLDEN, "dimer_long.json.gz")).read()))     # primers of 33..64 bases
+    return g
 
 
 FD = [("findimer_cluster0", "cluster0_candidates.fa", 3.96), ("findimer_cluster0_t3", "cluster0_candidates.fa", 3.0),
       ("findimer_syn_a", "findimer_syn_a.fa", 3.96), ("findimer_syn_a_t3", "findimer_syn_a.fa", 3.0),
       ("findimer_syn_b", "findimer_syn_b.fa", 3.96), ("findimer_syn_b_t3", "findimer_syn_b.fa", 3.0)]
-MS = ["maxset_shipped", "maxset_fake1", "maxset_fake2", "maxset_fake3"]
+# adaptor-tailed primers (12..59 nt, an NN-tailed adaptor among them; tests/golden/make_golden_dimer_long.py)
+FD += [("findimer_long_a", "findimer_long_a.fa", 3.96), ("findimer_long_a_t3", "findimer_long_a.fa", 3.0),
+       ("findimer_long_b", "findimer_long_b.fa", 3.96), ("findimer_long_b_t3", "findimer_long_b.fa", 3.0)]
+MS = ["maxset_shipped", "maxset_fake1", "maxset_fake2", "maxset_fake3", "maxset_long1", "maxset_long2"]
 # multi-cluster inputs with planted cross-cluster dimers (tests/golden/make_golden_maxset2.py): pairs are skipped, clusters go
 # to .next.xls (-m T), the maximum-set search back-tracks or dies as the reference does (-m F)
 MS_MULTI = [f"maxset_multi{i}" for i in range(1, 9)]
@@ -98,11 +103,11 @@ def test_maxprimerset_hip_matches_reference(name, method, hip_lib, gold, tmp_pat
     check_maxset(hip_lib, gold, name, method, tmp_path)
 
 
-def random_primers(seed, n, p_deg):
+def random_primers(seed, n, p_deg, max_len=32):
     rng = np.random.default_rng(seed)
     out = []
     for _ in range(n):
-        L = int(rng.integers(4, 33))
+        L = int(rng.integers(4, max_len + 1))
         s = [("ACGT"[int(rng.integers(0, 4))]) for _ in range(L)]
         for p in range(L):
             if rng.random() < p_deg:
@@ -165,3 +170,29 @@ def test_dimer_rows_with_more_hits_than_the_lds_buffer(hip_lib, oracle_lib, mode
     o = oracle_lib.context(0).dimer_scan(*args, cap=1 << 21)
     h = hip_lib.context(0).dimer_scan(*args)                     # default capacity 65536: overflows, reports the count, is re-run
     assert len(o) > 70000 and h.tolist() == o.tolist()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("seed,n,p_deg", [(21, 300, 0.0), (22, 200, 0.02), (23, 120, 0.05), (24, 40, 0.0)])
+def test_primers_of_up_to_64_bases_hip_equals_oracle(hip_lib, oracle_lib, seed, n, p_deg):
+    """Primers of 4..64 bases (the 64-bit-plane / 128-bit-string kernels take every list that holds one of more than 32), both
+    scan modes (end lengths up to 63 in the Maxprimerset mode) and an explicit pair list, planted 3' complementarity, 64-mers."""
+    seqs = random_primers(seed, n, p_deg, max_len=64)
+    seqs = [s if iupac.degeneracy(s) <= 256 else "".join(iupac.expand(c)[0] for c in s) for s in seqs]
+    rng = np.random.default_rng(seed)
+    x64 = "".join("ACGT"[int(x)] for x in rng.integers(0, 4, size=64))
+    # listed first (the "new" primers of the Maxprimerset mode): a 64-mer, a 64-mer whose 3' end pairs with 40 bases of its end, and
+    # a 48-mer whose 3' end pairs with 18 of them
+    seqs = [x64, "ACGTACGTACGTACGTACGTACGT" + iupac.revcomp(x64[-40:]), "TTGACCATGGATCCGGTTAAGCTTGACCAT" + iupac.revcomp(x64[-18:])] + seqs
+    codes, off = dimer.encode_primers(seqs)
+    assert int(np.diff(off).max()) == 64
+    hc, oc = hip_lib.context(0), oracle_lib.context(0)
+    for mode, thr in ((0, 3.96), (1, 3.0)):
+        args = (codes, off, mode, len(seqs) // 3, dimer.cached_loss_table(thr), dimer.dg_params(), dimer.dg_limit())
+        h, o = hc.dimer_scan(*args), oc.dimer_scan(*args)
+        assert len(o) > 0 and h.tolist() == o.tolist(), mode
+        assert int(o[:, 2].max()) == (18 if mode == 0 else 40)                               # the longest end found
+    pairs = rng.integers(0, len(seqs), size=(4000, 2)).astype(np.int32)
+    args = (codes, off, pairs, dimer.cached_loss_table(3.6), dimer.dg_params(), dimer.dg_limit())
+    got, want = hc.dimer_pairs(*args), oc.dimer_pairs(*args)
+    assert want.any() and got.tolist() == want.tolist()

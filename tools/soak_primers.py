@@ -35,7 +35,8 @@ def main():
         try:
             p_deg = float(rng.choice([0.0, 0.03, 0.1, 0.2]))
             # the oracle expands every primer: keep the all-pairs work of a case around a second of CPU
-            seqs = random_primers(seed, int(rng.integers(2, 260 if p_deg < 0.05 else 40)), p_deg)
+            # one case in four holds primers of up to 64 bases (the 64-bit-plane / 128-bit-string kernels)
+            seqs = random_primers(seed, int(rng.integers(2, 260 if p_deg < 0.05 else 40)), p_deg, max_len=64 if rng.random() < 0.25 else 32)
             seqs = [s_ if iupac.degeneracy(s_) <= 256 else "".join(iupac.expand(c)[0] for c in s_) for s_ in seqs]
             codes, off = dimer.encode_primers(seqs)
             for mode, thr in ((0, 3.96), (1, 3.0)):
