@@ -37,7 +37,7 @@
 extern "C" {
 #endif
 
-#define MP_MAX_K 28
+#define MP_MAX_K 31
 #define MP_WIN_SKIP 0x80000000u
 
 #define MP_OK 0

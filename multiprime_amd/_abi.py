@@ -12,7 +12,7 @@ import os
 
 import numpy as np
 
-MP_MAX_K = 28
+MP_MAX_K = 31
 MP_WIN_SKIP = 0x80000000
 MP_ERR_CAPACITY = -4
 MP_ERR_SHORT_WINDOW = -5

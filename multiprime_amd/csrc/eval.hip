@@ -458,7 +458,7 @@ __global__ __launch_bounds__(kBlock) void eval_bits_kernel(const EvalBitsArgs A)
     if (on_patch && slice * 64 * GW >= (int)T.stride) return;               // nothing of this window's patch planes left for the wave
     const size_t nw32 = T.stride;                     // 32-bit words per plane row of the tile
     const bool live = T.live;
-    const uint32_t kbits = (1u << A.k) - 1u;           // k <= MP_MAX_K = 28
+    const uint32_t kbits = (1u << A.k) - 1u;           // k <= MP_MAX_K = 31
     const uint32_t diff = CHAIN ? (__builtin_amdgcn_readfirstlane(A.diff_mask[item]) & kbits) : kbits;
     const uint32_t same = kbits & ~diff;
     uint32_t accP[CC], accF[CC], accR[CC];

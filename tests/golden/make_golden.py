@@ -54,6 +54,8 @@ FIXTURES = {
     "msa1000_k20_d64": (f"{T}/1000_fasta.msa", dict(CFG2, l=20, d=64, v=1)),
     "msa1000_k22_d64": (f"{T}/1000_fasta.msa", dict(CFG2, l=22, d=64, v=1)),
     "msa1000_k18_d10": (f"{T}/1000_fasta.msa", dict(CFG2, l=18, d=10, v=1)),
+    "msa1000_k30_d64": (f"{T}/1000_fasta.msa", dict(CFG2, l=30, d=64, v=2)),
+    "msa1000_k31_d64": (f"{T}/1000_fasta.msa", dict(CFG2, l=31, d=64, v=1)),
     "cluster0_v1": (f"{T}/results/Clusters_msa/Cluster_0_20727.tmsa", dict(YAML, v=1)),
     "cluster0_v2": (f"{T}/results/Clusters_msa/Cluster_0_20727.tmsa", dict(YAML, v=2)),
     "testfa": (f"{T}/test.fa", dict(DEF, v=1)),
@@ -63,6 +65,7 @@ FIXTURES = {
     "syn_ragged": ("@syn_ragged", dict(DEF, l=16, v=1, s=80)),
     "syn_v3_k27": ("@syn_v2", dict(DEF, l=27, v=3, d=32, s=100, c="1,-2", n=6)),
     "syn_edge": ("@syn_edge", dict(DEF, l=15, v=1, s=50, d=16, f=0.7)),
+    "syn_v2_k31": ("@syn_v2", dict(DEF, l=31, v=2, d=64, s=100, c="2,3,-1", n=6)),
 }
 
 

@@ -252,7 +252,7 @@ def test_candidate_grouping_paths_match_oracle(hip_lib, oracle_lib, monkeypatch,
 
 
 @pytest.mark.parametrize("n,k,v", [(1, 5, 0), (63, 2, 1), (64, 16, 2), (65, 17, 1), (257, 27, 2), (2049, 28, 1),
-                                   (33000, 28, 2), (8200, 3, 0), (16500, 21, 1), (700, 20, 3), (40000, 18, 3), (300, 12, 4)])
+                                   (33000, 28, 2), (300, 29, 1), (4100, 30, 3), (33000, 31, 2), (520, 31, 0), (8200, 3, 0), (16500, 21, 1), (700, 20, 3), (40000, 18, 3), (300, 12, 4)])
 def test_kernel_shapes_and_extreme_k(hip_lib, oracle_lib, monkeypatch, n, k, v):
     """Row counts around the word / block boundaries and the smallest and largest k, chains of every kind."""
     v = min(v, k - 1)
