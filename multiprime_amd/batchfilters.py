@@ -153,3 +153,25 @@ def information_of_primers(codes: np.ndarray, gc_range, distance: int):
             info.append("hairpin")
         out.append(gc if not info else "|".join(info))
     return out
+
+
+_FIRST_MASK = np.zeros(16, np.uint8)         # one-hot mask of the first member of a symbol (the reference's member order)
+for _sym, _mem in iupac.MEMBERS.items():
+    if _sym != "-":
+        _FIRST_MASK[iupac.MASK[_sym]] = iupac.MASK[_mem[0]]
+
+
+def hairpin_first_stem_of_primers(codes: np.ndarray, distance: int) -> np.ndarray:
+    """Primers_filter.hairpin_check of get_multiPrime (GM:373-384) per primer (all of one length): only the FIRST expansion of every
+    5-mer stem is tried (the reference's generator quirk), against any expansion of the tail `distance` bases further on."""
+    n, L = codes.shape
+    M = codes
+    stem = _COMP_MASK[_FIRST_MASK[M]]                      # complement of the first member, position by position
+    hit = np.zeros(n, bool)
+    for s in range(0, L - 5 - 5 - distance + 1):
+        for o in range(s + 5 + distance, L - 4):
+            ok = np.ones(n, bool)
+            for j in range(5):                              # RC(stem)[j] = comp(stem[4 - j]) must lie in the set at o + j
+                ok &= (stem[:, s + 4 - j] & M[:, o + j]) != 0
+            hit |= ok
+    return hit

@@ -19,11 +19,10 @@ import json
 import os
 import time
 from bisect import bisect_left
-from statistics import mean
 
 import numpy as np
 
-from . import host, iupac, thermo
+from . import batchfilters, host, iupac, thermo
 from ._abi import Library
 from .dimer import MAX_LEN, dg_limit, encode_primers
 from .filters import _REPEATS
@@ -136,6 +135,14 @@ class Primers_filter(object):
                 return True
         return False
 
+    def _hairpins(self, primers):
+        """hairpin_check of every primer: all at once on the symbol-code matrix when they have one length (they do: adaptor + k-mer)."""
+        if primers and len({len(p) for p in primers}) == 1:
+            codes = iupac.MASK_LUT[np.frombuffer("".join(primers).encode(), np.uint8)].reshape(len(primers), len(primers[0]))
+            if (codes != 0).all():
+                return batchfilters.hairpin_first_stem_of_primers(codes, self.distance).tolist()
+        return [self.hairpin_check(p) for p in primers]
+
     @staticmethod
     def GC_fraction(sequence):
         """GM:451-458: mean (not rounded) of the per-expansion GC fractions rounded to 3 decimals."""
@@ -163,9 +170,10 @@ class Primers_filter(object):
         """GM:477-497."""
         lo, hi = (float(x) for x in self.GC.split(","))
         keep = []
+        hairpin = dict(zip(self.primers, self._hairpins([info[0] for info in self.primers.values()])))
         for pos, info in self.primers.items():
             primer = info[0]
-            if self.hairpin_check(primer):
+            if hairpin[pos]:
                 continue
             gc = self.GC_fraction(primer)
             if gc > hi or gc < lo:
@@ -229,8 +237,9 @@ class Primers_filter(object):
             return
         fwd = [self.primers[p][0] for p in cand]
         rev = [iupac.revcomp(s) for s in fwd]
-        f_ok = [not (self.hairpin_check(adaptor[0] + s) or self.dege_filter_in_term_N_bp(s) or self.GC_clamp(s)) for s in fwd]
-        r_ok = [not (self.hairpin_check(adaptor[1] + s) or self.dege_filter_in_term_N_bp(s) or self.GC_clamp(s)) for s in rev]
+        hp_f, hp_r = self._hairpins([adaptor[0] + s for s in fwd]), self._hairpins([adaptor[1] + s for s in rev])
+        f_ok = [not (h or self.dege_filter_in_term_N_bp(s) or self.GC_clamp(s)) for h, s in zip(hp_f, fwd)]
+        r_ok = [not (h or self.dege_filter_in_term_N_bp(s) or self.GC_clamp(s)) for h, s in zip(hp_r, rev)]
         # every (start, stop) combination the reference reaches its dimer check with, in its order
         combos = []                       # (start index, stop index, distance)
         first_of = [0] * (len(cand) + 1)
@@ -301,7 +310,7 @@ class Primers_filter(object):
                         continue
                     all_coverage = self.number - n_non
                     cover_percentage = round(all_coverage / self.number, 4)
-                    average_tm = str(round(mean([tm[a], tm[b]]), 2))
+                    average_tm = str(round(iupac.exact_mean([tm[a], tm[b]]), 2))      # statistics.mean of two floats
                     primer_pairs.append((fwd[a], rev[b], str(dist) + ":" + average_tm + ":" + str(cover_percentage),
                                          all_coverage, str(cand[a]) + ":" + str(cand[b])))
 

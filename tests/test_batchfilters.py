@@ -77,3 +77,31 @@ def test_segmented_exact_means_equal_statistics_mean():
         else:
             vals = [rng.choice([0.0, 1e-9, 3.3, -7.25, 1e6]) for _ in range(seg[-1])]
         assert _exact_means(vals, seg) == [mean(vals[a:b]) for a, b in zip(seg[:-1], seg[1:])]
+
+
+def test_first_stem_hairpins_equal_the_pairing_step_scalar_check():
+    """batchfilters.hairpin_first_stem_of_primers against Primers_filter.hairpin_check (get_multiPrime's generator quirk: only the
+    first expansion of a stem is tried) on random degenerate primers of several lengths and distances."""
+    import random
+
+    import numpy as np
+
+    from multiprime_amd import batchfilters, iupac
+    from multiprime_amd.pairing import Primers_filter
+
+    class Stub:
+        pass
+    rng = random.Random(4)
+    for L, dist in ((18, 4), (47, 4), (24, 3), (16, 0), (33, 6)):
+        prim = []
+        for _ in range(300):
+            s = [rng.choice("ACGT") for _ in range(L)]
+            for p in range(L):
+                if rng.random() < 0.12:
+                    s[p] = rng.choice("RYMKSWHBVDN")
+            prim.append("".join(s))
+        stub = Stub()
+        stub.distance = dist
+        want = [Primers_filter.hairpin_check(stub, p) for p in prim]
+        codes = iupac.MASK_LUT[np.frombuffer("".join(prim).encode(), np.uint8)].reshape(len(prim), L)
+        assert batchfilters.hairpin_first_stem_of_primers(codes, dist).tolist() == want and any(want)
