@@ -124,26 +124,48 @@ __global__ __launch_bounds__(kBlock) void colplane_kernel(const uint32_t *__rest
 
 
 
-// histograms of two per-row integers: equal values inside a wave are added once (most rows share the value 0 / the alignment
-// width, and a device atomic per row on one address would serialise the launch)
+// histograms of two per-row integers.  Most rows share a value (0 leading gaps, the alignment width), and a device atomic per row on
+// one address would serialise the launch: equal values inside a wave are added once, a workgroup keeps the sums of the values it
+// meets in a small direct-mapped LDS table over its whole share of the rows (a value whose slot is taken goes to HBM directly), and
+// only the table leaves through device atomics — a handful per workgroup.
+constexpr int kHistCache = 256;
 __global__ __launch_bounds__(kBlock) void row_hist_kernel(const int32_t *__restrict__ lead, const int32_t *__restrict__ rstrip, int n_rows,
                                                           int n_bins, unsigned long long *__restrict__ hist, int *__restrict__ overflow) {
-    const int r = blockIdx.x * kBlock + threadIdx.x;
-    const bool active = r < n_rows;
+    __shared__ int s_tag[2][kHistCache];
+    __shared__ unsigned int s_cnt[2][kHistCache];
+    for (int i = threadIdx.x; i < 2 * kHistCache; i += kBlock) { (&s_tag[0][0])[i] = -1; (&s_cnt[0][0])[i] = 0; }
+    __syncthreads();
     const int lane = threadIdx.x & 63;
-    for (int which = 0; which < 2; which++) {
-        const int v = active ? (which ? rstrip[r] : lead[r]) : -1;
-        unsigned long long todo = __ballot(active);
-        while (todo) {
-            const int first = __ffsll((long long)todo) - 1;
-            const int v0 = __shfl(v, first);
-            const unsigned long long same = __ballot(active && v == v0);
-            if (lane == first) {
-                if (v0 >= 0 && v0 < n_bins) atomicAdd(&hist[(size_t)which * n_bins + v0], (unsigned long long)__popcll(same));
-                else atomicExch(overflow, 1);
+    const int rounds = (n_rows + (int)(gridDim.x * kBlock) - 1) / (int)(gridDim.x * kBlock);       // the same trip count for every wave
+    for (int it = 0; it < rounds; it++) {
+        const int r = (it * (int)gridDim.x + (int)blockIdx.x) * kBlock + (int)threadIdx.x;
+        const bool active = r < n_rows;
+        for (int which = 0; which < 2; which++) {
+            const int v = active ? (which ? rstrip[r] : lead[r]) : -1;
+            unsigned long long todo = __ballot(active);
+            while (todo) {
+                const int first = __ffsll((long long)todo) - 1;
+                const int v0 = __shfl(v, first);
+                const unsigned long long same = __ballot(active && v == v0);
+                if (lane == first) {
+                    const unsigned int n = (unsigned int)__popcll(same);
+                    if (v0 < 0 || v0 >= n_bins) atomicExch(overflow, 1);
+                    else {
+                        const int slot = v0 & (kHistCache - 1);
+                        const int seen = atomicCAS(&s_tag[which][slot], -1, v0);
+                        if (seen == -1 || seen == v0) atomicAdd(&s_cnt[which][slot], n);
+                        else atomicAdd(&hist[(size_t)which * n_bins + v0], (unsigned long long)n);
+                    }
+                }
+                todo &= ~same;
             }
-            todo &= ~same;
         }
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < 2 * kHistCache; i += kBlock) {
+        const int which = i / kHistCache, tag = (&s_tag[0][0])[i];
+        const unsigned int n = (&s_cnt[0][0])[i];
+        if (tag >= 0 && n) atomicAdd(&hist[(size_t)which * n_bins + tag], (unsigned long long)n);
     }
 }
 }  // namespace
@@ -241,7 +263,7 @@ int mp_row_histograms(mp_ctx *c, int32_t n_bins, int64_t *lead_hist, int64_t *rs
     hipError_t e = hipMemsetAsync(d_hist, 0, sizeof(unsigned long long) * 2 * (size_t)n_bins, c->stream);
     if (e == hipSuccess) e = hipMemsetAsync(d_over, 0, sizeof(int), c->stream);
     if (e == hipSuccess) {
-        hipLaunchKernelGGL(row_hist_kernel, dim3((unsigned)(c->n_pad / kBlock)), dim3(kBlock), 0, c->stream, (const int32_t *)c->lead,
+        hipLaunchKernelGGL(row_hist_kernel, dim3((unsigned)std::min(c->n_pad / kBlock, 256)), dim3(kBlock), 0, c->stream, (const int32_t *)c->lead,
                            (const int32_t *)c->rstrip, c->n_rows, (int)n_bins, d_hist, d_over);
         e = hipGetLastError();
     }
