@@ -82,9 +82,6 @@ class RowShards:
         out = [p[: n * row_bytes].cpu().numpy().view(dt).reshape((n,) + tail) for p, n in zip(parts, sizes)]
         return np.moveaxis(np.concatenate(out, axis=0), 0, axis)
 
-    def gather_rows(self, arr):
-        return self.gather_var(np.asarray(arr))
-
     def gather_columns(self, arr):
         """[m][n_local] per rank -> [m][n_total] (columns = rows of the alignment)."""
         return self.gather_var(arr, axis=1)
