@@ -33,6 +33,15 @@ for name in sys.argv[1:] or ["msa1000_k18_d64", "msa1000_k20_d64", "msa1000_k22_
             best = dt if best is None else min(best, dt)
         same = open(os.path.join(td, "out.tsv"), "rb").read() == open(os.path.join(G, name + ".tsv"), "rb").read()
         st = {k: round(v, 3) for k, v in app.stats.items() if isinstance(v, float)}
+        # the drop-in script as a user runs it: a fresh process (interpreter, numpy, HIP runtime start-up included)
+        import subprocess
+        t0 = time.time()
+        subprocess.check_call([sys.executable, os.path.join(REPO, "scripts", "multiPrime-core.py"), "-i", inp, "-o", os.path.join(td, "cli.tsv"),
+                               "-l", str(fl["l"]), "-n", str(fl["n"]), "-d", str(fl["d"]), "-v", str(fl["v"]), "-e", str(fl["e"]), "-g", fl["g"],
+                               "-s", str(fl["s"]), "-f", str(fl["f"]), "-c", fl["c"], "-a", str(fl["a"]), "-p", "1"], stdout=subprocess.DEVNULL)
+        cli = time.time() - t0
+        same = same and open(os.path.join(td, "cli.tsv"), "rb").read() == open(os.path.join(G, name + ".tsv"), "rb").read()
         print(json.dumps({"fixture": name, "n_seq": meta["n_seq"], "windows": meta["n_windows"], "wall_s": round(best, 3),
+                          "cli_process_s": round(cli, 2),
                           "reference_wall_s": meta["reference_wall_s"], "speedup": round(meta["reference_wall_s"] / best, 1),
                           "tsv_identical": same, "n_candidates": app.stats.get("n_candidates"), "phases": st}), flush=True)

@@ -26,10 +26,11 @@ out = ["# End-to-end wall time of the drop-in core step on one MI355X box, round
        "# (context_s of tools/load_bench.py below).  reference = multiPrime-core_V20.py, 1 core, authoring container (golden trace meta).",
        "# Every TSV byte-identical to the reference's.  Round-1 figures: profiles/r01_pipeline_times.txt; at mid-round (Python JSON writer,",
        "# scalar Tm / filters) the same fixtures took 0.07-1.3 s.",
-       "fixture             n_seq  windows   cands  wall_s    ref_s  speedup  phases >= 5 ms"]
+       "# cli_s = `python scripts/multiPrime-core.py ...` as a fresh process (interpreter, numpy, HIP start-up included); the reference's figure is its own process.",
+       "fixture             n_seq  windows   cands  wall_s   cli_s    ref_s  speedup  phases >= 5 ms"]
 for r in rows:
     ph = ", ".join(f"{k} {v}" for k, v in r["phases"].items() if v >= 0.005)
-    out.append(f"{r['fixture']:18s} {r['n_seq']:6d} {r['windows']:8d} {r['n_candidates']:7d} {r['wall_s']:7.3f} {r['reference_wall_s']:8.2f} "
+    out.append(f"{r['fixture']:18s} {r['n_seq']:6d} {r['windows']:8d} {r['n_candidates']:7d} {r['wall_s']:7.3f} {r.get('cli_process_s', float('nan')):7.2f} {r['reference_wall_s']:8.2f} "
                f"{r['speedup']:7.1f}x  {ph}")
 a, b = last_json(os.path.join(O, "scale_131k.txt")), last_json(os.path.join(O, "scale_1m.txt"))
 out.append("#")
