@@ -120,6 +120,8 @@ int mp_window_unique(mp_ctx *ctx, int64_t cap_entries, int32_t want_labels, int6
  * words: b0 at [0,n), b1 at [n,2n), g at [2n,3n) with n = total entries. */
 int mp_get_unique(mp_ctx *ctx, int64_t *win_off, uint32_t *words, int32_t *count, int32_t *first_row);
 int mp_get_labels(mp_ctx *ctx, int32_t w, int32_t *labels);
+/* The labels of n windows at once: labels[i][n_rows] = those of windows[i] (one synchronisation for all of them). */
+int mp_get_labels_many(mp_ctx *ctx, int32_t n, const int32_t *windows, int32_t *labels);
 
 /* (3b) per-window base and nearest-neighbour counts ------------------------------------------ */
 /* Replaces state_matrix (V20:541-554) and di_matrix / trans_matrix (V20:556-577), which the

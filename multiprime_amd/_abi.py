@@ -40,6 +40,7 @@ SYMBOLS = [
     ("mp_window_unique", C.c_int, [_p, C.c_int64, C.c_int32, C.POINTER(C.c_int64)]),
     ("mp_get_unique", C.c_int, [_p, _p, _p, _p, _p]),
     ("mp_get_labels", C.c_int, [_p, C.c_int32, _p]),
+    ("mp_get_labels_many", C.c_int, [_p, C.c_int32, _p, _p]),
     ("mp_eval_candidates", C.c_int, [_p, C.c_int32, _p, _p, C.c_uint32, C.c_uint32, _p]),
     ("mp_eval_masks", C.c_int, [_p, C.c_int32, _p, _p, C.c_uint32, C.c_uint32, _p, _p]),
     ("mp_eval_masks_resident", C.c_int, [_p, C.c_int32, _p, _p, C.c_uint32, C.c_uint32]),
@@ -218,8 +219,8 @@ class Context:
         """[len(windows)][n_rows] int32: mp_get_labels of each window as the library returns them (index of the row's entry inside
         the window's segment of mp_get_unique, -1 = the row is not in the histogram)."""
         out = np.empty((max(len(windows), 1), self.n_rows), np.int32)
-        for i, w in enumerate(windows):
-            self._ck(self.d.mp_get_labels(self.h, int(w), _ptr(out[i])))
+        wins = np.ascontiguousarray(windows, dtype=np.int32)
+        self._ck(self.d.mp_get_labels_many(self.h, len(wins), _ptr(wins), _ptr(out)))
         return out[: len(windows)]
 
     # (4)

@@ -315,7 +315,9 @@ class NN_degenerate(object):
                     self._write_bitsets(rows_out)
                 self.stats["bitsets_s"] = time.time() - t0
         if self.comm is None or self.comm.rank == 0:
+            t0 = time.time()
             self._write(rows_out, non_cov_out, gap_out)
+            self.stats["write_s"] = time.time() - t0
         self.stats["run_s"] = time.time() - t_run
         self.stats["n_windows"] = self.n_windows
         self.stats["n_rows"] = len(rows_out)

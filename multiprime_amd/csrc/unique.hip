@@ -556,6 +556,17 @@ int unique_wide(mp_ctx *c, int64_t cap, int32_t want_labels, int64_t *n_entries)
 
 }  // namespace
 
+namespace {
+__global__ __launch_bounds__(kBlock) void gather_labels_kernel(const int32_t *__restrict__ labels, const int32_t *__restrict__ windows, int n,
+                                                               int n_rows, int n_pad, int32_t *__restrict__ out) {
+    const long long total = (long long)n * n_rows;
+    for (long long i = (long long)blockIdx.x * kBlock + threadIdx.x; i < total; i += (long long)gridDim.x * kBlock) {
+        const int w = (int)(i / n_rows), r = (int)(i % n_rows);
+        out[i] = labels[(size_t)windows[w] * n_pad + r];
+    }
+}
+}  // namespace
+
 extern "C" {
 
 int mp_window_unique(mp_ctx *c, int64_t cap, int32_t want_labels, int64_t *n_entries) {
@@ -627,6 +638,32 @@ int mp_get_labels(mp_ctx *c, int32_t w, int32_t *labels) {
     HIPCK(c, hipMemcpy(labels, c->labels + (size_t)w * c->n_pad, sizeof(int32_t) * (size_t)c->n_rows, hipMemcpyDeviceToHost));
     return MP_OK;
 }
-
+int mp_get_labels_many(mp_ctx *c, int32_t n, const int32_t *windows, int32_t *labels) {
+    if (!c) return MP_ERR_ARG;
+    if (!c->labels) return fail(c, MP_ERR_ARG, "labels were not requested");
+    if (n < 0 || (n && (!windows || !labels))) return fail(c, MP_ERR_ARG, "mp_get_labels_many: bad arguments");
+    for (int32_t i = 0; i < n; i++)
+        if (windows[i] < 0 || windows[i] >= c->n_win) return fail(c, MP_ERR_ARG, "bad window");
+    HIPCK(c, hipSetDevice(c->dev));
+    if (n == 0) return MP_OK;
+    // the rows of the asked windows are gathered into one buffer on the device: one copy back instead of one per window
+    int32_t *d_win = nullptr, *d_out = nullptr;
+    int rc;
+    if ((rc = dev_alloc(c, &d_win, (size_t)n))) return rc;
+    if ((rc = dev_alloc(c, &d_out, (size_t)n * c->n_rows))) { dev_free(c, &d_win, (size_t)n); return rc; }
+    hipError_t e = hipMemcpyAsync(d_win, windows, sizeof(int32_t) * (size_t)n, hipMemcpyHostToDevice, c->stream);
+    if (e == hipSuccess) {
+        const long long total = (long long)n * c->n_rows;
+        hipLaunchKernelGGL(gather_labels_kernel, dim3((unsigned)std::min<long long>((total + kBlock - 1) / kBlock, 65535 * 16)), dim3(kBlock), 0,
+                           c->stream, (const int32_t *)c->labels, (const int32_t *)d_win, n, c->n_rows, c->n_pad, d_out);
+        e = hipGetLastError();
+    }
+    if (e == hipSuccess) e = hipMemcpyAsync(labels, d_out, sizeof(int32_t) * (size_t)n * c->n_rows, hipMemcpyDeviceToHost, c->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+    dev_free(c, &d_win, (size_t)n);
+    dev_free(c, &d_out, (size_t)n * c->n_rows);
+    if (e != hipSuccess) return fail(c, MP_ERR_DEVICE, "mp_get_labels_many: %s", hipGetErrorString(e));
+    return MP_OK;
+}
 
 }  // extern "C"

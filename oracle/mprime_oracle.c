@@ -398,6 +398,16 @@ int mp_get_labels(mp_ctx *c, int32_t w, int32_t *labels) {
     return MP_OK;
 }
 
+int mp_get_labels_many(mp_ctx *c, int32_t n, const int32_t *windows, int32_t *labels) {
+    if (!c || !c->labels) return c ? fail(c, MP_ERR_ARG, "labels were not requested") : MP_ERR_ARG;
+    if (n < 0 || (n && (!windows || !labels))) return fail(c, MP_ERR_ARG, "mp_get_labels_many: bad arguments");
+    for (int32_t i = 0; i < n; i++) {
+        int rc = mp_get_labels(c, windows[i], labels + (size_t)i * c->n_rows);
+        if (rc) return rc;
+    }
+    return MP_OK;
+}
+
 /* ---- candidate x sequence evaluation: V20:1103-1130 + Y_distance V20:229-233 --------------- */
 /* Y_distance: position j is a mismatch iff the concrete symbol is not in the IUPAC set of the
  * primer symbol; '-' is in no set (verified exhaustively against score_table). */
