@@ -22,32 +22,44 @@ static void host_code_lut(uint8_t *lut) {
     }
 }
 
-// thread = (row, 32-column chunk); lanes run along rows so that the plane stores coalesce
+// thread = (row, group of 4 chunks = 128 columns); lanes run along rows so that the plane stores coalesce.  A thread reads its 128
+// residues as eight 16-byte loads (rows start at any byte: the hardware takes unaligned global loads) — whole 128-byte lines of a
+// row per thread instead of 32 byte loads — and maps them through a copy of the symbol table in LDS.
+constexpr int kPackChunks = 4;
 __global__ __launch_bounds__(kBlock) void pack_kernel(const uint8_t *__restrict__ bytes, const int64_t *__restrict__ row_off,
-                                                      int n_rows, int n_pad, int /*n_chunks*/, uint32_t *__restrict__ planes) {
-    int r = blockIdx.x * kBlock + threadIdx.x;
-    int c = blockIdx.y;
+                                                      int n_rows, int n_pad, int n_chunks, uint32_t *__restrict__ planes) {
+    __shared__ uint8_t s_lut[256];
+    s_lut[threadIdx.x] = c_code_lut[threadIdx.x];              // kBlock == 256
+    __syncthreads();
+    const int r = blockIdx.x * kBlock + threadIdx.x;
+    const int c0 = blockIdx.y * kPackChunks;
     if (r >= n_pad) return;
-    uint32_t mA = 0, mC = 0, mG = 0, mT = 0;
-    if (r < n_rows) {
-        int64_t o = row_off[r];
-        int64_t len = row_off[r + 1] - o;
-        int64_t col0 = (int64_t)c * 32;
-        const uint8_t *p = bytes + o + col0;
-        int n = (int)(len - col0 < 32 ? (len - col0 < 0 ? 0 : len - col0) : 32);
-        for (int j = 0; j < n; j++) {
-            uint32_t code = c_code_lut[p[j]];
-            mA |= (code & 1u) << j;
-            mC |= ((code >> 1) & 1u) << j;
-            mG |= ((code >> 2) & 1u) << j;
-            mT |= ((code >> 3) & 1u) << j;
+    int64_t o = 0, len = 0;
+    if (r < n_rows) { o = row_off[r]; len = row_off[r + 1] - o; }
+    for (int q = 0; q < kPackChunks; q++) {
+        const int c = c0 + q;
+        if (c >= n_chunks) break;
+        uint32_t mA = 0, mC = 0, mG = 0, mT = 0;
+        const int64_t col0 = (int64_t)c * 32;
+        const int n = (int)(len - col0 < 32 ? (len - col0 < 0 ? 0 : len - col0) : 32);
+        if (n > 0) {
+            uint32_t w[8];                                      // (the byte buffer ends 64 bytes after the last row: reading past a row's end is in bounds)
+            __builtin_memcpy(w, bytes + o + col0, 32);
+#pragma unroll
+            for (int j = 0; j < 32; j++) {
+                const uint32_t code = j < n ? s_lut[(w[j >> 2] >> (8 * (j & 3))) & 255u] : 0u;
+                mA |= (code & 1u) << j;
+                mC |= ((code >> 1) & 1u) << j;
+                mG |= ((code >> 2) & 1u) << j;
+                mT |= ((code >> 3) & 1u) << j;
+            }
         }
+        const size_t base = ((size_t)c * 4) * n_pad + r;
+        planes[base] = mA;
+        planes[base + n_pad] = mC;
+        planes[base + 2 * (size_t)n_pad] = mG;
+        planes[base + 3 * (size_t)n_pad] = mT;
     }
-    size_t base = ((size_t)c * 4) * n_pad + r;
-    planes[base] = mA;
-    planes[base + n_pad] = mC;
-    planes[base + 2 * (size_t)n_pad] = mG;
-    planes[base + 3 * (size_t)n_pad] = mT;
 }
 
 // thread = row: prefix count of residues per chunk, leading-gap length and right-stripped length (V20:625-627), and the
@@ -104,21 +116,39 @@ __global__ __launch_bounds__(kBlock) void row_scan_kernel(const uint32_t *__rest
 // ended.  A concrete candidate symbol then needs ONE plane per position ("matches" = that plane), a
 // degenerate one the OR of its bases' planes.  IUPAC residues set several planes: windows that touch
 // one are always routed to the general path (patch list), never to the bit-sliced pass.
-__global__ __launch_bounds__(kBlock) void colplane_kernel(const uint32_t *__restrict__ planes, int n_pad, int /*n_chunks*/,
-                                                          unsigned long long *__restrict__ cols) {
-    const int r = blockIdx.x * kBlock + threadIdx.x;     // n_pad is a multiple of kBlock: every lane is live
+constexpr int kColBlock = 1024;           // 16 waves = 1024 rows per workgroup: a (column, base) row of 16 words leaves as one 128-byte line
+__global__ __launch_bounds__(kColBlock) void colplane_kernel(const uint32_t *__restrict__ planes, int n_pad, int /*n_chunks*/,
+                                                             unsigned long long *__restrict__ cols) {
+    __shared__ unsigned long long s_tile[32 * 4][kColBlock / 64];
+    const int r = blockIdx.x * kColBlock + threadIdx.x;
     const int c = blockIdx.y;
     const size_t np = (size_t)n_pad, nw = np / 64;
-    const size_t base = ((size_t)c * 4) * np + r;
-    const uint32_t mA = planes[base], mC = planes[base + np], mG = planes[base + 2 * np], mT = planes[base + 3 * np];
-    const int lane = threadIdx.x & 63;
+    uint32_t mA = 0, mC = 0, mG = 0, mT = 0;
+    if (r < n_pad) {
+        const size_t base = ((size_t)c * 4) * np + r;
+        mA = planes[base]; mC = planes[base + np]; mG = planes[base + 2 * np]; mT = planes[base + 3 * np];
+    }
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    // lane j of a wave ends up holding the four words of column j (the ballots over the wave's 64 rows)
+    unsigned long long kA = 0, kC = 0, kG = 0, kT = 0;
+#pragma unroll
     for (int j = 0; j < 32; j++) {
-        unsigned long long xA = __ballot((mA >> j) & 1u), xC = __ballot((mC >> j) & 1u);
-        unsigned long long xG = __ballot((mG >> j) & 1u), xT = __ballot((mT >> j) & 1u);
-        if (lane == 0) {
-            unsigned long long *dst = cols + ((size_t)(c * 32 + j) * 4) * nw + (size_t)(r >> 6);
-            dst[0] = xA; dst[nw] = xC; dst[2 * nw] = xG; dst[3 * nw] = xT;
-        }
+        const unsigned long long xA = __ballot((mA >> j) & 1u), xC = __ballot((mC >> j) & 1u);
+        const unsigned long long xG = __ballot((mG >> j) & 1u), xT = __ballot((mT >> j) & 1u);
+        if (lane == j) { kA = xA; kC = xC; kG = xG; kT = xT; }
+    }
+    if (lane < 32) {
+        s_tile[lane * 4 + 0][wave] = kA; s_tile[lane * 4 + 1][wave] = kC;
+        s_tile[lane * 4 + 2][wave] = kG; s_tile[lane * 4 + 3][wave] = kT;
+    }
+    __syncthreads();
+    // 128 (column, base) rows x 16 words: 8 threads per row store 16 bytes each
+    const int row = threadIdx.x >> 3, w2 = (threadIdx.x & 7) * 2;
+    const size_t word = (size_t)blockIdx.x * (kColBlock / 64) + w2;
+    if (word < nw) {                                             // nw is a multiple of 4 (n_pad of 256): pairs never straddle the end
+        unsigned long long *dst = cols + ((size_t)(c * 32 + (row >> 2)) * 4 + (row & 3)) * nw + word;
+        dst[0] = s_tile[row][w2];
+        dst[1] = s_tile[row][w2 + 1];
     }
 }
 
@@ -224,11 +254,12 @@ int mp_load_msa(mp_ctx *c, const uint8_t *bytes, const int64_t *row_off, int32_t
     HIPCK(c, hipMemcpyAsync(d_off, off0.data(), sizeof(int64_t) * (n_rows + 1), hipMemcpyHostToDevice, c->stream));
     HIPCK(c, hipMemsetAsync(c->ung, 0, sizeof(uint32_t) * np * c->ustride, c->stream));
     HIPCK(c, hipMemsetAsync(c->rlen, 0, sizeof(int32_t) * np, c->stream));
-    dim3 grid((unsigned)(c->n_pad / kBlock), (unsigned)c->n_chunks);
-    hipLaunchKernelGGL(pack_kernel, grid, dim3(kBlock), 0, c->stream, d_bytes, d_off, n_rows, c->n_pad, c->n_chunks, c->planes);
+    hipLaunchKernelGGL(pack_kernel, dim3((unsigned)(c->n_pad / kBlock), (unsigned)((c->n_chunks + kPackChunks - 1) / kPackChunks)), dim3(kBlock), 0,
+                       c->stream, d_bytes, d_off, n_rows, c->n_pad, c->n_chunks, c->planes);
     hipLaunchKernelGGL(row_scan_kernel, dim3(c->n_pad / kBlock), dim3(kBlock), 0, c->stream, c->planes, d_off, n_rows,
                        c->n_pad, c->n_chunks, c->cum, c->lead, c->rstrip, c->rlen, c->ung);
-    hipLaunchKernelGGL(colplane_kernel, grid, dim3(kBlock), 0, c->stream, c->planes, c->n_pad, c->n_chunks, c->cols);
+    hipLaunchKernelGGL(colplane_kernel, dim3((unsigned)((c->n_pad + kColBlock - 1) / kColBlock), (unsigned)c->n_chunks), dim3(kColBlock), 0, c->stream,
+                       c->planes, c->n_pad, c->n_chunks, c->cols);
     HIPCK(c, hipGetLastError());
     HIPCK(c, hipStreamSynchronize(c->stream));
     dev_free(c, &d_bytes, (size_t)total + 64);
