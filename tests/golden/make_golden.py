@@ -56,6 +56,10 @@ FIXTURES = {
     "msa1000_k18_d10": (f"{T}/1000_fasta.msa", dict(CFG2, l=18, d=10, v=1)),
     "msa1000_k30_d64": (f"{T}/1000_fasta.msa", dict(CFG2, l=30, d=64, v=2)),
     "msa1000_k31_d64": (f"{T}/1000_fasta.msa", dict(CFG2, l=31, d=64, v=1)),
+    # other corners of the flag space: one strict position from the 3' end, low coverage, few degenerate positions, tight entropy / GC
+    "msa1000_c1_f06": (f"{T}/1000_fasta.msa", dict(CFG2, l=19, d=16, v=2, c="1,-1", f=0.6, n=2)),
+    "ivc_e30_g": (f"{T}/variation_effect/IVC/IV_C.msa", dict(DEF, v=1, e=3.0, g="0.35,0.55", d=48, n=6, c="4")),
+    "cluster0_v0_d64": (f"{T}/results/Clusters_msa/Cluster_0_20727.tmsa", dict(YAML, v=0, d=64, n=8, f=0.9, a=2)),
     "cluster0_v1": (f"{T}/results/Clusters_msa/Cluster_0_20727.tmsa", dict(YAML, v=1)),
     "cluster0_v2": (f"{T}/results/Clusters_msa/Cluster_0_20727.tmsa", dict(YAML, v=2)),
     "testfa": (f"{T}/test.fa", dict(DEF, v=1)),

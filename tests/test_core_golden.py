@@ -13,8 +13,8 @@ from conftest import GOLDEN, golden_input, load_gz_json
 from multiprime_amd.core import NN_degenerate
 
 FAST = ["syn_iupac", "syn_v2", "syn_ragged", "syn_v3_k27", "syn_edge", "ivc_v0", "ivc_v1", "ivc_v2",
-        "msa1000_k18_d64", "msa1000_k20_d64", "msa1000_k22_d64", "msa1000_k18_d10", "msa1000_k30_d64", "msa1000_k31_d64", "syn_v2_k31"]
-FULL = FAST + ["cluster0_v1", "cluster0_v2", "testfa"]
+        "msa1000_k18_d64", "msa1000_k20_d64", "msa1000_k22_d64", "msa1000_k18_d10", "msa1000_k30_d64", "msa1000_k31_d64", "syn_v2_k31", "msa1000_c1_f06", "ivc_e30_g"]
+FULL = FAST + ["cluster0_v1", "cluster0_v2", "cluster0_v0_d64", "testfa"]
 
 
 def canon_noncov(d):

@@ -180,7 +180,7 @@ def test_plan_refuses_an_exponential_iupac_window():
 
 # ------------------------------------------------------------------------------------------------ reference internals
 TRACED = ["syn_iupac", "syn_v2", "syn_ragged", "syn_v3_k27", "syn_edge", "ivc_v1", "msa1000_k18_d64", "msa1000_k22_d64", "cluster0_v2", "msa1000_k30_d64",
-          "msa1000_k31_d64"]
+          "msa1000_k31_d64", "msa1000_c1_f06", "ivc_e30_g", "cluster0_v0_d64"]
 
 
 @pytest.mark.parametrize("name", TRACED)

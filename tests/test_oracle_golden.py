@@ -12,7 +12,7 @@ from conftest import golden_input, load_gz_json
 from multiprime_amd import iupac
 from multiprime_amd.core import NN_degenerate
 
-NAMES = ["syn_iupac", "syn_v2", "syn_ragged", "syn_v3_k27", "syn_edge", "ivc_v1", "msa1000_k18_d64", "msa1000_k22_d64", "msa1000_k30_d64", "msa1000_k31_d64",
+NAMES = ["syn_iupac", "syn_v2", "syn_ragged", "syn_v3_k27", "syn_edge", "ivc_v1", "msa1000_k18_d64", "msa1000_k22_d64", "msa1000_k30_d64", "msa1000_k31_d64", "msa1000_c1_f06", "ivc_e30_g", "cluster0_v0_d64",
          "cluster0_v2"]
 
 
