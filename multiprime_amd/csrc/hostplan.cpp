@@ -37,6 +37,32 @@ struct Key {                    // k symbol codes, one nibble each (position j =
     }
 };
 
+// Key of a window k-mer given as window words (b0, b1 = base index bits, g = gap flags; mprime.h): the bits of 16 positions are
+// spread to nibble lanes through a byte table and the one-hot symbol codes are formed for all of them at once.
+struct SpreadTable {
+    uint32_t t[256];
+    SpreadTable() {
+        for (int x = 0; x < 256; x++) {
+            uint32_t r = 0;
+            for (int j = 0; j < 8; j++) if ((x >> j) & 1) r |= 1u << (4 * j);
+            t[x] = r;
+        }
+    }
+    uint64_t operator()(uint32_t x16) const { return (uint64_t)t[x16 & 255u] | ((uint64_t)t[(x16 >> 8) & 255u] << 32); }
+};
+inline Key key_from_words(uint32_t b0, uint32_t b1, uint32_t g, uint32_t kmask) {
+    static const SpreadTable spread;
+    const uint32_t valid = kmask & ~g;
+    Key key;
+    for (int half = 0; half < 2; half++) {
+        const int sh = 16 * half;
+        const uint64_t v = spread((valid >> sh) & 0xFFFFu), s0 = spread((b0 >> sh) & 0xFFFFu), s1 = spread((b1 >> sh) & 0xFFFFu);
+        const uint64_t word = (v & ~s0 & ~s1) | ((v & s0 & ~s1) << 1) | ((v & ~s0 & s1) << 2) | ((v & s0 & s1) << 3);
+        (half ? key.hi : key.lo) = word;
+    }
+    return key;
+}
+
 inline uint64_t mix(uint64_t x) {
     x ^= x >> 33; x *= 0xff51afd7ed558ccdULL; x ^= x >> 33; x *= 0xc4ceb9fe1a85ec53ULL; x ^= x >> 33;
     return x;
@@ -396,6 +422,10 @@ void build_tables(Window &w, std::vector<Sight> &sights, int v, int64_t n_exc_co
     }
     w.gap_number = gsum;
     w.cover_number = csum - n_exp + n_exc_cover;      // cover_number counts sequences (V20:702), cover counts expansions
+}
+
+// look-ups into `cover` (perfect coverage of a candidate's expansions, nonsense count): only windows past the gates need them
+void build_cover_map(Window &w) {
     w.cover_map.reset(w.cover.size());
     for (size_t i = 0; i < w.cover.size(); i++) w.cover_map.find_or_insert(w.cover[i].key, w.cover, (int32_t)i);
 }
@@ -437,6 +467,7 @@ int plan_window(mp_plan *p, int wi, std::vector<Sight> &sights, int64_t n_exc_co
     if (bases < 4) { w.status = MP_WIN_FEW_BASES; return MP_OK; }                     // V20:736
     for (int j = 0; j < k; j++)
         if (freq[0 * k + j] + freq[1 * k + j] + freq[2 * k + j] + freq[3 * k + j] == 0) { w.status = MP_WIN_GAP_COLUMN; return MP_OK; }
+    build_cover_map(w);
     NNArr NN;
     memset(&NN, 0, sizeof NN);
     memcpy(NN.v, nn, sizeof(int64_t) * (size_t)(k - 1) * 16);
@@ -540,8 +571,7 @@ int mp_plan_create(const mp_plan_params *params, int64_t n_entries, const int32_
                 const int64_t i = eidx[(size_t)t];
                 const uint32_t b0 = e_words[i], b1 = e_words[(size_t)n_entries + i], g = e_words[2 * (size_t)n_entries + i] & kmask;
                 Sight s;
-                for (int j = 0; j < k; j++)
-                    s.key.set(j, (g >> j) & 1u ? 0u : 1u << (((b0 >> j) & 1u) | (((b1 >> j) & 1u) << 1)));
+                s.key = key_from_words(b0, b1, g, kmask);
                 s.count = e_count[i];
                 s.row = e_first[i];
                 s.sub = 0;
