@@ -1,10 +1,21 @@
 // api.hip — part of libmprime_hip.so: hand-written HIP (gfx950 / MI355X, wave64) behind the C ABI of
 // include/mprime.h.  Context lifetime and bookkeeping.
 #include "common.hpp"
+#include "evaltile.hpp"
 
 namespace mp {
 
+void free_tiles(mp_ctx *c) {
+    dev_free(c, &c->tile_rounds, (size_t)c->tile_n_rounds);
+    dev_free(c, &c->tile_bands, (size_t)c->tile_n_bands);
+    dev_free(c, &c->tile_prog, (size_t)c->tile_n_prog);
+    c->tile_n_rounds = c->tile_n_bands = c->tile_n_slices = c->tile_rc = c->tile_gw = c->tile_n_prog = 0;
+    c->tile_attr_set = false;
+}
+
 void free_eval(mp_ctx *c) {
+    free_tiles(c);
+    c->h_chains.clear(); c->h_events.clear(); c->h_cand_out.clear();
     dev_free(c, &c->items, (size_t)c->n_items);
     dev_free(c, &c->cand_n, (size_t)c->n_padded);
     dev_free(c, &c->cand_out, (size_t)c->n_padded);

@@ -49,6 +49,9 @@ struct ChainItem {
     uint32_t pos1, pos2, pos4;         // positions where that symbol has one / two / more bases
 };
 
+struct TileRound;
+struct TileBand;
+
 struct Nib {          // up to 32 symbol codes, one nibble each
     uint64_t lo, hi;
     __device__ uint32_t get(int j) const { return (uint32_t)((j < 16 ? lo >> (4 * j) : hi >> (4 * (j - 16))) & 15u); }
@@ -147,6 +150,15 @@ struct mp_ctx {
     mp::ChainItem *chain_items = nullptr;
     int32_t *table_ids = nullptr;
     int n_chain = 0, n_table = 0, n_events = 0, max_steps = 0;     // max_steps: members of the longest chain item
+    // LDS-tiled evaluation of the chain items (evaltile.hip): plan built on the first launch after an upload
+    std::vector<mp::ChainItem> h_chains;     // host copies of the chain items (ascending windows) and their events
+    std::vector<uint32_t> h_events;
+    std::vector<int32_t> h_cand_out;         // output slot of every padded candidate
+    mp::TileRound *tile_rounds = nullptr;
+    mp::TileBand *tile_bands = nullptr;
+    uint32_t *tile_prog = nullptr;
+    int tile_n_rounds = 0, tile_n_bands = 0, tile_n_slices = 0, tile_rc = 0, tile_gw = 0, tile_n_prog = 0;
+    bool tile_attr_set = false;
     unsigned launch_seq = 0;                 // launches since the last timing reset
     int32_t *cand_out = nullptr;
     uint32_t sF = 0, sR = 0;
@@ -197,6 +209,7 @@ void dev_free(mp_ctx *c, T **p, size_t n) {
 
 // release the device arrays of one stage (and of every stage that depends on it); api.hip
 void free_eval(mp_ctx *c);
+void free_tiles(mp_ctx *c);
 void free_unique(mp_ctx *c);
 void free_windows(mp_ctx *c);
 void free_msa(mp_ctx *c);

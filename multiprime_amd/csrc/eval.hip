@@ -7,6 +7,8 @@
 //   per-sequence coverage masks — mask_rows_kernel
 #include "common.hpp"
 #include "winwords.hpp"
+#include "bitslice.hpp"
+#include "evaltile.hpp"
 
 using namespace mp;
 
@@ -289,39 +291,6 @@ __global__ __launch_bounds__(kBlock) void patch_planes_kernel(const int32_t *__r
 //   eval_bits_kernel  — any 8 candidates: per position the match word of every possible symbol (11
 //       VALU per word, shared by the candidates), each candidate picks its word by register index.
 // The inputs (N*L/2 bytes of planes) stay in L2 / Infinity Cache across the windows of a launch.
-// truth table of v_bitop3_b32 D = f(S0,S1,S2): bit (S0<<2 | S1<<1 | S2) of the immediate
-template <typename F>
-constexpr int make_lut(F f) {
-    int t = 0;
-    for (int i = 0; i < 8; i++)
-        if (f((i >> 2) & 1, (i >> 1) & 1, i & 1)) t |= 1 << i;
-    return t;
-}
-constexpr int kLutOrAnd = make_lut([](int a, int b, int c) { return a | (b & c); });            // S0 | (S1 & S2)
-constexpr int kLutOrAndNot = make_lut([](int a, int b, int c) { return a | (b & (c ^ 1)); });   // S0 | (S1 & ~S2)
-constexpr int kLutOrNot = make_lut([](int a, int b, int) { return a | (b ^ 1); });              // S0 | ~S1
-constexpr int kLutOrNotAnd = make_lut([](int a, int b, int c) { return a | ((b ^ 1) & c); });   // S0 | (~S1 & S2)
-constexpr int kLutAndNotNot = make_lut([](int a, int b, int c) { return a & (b ^ 1) & (c ^ 1); });   // S0 & ~S1 & ~S2
-constexpr int kLutOr3 = make_lut([](int a, int b, int c) { return a | b | c; });
-constexpr int kLutAndOr = make_lut([](int a, int b, int c) { return (a & b) | c; });            // (S0 & S1) | S2
-static_assert(kLutOrAnd == 0xF8 && kLutAndNotNot == 0x10, "v_bitop3 truth tables");
-
-// add one "mismatch where NOT m" plane to saturating counters
-template <int LV>
-__device__ __forceinline__ void count_unmatched(uint32_t &t1, uint32_t &t2, uint32_t &t3, uint32_t &t4, uint32_t m) {
-    if (LV >= 4) t4 = __builtin_amdgcn_bitop3_b32(t4, t3, m, kLutOrAndNot);
-    if (LV >= 3) t3 = __builtin_amdgcn_bitop3_b32(t3, t2, m, kLutOrAndNot);
-    if (LV >= 2) t2 = __builtin_amdgcn_bitop3_b32(t2, t1, m, kLutOrAndNot);
-    t1 = __builtin_amdgcn_bitop3_b32(t1, m, m, kLutOrNot);
-}
-// add one "mismatch where d" plane
-template <int LV>
-__device__ __forceinline__ void count_plane(uint32_t &t1, uint32_t &t2, uint32_t &t3, uint32_t &t4, uint32_t d) {
-    if (LV >= 4) t4 = __builtin_amdgcn_bitop3_b32(t4, t3, d, kLutOrAnd);
-    if (LV >= 3) t3 = __builtin_amdgcn_bitop3_b32(t3, t2, d, kLutOrAnd);
-    if (LV >= 2) t2 = __builtin_amdgcn_bitop3_b32(t2, t1, d, kLutOrAnd);
-    t1 |= d;
-}
 
 struct BlockMap { int ny, ny_pad, n_items, per_band; };       // see map_block
 
@@ -340,78 +309,6 @@ struct EvalBitsArgs {
     PatchArgs patch;                   // patch / IUPAC rows: the first patch.n_blocks workgroups run on their planes
 };
 
-// Sum over the 64 lanes of a wave with DPP adds only (no LDS); the total ends up in lane 63.  All lanes active.
-__device__ __forceinline__ uint32_t wave_sum_lane63(uint32_t x) {
-    x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0xB1, 0xF, 0xF, true);     // quad_perm [1,0,3,2]
-    x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x4E, 0xF, 0xF, true);     // quad_perm [2,3,0,1]
-    x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x141, 0xF, 0xF, true);    // row_half_mirror
-    x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x140, 0xF, 0xF, true);    // row_mirror: every lane = its row's sum
-    x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x142, 0xA, 0xF, false);   // row_bcast15 into rows 1 and 3
-    x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x143, 0xC, 0xF, false);   // row_bcast31 into rows 2 and 3
-    return x;
-}
-
-// Block totals of the 8 x 3 per-thread popcounts without LDS round trips: two 16-bit counts per word (a wave's
-// sum is at most 64 * 32 * GW), six DPP adds per word leave the wave total in lane 63, which parks it in LDS for
-// the final 24 threads; those add the block's share to the global counters (F_mis = F_raw - perfect).
-template <int GW>
-__device__ __forceinline__ void block_commit(const uint32_t (&accP)[8], const uint32_t (&accF)[8], const uint32_t (&accR)[8],
-                                             uint32_t (&s_part)[kBlock / 64][12], const int32_t *cand_out, unsigned long long *out) {
-    constexpr int CC = 8;
-    static_assert(64 * 32 * GW < 65536, "packed wave sums must fit 16 bits");
-    uint32_t vals[3 * CC];
-#pragma unroll
-    for (int c = 0; c < CC; c++) { vals[3 * c] = accP[c]; vals[3 * c + 1] = accF[c]; vals[3 * c + 2] = accR[c]; }
-    uint32_t tot[3 * CC / 2];
-#pragma unroll
-    for (int q = 0; q < 3 * CC / 2; q++) tot[q] = wave_sum_lane63(vals[2 * q] | (vals[2 * q + 1] << 16));
-    if ((threadIdx.x & 63) == 63) {
-#pragma unroll
-        for (int q = 0; q < 3 * CC / 2; q++) s_part[threadIdx.x >> 6][q] = tot[q];
-    }
-    __syncthreads();
-    if (threadIdx.x < 3 * CC) {
-        const int c = threadIdx.x / 3, r = threadIdx.x % 3;
-        uint32_t mine = 0, perfect = 0;
-#pragma unroll
-        for (int w = 0; w < kBlock / 64; w++) {
-            mine += (s_part[w][threadIdx.x >> 1] >> (16 * (threadIdx.x & 1))) & 0xFFFFu;
-            perfect += (s_part[w][(3 * c) >> 1] >> (16 * ((3 * c) & 1))) & 0xFFFFu;
-        }
-        const uint32_t val = r ? mine - perfect : mine;
-        const int oc = cand_out[c];
-        if (oc >= 0 && val) atomicAdd(&out[(size_t)oc * 3 + r], (unsigned long long)val);
-    }
-}
-
-// The same for ONE wave (a patch unit): lane 63's totals go through the wave's own LDS row, lanes 0..23 add them.
-template <int GW>
-__device__ __forceinline__ void wave_commit(const uint32_t (&accP)[8], const uint32_t (&accF)[8], const uint32_t (&accR)[8],
-                                            uint32_t (&s_part)[kBlock / 64][12], const int32_t *cand_out, unsigned long long *out) {
-    constexpr int CC = 8;
-    uint32_t vals[3 * CC];
-#pragma unroll
-    for (int c = 0; c < CC; c++) { vals[3 * c] = accP[c]; vals[3 * c + 1] = accF[c]; vals[3 * c + 2] = accR[c]; }
-    uint32_t tot[3 * CC / 2];
-#pragma unroll
-    for (int q = 0; q < 3 * CC / 2; q++) tot[q] = wave_sum_lane63(vals[2 * q] | (vals[2 * q + 1] << 16));
-    const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    if (lane == 63) {
-#pragma unroll
-        for (int q = 0; q < 3 * CC / 2; q++) s_part[wv][q] = tot[q];
-    }
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-    if (lane < 3 * CC) {
-        const int c = lane / 3, r = lane % 3;
-        const uint32_t mine = (s_part[wv][lane >> 1] >> (16 * (lane & 1))) & 0xFFFFu;
-        const uint32_t perfect = (s_part[wv][(3 * c) >> 1] >> (16 * ((3 * c) & 1))) & 0xFFFFu;
-        const uint32_t val = r ? mine - perfect : mine;
-        const int oc = cand_out[c];
-        if (oc >= 0 && val) atomicAdd(&out[(size_t)oc * 3 + r], (unsigned long long)val);
-    }
-}
 
 // XCD-aware block mapping shared by both kernels: workgroup b runs on XCD b % 8 (observed dispatch order) and every
 // XCD has its own L2, so the (item, row slice) grid is laid out to let consecutive windows re-read their k-1 shared
@@ -596,7 +493,7 @@ __global__ __launch_bounds__(kBlock) void eval_bits_kernel(const EvalBitsArgs A)
             }
         }
     }
-    if (on_patch) wave_commit<GW>(accP, accF, accR, s_part, A.cand_out + it.cand0, A.out);
+    if (on_patch) wave_commit<GW>(accP, accF, accR, s_part[threadIdx.x >> 6], A.cand_out + it.cand0, A.out);
     else block_commit<GW>(accP, accF, accR, s_part, A.cand_out + it.cand0, A.out);
 }
 
@@ -790,7 +687,7 @@ __global__ __launch_bounds__(kBlock) void eval_chain_kernel(const EvalChainArgs 
     uint32_t accP[CC], accF[CC], accR[CC];
 #pragma unroll
     for (int c = 0; c < CC; c++) { accP[c] = acc[c] & 1023u; accF[c] = (acc[c] >> 10) & 1023u; accR[c] = acc[c] >> 20; }
-    if (on_patch) wave_commit<GW>(accP, accF, accR, s_part, A.cand_out + it.cand0, A.out);
+    if (on_patch) wave_commit<GW>(accP, accF, accR, s_part[threadIdx.x >> 6], A.cand_out + it.cand0, A.out);
     else block_commit<GW>(accP, accF, accR, s_part, A.cand_out + it.cand0, A.out);
 }
 
@@ -888,7 +785,7 @@ __global__ __launch_bounds__(kBlock) void eval_chain_long_kernel(const EvalChain
             }
         }
         if (on_patch) {
-            wave_commit<GW>(accP, accF, accR, s_part, A.cand_out + it.cand0 + g0, A.out);
+            wave_commit<GW>(accP, accF, accR, s_part[threadIdx.x >> 6], A.cand_out + it.cand0 + g0, A.out);
         } else {
             if (g0) __syncthreads();                       // the previous group's totals have been read out of s_part
             block_commit<GW>(accP, accF, accR, s_part, A.cand_out + it.cand0 + g0, A.out);
@@ -1152,6 +1049,33 @@ PatchArgs patch_args(const mp_ctx *c, int GW, int n_items, int unit_threads) {
     return pa;
 }
 
+// Plan of the LDS-tiled evaluation for the staged chain items (rebuilt after an upload or when the tile shape changes).
+int ensure_tile_plan(mp_ctx *c, int gw) {
+    if (c->tile_gw == gw && c->tile_rounds) return MP_OK;
+    free_tiles(c);
+    const int nw32 = c->n_pad / 32, tw = tile_words(gw);
+    const int per_cu = gw == 4 ? 1 : 2;
+    int groups = 256 * per_cu;
+    if (const char *e = getenv("MP_EVAL_TILE_GROUPS")) groups = std::max(1, atoi(e));
+    TilePlan P;
+    const int n_slices = (nw32 + tw - 1) / tw, rc_cols = tile_ring_cols(gw, per_cu);
+    plan_tiles(c->h_chains, c->h_events, c->h_cand_out, c->p0, c->k, c->sF, c->sR, gw, rc_cols, n_slices, groups, P);
+    int rc;
+    if ((rc = dev_alloc(c, &c->tile_rounds, P.rounds.size()))) return rc;
+    c->tile_n_rounds = (int)P.rounds.size();
+    if ((rc = dev_alloc(c, &c->tile_bands, P.bands.size()))) return rc;
+    c->tile_n_bands = (int)P.bands.size();
+    c->tile_gw = gw;
+    if ((rc = dev_alloc(c, &c->tile_prog, P.prog.size()))) return rc;
+    c->tile_n_prog = (int)P.prog.size();
+    HIPCK(c, hipMemcpy(c->tile_rounds, P.rounds.data(), sizeof(TileRound) * P.rounds.size(), hipMemcpyHostToDevice));
+    HIPCK(c, hipMemcpy(c->tile_bands, P.bands.data(), sizeof(TileBand) * P.bands.size(), hipMemcpyHostToDevice));
+    HIPCK(c, hipMemcpy(c->tile_prog, P.prog.data(), sizeof(uint32_t) * P.prog.size(), hipMemcpyHostToDevice));
+    c->tile_n_slices = n_slices;
+    c->tile_rc = rc_cols;
+    return MP_OK;
+}
+
 }  // namespace
 
 extern "C" {
@@ -1303,6 +1227,9 @@ int mp_eval_upload(mp_ctx *c, int32_t n_cand, const int32_t *cw, const uint8_t *
     c->n_chain = (int)chains.size(); c->n_table = (int)table_ids.size(); c->n_events = (int)events.size();
     c->max_steps = 0;
     for (const ChainItem &ch : chains) c->max_steps = std::max(c->max_steps, (int)ch.n_steps);
+    c->h_chains = chains;
+    c->h_events = events;
+    c->h_cand_out = co;
     if (c->n_chain) {
         if ((rc = dev_alloc(c, &c->chain_items, chains.size()))) return rc;
         HIPCK(c, hipMemcpy(c->chain_items, chains.data(), sizeof(ChainItem) * chains.size(), hipMemcpyHostToDevice));
@@ -1391,8 +1318,22 @@ int mp_eval_launch(mp_ctx *c, int64_t *device_out) {
             const BlockMap bm = block_map(cgw[cshape], c->n_chain, grid);
             EvalChainArgs ca{c->cols, c->excl, nw, c->p0, c->k, c->v, c->chain_items, c->chain_events, c->cand_out, c->sF, c->sR,
                              (unsigned long long *)device_out, bm, patch_args(c, cgw[cshape], c->n_chain, 64)};
-            hipLaunchKernelGGL((c->max_steps > kEvalCC ? lfn : cfn)[c->v][cshape], dim3(grid + (unsigned)ca.patch.n_blocks), dim3(kBlock), 0,
-                               c->stream, ca);
+            // LDS-tiled sweep (evaltile.hip) for chains of up to 8 members: the column planes of a band of windows are staged once
+            // per workgroup instead of being re-read from L2 by every covering window.  Measured SLOWER than the kernels below
+            // at every size (profiles/r03_tile_*.txt), so it runs only on request: MP_EVAL_TILE=2 / 4 row
+            // words per lane.
+            int tile_gw = 0;
+            if (const char *e = getenv("MP_EVAL_TILE")) { const int t = atoi(e); tile_gw = (t == 2 || t == 4) && c->max_steps <= kEvalCC ? t : 0; }
+            if (tile_gw) {
+                int rc = ensure_tile_plan(c, tile_gw);
+                if (rc) return rc;
+                if (ca.patch.n_blocks)          // the patch planes of the same items: wave-per-unit blocks of the chain kernel
+                    hipLaunchKernelGGL(cfn[c->v][cshape], dim3((unsigned)ca.patch.n_blocks), dim3(kBlock), 0, c->stream, ca);
+                if ((rc = launch_eval_tile(c, tile_gw, (unsigned long long *)device_out))) return rc;
+            } else {
+                hipLaunchKernelGGL((c->max_steps > kEvalCC ? lfn : cfn)[c->v][cshape], dim3(grid + (unsigned)ca.patch.n_blocks), dim3(kBlock), 0,
+                                   c->stream, ca);
+            }
         }
         const int n_tab = shape == 0 ? c->n_table : c->n_items;
         if (n_tab) {

@@ -4,7 +4,8 @@ candidates as bench.py); checks that every variant returns the counters of the f
 
   --mode rows   MP_EVAL_VARIANT numbers of the row-per-lane kernel (profiles/r01_variants.txt)
   --mode bits   bN = symbol-table kernel (MP_EVAL_BITS=N), cN = nested-chain kernel shape (MP_EVAL_CHAIN=N)
-                e.g. --variants b1 b2 c3 c7   (profiles/r01_variants_v4.txt)
+                tN = LDS-tiled sweep with N row words per lane (MP_EVAL_TILE=N), tN:G with G workgroups aimed at
+                e.g. --variants b1 b2 c3 c7 t4 t2   (profiles/r01_variants_v4.txt)
   --rows / --cands / --v   shard depth, candidates per window (a chain of that length), mismatch tolerance"""
 import argparse
 import json
@@ -58,8 +59,18 @@ def main():
         os.environ["MP_EVAL_MODE"] = a.mode
         if a.mode == "rows":
             os.environ["MP_EVAL_VARIANT"] = var
+        elif var.startswith("t"):                        # LDS-tiled sweep, tN[:groups] = N row words per lane
+            os.environ["MP_EVAL_BITS"] = "0"
+            os.environ.pop("MP_EVAL_CHAIN", None)
+            os.environ["MP_EVAL_TILE"] = var[1:].split(":")[0]
+            if ":" in var:
+                os.environ["MP_EVAL_TILE_GROUPS"] = var.split(":")[1]
+            else:
+                os.environ.pop("MP_EVAL_TILE_GROUPS", None)
+            ctx.eval_upload(cw, codes, sF, sR)           # a new plan
         elif var.startswith("c"):
             os.environ["MP_EVAL_BITS"] = "0"
+            os.environ["MP_EVAL_TILE"] = "0"
             os.environ["MP_EVAL_CHAIN"] = var[1:]
         else:
             os.environ["MP_EVAL_BITS"] = var[1:]
