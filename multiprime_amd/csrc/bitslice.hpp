@@ -114,4 +114,65 @@ __device__ __forceinline__ void wave_commit(const uint32_t (&accP)[8], const uin
     }
 }
 
+// Patch planes and the (item, row slice) -> workgroup mapping shared by eval.hip and evalprog.hip (see eval.hip)
+struct PatchArgs {
+    const uint32_t *pplanes;
+    const uint32_t *pvalid;
+    const PatchWin *pwin;      // [W]
+    int per_item;              // patch units per item (0: no patch rows anywhere); a unit = one WAVE in the evaluation kernels
+                               // (4 items' patch planes per workgroup: they are a few hundred rows each), one workgroup in window_stats
+    int n_blocks;              // workgroups holding the units, rounded up to a multiple of 8; they come first in the grid
+};
+
+struct WordTile {
+    const uint32_t *planes;    // plane (j, base) of the tile's first word: planes + (j * 4 + base) * stride
+    const uint32_t *mask;      // validity words: valid = mask[i] ^ mask_flip
+    uint32_t stride, mask_flip;
+    bool live;
+};
+
+// words [word0, word0 + GW) of the column planes of window `win` (valid = not excluded) ...
+__device__ __forceinline__ WordTile column_tile(const unsigned long long *cols, const unsigned long long *excl, int nw, int p0,
+                                                int win, int word0) {
+    const size_t nw32 = (size_t)nw * 2;
+    WordTile t;
+    t.planes = reinterpret_cast<const uint32_t *>(cols) + ((size_t)(p0 + win) * 4) * nw32 + word0;
+    t.mask = reinterpret_cast<const uint32_t *>(excl) + (size_t)win * nw32 + word0;
+    t.stride = (uint32_t)nw32;
+    t.mask_flip = 0xFFFFFFFFu;
+    t.live = word0 < (int)nw32;                        // nw32 % GW == 0 (n_pad % 256 == 0, GW <= 8)
+    return t;
+}
+// ... or of the window's patch planes
+__device__ __forceinline__ WordTile patch_tile(const PatchArgs &P, int win, int word0) {
+    const PatchWin pw = P.pwin[win];
+    WordTile t;
+    t.planes = P.pplanes + pw.poff + word0;
+    t.mask = P.pvalid + pw.voff + word0;
+    t.stride = (uint32_t)pw.npw;
+    t.mask_flip = 0u;
+    t.live = word0 < pw.npw;                           // npw % 8 == 0
+    return t;
+}
+
+struct BlockMap { int ny, ny_pad, n_items, per_band; };       // see map_block
+
+// XCD-aware block mapping shared by both kernels: workgroup b runs on XCD b % 8 (observed dispatch order) and every
+// XCD has its own L2, so the (item, row slice) grid is laid out to let consecutive windows re-read their k-1 shared
+// columns from ONE L2.  With 8 or more slices (ny_pad a multiple of 8) slice = b % ny_pad: an XCD owns slices.  With
+// fewer (ny_pad = 1, 2, 4) an XCD owns one slice and one of 8 / ny_pad contiguous BANDS of items — otherwise two
+// XCDs would walk the same slice with interleaved windows and each pull every column from HBM.
+__device__ __forceinline__ bool map_block(const BlockMap &M, unsigned b, int &slice, int &idx) {
+    if (M.ny_pad >= 8) {
+        slice = (int)(b % (unsigned)M.ny_pad);
+        idx = (int)(b / (unsigned)M.ny_pad);
+    } else {
+        const int xcd = (int)(b & 7u);
+        slice = xcd % M.ny_pad;
+        idx = (xcd / M.ny_pad) * M.per_band + (int)(b >> 3);
+        if ((int)(b >> 3) >= M.per_band) return false;
+    }
+    return slice < M.ny && idx < M.n_items;
+}
+
 }  // namespace mp

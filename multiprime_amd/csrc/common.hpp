@@ -154,6 +154,8 @@ struct mp_ctx {
     std::vector<mp::ChainItem> h_chains;     // host copies of the chain items (ascending windows) and their events
     std::vector<uint32_t> h_events;
     std::vector<int32_t> h_cand_out;         // output slot of every padded candidate
+    uint32_t *chain_prog = nullptr;          // fetch programs of the chain items (evalprog.hip), chains of up to 8 members only
+    size_t chain_prog_n = 0;
     mp::TileRound *tile_rounds = nullptr;
     mp::TileBand *tile_bands = nullptr;
     uint32_t *tile_prog = nullptr;

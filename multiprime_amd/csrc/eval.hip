@@ -9,6 +9,7 @@
 #include "winwords.hpp"
 #include "bitslice.hpp"
 #include "evaltile.hpp"
+#include "evalprog.hpp"
 
 using namespace mp;
 
@@ -196,46 +197,6 @@ __global__ __launch_bounds__(kBlock) void eval_kernel(const EvalArgs A) {
 // A bit-sliced workgroup then either covers a slice of the alignment's columns or the patch planes of its item's
 // window (`WordTile`); the kernels do not care which.
 // ----------------------------------------------------------------------------------------------
-struct PatchArgs {
-    const uint32_t *pplanes;
-    const uint32_t *pvalid;
-    const PatchWin *pwin;      // [W]
-    int per_item;              // patch units per item (0: no patch rows anywhere); a unit = one WAVE in the evaluation kernels
-                               // (4 items' patch planes per workgroup: they are a few hundred rows each), one workgroup in window_stats
-    int n_blocks;              // workgroups holding the units, rounded up to a multiple of 8; they come first in the grid
-};
-
-struct WordTile {
-    const uint32_t *planes;    // plane (j, base) of the tile's first word: planes + (j * 4 + base) * stride
-    const uint32_t *mask;      // validity words: valid = mask[i] ^ mask_flip
-    uint32_t stride, mask_flip;
-    bool live;
-};
-
-// words [word0, word0 + GW) of the column planes of window `win` (valid = not excluded) ...
-__device__ __forceinline__ WordTile column_tile(const unsigned long long *cols, const unsigned long long *excl, int nw, int p0,
-                                                int win, int word0) {
-    const size_t nw32 = (size_t)nw * 2;
-    WordTile t;
-    t.planes = reinterpret_cast<const uint32_t *>(cols) + ((size_t)(p0 + win) * 4) * nw32 + word0;
-    t.mask = reinterpret_cast<const uint32_t *>(excl) + (size_t)win * nw32 + word0;
-    t.stride = (uint32_t)nw32;
-    t.mask_flip = 0xFFFFFFFFu;
-    t.live = word0 < (int)nw32;                        // nw32 % GW == 0 (n_pad % 256 == 0, GW <= 8)
-    return t;
-}
-// ... or of the window's patch planes
-__device__ __forceinline__ WordTile patch_tile(const PatchArgs &P, int win, int word0) {
-    const PatchWin pw = P.pwin[win];
-    WordTile t;
-    t.planes = P.pplanes + pw.poff + word0;
-    t.mask = P.pvalid + pw.voff + word0;
-    t.stride = (uint32_t)pw.npw;
-    t.mask_flip = 0u;
-    t.live = word0 < pw.npw;                           // npw % 8 == 0
-    return t;
-}
-
 // one block per window: 64 rows per wave pass, one ballot per (position, base)
 __global__ __launch_bounds__(kBlock) void patch_planes_kernel(const int32_t *__restrict__ off_a, const uint32_t *__restrict__ words_a,
                                                               const int32_t *__restrict__ off_b, const uint32_t *__restrict__ words_b,
@@ -292,7 +253,6 @@ __global__ __launch_bounds__(kBlock) void patch_planes_kernel(const int32_t *__r
 //       VALU per word, shared by the candidates), each candidate picks its word by register index.
 // The inputs (N*L/2 bytes of planes) stay in L2 / Infinity Cache across the windows of a launch.
 
-struct BlockMap { int ny, ny_pad, n_items, per_band; };       // see map_block
 
 struct EvalBitsArgs {
     const unsigned long long *cols;    // [n_cols][4][nw]
@@ -309,24 +269,6 @@ struct EvalBitsArgs {
     PatchArgs patch;                   // patch / IUPAC rows: the first patch.n_blocks workgroups run on their planes
 };
 
-
-// XCD-aware block mapping shared by both kernels: workgroup b runs on XCD b % 8 (observed dispatch order) and every
-// XCD has its own L2, so the (item, row slice) grid is laid out to let consecutive windows re-read their k-1 shared
-// columns from ONE L2.  With 8 or more slices (ny_pad a multiple of 8) slice = b % ny_pad: an XCD owns slices.  With
-// fewer (ny_pad = 1, 2, 4) an XCD owns one slice and one of 8 / ny_pad contiguous BANDS of items — otherwise two
-// XCDs would walk the same slice with interleaved windows and each pull every column from HBM.
-__device__ __forceinline__ bool map_block(const BlockMap &M, unsigned b, int &slice, int &idx) {
-    if (M.ny_pad >= 8) {
-        slice = (int)(b % (unsigned)M.ny_pad);
-        idx = (int)(b / (unsigned)M.ny_pad);
-    } else {
-        const int xcd = (int)(b & 7u);
-        slice = xcd % M.ny_pad;
-        idx = (xcd / M.ny_pad) * M.per_band + (int)(b >> 3);
-        if ((int)(b >> 3) >= M.per_band) return false;
-    }
-    return slice < M.ny && idx < M.n_items;
-}
 
 // GW 32-bit words (32 sequences each) per thread, LV = v + 1 saturating counter levels.
 // CHAIN: positions where all 8 candidates carry the same symbol (not in diff_mask, from the host) update ONE
@@ -1230,6 +1172,13 @@ int mp_eval_upload(mp_ctx *c, int32_t n_cand, const int32_t *cw, const uint8_t *
     c->h_chains = chains;
     c->h_events = events;
     c->h_cand_out = co;
+    if (c->n_chain && c->max_steps <= kEvalCC && getenv("MP_EVAL_PROG") && atoi(getenv("MP_EVAL_PROG")) == 1) {          // fetch programs of the chain items (evalprog.hip)
+        std::vector<uint32_t> prog;
+        build_eval_programs(chains, events, co, k, sF, sR, prog);
+        if ((rc = dev_alloc(c, &c->chain_prog, prog.size()))) return rc;
+        c->chain_prog_n = prog.size();
+        HIPCK(c, hipMemcpy(c->chain_prog, prog.data(), sizeof(uint32_t) * prog.size(), hipMemcpyHostToDevice));
+    }
     if (c->n_chain) {
         if ((rc = dev_alloc(c, &c->chain_items, chains.size()))) return rc;
         HIPCK(c, hipMemcpy(c->chain_items, chains.data(), sizeof(ChainItem) * chains.size(), hipMemcpyHostToDevice));
@@ -1330,6 +1279,12 @@ int mp_eval_launch(mp_ctx *c, int64_t *device_out) {
                 if (ca.patch.n_blocks)          // the patch planes of the same items: wave-per-unit blocks of the chain kernel
                     hipLaunchKernelGGL(cfn[c->v][cshape], dim3((unsigned)ca.patch.n_blocks), dim3(kBlock), 0, c->stream, ca);
                 if ((rc = launch_eval_tile(c, tile_gw, (unsigned long long *)device_out))) return rc;
+            } else if (c->chain_prog && getenv("MP_EVAL_PROG") && atoi(getenv("MP_EVAL_PROG")) == 1) {
+                // program-driven kernel (evalprog.hip): same arithmetic and block map, fetches by buffer loads with D of them in
+                // flight all the time.  Measured equal to eval_chain_kernel within +-10 % (profiles/r03_prog_variants_*.txt, DESIGN.md
+                // section 9), so it runs only on request: MP_EVAL_PROG=1.
+                int rc = launch_eval_prog(c, cshape, bm, ca.patch, grid, (unsigned long long *)device_out);
+                if (rc) return rc;
             } else {
                 hipLaunchKernelGGL((c->max_steps > kEvalCC ? lfn : cfn)[c->v][cshape], dim3(grid + (unsigned)ca.patch.n_blocks), dim3(kBlock), 0,
                                    c->stream, ca);

@@ -1,0 +1,25 @@
+// evalprog.hpp — fetch programs of the chain items (evalprog.hip): layout constants and entry points.
+//
+// One block of kProgRegs x 64 32-bit entries per chain item, register q = entries [64 q, 64 q + 64), one entry per lane:
+//   register 0: lanes 0-23 the output slot (candidate index or -1) of counter lane / 3 — where the commit's lanes look for it;
+//               lanes 32-36 the header {win, cand0, n_steps, n_ev, n_fp}
+//   registers 1, 2: the n_fp fetches of the first pass (the most degenerate member over all k positions), one per base of a
+//               position's symbol: single-base positions first, then the others; kMore = further bases of this position follow,
+//               kCont = not the first base of its position
+//   registers 3, 4: the events (one lost base each), ascending by step
+// entry = plane row (window position * 4 + base) | strict-position flags | chain step << 24 (events)
+#pragma once
+
+#include "common.hpp"
+#include "bitslice.hpp"
+
+namespace mp {
+
+constexpr int kProgRegs = 5;
+constexpr uint32_t kRowMask = 0x7Fu, kStrictF = 1u << 20, kStrictR = 1u << 21, kMore = 1u << 28, kCont = 1u << 29;
+
+void build_eval_programs(const std::vector<ChainItem> &chains, const std::vector<uint32_t> &events, const std::vector<int32_t> &cand_out,
+                         int k, uint32_t sF, uint32_t sR, std::vector<uint32_t> &prog);
+int launch_eval_prog(mp_ctx *c, int shape, const BlockMap &bm, const PatchArgs &pa, unsigned grid, unsigned long long *device_out);
+
+}  // namespace mp

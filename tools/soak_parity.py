@@ -20,7 +20,8 @@ from test_hip_parity import chain_candidates, fuzz_msa  # noqa: E402
 
 ENVS = [{}, {"MP_EVAL_GROUP": "plain"}, {"MP_EVAL_GROUP": "nested"}, {"MP_EVAL_BITS": "1"}, {"MP_EVAL_BITS": "2"},
         {"MP_EVAL_CHAIN": "0"}, {"MP_EVAL_CHAIN": "3"}, {"MP_EVAL_CHAIN": "5"}, {"MP_EVAL_CHAIN": "7"}, {"MP_EVAL_CHAIN": "8"},
-        {"MP_EVAL_MODE": "rows"}, {"MP_EVAL_TILE": "4"}, {"MP_EVAL_TILE": "2"}, {"MP_EVAL_TILE": "0"}]
+        {"MP_EVAL_MODE": "rows"}, {"MP_EVAL_TILE": "4"}, {"MP_EVAL_TILE": "2"}, {"MP_EVAL_PROG": "1"},
+        {"MP_EVAL_PROG": "1", "MP_EVAL_CHAIN": "7"}, {"MP_EVAL_PROG": "1", "MP_EVAL_CHAIN": "3"}]
 KEYS = sorted({k for e in ENVS for k in e})
 
 

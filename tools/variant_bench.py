@@ -68,10 +68,12 @@ def main():
             else:
                 os.environ.pop("MP_EVAL_TILE_GROUPS", None)
             ctx.eval_upload(cw, codes, sF, sR)           # a new plan
-        elif var.startswith("c"):
+        elif var.startswith("c") or var.startswith("p"):  # cN: eval_chain_kernel shape N; pN: the program-driven kernel, same shapes
             os.environ["MP_EVAL_BITS"] = "0"
             os.environ["MP_EVAL_TILE"] = "0"
+            os.environ["MP_EVAL_PROG"] = "1" if var[0] == "p" else "0"
             os.environ["MP_EVAL_CHAIN"] = var[1:]
+            ctx.eval_upload(cw, codes, sF, sR)           # the programs are written at upload time
         else:
             os.environ["MP_EVAL_BITS"] = var[1:]
         for _ in range(3):
