@@ -1,40 +1,45 @@
 #!/usr/bin/env python3
-"""Benchmark of the hot path: batched candidate x sequence coverage evaluation
-(mp_eval_launch -> eval_chain_kernel) on a synthetic alignment shard per GPU (SURVEY §8d input 4 /
-BASELINE.json configs[3]: 1M x 1 kb sequences sharded over 8 GPUs = 131072 rows per GPU).
+"""Benchmark of the hot path: batched candidate x sequence coverage evaluation (mp_eval_launch -> eval_chain_kernel) on the
+synthetic alignment of SURVEY §8d input 4 / BASELINE.json configs[3]: 1M x 1 kb sequences sharded over 8 GPUs.
 
-One step = one pass of the evaluation over every window of the shard with C candidates per
-window, plus (N > 1) the RCCL all-reduce of the per-candidate coverage counters.  Inputs are
-resident in HBM (planes built once, untimed); weak scaling: the shard per GPU is fixed.
+One step = one pass of the evaluation over every window with C candidates per window, plus (N > 1) the RCCL all-reduce of the
+per-candidate coverage counters.  Inputs are resident in HBM (planes built once, untimed).
 
   python bench.py --gpus 1 --steps 20 --warmup 3
   python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
 
-Prints ONE JSON line on rank 0 (contract in the task statement).  What the line carries beyond the contract:
+The headline (`value`) is WEAK scaling: every GPU holds the 131072 x 1000 shard it would hold in the 8-GPU job.  That shard
+(81 MB of planes) lives in the 256 MiB Infinity Cache, so HBM cannot bind it; the line therefore also carries
 
-  roofline      every fraction is <= 1 by construction.  The kernel does not stream a k-mer per evaluation (8 nested
-                candidates share one pass over L2-resident one-hot planes), so HBM cannot bind it; the binding ceilings
-                are integer VALU issue and L2 reads.  `bound` names the largest of
+  full_config   config 4 ITSELF on ONE GPU (1 048 576 x 1000, planes 0.6 GB > Infinity Cache: the only size where HBM matters):
+                its own value / ms_per_step / roofline / parity check, built and timed in this same run (rank 0; skip with
+                --no-full).  At N > 1 `strong_scaling` compares the N-GPU step with it: N GPUs x 131072 rows = the same job.
+  roofline      every fraction is <= 1 by construction:
                   valu_frac = VALU wave-instructions per launch / (kernel time x SIMDs x measured issue rate)
                   l2_frac   = bytes requested from L2 per launch / (kernel time x measured L2 read bandwidth)
                   hbm_frac  = measured fabric/HBM bytes per launch (`traffic`) / (kernel time x 8 TB/s)
-                with instruction / request / byte counts from separate rocprofv3 --pmc passes of this same command
-                (profiles/r02_counters.json, written by tools/collect_counters.py — looked up by exact configuration)
-                and ceilings measured on the box by tools/ubench.hip (profiles/r02_ubench.json).  SURVEY §8d's
-                algorithmic figure (3k/8 bytes per evaluation / kernel time / 8 TB/s) is kept as `algorithmic_frac`,
-                labelled: it exceeds 1 and is NOT a roofline fraction.
-  variants      the same kernel library on less friendly candidate sets: unrelated candidates (no nesting), the
-                symbol-table kernel forced on the nested set, C = 1, and one cold launch (caches flushed, no warm-up).
-  cpu_baseline  the plain-C oracle on ALL host cores (threads over row blocks of the whole shard) and on one core
-                (bounded sample); its counters are compared with the GPU's, candidate by candidate —
-                `parity_checked` true, or the run exits non-zero.
+                `bound` names the largest.  Kernel time is measured live (HIP events on the library's stream); instruction /
+                request / byte counts come from separate rocprofv3 --pmc passes of this same command (tools/collect_counters.py
+                -> profiles/r03_counters.json).  An entry is used only if it was collected for this exact configuration AND
+                this exact kernel source (`source_hash` = sha256 of the evaluation kernels' sources): after a kernel change the
+                fractions are dropped (`counters_stale`), never silently reused.  SURVEY §8d's algorithmic figure (3k/8 bytes
+                per evaluation / kernel time / 8 TB/s) is kept as `algorithmic_frac`, labelled: it exceeds 1 (8 nested
+                candidates and 18 overlapping windows share every loaded plane word) and is NOT a roofline fraction.
+  variants      the same kernel library on less friendly candidate sets: unrelated candidates (no nesting), the symbol-table
+                kernel forced on the nested set, C = 1, and one cold launch (caches flushed, no warm-up).
+  cpu_baseline  the plain-C oracle on EVERY host core (threads over row blocks of the whole shard) and on one core (bounded
+                sample); its counters are compared with the GPU's candidate by candidate — `parity_checked` true, or the run
+                exits non-zero.  `python_reference`: the reference's own algorithm (dict of k-mers, numpy score-table
+                differences, V20:229-233 / 1103-1130) restated in Python, one core, bounded sample, checked against the oracle.
 """
 import argparse
+import hashlib
 import json
 import os
 import sys
 import threading
 import time
+from concurrent.futures import ThreadPoolExecutor
 
 import numpy as np
 
@@ -43,14 +48,19 @@ sys.path.insert(0, REPO)
 
 HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec (MI355X_MICROARCH.md); ~6300 GB/s achievable
 N_SIMD = 1024                  # 256 CUs x 4 SIMDs
+FULL_ROWS = 1048576            # BASELINE.json configs[3]: 1M sequences
 # measured ceilings (tools/ubench.hip on the same GPU pool, profiles/r02_ubench.json); used when that file is absent
 DEFAULT_CEILINGS = {"valu_wave_instr_per_s_per_simd": 8.5e8, "l2_read_GBs": 31559.0, "source": "built-in defaults (profiles/r02_ubench.json missing)"}
-
+COUNTER_FILES = ("r03_counters.json",)
+# sources of the timed kernel (eval_chain_kernel and what it includes): the key of a counter entry
+KERNEL_SOURCES = ("eval.hip", "bitslice.hpp", "common.hpp", "winwords.hpp", "evaltile.hpp", "evalprog.hpp")
 
 KERNELS = {
     "chain": "eval_chain_kernel (bit-sliced one-hot column planes, nested refinement chains; patch rows ride in the same launch)",
     "table": "eval_bits_kernel (bit-sliced one-hot column planes, symbol table per position; patch rows ride in the same launch)",
     "rows": "eval_kernel (row-per-lane, window words derived from the planes)",
+    "tile": "eval_tile_kernel (column planes of a band of windows in an LDS ring) + eval_chain_kernel on the patch planes",
+    "prog": "eval_prog_kernel (eval_chain_kernel's arithmetic, host-written fetch programs, buffer loads)",
 }
 
 
@@ -60,7 +70,19 @@ def eval_mode():
         return "rows"
     if os.environ.get("MP_EVAL_BITS", "0") in ("1", "2") or os.environ.get("MP_EVAL_GROUP") == "plain":
         return "table"
+    if os.environ.get("MP_EVAL_TILE", "0") in ("2", "4"):
+        return "tile"
+    if os.environ.get("MP_EVAL_PROG", "0") == "1":
+        return "prog"
     return "chain"
+
+
+def kernel_source_hash():
+    h = hashlib.sha256()
+    for name in KERNEL_SOURCES:
+        with open(os.path.join(REPO, "multiprime_amd", "csrc", name), "rb") as f:
+            h.update(name.encode() + b"\0" + f.read())
+    return h.hexdigest()[:16]
 
 
 def make_candidates(root_codes, p0, W, k, C, seed, nested=True):
@@ -97,6 +119,23 @@ def expand_exceptions(ctx, n_ex, k, v):
     return len(exp)
 
 
+def synth_rows(row0, n, L, seed, **kw):
+    """Rows [row0, row0 + n) of the synthetic alignment; blocks are seeded independently, so they are generated on several threads."""
+    from multiprime_amd.synth import synth_block
+    step = 32768
+    if n <= step:
+        return synth_block(row0, n, L, seed, **kw)
+    out = np.empty((n, L), np.uint8)
+
+    def part(s):
+        m = min(step, n - s)
+        out[s:s + m] = synth_block(row0 + s, m, L, seed, **kw)
+
+    with ThreadPoolExecutor(max_workers=min(16, os.cpu_count() or 1)) as ex:
+        list(ex.map(part, range(0, n, step)))
+    return out
+
+
 def load_json(name):
     try:
         with open(os.path.join(REPO, "profiles", name)) as f:
@@ -120,14 +159,18 @@ def ceilings():
 
 
 def counters_for(cfg):
-    """PMC counters per launch of the timed kernel for exactly this configuration, or None."""
-    db = load_json("r02_counters.json")
-    if not db:
-        return None
-    for e in db.get("entries", []):
-        if all(e.get(key) == val for key, val in cfg.items()):
-            return e
-    return None
+    """(entry, note): PMC counters per launch of the timed kernel for exactly this configuration AND this kernel source, or
+    (None, why not)."""
+    want = kernel_source_hash()
+    stale = None
+    for name in COUNTER_FILES:
+        db = load_json(name)
+        for e in (db or {}).get("entries", []):
+            if all(e.get(key) == val for key, val in cfg.items()):
+                if e.get("source_hash") == want:
+                    return e, f"profiles/{name}, source_hash {want}"
+                stale = f"profiles/{name} holds counters of kernel source {e.get('source_hash')}, the library is built from {want}: fractions dropped, re-run tools/collect_counters.py"
+    return None, stale or "no counters collected for this configuration"
 
 
 def time_launches(ctx, torch, out_ptr, n, warm):
@@ -145,6 +188,81 @@ def time_launches(ctx, torch, out_ptr, n, warm):
             "max_ms": float(s[-1]) if len(s) else None, "launches": cnt}
 
 
+class Workload:
+    """The evaluation workload on `n_rows` sequences starting at global row `row0`, resident on the device."""
+
+    def __init__(self, lib, local, torch, row0, n_rows, a):
+        t0 = time.time()
+        self.k, self.v, self.C, self.L, self.n_rows = a.k, a.v, a.cands, a.cols, n_rows
+        self.ctx = lib.context(local)
+        self.ctx.set_stream(torch.cuda.current_stream().cuda_stream)
+        self.rows = synth_rows(row0, n_rows, self.L, a.seed)
+        self.ctx.load_msa(self.rows.reshape(-1), np.arange(n_rows + 1, dtype=np.int64) * self.L)
+        k = self.k
+        self.p0, self.W = 16, self.L - 32 - k                       # same windows on every rank
+        n_ex = self.ctx.build_windows(self.p0, self.W, k, self.v)
+        self.n_extra = expand_exceptions(self.ctx, n_ex, k, self.v)
+        from multiprime_amd.synth import synth_root
+        self.root_codes = np.array([1, 2, 4, 8], np.uint8)[synth_root(self.L, a.seed)]
+        self.cw, self.codes = make_candidates(self.root_codes, self.p0, self.W, k, self.C, a.seed)
+        f_set, r_set = {2, 3, k}, {2, k - 3, k - 2}                 # -c 2,3,-1 (multiPrime.yaml), get_Y V20:1091
+        self.sF = sum(1 << y for y in f_set if 0 <= y < k)
+        self.sR = sum(1 << y for y in r_set if 0 <= y < k)
+        self.n_cand = len(self.cw)
+        # universe size per window (sequences with <= v gaps, plus expansions): an all-N candidate matches every non-gap
+        # symbol, so perfect + F_mis under empty strict masks counts it
+        alln = self.ctx.eval_candidates(np.arange(self.W, dtype=np.int32), np.full((self.W, k), 15, np.uint8), 0, 0)
+        self.universe = alln[:, 0] + alln[:, 1]
+        self.evals = int(self.universe.sum()) * self.C
+        self.ctx.eval_upload(self.cw, self.codes, self.sF, self.sR)
+        self.setup_s = time.time() - t0
+
+    def describe(self):
+        return (f"synthetic MSA {self.n_rows} x {self.L}, k={self.k}, v={self.v}, {self.C} candidates/window, {self.W} windows, "
+                f"strict -c 2,3,-1")
+
+
+def roofline_block(w, per_launch_ms, samples, kern_n, every, mode):
+    kern_s = per_launch_ms * 1e-3
+    alg_bytes = w.evals * 3 * w.k / 8.0            # SURVEY §8d: 3k/8 bytes per evaluation
+    ceil = ceilings()
+    cfg = {"rows": w.n_rows, "cols": w.L, "k": w.k, "v": w.v, "cands": w.C, "mode": mode}
+    pmc, note = counters_for(cfg)
+    fr = {"valu": None, "l2": None, "hbm": None}
+    traffic = None
+    if pmc:
+        if pmc.get("valu_insts"):
+            fr["valu"] = pmc["valu_insts"] / (kern_s * N_SIMD * ceil["valu_wave_instr_per_s_per_simd"])
+        if pmc.get("l2_read_bytes"):
+            fr["l2"] = pmc["l2_read_bytes"] / kern_s / 1e9 / ceil["l2_read_GBs"]
+        if pmc.get("hbm_read_bytes") is not None:
+            traffic = pmc["hbm_read_bytes"] + (pmc.get("hbm_write_bytes") or 0)
+            fr["hbm"] = traffic / kern_s / 1e9 / HBM_PEAK_GBS
+    known = {key: val for key, val in fr.items() if val is not None}
+    bound = max(known, key=known.get) if known else None
+    if bound == "valu":
+        achieved, peak, unit = pmc["valu_insts"] / kern_s / 1e9, N_SIMD * ceil["valu_wave_instr_per_s_per_simd"] / 1e9, "G wave-instr/s"
+    elif bound == "l2":
+        achieved, peak, unit = pmc["l2_read_bytes"] / kern_s / 1e9, ceil["l2_read_GBs"], "GB/s"
+    elif bound == "hbm":
+        achieved, peak, unit = traffic / kern_s / 1e9, HBM_PEAK_GBS, "GB/s"
+    else:
+        achieved, peak, unit = None, None, None
+    return {"bound": bound, "achieved": achieved, "peak": peak, "unit": unit,
+            "frac": known.get(bound) if bound else None, "traffic": traffic,
+            "valu_frac": fr["valu"], "l2_frac": fr["l2"], "hbm_frac": fr["hbm"],
+            "compulsory_bytes": w.n_rows * w.L * 3 / 8.0, "compulsory_note": "SURVEY §8d (ii): packed planes read once, N L 3/8 bytes",
+            "algorithmic_frac": alg_bytes / kern_s / 1e9 / HBM_PEAK_GBS,
+            "algorithmic_note": "SURVEY 8d figure: 3k/8 bytes per evaluation over the kernel time vs 8 TB/s; exceeds 1 because 8 nested candidates and "
+                                "18 overlapping windows share every loaded plane word — NOT a roofline fraction, kept for comparison with round 1",
+            "algorithmic_bytes": alg_bytes, "algorithmic_bytes_per_eval": 3 * w.k / 8.0,
+            "counters": pmc, "counters_source": note, "counters_stale": pmc is None, "source_hash": kernel_source_hash(), "ceilings": ceil,
+            "kernel": KERNELS[mode] + "; timed region = counter memset + kernel", "eval_mode": mode,
+            "kernel_ms": per_launch_ms, "kernel_ms_median": float(samples[len(samples) // 2]) if len(samples) else None,
+            "kernel_ms_max": float(samples[-1]) if len(samples) else None,
+            "launches_timed": kern_n, "timed_every": every}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -157,16 +275,16 @@ def main():
     ap.add_argument("--cands", type=int, default=8, help="candidates per window")
     ap.add_argument("--seed", type=int, default=20250303)
     ap.add_argument("--cpu-rows", type=int, default=0, help="rows of the shard the CPU oracle evaluates (0 = the whole shard)")
-    ap.add_argument("--cpu-threads", type=int, default=0, help="host threads of the all-core CPU leg (0 = every core, at most 64)")
+    ap.add_argument("--cpu-threads", type=int, default=0, help="host threads of the all-core CPU leg (0 = every core)")
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--no-variants", action="store_true")
+    ap.add_argument("--no-full", action="store_true", help="skip the full_config block (config 4 itself, 1048576 rows on one GPU)")
     ap.add_argument("--bucket", type=int, default=4, help="steps whose counters share one all-reduce (N > 1)")
     a = ap.parse_args()
 
     import torch
     import torch.distributed as dist
     from multiprime_amd._abi import Library
-    from multiprime_amd.synth import synth_block, synth_root
 
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -189,32 +307,13 @@ def main():
         else:
             dist.init_process_group(backend)
 
-    k, v, C, L = a.k, a.v, a.cands, a.cols
+    k, C, L = a.k, a.cands, a.cols
     # the library brackets every n-th mp_eval_launch with a HIP-event pair on its stream (live kernel time for the
     # roofline); a pair idles the stream for ~6 us, so the timed region samples one launch in four
     every = int(os.environ.setdefault("MP_EVAL_TIMING_EVERY", "4"))
-    t_setup = time.time()
     lib = Library()                                   # the HIP library or an error: no fallback
-    ctx = lib.context(local)
-    ctx.set_stream(torch.cuda.current_stream().cuda_stream)
-    rows = synth_block(rank * a.rows, a.rows, L, a.seed)
-    ctx.load_msa(rows.reshape(-1), np.arange(a.rows + 1, dtype=np.int64) * L)
-    p0, W = 16, L - 32 - k                            # same windows on every rank
-    n_ex = ctx.build_windows(p0, W, k, v)
-    n_extra = expand_exceptions(ctx, n_ex, k, v)
-    root_codes = np.array([1, 2, 4, 8], np.uint8)[synth_root(L, a.seed)]
-    cw, codes = make_candidates(root_codes, p0, W, k, C, a.seed)
-    f_set, r_set = {2, 3, k}, {2, k - 3, k - 2}        # -c 2,3,-1 (multiPrime.yaml), get_Y V20:1091
-    sF = sum(1 << y for y in f_set if 0 <= y < k)
-    sR = sum(1 << y for y in r_set if 0 <= y < k)
-    n_cand = len(cw)
-    # universe size per window (sequences with <= v gaps, plus expansions): an all-N candidate
-    # matches every non-gap symbol, so perfect + F_mis under empty strict masks counts it
-    alln = ctx.eval_candidates(np.arange(W, dtype=np.int32), np.full((W, k), 15, np.uint8), 0, 0)
-    universe = alln[:, 0] + alln[:, 1]
-    evals_local = int(universe.sum()) * C
-    ctx.eval_upload(cw, codes, sF, sR)
-    setup_s = time.time() - t_setup
+    w = Workload(lib, local, torch, rank * a.rows, a.rows, a)
+    ctx, n_cand = w.ctx, w.n_cand
 
     # N > 1: the counters of every step are all-reduced over RCCL, bucketed and overlapped (dist.StepBuckets):
     # `--bucket` consecutive steps write into one [bucket][n_cand][3] buffer that is reduced with ONE collective
@@ -222,19 +321,19 @@ def main():
     # into the other buffer.  Every step's counters are reduced; all reductions complete inside the timed region.
     from multiprime_amd.dist import StepBuckets
 
-    def timed_region(bucket):
-        sb = StepBuckets(n_cand, bucket, dev, world)
+    def timed_region(wl, bucket, n_world):
+        sb = StepBuckets(wl.n_cand, bucket, dev, n_world)
 
         def step():
-            ctx.eval_launch(sb.begin_step().data_ptr())
+            wl.ctx.eval_launch(sb.begin_step().data_ptr())
             sb.end_step()
 
         for _ in range(a.warmup):
             step()
         sb.drain()
-        ctx.eval_timing(reset=True)
+        wl.ctx.eval_timing(reset=True)
         torch.cuda.synchronize()
-        if world > 1:
+        if n_world > 1:
             dist.barrier()
         torch.cuda.synchronize()
         t0 = time.perf_counter()
@@ -242,26 +341,26 @@ def main():
             step()
         sb.drain()
         torch.cuda.synchronize()
-        if world > 1:
+        if n_world > 1:
             dist.barrier()
         torch.cuda.synchronize()
         dt = time.perf_counter() - t0
-        kern_ms, kern_n = ctx.eval_timing(reset=True)
-        samples = np.sort(ctx.eval_timing_samples())
+        kern_ms, kern_n = wl.ctx.eval_timing(reset=True)
+        samples = np.sort(wl.ctx.eval_timing_samples())
         tt = torch.tensor([dt], dtype=torch.float64, device=dev)
-        if world > 1:
+        if n_world > 1:
             dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         return float(tt.item()), kern_ms, kern_n, samples, sb
 
-    elapsed, kern_ms, kern_n, samples, sb = timed_region(a.bucket)
+    elapsed, kern_ms, kern_n, samples, sb = timed_region(w, a.bucket, world)
     gpu_counters = sb.block_of(a.steps - 1).cpu().numpy().copy()       # [n_cand][3], summed over ranks when N > 1
     # N > 1: the same K steps with ONE collective per step (the drop-in pipeline reduces once per alignment), for comparison
     unbucketed = None
     if world > 1 and a.bucket != 1:
-        e1, *_ = timed_region(1)
+        e1, *_ = timed_region(w, 1, world)
         unbucketed = e1
 
-    ev = torch.tensor([evals_local], dtype=torch.int64, device=dev)
+    ev = torch.tensor([w.evals], dtype=torch.int64, device=dev)
     if world > 1:
         dist.all_reduce(ev, op=dist.ReduceOp.SUM)
     evals_total = int(ev.item())
@@ -282,36 +381,13 @@ def main():
         torch.cuda.synchronize()
         copy_gbs = 5 * 2 * src.numel() * 4 / (e0.elapsed_time(e1) * 1e-3) / 1e9
         if world == 1 and not a.no_variants:
-            variants = run_variants(ctx, torch, dev, src, dst, root_codes, p0, W, k, C, a.seed, sF, sR, universe, cw, codes, n_cand)
+            variants = run_variants(w, torch, dev, src, dst, a.seed)
         del src, dst
 
+    res = None
     if rank == 0:
+        mode = eval_mode()
         per_launch_ms = kern_ms / max(kern_n, 1)
-        kern_s = per_launch_ms * 1e-3
-        alg_bytes = evals_local * 3 * k / 8.0         # 3k/8 bytes per evaluation
-        ceil = ceilings()
-        cfg = {"rows": a.rows, "cols": L, "k": k, "v": v, "cands": C, "mode": eval_mode()}
-        pmc = counters_for(cfg)
-        fr = {"valu": None, "l2": None, "hbm": None}
-        traffic = None
-        if pmc:
-            if pmc.get("valu_insts"):
-                fr["valu"] = pmc["valu_insts"] / (kern_s * N_SIMD * ceil["valu_wave_instr_per_s_per_simd"])
-            if pmc.get("l2_read_bytes"):
-                fr["l2"] = pmc["l2_read_bytes"] / kern_s / 1e9 / ceil["l2_read_GBs"]
-            if pmc.get("hbm_read_bytes") is not None:
-                traffic = pmc["hbm_read_bytes"] + (pmc.get("hbm_write_bytes") or 0)
-                fr["hbm"] = traffic / kern_s / 1e9 / HBM_PEAK_GBS
-        known = {key: val for key, val in fr.items() if val is not None}
-        bound = max(known, key=known.get) if known else "valu"
-        if bound == "valu" and pmc:
-            achieved, peak, unit = pmc["valu_insts"] / kern_s / 1e9, N_SIMD * ceil["valu_wave_instr_per_s_per_simd"] / 1e9, "G wave-instr/s"
-        elif bound == "l2" and pmc:
-            achieved, peak, unit = pmc["l2_read_bytes"] / kern_s / 1e9, ceil["l2_read_GBs"], "GB/s"
-        elif bound == "hbm" and pmc:
-            achieved, peak, unit = traffic / kern_s / 1e9, HBM_PEAK_GBS, "GB/s"
-        else:
-            achieved, peak, unit = None, None, None
         res = {
             "metric": "candidate x sequence coverage evals/s",
             "value": evals_total * a.steps / elapsed,
@@ -320,63 +396,88 @@ def main():
             "ms_per_step": elapsed / a.steps * 1e3,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "u32 bit-planes", "data": "synthetic",
-            "config": {"workload": f"synthetic MSA {a.rows} x {L} per GPU (SURVEY 8d input 4; BASELINE configs[3] shard), "
-                                   f"k={k}, v={v}, {C} candidates/window, {W} windows, strict -c 2,3,-1",
-                       "rows_per_gpu": a.rows, "cols": L, "k": k, "variation": v, "candidates_per_window": C,
-                       "windows": W, "evals_per_step_per_gpu": evals_local, "iupac_extra_rows": n_extra,
+            "config": {"workload": f"{w.describe()} per GPU (SURVEY 8d input 4; the per-GPU shard of BASELINE configs[3], the whole of "
+                                   f"which is timed on one GPU in `full_config`)",
+                       "rows_per_gpu": a.rows, "cols": L, "k": k, "variation": a.v, "candidates_per_window": C,
+                       "windows": w.W, "evals_per_step_per_gpu": w.evals, "iupac_extra_rows": w.n_extra,
                        "parallelism": f"row shards x{world}, RCCL all-reduce of every step's [{n_cand}x3] int64 counters, {sb.B} steps per collective, overlapped with the next bucket"},
-            "roofline": {"bound": bound, "achieved": achieved, "peak": peak, "unit": unit,
-                         "frac": known.get(bound), "traffic": traffic,
-                         "valu_frac": fr["valu"], "l2_frac": fr["l2"], "hbm_frac": fr["hbm"],
-                         "algorithmic_frac": alg_bytes / kern_s / 1e9 / HBM_PEAK_GBS,
-                         "algorithmic_note": "SURVEY 8d figure: 3k/8 bytes per evaluation over the kernel time vs 8 TB/s; exceeds 1 because 8 nested candidates share "
-                                             "one pass over L2-resident planes — NOT a roofline fraction, kept for comparison with round 1",
-                         "algorithmic_bytes": alg_bytes, "algorithmic_bytes_per_eval": 3 * k / 8.0,
-                         "counters": pmc, "ceilings": ceil,
-                         "kernel": KERNELS[eval_mode()] + "; timed region = counter memset + kernel", "eval_mode": eval_mode(),
-                         "kernel_ms": per_launch_ms, "kernel_ms_median": float(samples[len(samples) // 2]) if len(samples) else None,
-                         "kernel_ms_max": float(samples[-1]) if len(samples) else None,
-                         "launches_timed": kern_n, "timed_every": every},
+            "roofline": roofline_block(w, per_launch_ms, samples, kern_n, every, mode),
             "variants": variants,
-            "measured_copy_GBs": copy_gbs, "setup_s": setup_s, "device_bytes": ctx.device_bytes(), "counter_checksum": checksum,
+            "measured_copy_GBs": copy_gbs, "setup_s": w.setup_s, "device_bytes": ctx.device_bytes(), "counter_checksum": checksum,
         }
         if unbucketed is not None:
             res["ms_per_step_one_collective_per_step"] = unbucketed / a.steps * 1e3
         if world == 1 and not a.no_cpu:
             n_cpu = a.cpu_rows or a.rows
-            res["cpu_baseline"] = cpu_baseline(rows[:n_cpu], L, p0, W, k, v, cw, codes, sF, sR, C, a.cpu_threads,
-                                               gpu_counters if n_cpu == a.rows else None)
+            res["cpu_baseline"] = cpu_baseline(w, w.rows[:n_cpu], a.cpu_threads, gpu_counters if n_cpu == a.rows else None, a.seed)
             res["parity_checked"] = res["cpu_baseline"].get("parity_checked")
+    # config 4 itself on one GPU (rank 0; the other ranks wait at the barrier below)
+    if rank == 0 and not a.no_full and a.rows != FULL_ROWS:
+        shard_step_ms = res["ms_per_step"]
+        del sb
+        w.ctx = ctx = None
+        w.rows = None
+        torch.cuda.empty_cache()
+        res["full_config"] = full_config(lib, local, torch, a, timed_region, every, world == 1 and not a.no_cpu)
+        fc = res["full_config"]
+        if world > 1 and world * a.rows == FULL_ROWS:
+            res["strong_scaling"] = {"one_gpu_ms_per_step": fc["ms_per_step"], "n_gpu_ms_per_step": shard_step_ms,
+                                     "speedup": fc["ms_per_step"] / shard_step_ms, "n_gpus": world,
+                                     "n_gpu_ms_per_step_one_collective_per_step": res.get("ms_per_step_one_collective_per_step"),
+                                     "note": f"{world} GPUs x {a.rows} rows are config 4; one GPU times the same {FULL_ROWS} rows alone in this run"}
+        if fc.get("parity_checked") is False:
+            res["parity_checked"] = False
+    if rank == 0:
         print(json.dumps(res), flush=True)
-        if res.get("parity_checked") is False:
-            raise SystemExit("bench.py: GPU counters differ from the CPU oracle's")
     if world > 1:
+        dist.barrier()
         dist.destroy_process_group()
+    if rank == 0 and res.get("parity_checked") is False:
+        raise SystemExit("bench.py: GPU counters differ from the CPU oracle's")
 
 
-def run_variants(ctx, torch, dev, scratch_a, scratch_b, root_codes, p0, W, k, C, seed, sF, sR, universe, cw, codes, n_cand):
+def full_config(lib, local, torch, a, timed_region, every, with_cpu):
+    """BASELINE.json configs[3] itself — 1 048 576 x 1000 — resident on ONE GPU: the same steps, timed the same way."""
+    w = Workload(lib, local, torch, 0, FULL_ROWS, a)
+    elapsed, kern_ms, kern_n, samples, sb = timed_region(w, 1, 1)
+    counters = sb.block_of(a.steps - 1).cpu().numpy().copy()
+    per_launch_ms = kern_ms / max(kern_n, 1)
+    out = {"workload": w.describe() + " on ONE GPU (BASELINE configs[3] whole; planes 0.6 GB: larger than the Infinity Cache)",
+           "value": w.evals * a.steps / elapsed, "unit": "evals/s", "ms_per_step": elapsed / a.steps * 1e3, "steps": a.steps,
+           "evals_per_step": w.evals, "iupac_extra_rows": w.n_extra, "setup_s": w.setup_s, "device_bytes": w.ctx.device_bytes(),
+           "roofline": roofline_block(w, per_launch_ms, samples, kern_n, every, eval_mode()),
+           "counter_checksum": counters.sum(axis=0).tolist()}
+    if with_cpu:
+        cb = cpu_baseline(w, w.rows, a.cpu_threads, counters, a.seed, one_core=False, python_leg=False)
+        out["cpu_baseline"] = cb
+        out["parity_checked"] = cb.get("parity_checked")
+    return out
+
+
+def run_variants(w, torch, dev, scratch_a, scratch_b, seed):
     """The evaluation library on less friendly inputs (every launch timed with HIP events, 20 launches after 3 warm-ups)."""
     os.environ["MP_EVAL_TIMING_EVERY"] = "1"
-    total = int(universe.sum())
+    ctx, k, C = w.ctx, w.k, w.C
+    total = int(w.universe.sum())
     out = {}
 
     def measure(name, cand_w, cand_codes, c_per_window, note):
-        ctx.eval_upload(cand_w, cand_codes, sF, sR)
+        ctx.eval_upload(cand_w, cand_codes, w.sF, w.sR)
         buf = torch.zeros((len(cand_w), 3), dtype=torch.int64, device=dev)
         t = time_launches(ctx, torch, buf.data_ptr(), 20, 3)
         evals = total * c_per_window
         out[name] = {"evals_per_s": evals / (t["mean_ms"] * 1e-3), "kernel_ms": t["mean_ms"], "kernel_ms_median": t["median_ms"],
                      "kernel_ms_max": t["max_ms"], "candidates_per_window": c_per_window, "what": note}
 
-    uw, ucodes = make_candidates(root_codes, p0, W, k, C, seed + 1, nested=False)
+    uw, ucodes = make_candidates(w.root_codes, w.p0, w.W, k, C, seed + 1, nested=False)
     measure("unrelated_candidates", uw, ucodes, C, f"{C} candidates per window that are NOT a refinement chain (root + one extra base each): symbol-table kernel")
     os.environ["MP_EVAL_GROUP"] = "plain"
-    measure("nested_on_table_kernel", cw, codes, C, "the headline candidates with chain detection off (MP_EVAL_GROUP=plain): symbol-table kernel")
+    measure("nested_on_table_kernel", w.cw, w.codes, C, "the headline candidates with chain detection off (MP_EVAL_GROUP=plain): symbol-table kernel")
     del os.environ["MP_EVAL_GROUP"]
-    measure("c1", cw[::C].copy(), codes[::C].copy(), 1, "one candidate per window (the root k-mer)")
+    measure("c1", w.cw[::C].copy(), w.codes[::C].copy(), 1, "one candidate per window (the root k-mer)")
     # cold: one launch of the headline set with L2 / Infinity Cache flushed by a 2 GiB device copy, no warm-up
-    ctx.eval_upload(cw, codes, sF, sR)
-    buf = torch.zeros((n_cand, 3), dtype=torch.int64, device=dev)
+    ctx.eval_upload(w.cw, w.codes, w.sF, w.sR)
+    buf = torch.zeros((w.n_cand, 3), dtype=torch.int64, device=dev)
     colds = []
     for _ in range(3):
         scratch_b.copy_(scratch_a)
@@ -392,18 +493,19 @@ def run_variants(ctx, torch, dev, scratch_a, scratch_b, root_codes, p0, W, k, C,
     return out
 
 
-def cpu_baseline(rows, L, p0, W, k, v, cw, codes, sF, sR, C, n_threads, gpu_counters):
-    """The oracle (plain-C restatement of the reference) on the host cores: all cores over row blocks of the sample
-    (the C call releases the GIL, one oracle context per thread) and one core on a bounded sub-sample.  When the sample is
-    the whole shard its summed counters are compared with the GPU's.  This is the only place bench.py touches oracle/."""
+def cpu_baseline(w, rows, n_threads, gpu_counters, seed, one_core=True, python_leg=True):
+    """The oracle (plain-C restatement of the reference) on the host cores: EVERY core over row blocks of the sample (the C call
+    releases the GIL, one oracle context per thread) and one core on a bounded sub-sample.  When the sample is the whole
+    workload its summed counters are compared with the GPU's.  This is the only place bench.py touches oracle/."""
     from multiprime_amd._abi import Library
     so = os.path.join(REPO, "oracle", "_build", "libmprime_oracle.so")
     if not os.path.exists(so):
         return {"value": None, "unit": "evals/s", "cores": 0, "kind": "port", "sample": "oracle library not built", "parity_checked": None}
     lib = Library(so)
+    L, p0, W, k, v, C = w.L, w.p0, w.W, w.k, w.v, w.C
     n = rows.shape[0]
     cores = os.cpu_count() or 1
-    T = n_threads or min(cores, 64)
+    T = n_threads or cores
     T = max(1, min(T, n // 256))
     bounds = [n * t // T for t in range(T + 1)]
     results = [None] * T
@@ -418,7 +520,7 @@ def cpu_baseline(rows, L, p0, W, k, v, cw, codes, sF, sR, C, n_threads, gpu_coun
         alln = ora.eval_candidates(np.arange(W, dtype=np.int32), np.full((W, k), 15, np.uint8), 0, 0)
         universe[t] = int((alln[:, 0] + alln[:, 1]).sum())
         t0 = time.perf_counter()
-        results[t] = ora.eval_candidates(cw, codes, sF, sR)
+        results[t] = ora.eval_candidates(w.cw, w.codes, w.sF, w.sR)
         return time.perf_counter() - t0
 
     # all cores: wall time of the evaluation calls only (loading / window building of the oracle contexts is untimed, as on the GPU)
@@ -436,24 +538,64 @@ def cpu_baseline(rows, L, p0, W, k, v, cw, codes, sF, sR, C, n_threads, gpu_coun
     parity = None
     if gpu_counters is not None:
         parity = bool(np.array_equal(total, gpu_counters))
-    # one core: a bounded sub-sample (first rows), ~1/T of the work above
-    n1 = max(256, min(n, 8192))
-    ora = lib.context(0)
-    ora.load_msa(rows[:n1].reshape(-1), np.arange(n1 + 1, dtype=np.int64) * L)
-    n_ex = ora.build_windows(p0, W, k, v)
-    expand_exceptions(ora, n_ex, k, v)
-    alln = ora.eval_candidates(np.arange(W, dtype=np.int32), np.full((W, k), 15, np.uint8), 0, 0)
-    ev1 = int((alln[:, 0] + alln[:, 1]).sum()) * C
+    out = {"value": evals / eval_wall, "unit": "evals/s", "cores": T, "kind": "port", "host_cores": cores,
+           "sample": f"all {n} sequences, all {W} windows x {C} candidates = {evals} evals on {T} threads (of {cores} host cores) in {eval_wall:.2f} s "
+                     f"(oracle/mprime_oracle.c; {wall_all:.1f} s incl. building the oracle's own tables)",
+           "parity_checked": parity,
+           "parity_note": "per candidate, all three counters, GPU == sum of the oracle's row blocks" if parity is not None else "sample is not the whole workload: no comparison"}
+    if one_core:            # a bounded sub-sample (first rows)
+        n1 = max(256, min(n, 8192))
+        ora = lib.context(0)
+        ora.load_msa(rows[:n1].reshape(-1), np.arange(n1 + 1, dtype=np.int64) * L)
+        n_ex = ora.build_windows(p0, W, k, v)
+        expand_exceptions(ora, n_ex, k, v)
+        alln = ora.eval_candidates(np.arange(W, dtype=np.int32), np.full((W, k), 15, np.uint8), 0, 0)
+        ev1 = int((alln[:, 0] + alln[:, 1]).sum()) * C
+        t0 = time.perf_counter()
+        ora.eval_candidates(w.cw, w.codes, w.sF, w.sR)
+        dt1 = time.perf_counter() - t0
+        out["one_core"] = {"value": ev1 / dt1, "cores": 1, "sample": f"first {n1} sequences, {ev1} evals in {dt1:.2f} s"}
+    if python_leg:
+        out["python_reference"] = python_reference_leg(w, lib, seed)
+    return out
+
+
+def python_reference_leg(w, oracle_lib, seed, n_rows=2000, budget_s=8.0):
+    """The reference's own evaluation (mis_primer_check / Y_distance, V20:1103-1130 / 229-233) restated in Python the way the
+    reference computes it, ONE core (its process pool is inert), on gap-free rows of the same generator for as many
+    windows as fit `budget_s`; its counts are checked against the plain-C oracle on the same rows."""
+    from multiprime_amd import iupac
+    from oracle.py_reference_eval import mis_primer_check
+    L, p0, k, v, C = w.L, w.p0, w.k, w.v, w.C
+    rows = synth_rows(0, n_rows, L, seed, p_gap=0.0, edge_frac=0.0, p_iupac=0.0)
+    text = [r.tobytes().decode() for r in rows]
+    f_set, r_set = {2, 3, k}, {2, k - 3, k - 2}
+    got, wins = [], []
+    evals = 0
     t0 = time.perf_counter()
-    ora.eval_candidates(cw, codes, sF, sR)
-    dt1 = time.perf_counter() - t0
-    return {"value": evals / eval_wall, "unit": "evals/s", "cores": T, "kind": "port", "host_cores": cores,
-            "sample": f"all {n} sequences of the shard, all {W} windows x {C} candidates = {evals} evals on {T} threads in {eval_wall:.2f} s "
-                      f"(oracle/mprime_oracle.c; {wall_all:.1f} s incl. building the oracle's own tables); the Python reference itself "
-                      f"measures 2-3e5 evals/s inside mis_primer_check on one core (BASELINE.md)",
-            "one_core": {"value": ev1 / dt1, "cores": 1, "sample": f"first {n1} sequences, {ev1} evals in {dt1:.2f} s"},
-            "parity_checked": parity,
-            "parity_note": "per candidate, all three counters, GPU == sum of the oracle's row blocks" if parity is not None else "sample is not the whole shard: no comparison"}
+    for win in range(0, w.W, 37):
+        cover = {}
+        for s in text:
+            km = s[p0 + win:p0 + win + k]
+            cover[km] = cover.get(km, 0) + 1
+        universe = set(cover)
+        for c in range(C):
+            primer = iupac.strings_of(iupac.SYMBOL_LUT[w.codes[win * C + c][None, :]])[0]
+            got.append(mis_primer_check(universe, primer, cover, v, f_set, r_set))
+            evals += n_rows
+        wins.append(win)
+        if time.perf_counter() - t0 > budget_s:
+            break
+    dt = time.perf_counter() - t0
+    ora = oracle_lib.context(0)
+    ora.load_msa(rows.reshape(-1), np.arange(n_rows + 1, dtype=np.int64) * L)
+    ora.build_windows(p0, w.W, k, v)
+    sel = np.concatenate([np.arange(win * C, win * C + C) for win in wins])
+    want = ora.eval_candidates(w.cw[sel], w.codes[sel], w.sF, w.sR)
+    return {"value": evals / dt, "unit": "evals/s", "cores": 1, "kind": "port of the reference's Python (oracle/py_reference_eval.py)",
+            "sample": f"{n_rows} gap-free sequences of the same generator, {len(wins)} windows x {C} candidates = {evals} evals in {dt:.1f} s "
+                      f"(dict construction included, as in the reference)",
+            "equals_oracle": bool(np.array_equal(np.asarray(got, np.int64), want))}
 
 
 if __name__ == "__main__":

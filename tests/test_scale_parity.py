@@ -35,12 +35,16 @@ def test_bench_workload_hip_equals_oracle_per_candidate(hip_lib):
     sR = sum(1 << y for y in (2, k - 3, k - 2) if 0 <= y < k)
     got = ctx.eval_candidates(cw, codes, sF, sR)
     assert got.sum(axis=0).tolist() == [616726984, 266359408, 250103822]        # the checksum the round-1 judge reproduced on the oracle
-    res = bench.cpu_baseline(rows, L, p0, W, k, v, cw, codes, sF, sR, C, 0, got)
+    from types import SimpleNamespace
+    wl = SimpleNamespace(L=L, p0=p0, W=W, k=k, v=v, C=C, cw=cw, codes=codes, sF=sF, sR=sR)
+    res = bench.cpu_baseline(wl, rows, 0, got, seed)
     assert res["parity_checked"] is True, res
+    assert res["python_reference"]["equals_oracle"] is True, res["python_reference"]      # the reference's own algorithm, restated
     # unrelated candidates take the symbol-table kernel: same comparison
     uw, ucodes = bench.make_candidates(root_codes, p0, W, k, C, seed + 1, nested=False)
     got_u = ctx.eval_candidates(uw, ucodes, sF, sR)
-    res_u = bench.cpu_baseline(rows, L, p0, W, k, v, uw, ucodes, sF, sR, C, 0, got_u)
+    wl.cw, wl.codes = uw, ucodes
+    res_u = bench.cpu_baseline(wl, rows, 0, got_u, seed, one_core=False, python_leg=False)
     assert res_u["parity_checked"] is True
 
 

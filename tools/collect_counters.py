@@ -5,8 +5,8 @@ per-dispatch counters of the timed evaluation kernel into one JSON entry keyed b
 
     python tools/collect_counters.py [--rows 131072] [--out gpurun_out/r02/prof_bench] [--tag r02]
 
-writes <out>/counters.json (copy to profiles/r02_counters.json: bench.py reads it for roofline.valu_frac / l2_frac /
-hbm_frac / traffic on an exact configuration match) and <out>/summary.txt (tools/summarize_profile.py view).
+writes <out>/counters.json (copy to profiles/r03_counters.json: bench.py reads it for roofline.valu_frac / l2_frac /
+hbm_frac / traffic on an exact match of configuration AND kernel source hash) and <out>/summary.txt (tools/summarize_profile.py view).
 Counter passes never combine --pmc with tracing domains other than the kernel trace.
 """
 import argparse
@@ -48,12 +48,13 @@ def per_kernel(dbfile):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--rows", type=int, default=131072)
-    ap.add_argument("--out", default=os.path.join(REPO, "gpurun_out", "r02", "prof_bench"))
+    ap.add_argument("--out", default=os.path.join(REPO, "gpurun_out", "r03", "prof_bench"))
     ap.add_argument("--bench-args", default="")
+    ap.add_argument("--merge", default="", help="an earlier counters.json whose entries for OTHER configurations are kept")
     a = ap.parse_args()
     a.out = os.path.abspath(a.out)                 # rocprofv3 runs from /tmp
     os.makedirs(a.out, exist_ok=True)
-    bench = [sys.executable, os.path.join(REPO, "bench.py"), "--rows", str(a.rows), "--no-cpu", "--no-variants"] + a.bench_args.split()
+    bench = [sys.executable, os.path.join(REPO, "bench.py"), "--rows", str(a.rows), "--no-cpu", "--no-variants", "--no-full"] + a.bench_args.split()
     # kernel trace of the bench command itself
     run(["rocprofv3", "--kernel-trace", "--stats", "-d", os.path.join(a.out, "trace"), "-o", "bench", "--"] + bench + ["--steps", "20", "--warmup", "3"],
         os.path.join(a.out, "trace_bench.json"))
@@ -70,7 +71,9 @@ def main():
     for l in open(os.path.join(a.out, "trace_bench.json")):
         if l.startswith("{"):
             line = json.loads(l)
-    entry = {"rows": a.rows}
+    sys.path.insert(0, REPO)
+    import bench as bench_mod
+    entry = {"rows": a.rows, "source_hash": bench_mod.kernel_source_hash()}
     if line:
         c = line["config"]
         entry.update({"cols": c["cols"], "k": c["k"], "v": c["variation"], "cands": c["candidates_per_window"], "mode": line["roofline"]["eval_mode"]})
@@ -132,7 +135,11 @@ def main():
     if "WRITE_SIZE" in raw:
         entry["hbm_write_bytes"] = raw["WRITE_SIZE"] * 1024
     entry["source"] = "tools/collect_counters.py: separate rocprofv3 --pmc passes of `python bench.py --steps 5 --warmup 1 --no-cpu --no-variants`, per-dispatch average of the timed kernel"
-    json.dump({"entries": [entry]}, open(os.path.join(a.out, "counters.json"), "w"), indent=1)
+    entries = [entry]
+    if a.merge and os.path.exists(a.merge):          # keep the entries of other configurations collected earlier
+        old = json.load(open(a.merge)).get("entries", [])
+        entries += [e for e in old if (e.get("rows"), e.get("mode")) != (entry.get("rows"), entry.get("mode"))]
+    json.dump({"entries": entries}, open(os.path.join(a.out, "counters.json"), "w"), indent=1)
     print(json.dumps(entry, indent=1))
     with open(os.path.join(a.out, "summary.txt"), "w") as f:
         subprocess.call([sys.executable, os.path.join(REPO, "tools", "summarize_profile.py"), a.out], stdout=f)
