@@ -70,7 +70,9 @@ class MprimeError(RuntimeError):
 class Library:
     """A shared library exporting the mprime C ABI."""
 
-    def __init__(self, path: str = HIP_LIB):
+    def __init__(self, path: str | None = None):
+        # MPRIME_LIBRARY: another build of the same C ABI (a debug build of this library; the ABI checker the tests load)
+        path = path or os.environ.get("MPRIME_LIBRARY") or HIP_LIB
         if not os.path.exists(path):
             raise MprimeError(-2, f"{path} is missing — build it with `python -c 'import __graft_entry__ as g; g.build()'` "
                                   "(hipcc --offload-arch=gfx950); there is no CPU fallback")

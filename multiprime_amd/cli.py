@@ -5,18 +5,35 @@ program instead of the reference script without touching the rule:
     python {scripts_dir}/multiPrime-core.py -i {tmsa} -n 4 -d 10 -v 1 -c 2,3,-1 -g 0.2,0.7 -s 150 \\
            -l 18 -e 3.6 -o {out} -f 0.7 -p 1
 
-Extra, optional flags: --device (GPU ordinal), --no-json (skip the two O(windows x sequences)
-JSON side files, which stop being writable at ~10^5 sequences — SURVEY §7 "hard parts").
+Extra, optional flags (additions must stay optional):
+  --device D     GPU ordinal (default: LOCAL_RANK under a launcher, else 0)
+  --no-json      skip the two O(windows x sequences) JSON side files, which stop being writable at ~10^5 sequences
+  --bitsets      also write <out>.coverage_bitsets.npz (the bitset form of those files)
+  --ngpu N       run on N GPUs of this node: the program re-launches itself as N ranks (torch.distributed.run, 127.0.0.1).
+                 The same happens without the flag when a launcher started it (WORLD_SIZE > 1).  What the ranks share:
+                   one alignment (-i / -o):  its ROWS — contiguous blocks, one all-reduce of the coverage counters over
+                                             RCCL (multiprime_amd/dist.py, SURVEY §8e); rank 0 writes the files;
+                   --batch:                  the CLUSTERS — rank r takes lines r, r + N, ... of the batch file, no collective.
+  --batch FILE   many alignments in ONE process per GPU: FILE holds one `input<TAB>output` pair per line, every pair runs
+                 with this command's flags.  The fixed cost of a process (interpreter, numpy, HIP runtime: 0.3-0.4 s, more
+                 than the work of a 500-sequence cluster) is paid once instead of once per cluster; a Snakemake workflow
+                 replaces the per-cluster rule by one rule over the cluster list.  Prints the reference's closing line per
+                 pair and one JSON summary (clusters per second) at the end.
 """
 from __future__ import annotations
 
 import argparse
+import json
+import os
+import socket
+import subprocess
+import sys
 import time
 
 
 def parse_args(argv=None):
     p = argparse.ArgumentParser(description="For degenerate primer design (MI355X-native core step)")
-    p.add_argument("-i", "--input", type=str, required=True, metavar="<file>",
+    p.add_argument("-i", "--input", type=str, default=None, metavar="<file>",
                    help="Input file: multi-alignment output (muscle or others).")
     p.add_argument("-l", "--plen", type=int, default=18, metavar="<int>", help="Length of primer. Default: 18.")
     p.add_argument("-n", "--dnum", type=int, default=4, metavar="<int>", help="Max number of degenerate. Default: 4.")
@@ -32,34 +49,123 @@ def parse_args(argv=None):
     p.add_argument("-p", "--proc", type=int, default=20, metavar="<int>",
                    help="Accepted for compatibility (the reference's process pool is inert; the work runs on the GPU).")
     p.add_argument("-a", "--away", type=int, default=4, metavar="<int>", help="Hairpin: minimal distance of paired bases. Default: 4.")
-    p.add_argument("-o", "--out", type=str, required=True, metavar="<file>", help="output file")
-    p.add_argument("--device", type=int, default=0, help="GPU ordinal (default 0)")
+    p.add_argument("-o", "--out", type=str, default=None, metavar="<file>", help="output file")
+    p.add_argument("--device", type=int, default=None, help="GPU ordinal (default: LOCAL_RANK under a launcher, else 0)")
+    p.add_argument("--ngpu", type=int, default=1, help="GPUs of this node to use: re-launches this command as that many ranks")
+    p.add_argument("--batch", type=str, default=None, metavar="<file>",
+                   help="file of `input<TAB>output` lines: all of them in one process per GPU with this command's flags")
     p.add_argument("--no-json", action="store_true", help="do not write the two *_seq_id_json side files")
     p.add_argument("--bitsets", action="store_true",
                    help="also write <out>.coverage_bitsets.npz: per window, one bit per sequence the primer does not "
                         "reach (the bitset form of the JSON files; scripts/get_multiPrime.py reads it when the JSON is absent)")
     p.add_argument("--stats", action="store_true", help="print per-phase timings to stderr")
-    return p.parse_args(argv)
+    args = p.parse_args(argv)
+    if args.batch is None and (args.input is None or args.out is None):
+        p.error("the following arguments are required: -i/--input, -o/--out (or --batch)")      # exit code 2, like the reference's parser
+    if args.ngpu < 1:
+        p.error("--ngpu must be at least 1")
+    return args
+
+
+def _launcher_env():
+    return int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1")), int(os.environ.get("LOCAL_RANK", "0"))
+
+
+def _respawn(n, argv):
+    """This same command as n ranks on this node (one process per GPU), rendezvous on 127.0.0.1."""
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    rest, skip = [], False
+    for tok in (sys.argv[1:] if argv is None else list(argv)):
+        if skip:
+            skip = False
+        elif tok == "--ngpu":
+            skip = True
+        elif not tok.startswith("--ngpu="):
+            rest.append(tok)
+    script = os.path.abspath(sys.argv[0]) if argv is None else os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))),
+                                                                            "scripts", "multiPrime-core.py")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), script] + rest
+    return subprocess.call(cmd)
+
+
+def _core(args, inp, out, device, comm):
+    from .core import NN_degenerate
+    return NN_degenerate(seq_file=inp, primer_length=args.plen, coverage=args.fraction,
+                         number_of_dege_bases=args.dnum, score_of_dege_bases=args.degeneracy,
+                         raw_entropy_threshold=args.entropy, product_len=args.size, position=args.coordinate,
+                         variation=args.variation, distance=args.away, GC=args.gc, nproc=args.proc, outfile=out,
+                         device=device, comm=comm, write_json=not args.no_json, write_bitsets=args.bitsets)
+
+
+def _closing_line(e1, e2):
+    # same closing line as the reference (V20:1193-1198): it lands in the Snakemake rule's log
+    print("INFO {} Total times: {}".format(time.strftime("%Y-%m-%d %H:%M:%S", time.localtime(time.time())),
+                                           round(float(e2 - e1), 2)), flush=True)
+
+
+def _run_batch(args, rank, world, device):
+    pairs = []
+    with open(args.batch) as f:
+        for line in f:
+            tok = line.split()
+            if not tok or tok[0].startswith("#"):
+                continue
+            if len(tok) != 2:
+                raise SystemExit(f"{args.batch}: expected `input<TAB>output`, got: {line.rstrip()}")
+            pairs.append(tok)
+    t0 = time.time()
+    mine = pairs[rank::world]
+    rows = 0
+    for inp, out in mine:
+        e1 = time.time()
+        app = _core(args, inp, out, device, None)
+        app.run()
+        rows += app.total_sequence_number
+        app.ctx.close()
+        _closing_line(e1, time.time())
+    dt = time.time() - t0
+    print(json.dumps({"batch": args.batch, "rank": rank, "n_ranks": world, "clusters": len(mine), "sequences": rows,
+                      "seconds": round(dt, 3), "clusters_per_s": round(len(mine) / dt, 2) if dt > 0 else None}), flush=True)
 
 
 def main(argv=None):
-    from .core import NN_degenerate
     args = parse_args(argv)
+    rank, world, local = _launcher_env()
+    if args.ngpu > 1 and world == 1:
+        sys.exit(_respawn(args.ngpu, argv))
+    device = args.device if args.device is not None else local
+    if args.batch is not None:
+        _run_batch(args, rank, world, device)           # clusters are independent: no process group, no collective
+        return
+    comm = None
+    if world > 1:                                       # one alignment on several GPUs: its rows are sharded
+        import torch
+        import torch.distributed as dist
+        from .dist import RowShards
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        backend = os.environ.get("MP_DIST_BACKEND") or ("nccl" if torch.cuda.is_available() else "gloo")
+        if backend == "nccl":
+            torch.cuda.set_device(device)
+            dist.init_process_group("nccl", device_id=torch.device("cuda", device))
+        else:
+            dist.init_process_group(backend)
+        comm = RowShards()
     e1 = time.time()
-    app = NN_degenerate(seq_file=args.input, primer_length=args.plen, coverage=args.fraction,
-                        number_of_dege_bases=args.dnum, score_of_dege_bases=args.degeneracy,
-                        raw_entropy_threshold=args.entropy, product_len=args.size, position=args.coordinate,
-                        variation=args.variation, distance=args.away, GC=args.gc, nproc=args.proc, outfile=args.out,
-                        device=args.device, write_json=not args.no_json, write_bitsets=args.bitsets)
-    app.run()
+    try:
+        app = _core(args, args.input, args.out, device, comm)
+        app.run()
+    finally:
+        if comm is not None:
+            import torch.distributed as dist
+            dist.destroy_process_group()
     e2 = time.time()
-    if args.stats:
-        import json
-        import sys
+    if args.stats and rank == 0:
         print(json.dumps({k: (round(v, 4) if isinstance(v, float) else v) for k, v in app.stats.items()}), file=sys.stderr)
-    # same closing line as the reference (V20:1193-1198): it lands in the Snakemake rule's log
-    print("INFO {} Total times: {}".format(time.strftime("%Y-%m-%d %H:%M:%S", time.localtime(time.time())),
-                                           round(float(e2 - e1), 2)))
+    if rank == 0:
+        _closing_line(e1, e2)
 
 
 if __name__ == "__main__":

@@ -1,22 +1,26 @@
-"""Drop-in for scripts/primer_coverage_validation_by_BWT_V9.py ("BWT") — SURVEY §8f-3: which primer pairs of a primer
-set amplify which sequences of a database when a few mismatches are tolerated, with the bowtie2 + samtools mapping step
-(BWT:264-300) replaced by one exhaustive GPU scan (mp_kmm_scan, csrc/scan.hip).
+"""Drop-in for scripts/primer_coverage_validation_by_BWT_V9.py ("V9") — SURVEY §8f-3: which primer pairs of a primer set
+amplify which sequences of a database when a few mismatches are tolerated.  The reference maps the expanded 3' terms with
+bowtie2, splits the SAM by strand with samtools (V9:264-286) and pairs the surviving sites per sequence; here the mapping is
+ONE exhaustive GPU scan (mp_kmm_scan, csrc/scan.hip) and the rest is restated in three stages of its own:
 
-Same class (`off_targets`), flags and output files as the reference script:
-  <out>                   Chrom (or Genes) / Start / Stop / Primer_F / Primer_R / Product length
-  <out>.pair.num          primer pairs by number of products and of distinct targets
-  <out>.total.acc.num     number of covered sequences (and of all targets with -d)
-  <out>.unmatched.fa      with -d <pickle>: the records no pair reaches
-  <primers>.term.fa       the expanded 3' terms (BWT:205-239) — written as the reference does
+  TermTable    the reads: every distinct 3' term of the primer file, expanded (V9:205-239)  ->  <primers>.term.fa
+  sites        {strand: {sequence: {start: primer}}} — from the GPU scan, or, exactly as the reference does when it finds them
+               (V9:270-271), from existing <primers>.for.sam / .rev.sam files filtered by the MD:Z rule of build_dict (V9:241-262)
+  amplicons    per sequence, the (forward start, reverse start) combinations inside the size range (V9:318-345), vectorised
+  reports      <out>, <out>.pair.num, <out>.total.acc.num, <out>.unmatched.fa (V9:377-398)
 
-PARITY UNPINNED.  bowtie2 and samtools are not installed in the authoring image, so no reference output could be
-recorded.  What is restated exactly is everything the script itself does around the mapper (get_term, the MD:Z filter of
-build_dict, PCR_product, the writers); the mapper is replaced by its acceptance rule under default end-to-end scoring:
-an ungapped alignment with at most floor((0.6 + 0.6 L) / 6) mismatches (bowtie2's minimum score -0.6 - 0.6 L at 6 per
-mismatch; `--max-mismatch` overrides), reported on both strands (`-a`).  Differences to expect against a real bowtie2 run:
-gapped alignments are not reported; bowtie2's seed heuristics (-N, -L 8) can MISS alignments this scan finds; ties in
-`dict(F_dict[gene])` (several primers at one start) resolve by pattern order here, by SAM order there; genes are written in
-database order, the reference's order follows a set().
+Same class name (`off_targets`), constructor arguments, flags and output files as the reference script.
+
+PARITY: everything around the mapper is pinned to the reference — tests/golden/validate.json.gz holds what the unmodified V9
+class writes for hand-written and seeded SAM input (tests/golden/make_golden_validate.py), this module reproduces it from the
+same SAM text, and the GPU scan is checked end to end against the same stages fed with the SAM lines its hits stand for.  The
+MAPPER ITSELF IS UNPINNED: bowtie2 / samtools are not installed in the authoring image.  It is replaced by its acceptance rule
+under default end-to-end scoring — an ungapped alignment with at most floor((0.6 + 0.6 L) / 6) mismatches (minimum score
+-0.6 - 0.6 L at 6 per mismatch; `--max-mismatch` overrides), both strands, every site (`-a`).  Against a real bowtie2 run
+expect: no gapped alignments here; sites bowtie2's seed heuristics (-N, -L 8) miss are found here.
+
+Orders the reference takes from a Python set (sequences in <out>, names inside a shared term id, unmatched records) are
+deterministic here: first appearance in the forward sites / the primer file / sorted names.
 """
 from __future__ import annotations
 
@@ -24,35 +28,25 @@ import os
 import pickle
 import re
 import time
-from bisect import bisect_left
-from collections import defaultdict
 from pathlib import Path
 
 import numpy as np
 
 from . import iupac
 from ._abi import Library
+from .dimer import PATTERN_MAX_LEN
 
-_DEGENERATE = set("RYMKSWHBVDN")
+_READ_INDEX = re.compile(r"_\d+$")          # a read name ends in the index of its expansion (V9:249)
+_MD_TAG = re.compile(r"MD:Z:(\w+)")
+_DIGITS = re.compile(r"\d+")
 
 
 def degenerate_seq(primer: str):
-    """BWT:193-203: expansions in itertools.product order; symbols outside the IUPAC table stay as they are."""
-    parts = [iupac.MEMBERS[ch] if ch in _DEGENERATE else ch for ch in primer]
+    """Concrete sequences of a degenerate one in itertools.product order (V9:193-203); other characters stay as they are."""
     out = [""]
-    for p in parts:
-        out = [a + b for a in out for b in p]
+    for ch in primer:
+        out = [a + b for a in out for b in (iupac.MEMBERS[ch] if ch in "RYMKSWHBVDN" else ch)]
     return out
-
-
-def closest(my_list, my_number1, my_number2):
-    """BWT:160-168."""
-    index_left = bisect_left(my_list, my_number1)
-    if my_number2 > my_list[-1]:
-        index_right = len(my_list) - 1
-    else:
-        index_right = bisect_left(my_list, my_number2) - 1
-    return index_left, index_right
 
 
 def bowtie2_mismatch_budget(length: int) -> int:
@@ -60,11 +54,78 @@ def bowtie2_mismatch_budget(length: int) -> int:
     return int((0.6 + 0.6 * length) // 6)
 
 
+class TermTable:
+    """The reads of the mapping step: expanded 3' terms -> read name (V9:205-239).  A line of the primer file that starts with
+    '>' names the lines after it; every other line is a primer (the reference does not join wrapped records, nor does this)."""
+
+    def __init__(self, primer_file, term_len):
+        owners = {}                                  # term -> primer names, file order
+        name = None
+        with open(primer_file) as f:
+            for line in f:
+                text = line.strip()
+                if line.startswith(">"):
+                    name = text.lstrip(">")
+                else:
+                    owners.setdefault(text if term_len == 0 else text[-term_len:], []).append(name)
+        self.reads = {}                              # concrete sequence -> the ids that expand to it
+        for term, names in owners.items():
+            stem = "_".join(dict.fromkeys(names))
+            for j, seq in enumerate(degenerate_seq(term)):
+                self.reads.setdefault(seq, []).append(f"{stem}_{j}")
+
+    def names(self):
+        return ["_".join(ids) for ids in self.reads.values()]
+
+    def write(self, path):
+        with open(path, "w") as fo:
+            fo.writelines(f">{name}\n{seq}\n" for seq, name in zip(self.reads, self.names()))
+
+
+def sites_of_sam(path, threshold):
+    """{sequence: {0-based start: primer}} of one strand's SAM file under build_dict's rule (V9:241-262): an alignment counts
+    when the number its MD:Z tag ENDS with — read from the tag's last two characters only, so 12 for "5A12" but 0 for "15C10"
+    — is at least `threshold`; lines without the tag (unaligned reads) do not count.  Later lines replace earlier ones at the
+    same start (the reference turns its list into a dict, V9:320-322)."""
+    sites = {}
+    with open(path) as f:
+        for line in f:
+            col = line.strip().split("\t")
+            tag = _MD_TAG.search("\t".join(col[11:]))
+            if tag and int(_DIGITS.search(tag.group(1)[-2:]).group()) >= threshold:
+                sites.setdefault(col[2], {})[int(col[3]) - 1] = _READ_INDEX.split(col[0])[0]
+    return sites
+
+
+def amplicons(forward, reverse, size_lo, size_hi):
+    """(start, stop, forward primer, reverse primer, length) of one sequence, in the reference's order (V9:318-345): starts
+    ascending, stops ascending, length = stop - start + 1 strictly inside (size_lo, size_hi).  Two quirks are kept: no product
+    at all when the sites cannot be closer than size_hi or farther than size_lo as a whole, and the FIRST start without a
+    reverse site in [start + size_lo, start + size_hi) ends the search for the later starts as well."""
+    starts = np.fromiter(sorted(forward), np.int64, len(forward))
+    stops = np.fromiter(sorted(reverse), np.int64, len(reverse))
+    if stops[0] - starts[-1] > size_hi or stops[-1] - starts[0] < size_lo:
+        return []
+    first = np.searchsorted(stops, starts + size_lo, "left")
+    last = np.where(starts + size_hi > stops[-1], len(stops) - 1, np.searchsorted(stops, starts + size_hi, "left") - 1)
+    dead = np.nonzero(first > last)[0]
+    n_live = int(dead[0]) if len(dead) else len(starts)
+    # stop - start + 1 < size_hi; from `first` on stop >= start + size_lo, so the lower bound holds already
+    last = np.minimum(last, np.searchsorted(stops, starts + size_hi - 1, "left") - 1)
+    out = []
+    for i in range(n_live):
+        a = int(starts[i])
+        for b in stops[first[i]:last[i] + 1].tolist():
+            if b - a + 1 > size_lo:
+                out.append((a, b, forward[a], reverse[b], b - a + 1))
+    return out
+
+
 class off_targets(object):
     def __init__(self, primer_file, term_length, reference_file, PCR_product_size, mismatch_num, outfile, term_threshold,
                  bowtie="bowtie2", nproc=20, targets="None", *, library: Library | None = None, device: int = 0, max_mismatch=None):
         self.bowtie = bowtie                    # accepted for compatibility: no external mapper is run
-        self.term_threshold = term_threshold
+        self.term_threshold = int(term_threshold)
         self.nproc = nproc
         self.term_len = term_length
         self.primer_file = primer_file
@@ -74,141 +135,95 @@ class off_targets(object):
         self.mismatch_num = mismatch_num        # bowtie's -N / -n: seed sensitivity only, the scan is exhaustive
         self.targets = targets
         self.max_mismatch = max_mismatch
-        self.lib = library if library is not None else Library()
-        self.ctx = self.lib.context(device)
+        self._library, self._device = library, device
         self.stats = {}
 
-    def get_term(self):
-        """BWT:205-239."""
-        Output = Path(self.primer_file).parent.joinpath(Path(self.primer_file).stem).with_suffix(".term.fa")
-        term_len = self.term_len
-        term_list = defaultdict(list)
-        seq_ID = defaultdict(list)
-        with open(self.primer_file, "r") as f:
-            for i in f:
-                if i.startswith(">"):
-                    value = i.strip().lstrip(">")
-                else:
-                    key = i.strip() if term_len == 0 else i.strip()[-term_len:]
-                    term_list[key].append(value)
-        for k in term_list.keys():
-            Id = "_".join(dict.fromkeys(term_list[k]))           # the reference joins a set(): first-seen order here
-            expand_seq = degenerate_seq(k)
-            if len(expand_seq) > 1:
-                for j in range(len(expand_seq)):
-                    seq_ID[expand_seq[j]].append(Id + "_" + str(j))
-            else:
-                seq_ID[k].append(Id + "_0")
-        with open(Output, "w") as fo:
-            for seq in seq_ID.keys():
-                fo.write(">" + "_".join(seq_ID[seq]) + "\n" + seq + "\n")
-        return seq_ID
+    def _beside_primers(self, suffix):
+        return Path(self.primer_file).parent.joinpath(Path(self.primer_file).stem).with_suffix(suffix)
 
-    def _reference_records(self):
+    # -- sites from the GPU ------------------------------------------------------------------------------------------------
+    def scan(self, table: TermTable):
+        """Both strands' sites from one exhaustive k-mismatch scan of the reference FASTA (replaces V9:264-316)."""
         from .host import Fasta
         path = str(self.reference_file)
         if not os.path.exists(path):
             raise FileNotFoundError(path + ": the scan needs the reference FASTA itself (a bowtie index prefix is not enough)")
+        t0 = time.time()
         fa = Fasta(path)
         data, row_off = fa.rows()
-        names = [s[1:] if s.startswith(">") else s for s in fa.ids]     # bowtie names a reference by its first token
-        return names, data, row_off
-
-    def scan(self, seq_ID):
-        """Replaces bowtie_map + build_dict_run (BWT:241-316): {gene: [[start, primer], ...]} for both strands."""
-        t0 = time.time()
-        names, data, row_off = self._reference_records()
-        reads = [(seq, "_".join(ids)) for seq, ids in seq_ID.items()]
-        usable = [(i, seq) for i, (seq, _) in enumerate(reads) if seq and not set(seq.upper()) - set("ACGT") and 4 <= len(seq) <= 32]
-        forward_dict, reverse_dict = defaultdict(list), defaultdict(list)
-        by_budget = defaultdict(list)
-        for i, seq in usable:
-            budget = self.max_mismatch if self.max_mismatch is not None else bowtie2_mismatch_budget(len(seq))
-            by_budget[budget].append((i, seq.upper()))
-        all_hits = []
-        for budget, group in by_budget.items():
-            codes = iupac.MASK_LUT[np.frombuffer("".join(s for _, s in group).encode(), np.uint8)]
-            off = np.zeros(len(group) + 1, np.int32)
-            np.cumsum([len(s) for _, s in group], out=off[1:])
-            h = self.ctx.kmm_scan(data, row_off, codes, off, budget, int(self.term_threshold))
+        genes = [s[1:] if s.startswith(">") else s for s in fa.ids]          # a mapper names a sequence by its first token
+        seqs, names = list(table.reads), table.names()
+        for seq, name in zip(seqs, names):
+            if set(seq.upper()) - set("ACGT") or not 4 <= len(seq) <= PATTERN_MAX_LEN:
+                # the reference hands any read to bowtie2; this build packs a read into 64 bits (INTEGRATION.md, "Limits")
+                raise ValueError(f"read {name} ({seq}): the scan takes 4..{PATTERN_MAX_LEN} bases of ACGT after expansion; "
+                                 f"use -l to map the 3' term of longer primers")
+        lib = self._library if self._library is not None else Library()
+        ctx = lib.context(self._device)
+        budgets = {}
+        for i, seq in enumerate(seqs):
+            budgets.setdefault(self.max_mismatch if self.max_mismatch is not None else bowtie2_mismatch_budget(len(seq)), []).append(i)
+        found = []
+        for budget, members in budgets.items():
+            codes = iupac.MASK_LUT[np.frombuffer("".join(seqs[i].upper() for i in members).encode(), np.uint8)]
+            off = np.zeros(len(members) + 1, np.int32)
+            np.cumsum([len(seqs[i]) for i in members], out=off[1:])
+            h = ctx.kmm_scan(data, row_off, codes, off, budget, self.term_threshold)
             if len(h):
                 h = h.copy()
-                h[:, 2] = np.asarray([i for i, _ in group], np.int32)[h[:, 2]]
-                all_hits.append(h)
+                h[:, 2] = np.asarray(members, np.int32)[h[:, 2]]
+                found.append(h)
+        ctx.close()
         self.stats["scan_s"] = time.time() - t0
-        if all_hits:
-            h = np.concatenate(all_hits)
-            h = h[np.lexsort((h[:, 1], h[:, 0], h[:, 2]))]           # SAM order: read by read
-            for row, pos, pat, strand in h.tolist():
-                primer = re.split(r"_\d+$", reads[pat][1])[0]        # BWT:249
-                (reverse_dict if strand else forward_dict)[names[row]].append([pos, primer])
-        print("Number of genes with candidate primers: forward ==> {}; reverse ==> {}.".format(len(forward_dict), len(reverse_dict)))
-        both = set(forward_dict.keys()).intersection(reverse_dict.keys())
-        target_gene = [g for g in dict.fromkeys(names) if g in both]
+        sites = ({}, {})
+        if found:
+            h = np.concatenate(found)
+            h = h[np.lexsort((h[:, 1], h[:, 0], h[:, 2]))]                  # read by read, as a mapper reports them
+            primers = [_READ_INDEX.split(n)[0] for n in names]
+            for row, pos, read, strand in h.tolist():
+                sites[strand].setdefault(genes[row], {})[pos] = primers[read]
+        return sites
+
+    # -- reports -------------------------------------------------------------------------------------------------------------
+    def _report(self, forward, reverse):
+        print("Number of genes with candidate primers: forward ==> {}; reverse ==> {}.".format(len(forward), len(reverse)))
+        both = [g for g in forward if g in reverse]
         print("Number of genes with candidate primer pairs: {}.".format(len(both)))
-        return target_gene, forward_dict, reverse_dict
-
-    def PCR_product(self, gene, F_dict, R_dict):
-        """BWT:318-359; returns the lines instead of queueing them."""
-        out = []
-        product_len = self.PCR_size.split(",")
-        primer_F = dict(F_dict[gene])
-        position_start = sorted(primer_F.keys())
-        primer_R = dict(R_dict[gene])
-        position_stop = sorted(primer_R.keys())
-        if int(position_stop[0]) - int(position_start[-1]) > int(product_len[1]):
-            pass
-        elif int(position_stop[-1]) - int(position_start[0]) < int(product_len[0]):
-            pass
-        else:
-            for start in range(len(position_start)):
-                stop_index_start, stop_index_stop = closest(position_stop, position_start[start] + int(product_len[0]),
-                                                            position_start[start] + int(product_len[1]))
-                if stop_index_start > stop_index_stop:
-                    break
-                for stop in range(stop_index_start, stop_index_stop + 1):
-                    distance = int(position_stop[stop]) - int(position_start[start]) + 1
-                    if distance > int(product_len[1]):
-                        break
-                    elif int(product_len[0]) < distance < int(product_len[1]):
-                        out.append((gene, int(position_start[start]), int(position_stop[stop]), primer_F[position_start[start]],
-                                    primer_R[position_stop[stop]], distance))
-        return out
-
-    def run(self):
-        seq_ID = self.get_term()
-        target_gene, forward_dict, reverse_dict = self.scan(seq_ID)
-        primer_pair_id = defaultdict(int)
-        primer_pair_acc = defaultdict(list)
-        acc_id = set()
+        lo, hi = (int(x) for x in self.PCR_size.split(",")[:2])
+        per_pair = {}                                                       # "F<TAB>R" -> [products, {sequences}]
+        covered = set()
         with open(self.outfile, "w") as fo:
-            fo.write("\t".join(["Chrom (or Genes)", "Start", "Stop", "Primer_F", "Primer_R", "Product length"]) + "\n")
-            for gene in target_gene:
-                for res in self.PCR_product(gene, forward_dict, reverse_dict):
-                    primer_pair_id[res[3] + "\t" + res[4]] += 1
-                    primer_pair_acc[res[3] + "\t" + res[4]].append(res[0])
-                    acc_id.add(res[0])
-                    fo.write("\t".join(map(str, res)) + "\n")
-        primer_pair_id_sort = sorted(primer_pair_id.items(), key=lambda x: x[1], reverse=True)
-        target_seq = set()
+            fo.write("Chrom (or Genes)\tStart\tStop\tPrimer_F\tPrimer_R\tProduct length\n")
+            for gene in both:
+                for start, stop, pf, pr, length in amplicons(forward[gene], reverse[gene], lo, hi):
+                    fo.write(f"{gene}\t{start}\t{stop}\t{pf}\t{pr}\t{length}\n")
+                    tally = per_pair.setdefault(pf + "\t" + pr, [0, set()])
+                    tally[0] += 1
+                    tally[1].add(gene)
+                    covered.add(gene)
         with open(self.outfile + ".pair.num", "w") as fo:
             fo.write("Primer_F\tPrimer_R\tPair_num\ttarget accession number\n")
-            for k in primer_pair_id_sort:
-                primer_pair_acc_set = set(primer_pair_acc[k[0]])
-                target_seq = target_seq.union(primer_pair_acc_set)
-                fo.write(k[0] + "\t" + str(k[1]) + "\t" + str(len(primer_pair_acc_set)) + "\n")
-        with open(self.outfile + ".total.acc.num", "w") as fo2:
-            fo2.write("total coverage of primer set (PS) is: {}\n".format(len(acc_id)))
-        if self.targets != "None":
-            with open(self.outfile + ".unmatched.fa", "w") as out:
-                with open(self.targets, "rb") as raw_total_seq_dict:
-                    total_dict = pickle.load(raw_total_seq_dict)
-                print(len(set(total_dict.keys())), len(target_seq))
-                unmatched_seq_set = set(total_dict.keys()) - target_seq
-                with open(self.outfile + ".total.acc.num", "a+") as fo3:
-                    fo3.write("total target number is: {}\n".format(len(total_dict.keys())))
-                for unmatch in sorted(unmatched_seq_set):
-                    out.write(total_dict[unmatch])
+            for pair, (n, genes) in sorted(per_pair.items(), key=lambda kv: kv[1][0], reverse=True):
+                fo.write(f"{pair}\t{n}\t{len(genes)}\n")
+        with open(self.outfile + ".total.acc.num", "w") as fo:
+            fo.write("total coverage of primer set (PS) is: {}\n".format(len(covered)))
+            if self.targets != "None":
+                with open(self.targets, "rb") as f:
+                    records = pickle.load(f)                                # {name: FASTA record text} (prepare_fa_pickle.py)
+                print(len(records), len(covered))
+                fo.write("total target number is: {}\n".format(len(records)))
+                with open(self.outfile + ".unmatched.fa", "w") as out:
+                    out.writelines(records[name] for name in sorted(set(records) - covered))
+
+    def run(self):
+        table = TermTable(self.primer_file, self.term_len)
+        table.write(self._beside_primers(".term.fa"))
+        sams = [self._beside_primers(".for.sam"), self._beside_primers(".rev.sam")]
+        if all(p.exists() for p in sams):                                   # V9:270-271: existing SAM files are used, nothing is mapped
+            forward, reverse = (sites_of_sam(p, self.term_threshold) for p in sams)
+        else:
+            forward, reverse = self.scan(table)
+        self._report(forward, reverse)
 
 
 def parse_args(argv=None):

@@ -1,0 +1,85 @@
+"""The drop-in command itself on several ranks (CPU, gloo): `scripts/multiPrime-core.py` under torch.distributed.run shards the
+rows of ONE alignment (rank 0 writes, bytes equal the reference's files), `--ngpu N` launches the ranks itself, and `--batch`
+spreads CLUSTERS over the ranks without a collective.  The device calls go to the ABI checker (MPRIME_LIBRARY), as in
+test_multirank.py; the command line, the launcher glue and the collectives are the product's."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+from conftest import REPO, golden_input, load_gz_json
+from test_core_golden import check_outputs
+
+SCRIPT = os.path.join(REPO, "scripts", "multiPrime-core.py")
+
+
+def _flags(name):
+    fl = load_gz_json(name + ".trace.json.gz")["meta"]["flags"]
+    return ["-l", str(fl["l"]), "-n", str(fl["n"]), "-d", str(fl["d"]), "-v", str(fl["v"]), "-e", str(fl["e"]), "-g", fl["g"],
+            "-s", str(fl["s"]), "-f", str(fl["f"]), "-c", fl["c"], "-a", str(fl["a"]), "-p", "1"]
+
+
+def _env(oracle_lib):
+    env = dict(os.environ, MPRIME_LIBRARY=oracle_lib.path, MP_DIST_BACKEND="gloo", MASTER_ADDR="127.0.0.1")
+    for key in ("RANK", "WORLD_SIZE", "LOCAL_RANK"):
+        env.pop(key, None)
+    return env
+
+
+def _input(name, tmp_path):
+    meta = load_gz_json(name + ".trace.json.gz")["meta"]
+    inp = tmp_path / (name + ".fa")
+    inp.write_bytes(golden_input(meta["input"]))
+    return inp
+
+
+@pytest.mark.parametrize("name,world", [("ivc_v1", 2), ("syn_ragged", 3)])
+def test_drop_in_under_the_launcher_shards_rows(name, world, oracle_lib, tmp_path):
+    inp, out = _input(name, tmp_path), tmp_path / (name + ".out")
+    port = 29600 + (os.getpid() % 2000)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), SCRIPT, "-i", str(inp), "-o", str(out)] + _flags(name)
+    r = subprocess.run(cmd, env=_env(oracle_lib), capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert r.stdout.count("Total times") == 1                      # rank 0 alone reports
+    check_outputs(name, out)                                        # TSV and both JSON side files, byte for byte
+
+
+def test_ngpu_flag_launches_the_ranks_itself(oracle_lib, tmp_path):
+    name = "syn_iupac"
+    inp, out = _input(name, tmp_path), tmp_path / (name + ".out")
+    r = subprocess.run([sys.executable, SCRIPT, "-i", str(inp), "-o", str(out), "--ngpu", "2"] + _flags(name), env=_env(oracle_lib),
+                       capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    check_outputs(name, out)
+
+
+def test_batch_mode_spreads_clusters_over_ranks(oracle_lib, tmp_path):
+    """Three alignments with one flag set (ivc_v1's): one process per rank, rank r takes lines r, r + 2, ..."""
+    name = "ivc_v1"
+    inp = _input(name, tmp_path)
+    outs = [tmp_path / f"c{i}.out" for i in range(3)]
+    batch = tmp_path / "batch.tsv"
+    batch.write_text("# input\toutput\n" + "".join(f"{inp}\t{o}\n" for o in outs))
+    r = subprocess.run([sys.executable, SCRIPT, "--batch", str(batch), "--ngpu", "2"] + _flags(name), env=_env(oracle_lib),
+                       capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-2000:]
+    for o in outs:
+        check_outputs(name, o)
+    summaries = [json.loads(line) for line in r.stdout.splitlines() if line.startswith("{")]
+    assert sorted(s["clusters"] for s in summaries) == [1, 2] and r.stdout.count("Total times") == 3
+
+
+def test_single_process_batch_and_missing_arguments(oracle_lib, tmp_path):
+    name = "syn_edge"
+    inp, out = _input(name, tmp_path), tmp_path / "one.out"
+    batch = tmp_path / "batch.tsv"
+    batch.write_text(f"{inp}\t{out}\n")
+    r = subprocess.run([sys.executable, SCRIPT, "--batch", str(batch)] + _flags(name), env=_env(oracle_lib), capture_output=True, text=True,
+                       timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    check_outputs(name, out)
+    r = subprocess.run([sys.executable, SCRIPT, "-i", str(inp)], env=_env(oracle_lib), capture_output=True, text=True, timeout=120)
+    assert r.returncode == 2 and "required" in r.stderr                # argparse's exit code, like the reference's parser
