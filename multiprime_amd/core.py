@@ -491,6 +491,12 @@ class NN_degenerate(object):
             off, words = self._dev_entries
             ex_w, x_row, ex_codes = self._exc
             ids_bytes, ids_off = self._fasta.ids_raw()
+            if len(wins) * self.ctx.n_rows > (1 << 28):
+                # the writer takes one label per (output window, sequence): 4 bytes each on the host, and the files themselves
+                # list an id per uncovered sequence and window (the reference cannot write them at this depth either)
+                print("Warning: the two *_seq_id_json side files need {:.1f} GB of labels for {} windows x {} sequences; "
+                      "--no-json --bitsets writes the same sets as bitsets.".format(len(wins) * self.ctx.n_rows * 4 / 1e9, len(wins),
+                                                                                   self.ctx.n_rows), file=sys.stderr)
             self.plan.write_side_files(wins, [int(r[0]) for r in rows_out], codes, self._sF, self._sR, off, words,
                                        self.ctx.get_labels_raw(wins), ex_w, x_row, ex_codes, ids_bytes, ids_off,
                                        self.outfile + ".non_coverage_seq_id_json", self.outfile + ".gap_seq_id_json")

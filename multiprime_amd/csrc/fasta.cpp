@@ -32,7 +32,9 @@ struct Event {                                                   // per line tha
     uint64_t hash;              // of the id token
 };
 
-inline bool is_space(uint8_t c) { return c == ' ' || (c >= 9 && c <= 13); }      // bytes.strip()
+// str.strip() of a text-mode line, ASCII range: space, \t \n \v \f \r and the separators 0x1c-0x1f (str.isspace is true for
+// them; bytes.strip() would leave them).  Non-ASCII white space (U+0085, U+00A0, ...) is not stripped: INTEGRATION.md.
+inline bool is_space(uint8_t c) { return c == ' ' || (c >= 9 && c <= 13) || (c >= 0x1c && c <= 0x1f); }
 
 inline uint64_t hash_bytes(const uint8_t *p, size_t n) {
     uint64_t h = 0xcbf29ce484222325ULL ^ (n * 0x9E3779B97F4A7C15ULL);
@@ -135,11 +137,17 @@ void scan_chunk(const uint8_t *b, int64_t n, int64_t begin, int64_t end, std::ve
         // the line is [p, q), q = its terminator or the end of the buffer
         int64_t q = p;
         {
-            const uint8_t *nl = (const uint8_t *)memchr(b + p, '\n', (size_t)(n - p));
-            int64_t qn = nl ? (int64_t)(nl - b) : n;
-            // a lone \r inside [p, qn) also ends the line (rare: only look when one exists)
-            const uint8_t *cr = (const uint8_t *)memchr(b + p, '\r', (size_t)(qn - p));
-            q = cr ? (int64_t)(cr - b) : qn;
+            // \n or a lone \r, whichever comes first.  The search window doubles until it holds one of them, so a file whose
+            // lines end in \r alone is not scanned to its end once per line.
+            int64_t lim = std::min<int64_t>(n, p + 256);
+            for (;;) {
+                const uint8_t *nl = (const uint8_t *)memchr(b + p, '\n', (size_t)(lim - p));
+                const int64_t qn = nl ? (int64_t)(nl - b) : lim;
+                const uint8_t *cr = (const uint8_t *)memchr(b + p, '\r', (size_t)(qn - p));
+                q = cr ? (int64_t)(cr - b) : qn;
+                if (nl || cr || lim == n) break;
+                lim = std::min<int64_t>(n, p + 2 * (lim - p));
+            }
         }
         int64_t next = q;
         if (q < n) next = (b[q] == '\r' && q + 1 < n && b[q + 1] == '\n') ? q + 2 : q + 1;

@@ -12,11 +12,13 @@
 #include <algorithm>
 #include <atomic>
 #include <cmath>
+#include <cerrno>
 #include <cstdarg>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <limits>
+#include <new>
 #include <string>
 #include <thread>
 #include <unordered_map>
@@ -518,6 +520,11 @@ const char *mp_plan_error(const mp_plan *p) { return p ? p->err : "mp_plan_creat
 
 void mp_plan_destroy(mp_plan *p) { delete p; }
 
+// the body of mp_plan_create; allocation failures (here and in the worker threads) leave as MP_ERR_NOMEM, never as exceptions
+static int plan_create_body(mp_plan *p, int64_t n_entries, const int32_t *e_window, const uint32_t *e_words, const int64_t *e_count,
+                            const int64_t *e_first, int64_t n_exc, const int32_t *x_window, const int64_t *x_row, const uint8_t *x_codes,
+                            const int64_t *freq, const int64_t *nn);
+
 int mp_plan_create(const mp_plan_params *params, int64_t n_entries, const int32_t *e_window, const uint32_t *e_words,
                    const int64_t *e_count, const int64_t *e_first, int64_t n_exc, const int32_t *x_window,
                    const int64_t *x_row, const uint8_t *x_codes, const int64_t *freq, const int64_t *nn, mp_plan **out) {
@@ -528,6 +535,18 @@ int mp_plan_create(const mp_plan_params *params, int64_t n_entries, const int32_
     if (!p) return MP_ERR_NOMEM;
     *out = p;                                  // returned even on failure so that the caller can read the message
     p->P = *params;
+    try {
+        return plan_create_body(p, n_entries, e_window, e_words, e_count, e_first, n_exc, x_window, x_row, x_codes, freq, nn);
+    } catch (const std::bad_alloc &) {
+        return pfail(p, MP_ERR_NOMEM, "mp_plan_create: out of memory");
+    } catch (const std::exception &e) {
+        return pfail(p, MP_ERR_ARG, "mp_plan_create: %s", e.what());
+    }
+}
+
+static int plan_create_body(mp_plan *p, int64_t n_entries, const int32_t *e_window, const uint32_t *e_words, const int64_t *e_count,
+                            const int64_t *e_first, int64_t n_exc, const int32_t *x_window, const int64_t *x_row, const uint8_t *x_codes,
+                            const int64_t *freq, const int64_t *nn) {
     const mp_plan_params &P = p->P;
     const int k = P.k, W = P.n_windows;
     if (k < 2 || k > 32 || W < 0 || P.v < 0 || P.total_sequences <= 0) return pfail(p, MP_ERR_ARG, "mp_plan_create: bad parameters");
@@ -552,16 +571,12 @@ int mp_plan_create(const mp_plan_params *params, int64_t n_entries, const int32_
         std::vector<int64_t> cux(xoff.begin(), xoff.end() - 1);
         for (int64_t i = 0; i < n_exc; i++) xidx[(size_t)cux[(size_t)x_window[i]]++] = i;
     }
-    try {
-        p->win.resize((size_t)W);
-    } catch (...) {
-        return pfail(p, MP_ERR_NOMEM, "mp_plan_create: out of memory");
-    }
+    p->win.resize((size_t)W);
     const uint32_t kmask = k == 32 ? 0xFFFFFFFFu : ((1u << k) - 1u);
     const double max_exp = 1 << 22;            // expansions of one exception k-mer the host is willing to enumerate
     std::atomic<int> next{0}, failed{0};       // failed: 0 or the MP_ERR_* code of the first failure
     const int n_thr = resolve_threads(P.n_threads, W);
-    auto worker = [&]() {
+    auto work = [&]() {
         std::vector<Sight> sights;
         for (;;) {
             int w = next.fetch_add(1);
@@ -613,6 +628,17 @@ int mp_plan_create(const mp_plan_params *params, int64_t n_entries, const int32_
                 std::vector<Entry>().swap(ww.gap);
                 std::vector<int32_t>().swap(ww.cover_map.slot);
             }
+        }
+    };
+    auto worker = [&]() {                      // an exception must not leave a thread (std::terminate) nor cross the C boundary
+        try {
+            work();
+        } catch (const std::bad_alloc &) {
+            int zero = 0;
+            if (failed.compare_exchange_strong(zero, MP_ERR_NOMEM)) pfail(p, MP_ERR_NOMEM, "mp_plan_create: out of memory while planning the windows");
+        } catch (const std::exception &e) {
+            int zero = 0;
+            if (failed.compare_exchange_strong(zero, MP_ERR_ARG)) pfail(p, MP_ERR_ARG, "mp_plan_create: %s", e.what());
         }
     };
     if (n_thr <= 1) worker();
@@ -928,8 +954,12 @@ extern "C" int mp_plan_write_side_files(const mp_plan *p, int32_t n_out, const i
     if (!p->P.keep_tables) return MP_ERR_ARG;
     const int k = p->P.k, v = p->P.v;
     const uint32_t kmask = k == 32 ? 0xFFFFFFFFu : ((1u << k) - 1u);
-    FILE *fn = fopen(noncov_path, "wb"), *fg = fopen(gap_path, "wb");
-    if (!fn || !fg) { if (fn) fclose(fn); if (fg) fclose(fg); return MP_ERR_ARG; }
+    mp_plan *pm = const_cast<mp_plan *>(p);                              // the message buffer only
+    FILE *fn = fopen(noncov_path, "wb");
+    if (!fn) return pfail(pm, MP_ERR_ARG, "%s: %s", noncov_path, strerror(errno));
+    FILE *fg = fopen(gap_path, "wb");
+    if (!fg) { const int e = errno; fclose(fn); return pfail(pm, MP_ERR_ARG, "%s: %s", gap_path, strerror(e)); }
+    try {
     Out on(fn), og(fg);
     // exceptions grouped by window, ascending rows
     std::vector<int64_t> xorder((size_t)n_exc);
@@ -1049,7 +1079,11 @@ extern "C" int mp_plan_write_side_files(const mp_plan *p, int32_t n_out, const i
         og.put(oi + 1 < n_out ? ",\n" : "\n}");
     }
     on.flush(); og.flush();
+    } catch (const std::exception &) {                                  // bad_alloc of the id / row tables: no exception leaves the C ABI
+        fclose(fn); fclose(fg);
+        return pfail(pm, MP_ERR_NOMEM, "mp_plan_write_side_files: out of memory");
+    }
     const bool bad = ferror(fn) || ferror(fg);
     fclose(fn); fclose(fg);
-    return bad ? MP_ERR_ARG : MP_OK;
+    return bad ? pfail(pm, MP_ERR_ARG, "write error on %s / %s", noncov_path, gap_path) : MP_OK;
 }

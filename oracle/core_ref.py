@@ -99,15 +99,16 @@ def parse_records(raw: bytes):
     """parse_seq's record semantics (V20:441-455) in plain Python: the checker of csrc/fasta.cpp."""
     pieces = {}
     cur = None
-    for line in raw.splitlines():
+    white = b" \t\n\r\x0b\x0c\x1c\x1d\x1e\x1f"      # str.strip() of a text-mode line, ASCII range (bytes.strip() keeps 0x1c-0x1f)
+    for line in raw.splitlines():                   # bytes: \n, \r\n and \r end a line, nothing else (text mode's universal newlines)
         if line.startswith(b"#"):
             continue
         if line.startswith(b">"):
-            cur = line.strip().split(b" ")[0]
+            cur = line.strip(white).split(b" ")[0]
         else:
             if cur is None:
                 raise ValueError("sequence data before the first '>' header")
-            pieces.setdefault(cur, []).append(line.strip())
+            pieces.setdefault(cur, []).append(line.strip(white))
     ids = [k.decode("utf-8", errors="surrogateescape") for k in pieces]
     rows = [b"".join(v) for v in pieces.values()]
     lens = np.fromiter((len(r) for r in rows), dtype=np.int64, count=len(rows))

@@ -40,7 +40,7 @@ def _fuzz_fasta(rng):
             out.append(t)                                             # blank line
         else:
             body = bytes(rng.choice(np.frombuffer(b"ACGTacgtNRY-.*x", np.uint8), size=int(rng.integers(0, 40))))
-            pad = [b"", b" ", b"\t", b"  "][int(rng.integers(0, 4))]
+            pad = [b"", b" ", b"\t", b"  ", b"\x1c", b"\x1f ", b"\x0b"][int(rng.integers(0, 7))]     # str.strip() takes 0x1c-0x1f too
             out.append(pad + body + pad + t)
     raw = b"".join(out)
     if rng.random() < 0.3:
@@ -79,6 +79,16 @@ def test_fasta_parser_edge_cases(tmp_path):
     assert fa.ids == [">a", ">b"] and fa.rows()[0].tobytes() == b"ACGTACTTTT"
     with pytest.raises(OSError):
         host.Fasta(str(tmp_path / "missing.fa"))
+
+
+def test_lone_carriage_return_files_parse_in_linear_time():
+    """Classic-Mac line ends: the terminator search must not run to the end of the file for every line."""
+    import time
+    raw = b"".join(b">s%d\r" % i + b"ACGTACGTAC" * 6 + b"\r" for i in range(150000))       # 11 MB, no \n anywhere
+    t0 = time.time()
+    fa = host.Fasta(raw=raw, n_threads=1)
+    assert fa.n_rows == 150000 and fa.rows()[1][-1] == 150000 * 60
+    assert time.time() - t0 < 5.0
 
 
 def test_fasta_parser_large_file_threads(tmp_path):
