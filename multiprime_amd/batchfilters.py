@@ -1,4 +1,4 @@
-"""The per-primer string filters and Tm of the core step (filters.py, thermo.py — V20:282-336, 387-416, 507-521) for ALL output
+"""The per-primer string filters and Tm of the core step (oracle/filters_ref.py, thermo.py — V20:282-336, 387-416, 507-521) for ALL output
 primers of an alignment at once, on symbol-code matrices with numpy.
 
 Same results as the scalar functions, value for value (tests/test_batchfilters.py runs both on random degenerate primers;

@@ -8,6 +8,7 @@ reference's `degenerate_base` lists (V20:105-107).
 """
 from __future__ import annotations
 
+import re
 from itertools import product
 
 import numpy as np
@@ -148,3 +149,22 @@ def strings_of(chars: np.ndarray) -> list[str]:
         return [""] * n
     buf = np.ascontiguousarray(chars).tobytes().decode("ascii")      # one decode, then n slices
     return [buf[i:i + k] for i in range(0, n * k, k)]
+
+
+def _repeat_patterns():
+    """The ACGT members of the reference's `di_nucleotides` set (V20:196-207): XXXX, (XY)x4 with X != Y, (XYZ)x3 with X != Y and
+    Y != Z (the reference's `i != j != k` is a chained comparison, so X == Z is allowed).  Members containing '#' can never match
+    a primer."""
+    pats = set()
+    for a in "ACGT":
+        pats.add(a * 4)
+        for b in "ACGT":
+            if a != b:
+                pats.add((a + b) * 4)
+            for c in "ACGT":
+                if a != b and b != c:
+                    pats.add((a + b + c) * 3)
+    return pats
+
+
+REPEATS = re.compile("|".join(sorted(_repeat_patterns())))

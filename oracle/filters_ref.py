@@ -1,35 +1,16 @@
-"""Per-window string filters of the core step (host side): GC content, low-complexity
-repeats, hairpin, and the 3'-end self-dimer test (V20:387-416, 457-521).
-
-They run once per surviving window on one primer of <= `degeneracy` expansions — O(1) per
-window, which is why they stay on the host.
+"""TEST INFRASTRUCTURE — scalar restatements of the reference's per-primer string filters (GC content, low-complexity repeats,
+hairpin, the 3'-end self-dimer test; V20:387-416, 457-521), one primer at a time, pinned to V20's known answers in
+tests/test_kat.py.  The product computes the same values for all output primers at once (multiprime_amd/batchfilters.py, the dimer
+kernels); these functions are its checker (tests/test_batchfilters.py) and serve oracle/core_ref.py.  Nothing under multiprime_amd/
+imports this module.
 """
 from __future__ import annotations
 
 import re
 from statistics import mean
 
-from .iupac import exact_mean, expand, occurs_in_some_expansion, revcomp
-from .thermo import delta_g, penalty_points
-
-
-def _repeat_patterns():
-    """The ACGT members of the reference's `di_nucleotides` set (V20:196-207): XXXX, (XY)x4 with
-    X != Y, (XYZ)x3 with X != Y and Y != Z (the reference's `i != j != k` is a chained
-    comparison, so X == Z is allowed).  Members containing '#' can never match a primer."""
-    pats = set()
-    for a in "ACGT":
-        pats.add(a * 4)
-        for b in "ACGT":
-            if a != b:
-                pats.add((a + b) * 4)
-            for c in "ACGT":
-                if a != b and b != c:
-                    pats.add((a + b + c) * 3)
-    return pats
-
-
-_REPEATS = re.compile("|".join(sorted(_repeat_patterns())))
+from multiprime_amd.iupac import REPEATS as _REPEATS, exact_mean, expand, occurs_in_some_expansion, revcomp
+from multiprime_amd.thermo import delta_g, penalty_points
 
 
 def gc_fraction(primer: str) -> float:

@@ -4,7 +4,8 @@ value for value on random degenerate primers of several lengths."""
 import numpy as np
 import pytest
 
-from multiprime_amd import batchfilters, filters, iupac, thermo
+from multiprime_amd import batchfilters, iupac, thermo
+from oracle import filters_ref as filters
 
 
 def random_primers(seed, n, k, p_deg):

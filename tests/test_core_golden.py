@@ -91,6 +91,15 @@ def test_native_json_writer_equals_python_writer(name, oracle_lib, tmp_path, mon
 
 
 def test_native_json_writer_escapes_ids_like_json_dump(oracle_lib, tmp_path, monkeypatch):
+    _special_ids(oracle_lib, tmp_path, monkeypatch)
+
+
+@pytest.mark.gpu
+def test_special_ids_through_the_gpu_path(hip_lib, tmp_path, monkeypatch):
+    _special_ids(hip_lib, tmp_path, monkeypatch)
+
+
+def _special_ids(lib, tmp_path, monkeypatch):
     """ids with quotes, backslashes, control bytes, non-ASCII UTF-8 (BMP and astral) and invalid UTF-8 (surrogateescape): the
     native writer's strings are json.dump's (ensure_ascii) and the file reads back to the same dicts."""
     import random
@@ -116,7 +125,7 @@ def test_native_json_writer_escapes_ids_like_json_dump(oracle_lib, tmp_path, mon
         monkeypatch.setenv("MP_JSON_WRITER", mode)
         app = NN_degenerate(seq_file=str(d / "in.fa"), primer_length=18, coverage=0.3, number_of_dege_bases=4, score_of_dege_bases=16,
                             product_len=30, position="1,2,-1", variation=1, GC="0.2,0.8", nproc=1, outfile=str(d / "o"),
-                            library=oracle_lib)
+                            library=lib)
         app.run()
         outs.append(_side_bytes(d / "o"))
         assert len(open(d / "o").read().splitlines()) > 1
