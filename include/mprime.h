@@ -270,6 +270,35 @@ int mp_kmm_scan(mp_ctx *ctx, const uint8_t *bytes, const int64_t *row_off, int32
                 const uint8_t *pat_codes, const int32_t *pat_off, int32_t max_mismatch, int32_t term, int64_t cap_hits,
                 int32_t *hits, int64_t *n_hits);
 
+/* (9) row shards over several GPUs — SURVEY §8e --------------------------------------------------------------------------- */
+/* The reference is one process (its -p pool is inert, V20:1143).  Here every O(N) quantity of the path is a sum over sequences,
+ * so N processes (one per GPU) each load a contiguous block of the alignment's rows (mp_reserve_columns + mp_load_msa), build
+ * the same windows, and exchange: ONE all-reduce (sum, int64) of the [n_candidates x 3] counters of mp_eval_*, one of the
+ * mp_window_stats tables, and variable-length all-gathers of the packed host tables (histogram entries, exceptions).  The
+ * transport is RCCL over xGMI, opened on the first call.  A host in any language drives it:
+ *     rank 0: mp_comm_unique_id(id)  ->  id to every rank (MPI_Bcast, a socket, a file — the host's business)
+ *     all:    mp_comm_init(ctx, n_ranks, rank, id)                 (collective: every rank calls it)
+ *     all:    mp_eval_candidates_allreduce(...) instead of mp_eval_candidates; mp_comm_allreduce_host_i64 on the
+ *             mp_window_stats tables; mp_comm_allgather_i64 + mp_comm_allgatherv for the tables
+ * n_ranks = 1 is valid without RCCL (every collective is the identity).  Collectives are enqueued on the context's stream
+ * (mp_set_stream) straight behind the kernels; the *_host_* / gather forms return when the result is in the caller's buffer.
+ * Every rank must issue the same collectives in the same order.  The checker library implements n_ranks = 1 only. */
+#define MP_COMM_ID_BYTES 128
+int mp_comm_unique_id(uint8_t *id);                                        /* id[MP_COMM_ID_BYTES] */
+int mp_comm_init(mp_ctx *ctx, int32_t n_ranks, int32_t rank, const uint8_t *id);
+int mp_comm_destroy(mp_ctx *ctx);
+/* in place, sum over ranks; `device_buf` is device memory, the call only enqueues */
+int mp_comm_allreduce_i64(mp_ctx *ctx, int64_t *device_buf, int64_t n);
+/* the same for a host buffer: returns with the sums in `host_buf` */
+int mp_comm_allreduce_host_i64(mp_ctx *ctx, int64_t *host_buf, int64_t n);
+/* out[r] = rank r's `value` (lengths of a variable-length gather) */
+int mp_comm_allgather_i64(mp_ctx *ctx, int64_t value, int64_t *out);
+/* recv = rank 0's bytes, rank 1's bytes, ...; counts[r] = bytes of rank r (counts[rank] == n_bytes); host buffers */
+int mp_comm_allgatherv(mp_ctx *ctx, const void *send, int64_t n_bytes, const int64_t *counts, void *recv);
+/* mp_eval_candidates over this rank's rows + the all-reduce of the counters on the same stream: out = the global counts */
+int mp_eval_candidates_allreduce(mp_ctx *ctx, int32_t n_cand, const int32_t *cand_window, const uint8_t *cand_codes,
+                                 uint32_t strictF, uint32_t strictR, int64_t *out);
+
 /* Memory the context holds on the device, in bytes (window words, planes, tables). */
 int mp_device_bytes(mp_ctx *ctx, int64_t *bytes);
 

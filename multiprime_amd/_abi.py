@@ -57,8 +57,17 @@ SYMBOLS = [
     ("mp_pair_coverage", C.c_int, [_p, C.c_int32, C.c_int32, _p, _p, C.c_int64, _p, _p]),
     ("mp_pcr_scan", C.c_int, [_p, _p, _p, C.c_int32, C.c_int32, _p, _p, _p]),
     ("mp_kmm_scan", C.c_int, [_p, _p, _p, C.c_int32, C.c_int32, _p, _p, C.c_int32, C.c_int32, C.c_int64, _p, C.POINTER(C.c_int64)]),
+    ("mp_comm_unique_id", C.c_int, [_p]),
+    ("mp_comm_init", C.c_int, [_p, C.c_int32, C.c_int32, _p]),
+    ("mp_comm_destroy", C.c_int, [_p]),
+    ("mp_comm_allreduce_i64", C.c_int, [_p, _p, C.c_int64]),
+    ("mp_comm_allreduce_host_i64", C.c_int, [_p, _p, C.c_int64]),
+    ("mp_comm_allgather_i64", C.c_int, [_p, C.c_int64, _p]),
+    ("mp_comm_allgatherv", C.c_int, [_p, _p, C.c_int64, _p, _p]),
+    ("mp_eval_candidates_allreduce", C.c_int, [_p, C.c_int32, _p, _p, C.c_uint32, C.c_uint32, _p]),
     ("mp_device_bytes", C.c_int, [_p, C.POINTER(C.c_int64)]),
 ]
+COMM_ID_BYTES = 128
 
 
 class MprimeError(RuntimeError):
@@ -240,6 +249,48 @@ class Context:
         out = np.zeros((len(cand_window), 3), np.int64)
         self._ck(self.d.mp_eval_candidates(self.h, len(cand_window), _ptr(cand_window), _ptr(cand_codes),
                                            strictF, strictR, _ptr(out)))
+        return out
+
+    # -- row shards (mprime.h section 9): RCCL behind the C ABI ---------------------------------------------------------------
+    def comm_unique_id(self) -> bytes:
+        buf = (C.c_uint8 * COMM_ID_BYTES)()
+        rc = self.d.mp_comm_unique_id(buf)
+        if rc != 0:
+            raise MprimeError(rc, "mp_comm_unique_id failed (librccl.so not loadable?)")
+        return bytes(buf)
+
+    def comm_init(self, n_ranks: int, rank: int, unique_id: bytes | None):
+        buf = (C.c_uint8 * COMM_ID_BYTES).from_buffer_copy(unique_id) if unique_id is not None else None
+        self._ck(self.d.mp_comm_init(self.h, n_ranks, rank, buf))
+
+    def comm_destroy(self):
+        self._ck(self.d.mp_comm_destroy(self.h))
+
+    def comm_allreduce_device(self, device_ptr: int, n: int):
+        self._ck(self.d.mp_comm_allreduce_i64(self.h, C.c_void_p(device_ptr), n))
+
+    def comm_sum(self, a) -> np.ndarray:
+        """Element-wise sum over the ranks of an int64 host array."""
+        out = np.ascontiguousarray(a, dtype=np.int64).copy()
+        self._ck(self.d.mp_comm_allreduce_host_i64(self.h, _ptr(out), out.size))
+        return out
+
+    def comm_gather_bytes(self, payload: np.ndarray, n_ranks: int):
+        """(concatenation over ranks of a byte array whose length differs per rank, lengths per rank)."""
+        payload = np.ascontiguousarray(payload, dtype=np.uint8)
+        counts = np.zeros(n_ranks, np.int64)
+        self._ck(self.d.mp_comm_allgather_i64(self.h, payload.size, _ptr(counts)))
+        out = np.empty(int(counts.sum()), np.uint8)
+        self._ck(self.d.mp_comm_allgatherv(self.h, _ptr(payload) if payload.size else None, payload.size, _ptr(counts),
+                                           _ptr(out) if out.size else None))
+        return out, counts
+
+    def eval_candidates_allreduce(self, cand_window, cand_codes, strictF: int, strictR: int) -> np.ndarray:
+        cand_window = np.ascontiguousarray(cand_window, dtype=np.int32)
+        cand_codes = np.ascontiguousarray(cand_codes, dtype=np.uint8).reshape(len(cand_window), self.k)
+        out = np.zeros((len(cand_window), 3), np.int64)
+        self._ck(self.d.mp_eval_candidates_allreduce(self.h, len(cand_window), _ptr(cand_window), _ptr(cand_codes), strictF, strictR,
+                                                     _ptr(out)))
         return out
 
     def eval_masks(self, cand_window, cand_codes, strictF: int, strictR: int):

@@ -127,6 +127,8 @@ class NN_degenerate(object):
         if "error" in made:
             raise made["error"]
         self.ctx = made["ctx"]
+        if comm is not None:
+            comm.attach(self.ctx)                                      # GPUs: the library's own RCCL communicator (dist.py)
         self.stats["parse_s"] = time.time() - t0
         t0 = time.time()
         width = int(np.diff(row_off).max())                           # longest record (of ALL rows)

@@ -105,6 +105,7 @@ void mp_destroy(mp_ctx *c) {
     if (!c) return;
     (void)hipSetDevice(c->dev);
     (void)hipDeviceSynchronize();
+    free_comm(c);
     free_msa(c);
     dev_free(c, &c->tmp_out, (size_t)c->tmp_out_n);
     dev_free(c, &c->dm_loss, (size_t)(MP_DIMER_MAX_LEN + 1) * (MP_DIMER_MAX_LEN + 1) * 64);

@@ -1,0 +1,223 @@
+// comm.hip — part of libmprime_hip.so: row-shard collectives behind the C ABI of include/mprime.h (mp_comm_*).
+// One process per GPU; every rank holds a contiguous block of the alignment's rows and the same windows.  What crosses ranks:
+//   * ONE all-reduce (sum, int64) of the [n_candidates x 3] coverage counters per alignment, enqueued on the context's stream
+//     straight after the evaluation kernel (no host round trip, no second stream) — mp_comm_allreduce_i64 /
+//     mp_eval_candidates_allreduce; the same for the per-window base / pair statistics;
+//   * variable-length all-gathers of packed host tables (histogram entries, IUPAC exceptions, per-window results) —
+//     mp_comm_allgather_i64 for the lengths, mp_comm_allgatherv for the payloads.
+// RCCL over xGMI carries them: messages are KB to a few MB, latency-bound on the point-to-point links, so there is one collective
+// per quantity and alignment, never one per window.  librccl is opened on the first mp_comm_* call (dlopen): a single-GPU user
+// of the library never loads it.  The communicator's id travels between the ranks by whatever the host has (the Python host
+// broadcasts it over its torch.distributed store, INTEGRATION.md shows an MPI / socket host).
+#include "common.hpp"
+
+#include <dlfcn.h>
+#include <rccl/rccl.h>
+
+#include <mutex>
+
+using namespace mp;
+
+namespace {
+
+struct Rccl {
+    void *lib = nullptr;
+    ncclResult_t (*GetUniqueId)(ncclUniqueId *) = nullptr;
+    ncclResult_t (*CommInitRank)(ncclComm_t *, int, ncclUniqueId, int) = nullptr;
+    ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+    ncclResult_t (*AllReduce)(const void *, void *, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*AllGather)(const void *, void *, size_t, ncclDataType_t, ncclComm_t, hipStream_t) = nullptr;
+    const char *(*GetErrorString)(ncclResult_t) = nullptr;
+    const char *error = nullptr;
+};
+
+Rccl &rccl() {
+    static Rccl r;
+    static std::once_flag once;
+    std::call_once(once, [] {
+        for (const char *name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"}) {
+            r.lib = dlopen(name, RTLD_NOW | RTLD_LOCAL);
+            if (r.lib) break;
+        }
+        if (!r.lib) { r.error = "librccl.so not found (dlopen)"; return; }
+        auto sym = [&](const char *s) { void *p = dlsym(r.lib, s); if (!p) r.error = "librccl.so lacks an expected symbol"; return p; };
+        r.GetUniqueId = reinterpret_cast<decltype(r.GetUniqueId)>(sym("ncclGetUniqueId"));
+        r.CommInitRank = reinterpret_cast<decltype(r.CommInitRank)>(sym("ncclCommInitRank"));
+        r.CommDestroy = reinterpret_cast<decltype(r.CommDestroy)>(sym("ncclCommDestroy"));
+        r.AllReduce = reinterpret_cast<decltype(r.AllReduce)>(sym("ncclAllReduce"));
+        r.AllGather = reinterpret_cast<decltype(r.AllGather)>(sym("ncclAllGather"));
+        r.GetErrorString = reinterpret_cast<decltype(r.GetErrorString)>(sym("ncclGetErrorString"));
+    });
+    return r;
+}
+
+#define NCCLCK(c, call)                                                                                          \
+    do {                                                                                                         \
+        ncclResult_t r_ = (call);                                                                                \
+        if (r_ != ncclSuccess) return fail((c), MP_ERR_DEVICE, "%s: %s", #call, rccl().GetErrorString(r_));     \
+    } while (0)
+
+static_assert(MP_COMM_ID_BYTES == NCCL_UNIQUE_ID_BYTES, "the ABI's id is an RCCL unique id");
+
+int need_comm(mp_ctx *c) {
+    if (!c) return MP_ERR_ARG;
+    if (c->n_ranks <= 0) return fail(c, MP_ERR_ARG, "no communicator (mp_comm_init has not run)");
+    return MP_OK;
+}
+
+// device scratch of at least n bytes
+int scratch(mp_ctx *c, size_t n) {
+    if (c->comm_scratch_n >= n) return MP_OK;
+    dev_free(c, &c->comm_scratch, c->comm_scratch_n);
+    c->comm_scratch_n = 0;
+    int rc = dev_alloc(c, &c->comm_scratch, n);
+    if (rc) return rc;
+    c->comm_scratch_n = n;
+    return MP_OK;
+}
+
+}  // namespace
+
+namespace mp {
+
+void free_comm(mp_ctx *c) {
+    if (c->comm && rccl().CommDestroy) (void)rccl().CommDestroy(reinterpret_cast<ncclComm_t>(c->comm));
+    c->comm = nullptr;
+    c->n_ranks = 0; c->rank = 0;
+    dev_free(c, &c->comm_scratch, c->comm_scratch_n);
+    c->comm_scratch_n = 0;
+}
+
+}  // namespace mp
+
+extern "C" {
+
+int mp_comm_unique_id(uint8_t *id) {
+    if (!id) return MP_ERR_ARG;
+    Rccl &r = rccl();
+    if (r.error) return MP_ERR_DEVICE;
+    ncclUniqueId u;
+    if (r.GetUniqueId(&u) != ncclSuccess) return MP_ERR_DEVICE;
+    memcpy(id, u.internal, MP_COMM_ID_BYTES);
+    return MP_OK;
+}
+
+int mp_comm_init(mp_ctx *c, int32_t n_ranks, int32_t rank, const uint8_t *id) {
+    if (!c) return MP_ERR_ARG;
+    if (n_ranks < 1 || rank < 0 || rank >= n_ranks || (n_ranks > 1 && !id)) return fail(c, MP_ERR_ARG, "mp_comm_init: bad arguments");
+    HIPCK(c, hipSetDevice(c->dev));
+    free_comm(c);
+    // a world of one needs no RCCL: every collective is the identity.  MP_COMM_FORCE_RCCL=1 (tests on a single GPU) creates the
+    // one-rank communicator anyway and sends every collective through RCCL
+    if (n_ranks > 1 || (getenv("MP_COMM_FORCE_RCCL") && id)) {
+        Rccl &r = rccl();
+        if (r.error) return fail(c, MP_ERR_DEVICE, "mp_comm_init: %s", r.error);
+        ncclUniqueId u;
+        memcpy(u.internal, id, MP_COMM_ID_BYTES);
+        ncclComm_t comm = nullptr;
+        NCCLCK(c, r.CommInitRank(&comm, n_ranks, u, rank));
+        c->comm = comm;
+    }
+    c->n_ranks = n_ranks; c->rank = rank;
+    return MP_OK;
+}
+
+int mp_comm_destroy(mp_ctx *c) {
+    if (!c) return MP_ERR_ARG;
+    (void)hipSetDevice(c->dev);
+    (void)hipStreamSynchronize(c->stream);
+    free_comm(c);
+    return MP_OK;
+}
+
+int mp_comm_allreduce_i64(mp_ctx *c, int64_t *device_buf, int64_t n) {
+    int rc = need_comm(c);
+    if (rc) return rc;
+    if (n < 0 || (n && !device_buf)) return fail(c, MP_ERR_ARG, "mp_comm_allreduce_i64: bad arguments");
+    if (!c->comm || n == 0) return MP_OK;
+    HIPCK(c, hipSetDevice(c->dev));
+    NCCLCK(c, rccl().AllReduce(device_buf, device_buf, (size_t)n, ncclInt64, ncclSum, reinterpret_cast<ncclComm_t>(c->comm), c->stream));
+    return MP_OK;
+}
+
+int mp_comm_allreduce_host_i64(mp_ctx *c, int64_t *host_buf, int64_t n) {
+    int rc = need_comm(c);
+    if (rc) return rc;
+    if (n < 0 || (n && !host_buf)) return fail(c, MP_ERR_ARG, "mp_comm_allreduce_host_i64: bad arguments");
+    if (!c->comm || n == 0) return MP_OK;
+    HIPCK(c, hipSetDevice(c->dev));
+    if ((rc = scratch(c, (size_t)n * 8))) return rc;
+    HIPCK(c, hipMemcpyAsync(c->comm_scratch, host_buf, (size_t)n * 8, hipMemcpyHostToDevice, c->stream));
+    if ((rc = mp_comm_allreduce_i64(c, reinterpret_cast<int64_t *>(c->comm_scratch), n))) return rc;
+    HIPCK(c, hipMemcpyAsync(host_buf, c->comm_scratch, (size_t)n * 8, hipMemcpyDeviceToHost, c->stream));
+    HIPCK(c, hipStreamSynchronize(c->stream));
+    return MP_OK;
+}
+
+int mp_comm_allgather_i64(mp_ctx *c, int64_t value, int64_t *out) {
+    int rc = need_comm(c);
+    if (rc) return rc;
+    if (!out) return fail(c, MP_ERR_ARG, "mp_comm_allgather_i64: null output");
+    if (!c->comm) { out[0] = value; return MP_OK; }
+    HIPCK(c, hipSetDevice(c->dev));
+    const size_t R = (size_t)c->n_ranks;
+    if ((rc = scratch(c, (R + 1) * 8))) return rc;
+    int64_t *d = reinterpret_cast<int64_t *>(c->comm_scratch);
+    HIPCK(c, hipMemcpyAsync(d + R, &value, 8, hipMemcpyHostToDevice, c->stream));
+    NCCLCK(c, rccl().AllGather(d + R, d, 1, ncclInt64, reinterpret_cast<ncclComm_t>(c->comm), c->stream));
+    HIPCK(c, hipMemcpyAsync(out, d, R * 8, hipMemcpyDeviceToHost, c->stream));
+    HIPCK(c, hipStreamSynchronize(c->stream));
+    return MP_OK;
+}
+
+int mp_comm_allgatherv(mp_ctx *c, const void *send, int64_t n_bytes, const int64_t *counts, void *recv) {
+    int rc = need_comm(c);
+    if (rc) return rc;
+    if (n_bytes < 0 || !counts || (n_bytes && !send)) return fail(c, MP_ERR_ARG, "mp_comm_allgatherv: bad arguments");
+    if (counts[c->rank] != n_bytes) return fail(c, MP_ERR_ARG, "mp_comm_allgatherv: counts[rank] differs from the bytes sent");
+    int64_t total = 0, widest = 0;
+    for (int r = 0; r < c->n_ranks; r++) {
+        if (counts[r] < 0) return fail(c, MP_ERR_ARG, "mp_comm_allgatherv: negative count");
+        total += counts[r];
+        widest = std::max(widest, counts[r]);
+    }
+    if (total && !recv) return fail(c, MP_ERR_ARG, "mp_comm_allgatherv: null output");
+    if (!c->comm) { if (n_bytes) memcpy(recv, send, (size_t)n_bytes); return MP_OK; }
+    if (widest == 0) return MP_OK;
+    HIPCK(c, hipSetDevice(c->dev));
+    // every rank's payload padded to the widest one (16-byte granules), gathered in one collective, unpadded on the way out
+    const size_t slot = ((size_t)widest + 15) / 16 * 16, R = (size_t)c->n_ranks;
+    if ((rc = scratch(c, slot * (R + 1)))) return rc;
+    uint8_t *d = c->comm_scratch;
+    if (n_bytes) HIPCK(c, hipMemcpyAsync(d + slot * R, send, (size_t)n_bytes, hipMemcpyHostToDevice, c->stream));
+    NCCLCK(c, rccl().AllGather(d + slot * R, d, slot, ncclUint8, reinterpret_cast<ncclComm_t>(c->comm), c->stream));
+    size_t at = 0;
+    for (size_t r = 0; r < R; r++) {
+        if (counts[r]) HIPCK(c, hipMemcpyAsync(static_cast<uint8_t *>(recv) + at, d + slot * r, (size_t)counts[r], hipMemcpyDeviceToHost, c->stream));
+        at += (size_t)counts[r];
+    }
+    HIPCK(c, hipStreamSynchronize(c->stream));
+    return MP_OK;
+}
+
+int mp_eval_candidates_allreduce(mp_ctx *c, int32_t n_cand, const int32_t *cw, const uint8_t *codes, uint32_t sF, uint32_t sR, int64_t *out) {
+    int rc = need_comm(c);
+    if (rc) return rc;
+    if ((rc = mp_eval_upload(c, n_cand, cw, codes, sF, sR))) return rc;
+    if (n_cand == 0) return MP_OK;
+    if (!out) return fail(c, MP_ERR_ARG, "null output");
+    if (c->tmp_out_n < 3 * n_cand) {
+        dev_free(c, &c->tmp_out, (size_t)c->tmp_out_n);
+        c->tmp_out_n = 0;
+        if ((rc = dev_alloc(c, &c->tmp_out, (size_t)3 * n_cand))) return rc;
+        c->tmp_out_n = 3 * n_cand;
+    }
+    // kernel, collective and copy queue up on one stream: nothing waits on the host in between
+    if ((rc = mp_eval_launch(c, (int64_t *)c->tmp_out))) return rc;
+    if ((rc = mp_comm_allreduce_i64(c, (int64_t *)c->tmp_out, (int64_t)3 * n_cand))) return rc;
+    HIPCK(c, hipMemcpyAsync(out, c->tmp_out, sizeof(int64_t) * 3 * (size_t)n_cand, hipMemcpyDeviceToHost, c->stream));
+    HIPCK(c, hipStreamSynchronize(c->stream));
+    return MP_OK;
+}
+
+}  // extern "C"

@@ -171,6 +171,11 @@ struct mp_ctx {
     std::vector<float> ev_samples, ev_last;     // per-launch durations since the last reset / as of the last mp_eval_timing call
     int ev_n = 0;
     int eval_variant = 0;
+    // row-shard collectives (comm.hip): an RCCL communicator (ncclComm_t) when n_ranks > 1
+    void *comm = nullptr;
+    int n_ranks = 0, rank = 0;               // n_ranks 0: mp_comm_init has not run
+    uint8_t *comm_scratch = nullptr;
+    size_t comm_scratch_n = 0;
 };
 
 namespace mp {
@@ -212,6 +217,7 @@ void dev_free(mp_ctx *c, T **p, size_t n) {
 // release the device arrays of one stage (and of every stage that depends on it); api.hip
 void free_eval(mp_ctx *c);
 void free_tiles(mp_ctx *c);
+void free_comm(mp_ctx *c);
 void free_unique(mp_ctx *c);
 void free_windows(mp_ctx *c);
 void free_msa(mp_ctx *c);

@@ -15,6 +15,11 @@ over xGMI on ROCm, "gloo" in the CPU tests):
 The host control flow is replicated on every rank (it is deterministic given the merged
 tables), rank 0 writes the files.  Results are identical for 1/2/4/8 shards: integer sums are
 associative and the merged tables reproduce the single-process insertion order.
+
+Transport.  On GPUs the collectives are the library's own (mprime.h section 9, csrc/comm.hip): RCCL calls on the context's stream,
+the counters' all-reduce queued straight behind the evaluation kernel — `attach()` creates the communicator from an id rank 0
+draws and this module broadcasts; torch.distributed then only carries that id and the barrier of the launcher.  With
+MP_NATIVE_COMM=0, and in the CPU tests (gloo, the ABI checker has no collectives), the same exchanges go through torch.distributed.
 """
 from __future__ import annotations
 
@@ -35,6 +40,19 @@ class RowShards:
         self.n_local = 0
         self.n_total = 0
         self.global_labels = None
+        self.native = None          # the context whose RCCL communicator carries the collectives (attach)
+
+    def attach(self, ctx):
+        """Collectives through the library's own communicator when this is a GPU run of the HIP library."""
+        import os
+        if not (self.on_gpu and ctx.lib.backend == "hip") or os.environ.get("MP_NATIVE_COMM", "1") == "0" or self.group is not None:
+            return
+        dev = self._device()
+        raw = ctx.comm_unique_id() if self.rank == 0 else bytes(128)
+        box = torch.frombuffer(bytearray(raw), dtype=torch.uint8).to(dev)
+        dist.broadcast(box, src=0, group=self.group)
+        ctx.comm_init(self.world, self.rank, bytes(box.cpu().numpy().tobytes()))
+        self.native = ctx
 
     # -- sharding ------------------------------------------------------------------------------
     def bounds(self, n_rows):
@@ -67,6 +85,10 @@ class RowShards:
         arr = np.ascontiguousarray(np.moveaxis(np.asarray(arr), axis, 0))
         tail, dt = arr.shape[1:], arr.dtype
         row_bytes = int(np.prod(tail, dtype=np.int64)) * dt.itemsize
+        if self.native is not None:
+            flat, counts = self.native.comm_gather_bytes(arr.reshape(-1).view(np.uint8), self.world)
+            n = int(counts.sum()) // max(row_bytes, 1)
+            return np.moveaxis(flat.view(dt).reshape((n,) + tail), 0, axis)
         dev = self._device()
         n_local = torch.tensor([arr.shape[0]], dtype=torch.int64, device=dev)
         sizes = [torch.zeros(1, dtype=torch.int64, device=dev) for _ in range(self.world)]
@@ -134,6 +156,8 @@ class RowShards:
     # -- evaluation ----------------------------------------------------------------------------
     def sum_int64(self, a):
         """Element-wise sum over the ranks of an int64 array every rank holds (per-window statistics)."""
+        if self.native is not None:
+            return self.native.comm_sum(a).reshape(np.shape(a))
         t = torch.from_numpy(np.ascontiguousarray(a, dtype=np.int64))
         if self.on_gpu:
             t = t.to(torch.device("cuda", torch.cuda.current_device()))
@@ -143,6 +167,8 @@ class RowShards:
     def eval_allreduce(self, ctx, cand_window, cand_codes, sF, sR):
         """Local evaluation + the single all-reduce of the counter block."""
         n = len(cand_window)
+        if self.native is not None:      # kernel, RCCL all-reduce and the copy back on one stream, inside the library
+            return ctx.eval_candidates_allreduce(cand_window, cand_codes, sF, sR)
         if self.on_gpu:
             dev = torch.device("cuda", torch.cuda.current_device())
             out = torch.zeros((n, 3), dtype=torch.int64, device=dev)

@@ -22,6 +22,7 @@
 
 struct mp_ctx {
     char err[512];
+    int32_t n_ranks;  /* 1 after mp_comm_init (the only world the checker knows) */
     int32_t n_rows, reserve_cols;
     char **rows;      /* mapped characters, NUL-terminated */
     int32_t *len;
@@ -541,6 +542,51 @@ int mp_device_bytes(mp_ctx *c, int64_t *bytes) {
     if (!c || !bytes) return MP_ERR_ARG;
     *bytes = 0;
     return MP_OK;
+}
+
+/* (9) row shards: the checker is one process — a world of one rank, where every collective is the identity (mprime.h).  The
+ * multi-rank tests run one checker per rank and let the Python host's gloo collectives stand in for RCCL (tests/test_multirank.py). */
+static int one_rank(mp_ctx *c) {
+    if (!c) return MP_ERR_ARG;
+    return c->n_ranks == 1 ? MP_OK : fail(c, MP_ERR_ARG, "no communicator (mp_comm_init has not run)");
+}
+int mp_comm_unique_id(uint8_t *id) {
+    if (!id) return MP_ERR_ARG;
+    memset(id, 0, MP_COMM_ID_BYTES);
+    return MP_OK;
+}
+int mp_comm_init(mp_ctx *c, int32_t n_ranks, int32_t rank, const uint8_t *id) {
+    (void)id;
+    if (!c) return MP_ERR_ARG;
+    if (n_ranks != 1 || rank != 0) return fail(c, MP_ERR_ARG, "the checker library has no collectives: n_ranks must be 1");
+    c->n_ranks = 1;
+    return MP_OK;
+}
+int mp_comm_destroy(mp_ctx *c) {
+    if (!c) return MP_ERR_ARG;
+    c->n_ranks = 0;
+    return MP_OK;
+}
+int mp_comm_allreduce_i64(mp_ctx *c, int64_t *buf, int64_t n) { (void)buf; (void)n; return one_rank(c); }
+int mp_comm_allreduce_host_i64(mp_ctx *c, int64_t *buf, int64_t n) { (void)buf; (void)n; return one_rank(c); }
+int mp_comm_allgather_i64(mp_ctx *c, int64_t value, int64_t *out) {
+    int rc = one_rank(c);
+    if (rc) return rc;
+    if (!out) return fail(c, MP_ERR_ARG, "null output");
+    out[0] = value;
+    return MP_OK;
+}
+int mp_comm_allgatherv(mp_ctx *c, const void *send, int64_t n_bytes, const int64_t *counts, void *recv) {
+    int rc = one_rank(c);
+    if (rc) return rc;
+    if (n_bytes < 0 || !counts || counts[0] != n_bytes || (n_bytes && (!send || !recv))) return fail(c, MP_ERR_ARG, "mp_comm_allgatherv: bad arguments");
+    if (n_bytes) memcpy(recv, send, (size_t)n_bytes);
+    return MP_OK;
+}
+int mp_eval_candidates_allreduce(mp_ctx *c, int32_t n_cand, const int32_t *cw, const uint8_t *codes, uint32_t sF, uint32_t sR, int64_t *out) {
+    int rc = one_rank(c);
+    if (rc) return rc;
+    return mp_eval_candidates(c, n_cand, cw, codes, sF, sR, out);
 }
 
 /* =================================================================================================

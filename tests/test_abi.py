@@ -13,7 +13,7 @@ from multiprime_amd import _abi
 def header_symbols(name="mprime.h"):
     src = open(os.path.join(REPO, "include", name)).read()
     src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
-    return sorted(set(re.findall(r"\b(mp_[a-z_]+)\s*\(", src)))
+    return sorted(set(re.findall(r"\b(mp_[a-z0-9_]+)\s*\(", src)))
 
 
 def test_binding_covers_header():

@@ -92,10 +92,16 @@ def test_sharded_run_with_window_split_planning(name, world, oracle_lib, tmp_pat
 
 
 @pytest.mark.gpu
-def test_rccl_path_single_rank(tmp_path):
-    """The device branch of RowShards (candidate counters in a torch CUDA tensor, mp_eval_launch on torch's
-    stream, all-reduce over RCCL) with a world of one GPU: the multi-GPU code path the driver's 8-GPU run
-    takes, minus the other ranks."""
+@pytest.mark.parametrize("transport", ["library", "torch"])
+def test_rccl_path_single_rank(transport, tmp_path, monkeypatch):
+    """The device branch of RowShards with a world of one GPU: the multi-GPU code path the driver's 8-GPU run takes, minus the
+    other ranks.  "library": the collectives are the C ABI's (mp_comm_*, csrc/comm.hip) — a real one-rank RCCL communicator
+    (MP_COMM_FORCE_RCCL), the counters' all-reduce queued behind the evaluation kernel inside the library.  "torch": the same
+    exchanges through torch.distributed's RCCL backend (MP_NATIVE_COMM=0)."""
+    if transport == "library":
+        monkeypatch.setenv("MP_COMM_FORCE_RCCL", "1")
+    else:
+        monkeypatch.setenv("MP_NATIVE_COMM", "0")
     import torch
     import torch.distributed as dist
     from multiprime_amd._abi import Library
@@ -115,10 +121,12 @@ def test_rccl_path_single_rank(tmp_path):
             out = tmp_path / (name + ".out")
             comm = RowShards()
             assert comm.on_gpu
-            NN_degenerate(seq_file=str(inp), primer_length=fl["l"], coverage=fl["f"], number_of_dege_bases=fl["n"],
+            app1 = NN_degenerate(seq_file=str(inp), primer_length=fl["l"], coverage=fl["f"], number_of_dege_bases=fl["n"],
                           score_of_dege_bases=fl["d"], raw_entropy_threshold=fl["e"], product_len=fl["s"], position=fl["c"],
                           variation=fl["v"], distance=fl["a"], GC=fl["g"], nproc=1, outfile=str(out), library=Library(),
-                          comm=comm).run()
+                          comm=comm)
+            assert (comm.native is not None) == (transport == "library")
+            app1.run()
             check_outputs(name, out)
             # the window-split planning path (no JSON side files): candidates and results travel through RCCL all_gathers
             out2 = tmp_path / (name + ".nojson.out")
@@ -130,6 +138,49 @@ def test_rccl_path_single_rank(tmp_path):
             assert app._win_split and out2.read_bytes() == out.read_bytes()
     finally:
         dist.destroy_process_group()
+
+
+@pytest.mark.gpu
+def test_comm_exports_on_one_gpu(hip_lib, monkeypatch):
+    """mprime.h section 9 through a one-rank RCCL communicator: sums, gathers and the fused evaluate + all-reduce."""
+    import numpy as np
+    from test_hip_parity import fuzz_msa
+    monkeypatch.setenv("MP_COMM_FORCE_RCCL", "1")
+    ctx = hip_lib.context(0)
+    with pytest.raises(Exception):
+        ctx.comm_sum(np.arange(4))                                   # no communicator yet
+    uid = ctx.comm_unique_id()
+    assert len(uid) == 128 and any(uid)
+    ctx.comm_init(1, 0, uid)
+    a = np.arange(1000, dtype=np.int64).reshape(10, 100) - 37
+    assert np.array_equal(ctx.comm_sum(a), a)
+    blob = np.frombuffer(bytes(range(256)) * 5, np.uint8)
+    got, counts = ctx.comm_gather_bytes(blob, 1)
+    assert counts.tolist() == [blob.size] and got.tobytes() == blob.tobytes()
+    got, counts = ctx.comm_gather_bytes(np.zeros(0, np.uint8), 1)
+    assert counts.tolist() == [0] and got.size == 0
+    data, off, _ = fuzz_msa(5, 3000, 150, ragged=False, p_gap=0.02, p_iupac=0.0)
+    ctx.load_msa(data, off)
+    k, W = 18, 100
+    ctx.build_windows(3, W, k, 1)
+    rng = np.random.default_rng(2)
+    cw = np.repeat(np.arange(W, dtype=np.int32), 2)
+    codes = rng.integers(1, 16, size=(len(cw), k)).astype(np.uint8)
+    assert np.array_equal(ctx.eval_candidates_allreduce(cw, codes, 12, 3 << 14), ctx.eval_candidates(cw, codes, 12, 3 << 14))
+    ctx.comm_destroy()
+    with pytest.raises(Exception):
+        ctx.comm_sum(np.arange(4))
+
+
+def test_comm_exports_of_the_checker_are_a_world_of_one(oracle_lib):
+    import numpy as np
+    ctx = oracle_lib.context(0)
+    with pytest.raises(Exception):
+        ctx.comm_init(2, 0, bytes(128))                              # the ABI checker has no collectives
+    ctx.comm_init(1, 0, None)
+    assert ctx.comm_sum(np.arange(5)).tolist() == [0, 1, 2, 3, 4]
+    got, counts = ctx.comm_gather_bytes(np.arange(7, dtype=np.uint8), 1)
+    assert got.tolist() == list(range(7)) and counts.tolist() == [7]
 
 
 @pytest.mark.gpu
