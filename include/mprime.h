@@ -216,7 +216,7 @@ int mp_eval_timing_samples(mp_ctx *ctx, int32_t cap, float *ms, int32_t *n);
  * hits has room for cap_hits records; *n_hits returns the number found (may exceed cap_hits,
  * in which case only the first cap_hits written are valid).  Order of records is unspecified. */
 #define MP_DIMER_MAX_LEN 64      /* primers of the dimer scans (adaptor-tailed primers included) */
-#define MP_PATTERN_MAX_LEN 32    /* primers / patterns of the sequence scans (mp_pcr_scan, mp_kmm_scan): 2 bits per base in 64 */
+#define MP_PATTERN_MAX_LEN 64    /* primers / patterns of the sequence scans (mp_pcr_scan, mp_kmm_scan): 2 bits per base in one or two 64-bit words */
 int mp_dimer_scan(mp_ctx *ctx, int32_t n_primers, const uint8_t *codes, const int32_t *off, int32_t mode,
                   int32_t n_new, const uint8_t *loss_hit, const double *dg_params, double dg_limit,
                   int64_t cap_hits, int32_t *hits, int64_t *n_hits);

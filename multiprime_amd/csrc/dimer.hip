@@ -524,6 +524,53 @@ __device__ inline int pcr_find(const uint8_t *__restrict__ s, int from, int to, 
     return -1;
 }
 
+// Primers of 33..MP_PATTERN_MAX_LEN bases (adaptor-tailed primers) do not fit the 64-bit rolling window: the per-thread search
+// then compares characters — expansion `idx` of the codes (itertools.product order: last position fastest) written out as bases,
+// or as the bases of its reverse complement, and matched position by position.  Only the fallback paths use it (pair tables
+// beyond 4096 expansions, sequences with more occurrences than the block kernel's list holds).
+__device__ inline void pcr_expansion(const uint8_t *__restrict__ codes, int L, unsigned long long idx, bool rc, uint8_t (&pat)[MP_PATTERN_MAX_LEN]) {
+    for (int j = L - 1; j >= 0; j--) {
+        const uint32_t m = codes[j] & 15u, sz = c_msize[m];
+        const uint8_t b = c_member[m][idx % sz];
+        idx /= sz;
+        if (rc) pat[L - 1 - j] = (uint8_t)(3 - b);
+        else pat[j] = b;
+    }
+}
+__device__ inline unsigned long long pcr_degeneracy(const uint8_t *__restrict__ codes, int L) {
+    unsigned long long d = 1;
+    for (int j = 0; j < L; j++) d *= c_msize[codes[j] & 15u];          // check_primers bounds the product
+    return d;
+}
+__device__ inline int pcr_find_chars(const uint8_t *__restrict__ s, int from, int to, const uint8_t (&pat)[MP_PATTERN_MAX_LEN], int L) {
+    for (int pos = from; pos + L <= to; pos++) {
+        int j = 0;
+        while (j < L && pcr_base(s[pos + j]) == (int)pat[j]) j++;
+        if (j == L) return pos;
+    }
+    return -1;
+}
+// the reference's order for one (pair, sequence) on characters: first forward expansion that occurs and whose Product holds a
+// reverse expansion (extract_PCR_product_V1.py:189-216)
+__device__ inline void pcr_resolve_chars(const uint8_t *__restrict__ s, int len, const uint8_t *__restrict__ cf, int lf,
+                                         const uint8_t *__restrict__ cr, int lr, int32_t (&res)[4]) {
+    const unsigned long long df = pcr_degeneracy(cf, lf), dr = pcr_degeneracy(cr, lr);
+    uint8_t f[MP_PATTERN_MAX_LEN], r[MP_PATTERN_MAX_LEN];
+    for (unsigned long long fi = 0; fi < df && res[0] < 0; fi++) {
+        pcr_expansion(cf, lf, fi, false, f);
+        const int p1 = pcr_find_chars(s, 0, len, f, lf);
+        if (p1 < 0) continue;
+        const int p2 = pcr_find_chars(s, p1 + lf, len, f, lf);
+        const int end = p2 < 0 ? len : p2;
+        for (unsigned long long ri = 0; ri < dr; ri++) {
+            pcr_expansion(cr, lr, ri, true, r);
+            const int q = pcr_find_chars(s, p1, end, r, lr);
+            if (q >= 0) { res[0] = (int32_t)fi; res[1] = p1; res[2] = (int32_t)ri; res[3] = q; break; }
+        }
+    }
+}
+
+template <bool LONG>
 __global__ __launch_bounds__(kBlock) void pcr_kernel(const uint8_t *__restrict__ bytes, const int64_t *__restrict__ row_off,
                                                      int n_rows, const uint8_t *__restrict__ codes,
                                                      const int32_t *__restrict__ off, int32_t *__restrict__ out) {
@@ -532,6 +579,13 @@ __global__ __launch_bounds__(kBlock) void pcr_kernel(const uint8_t *__restrict__
     const uint8_t *s = bytes + row_off[row];
     const int len = (int)(row_off[row + 1] - row_off[row]);
     const int lf = off[2 * p + 1] - off[2 * p], lr = off[2 * p + 2] - off[2 * p + 1];
+    if constexpr (LONG) {
+        int32_t res[4] = {-1, -1, -1, -1};
+        pcr_resolve_chars(s, len, codes + off[2 * p], lf, codes + off[2 * p + 1], lr, res);
+        int32_t *o = out + ((size_t)p * n_rows + row) * 4;
+        o[0] = res[0]; o[1] = res[1]; o[2] = res[2]; o[3] = res[3];
+        return;
+    }
     Nib cf, cr;
     cf.lo = cf.hi = cr.lo = cr.hi = 0;
     for (int j = 0; j < lf; j++) cf.set(j, codes[off[2 * p] + j]);
@@ -567,10 +621,11 @@ __global__ __launch_bounds__(kBlock) void pcr_kernel(const uint8_t *__restrict__
 // on that short list.  A sequence with more occurrences than the list holds falls back to the rolling scan above.
 // Traffic: the text once (1 byte per base); the work is integer VALU, ~6 wave-instructions per (64 positions, pattern).
 constexpr int kPcrSeg = 4096;                        // positions packed per round
-constexpr int kPcrSegWords = kPcrSeg / 32 + 2;
 constexpr int kPcrHits = 3072;                       // occurrences kept per sequence
 
-struct PcrPat { unsigned long long word, lenmask; int32_t len, pad; };
+// NW = 64-bit words of a pattern: 1 up to 32 bases, 2 up to MP_PATTERN_MAX_LEN = 64
+template <int NW>
+struct PcrPat { unsigned long long word[NW], lenmask[NW]; int32_t len, pad; };
 struct PcrPair { int32_t f0, nf, r0, nr; };         // pattern ranges of a pair: forward expansions, then RC(reverse expansions)
 
 __device__ inline int pcr_first(const uint32_t *__restrict__ s_pos, const uint16_t *__restrict__ s_pat, int n, int pat, int from, int to_excl) {
@@ -580,10 +635,12 @@ __device__ inline int pcr_first(const uint32_t *__restrict__ s_pos, const uint16
     return best == 0x7fffffff ? -1 : best;
 }
 
+template <int NW>
 __global__ __launch_bounds__(kBlock) void pcr_block_kernel(const uint8_t *__restrict__ bytes, const int64_t *__restrict__ row_off, int n_rows,
-                                                           const PcrPat *__restrict__ pats, int n_pats, const PcrPair *__restrict__ pairs,
+                                                           const PcrPat<NW> *__restrict__ pats, int n_pats, const PcrPair *__restrict__ pairs,
                                                            int n_pairs, const uint8_t *__restrict__ codes, const int32_t *__restrict__ off,
                                                            int32_t *__restrict__ out) {
+    constexpr int kPcrSegWords = kPcrSeg / 32 + 1 + NW;
     __shared__ unsigned long long s_b[kPcrSegWords], s_n[kPcrSegWords];
     __shared__ uint32_t s_pos[kPcrHits];
     __shared__ uint16_t s_pat[kPcrHits];
@@ -611,12 +668,21 @@ __global__ __launch_bounds__(kBlock) void pcr_block_kernel(const uint8_t *__rest
             const int p = base + q;
             if (p >= len) break;
             const int w = q >> 5, sh = (q & 31) * 2;
-            unsigned long long win = s_b[w] >> sh, nw = s_n[w] >> sh;
-            if (sh) { win |= s_b[w + 1] << (64 - sh); nw |= s_n[w + 1] << (64 - sh); }
+            unsigned long long win[NW], nw[NW];
+#pragma unroll
+            for (int t = 0; t < NW; t++) {
+                win[t] = s_b[w + t] >> sh; nw[t] = s_n[w + t] >> sh;
+                if (sh) { win[t] |= s_b[w + t + 1] << (64 - sh); nw[t] |= s_n[w + t + 1] << (64 - sh); }
+            }
             for (int i = 0; i < n_pats; i++) {
-                const PcrPat P = pats[i];                                  // uniform index: scalar loads
-                const unsigned long long x = win ^ P.word;
-                if (((((x | (x >> 1)) & kOdd) | nw) & P.lenmask) == 0 && p + P.len <= len) {
+                const PcrPat<NW> P = pats[i];                              // uniform index: scalar loads
+                unsigned long long diff = 0;
+#pragma unroll
+                for (int t = 0; t < NW; t++) {
+                    const unsigned long long x = win[t] ^ P.word[t];
+                    diff |= (((x | (x >> 1)) & kOdd) | nw[t]) & P.lenmask[t];
+                }
+                if (diff == 0 && p + P.len <= len) {
                     const int h = atomicAdd(&s_nh, 1);
                     if (h < kPcrHits) { s_pos[h] = (uint32_t)p; s_pat[h] = (uint16_t)i; }
                 }
@@ -644,6 +710,12 @@ __global__ __launch_bounds__(kBlock) void pcr_block_kernel(const uint8_t *__rest
         } else {
             // too many occurrences for the list (low-complexity sequence): the rolling scan of pcr_kernel for this (pair, sequence)
             const int lf = off[2 * pr + 1] - off[2 * pr], lr = off[2 * pr + 2] - off[2 * pr + 1];
+            if constexpr (NW > 1) {
+                pcr_resolve_chars(s, len, codes + off[2 * pr], lf, codes + off[2 * pr + 1], lr, res);
+                int32_t *o = out + ((size_t)pr * n_rows + row) * 4;
+                o[0] = res[0]; o[1] = res[1]; o[2] = res[2]; o[3] = res[3];
+                continue;
+            }
             Nib cf, cr;
             cf.lo = cf.hi = cr.lo = cr.hi = 0;
             for (int j = 0; j < lf; j++) cf.set(j, codes[off[2 * pr] + j]);
@@ -913,7 +985,10 @@ int mp_pcr_scan(mp_ctx *c, const uint8_t *bytes, const int64_t *row_off, int32_t
     HIPCK(c, hipMemcpyAsync(d_off, off, sizeof(int32_t) * ((size_t)2 * n_pairs + 1), hipMemcpyHostToDevice, c->stream));
     // pattern table of the block-per-sequence kernel: every forward expansion and RC(reverse expansion), in expansion order
     static const char *members[16] = {"", "A", "C", "AC", "G", "AG", "GC", "GAC", "T", "AT", "CT", "ATC", "GT", "GAT", "GTC", "ATGC"};
-    std::vector<PcrPat> pats;
+    int longest = 0;
+    for (int32_t q = 0; q < 2 * n_pairs; q++) longest = std::max(longest, off[q + 1] - off[q]);
+    const bool two_words = longest > 32;            // one primer longer than 32 bases: two-word patterns / character search for the call
+    std::vector<PcrPat<2>> pats;                    // built two words wide, narrowed below when one suffices
     std::vector<PcrPair> prs((size_t)n_pairs);
     bool fits = !getenv("MP_PCR_ROLLING");
     for (int32_t p = 0; p < n_pairs && fits; p++) {
@@ -934,32 +1009,43 @@ int mp_pcr_scan(mp_ctx *c, const uint8_t *bytes, const int64_t *row_off, int32_t
                     idx /= sz;
                     base[j] = ch == 'A' ? 0 : ch == 'C' ? 1 : ch == 'G' ? 2 : 3;
                 }
-                PcrPat P{};
+                PcrPat<2> P{};
                 for (int j = 0; j < L; j++) {
                     const int code = side == 0 ? base[j] : 3 - base[L - 1 - j];     // the text reads RC(reverse expansion)
-                    P.word |= (unsigned long long)code << (2 * j);
-                    P.lenmask |= 1ull << (2 * j);
+                    P.word[j >> 5] |= (unsigned long long)code << (2 * (j & 31));
+                    P.lenmask[j >> 5] |= 1ull << (2 * (j & 31));
                 }
                 P.len = L;
                 pats.push_back(P);
             }
         }
     }
-    PcrPat *d_pats = nullptr;
+    std::vector<PcrPat<1>> narrow;
+    if (fits && !two_words)
+        for (const PcrPat<2> &P : pats) narrow.push_back(PcrPat<1>{{P.word[0]}, {P.lenmask[0]}, P.len, 0});
+    const size_t pat_bytes = two_words ? sizeof(PcrPat<2>) * pats.size() : sizeof(PcrPat<1>) * narrow.size();
+    uint8_t *d_pats = nullptr;
     PcrPair *d_prs = nullptr;
     if (fits) {
-        if ((rc = dev_alloc(c, &d_pats, pats.size())) || (rc = dev_alloc(c, &d_prs, prs.size()))) {
-            dev_free(c, &d_pats, pats.size()); dev_free(c, &d_prs, prs.size());
+        if ((rc = dev_alloc(c, &d_pats, pat_bytes)) || (rc = dev_alloc(c, &d_prs, prs.size()))) {
+            dev_free(c, &d_pats, pat_bytes); dev_free(c, &d_prs, prs.size());
             fits = false;
         }
     }
     if (fits) {
-        HIPCK(c, hipMemcpyAsync(d_pats, pats.data(), sizeof(PcrPat) * pats.size(), hipMemcpyHostToDevice, c->stream));
+        HIPCK(c, hipMemcpyAsync(d_pats, two_words ? (const void *)pats.data() : (const void *)narrow.data(), pat_bytes, hipMemcpyHostToDevice, c->stream));
         HIPCK(c, hipMemcpyAsync(d_prs, prs.data(), sizeof(PcrPair) * prs.size(), hipMemcpyHostToDevice, c->stream));
-        hipLaunchKernelGGL(pcr_block_kernel, dim3((unsigned)n_rows), dim3(kBlock), 0, c->stream, d_bytes, d_roff, n_rows, (const PcrPat *)d_pats,
-                           (int)pats.size(), (const PcrPair *)d_prs, n_pairs, d_codes, d_off, d_out);
+        if (two_words)
+            hipLaunchKernelGGL(pcr_block_kernel<2>, dim3((unsigned)n_rows), dim3(kBlock), 0, c->stream, d_bytes, d_roff, n_rows,
+                               reinterpret_cast<const PcrPat<2> *>(d_pats), (int)pats.size(), (const PcrPair *)d_prs, n_pairs, d_codes, d_off, d_out);
+        else
+            hipLaunchKernelGGL(pcr_block_kernel<1>, dim3((unsigned)n_rows), dim3(kBlock), 0, c->stream, d_bytes, d_roff, n_rows,
+                               reinterpret_cast<const PcrPat<1> *>(d_pats), (int)narrow.size(), (const PcrPair *)d_prs, n_pairs, d_codes, d_off, d_out);
+    } else if (two_words) {
+        hipLaunchKernelGGL(pcr_kernel<true>, dim3((unsigned)((n_rows + kBlock - 1) / kBlock), (unsigned)n_pairs), dim3(kBlock), 0, c->stream,
+                           d_bytes, d_roff, n_rows, d_codes, d_off, d_out);
     } else {
-        hipLaunchKernelGGL(pcr_kernel, dim3((unsigned)((n_rows + kBlock - 1) / kBlock), (unsigned)n_pairs), dim3(kBlock), 0, c->stream,
+        hipLaunchKernelGGL(pcr_kernel<false>, dim3((unsigned)((n_rows + kBlock - 1) / kBlock), (unsigned)n_pairs), dim3(kBlock), 0, c->stream,
                            d_bytes, d_roff, n_rows, d_codes, d_off, d_out);
     }
     HIPCK(c, hipGetLastError());
@@ -967,7 +1053,7 @@ int mp_pcr_scan(mp_ctx *c, const uint8_t *bytes, const int64_t *row_off, int32_t
     HIPCK(c, hipStreamSynchronize(c->stream));
     dev_free(c, &d_bytes, total + 16); dev_free(c, &d_roff, (size_t)n_rows + 1); dev_free(c, &d_codes, ncodes);
     dev_free(c, &d_off, (size_t)2 * n_pairs + 1); dev_free(c, &d_out, nout);
-    dev_free(c, &d_pats, pats.size()); dev_free(c, &d_prs, prs.size());
+    dev_free(c, &d_pats, pat_bytes); dev_free(c, &d_prs, prs.size());
     return MP_OK;
 }
 

@@ -4,8 +4,9 @@
 //
 // Shape: a workgroup owns one segment of one sequence.  It packs the segment once into LDS — 2 bits per base plus a
 // "never matches" bit for everything outside ACGT — and every thread then slides over its start positions: the 32-base
-// window at a position is two LDS words and a funnel shift, and one pattern costs an XOR, a fold of the two bits of each
-// base, a mask, a popcount and two compares.  The pattern table (code word, length mask, trailing-run mask per strand) is
+// window at a position is two LDS words and a funnel shift (a second 32-base window for patterns of 33..64 bases: the
+// two-word kernel), and one pattern costs an XOR, a fold of the two bits of each base, a mask, a popcount and two compares
+// per word.  The pattern table (code word, length mask, trailing-run mask per strand) is
 // wave-uniform and arrives through scalar loads.  HBM traffic is the text once (1 byte per base); the work is integer VALU:
 // ~10 wave-instructions per (64 positions, pattern).
 #include "common.hpp"
@@ -15,19 +16,22 @@ using namespace mp;
 namespace {
 
 constexpr int kSeg = 8192;                       // start positions per workgroup
-constexpr int kSegWords = kSeg / 32 + 2;         // 64-bit words of 32 bases, with the 32-base overhang
 
+// NW = 64-bit words of a pattern: 1 up to 32 bases, 2 up to MP_PATTERN_MAX_LEN = 64 (adaptor-tailed primers)
+template <int NW>
 struct KmmPat {
-    unsigned long long word;      // base j of the aligned text at bits 2j (A0 C1 G2 T3)
-    unsigned long long lenmask;   // bit 2j set for j < len
-    unsigned long long termmask;  // bit 2j set for the last `term` positions in reference orientation (all of lenmask if term > len)
+    unsigned long long word[NW];      // base j of the aligned text at bits 2 (j % 32) of word j / 32 (A0 C1 G2 T3)
+    unsigned long long lenmask[NW];   // bit 2j set for j < len
+    unsigned long long termmask[NW];  // bit 2j set for the last `term` positions in reference orientation (all of lenmask if term > len)
     int32_t len, id, strand, never;   // never: term > len — the trailing match run cannot reach the threshold
 };
 
+template <int NW>
 __global__ __launch_bounds__(kBlock) void kmm_kernel(const uint8_t *__restrict__ bytes, const int64_t *__restrict__ row_off,
                                                      const int32_t *__restrict__ blk_row, const int32_t *__restrict__ blk_seg,
-                                                     const KmmPat *__restrict__ pats, int n_pats, int max_mm, long long cap,
+                                                     const KmmPat<NW> *__restrict__ pats, int n_pats, int max_mm, long long cap,
                                                      int32_t *__restrict__ hits, unsigned long long *__restrict__ n_hits) {
+    constexpr int kSegWords = kSeg / 32 + 1 + NW;      // 64-bit words of 32 bases, with the overhang of the longest pattern
     __shared__ unsigned long long s_b[kSegWords];      // 2-bit codes
     __shared__ unsigned long long s_n[kSegWords];      // 0b01 at positions that match nothing (non-ACGT, past the end)
     const int row = blk_row[blockIdx.x], seg = blk_seg[blockIdx.x];
@@ -61,18 +65,53 @@ __global__ __launch_bounds__(kBlock) void kmm_kernel(const uint8_t *__restrict__
         const long long p = base + q;
         if (p >= len) break;
         const int w = q >> 5, sh = (q & 31) * 2;
-        unsigned long long win = s_b[w] >> sh, nw = s_n[w] >> sh;
-        if (sh) { win |= s_b[w + 1] << (64 - sh); nw |= s_n[w + 1] << (64 - sh); }
+        unsigned long long win[NW], nw[NW];
+#pragma unroll
+        for (int t = 0; t < NW; t++) {
+            win[t] = s_b[w + t] >> sh; nw[t] = s_n[w + t] >> sh;
+            if (sh) { win[t] |= s_b[w + t + 1] << (64 - sh); nw[t] |= s_n[w + t + 1] << (64 - sh); }
+        }
         for (int i = 0; i < n_pats; i++) {
-            const KmmPat P = pats[i];                   // uniform index: scalar loads
-            const unsigned long long x = win ^ P.word;
-            const unsigned long long mm = (((x | (x >> 1)) & kOdd) | nw) & P.lenmask;
-            if ((int)__popcll(mm) <= max_mm && (mm & P.termmask) == 0 && !P.never && p + P.len <= len) {
+            const KmmPat<NW> P = pats[i];               // uniform index: scalar loads
+            int n_mm = 0;
+            unsigned long long in_term = 0;
+#pragma unroll
+            for (int t = 0; t < NW; t++) {
+                const unsigned long long x = win[t] ^ P.word[t];
+                const unsigned long long mm = (((x | (x >> 1)) & kOdd) | nw[t]) & P.lenmask[t];
+                n_mm += (int)__popcll(mm);
+                in_term |= mm & P.termmask[t];
+            }
+            if (n_mm <= max_mm && in_term == 0 && !P.never && p + P.len <= len) {
                 const unsigned long long idx = atomicAdd(n_hits, 1ull);
                 if ((long long)idx < cap) {
                     hits[4 * idx] = row; hits[4 * idx + 1] = (int32_t)p; hits[4 * idx + 2] = P.id; hits[4 * idx + 3] = P.strand;
                 }
             }
+        }
+    }
+}
+
+// both strands of every pattern as kernel table entries
+template <int NW>
+void kmm_patterns(int32_t n_pat, const uint8_t *pat_codes, const int32_t *pat_off, int32_t term, std::vector<KmmPat<NW>> &pats) {
+    for (int32_t i = 0; i < n_pat; i++) {
+        const int len = pat_off[i + 1] - pat_off[i];
+        int b[MP_PATTERN_MAX_LEN];
+        for (int j = 0; j < len; j++) {
+            const uint8_t m = pat_codes[pat_off[i] + j];
+            b[j] = m == 1 ? 0 : m == 2 ? 1 : m == 4 ? 2 : 3;
+        }
+        for (int strand = 0; strand < 2; strand++) {
+            KmmPat<NW> P{};
+            for (int j = 0; j < len; j++) {
+                const int code = strand == 0 ? b[j] : 3 - b[len - 1 - j];      // the text reads the pattern / its reverse complement
+                P.word[j >> 5] |= (unsigned long long)code << (2 * (j & 31));
+                P.lenmask[j >> 5] |= 1ull << (2 * (j & 31));
+                if (j >= len - term) P.termmask[j >> 5] |= 1ull << (2 * (j & 31));
+            }
+            P.len = len; P.id = i; P.strand = strand; P.never = term > len;
+            pats.push_back(P);
         }
     }
 }
@@ -90,28 +129,24 @@ int mp_kmm_scan(mp_ctx *c, const uint8_t *bytes, const int64_t *row_off, int32_t
     HIPCK(c, hipSetDevice(c->dev));
     *n_hits = 0;
     if (n_rows == 0 || n_pat == 0) return MP_OK;
-    std::vector<KmmPat> pats;
+    int longest = 0;
     for (int32_t i = 0; i < n_pat; i++) {
         const int len = pat_off[i + 1] - pat_off[i];
         if (len < 4 || len > MP_PATTERN_MAX_LEN) return fail(c, MP_ERR_ARG, "pattern %d has length %d (4..%d supported)", i, len, MP_PATTERN_MAX_LEN);
-        int b[MP_PATTERN_MAX_LEN];
         for (int j = 0; j < len; j++) {
             const uint8_t m = pat_codes[pat_off[i] + j];
             if (m != 1 && m != 2 && m != 4 && m != 8) return fail(c, MP_ERR_ARG, "pattern %d is not a concrete A/C/G/T sequence", i);
-            b[j] = m == 1 ? 0 : m == 2 ? 1 : m == 4 ? 2 : 3;
         }
-        for (int strand = 0; strand < 2; strand++) {
-            KmmPat P{};
-            for (int j = 0; j < len; j++) {
-                const int code = strand == 0 ? b[j] : 3 - b[len - 1 - j];      // the text reads the pattern / its reverse complement
-                P.word |= (unsigned long long)code << (2 * j);
-                P.lenmask |= 1ull << (2 * j);
-                if (j >= len - term) P.termmask |= 1ull << (2 * j);
-            }
-            P.len = len; P.id = i; P.strand = strand; P.never = term > len;
-            pats.push_back(P);
-        }
+        longest = std::max(longest, len);
     }
+    const bool two_words = longest > 32;             // one pattern longer than 32 bases: the two-word kernel for the whole call
+    std::vector<KmmPat<1>> pats1;
+    std::vector<KmmPat<2>> pats2;
+    if (two_words) kmm_patterns<2>(n_pat, pat_codes, pat_off, term, pats2);
+    else kmm_patterns<1>(n_pat, pat_codes, pat_off, term, pats1);
+    const size_t n_entries = two_words ? pats2.size() : pats1.size();
+    const size_t pat_bytes = two_words ? sizeof(KmmPat<2>) * pats2.size() : sizeof(KmmPat<1>) * pats1.size();
+    const void *pat_src = two_words ? (const void *)pats2.data() : (const void *)pats1.data();
     std::vector<int32_t> blk_row, blk_seg;
     for (int32_t r = 0; r < n_rows; r++) {
         const int64_t len = row_off[r + 1] - row_off[r];
@@ -123,29 +158,33 @@ int mp_kmm_scan(mp_ctx *c, const uint8_t *bytes, const int64_t *row_off, int32_t
     uint8_t *d_bytes = nullptr;
     int64_t *d_roff = nullptr;
     int32_t *d_brow = nullptr, *d_bseg = nullptr, *d_hits = nullptr;
-    KmmPat *d_pats = nullptr;
+    uint8_t *d_pats = nullptr;
     unsigned long long *d_n = nullptr;
     const size_t hcap = (size_t)std::max<int64_t>(cap, 1) * 4;
     int rc = MP_OK;
     auto cleanup = [&]() {
         dev_free(c, &d_bytes, total + 16); dev_free(c, &d_roff, (size_t)n_rows + 1); dev_free(c, &d_brow, nb); dev_free(c, &d_bseg, nb);
-        dev_free(c, &d_hits, hcap); dev_free(c, &d_pats, pats.size()); dev_free(c, &d_n, 1);
+        dev_free(c, &d_hits, hcap); dev_free(c, &d_pats, pat_bytes); dev_free(c, &d_n, 1);
     };
     std::vector<int64_t> roff((size_t)n_rows + 1);
     for (int32_t r = 0; r <= n_rows; r++) roff[(size_t)r] = row_off[r] - row_off[0];
     hipError_t e = hipSuccess;
     if ((rc = dev_alloc(c, &d_bytes, total + 16)) || (rc = dev_alloc(c, &d_roff, (size_t)n_rows + 1)) || (rc = dev_alloc(c, &d_brow, nb)) ||
-        (rc = dev_alloc(c, &d_bseg, nb)) || (rc = dev_alloc(c, &d_hits, hcap)) || (rc = dev_alloc(c, &d_pats, pats.size())) ||
+        (rc = dev_alloc(c, &d_bseg, nb)) || (rc = dev_alloc(c, &d_hits, hcap)) || (rc = dev_alloc(c, &d_pats, pat_bytes)) ||
         (rc = dev_alloc(c, &d_n, 1))) { cleanup(); return rc; }
     if (e == hipSuccess) e = hipMemcpyAsync(d_bytes, bytes + row_off[0], total, hipMemcpyHostToDevice, c->stream);
     if (e == hipSuccess) e = hipMemcpyAsync(d_roff, roff.data(), sizeof(int64_t) * roff.size(), hipMemcpyHostToDevice, c->stream);
     if (e == hipSuccess) e = hipMemcpyAsync(d_brow, blk_row.data(), sizeof(int32_t) * nb, hipMemcpyHostToDevice, c->stream);
     if (e == hipSuccess) e = hipMemcpyAsync(d_bseg, blk_seg.data(), sizeof(int32_t) * nb, hipMemcpyHostToDevice, c->stream);
-    if (e == hipSuccess) e = hipMemcpyAsync(d_pats, pats.data(), sizeof(KmmPat) * pats.size(), hipMemcpyHostToDevice, c->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(d_pats, pat_src, pat_bytes, hipMemcpyHostToDevice, c->stream);
     if (e == hipSuccess) e = hipMemsetAsync(d_n, 0, sizeof(unsigned long long), c->stream);
     if (e == hipSuccess) {
-        hipLaunchKernelGGL(kmm_kernel, dim3((unsigned)nb), dim3(kBlock), 0, c->stream, d_bytes, d_roff, d_brow, d_bseg, d_pats,
-                           (int)pats.size(), (int)max_mm, (long long)cap, d_hits, d_n);
+        if (two_words)
+            hipLaunchKernelGGL(kmm_kernel<2>, dim3((unsigned)nb), dim3(kBlock), 0, c->stream, d_bytes, d_roff, d_brow, d_bseg,
+                               reinterpret_cast<const KmmPat<2> *>(d_pats), (int)n_entries, (int)max_mm, (long long)cap, d_hits, d_n);
+        else
+            hipLaunchKernelGGL(kmm_kernel<1>, dim3((unsigned)nb), dim3(kBlock), 0, c->stream, d_bytes, d_roff, d_brow, d_bseg,
+                               reinterpret_cast<const KmmPat<1> *>(d_pats), (int)n_entries, (int)max_mm, (long long)cap, d_hits, d_n);
         e = hipGetLastError();
     }
     unsigned long long n = 0;

@@ -22,7 +22,7 @@ from . import iupac, thermo
 from ._abi import Library
 
 MAX_LEN = 64               # MP_DIMER_MAX_LEN: primers of the dimer scans (adaptor-tailed primers included)
-PATTERN_MAX_LEN = 32       # MP_PATTERN_MAX_LEN: primers of the sequence scans (in-silico PCR, validation)
+PATTERN_MAX_LEN = 64       # MP_PATTERN_MAX_LEN: primers of the sequence scans (in-silico PCR, validation)
 HEADERS = ["Primer_ID", "Primer seq", "Primer end", "Delta G", "Primer end length", "End (distance 1)", "End (GC)",
            "Dimer-primer_ID", "Dimer-primer seq", "End (distance 2)", "Loss"]
 

@@ -20,6 +20,10 @@ CASES = {   # golden key -> (reference fasta, primer source, format)
 }
 
 
+# primers of 41-52 nt (adaptor-tailed): recorded by tests/golden/make_golden_pcr_long.py
+LONG_CASES = {"long_fa": ("pcr_long_ref.fa", "pcr_long_primers.fa", "fa"), "long_seq": ("pcr_long_ref.fa", None, "seq")}
+
+
 def unzip(name, tmp_path):
     path = tmp_path / name
     path.write_bytes(gzip.open(os.path.join(GOLDEN, "inputs", name + ".gz")).read())
@@ -27,8 +31,14 @@ def unzip(name, tmp_path):
 
 
 def check(case, lib, tmp_path):
-    gold = json.loads(gzip.open(os.path.join(GOLDEN, "pcr.json.gz")).read())[case]
-    ref_name, primers, fmt = CASES[case]
+    if case in LONG_CASES:
+        book = json.loads(gzip.open(os.path.join(GOLDEN, "pcr_long.json.gz")).read())
+        gold = book[case]
+        ref_name, primers, fmt = LONG_CASES[case]
+        primers = primers or book["long_seq_primers"]
+    else:
+        gold = json.loads(gzip.open(os.path.join(GOLDEN, "pcr.json.gz")).read())[case]
+        ref_name, primers, fmt = CASES[case]
     ref = unzip(ref_name, tmp_path)
     primer_arg = primers if fmt == "seq" else unzip(primers, tmp_path)
     od, cov = tmp_path / "out", tmp_path / "cov.xls"
@@ -40,24 +50,24 @@ def check(case, lib, tmp_path):
     assert [l for l in lines if not l.startswith("Number of")] == gold["coverage_totals"]
 
 
-@pytest.mark.parametrize("case", list(CASES))
+@pytest.mark.parametrize("case", list(CASES) + list(LONG_CASES))
 def test_pcr_matches_reference(case, oracle_lib, tmp_path):
     check(case, oracle_lib, tmp_path)
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("case", list(CASES))
+@pytest.mark.parametrize("case", list(CASES) + list(LONG_CASES))
 def test_pcr_hip_matches_reference(case, hip_lib, tmp_path):
     check(case, hip_lib, tmp_path)
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("rolling", [False, True])
-def test_pcr_kernels_equal_oracle_on_random_database(rolling, hip_lib, oracle_lib, monkeypatch):
+@pytest.mark.parametrize("rolling,long_primers", [(False, False), (True, False), (False, True), (True, True)])
+def test_pcr_kernels_equal_oracle_on_random_database(rolling, long_primers, hip_lib, oracle_lib, monkeypatch):
     """Both in-silico PCR kernels — block-per-sequence (LDS-packed segments, occurrence list) and the rolling scan it falls
     back to (also forced for a sequence whose occurrence list overflows) — against the oracle: degenerate primers planted into
     random sequences incl. lower case, N, repeated forward sites, sequences longer than one 4096-position segment and a
-    low-complexity sequence with thousands of occurrences."""
+    low-complexity sequence with thousands of occurrences.  long_primers: 28-64 nt, the two-word forms of both kernels."""
     import numpy as np
     from multiprime_amd import iupac
     from multiprime_amd.dimer import encode_primers
@@ -67,8 +77,9 @@ def test_pcr_kernels_equal_oracle_on_random_database(rolling, hip_lib, oracle_li
     comp = str.maketrans("ACGT", "TGCA")
     primers = []
     for _ in range(12):
-        f = "".join(rng.choice(list("ACGT"), size=int(rng.integers(16, 24))))
-        r = "".join(rng.choice(list("ACGT"), size=int(rng.integers(16, 24))))
+        lo, hi = (16, 24) if not long_primers else (28, 64)          # long: two-word patterns, character search in the fall-backs
+        f = "".join(rng.choice(list("ACGT"), size=int(rng.integers(lo, hi + 1))))
+        r = "".join(rng.choice(list("ACGT"), size=int(rng.integers(lo, hi + 1))))
         f = f[:5] + "R" + f[6:] if rng.random() < 0.5 else f
         r = r[:7] + "Y" + r[8:12] + "N" + r[13:] if rng.random() < 0.5 else r
         primers += [f, r]

@@ -33,7 +33,7 @@ def brute(seqs, pats, max_mm, term):
     return sorted(hits)
 
 
-def make_case(rng, n_rows, max_len, n_pat):
+def make_case(rng, n_rows, max_len, n_pat, pat_len=(6, 25)):
     seqs = []
     for _ in range(n_rows):
         n = int(rng.integers(0, max_len))
@@ -45,7 +45,7 @@ def make_case(rng, n_rows, max_len, n_pat):
         seqs.append("".join(s))
     pats = []
     for _ in range(n_pat):
-        m = int(rng.integers(6, 25))
+        m = int(rng.integers(*pat_len))
         src = seqs[int(rng.integers(0, n_rows))].upper().replace("N", "A")
         if len(src) > m + 2 and rng.random() < 0.8:            # planted: a slice of a sequence, maybe mutated, maybe reverse-complemented
             a = int(rng.integers(0, len(src) - m))
@@ -78,6 +78,23 @@ def test_oracle_scan_equals_brute_force(seed, oracle_lib):
     seqs, pats = make_case(rng, 12, 300, 10)
     for max_mm, term in ((0, 0), (1, 4), (2, 3), (1, 30)):
         assert scan(oracle_lib, seqs, pats, max_mm, term) == brute(seqs, pats, max_mm, term)
+
+
+def test_oracle_scan_equals_brute_force_on_long_patterns(oracle_lib):
+    rng = np.random.default_rng(77)
+    seqs, pats = make_case(rng, 10, 400, 8, pat_len=(30, 65))           # up to MP_PATTERN_MAX_LEN = 64 bases
+    assert max(len(p) for p in pats) > 40
+    for max_mm, term in ((2, 4), (4, 0)):
+        assert scan(oracle_lib, seqs, pats, max_mm, term) == brute(seqs, pats, max_mm, term)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("seed", range(3))
+def test_hip_scan_equals_oracle_on_long_patterns(seed, hip_lib, oracle_lib):
+    rng = np.random.default_rng(300 + seed)
+    seqs, pats = make_case(rng, 30, 20000, 16, pat_len=(20, 65))         # the two-word kernel (one pattern beyond 32 bases)
+    for max_mm, term in ((2, 4), (5, 0), (0, 8)):
+        assert scan(hip_lib, seqs, pats, max_mm, term) == scan(oracle_lib, seqs, pats, max_mm, term)
 
 
 @pytest.mark.gpu
@@ -272,7 +289,7 @@ def test_reads_the_scan_cannot_take_are_refused_by_name(oracle_lib, tmp_path):
     ref = tmp_path / "ref.fa"
     ref.write_text(">g\n" + "ACGT" * 40 + "\n")
     primers = tmp_path / "p.fa"
-    primers.write_text(">long\n" + "ACGT" * 9 + "\n")                           # 36 nt, whole primer
+    primers.write_text(">long\n" + "ACGT" * 17 + "\n")                          # 68 nt, whole primer: beyond MP_PATTERN_MAX_LEN
     app = off_targets(primer_file=str(primers), term_length=0, reference_file=str(ref), PCR_product_size="50,1200", mismatch_num=1,
                       outfile=str(tmp_path / "o"), term_threshold=4, library=oracle_lib)
     with pytest.raises(ValueError, match="long_0"):
