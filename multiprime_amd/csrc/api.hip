@@ -72,6 +72,7 @@ void free_msa(mp_ctx *c) {
     size_t np = (size_t)c->n_pad;
     dev_free(c, &c->planes, (size_t)c->n_chunks * 4 * np);
     dev_free(c, &c->cols, (size_t)c->n_chunks * 32 * 4 * (np / 64));
+    dev_free(c, &c->cons, (size_t)c->n_chunks * 32);
     dev_free(c, &c->cum, ((size_t)c->n_chunks + 1) * np);
     dev_free(c, &c->ung, np * c->ustride);
     dev_free(c, &c->lead, np); dev_free(c, &c->rstrip, np); dev_free(c, &c->rlen, np);

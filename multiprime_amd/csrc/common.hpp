@@ -97,6 +97,7 @@ struct mp_ctx {
     int reserve_cols = 0;                    // mp_reserve_columns: minimum alignment width (row shards)
     uint32_t *planes = nullptr, *cum = nullptr, *ung = nullptr;
     unsigned long long *cols = nullptr;      // [n_chunks*32][4][n_pad/64]
+    uint8_t *cons = nullptr;                 // [n_chunks*32] most frequent base of every column (unique.hip), made on first use
     int32_t *lead = nullptr, *rstrip = nullptr, *rlen = nullptr;
     // windows
     int p0 = 0, n_win = 0, k = 0, v = 0;
