@@ -923,6 +923,13 @@ __global__ __launch_bounds__(kBlock) void mask_pair_kernel(const unsigned long l
     if (lane == 0) out[p] = cnt;
 }
 
+__global__ __launch_bounds__(kBlock) void zero_kernel(unsigned long long *__restrict__ p, size_t n) {
+    const size_t i0 = ((size_t)blockIdx.x * kBlock + threadIdx.x) * 4;
+#pragma unroll
+    for (int j = 0; j < 4; j++)
+        if (i0 + j < n) p[i0 + j] = 0ull;
+}
+
 typedef void (*EvalBitsFn)(const EvalBitsArgs);
 typedef void (*EvalChainFn)(const EvalChainArgs);
 
@@ -1201,7 +1208,13 @@ int mp_eval_launch(mp_ctx *c, int64_t *device_out) {
     if (!device_out) return fail(c, MP_ERR_ARG, "null output");
     HIPCK(c, hipSetDevice(c->dev));
     if (c->n_cand == 0) return MP_OK;
-    HIPCK(c, hipMemsetAsync(device_out, 0, sizeof(int64_t) * 3 * (size_t)c->n_cand, c->stream));
+    // the counters are summed with atomics: they start at zero.  A launch of our own: the runtime's fill kernel takes 6 us per call
+    // at this size (profiles/r02_pipeline_kernels.txt), a fifth of the evaluation itself
+    {
+        const size_t n = 3 * (size_t)c->n_cand;
+        hipLaunchKernelGGL(zero_kernel, dim3((unsigned)((n + 4 * kBlock - 1) / (4 * kBlock))), dim3(kBlock), 0, c->stream,
+                           reinterpret_cast<unsigned long long *>(device_out), n);
+    }
     // enough blocks to fill 256 CUs several times over, each with at least 1024 sequences
     int max_split = (c->n_pad + 1023) / 1024;
     int want = (4096 + c->n_items - 1) / c->n_items;
@@ -1250,9 +1263,11 @@ int mp_eval_launch(mp_ctx *c, int64_t *device_out) {
             // threads at that size), 4 x 3 from 16384, else 2 x 6 / 1 x 6.  MP_EVAL_CHAIN overrides (tools/variant_bench.py).
             const int nw32 = 2 * nw;
             int cshape = nw32 >= 4 * kBlock ? 7 : (nw32 >= 2 * kBlock ? 3 : (nw32 >= kBlock ? 0 : 5));
-            if (const char *e = getenv("MP_EVAL_CHAIN")) { cshape = atoi(e); if (cshape < 0 || cshape > 8) cshape = 0; }
-            // (plane rows and patch planes are padded to multiples of 8 words: 8 words per thread is the widest legal shape)
-            static const int cgw[9] = {2, 2, 2, 4, 4, 1, 8, 8, 8};
+            const bool use_prog = c->chain_prog && getenv("MP_EVAL_PROG") && atoi(getenv("MP_EVAL_PROG")) == 1;
+            if (const char *e = getenv("MP_EVAL_CHAIN")) { cshape = atoi(e); if (cshape < 0 || cshape > (use_prog ? 9 : 8)) cshape = 0; }
+            // (plane rows and patch planes are padded to multiples of 8 words: 8 words per thread is the widest shape of
+            // eval_chain_kernel; shape 9 — 16 words per thread, two groups of 8 — exists in the program-driven kernel only)
+            static const int cgw[10] = {2, 2, 2, 4, 4, 1, 8, 8, 8, 16};
 #define CHAIN_ROW(LV) {eval_chain_kernel<LV, 2, 6>, eval_chain_kernel<LV, 2, 3>, eval_chain_kernel<LV, 2, 9>, eval_chain_kernel<LV, 4, 3>, \
                        eval_chain_kernel<LV, 4, 6>, eval_chain_kernel<LV, 1, 6>, eval_chain_kernel<LV, 8, 2>, eval_chain_kernel<LV, 8, 4>, \
                        eval_chain_kernel<LV, 8, 1>}
@@ -1279,7 +1294,7 @@ int mp_eval_launch(mp_ctx *c, int64_t *device_out) {
                 if (ca.patch.n_blocks)          // the patch planes of the same items: wave-per-unit blocks of the chain kernel
                     hipLaunchKernelGGL(cfn[c->v][cshape], dim3((unsigned)ca.patch.n_blocks), dim3(kBlock), 0, c->stream, ca);
                 if ((rc = launch_eval_tile(c, tile_gw, (unsigned long long *)device_out))) return rc;
-            } else if (c->chain_prog && getenv("MP_EVAL_PROG") && atoi(getenv("MP_EVAL_PROG")) == 1) {
+            } else if (use_prog) {
                 // program-driven kernel (evalprog.hip): same arithmetic and block map, fetches by buffer loads with D of them in
                 // flight all the time.  Measured equal to eval_chain_kernel within +-10 % (profiles/r03_prog_variants_*.txt, DESIGN.md
                 // section 9), so it runs only on request: MP_EVAL_PROG=1.

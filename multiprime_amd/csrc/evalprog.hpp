@@ -2,10 +2,11 @@
 //
 // One block of kProgRegs x 64 32-bit entries per chain item, register q = entries [64 q, 64 q + 64), one entry per lane:
 //   register 0: lanes 0-23 the output slot (candidate index or -1) of counter lane / 3 — where the commit's lanes look for it;
-//               lanes 32-36 the header {win, cand0, n_steps, n_ev, n_fp}
-//   registers 1, 2: the n_fp fetches of the first pass (the most degenerate member over all k positions), one per base of a
-//               position's symbol: single-base positions first, then the others; kMore = further bases of this position follow,
-//               kCont = not the first base of its position
+//               lanes 32-40 the header {win, n_steps, n_ev, nA, nB, nC, nD, nE, wide}
+//   registers 1, 2: the fetches of the first pass (the most degenerate member over all k positions), one per base of a position's
+//               symbol, grouped by what their consumption needs: nA single-base positions without a strict position, nB with
+//               one; nC two-base positions (two entries each) without, nD with; then nE entries of the positions with three or
+//               four bases (kMore = further bases of this position follow).  wide = 1: more than 64 entries or events (two registers)
 //   registers 3, 4: the events (one lost base each), ascending by step
 // entry = plane row (window position * 4 + base) | strict-position flags | chain step << 24 (events)
 #pragma once
@@ -16,7 +17,7 @@
 namespace mp {
 
 constexpr int kProgRegs = 5;
-constexpr uint32_t kRowMask = 0x7Fu, kStrictF = 1u << 20, kStrictR = 1u << 21, kMore = 1u << 28, kCont = 1u << 29;
+constexpr uint32_t kRowMask = 0x7Fu, kStrictF = 1u << 20, kStrictR = 1u << 21, kMore = 1u << 28;
 
 void build_eval_programs(const std::vector<ChainItem> &chains, const std::vector<uint32_t> &events, const std::vector<int32_t> &cand_out,
                          int k, uint32_t sF, uint32_t sR, std::vector<uint32_t> &prog);

@@ -51,6 +51,7 @@ struct HistArgs {
     const int32_t *patch_off;             // [W+1] slow pairs of every window (mp_build_windows): rows and window words
     const int32_t *patch_rows;
     const uint32_t *patch_words;
+    unsigned long long *prof;             // MP_HIST_PROF: [workgroup][8] shader-clock stamps of hist_kernel's phases (null: none)
 };
 
 // merge one (key, count, first row) into the window's global table
@@ -91,9 +92,12 @@ __global__ __launch_bounds__(kBlock) void hist_kernel(const HistArgs A) {
     const size_t np = (size_t)A.M.n_pad;
     const int r0 = slice * A.rows_per_block;
     const int r1 = min(r0 + A.rows_per_block, A.M.n_pad);
+    auto stamp = [&](int i) { if (A.prof && threadIdx.x == 0) A.prof[(size_t)blockIdx.x * 8 + i] = clock64(); };
+    stamp(0);
     for (int i = threadIdx.x; i < kLdsSlots; i += kBlock) { s_key[i] = kNoKey; s_cnt[i] = 0; s_min[i] = kEmpty; }
     if (threadIdx.x == 0) s_used = 0;
     __syncthreads();
+    stamp(1);
     const int lane = threadIdx.x & 63;
     const uint32_t *P = A.M.planes + ((size_t)(p >> 5) * 4) * np;
     auto flush = [&]() {
@@ -167,6 +171,8 @@ __global__ __launch_bounds__(kBlock) void hist_kernel(const HistArgs A) {
         }
     }
     __syncthreads();
+    stamp(2);
+    if (threadIdx.x == 0 && A.prof) A.prof[(size_t)blockIdx.x * 8 + 6] = (unsigned long long)s_used;
     if (s_used > kLdsLimit) {
         flush();
         __syncthreads();
@@ -200,7 +206,11 @@ __global__ __launch_bounds__(kBlock) void hist_kernel(const HistArgs A) {
             }
         }
     }
+    stamp(3);
+    if (threadIdx.x == 0 && A.prof) A.prof[(size_t)blockIdx.x * 8 + 7] = (unsigned long long)s_used;
     flush();
+    __syncthreads();
+    stamp(4);
 }
 
 // ---- consensus-filtered form -------------------------------------------------------------------------------------------------
@@ -625,7 +635,7 @@ int unique_packed(mp_ctx *c, int64_t cap, int32_t want_labels, int64_t *n_entrie
         HIPCK(c, hipMemsetAsync(c->u_wcount, 0, sizeof(int32_t) * W, c->stream));
         HIPCK(c, hipMemsetAsync(c->u_over, 0, sizeof(int32_t) * W, c->stream));
         HistArgs A{msa_args(c), c->p0, c->k, c->n_win, 0, 0, 0, c->g_key, c->g_cnt, c->g_min, slots, c->u_over,
-                   c->n_patch ? c->patch_off : (const int32_t *)nullptr, c->patch_rows, c->patch_words};
+                   c->n_patch ? c->patch_off : (const int32_t *)nullptr, c->patch_rows, c->patch_words, nullptr};
         // enough workgroups to fill 256 CUs several times over, slices of at least 4096 rows
         int n_slices = (int)std::max<size_t>(1, std::min<size_t>((np + 4095) / 4096, (8192 + W - 1) / W));
         if (const char *e = getenv("MP_HIST_SLICES")) n_slices = std::max(1, atoi(e));
@@ -639,7 +649,20 @@ int unique_packed(mp_ctx *c, int64_t cap, int32_t want_labels, int64_t *n_entrie
         // section 9) — both kernels spend their time in the latency chain LDS insert -> barrier -> flush, not in deriving k-mers.
         const char *hmode = getenv("MP_HIST_MODE");
         if (!(hmode && !strcmp(hmode, "cons"))) {
+            const char *prof_path = getenv("MP_HIST_PROF");       // debugging: phase stamps of every workgroup written to that file
+            if (prof_path) {
+                HIPCK(c, hipMalloc((void **)&A.prof, (size_t)blocks * 64));
+                HIPCK(c, hipMemsetAsync(A.prof, 0, (size_t)blocks * 64, c->stream));
+            }
             hipLaunchKernelGGL(hist_kernel, dim3(blocks), dim3(kBlock), 0, c->stream, A);
+            if (prof_path) {
+                std::vector<unsigned long long> h((size_t)blocks * 8);
+                HIPCK(c, hipStreamSynchronize(c->stream));
+                HIPCK(c, hipMemcpy(h.data(), A.prof, h.size() * 8, hipMemcpyDeviceToHost));
+                (void)hipFree(A.prof);
+                A.prof = nullptr;
+                if (FILE *f = fopen(prof_path, "wb")) { fwrite(h.data(), 8, h.size(), f); fclose(f); }
+            }
         } else {
             const int n_cols = c->n_chunks * 32, nw32 = c->n_pad / 32;
             if (!c->cons) {

@@ -31,6 +31,7 @@ def main():
                     help="rows mode: MP_EVAL_VARIANT numbers; bits mode: bN = MP_EVAL_BITS=N (symbol-table kernel), "
                          "cN = nested-chain kernel shape MP_EVAL_CHAIN=N")
     ap.add_argument("--generic-v", action="store_true")
+    ap.add_argument("--wins", type=int, default=0, help="evaluate only the first N windows (scaling experiments)")
     ap.add_argument("--mode", choices=["rows", "bits"], default="rows",
                     help="rows: MP_EVAL_VARIANT of the row-per-lane kernel; bits: MP_EVAL_BITS shapes of the bit-sliced kernel")
     a = ap.parse_args()
@@ -42,6 +43,8 @@ def main():
     rows = synth_block(0, a.rows, L, 20250303)
     ctx.load_msa(rows.reshape(-1), np.arange(a.rows + 1, dtype=np.int64) * L)
     p0, W = 16, L - 32 - k
+    if a.wins:
+        W = min(W, a.wins)
     n_ex = ctx.build_windows(p0, W, k, v)
     bench.expand_exceptions(ctx, n_ex, k, v)
     root_codes = np.array([1, 2, 4, 8], np.uint8)[synth_root(L, 20250303)]
@@ -68,10 +71,11 @@ def main():
             else:
                 os.environ.pop("MP_EVAL_TILE_GROUPS", None)
             ctx.eval_upload(cw, codes, sF, sR)           # a new plan
-        elif var.startswith("c") or var.startswith("p"):  # cN: eval_chain_kernel shape N; pN: the program-driven kernel, same shapes
+        elif var[0] in "cpq":  # cN: eval_chain_kernel shape N; pN: the program-driven kernel, same shapes (+ 9); qN: the same with a wave per item
             os.environ["MP_EVAL_BITS"] = "0"
             os.environ["MP_EVAL_TILE"] = "0"
-            os.environ["MP_EVAL_PROG"] = "1" if var[0] == "p" else "0"
+            os.environ["MP_EVAL_PROG"] = "1" if var[0] in "pq" else "0"
+            os.environ["MP_EVAL_QUAD"] = "1" if var[0] == "q" else "0"
             os.environ["MP_EVAL_CHAIN"] = var[1:]
             ctx.eval_upload(cw, codes, sF, sR)           # the programs are written at upload time
         else:
