@@ -16,7 +16,9 @@ The headline (`value`) is WEAK scaling: every GPU holds the 131072 x 1000 shard 
                 --no-full).  At N > 1 `strong_scaling` compares the N-GPU step with it: N GPUs x 131072 rows = the same job.
   roofline      every fraction is <= 1 by construction:
                   valu_frac = VALU wave-instructions per launch / (kernel time x SIMDs x measured issue rate)
-                  l2_frac   = bytes requested from L2 per launch / (kernel time x measured L2 read bandwidth)
+                  l2_frac   = bytes requested from L2 per launch / (kernel time x measured L2 read bandwidth).  Round 3 showed what
+                              that ceiling is: 31.4 TB/s = 256 CUs x 64 B/clk, the rate at which a CU's vector memory path hands
+                              data to registers (L1 hits do not go faster: profiles/r03_eval_limits.txt) — a CU-side limit
                   hbm_frac  = measured fabric/HBM bytes per launch (`traffic`) / (kernel time x 8 TB/s)
                 `bound` names the largest.  Kernel time is measured live (HIP events on the library's stream); instruction /
                 request / byte counts come from separate rocprofv3 --pmc passes of this same command (tools/collect_counters.py
@@ -256,6 +258,9 @@ def roofline_block(w, per_launch_ms, samples, kern_n, every, mode):
             "algorithmic_note": "SURVEY 8d figure: 3k/8 bytes per evaluation over the kernel time vs 8 TB/s; exceeds 1 because 8 nested candidates and "
                                 "18 overlapping windows share every loaded plane word — NOT a roofline fraction, kept for comparison with round 1",
             "algorithmic_bytes": alg_bytes, "algorithmic_bytes_per_eval": 3 * w.k / 8.0,
+            "bound_note": "l2 = bytes the vector memory path returns to registers over the rate measured for L2-resident reads, 31.4 TB/s = 256 CUs x 64 B/clk "
+                          "(a CU-side ceiling: serving the same loads from L1 does not change the time); in steady state the kernel runs at 72 % of it, "
+                          "the rest of a launch is ~10 us that do not scale with the work (profiles/r03_eval_limits.txt)",
             "counters": pmc, "counters_source": note, "counters_stale": pmc is None, "source_hash": kernel_source_hash(), "ceilings": ceil,
             "kernel": KERNELS[mode] + "; timed region = counter memset + kernel", "eval_mode": mode,
             "kernel_ms": per_launch_ms, "kernel_ms_median": float(samples[len(samples) // 2]) if len(samples) else None,
