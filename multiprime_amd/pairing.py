@@ -183,14 +183,11 @@ class Primers_filter(object):
         return sorted(keep)
 
     @staticmethod
-    def closest(my_list, my_number1, my_number2):
-        """GM:499-507."""
-        index_left = bisect_left(my_list, my_number1)
-        if my_number2 > my_list[-1]:
-            index_right = len(my_list) - 1
-        else:
-            index_right = bisect_left(my_list, my_number2) - 1
-        return index_left, index_right
+    def closest(positions, lo, hi):
+        """Index range [first, last] of the sorted `positions` inside [lo, hi) — `hi` past the last position keeps the last index
+        (GM:499-507: first > last when the range holds none)."""
+        last = len(positions) - 1 if hi > positions[-1] else bisect_left(positions, hi) - 1
+        return bisect_left(positions, lo), last
 
     # ---- sequence bitsets --------------------------------------------------------------------------
     def _bitsets(self, cand):
