@@ -5,6 +5,37 @@
 
 namespace mp {
 
+namespace {
+struct FillArgs { uint32_t *p[kMaxFillSegs]; unsigned long long words[kMaxFillSegs]; uint32_t value[kMaxFillSegs]; unsigned first_block[kMaxFillSegs + 1]; int n; };
+// thread = 4 consecutive words of one segment
+__global__ __launch_bounds__(kBlock) void fill_kernel(const FillArgs A) {
+    int s = 0;
+    while (s + 1 < A.n && blockIdx.x >= A.first_block[s + 1]) s++;
+    const unsigned long long w0 = ((unsigned long long)(blockIdx.x - A.first_block[s]) * kBlock + threadIdx.x) * 4ull;
+    const uint32_t val = A.value[s];
+    uint32_t *dst = A.p[s] + w0;
+    if (w0 + 4 <= A.words[s]) *reinterpret_cast<uint4 *>(dst) = uint4{val, val, val, val};
+    else
+        for (unsigned long long w = w0; w < A.words[s]; w++) A.p[s][w] = val;
+}
+}  // namespace
+
+int fill_segments(mp_ctx *c, const FillSeg *segs, int n) {
+    FillArgs A{};
+    unsigned blocks = 0;
+    for (int i = 0; i < n && A.n < kMaxFillSegs; i++) {
+        if (!segs[i].p || !segs[i].bytes) continue;
+        A.p[A.n] = (uint32_t *)segs[i].p; A.words[A.n] = segs[i].bytes / 4; A.value[A.n] = segs[i].value; A.first_block[A.n] = blocks;
+        blocks += (unsigned)((A.words[A.n] + (size_t)kBlock * 4 - 1) / ((size_t)kBlock * 4));
+        A.n++;
+    }
+    if (!A.n) return MP_OK;
+    A.first_block[A.n] = blocks;
+    hipLaunchKernelGGL(fill_kernel, dim3(blocks), dim3(kBlock), 0, c->stream, A);
+    HIPCK(c, hipGetLastError());
+    return MP_OK;
+}
+
 void free_tiles(mp_ctx *c) {
     dev_free(c, &c->tile_rounds, (size_t)c->tile_n_rounds);
     dev_free(c, &c->tile_bands, (size_t)c->tile_n_bands);

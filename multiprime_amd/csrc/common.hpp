@@ -215,6 +215,12 @@ void dev_free(mp_ctx *c, T **p, size_t n) {
     }
 }
 
+// Several arrays set to a 32-bit pattern by ONE kernel launch (a stage's counters, cursors and tables used to cost one runtime fill
+// dispatch each, ~6 us apiece).  Sizes in bytes, multiples of 4; pointers from hipMalloc.  api.hip
+struct FillSeg { void *p; size_t bytes; uint32_t value; };
+constexpr int kMaxFillSegs = 8;
+int fill_segments(mp_ctx *c, const FillSeg *segs, int n);
+
 // release the device arrays of one stage (and of every stage that depends on it); api.hip
 void free_eval(mp_ctx *c);
 void free_tiles(mp_ctx *c);

@@ -98,7 +98,7 @@ __device__ inline bool dimer_combo(const Nib &cx, const Nib &cy, int lx, int ly,
 template <int G>
 __device__ inline bool dimer_pair_group(const uint8_t *__restrict__ codes, const int32_t *__restrict__ off, int x, int y, int mode,
                                         const uint8_t *__restrict__ loss_hit, int l0, int gc_rows, const double *__restrict__ dg,
-                                        double dg_limit, int32_t (&rec)[4]) {
+                                        double dg_limit, int32_t (&rec)[4], int sub = 0, int split = 1) {
     const int lane = threadIdx.x & 63, gl = lane & (G - 1), g0 = lane & ~(G - 1);
     const unsigned long long gmask = (G == 64 ? ~0ull : ((1ull << (G & 63)) - 1ull)) << g0;
     const int lx = off[x + 1] - off[x], ly = off[y + 1] - off[y];
@@ -120,7 +120,9 @@ __device__ inline bool dimer_pair_group(const uint8_t *__restrict__ codes, const
     }
     unsigned long long total = 0;
     for (int j = 0; j < n_l; j++) total += __shfl(cnt[j / G], g0 + (j % G));
-    for (unsigned long long t0 = 0; t0 < total; t0 += G) {
+    // (sub, split): this group takes every split-th step of the walk, starting at step sub — a yes/no caller spreads one pair over
+    // `split` groups and ORs their answers; the first passing combination is the lowest group's only when split = 1
+    for (unsigned long long t0 = (unsigned long long)sub * G; t0 < total; t0 += (unsigned long long)split * G) {
         const unsigned long long id = t0 + gl;
         bool hit = false;
         int l = 0, idx = 0;
@@ -156,9 +158,12 @@ constexpr int kStageRow = kStageGc * 64;
 constexpr int kNdg = 16 + 32 + MP_DIMER_MAX_LEN + 1 + 1;
 
 // explicit ordered pairs or an all-pairs scan, G lanes per pair, tables staged in LDS; persistent workgroups stride over the pairs
+// split > 1 (explicit pairs with flags only): `split` groups per pair, each on its own share of the pair's combinations; flags must
+// be zero before the launch and a group writes only a hit (the self-dimer test of the core step has one pair per window primer —
+// a few thousand at most — and a primer of degeneracy 64 has 57 000 combinations: one group would walk them alone for 0.14 ms)
 template <int G>
 __global__ __launch_bounds__(kBlock) void dimer_group_kernel(const DimerArgs A, long long n_pairs, const int32_t *__restrict__ pairs,
-                                                             uint8_t *__restrict__ flags) {
+                                                             uint8_t *__restrict__ flags, int split) {
     __shared__ uint8_t s_loss[kLossRows * kStageRow];
     __shared__ double s_dg[kNdg];
     for (int i = threadIdx.x; i < kLossRows * kStageRow / 16; i += kBlock) {
@@ -170,7 +175,9 @@ __global__ __launch_bounds__(kBlock) void dimer_group_kernel(const DimerArgs A, 
     // pairs whose end lengths all lie in 5..31 use the staged rows; the rare others (primers shorter than 5, 32-mers) the global table
     const int per_block = kBlock / G;
     const int gl = threadIdx.x & (G - 1);
-    for (long long p = (long long)blockIdx.x * per_block + threadIdx.x / G; p < n_pairs; p += (long long)gridDim.x * per_block) {
+    for (long long vp = (long long)blockIdx.x * per_block + threadIdx.x / G; vp < n_pairs * split; vp += (long long)gridDim.x * per_block) {
+        const long long p = vp / split;
+        const int sub = (int)(vp % split);
         int x, y;
         if (pairs) { x = pairs[2 * p]; y = pairs[2 * p + 1]; }
         else {
@@ -180,10 +187,10 @@ __global__ __launch_bounds__(kBlock) void dimer_group_kernel(const DimerArgs A, 
         const int lx = A.off[x + 1] - A.off[x];
         const bool staged = lx <= 31 && (A.mode != 0 || lx >= 5);          // every end length of this pair lies in 5..31
         int32_t rec[4];
-        const bool hit = staged ? dimer_pair_group<G>(A.codes, A.off, x, y, A.mode, s_loss, kLossL0, kStageGc, s_dg, A.dg_limit, rec)
-                                : dimer_pair_group<G>(A.codes, A.off, x, y, A.mode, A.loss_hit, 0, MP_DIMER_MAX_LEN + 1, A.dg, A.dg_limit, rec);
+        const bool hit = staged ? dimer_pair_group<G>(A.codes, A.off, x, y, A.mode, s_loss, kLossL0, kStageGc, s_dg, A.dg_limit, rec, sub, split)
+                                : dimer_pair_group<G>(A.codes, A.off, x, y, A.mode, A.loss_hit, 0, MP_DIMER_MAX_LEN + 1, A.dg, A.dg_limit, rec, sub, split);
         if (gl != 0) continue;
-        if (flags) flags[p] = hit ? 1 : 0;
+        if (flags) { if (split == 1) flags[p] = hit ? 1 : 0; else if (hit) flags[p] = 1; }
         else if (hit) {
             unsigned long long h = atomicAdd(A.n_hits, 1ull);
             if ((long long)h < A.cap) {
@@ -867,8 +874,8 @@ int mp_dimer_scan(mp_ctx *c, int32_t n, const uint8_t *codes, const int32_t *off
         hipLaunchKernelGGL(dimer_rows_kernel<false>, dim3((unsigned)n), dim3(kBlock), 0, c->stream, da, (const PrimRec<false> *)d_prim);
     } else {
         const unsigned blocks = (unsigned)std::min<long long>((all + kBlock / G - 1) / (kBlock / G), 256 * 16);
-        if (G == 64) hipLaunchKernelGGL(dimer_group_kernel<64>, dim3(blocks), dim3(kBlock), 0, c->stream, da, all, (const int32_t *)nullptr, (uint8_t *)nullptr);
-        else hipLaunchKernelGGL(dimer_group_kernel<16>, dim3(blocks), dim3(kBlock), 0, c->stream, da, all, (const int32_t *)nullptr, (uint8_t *)nullptr);
+        if (G == 64) hipLaunchKernelGGL(dimer_group_kernel<64>, dim3(blocks), dim3(kBlock), 0, c->stream, da, all, (const int32_t *)nullptr, (uint8_t *)nullptr, 1);
+        else hipLaunchKernelGGL(dimer_group_kernel<16>, dim3(blocks), dim3(kBlock), 0, c->stream, da, all, (const int32_t *)nullptr, (uint8_t *)nullptr, 1);
     }
     HIPCK(c, hipGetLastError());
     unsigned long long nh = 0;
@@ -917,9 +924,15 @@ int mp_dimer_pairs(mp_ctx *c, int32_t n, const uint8_t *codes, const int32_t *of
                            (const PrimRec<false> *)d_prim, (long long)n_pairs, d_pairs, c->dm_loss, c->dm_dg, dg_limit, d_flags);
     } else {
         DimerArgs da{d_codes, d_off, n, 0, 0, c->dm_loss, c->dm_dg, dg_limit, 0, nullptr, nullptr};
-        const unsigned blocks = (unsigned)std::min<long long>((n_pairs + kBlock / G - 1) / (kBlock / G), 256 * 16);
-        if (G == 64) hipLaunchKernelGGL(dimer_group_kernel<64>, dim3(blocks), dim3(kBlock), 0, c->stream, da, (long long)n_pairs, (const int32_t *)d_pairs, d_flags);
-        else hipLaunchKernelGGL(dimer_group_kernel<16>, dim3(blocks), dim3(kBlock), 0, c->stream, da, (long long)n_pairs, (const int32_t *)d_pairs, d_flags);
+        // few pairs: several groups per pair, until the chip's wave slots are covered about twice
+        int split = 1;
+        if (const char *e = getenv("MP_DIMER_SPLIT")) split = std::max(1, std::min(64, atoi(e)));
+        else while (split < 16 && (long long)n_pairs * split * G < 2LL * 256 * 2048) split *= 2;
+        if (split > 1) HIPCK(c, hipMemsetAsync(d_flags, 0, (size_t)n_pairs, c->stream));
+        const long long groups = (long long)n_pairs * split;
+        const unsigned blocks = (unsigned)std::min<long long>((groups + kBlock / G - 1) / (kBlock / G), 256 * 16);
+        if (G == 64) hipLaunchKernelGGL(dimer_group_kernel<64>, dim3(blocks), dim3(kBlock), 0, c->stream, da, (long long)n_pairs, (const int32_t *)d_pairs, d_flags, split);
+        else hipLaunchKernelGGL(dimer_group_kernel<16>, dim3(blocks), dim3(kBlock), 0, c->stream, da, (long long)n_pairs, (const int32_t *)d_pairs, d_flags, split);
     }
     HIPCK(c, hipGetLastError());
     HIPCK(c, hipMemcpyAsync(flags, d_flags, (size_t)n_pairs, hipMemcpyDeviceToHost, c->stream));

@@ -197,17 +197,23 @@ __global__ __launch_bounds__(kBlock) void eval_kernel(const EvalArgs A) {
 // A bit-sliced workgroup then either covers a slice of the alignment's columns or the patch planes of its item's
 // window (`WordTile`); the kernels do not care which.
 // ----------------------------------------------------------------------------------------------
-// one block per window: 64 rows per wave pass, one ballot per (position, base)
+// one block per (window, run of kPatchRun patch rows) — the host lists the runs, so a window with a hundred thousand patch rows is
+// spread over as many CUs as it has runs; 64 rows per wave pass, one ballot per (position, base); the padding words up to npw are
+// written here as well (no fill beforehand)
+constexpr int kPatchRun = 1024;
+struct PatchRun { int32_t win, row0; };
 __global__ __launch_bounds__(kBlock) void patch_planes_kernel(const int32_t *__restrict__ off_a, const uint32_t *__restrict__ words_a,
                                                               const int32_t *__restrict__ off_b, const uint32_t *__restrict__ words_b,
-                                                              const PatchWin *__restrict__ pwin, int k, int v,
+                                                              const PatchWin *__restrict__ pwin, const PatchRun *__restrict__ runs, int k, int v,
                                                               uint32_t *__restrict__ pplanes, uint32_t *__restrict__ pvalid) {
-    const int win = blockIdx.x;
+    const PatchRun run = runs[blockIdx.x];
+    const int win = run.win;
     const PatchWin pw = pwin[win];
     const int na = off_a ? off_a[win + 1] - off_a[win] : 0, nb = off_b ? off_b[win + 1] - off_b[win] : 0;
     const uint32_t kmask = (1u << k) - 1u;
     const int lane = threadIdx.x & 63;
-    for (int r0 = (threadIdx.x >> 6) * 64; r0 < na + nb; r0 += kBlock) {          // uniform per wave
+    const int end = min(run.row0 + kPatchRun, pw.npw * 32);                        // npw is a multiple of 8 words: whole 64-row passes
+    for (int r0 = run.row0 + (threadIdx.x >> 6) * 64; r0 < end; r0 += kBlock) {    // uniform per wave
         const int e = r0 + lane;
         uint32_t b0 = 0, b1 = 0, g = 0xFFFFFFFFu;
         if (e < na) {
@@ -219,20 +225,23 @@ __global__ __launch_bounds__(kBlock) void patch_planes_kernel(const int32_t *__r
         }
         const bool ok = e < na + nb && !(g & MP_WIN_SKIP) && (int)__popc(g & kmask) <= v;
         const unsigned long long okb = __ballot(ok);
-        const int w0 = r0 >> 5;                                                    // r0 % 64 == 0; npw is even
-        if (lane == 0) { pvalid[pw.voff + w0] = (uint32_t)okb; pvalid[pw.voff + w0 + 1] = (uint32_t)(okb >> 32); }
+        const int w0 = r0 >> 5;                                                    // r0 % 64 == 0
+        if (lane == 0) *reinterpret_cast<uint2 *>(pvalid + pw.voff + w0) = uint2{(uint32_t)okb, (uint32_t)(okb >> 32)};
+        // lane (j * 4 + b) keeps the ballot of its (position, base) and stores it: one 8-byte store per lane instead of 4k from lane 0
+        unsigned long long mine = 0, mine2 = 0;
         for (int j = 0; j < k; j++) {
             const bool base_here = ok && !((g >> j) & 1u);
             const uint32_t code = ((b0 >> j) & 1u) | (((b1 >> j) & 1u) << 1);
 #pragma unroll
             for (uint32_t b = 0; b < 4; b++) {
                 const unsigned long long bal = __ballot(base_here && code == b);
-                if (lane == 0) {
-                    uint32_t *dst = pplanes + pw.poff + ((size_t)j * 4 + b) * pw.npw + w0;
-                    dst[0] = (uint32_t)bal; dst[1] = (uint32_t)(bal >> 32);
-                }
+                const int slot = j * 4 + (int)b;
+                if (lane == (slot & 63)) { if (slot < 64) mine = bal; else mine2 = bal; }
             }
         }
+        if (lane < k * 4) *reinterpret_cast<uint2 *>(pplanes + pw.poff + (size_t)lane * pw.npw + w0) = uint2{(uint32_t)mine, (uint32_t)(mine >> 32)};
+        if (lane + 64 < k * 4)
+            *reinterpret_cast<uint2 *>(pplanes + pw.poff + (size_t)(lane + 64) * pw.npw + w0) = uint2{(uint32_t)mine2, (uint32_t)(mine2 >> 32)};
     }
 }
 
@@ -958,6 +967,7 @@ int ensure_patch_planes(mp_ctx *c) {
     c->max_npw = 0;
     const size_t W = (size_t)c->n_win;
     std::vector<PatchWin> pw(W);
+    std::vector<PatchRun> runs;
     size_t poff = 0, voff = 0;
     for (size_t w = 0; w < W; w++) {
         const int n = (c->h_patch_off[w + 1] - c->h_patch_off[w]) + (c->h_extra_off[w + 1] - c->h_extra_off[w]);
@@ -967,22 +977,25 @@ int ensure_patch_planes(mp_ctx *c) {
         poff += (size_t)c->k * 4 * npw;
         voff += (size_t)npw;
         c->max_npw = std::max(c->max_npw, npw);
+        for (int r0 = 0; r0 < npw * 32; r0 += kPatchRun) runs.push_back(PatchRun{(int32_t)w, r0});
     }
     int rc;
     if ((rc = dev_alloc(c, &c->pwin, W))) return rc;
     HIPCK(c, hipMemcpyAsync(c->pwin, pw.data(), sizeof(PatchWin) * W, hipMemcpyHostToDevice, c->stream));
+    PatchRun *d_runs = nullptr;
     if (poff) {
         if ((rc = dev_alloc(c, &c->pplanes, poff))) return rc;
         if ((rc = dev_alloc(c, &c->pvalid, voff))) return rc;
         c->pp_words = poff; c->pv_words = voff;
-        HIPCK(c, hipMemsetAsync(c->pplanes, 0, sizeof(uint32_t) * poff, c->stream));
-        HIPCK(c, hipMemsetAsync(c->pvalid, 0, sizeof(uint32_t) * voff, c->stream));
-        hipLaunchKernelGGL(patch_planes_kernel, dim3((unsigned)W), dim3(kBlock), 0, c->stream,
+        if ((rc = dev_alloc(c, &d_runs, runs.size()))) return rc;
+        HIPCK(c, hipMemcpyAsync(d_runs, runs.data(), sizeof(PatchRun) * runs.size(), hipMemcpyHostToDevice, c->stream));
+        hipLaunchKernelGGL(patch_planes_kernel, dim3((unsigned)runs.size()), dim3(kBlock), 0, c->stream,
                            c->n_patch ? c->patch_off : (const int32_t *)nullptr, c->patch_words,
-                           c->n_extra ? c->extra_off : (const int32_t *)nullptr, c->extra_words, c->pwin, c->k, c->v, c->pplanes, c->pvalid);
+                           c->n_extra ? c->extra_off : (const int32_t *)nullptr, c->extra_words, c->pwin, d_runs, c->k, c->v, c->pplanes, c->pvalid);
         HIPCK(c, hipGetLastError());
     }
-    HIPCK(c, hipStreamSynchronize(c->stream));            // pw is a host temporary
+    HIPCK(c, hipStreamSynchronize(c->stream));            // pw and runs are host temporaries
+    dev_free(c, &d_runs, runs.size());
     c->pp_dirty = false;
     return MP_OK;
 }
@@ -1181,7 +1194,9 @@ int mp_eval_upload(mp_ctx *c, int32_t n_cand, const int32_t *cw, const uint8_t *
     c->h_cand_out = co;
     if (c->n_chain && c->max_steps <= kEvalCC && getenv("MP_EVAL_PROG") && atoi(getenv("MP_EVAL_PROG")) == 1) {          // fetch programs of the chain items (evalprog.hip)
         std::vector<uint32_t> prog;
-        build_eval_programs(chains, events, co, k, sF, sR, prog);
+        int pshape = 7;                            // the programs carry the LDS slots of the shape that will run them
+        if (const char *e = getenv("MP_EVAL_CHAIN")) { pshape = atoi(e); if (pshape < 0 || pshape >= kProgShapes) pshape = 7; }
+        build_eval_programs(chains, events, co, k, sF, sR, kProgKeep[pshape], prog);
         if ((rc = dev_alloc(c, &c->chain_prog, prog.size()))) return rc;
         c->chain_prog_n = prog.size();
         HIPCK(c, hipMemcpy(c->chain_prog, prog.data(), sizeof(uint32_t) * prog.size(), hipMemcpyHostToDevice));
@@ -1264,10 +1279,10 @@ int mp_eval_launch(mp_ctx *c, int64_t *device_out) {
             const int nw32 = 2 * nw;
             int cshape = nw32 >= 4 * kBlock ? 7 : (nw32 >= 2 * kBlock ? 3 : (nw32 >= kBlock ? 0 : 5));
             const bool use_prog = c->chain_prog && getenv("MP_EVAL_PROG") && atoi(getenv("MP_EVAL_PROG")) == 1;
-            if (const char *e = getenv("MP_EVAL_CHAIN")) { cshape = atoi(e); if (cshape < 0 || cshape > (use_prog ? 9 : 8)) cshape = 0; }
+            if (const char *e = getenv("MP_EVAL_CHAIN")) { cshape = atoi(e); if (cshape < 0 || cshape > (use_prog ? kProgShapes - 1 : 8)) cshape = 0; }
             // (plane rows and patch planes are padded to multiples of 8 words: 8 words per thread is the widest shape of
-            // eval_chain_kernel; shape 9 — 16 words per thread, two groups of 8 — exists in the program-driven kernel only)
-            static const int cgw[10] = {2, 2, 2, 4, 4, 1, 8, 8, 8, 16};
+            // eval_chain_kernel; shapes 9-12 — 16 words per thread, event planes parked in LDS — exist in the program-driven kernel only)
+            const int *cgw = kProgWords;
 #define CHAIN_ROW(LV) {eval_chain_kernel<LV, 2, 6>, eval_chain_kernel<LV, 2, 3>, eval_chain_kernel<LV, 2, 9>, eval_chain_kernel<LV, 4, 3>, \
                        eval_chain_kernel<LV, 4, 6>, eval_chain_kernel<LV, 1, 6>, eval_chain_kernel<LV, 8, 2>, eval_chain_kernel<LV, 8, 4>, \
                        eval_chain_kernel<LV, 8, 1>}

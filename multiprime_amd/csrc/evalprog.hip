@@ -71,9 +71,28 @@ struct Lane {
 
 // WIDE: an item with more than 64 first-pass entries or events (k > 16 with many degenerate positions): entries come out of two
 // registers.  Everything else is one v_readlane per entry.
-template <int LV, int GW, int D, bool WIDE>
-__device__ __forceinline__ void run_item(const Prog &P, const Lane<GW> &L, const uint32_t (&valid)[GW], uint32_t (&acc)[16]) {
+// KS > 0: the planes a later event needs again are parked in LDS when the first pass fetches them (`keep`: the wave's own
+// KS x 64 x GW words) — every event plane IS one of the first pass's planes, because the most degenerate member holds every base a
+// later member loses — so the walk down the chain reads LDS instead of waiting for memory once per event.
+template <int LV, int GW, int D, bool WIDE, int KS>
+__device__ __forceinline__ void run_item(const Prog &P, const Lane<GW> &L, const uint32_t (&valid)[GW], uint32_t (&acc)[16], uint32_t *keep) {
     constexpr int CC = 8;
+    const int lane = (int)(threadIdx.x & 63);
+    auto park = [&](uint32_t en, const uint32_t (&d)[GW]) {              // slot (en >> 8) & 15 of the wave's scratch
+        uint32_t *dst = keep + (((en >> 8) & 15u) * 64 + (uint32_t)lane) * GW;
+        if constexpr (GW == 2) *reinterpret_cast<uint2 *>(dst) = uint2{d[0], d[1]};
+#pragma unroll
+        for (int q = 0; q < GW / 4; q++) *reinterpret_cast<u32x4 *>(dst + 4 * q) = u32x4{d[4 * q], d[4 * q + 1], d[4 * q + 2], d[4 * q + 3]};
+    };
+    auto unpark = [&](uint32_t en, uint32_t (&d)[GW]) {
+        const uint32_t *src = keep + (((en >> 8) & 15u) * 64 + (uint32_t)lane) * GW;
+        if constexpr (GW == 2) { const uint2 v = *reinterpret_cast<const uint2 *>(src); d[0] = v.x; d[1] = v.y; }
+#pragma unroll
+        for (int q = 0; q < GW / 4; q++) {
+            const u32x4 v = *reinterpret_cast<const u32x4 *>(src + 4 * q);
+            d[4 * q] = v.x; d[4 * q + 1] = v.y; d[4 * q + 2] = v.z; d[4 * q + 3] = v.w;
+        }
+    };
     const int n_steps = (int)lane_of(P.r[0], 33), n_ev = (int)lane_of(P.r[0], 34);
     const int nA = (int)lane_of(P.r[0], 35), nB = (int)lane_of(P.r[0], 36), nC = (int)lane_of(P.r[0], 37), nD = (int)lane_of(P.r[0], 38);
     const int nE = (int)lane_of(P.r[0], 39);
@@ -132,6 +151,7 @@ __device__ __forceinline__ void run_item(const Prog &P, const Lane<GW> &L, const
             for (int u = 0; u < D2; u++) { en[u] = pass_entry(q + 2 * u); L.fetch(en[u], la[u]); L.fetch(pass_entry(q + 2 * u + 1), lb[u]); }
 #pragma unroll
             for (int u = 0; u < D2; u++) {
+                if (KS > 0 && (en[u] & kKeepNext)) park(en[u], lb[u]);     // the pair's second base is the one a later member loses
 #pragma unroll
                 for (int i = 0; i < GW; i++) la[u][i] |= lb[u][i];
                 count(la[u]);
@@ -144,6 +164,7 @@ __device__ __forceinline__ void run_item(const Prog &P, const Lane<GW> &L, const
             const uint32_t en = pass_entry(q);
             L.fetch(en, la);
             L.fetch(pass_entry(q + 1), lb);
+            if (KS > 0 && (en & kKeepNext)) park(en, lb);
 #pragma unroll
             for (int i = 0; i < GW; i++) la[i] |= lb[i];
             count(la);
@@ -167,6 +188,7 @@ __device__ __forceinline__ void run_item(const Prog &P, const Lane<GW> &L, const
                 q++;
                 uint32_t pl[GW];
                 L.fetch(en, pl);
+                if (KS > 0 && (en & kKeepThis)) park(en, pl);
 #pragma unroll
                 for (int i = 0; i < GW; i++) m[i] |= pl[i];
             } while ((en & kMore) && q < end);
@@ -185,7 +207,8 @@ __device__ __forceinline__ void run_item(const Prog &P, const Lane<GW> &L, const
 #pragma unroll 1
             while (e < n_ev && (int)((evw >> 24) & 15u) == s) {
                 uint32_t d[GW];
-                L.fetch(evw, d);
+                if (KS > 0 && (evw & kKeepThis)) unpark(evw, d);
+                else L.fetch(evw, d);
 #pragma unroll
                 for (int i = 0; i < GW; i++) count_plane<LV>(t1[i], t2[i], t3[i], t4[i], d[i]);
                 if (evw & (kStrictF | kStrictR)) {
@@ -213,12 +236,14 @@ __device__ __forceinline__ void run_item(const Prog &P, const Lane<GW> &L, const
     }
 }
 
-template <int LV, int GW, int D>
+template <int LV, int GW, int D, int KS>
 __global__ __launch_bounds__(kBlock) void eval_prog_kernel(const EvalProgArgs A) {
     static_assert(GW <= 8 || GW == 16, "plane rows are padded to multiples of 8 words");
+    static_assert(KS == 0 || GW >= 2, "parked planes move as 8- or 16-byte vectors");
     constexpr int CC = 8, NG = (GW + 7) / 8;
     constexpr bool kPacked = 32 * GW < 1024;               // three 10-bit counts per register
     __shared__ uint32_t s_part[kBlock / 64][3 * CC / 2];
+    __shared__ __align__(16) uint32_t s_keep[KS > 0 ? (kBlock / 64) * KS * 64 * GW : 4];
     const bool on_patch = (int)blockIdx.x < A.patch.n_blocks;
     const int lane = (int)(threadIdx.x & 63);
     int slice, item, word0;
@@ -283,8 +308,9 @@ __global__ __launch_bounds__(kBlock) void eval_prog_kernel(const EvalProgArgs A)
     uint32_t acc[2 * CC];
 #pragma unroll
     for (int c = 0; c < 2 * CC; c++) acc[c] = 0;
-    if (lane_of(P.r[0], 40)) run_item<LV, GW, D, true>(P, L, valid, acc);
-    else run_item<LV, GW, D, false>(P, L, valid, acc);
+    uint32_t *keep = s_keep + (KS > 0 ? (threadIdx.x >> 6) * (KS * 64 * GW) : 0);
+    if (lane_of(P.r[0], 40)) run_item<LV, GW, D, true, KS>(P, L, valid, acc, keep);
+    else run_item<LV, GW, D, false, KS>(P, L, valid, acc, keep);
     // commit: wave totals by DPP (bitslice.hpp), the output slots of the 24 counters come from lanes 0-23 of program register 0
     uint32_t tot[3 * CC / 2];
     if constexpr (kPacked) {
@@ -345,7 +371,7 @@ namespace mp {
 // One fixed block of kProgRegs x 64 entries per chain item (layout: evalprog.hpp).  Chains of at most 8 members only: 4 k <= 124
 // first-pass entries and 3 k <= 93 events are the most k <= 31 allows, each within its two registers.
 void build_eval_programs(const std::vector<ChainItem> &chains, const std::vector<uint32_t> &events, const std::vector<int32_t> &cand_out,
-                         int k, uint32_t sF, uint32_t sR, std::vector<uint32_t> &prog) {
+                         int k, uint32_t sF, uint32_t sR, int keep_slots, std::vector<uint32_t> &prog) {
     prog.assign(chains.size() * (size_t)(kProgRegs * 64), 0u);
     const uint32_t any_strict = sF | sR;
     for (size_t i = 0; i < chains.size(); i++) {
@@ -355,6 +381,12 @@ void build_eval_programs(const std::vector<ChainItem> &chains, const std::vector
         };
         auto sym = [&](int j) { return (ch.sym[j >> 3] >> (4 * (j & 7))) & 15u; };
         uint32_t *blk = prog.data() + i * (size_t)(kProgRegs * 64);
+        // the first `keep_slots` events get a slot of the wave's LDS scratch: slot_of[position * 4 + base] = slot + 1
+        int slot_of[MP_MAX_K * 4 + 4] = {0};
+        for (int q = 0; q < ch.n_ev && q < keep_slots; q++) {
+            const uint32_t ev = events[(size_t)ch.ev0 + (size_t)q];
+            slot_of[(ev & 255u) * 4 + (uint32_t)__builtin_ctz((ev >> 8) & 15u)] = q + 1;
+        }
         int n_fp = 0, n[5] = {0, 0, 0, 0, 0};
         for (int list = 0; list < 5; list++)              // A, B: one base without / with a strict position; C, D: two bases; E: the rest
             for (int j = 0; j < k; j++) {
@@ -363,11 +395,14 @@ void build_eval_programs(const std::vector<ChainItem> &chains, const std::vector
                 const bool st = (any_strict >> j) & 1u;
                 const int mine = nb == 1 ? (st ? 1 : 0) : (nb == 2 ? (st ? 3 : 2) : 4);
                 if (mine != list || nb == 0) continue;
-                uint32_t rest = sy;
-                while (rest) {
-                    const int base = __builtin_ctz(rest);
-                    rest &= rest - 1u;
-                    blk[64 + n_fp++] = entry(j, base) | (rest ? kMore : 0u);
+                int bases[4], nbase = 0;
+                for (uint32_t rest = sy; rest; rest &= rest - 1u) bases[nbase++] = __builtin_ctz(rest);
+                if (nb == 2 && slot_of[j * 4 + bases[0]]) std::swap(bases[0], bases[1]);      // a pair's parked base goes second
+                for (int t = 0; t < nbase; t++) {
+                    uint32_t e = entry(j, bases[t]) | (t + 1 < nbase ? kMore : 0u);
+                    if (nb == 2 && t == 0 && slot_of[j * 4 + bases[1]]) e |= kKeepNext | ((uint32_t)(slot_of[j * 4 + bases[1]] - 1) << 8);
+                    if (nb > 2 && slot_of[j * 4 + bases[t]]) e |= kKeepThis | ((uint32_t)(slot_of[j * 4 + bases[t]] - 1) << 8);
+                    blk[64 + n_fp++] = e;
                 }
                 n[list]++;
             }
@@ -375,7 +410,8 @@ void build_eval_programs(const std::vector<ChainItem> &chains, const std::vector
         for (int j = 0; j < k; j++) if (__builtin_popcount(sym(j)) > 2) n_e_entries += __builtin_popcount(sym(j));
         for (int q = 0; q < ch.n_ev; q++) {
             const uint32_t ev = events[(size_t)ch.ev0 + (size_t)q];          // position | lost base (one-hot) << 8 | step << 16
-            blk[192 + q] = entry((int)(ev & 255u), __builtin_ctz((ev >> 8) & 15u)) | ((ev >> 16) << 24);
+            blk[192 + q] = entry((int)(ev & 255u), __builtin_ctz((ev >> 8) & 15u)) | ((ev >> 16) << 24) |
+                           (q < keep_slots ? kKeepThis | ((uint32_t)q << 8) : 0u);
         }
         for (int t = 0; t < 24; t++) blk[t] = (uint32_t)cand_out[(size_t)ch.cand0 + (size_t)(t / 3)];
         const uint32_t head[9] = {(uint32_t)ch.win, (uint32_t)ch.n_steps, (uint32_t)ch.n_ev, (uint32_t)n[0], (uint32_t)n[1], (uint32_t)n[2],
@@ -384,18 +420,21 @@ void build_eval_programs(const std::vector<ChainItem> &chains, const std::vector
     }
 }
 
-// shape: words per thread x fetches per group, as eval_chain_kernel's MP_EVAL_CHAIN table; shape 9 = 16 words per thread
+// shape 0-8: words per thread x fetches per group as eval_chain_kernel's MP_EVAL_CHAIN table; 9 = 16 words per thread; 10-12 park the
+// event planes in LDS (kProgKeep[shape] slots per wave): 4 words x 8 slots, 4 x 4, 8 x 4
 int launch_eval_prog(mp_ctx *c, int shape, const BlockMap &bm, const PatchArgs &pa, unsigned grid, unsigned long long *device_out) {
-#define PROG_ROW(LV) {eval_prog_kernel<LV, 2, 6>, eval_prog_kernel<LV, 2, 3>, eval_prog_kernel<LV, 2, 8>, eval_prog_kernel<LV, 4, 3>, \
-                      eval_prog_kernel<LV, 4, 6>, eval_prog_kernel<LV, 1, 6>, eval_prog_kernel<LV, 8, 2>, eval_prog_kernel<LV, 8, 4>, \
-                      eval_prog_kernel<LV, 8, 1>, eval_prog_kernel<LV, 16, 2>}
-    static const ProgFn fn[4][10] = {PROG_ROW(1), PROG_ROW(2), PROG_ROW(3), PROG_ROW(4)};
+#define PROG_ROW(LV) {eval_prog_kernel<LV, 2, 6, 0>, eval_prog_kernel<LV, 2, 3, 0>, eval_prog_kernel<LV, 2, 8, 0>, eval_prog_kernel<LV, 4, 3, 0>, \
+                      eval_prog_kernel<LV, 4, 6, 0>, eval_prog_kernel<LV, 1, 6, 0>, eval_prog_kernel<LV, 8, 2, 0>, eval_prog_kernel<LV, 8, 4, 0>, \
+                      eval_prog_kernel<LV, 8, 1, 0>, eval_prog_kernel<LV, 16, 2, 0>, eval_prog_kernel<LV, 4, 4, 8>, eval_prog_kernel<LV, 4, 4, 4>, \
+                      eval_prog_kernel<LV, 8, 4, 4>, eval_prog_kernel<LV, 4, 8, 8>, eval_prog_kernel<LV, 4, 6, 6>, eval_prog_kernel<LV, 4, 6, 4>, \
+                      eval_prog_kernel<LV, 4, 4, 5>, eval_prog_kernel<LV, 4, 4, 6>, eval_prog_kernel<LV, 2, 8, 8>, eval_prog_kernel<LV, 2, 6, 8>, \
+                      eval_prog_kernel<LV, 4, 2, 4>, eval_prog_kernel<LV, 4, 3, 5>}
+    static const ProgFn fn[4][kProgShapes] = {PROG_ROW(1), PROG_ROW(2), PROG_ROW(3), PROG_ROW(4)};
 #undef PROG_ROW
     EvalProgArgs a{reinterpret_cast<const uint32_t *>(c->cols), reinterpret_cast<const uint32_t *>(c->excl), c->n_pad / 32, c->p0,
                    c->chain_prog, device_out, bm, pa, 0};
     if (getenv("MP_EVAL_QUAD") && atoi(getenv("MP_EVAL_QUAD")) == 1) {
-        static const int gw_of[10] = {2, 2, 2, 4, 4, 1, 8, 8, 8, 16};
-        const int groups = (c->n_pad / 32 + 64 * gw_of[shape] - 1) / (64 * gw_of[shape]);
+        const int groups = (c->n_pad / 32 + 64 * kProgWords[shape] - 1) / (64 * kProgWords[shape]);
         a.quad_slices = (groups + 7) / 8 * 8;
         grid = (unsigned)((bm.n_items + kBlock / 64 - 1) / (kBlock / 64)) * (unsigned)a.quad_slices;
     }

@@ -252,8 +252,8 @@ int mp_load_msa(mp_ctx *c, const uint8_t *bytes, const int64_t *row_off, int32_t
     for (int r = 0; r <= n_rows; r++) off0[r] = row_off[r] - row_off[0];
     HIPCK(c, hipMemcpyAsync(d_bytes, bytes + row_off[0], (size_t)total, hipMemcpyHostToDevice, c->stream));
     HIPCK(c, hipMemcpyAsync(d_off, off0.data(), sizeof(int64_t) * (n_rows + 1), hipMemcpyHostToDevice, c->stream));
-    HIPCK(c, hipMemsetAsync(c->ung, 0, sizeof(uint32_t) * np * c->ustride, c->stream));
-    HIPCK(c, hipMemsetAsync(c->rlen, 0, sizeof(int32_t) * np, c->stream));
+    const FillSeg init[2] = {{c->ung, sizeof(uint32_t) * np * c->ustride, 0u}, {c->rlen, sizeof(int32_t) * np, 0u}};
+    if ((rc = fill_segments(c, init, 2))) return rc;
     hipLaunchKernelGGL(pack_kernel, dim3((unsigned)(c->n_pad / kBlock), (unsigned)((c->n_chunks + kPackChunks - 1) / kPackChunks)), dim3(kBlock), 0,
                        c->stream, d_bytes, d_off, n_rows, c->n_pad, c->n_chunks, c->planes);
     hipLaunchKernelGGL(row_scan_kernel, dim3(c->n_pad / kBlock), dim3(kBlock), 0, c->stream, c->planes, d_off, n_rows,

@@ -54,12 +54,11 @@ struct HistArgs {
     unsigned long long *prof;             // MP_HIST_PROF: [workgroup][8] shader-clock stamps of hist_kernel's phases (null: none)
 };
 
-// merge one (key, count, first row) into the window's global table
-__device__ inline void global_insert(const HistArgs &A, int w, unsigned long long key, uint32_t cnt, uint32_t row) {
+// merge one (key, count, first row) into the window's global table, probing from slot h
+__device__ inline void global_insert_from(const HistArgs &A, int w, unsigned long long key, uint32_t cnt, uint32_t row, uint32_t h, int probe0) {
     const uint32_t mask = (uint32_t)A.g_slots - 1u;
     unsigned long long *K = A.g_key + (size_t)w * A.g_slots;
-    uint32_t h = hash64(key) & mask;
-    for (int probe = 0; probe < A.g_slots; probe++) {
+    for (int probe = probe0; probe < A.g_slots; probe++) {
         unsigned long long old = K[h];
         if (old == kNoKey) {
             old = atomicCAS(&K[h], kNoKey, key);
@@ -73,6 +72,46 @@ __device__ inline void global_insert(const HistArgs &A, int w, unsigned long lon
         h = (h + 1) & mask;
     }
     A.g_over[w] = 1;
+}
+__device__ inline void global_insert(const HistArgs &A, int w, unsigned long long key, uint32_t cnt, uint32_t row) {
+    global_insert_from(A, w, key, cnt, row, hash64(key) & ((uint32_t)A.g_slots - 1u), 0);
+}
+
+// The workgroup's LDS table into the window's global table.  A thread owns kLdsSlots / kBlock slots and takes them through the
+// merge TOGETHER: all their first-probe reads, then all the claims, then the (unreturned) count / first-row atomics — two global
+// round trips for the whole set instead of three or four per occupied slot one after the other; only a slot whose first probe meets
+// a different key walks on alone.
+__device__ inline void flush_table(const HistArgs &A, int w, unsigned long long *s_key, uint32_t *s_cnt, uint32_t *s_min) {
+    constexpr int S = kLdsSlots / kBlock;
+    const uint32_t mask = (uint32_t)A.g_slots - 1u;
+    unsigned long long *K = A.g_key + (size_t)w * A.g_slots;
+    unsigned long long key[S], old[S];
+    uint32_t cnt[S], mn[S], h[S];
+#pragma unroll
+    for (int u = 0; u < S; u++) {
+        const int i = threadIdx.x + u * kBlock;
+        key[u] = s_key[i]; cnt[u] = s_cnt[i]; mn[u] = s_min[i];
+        s_key[i] = kNoKey; s_cnt[i] = 0; s_min[i] = kEmpty;
+        h[u] = hash64(key[u]) & mask;
+    }
+#pragma unroll
+    for (int u = 0; u < S; u++) old[u] = key[u] != kNoKey ? K[h[u]] : 0ull;
+#pragma unroll
+    for (int u = 0; u < S; u++)
+        if (key[u] != kNoKey && old[u] == kNoKey) {
+            old[u] = atomicCAS(&K[h[u]], kNoKey, key[u]);
+            if (old[u] == kNoKey) old[u] = key[u];
+        }
+#pragma unroll
+    for (int u = 0; u < S; u++)
+        if (key[u] != kNoKey) {
+            if (old[u] == key[u]) {
+                atomicAdd(&A.g_cnt[(size_t)w * A.g_slots + h[u]], cnt[u]);
+                atomicMin(&A.g_min[(size_t)w * A.g_slots + h[u]], mn[u]);
+            } else {
+                global_insert_from(A, w, key[u], cnt[u], mn[u], (h[u] + 1) & mask, 1);
+            }
+        }
 }
 
 __global__ __launch_bounds__(kBlock) void hist_kernel(const HistArgs A) {
@@ -100,13 +139,7 @@ __global__ __launch_bounds__(kBlock) void hist_kernel(const HistArgs A) {
     stamp(1);
     const int lane = threadIdx.x & 63;
     const uint32_t *P = A.M.planes + ((size_t)(p >> 5) * 4) * np;
-    auto flush = [&]() {
-        for (int i = threadIdx.x; i < kLdsSlots; i += kBlock) {
-            const unsigned long long key = s_key[i];
-            if (key != kNoKey) global_insert(A, w, key, s_cnt[i], s_min[i]);
-            s_key[i] = kNoKey; s_cnt[i] = 0; s_min[i] = kEmpty;
-        }
-    };
+    auto flush = [&]() { flush_table(A, w, s_key, s_cnt, s_min); };
     uint32_t nx[8];
     int nlen = 0;
     {
@@ -151,14 +184,19 @@ __global__ __launch_bounds__(kBlock) void hist_kernel(const HistArgs A) {
             if (lane == lead) cnt = (uint32_t)__popcll(grp);
             else if (todo && key == k0) todo = false;
         }
+        bool claimed = false;
         if (todo) {
             uint32_t h = hash64(key) & (kLdsSlots - 1);
             for (;;) {
                 unsigned long long old = atomicCAS(&s_key[h], kNoKey, key);
-                if (old == kNoKey) { atomicAdd(&s_used, 1); old = key; }
+                if (old == kNoKey) { claimed = true; old = key; }
                 if (old == key) { atomicAdd(&s_cnt[h], cnt); atomicMin(&s_min[h], (uint32_t)r); break; }
                 h = (h + 1) & (kLdsSlots - 1);
             }
+        }
+        {   // one fill-count update per wave, not one per claimed slot (they all hit the same LDS word)
+            const unsigned long long cl = __ballot(claimed);
+            if (cl && lane == 0) atomicAdd(&s_used, (int)__popcll(cl));
         }
         if (((base - r0) / kBlock) % kCheckEvery == kCheckEvery - 1) {
             __syncthreads();
@@ -414,36 +452,51 @@ __global__ __launch_bounds__(kBlock) void count_kernel(const unsigned long long 
 // walks the window's table with a running count in LDS: no global atomics (a returning atomic per wave on ~1000 hot
 // addresses made the first version 0.7 ms at 131072 x 1000 for 128 MB of reads).
 __global__ __launch_bounds__(kBlock) void compact_kernel(const CompactArgs A) {
-    __shared__ int s_wave[kBlock / 64];
+    constexpr int U = 8, NWV = kBlock / 64;                   // a thread takes U slots per pass: U independent loads in flight, one barrier pair per pass
+    __shared__ int s_part[U * NWV];
     __shared__ int s_base;
     const int w = blockIdx.x;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     if (threadIdx.x == 0) s_base = 0;
     __syncthreads();
     const uint32_t kmask = (1u << A.k) - 1u;
-    for (int i0 = 0; i0 < A.g_slots; i0 += kBlock) {
-        const size_t s = (size_t)w * A.g_slots + i0 + threadIdx.x;
-        const unsigned long long key = A.g_key[s];
-        const bool occ = key != kNoKey;
-        const unsigned long long m = __ballot(occ);
-        if (lane == 0) s_wave[wave] = (int)__popcll(m);
+    for (int i0 = 0; i0 < A.g_slots; i0 += U * kBlock) {     // g_slots is a power of two >= kBlock: a pass is whole or the table's only one
+        unsigned long long key[U], m[U];
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+            const int i = i0 + u * kBlock + threadIdx.x;
+            key[u] = i < A.g_slots ? A.g_key[(size_t)w * A.g_slots + i] : kNoKey;
+        }
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+            m[u] = __ballot(key[u] != kNoKey);
+            if (lane == 0) s_part[u * NWV + wave] = (int)__popcll(m[u]);
+        }
         __syncthreads();
-        int before = s_base;
-        for (int q = 0; q < wave; q++) before += s_wave[q];
-        if (occ) {
-            const int idx = before + (int)__popcll(m & ((1ull << lane) - 1ull));
+        int before = s_base, run = 0, mine[U];
+#pragma unroll
+        for (int q = 0; q < U * NWV; q++) {                  // slot order: pass-local index u * kBlock + wave * 64 + lane
+            if (q % NWV == 0) mine[q / NWV] = 0;
+            if (q % NWV == wave) mine[q / NWV] = run;
+            run += s_part[q];
+        }
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+            if (key[u] == kNoKey) continue;
+            const size_t s = (size_t)w * A.g_slots + i0 + u * kBlock + threadIdx.x;
+            const int idx = before + mine[u] + (int)__popcll(m[u] & ((1ull << lane) - 1ull));
             A.g_idx[s] = idx;
             const long long e = A.win_base[w] + idx;
             if (e < A.cap) {
-                A.b0[e] = (uint32_t)key & kmask;
-                A.b1[e] = (uint32_t)(key >> A.k) & kmask;
-                A.g[e] = (uint32_t)(key >> (2 * A.k)) & kmask;
+                A.b0[e] = (uint32_t)key[u] & kmask;
+                A.b1[e] = (uint32_t)(key[u] >> A.k) & kmask;
+                A.g[e] = (uint32_t)(key[u] >> (2 * A.k)) & kmask;
                 A.count[e] = (int32_t)A.g_cnt[s];
                 A.first[e] = (int32_t)A.g_min[s];
             }
         }
         __syncthreads();
-        if (threadIdx.x == 0) { int t = 0; for (int q = 0; q < kBlock / 64; q++) t += s_wave[q]; s_base += t; }
+        if (threadIdx.x == 0) s_base = before + run;
         __syncthreads();
     }
 }
@@ -629,11 +682,9 @@ int unique_packed(mp_ctx *c, int64_t cap, int32_t want_labels, int64_t *n_entrie
         if ((rc = dev_alloc(c, &c->g_cnt, n))) return rc;
         if ((rc = dev_alloc(c, &c->g_min, n))) return rc;
         if ((rc = dev_alloc(c, &c->g_idx, n))) return rc;
-        HIPCK(c, hipMemsetAsync(c->g_key, 0xFF, sizeof(unsigned long long) * n, c->stream));
-        HIPCK(c, hipMemsetAsync(c->g_cnt, 0, sizeof(uint32_t) * n, c->stream));
-        HIPCK(c, hipMemsetAsync(c->g_min, 0xFF, sizeof(uint32_t) * n, c->stream));
-        HIPCK(c, hipMemsetAsync(c->u_wcount, 0, sizeof(int32_t) * W, c->stream));
-        HIPCK(c, hipMemsetAsync(c->u_over, 0, sizeof(int32_t) * W, c->stream));
+        const FillSeg init[5] = {{c->g_key, sizeof(unsigned long long) * n, 0xFFFFFFFFu}, {c->g_cnt, sizeof(uint32_t) * n, 0u}, {c->g_min, sizeof(uint32_t) * n, 0xFFFFFFFFu},
+                                 {c->u_wcount, sizeof(int32_t) * W, 0u}, {c->u_over, sizeof(int32_t) * W, 0u}};
+        if ((rc = fill_segments(c, init, 5))) return rc;
         HistArgs A{msa_args(c), c->p0, c->k, c->n_win, 0, 0, 0, c->g_key, c->g_cnt, c->g_min, slots, c->u_over,
                    c->n_patch ? c->patch_off : (const int32_t *)nullptr, c->patch_rows, c->patch_words, nullptr};
         // enough workgroups to fill 256 CUs several times over, slices of at least 4096 rows

@@ -195,7 +195,6 @@ int mp_build_windows(mp_ctx *c, int32_t p0, int32_t n_win, int32_t k, int32_t v,
     if ((rc = dev_alloc(c, &c->ex_count, 1))) return rc;
     if ((rc = dev_alloc(c, &c->err_flag, 4))) return rc;
     if ((rc = dev_alloc(c, &c->extra_off, (size_t)n_win + 1))) return rc;
-    HIPCK(c, hipMemsetAsync(c->extra_off, 0, sizeof(int32_t) * ((size_t)n_win + 1), c->stream));
     const size_t nw = np / 64;
     if ((rc = dev_alloc(c, &c->excl, (size_t)n_win * nw))) return rc;
     if ((rc = dev_alloc(c, &c->patch_count, (size_t)n_win * kCtrStride))) return rc;
@@ -203,10 +202,9 @@ int mp_build_windows(mp_ctx *c, int32_t p0, int32_t n_win, int32_t k, int32_t v,
     if ((rc = dev_alloc(c, &c->patch_cursor, (size_t)n_win * kCtrStride))) return rc;
     const dim3 grid((unsigned)((c->n_pad + kClsBlock - 1) / kClsBlock), (unsigned)(((p0 + n_win - 1) >> 5) - (p0 >> 5) + 1));   // y: chunks holding window starts
     const MsaArgs M = msa_args(c);
-    HIPCK(c, hipMemsetAsync(c->ex_count, 0, sizeof(int), c->stream));
-    HIPCK(c, hipMemsetAsync(c->err_flag, 0, 4 * sizeof(int), c->stream));
-    HIPCK(c, hipMemsetAsync(c->excl, 0, sizeof(unsigned long long) * (size_t)n_win * nw, c->stream));
-    HIPCK(c, hipMemsetAsync(c->patch_count, 0, sizeof(int32_t) * (size_t)n_win * kCtrStride, c->stream));
+    const FillSeg init[5] = {{c->extra_off, sizeof(int32_t) * ((size_t)n_win + 1), 0u}, {c->ex_count, sizeof(int), 0u}, {c->err_flag, 4 * sizeof(int), 0u},
+                             {c->excl, sizeof(unsigned long long) * (size_t)n_win * nw, 0u}, {c->patch_count, sizeof(int32_t) * (size_t)n_win * kCtrStride, 0u}};
+    if ((rc = fill_segments(c, init, 5))) return rc;
     lap("build_windows: alloc+memset");
     hipLaunchKernelGGL(classify_kernel, grid, dim3(kClsBlock), 0, c->stream, M, p0, n_win, k, v,
                        PatchOut{0, c->excl, c->patch_count, nullptr, nullptr, nullptr, nullptr});

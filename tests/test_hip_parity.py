@@ -258,7 +258,8 @@ def test_candidate_grouping_paths_match_oracle(hip_lib, oracle_lib, monkeypatch,
     settings = [{}, {"MP_EVAL_GROUP": "plain"}, {"MP_EVAL_GROUP": "nested"}, {"MP_EVAL_BITS": "1"}, {"MP_EVAL_BITS": "2"},
                 {"MP_EVAL_CHAIN": "0"}, {"MP_EVAL_CHAIN": "3"}, {"MP_EVAL_CHAIN": "5"}, {"MP_EVAL_CHAIN": "7"},
                 {"MP_EVAL_MODE": "rows"}, {"MP_EVAL_TILE": "4"}, {"MP_EVAL_TILE": "2"}, {"MP_EVAL_PROG": "1"},
-                {"MP_EVAL_PROG": "1", "MP_EVAL_CHAIN": "3"}, {"MP_EVAL_PROG": "1", "MP_EVAL_CHAIN": "7"}]
+                {"MP_EVAL_PROG": "1", "MP_EVAL_CHAIN": "3"}, {"MP_EVAL_PROG": "1", "MP_EVAL_CHAIN": "7"},
+                {"MP_EVAL_PROG": "1", "MP_EVAL_CHAIN": "10"}, {"MP_EVAL_PROG": "1", "MP_EVAL_CHAIN": "11"}, {"MP_EVAL_PROG": "1", "MP_EVAL_CHAIN": "12"}]
     for env in settings:
         with monkeypatch.context() as m:
             for key, val in env.items():
@@ -288,7 +289,8 @@ def test_kernel_shapes_and_extreme_k(hip_lib, oracle_lib, monkeypatch, n, k, v):
         cw, codes = chain_candidates(rng, root, W, k, kind)
         want = ora.eval_candidates(cw, codes, sF, sR)
         for env in ({}, {"MP_EVAL_GROUP": "plain"}, {"MP_EVAL_CHAIN": "0"}, {"MP_EVAL_CHAIN": "6"}, {"MP_EVAL_TILE": "4"}, {"MP_EVAL_TILE": "2"},
-                    {"MP_EVAL_PROG": "1"}, {"MP_EVAL_PROG": "1", "MP_EVAL_CHAIN": "6"}):
+                    {"MP_EVAL_PROG": "1"}, {"MP_EVAL_PROG": "1", "MP_EVAL_CHAIN": "6"}, {"MP_EVAL_PROG": "1", "MP_EVAL_CHAIN": "10"},
+                    {"MP_EVAL_PROG": "1", "MP_EVAL_CHAIN": "11"}, {"MP_EVAL_PROG": "1", "MP_EVAL_CHAIN": "12"}):
             with monkeypatch.context() as m:
                 for key, val in env.items():
                     m.setenv(key, val)
