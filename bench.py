@@ -55,26 +55,28 @@ FULL_ROWS = 1048576            # BASELINE.json configs[3]: 1M sequences
 DEFAULT_CEILINGS = {"valu_wave_instr_per_s_per_simd": 8.5e8, "l2_read_GBs": 31559.0, "source": "built-in defaults (profiles/r02_ubench.json missing)"}
 COUNTER_FILES = ("r03_counters.json",)
 # sources of the timed kernel (eval_chain_kernel and what it includes): the key of a counter entry
-KERNEL_SOURCES = ("eval.hip", "bitslice.hpp", "common.hpp", "winwords.hpp", "evaltile.hpp", "evalprog.hpp")
+KERNEL_SOURCES = ("eval.hip", "evalprog.hip", "bitslice.hpp", "common.hpp", "winwords.hpp", "evaltile.hpp", "evalprog.hpp")
+PROG_FROM_ROWS = 393216      # eval.hip (mp_eval_upload): from this many (padded) rows up the program-driven kernel walks the chains
 
 KERNELS = {
     "chain": "eval_chain_kernel (bit-sliced one-hot column planes, nested refinement chains; patch rows ride in the same launch)",
     "table": "eval_bits_kernel (bit-sliced one-hot column planes, symbol table per position; patch rows ride in the same launch)",
     "rows": "eval_kernel (row-per-lane, window words derived from the planes)",
     "tile": "eval_tile_kernel (column planes of a band of windows in an LDS ring) + eval_chain_kernel on the patch planes",
-    "prog": "eval_prog_kernel (eval_chain_kernel's arithmetic, host-written fetch programs, buffer loads)",
+    "prog": "eval_prog_kernel (eval_chain_kernel's arithmetic, host-written fetch programs, buffer loads, event planes parked in LDS; patch rows ride in the same launch)",
 }
 
 
-def eval_mode():
-    """Which evaluation kernels the library's environment switches select (defaults: the nested-chain kernel)."""
+def eval_mode(n_rows=0):
+    """Which evaluation kernels the library's environment switches select (defaults: the nested-chain kernel, in its program-driven
+    form from PROG_FROM_ROWS rows up)."""
     if os.environ.get("MP_EVAL_MODE") == "rows":
         return "rows"
     if os.environ.get("MP_EVAL_BITS", "0") in ("1", "2") or os.environ.get("MP_EVAL_GROUP") == "plain":
         return "table"
     if os.environ.get("MP_EVAL_TILE", "0") in ("2", "4"):
         return "tile"
-    if os.environ.get("MP_EVAL_PROG", "0") == "1":
+    if os.environ.get("MP_EVAL_PROG", "1" if n_rows >= PROG_FROM_ROWS else "0") == "1":
         return "prog"
     return "chain"
 
@@ -391,7 +393,7 @@ def main():
 
     res = None
     if rank == 0:
-        mode = eval_mode()
+        mode = eval_mode(w.n_rows)
         per_launch_ms = kern_ms / max(kern_n, 1)
         res = {
             "metric": "candidate x sequence coverage evals/s",
@@ -450,7 +452,7 @@ def full_config(lib, local, torch, a, timed_region, every, with_cpu):
     out = {"workload": w.describe() + " on ONE GPU (BASELINE configs[3] whole; planes 0.6 GB: larger than the Infinity Cache)",
            "value": w.evals * a.steps / elapsed, "unit": "evals/s", "ms_per_step": elapsed / a.steps * 1e3, "steps": a.steps,
            "evals_per_step": w.evals, "iupac_extra_rows": w.n_extra, "setup_s": w.setup_s, "device_bytes": w.ctx.device_bytes(),
-           "roofline": roofline_block(w, per_launch_ms, samples, kern_n, every, eval_mode()),
+           "roofline": roofline_block(w, per_launch_ms, samples, kern_n, every, eval_mode(w.n_rows)),
            "counter_checksum": counters.sum(axis=0).tolist()}
     if with_cpu:
         cb = cpu_baseline(w, w.rows, a.cpu_threads, counters, a.seed, one_core=False, python_leg=False)

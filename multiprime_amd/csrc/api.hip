@@ -49,6 +49,7 @@ void free_eval(mp_ctx *c) {
     c->h_chains.clear(); c->h_events.clear(); c->h_cand_out.clear();
     dev_free(c, &c->chain_prog, c->chain_prog_n);
     c->chain_prog_n = 0;
+    c->prog_shape = -1;
     dev_free(c, &c->items, (size_t)c->n_items);
     dev_free(c, &c->cand_n, (size_t)c->n_padded);
     dev_free(c, &c->cand_out, (size_t)c->n_padded);

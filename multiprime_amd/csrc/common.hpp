@@ -157,6 +157,7 @@ struct mp_ctx {
     std::vector<int32_t> h_cand_out;         // output slot of every padded candidate
     uint32_t *chain_prog = nullptr;          // fetch programs of the chain items (evalprog.hip), chains of up to 8 members only
     size_t chain_prog_n = 0;
+    int prog_shape = -1;                     // eval_prog_kernel shape the programs were written for (-1: eval_chain_kernel runs the chains)
     mp::TileRound *tile_rounds = nullptr;
     mp::TileBand *tile_bands = nullptr;
     uint32_t *tile_prog = nullptr;

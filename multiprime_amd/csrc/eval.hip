@@ -1192,11 +1192,21 @@ int mp_eval_upload(mp_ctx *c, int32_t n_cand, const int32_t *cw, const uint8_t *
     c->h_chains = chains;
     c->h_events = events;
     c->h_cand_out = co;
-    if (c->n_chain && c->max_steps <= kEvalCC && getenv("MP_EVAL_PROG") && atoi(getenv("MP_EVAL_PROG")) == 1) {          // fetch programs of the chain items (evalprog.hip)
-        std::vector<uint32_t> prog;
-        int pshape = 7;                            // the programs carry the LDS slots of the shape that will run them
-        if (const char *e = getenv("MP_EVAL_CHAIN")) { pshape = atoi(e); if (pshape < 0 || pshape >= kProgShapes) pshape = 7; }
-        build_eval_programs(chains, events, co, k, sF, sR, kProgKeep[pshape], prog);
+    // Which kernel walks the chains.  eval_prog_kernel (evalprog.hip: host-written fetch programs, buffer loads, event planes parked
+    // in LDS) is faster from about 400 000 rows up, where the planes no longer come out of L2 (shape 11: 1.122 vs 1.193 ms / 10 steps at
+    // 524 288 rows, 0.217-0.223 vs 0.240-0.242 ms at 1 048 576; slower below: 0.0549 vs 0.0524 ms at 262 144 —
+    // profiles/r03_prog_keep.txt); eval_chain_kernel otherwise.  MP_EVAL_PROG=1 / 0 forces one of them, MP_EVAL_CHAIN the shape.
+    c->prog_shape = -1;
+    if (c->n_chain && c->max_steps <= kEvalCC) {
+        const char *pe = getenv("MP_EVAL_PROG");
+        if (pe ? atoi(pe) == 1 : c->n_pad >= 393216) {
+            c->prog_shape = pe ? 7 : 11;
+            if (const char *e = getenv("MP_EVAL_CHAIN")) { const int sh = atoi(e); if (pe && sh >= 0 && sh < kProgShapes) c->prog_shape = sh; }
+        }
+    }
+    if (c->prog_shape >= 0) {
+        std::vector<uint32_t> prog;                // the programs carry the LDS slots of the shape that will run them
+        build_eval_programs(chains, events, co, k, sF, sR, kProgKeep[c->prog_shape], prog);
         if ((rc = dev_alloc(c, &c->chain_prog, prog.size()))) return rc;
         c->chain_prog_n = prog.size();
         HIPCK(c, hipMemcpy(c->chain_prog, prog.data(), sizeof(uint32_t) * prog.size(), hipMemcpyHostToDevice));
@@ -1278,8 +1288,9 @@ int mp_eval_launch(mp_ctx *c, int64_t *device_out) {
             // threads at that size), 4 x 3 from 16384, else 2 x 6 / 1 x 6.  MP_EVAL_CHAIN overrides (tools/variant_bench.py).
             const int nw32 = 2 * nw;
             int cshape = nw32 >= 4 * kBlock ? 7 : (nw32 >= 2 * kBlock ? 3 : (nw32 >= kBlock ? 0 : 5));
-            const bool use_prog = c->chain_prog && getenv("MP_EVAL_PROG") && atoi(getenv("MP_EVAL_PROG")) == 1;
-            if (const char *e = getenv("MP_EVAL_CHAIN")) { cshape = atoi(e); if (cshape < 0 || cshape > (use_prog ? kProgShapes - 1 : 8)) cshape = 0; }
+            const bool use_prog = c->chain_prog && c->prog_shape >= 0;
+            if (use_prog) cshape = c->prog_shape;
+            else if (const char *e = getenv("MP_EVAL_CHAIN")) { cshape = atoi(e); if (cshape < 0 || cshape > 8) cshape = 0; }
             // (plane rows and patch planes are padded to multiples of 8 words: 8 words per thread is the widest shape of
             // eval_chain_kernel; shapes 9-12 — 16 words per thread, event planes parked in LDS — exist in the program-driven kernel only)
             const int *cgw = kProgWords;
@@ -1310,9 +1321,7 @@ int mp_eval_launch(mp_ctx *c, int64_t *device_out) {
                     hipLaunchKernelGGL(cfn[c->v][cshape], dim3((unsigned)ca.patch.n_blocks), dim3(kBlock), 0, c->stream, ca);
                 if ((rc = launch_eval_tile(c, tile_gw, (unsigned long long *)device_out))) return rc;
             } else if (use_prog) {
-                // program-driven kernel (evalprog.hip): same arithmetic and block map, fetches by buffer loads with D of them in
-                // flight all the time.  Measured equal to eval_chain_kernel within +-10 % (profiles/r03_prog_variants_*.txt, DESIGN.md
-                // section 9), so it runs only on request: MP_EVAL_PROG=1.
+                // program-driven kernel (evalprog.hip): same arithmetic and block map (chosen at upload time, see there)
                 int rc = launch_eval_prog(c, cshape, bm, ca.patch, grid, (unsigned long long *)device_out);
                 if (rc) return rc;
             } else {

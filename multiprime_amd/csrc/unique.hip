@@ -77,12 +77,13 @@ __device__ inline void global_insert(const HistArgs &A, int w, unsigned long lon
     global_insert_from(A, w, key, cnt, row, hash64(key) & ((uint32_t)A.g_slots - 1u), 0);
 }
 
-// The workgroup's LDS table into the window's global table.  A thread owns kLdsSlots / kBlock slots and takes them through the
+// The workgroup's LDS table into the window's global table.  A thread owns SLOTS / kBlock slots and takes them through the
 // merge TOGETHER: all their first-probe reads, then all the claims, then the (unreturned) count / first-row atomics — two global
 // round trips for the whole set instead of three or four per occupied slot one after the other; only a slot whose first probe meets
 // a different key walks on alone.
+template <int SLOTS>
 __device__ inline void flush_table(const HistArgs &A, int w, unsigned long long *s_key, uint32_t *s_cnt, uint32_t *s_min) {
-    constexpr int S = kLdsSlots / kBlock;
+    constexpr int S = SLOTS / kBlock;
     const uint32_t mask = (uint32_t)A.g_slots - 1u;
     unsigned long long *K = A.g_key + (size_t)w * A.g_slots;
     unsigned long long key[S], old[S];
@@ -114,7 +115,13 @@ __device__ inline void flush_table(const HistArgs &A, int w, unsigned long long 
         }
 }
 
+// SLOTS x 16 bytes of LDS per workgroup decide how many workgroups a CU holds (160 KB: 4 at 2048 slots — the table plus the fill
+// counter is 8 bytes over 32 KB — 9 at 1024); CHECK = iterations between two fill checks (each costs the workgroup a barrier); the
+// table is flushed above SLOTS - CHECK * kBlock - 128 entries: the next CHECK iterations add at most CHECK * kBlock keys.
+template <int SLOTS, int CHECK>
 __global__ __launch_bounds__(kBlock) void hist_kernel(const HistArgs A) {
+    constexpr int kLdsSlots = SLOTS, kCheckEvery = CHECK, kLdsLimit = SLOTS - CHECK * kBlock - 128;
+    static_assert(kLdsLimit >= 256, "the table must hold a few iterations' keys");
     __shared__ unsigned long long s_key[kLdsSlots];
     __shared__ uint32_t s_cnt[kLdsSlots];
     __shared__ uint32_t s_min[kLdsSlots];
@@ -139,7 +146,7 @@ __global__ __launch_bounds__(kBlock) void hist_kernel(const HistArgs A) {
     stamp(1);
     const int lane = threadIdx.x & 63;
     const uint32_t *P = A.M.planes + ((size_t)(p >> 5) * 4) * np;
-    auto flush = [&]() { flush_table(A, w, s_key, s_cnt, s_min); };
+    auto flush = [&]() { flush_table<SLOTS>(A, w, s_key, s_cnt, s_min); };
     uint32_t nx[8];
     int nlen = 0;
     {
@@ -705,7 +712,11 @@ int unique_packed(mp_ctx *c, int64_t cap, int32_t want_labels, int64_t *n_entrie
                 HIPCK(c, hipMalloc((void **)&A.prof, (size_t)blocks * 64));
                 HIPCK(c, hipMemsetAsync(A.prof, 0, (size_t)blocks * 64, c->stream));
             }
-            hipLaunchKernelGGL(hist_kernel, dim3(blocks), dim3(kBlock), 0, c->stream, A);
+            int lds_slots = 2048;
+            if (const char *e = getenv("MP_HIST_LDS")) lds_slots = atoi(e);
+            if (lds_slots == 1024) hipLaunchKernelGGL((hist_kernel<1024, 1>), dim3(blocks), dim3(kBlock), 0, c->stream, A);
+            else if (lds_slots == 1536) hipLaunchKernelGGL((hist_kernel<1024, 2>), dim3(blocks), dim3(kBlock), 0, c->stream, A);
+            else hipLaunchKernelGGL((hist_kernel<2048, 4>), dim3(blocks), dim3(kBlock), 0, c->stream, A);
             if (prof_path) {
                 std::vector<unsigned long long> h((size_t)blocks * 8);
                 HIPCK(c, hipStreamSynchronize(c->stream));
