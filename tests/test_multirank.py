@@ -233,3 +233,95 @@ def test_bucketed_overlapped_allreduce_reduces_every_step(world, steps, bucket):
     port = 31500 + (os.getpid() % 2000)
     mp.spawn(_bucket_worker, args=(world, port, steps, bucket, q), nprocs=world, join=True)
     assert q.get() is True
+
+
+def _gather_worker(rank, world, port, q):
+    sys.path.insert(0, REPO)
+    import numpy as np
+    import torch.distributed as dist
+    from multiprime_amd.dist import RowShards
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        sh = RowShards()
+        sizes = [400000, 0, 7, 123457][:world]
+        rng = np.random.default_rng(100 + rank)
+        mine = rng.integers(-2 ** 62, 2 ** 62, size=(sizes[rank], 5), dtype=np.int64)
+        got = sh.gather_var(mine)
+        want = np.concatenate([np.random.default_rng(100 + r).integers(-2 ** 62, 2 ** 62, size=(sizes[r], 5), dtype=np.int64) for r in range(world)])
+        ok = got.shape == want.shape and bool((got == want).all())
+        cols = sh.gather_columns(np.full((3, sizes[rank] % 1000), rank, np.uint8))          # [m][n_local] -> [m][n_total]
+        ok = ok and cols.shape == (3, sum(s % 1000 for s in sizes)) and cols.dtype == np.uint8
+        ok = ok and cols[1].tolist() == [r for r in range(world) for _ in range(sizes[r] % 1000)]
+        empty = sh.gather_var(np.zeros((0, 2), np.int32))                                    # nobody has anything
+        ok = ok and empty.shape == (0, 2)
+        if rank == 0:
+            q.put(ok)
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 4])
+def test_gather_var_with_large_and_skewed_payloads(world):
+    """The packed all-gather behind the histogram / exception exchange with what a high-entropy alignment produces: megabytes on one
+    rank, nothing on another, a handful of rows on a third; empty everywhere; the column-wise form."""
+    ctx = mp.get_context("spawn")
+    q = ctx.SimpleQueue()
+    port = 25500 + (os.getpid() % 2000)
+    mp.spawn(_gather_worker, args=(world, port, q), nprocs=world, join=True)
+    assert q.get() is True
+
+
+def _entropy_worker(rank, world, port, inp, out, lib_path):
+    sys.path.insert(0, REPO)
+    import torch.distributed as dist
+    from multiprime_amd._abi import Library
+    from multiprime_amd.core import NN_degenerate
+    from multiprime_amd.dist import RowShards
+    comm = None
+    if world > 1:
+        os.environ["MASTER_ADDR"] = "127.0.0.1"
+        os.environ["MASTER_PORT"] = str(port)
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+        comm = RowShards()
+    try:
+        app = NN_degenerate(seq_file=inp, primer_length=18, coverage=0.05, number_of_dege_bases=6, score_of_dege_bases=64,
+                            raw_entropy_threshold=9.0, product_len=100, position="2,3,-1", variation=2, distance=4, GC="0.2,0.8",
+                            nproc=1, outfile=out, library=Library(lib_path), comm=comm, write_bitsets=True, write_json=True)
+        app.run()
+    finally:
+        if world > 1:
+            dist.destroy_process_group()
+
+
+def test_high_entropy_alignment_sharded_equals_single(oracle_lib, tmp_path):
+    """An alignment in which nearly every (row, window) pair is a k-mer of its own — histogram entries ~ rows x windows, the case the
+    packed gather was never exercised with — gives the same files on 3 row shards as in one process."""
+    import numpy as np
+    rng = np.random.default_rng(77)
+    n, L = 240, 160
+    root = rng.integers(0, 4, L)
+    rows = []
+    for r in range(n):
+        s = root.copy()
+        flip = rng.random(L) < 0.22                       # one mutation every ~4.5 columns: almost no 18-mer survives intact
+        s[flip] = rng.integers(0, 4, int(flip.sum()))
+        txt = "".join("ACGT"[b] for b in s)
+        if r % 17 == 0:
+            txt = "-" * (r % 9) + txt[r % 9:]
+        rows.append(f">s{r}\n{txt}\n")
+    inp = tmp_path / "entropy.fa"
+    inp.write_text("".join(rows))
+    outs = {}
+    for world in (1, 3):
+        out = tmp_path / f"entropy_w{world}.out"
+        port = 27500 + (os.getpid() % 2000) + world
+        mp.spawn(_entropy_worker, args=(world, port, str(inp), str(out), oracle_lib.path), nprocs=world, join=True)
+        outs[world] = out
+    for suffix in ("", ".gap_seq_id_json", ".non_coverage_seq_id_json"):
+        a, b = str(outs[1]) + suffix, str(outs[3]) + suffix
+        assert os.path.exists(a) == os.path.exists(b), suffix
+        if os.path.exists(a):
+            assert open(a, "rb").read() == open(b, "rb").read(), suffix
+    assert os.path.getsize(outs[1]) > 0
