@@ -1,5 +1,7 @@
 // api.hip — part of libmprime_hip.so: hand-written HIP (gfx950 / MI355X, wave64) behind the C ABI of
 // include/mprime.h.  Context lifetime and bookkeeping.
+#include <vector>
+
 #include "common.hpp"
 #include "evaltile.hpp"
 
@@ -130,6 +132,17 @@ int mp_create(int device, mp_ctx **out) {
     mp_ctx *c = new mp_ctx();
     c->dev = device;
     if (pack_init() != MP_OK || dimer_init() != MP_OK) { delete c; return MP_ERR_DEVICE; }
+    {   // The runtime sets up its path for copies to and from pageable host memory on first use: 8 ms in front of the first counter
+        // read-back of mp_build_windows (MP_TRACE).  The drop-in creates the context beside the FASTA parse, so that is paid here.
+        std::vector<uint32_t> h((size_t)1 << 16, 0u);
+        uint32_t *d = nullptr;
+        if (hipMalloc((void **)&d, h.size() * sizeof(uint32_t)) == hipSuccess) {
+            (void)hipMemcpyAsync(d, h.data(), h.size() * sizeof(uint32_t), hipMemcpyHostToDevice, c->stream);
+            (void)hipMemcpyAsync(h.data(), d, h.size() * sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream);
+            (void)hipStreamSynchronize(c->stream);
+            (void)hipFree(d);
+        }
+    }
     *out = c;
     return MP_OK;
 }

@@ -276,6 +276,8 @@ struct EvalBitsArgs {
     const uint32_t *diff_mask;         // [item] positions where the item's candidates do not all carry the same symbol
     const int32_t *item_ids;           // items this launch covers (null: all of them)
     PatchArgs patch;                   // patch / IUPAC rows: the first patch.n_blocks workgroups run on their planes
+    uint32_t *mask_f, *mask_r;         // MASKS form: [candidate][2 nw] "not covered" bit sets instead of counts (mp_eval_masks)
+    int n_rows;
 };
 
 
@@ -284,7 +286,11 @@ struct EvalBitsArgs {
 // shared set of counters (c1..) with one match word; only the positions where they differ run the symbol
 // table, the register-indexed select and the per-candidate updates.  The two counter sets add up exactly at the
 // end (saturating sums: >=1: a1|b1, >=2: a2|b2|a1&b1, ...).
-template <int LV, int GW, bool CHAIN, int D>
+// MASKS: the same pass, but what leaves the thread is the bit set itself — per candidate the words "not covered as a forward /
+// reverse primer" (V20:689-698, 1107-1127: more than v gaps, too many mismatches, or a mismatch at a strict position) of the plain
+// rows, 32 per word exactly as the registers hold them: ~(valid & ~far & ~strict) inside the alignment's rows.  `excl` rows come
+// out as 1; the ones among them that are not plain column slices (the window's patch list) are then ASSIGNED by mask_patch_kernel.
+template <int LV, int GW, bool CHAIN, int D, bool MASKS = false>
 __global__ __launch_bounds__(kBlock) void eval_bits_kernel(const EvalBitsArgs A) {
     constexpr int CC = 8;
     __shared__ uint32_t s_part[kBlock / 64][3 * CC / 2];
@@ -429,6 +435,8 @@ __global__ __launch_bounds__(kBlock) void eval_bits_kernel(const EvalBitsArgs A)
 #pragma unroll
         for (int i = 0; i < GW; i++) {
             const uint32_t valid = T.mask[i] ^ T.mask_flip;
+            const int row0 = (word0 + i) * 32;                 // MASKS: bits of rows past the alignment's last stay 0
+            const uint32_t inside = row0 + 32 <= A.n_rows ? 0xFFFFFFFFu : (row0 >= A.n_rows ? 0u : ((1u << (A.n_rows - row0)) - 1u));
 #pragma unroll
             for (int c = 0; c < CC; c++) {
                 // exact saturating sum of the shared and the per-candidate counters
@@ -438,12 +446,22 @@ __global__ __launch_bounds__(kBlock) void eval_bits_kernel(const EvalBitsArgs A)
                 if (LV >= 3) far = t3[c][i] | c3[i] | (t2[c][i] & c1[i]) | (t1[c][i] & c2[i]);
                 if (LV >= 4) far = t4[c][i] | c4[i] | (t3[c][i] & c1[i]) | (t2[c][i] & c2[i]) | (t1[c][i] & c3[i]);
                 const uint32_t bf = sf[c][i] | csf[i], br = sr[c][i] | csr[i];
+                if (MASKS) {
+                    const int oc = A.cand_out[it.cand0 + c];
+                    if (oc >= 0) {
+                        const size_t at = (size_t)oc * nw32 + (size_t)(word0 + i);
+                        A.mask_f[at] = ~__builtin_amdgcn_bitop3_b32(valid, far, bf, kLutAndNotNot) & inside;
+                        A.mask_r[at] = ~__builtin_amdgcn_bitop3_b32(valid, far, br, kLutAndNotNot) & inside;
+                    }
+                    continue;
+                }
                 accP[c] += __popc(valid & ~a1);
                 accF[c] += __popc(__builtin_amdgcn_bitop3_b32(valid, far, bf, kLutAndNotNot));
                 accR[c] += __popc(__builtin_amdgcn_bitop3_b32(valid, far, br, kLutAndNotNot));
             }
         }
     }
+    if (MASKS) return;
     if (on_patch) wave_commit<GW>(accP, accF, accR, s_part[threadIdx.x >> 6], A.cand_out + it.cand0, A.out);
     else block_commit<GW>(accP, accF, accR, s_part, A.cand_out + it.cand0, A.out);
 }
@@ -892,15 +910,19 @@ __global__ __launch_bounds__(kBlock) void mask_patch_kernel(const EvalArgs A, co
     const size_t nw = (size_t)A.n_pad / 64;
     for (int e = patch_off[it.win] + threadIdx.x; e < patch_off[it.win + 1]; e += kBlock) {
         const uint32_t b0 = patch_words[3 * (size_t)e], b1 = patch_words[3 * (size_t)e + 1], g = patch_words[3 * (size_t)e + 2];
-        if (g & MP_WIN_SKIP) continue;                            // IUPAC k-mer (the host owns it) or a too-short row
+        const bool skip = g & MP_WIN_SKIP;                        // IUPAC k-mer (the host owns it) or a too-short row: both bits 0
         const int r = patch_rows[e];
+        const unsigned long long bit = 1ull << (r & 63);
         for (int c = 0; c < CC; c++) {
             const int oc = A.cand_out[it.cand0 + c];
             if (oc < 0) continue;
-            bool bad_f, bad_r;
-            mask_decide(b0, b1, g & A.kmask, A.cand_n[it.cand0 + c], A, bad_f, bad_r);
-            if (bad_f) atomicOr(&not_f[(size_t)oc * nw + (size_t)(r >> 6)], 1ull << (r & 63));
-            if (bad_r) atomicOr(&not_r[(size_t)oc * nw + (size_t)(r >> 6)], 1ull << (r & 63));
+            bool bad_f = false, bad_r = false;
+            if (!skip) mask_decide(b0, b1, g & A.kmask, A.cand_n[it.cand0 + c], A, bad_f, bad_r);
+            // the bit-sliced pass left a 1 for every row `excl` flags: the patch rows get their own verdict either way
+            if (bad_f) atomicOr(&not_f[(size_t)oc * nw + (size_t)(r >> 6)], bit);
+            else atomicAnd(&not_f[(size_t)oc * nw + (size_t)(r >> 6)], ~bit);
+            if (bad_r) atomicOr(&not_r[(size_t)oc * nw + (size_t)(r >> 6)], bit);
+            else atomicAnd(&not_r[(size_t)oc * nw + (size_t)(r >> 6)], ~bit);
         }
     }
 }
@@ -998,6 +1020,18 @@ int ensure_patch_planes(mp_ctx *c) {
     dev_free(c, &d_runs, runs.size());
     c->pp_dirty = false;
     return MP_OK;
+}
+
+// workgroups of a bit-sliced launch: n_items items x the row slices of nw 64-bit words at GW 32-bit words per thread (bitslice.hpp)
+BlockMap make_block_map(int nw, int GW, int n_items, unsigned &grid) {
+    BlockMap m;
+    m.ny = std::max(1, (2 * nw / GW + kBlock - 1) / kBlock);
+    m.ny_pad = m.ny > 4 ? (m.ny + 7) / 8 * 8 : (m.ny > 2 ? 4 : m.ny);
+    m.n_items = n_items;
+    const int bands = m.ny_pad >= 8 ? 1 : 8 / m.ny_pad;
+    m.per_band = (n_items + bands - 1) / bands;
+    grid = m.ny_pad >= 8 ? (unsigned)((size_t)n_items * m.ny_pad) : (unsigned)(8 * (size_t)m.per_band);
+    return m;
 }
 
 // patch units of a launch over n_items items with GW words per thread and unit_threads threads per unit
@@ -1267,16 +1301,7 @@ int mp_eval_launch(mp_ctx *c, int64_t *device_out) {
         int shape = 0;
         if (const char *e = getenv("MP_EVAL_BITS")) { shape = atoi(e); if (shape < 0 || shape > 2) shape = 0; }
         const int nw = c->n_pad / 64;
-        auto block_map = [&](int GW, int n_items, unsigned &grid) {
-            BlockMap m;
-            m.ny = std::max(1, (2 * nw / GW + kBlock - 1) / kBlock);
-            m.ny_pad = m.ny > 4 ? (m.ny + 7) / 8 * 8 : (m.ny > 2 ? 4 : m.ny);
-            m.n_items = n_items;
-            const int bands = m.ny_pad >= 8 ? 1 : 8 / m.ny_pad;
-            m.per_band = (n_items + bands - 1) / bands;
-            grid = m.ny_pad >= 8 ? (unsigned)((size_t)n_items * m.ny_pad) : (unsigned)(8 * (size_t)m.per_band);
-            return m;
-        };
+        auto block_map = [&](int GW, int n_items, unsigned &grid) { return make_block_map(nw, GW, n_items, grid); };
         { int rc = ensure_patch_planes(c); if (rc) return rc; }
         static const EvalBitsFn tfn[4][2] = {{eval_bits_kernel<1, 2, true, 1>, eval_bits_kernel<1, 2, false, 1>},
                                              {eval_bits_kernel<2, 2, true, 1>, eval_bits_kernel<2, 2, false, 1>},
@@ -1335,7 +1360,7 @@ int mp_eval_launch(mp_ctx *c, int64_t *device_out) {
             const BlockMap bm = block_map(2, n_tab, grid);
             EvalBitsArgs ba{c->cols, c->excl, nw, c->p0, c->k, c->v, c->items, c->cand_symT, c->cand_out, c->sF, c->sR,
                             (unsigned long long *)device_out, bm, c->cand_diff, shape == 0 ? c->table_ids : (const int32_t *)nullptr,
-                            patch_args(c, 2, n_tab, 64)};
+                            patch_args(c, 2, n_tab, 64), nullptr, nullptr, c->n_rows};
             hipLaunchKernelGGL(tfn[c->v][shape == 1 ? 1 : 0], dim3(grid + (unsigned)ba.patch.n_blocks), dim3(kBlock), 0, c->stream, ba);
         }
     } else {
@@ -1450,8 +1475,22 @@ int mp_eval_masks_resident(mp_ctx *c, int32_t n_cand, const int32_t *cw, const u
     c->n_masks = n_cand;
     EvalArgs ea{msa_args(c), c->p0, c->n_pad, c->k, c->items, c->cand_n, c->cand_out, nullptr, nullptr, c->sF, c->sR, c->v,
                 (1u << c->k) - 1u, 0, nullptr};
-    const dim3 grid((unsigned)c->n_items, (unsigned)(c->n_pad / kBlock));
-    hipLaunchKernelGGL((mask_rows_kernel<kEvalCC>), grid, dim3(kBlock), 0, c->stream, ea, c->n_rows, c->mask_f, c->mask_r);
+    // the plain rows: bit-sliced on the column planes (the evaluation pass itself, its final words stored instead of counted);
+    // MP_MASK_MODE=rows keeps the row-per-thread kernel of rounds 1-2 (0.32 ms against 0.0x ms at 131072 rows x 410 windows)
+    const char *mm = getenv("MP_MASK_MODE");
+    if ((mm && !strcmp(mm, "rows")) || c->v > 3) {                 // (four counter levels in the bit-sliced kernels: v <= 3)
+        const dim3 grid((unsigned)c->n_items, (unsigned)(c->n_pad / kBlock));
+        hipLaunchKernelGGL((mask_rows_kernel<kEvalCC>), grid, dim3(kBlock), 0, c->stream, ea, c->n_rows, c->mask_f, c->mask_r);
+    } else {
+        static const EvalBitsFn mfn[4] = {eval_bits_kernel<1, 2, true, 1, true>, eval_bits_kernel<2, 2, true, 1, true>,
+                                          eval_bits_kernel<3, 2, true, 1, true>, eval_bits_kernel<4, 2, true, 1, true>};
+        unsigned grid;
+        const BlockMap bm = make_block_map((int)nw, 2, c->n_items, grid);
+        PatchArgs none{nullptr, nullptr, nullptr, 0, 0};
+        EvalBitsArgs ba{c->cols, c->excl, (int)nw, c->p0, c->k, c->v, c->items, c->cand_symT, c->cand_out, c->sF, c->sR, nullptr, bm, c->cand_diff,
+                        nullptr, none, reinterpret_cast<uint32_t *>(c->mask_f), reinterpret_cast<uint32_t *>(c->mask_r), c->n_rows};
+        hipLaunchKernelGGL(mfn[c->v], dim3(grid), dim3(kBlock), 0, c->stream, ba);
+    }
     if (c->n_patch)
         hipLaunchKernelGGL((mask_patch_kernel<kEvalCC>), dim3((unsigned)c->n_items), dim3(kBlock), 0, c->stream, ea, (const int32_t *)c->patch_off,
                            (const int32_t *)c->patch_rows, (const uint32_t *)c->patch_words, c->mask_f, c->mask_r);

@@ -670,6 +670,7 @@ int alloc_entries(mp_ctx *c, int64_t cap) {
 int unique_packed(mp_ctx *c, int64_t cap, int32_t want_labels, int64_t *n_entries) {
     const size_t W = (size_t)c->n_win, np = (size_t)c->n_pad;
     int rc;
+    Lap lap(c->stream);
     if ((rc = dev_alloc(c, &c->u_over, W))) return rc;
     if ((rc = dev_alloc(c, &c->u_wcount, W))) return rc;
     if ((rc = dev_alloc(c, &c->u_wbase, W))) return rc;
@@ -691,7 +692,9 @@ int unique_packed(mp_ctx *c, int64_t cap, int32_t want_labels, int64_t *n_entrie
         if ((rc = dev_alloc(c, &c->g_idx, n))) return rc;
         const FillSeg init[5] = {{c->g_key, sizeof(unsigned long long) * n, 0xFFFFFFFFu}, {c->g_cnt, sizeof(uint32_t) * n, 0u}, {c->g_min, sizeof(uint32_t) * n, 0xFFFFFFFFu},
                                  {c->u_wcount, sizeof(int32_t) * W, 0u}, {c->u_over, sizeof(int32_t) * W, 0u}};
+        lap("unique: table alloc");
         if ((rc = fill_segments(c, init, 5))) return rc;
+        lap("unique: table fill");
         HistArgs A{msa_args(c), c->p0, c->k, c->n_win, 0, 0, 0, c->g_key, c->g_cnt, c->g_min, slots, c->u_over,
                    c->n_patch ? c->patch_off : (const int32_t *)nullptr, c->patch_rows, c->patch_words, nullptr};
         // enough workgroups to fill 256 CUs several times over, slices of at least 4096 rows
@@ -735,11 +738,13 @@ int unique_packed(mp_ctx *c, int64_t cap, int32_t want_labels, int64_t *n_entrie
             ConsArgs C{reinterpret_cast<const uint32_t *>(c->cols), reinterpret_cast<const uint32_t *>(c->excl), c->cons, nw32};
             hipLaunchKernelGGL(hist_cons_kernel, dim3(blocks), dim3(kBlock), 0, c->stream, A, C);
         }
+        lap("unique: histogram");
         hipLaunchKernelGGL(count_kernel, dim3((unsigned)W), dim3(kBlock), 0, c->stream, (const unsigned long long *)c->g_key, slots, c->u_wcount);
         HIPCK(c, hipGetLastError());
         HIPCK(c, hipMemcpyAsync(used.data(), c->u_wcount, sizeof(int32_t) * W, hipMemcpyDeviceToHost, c->stream));
         HIPCK(c, hipMemcpyAsync(over.data(), c->u_over, sizeof(int32_t) * W, hipMemcpyDeviceToHost, c->stream));
         HIPCK(c, hipStreamSynchronize(c->stream));
+        lap("unique: count + d2h");
         bool any_over = false;
         for (size_t w = 0; w < W; w++) any_over |= over[w] != 0 || used[w] > slots - slots / 8;
         if (!any_over) break;
@@ -768,6 +773,7 @@ int unique_packed(mp_ctx *c, int64_t cap, int32_t want_labels, int64_t *n_entrie
         HIPCK(c, hipGetLastError());
     }
     HIPCK(c, hipStreamSynchronize(c->stream));
+    lap("unique: entries alloc+compact");
     dev_free(c, &d_cursor, W);
     c->u_n = total;
     return MP_OK;
@@ -862,6 +868,7 @@ int mp_get_unique(mp_ctx *c, int64_t *win_off, uint32_t *words, int32_t *count, 
         for (size_t w = 0; w < W; w++) { if (c->h_wbase[w] != o) { in_order = false; break; } o += c->h_wcount[w]; }
     }
     if (in_order) {
+        Lap lap(c->stream);
         if (n) {
             HIPCK(c, hipMemcpyAsync(words, c->u_b0, 4 * n, hipMemcpyDeviceToHost, c->stream));
             HIPCK(c, hipMemcpyAsync(words + n, c->u_b1, 4 * n, hipMemcpyDeviceToHost, c->stream));
@@ -870,6 +877,7 @@ int mp_get_unique(mp_ctx *c, int64_t *win_off, uint32_t *words, int32_t *count, 
             HIPCK(c, hipMemcpyAsync(first_row, c->u_first, 4 * n, hipMemcpyDeviceToHost, c->stream));
             HIPCK(c, hipStreamSynchronize(c->stream));
         }
+        lap("get_unique: d2h");
         int64_t o = 0;
         for (size_t w = 0; w < W; w++) { win_off[w] = o; o += c->h_wcount[w]; }
         win_off[W] = o;

@@ -268,6 +268,44 @@ def test_candidate_grouping_paths_match_oracle(hip_lib, oracle_lib, monkeypatch,
         assert np.array_equal(got, want), f"counters differ with {env or 'defaults'}"
 
 
+@pytest.mark.parametrize("n,v,ragged", [(77, 0, False), (300, 1, False), (2100, 2, False), (9000, 3, False), (40000, 1, False), (513, 4, False), (6, 1, True), (5, 2, True)])
+def test_coverage_masks_match_oracle(hip_lib, oracle_lib, monkeypatch, n, v, ragged):
+    """mp_eval_masks: the bit-sliced form (the evaluation pass storing its final words; v <= 3) and the row-per-thread form
+    (MP_MASK_MODE=rows; any v) against the oracle, bit for bit — alignments with edge gaps, ragged ends, IUPAC codes, rows with
+    more than v gaps, candidate groups of every kind, row counts off the word boundaries."""
+    L, k, p0 = 110, 18, 3
+    data, off, _ = fuzz_msa(1234 + n + v, n, L, ragged=ragged, p_gap=0.05, p_iupac=0.004)
+    W = L - p0 - k - 2
+    rng = np.random.default_rng(n * 3 + v)
+    root = np.array([1, 2, 4, 8], np.uint8)[rng.integers(0, 4, size=L)]
+    cw, codes = chain_candidates(rng, root, W, k, "mixed")
+    keep = rng.permutation(len(cw))[:120]
+    keep.sort()
+    cw, codes = cw[keep], codes[keep]
+    sF = sum(1 << y for y in (2, 3))
+    sR = sum(1 << y for y in (2, k - 3, k - 2))
+    hip, ora = both(hip_lib, oracle_lib, data, off)
+    if ragged:
+        W = int(np.sort(np.diff(off))[n // 4]) - k - p0       # stay where most rows still have residues
+        sel = cw < W
+        cw, codes = cw[sel], codes[sel]
+    try:
+        hip.build_windows(p0, W, k, v)
+    except Exception as e:                                    # a short-window error must be raised by both
+        with pytest.raises(type(e)):
+            ora.build_windows(p0, W, k, v)
+        return
+    ora.build_windows(p0, W, k, v)
+    want = ora.eval_masks(cw, codes, sF, sR)
+    for env in ({}, {"MP_MASK_MODE": "rows"}):
+        with monkeypatch.context() as m:
+            for key, val in env.items():
+                m.setenv(key, val)
+            got = hip.eval_masks(cw, codes, sF, sR)
+        for x, y, which in zip(got, want, ("not_f", "not_r")):
+            assert np.array_equal(x, y), f"{which} differs with {env or 'defaults'}"
+
+
 @pytest.mark.parametrize("n,k,v", [(1, 5, 0), (63, 2, 1), (64, 16, 2), (65, 17, 1), (257, 27, 2), (2049, 28, 1),
                                    (33000, 28, 2), (300, 29, 1), (4100, 30, 3), (33000, 31, 2), (520, 31, 0), (8200, 3, 0), (16500, 21, 1), (700, 20, 3), (40000, 18, 3), (300, 12, 4)])
 def test_kernel_shapes_and_extreme_k(hip_lib, oracle_lib, monkeypatch, n, k, v):
