@@ -826,6 +826,11 @@ struct Scratch {
 };
 
 // lanes per pair: one thread per pair once there are enough pairs to fill the chip several times over, else a sub-wave
+// dimer_group_kernel's workgroups stage 54 KB of tables into LDS before their first pair and then stride over the pairs: two fit a
+// CU, so two per CU is the whole grid (a grid of one workgroup per four pairs staged the tables 1800 times for the core step's
+// self-dimer test)
+constexpr long long kGroupGrid = 2 * 256;
+
 static int lanes_per_pair(long long n_pairs, int longest) {
     if (longest > 32) return 1;                         // primers of more than 32 bases: only the thread-per-pair kernels hold them
     if (const char *e = getenv("MP_DIMER_LANES")) { int g = atoi(e); if (g == 1 || g == 16 || g == 64) return g; }
@@ -873,7 +878,7 @@ int mp_dimer_scan(mp_ctx *c, int32_t n, const uint8_t *codes, const int32_t *off
         hipLaunchKernelGGL(prim_kernel<false>, dim3((unsigned)((n + kBlock - 1) / kBlock)), dim3(kBlock), 0, c->stream, d_codes, d_off, (int)n, d_prim);
         hipLaunchKernelGGL(dimer_rows_kernel<false>, dim3((unsigned)n), dim3(kBlock), 0, c->stream, da, (const PrimRec<false> *)d_prim);
     } else {
-        const unsigned blocks = (unsigned)std::min<long long>((all + kBlock / G - 1) / (kBlock / G), 256 * 16);
+        const unsigned blocks = (unsigned)std::min<long long>((all + kBlock / G - 1) / (kBlock / G), kGroupGrid);
         if (G == 64) hipLaunchKernelGGL(dimer_group_kernel<64>, dim3(blocks), dim3(kBlock), 0, c->stream, da, all, (const int32_t *)nullptr, (uint8_t *)nullptr, 1);
         else hipLaunchKernelGGL(dimer_group_kernel<16>, dim3(blocks), dim3(kBlock), 0, c->stream, da, all, (const int32_t *)nullptr, (uint8_t *)nullptr, 1);
     }
@@ -927,10 +932,10 @@ int mp_dimer_pairs(mp_ctx *c, int32_t n, const uint8_t *codes, const int32_t *of
         // few pairs: several groups per pair, until the chip's wave slots are covered about twice
         int split = 1;
         if (const char *e = getenv("MP_DIMER_SPLIT")) split = std::max(1, std::min(64, atoi(e)));
-        else while (split < 16 && (long long)n_pairs * split * G < 2LL * 256 * 2048) split *= 2;
+        else while (split < 16 && (long long)n_pairs * split * G < 4LL * kGroupGrid * kBlock) split *= 2;
         if (split > 1) HIPCK(c, hipMemsetAsync(d_flags, 0, (size_t)n_pairs, c->stream));
         const long long groups = (long long)n_pairs * split;
-        const unsigned blocks = (unsigned)std::min<long long>((groups + kBlock / G - 1) / (kBlock / G), 256 * 16);
+        const unsigned blocks = (unsigned)std::min<long long>((groups + kBlock / G - 1) / (kBlock / G), kGroupGrid);
         if (G == 64) hipLaunchKernelGGL(dimer_group_kernel<64>, dim3(blocks), dim3(kBlock), 0, c->stream, da, (long long)n_pairs, (const int32_t *)d_pairs, d_flags, split);
         else hipLaunchKernelGGL(dimer_group_kernel<16>, dim3(blocks), dim3(kBlock), 0, c->stream, da, (long long)n_pairs, (const int32_t *)d_pairs, d_flags, split);
     }
