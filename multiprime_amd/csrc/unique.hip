@@ -28,11 +28,13 @@ __device__ inline uint32_t hash3(uint32_t a, uint32_t b, uint32_t c) {
     h = (h ^ (h >> 13)) + c * 0xC2B2AE3Du;
     return h ^ (h >> 16);
 }
-// two 32-bit multiplies and three shifts (a 64-bit multiply is four quarter-rate v_mul on gfx950; the first version's
-// splitmix hash was a fifth of the kernel's VALU time)
+// three 24-bit multiplies (full rate on gfx950; a 32-bit v_mul_lo is quarter rate and the first version's splitmix hash was a
+// fifth of the kernel's VALU time) over the key's bits 0-23 / 24-47 / 48-63, two folds: on the bench alignment's k-mers the LDS
+// insert needs 1.66 probe rounds per wave and the global table 1.02 probes per key, the same as with two 32-bit multiplies
 __device__ inline uint32_t hash64(unsigned long long x) {
-    uint32_t h = (uint32_t)x * 0x9E3779B1u + (uint32_t)(x >> 32) * 0x85EBCA77u;
-    h ^= h >> 15; h *= 0xC2B2AE3Du; h ^= h >> 13;
+    uint32_t h = __umul24((uint32_t)x & 0xFFFFFFu, 0x9E3779u) ^ __umul24((uint32_t)(x >> 24) & 0xFFFFFFu, 0x85EBCBu) ^
+                 __umul24((uint32_t)(x >> 48), 0xC2B2AFu);
+    h ^= h >> 15; h ^= h >> 7;
     return h;
 }
 
@@ -77,50 +79,54 @@ __device__ inline void global_insert(const HistArgs &A, int w, unsigned long lon
     global_insert_from(A, w, key, cnt, row, hash64(key) & ((uint32_t)A.g_slots - 1u), 0);
 }
 
-// The workgroup's LDS table into the window's global table.  A thread owns SLOTS / kBlock slots and takes them through the
-// merge TOGETHER: all their first-probe reads, then all the claims, then the (unreturned) count / first-row atomics — two global
-// round trips for the whole set instead of three or four per occupied slot one after the other; only a slot whose first probe meets
-// a different key walks on alone.
+// The workgroup's LDS table into the window's global table.  A thread owns SLOTS / kBlock slots and takes them through the merge four
+// at a time: their first-probe reads together, then the claims, then the (unreturned) count / first-row atomics — two global round
+// trips per four slots instead of two or three per occupied slot one after the other (the flush is a third of a workgroup's life and
+// all of it is global latency); a slot whose first probe meets another key walks on alone.
 template <int SLOTS>
 __device__ inline void flush_table(const HistArgs &A, int w, unsigned long long *s_key, uint32_t *s_cnt, uint32_t *s_min) {
-    constexpr int S = SLOTS / kBlock;
+    constexpr int S = 4;
+    static_assert(SLOTS % (S * kBlock) == 0, "whole groups of slots per thread");
     const uint32_t mask = (uint32_t)A.g_slots - 1u;
     unsigned long long *K = A.g_key + (size_t)w * A.g_slots;
-    unsigned long long key[S], old[S];
-    uint32_t cnt[S], mn[S], h[S];
+#pragma unroll 1
+    for (int i0 = threadIdx.x; i0 < SLOTS; i0 += S * kBlock) {
+        unsigned long long key[S], old[S];
+        uint32_t cnt[S], mn[S], h[S];
 #pragma unroll
-    for (int u = 0; u < S; u++) {
-        const int i = threadIdx.x + u * kBlock;
-        key[u] = s_key[i]; cnt[u] = s_cnt[i]; mn[u] = s_min[i];
-        s_key[i] = kNoKey; s_cnt[i] = 0; s_min[i] = kEmpty;
-        h[u] = hash64(key[u]) & mask;
-    }
-#pragma unroll
-    for (int u = 0; u < S; u++) old[u] = key[u] != kNoKey ? K[h[u]] : 0ull;
-#pragma unroll
-    for (int u = 0; u < S; u++)
-        if (key[u] != kNoKey && old[u] == kNoKey) {
-            old[u] = atomicCAS(&K[h[u]], kNoKey, key[u]);
-            if (old[u] == kNoKey) old[u] = key[u];
+        for (int u = 0; u < S; u++) {
+            const int i = i0 + u * kBlock;
+            key[u] = s_key[i]; cnt[u] = s_cnt[i]; mn[u] = s_min[i];
+            s_key[i] = kNoKey; s_cnt[i] = 0; s_min[i] = kEmpty;
+            h[u] = hash64(key[u]) & mask;
         }
 #pragma unroll
-    for (int u = 0; u < S; u++)
-        if (key[u] != kNoKey) {
-            if (old[u] == key[u]) {
-                atomicAdd(&A.g_cnt[(size_t)w * A.g_slots + h[u]], cnt[u]);
-                atomicMin(&A.g_min[(size_t)w * A.g_slots + h[u]], mn[u]);
-            } else {
-                global_insert_from(A, w, key[u], cnt[u], mn[u], (h[u] + 1) & mask, 1);
+        for (int u = 0; u < S; u++) old[u] = key[u] != kNoKey ? K[h[u]] : 0ull;
+#pragma unroll
+        for (int u = 0; u < S; u++)
+            if (key[u] != kNoKey && old[u] == kNoKey) {
+                old[u] = atomicCAS(&K[h[u]], kNoKey, key[u]);
+                if (old[u] == kNoKey) old[u] = key[u];
             }
-        }
+#pragma unroll
+        for (int u = 0; u < S; u++)
+            if (key[u] != kNoKey) {
+                if (old[u] == key[u]) {
+                    atomicAdd(&A.g_cnt[(size_t)w * A.g_slots + h[u]], cnt[u]);
+                    atomicMin(&A.g_min[(size_t)w * A.g_slots + h[u]], mn[u]);
+                } else {
+                    global_insert_from(A, w, key[u], cnt[u], mn[u], (h[u] + 1) & mask, 1);
+                }
+            }
+    }
 }
 
 // SLOTS x 16 bytes of LDS per workgroup decide how many workgroups a CU holds (160 KB: 4 at 2048 slots — the table plus the fill
-// counter is 8 bytes over 32 KB — 9 at 1024); CHECK = iterations between two fill checks (each costs the workgroup a barrier); the
-// table is flushed above SLOTS - CHECK * kBlock - 128 entries: the next CHECK iterations add at most CHECK * kBlock keys.
+// counter is 8 bytes over 32 KB); CHECK = iterations (of 1024 rows) between two fill checks (each costs the workgroup a barrier); the
+// table is flushed above SLOTS - CHECK * 1024 - 128 entries: the next CHECK iterations add at most CHECK * 1024 keys.
 template <int SLOTS, int CHECK>
 __global__ __launch_bounds__(kBlock) void hist_kernel(const HistArgs A) {
-    constexpr int kLdsSlots = SLOTS, kCheckEvery = CHECK, kLdsLimit = SLOTS - CHECK * kBlock - 128;
+    constexpr int kLdsSlots = SLOTS, kCheckEvery = CHECK, kLdsLimit = SLOTS - CHECK * kBlock * 4 - 128;     // 4 rows per thread and iteration
     static_assert(kLdsLimit >= 256, "the table must hold a few iterations' keys");
     __shared__ unsigned long long s_key[kLdsSlots];
     __shared__ uint32_t s_cnt[kLdsSlots];
@@ -147,65 +153,78 @@ __global__ __launch_bounds__(kBlock) void hist_kernel(const HistArgs A) {
     const int lane = threadIdx.x & 63;
     const uint32_t *P = A.M.planes + ((size_t)(p >> 5) * 4) * np;
     auto flush = [&]() { flush_table<SLOTS>(A, w, s_key, s_cnt, s_min); };
-    uint32_t nx[8];
-    int nlen = 0;
-    {
-        const int r = r0 + threadIdx.x;
-        if (r < r1) {
+    // A thread takes FOUR consecutive rows per iteration: the eight plane words of the four rows arrive as eight 16-byte buffer loads
+    // (row byte offset in a vector register, plane offset in a scalar one).  One-word loads are what round 2 used: a CU returns them at
+    // 20 B/clk (`ubench`: 11 TB/s over the chip, against 31 TB/s for 16-byte loads), and 18.8 M of them per launch were half the
+    // kernel's time on that path alone.
+    constexpr int RPT = 4;
+    typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+    const __amdgpu_buffer_rsrc_t prs = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint32_t *>(P), 0, 0x7FFFFFFF, 0x00020000);
+    const __amdgpu_buffer_rsrc_t lrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<int32_t *>(A.M.rlen), 0, 0x7FFFFFFF, 0x00020000);
+    const int plane_bytes = (int)(np * 4);
+    // two register sets take turns: while one iteration's rows are hashed the next one's plane words arrive in the other set
+    // (a single set copied at the top of every iteration cost 36 register moves per thread and iteration)
+    struct Rows { u32x4 w[8], len; };
+    auto fetch = [&](Rows &R, int r4) {
+        if (r4 < r1) {                                        // r0, r1 and n_pad are multiples of 256: a thread's four rows exist together
 #pragma unroll
-            for (int j = 0; j < 8; j++) nx[j] = P[(size_t)j * np + r];
-            nlen = A.M.rlen[r];
+            for (int j = 0; j < 8; j++) R.w[j] = __builtin_amdgcn_raw_buffer_load_b128(prs, r4 * 4, j * plane_bytes, 0);
+            R.len = __builtin_amdgcn_raw_buffer_load_b128(lrs, r4 * 4, 0, 0);
         }
-    }
-    for (int base = r0; base < r1; base += kBlock) {
-        const int r = base + threadIdx.x;
-        uint32_t cw[8];
+    };
+    auto hash_rows = [&](const Rows &R, int r4, int iter) {
+        const u32x4 (&cw)[8] = R.w;
+        const u32x4 len4 = R.len;
+        unsigned long long claims = 0;
+        const bool mine = r4 < r1;
+        // (1) straight-line: the window words of the thread's four rows (a lane without rows computes on stale registers and is masked
+        // by `ok`); per row index u the first live lane's k-mer comes through v_readlane (no LDS round trip) and the lanes that carry
+        // it fold into that lane
+        unsigned long long key[RPT];
+        uint32_t cnt[RPT], h[RPT];
+        bool todo[RPT];
 #pragma unroll
-        for (int j = 0; j < 8; j++) cw[j] = nx[j];
-        const int len = nlen;
-        {
-            const int rn = r + kBlock;                 // next iteration's plane words: in flight while this one hashes
-            if (rn < r1) {
-#pragma unroll
-                for (int j = 0; j < 8; j++) nx[j] = P[(size_t)j * np + rn];
-                nlen = A.M.rlen[rn];
-            }
-        }
-        bool todo = false;
-        unsigned long long key = kNoKey;
-        if (r < A.M.n_rows) {
+        for (int u = 0; u < RPT; u++) {
             uint32_t b0, b1, g;
             // plain column slices only: the repaired / IUPAC / ragged rows of the window come from the patch list below
-            if (fast_words(p, k, kmask, len, cw[0], cw[1], cw[2], cw[3], cw[4], cw[5], cw[6], cw[7], b0, b1, g)) {
-                todo = true;
-                key = (unsigned long long)b0 | ((unsigned long long)b1 << k) | ((unsigned long long)g << (2 * k));
+            const bool plain = fast_words(p, k, kmask, (int)len4[u], cw[0][u], cw[1][u], cw[2][u], cw[3][u], cw[4][u], cw[5][u], cw[6][u], cw[7][u], b0, b1, g);
+            const bool ok = plain & mine & (r4 + u < A.M.n_rows);
+            key[u] = (unsigned long long)b0 | ((unsigned long long)b1 << k) | ((unsigned long long)g << (2 * k));
+            const unsigned long long pending = __ballot(ok);
+            const int lead = __builtin_amdgcn_readfirstlane(pending ? __ffsll((long long)pending) - 1 : 0);
+            const unsigned long long k0 = (unsigned long long)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)key[u], lead) |
+                                          ((unsigned long long)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(key[u] >> 32), lead) << 32);
+            const bool same = ok & (key[u] == k0);
+            const unsigned long long grp = __ballot(same);             // (every lane votes: not inside the conditional below)
+            cnt[u] = lane == lead ? (uint32_t)__popcll(grp) : 1u;
+            todo[u] = ok & (!same | (lane == lead));
+            h[u] = hash64(key[u]) & (kLdsSlots - 1);
+        }
+        // (2) the first probes of all four rows leave together (four LDS round trips overlap instead of following each other); a row
+        // whose first slot holds another key walks on alone
+        unsigned long long old[RPT];
+#pragma unroll
+        for (int u = 0; u < RPT; u++) old[u] = todo[u] ? atomicCAS(&s_key[h[u]], kNoKey, key[u]) : key[u];
+#pragma unroll
+        for (int u = 0; u < RPT; u++) {
+            bool claimed = false;
+            if (todo[u]) {
+                const uint32_t row = (uint32_t)(r4 + u);
+                if (old[u] == kNoKey) { claimed = true; old[u] = key[u]; }
+                uint32_t hh = h[u];
+                while (old[u] != key[u]) {
+                    hh = (hh + 1) & (kLdsSlots - 1);
+                    old[u] = atomicCAS(&s_key[hh], kNoKey, key[u]);
+                    if (old[u] == kNoKey) { claimed = true; old[u] = key[u]; }
+                }
+                atomicAdd(&s_cnt[hh], cnt[u]);
+                atomicMin(&s_min[hh], row);
             }
+            claims += __popcll(__ballot(claimed));
         }
-        // fold the first lane's k-mer over the wave, then every other distinct lane inserts its own
-        const unsigned long long pending = __ballot(todo);
-        uint32_t cnt = 1;
-        if (pending) {
-            const int lead = __ffsll((long long)pending) - 1;
-            const unsigned long long k0 = __shfl(key, lead);
-            const unsigned long long grp = __ballot(todo && key == k0);
-            if (lane == lead) cnt = (uint32_t)__popcll(grp);
-            else if (todo && key == k0) todo = false;
-        }
-        bool claimed = false;
-        if (todo) {
-            uint32_t h = hash64(key) & (kLdsSlots - 1);
-            for (;;) {
-                unsigned long long old = atomicCAS(&s_key[h], kNoKey, key);
-                if (old == kNoKey) { claimed = true; old = key; }
-                if (old == key) { atomicAdd(&s_cnt[h], cnt); atomicMin(&s_min[h], (uint32_t)r); break; }
-                h = (h + 1) & (kLdsSlots - 1);
-            }
-        }
-        {   // one fill-count update per wave, not one per claimed slot (they all hit the same LDS word)
-            const unsigned long long cl = __ballot(claimed);
-            if (cl && lane == 0) atomicAdd(&s_used, (int)__popcll(cl));
-        }
-        if (((base - r0) / kBlock) % kCheckEvery == kCheckEvery - 1) {
+        // one fill-count update per wave and iteration, not one per claimed slot (they all hit the same LDS word)
+        if (claims && lane == 0) atomicAdd(&s_used, (int)claims);
+        if (iter % kCheckEvery == kCheckEvery - 1) {
             __syncthreads();
             if (s_used > kLdsLimit) {                 // uniform: read after the barrier
                 flush();
@@ -213,6 +232,20 @@ __global__ __launch_bounds__(kBlock) void hist_kernel(const HistArgs A) {
                 if (threadIdx.x == 0) s_used = 0;
                 __syncthreads();
             }
+        }
+    };
+    {
+        constexpr int kStep = kBlock * RPT;
+        Rows Ra, Rb;
+        const int t4 = (int)threadIdx.x * RPT;
+        fetch(Ra, r0 + t4);
+        int iter = 0;
+        for (int base = r0; base < r1; base += 2 * kStep, iter += 2) {      // uniform trip count: the barriers inside are reached by all
+            fetch(Rb, base + kStep + t4);
+            hash_rows(Ra, base + t4, iter);
+            if (base + kStep >= r1) break;
+            fetch(Ra, base + 2 * kStep + t4);
+            hash_rows(Rb, base + kStep + t4, iter + 1);
         }
     }
     __syncthreads();
@@ -225,7 +258,8 @@ __global__ __launch_bounds__(kBlock) void hist_kernel(const HistArgs A) {
         __syncthreads();
     }
     if (slice == 0 && A.patch_off) {
-        // the window's slow pairs (edge-gap repair, ragged end): their k-mers were derived once by repair_kernel
+        // the window's slow pairs (edge-gap repair, ragged end): their k-mers were derived once by repair_kernel (spreading them over
+        // the window's slices was tried: every workgroup then pays the section, 764 -> 799 us)
         const int e0 = A.patch_off[w], e1 = A.patch_off[w + 1];
         for (int eb = e0; eb < e1; eb += kBlock) {
             const int e = eb + threadIdx.x;
@@ -717,9 +751,8 @@ int unique_packed(mp_ctx *c, int64_t cap, int32_t want_labels, int64_t *n_entrie
             }
             int lds_slots = 2048;
             if (const char *e = getenv("MP_HIST_LDS")) lds_slots = atoi(e);
-            if (lds_slots == 1024) hipLaunchKernelGGL((hist_kernel<1024, 1>), dim3(blocks), dim3(kBlock), 0, c->stream, A);
-            else if (lds_slots == 1536) hipLaunchKernelGGL((hist_kernel<1024, 2>), dim3(blocks), dim3(kBlock), 0, c->stream, A);
-            else hipLaunchKernelGGL((hist_kernel<2048, 4>), dim3(blocks), dim3(kBlock), 0, c->stream, A);
+            if (lds_slots == 4096) hipLaunchKernelGGL((hist_kernel<4096, 2>), dim3(blocks), dim3(kBlock), 0, c->stream, A);
+            else hipLaunchKernelGGL((hist_kernel<2048, 1>), dim3(blocks), dim3(kBlock), 0, c->stream, A);
             if (prof_path) {
                 std::vector<unsigned long long> h((size_t)blocks * 8);
                 HIPCK(c, hipStreamSynchronize(c->stream));

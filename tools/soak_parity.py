@@ -23,7 +23,7 @@ ENVS = [{}, {"MP_EVAL_GROUP": "plain"}, {"MP_EVAL_GROUP": "nested"}, {"MP_EVAL_B
         {"MP_EVAL_MODE": "rows"}, {"MP_EVAL_TILE": "4"}, {"MP_EVAL_TILE": "2"}, {"MP_EVAL_PROG": "1"},
         {"MP_EVAL_PROG": "1", "MP_EVAL_CHAIN": "7"}, {"MP_EVAL_PROG": "1", "MP_EVAL_CHAIN": "3"},
         {"MP_EVAL_PROG": "1", "MP_EVAL_CHAIN": "11"}, {"MP_EVAL_PROG": "1", "MP_EVAL_CHAIN": "10"}, {"MP_EVAL_PROG": "1", "MP_EVAL_CHAIN": "12"},
-        {"MP_HIST_LDS": "1024"}]
+        {"MP_HIST_LDS": "4096"}]
 KEYS = sorted({k for e in ENVS for k in e})
 
 
