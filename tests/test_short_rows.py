@@ -34,6 +34,44 @@ def test_short_row_is_rejected_like_the_reference_fails(oracle_lib, tmp_path, ca
     _run(oracle_lib, tmp_path, capsys)
 
 
+def _run_more(lib, tmp_path, capsys):
+    """tests/golden/short_rows_more.json: an empty record and a ragged tail make the reference die the same way (exit 1, ValueError in
+    Y_distance, no TSV) and this build refuse the alignment; a row with 17 residues BETWEEN gaps does not bother the reference (its
+    slices keep their length) and must not bother this build either: same TSV, byte for byte."""
+    recs = json.load(open(os.path.join(GOLDEN, "short_rows_more.json")))
+    assert set(recs) == {"empty_record", "seventeen_residues_between_gaps", "ragged_tail"}
+    for name, rec in recs.items():
+        inp = tmp_path / (name + ".fa")
+        inp.write_text(rec["input"])
+        fl = dict(zip(rec["flags"][::2], rec["flags"][1::2]))
+        out = tmp_path / (name + ".out")
+        app = NN_degenerate(seq_file=str(inp), primer_length=int(fl["-l"]), coverage=float(fl["-f"]), number_of_dege_bases=int(fl["-n"]),
+                            score_of_dege_bases=int(fl["-d"]), raw_entropy_threshold=float(fl["-e"]), product_len=int(fl["-s"]),
+                            position=fl["-c"], variation=int(fl["-v"]), distance=4, GC=fl["-g"], nproc=1, outfile=str(out), library=lib)
+        if rec["reference_returncode"] == 0:
+            app.run()
+            capsys.readouterr()
+            assert out.read_text() == rec["reference_tsv"], name
+        else:
+            assert rec["reference_returncode"] == 1 and not rec["reference_wrote_tsv"]
+            assert rec["reference_last_stderr_line"].startswith("ValueError: operands could not be broadcast")
+            with pytest.raises(SystemExit) as e:
+                app.run()
+            assert e.value.code == 1, name
+            msg = capsys.readouterr().out
+            assert "fewer than 18 residues" in msg and "row %d" % rec["first_short_row"] in msg, (name, msg)
+            assert not out.exists()
+
+
+def test_more_short_row_shapes_behave_like_the_reference(oracle_lib, tmp_path, capsys):
+    _run_more(oracle_lib, tmp_path, capsys)
+
+
+@pytest.mark.gpu
+def test_more_short_row_shapes_on_gpu(hip_lib, tmp_path, capsys):
+    _run_more(hip_lib, tmp_path, capsys)
+
+
 @pytest.mark.gpu
 def test_short_row_is_rejected_on_gpu(hip_lib, tmp_path, capsys):
     _run(hip_lib, tmp_path, capsys)
