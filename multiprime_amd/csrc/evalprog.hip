@@ -420,15 +420,14 @@ void build_eval_programs(const std::vector<ChainItem> &chains, const std::vector
     }
 }
 
-// shape 0-8: words per thread x fetches per group as eval_chain_kernel's MP_EVAL_CHAIN table; 9 = 16 words per thread; 10-12 park the
-// event planes in LDS (kProgKeep[shape] slots per wave): 4 words x 8 slots, 4 x 4, 8 x 4
+// shape 0-8: words per thread x fetches per group as eval_chain_kernel's MP_EVAL_CHAIN table; 9 = 16 words per thread; 10-13 park the
+// event planes in LDS (kProgKeep[shape] slots per wave): 4 words x 8 slots, 4 x 4 (the default from 393 216 rows up), 8 x 4, 4 x 4 with
+// two fetches in flight (eight more shapes were measured and dropped: profiles/r03_prog_keep.txt)
 int launch_eval_prog(mp_ctx *c, int shape, const BlockMap &bm, const PatchArgs &pa, unsigned grid, unsigned long long *device_out) {
 #define PROG_ROW(LV) {eval_prog_kernel<LV, 2, 6, 0>, eval_prog_kernel<LV, 2, 3, 0>, eval_prog_kernel<LV, 2, 8, 0>, eval_prog_kernel<LV, 4, 3, 0>, \
                       eval_prog_kernel<LV, 4, 6, 0>, eval_prog_kernel<LV, 1, 6, 0>, eval_prog_kernel<LV, 8, 2, 0>, eval_prog_kernel<LV, 8, 4, 0>, \
                       eval_prog_kernel<LV, 8, 1, 0>, eval_prog_kernel<LV, 16, 2, 0>, eval_prog_kernel<LV, 4, 4, 8>, eval_prog_kernel<LV, 4, 4, 4>, \
-                      eval_prog_kernel<LV, 8, 4, 4>, eval_prog_kernel<LV, 4, 8, 8>, eval_prog_kernel<LV, 4, 6, 6>, eval_prog_kernel<LV, 4, 6, 4>, \
-                      eval_prog_kernel<LV, 4, 4, 5>, eval_prog_kernel<LV, 4, 4, 6>, eval_prog_kernel<LV, 2, 8, 8>, eval_prog_kernel<LV, 2, 6, 8>, \
-                      eval_prog_kernel<LV, 4, 2, 4>, eval_prog_kernel<LV, 4, 3, 5>}
+                      eval_prog_kernel<LV, 8, 4, 4>, eval_prog_kernel<LV, 4, 2, 4>}
     static const ProgFn fn[4][kProgShapes] = {PROG_ROW(1), PROG_ROW(2), PROG_ROW(3), PROG_ROW(4)};
 #undef PROG_ROW
     EvalProgArgs a{reinterpret_cast<const uint32_t *>(c->cols), reinterpret_cast<const uint32_t *>(c->excl), c->n_pad / 32, c->p0,

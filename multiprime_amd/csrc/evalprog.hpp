@@ -21,9 +21,9 @@ constexpr uint32_t kRowMask = 0x7Fu, kStrictF = 1u << 20, kStrictR = 1u << 21, k
 // bits 8-11: a slot of the wave's LDS scratch; kKeepNext (first entry of a two-base position): park the NEXT entry's plane there;
 // kKeepThis: park this entry's plane (positions with three or four bases) / an event: the plane waits in that slot
 constexpr uint32_t kKeepNext = 1u << 12, kKeepThis = 1u << 13;
-constexpr int kProgShapes = 22;
-constexpr int kProgWords[kProgShapes] = {2, 2, 2, 4, 4, 1, 8, 8, 8, 16, 4, 4, 8, 4, 4, 4, 4, 4, 2, 2, 4, 4};      // row words per thread of a shape
-constexpr int kProgKeep[kProgShapes] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 8, 4, 4, 8, 6, 4, 5, 6, 8, 8, 4, 5};       // LDS slots per wave for parked event planes
+constexpr int kProgShapes = 14;
+constexpr int kProgWords[kProgShapes] = {2, 2, 2, 4, 4, 1, 8, 8, 8, 16, 4, 4, 8, 4};      // row words per thread of a shape
+constexpr int kProgKeep[kProgShapes] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 8, 4, 4, 4};       // LDS slots per wave for parked event planes
 
 void build_eval_programs(const std::vector<ChainItem> &chains, const std::vector<uint32_t> &events, const std::vector<int32_t> &cand_out,
                          int k, uint32_t sF, uint32_t sR, int keep_slots, std::vector<uint32_t> &prog);
