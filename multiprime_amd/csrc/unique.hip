@@ -910,6 +910,7 @@ int mp_get_unique(mp_ctx *c, int64_t *win_off, uint32_t *words, int32_t *count, 
             HIPCK(c, hipMemcpyAsync(first_row, c->u_first, 4 * n, hipMemcpyDeviceToHost, c->stream));
             HIPCK(c, hipStreamSynchronize(c->stream));
         }
+        if (lap.on) fprintf(stderr, "[mprime] get_unique: %zu entries, %.1f MB\n", n, 20.0 * (double)n / 1e6);
         lap("get_unique: d2h");
         int64_t o = 0;
         for (size_t w = 0; w < W; w++) { win_off[w] = o; o += c->h_wcount[w]; }

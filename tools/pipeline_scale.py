@@ -34,6 +34,11 @@ with tempfile.TemporaryDirectory() as td:
                         raw_entropy_threshold=3.6, product_len=150, position="2,3,-1", variation=1, distance=4, GC="0.2,0.7",
                         nproc=1, outfile=os.path.join(td, "out.tsv"), write_json=False, write_bitsets=a.file, keep_bitsets=not a.file)
     app.run()
+    if os.environ.get("MP_REPEAT_UNIQUE"):                      # debugging: the histogram read-back again, in the same process
+        for _ in range(3):
+            t0 = time.time()
+            app.ctx.window_unique(want_labels=False, sort=False)
+            print("window_unique again: %.4f s" % (time.time() - t0), file=sys.stderr)
     wall = time.time() - t0
     n_out = sum(1 for _ in open(os.path.join(td, "out.tsv"))) - 1
     # pairing stage straight from the coverage bitsets (no JSON exists at this depth)
