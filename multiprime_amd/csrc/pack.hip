@@ -62,24 +62,38 @@ __global__ __launch_bounds__(kBlock) void pack_kernel(const uint8_t *__restrict_
     }
 }
 
-// thread = row: prefix count of residues per chunk, leading-gap length and right-stripped length (V20:625-627), and the
-// row's gap-free residue string `ung` (what `.replace("-", "")` gives, V20:673/679): residues are appended in a 64-bit
-// nibble buffer and stored a word at a time into the word-major array, so a wave's stores of one word index coalesce.
-// (Round 1 appended per (row, chunk) with atomicOr into a row-major array: 0.89 ms at 131072 x 1000.)
+// thread = (row, one of kScanSegs runs of chunks): prefix count of residues per chunk, leading-gap length and right-stripped length
+// (V20:625-627), and the row's gap-free residue string `ung` (what `.replace("-", "")` gives, V20:673/679): residues are appended in a
+// 64-bit nibble buffer and stored a word at a time into the word-major array, so a wave's stores of one word index coalesce.
+// (Round 1 appended per (row, chunk) with atomicOr into a row-major array: 0.89 ms at 131072 x 1000; round 2: one thread per row,
+// 0.145 ms — 2048 waves of a long dependent loop, two per SIMD.)  A segment first counts the residues in front of it (plane words only),
+// then packs its own chunks from that nibble offset on; the words it shares with its neighbours (the first and the last it touches)
+// are ORed into the zero-filled array, the others stored.  lead / rstrip: the segment that sees the row's first residue writes `lead`,
+// every segment with a residue raises `rstrip` (zero-filled) with atomicMax.
+constexpr int kScanSegs = 4;
 __global__ __launch_bounds__(kBlock) void row_scan_kernel(const uint32_t *__restrict__ planes, const int64_t *__restrict__ row_off,
                                                           int n_rows, int n_pad, int n_chunks, uint32_t *__restrict__ cum,
                                                           int32_t *__restrict__ lead, int32_t *__restrict__ rstrip,
                                                           int32_t *__restrict__ rlen, uint32_t *__restrict__ ung) {
-    int r = blockIdx.x * kBlock + threadIdx.x;
+    const int r = blockIdx.x * kBlock + threadIdx.x, seg = blockIdx.y;
     if (r >= n_pad) return;
     const size_t np = (size_t)n_pad;
+    const int per = (n_chunks + kScanSegs - 1) / kScanSegs;
+    const int c0 = min(n_chunks, seg * per), c1 = min(n_chunks, c0 + per);
+    auto residues = [&](int c) {
+        const size_t base = ((size_t)c * 4) * np + r;
+        return planes[base] | planes[base + np] | planes[base + 2 * np] | planes[base + 3 * np];
+    };
     uint32_t run = 0;
+    for (int c = 0; c < c0; c++) run += __popc(residues(c));
+    const uint32_t before = run;
     int first = -1, last = 0;
     unsigned long long buf = 0;
-    int nb = 0;
-    size_t widx = 0;
-    for (int c = 0; c < n_chunks; c++) {
-        size_t base = ((size_t)c * 4) * np + r;
+    int nb = (int)(before & 7u);                          // the segment's first word starts at this nibble
+    size_t widx = before >> 3;
+    bool shared = true;                                   // the next word to leave is the segment's first: a neighbour may hold part of it
+    for (int c = c0; c < c1; c++) {
+        const size_t base = ((size_t)c * 4) * np + r;
         const uint32_t mA = planes[base], mC = planes[base + np], mG = planes[base + 2 * np], mT = planes[base + 3 * np];
         uint32_t ng = mA | mC | mG | mT;
         cum[(size_t)c * np + r] = run;
@@ -94,20 +108,24 @@ __global__ __launch_bounds__(kBlock) void row_scan_kernel(const uint32_t *__rest
             const unsigned long long code = ((mA >> j) & 1u) | (((mC >> j) & 1u) << 1) | (((mG >> j) & 1u) << 2) | (((mT >> j) & 1u) << 3);
             buf |= code << (4 * nb);
             if (++nb == 16) {
-                ung[widx * np + r] = (uint32_t)buf;
+                if (shared) atomicOr(&ung[widx * np + r], (uint32_t)buf);
+                else ung[widx * np + r] = (uint32_t)buf;
                 ung[(widx + 1) * np + r] = (uint32_t)(buf >> 32);
+                shared = false;
                 widx += 2; buf = 0; nb = 0;
             }
         }
     }
-    if (nb > 0) ung[widx * np + r] = (uint32_t)buf;
-    if (nb > 8) ung[(widx + 1) * np + r] = (uint32_t)(buf >> 32);
-    cum[(size_t)n_chunks * np + r] = run;
+    // the tail: up to two words, the last of which the next segment may continue
+    if (nb > 0) atomicOr(&ung[widx * np + r], (uint32_t)buf);
+    if (nb > 8) atomicOr(&ung[(widx + 1) * np + r], (uint32_t)(buf >> 32));
+    if (c1 == n_chunks && c0 < c1) cum[(size_t)n_chunks * np + r] = run;
     if (r < n_rows) {
-        int len = (int)(row_off[r + 1] - row_off[r]);
-        lead[r] = first < 0 ? len : first;
-        rstrip[r] = last;
-        rlen[r] = len;
+        const int len = (int)(row_off[r + 1] - row_off[r]);
+        if (seg == 0) rlen[r] = len;
+        if (before == 0 && first >= 0) lead[r] = first;                               // nothing in front of this segment's first residue
+        if (c1 == n_chunks && c0 < c1 && run == 0) lead[r] = len;                     // a row without residues
+        if (first >= 0) atomicMax(&rstrip[r], last);
     }
 }
 
@@ -252,11 +270,11 @@ int mp_load_msa(mp_ctx *c, const uint8_t *bytes, const int64_t *row_off, int32_t
     for (int r = 0; r <= n_rows; r++) off0[r] = row_off[r] - row_off[0];
     HIPCK(c, hipMemcpyAsync(d_bytes, bytes + row_off[0], (size_t)total, hipMemcpyHostToDevice, c->stream));
     HIPCK(c, hipMemcpyAsync(d_off, off0.data(), sizeof(int64_t) * (n_rows + 1), hipMemcpyHostToDevice, c->stream));
-    const FillSeg init[2] = {{c->ung, sizeof(uint32_t) * np * c->ustride, 0u}, {c->rlen, sizeof(int32_t) * np, 0u}};
-    if ((rc = fill_segments(c, init, 2))) return rc;
+    const FillSeg init[3] = {{c->ung, sizeof(uint32_t) * np * c->ustride, 0u}, {c->rlen, sizeof(int32_t) * np, 0u}, {c->rstrip, sizeof(int32_t) * np, 0u}};
+    if ((rc = fill_segments(c, init, 3))) return rc;
     hipLaunchKernelGGL(pack_kernel, dim3((unsigned)(c->n_pad / kBlock), (unsigned)((c->n_chunks + kPackChunks - 1) / kPackChunks)), dim3(kBlock), 0,
                        c->stream, d_bytes, d_off, n_rows, c->n_pad, c->n_chunks, c->planes);
-    hipLaunchKernelGGL(row_scan_kernel, dim3(c->n_pad / kBlock), dim3(kBlock), 0, c->stream, c->planes, d_off, n_rows,
+    hipLaunchKernelGGL(row_scan_kernel, dim3((unsigned)(c->n_pad / kBlock), (unsigned)kScanSegs), dim3(kBlock), 0, c->stream, c->planes, d_off, n_rows,
                        c->n_pad, c->n_chunks, c->cum, c->lead, c->rstrip, c->rlen, c->ung);
     hipLaunchKernelGGL(colplane_kernel, dim3((unsigned)((c->n_pad + kColBlock - 1) / kColBlock), (unsigned)c->n_chunks), dim3(kColBlock), 0, c->stream,
                        c->planes, c->n_pad, c->n_chunks, c->cols);
