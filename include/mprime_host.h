@@ -135,6 +135,14 @@ int mp_plan_write_side_files(const mp_plan *p, int32_t n_out, const int32_t *out
                              const uint32_t *dev_words, int64_t n_dev, const int32_t *labels, int32_t n_rows, int64_t n_exc,
                              const int32_t *x_window, const int64_t *x_row, const uint8_t *x_codes, const uint8_t *ids,
                              const int64_t *id_off, const char *noncov_path, const char *gap_path);
+/* The same files written in several calls, each for a run of consecutive output windows with the labels of just those windows (a
+ * 10^6-row alignment with 900 output windows would otherwise need 3.6 GB of labels at once): part bit 0 = this is the first run (the
+ * files are created), bit 1 = the last one (the objects are closed); part = 3 is mp_plan_write_side_files.  Same bytes. */
+int mp_plan_write_side_files_part(const mp_plan *p, int32_t n_out, const int32_t *out_window, const int64_t *out_pos,
+                                  const uint8_t *primer_codes, uint32_t strictF, uint32_t strictR, const int64_t *dev_off,
+                                  const uint32_t *dev_words, int64_t n_dev, const int32_t *labels, int32_t n_rows, int64_t n_exc,
+                                  const int32_t *x_window, const int64_t *x_row, const uint8_t *x_codes, const uint8_t *ids,
+                                  const int64_t *id_off, const char *noncov_path, const char *gap_path, int32_t part);
 
 /* Expansions of n k-mers of symbol codes (degenerate_seq, V20:368-380) in the reference's order; out_src[i] = index
  * of the k-mer expansion i comes from.  *n_out returns the number needed; MP_ERR_CAPACITY if cap is too small. */

@@ -493,15 +493,19 @@ class NN_degenerate(object):
             off, words = self._dev_entries
             ex_w, x_row, ex_codes = self._exc
             ids_bytes, ids_off = self._fasta.ids_raw()
-            if len(wins) * self.ctx.n_rows > (1 << 28):
-                # the writer takes one label per (output window, sequence): 4 bytes each on the host, and the files themselves
-                # list an id per uncovered sequence and window (the reference cannot write them at this depth either)
-                print("Warning: the two *_seq_id_json side files need {:.1f} GB of labels for {} windows x {} sequences; "
-                      "--no-json --bitsets writes the same sets as bitsets.".format(len(wins) * self.ctx.n_rows * 4 / 1e9, len(wins),
-                                                                                   self.ctx.n_rows), file=sys.stderr)
-            self.plan.write_side_files(wins, [int(r[0]) for r in rows_out], codes, self._sF, self._sR, off, words,
-                                       self.ctx.get_labels_raw(wins), ex_w, x_row, ex_codes, ids_bytes, ids_off,
-                                       self.outfile + ".non_coverage_seq_id_json", self.outfile + ".gap_seq_id_json")
+            # The writer takes one label per (output window, sequence) — 4 bytes each on the host, 3.6 GB for 900 windows of a 10^6-row
+            # alignment — so it is fed runs of windows whose labels stay under 256 MB (MP_JSON_BATCH: windows per run, for the tests).
+            n_out, n_rows = len(wins), max(int(self.ctx.n_rows), 1)
+            run = max(1, (1 << 26) // n_rows)
+            if os.environ.get("MP_JSON_BATCH"):
+                run = max(1, int(os.environ["MP_JSON_BATCH"]))
+            pos = [int(r[0]) for r in rows_out]
+            for a in range(0, max(n_out, 1), run):
+                b = min(n_out, a + run)
+                part = (1 if a == 0 else 0) | (2 if b >= n_out else 0)
+                self.plan.write_side_files(wins[a:b], pos[a:b], codes[a:b], self._sF, self._sR, off, words,
+                                           self.ctx.get_labels_raw(wins[a:b]), ex_w, x_row, ex_codes, ids_bytes, ids_off,
+                                           self.outfile + ".non_coverage_seq_id_json", self.outfile + ".gap_seq_id_json", part=part)
         elif self.write_json:
             with open(self.outfile + ".non_coverage_seq_id_json", "w") as fj:      # V20:1172-1173 json.dump(.., indent=4)
                 _dump_side_file(non_cov_out, fj, True)

@@ -949,15 +949,27 @@ extern "C" int mp_plan_write_side_files(const mp_plan *p, int32_t n_out, const i
                                         const uint32_t *dev_words, int64_t n_dev, const int32_t *labels, int32_t n_rows, int64_t n_exc,
                                         const int32_t *x_window, const int64_t *x_row, const uint8_t *x_codes, const uint8_t *ids,
                                         const int64_t *id_off, const char *noncov_path, const char *gap_path) {
+    return mp_plan_write_side_files_part(p, n_out, out_window, out_pos, primer_codes, strictF, strictR, dev_off, dev_words, n_dev, labels, n_rows,
+                                         n_exc, x_window, x_row, x_codes, ids, id_off, noncov_path, gap_path, 3);
+}
+
+extern "C" int mp_plan_write_side_files_part(const mp_plan *p, int32_t n_out, const int32_t *out_window, const int64_t *out_pos,
+                                             const uint8_t *primer_codes, uint32_t strictF, uint32_t strictR, const int64_t *dev_off,
+                                             const uint32_t *dev_words, int64_t n_dev, const int32_t *labels, int32_t n_rows, int64_t n_exc,
+                                             const int32_t *x_window, const int64_t *x_row, const uint8_t *x_codes, const uint8_t *ids,
+                                             const int64_t *id_off, const char *noncov_path, const char *gap_path, int32_t part) {
+    const bool first_part = part & 1, last_part = part & 2;
+    if (!first_part && n_out <= 0) return MP_ERR_ARG;                    // a continuation holds at least one window
+    if (first_part && !last_part && n_out <= 0) return MP_ERR_ARG;
     if (!p || n_out < 0 || n_rows < 0 || !noncov_path || !gap_path || (n_out && (!out_window || !out_pos || !primer_codes || !dev_off || !labels || !ids || !id_off)))
         return MP_ERR_ARG;
     if (!p->P.keep_tables) return MP_ERR_ARG;
     const int k = p->P.k, v = p->P.v;
     const uint32_t kmask = k == 32 ? 0xFFFFFFFFu : ((1u << k) - 1u);
     mp_plan *pm = const_cast<mp_plan *>(p);                              // the message buffer only
-    FILE *fn = fopen(noncov_path, "wb");
+    FILE *fn = fopen(noncov_path, first_part ? "wb" : "ab");
     if (!fn) return pfail(pm, MP_ERR_ARG, "%s: %s", noncov_path, strerror(errno));
-    FILE *fg = fopen(gap_path, "wb");
+    FILE *fg = fopen(gap_path, first_part ? "wb" : "ab");
     if (!fg) { const int e = errno; fclose(fn); return pfail(pm, MP_ERR_ARG, "%s: %s", gap_path, strerror(e)); }
     try {
     Out on(fn), og(fg);
@@ -985,8 +997,9 @@ extern "C" int mp_plan_write_side_files(const mp_plan *p, int32_t n_out, const i
         o.pad(ind);
         o.put("]");
     };
-    on.put(n_out ? "{\n" : "{}");
-    og.put(n_out ? "{\n" : "{}");
+    // a continuation starts with the separator the previous part left out
+    on.put(first_part ? (n_out ? "{\n" : "{}") : ",\n");
+    og.put(first_part ? (n_out ? "{\n" : "{}") : ",\n");
     for (int32_t oi = 0; oi < n_out; oi++) {
         const int32_t w = out_window[oi];
         if (w < 0 || (size_t)w >= p->win.size()) { fclose(fn); fclose(fg); return MP_ERR_ARG; }
@@ -1056,7 +1069,7 @@ extern "C" int mp_plan_write_side_files(const mp_plan *p, int32_t n_out, const i
             on.put(side == 0 ? ",\n" : "\n");
         }
         on.pad(4); on.put("]");
-        on.put(oi + 1 < n_out ? ",\n" : "\n}");
+        on.put(oi + 1 < n_out ? ",\n" : (last_part ? "\n}" : ""));
         // ---- gap_seq_id: expansions of the gap_sequence keys in insertion order (V20:698)
         og.pad(4); og.put("\""); og.put(num); og.put("\": ");
         std::vector<Key> gkeys;
@@ -1076,7 +1089,7 @@ extern "C" int mp_plan_write_side_files(const mp_plan *p, int32_t n_out, const i
             }
             og.put("\n"); og.pad(4); og.put("}");
         }
-        og.put(oi + 1 < n_out ? ",\n" : "\n}");
+        og.put(oi + 1 < n_out ? ",\n" : (last_part ? "\n}" : ""));
     }
     on.flush(); og.flush();
     } catch (const std::exception &) {                                  // bad_alloc of the id / row tables: no exception leaves the C ABI

@@ -44,6 +44,8 @@ HOST_SYMBOLS = [
     ("mp_plan_window_table", C.c_int, [_p, C.c_int32, C.c_int32, C.c_int64, _p, _p, _p, C.POINTER(C.c_int64)]),
     ("mp_plan_write_side_files", C.c_int, [_p, C.c_int32, _p, _p, _p, C.c_uint32, C.c_uint32, _p, _p, C.c_int64, _p, C.c_int32, C.c_int64,
                                            _p, _p, _p, _p, _p, C.c_char_p, C.c_char_p]),
+    ("mp_plan_write_side_files_part", C.c_int, [_p, C.c_int32, _p, _p, _p, C.c_uint32, C.c_uint32, _p, _p, C.c_int64, _p, C.c_int32, C.c_int64,
+                                                _p, _p, _p, _p, _p, C.c_char_p, C.c_char_p, C.c_int32]),
     ("mp_expand_kmer_words", C.c_int, [C.c_int32, C.c_int64, _p, C.c_int64, _p, _p, C.POINTER(C.c_int64)]),
     ("mp_expand_kmers", C.c_int, [C.c_int32, C.c_int64, _p, C.c_int64, _p, _p, C.POINTER(C.c_int64)]),
 ]
@@ -289,8 +291,9 @@ class Plan:
         return codes[:m], counts[:m], first[:m]
 
     def write_side_files(self, out_window, out_pos, primer_codes, strictF, strictR, dev_off, dev_words, labels, x_window, x_row,
-                         x_codes, ids_bytes, ids_off, noncov_path, gap_path):
-        """The two JSON side files of the core step, written natively (byte-identical to json.dump(..., indent=4))."""
+                         x_codes, ids_bytes, ids_off, noncov_path, gap_path, part=3):
+        """The two JSON side files of the core step, written natively (byte-identical to json.dump(..., indent=4)).  `part`: bit 0 =
+        first run of output windows (creates the files), bit 1 = last run (closes the objects); 3 = all of them in one call."""
         out_window = np.ascontiguousarray(out_window, dtype=np.int32)
         out_pos = np.ascontiguousarray(out_pos, dtype=np.int64)
         primer_codes = np.ascontiguousarray(primer_codes, dtype=np.uint8).reshape(len(out_window), self.k)
@@ -304,10 +307,10 @@ class Plan:
         x_codes = np.ascontiguousarray(x_codes, dtype=np.uint8)
         ids_bytes = np.ascontiguousarray(ids_bytes, dtype=np.uint8)
         ids_off = np.ascontiguousarray(ids_off, dtype=np.int64)
-        self._ck(self.d.mp_plan_write_side_files(self.h, len(out_window), _ptr(out_window), _ptr(out_pos), _ptr(primer_codes), int(strictF),
-                                                 int(strictR), _ptr(dev_off), _ptr(dev_words), n_dev, _ptr(labels), n_rows, len(x_window),
-                                                 _ptr(x_window), _ptr(x_row), _ptr(x_codes), _ptr(ids_bytes), _ptr(ids_off),
-                                                 os.fsencode(noncov_path), os.fsencode(gap_path)))
+        self._ck(self.d.mp_plan_write_side_files_part(self.h, len(out_window), _ptr(out_window), _ptr(out_pos), _ptr(primer_codes), int(strictF),
+                                                      int(strictR), _ptr(dev_off), _ptr(dev_words), n_dev, _ptr(labels), n_rows, len(x_window),
+                                                      _ptr(x_window), _ptr(x_row), _ptr(x_codes), _ptr(ids_bytes), _ptr(ids_off),
+                                                      os.fsencode(noncov_path), os.fsencode(gap_path), int(part)))
 
     def close(self):
         if getattr(self, "h", None):

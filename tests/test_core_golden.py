@@ -90,6 +90,19 @@ def test_native_json_writer_equals_python_writer(name, oracle_lib, tmp_path, mon
     assert _side_bytes(out_n) == _side_bytes(out_p)
 
 
+@pytest.mark.parametrize("name,run", [("syn_iupac", 1), ("syn_edge", 2), ("ivc_v2", 3), ("cluster0_v2", 7), ("msa1000_k18_d10", 1000)])
+def test_native_json_writer_in_runs_of_windows(name, run, oracle_lib, tmp_path, monkeypatch):
+    """mp_plan_write_side_files_part: the side files written a few output windows at a time (what a deep alignment needs, where
+    the labels of all output windows would be gigabytes) are the same bytes as written in one call."""
+    (tmp_path / "whole").mkdir()
+    (tmp_path / "runs").mkdir()
+    monkeypatch.setenv("MP_JSON_BATCH", "100000")
+    _, out_w = run_fixture(name, oracle_lib, tmp_path / "whole")
+    monkeypatch.setenv("MP_JSON_BATCH", str(run))
+    _, out_r = run_fixture(name, oracle_lib, tmp_path / "runs")
+    assert _side_bytes(out_w) == _side_bytes(out_r)
+
+
 def test_native_json_writer_escapes_ids_like_json_dump(oracle_lib, tmp_path, monkeypatch):
     _special_ids(oracle_lib, tmp_path, monkeypatch)
 
