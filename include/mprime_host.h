@@ -86,6 +86,12 @@ typedef struct mp_plan_params {
 int mp_plan_create(const mp_plan_params *params, int64_t n_entries, const int32_t *e_window, const uint32_t *e_words,
                    const int64_t *e_count, const int64_t *e_first, int64_t n_exc, const int32_t *x_window,
                    const int64_t *x_row, const uint8_t *x_codes, const int64_t *freq, const int64_t *nn, mp_plan **out);
+/* The same for the entries of ONE rank exactly as mp_get_unique returned them: window segments e_off [W+1] (entries of window w at
+ * [e_off[w], e_off[w+1])), e_words as above, 32-bit counts and LOCAL first rows (row_base is added) — no per-entry window array, no
+ * widening copies on the caller's side. */
+int mp_plan_create_segments(const mp_plan_params *params, const int64_t *e_off, const uint32_t *e_words, const int32_t *e_count,
+                            const int32_t *e_first, int64_t row_base, int64_t n_exc, const int32_t *x_window, const int64_t *x_row,
+                            const uint8_t *x_codes, const int64_t *freq, const int64_t *nn, mp_plan **out);
 void mp_plan_destroy(mp_plan *p);
 const char *mp_plan_error(const mp_plan *p);
 

@@ -205,10 +205,21 @@ class NN_degenerate(object):
         off, words, count, first = self.ctx.window_unique(want_labels=self.write_json, sort=self.write_json and not self._native_json)
         self.stats["unique_s"] = time.time() - t0
         t0 = time.time()
-        e_window = np.repeat(np.arange(W, dtype=np.int32), np.diff(off))
-        e_first = first.astype(np.int64) + row_base
         x_row = ex_r.astype(np.int64) + row_base
         self._dev_entries = (off, words)
+        if self.comm is None:
+            # one rank: the read-back goes to the planning stage as it stands (window segments, 32-bit counts and first rows)
+            self._exc = (ex_w, x_row, ex_codes)
+            self._win_split = False
+            plan = host.Plan(k=k, v=v, n_windows=W, total_sequences=self.total_sequence_number, coverage=self.coverage,
+                             entropy_threshold=self.entropy_threshold, max_degeneracy=self.score_of_dege_bases,
+                             max_dege_positions=self.number_of_dege_bases, e_off=off, e_words=words, e_count=count, e_first=first,
+                             row_base=row_base, x_window=ex_w, x_row=x_row, x_codes=ex_codes, freq=self._freq, nn=self._nn,
+                             keep_tables=keep)
+            self.stats["plan_s"] = time.time() - t0
+            return plan
+        e_window = np.repeat(np.arange(W, dtype=np.int32), np.diff(off))
+        e_first = first.astype(np.int64) + row_base
         if self.comm is not None:
             e_window, words, count, e_first = self.comm.gather_entries(e_window, words, count, e_first)
             ex_w, x_row, ex_codes = self.comm.gather_exceptions(ex_w, x_row, ex_codes, k)

@@ -521,13 +521,23 @@ const char *mp_plan_error(const mp_plan *p) { return p ? p->err : "mp_plan_creat
 void mp_plan_destroy(mp_plan *p) { delete p; }
 
 // the body of mp_plan_create; allocation failures (here and in the worker threads) leave as MP_ERR_NOMEM, never as exceptions
-static int plan_create_body(mp_plan *p, int64_t n_entries, const int32_t *e_window, const uint32_t *e_words, const int64_t *e_count,
-                            const int64_t *e_first, int64_t n_exc, const int32_t *x_window, const int64_t *x_row, const uint8_t *x_codes,
+// entries either as (e_window, 64-bit counts and global first rows) in any order, or — one rank's read-back as it stands — as window
+// segments e_off [W+1] with 32-bit counts and local first rows (+ row_base)
+struct EntryInput {
+    int64_t n;
+    const int32_t *window;
+    const int64_t *off;
+    const uint32_t *words;
+    const int64_t *count64, *first64;
+    const int32_t *count32, *first32;
+    int64_t row_base;
+    int64_t count(int64_t i) const { return count64 ? count64[i] : (int64_t)count32[i]; }
+    int64_t first(int64_t i) const { return first64 ? first64[i] : (int64_t)first32[i] + row_base; }
+};
+static int plan_create_body(mp_plan *p, const EntryInput &E, int64_t n_exc, const int32_t *x_window, const int64_t *x_row, const uint8_t *x_codes,
                             const int64_t *freq, const int64_t *nn);
-
-int mp_plan_create(const mp_plan_params *params, int64_t n_entries, const int32_t *e_window, const uint32_t *e_words,
-                   const int64_t *e_count, const int64_t *e_first, int64_t n_exc, const int32_t *x_window,
-                   const int64_t *x_row, const uint8_t *x_codes, const int64_t *freq, const int64_t *nn, mp_plan **out) {
+static int plan_create_guarded(const mp_plan_params *params, const EntryInput &E, int64_t n_exc, const int32_t *x_window, const int64_t *x_row,
+                               const uint8_t *x_codes, const int64_t *freq, const int64_t *nn, mp_plan **out) {
     if (!out) return MP_ERR_ARG;
     *out = nullptr;
     if (!params || !freq || !nn) return MP_ERR_ARG;
@@ -536,7 +546,7 @@ int mp_plan_create(const mp_plan_params *params, int64_t n_entries, const int32_
     *out = p;                                  // returned even on failure so that the caller can read the message
     p->P = *params;
     try {
-        return plan_create_body(p, n_entries, e_window, e_words, e_count, e_first, n_exc, x_window, x_row, x_codes, freq, nn);
+        return plan_create_body(p, E, n_exc, x_window, x_row, x_codes, freq, nn);
     } catch (const std::bad_alloc &) {
         return pfail(p, MP_ERR_NOMEM, "mp_plan_create: out of memory");
     } catch (const std::exception &e) {
@@ -544,30 +554,59 @@ int mp_plan_create(const mp_plan_params *params, int64_t n_entries, const int32_
     }
 }
 
-static int plan_create_body(mp_plan *p, int64_t n_entries, const int32_t *e_window, const uint32_t *e_words, const int64_t *e_count,
-                            const int64_t *e_first, int64_t n_exc, const int32_t *x_window, const int64_t *x_row, const uint8_t *x_codes,
+int mp_plan_create(const mp_plan_params *params, int64_t n_entries, const int32_t *e_window, const uint32_t *e_words,
+                   const int64_t *e_count, const int64_t *e_first, int64_t n_exc, const int32_t *x_window,
+                   const int64_t *x_row, const uint8_t *x_codes, const int64_t *freq, const int64_t *nn, mp_plan **out) {
+    if (n_entries < 0 || (n_entries && (!e_window || !e_words || !e_count || !e_first))) return MP_ERR_ARG;
+    const EntryInput E{n_entries, e_window, nullptr, e_words, e_count, e_first, nullptr, nullptr, 0};
+    return plan_create_guarded(params, E, n_exc, x_window, x_row, x_codes, freq, nn, out);
+}
+
+int mp_plan_create_segments(const mp_plan_params *params, const int64_t *e_off, const uint32_t *e_words, const int32_t *e_count,
+                            const int32_t *e_first, int64_t row_base, int64_t n_exc, const int32_t *x_window, const int64_t *x_row,
+                            const uint8_t *x_codes, const int64_t *freq, const int64_t *nn, mp_plan **out) {
+    if (!params || !e_off || params->n_windows < 0) return MP_ERR_ARG;
+    const int64_t n = e_off[params->n_windows];
+    if (n < 0 || (n && (!e_words || !e_count || !e_first))) return MP_ERR_ARG;
+    const EntryInput E{n, nullptr, e_off, e_words, nullptr, nullptr, e_count, e_first, row_base};
+    return plan_create_guarded(params, E, n_exc, x_window, x_row, x_codes, freq, nn, out);
+}
+
+static int plan_create_body(mp_plan *p, const EntryInput &E, int64_t n_exc, const int32_t *x_window, const int64_t *x_row, const uint8_t *x_codes,
                             const int64_t *freq, const int64_t *nn) {
     const mp_plan_params &P = p->P;
     const int k = P.k, W = P.n_windows;
+    const int64_t n_entries = E.n;
+    const int32_t *e_window = E.window;
+    const uint32_t *e_words = E.words;
     if (k < 2 || k > 32 || W < 0 || P.v < 0 || P.total_sequences <= 0) return pfail(p, MP_ERR_ARG, "mp_plan_create: bad parameters");
-    if (n_entries < 0 || n_exc < 0 || (n_entries && (!e_window || !e_words || !e_count || !e_first)) ||
-        (n_exc && (!x_window || !x_row || !x_codes)))
-        return pfail(p, MP_ERR_ARG, "mp_plan_create: bad arguments");
+    if (n_exc < 0 || (n_exc && (!x_window || !x_row || !x_codes))) return pfail(p, MP_ERR_ARG, "mp_plan_create: bad arguments");
     // counting sort of entries and exceptions by window
     std::vector<int64_t> eoff((size_t)W + 1, 0), xoff((size_t)W + 1, 0);
-    for (int64_t i = 0; i < n_entries; i++) {
-        if (e_window[i] < 0 || e_window[i] >= W) return pfail(p, MP_ERR_ARG, "entry %lld: window %d out of range", (long long)i, e_window[i]);
-        eoff[(size_t)e_window[i] + 1]++;
+    bool e_sorted = true;                      // one rank's histogram read-back arrives window by window: no scatter needed then
+    if (E.off) {
+        for (int w = 0; w <= W; w++) {
+            if (E.off[w] < 0 || (w && E.off[w] < E.off[w - 1])) return pfail(p, MP_ERR_ARG, "window offsets must not decrease");
+            eoff[(size_t)w] = E.off[w];
+        }
+        if (E.off[0] != 0) return pfail(p, MP_ERR_ARG, "window offsets must start at 0");
+    } else {
+        for (int64_t i = 0; i < n_entries; i++) {
+            if (e_window[i] < 0 || e_window[i] >= W) return pfail(p, MP_ERR_ARG, "entry %lld: window %d out of range", (long long)i, e_window[i]);
+            eoff[(size_t)e_window[i] + 1]++;
+            e_sorted &= i == 0 || e_window[i - 1] <= e_window[i];
+        }
     }
     for (int64_t i = 0; i < n_exc; i++) {
         if (x_window[i] < 0 || x_window[i] >= W) return pfail(p, MP_ERR_ARG, "exception %lld: window %d out of range", (long long)i, x_window[i]);
         xoff[(size_t)x_window[i] + 1]++;
     }
-    for (int w = 0; w < W; w++) { eoff[(size_t)w + 1] += eoff[(size_t)w]; xoff[(size_t)w + 1] += xoff[(size_t)w]; }
-    std::vector<int64_t> eidx((size_t)n_entries), xidx((size_t)n_exc);
+    for (int w = 0; w < W; w++) { if (!E.off) eoff[(size_t)w + 1] += eoff[(size_t)w]; xoff[(size_t)w + 1] += xoff[(size_t)w]; }
+    std::vector<int64_t> eidx(e_sorted ? 0 : (size_t)n_entries), xidx((size_t)n_exc);
     {
         std::vector<int64_t> cur(eoff.begin(), eoff.end() - 1);
-        for (int64_t i = 0; i < n_entries; i++) eidx[(size_t)cur[(size_t)e_window[i]]++] = i;
+        if (!e_sorted)
+            for (int64_t i = 0; i < n_entries; i++) eidx[(size_t)cur[(size_t)e_window[i]]++] = i;
         std::vector<int64_t> cux(xoff.begin(), xoff.end() - 1);
         for (int64_t i = 0; i < n_exc; i++) xidx[(size_t)cux[(size_t)x_window[i]]++] = i;
     }
@@ -583,12 +622,12 @@ static int plan_create_body(mp_plan *p, int64_t n_entries, const int32_t *e_wind
             if (w >= W || failed.load()) break;
             sights.clear();
             for (int64_t t = eoff[(size_t)w]; t < eoff[(size_t)w + 1]; t++) {
-                const int64_t i = eidx[(size_t)t];
+                const int64_t i = e_sorted ? t : eidx[(size_t)t];
                 const uint32_t b0 = e_words[i], b1 = e_words[(size_t)n_entries + i], g = e_words[2 * (size_t)n_entries + i] & kmask;
                 Sight s;
                 s.key = key_from_words(b0, b1, g, kmask);
-                s.count = e_count[i];
-                s.row = e_first[i];
+                s.count = E.count(i);
+                s.row = E.first(i);
                 s.sub = 0;
                 s.ngap = __builtin_popcount(g);
                 sights.push_back(s);

@@ -32,6 +32,7 @@ HOST_SYMBOLS = [
     ("mp_fasta_ids", C.c_int, [_p, _p, _p]),
     ("mp_file_count_newlines", C.c_int, [C.c_char_p, C.c_int32, C.POINTER(C.c_int64)]),
     ("mp_plan_create", C.c_int, [C.POINTER(PlanParams), C.c_int64, _p, _p, _p, _p, C.c_int64, _p, _p, _p, _p, _p, C.POINTER(_p)]),
+    ("mp_plan_create_segments", C.c_int, [C.POINTER(PlanParams), _p, _p, _p, _p, C.c_int64, C.c_int64, _p, _p, _p, _p, _p, C.POINTER(_p)]),
     ("mp_plan_destroy", None, [_p]),
     ("mp_plan_error", C.c_char_p, [_p]),
     ("mp_plan_windows", C.c_int, [_p, _p, _p, _p, _p, _p]),
@@ -193,16 +194,29 @@ class Plan:
     """Per-window planning of one alignment (mp_plan_*)."""
 
     def __init__(self, *, k, v, n_windows, total_sequences, coverage, entropy_threshold, max_degeneracy, max_dege_positions,
-                 e_window, e_words, e_count, e_first, x_window, x_row, x_codes, freq, nn, keep_tables=False, n_threads=0):
+                 e_window=None, e_words, e_count, e_first, x_window, x_row, x_codes, freq, nn, keep_tables=False, n_threads=0,
+                 e_off=None, row_base=0):
+        """Entries either with a window per entry (`e_window`, any order: several ranks' tables concatenated; counts and GLOBAL first
+        rows as int64) or as ONE rank's read-back as it stands: `e_off` [W+1] window segments, int32 counts and LOCAL first rows plus
+        `row_base` (mp_plan_create_segments: no per-entry window array, no widening copies)."""
         self.d = dll()
         self.k, self.W = int(k), int(n_windows)
         P = PlanParams(int(k), int(v), int(n_windows), int(n_threads), int(total_sequences), float(coverage), float(entropy_threshold),
                        float(max_degeneracy), int(max_dege_positions), int(bool(keep_tables)))
-        e_window = np.ascontiguousarray(e_window, dtype=np.int32)
-        n = len(e_window)
+        segments = e_off is not None
+        if segments:
+            e_off = np.ascontiguousarray(e_off, dtype=np.int64)
+            assert len(e_off) == self.W + 1
+            n = int(e_off[-1])
+            e_count = np.ascontiguousarray(e_count, dtype=np.int32)
+            e_first = np.ascontiguousarray(e_first, dtype=np.int32)
+        else:
+            e_window = np.ascontiguousarray(e_window, dtype=np.int32)
+            n = len(e_window)
+            e_count = np.ascontiguousarray(e_count, dtype=np.int64)
+            e_first = np.ascontiguousarray(e_first, dtype=np.int64)
         e_words = np.ascontiguousarray(e_words, dtype=np.uint32).reshape(3, n)
-        e_count = np.ascontiguousarray(e_count, dtype=np.int64)
-        e_first = np.ascontiguousarray(e_first, dtype=np.int64)
+        assert len(e_count) == n and len(e_first) == n
         x_window = np.ascontiguousarray(x_window, dtype=np.int32)
         x_row = np.ascontiguousarray(x_row, dtype=np.int64)
         x_codes = np.ascontiguousarray(x_codes, dtype=np.uint8).reshape(len(x_window), self.k)
@@ -210,8 +224,12 @@ class Plan:
         nn = np.ascontiguousarray(nn, dtype=np.int64)
         assert freq.shape == (self.W, 4, self.k) and nn.shape == (self.W, self.k - 1, 4, 4)
         h = _p()
-        rc = self.d.mp_plan_create(C.byref(P), n, _ptr(e_window), _ptr(e_words), _ptr(e_count), _ptr(e_first), len(x_window),
-                                   _ptr(x_window), _ptr(x_row), _ptr(x_codes), _ptr(freq), _ptr(nn), C.byref(h))
+        if segments:
+            rc = self.d.mp_plan_create_segments(C.byref(P), _ptr(e_off), _ptr(e_words), _ptr(e_count), _ptr(e_first), int(row_base), len(x_window),
+                                                _ptr(x_window), _ptr(x_row), _ptr(x_codes), _ptr(freq), _ptr(nn), C.byref(h))
+        else:
+            rc = self.d.mp_plan_create(C.byref(P), n, _ptr(e_window), _ptr(e_words), _ptr(e_count), _ptr(e_first), len(x_window),
+                                       _ptr(x_window), _ptr(x_row), _ptr(x_codes), _ptr(freq), _ptr(nn), C.byref(h))
         self.h = h
         if rc != 0:
             msg = self.d.mp_plan_error(h).decode() if h else "mp_plan_create failed"
