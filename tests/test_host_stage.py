@@ -166,6 +166,57 @@ def test_tables_equal_row_by_row_replay(seed):
     assert cn[0] == len(cover_rows) and gn[0] == len(gap_rows)
 
 
+@pytest.mark.parametrize("seed", range(8))
+def test_segment_form_of_plan_create_equals_the_general_form(seed):
+    """mp_plan_create_segments (one rank's read-back as it stands: window offsets, 32-bit counts, LOCAL first rows + row_base) builds the
+    plan mp_plan_create builds from the same entries given with a window per entry, 64-bit counts and global first rows — in window
+    order and shuffled (the counting-sort path)."""
+    rng = np.random.default_rng(100 + seed)
+    k, v, W = 8, 1, int(rng.integers(1, 12))
+    row_base = int(rng.integers(0, 5000))
+    per = rng.integers(0, 30, size=W)
+    off = np.zeros(W + 1, np.int64)
+    np.cumsum(per, out=off[1:])
+    n = int(off[-1])
+    root = rng.integers(0, 4, size=(W, k))
+    chars = np.empty((n, k), np.uint8)
+    for w in range(W):
+        seen = set()
+        for i in range(off[w], off[w + 1]):
+            while True:                                                    # distinct k-mers inside a window, close to its root
+                s = root[w].copy()
+                m = rng.random(k) < 0.25
+                s[m] = rng.integers(0, 5, size=int(m.sum()))
+                if tuple(s) not in seen:
+                    seen.add(tuple(s))
+                    break
+            chars[i] = np.frombuffer(b"ACGT-", np.uint8)[s]
+    words = iupac.words_of_kmers(chars).T.copy() if n else np.zeros((3, 0), np.uint32)
+    count = rng.integers(1, 40, size=n).astype(np.int32)
+    first = rng.permutation(n).astype(np.int32)                      # distinct first rows: ties would leave the insertion order open
+    e_window = np.repeat(np.arange(W, dtype=np.int32), per)
+    freq = rng.integers(1, 50, size=(W, 4, k)).astype(np.int64)
+    nn = rng.integers(1, 50, size=(W, k - 1, 4, 4)).astype(np.int64)
+    common = dict(k=k, v=v, n_windows=W, total_sequences=max(n, 1) + row_base, coverage=0.1, entropy_threshold=100.0, max_degeneracy=16,
+                  max_dege_positions=3, x_window=np.zeros(0, np.int32), x_row=np.zeros(0, np.int64), x_codes=np.zeros((0, k), np.uint8),
+                  freq=freq, nn=nn, keep_tables=True)
+    seg = host.Plan(e_off=off, e_words=words, e_count=count, e_first=first, row_base=row_base, **common)
+    order = rng.permutation(n)
+    plans = [host.Plan(e_window=e_window, e_words=words, e_count=count.astype(np.int64), e_first=first.astype(np.int64) + row_base, **common),
+             host.Plan(e_window=e_window[order], e_words=np.ascontiguousarray(words[:, order]), e_count=count[order].astype(np.int64),
+                       e_first=first[order].astype(np.int64) + row_base, **common)]
+    for gen in plans:
+        for a, b in zip(seg.windows(), gen.windows()):
+            assert np.array_equal(np.asarray(a), np.asarray(b), equal_nan=True)
+        assert (seg.n_planned, seg.n_candidates) == (gen.n_planned, gen.n_candidates)
+        for a, b in zip(seg.candidates(), gen.candidates()):
+            assert np.array_equal(a, b)
+        for w in range(W):
+            for which in (0, 1):
+                for a, b in zip(seg.window_table(w, which), gen.window_table(w, which)):
+                    assert np.array_equal(a, b)
+
+
 def test_expand_kmers_is_itertools_product_order():
     rng = np.random.default_rng(3)
     syms = "ACGTRYMKSWHBVDN-"
