@@ -29,7 +29,29 @@ HEADERS = ["Primer_ID", "Primer seq", "Primer end", "Delta G", "Primer end lengt
 
 def loss_table(threshold: float) -> np.ndarray:
     """loss_hit[l][GC][d2] = Penalty_points(l, GC, 0, d2) >= threshold  (FD:90-92, 207)."""
-    # 2**l * 2**GC is the integer 2**(l+GC): the value depends on (l + GC, d2) only
+    # 2**l * 2**GC is the integer 2**(l+GC): the value depends on (l + GC, d2) only, and it does not fall when l + GC grows — per d2
+    # the first sum that passes is found by bisection with the reference's own expression (512 calls instead of 8256: this table is
+    # built once per process and was a fifth of a 40 ms core step; tests/test_dimer.py compares it with the full evaluation)
+    n_sum = 2 * MAX_LEN + 1
+    first = np.empty(64, np.int64)
+    for d2 in range(64):
+        lo, hi = 0, n_sum                      # first sum in [lo, hi] whose points reach the threshold (hi = n_sum: none)
+        while lo < hi:
+            mid = (lo + hi) // 2
+            if thermo.penalty_points(mid, 0, 0, d2) >= threshold:
+                hi = mid
+            else:
+                lo = mid + 1
+        first[d2] = lo
+    by_sum = (np.arange(n_sum)[:, None] >= first[None, :]).astype(np.uint8)
+    l, gc = np.arange(MAX_LEN + 1)[:, None], np.arange(MAX_LEN + 1)[None, :]
+    t = by_sum[l + gc]                                                     # [l][gc][d2]
+    t[(gc > l) | (l == 0)] = 0                                             # an end of l bases holds at most l G/C; there is no end of length 0
+    return np.ascontiguousarray(t)
+
+
+def loss_table_by_evaluation(threshold: float) -> np.ndarray:
+    """The same table, every entry from the reference's expression (the checker of loss_table's bisection)."""
     by_sum = np.array([[thermo.penalty_points(sm, 0, 0, d2) >= threshold for d2 in range(64)] for sm in range(2 * MAX_LEN + 1)],
                       np.uint8)
     t = np.zeros((MAX_LEN + 1, MAX_LEN + 1, 64), np.uint8)

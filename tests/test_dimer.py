@@ -196,3 +196,11 @@ def test_primers_of_up_to_64_bases_hip_equals_oracle(hip_lib, oracle_lib, seed, 
     args = (codes, off, pairs, dimer.cached_loss_table(3.6), dimer.dg_params(), dimer.dg_limit())
     got, want = hc.dimer_pairs(*args), oc.dimer_pairs(*args)
     assert want.any() and got.tolist() == want.tolist()
+
+
+@pytest.mark.parametrize("threshold", [3.0, 2.0, 4.5, 0.0, -3.0, 10.0, 60.0, 3.0000000001, 17.76])
+def test_loss_table_bisection_equals_entry_by_entry_evaluation(threshold):
+    """dimer.loss_table finds, per d2, the first l + GC that passes by bisection (the points do not fall with l + GC); the table is the
+    one every entry of which comes from the reference's Penalty_points expression (FD:90-92)."""
+    from multiprime_amd import dimer
+    assert np.array_equal(dimer.loss_table(threshold), dimer.loss_table_by_evaluation(threshold))
