@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
-"""Benchmark of the hot path: batched candidate x sequence coverage evaluation (mp_eval_launch -> eval_chain_kernel) on the
-synthetic alignment of SURVEY §8d input 4 / BASELINE.json configs[3]: 1M x 1 kb sequences sharded over 8 GPUs.
+"""Benchmark of the hot path: batched candidate x sequence coverage evaluation (mp_eval_launch) on the synthetic alignment of
+SURVEY §8d input 4 / BASELINE.json configs[3]: 1M x 1 kb sequences, sharded over the GPUs of the job.
 
 One step = one pass of the evaluation over every window with C candidates per window, plus (N > 1) the RCCL all-reduce of the
 per-candidate coverage counters.  Inputs are resident in HBM (planes built once, untimed).
@@ -8,31 +8,33 @@ per-candidate coverage counters.  Inputs are resident in HBM (planes built once,
   python bench.py --gpus 1 --steps 20 --warmup 3
   python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
 
-The headline (`value`) is WEAK scaling: every GPU holds the 131072 x 1000 shard it would hold in the 8-GPU job.  That shard
-(81 MB of planes) lives in the 256 MiB Infinity Cache, so HBM cannot bind it; the line therefore also carries
+The workload is config 4 at every N: 1 048 576 x 1000 rows in all, 1 048 576 / N per GPU (`scaling: "strong"`).  At N = 1 the
+headline (`value`, `ms_per_step`, `config.workload`, `roofline`, `cpu_baseline`) is config 4 itself on one GPU — the one size
+where HBM can bind (planes 0.5 GB > Infinity Cache).  `--rows R` fixes the rows per GPU instead (weak scaling, `scaling: "weak"`).
+At N > 1 the headline step does ONE collective per step, as the drop-in pipeline does per alignment; the bucketed, overlapped
+form (`--bucket` steps per collective, dist.StepBuckets) is the side key `ms_per_step_bucketed`.
 
-  full_config   config 4 ITSELF on ONE GPU (1 048 576 x 1000, planes 0.6 GB > Infinity Cache: the only size where HBM matters):
-                its own value / ms_per_step / roofline / parity check, built and timed in this same run (rank 0; skip with
-                --no-full).  At N > 1 `strong_scaling` compares the N-GPU step with it: N GPUs x 131072 rows = the same job.
-  roofline      every fraction is <= 1 by construction:
+  weak_shard    N = 1 only: the 131072 x 1000 shard one GPU holds in the 8-GPU job (81 MB of planes: lives in the Infinity Cache),
+                timed the same way in this same run (skip with --no-shard) — what the per-GPU kernel time of an N = 8 run should be.
+  roofline      `frac` = the HBM fraction: measured fabric/HBM bytes per launch (`traffic`, rocprofv3 counters) / kernel time /
+                8 TB/s.  Beside it, every fraction that can bind (all <= 1 by construction):
                   valu_frac = VALU wave-instructions per launch / (kernel time x SIMDs x measured issue rate)
-                  l2_frac   = bytes requested from L2 per launch / (kernel time x measured L2 read bandwidth).  Round 3 showed what
-                              that ceiling is: 31.4 TB/s = 256 CUs x 64 B/clk, the rate at which a CU's vector memory path hands
-                              data to registers (L1 hits do not go faster: profiles/r03_eval_limits.txt) — a CU-side limit
-                  hbm_frac  = measured fabric/HBM bytes per launch (`traffic`) / (kernel time x 8 TB/s)
+                  l2_frac   = bytes returned to registers per launch / (kernel time x 31.4 TB/s = 256 CUs x 64 B/clk)
+                  hbm_frac  = frac
                 `bound` names the largest.  Kernel time is measured live (HIP events on the library's stream); instruction /
                 request / byte counts come from separate rocprofv3 --pmc passes of this same command (tools/collect_counters.py
-                -> profiles/r03_counters.json).  An entry is used only if it was collected for this exact configuration AND
+                -> profiles/r04_counters.json).  An entry is used only if it was collected for this exact configuration AND
                 this exact kernel source (`source_hash` = sha256 of the evaluation kernels' sources): after a kernel change the
                 fractions are dropped (`counters_stale`), never silently reused.  SURVEY §8d's algorithmic figure (3k/8 bytes
                 per evaluation / kernel time / 8 TB/s) is kept as `algorithmic_frac`, labelled: it exceeds 1 (8 nested
                 candidates and 18 overlapping windows share every loaded plane word) and is NOT a roofline fraction.
-  variants      the same kernel library on less friendly candidate sets: unrelated candidates (no nesting), the symbol-table
-                kernel forced on the nested set, C = 1, and one cold launch (caches flushed, no warm-up).
-  cpu_baseline  the plain-C oracle on EVERY host core (threads over row blocks of the whole shard) and on one core (bounded
+  variants      (weak_shard) the same kernel library on less friendly candidate sets: unrelated candidates (no nesting), the
+                symbol-table kernel forced on the nested set, C = 1, and one cold launch (caches flushed, no warm-up).
+  cpu_baseline  the plain-C oracle on EVERY host core (threads over row blocks of the whole workload) and on one core (bounded
                 sample); its counters are compared with the GPU's candidate by candidate — `parity_checked` true, or the run
                 exits non-zero.  `python_reference`: the reference's own algorithm (dict of k-mers, numpy score-table
                 differences, V20:229-233 / 1103-1130) restated in Python, one core, bounded sample, checked against the oracle.
+  comm          N > 1: what the communicator reports (`rccl_ranks_seen`, the librccl in use), per-rank step time min / max.
 """
 import argparse
 import hashlib
@@ -51,9 +53,10 @@ sys.path.insert(0, REPO)
 HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec (MI355X_MICROARCH.md); ~6300 GB/s achievable
 N_SIMD = 1024                  # 256 CUs x 4 SIMDs
 FULL_ROWS = 1048576            # BASELINE.json configs[3]: 1M sequences
+SHARD_ROWS = 131072            # what one GPU holds of it in the 8-GPU job
 # measured ceilings (tools/ubench.hip on the same GPU pool, profiles/r02_ubench.json); used when that file is absent
 DEFAULT_CEILINGS = {"valu_wave_instr_per_s_per_simd": 8.5e8, "l2_read_GBs": 31559.0, "source": "built-in defaults (profiles/r02_ubench.json missing)"}
-COUNTER_FILES = ("r03_counters.json",)
+COUNTER_FILES = ("r04_counters.json", "r03_counters.json")
 # sources of the timed kernel (eval_chain_kernel and what it includes): the key of a counter entry
 KERNEL_SOURCES = ("eval.hip", "evalprog.hip", "bitslice.hpp", "common.hpp", "winwords.hpp", "evaltile.hpp", "evalprog.hpp")
 PROG_FROM_ROWS = 393216      # eval.hip (mp_eval_upload): from this many (padded) rows up the program-driven kernel walks the chains
@@ -244,16 +247,10 @@ def roofline_block(w, per_launch_ms, samples, kern_n, every, mode):
             fr["hbm"] = traffic / kern_s / 1e9 / HBM_PEAK_GBS
     known = {key: val for key, val in fr.items() if val is not None}
     bound = max(known, key=known.get) if known else None
-    if bound == "valu":
-        achieved, peak, unit = pmc["valu_insts"] / kern_s / 1e9, N_SIMD * ceil["valu_wave_instr_per_s_per_simd"] / 1e9, "G wave-instr/s"
-    elif bound == "l2":
-        achieved, peak, unit = pmc["l2_read_bytes"] / kern_s / 1e9, ceil["l2_read_GBs"], "GB/s"
-    elif bound == "hbm":
-        achieved, peak, unit = traffic / kern_s / 1e9, HBM_PEAK_GBS, "GB/s"
-    else:
-        achieved, peak, unit = None, None, None
-    return {"bound": bound, "achieved": achieved, "peak": peak, "unit": unit,
-            "frac": known.get(bound) if bound else None, "traffic": traffic,
+    # `frac` is the HBM fraction (north_star's bar): counter bytes / kernel time / 8 TB/s; `bound` names the largest of the three
+    achieved = traffic / kern_s / 1e9 if traffic is not None else None
+    return {"bound": bound, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "frac": fr["hbm"], "traffic": traffic,
             "valu_frac": fr["valu"], "l2_frac": fr["l2"], "hbm_frac": fr["hbm"],
             "compulsory_bytes": w.n_rows * w.L * 3 / 8.0, "compulsory_note": "SURVEY §8d (ii): packed planes read once, N L 3/8 bytes",
             "algorithmic_frac": alg_bytes / kern_s / 1e9 / HBM_PEAK_GBS,
@@ -275,18 +272,19 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=40)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--rows", type=int, default=131072, help="sequences per GPU (weak scaling)")
+    ap.add_argument("--rows", type=int, default=0, help="sequences per GPU (weak scaling); 0 = config 4 split over the GPUs: 1048576 / N each (strong scaling)")
     ap.add_argument("--cols", type=int, default=1000)
     ap.add_argument("--k", type=int, default=18)
     ap.add_argument("--v", type=int, default=1)
     ap.add_argument("--cands", type=int, default=8, help="candidates per window")
     ap.add_argument("--seed", type=int, default=20250303)
-    ap.add_argument("--cpu-rows", type=int, default=0, help="rows of the shard the CPU oracle evaluates (0 = the whole shard)")
+    ap.add_argument("--cpu-rows", type=int, default=0, help="rows of the workload the CPU oracle evaluates (0 = all of them)")
     ap.add_argument("--cpu-threads", type=int, default=0, help="host threads of the all-core CPU leg (0 = every core)")
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--no-variants", action="store_true")
-    ap.add_argument("--no-full", action="store_true", help="skip the full_config block (config 4 itself, 1048576 rows on one GPU)")
-    ap.add_argument("--bucket", type=int, default=4, help="steps whose counters share one all-reduce (N > 1)")
+    ap.add_argument("--no-shard", "--no-full", dest="no_shard", action="store_true",
+                    help="N = 1: skip the weak_shard block (the 131072-row shard of the 8-GPU job)")
+    ap.add_argument("--bucket", type=int, default=4, help="steps per collective of the bucketed side measurement (N > 1)")
     a = ap.parse_args()
 
     import torch
@@ -300,6 +298,10 @@ def main():
         raise SystemExit(f"--gpus {a.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {a.gpus}")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the product has no CPU path")
+    strong = a.rows == 0
+    if strong and FULL_ROWS % world:
+        raise SystemExit(f"config 4 ({FULL_ROWS} rows) does not split evenly over {world} GPUs: pass --rows")
+    rows_per_gpu = FULL_ROWS // world if strong else a.rows
     # MP_BENCH_BACKEND=gloo (testing only): several ranks on whatever GPUs the box has, collectives through the host —
     # exercises the N > 1 control flow of this file on a 1-GPU box; RCCL itself refuses two ranks on one device
     backend = os.environ.get("MP_BENCH_BACKEND", "nccl")
@@ -319,13 +321,13 @@ def main():
     # roofline); a pair idles the stream for ~6 us, so the timed region samples one launch in four
     every = int(os.environ.setdefault("MP_EVAL_TIMING_EVERY", "4"))
     lib = Library()                                   # the HIP library or an error: no fallback
-    w = Workload(lib, local, torch, rank * a.rows, a.rows, a)
+    w = Workload(lib, local, torch, rank * rows_per_gpu, rows_per_gpu, a)
     ctx, n_cand = w.ctx, w.n_cand
 
-    # N > 1: the counters of every step are all-reduced over RCCL, bucketed and overlapped (dist.StepBuckets):
-    # `--bucket` consecutive steps write into one [bucket][n_cand][3] buffer that is reduced with ONE collective
-    # (xGMI rings are latency-bound at 180 KB per step), on RCCL's stream, while the next bucket's steps evaluate
-    # into the other buffer.  Every step's counters are reduced; all reductions complete inside the timed region.
+    # N > 1: the counters of every step are all-reduced over RCCL inside the timed region.  Headline: ONE collective per step
+    # (what the drop-in pipeline does per alignment).  Side key: `--bucket` consecutive steps write into one [bucket][n_cand][3]
+    # buffer that is reduced with one collective on RCCL's stream while the next bucket's steps evaluate into the other buffer
+    # (dist.StepBuckets; xGMI rings are latency-bound at 180 KB per step).
     from multiprime_amd.dist import StepBuckets
 
     def timed_region(wl, bucket, n_world):
@@ -354,18 +356,17 @@ def main():
         dt = time.perf_counter() - t0
         kern_ms, kern_n = wl.ctx.eval_timing(reset=True)
         samples = np.sort(wl.ctx.eval_timing_samples())
-        tt = torch.tensor([dt], dtype=torch.float64, device=dev)
+        tt = torch.tensor([dt, -dt], dtype=torch.float64, device=dev)
         if n_world > 1:
             dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        return float(tt.item()), kern_ms, kern_n, samples, sb
+        return float(tt[0].item()), kern_ms, kern_n, samples, sb, (-float(tt[1].item()), float(tt[0].item()))
 
-    elapsed, kern_ms, kern_n, samples, sb = timed_region(w, a.bucket, world)
+    elapsed, kern_ms, kern_n, samples, sb, spread = timed_region(w, 1, world)
     gpu_counters = sb.block_of(a.steps - 1).cpu().numpy().copy()       # [n_cand][3], summed over ranks when N > 1
-    # N > 1: the same K steps with ONE collective per step (the drop-in pipeline reduces once per alignment), for comparison
-    unbucketed = None
-    if world > 1 and a.bucket != 1:
-        e1, *_ = timed_region(w, 1, world)
-        unbucketed = e1
+    bucketed = None
+    if world > 1 and a.bucket > 1:
+        e1, *_ = timed_region(w, a.bucket, world)
+        bucketed = e1
 
     ev = torch.tensor([w.evals], dtype=torch.int64, device=dev)
     if world > 1:
@@ -373,9 +374,26 @@ def main():
     evals_total = int(ev.item())
     checksum = gpu_counters.sum(axis=0).tolist()
 
+    # what the communicator itself says (N > 1): the ranks RCCL saw, through a communicator of the library's own
+    comm_info = None
+    if world > 1:
+        comm_info = {"backend": backend, "torch_world": dist.get_world_size()}
+        if backend == "nccl":
+            try:
+                raw = ctx.comm_unique_id() if rank == 0 else bytes(128)
+                box = torch.frombuffer(bytearray(raw), dtype=torch.uint8).to(dev)
+                dist.broadcast(box, src=0)
+                ctx.comm_init(world, rank, bytes(box.cpu().numpy().tobytes()))
+                seen = ctx.comm_describe()
+                one = ctx.comm_sum(np.ones(1, np.int64))
+                comm_info.update({"rccl_ranks_seen": seen[0], "rccl_rank": seen[1], "rccl_library": seen[2],
+                                  "sum_of_ones": int(one[0])})
+                ctx.comm_destroy()
+            except Exception as e:                                      # reported, not fatal: the timed steps above ran on torch's RCCL
+                comm_info["library_communicator_error"] = str(e)
+
     # measured device-copy bandwidth (SURVEY §8d asks for it next to the spec peak): 1 GiB d2d, read + write
     copy_gbs = None
-    variants = None
     if rank == 0:
         src = torch.empty(1 << 28, dtype=torch.float32, device=dev)
         dst = torch.empty_like(src)
@@ -387,52 +405,47 @@ def main():
         e1.record()
         torch.cuda.synchronize()
         copy_gbs = 5 * 2 * src.numel() * 4 / (e0.elapsed_time(e1) * 1e-3) / 1e9
-        if world == 1 and not a.no_variants:
-            variants = run_variants(w, torch, dev, src, dst, a.seed)
         del src, dst
 
     res = None
     if rank == 0:
         mode = eval_mode(w.n_rows)
         per_launch_ms = kern_ms / max(kern_n, 1)
+        whole = "BASELINE configs[3] itself" if strong else f"{world * rows_per_gpu} rows in all"
         res = {
             "metric": "candidate x sequence coverage evals/s",
             "value": evals_total * a.steps / elapsed,
             "unit": "evals/s",
             "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
             "ms_per_step": elapsed / a.steps * 1e3,
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "higher_is_better": True, "scaling": "strong" if strong else "weak", "vs_baseline": None,
             "dtype": "u32 bit-planes", "data": "synthetic",
-            "config": {"workload": f"{w.describe()} per GPU (SURVEY 8d input 4; the per-GPU shard of BASELINE configs[3], the whole of "
-                                   f"which is timed on one GPU in `full_config`)",
-                       "rows_per_gpu": a.rows, "cols": L, "k": k, "variation": a.v, "candidates_per_window": C,
-                       "windows": w.W, "evals_per_step_per_gpu": w.evals, "iupac_extra_rows": w.n_extra,
-                       "parallelism": f"row shards x{world}, RCCL all-reduce of every step's [{n_cand}x3] int64 counters, {sb.B} steps per collective, overlapped with the next bucket"},
+            "config": {"workload": f"{w.describe()} per GPU x {world} GPU(s) = {whole} (SURVEY 8d input 4; synthetic 1M x 1 kb, row shards)",
+                       "rows_per_gpu": rows_per_gpu, "rows_total": world * rows_per_gpu, "cols": L, "k": k, "variation": a.v,
+                       "candidates_per_window": C, "windows": w.W, "evals_per_step_per_gpu": w.evals, "iupac_extra_rows": w.n_extra,
+                       "parallelism": (f"row shards x{world}, one RCCL all-reduce of the [{n_cand}x3] int64 counters per step" if world > 1
+                                       else "one GPU holds every row")},
             "roofline": roofline_block(w, per_launch_ms, samples, kern_n, every, mode),
-            "variants": variants,
             "measured_copy_GBs": copy_gbs, "setup_s": w.setup_s, "device_bytes": ctx.device_bytes(), "counter_checksum": checksum,
         }
-        if unbucketed is not None:
-            res["ms_per_step_one_collective_per_step"] = unbucketed / a.steps * 1e3
+        if world > 1:
+            res["step_time_ranks_ms"] = {"min": spread[0] / a.steps * 1e3, "max": spread[1] / a.steps * 1e3}
+            res["comm"] = comm_info
+        if bucketed is not None:
+            res["ms_per_step_bucketed"] = bucketed / a.steps * 1e3
+            res["bucket"] = a.bucket
         if world == 1 and not a.no_cpu:
-            n_cpu = a.cpu_rows or a.rows
-            res["cpu_baseline"] = cpu_baseline(w, w.rows[:n_cpu], a.cpu_threads, gpu_counters if n_cpu == a.rows else None, a.seed)
+            n_cpu = a.cpu_rows or rows_per_gpu
+            res["cpu_baseline"] = cpu_baseline(w, w.rows[:n_cpu], a.cpu_threads, gpu_counters if n_cpu == rows_per_gpu else None, a.seed)
             res["parity_checked"] = res["cpu_baseline"].get("parity_checked")
-    # config 4 itself on one GPU (rank 0; the other ranks wait at the barrier below)
-    if rank == 0 and not a.no_full and a.rows != FULL_ROWS:
-        shard_step_ms = res["ms_per_step"]
+    # N = 1: the shard one GPU holds in the 8-GPU job, timed the same way (with the variant measurements)
+    if rank == 0 and world == 1 and not a.no_shard and rows_per_gpu != SHARD_ROWS:
         del sb
         w.ctx = ctx = None
         w.rows = None
         torch.cuda.empty_cache()
-        res["full_config"] = full_config(lib, local, torch, a, timed_region, every, world == 1 and not a.no_cpu)
-        fc = res["full_config"]
-        if world > 1 and world * a.rows == FULL_ROWS:
-            res["strong_scaling"] = {"one_gpu_ms_per_step": fc["ms_per_step"], "n_gpu_ms_per_step": shard_step_ms,
-                                     "speedup": fc["ms_per_step"] / shard_step_ms, "n_gpus": world,
-                                     "n_gpu_ms_per_step_one_collective_per_step": res.get("ms_per_step_one_collective_per_step"),
-                                     "note": f"{world} GPUs x {a.rows} rows are config 4; one GPU times the same {FULL_ROWS} rows alone in this run"}
-        if fc.get("parity_checked") is False:
+        res["weak_shard"] = weak_shard(lib, local, torch, dev, a, timed_region, every, not a.no_cpu)
+        if res["weak_shard"].get("parity_checked") is False:
             res["parity_checked"] = False
     if rank == 0:
         print(json.dumps(res), flush=True)
@@ -443,17 +456,22 @@ def main():
         raise SystemExit("bench.py: GPU counters differ from the CPU oracle's")
 
 
-def full_config(lib, local, torch, a, timed_region, every, with_cpu):
-    """BASELINE.json configs[3] itself — 1 048 576 x 1000 — resident on ONE GPU: the same steps, timed the same way."""
-    w = Workload(lib, local, torch, 0, FULL_ROWS, a)
-    elapsed, kern_ms, kern_n, samples, sb = timed_region(w, 1, 1)
+def weak_shard(lib, local, torch, dev, a, timed_region, every, with_cpu):
+    """The 131072 x 1000 shard one GPU holds when config 4 is spread over 8 GPUs: the same steps, timed the same way, on one GPU."""
+    w = Workload(lib, local, torch, 0, SHARD_ROWS, a)
+    elapsed, kern_ms, kern_n, samples, sb, _ = timed_region(w, 1, 1)
     counters = sb.block_of(a.steps - 1).cpu().numpy().copy()
     per_launch_ms = kern_ms / max(kern_n, 1)
-    out = {"workload": w.describe() + " on ONE GPU (BASELINE configs[3] whole; planes 0.6 GB: larger than the Infinity Cache)",
+    out = {"workload": w.describe() + " on ONE GPU (the per-GPU shard of BASELINE configs[3] at N = 8; planes 81 MB: inside the Infinity Cache)",
            "value": w.evals * a.steps / elapsed, "unit": "evals/s", "ms_per_step": elapsed / a.steps * 1e3, "steps": a.steps,
            "evals_per_step": w.evals, "iupac_extra_rows": w.n_extra, "setup_s": w.setup_s, "device_bytes": w.ctx.device_bytes(),
            "roofline": roofline_block(w, per_launch_ms, samples, kern_n, every, eval_mode(w.n_rows)),
            "counter_checksum": counters.sum(axis=0).tolist()}
+    if not a.no_variants:
+        src = torch.empty(1 << 28, dtype=torch.float32, device=dev)
+        dst = torch.empty_like(src)
+        out["variants"] = run_variants(w, torch, dev, src, dst, a.seed)
+        del src, dst
     if with_cpu:
         cb = cpu_baseline(w, w.rows, a.cpu_threads, counters, a.seed, one_core=False, python_leg=False)
         out["cpu_baseline"] = cb

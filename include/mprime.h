@@ -288,6 +288,10 @@ int mp_kmm_scan(mp_ctx *ctx, const uint8_t *bytes, const int64_t *row_off, int32
 int mp_comm_unique_id(uint8_t *id);                                        /* id[MP_COMM_ID_BYTES] */
 int mp_comm_init(mp_ctx *ctx, int32_t n_ranks, int32_t rank, const uint8_t *id);
 int mp_comm_destroy(mp_ctx *ctx);
+/* what the communicator itself reports: ranks_seen[0] = its size, ranks_seen[1] = this rank (ncclCommCount / ncclCommUserRank; the
+ * arguments of mp_comm_init for a world of one without RCCL), and the file the RCCL entry points were resolved from ("" when RCCL is
+ * not in use).  For run logs: shows that N ranks really formed ONE communicator and which librccl carried it. */
+int mp_comm_describe(mp_ctx *ctx, int32_t *ranks_seen, char *library_path, int32_t path_bytes);
 /* in place, sum over ranks; `device_buf` is device memory, the call only enqueues */
 int mp_comm_allreduce_i64(mp_ctx *ctx, int64_t *device_buf, int64_t n);
 /* the same for a host buffer: returns with the sums in `host_buf` */

@@ -60,6 +60,7 @@ SYMBOLS = [
     ("mp_comm_unique_id", C.c_int, [_p]),
     ("mp_comm_init", C.c_int, [_p, C.c_int32, C.c_int32, _p]),
     ("mp_comm_destroy", C.c_int, [_p]),
+    ("mp_comm_describe", C.c_int, [_p, _p, C.c_char_p, C.c_int32]),
     ("mp_comm_allreduce_i64", C.c_int, [_p, _p, C.c_int64]),
     ("mp_comm_allreduce_host_i64", C.c_int, [_p, _p, C.c_int64]),
     ("mp_comm_allgather_i64", C.c_int, [_p, C.c_int64, _p]),
@@ -265,6 +266,13 @@ class Context:
 
     def comm_destroy(self):
         self._ck(self.d.mp_comm_destroy(self.h))
+
+    def comm_describe(self):
+        """(ranks the communicator reports, this rank as it reports it, path of the librccl in use or '')."""
+        seen = np.zeros(2, np.int32)
+        buf = C.create_string_buffer(512)
+        self._ck(self.d.mp_comm_describe(self.h, _ptr(seen), buf, 512))
+        return int(seen[0]), int(seen[1]), buf.value.decode()
 
     def comm_allreduce_device(self, device_ptr: int, n: int):
         self._ck(self.d.mp_comm_allreduce_i64(self.h, C.c_void_p(device_ptr), n))

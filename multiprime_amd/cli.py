@@ -6,7 +6,8 @@ program instead of the reference script without touching the rule:
            -l 18 -e 3.6 -o {out} -f 0.7 -p 1
 
 Extra, optional flags (additions must stay optional):
-  --device D     GPU ordinal (default: LOCAL_RANK under a launcher, else 0)
+  --device D     GPU ordinal (default 0).  With several ranks it is the ordinal of LOCAL_RANK 0: rank r of the node opens D + r
+                 (MP_SHARE_DEVICE=1: every rank opens D — several ranks on one GPU, for tests)
   --no-json      skip the two O(windows x sequences) JSON side files, which stop being writable at ~10^5 sequences
   --bitsets      also write <out>.coverage_bitsets.npz (the bitset form of those files)
   --ngpu N       run on N GPUs of this node: the program re-launches itself as N ranks (torch.distributed.run, 127.0.0.1).
@@ -50,7 +51,7 @@ def parse_args(argv=None):
                    help="Accepted for compatibility (the reference's process pool is inert; the work runs on the GPU).")
     p.add_argument("-a", "--away", type=int, default=4, metavar="<int>", help="Hairpin: minimal distance of paired bases. Default: 4.")
     p.add_argument("-o", "--out", type=str, default=None, metavar="<file>", help="output file")
-    p.add_argument("--device", type=int, default=None, help="GPU ordinal (default: LOCAL_RANK under a launcher, else 0)")
+    p.add_argument("--device", type=int, default=None, help="GPU ordinal (default 0); with several ranks: the ordinal of local rank 0, rank r opens D + r")
     p.add_argument("--ngpu", type=int, default=1, help="GPUs of this node to use: re-launches this command as that many ranks")
     p.add_argument("--batch", type=str, default=None, metavar="<file>",
                    help="file of `input<TAB>output` lines: all of them in one process per GPU with this command's flags")
@@ -136,7 +137,9 @@ def main(argv=None):
     rank, world, local = _launcher_env()
     if args.ngpu > 1 and world == 1:
         sys.exit(_respawn(args.ngpu, argv))
-    device = args.device if args.device is not None else local
+    # several ranks must not open the same GPU (RCCL refuses duplicate devices): --device is then the first rank's ordinal
+    base = args.device if args.device is not None else 0
+    device = base if world == 1 or os.environ.get("MP_SHARE_DEVICE") == "1" else base + local
     if args.batch is not None:
         _run_batch(args, rank, world, device)           # clusters are independent: no process group, no collective
         return

@@ -12,9 +12,11 @@
 #include "common.hpp"
 
 #include <dlfcn.h>
+#include <link.h>
 #include <rccl/rccl.h>
 
 #include <mutex>
+#include <string>
 
 using namespace mp;
 
@@ -28,17 +30,43 @@ struct Rccl {
     ncclResult_t (*AllReduce)(const void *, void *, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t) = nullptr;
     ncclResult_t (*AllGather)(const void *, void *, size_t, ncclDataType_t, ncclComm_t, hipStream_t) = nullptr;
     const char *(*GetErrorString)(ncclResult_t) = nullptr;
+    ncclResult_t (*CommCount)(const ncclComm_t, int *) = nullptr;          // optional (mp_comm_describe)
+    ncclResult_t (*CommUserRank)(const ncclComm_t, int *) = nullptr;
     const char *error = nullptr;
+    char path[512] = {0};              // the file the entry points came from (mp_comm_library)
 };
+
+// An RCCL that is already mapped into the process (torch's own copy under torch/lib, a host application's) is reused: two copies of
+// RCCL in one process would each build their own topology and transports on the same GPU.  dl_iterate_phdr finds it whatever
+// name it was loaded under (torch's librccl.so carries no SONAME).
+int find_loaded_rccl(struct dl_phdr_info *info, size_t, void *data) {
+    const char *n = info->dlpi_name;
+    if (!n || !*n) return 0;
+    const char *b = strrchr(n, '/');
+    b = b ? b + 1 : n;
+    if (strncmp(b, "librccl.so", 10) != 0) return 0;
+    *static_cast<std::string *>(data) = n;
+    return 1;
+}
 
 Rccl &rccl() {
     static Rccl r;
     static std::once_flag once;
     std::call_once(once, [] {
-        for (const char *name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"}) {
-            r.lib = dlopen(name, RTLD_NOW | RTLD_LOCAL);
-            if (r.lib) break;
+        // MP_RCCL_LIBRARY: an explicit library (the tests' shared-memory stand-in that lets several ranks share one GPU)
+        if (const char *forced = getenv("MP_RCCL_LIBRARY")) {
+            r.lib = dlopen(forced, RTLD_NOW | RTLD_LOCAL);
+            if (!r.lib) { r.error = "MP_RCCL_LIBRARY could not be opened (dlopen)"; return; }
         }
+        if (!r.lib) {
+            std::string loaded;
+            if (dl_iterate_phdr(find_loaded_rccl, &loaded)) r.lib = dlopen(loaded.c_str(), RTLD_NOW | RTLD_LOCAL | RTLD_NOLOAD);
+        }
+        if (!r.lib)
+            for (const char *name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"}) {
+                r.lib = dlopen(name, RTLD_NOW | RTLD_LOCAL);
+                if (r.lib) break;
+            }
         if (!r.lib) { r.error = "librccl.so not found (dlopen)"; return; }
         auto sym = [&](const char *s) { void *p = dlsym(r.lib, s); if (!p) r.error = "librccl.so lacks an expected symbol"; return p; };
         r.GetUniqueId = reinterpret_cast<decltype(r.GetUniqueId)>(sym("ncclGetUniqueId"));
@@ -47,6 +75,11 @@ Rccl &rccl() {
         r.AllReduce = reinterpret_cast<decltype(r.AllReduce)>(sym("ncclAllReduce"));
         r.AllGather = reinterpret_cast<decltype(r.AllGather)>(sym("ncclAllGather"));
         r.GetErrorString = reinterpret_cast<decltype(r.GetErrorString)>(sym("ncclGetErrorString"));
+        r.CommCount = reinterpret_cast<decltype(r.CommCount)>(dlsym(r.lib, "ncclCommCount"));
+        r.CommUserRank = reinterpret_cast<decltype(r.CommUserRank)>(dlsym(r.lib, "ncclCommUserRank"));
+        Dl_info where;
+        if (r.GetUniqueId && dladdr(reinterpret_cast<void *>(r.GetUniqueId), &where) && where.dli_fname)
+            snprintf(r.path, sizeof r.path, "%s", where.dli_fname);
     });
     return r;
 }
@@ -127,6 +160,24 @@ int mp_comm_destroy(mp_ctx *c) {
     (void)hipSetDevice(c->dev);
     (void)hipStreamSynchronize(c->stream);
     free_comm(c);
+    return MP_OK;
+}
+
+int mp_comm_describe(mp_ctx *c, int32_t *ranks_seen, char *library_path, int32_t path_bytes) {
+    int rc = need_comm(c);
+    if (rc) return rc;
+    if (!ranks_seen || (path_bytes > 0 && !library_path)) return fail(c, MP_ERR_ARG, "mp_comm_describe: null output");
+    ranks_seen[0] = c->n_ranks; ranks_seen[1] = c->rank;
+    if (path_bytes > 0) library_path[0] = 0;
+    if (!c->comm) return MP_OK;
+    Rccl &r = rccl();
+    int n = -1, me = -1;
+    if (r.CommCount && r.CommUserRank) {
+        NCCLCK(c, r.CommCount(reinterpret_cast<ncclComm_t>(c->comm), &n));
+        NCCLCK(c, r.CommUserRank(reinterpret_cast<ncclComm_t>(c->comm), &me));
+        ranks_seen[0] = n; ranks_seen[1] = me;
+    }
+    if (path_bytes > 0) snprintf(library_path, (size_t)path_bytes, "%s", r.path);
     return MP_OK;
 }
 

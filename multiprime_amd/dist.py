@@ -43,15 +43,31 @@ class RowShards:
         self.native = None          # the context whose RCCL communicator carries the collectives (attach)
 
     def attach(self, ctx):
-        """Collectives through the library's own communicator when this is a GPU run of the HIP library."""
+        """Collectives through the library's own communicator when this is a GPU run of the HIP library.  MP_NATIVE_COMM=0 keeps
+        them in torch.distributed; MP_NATIVE_COMM=force takes the library's transport even when torch.distributed runs on gloo
+        (the tests: several ranks on one GPU with MP_RCCL_LIBRARY pointing at tests/stub_rccl).
+        Rank 0 draws the id; what it broadcasts is a status byte + the id, so that a rank 0 that cannot load RCCL makes EVERY rank
+        raise (or, unforced, fall back to torch's transport) instead of leaving the others blocked in the broadcast."""
         import os
-        if not (self.on_gpu and ctx.lib.backend == "hip") or os.environ.get("MP_NATIVE_COMM", "1") == "0" or self.group is not None:
+        mode = os.environ.get("MP_NATIVE_COMM", "1")
+        forced = mode == "force"
+        if ctx.lib.backend != "hip" or mode == "0" or self.group is not None or not (self.on_gpu or forced):
             return
         dev = self._device()
-        raw = ctx.comm_unique_id() if self.rank == 0 else bytes(128)
+        raw, why = bytes(129), ""
+        if self.rank == 0:
+            try:
+                raw = b"\x01" + ctx.comm_unique_id()
+            except Exception as e:                                   # librccl not loadable, RCCL error: told to everyone below
+                why = str(e)
         box = torch.frombuffer(bytearray(raw), dtype=torch.uint8).to(dev)
         dist.broadcast(box, src=0, group=self.group)
-        ctx.comm_init(self.world, self.rank, bytes(box.cpu().numpy().tobytes()))
+        got = bytes(box.cpu().numpy().tobytes())
+        if got[0] != 1:
+            if forced or self.on_gpu and os.environ.get("MP_NATIVE_COMM_STRICT"):
+                raise RuntimeError("rank 0 could not create an RCCL unique id" + (": " + why if why else ""))
+            return                                                   # all ranks alike: torch.distributed carries the collectives
+        ctx.comm_init(self.world, self.rank, got[1:])
         self.native = ctx
 
     # -- sharding ------------------------------------------------------------------------------

@@ -567,6 +567,14 @@ int mp_comm_destroy(mp_ctx *c) {
     c->n_ranks = 0;
     return MP_OK;
 }
+int mp_comm_describe(mp_ctx *c, int32_t *ranks_seen, char *library_path, int32_t path_bytes) {
+    int rc = one_rank(c);
+    if (rc) return rc;
+    if (!ranks_seen || (path_bytes > 0 && !library_path)) return fail(c, MP_ERR_ARG, "mp_comm_describe: null output");
+    ranks_seen[0] = 1; ranks_seen[1] = 0;
+    if (path_bytes > 0) library_path[0] = 0;
+    return MP_OK;
+}
 int mp_comm_allreduce_i64(mp_ctx *c, int64_t *buf, int64_t n) { (void)buf; (void)n; return one_rank(c); }
 int mp_comm_allreduce_host_i64(mp_ctx *c, int64_t *buf, int64_t n) { (void)buf; (void)n; return one_rank(c); }
 int mp_comm_allgather_i64(mp_ctx *c, int64_t value, int64_t *out) {
