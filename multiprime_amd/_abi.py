@@ -71,6 +71,16 @@ SYMBOLS = [
 COMM_ID_BYTES = 128
 
 
+def prefer_staged_copies():
+    """For the drop-in command lines, called before anything starts the HIP runtime: read-backs into ordinary numpy arrays go
+    through the runtime's staging buffers instead of page-locking the array for one use (GPU_PINNED_MIN_XFER_SIZE = 256 MiB: the
+    58 MB of histogram entries of a 131072 x 1000 alignment take 6.5 ms instead of 27-32 ms, csrc/api.hip).  A process-wide runtime
+    setting, hence a decision of the PROGRAM, not of the library: the class API leaves it alone.  A value the user exported, or
+    MP_KEEP_PIN_THRESHOLD, wins."""
+    if not os.environ.get("MP_KEEP_PIN_THRESHOLD"):
+        os.environ.setdefault("GPU_PINNED_MIN_XFER_SIZE", "256")
+
+
 class MprimeError(RuntimeError):
     def __init__(self, code, msg):
         super().__init__(f"mprime error {code}: {msg}")

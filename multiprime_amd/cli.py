@@ -133,6 +133,8 @@ def _run_batch(args, rank, world, device):
 
 
 def main(argv=None):
+    from ._abi import prefer_staged_copies
+    prefer_staged_copies()                      # a command line owns its process: see _abi.prefer_staged_copies
     args = parse_args(argv)
     rank, world, local = _launcher_env()
     if args.ngpu > 1 and world == 1:

@@ -119,16 +119,10 @@ void free_msa(mp_ctx *c) {
 using namespace mp;
 
 // Copies between the device and ordinary (pageable) host memory: from a minimum size on, the HIP runtime page-locks the user's
-// range for the transfer instead of going through its own staging buffers.  The buffers this library is handed are used once
-// (numpy arrays of a result), so that locking is pure cost: the 58 MB of histogram entries of a 131072 x 1000 alignment take
-// 27-32 ms to read back with it and 6.5 ms without (MP_TRACE; same in a loop: 2.5 ms once the range is known to the runtime).
-// The threshold is a runtime setting read when the runtime starts; it is raised to 256 MiB here (a 1 GB alignment still uploads
-// faster with the locking: 24 against 50 ms) unless the user set it or MP_KEEP_PIN_THRESHOLD is set — which only takes effect when
-// the process has not started the HIP runtime yet (the drop-in scripts).  Done when the library is loaded, in the loading thread:
-// setenv must not run beside another thread's getenv, and mp_create runs beside the FASTA parser in the drop-in.
-__attribute__((constructor)) static void raise_pin_threshold() {
-    if (!getenv("MP_KEEP_PIN_THRESHOLD")) setenv("GPU_PINNED_MIN_XFER_SIZE", "256", 0);
-}
+// range for the transfer instead of going through its own staging buffers — pure cost for buffers that are used once (the 58 MB of
+// histogram entries of a 131072 x 1000 alignment: 27-32 ms with it, 6.5 ms without).  The threshold (GPU_PINNED_MIN_XFER_SIZE) is a
+// process-wide runtime setting read when the runtime starts, so it is NOT this library's to change: the drop-in command lines raise
+// it before anything starts the HIP runtime (multiprime_amd/_abi.py prefer_staged_copies); a host application decides for itself.
 
 extern "C" {
 

@@ -179,6 +179,8 @@ def parse_args(argv=None):
 
 
 def main(argv=None):
+    from ._abi import prefer_staged_copies
+    prefer_staged_copies()                      # a command line owns its process: see _abi.prefer_staged_copies
     e1 = time.time()
     options, _ = parse_args(argv)
     Primers_filter(ref_file=options.ref, primer_file=options.input, adaptor=options.adaptor, rep_seq_number=options.maxseq,

@@ -172,6 +172,8 @@ def run(options, library: Library | None = None):
 
 
 def main(argv=None):
+    from ._abi import prefer_staged_copies
+    prefer_staged_copies()                      # a command line owns its process: see _abi.prefer_staged_copies
     run(parse_args(argv))
 
 

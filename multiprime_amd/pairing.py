@@ -352,6 +352,8 @@ def parse_args(argv=None):
 
 
 def main(argv=None):
+    from ._abi import prefer_staged_copies
+    prefer_staged_copies()                      # a command line owns its process: see _abi.prefer_staged_copies
     args = parse_args(argv)
     e1 = time.time()
     Primers_filter(ref_file=args.ref, primer_file=args.input, adaptor=args.adaptor, rep_seq_number=args.maxseq,

@@ -145,6 +145,8 @@ def parse_args(argv=None):
 
 
 def main(argv=None):
+    from ._abi import prefer_staged_copies
+    prefer_staged_copies()                      # a command line owns its process: see _abi.prefer_staged_copies
     o = parse_args(argv)
     e1 = time.time()
     Product(primer_file=o.input, output_file=o.out, ref_file=o.ref, file_format=o.format, coverage=o.stast, nproc=o.process,

@@ -25,6 +25,7 @@ deterministic here: first appearance in the forward sites / the primer file / so
 from __future__ import annotations
 
 import os
+import sys
 import pickle
 import re
 import time
@@ -153,27 +154,37 @@ class off_targets(object):
         data, row_off = fa.rows()
         genes = [s[1:] if s.startswith(">") else s for s in fa.ids]          # a mapper names a sequence by its first token
         seqs, names = list(table.reads), table.names()
-        for seq, name in zip(seqs, names):
-            if set(seq.upper()) - set("ACGT") or not 4 <= len(seq) <= PATTERN_MAX_LEN:
-                # the reference hands any read to bowtie2; this build packs a read into 64 bits ("Limits")
-                raise ValueError(f"read {name} ({seq}): the scan takes 4..{PATTERN_MAX_LEN} bases of ACGT after expansion; "
-                                 f"use -l to map the 3' term of longer primers")
+        # The reference hands every read to bowtie2, which ignores what it cannot align (an empty read from a blank line of the
+        # primer file — V9 get_term keeps it as key "" —, a read with U / I / N left after expansion).  This build does the same:
+        # such reads find nothing, with a warning naming them.  Only when NO read is usable is that an error.  A read beyond the
+        # packed pattern width is reported too ("Limits": use -l to map the 3' term of longer primers).
+        usable = [i for i, seq in enumerate(seqs)
+                  if seq and not (set(seq.upper()) - set("ACGT")) and 4 <= len(seq) <= PATTERN_MAX_LEN]
+        skipped = [names[i] for i in range(len(seqs)) if i not in set(usable)]
+        if skipped:
+            print("Warning: {} read(s) not scanned (empty, not ACGT after expansion, or outside 4..{} bases): {}".format(
+                len(skipped), PATTERN_MAX_LEN, ", ".join(repr(n) for n in skipped[:20]) + (" ..." if len(skipped) > 20 else "")),
+                file=sys.stderr)
+        if not usable:
+            raise ValueError(f"no usable read: the scan takes 4..{PATTERN_MAX_LEN} bases of ACGT after expansion")
         lib = self._library if self._library is not None else Library()
         ctx = lib.context(self._device)
-        budgets = {}
-        for i, seq in enumerate(seqs):
-            budgets.setdefault(self.max_mismatch if self.max_mismatch is not None else bowtie2_mismatch_budget(len(seq)), []).append(i)
         found = []
-        for budget, members in budgets.items():
-            codes = iupac.MASK_LUT[np.frombuffer("".join(seqs[i].upper() for i in members).encode(), np.uint8)]
-            off = np.zeros(len(members) + 1, np.int32)
-            np.cumsum([len(seqs[i]) for i in members], out=off[1:])
-            h = ctx.kmm_scan(data, row_off, codes, off, budget, self.term_threshold)
-            if len(h):
-                h = h.copy()
-                h[:, 2] = np.asarray(members, np.int32)[h[:, 2]]
-                found.append(h)
-        ctx.close()
+        try:
+            budgets = {}
+            for i in usable:
+                budgets.setdefault(self.max_mismatch if self.max_mismatch is not None else bowtie2_mismatch_budget(len(seqs[i])), []).append(i)
+            for budget, members in budgets.items():
+                codes = iupac.MASK_LUT[np.frombuffer("".join(seqs[i].upper() for i in members).encode(), np.uint8)]
+                off = np.zeros(len(members) + 1, np.int32)
+                np.cumsum([len(seqs[i]) for i in members], out=off[1:])
+                h = ctx.kmm_scan(data, row_off, codes, off, budget, self.term_threshold)
+                if len(h):
+                    h = h.copy()
+                    h[:, 2] = np.asarray(members, np.int32)[h[:, 2]]
+                    found.append(h)
+        finally:
+            ctx.close()
         self.stats["scan_s"] = time.time() - t0
         sites = ({}, {})
         if found:
@@ -245,6 +256,8 @@ def parse_args(argv=None):
 
 
 def main(argv=None):
+    from ._abi import prefer_staged_copies
+    prefer_staged_copies()                      # a command line owns its process: see _abi.prefer_staged_copies
     args = parse_args(argv)
     e1 = time.time()
     off_targets(primer_file=args.input, term_length=args.len, reference_file=args.ref, PCR_product_size=args.size,
