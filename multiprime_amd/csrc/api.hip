@@ -48,6 +48,7 @@ void free_tiles(mp_ctx *c) {
 
 void free_eval(mp_ctx *c) {
     free_tiles(c);
+    free_slide(c);
     c->h_chains.clear(); c->h_events.clear(); c->h_cand_out.clear();
     dev_free(c, &c->chain_prog, c->chain_prog_n);
     c->chain_prog_n = 0;
@@ -105,7 +106,7 @@ void free_msa(mp_ctx *c) {
     free_windows(c);
     size_t np = (size_t)c->n_pad;
     dev_free(c, &c->planes, (size_t)c->n_chunks * 4 * np);
-    dev_free(c, &c->cols, (size_t)c->n_chunks * 32 * 4 * (np / 64));
+    dev_free(c, &c->cols, ((size_t)c->n_chunks * 32 * 4 + 1) * (np / 64));
     dev_free(c, &c->cons, (size_t)c->n_chunks * 32);
     dev_free(c, &c->cum, ((size_t)c->n_chunks + 1) * np);
     dev_free(c, &c->ung, np * c->ustride);

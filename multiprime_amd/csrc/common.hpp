@@ -51,6 +51,7 @@ struct ChainItem {
 
 struct TileRound;
 struct TileBand;
+struct SlideBand;
 
 struct Nib {          // up to 32 symbol codes, one nibble each
     uint64_t lo, hi;
@@ -158,6 +159,14 @@ struct mp_ctx {
     uint32_t *chain_prog = nullptr;          // fetch programs of the chain items (evalprog.hip), chains of up to 8 members only
     size_t chain_prog_n = 0;
     int prog_shape = -1;                     // eval_prog_kernel shape the programs were written for (-1: eval_chain_kernel runs the chains)
+    // sliding evaluation (evalslide.hip): plan of the staged chain items; slide_items = 0: the first-pass kernels run every item
+    mp::SlideBand *slide_bands = nullptr;
+    uint32_t *slide_iters = nullptr, *slide_recs = nullptr;
+    size_t slide_n_iters = 0;
+    int slide_items = 0, slide_n_bands = 0, slide_max_items = 0, slide_ns = 0, slide_gw = 0;
+    uint32_t slide_spos = 0, slide_fmask = 0, slide_rmask = 0;
+    mp::ChainItem *chain_rest = nullptr;     // the chain items the plan leaves to the first-pass kernel
+    int n_rest = 0, rest_max_steps = 0;
     mp::TileRound *tile_rounds = nullptr;
     mp::TileBand *tile_bands = nullptr;
     uint32_t *tile_prog = nullptr;
@@ -225,6 +234,7 @@ int fill_segments(mp_ctx *c, const FillSeg *segs, int n);
 // release the device arrays of one stage (and of every stage that depends on it); api.hip
 void free_eval(mp_ctx *c);
 void free_tiles(mp_ctx *c);
+void free_slide(mp_ctx *c);
 void free_comm(mp_ctx *c);
 void free_unique(mp_ctx *c);
 void free_windows(mp_ctx *c);

@@ -10,6 +10,7 @@
 #include "bitslice.hpp"
 #include "evaltile.hpp"
 #include "evalprog.hpp"
+#include "evalslide.hpp"
 
 using namespace mp;
 
@@ -1230,8 +1231,11 @@ int mp_eval_upload(mp_ctx *c, int32_t n_cand, const int32_t *cw, const uint8_t *
     // in LDS) is faster from about 400 000 rows up, where the planes no longer come out of L2 (shape 11: 1.122 vs 1.193 ms / 10 steps at
     // 524 288 rows, 0.217-0.223 vs 0.240-0.242 ms at 1 048 576; slower below: 0.0549 vs 0.0524 ms at 262 144 —
     // profiles/r03_prog_keep.txt); eval_chain_kernel otherwise.  MP_EVAL_PROG=1 / 0 forces one of them, MP_EVAL_CHAIN the shape.
+    // The sliding kernel (evalslide.hip) takes the chain items it can (all of them in a refinement run); what it leaves out stays with
+    // the first-pass kernel below.  MP_EVAL_SLIDE=0 / 1 forbids / forces it.
+    if (c->n_chain && (rc = upload_eval_slide(c, chains, events, co))) return rc;
     c->prog_shape = -1;
-    if (c->n_chain && c->max_steps <= kEvalCC) {
+    if (c->n_chain && c->max_steps <= kEvalCC && c->slide_items == 0) {
         const char *pe = getenv("MP_EVAL_PROG");
         if (pe ? atoi(pe) == 1 : c->n_pad >= 393216) {
             c->prog_shape = pe ? 7 : 11;
@@ -1337,6 +1341,22 @@ int mp_eval_launch(mp_ctx *c, int64_t *device_out) {
             // per workgroup instead of being re-read from L2 by every covering window.  Measured SLOWER than the kernels below
             // at every size (profiles/r03_tile_*.txt), so it runs only on request: MP_EVAL_TILE=2 / 4 row
             // words per lane.
+            if (c->slide_items > 0) {
+                // sliding evaluation: the patch planes of ALL chain items and the column planes of the items the plan left out run on
+                // the first-pass kernel, the rest slides
+                if (ca.patch.n_blocks)
+                    hipLaunchKernelGGL((c->max_steps > kEvalCC ? lfn : cfn)[c->v][cshape], dim3((unsigned)ca.patch.n_blocks), dim3(kBlock), 0, c->stream, ca);
+                if (c->n_rest) {
+                    unsigned rgrid;
+                    const BlockMap rbm = block_map(cgw[cshape], c->n_rest, rgrid);
+                    PatchArgs none{nullptr, nullptr, nullptr, 0, 0};
+                    EvalChainArgs ra{c->cols, c->excl, nw, c->p0, c->k, c->v, c->chain_rest, c->chain_events, c->cand_out, c->sF, c->sR,
+                                     (unsigned long long *)device_out, rbm, none};
+                    hipLaunchKernelGGL((c->rest_max_steps > kEvalCC ? lfn : cfn)[c->v][cshape], dim3(rgrid), dim3(kBlock), 0, c->stream, ra);
+                }
+                int rc = launch_eval_slide(c, (unsigned long long *)device_out);
+                if (rc) return rc;
+            } else {
             int tile_gw = 0;
             if (const char *e = getenv("MP_EVAL_TILE")) { const int t = atoi(e); tile_gw = (t == 2 || t == 4) && c->max_steps <= kEvalCC ? t : 0; }
             if (tile_gw) {
@@ -1352,6 +1372,7 @@ int mp_eval_launch(mp_ctx *c, int64_t *device_out) {
             } else {
                 hipLaunchKernelGGL((c->max_steps > kEvalCC ? lfn : cfn)[c->v][cshape], dim3(grid + (unsigned)ca.patch.n_blocks), dim3(kBlock), 0,
                                    c->stream, ca);
+            }
             }
         }
         const int n_tab = shape == 0 ? c->n_table : c->n_items;

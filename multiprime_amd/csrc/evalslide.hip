@@ -1,0 +1,277 @@
+// evalslide.hip — part of libmprime_hip.so: hand-written HIP (gfx950 / MI355X, wave64) behind the C ABI of include/mprime.h.
+// Candidate x sequence coverage evaluation of nested refinement chains (mis_primer_check + Y_distance, V20:1103-1130, 229-233) by
+// SLIDING along the windows: eval_slide_kernel.  The arithmetic and the plan are in slidecore.hpp / slideplan.hpp (shared with the
+// CPU emulation tools/slide_emul.cpp); this file is the GPU environment of the band routine and its launch.
+//
+// Why: the first-pass kernels (eval.hip, evalprog.hip) fetch the k (or more) column planes of a window's most degenerate member for
+// EVERY window, so every plane word leaves L2 ~18 times — they are bound by the rate at which a CU's vector memory path returns
+// data to registers (64 B/clk per CU).  Here a wave keeps the bit-sliced mismatch count of the per-column
+// reference k-mer and moves it from window to window with ONE plane fetch (plus the chain's event planes, fetched once per item and
+// used twice: as corrections of the count and as the steps of the walk): ~9 fetches per window and 32-row word instead of ~33.
+//
+// Work decomposition: workgroup = 4 waves = 4 x 64 lanes x GW row words, one BAND of consecutive windows (k - 1 warm-up columns,
+// then one column per window).  grid = bands x row slices, slice = blockIdx % slices: workgroup b runs on XCD b % 8, so an XCD owns
+// row slices and walks the bands in order — consecutive bands find their columns in that XCD's L2, HBM sees every plane once.
+// LDS: per wave a ring of the last k reference-mismatch words of its rows (the column sliding out shares the slot of the one
+// sliding in; strict positions read theirs), per workgroup the 24 counters of every item of the band: waves add their totals there
+// (ds_add), one flush of global atomics per workgroup and band.
+#include "common.hpp"
+#include "bitslice.hpp"
+#include "slidecore.hpp"
+#include "evalslide.hpp"
+
+using namespace mp;
+
+namespace {
+
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+
+struct SlideKernArgs {
+    SlideArgs A;
+    const uint32_t *cols32;            // [n_cols][4][nw32] one-hot column planes
+    const uint32_t *excl32;            // [W][nw32]
+    int nw32;
+    unsigned long long *out;
+    int wc, wc_pad;                    // row slices of 256 x GW words; padded to a multiple of 8 (a slice stays on one XCD)
+    int max_items;                     // items of the largest band (LDS table rows)
+};
+
+template <int GW>
+struct DevEnv {
+    const SlideKernArgs &K;
+    __amdgpu_buffer_rsrc_t rs_cols, rs_excl;
+    int voff, lane;
+    uint32_t row_bytes;
+    bool live;
+    uint32_t *ring;                    // this lane's GW words of slot 0; slots are 64 * GW words apart
+    uint32_t *part;                    // the wave's 4 x 12 words for its rows' packed sums
+    uint32_t *tab;                     // the workgroup's counters [item of the band][12]
+    uint32_t itv;                      // 64 iteration words, one per lane
+    uint32_t live_mask;
+
+    __device__ __forceinline__ DevEnv(const SlideKernArgs &k) : K(k) {}
+    __device__ __forceinline__ SlideBand uband(int b) const {
+        const SlideBand *p = K.A.bands + b;
+        SlideBand r;
+        r.w0 = __builtin_amdgcn_readfirstlane(p->w0); r.n_win = __builtin_amdgcn_readfirstlane(p->n_win);
+        r.item0 = __builtin_amdgcn_readfirstlane(p->item0); r.n_items = __builtin_amdgcn_readfirstlane(p->n_items);
+        r.iter0 = __builtin_amdgcn_readfirstlane(p->iter0); r.pad = 0;
+        return r;
+    }
+    // iteration words arrive 64 at a time, one per lane (the array is padded by 64 words)
+    __device__ __forceinline__ void load_iters(int idx) { itv = K.A.iters[(size_t)idx + (size_t)lane]; }
+    __device__ __forceinline__ uint32_t iter_word(int j) const { return (uint32_t)__builtin_amdgcn_readlane((int)itv, j); }
+    // an item's record: its 32 words, one per lane of a register; a word leaves with one v_readlane
+    typedef uint32_t Rec;
+    __device__ __forceinline__ Rec load_rec(int item) const { return K.A.recs[(size_t)item * kSlideRec + (size_t)(lane & 31)]; }
+    __device__ __forceinline__ uint32_t rec_word(Rec r, int q) const { return (uint32_t)__builtin_amdgcn_readlane((int)r, q); }
+    __device__ __forceinline__ uint32_t rec_word_dyn(Rec r, int q) const { return (uint32_t)__builtin_amdgcn_readlane((int)r, q); }
+    __device__ __forceinline__ void load(__amdgpu_buffer_rsrc_t rs, int soff, uint32_t (&d)[GW]) const {
+        if constexpr (GW == 4) {
+            const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rs, voff, soff, 0);
+            d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w;
+        } else if constexpr (GW == 2) {
+            const u32x2 v = __builtin_amdgcn_raw_buffer_load_b64(rs, voff, soff, 0);
+            d[0] = v.x; d[1] = v.y;
+        } else {
+            d[0] = __builtin_amdgcn_raw_buffer_load_b32(rs, voff, soff, 0);
+        }
+    }
+    __device__ __forceinline__ void fetch(uint32_t row_off, uint32_t (&d)[GW]) const { load(rs_cols, (int)row_off, d); }
+    __device__ __forceinline__ void valid_of(uint32_t row_off, uint32_t (&v)[GW]) const {
+        load(rs_excl, (int)row_off, v);
+#pragma unroll
+        for (int i = 0; i < GW; i++) v[i] = bop<kSlAndNot>(live_mask, v[i], 0u);
+    }
+    // the lane's GW words of a ring slot move as one 4 / 8 / 16-byte LDS access
+    __device__ __forceinline__ void ring_put(uint32_t *p, const uint32_t (&v)[GW]) const {
+        if constexpr (GW == 4) *reinterpret_cast<u32x4 *>(p) = u32x4{v[0], v[1], v[2], v[3]};
+        else if constexpr (GW == 2) *reinterpret_cast<u32x2 *>(p) = u32x2{v[0], v[1]};
+        else p[0] = v[0];
+    }
+    __device__ __forceinline__ void ring_get(const uint32_t *p, uint32_t (&v)[GW]) const {
+        if constexpr (GW == 4) { const u32x4 t = *reinterpret_cast<const u32x4 *>(p); v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w; }
+        else if constexpr (GW == 2) { const u32x2 t = *reinterpret_cast<const u32x2 *>(p); v[0] = t.x; v[1] = t.y; }
+        else v[0] = p[0];
+    }
+    __device__ __forceinline__ void ring_zero(int k) {
+        uint32_t z[GW];
+#pragma unroll
+        for (int i = 0; i < GW; i++) z[i] = 0u;
+        for (int s = 0; s < k; s++) ring_put(ring + s * (64 * GW), z);
+    }
+    __device__ __forceinline__ void ring_swap(int slot, const uint32_t (&in)[GW], uint32_t (&o)[GW]) {
+        uint32_t *p = ring + slot * (64 * GW);
+        ring_get(p, o);
+        ring_put(p, in);
+    }
+    __device__ __forceinline__ void ring_read(int slot, uint32_t (&o)[GW]) const { ring_get(ring + slot * (64 * GW), o); }
+    // The wave's OUT counts of the item's 8 member slots into the workgroup's table: 12 words per item, two 16-bit counts each
+    // (registers 0-7: out1 | outF << 16 of slot q; 8-11: outR of slots 2 (q - 8), 2 (q - 8) + 1) — a workgroup covers 4 x 64 x 32 GW
+    // <= 32768 rows, so a field never carries.  Four DPP steps leave every row of 16 lanes with its sum, the rows' last lanes park
+    // theirs, lanes 0-11 add the four rows of their register and hand the packed pair to the table (ds_add, one address per lane:
+    // lanes of one wave never collide — eight lanes adding to ONE address took twice the whole kernel's time).
+    __device__ __forceinline__ void commit(int idx, const uint32_t (&accPF)[8], const uint32_t (&accR)[4]) {
+        uint32_t x[12];
+#pragma unroll
+        for (int q = 0; q < 8; q++) x[q] = accPF[q];
+#pragma unroll
+        for (int q = 0; q < 4; q++) x[8 + q] = accR[q];
+#pragma unroll
+        for (int q = 0; q < 12; q++) {
+            x[q] += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x[q], 0xB1, 0xF, 0xF, true);     // quad_perm [1,0,3,2]
+            x[q] += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x[q], 0x4E, 0xF, 0xF, true);     // quad_perm [2,3,0,1]
+            x[q] += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x[q], 0x141, 0xF, 0xF, true);    // row_half_mirror
+            x[q] += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x[q], 0x140, 0xF, 0xF, true);    // row_mirror: every lane = its row's sum
+        }
+        if ((lane & 15) == 15) {
+            u32x4 *row = reinterpret_cast<u32x4 *>(part + (lane >> 4) * 12);
+            row[0] = u32x4{x[0], x[1], x[2], x[3]};
+            row[1] = u32x4{x[4], x[5], x[6], x[7]};
+            row[2] = u32x4{x[8], x[9], x[10], x[11]};
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        if (lane < 12) atomicAdd(&tab[idx * 12 + lane], part[lane] + part[12 + lane] + part[24 + lane] + part[36 + lane]);
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();                            // `part` is written again by the next item
+    }
+};
+
+template <int LV, int GW>
+__global__ __launch_bounds__(kBlock) void eval_slide_kernel(const SlideKernArgs K) {
+    extern __shared__ __align__(16) uint32_t lds[];
+    const int slice = (int)(blockIdx.x % (unsigned)K.wc_pad), band = (int)(blockIdx.x / (unsigned)K.wc_pad);
+    if (slice >= K.wc) return;
+    const int wv = (int)(threadIdx.x >> 6), lane = (int)(threadIdx.x & 63);
+    const int ring_words = K.A.k * 64 * GW;
+    uint32_t *tab = lds + (kBlock / 64) * ring_words + (kBlock / 64) * 48;
+    DevEnv<GW> env(K);
+    env.lane = lane;
+    env.ring = lds + wv * ring_words + lane * GW;
+    env.part = lds + (kBlock / 64) * ring_words + wv * 48;
+    env.tab = tab;
+    env.itv = 0u;
+    const int word0 = (slice * kBlock + (int)threadIdx.x) * GW;
+    env.live = word0 < K.nw32;                         // nw32 is a multiple of 8 >= GW: a lane's words are inside the row or all past it
+    env.voff = env.live ? word0 * 4 : 0;
+    env.live_mask = env.live ? 0xFFFFFFFFu : 0u;
+    env.row_bytes = (uint32_t)K.nw32 * 4u;
+    env.rs_cols = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint32_t *>(K.cols32), 0, 0x7FFFFFFF, 0x00020000);
+    env.rs_excl = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint32_t *>(K.excl32), 0, 0x7FFFFFFF, 0x00020000);
+    const SlideBand bd = env.uband(band);
+    for (int i = (int)threadIdx.x; i < bd.n_items * 12; i += kBlock) tab[i] = 0u;
+    __syncthreads();
+    const bool wave_live = (slice * kBlock + wv * 64) * GW < K.nw32;          // some lane of the wave holds rows
+    if (wave_live) slide_band<LV, GW, true>(env, K.A, band);
+    __syncthreads();
+    // One flush per workgroup and band.  The table holds OUT rows; member t of an item reports its slot's counts turned round:
+    // perfect = rows - out1, forward (1..v mismatches, none at a strict position) = out1 - outF, reverse = out1 - outR.
+    int live_waves = 0;
+    for (int w = 0; w < kBlock / 64; w++) live_waves += (slice * kBlock + w * 64) * GW < K.nw32 ? 1 : 0;
+    const uint32_t rows = (uint32_t)live_waves * 64u * 32u * GW;
+    for (int i = (int)threadIdx.x; i < bd.n_items * 24; i += kBlock) {
+        const int item = i / 24, r = i % 24, t = r / 3, kind = r % 3;                  // 0 perfect, 1 forward, 2 reverse
+        const uint32_t *rec = K.A.recs + (size_t)(bd.item0 + item) * kSlideRec;
+        const int oc = (int)rec[8 + t];
+        if (oc < 0) continue;
+        const int slot = (int)((rec[26] >> (4 * t)) & 15u);
+        const uint32_t *row = tab + item * 12;
+        const uint32_t out1 = row[slot] & 0xFFFFu, outF = row[slot] >> 16, outR = (row[8 + (slot >> 1)] >> (16 * (slot & 1))) & 0xFFFFu;
+        const uint32_t val = kind == 0 ? rows - out1 : out1 - (kind == 1 ? outF : outR);
+        if (val) atomicAdd(&K.out[(size_t)oc * 3 + kind], (unsigned long long)val);
+    }
+}
+
+typedef void (*SlideFn)(const SlideKernArgs);
+
+}  // namespace
+
+namespace mp {
+
+void free_slide(mp_ctx *c) {
+    dev_free(c, &c->slide_bands, (size_t)c->slide_n_bands);
+    dev_free(c, &c->slide_iters, c->slide_n_iters);
+    dev_free(c, &c->slide_recs, (size_t)c->slide_items * kSlideRec);
+    dev_free(c, &c->chain_rest, (size_t)c->n_rest);
+    c->slide_items = c->slide_n_bands = c->slide_max_items = 0;
+    c->slide_n_iters = 0;
+    c->n_rest = c->rest_max_steps = 0;
+}
+
+// MP_EVAL_SLIDE=0 keeps the first-pass kernels; =1 forces the sliding kernel at any size; default: from 65536 rows up (below, a launch
+// is a handful of workgroups and the bands' warm-up columns outweigh what sliding saves).  MP_SLIDE_GW (1, 2, 4): row words per lane;
+// MP_SLIDE_BAND: windows per band.
+int upload_eval_slide(mp_ctx *c, const std::vector<ChainItem> &chains, const std::vector<uint32_t> &events, const std::vector<int32_t> &cand_out) {
+    free_slide(c);
+    const char *se = getenv("MP_EVAL_SLIDE");
+    if (chains.empty() || c->v > 3 || (se ? atoi(se) != 1 : c->n_pad < 65536)) return MP_OK;
+    const int nw32 = c->n_pad / 32, n_cols = c->n_chunks * 32;
+    if (((unsigned long long)n_cols * 4ull + 1ull) * (unsigned long long)nw32 * 4ull >= 0x7FFFFFFFull) return MP_OK;     // plane rows are addressed by a 32-bit scalar offset
+    if ((unsigned long long)c->n_win * (unsigned long long)nw32 * 4ull >= 0x7FFFFFFFull) return MP_OK;
+    int gw = nw32 >= 16384 ? 2 : 1;
+    if (const char *e = getenv("MP_SLIDE_GW")) { const int g = atoi(e); if (g == 1 || g == 2 || g == 4) gw = g; }
+    const int wc = (nw32 + kBlock * gw - 1) / (kBlock * gw);
+    // enough workgroups for 256 CUs x 4 resident workgroups a few times over, bands of 4..32 windows
+    int span = chains.back().win - chains.front().win + 1;
+    int band = std::max(4, std::min(32, (int)((long long)span * wc / 3072)));
+    if (const char *e = getenv("MP_SLIDE_BAND")) band = std::max(1, atoi(e));
+    std::vector<SlideChainIn> in(chains.size());
+    for (size_t i = 0; i < chains.size(); i++) {
+        const ChainItem &ch = chains[i];
+        in[i] = SlideChainIn{ch.win, ch.cand0, ch.n_steps, ch.ev0, ch.n_ev, {ch.sym[0], ch.sym[1], ch.sym[2], ch.sym[3]}};
+    }
+    SlidePlan P;
+    if (!build_slide_plan(in, events, cand_out, c->k, c->sF, c->sR, c->p0, n_cols, band, (uint32_t)nw32 * 4u, true, P)) return MP_OK;
+    P.iters.resize(P.iters.size() + 64, 0u);                      // uiter reads 64 words at a time
+    int rc;
+    if ((rc = dev_alloc(c, &c->slide_bands, P.bands.size()))) return rc;
+    c->slide_n_bands = (int)P.bands.size();
+    if ((rc = dev_alloc(c, &c->slide_iters, P.iters.size()))) return rc;
+    c->slide_n_iters = P.iters.size();
+    c->slide_items = (int)P.item_of.size();
+    if ((rc = dev_alloc(c, &c->slide_recs, P.recs.size()))) return rc;
+    HIPCK(c, hipMemcpy(c->slide_bands, P.bands.data(), sizeof(SlideBand) * P.bands.size(), hipMemcpyHostToDevice));
+    HIPCK(c, hipMemcpy(c->slide_iters, P.iters.data(), sizeof(uint32_t) * P.iters.size(), hipMemcpyHostToDevice));
+    HIPCK(c, hipMemcpy(c->slide_recs, P.recs.data(), sizeof(uint32_t) * P.recs.size(), hipMemcpyHostToDevice));
+    c->slide_max_items = P.max_items_band;
+    c->slide_ns = P.ns; c->slide_spos = P.spos; c->slide_fmask = P.fmask; c->slide_rmask = P.rmask;
+    c->slide_gw = gw;
+    if (!P.rest.empty()) {
+        std::vector<ChainItem> rest;
+        for (int32_t i : P.rest) { rest.push_back(chains[(size_t)i]); c->rest_max_steps = std::max(c->rest_max_steps, (int)chains[(size_t)i].n_steps); }
+        if ((rc = dev_alloc(c, &c->chain_rest, rest.size()))) return rc;
+        c->n_rest = (int)rest.size();
+        HIPCK(c, hipMemcpy(c->chain_rest, rest.data(), sizeof(ChainItem) * rest.size(), hipMemcpyHostToDevice));
+    }
+    return MP_OK;
+}
+
+int launch_eval_slide(mp_ctx *c, unsigned long long *device_out) {
+#define SLIDE_ROW(LV) {eval_slide_kernel<LV, 1>, eval_slide_kernel<LV, 2>, eval_slide_kernel<LV, 4>}
+    static const SlideFn fn[4][3] = {SLIDE_ROW(1), SLIDE_ROW(2), SLIDE_ROW(3), SLIDE_ROW(4)};
+#undef SLIDE_ROW
+    const int gw = c->slide_gw, gi = gw == 4 ? 2 : gw - 1;
+    const int nw32 = c->n_pad / 32;
+    SlideKernArgs K;
+    K.A = SlideArgs{c->slide_bands, c->slide_iters, c->slide_recs, c->k, c->p0, c->slide_ns, c->slide_spos, c->slide_fmask, c->slide_rmask,
+                    (uint32_t)nw32 * 4u};
+    K.cols32 = reinterpret_cast<const uint32_t *>(c->cols);
+    K.excl32 = reinterpret_cast<const uint32_t *>(c->excl);
+    K.nw32 = nw32;
+    K.out = device_out;
+    K.wc = (nw32 + kBlock * gw - 1) / (kBlock * gw);
+    K.wc_pad = K.wc >= 8 ? (K.wc + 7) / 8 * 8 : K.wc;
+    K.max_items = c->slide_max_items;
+    const size_t lds = ((size_t)(kBlock / 64) * ((size_t)c->k * 64 * gw + 48) + (size_t)c->slide_max_items * 12) * sizeof(uint32_t);
+    if (lds > 160 * 1024) return fail(c, MP_ERR_ARG, "sliding evaluation: a band needs %zu bytes of LDS", lds);
+    SlideFn f = fn[c->v][gi];
+    if (lds > 48 * 1024) HIPCK(c, hipFuncSetAttribute(reinterpret_cast<const void *>(f), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL(f, dim3((unsigned)c->slide_n_bands * (unsigned)K.wc_pad), dim3(kBlock), lds, c->stream, K);
+    HIPCK(c, hipGetLastError());
+    return MP_OK;
+}
+
+}  // namespace mp

@@ -1,0 +1,15 @@
+// evalslide.hpp — the sliding evaluation of nested refinement chains (evalslide.hip; plan: slideplan.hpp, band routine: slidecore.hpp).
+#pragma once
+
+#include "common.hpp"
+#include "slideplan.hpp"
+
+namespace mp {
+
+// Builds the plan for the staged chain items and uploads it; c->slide_items = 0 when nothing slides (the first-pass kernels keep
+// every item).  Items the plan leaves out are collected in c->chain_rest for the first-pass kernel.
+int upload_eval_slide(mp_ctx *c, const std::vector<ChainItem> &chains, const std::vector<uint32_t> &events, const std::vector<int32_t> &cand_out);
+int launch_eval_slide(mp_ctx *c, unsigned long long *device_out);
+void free_slide(mp_ctx *c);
+
+}  // namespace mp

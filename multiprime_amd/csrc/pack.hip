@@ -260,7 +260,8 @@ int mp_load_msa(mp_ctx *c, const uint8_t *bytes, const int64_t *row_off, int32_t
     if ((rc = dev_alloc(c, &d_bytes, (size_t)total + 64))) return rc;
     if ((rc = dev_alloc(c, &d_off, (size_t)n_rows + 1))) return rc;
     if ((rc = dev_alloc(c, &c->planes, (size_t)c->n_chunks * 4 * np))) return rc;
-    if ((rc = dev_alloc(c, &c->cols, (size_t)c->n_chunks * 32 * 4 * (np / 64)))) return rc;
+    // + one all-zero plane row behind the last column's: the sliding evaluation points plane-less fetches at it (evalslide.hip)
+    if ((rc = dev_alloc(c, &c->cols, ((size_t)c->n_chunks * 32 * 4 + 1) * (np / 64)))) return rc;
     if ((rc = dev_alloc(c, &c->cum, ((size_t)c->n_chunks + 1) * np))) return rc;
     if ((rc = dev_alloc(c, &c->ung, np * c->ustride))) return rc;
     if ((rc = dev_alloc(c, &c->lead, np))) return rc;
@@ -270,8 +271,9 @@ int mp_load_msa(mp_ctx *c, const uint8_t *bytes, const int64_t *row_off, int32_t
     for (int r = 0; r <= n_rows; r++) off0[r] = row_off[r] - row_off[0];
     HIPCK(c, hipMemcpyAsync(d_bytes, bytes + row_off[0], (size_t)total, hipMemcpyHostToDevice, c->stream));
     HIPCK(c, hipMemcpyAsync(d_off, off0.data(), sizeof(int64_t) * (n_rows + 1), hipMemcpyHostToDevice, c->stream));
-    const FillSeg init[3] = {{c->ung, sizeof(uint32_t) * np * c->ustride, 0u}, {c->rlen, sizeof(int32_t) * np, 0u}, {c->rstrip, sizeof(int32_t) * np, 0u}};
-    if ((rc = fill_segments(c, init, 3))) return rc;
+    const FillSeg init[4] = {{c->ung, sizeof(uint32_t) * np * c->ustride, 0u}, {c->rlen, sizeof(int32_t) * np, 0u}, {c->rstrip, sizeof(int32_t) * np, 0u},
+                             {c->cols + (size_t)c->n_chunks * 32 * 4 * (np / 64), sizeof(unsigned long long) * (np / 64), 0u}};
+    if ((rc = fill_segments(c, init, 4))) return rc;
     hipLaunchKernelGGL(pack_kernel, dim3((unsigned)(c->n_pad / kBlock), (unsigned)((c->n_chunks + kPackChunks - 1) / kPackChunks)), dim3(kBlock), 0,
                        c->stream, d_bytes, d_off, n_rows, c->n_pad, c->n_chunks, c->planes);
     hipLaunchKernelGGL(row_scan_kernel, dim3((unsigned)(c->n_pad / kBlock), (unsigned)kScanSegs), dim3(kBlock), 0, c->stream, c->planes, d_off, n_rows,

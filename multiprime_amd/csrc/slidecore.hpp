@@ -49,6 +49,8 @@ constexpr int kSlAndNot = slide_lut([](bool a, bool b, bool) { return a && !b; }
 constexpr int kSlOr3 = slide_lut([](bool a, bool b, bool c) { return a || b || c; });
 constexpr int kSlOrAnd = slide_lut([](bool a, bool b, bool c) { return a || (b && c); });                // a | (b & c)
 constexpr int kSlAndNotNot = slide_lut([](bool a, bool b, bool c) { return a && !b && !c; });
+constexpr int kSlOrNot = slide_lut([](bool a, bool b, bool) { return a || !b; });                         // a | ~b
+constexpr int kSlOrOrNot = slide_lut([](bool a, bool b, bool c) { return a || b || !c; });               // a | b | ~c
 
 SLIDE_HD int slide_popc(uint32_t x) {
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -76,44 +78,222 @@ struct SlideArgs {
     const uint32_t *recs;
     int k, p0, ns;
     uint32_t spos, fmask, rmask;
+    uint32_t row_scale;                // plane row -> what Env::fetch takes (bytes of a plane row on the GPU, 1 in the emulation)
 };
 
+// The planes an item needs beyond the sliding count: its event planes (entries 1 .. n_slots - 1) and the rows its window lets the
+// column-plane pass count.  Requested one item AHEAD of their use (slide_band), so that an item's memory latency hides behind the
+// arithmetic of the item before it.
+template <int GW>
+struct SlideFetch {
+    uint32_t d[kSlideKept + 1][GW];     // d[0] is unused
+    uint32_t valid[GW];
+};
+
+// Always the same eight requests (the rows of the window + seven planes; a slot the item does not have reads the all-zero row
+// behind the last column): no branch, so the loads stay in flight behind the item that is being computed.  The record holds what a
+// fetch takes as it stands.
+template <int GW, class Env>
+SLIDE_HD void slide_request(Env &env, const typename Env::Rec &rec, SlideFetch<GW> &F) {
+    env.valid_of(env.rec_word(rec, 29), F.valid);
+#pragma unroll
+    for (int s = 1; s <= kSlideKept; s++) env.fetch(env.rec_word(rec, s), F.d[s]);
+}
+
+// One item: all eight member slots, straight-line (a slot the item does not have repeats the counts of the one before it — its plane
+// is the all-zero row — and reports to nobody).  SIMPLE (the host's flag; every chain of a refinement run has it): every event plane is
+// the plane of a base beyond the reference — no per-plane masks in the carry-save sum.
+template <int LV, int GW, bool SIMPLE, class Env>
+SLIDE_HD void slide_item(Env &env, const SlideArgs &A, const typename Env::Rec &rec, uint32_t hdr, const SlideCount (&cnt)[GW],
+                         const uint32_t (&sv)[kSlideStrict][GW], const SlideFetch<GW> &F, uint32_t (&accPF)[8], uint32_t (&accR)[4]) {
+    const int n_extra = (int)((hdr >> 8) & 15u);
+    const uint32_t flags = env.rec_word(rec, 28);
+    // (b) mismatch count of the most degenerate member: the reference's count minus the planes of the bases it accepts beyond
+    // the reference — a 7-input carry-save sum, then a 5-bit minus 3-bit subtraction
+    SlideCount c0[GW];
+    uint32_t sub[kSlideKept + 1];
+#pragma unroll
+    for (int s = 1; s <= kSlideKept; s++) sub[s] = SIMPLE ? 0xFFFFFFFFu : (uint32_t)((int32_t)(flags << (15 - s)) >> 31);      // bit 16 + s
+#pragma unroll
+    for (int i = 0; i < GW; i++) {
+        uint32_t e[kSlideKept + 1];
+#pragma unroll
+        for (int s = 1; s <= kSlideKept; s++) e[s] = SIMPLE ? F.d[s][i] : (F.d[s][i] & sub[s]);
+        const uint32_t sa = bop<kSlXor3>(e[1], e[2], e[3]), ca = bop<kSlMaj>(e[1], e[2], e[3]);
+        const uint32_t sb = bop<kSlXor3>(e[4], e[5], e[6]), cb = bop<kSlMaj>(e[4], e[5], e[6]);
+        const uint32_t s0 = bop<kSlXor3>(sa, sb, e[7]), cc = bop<kSlMaj>(sa, sb, e[7]);
+        const uint32_t s1 = bop<kSlXor3>(ca, cb, cc), s2 = bop<kSlMaj>(ca, cb, cc);
+        const SlideCount c = cnt[i];
+        SlideCount r;
+        r.b0 = c.b0 ^ s0;
+        uint32_t br = bop<kSlAndNot>(s0, c.b0, 0u);
+        r.b1 = bop<kSlXor3>(c.b1, s1, br); br = bop<kSlBorrow>(c.b1, s1, br);
+        r.b2 = bop<kSlXor3>(c.b2, s2, br); br = bop<kSlBorrow>(c.b2, s2, br);
+        r.b3 = c.b3 ^ br; br = bop<kSlAndNot>(br, c.b3, 0u);
+        r.b4 = c.b4 ^ br;
+        c0[i] = r;
+    }
+    // corrections that are not events (rare): one plane each, straight onto the count
+    if (n_extra) {
+        const uint32_t row0 = env.rec_word(rec, 30);
+#pragma unroll 1
+        for (int x = 0; x < n_extra; x++) {
+            const uint32_t ex = env.rec_word_dyn(rec, 16 + x);
+            uint32_t pl[GW];
+            env.fetch(row0 + (ex & 127u) * A.row_scale, pl);
+            const uint32_t up = (ex & kSlSub) ? 0u : 0xFFFFFFFFu;
+#pragma unroll
+            for (int i = 0; i < GW; i++) slide_updown(c0[i], pl[i], up);
+        }
+    }
+    // Saturating thermometer counters of the walk, kept as "rows that are OUT": T[j] = "at least j mismatches" (T[1] also holds the
+    // rows the window does not count at all), DF / DR = "not a forward / reverse hit": more than v mismatches, a mismatch at a strict
+    // position, or not counted.  All of them only grow along the chain, so an event plane is one instruction per word and set, and what
+    // is counted per member slot is the OUT rows — the flush turns them round (perfect = rows - out1, forward = out1 - outF).
+    uint32_t T[4][GW], DF[GW], DR[GW];
+    const uint32_t sm_lo = env.rec_word(rec, 24), sm_hi = env.rec_word(rec, 25);
+#pragma unroll
+    for (int i = 0; i < GW; i++) DF[i] = DR[i] = 0u;
+    // strict positions of the most degenerate member: the reference's mismatch word there, minus the rows a SUB plane of that
+    // position takes back (they carry a base the member accepts)
+#pragma unroll
+    for (int q = 0; q < kSlideStrict; q++) {
+        if (q >= 4 && A.ns <= 4) break;
+        const uint32_t sm = ((q < 4 ? sm_lo : sm_hi) >> (8 * (q & 3))) & 255u;
+        uint32_t v[GW];
+#pragma unroll
+        for (int i = 0; i < GW; i++) v[i] = sv[q][i];
+        if (sm) {
+            uint32_t x[GW];
+#pragma unroll
+            for (int i = 0; i < GW; i++) x[i] = 0u;
+#pragma unroll
+            for (int s = 1; s <= kSlideKept; s++) {
+                const uint32_t m = (uint32_t)((int32_t)(sm << (31 - s)) >> 31);
+#pragma unroll
+                for (int i = 0; i < GW; i++) x[i] = bop<kSlOrAnd>(x[i], F.d[s][i], m);
+            }
+#pragma unroll
+            for (int i = 0; i < GW; i++) v[i] = bop<kSlAndNot>(v[i], x[i], 0u);
+        }
+        const uint32_t fF = (uint32_t)((int32_t)(A.fmask << (31 - q)) >> 31), fR = (uint32_t)((int32_t)(A.rmask << (31 - q)) >> 31);
+#pragma unroll
+        for (int i = 0; i < GW; i++) {
+            DF[i] = bop<kSlOrAnd>(DF[i], v[i], fF);
+            DR[i] = bop<kSlOrAnd>(DR[i], v[i], fR);
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < GW; i++) {
+        const SlideCount c = c0[i];
+        const uint32_t hi = bop<kSlOr3>(c.b2, c.b3, c.b4);
+        const uint32_t t1 = bop<kSlOr3>(c.b0, c.b1, hi), t2 = c.b1 | hi, t3 = bop<kSlOrAnd>(hi, c.b1, c.b0);
+        const uint32_t far = LV == 1 ? t1 : (LV == 2 ? t2 : (LV == 3 ? t3 : hi));
+        T[0][i] = bop<kSlOrNot>(t1, F.valid[i], 0u);                    // t1 | ~valid
+        T[1][i] = t2; T[2][i] = t3; T[3][i] = hi;
+        DF[i] = bop<kSlOrOrNot>(DF[i], far, F.valid[i]);
+        DR[i] = bop<kSlOrOrNot>(DR[i], far, F.valid[i]);
+    }
+    // (c) walk down the chain: event plane s, then member slot s is counted.  Counts leave in the layout the wave sums want:
+    // accPF[s] = out1 | outF << 16, accR[s / 2] = outR of an even slot | outR of the odd one << 16
+#pragma unroll
+    for (int s = 0; s < 8; s++) {
+        if (s > 0) {
+            const bool stF = (flags >> s) & 1u, stR = (flags >> (8 + s)) & 1u;
+#pragma unroll
+            for (int i = 0; i < GW; i++) {
+                const uint32_t d = F.d[s][i];
+                // one more mismatch puts a row OUT when it already has v of them (T[LV - 2]; any row when v = 0) or the position is strict
+                if (LV == 1 || stF) DF[i] |= d;
+                else DF[i] = bop<kSlOrAnd>(DF[i], d, T[LV >= 2 ? LV - 2 : 0][i]);
+                if (LV == 1 || stR) DR[i] |= d;
+                else DR[i] = bop<kSlOrAnd>(DR[i], d, T[LV >= 2 ? LV - 2 : 0][i]);
+                if (LV >= 4) T[2][i] = bop<kSlOrAnd>(T[2][i], T[1][i], d);
+                if (LV >= 3) T[1][i] = bop<kSlOrAnd>(T[1][i], T[0][i], d);
+                T[0][i] |= d;
+            }
+        }
+        uint32_t nP = 0, nF = 0, nR = 0;
+#pragma unroll
+        for (int i = 0; i < GW; i++) {
+            nP += (uint32_t)slide_popc(T[0][i]);
+            nF += (uint32_t)slide_popc(DF[i]);
+            nR += (uint32_t)slide_popc(DR[i]);
+        }
+        accPF[s] = nP | (nF << 16);
+        if (s & 1) accR[s >> 1] |= nR << 16;
+        else accR[s >> 1] = nR;
+    }
+}
+
 // One band.  Env provides (all arrays are [GW] words of this lane):
-//   uband(b) -> SlideBand, uiter(idx) -> uint32_t, urec(item, dword) -> uint32_t      wave-uniform values
-//   fetch(plane_row, d)                the lane's words of column plane row `plane_row` (= column * 4 + base)
-//   valid_of(window, v)                rows the column-plane pass may count for this window
-//   ring_swap(slot, in, out, have_old) out = ring[slot] (0 when !have_old); ring[slot] = in
-//   ring_read(slot, out)
-//   commit(item_in_band, item, acc)    the lane's packed counts of the item's 8 member slots (perfect | forward << 10 | reverse << 20)
-template <int LV, int GW, class Env>
+//   uband(b) -> SlideBand; load_iters(idx) then iter_word(j) = iteration word idx + j, j < 64             wave-uniform values
+//   Rec, load_rec(item) -> Rec, rec_word(rec, q) (q a constant), rec_word_dyn(rec, q)                      an item's record
+//   fetch(plane_row x row_scale, d)    the lane's words of column plane row `plane_row` (= column * 4 + base)
+//   valid_of(window x row_scale, v)    rows the column-plane pass may count for this window
+//   ring_zero(k); ring_swap(slot, in, out): out = ring[slot], ring[slot] = in; ring_read(slot, out)
+//   commit(item_in_band, accPF, accR)  the lane's OUT counts of the item's 8 member slots (layout: slide_item)
+// Software pipeline: the column sliding in is requested two iterations ahead, an item's record two items ahead, its planes one item
+// ahead — a wave has few neighbours on its SIMD (the ring takes LDS), so it hides its own latencies.  The two register sets of each
+// pipeline swap ROLES (two copies of the iteration, two of the item, by parity), never contents: a register copy would wait for the
+// youngest load, and so would a branch that picks the set.
+// ONLY_SIMPLE: the plan holds simple items without extra corrections only (build_slide_plan's simple_only; the GPU kernel).
+template <int LV, int GW, bool ONLY_SIMPLE, class Env>
 SLIDE_HD void slide_band(Env &env, const SlideArgs &A, int band_index) {
-    static_assert(LV >= 1 && LV <= 4 && 32 * GW < 1024, "three 10-bit counts per register");
+    static_assert(LV >= 1 && LV <= 4 && GW >= 1 && GW <= 4, "counter levels / words per lane");
     const SlideBand bd = env.uband(band_index);
     const int k = A.k;
     SlideCount cnt[GW];
 #pragma unroll
     for (int i = 0; i < GW; i++) cnt[i] = SlideCount{0u, 0u, 0u, 0u, 0u};
+    env.ring_zero(k);                                                   // a slot's first visitor slides nothing out
     int slot = 0;
-#pragma unroll 1
-    for (int t = -(k - 1); t < bd.n_win; t++) {
-        const uint32_t it0 = env.uiter(bd.iter0 + 2 * (t + k - 1)), it1 = env.uiter(bd.iter0 + 2 * (t + k - 1) + 1);
+    const int n_iter = bd.n_win + k - 1;                                // k - 1 warm-up columns, then one column per window
+    const int last_item = bd.item0 + bd.n_items - 1;
+    // item pipeline: records of the next two items, planes of the next one (set 0 first)
+    typename Env::Rec rec0 = env.load_rec(bd.item0), rec1 = env.load_rec(bd.item0 + 1 <= last_item ? bd.item0 + 1 : last_item);
+    SlideFetch<GW> F0, F1;
+    slide_request<GW>(env, rec0, F0);
+    int done = 0;                                                       // items of the band behind us
+    // column pipeline: iteration j's column waits in set j & 1
+    uint32_t bA[GW], bB[GW];
+    env.load_iters(bd.iter0);
+    env.fetch(env.iter_word(0), bA);
+    env.fetch(env.iter_word(n_iter > 1 ? 2 : 0), bB);
+
+    auto item = [&](typename Env::Rec &rec_cur, typename Env::Rec &rec_other, const SlideFetch<GW> &F_cur, SlideFetch<GW> &F_other,
+                    const uint32_t (&sv)[kSlideStrict][GW]) __attribute__((always_inline)) {
+        const int after = bd.item0 + done + 2;
+        const typename Env::Rec rec = rec_cur;
+        rec_cur = env.load_rec(after <= last_item ? after : last_item);
+        slide_request<GW>(env, rec_other, F_other);                    // (behind the band's last item: that item's again, unused)
+        const uint32_t hdr = env.rec_word(rec, 0);
+        uint32_t accPF[8], accR[4];
+        if (ONLY_SIMPLE || (hdr & kSlSimple)) slide_item<LV, GW, true>(env, A, rec, hdr, cnt, sv, F_cur, accPF, accR);
+        else slide_item<LV, GW, false>(env, A, rec, hdr, cnt, sv, F_cur, accPF, accR);
+        env.commit(done, accPF, accR);
+        done++;
+    };
+    // one iteration: the column waiting in `b` slides in, `b` is refilled with the column two iterations on, the window's items run
+    auto iteration = [&](uint32_t (&b)[GW], int j) __attribute__((always_inline)) {
+        const uint32_t it1 = env.iter_word(2 * j + 1);
         uint32_t bn[GW], bo[GW];
-        env.fetch(it0, bn);
 #pragma unroll
-        for (int i = 0; i < GW; i++) bn[i] = ~bn[i];                   // rows that do not carry the reference base here
-        env.ring_swap(slot, bn, bo, t >= 1);                           // the column sliding out shares the slot (k columns apart)
+        for (int i = 0; i < GW; i++) bn[i] = ~b[i];                    // rows that do not carry the reference base here
+        env.fetch(env.iter_word(2 * j + 4), b);                        // (past the band's end: a row of the next band, unused)
+        env.ring_swap(slot, bn, bo);                                   // the column sliding out shares the slot (k columns apart)
 #pragma unroll
         for (int i = 0; i < GW; i++) slide_updown(cnt[i], bn[i] ^ bo[i], bn[i]);
         const int slot_now = slot;
         slot = slot + 1 == k ? 0 : slot + 1;
         const int n_items = (int)(it1 >> 24);
-        if (t < 0 || n_items == 0) continue;
-        const int win = bd.w0 + t;
-        // mismatch words of the reference at the strict positions of this window, out of the ring
+        if (n_items == 0) return;                                      // warming up, or a window without chains
+        // mismatch words of the reference at the strict positions of this window, out of the ring (slots beyond the launch's strict
+        // positions read position 0 and meet empty masks)
         uint32_t sv[kSlideStrict][GW];
 #pragma unroll
         for (int q = 0; q < kSlideStrict; q++) {
-            if (q < A.ns) {
+            if (q < 4 || A.ns > 4) {
                 int s = slot_now + 1 + (int)((A.spos >> (5 * q)) & 31u);
                 if (s >= k) s -= k;
                 env.ring_read(s, sv[q]);
@@ -122,132 +302,23 @@ SLIDE_HD void slide_band(Env &env, const SlideArgs &A, int band_index) {
                 for (int i = 0; i < GW; i++) sv[q][i] = 0u;
             }
         }
-        uint32_t valid[GW];
-        env.valid_of(win, valid);
-        const int first = (int)(it1 & 0xFFFFFFu);
 #pragma unroll 1
         for (int ii = 0; ii < n_items; ii++) {
-            const int item = bd.item0 + first + ii;
-            const uint32_t hdr = env.urec(item, 0);
-            const int n_slots = (int)(hdr & 15u), n_extra = (int)((hdr >> 8) & 15u);
-            const uint32_t row0 = (uint32_t)(A.p0 + win) * 4u;
-            // (a) the event planes, once, into registers
-            uint32_t en[kSlideKept + 1], d[kSlideKept + 1][GW];
-#pragma unroll
-            for (int s = 1; s <= kSlideKept; s++) {
-                en[s] = s < n_slots ? env.urec(item, s) : 0u;
-                if (en[s] & kSlPresent) env.fetch(row0 + (en[s] & 127u), d[s]);
-                else {
-#pragma unroll
-                    for (int i = 0; i < GW; i++) d[s][i] = 0u;
-                }
-            }
-            // (b) mismatch count of the most degenerate member: the reference's count minus the planes of the bases it accepts beyond
-            // the reference — a 7-input carry-save sum, then a 5-bit minus 3-bit subtraction
-            uint32_t t1[GW], t2[GW], t3[GW], t4[GW], sf[GW], sr[GW];
-            SlideCount c0[GW];
-#pragma unroll
-            for (int i = 0; i < GW; i++) {
-                uint32_t e[kSlideKept + 1];
-#pragma unroll
-                for (int s = 1; s <= kSlideKept; s++) e[s] = (en[s] & kSlSub) ? d[s][i] : 0u;
-                const uint32_t sa = bop<kSlXor3>(e[1], e[2], e[3]), ca = bop<kSlMaj>(e[1], e[2], e[3]);
-                const uint32_t sb = bop<kSlXor3>(e[4], e[5], e[6]), cb = bop<kSlMaj>(e[4], e[5], e[6]);
-                const uint32_t s0 = bop<kSlXor3>(sa, sb, e[7]), cc = bop<kSlMaj>(sa, sb, e[7]);
-                const uint32_t s1 = bop<kSlXor3>(ca, cb, cc), s2 = bop<kSlMaj>(ca, cb, cc);
-                const SlideCount c = cnt[i];
-                SlideCount r;
-                r.b0 = c.b0 ^ s0;
-                uint32_t br = bop<kSlAndNot>(s0, c.b0, 0u);
-                r.b1 = bop<kSlXor3>(c.b1, s1, br); br = bop<kSlBorrow>(c.b1, s1, br);
-                r.b2 = bop<kSlXor3>(c.b2, s2, br); br = bop<kSlBorrow>(c.b2, s2, br);
-                r.b3 = c.b3 ^ br; br = bop<kSlAndNot>(br, c.b3, 0u);
-                r.b4 = c.b4 ^ br;
-                c0[i] = r;
-            }
-            // corrections that are not events (rare): one plane each, straight onto the count
-#pragma unroll 1
-            for (int x = 0; x < n_extra; x++) {
-                const uint32_t ex = env.urec(item, 16 + x);
-                uint32_t pl[GW];
-                env.fetch(row0 + (ex & 127u), pl);
-                const uint32_t up = (ex & kSlSub) ? 0u : 0xFFFFFFFFu;
-#pragma unroll
-                for (int i = 0; i < GW; i++) slide_updown(c0[i], pl[i], up);
-            }
-            // saturating thermometer counters of the walk: t_j = "at least j mismatches"
-#pragma unroll
-            for (int i = 0; i < GW; i++) {
-                const SlideCount c = c0[i];
-                const uint32_t hi = bop<kSlOr3>(c.b2, c.b3, c.b4);
-                t1[i] = bop<kSlOr3>(c.b0, c.b1, hi);
-                t2[i] = c.b1 | hi;
-                t3[i] = bop<kSlOrAnd>(hi, c.b1, c.b0);
-                t4[i] = hi;
-            }
-            // strict positions of the most degenerate member: the reference's mismatch word there, minus the rows a SUB plane of that
-            // position takes back (they carry a base the member accepts)
-            const uint32_t sm_lo = env.urec(item, 24), sm_hi = env.urec(item, 25);
-#pragma unroll
-            for (int i = 0; i < GW; i++) sf[i] = sr[i] = 0u;
-#pragma unroll
-            for (int q = 0; q < kSlideStrict; q++) {
-                if (q >= A.ns) break;
-                const uint32_t sm = ((q < 4 ? sm_lo : sm_hi) >> (8 * (q & 3))) & 255u;
-                uint32_t v[GW];
-#pragma unroll
-                for (int i = 0; i < GW; i++) v[i] = sv[q][i];
-                if (sm) {
-#pragma unroll
-                    for (int s = 1; s <= kSlideKept; s++)
-                        if ((sm >> s) & 1u) {
-#pragma unroll
-                            for (int i = 0; i < GW; i++) v[i] ^= d[s][i];
-                        }
-                }
-                const uint32_t fF = ((A.fmask >> q) & 1u) ? 0xFFFFFFFFu : 0u, fR = ((A.rmask >> q) & 1u) ? 0xFFFFFFFFu : 0u;
-#pragma unroll
-                for (int i = 0; i < GW; i++) {
-                    sf[i] = bop<kSlOrAnd>(sf[i], v[i], fF);
-                    sr[i] = bop<kSlOrAnd>(sr[i], v[i], fR);
-                }
-            }
-            // (c) walk down the chain: event plane s, then member slot s is counted
-            uint32_t acc[8];
-#pragma unroll
-            for (int s = 0; s < 8; s++) {
-                acc[s] = 0u;
-                if (s >= n_slots) continue;
-                if (s > 0 && (en[s] & kSlPresent)) {
-#pragma unroll
-                    for (int i = 0; i < GW; i++) {
-                        if (LV >= 4) t4[i] = bop<kSlOrAnd>(t4[i], t3[i], d[s][i]);
-                        if (LV >= 3) t3[i] = bop<kSlOrAnd>(t3[i], t2[i], d[s][i]);
-                        if (LV >= 2) t2[i] = bop<kSlOrAnd>(t2[i], t1[i], d[s][i]);
-                        t1[i] |= d[s][i];
-                    }
-                    if (en[s] & (kSlStrictF | kSlStrictR)) {
-                        const uint32_t fF = (en[s] & kSlStrictF) ? 0xFFFFFFFFu : 0u, fR = (en[s] & kSlStrictR) ? 0xFFFFFFFFu : 0u;
-#pragma unroll
-                        for (int i = 0; i < GW; i++) {
-                            sf[i] = bop<kSlOrAnd>(sf[i], d[s][i], fF);
-                            sr[i] = bop<kSlOrAnd>(sr[i], d[s][i], fR);
-                        }
-                    }
-                }
-                if ((int32_t)env.urec(item, 8 + s) < 0) continue;      // a slot in the middle of a step: no member to count
-                uint32_t nP = 0, nF = 0, nR = 0;
-#pragma unroll
-                for (int i = 0; i < GW; i++) {
-                    const uint32_t far = LV == 1 ? t1[i] : (LV == 2 ? t2[i] : (LV == 3 ? t3[i] : t4[i]));
-                    nP += (uint32_t)slide_popc(bop<kSlAndNot>(valid[i], t1[i], 0u));
-                    nF += (uint32_t)slide_popc(bop<kSlAndNotNot>(valid[i], far, sf[i]));
-                    nR += (uint32_t)slide_popc(bop<kSlAndNotNot>(valid[i], far, sr[i]));
-                }
-                acc[s] = nP | (nF << 10) | (nR << 20);
-            }
-            env.commit(first + ii, item, acc);
+            if (done & 1) item(rec1, rec0, F1, F0, sv);
+            else item(rec0, rec1, F0, F1, sv);
         }
+    };
+#pragma unroll 1
+    for (int base = 0; base < n_iter; base += 30) {                     // 64 iteration words = 32 iterations, two of them look-ahead
+        if (base) env.load_iters(bd.iter0 + 2 * base);
+        const int n_here = n_iter - base < 30 ? n_iter - base : 30;     // 30 is even: an iteration's parity is that of j
+        int j = 0;
+#pragma unroll 1
+        for (; j + 1 < n_here; j += 2) {
+            iteration(bA, j);
+            iteration(bB, j + 1);
+        }
+        if (j < n_here) iteration(bA, j);                               // (an odd tail ends the band)
     }
 }
 
