@@ -58,8 +58,10 @@ SHARD_ROWS = 131072            # what one GPU holds of it in the 8-GPU job
 DEFAULT_CEILINGS = {"valu_wave_instr_per_s_per_simd": 8.5e8, "l2_read_GBs": 31559.0, "source": "built-in defaults (profiles/r02_ubench.json missing)"}
 COUNTER_FILES = ("r04_counters.json", "r03_counters.json")
 # sources of the timed kernel (eval_chain_kernel and what it includes): the key of a counter entry
-KERNEL_SOURCES = ("eval.hip", "evalprog.hip", "bitslice.hpp", "common.hpp", "winwords.hpp", "evaltile.hpp", "evalprog.hpp")
-PROG_FROM_ROWS = 393216      # eval.hip (mp_eval_upload): from this many (padded) rows up the program-driven kernel walks the chains
+KERNEL_SOURCES = ("eval.hip", "evalprog.hip", "evalslide.hip", "slidecore.hpp", "slideplan.hpp", "evalslide.hpp", "bitslice.hpp", "common.hpp",
+                  "winwords.hpp", "evaltile.hpp", "evalprog.hpp")
+SLIDE_FROM_ROWS = 393216     # evalslide.hip (upload_eval_slide): from this many (padded) rows up the chains are evaluated by sliding
+PROG_FROM_ROWS = 393216      # eval.hip (mp_eval_upload): the program-driven first-pass kernel, when sliding is switched off
 
 KERNELS = {
     "chain": "eval_chain_kernel (bit-sliced one-hot column planes, nested refinement chains; patch rows ride in the same launch)",
@@ -67,6 +69,8 @@ KERNELS = {
     "rows": "eval_kernel (row-per-lane, window words derived from the planes)",
     "tile": "eval_tile_kernel (column planes of a band of windows in an LDS ring) + eval_chain_kernel on the patch planes",
     "prog": "eval_prog_kernel (eval_chain_kernel's arithmetic, host-written fetch programs, buffer loads, event planes parked in LDS; patch rows ride in the same launch)",
+    "slide": "eval_slide_kernel (5-bit bit-sliced mismatch count of a per-column reference sliding along the windows, event planes fetched once per chain; "
+             "patch rows on eval_chain_kernel in the same step)",
 }
 
 
@@ -79,6 +83,8 @@ def eval_mode(n_rows=0):
         return "table"
     if os.environ.get("MP_EVAL_TILE", "0") in ("2", "4"):
         return "tile"
+    if os.environ.get("MP_EVAL_SLIDE", "1" if n_rows >= SLIDE_FROM_ROWS else "0") == "1":
+        return "slide"
     if os.environ.get("MP_EVAL_PROG", "1" if n_rows >= PROG_FROM_ROWS else "0") == "1":
         return "prog"
     return "chain"

@@ -94,8 +94,9 @@ void free_windows(mp_ctx *c) {
     dev_free(c, &c->ex, (size_t)c->ex_cap);
     dev_free(c, &c->ex_count, 1);
     dev_free(c, &c->err_flag, 4);
+    dev_free(c, &c->qplanes, c->pp_words); dev_free(c, &c->qvalid, c->pv_words);
     dev_free(c, &c->pplanes, c->pp_words); dev_free(c, &c->pvalid, c->pv_words); dev_free(c, &c->pwin, (size_t)c->n_win);
-    c->pp_words = c->pv_words = 0; c->max_npw = 0; c->pp_dirty = true;
+    c->pp_words = c->pv_words = 0; c->max_npw = 0; c->pp_dirty = true; c->qp_dirty = true;
     dev_free(c, &c->extra_off, (size_t)c->n_win + 1);
     dev_free(c, &c->extra_words, (size_t)3 * c->n_extra);
     c->ex_cap = 0; c->n_extra = 0; c->n_win = 0;

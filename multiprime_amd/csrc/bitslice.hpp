@@ -88,7 +88,7 @@ __device__ __forceinline__ void block_commit(const uint32_t (&accP)[8], const ui
 // (`row`, 12 words), lanes 0..23 add them.
 template <int GW>
 __device__ __forceinline__ void wave_commit(const uint32_t (&accP)[8], const uint32_t (&accF)[8], const uint32_t (&accR)[8],
-                                            uint32_t *row, const int32_t *cand_out, unsigned long long *out) {
+                                            uint32_t *row, const int32_t *cand_out, unsigned long long *out, bool negative = false) {
     constexpr int CC = 8;
     uint32_t vals[3 * CC];
 #pragma unroll
@@ -110,7 +110,7 @@ __device__ __forceinline__ void wave_commit(const uint32_t (&accP)[8], const uin
         const uint32_t perfect = (row[(3 * c) >> 1] >> (16 * ((3 * c) & 1))) & 0xFFFFu;
         const uint32_t val = r ? mine - perfect : mine;
         const int oc = cand_out[c];
-        if (oc >= 0 && val) atomicAdd(&out[(size_t)oc * 3 + r], (unsigned long long)val);
+        if (oc >= 0 && val) atomicAdd(&out[(size_t)oc * 3 + r], negative ? 0ull - (unsigned long long)val : (unsigned long long)val);
     }
 }
 
@@ -122,6 +122,13 @@ struct PatchArgs {
     int per_item;              // patch units per item (0: no patch rows anywhere); a unit = one WAVE in the evaluation kernels
                                // (4 items' patch planes per workgroup: they are a few hundred rows each), one workgroup in window_stats
     int n_blocks;              // workgroups holding the units, rounded up to a multiple of 8; they come first in the grid
+    // Sliding evaluation (evalslide.hip): its column pass counts EVERY row of a window (no exclusion words), so the rows of the patch
+    // list are counted there as plain column slices although their k-mer is the repaired one.  A second run of neg_blocks workgroups
+    // (blockIdx in [n_blocks, n_blocks + neg_blocks)) evaluates exactly those plain slices, on planes of their own, for the items that
+    // slide (EvalChainArgs::neg_items) and SUBTRACTS what it finds.
+    const uint32_t *qplanes;
+    const uint32_t *qvalid;
+    int neg_blocks;            // 0: no second run
 };
 
 struct WordTile {
@@ -152,6 +159,18 @@ __device__ __forceinline__ WordTile patch_tile(const PatchArgs &P, int win, int 
     t.stride = (uint32_t)pw.npw;
     t.mask_flip = 0u;
     t.live = word0 < pw.npw;                           // npw % 8 == 0
+    return t;
+}
+
+// ... or of the plain column slices of the window's patch-list rows (the subtracting run)
+__device__ __forceinline__ WordTile plain_tile(const PatchArgs &P, int win, int word0) {
+    const PatchWin pw = P.pwin[win];
+    WordTile t;
+    t.planes = P.qplanes + pw.poff + word0;
+    t.mask = P.qvalid + pw.voff + word0;
+    t.stride = (uint32_t)pw.npw;
+    t.mask_flip = 0u;
+    t.live = word0 < pw.npw;
     return t;
 }
 

@@ -119,6 +119,8 @@ struct mp_ctx {
     // (position-major, like `cols` but per window), so the bit-sliced kernels cover them too; built on demand
     std::vector<int32_t> h_patch_off, h_extra_off;       // host copies of the two per-window offset tables
     uint32_t *pplanes = nullptr, *pvalid = nullptr;
+    uint32_t *qplanes = nullptr, *qvalid = nullptr;      // plain column slices of the patch-list rows (sliding evaluation), same layout
+    bool qp_dirty = true;
     mp::PatchWin *pwin = nullptr;                        // [W]
     size_t pp_words = 0, pv_words = 0;
     int max_npw = 0;                                     // widest window, in 32-row words
@@ -166,6 +168,7 @@ struct mp_ctx {
     int slide_items = 0, slide_n_bands = 0, slide_max_items = 0, slide_ns = 0, slide_gw = 0;
     uint32_t slide_spos = 0, slide_fmask = 0, slide_rmask = 0;
     mp::ChainItem *chain_rest = nullptr;     // the chain items the plan leaves to the first-pass kernel
+    mp::ChainItem *chain_slid = nullptr;     // the chain items that slide (slide_items of them): the patch pass subtracts their plain slices
     int n_rest = 0, rest_max_steps = 0;
     mp::TileRound *tile_rounds = nullptr;
     mp::TileBand *tile_bands = nullptr;

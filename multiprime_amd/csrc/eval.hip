@@ -246,6 +246,56 @@ __global__ __launch_bounds__(kBlock) void patch_planes_kernel(const int32_t *__r
     }
 }
 
+// The same layout for the PLAIN column slices of the window's patch-list rows (the extra rows have none): bit (position j, base b) =
+// the row carries base b at column p0 + win + j — straight out of the row-major bit planes; a gap and an IUPAC cell set none,
+// exactly as the column planes hold them.  Validity = every patch-list row.  (Sliding evaluation: PatchArgs::qplanes.)
+__global__ __launch_bounds__(kBlock) void plain_planes_kernel(const int32_t *__restrict__ off_a, const int32_t *__restrict__ rows_a,
+                                                              const PatchWin *__restrict__ pwin, const PatchRun *__restrict__ runs,
+                                                              const uint32_t *__restrict__ planes, int n_pad, int n_chunks, int p0, int k,
+                                                              uint32_t *__restrict__ qplanes, uint32_t *__restrict__ qvalid) {
+    const PatchRun run = runs[blockIdx.x];
+    const int win = run.win;
+    const PatchWin pw = pwin[win];
+    const int na = off_a ? off_a[win + 1] - off_a[win] : 0;
+    const uint32_t kmask = (1u << k) - 1u;
+    const int lane = threadIdx.x & 63;
+    const int p = p0 + win, c0 = p >> 5, sh = p & 31;
+    const size_t np = (size_t)n_pad;
+    const int end = min(run.row0 + kPatchRun, pw.npw * 32);
+    for (int r0 = run.row0 + (threadIdx.x >> 6) * 64; r0 < end; r0 += kBlock) {    // uniform per wave
+        const int e = r0 + lane;
+        const bool ok = e < na;
+        uint32_t m[4] = {0u, 0u, 0u, 0u};
+        if (ok) {
+            const int r = rows_a[(size_t)off_a[win] + e];
+#pragma unroll
+            for (int b = 0; b < 4; b++) {
+                const uint32_t lo = planes[((size_t)c0 * 4 + b) * np + r];
+                const uint32_t hi = c0 + 1 < n_chunks ? planes[((size_t)(c0 + 1) * 4 + b) * np + r] : 0u;
+                m[b] = (sh ? (lo >> sh) | (hi << (32 - sh)) : lo) & kmask;
+            }
+            const uint32_t multi = (m[0] & (m[1] | m[2] | m[3])) | (m[1] & (m[2] | m[3])) | (m[2] & m[3]);     // IUPAC cells: none set, as colplane_kernel leaves them
+#pragma unroll
+            for (int b = 0; b < 4; b++) m[b] &= ~multi;
+        }
+        const unsigned long long okb = __ballot(ok);
+        const int w0 = r0 >> 5;
+        if (lane == 0) *reinterpret_cast<uint2 *>(qvalid + pw.voff + w0) = uint2{(uint32_t)okb, (uint32_t)(okb >> 32)};
+        unsigned long long mine = 0, mine2 = 0;
+        for (int j = 0; j < k; j++) {
+#pragma unroll
+            for (int b = 0; b < 4; b++) {
+                const unsigned long long bal = __ballot((m[b] >> j) & 1u);
+                const int slot = j * 4 + b;
+                if (lane == (slot & 63)) { if (slot < 64) mine = bal; else mine2 = bal; }
+            }
+        }
+        if (lane < k * 4) *reinterpret_cast<uint2 *>(qplanes + pw.poff + (size_t)lane * pw.npw + w0) = uint2{(uint32_t)mine, (uint32_t)(mine >> 32)};
+        if (lane + 64 < k * 4)
+            *reinterpret_cast<uint2 *>(qplanes + pw.poff + (size_t)(lane + 64) * pw.npw + w0) = uint2{(uint32_t)mine2, (uint32_t)(mine2 >> 32)};
+    }
+}
+
 // ----------------------------------------------------------------------------------------------
 // (4b) bit-sliced evaluation: 32 sequences per register word
 // ----------------------------------------------------------------------------------------------
@@ -487,6 +537,8 @@ struct EvalChainArgs {
     unsigned long long *out;
     BlockMap map;
     PatchArgs patch;                   // patch / IUPAC rows: the first patch.n_blocks workgroups run on their planes
+    const ChainItem *neg_items;        // the items of the subtracting run (patch.neg_blocks workgroups), n_neg of them
+    int n_neg;
 };
 
 // One pass of the first candidate over the positions in `rem` whose symbol has NB bases (NB = 4: three or four,
@@ -564,20 +616,25 @@ __global__ __launch_bounds__(kBlock) void eval_chain_kernel(const EvalChainArgs 
     static_assert(GW <= 8, "plane rows are padded to multiples of 8 words");
     constexpr int CC = 8;
     __shared__ uint32_t s_part[kBlock / 64][3 * CC / 2];
-    const bool on_patch = (int)blockIdx.x < A.patch.n_blocks;
+    // the patch units come first; a second run of them (sliding evaluation) subtracts the plain slices of the items that slide
+    const int patch_blocks = A.patch.n_blocks + A.patch.neg_blocks;
+    const bool on_patch = (int)blockIdx.x < patch_blocks;
+    const bool negative = on_patch && (int)blockIdx.x >= A.patch.n_blocks;
     int slice, item, word0;
     if (on_patch) {                                    // a wave per patch unit: everything below is wave-uniform
-        const int unit = __builtin_amdgcn_readfirstlane((int)(blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6)));
+        const int pb = (int)blockIdx.x - (negative ? A.patch.n_blocks : 0);
+        const int unit = __builtin_amdgcn_readfirstlane(pb * (kBlock / 64) + (int)(threadIdx.x >> 6));
         item = unit / A.patch.per_item;
         slice = unit % A.patch.per_item;
-        if (item >= A.map.n_items) return;
+        if (item >= (negative ? A.n_neg : A.map.n_items)) return;
         word0 = (slice * 64 + (int)(threadIdx.x & 63)) * GW;
     } else {
-        if (!map_block(A.map, blockIdx.x - A.patch.n_blocks, slice, item)) return;
+        if (!map_block(A.map, blockIdx.x - patch_blocks, slice, item)) return;
         word0 = (slice * kBlock + threadIdx.x) * GW;
     }
-    const ChainItem it = A.items[item];
-    const WordTile T = on_patch ? patch_tile(A.patch, it.win, word0) : column_tile(A.cols, A.excl, A.nw, A.p0, it.win, word0);
+    const ChainItem it = negative ? A.neg_items[item] : A.items[item];
+    const WordTile T = !on_patch ? column_tile(A.cols, A.excl, A.nw, A.p0, it.win, word0)
+                                 : (negative ? plain_tile(A.patch, it.win, word0) : patch_tile(A.patch, it.win, word0));
     if (on_patch && slice * 64 * GW >= (int)T.stride) return;               // nothing of this window's patch planes left for the wave
     const size_t nw32 = T.stride;
     const bool live = T.live;
@@ -657,7 +714,7 @@ __global__ __launch_bounds__(kBlock) void eval_chain_kernel(const EvalChainArgs 
     uint32_t accP[CC], accF[CC], accR[CC];
 #pragma unroll
     for (int c = 0; c < CC; c++) { accP[c] = acc[c] & 1023u; accF[c] = (acc[c] >> 10) & 1023u; accR[c] = acc[c] >> 20; }
-    if (on_patch) wave_commit<GW>(accP, accF, accR, s_part[threadIdx.x >> 6], A.cand_out + it.cand0, A.out);
+    if (on_patch) wave_commit<GW>(accP, accF, accR, s_part[threadIdx.x >> 6], A.cand_out + it.cand0, A.out, negative);
     else block_commit<GW>(accP, accF, accR, s_part, A.cand_out + it.cand0, A.out);
 }
 
@@ -670,20 +727,25 @@ __global__ __launch_bounds__(kBlock) void eval_chain_long_kernel(const EvalChain
     static_assert(GW <= 8, "plane rows are padded to multiples of 8 words");
     constexpr int CC = 8;
     __shared__ uint32_t s_part[kBlock / 64][3 * CC / 2];
-    const bool on_patch = (int)blockIdx.x < A.patch.n_blocks;
+    // the patch units come first; a second run of them (sliding evaluation) subtracts the plain slices of the items that slide
+    const int patch_blocks = A.patch.n_blocks + A.patch.neg_blocks;
+    const bool on_patch = (int)blockIdx.x < patch_blocks;
+    const bool negative = on_patch && (int)blockIdx.x >= A.patch.n_blocks;
     int slice, item, word0;
     if (on_patch) {                                    // a wave per patch unit: everything below is wave-uniform
-        const int unit = __builtin_amdgcn_readfirstlane((int)(blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6)));
+        const int pb = (int)blockIdx.x - (negative ? A.patch.n_blocks : 0);
+        const int unit = __builtin_amdgcn_readfirstlane(pb * (kBlock / 64) + (int)(threadIdx.x >> 6));
         item = unit / A.patch.per_item;
         slice = unit % A.patch.per_item;
-        if (item >= A.map.n_items) return;
+        if (item >= (negative ? A.n_neg : A.map.n_items)) return;
         word0 = (slice * 64 + (int)(threadIdx.x & 63)) * GW;
     } else {
-        if (!map_block(A.map, blockIdx.x - A.patch.n_blocks, slice, item)) return;
+        if (!map_block(A.map, blockIdx.x - patch_blocks, slice, item)) return;
         word0 = (slice * kBlock + threadIdx.x) * GW;
     }
-    const ChainItem it = A.items[item];
-    const WordTile T = on_patch ? patch_tile(A.patch, it.win, word0) : column_tile(A.cols, A.excl, A.nw, A.p0, it.win, word0);
+    const ChainItem it = negative ? A.neg_items[item] : A.items[item];
+    const WordTile T = !on_patch ? column_tile(A.cols, A.excl, A.nw, A.p0, it.win, word0)
+                                 : (negative ? plain_tile(A.patch, it.win, word0) : patch_tile(A.patch, it.win, word0));
     if (on_patch && slice * 64 * GW >= (int)T.stride) return;               // nothing of this window's patch planes left for the wave
     const size_t nw32 = T.stride;
     const bool live = T.live;
@@ -755,7 +817,7 @@ __global__ __launch_bounds__(kBlock) void eval_chain_long_kernel(const EvalChain
             }
         }
         if (on_patch) {
-            wave_commit<GW>(accP, accF, accR, s_part[threadIdx.x >> 6], A.cand_out + it.cand0 + g0, A.out);
+            wave_commit<GW>(accP, accF, accR, s_part[threadIdx.x >> 6], A.cand_out + it.cand0 + g0, A.out, negative);
         } else {
             if (g0) __syncthreads();                       // the previous group's totals have been read out of s_part
             block_commit<GW>(accP, accF, accR, s_part, A.cand_out + it.cand0 + g0, A.out);
@@ -1023,6 +1085,35 @@ int ensure_patch_planes(mp_ctx *c) {
     return MP_OK;
 }
 
+// The plain-slice planes of the patch-list rows (same sizes and offsets as the patch planes): built when the sliding evaluation first
+// needs them after the window lists changed.
+int ensure_plain_planes(mp_ctx *c) {
+    int rc = ensure_patch_planes(c);
+    if (rc) return rc;
+    if (!c->qp_dirty) return MP_OK;
+    dev_free(c, &c->qplanes, c->pp_words); dev_free(c, &c->qvalid, c->pv_words);
+    if (c->pp_words == 0) { c->qp_dirty = false; return MP_OK; }
+    if ((rc = dev_alloc(c, &c->qplanes, c->pp_words))) return rc;
+    if ((rc = dev_alloc(c, &c->qvalid, c->pv_words))) return rc;
+    std::vector<PatchRun> runs;
+    for (size_t w = 0; w < (size_t)c->n_win; w++) {
+        const int n = (c->h_patch_off[w + 1] - c->h_patch_off[w]) + (c->h_extra_off[w + 1] - c->h_extra_off[w]);
+        const int npw = ((n + 31) / 32 + 7) / 8 * 8;
+        for (int r0 = 0; r0 < npw * 32; r0 += kPatchRun) runs.push_back(PatchRun{(int32_t)w, r0});
+    }
+    PatchRun *d_runs = nullptr;
+    if ((rc = dev_alloc(c, &d_runs, runs.size()))) return rc;
+    HIPCK(c, hipMemcpyAsync(d_runs, runs.data(), sizeof(PatchRun) * runs.size(), hipMemcpyHostToDevice, c->stream));
+    hipLaunchKernelGGL(plain_planes_kernel, dim3((unsigned)runs.size()), dim3(kBlock), 0, c->stream,
+                       c->n_patch ? c->patch_off : (const int32_t *)nullptr, (const int32_t *)c->patch_rows, c->pwin, d_runs, c->planes, c->n_pad,
+                       c->n_chunks, c->p0, c->k, c->qplanes, c->qvalid);
+    HIPCK(c, hipGetLastError());
+    HIPCK(c, hipStreamSynchronize(c->stream));
+    dev_free(c, &d_runs, runs.size());
+    c->qp_dirty = false;
+    return MP_OK;
+}
+
 // workgroups of a bit-sliced launch: n_items items x the row slices of nw 64-bit words at GW 32-bit words per thread (bitslice.hpp)
 BlockMap make_block_map(int nw, int GW, int n_items, unsigned &grid) {
     BlockMap m;
@@ -1037,7 +1128,7 @@ BlockMap make_block_map(int nw, int GW, int n_items, unsigned &grid) {
 
 // patch units of a launch over n_items items with GW words per thread and unit_threads threads per unit
 PatchArgs patch_args(const mp_ctx *c, int GW, int n_items, int unit_threads) {
-    PatchArgs pa{c->pplanes, c->pvalid, c->pwin, 0, 0};
+    PatchArgs pa{c->pplanes, c->pvalid, c->pwin, 0, 0, nullptr, nullptr, 0};
     if (c->max_npw > 0 && n_items > 0) {
         pa.per_item = (c->max_npw + unit_threads * GW - 1) / (unit_threads * GW);
         const long long units = (long long)pa.per_item * n_items, per_block = kBlock / unit_threads;
@@ -1336,7 +1427,7 @@ int mp_eval_launch(mp_ctx *c, int64_t *device_out) {
             unsigned grid;
             const BlockMap bm = block_map(cgw[cshape], c->n_chain, grid);
             EvalChainArgs ca{c->cols, c->excl, nw, c->p0, c->k, c->v, c->chain_items, c->chain_events, c->cand_out, c->sF, c->sR,
-                             (unsigned long long *)device_out, bm, patch_args(c, cgw[cshape], c->n_chain, 64)};
+                             (unsigned long long *)device_out, bm, patch_args(c, cgw[cshape], c->n_chain, 64), nullptr, 0};
             // LDS-tiled sweep (evaltile.hip) for chains of up to 8 members: the column planes of a band of windows are staged once
             // per workgroup instead of being re-read from L2 by every covering window.  Measured SLOWER than the kernels below
             // at every size (profiles/r03_tile_*.txt), so it runs only on request: MP_EVAL_TILE=2 / 4 row
@@ -1344,14 +1435,23 @@ int mp_eval_launch(mp_ctx *c, int64_t *device_out) {
             if (c->slide_items > 0) {
                 // sliding evaluation: the patch planes of ALL chain items and the column planes of the items the plan left out run on
                 // the first-pass kernel, the rest slides
-                if (ca.patch.n_blocks)
-                    hipLaunchKernelGGL((c->max_steps > kEvalCC ? lfn : cfn)[c->v][cshape], dim3((unsigned)ca.patch.n_blocks), dim3(kBlock), 0, c->stream, ca);
+                // (the sliding kernel counts every row of a window as a plain column slice: the patch planes add the patch-list rows'
+                // real k-mers, their plain-slice planes take the plain counts back — the exclusion words are not read at all)
+                if (ca.patch.n_blocks) {
+                    { int rc = ensure_plain_planes(c); if (rc) return rc; }
+                    EvalChainArgs pa2 = ca;
+                    const PatchArgs neg = patch_args(c, cgw[cshape], c->slide_items, 64);
+                    pa2.patch.qplanes = c->qplanes; pa2.patch.qvalid = c->qvalid; pa2.patch.neg_blocks = neg.n_blocks;
+                    pa2.neg_items = c->chain_slid; pa2.n_neg = c->slide_items;
+                    hipLaunchKernelGGL((c->max_steps > kEvalCC ? lfn : cfn)[c->v][cshape], dim3((unsigned)(ca.patch.n_blocks + neg.n_blocks)),
+                                       dim3(kBlock), 0, c->stream, pa2);
+                }
                 if (c->n_rest) {
                     unsigned rgrid;
                     const BlockMap rbm = block_map(cgw[cshape], c->n_rest, rgrid);
-                    PatchArgs none{nullptr, nullptr, nullptr, 0, 0};
+                    PatchArgs none{nullptr, nullptr, nullptr, 0, 0, nullptr, nullptr, 0};
                     EvalChainArgs ra{c->cols, c->excl, nw, c->p0, c->k, c->v, c->chain_rest, c->chain_events, c->cand_out, c->sF, c->sR,
-                                     (unsigned long long *)device_out, rbm, none};
+                                     (unsigned long long *)device_out, rbm, none, nullptr, 0};
                     hipLaunchKernelGGL((c->rest_max_steps > kEvalCC ? lfn : cfn)[c->v][cshape], dim3(rgrid), dim3(kBlock), 0, c->stream, ra);
                 }
                 int rc = launch_eval_slide(c, (unsigned long long *)device_out);
@@ -1508,7 +1608,7 @@ int mp_eval_masks_resident(mp_ctx *c, int32_t n_cand, const int32_t *cw, const u
                                           eval_bits_kernel<3, 2, true, 1, true>, eval_bits_kernel<4, 2, true, 1, true>};
         unsigned grid;
         const BlockMap bm = make_block_map((int)nw, 2, c->n_items, grid);
-        PatchArgs none{nullptr, nullptr, nullptr, 0, 0};
+        PatchArgs none{nullptr, nullptr, nullptr, 0, 0, nullptr, nullptr, 0};
         EvalBitsArgs ba{c->cols, c->excl, (int)nw, c->p0, c->k, c->v, c->items, c->cand_symT, c->cand_out, c->sF, c->sR, nullptr, bm, c->cand_diff,
                         nullptr, none, reinterpret_cast<uint32_t *>(c->mask_f), reinterpret_cast<uint32_t *>(c->mask_r), c->n_rows};
         hipLaunchKernelGGL(mfn[c->v], dim3(grid), dim3(kBlock), 0, c->stream, ba);

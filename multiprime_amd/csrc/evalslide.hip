@@ -101,11 +101,7 @@ struct DevEnv {
         for (int i = 0; i < GW; i++) z[i] = 0u;
         for (int s = 0; s < k; s++) ring_put(ring + s * (64 * GW), z);
     }
-    __device__ __forceinline__ void ring_swap(int slot, const uint32_t (&in)[GW], uint32_t (&o)[GW]) {
-        uint32_t *p = ring + slot * (64 * GW);
-        ring_get(p, o);
-        ring_put(p, in);
-    }
+    __device__ __forceinline__ void ring_write(int slot, const uint32_t (&in)[GW]) { ring_put(ring + slot * (64 * GW), in); }
     __device__ __forceinline__ void ring_read(int slot, uint32_t (&o)[GW]) const { ring_get(ring + slot * (64 * GW), o); }
     // The wave's OUT counts of the item's 8 member slots into the workgroup's table: 12 words per item, two 16-bit counts each
     // (registers 0-7: out1 | outF << 16 of slot q; 8-11: outR of slots 2 (q - 8), 2 (q - 8) + 1) — a workgroup covers 4 x 64 x 32 GW
@@ -156,16 +152,16 @@ __global__ __launch_bounds__(kBlock) void eval_slide_kernel(const SlideKernArgs 
     env.itv = 0u;
     const int word0 = (slice * kBlock + (int)threadIdx.x) * GW;
     env.live = word0 < K.nw32;                         // nw32 is a multiple of 8 >= GW: a lane's words are inside the row or all past it
-    env.voff = env.live ? word0 * 4 : 0;
+    env.voff = env.live ? word0 * 4 : 0x7FFFFF00;           // past num_records: a lane without rows reads zeros (all gaps: never counted)
     env.live_mask = env.live ? 0xFFFFFFFFu : 0u;
     env.row_bytes = (uint32_t)K.nw32 * 4u;
-    env.rs_cols = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint32_t *>(K.cols32), 0, 0x7FFFFFFF, 0x00020000);
-    env.rs_excl = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint32_t *>(K.excl32), 0, 0x7FFFFFFF, 0x00020000);
+    env.rs_cols = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint32_t *>(K.cols32), 0, 0x7FFFFF00, 0x00020000);
+    env.rs_excl = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint32_t *>(K.excl32), 0, 0x7FFFFF00, 0x00020000);
     const SlideBand bd = env.uband(band);
     for (int i = (int)threadIdx.x; i < bd.n_items * 12; i += kBlock) tab[i] = 0u;
     __syncthreads();
     const bool wave_live = (slice * kBlock + wv * 64) * GW < K.nw32;          // some lane of the wave holds rows
-    if (wave_live) slide_band<LV, GW, true>(env, K.A, band);
+    if (wave_live) slide_band<LV, GW, true, false>(env, K.A, band);
     __syncthreads();
     // One flush per workgroup and band.  The table holds OUT rows; member t of an item reports its slot's counts turned round:
     // perfect = rows - out1, forward (1..v mismatches, none at a strict position) = out1 - outF, reverse = out1 - outR.
@@ -196,27 +192,35 @@ void free_slide(mp_ctx *c) {
     dev_free(c, &c->slide_iters, c->slide_n_iters);
     dev_free(c, &c->slide_recs, (size_t)c->slide_items * kSlideRec);
     dev_free(c, &c->chain_rest, (size_t)c->n_rest);
+    dev_free(c, &c->chain_slid, (size_t)c->slide_items);
     c->slide_items = c->slide_n_bands = c->slide_max_items = 0;
     c->slide_n_iters = 0;
     c->n_rest = c->rest_max_steps = 0;
 }
 
-// MP_EVAL_SLIDE=0 keeps the first-pass kernels; =1 forces the sliding kernel at any size; default: from 65536 rows up (below, a launch
-// is a handful of workgroups and the bands' warm-up columns outweigh what sliding saves).  MP_SLIDE_GW (1, 2, 4): row words per lane;
-// MP_SLIDE_BAND: windows per band.
+// MP_EVAL_SLIDE=0 keeps the first-pass kernels; =1 forces the sliding kernel at any size; default: from 393216 rows up (below, the bands
+// that fill the chip are so short that their k - 1 warm-up columns outweigh what sliding saves: profiles/r04_slide_sizes.txt).
+// MP_SLIDE_GW (1, 2, 4): row words per lane; MP_SLIDE_BAND: windows per band.
 int upload_eval_slide(mp_ctx *c, const std::vector<ChainItem> &chains, const std::vector<uint32_t> &events, const std::vector<int32_t> &cand_out) {
     free_slide(c);
     const char *se = getenv("MP_EVAL_SLIDE");
-    if (chains.empty() || c->v > 3 || (se ? atoi(se) != 1 : c->n_pad < 65536)) return MP_OK;
+    // (k > v: the column pass runs without exclusion words and relies on an all-gap slice — a padding row — having more than v mismatches)
+    if (chains.empty() || c->v > 3 || c->k <= c->v || (se ? atoi(se) != 1 : c->n_pad < 393216)) return MP_OK;
     const int nw32 = c->n_pad / 32, n_cols = c->n_chunks * 32;
     if (((unsigned long long)n_cols * 4ull + 1ull) * (unsigned long long)nw32 * 4ull >= 0x7FFFFFFFull) return MP_OK;     // plane rows are addressed by a 32-bit scalar offset
     if ((unsigned long long)c->n_win * (unsigned long long)nw32 * 4ull >= 0x7FFFFFFFull) return MP_OK;
-    int gw = nw32 >= 16384 ? 2 : 1;
+    int gw = 2;
     if (const char *e = getenv("MP_SLIDE_GW")) { const int g = atoi(e); if (g == 1 || g == 2 || g == 4) gw = g; }
-    const int wc = (nw32 + kBlock * gw - 1) / (kBlock * gw);
-    // enough workgroups for 256 CUs x 4 resident workgroups a few times over, bands of 4..32 windows
-    int span = chains.back().win - chains.front().win + 1;
-    int band = std::max(4, std::min(32, (int)((long long)span * wc / 3072)));
+    const int wc = (nw32 + kBlock * gw - 1) / (kBlock * gw), wc_pad = wc >= 8 ? (wc + 7) / 8 * 8 : wc;
+    // Bands: ONE round of workgroups where that leaves bands of at most 96 windows — 256 CUs x 4 resident workgroups (VGPRs and the
+    // rings' LDS allow four) = 1024 at a time, so 1024 / slices bands; every workgroup does the same work, a second round would
+    // only add warm-up columns (0.184 ms with 16 bands of 60 windows against 0.190 with 32 of 30 at 1 048 576 rows).  More rounds
+    // when a band would be longer, never bands shorter than 8 windows.
+    const int span = chains.back().win - chains.front().win + 1;
+    const int per_round = std::max(1, 1024 / std::max(1, wc_pad));
+    int band = (span + per_round - 1) / per_round;
+    for (int r = 2; band > 96; r++) band = (span + per_round * r - 1) / (per_round * r);
+    band = std::max(8, band);
     if (const char *e = getenv("MP_SLIDE_BAND")) band = std::max(1, atoi(e));
     std::vector<SlideChainIn> in(chains.size());
     for (size_t i = 0; i < chains.size(); i++) {
@@ -239,6 +243,12 @@ int upload_eval_slide(mp_ctx *c, const std::vector<ChainItem> &chains, const std
     c->slide_max_items = P.max_items_band;
     c->slide_ns = P.ns; c->slide_spos = P.spos; c->slide_fmask = P.fmask; c->slide_rmask = P.rmask;
     c->slide_gw = gw;
+    {
+        std::vector<ChainItem> slid;
+        for (int32_t i : P.item_of) slid.push_back(chains[(size_t)i]);
+        if ((rc = dev_alloc(c, &c->chain_slid, slid.size()))) return rc;
+        HIPCK(c, hipMemcpy(c->chain_slid, slid.data(), sizeof(ChainItem) * slid.size(), hipMemcpyHostToDevice));
+    }
     if (!P.rest.empty()) {
         std::vector<ChainItem> rest;
         for (int32_t i : P.rest) { rest.push_back(chains[(size_t)i]); c->rest_max_steps = std::max(c->rest_max_steps, (int)chains[(size_t)i].n_steps); }

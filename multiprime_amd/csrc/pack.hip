@@ -132,7 +132,7 @@ __global__ __launch_bounds__(kBlock) void row_scan_kernel(const uint32_t *__rest
 // Column planes for the bit-sliced evaluation: cols[col][4][Npad/64] u64, bit r%64 of word r/64 =
 // sequence r; one plane per base (A, C, G, T), all four clear where the sequence has a gap or has
 // ended.  A concrete candidate symbol then needs ONE plane per position ("matches" = that plane), a
-// degenerate one the OR of its bases' planes.  IUPAC residues set several planes: windows that touch
+// degenerate one the OR of its bases' planes.  An IUPAC residue sets none either: windows that touch
 // one are always routed to the general path (patch list), never to the bit-sliced pass.
 constexpr int kColBlock = 1024;           // 16 waves = 1024 rows per workgroup: a (column, base) row of 16 words leaves as one 128-byte line
 __global__ __launch_bounds__(kColBlock) void colplane_kernel(const uint32_t *__restrict__ planes, int n_pad, int /*n_chunks*/,
@@ -145,6 +145,10 @@ __global__ __launch_bounds__(kColBlock) void colplane_kernel(const uint32_t *__r
     if (r < n_pad) {
         const size_t base = ((size_t)c * 4) * np + r;
         mA = planes[base]; mC = planes[base + np]; mG = planes[base + 2 * np]; mT = planes[base + 3 * np];
+        // an IUPAC cell (several bases) leaves NO plane set, like a gap: every consumer keeps windows that touch one away from these
+        // planes anyway (patch list), and the sliding evaluation's arithmetic wants at most one base per cell (evalslide.hip)
+        const uint32_t multi = (mA & (mC | mG | mT)) | (mC & (mG | mT)) | (mG & mT);
+        mA &= ~multi; mC &= ~multi; mG &= ~multi; mT &= ~multi;
     }
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     // lane j of a wave ends up holding the four words of column j (the ballots over the wave's 64 rows)

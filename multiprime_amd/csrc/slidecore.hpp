@@ -90,12 +90,12 @@ struct SlideFetch {
     uint32_t valid[GW];
 };
 
-// Always the same eight requests (the rows of the window + seven planes; a slot the item does not have reads the all-zero row
+// Always the same requests (with USE_VALID the rows the window counts, then seven planes; a slot the item does not have reads the all-zero row
 // behind the last column): no branch, so the loads stay in flight behind the item that is being computed.  The record holds what a
 // fetch takes as it stands.
-template <int GW, class Env>
+template <int GW, bool USE_VALID, class Env>
 SLIDE_HD void slide_request(Env &env, const typename Env::Rec &rec, SlideFetch<GW> &F) {
-    env.valid_of(env.rec_word(rec, 29), F.valid);
+    if (USE_VALID) env.valid_of(env.rec_word(rec, 29), F.valid);
 #pragma unroll
     for (int s = 1; s <= kSlideKept; s++) env.fetch(env.rec_word(rec, s), F.d[s]);
 }
@@ -103,7 +103,7 @@ SLIDE_HD void slide_request(Env &env, const typename Env::Rec &rec, SlideFetch<G
 // One item: all eight member slots, straight-line (a slot the item does not have repeats the counts of the one before it — its plane
 // is the all-zero row — and reports to nobody).  SIMPLE (the host's flag; every chain of a refinement run has it): every event plane is
 // the plane of a base beyond the reference — no per-plane masks in the carry-save sum.
-template <int LV, int GW, bool SIMPLE, class Env>
+template <int LV, int GW, bool SIMPLE, bool USE_VALID, class Env>
 SLIDE_HD void slide_item(Env &env, const SlideArgs &A, const typename Env::Rec &rec, uint32_t hdr, const SlideCount (&cnt)[GW],
                          const uint32_t (&sv)[kSlideStrict][GW], const SlideFetch<GW> &F, uint32_t (&accPF)[8], uint32_t (&accR)[4]) {
     const int n_extra = (int)((hdr >> 8) & 15u);
@@ -189,10 +189,10 @@ SLIDE_HD void slide_item(Env &env, const SlideArgs &A, const typename Env::Rec &
         const uint32_t hi = bop<kSlOr3>(c.b2, c.b3, c.b4);
         const uint32_t t1 = bop<kSlOr3>(c.b0, c.b1, hi), t2 = c.b1 | hi, t3 = bop<kSlOrAnd>(hi, c.b1, c.b0);
         const uint32_t far = LV == 1 ? t1 : (LV == 2 ? t2 : (LV == 3 ? t3 : hi));
-        T[0][i] = bop<kSlOrNot>(t1, F.valid[i], 0u);                    // t1 | ~valid
+        T[0][i] = USE_VALID ? bop<kSlOrNot>(t1, F.valid[i], 0u) : t1;   // t1 | ~valid
         T[1][i] = t2; T[2][i] = t3; T[3][i] = hi;
-        DF[i] = bop<kSlOrOrNot>(DF[i], far, F.valid[i]);
-        DR[i] = bop<kSlOrOrNot>(DR[i], far, F.valid[i]);
+        DF[i] = USE_VALID ? bop<kSlOrOrNot>(DF[i], far, F.valid[i]) : (DF[i] | far);
+        DR[i] = USE_VALID ? bop<kSlOrOrNot>(DR[i], far, F.valid[i]) : (DR[i] | far);
     }
     // (c) walk down the chain: event plane s, then member slot s is counted.  Counts leave in the layout the wave sums want:
     // accPF[s] = out1 | outF << 16, accR[s / 2] = outR of an even slot | outR of the odd one << 16
@@ -231,14 +231,17 @@ SLIDE_HD void slide_item(Env &env, const SlideArgs &A, const typename Env::Rec &
 //   Rec, load_rec(item) -> Rec, rec_word(rec, q) (q a constant), rec_word_dyn(rec, q)                      an item's record
 //   fetch(plane_row x row_scale, d)    the lane's words of column plane row `plane_row` (= column * 4 + base)
 //   valid_of(window x row_scale, v)    rows the column-plane pass may count for this window
-//   ring_zero(k); ring_swap(slot, in, out): out = ring[slot], ring[slot] = in; ring_read(slot, out)
+//   ring_zero(k); ring_write(slot, in); ring_read(slot, out)
 //   commit(item_in_band, accPF, accR)  the lane's OUT counts of the item's 8 member slots (layout: slide_item)
 // Software pipeline: the column sliding in is requested two iterations ahead, an item's record two items ahead, its planes one item
 // ahead — a wave has few neighbours on its SIMD (the ring takes LDS), so it hides its own latencies.  The two register sets of each
 // pipeline swap ROLES (two copies of the iteration, two of the item, by parity), never contents: a register copy would wait for the
 // youngest load, and so would a branch that picks the set.
 // ONLY_SIMPLE: the plan holds simple items without extra corrections only (build_slide_plan's simple_only; the GPU kernel).
-template <int LV, int GW, bool ONLY_SIMPLE, class Env>
+// USE_VALID false (the GPU kernel): every row of a window is counted as its plain column slice — rows with more than v gaps or past the
+// alignment's end never reach a count anyway (a gap mismatches everything), and what the caller must NOT count as a plain slice (edge-
+// gap repaired rows, IUPAC rows) it takes back itself (eval.hip: the subtracting run on the plain-slice planes of the patch list).
+template <int LV, int GW, bool ONLY_SIMPLE, bool USE_VALID, class Env>
 SLIDE_HD void slide_band(Env &env, const SlideArgs &A, int band_index) {
     static_assert(LV >= 1 && LV <= 4 && GW >= 1 && GW <= 4, "counter levels / words per lane");
     const SlideBand bd = env.uband(band_index);
@@ -253,7 +256,7 @@ SLIDE_HD void slide_band(Env &env, const SlideArgs &A, int band_index) {
     // item pipeline: records of the next two items, planes of the next one (set 0 first)
     typename Env::Rec rec0 = env.load_rec(bd.item0), rec1 = env.load_rec(bd.item0 + 1 <= last_item ? bd.item0 + 1 : last_item);
     SlideFetch<GW> F0, F1;
-    slide_request<GW>(env, rec0, F0);
+    slide_request<GW, USE_VALID>(env, rec0, F0);
     int done = 0;                                                       // items of the band behind us
     // column pipeline: iteration j's column waits in set j & 1
     uint32_t bA[GW], bB[GW];
@@ -266,26 +269,28 @@ SLIDE_HD void slide_band(Env &env, const SlideArgs &A, int band_index) {
         const int after = bd.item0 + done + 2;
         const typename Env::Rec rec = rec_cur;
         rec_cur = env.load_rec(after <= last_item ? after : last_item);
-        slide_request<GW>(env, rec_other, F_other);                    // (behind the band's last item: that item's again, unused)
+        slide_request<GW, USE_VALID>(env, rec_other, F_other);                    // (behind the band's last item: that item's again, unused)
         const uint32_t hdr = env.rec_word(rec, 0);
         uint32_t accPF[8], accR[4];
-        if (ONLY_SIMPLE || (hdr & kSlSimple)) slide_item<LV, GW, true>(env, A, rec, hdr, cnt, sv, F_cur, accPF, accR);
-        else slide_item<LV, GW, false>(env, A, rec, hdr, cnt, sv, F_cur, accPF, accR);
+        if (ONLY_SIMPLE || (hdr & kSlSimple)) slide_item<LV, GW, true, USE_VALID>(env, A, rec, hdr, cnt, sv, F_cur, accPF, accR);
+        else slide_item<LV, GW, false, USE_VALID>(env, A, rec, hdr, cnt, sv, F_cur, accPF, accR);
         env.commit(done, accPF, accR);
         done++;
     };
-    // one iteration: the column waiting in `b` slides in, `b` is refilled with the column two iterations on, the window's items run
-    auto iteration = [&](uint32_t (&b)[GW], int j) __attribute__((always_inline)) {
+    // one iteration: the column waiting in `b` slides in (the column it pushes out of the ring was read an iteration ago into `bo`),
+    // `b` is refilled with the column two iterations on, `bo` with the next iteration's outgoing column, the window's items run
+    auto iteration = [&](uint32_t (&b)[GW], uint32_t (&bo)[GW], uint32_t (&bo_next)[GW], int j) __attribute__((always_inline)) {
         const uint32_t it1 = env.iter_word(2 * j + 1);
-        uint32_t bn[GW], bo[GW];
+        uint32_t bn[GW];
 #pragma unroll
         for (int i = 0; i < GW; i++) bn[i] = ~b[i];                    // rows that do not carry the reference base here
         env.fetch(env.iter_word(2 * j + 4), b);                        // (past the band's end: a row of the next band, unused)
-        env.ring_swap(slot, bn, bo);                                   // the column sliding out shares the slot (k columns apart)
 #pragma unroll
         for (int i = 0; i < GW; i++) slide_updown(cnt[i], bn[i] ^ bo[i], bn[i]);
+        env.ring_write(slot, bn);                                      // the column sliding out shared the slot (k columns apart)
         const int slot_now = slot;
         slot = slot + 1 == k ? 0 : slot + 1;
+        env.ring_read(slot, bo_next);
         const int n_items = (int)(it1 >> 24);
         if (n_items == 0) return;                                      // warming up, or a window without chains
         // mismatch words of the reference at the strict positions of this window, out of the ring (slots beyond the launch's strict
@@ -308,6 +313,8 @@ SLIDE_HD void slide_band(Env &env, const SlideArgs &A, int band_index) {
             else item(rec0, rec1, F0, F1, sv);
         }
     };
+    uint32_t boA[GW], boB[GW];
+    env.ring_read(0, boA);                                              // zeros: the first k columns push nothing out
 #pragma unroll 1
     for (int base = 0; base < n_iter; base += 30) {                     // 64 iteration words = 32 iterations, two of them look-ahead
         if (base) env.load_iters(bd.iter0 + 2 * base);
@@ -315,10 +322,10 @@ SLIDE_HD void slide_band(Env &env, const SlideArgs &A, int band_index) {
         int j = 0;
 #pragma unroll 1
         for (; j + 1 < n_here; j += 2) {
-            iteration(bA, j);
-            iteration(bB, j + 1);
+            iteration(bA, boA, boB, j);
+            iteration(bB, boB, boA, j + 1);
         }
-        if (j < n_here) iteration(bA, j);                               // (an odd tail ends the band)
+        if (j < n_here) iteration(bA, boA, boB, j);                     // (an odd tail ends the band)
     }
 }
 

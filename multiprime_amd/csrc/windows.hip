@@ -229,7 +229,7 @@ int mp_build_windows(mp_ctx *c, int32_t p0, int32_t n_win, int32_t k, int32_t v,
     HIPCK(c, hipMemcpyAsync(c->patch_off, po.data(), sizeof(int32_t) * po.size(), hipMemcpyHostToDevice, c->stream));
     c->h_patch_off = po;
     c->h_extra_off.assign((size_t)n_win + 1, 0);
-    c->pp_dirty = true;
+    c->pp_dirty = true; c->qp_dirty = true;
     c->ex_host.clear();
     if (n_exc) *n_exc = 0;
     lap("build_windows: counts+offsets");
@@ -297,7 +297,7 @@ int mp_set_extra_rows(mp_ctx *c, int32_t n, const int32_t *win, const uint32_t *
     for (int w = 0; w < c->n_win; w++) off[(size_t)w + 1] += off[(size_t)w];
     HIPCK(c, hipMemcpy(c->extra_off, off.data(), sizeof(int32_t) * off.size(), hipMemcpyHostToDevice));
     c->h_extra_off = off;
-    c->pp_dirty = true;
+    c->pp_dirty = true; c->qp_dirty = true;
     if (n > 0) {
         int rc;
         if ((rc = dev_alloc(c, &c->extra_words, (size_t)3 * n))) return rc;
