@@ -59,7 +59,7 @@ DEFAULT_CEILINGS = {"valu_wave_instr_per_s_per_simd": 8.5e8, "l2_read_GBs": 3155
 COUNTER_FILES = ("r04_counters.json", "r03_counters.json")
 # sources of the timed kernel (eval_chain_kernel and what it includes): the key of a counter entry
 KERNEL_SOURCES = ("eval.hip", "evalprog.hip", "evalslide.hip", "slidecore.hpp", "slideplan.hpp", "evalslide.hpp", "bitslice.hpp", "common.hpp",
-                  "winwords.hpp", "evaltile.hpp", "evalprog.hpp")
+                  "winwords.hpp", "evalprog.hpp")
 SLIDE_FROM_ROWS = 393216     # evalslide.hip (upload_eval_slide): from this many (padded) rows up the chains are evaluated by sliding
 PROG_FROM_ROWS = 393216      # eval.hip (mp_eval_upload): the program-driven first-pass kernel, when sliding is switched off
 
@@ -67,22 +67,21 @@ KERNELS = {
     "chain": "eval_chain_kernel (bit-sliced one-hot column planes, nested refinement chains; patch rows ride in the same launch)",
     "table": "eval_bits_kernel (bit-sliced one-hot column planes, symbol table per position; patch rows ride in the same launch)",
     "rows": "eval_kernel (row-per-lane, window words derived from the planes)",
-    "tile": "eval_tile_kernel (column planes of a band of windows in an LDS ring) + eval_chain_kernel on the patch planes",
     "prog": "eval_prog_kernel (eval_chain_kernel's arithmetic, host-written fetch programs, buffer loads, event planes parked in LDS; patch rows ride in the same launch)",
     "slide": "eval_slide_kernel (5-bit bit-sliced mismatch count of a per-column reference sliding along the windows, event planes fetched once per chain; "
              "patch rows on eval_chain_kernel in the same step)",
 }
 
 
-def eval_mode(n_rows=0):
-    """Which evaluation kernels the library's environment switches select (defaults: the nested-chain kernel, in its program-driven
-    form from PROG_FROM_ROWS rows up)."""
+def eval_mode(n_rows=0, ctx=None):
+    """Which evaluation kernel runs the nested chains: what the library says about the staged candidates (mp_eval_plan_info), else
+    what its environment switches select (defaults: sliding from SLIDE_FROM_ROWS rows up, the nested-chain kernel below)."""
+    if ctx is not None and ctx.eval_plan_info()["sliding_items"]:
+        return "slide"
     if os.environ.get("MP_EVAL_MODE") == "rows":
         return "rows"
     if os.environ.get("MP_EVAL_BITS", "0") in ("1", "2") or os.environ.get("MP_EVAL_GROUP") == "plain":
         return "table"
-    if os.environ.get("MP_EVAL_TILE", "0") in ("2", "4"):
-        return "tile"
     if os.environ.get("MP_EVAL_SLIDE", "1" if n_rows >= SLIDE_FROM_ROWS else "0") == "1":
         return "slide"
     if os.environ.get("MP_EVAL_PROG", "1" if n_rows >= PROG_FROM_ROWS else "0") == "1":
@@ -263,11 +262,11 @@ def roofline_block(w, per_launch_ms, samples, kern_n, every, mode):
             "algorithmic_note": "SURVEY 8d figure: 3k/8 bytes per evaluation over the kernel time vs 8 TB/s; exceeds 1 because 8 nested candidates and "
                                 "18 overlapping windows share every loaded plane word — NOT a roofline fraction, kept for comparison with round 1",
             "algorithmic_bytes": alg_bytes, "algorithmic_bytes_per_eval": 3 * w.k / 8.0,
-            "bound_note": "l2 = bytes the vector memory path returns to registers over the rate measured for L2-resident reads, 31.4 TB/s = 256 CUs x 64 B/clk "
-                          "(a CU-side ceiling: serving the same loads from L1 does not change the time); in steady state the kernel runs at 72 % of it, "
-                          "the rest of a launch is ~10 us that do not scale with the work (profiles/r03_eval_limits.txt)",
+            "bound_note": "valu = vector instructions over the measured issue rate (scalar instructions share the slots: profiles/r03_ubench_salu.json); "
+                          "l2 = bytes the vector memory path returns to registers over 31.4 TB/s = 256 CUs x 64 B/clk (what bound the first-pass kernels; "
+                          "the sliding kernel returns a quarter of their bytes); hbm = fabric bytes (L2 misses: Infinity Cache or HBM) over 8 TB/s",
             "counters": pmc, "counters_source": note, "counters_stale": pmc is None, "source_hash": kernel_source_hash(), "ceilings": ceil,
-            "kernel": KERNELS[mode] + "; timed region = counter memset + kernel", "eval_mode": mode,
+            "kernel": KERNELS[mode] + "; timed region = counter memset + every kernel of the step", "eval_mode": mode,
             "kernel_ms": per_launch_ms, "kernel_ms_median": float(samples[len(samples) // 2]) if len(samples) else None,
             "kernel_ms_max": float(samples[-1]) if len(samples) else None,
             "launches_timed": kern_n, "timed_every": every}
@@ -415,7 +414,7 @@ def main():
 
     res = None
     if rank == 0:
-        mode = eval_mode(w.n_rows)
+        mode = eval_mode(w.n_rows, ctx)
         per_launch_ms = kern_ms / max(kern_n, 1)
         whole = "BASELINE configs[3] itself" if strong else f"{world * rows_per_gpu} rows in all"
         res = {
@@ -471,7 +470,7 @@ def weak_shard(lib, local, torch, dev, a, timed_region, every, with_cpu):
     out = {"workload": w.describe() + " on ONE GPU (the per-GPU shard of BASELINE configs[3] at N = 8; planes 81 MB: inside the Infinity Cache)",
            "value": w.evals * a.steps / elapsed, "unit": "evals/s", "ms_per_step": elapsed / a.steps * 1e3, "steps": a.steps,
            "evals_per_step": w.evals, "iupac_extra_rows": w.n_extra, "setup_s": w.setup_s, "device_bytes": w.ctx.device_bytes(),
-           "roofline": roofline_block(w, per_launch_ms, samples, kern_n, every, eval_mode(w.n_rows)),
+           "roofline": roofline_block(w, per_launch_ms, samples, kern_n, every, eval_mode(w.n_rows, w.ctx)),
            "counter_checksum": counters.sum(axis=0).tolist()}
     if not a.no_variants:
         src = torch.empty(1 << 28, dtype=torch.float32, device=dev)

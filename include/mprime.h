@@ -185,6 +185,10 @@ int mp_eval_timing(mp_ctx *ctx, int32_t reset, double *total_ms, int32_t *n_laun
 /* The individual durations (milliseconds) behind the totals of the LAST mp_eval_timing call, at most 4096 since its
  * reset: *n returns how many there are, the first min(*n, cap) are written (median / maximum for bench.py). */
 int mp_eval_timing_samples(mp_ctx *ctx, int32_t cap, float *ms, int32_t *n);
+/* How the staged candidates (mp_eval_upload) will be evaluated, for run logs and tests: info[0] = nested chain items, info[1] =
+ * symbol-table items, info[2] = chain items the sliding kernel takes (0: the first-pass kernels run all of them), info[3] = chain
+ * items left to the first-pass kernel beside it.  The checker reports zeros. */
+int mp_eval_plan_info(mp_ctx *ctx, int32_t *info);
 
 /* (5) 3'-end dimer scan — SURVEY §8a rows D and M ------------------------------------------- */
 /* Replaces the search loops of Dimer.dimer_check (scripts/finDimer_V4.py:191-224) and of

@@ -51,6 +51,7 @@ SYMBOLS = [
     ("mp_eval_launch", C.c_int, [_p, _p]),
     ("mp_eval_timing", C.c_int, [_p, C.c_int32, C.POINTER(C.c_double), C.POINTER(C.c_int32)]),
     ("mp_eval_timing_samples", C.c_int, [_p, C.c_int32, _p, C.POINTER(C.c_int32)]),
+    ("mp_eval_plan_info", C.c_int, [_p, _p]),
     ("mp_dimer_scan", C.c_int, [_p, C.c_int32, _p, _p, C.c_int32, C.c_int32, _p, _p, C.c_double, C.c_int64, _p,
                                 C.POINTER(C.c_int64)]),
     ("mp_dimer_pairs", C.c_int, [_p, C.c_int32, _p, _p, C.c_int64, _p, _p, _p, C.c_double, _p]),
@@ -363,6 +364,12 @@ class Context:
         ms, n = C.c_double(0), C.c_int32(0)
         self._ck(self.d.mp_eval_timing(self.h, int(reset), C.byref(ms), C.byref(n)))
         return ms.value, n.value
+
+    def eval_plan_info(self) -> dict:
+        """Which kernels the staged candidates go to (mp_eval_plan_info)."""
+        info = np.zeros(4, np.int32)
+        self._ck(self.d.mp_eval_plan_info(self.h, _ptr(info)))
+        return {"chain_items": int(info[0]), "table_items": int(info[1]), "sliding_items": int(info[2]), "first_pass_chain_items": int(info[3])}
 
     def eval_timing_samples(self) -> np.ndarray:
         """Durations (ms) of the timed launches behind the last eval_timing() call."""

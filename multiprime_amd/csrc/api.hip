@@ -3,7 +3,6 @@
 #include <vector>
 
 #include "common.hpp"
-#include "evaltile.hpp"
 
 namespace mp {
 
@@ -38,16 +37,7 @@ int fill_segments(mp_ctx *c, const FillSeg *segs, int n) {
     return MP_OK;
 }
 
-void free_tiles(mp_ctx *c) {
-    dev_free(c, &c->tile_rounds, (size_t)c->tile_n_rounds);
-    dev_free(c, &c->tile_bands, (size_t)c->tile_n_bands);
-    dev_free(c, &c->tile_prog, (size_t)c->tile_n_prog);
-    c->tile_n_rounds = c->tile_n_bands = c->tile_n_slices = c->tile_rc = c->tile_gw = c->tile_n_prog = 0;
-    c->tile_attr_set = false;
-}
-
 void free_eval(mp_ctx *c) {
-    free_tiles(c);
     free_slide(c);
     c->h_chains.clear(); c->h_events.clear(); c->h_cand_out.clear();
     dev_free(c, &c->chain_prog, c->chain_prog_n);
@@ -108,7 +98,6 @@ void free_msa(mp_ctx *c) {
     size_t np = (size_t)c->n_pad;
     dev_free(c, &c->planes, (size_t)c->n_chunks * 4 * np);
     dev_free(c, &c->cols, ((size_t)c->n_chunks * 32 * 4 + 1) * (np / 64));
-    dev_free(c, &c->cons, (size_t)c->n_chunks * 32);
     dev_free(c, &c->cum, ((size_t)c->n_chunks + 1) * np);
     dev_free(c, &c->ung, np * c->ustride);
     dev_free(c, &c->lead, np); dev_free(c, &c->rstrip, np); dev_free(c, &c->rlen, np);

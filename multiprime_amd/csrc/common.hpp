@@ -49,8 +49,6 @@ struct ChainItem {
     uint32_t pos1, pos2, pos4;         // positions where that symbol has one / two / more bases
 };
 
-struct TileRound;
-struct TileBand;
 struct SlideBand;
 
 struct Nib {          // up to 32 symbol codes, one nibble each
@@ -98,7 +96,6 @@ struct mp_ctx {
     int reserve_cols = 0;                    // mp_reserve_columns: minimum alignment width (row shards)
     uint32_t *planes = nullptr, *cum = nullptr, *ung = nullptr;
     unsigned long long *cols = nullptr;      // [n_chunks*32][4][n_pad/64]
-    uint8_t *cons = nullptr;                 // [n_chunks*32] most frequent base of every column (unique.hip), made on first use
     int32_t *lead = nullptr, *rstrip = nullptr, *rlen = nullptr;
     // windows
     int p0 = 0, n_win = 0, k = 0, v = 0;
@@ -154,7 +151,7 @@ struct mp_ctx {
     mp::ChainItem *chain_items = nullptr;
     int32_t *table_ids = nullptr;
     int n_chain = 0, n_table = 0, n_events = 0, max_steps = 0;     // max_steps: members of the longest chain item
-    // LDS-tiled evaluation of the chain items (evaltile.hip): plan built on the first launch after an upload
+    // host copies of the staged chain items (evalslide.hip builds its plan from them)
     std::vector<mp::ChainItem> h_chains;     // host copies of the chain items (ascending windows) and their events
     std::vector<uint32_t> h_events;
     std::vector<int32_t> h_cand_out;         // output slot of every padded candidate
@@ -170,11 +167,6 @@ struct mp_ctx {
     mp::ChainItem *chain_rest = nullptr;     // the chain items the plan leaves to the first-pass kernel
     mp::ChainItem *chain_slid = nullptr;     // the chain items that slide (slide_items of them): the patch pass subtracts their plain slices
     int n_rest = 0, rest_max_steps = 0;
-    mp::TileRound *tile_rounds = nullptr;
-    mp::TileBand *tile_bands = nullptr;
-    uint32_t *tile_prog = nullptr;
-    int tile_n_rounds = 0, tile_n_bands = 0, tile_n_slices = 0, tile_rc = 0, tile_gw = 0, tile_n_prog = 0;
-    bool tile_attr_set = false;
     unsigned launch_seq = 0;                 // launches since the last timing reset
     int32_t *cand_out = nullptr;
     uint32_t sF = 0, sR = 0;
@@ -236,7 +228,6 @@ int fill_segments(mp_ctx *c, const FillSeg *segs, int n);
 
 // release the device arrays of one stage (and of every stage that depends on it); api.hip
 void free_eval(mp_ctx *c);
-void free_tiles(mp_ctx *c);
 void free_slide(mp_ctx *c);
 void free_comm(mp_ctx *c);
 void free_unique(mp_ctx *c);

@@ -8,7 +8,6 @@
 #include "common.hpp"
 #include "winwords.hpp"
 #include "bitslice.hpp"
-#include "evaltile.hpp"
 #include "evalprog.hpp"
 #include "evalslide.hpp"
 
@@ -1137,33 +1136,6 @@ PatchArgs patch_args(const mp_ctx *c, int GW, int n_items, int unit_threads) {
     return pa;
 }
 
-// Plan of the LDS-tiled evaluation for the staged chain items (rebuilt after an upload or when the tile shape changes).
-int ensure_tile_plan(mp_ctx *c, int gw) {
-    if (c->tile_gw == gw && c->tile_rounds) return MP_OK;
-    free_tiles(c);
-    const int nw32 = c->n_pad / 32, tw = tile_words(gw);
-    const int per_cu = gw == 4 ? 1 : 2;
-    int groups = 256 * per_cu;
-    if (const char *e = getenv("MP_EVAL_TILE_GROUPS")) groups = std::max(1, atoi(e));
-    TilePlan P;
-    const int n_slices = (nw32 + tw - 1) / tw, rc_cols = tile_ring_cols(gw, per_cu);
-    plan_tiles(c->h_chains, c->h_events, c->h_cand_out, c->p0, c->k, c->sF, c->sR, gw, rc_cols, n_slices, groups, P);
-    int rc;
-    if ((rc = dev_alloc(c, &c->tile_rounds, P.rounds.size()))) return rc;
-    c->tile_n_rounds = (int)P.rounds.size();
-    if ((rc = dev_alloc(c, &c->tile_bands, P.bands.size()))) return rc;
-    c->tile_n_bands = (int)P.bands.size();
-    c->tile_gw = gw;
-    if ((rc = dev_alloc(c, &c->tile_prog, P.prog.size()))) return rc;
-    c->tile_n_prog = (int)P.prog.size();
-    HIPCK(c, hipMemcpy(c->tile_rounds, P.rounds.data(), sizeof(TileRound) * P.rounds.size(), hipMemcpyHostToDevice));
-    HIPCK(c, hipMemcpy(c->tile_bands, P.bands.data(), sizeof(TileBand) * P.bands.size(), hipMemcpyHostToDevice));
-    HIPCK(c, hipMemcpy(c->tile_prog, P.prog.data(), sizeof(uint32_t) * P.prog.size(), hipMemcpyHostToDevice));
-    c->tile_n_slices = n_slices;
-    c->tile_rc = rc_cols;
-    return MP_OK;
-}
-
 }  // namespace
 
 extern "C" {
@@ -1428,10 +1400,6 @@ int mp_eval_launch(mp_ctx *c, int64_t *device_out) {
             const BlockMap bm = block_map(cgw[cshape], c->n_chain, grid);
             EvalChainArgs ca{c->cols, c->excl, nw, c->p0, c->k, c->v, c->chain_items, c->chain_events, c->cand_out, c->sF, c->sR,
                              (unsigned long long *)device_out, bm, patch_args(c, cgw[cshape], c->n_chain, 64), nullptr, 0};
-            // LDS-tiled sweep (evaltile.hip) for chains of up to 8 members: the column planes of a band of windows are staged once
-            // per workgroup instead of being re-read from L2 by every covering window.  Measured SLOWER than the kernels below
-            // at every size (profiles/r03_tile_*.txt), so it runs only on request: MP_EVAL_TILE=2 / 4 row
-            // words per lane.
             if (c->slide_items > 0) {
                 // sliding evaluation: the patch planes of ALL chain items and the column planes of the items the plan left out run on
                 // the first-pass kernel, the rest slides
@@ -1457,15 +1425,7 @@ int mp_eval_launch(mp_ctx *c, int64_t *device_out) {
                 int rc = launch_eval_slide(c, (unsigned long long *)device_out);
                 if (rc) return rc;
             } else {
-            int tile_gw = 0;
-            if (const char *e = getenv("MP_EVAL_TILE")) { const int t = atoi(e); tile_gw = (t == 2 || t == 4) && c->max_steps <= kEvalCC ? t : 0; }
-            if (tile_gw) {
-                int rc = ensure_tile_plan(c, tile_gw);
-                if (rc) return rc;
-                if (ca.patch.n_blocks)          // the patch planes of the same items: wave-per-unit blocks of the chain kernel
-                    hipLaunchKernelGGL(cfn[c->v][cshape], dim3((unsigned)ca.patch.n_blocks), dim3(kBlock), 0, c->stream, ca);
-                if ((rc = launch_eval_tile(c, tile_gw, (unsigned long long *)device_out))) return rc;
-            } else if (use_prog) {
+            if (use_prog) {
                 // program-driven kernel (evalprog.hip): same arithmetic and block map (chosen at upload time, see there)
                 int rc = launch_eval_prog(c, cshape, bm, ca.patch, grid, (unsigned long long *)device_out);
                 if (rc) return rc;
@@ -1518,6 +1478,12 @@ int mp_eval_timing(mp_ctx *c, int32_t reset, double *total_ms, int32_t *n_launch
     if (n_launches) *n_launches = c->ev_n;
     c->ev_last = c->ev_samples;
     if (reset) { c->ev_ms = 0; c->ev_n = 0; c->launch_seq = 0; c->ev_samples.clear(); }      // the first launch after a reset is a timed one
+    return MP_OK;
+}
+
+int mp_eval_plan_info(mp_ctx *c, int32_t *info) {
+    if (!c || !info) return MP_ERR_ARG;
+    info[0] = c->n_chain; info[1] = c->n_table; info[2] = c->slide_items; info[3] = c->slide_items ? c->n_rest : 0;
     return MP_OK;
 }
 

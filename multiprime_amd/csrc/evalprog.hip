@@ -37,8 +37,6 @@ struct EvalProgArgs {
     unsigned long long *out;
     BlockMap map;
     PatchArgs patch;                   // patch / IUPAC rows: the first patch.n_blocks workgroups run on their planes
-    int quad_slices;                   // > 0: a workgroup = 4 consecutive items x ONE group of 64 x GW row words (a wave per item); the
-                                       // value = word groups per item, rounded up to a multiple of 8 (a group stays on one XCD)
 };
 
 struct Prog { uint32_t r[kProgRegs]; };
@@ -253,19 +251,11 @@ __global__ __launch_bounds__(kBlock) void eval_prog_kernel(const EvalProgArgs A)
         slice = unit % A.patch.per_item;
         if (item >= A.map.n_items) return;
         word0 = (slice * 64 + lane) * GW;
-    } else if (A.quad_slices) {
-        // the four waves of a workgroup take four CONSECUTIVE items over the same row words: their windows share all but three of
-        // their columns, and what one wave pulled into the CU's vector cache the next ones find there
-        const unsigned b = blockIdx.x - A.patch.n_blocks;
-        slice = (int)(b % (unsigned)A.quad_slices);
-        item = (int)(b / (unsigned)A.quad_slices) * (kBlock / 64) + (int)(threadIdx.x >> 6);
-        if (item >= A.map.n_items) return;
-        word0 = (slice * 64 + lane) * GW;
     } else {
         if (!map_block(A.map, blockIdx.x - A.patch.n_blocks, slice, item)) return;
         word0 = (slice * kBlock + (int)threadIdx.x) * GW;
     }
-    const bool per_wave = on_patch || A.quad_slices != 0;      // the wave commits its own totals
+    const bool per_wave = on_patch;                            // a patch unit's wave commits its own totals
     Prog P;
     {
         const uint32_t *src = A.prog + (size_t)item * (kProgRegs * 64) + lane;
@@ -431,12 +421,7 @@ int launch_eval_prog(mp_ctx *c, int shape, const BlockMap &bm, const PatchArgs &
     static const ProgFn fn[4][kProgShapes] = {PROG_ROW(1), PROG_ROW(2), PROG_ROW(3), PROG_ROW(4)};
 #undef PROG_ROW
     EvalProgArgs a{reinterpret_cast<const uint32_t *>(c->cols), reinterpret_cast<const uint32_t *>(c->excl), c->n_pad / 32, c->p0,
-                   c->chain_prog, device_out, bm, pa, 0};
-    if (getenv("MP_EVAL_QUAD") && atoi(getenv("MP_EVAL_QUAD")) == 1) {
-        const int groups = (c->n_pad / 32 + 64 * kProgWords[shape] - 1) / (64 * kProgWords[shape]);
-        a.quad_slices = (groups + 7) / 8 * 8;
-        grid = (unsigned)((bm.n_items + kBlock / 64 - 1) / (kBlock / 64)) * (unsigned)a.quad_slices;
-    }
+                   c->chain_prog, device_out, bm, pa};
     hipLaunchKernelGGL(fn[c->v][shape], dim3(grid + (unsigned)pa.n_blocks), dim3(kBlock), 0, c->stream, a);
     HIPCK(c, hipGetLastError());
     return MP_OK;

@@ -292,176 +292,6 @@ __global__ __launch_bounds__(kBlock) void hist_kernel(const HistArgs A) {
     stamp(4);
 }
 
-// ---- consensus-filtered form -------------------------------------------------------------------------------------------------
-// Most rows of a window carry the window's consensus k-mer, and telling them apart needs no k-mer at all: on the one-hot COLUMN
-// planes (`cols`, 32 sequences per word) "row equals the consensus at every one of the k columns" is the AND of k plane words.
-// hist_cons_kernel therefore splits its slice (at most 8192 rows) in two with k coalesced word loads per 32 rows: the rows equal
-// to the consensus string (counted with a popcount, first row by a count-trailing-zeros: ONE table entry per slice) and the
-// others, whose row numbers go into a dense list in LDS.  Only the listed rows take the per-row path of hist_kernel (eight plane
-// words, window words, hash, LDS insert) — and they take it with full waves, because the list is dense.  On the bench shard 62 %
-// of the (row, window) pairs never leave the bit planes; on conserved alignments nearly all of them.  Rows `excl` flags (IUPAC
-// codes, edge gaps, more than v gaps, padding) are always listed, so the per-row rules decide about them exactly as before.
-constexpr int kConsRows = 8192;           // most rows a workgroup's slice holds in this form: the list is 16 KB of LDS
-struct ConsArgs {
-    const uint32_t *cols32;               // [n_cols][4][nw32] one-hot column planes
-    const uint32_t *excl32;               // [W][nw32]
-    const uint8_t *cons;                  // [n_cols] a base (0..3) per alignment column: the most frequent one
-    int nw32;
-};
-
-// most frequent base of every alignment column (ties: the lower base index; a column without bases: A) — any string would be a
-// correct reference for the split, the most frequent bases make the listed rows few
-__global__ __launch_bounds__(kBlock) void column_consensus_kernel(const uint32_t *__restrict__ cols32, int nw32, int n_cols, uint8_t *__restrict__ cons) {
-    const int col = blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6), lane = threadIdx.x & 63;
-    if (col >= n_cols) return;
-    uint32_t n[4] = {0, 0, 0, 0};
-    for (int w = lane; w < nw32; w += 64)
-#pragma unroll
-        for (int b = 0; b < 4; b++) n[b] += __popc(cols32[((size_t)col * 4 + b) * (size_t)nw32 + w]);
-#pragma unroll
-    for (int b = 0; b < 4; b++)
-        for (int sft = 32; sft >= 1; sft >>= 1) n[b] += __shfl_xor(n[b], sft);
-    if (lane == 0) {
-        int best = 0;
-        for (int b = 1; b < 4; b++) if (n[b] > n[best]) best = b;
-        cons[col] = (uint8_t)best;
-    }
-}
-
-__global__ __launch_bounds__(kBlock) void hist_cons_kernel(const HistArgs A, const ConsArgs C) {
-    __shared__ unsigned long long s_key[kLdsSlots];
-    __shared__ uint32_t s_cnt[kLdsSlots];
-    __shared__ uint32_t s_min[kLdsSlots];
-    __shared__ uint16_t s_list[kConsRows];
-    __shared__ uint32_t s_z[kConsRows / 32];
-    __shared__ int s_base[kConsRows / 32];
-    __shared__ uint8_t s_cons[MP_MAX_K + 1];
-    __shared__ int s_used, s_nlist;
-    __shared__ uint32_t s_c0, s_f0;
-    __shared__ unsigned long long s_key0;
-    const int xcd = blockIdx.x & 7, q = blockIdx.x >> 3;
-    const int wl = q % A.win_per_xcd, slice = q / A.win_per_xcd;
-    const int w = xcd * A.win_per_xcd + wl;
-    if (w >= A.n_win || slice >= A.n_slices) return;
-    const int k = A.k;
-    const uint32_t kmask = (1u << k) - 1u;
-    const int p = A.p0 + w;
-    const size_t np = (size_t)A.M.n_pad;
-    const int r0 = slice * A.rows_per_block;                  // a multiple of 256 rows: whole 32-row words
-    const int r1 = min(r0 + A.rows_per_block, A.M.n_pad);
-    for (int i = threadIdx.x; i < kLdsSlots; i += kBlock) { s_key[i] = kNoKey; s_cnt[i] = 0; s_min[i] = kEmpty; }
-    if (threadIdx.x == 0) s_used = 0;
-    if (threadIdx.x < 64) {                                   // the consensus string of the window and its key (no gaps: g = 0)
-        const int j = threadIdx.x;
-        const uint32_t cb = j < k ? C.cons[p + j] : 0u;
-        if (j < k) s_cons[j] = (uint8_t)cb;
-        const unsigned long long b0 = __ballot(cb & 1u), b1 = __ballot((cb >> 1) & 1u);
-        if (j == 0) s_key0 = (b0 & kmask) | ((b1 & kmask) << k);
-    }
-    const uint32_t *P = A.M.planes + ((size_t)(p >> 5) * 4) * np;
-    auto insert = [&](unsigned long long key, uint32_t cnt, uint32_t row) {
-        uint32_t h = hash64(key) & (kLdsSlots - 1);
-        for (;;) {
-            unsigned long long old = atomicCAS(&s_key[h], kNoKey, key);
-            if (old == kNoKey) { atomicAdd(&s_used, 1); old = key; }
-            if (old == key) { atomicAdd(&s_cnt[h], cnt); atomicMin(&s_min[h], row); break; }
-            h = (h + 1) & (kLdsSlots - 1);
-        }
-    };
-    auto flush_if_full = [&]() {                              // all threads; uniform decision
-        __syncthreads();
-        if (s_used > kLdsLimit) {
-            for (int i = threadIdx.x; i < kLdsSlots; i += kBlock) {
-                const unsigned long long key = s_key[i];
-                if (key != kNoKey) global_insert(A, w, key, s_cnt[i], s_min[i]);
-                s_key[i] = kNoKey; s_cnt[i] = 0; s_min[i] = kEmpty;
-            }
-            __syncthreads();
-            if (threadIdx.x == 0) s_used = 0;
-            __syncthreads();
-        }
-    };
-    // the slice in blocks of at most kConsRows rows (the list's capacity); the LDS table lives across them
-    for (int s0 = r0; s0 < r1; s0 += kConsRows) {
-        const int s1 = min(s0 + kConsRows, r1);
-        __syncthreads();
-        if (threadIdx.x == 0) { s_nlist = 0; s_c0 = 0; s_f0 = kEmpty; }
-        __syncthreads();
-        // (1) split, a thread per word of 32 rows: z = rows that are NOT the consensus string (or that `excl` flags)
-        const int n_words = (s1 - s0) / 32;                   // <= 256; r0 and kConsRows are multiples of 256 rows
-        if ((int)threadIdx.x < n_words) {
-            const int word = (s0 >> 5) + (int)threadIdx.x;
-            uint32_t m = 0xFFFFFFFFu;
-            const uint32_t *col0 = C.cols32 + (size_t)p * 4 * (size_t)C.nw32 + word;
-#pragma unroll 8
-            for (int j = 0; j < k; j++) m &= col0[((size_t)j * 4 + s_cons[j]) * (size_t)C.nw32];
-            const uint32_t z = ~m | C.excl32[(size_t)w * (size_t)C.nw32 + word];
-            const uint32_t same = ~z;
-            if (same) { atomicAdd(&s_c0, (uint32_t)__popc(same)); atomicMin(&s_f0, (uint32_t)(word * 32 + __ffs(same) - 1)); }
-            s_z[threadIdx.x] = z;
-            s_base[threadIdx.x] = z ? atomicAdd(&s_nlist, __popc(z)) : 0;       // the list's order does not matter
-        }
-        __syncthreads();
-        // (2) the listed rows, every thread its share of the block's rows: no serial bit loops
-        for (int q0 = threadIdx.x; q0 < s1 - s0; q0 += kBlock) {
-            const uint32_t z = s_z[q0 >> 5], bit = 1u << (q0 & 31);
-            if (z & bit) s_list[s_base[q0 >> 5] + __popc(z & (bit - 1u))] = (uint16_t)q0;
-        }
-        if (threadIdx.x == 0 && s_c0) insert(s_key0, s_c0, s_f0);               // all consensus rows of the block: one entry
-        __syncthreads();
-        // (3) the per-row path of hist_kernel over the dense list; the next iteration's plane words are in flight meanwhile
-        const int n_list = s_nlist;
-        uint32_t nx[8];
-        int nlen = 0, nr = -1;
-        auto fetch = [&](int i) {
-            nr = -1;
-            if (i < n_list) {
-                const int r = s0 + (int)s_list[i];
-                if (r < A.M.n_rows) {
-                    nr = r;
-#pragma unroll
-                    for (int j = 0; j < 8; j++) nx[j] = P[(size_t)j * np + r];
-                    nlen = A.M.rlen[r];
-                }
-            }
-        };
-        fetch(threadIdx.x);
-        for (int i0 = 0; i0 < n_list; i0 += kBlock) {
-            uint32_t cw[8];
-#pragma unroll
-            for (int j = 0; j < 8; j++) cw[j] = nx[j];
-            const int r = nr, len = nlen;
-            fetch(i0 + kBlock + (int)threadIdx.x);
-            if (r >= 0) {
-                uint32_t b0, b1, g;
-                // plain column slices only: the repaired / IUPAC / ragged rows of the window come from the patch list below
-                if (fast_words(p, k, kmask, len, cw[0], cw[1], cw[2], cw[3], cw[4], cw[5], cw[6], cw[7], b0, b1, g))
-                    insert((unsigned long long)b0 | ((unsigned long long)b1 << k) | ((unsigned long long)g << (2 * k)), 1u, (uint32_t)r);
-            }
-            if ((i0 / kBlock) % kCheckEvery == kCheckEvery - 1) flush_if_full();
-        }
-        flush_if_full();
-    }
-    if (slice == 0 && A.patch_off) {
-        // the window's slow pairs (edge-gap repair, ragged end): their k-mers were derived once by repair_kernel
-        const int e0 = A.patch_off[w], e1 = A.patch_off[w + 1];
-        for (int eb = e0; eb < e1; eb += kBlock) {
-            const int e = eb + threadIdx.x;
-            if (e < e1) {
-                const uint32_t b0 = A.patch_words[3 * (size_t)e], b1 = A.patch_words[3 * (size_t)e + 1], g = A.patch_words[3 * (size_t)e + 2];
-                if (!(g & MP_WIN_SKIP))
-                    insert((unsigned long long)b0 | ((unsigned long long)b1 << k) | ((unsigned long long)(g & kmask) << (2 * k)), 1u,
-                           (uint32_t)A.patch_rows[e]);
-            }
-            flush_if_full();
-        }
-    }
-    __syncthreads();
-    for (int i = threadIdx.x; i < kLdsSlots; i += kBlock) {
-        const unsigned long long key = s_key[i];
-        if (key != kNoKey) global_insert(A, w, key, s_cnt[i], s_min[i]);
-    }
-}
 
 struct CompactArgs {
     const unsigned long long *g_key;
@@ -738,12 +568,7 @@ int unique_packed(mp_ctx *c, int64_t cap, int32_t want_labels, int64_t *n_entrie
         A.n_slices = (int)((np + A.rows_per_block - 1) / A.rows_per_block);
         A.win_per_xcd = (int)((W + 7) / 8);
         const unsigned blocks = 8u * (unsigned)A.win_per_xcd * (unsigned)A.n_slices;
-        // MP_HIST_MODE=cons: the consensus-filtered form — rows equal to the window's consensus string are counted on the column
-        // planes, the others take the per-row path from a dense list.  Fewer instructions (VALU 196 M -> 135 M, half the loads)
-        // but NOT faster: 1075 us against hist_kernel's 898 us at 131072 x 1000 (profiles/r03_hist_variants.txt, DESIGN.md
-        // section 9) — both kernels spend their time in the latency chain LDS insert -> barrier -> flush, not in deriving k-mers.
-        const char *hmode = getenv("MP_HIST_MODE");
-        if (!(hmode && !strcmp(hmode, "cons"))) {
+        {
             const char *prof_path = getenv("MP_HIST_PROF");       // debugging: phase stamps of every workgroup written to that file
             if (prof_path) {
                 HIPCK(c, hipMalloc((void **)&A.prof, (size_t)blocks * 64));
@@ -761,15 +586,6 @@ int unique_packed(mp_ctx *c, int64_t cap, int32_t want_labels, int64_t *n_entrie
                 A.prof = nullptr;
                 if (FILE *f = fopen(prof_path, "wb")) { fwrite(h.data(), 8, h.size(), f); fclose(f); }
             }
-        } else {
-            const int n_cols = c->n_chunks * 32, nw32 = c->n_pad / 32;
-            if (!c->cons) {
-                if ((rc = dev_alloc(c, &c->cons, (size_t)n_cols))) return rc;
-                hipLaunchKernelGGL(column_consensus_kernel, dim3((unsigned)((n_cols + kBlock / 64 - 1) / (kBlock / 64))), dim3(kBlock), 0, c->stream,
-                                   reinterpret_cast<const uint32_t *>(c->cols), nw32, n_cols, c->cons);
-            }
-            ConsArgs C{reinterpret_cast<const uint32_t *>(c->cols), reinterpret_cast<const uint32_t *>(c->excl), c->cons, nw32};
-            hipLaunchKernelGGL(hist_cons_kernel, dim3(blocks), dim3(kBlock), 0, c->stream, A, C);
         }
         lap("unique: histogram");
         hipLaunchKernelGGL(count_kernel, dim3((unsigned)W), dim3(kBlock), 0, c->stream, (const unsigned long long *)c->g_key, slots, c->u_wcount);

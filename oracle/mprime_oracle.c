@@ -531,6 +531,12 @@ int mp_eval_timing(mp_ctx *c, int32_t reset, double *ms, int32_t *n) {
     return MP_OK;
 }
 
+int mp_eval_plan_info(mp_ctx *c, int32_t *info) {
+    if (!c || !info) return MP_ERR_ARG;
+    info[0] = info[1] = info[2] = info[3] = 0;
+    return MP_OK;
+}
+
 int mp_eval_timing_samples(mp_ctx *c, int32_t cap, float *ms, int32_t *n) {
     (void)cap; (void)ms;
     if (!c || !n) return MP_ERR_ARG;

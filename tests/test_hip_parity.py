@@ -120,21 +120,6 @@ def test_every_abi_output_matches_oracle(hip_lib, oracle_lib, seed, n, L, ragged
         assert h.eval_candidates(cw2, cand, sF, sR).tolist() == o.eval_candidates(cw2, cand, sF, sR).tolist()
 
 
-@pytest.mark.gpu
-@pytest.mark.parametrize("n,p_iupac", [(3000, 0.0), (20000, 0.002), (70000, 0.0)])
-def test_consensus_filtered_histogram_equals_oracle(hip_lib, oracle_lib, monkeypatch, n, p_iupac):
-    """MP_HIST_MODE=cons (hist_cons_kernel: consensus rows counted on the column planes, the rest from a dense list): same
-    (k-mer, count, first row) entries as the oracle, several slices per window, edge gaps and IUPAC rows in the mix."""
-    monkeypatch.setenv("MP_HIST_MODE", "cons")
-    data, off, _ = fuzz_msa(9 + n, n, 140, ragged=False, p_gap=0.01, p_iupac=p_iupac, edge=0.2)
-    hip, ora = both(hip_lib, oracle_lib, data, off)
-    for c in (hip, ora):
-        c.build_windows(2, 100, 18, 1)
-    got, want = hip.window_unique(), ora.window_unique()
-    for a, b in zip(got[:4], want[:4]):
-        assert np.array_equal(a, b)
-
-
 def test_many_distinct_kmers_take_the_global_table_path(hip_lib, oracle_lib):
     # random (non-homologous) rows: every window holds ~n distinct k-mers, far more than the LDS table
     rng = np.random.default_rng(9)
@@ -257,7 +242,8 @@ def test_candidate_grouping_paths_match_oracle(hip_lib, oracle_lib, monkeypatch,
     want = ora.eval_candidates(cw, codes, sF, sR)
     settings = [{}, {"MP_EVAL_GROUP": "plain"}, {"MP_EVAL_GROUP": "nested"}, {"MP_EVAL_BITS": "1"}, {"MP_EVAL_BITS": "2"},
                 {"MP_EVAL_CHAIN": "0"}, {"MP_EVAL_CHAIN": "3"}, {"MP_EVAL_CHAIN": "5"}, {"MP_EVAL_CHAIN": "7"},
-                {"MP_EVAL_MODE": "rows"}, {"MP_EVAL_TILE": "4"}, {"MP_EVAL_TILE": "2"}, {"MP_EVAL_PROG": "1"},
+                {"MP_EVAL_MODE": "rows"}, {"MP_EVAL_SLIDE": "1"}, {"MP_EVAL_SLIDE": "1", "MP_SLIDE_GW": "1", "MP_SLIDE_BAND": "5"},
+                {"MP_EVAL_SLIDE": "1", "MP_SLIDE_GW": "4", "MP_SLIDE_BAND": "64"}, {"MP_EVAL_PROG": "1"},
                 {"MP_EVAL_PROG": "1", "MP_EVAL_CHAIN": "3"}, {"MP_EVAL_PROG": "1", "MP_EVAL_CHAIN": "7"},
                 {"MP_EVAL_PROG": "1", "MP_EVAL_CHAIN": "10"}, {"MP_EVAL_PROG": "1", "MP_EVAL_CHAIN": "11"}, {"MP_EVAL_PROG": "1", "MP_EVAL_CHAIN": "12"}]
     for env in settings:
@@ -326,7 +312,7 @@ def test_kernel_shapes_and_extreme_k(hip_lib, oracle_lib, monkeypatch, n, k, v):
     for kind in ("up", "down", "mixed"):
         cw, codes = chain_candidates(rng, root, W, k, kind)
         want = ora.eval_candidates(cw, codes, sF, sR)
-        for env in ({}, {"MP_EVAL_GROUP": "plain"}, {"MP_EVAL_CHAIN": "0"}, {"MP_EVAL_CHAIN": "6"}, {"MP_EVAL_TILE": "4"}, {"MP_EVAL_TILE": "2"},
+        for env in ({}, {"MP_EVAL_GROUP": "plain"}, {"MP_EVAL_CHAIN": "0"}, {"MP_EVAL_CHAIN": "6"}, {"MP_EVAL_SLIDE": "1"}, {"MP_EVAL_SLIDE": "1", "MP_SLIDE_GW": "1", "MP_SLIDE_BAND": "3"},
                     {"MP_EVAL_PROG": "1"}, {"MP_EVAL_PROG": "1", "MP_EVAL_CHAIN": "6"}, {"MP_EVAL_PROG": "1", "MP_EVAL_CHAIN": "10"},
                     {"MP_EVAL_PROG": "1", "MP_EVAL_CHAIN": "11"}, {"MP_EVAL_PROG": "1", "MP_EVAL_CHAIN": "12"}):
             with monkeypatch.context() as m:

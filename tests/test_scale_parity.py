@@ -49,6 +49,34 @@ def test_bench_workload_hip_equals_oracle_per_candidate(hip_lib):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("rows_n,v", [(524288, 1), (400000, 2)])
+def test_sliding_kernel_at_depth_equals_oracle_per_candidate(hip_lib, rows_n, v):
+    """From 393216 rows up the chains are evaluated by the sliding kernel (evalslide.hip): every candidate's three counters against
+    the C oracle on all host cores — nested chains (they slide) and, in the same upload, unrelated candidates (symbol-table kernel)."""
+    sys.path.insert(0, REPO)
+    import bench
+    from types import SimpleNamespace
+    L, k, C, seed = 700, 18, 8, 77
+    rows = bench.synth_rows(0, rows_n, L, seed)
+    ctx = hip_lib.context(0)
+    ctx.load_msa(rows.reshape(-1), np.arange(rows_n + 1, dtype=np.int64) * L)
+    p0, W = 16, L - 32 - k
+    n_ex = ctx.build_windows(p0, W, k, v)
+    bench.expand_exceptions(ctx, n_ex, k, v)
+    root_codes = np.array([1, 2, 4, 8], np.uint8)[synth_root(L, seed)]
+    cw, codes = bench.make_candidates(root_codes, p0, W, k, C, seed)
+    sF = sum(1 << y for y in (2, 3, k) if 0 <= y < k)
+    sR = sum(1 << y for y in (2, k - 3, k - 2) if 0 <= y < k)
+    got = ctx.eval_candidates(cw, codes, sF, sR)
+    info = ctx.eval_plan_info()
+    assert info["sliding_items"] == W and info["first_pass_chain_items"] == 0, info
+    wl = SimpleNamespace(L=L, p0=p0, W=W, k=k, v=v, C=C, cw=cw, codes=codes, sF=sF, sR=sR)
+    res = bench.cpu_baseline(wl, rows, 0, got, seed, one_core=False, python_leg=False)
+    assert res["parity_checked"] is True, res
+    ctx.close()
+
+
+@pytest.mark.gpu
 def test_config3_scale_core_step_hip_equals_oracle(hip_lib, oracle_lib, tmp_path):
     rows = synth_block(0, 20727, 1951, 31)
     fa = tmp_path / "c3.fa"

@@ -48,7 +48,7 @@ def per_kernel(dbfile):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--rows", type=int, default=131072)
-    ap.add_argument("--out", default=os.path.join(REPO, "gpurun_out", "r03", "prof_bench"))
+    ap.add_argument("--out", default=os.path.join(REPO, "gpurun_out", "r04", "prof_bench"))
     ap.add_argument("--bench-args", default="")
     ap.add_argument("--merge", default="", help="an earlier counters.json whose entries for OTHER configurations are kept")
     a = ap.parse_args()
@@ -84,17 +84,23 @@ def main():
         rows = list(db.execute("select name, count(*), avg(duration), min(duration), max(duration) from kernels where name like '%eval_%' group by name order by sum(duration) desc"))
         if rows:
             kern = rows[0][0]
-            entry["kernel"] = kern.replace("(anonymous namespace)::", "").split("(")[0].replace("void ", "").strip() + " (incl. the patch-plane waves)"
+            entry["kernel"] = kern.replace("(anonymous namespace)::", "").split("(")[0].replace("void ", "").strip() + " (counters: summed with the other eval_ kernels of a step)"
+            entry["trace_all"] = [{"kernel": r[0].replace("(anonymous namespace)::", "").split("(")[0].replace("void ", "").strip(), "dispatches": r[1], "avg_us": r[2] / 1e3} for r in rows]
             entry["trace"] = {"dispatches": rows[0][1], "avg_us": rows[0][2] / 1e3, "min_us": rows[0][3] / 1e3, "max_us": rows[0][4] / 1e3,
                               "note": "rocprofv3 --kernel-trace of `bench.py --steps 20 --warmup 3`"}
-    raw = {}
+    # a step = every evaluation kernel of one mp_eval_launch (the sliding kernel + eval_chain_kernel on the patch planes): per
+    # kernel the per-dispatch average, summed over the kernels; one dispatch of each per step
+    raw, per_kernel_raw = {}, {}
     for tag in PASSES:
         dbs = glob.glob(os.path.join(a.out, "pmc_" + tag, "**", "*.db"), recursive=True)
         if not dbs:
             continue
         for (name, cname), vals in per_kernel(dbs[0]).items():
-            if "eval_" in name and (kern is None or name == kern):
-                raw[cname] = sum(vals) / len(vals)
+            if "eval_" in name:
+                short = name.replace("(anonymous namespace)::", "").split("(")[0].replace("void ", "").strip()
+                per_kernel_raw.setdefault(short, {})[cname] = sum(vals) / len(vals)
+                raw[cname] = raw.get(cname, 0.0) + sum(vals) / len(vals)
+    entry["kernels_of_a_step"] = per_kernel_raw
     entry["raw_counters_per_launch"] = raw
     # calibration: bytes per TCP->TCC read request on coalesced dword / dwordx4 reads of known size
     cal = {}
