@@ -69,7 +69,8 @@ def test_sliding_kernel_at_depth_equals_oracle_per_candidate(hip_lib, rows_n, v)
     sR = sum(1 << y for y in (2, k - 3, k - 2) if 0 <= y < k)
     got = ctx.eval_candidates(cw, codes, sF, sR)
     info = ctx.eval_plan_info()
-    assert info["sliding_items"] == W and info["first_pass_chain_items"] == 0, info
+    # (nearly) every chain slides; one whose refinement drops the column's reference base stays with the first-pass kernel
+    assert info["sliding_items"] >= 0.95 * W and info["sliding_items"] + info["first_pass_chain_items"] == info["chain_items"] == W, info
     wl = SimpleNamespace(L=L, p0=p0, W=W, k=k, v=v, C=C, cw=cw, codes=codes, sF=sF, sR=sR)
     res = bench.cpu_baseline(wl, rows, 0, got, seed, one_core=False, python_leg=False)
     assert res["parity_checked"] is True, res
