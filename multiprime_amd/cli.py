@@ -19,7 +19,9 @@ Extra, optional flags (additions must stay optional):
                  with this command's flags.  The fixed cost of a process (interpreter, numpy, HIP runtime: 0.3-0.4 s, more
                  than the work of a 500-sequence cluster) is paid once instead of once per cluster; a Snakemake workflow
                  replaces the per-cluster rule by one rule over the cluster list.  Prints the reference's closing line per
-                 pair and one JSON summary (clusters per second) at the end.
+                 pair and one JSON summary (clusters per second) at the end.  --batch-workers T: clusters in flight per GPU
+                 (threads with a context each; default up to 8): a small cluster is host-bound, several of them overlap.
+                 --batch-procs P: P processes per GPU share its clusters (the per-cluster Python does not scale over threads).
 """
 from __future__ import annotations
 
@@ -27,6 +29,7 @@ import argparse
 import json
 import os
 import socket
+import threading
 import subprocess
 import sys
 import time
@@ -55,6 +58,11 @@ def parse_args(argv=None):
     p.add_argument("--ngpu", type=int, default=1, help="GPUs of this node to use: re-launches this command as that many ranks")
     p.add_argument("--batch", type=str, default=None, metavar="<file>",
                    help="file of `input<TAB>output` lines: all of them in one process per GPU with this command's flags")
+    p.add_argument("--batch-workers", type=int, default=0, metavar="<int>",
+                   help="--batch: clusters in flight per GPU (worker threads, a context each); default: up to 8")
+    p.add_argument("--batch-procs", type=int, default=1, metavar="<int>",
+                   help="--batch: processes per GPU that share its clusters (each with its own worker threads); default 1")
+    p.add_argument("--batch-part", type=str, default=None, help=argparse.SUPPRESS)       # "i/n": set by --batch-procs for its children
     p.add_argument("--no-json", action="store_true", help="do not write the two *_seq_id_json side files")
     p.add_argument("--bitsets", action="store_true",
                    help="also write <out>.coverage_bitsets.npz: per window, one bit per sequence the primer does not "
@@ -92,13 +100,13 @@ def _respawn(n, argv):
     return subprocess.call(cmd)
 
 
-def _core(args, inp, out, device, comm):
+def _core(args, inp, out, device, comm, context=None):
     from .core import NN_degenerate
     return NN_degenerate(seq_file=inp, primer_length=args.plen, coverage=args.fraction,
                          number_of_dege_bases=args.dnum, score_of_dege_bases=args.degeneracy,
                          raw_entropy_threshold=args.entropy, product_len=args.size, position=args.coordinate,
                          variation=args.variation, distance=args.away, GC=args.gc, nproc=args.proc, outfile=out,
-                         device=device, comm=comm, write_json=not args.no_json, write_bitsets=args.bitsets)
+                         device=device, comm=comm, write_json=not args.no_json, write_bitsets=args.bitsets, context=context)
 
 
 def _closing_line(e1, e2):
@@ -119,16 +127,71 @@ def _run_batch(args, rank, world, device):
             pairs.append(tok)
     t0 = time.time()
     mine = pairs[rank::world]
-    rows = 0
-    for inp, out in mine:
-        e1 = time.time()
-        app = _core(args, inp, out, device, None)
-        app.run()
-        rows += app.total_sequence_number
-        app.ctx.close()
-        _closing_line(e1, time.time())
+    if args.batch_part:                                  # a child of --batch-procs: its share of this rank's clusters
+        i, n = (int(x) for x in args.batch_part.split("/"))
+        mine = mine[i::n]
+    elif args.batch_procs > 1 and len(mine) > 1:
+        # Several PROCESSES on this GPU: the per-cluster Python (filters, TSV rows, array plumbing) holds the interpreter lock, so
+        # threads stop scaling at ~60 clusters/s; processes do not share it.  Each child pays its own start-up (0.3-0.4 s, in parallel).
+        n = min(args.batch_procs, len(mine))
+        argv = [a for a in sys.argv[1:]]
+        kids = [subprocess.Popen([sys.executable, os.path.abspath(sys.argv[0])] + argv + ["--batch-part", f"{i}/{n}", "--device", str(device)],
+                                 env=dict(os.environ, RANK=str(rank), WORLD_SIZE=str(world), MP_SHARE_DEVICE="1"))
+                for i in range(n)]
+        codes = [k.wait() for k in kids]
+        dt = time.time() - t0
+        print(json.dumps({"batch": args.batch, "rank": rank, "n_ranks": world, "clusters": len(mine), "processes": n,
+                          "seconds": round(dt, 3), "clusters_per_s": round(len(mine) / dt, 2) if dt > 0 else None}), flush=True)
+        if any(codes):
+            raise SystemExit(next(c for c in codes if c))
+        return
+    # Several clusters in flight on this GPU: worker threads, each with a context (stream) of its own.  A 500-sequence
+    # cluster is ~1 ms of device work inside ~20 ms of host work (FASTA, planning, the O(windows x sequences) side files), most of it
+    # native code that releases the interpreter lock — so the clusters overlap instead of queueing behind one another.
+    workers = max(1, min(args.batch_workers if args.batch_workers > 0 else min(8, (os.cpu_count() or 1) // 8 or 1), len(mine) or 1))
+    rows, lock, errors = [0], threading.Lock(), []
+    todo = iter(mine)
+
+    def work():
+        ctx = None                                       # one context per worker, kept across its clusters
+        try:
+            while True:
+                with lock:
+                    pair = next(todo, None)
+                if pair is None or errors:
+                    return
+                inp, out = pair
+                try:
+                    e1 = time.time()
+                    app = _core(args, inp, out, device, None, context=ctx)
+                    ctx = app.ctx
+                    app.run()
+                    with lock:
+                        rows[0] += app.total_sequence_number
+                        _closing_line(e1, time.time())
+                except BaseException as e:               # SystemExit of a refused alignment included: reported, the batch stops
+                    with lock:
+                        errors.append((inp, e))
+                    return
+        finally:
+            if ctx is not None:
+                ctx.close()
+
+    if workers == 1:
+        work()
+    else:
+        th = [threading.Thread(target=work) for _ in range(workers)]
+        for t in th:
+            t.start()
+        for t in th:
+            t.join()
+    if errors:
+        inp, e = errors[0]
+        if isinstance(e, SystemExit):
+            raise SystemExit(e.code)
+        raise RuntimeError(f"{inp}: {e}") from e
     dt = time.time() - t0
-    print(json.dumps({"batch": args.batch, "rank": rank, "n_ranks": world, "clusters": len(mine), "sequences": rows,
+    print(json.dumps({"batch": args.batch, "rank": rank, "n_ranks": world, "clusters": len(mine), "sequences": rows[0], "workers": workers,
                       "seconds": round(dt, 3), "clusters_per_s": round(len(mine) / dt, 2) if dt > 0 else None}), flush=True)
 
 

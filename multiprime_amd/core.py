@@ -74,7 +74,7 @@ class NN_degenerate(object):
     def __init__(self, seq_file, primer_length=18, coverage=0.8, number_of_dege_bases=18, score_of_dege_bases=1000,
                  product_len=250, position="2,-1", variation=2, raw_entropy_threshold=3.6, distance=4, GC="0.4,0.6",
                  nproc=10, outfile="", *, library: Library | None = None, device: int = 0, comm=None,
-                 write_json: bool = True, write_bitsets: bool = False, keep_bitsets: bool = False):
+                 write_json: bool = True, write_bitsets: bool = False, keep_bitsets: bool = False, context=None):
         self.primer_length = int(primer_length)
         self.coverage = coverage
         self.number_of_dege_bases = number_of_dege_bases
@@ -109,7 +109,9 @@ class NN_degenerate(object):
 
         def make_context():
             try:
-                made["ctx"] = self.lib.context(device)
+                # `context`: a context the caller keeps across alignments (the batch workers): loading a new alignment releases the
+                # old one's arrays, the stream and the runtime's warmed-up copy path stay
+                made["ctx"] = context if context is not None else self.lib.context(device)
             except BaseException as e:                                 # re-raised below, in the constructor's thread
                 made["error"] = e
 

@@ -83,3 +83,22 @@ def test_single_process_batch_and_missing_arguments(oracle_lib, tmp_path):
     check_outputs(name, out)
     r = subprocess.run([sys.executable, SCRIPT, "-i", str(inp)], env=_env(oracle_lib), capture_output=True, text=True, timeout=120)
     assert r.returncode == 2 and "required" in r.stderr                # argparse's exit code, like the reference's parser
+
+
+def test_batch_workers_and_processes_on_one_gpu(oracle_lib, tmp_path):
+    """`--batch` with several clusters in flight: worker threads (a context each, kept across clusters) and `--batch-procs` child
+    processes that share the list — every cluster's files equal the reference's whichever way they were scheduled."""
+    name = "syn_iupac"
+    inp = _input(name, tmp_path)
+    for tag, extra in (("threads", ["--batch-workers", "3"]), ("procs", ["--batch-procs", "2", "--batch-workers", "2"])):
+        outs = [tmp_path / f"{tag}{i}.out" for i in range(5)]
+        batch = tmp_path / f"{tag}.tsv"
+        batch.write_text("".join(f"{inp}\t{o}\n" for o in outs))
+        r = subprocess.run([sys.executable, SCRIPT, "--batch", str(batch)] + extra + _flags(name), env=_env(oracle_lib), capture_output=True,
+                           text=True, timeout=900)
+        assert r.returncode == 0, r.stderr[-2000:]
+        for o in outs:
+            check_outputs(name, o)
+        assert r.stdout.count("Total times") == 5
+        last = [json.loads(line) for line in r.stdout.splitlines() if line.startswith("{")][-1]
+        assert last["clusters"] == 5 and (last.get("processes") == 2 if tag == "procs" else last["workers"] == 3)

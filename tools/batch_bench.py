@@ -38,6 +38,8 @@ def main():
     ap.add_argument("--clusters", type=int, default=64)
     ap.add_argument("--rows", type=int, default=500)
     ap.add_argument("--seed", type=int, default=20250303)
+    ap.add_argument("--no-per-cluster", action="store_true", help="skip the one-process-per-cluster leg")
+    ap.add_argument("--workers", default="0", help="comma list of --batch-workers[xPROCS] settings to time (0 = the default), e.g. 2x4")
     a = ap.parse_args()
     rng = np.random.default_rng(a.seed)
     cols = rng.integers(800, 2000, size=a.clusters)
@@ -50,22 +52,29 @@ def main():
             inputs.append(fa)
         subprocess.run([sys.executable, SCRIPT, "-i", inputs[0], "-o", os.path.join(wd, "warm.out")] + FLAGS, check=True, capture_output=True)
         t0 = time.time()
-        for i, fa in enumerate(inputs):
+        for i, fa in enumerate(inputs if not a.no_per_cluster else inputs[:4]):
             subprocess.run([sys.executable, SCRIPT, "-i", fa, "-o", os.path.join(wd, f"p{i}.out")] + FLAGS, check=True, capture_output=True)
-        per_cluster_s = time.time() - t0
+        per_cluster_s = (time.time() - t0) * (1 if not a.no_per_cluster else a.clusters / 4)
         batch = os.path.join(wd, "batch.tsv")
         with open(batch, "w") as f:
             f.writelines(f"{fa}\t{os.path.join(wd, f'b{i}.out')}\n" for i, fa in enumerate(inputs))
-        t0 = time.time()
-        r = subprocess.run([sys.executable, SCRIPT, "--batch", batch] + FLAGS, check=True, capture_output=True, text=True)
-        batch_s = time.time() - t0
-        same = all(digest(os.path.join(wd, f"p{i}.out")) == digest(os.path.join(wd, f"b{i}.out")) for i in range(a.clusters))
+        by_workers = {}
+        for wk in a.workers.split(","):
+            t0 = time.time()
+            wt, _, procs = wk.partition("x")
+            r = subprocess.run([sys.executable, SCRIPT, "--batch", batch, "--batch-workers", wt, "--batch-procs", procs or "1"] + FLAGS, check=True,
+                               capture_output=True, text=True)
+            batch_s = time.time() - t0
+            inner = [json.loads(line) for line in r.stdout.splitlines() if line.startswith("{") and ("processes" in line or not procs)][-1]
+            by_workers[wk] = {"process_s": round(batch_s, 2), "clusters_per_s": round(a.clusters / batch_s, 2),
+                              "inner_clusters_per_s": inner["clusters_per_s"], "workers": inner.get("workers")}
+        same = all(digest(os.path.join(wd, f"p{i}.out")) == digest(os.path.join(wd, f"b{i}.out")) for i in range(a.clusters if not a.no_per_cluster else 4))
         inner = [json.loads(line) for line in r.stdout.splitlines() if line.startswith("{")][-1]
         primers = sum(sum(1 for _ in open(os.path.join(wd, f"b{i}.out"))) - 1 for i in range(a.clusters))
     print(json.dumps({"clusters": a.clusters, "rows_per_cluster": a.rows, "columns": [int(cols.min()), int(cols.max())], "flags": " ".join(FLAGS),
                       "per_cluster_processes_s": round(per_cluster_s, 2), "per_cluster_clusters_per_s": round(a.clusters / per_cluster_s, 2),
                       "batch_process_s": round(batch_s, 2), "batch_clusters_per_s": round(a.clusters / batch_s, 2),
-                      "batch_inner_clusters_per_s": inner["clusters_per_s"], "identical_outputs": same, "primers_written": primers,
+                      "batch_inner_clusters_per_s": inner["clusters_per_s"], "batch_by_workers": by_workers, "identical_outputs": same, "primers_written": primers,
                       "reference_note": "the reference takes 50-62 s per 500-sequence cluster (BASELINE.md)"}))
 
 
