@@ -10,6 +10,7 @@
 #include "bitslice.hpp"
 #include "evalprog.hpp"
 #include "evalslide.hpp"
+#include "chainbody.hpp"
 
 using namespace mp;
 
@@ -516,205 +517,12 @@ __global__ __launch_bounds__(kBlock) void eval_bits_kernel(const EvalBitsArgs A)
     else block_commit<GW>(accP, accF, accR, s_part, A.cand_out + it.cand0, A.out);
 }
 
-// ----------------------------------------------------------------------------------------------
-// (4c) bit-sliced evaluation of a NESTED chain: the candidates of the item, ordered from the most degenerate
-// one down, each accept a subset of what the previous one accepts (a refinement chain read backwards).  Then
-// the mismatch counters of candidate s are those of candidate s-1 plus, for every position whose symbol lost
-// bases in between, one bit plane d = "the sequence's base is one of the lost ones" — for one lost base that is
-// the base's column plane as loaded.  Counters only ever grow, so saturating bit-sliced counters stay exact.
-// Work per 32 sequences at v = 1: k positions once (1 load + 2-4 VALU each, for the first candidate) + 1 load and
-// 2-4 VALU per event + 6 VALU per candidate, against 4 loads and ~45 VALU per position in the symbol-table kernel.
-// ----------------------------------------------------------------------------------------------
-struct EvalChainArgs {
-    const unsigned long long *cols;    // [n_cols][4][nw]
-    const unsigned long long *excl;    // [W][nw]
-    int nw, p0, k, v;
-    const ChainItem *items;
-    const uint32_t *events;            // position | lost base (one-hot) << 8 | step << 16, ascending by step
-    const int32_t *cand_out;
-    uint32_t sF, sR;
-    unsigned long long *out;
-    BlockMap map;
-    PatchArgs patch;                   // patch / IUPAC rows: the first patch.n_blocks workgroups run on their planes
-    const ChainItem *neg_items;        // the items of the subtracting run (patch.neg_blocks workgroups), n_neg of them
-    int n_neg;
-};
-
-// One pass of the first candidate over the positions in `rem` whose symbol has NB bases (NB = 4: three or four,
-// all planes loaded and masked).  D positions of loads are requested before the first one is consumed; no other
-// load sits in between, so each position waits for exactly its own words.
-template <int LV, int GW, int D, int NB>
-__device__ __forceinline__ void chain_first_pass(uint32_t rem, const uint32_t *Pw, size_t nw32, unsigned long long sy_lo,
-                                                 unsigned long long sy_hi, uint32_t sF, uint32_t sR, uint32_t (&t1)[GW],
-                                                 uint32_t (&t2)[GW], uint32_t (&t3)[GW], uint32_t (&t4)[GW], uint32_t (&sf)[GW],
-                                                 uint32_t (&sr)[GW]) {
-#pragma unroll 1
-    while (rem) {
-        int js[D]; bool has[D];
-        uint32_t ld[D][NB][GW], sys[D];
-#pragma unroll
-        for (int u = 0; u < D; u++) {
-            has[u] = rem != 0u;
-            js[u] = has[u] ? __builtin_ctz(rem) : js[0];
-            rem &= rem - 1u;
-            const int j = js[u];
-            const uint32_t sy = (uint32_t)((j < 16 ? sy_lo : sy_hi) >> (4 * (j & 15))) & 15u;
-            sys[u] = sy;
-            const uint32_t *P = Pw + (size_t)j * 4 * nw32;
-            if (NB == 4) {
-#pragma unroll
-                for (int b = 0; b < 4; b++)
-#pragma unroll
-                    for (int i = 0; i < GW; i++) ld[u][b][i] = P[b * nw32 + i];
-            } else {
-                const uint32_t second = sy & (sy - 1u);
-                const size_t b0 = (size_t)__builtin_ctz(sy | 16u), b1 = (size_t)__builtin_ctz(second | 16u);
-#pragma unroll
-                for (int i = 0; i < GW; i++) {
-                    ld[u][0][i] = P[b0 * nw32 + i];
-                    if (NB == 2) ld[u][1][i] = P[b1 * nw32 + i];
-                }
-            }
-        }
-#pragma unroll
-        for (int u = 0; u < D; u++) {
-            if (!has[u]) break;
-            const int j = js[u];
-            uint32_t m[GW];
-            if (NB == 4) {
-                const uint32_t sy = sys[u];
-                const uint32_t kA = (sy & 1u) ? 0xFFFFFFFFu : 0u, kC = (sy & 2u) ? 0xFFFFFFFFu : 0u;
-                const uint32_t kG = (sy & 4u) ? 0xFFFFFFFFu : 0u, kT = (sy & 8u) ? 0xFFFFFFFFu : 0u;
-#pragma unroll
-                for (int i = 0; i < GW; i++) {
-                    m[i] = ld[u][0][i] & kA;
-                    m[i] = __builtin_amdgcn_bitop3_b32(ld[u][1][i], kC, m[i], kLutAndOr);
-                    m[i] = __builtin_amdgcn_bitop3_b32(ld[u][2][i], kG, m[i], kLutAndOr);
-                    m[i] = __builtin_amdgcn_bitop3_b32(ld[u][3][i], kT, m[i], kLutAndOr);
-                }
-            } else {
-#pragma unroll
-                for (int i = 0; i < GW; i++) m[i] = NB == 2 ? (ld[u][0][i] | ld[u][1][i]) : ld[u][0][i];
-            }
-#pragma unroll
-            for (int i = 0; i < GW; i++) count_unmatched<LV>(t1[i], t2[i], t3[i], t4[i], m[i]);
-            if (((sF | sR) >> j) & 1u) {
-                const uint32_t fF = ((sF >> j) & 1u) ? 0xFFFFFFFFu : 0u, fR = ((sR >> j) & 1u) ? 0xFFFFFFFFu : 0u;
-#pragma unroll
-                for (int i = 0; i < GW; i++) {
-                    sf[i] = __builtin_amdgcn_bitop3_b32(sf[i], m[i], fF, kLutOrNotAnd);
-                    sr[i] = __builtin_amdgcn_bitop3_b32(sr[i], m[i], fR, kLutOrNotAnd);
-                }
-            }
-        }
-    }
-}
-
+// (4c) bit-sliced evaluation of a NESTED chain: chainbody.hpp (the workgroup's work as a device function: the sliding launch runs its
+// patch units through the same code)
 template <int LV, int GW, int D>
 __global__ __launch_bounds__(kBlock) void eval_chain_kernel(const EvalChainArgs A) {
-    static_assert(GW <= 8, "plane rows are padded to multiples of 8 words");
-    constexpr int CC = 8;
-    __shared__ uint32_t s_part[kBlock / 64][3 * CC / 2];
-    // the patch units come first; a second run of them (sliding evaluation) subtracts the plain slices of the items that slide
-    const int patch_blocks = A.patch.n_blocks + A.patch.neg_blocks;
-    const bool on_patch = (int)blockIdx.x < patch_blocks;
-    const bool negative = on_patch && (int)blockIdx.x >= A.patch.n_blocks;
-    int slice, item, word0;
-    if (on_patch) {                                    // a wave per patch unit: everything below is wave-uniform
-        const int pb = (int)blockIdx.x - (negative ? A.patch.n_blocks : 0);
-        const int unit = __builtin_amdgcn_readfirstlane(pb * (kBlock / 64) + (int)(threadIdx.x >> 6));
-        item = unit / A.patch.per_item;
-        slice = unit % A.patch.per_item;
-        if (item >= (negative ? A.n_neg : A.map.n_items)) return;
-        word0 = (slice * 64 + (int)(threadIdx.x & 63)) * GW;
-    } else {
-        if (!map_block(A.map, blockIdx.x - patch_blocks, slice, item)) return;
-        word0 = (slice * kBlock + threadIdx.x) * GW;
-    }
-    const ChainItem it = negative ? A.neg_items[item] : A.items[item];
-    const WordTile T = !on_patch ? column_tile(A.cols, A.excl, A.nw, A.p0, it.win, word0)
-                                 : (negative ? plain_tile(A.patch, it.win, word0) : patch_tile(A.patch, it.win, word0));
-    if (on_patch && slice * 64 * GW >= (int)T.stride) return;               // nothing of this window's patch planes left for the wave
-    const size_t nw32 = T.stride;
-    const bool live = T.live;
-    // the three counts of a chain member are written once (when the walk reaches it) and are at most 32 * GW <= 256 per thread:
-    // one register per member (10 bits each) instead of three keeps the kernel at 8 waves per SIMD
-    static_assert(32 * GW < 1024, "three counts per register need 10 bits each");
-    uint32_t acc[CC];
-#pragma unroll
-    for (int c = 0; c < CC; c++) acc[c] = 0;
-    if (live) {
-        uint32_t t1[GW], t2[GW], t3[GW], t4[GW], sf[GW], sr[GW];
-#pragma unroll
-        for (int i = 0; i < GW; i++) t1[i] = t2[i] = t3[i] = t4[i] = sf[i] = sr[i] = 0;
-        const uint32_t *Pw = T.planes;
-        const unsigned long long sy_lo = it.sym[0] | ((unsigned long long)it.sym[1] << 32);
-        const unsigned long long sy_hi = it.sym[2] | ((unsigned long long)it.sym[3] << 32);
-        // (1) the first candidate over all k positions, grouped by the number of bases of its symbol there
-        chain_first_pass<LV, GW, D, 1>(it.pos1, Pw, nw32, sy_lo, sy_hi, A.sF, A.sR, t1, t2, t3, t4, sf, sr);
-        chain_first_pass<LV, GW, (D + 1) / 2, 2>(it.pos2, Pw, nw32, sy_lo, sy_hi, A.sF, A.sR, t1, t2, t3, t4, sf, sr);
-        chain_first_pass<LV, GW, (D + 3) / 4, 4>(it.pos4, Pw, nw32, sy_lo, sy_hi, A.sF, A.sR, t1, t2, t3, t4, sf, sr);
-        uint32_t valid[GW];
-        {
-#pragma unroll
-            for (int i = 0; i < GW; i++) valid[i] = T.mask[i] ^ T.mask_flip;
-        }
-        // (2) walk down the chain: apply the events of step s, then count candidate s
-        const uint32_t *ev = A.events + it.ev0;
-        int e = 0;
-        uint32_t evw = it.n_ev ? ev[0] : (1u << 8);
-        uint32_t cur[GW];
-        {
-            const uint32_t *P = Pw + ((size_t)(evw & 255u) * 4 + (size_t)__builtin_ctz(((evw >> 8) & 15u) | 16u)) * nw32;
-#pragma unroll
-            for (int i = 0; i < GW; i++) cur[i] = P[i];
-        }
-#pragma unroll
-        for (int s = 0; s < CC; s++) {
-            if (s >= it.n_steps) break;
-            if (s > 0) {
-#pragma unroll 1
-                while (e < it.n_ev && (int)(evw >> 16) == s) {
-                    e++;
-                    const uint32_t evn = e < it.n_ev ? ev[e] : evw;          // the plane of the next event is on its way
-                    uint32_t nxt[GW];
-                    {
-                        const uint32_t *P = Pw + ((size_t)(evn & 255u) * 4 + (size_t)__builtin_ctz(((evn >> 8) & 15u) | 16u)) * nw32;
-#pragma unroll
-                        for (int i = 0; i < GW; i++) nxt[i] = P[i];
-                    }
-                    const uint32_t j = evw & 255u;
-#pragma unroll
-                    for (int i = 0; i < GW; i++) count_plane<LV>(t1[i], t2[i], t3[i], t4[i], cur[i]);
-                    if (((A.sF | A.sR) >> j) & 1u) {
-                        const uint32_t fF = ((A.sF >> j) & 1u) ? 0xFFFFFFFFu : 0u, fR = ((A.sR >> j) & 1u) ? 0xFFFFFFFFu : 0u;
-#pragma unroll
-                        for (int i = 0; i < GW; i++) {
-                            sf[i] = __builtin_amdgcn_bitop3_b32(sf[i], cur[i], fF, kLutOrAnd);
-                            sr[i] = __builtin_amdgcn_bitop3_b32(sr[i], cur[i], fR, kLutOrAnd);
-                        }
-                    }
-#pragma unroll
-                    for (int i = 0; i < GW; i++) cur[i] = nxt[i];
-                    evw = evn;
-                }
-            }
-            uint32_t nP = 0, nF = 0, nR = 0;
-#pragma unroll
-            for (int i = 0; i < GW; i++) {
-                const uint32_t far = LV == 1 ? t1[i] : (LV == 2 ? t2[i] : (LV == 3 ? t3[i] : t4[i]));
-                nP += __popc(valid[i] & ~t1[i]);
-                nF += __popc(__builtin_amdgcn_bitop3_b32(valid[i], far, sf[i], kLutAndNotNot));
-                nR += __popc(__builtin_amdgcn_bitop3_b32(valid[i], far, sr[i], kLutAndNotNot));
-            }
-            acc[s] = nP | (nF << 10) | (nR << 20);
-        }
-    }
-    uint32_t accP[CC], accF[CC], accR[CC];
-#pragma unroll
-    for (int c = 0; c < CC; c++) { accP[c] = acc[c] & 1023u; accF[c] = (acc[c] >> 10) & 1023u; accR[c] = acc[c] >> 20; }
-    if (on_patch) wave_commit<GW>(accP, accF, accR, s_part[threadIdx.x >> 6], A.cand_out + it.cand0, A.out, negative);
-    else block_commit<GW>(accP, accF, accR, s_part, A.cand_out + it.cand0, A.out);
+    __shared__ uint32_t s_part[kBlock / 64][12];
+    eval_chain_block<LV, GW, D>(A, s_part, blockIdx.x);
 }
 
 // The same for chains of more than 8 members (up to 64): the members are counted 8 at a time — one group of output
@@ -1405,14 +1213,20 @@ int mp_eval_launch(mp_ctx *c, int64_t *device_out) {
                 // the first-pass kernel, the rest slides
                 // (the sliding kernel counts every row of a window as a plain column slice: the patch planes add the patch-list rows'
                 // real k-mers, their plain-slice planes take the plain counts back — the exclusion words are not read at all)
+                EvalChainArgs pa2 = ca;
+                int patch_blocks = 0;
                 if (ca.patch.n_blocks) {
                     { int rc = ensure_plain_planes(c); if (rc) return rc; }
-                    EvalChainArgs pa2 = ca;
-                    const PatchArgs neg = patch_args(c, cgw[cshape], c->slide_items, 64);
+                    // patch units are laid out for 8 words per thread (the shape the sliding launch runs them in)
+                    pa2.patch = patch_args(c, 8, c->n_chain, 64);
+                    const PatchArgs neg = patch_args(c, 8, c->slide_items, 64);
                     pa2.patch.qplanes = c->qplanes; pa2.patch.qvalid = c->qvalid; pa2.patch.neg_blocks = neg.n_blocks;
                     pa2.neg_items = c->chain_slid; pa2.n_neg = c->slide_items;
-                    hipLaunchKernelGGL((c->max_steps > kEvalCC ? lfn : cfn)[c->v][cshape], dim3((unsigned)(ca.patch.n_blocks + neg.n_blocks)),
-                                       dim3(kBlock), 0, c->stream, pa2);
+                    patch_blocks = pa2.patch.n_blocks + neg.n_blocks;
+                    if (c->max_steps > kEvalCC) {                 // chains of more than 8 members: the long-chain kernel, a launch of its own
+                        hipLaunchKernelGGL(lfn[c->v][7], dim3((unsigned)patch_blocks), dim3(kBlock), 0, c->stream, pa2);
+                        patch_blocks = 0;
+                    }
                 }
                 if (c->n_rest) {
                     unsigned rgrid;
@@ -1422,7 +1236,7 @@ int mp_eval_launch(mp_ctx *c, int64_t *device_out) {
                                      (unsigned long long *)device_out, rbm, none, nullptr, 0};
                     hipLaunchKernelGGL((c->rest_max_steps > kEvalCC ? lfn : cfn)[c->v][cshape], dim3(rgrid), dim3(kBlock), 0, c->stream, ra);
                 }
-                int rc = launch_eval_slide(c, (unsigned long long *)device_out);
+                int rc = launch_eval_slide(c, (unsigned long long *)device_out, patch_blocks ? &pa2 : nullptr, patch_blocks);
                 if (rc) return rc;
             } else {
             if (use_prog) {

@@ -19,6 +19,7 @@
 #include "bitslice.hpp"
 #include "slidecore.hpp"
 #include "evalslide.hpp"
+#include "chainbody.hpp"
 
 using namespace mp;
 
@@ -35,6 +36,8 @@ struct SlideKernArgs {
     unsigned long long *out;
     int wc, wc_pad;                    // row slices of 256 x GW words; padded to a multiple of 8 (a slice stays on one XCD)
     int max_items;                     // items of the largest band (LDS table rows)
+    int n_slide_blocks;                // the grid's first workgroups slide; the rest run the step's patch units (chainbody.hpp)
+    EvalChainArgs chain;
 };
 
 template <int GW>
@@ -139,6 +142,13 @@ struct DevEnv {
 template <int LV, int GW>
 __global__ __launch_bounds__(kBlock) void eval_slide_kernel(const SlideKernArgs K) {
     extern __shared__ __align__(16) uint32_t lds[];
+    if ((int)blockIdx.x >= K.n_slide_blocks) {
+        // the tail of the grid: the patch-list rows of the same step (their real k-mers added, their plain slices taken back) — no
+        // launch of their own, they fill the slots the sliding workgroups leave as they finish
+        uint32_t(&s_part)[kBlock / 64][12] = *reinterpret_cast<uint32_t(*)[kBlock / 64][12]>(lds);
+        eval_chain_block<LV, 8, 4>(K.chain, s_part, blockIdx.x - (unsigned)K.n_slide_blocks);
+        return;
+    }
     const int slice = (int)(blockIdx.x % (unsigned)K.wc_pad), band = (int)(blockIdx.x / (unsigned)K.wc_pad);
     if (slice >= K.wc) return;
     const int wv = (int)(threadIdx.x >> 6), lane = (int)(threadIdx.x & 63);
@@ -259,7 +269,7 @@ int upload_eval_slide(mp_ctx *c, const std::vector<ChainItem> &chains, const std
     return MP_OK;
 }
 
-int launch_eval_slide(mp_ctx *c, unsigned long long *device_out) {
+int launch_eval_slide(mp_ctx *c, unsigned long long *device_out, const EvalChainArgs *patch, int patch_blocks) {
 #define SLIDE_ROW(LV) {eval_slide_kernel<LV, 1>, eval_slide_kernel<LV, 2>, eval_slide_kernel<LV, 4>}
     static const SlideFn fn[4][3] = {SLIDE_ROW(1), SLIDE_ROW(2), SLIDE_ROW(3), SLIDE_ROW(4)};
 #undef SLIDE_ROW
@@ -275,11 +285,14 @@ int launch_eval_slide(mp_ctx *c, unsigned long long *device_out) {
     K.wc = (nw32 + kBlock * gw - 1) / (kBlock * gw);
     K.wc_pad = K.wc >= 8 ? (K.wc + 7) / 8 * 8 : K.wc;
     K.max_items = c->slide_max_items;
+    K.n_slide_blocks = c->slide_n_bands * K.wc_pad;
+    if (patch) K.chain = *patch;
+    else { memset(&K.chain, 0, sizeof K.chain); patch_blocks = 0; }
     const size_t lds = ((size_t)(kBlock / 64) * ((size_t)c->k * 64 * gw + 48) + (size_t)c->slide_max_items * 12) * sizeof(uint32_t);
     if (lds > 160 * 1024) return fail(c, MP_ERR_ARG, "sliding evaluation: a band needs %zu bytes of LDS", lds);
     SlideFn f = fn[c->v][gi];
     if (lds > 48 * 1024) HIPCK(c, hipFuncSetAttribute(reinterpret_cast<const void *>(f), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    hipLaunchKernelGGL(f, dim3((unsigned)c->slide_n_bands * (unsigned)K.wc_pad), dim3(kBlock), lds, c->stream, K);
+    hipLaunchKernelGGL(f, dim3((unsigned)K.n_slide_blocks + (unsigned)patch_blocks), dim3(kBlock), lds, c->stream, K);
     HIPCK(c, hipGetLastError());
     return MP_OK;
 }

@@ -9,7 +9,10 @@ namespace mp {
 // Builds the plan for the staged chain items and uploads it; c->slide_items = 0 when nothing slides (the first-pass kernels keep
 // every item).  Items the plan leaves out are collected in c->chain_rest for the first-pass kernel.
 int upload_eval_slide(mp_ctx *c, const std::vector<ChainItem> &chains, const std::vector<uint32_t> &events, const std::vector<int32_t> &cand_out);
-int launch_eval_slide(mp_ctx *c, unsigned long long *device_out);
+struct EvalChainArgs;
+// `patch` (may be null) = the patch units of the same step (eval.hip: positive and subtracting run), `patch_blocks` workgroups of
+// eval_chain_block<LV, 8, 4>: they run as the tail of the sliding kernel's own grid instead of a launch of their own.
+int launch_eval_slide(mp_ctx *c, unsigned long long *device_out, const EvalChainArgs *patch, int patch_blocks);
 void free_slide(mp_ctx *c);
 
 }  // namespace mp
