@@ -60,7 +60,7 @@ COUNTER_FILES = ("r04_counters.json", "r03_counters.json")
 # sources of the timed kernel (eval_chain_kernel and what it includes): the key of a counter entry
 KERNEL_SOURCES = ("eval.hip", "evalprog.hip", "evalslide.hip", "slidecore.hpp", "slideplan.hpp", "evalslide.hpp", "bitslice.hpp", "common.hpp",
                   "winwords.hpp", "evalprog.hpp")
-SLIDE_FROM_ROWS = 393216     # evalslide.hip (upload_eval_slide): from this many (padded) rows up the chains are evaluated by sliding
+SLIDE_FROM_ROWS = 262145     # evalslide.hip (upload_eval_slide): above 262144 (padded) rows the chains are evaluated by sliding
 PROG_FROM_ROWS = 393216      # eval.hip (mp_eval_upload): the program-driven first-pass kernel, when sliding is switched off
 
 KERNELS = {

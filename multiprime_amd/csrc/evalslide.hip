@@ -208,14 +208,16 @@ void free_slide(mp_ctx *c) {
     c->n_rest = c->rest_max_steps = 0;
 }
 
-// MP_EVAL_SLIDE=0 keeps the first-pass kernels; =1 forces the sliding kernel at any size; default: from 393216 rows up (below, the bands
-// that fill the chip are so short that their k - 1 warm-up columns outweigh what sliding saves: profiles/r04_slide_sizes.txt).
+// MP_EVAL_SLIDE=0 keeps the first-pass kernels; =1 forces the sliding kernel at any size; default: above 262144 rows (at and below, the
+// bands that fill the chip are so short that their k - 1 warm-up columns outweigh what sliding saves, and the column planes still
+// come out of L2 / the Infinity Cache for the first-pass kernel: equal at 262144, 18-24 % faster from 327680 up —
+// profiles/r04_slide_sizes.txt).
 // MP_SLIDE_GW (1, 2, 4): row words per lane; MP_SLIDE_BAND: windows per band.
 int upload_eval_slide(mp_ctx *c, const std::vector<ChainItem> &chains, const std::vector<uint32_t> &events, const std::vector<int32_t> &cand_out) {
     free_slide(c);
     const char *se = getenv("MP_EVAL_SLIDE");
     // (k > v: the column pass runs without exclusion words and relies on an all-gap slice — a padding row — having more than v mismatches)
-    if (chains.empty() || c->v > 3 || c->k <= c->v || (se ? atoi(se) != 1 : c->n_pad < 393216)) return MP_OK;
+    if (chains.empty() || c->v > 3 || c->k <= c->v || (se ? atoi(se) != 1 : c->n_pad <= 262144)) return MP_OK;
     const int nw32 = c->n_pad / 32, n_cols = c->n_chunks * 32;
     if (((unsigned long long)n_cols * 4ull + 1ull) * (unsigned long long)nw32 * 4ull >= 0x7FFFFFFFull) return MP_OK;     // plane rows are addressed by a 32-bit scalar offset
     if ((unsigned long long)c->n_win * (unsigned long long)nw32 * 4ull >= 0x7FFFFFFFull) return MP_OK;

@@ -32,6 +32,8 @@ import numpy as np
 
 REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, REPO)
+from multiprime_amd._abi import prefer_staged_copies  # noqa: E402
+prefer_staged_copies()            # a program's own decision, before the HIP runtime starts (multiprime_amd/_abi.py)
 from multiprime_amd.core import NN_degenerate  # noqa: E402
 from multiprime_amd.synth import synth_block, to_fasta  # noqa: E402
 

@@ -11,6 +11,8 @@ import tempfile
 
 REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, REPO)
+from multiprime_amd._abi import prefer_staged_copies  # noqa: E402
+prefer_staged_copies()            # a program's own decision, before the HIP runtime starts (multiprime_amd/_abi.py)
 from multiprime_amd.core import NN_degenerate  # noqa: E402
 
 name = sys.argv[1] if len(sys.argv) > 1 else "cluster0_v2"
