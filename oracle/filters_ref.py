@@ -9,8 +9,8 @@ from __future__ import annotations
 import re
 from statistics import mean
 
-from multiprime_amd.iupac import REPEATS as _REPEATS, exact_mean, expand, occurs_in_some_expansion, revcomp
-from multiprime_amd.thermo import delta_g, penalty_points
+from oracle.iupac_ref import REPEATS as _REPEATS, exact_mean, expand, occurs_in_some_expansion, revcomp
+from oracle.thermo_ref import delta_g, penalty_points
 
 
 def gc_fraction(primer: str) -> float:
