@@ -18,13 +18,16 @@
  * Encodings
  *   symbol code   4-bit IUPAC base-set mask: A=1 C=2 G=4 T=8, R=A|G ... ; '-' (and anything
  *                 V20:453 maps to '-', N included) = 0.
- *   window words  one (window,row) k-mer = three uint32: b0,b1 = low/high bit of the base
+ *   window words  one (window,row) k-mer = three words: b0,b1 = low/high bit of the base
  *                 index (A=0,C=1,G=2,T=3; 0 where gap), g = gap flag; bit j = window position
- *                 j (0 = 5' end), k <= MP_MAX_K.  g bit 31 (MP_WIN_SKIP) marks a slot that is
- *                 not part of the evaluated universe (its window holds an IUPAC code and was
- *                 handed to the host as an exception, or the row does not exist).
+ *                 j (0 = 5' end), k <= MP_MAX_K.  A word is a uint32 while k <= MP_NARROW_K (31)
+ *                 and a uint64 for 32 <= k <= 63 (MP_WORD_BYTES(k)); arrays of words are passed
+ *                 as void pointers.  The top bit of g (MP_WIN_SKIP, bit 31 / MP_WIN_SKIP64, bit
+ *                 63) marks a slot that is not part of the evaluated universe (its window holds
+ *                 an IUPAC code and was handed to the host as an exception, or the row does not
+ *                 exist).
  *   candidate     k symbol codes (one uint8 each), 5'->3'.
- *   strict mask   bit j set = a mismatch at 0-based position j disqualifies (V20:1091-1101
+ *   strict mask   uint64, bit j set = a mismatch at 0-based position j disqualifies (V20:1091-1101
  *                 get_Y; entries outside [0,k) are dropped by the host, as they can never
  *                 equal a mismatch index).
  */
@@ -37,8 +40,11 @@
 extern "C" {
 #endif
 
-#define MP_MAX_K 31
+#define MP_MAX_K 63            /* the reference takes any -l (V20:64-65); here one k-mer fits one machine word per plane */
+#define MP_NARROW_K 31         /* up to here window words are 32-bit */
+#define MP_WORD_BYTES(k) ((k) <= MP_NARROW_K ? 4 : 8)
 #define MP_WIN_SKIP 0x80000000u
+#define MP_WIN_SKIP64 0x8000000000000000ull
 
 #define MP_OK 0
 #define MP_ERR_ARG (-1)          /* bad argument / call order */
@@ -101,10 +107,10 @@ int mp_get_exceptions(mp_ctx *ctx, int32_t cap, int32_t *ex_window, int32_t *ex_
 
 /* Concrete expansions of exception k-mers with <= v gaps, as extra rows of the evaluated
  * universe: window[i] ascending (relative to p0), words[3*i..3*i+2] = b0,b1,g. */
-int mp_set_extra_rows(mp_ctx *ctx, int32_t n_extra, const int32_t *window, const uint32_t *words);
+int mp_set_extra_rows(mp_ctx *ctx, int32_t n_extra, const int32_t *window, const void *words);
 
 /* Parity/debug: window words of rows [row0,row0+n) of window w: out[0..n)=b0, [n..2n)=b1, [2n..3n)=g */
-int mp_get_window_words(mp_ctx *ctx, int32_t w, int32_t row0, int32_t n, uint32_t *out);
+int mp_get_window_words(mp_ctx *ctx, int32_t w, int32_t row0, int32_t n, void *out);
 
 /* (3) per-window k-mer histogram ----------------------------------------------------------- */
 /* Replaces the dictionary building of get_primers (V20:689-711: cover / gap_sequence counts
@@ -118,7 +124,7 @@ int mp_window_unique(mp_ctx *ctx, int64_t cap_entries, int32_t want_labels, int6
 
 /* Entries of window w are [win_off[w], win_off[w+1]); order inside a window is unspecified.
  * words: b0 at [0,n), b1 at [n,2n), g at [2n,3n) with n = total entries. */
-int mp_get_unique(mp_ctx *ctx, int64_t *win_off, uint32_t *words, int32_t *count, int32_t *first_row);
+int mp_get_unique(mp_ctx *ctx, int64_t *win_off, void *words, int32_t *count, int32_t *first_row);
 int mp_get_labels(mp_ctx *ctx, int32_t w, int32_t *labels);
 /* The labels of n windows at once: labels[i][n_rows] = those of windows[i] (one synchronisation for all of them). */
 int mp_get_labels_many(mp_ctx *ctx, int32_t n, const int32_t *windows, int32_t *labels);
@@ -144,7 +150,7 @@ int mp_window_stats(mp_ctx *ctx, int64_t *freq, int64_t *nn);
  *   out[3c+2] += 0 < |D| <= v and D & strictR == 0    R_mis_cover       (V20:1127)
  * One call = one batched launch over all candidates. */
 int mp_eval_candidates(mp_ctx *ctx, int32_t n_cand, const int32_t *cand_window, const uint8_t *cand_codes,
-                       uint32_t strictF, uint32_t strictR, int64_t *out);
+                       uint64_t strictF, uint64_t strictR, int64_t *out);
 
 /* (4c) per-sequence coverage masks ----------------------------------------------------------- */
 /* The bitset form of the two JSON side files (V20:1172-1177) for one candidate per entry: for
@@ -155,7 +161,7 @@ int mp_eval_candidates(mp_ctx *ctx, int32_t n_cand, const int32_t *cand_window, 
  * Each mask is (n_rows + 63) / 64 words.  This is what the pairing stage needs and it
  * scales as bits, not id strings. */
 int mp_eval_masks(mp_ctx *ctx, int32_t n_cand, const int32_t *cand_window, const uint8_t *cand_codes,
-                  uint32_t strictF, uint32_t strictR, uint64_t *not_f, uint64_t *not_r);
+                  uint64_t strictF, uint64_t strictR, uint64_t *not_f, uint64_t *not_r);
 
 /* (4d) the same masks kept on the device — the hand-off to the pairing stage when core and pairing run in one process:
  * mp_eval_masks_resident computes them and leaves them in the context ([n_cand][row words]); mp_masks_set_bits applies the
@@ -164,7 +170,7 @@ int mp_eval_masks(mp_ctx *ctx, int32_t n_cand, const int32_t *cand_window, const
  * pair (i, j), popcount(not_f[i] | not_r[j]) — the sequences a forward primer at window i or a reverse primer at window j
  * does not reach (get_multiPrime_V8.py:560-569) — without the masks ever leaving HBM. */
 int mp_eval_masks_resident(mp_ctx *ctx, int32_t n_cand, const int32_t *cand_window, const uint8_t *cand_codes,
-                           uint32_t strictF, uint32_t strictR);
+                           uint64_t strictF, uint64_t strictR);
 int mp_masks_set_bits(mp_ctx *ctx, int64_t n, const int32_t *mask_index, const int32_t *row, const uint8_t *which, const uint8_t *value);
 int mp_masks_fetch(mp_ctx *ctx, uint64_t *not_f, uint64_t *not_r);
 int mp_pair_coverage_resident(mp_ctx *ctx, int64_t n_pairs, const int32_t *pairs, int32_t *out);
@@ -174,7 +180,7 @@ int mp_pair_coverage_resident(mp_ctx *ctx, int64_t n_pairs, const int32_t *pairs
  * [n_cand][3] int64 counters in `device_out` (device memory owned by the caller, e.g. a torch
  * tensor that is then all-reduced over RCCL).  The oracle treats device_out as host memory. */
 int mp_eval_upload(mp_ctx *ctx, int32_t n_cand, const int32_t *cand_window, const uint8_t *cand_codes,
-                   uint32_t strictF, uint32_t strictR);
+                   uint64_t strictF, uint64_t strictR);
 int mp_eval_launch(mp_ctx *ctx, int64_t *device_out);
 
 /* HIP-event timing of the evaluation kernels themselves (recorded on the context's stream around
@@ -306,7 +312,7 @@ int mp_comm_allgather_i64(mp_ctx *ctx, int64_t value, int64_t *out);
 int mp_comm_allgatherv(mp_ctx *ctx, const void *send, int64_t n_bytes, const int64_t *counts, void *recv);
 /* mp_eval_candidates over this rank's rows + the all-reduce of the counters on the same stream: out = the global counts */
 int mp_eval_candidates_allreduce(mp_ctx *ctx, int32_t n_cand, const int32_t *cand_window, const uint8_t *cand_codes,
-                                 uint32_t strictF, uint32_t strictR, int64_t *out);
+                                 uint64_t strictF, uint64_t strictR, int64_t *out);
 
 /* Memory the context holds on the device, in bytes (window words, planes, tables). */
 int mp_device_bytes(mp_ctx *ctx, int64_t *bytes);

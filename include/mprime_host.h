@@ -83,13 +83,13 @@ typedef struct mp_plan_params {
  *     position fastest) unless it has more than v gaps (then it is a gap_sequence key as it stands, V20:689-698);
  * then applies the gates, computes the entropies, takes the seeds from freq [W][4][k] / nn [W][k-1][4][4]
  * (mp_window_stats, summed over shards) and derives the whole refinement chain of every seed. */
-int mp_plan_create(const mp_plan_params *params, int64_t n_entries, const int32_t *e_window, const uint32_t *e_words,
+int mp_plan_create(const mp_plan_params *params, int64_t n_entries, const int32_t *e_window, const void *e_words,
                    const int64_t *e_count, const int64_t *e_first, int64_t n_exc, const int32_t *x_window,
                    const int64_t *x_row, const uint8_t *x_codes, const int64_t *freq, const int64_t *nn, mp_plan **out);
 /* The same for the entries of ONE rank exactly as mp_get_unique returned them: window segments e_off [W+1] (entries of window w at
  * [e_off[w], e_off[w+1])), e_words as above, 32-bit counts and LOCAL first rows (row_base is added) — no per-entry window array, no
  * widening copies on the caller's side. */
-int mp_plan_create_segments(const mp_plan_params *params, const int64_t *e_off, const uint32_t *e_words, const int32_t *e_count,
+int mp_plan_create_segments(const mp_plan_params *params, const int64_t *e_off, const void *e_words, const int32_t *e_count,
                             const int32_t *e_first, int64_t row_base, int64_t n_exc, const int32_t *x_window, const int64_t *x_row,
                             const uint8_t *x_codes, const int64_t *freq, const int64_t *nn, mp_plan **out);
 void mp_plan_destroy(mp_plan *p);
@@ -137,16 +137,16 @@ int mp_plan_window_table(const mp_plan *p, int32_t w, int32_t which, int64_t cap
  *   labels [n_out][n_rows] — mp_get_labels of each output window (index of the row's entry inside its window, -1 = none),
  *   the exception list (x_window, x_row, x_codes) and the ids (raw bytes + offsets, decoded as UTF-8 / surrogateescape). */
 int mp_plan_write_side_files(const mp_plan *p, int32_t n_out, const int32_t *out_window, const int64_t *out_pos,
-                             const uint8_t *primer_codes, uint32_t strictF, uint32_t strictR, const int64_t *dev_off,
-                             const uint32_t *dev_words, int64_t n_dev, const int32_t *labels, int32_t n_rows, int64_t n_exc,
+                             const uint8_t *primer_codes, uint64_t strictF, uint64_t strictR, const int64_t *dev_off,
+                             const void *dev_words, int64_t n_dev, const int32_t *labels, int32_t n_rows, int64_t n_exc,
                              const int32_t *x_window, const int64_t *x_row, const uint8_t *x_codes, const uint8_t *ids,
                              const int64_t *id_off, const char *noncov_path, const char *gap_path);
 /* The same files written in several calls, each for a run of consecutive output windows with the labels of just those windows (a
  * 10^6-row alignment with 900 output windows would otherwise need 3.6 GB of labels at once): part bit 0 = this is the first run (the
  * files are created), bit 1 = the last one (the objects are closed); part = 3 is mp_plan_write_side_files.  Same bytes. */
 int mp_plan_write_side_files_part(const mp_plan *p, int32_t n_out, const int32_t *out_window, const int64_t *out_pos,
-                                  const uint8_t *primer_codes, uint32_t strictF, uint32_t strictR, const int64_t *dev_off,
-                                  const uint32_t *dev_words, int64_t n_dev, const int32_t *labels, int32_t n_rows, int64_t n_exc,
+                                  const uint8_t *primer_codes, uint64_t strictF, uint64_t strictR, const int64_t *dev_off,
+                                  const void *dev_words, int64_t n_dev, const int32_t *labels, int32_t n_rows, int64_t n_exc,
                                   const int32_t *x_window, const int64_t *x_row, const uint8_t *x_codes, const uint8_t *ids,
                                   const int64_t *id_off, const char *noncov_path, const char *gap_path, int32_t part);
 
@@ -154,7 +154,7 @@ int mp_plan_write_side_files_part(const mp_plan *p, int32_t n_out, const int32_t
  * of the k-mer expansion i comes from.  *n_out returns the number needed; MP_ERR_CAPACITY if cap is too small. */
 int mp_expand_kmers(int32_t k, int64_t n, const uint8_t *codes, int64_t cap, uint8_t *out_codes, int64_t *out_src, int64_t *n_out);
 /* The same expansions as window words (b0, b1, g of mprime.h, three per expansion) — what mp_set_extra_rows takes. */
-int mp_expand_kmer_words(int32_t k, int64_t n, const uint8_t *codes, int64_t cap, uint32_t *out_words, int64_t *out_src,
+int mp_expand_kmer_words(int32_t k, int64_t n, const uint8_t *codes, int64_t cap, void *out_words, int64_t *out_src,
                          int64_t *n_out);
 
 #ifdef __cplusplus

@@ -12,7 +12,13 @@ import os
 
 import numpy as np
 
-MP_MAX_K = 31
+MP_MAX_K = 63
+MP_NARROW_K = 31          # window words are uint32 up to here, uint64 above (mprime.h MP_WORD_BYTES)
+
+
+def word_dtype(k: int):
+    """numpy dtype of the window words of primer length k."""
+    return np.uint32 if k <= MP_NARROW_K else np.uint64
 MP_WIN_SKIP = 0x80000000
 MP_ERR_CAPACITY = -4
 MP_ERR_SHORT_WINDOW = -5
@@ -41,13 +47,13 @@ SYMBOLS = [
     ("mp_get_unique", C.c_int, [_p, _p, _p, _p, _p]),
     ("mp_get_labels", C.c_int, [_p, C.c_int32, _p]),
     ("mp_get_labels_many", C.c_int, [_p, C.c_int32, _p, _p]),
-    ("mp_eval_candidates", C.c_int, [_p, C.c_int32, _p, _p, C.c_uint32, C.c_uint32, _p]),
-    ("mp_eval_masks", C.c_int, [_p, C.c_int32, _p, _p, C.c_uint32, C.c_uint32, _p, _p]),
-    ("mp_eval_masks_resident", C.c_int, [_p, C.c_int32, _p, _p, C.c_uint32, C.c_uint32]),
+    ("mp_eval_candidates", C.c_int, [_p, C.c_int32, _p, _p, C.c_uint64, C.c_uint64, _p]),
+    ("mp_eval_masks", C.c_int, [_p, C.c_int32, _p, _p, C.c_uint64, C.c_uint64, _p, _p]),
+    ("mp_eval_masks_resident", C.c_int, [_p, C.c_int32, _p, _p, C.c_uint64, C.c_uint64]),
     ("mp_masks_set_bits", C.c_int, [_p, C.c_int64, _p, _p, _p, _p]),
     ("mp_masks_fetch", C.c_int, [_p, _p, _p]),
     ("mp_pair_coverage_resident", C.c_int, [_p, C.c_int64, _p, _p]),
-    ("mp_eval_upload", C.c_int, [_p, C.c_int32, _p, _p, C.c_uint32, C.c_uint32]),
+    ("mp_eval_upload", C.c_int, [_p, C.c_int32, _p, _p, C.c_uint64, C.c_uint64]),
     ("mp_eval_launch", C.c_int, [_p, _p]),
     ("mp_eval_timing", C.c_int, [_p, C.c_int32, C.POINTER(C.c_double), C.POINTER(C.c_int32)]),
     ("mp_eval_timing_samples", C.c_int, [_p, C.c_int32, _p, C.POINTER(C.c_int32)]),
@@ -66,7 +72,7 @@ SYMBOLS = [
     ("mp_comm_allreduce_host_i64", C.c_int, [_p, _p, C.c_int64]),
     ("mp_comm_allgather_i64", C.c_int, [_p, C.c_int64, _p]),
     ("mp_comm_allgatherv", C.c_int, [_p, _p, C.c_int64, _p, _p]),
-    ("mp_eval_candidates_allreduce", C.c_int, [_p, C.c_int32, _p, _p, C.c_uint32, C.c_uint32, _p]),
+    ("mp_eval_candidates_allreduce", C.c_int, [_p, C.c_int32, _p, _p, C.c_uint64, C.c_uint64, _p]),
     ("mp_device_bytes", C.c_int, [_p, C.POINTER(C.c_int64)]),
 ]
 COMM_ID_BYTES = 128
@@ -188,12 +194,12 @@ class Context:
 
     def set_extra_rows(self, window: np.ndarray, words: np.ndarray):
         window = np.ascontiguousarray(window, dtype=np.int32)
-        words = np.ascontiguousarray(words, dtype=np.uint32).reshape(-1, 3)
+        words = np.ascontiguousarray(words, dtype=word_dtype(self.k)).reshape(-1, 3)
         self._ck(self.d.mp_set_extra_rows(self.h, len(window), _ptr(window), _ptr(words)))
 
     def get_window_words(self, w: int, row0: int = 0, n: int | None = None) -> np.ndarray:
         n = self.n_rows - row0 if n is None else n
-        out = np.empty((3, n), np.uint32)
+        out = np.empty((3, n), word_dtype(self.k))
         self._ck(self.d.mp_get_window_words(self.h, w, row0, n, _ptr(out)))
         return out
 
@@ -211,13 +217,12 @@ class Context:
         self._ck(rc)
         n = int(n.value)
         off = np.empty(self.n_win + 1, np.int64)
-        words = np.empty((3, max(n, 1)), np.uint32)
         count = np.empty(max(n, 1), np.int32)
         first = np.empty(max(n, 1), np.int32)
         # the C side packs words as [3][n]; allocate exactly so the strides agree
-        wbuf = np.empty(3 * max(n, 1), np.uint32)
+        wbuf = np.empty(3 * max(n, 1), word_dtype(self.k))
         self._ck(self.d.mp_get_unique(self.h, _ptr(off), _ptr(wbuf), _ptr(count), _ptr(first)))
-        words = wbuf[:3 * n].reshape(3, n) if n else np.zeros((3, 0), np.uint32)
+        words = wbuf[:3 * n].reshape(3, n) if n else np.zeros((3, 0), word_dtype(self.k))
         count, first = count[:n], first[:n]
         self._off = off
         if not sort:

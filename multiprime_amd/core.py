@@ -93,9 +93,9 @@ class NN_degenerate(object):
         self.mask_index = {}
         self.comm = comm                        # multiprime_amd.dist.RowShards or None
         k = self.primer_length
-        if not 2 <= k <= 31:
-            # the reference has no such limit; documented in INTEGRATION.md (window words are 32-bit, MP_MAX_K)
-            print("Error: primer length must be in [2, 31] for this build (packed window words).")
+        if not 2 <= k <= 63:
+            # the reference has no such limit; documented in INTEGRATION.md (one k-mer = one machine word per plane, MP_MAX_K)
+            print("Error: primer length must be in [2, 63] for this build (one window word per k-mer).")
             sys.exit(2)
         self.Y_strict, self.Y_strict_R = msa.strict_sets(position, k)
         self._sF = msa.strict_mask(self.Y_strict, k)

@@ -44,7 +44,7 @@ void free_eval(mp_ctx *c) {
     c->chain_prog_n = 0;
     c->prog_shape = -1;
     dev_free(c, &c->items, (size_t)c->n_items);
-    dev_free(c, &c->cand_n, (size_t)c->n_padded);
+    dev_free(c, &c->cand_n, (size_t)c->n_padded * wsz(c));
     dev_free(c, &c->cand_out, (size_t)c->n_padded);
     dev_free(c, &c->cand_symT, (size_t)c->n_items * 32);
     dev_free(c, &c->cand_diff, (size_t)c->n_items);
@@ -57,7 +57,7 @@ void free_eval(mp_ctx *c) {
 
 void free_unique(mp_ctx *c) {
     size_t cap = (size_t)c->u_cap, W = (size_t)c->n_win;
-    dev_free(c, &c->u_b0, cap); dev_free(c, &c->u_b1, cap); dev_free(c, &c->u_g, cap);
+    dev_free(c, &c->u_b0, cap * wsz(c)); dev_free(c, &c->u_b1, cap * wsz(c)); dev_free(c, &c->u_g, cap * wsz(c));
     dev_free(c, &c->u_count, cap); dev_free(c, &c->u_first, cap);
     dev_free(c, &c->labels, W * c->n_pad);
     dev_free(c, &c->u_over, W); dev_free(c, &c->u_wcount, W); dev_free(c, &c->u_wbase, W);
@@ -78,7 +78,7 @@ void free_windows(mp_ctx *c) {
     dev_free(c, &c->patch_count, (size_t)c->n_win * 32);
     dev_free(c, &c->patch_off, (size_t)c->n_win + 1);
     dev_free(c, &c->patch_cursor, (size_t)c->n_win * 32);
-    dev_free(c, &c->patch_words, (size_t)3 * c->n_patch);
+    dev_free(c, &c->patch_words, (size_t)3 * c->n_patch * wsz(c));
     dev_free(c, &c->patch_rows, (size_t)c->n_patch);
     c->n_patch = c->max_patch = 0;
     dev_free(c, &c->ex, (size_t)c->ex_cap);
@@ -88,7 +88,7 @@ void free_windows(mp_ctx *c) {
     dev_free(c, &c->pplanes, c->pp_words); dev_free(c, &c->pvalid, c->pv_words); dev_free(c, &c->pwin, (size_t)c->n_win);
     c->pp_words = c->pv_words = 0; c->max_npw = 0; c->pp_dirty = true; c->qp_dirty = true;
     dev_free(c, &c->extra_off, (size_t)c->n_win + 1);
-    dev_free(c, &c->extra_words, (size_t)3 * c->n_extra);
+    dev_free(c, &c->extra_words, (size_t)3 * c->n_extra * wsz(c));
     c->ex_cap = 0; c->n_extra = 0; c->n_win = 0;
     c->ex_host.clear();
 }

@@ -251,7 +251,7 @@ int mp_comm_allgatherv(mp_ctx *c, const void *send, int64_t n_bytes, const int64
     return MP_OK;
 }
 
-int mp_eval_candidates_allreduce(mp_ctx *c, int32_t n_cand, const int32_t *cw, const uint8_t *codes, uint32_t sF, uint32_t sR, int64_t *out) {
+int mp_eval_candidates_allreduce(mp_ctx *c, int32_t n_cand, const int32_t *cw, const uint8_t *codes, uint64_t sF, uint64_t sR, int64_t *out) {
     int rc = need_comm(c);
     if (rc) return rc;
     if ((rc = mp_eval_upload(c, n_cand, cw, codes, sF, sR))) return rc;

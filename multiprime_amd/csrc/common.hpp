@@ -37,7 +37,7 @@ constexpr int kHashSlots = 4096;          // LDS hash table slots per window (un
 constexpr int kHashLimit = 3584;          // load limit before the window is handed to the global-table path
 constexpr int kEvalCC = 8;                // candidates evaluated per block pass
 
-struct ExRec { int32_t win, row; uint64_t lo, hi; };          // exception k-mer, 16+12 nibbles
+struct ExRec { int32_t win, row; uint64_t q[4]; };          // exception k-mer: up to 64 symbol nibbles (NibT words)
 struct EvalItem { int32_t win, cand0; };                       // one block's work: window + first padded candidate
 // Patch planes of one window: k x 4 plane rows of npw words from pplanes[poff], npw validity words from pvalid[voff]
 struct PatchWin { int32_t poff, voff, npw; };
@@ -51,20 +51,47 @@ struct ChainItem {
 
 struct SlideBand;
 
-struct Nib {          // up to 32 symbol codes, one nibble each
-    uint64_t lo, hi;
-    __device__ uint32_t get(int j) const { return (uint32_t)((j < 16 ? lo >> (4 * j) : hi >> (4 * (j - 16))) & 15u); }
+// up to 16 * NQ symbol codes, one nibble each (position j = nibble j & 15 of word j >> 4).  NQ = 2: the k-mers of 32-bit window
+// words (the code of rounds 1-3, two named halves); NQ = 4: primers of 32..63 bases — the word index is a run-time value there, taken
+// through selects so that the words stay in registers.
+template <int NQ> struct NibT {
+    uint64_t q[NQ];
+    __device__ void clear() {
+#pragma unroll
+        for (int i = 0; i < NQ; i++) q[i] = 0;
+    }
+    __device__ uint32_t get(int j) const {
+        const int wi = j >> 4;
+        uint64_t w = q[0];
+#pragma unroll
+        for (int i = 1; i < NQ; i++) w = wi == i ? q[i] : w;
+        return (uint32_t)(w >> (4 * (j & 15))) & 15u;
+    }
     __device__ void set(int j, uint32_t v) {
-        if (j < 16) lo = (lo & ~(15ull << (4 * j))) | ((uint64_t)v << (4 * j));
-        else hi = (hi & ~(15ull << (4 * (j - 16)))) | ((uint64_t)v << (4 * (j - 16)));
+        const int wi = j >> 4, sh = 4 * (j & 15);
+#pragma unroll
+        for (int i = 0; i < NQ; i++)
+            if (wi == i) q[i] = (q[i] & ~(15ull << sh)) | ((uint64_t)v << sh);
     }
     __device__ void shift_up(int n) {      // move every nibble n positions towards the 3' end
-        int s = 4 * n;
+        const int s = 4 * n, ws = s >> 6, bs = s & 63;
         if (s == 0) return;
-        if (s >= 64) { hi = lo << (s - 64); lo = 0; }
-        else { hi = (hi << s) | (lo >> (64 - s)); lo <<= s; }
+        uint64_t out[NQ];
+#pragma unroll
+        for (int i = 0; i < NQ; i++) {
+            uint64_t a = 0, b = 0;           // a = q[i - ws], b = q[i - ws - 1]
+#pragma unroll
+            for (int t = 0; t < NQ; t++) {
+                if (t == i - ws) a = q[t];
+                if (t == i - ws - 1) b = q[t];
+            }
+            out[i] = bs ? (a << bs) | (b >> (64 - bs)) : a;
+        }
+#pragma unroll
+        for (int i = 0; i < NQ; i++) q[i] = out[i];
     }
 };
+typedef NibT<2> Nib;
 
 }  // namespace mp
 
@@ -99,6 +126,7 @@ struct mp_ctx {
     int32_t *lead = nullptr, *rstrip = nullptr, *rlen = nullptr;
     // windows
     int p0 = 0, n_win = 0, k = 0, v = 0;
+    bool wide = false;                       // k > MP_NARROW_K: window words are 64-bit (patch_words, extra_words, u_b0/u_b1/u_g hold two uint32 per word)
     unsigned long long *excl = nullptr;      // [W][n_pad/64]; non-null = windows are built
     int32_t *patch_count = nullptr, *patch_off = nullptr, *patch_cursor = nullptr;
     uint32_t *patch_words = nullptr;         // [n_patch][3] window words of the slow pairs (SKIP = exception / too short)
@@ -169,7 +197,7 @@ struct mp_ctx {
     int n_rest = 0, rest_max_steps = 0;
     unsigned launch_seq = 0;                 // launches since the last timing reset
     int32_t *cand_out = nullptr;
-    uint32_t sF = 0, sR = 0;
+    uint64_t sF = 0, sR = 0;
     unsigned long long *tmp_out = nullptr;
     int tmp_out_n = 0;
     std::vector<std::pair<hipEvent_t, hipEvent_t>> ev_busy, ev_free;
@@ -186,6 +214,8 @@ struct mp_ctx {
 
 namespace mp {
 
+
+inline size_t wsz(const mp_ctx *c) { return c->wide ? 2 : 1; }      // uint32 units per window word
 
 inline int fail(mp_ctx *c, int code, const char *fmt, ...) {
     va_list ap;

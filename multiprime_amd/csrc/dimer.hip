@@ -103,7 +103,7 @@ __device__ inline bool dimer_pair_group(const uint8_t *__restrict__ codes, const
     const unsigned long long gmask = (G == 64 ? ~0ull : ((1ull << (G & 63)) - 1ull)) << g0;
     const int lx = off[x + 1] - off[x], ly = off[y + 1] - off[y];
     Nib cx, cy;
-    cx.lo = cx.hi = cy.lo = cy.hi = 0;
+    cx.clear(); cy.clear();
     for (int p = 0; p < lx; p++) cx.set(p, codes[off[x] + p]);
     for (int p = 0; p < ly; p++) cy.set(p, codes[off[y] + p]);
     const uint32_t dy = dm_degeneracy(cy, 0, ly);
@@ -594,7 +594,7 @@ __global__ __launch_bounds__(kBlock) void pcr_kernel(const uint8_t *__restrict__
         return;
     }
     Nib cf, cr;
-    cf.lo = cf.hi = cr.lo = cr.hi = 0;
+    cf.clear(); cr.clear();
     for (int j = 0; j < lf; j++) cf.set(j, codes[off[2 * p] + j]);
     for (int j = 0; j < lr; j++) cr.set(j, codes[off[2 * p + 1] + j]);
     const uint32_t df = dm_degeneracy(cf, 0, lf), dr = dm_degeneracy(cr, 0, lr);
@@ -724,7 +724,7 @@ __global__ __launch_bounds__(kBlock) void pcr_block_kernel(const uint8_t *__rest
                 continue;
             }
             Nib cf, cr;
-            cf.lo = cf.hi = cr.lo = cr.hi = 0;
+            cf.clear(); cr.clear();
             for (int j = 0; j < lf; j++) cf.set(j, codes[off[2 * pr] + j]);
             for (int j = 0; j < lr; j++) cr.set(j, codes[off[2 * pr + 1] + j]);
             const uint32_t df = dm_degeneracy(cf, 0, lf), dr = dm_degeneracy(cr, 0, lr);

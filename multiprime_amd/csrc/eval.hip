@@ -28,23 +28,28 @@ namespace {
 // block (F_mis = F_raw - perfect), which saves the |D| != 0 test per evaluation.
 // VMODE 1 (v == 1, the pipeline default): |D| <= 1  <=>  mm & (mm-1) == 0, so
 //   F_raw <=> mm & ((mm-1) | strictF) == 0  — one v_add, one v_bitop3, one compare, no popcount.
-__device__ inline uint32_t bfi(uint32_t s, uint32_t a, uint32_t b) { return (s & a) | (~s & b); }
+template <typename W> __device__ inline W bfi(W s, W a, W b) { return (s & a) | (~s & b); }
 
-struct EvalArgs {
+// W = the window word type (winwords.hpp): uint32_t for k <= 31, uint64_t for primers of 32..63 bases, which only this row-per-lane
+// path evaluates (the bit-sliced kernels keep 32 positions per item)
+template <typename W> struct alignas(4 * sizeof(W)) CandN { W x, y, z, w; };      // nA,nC,nG,nT of one candidate (uint4 for W = uint32_t)
+template <typename W>
+struct EvalArgsT {
     MsaArgs M;                  // window words are derived from the planes on the fly (winwords.hpp)
     int p0;
     int n_pad, k;
     const EvalItem *items;
-    const uint4 *cand_n;        // [padded cand] nA,nC,nG,nT
+    const CandN<W> *cand_n;     // [padded cand] nA,nC,nG,nT
     const int32_t *cand_out;    // [padded cand] index into out or -1
     const int32_t *extra_off;   // [W+1] or nullptr
-    const uint32_t *extra_words;
-    uint32_t sF, sR;
+    const W *extra_words;
+    W sF, sR;
     int v;
-    uint32_t kmask;
+    W kmask;
     int rows_per_split;
     unsigned long long *out;
 };
+typedef EvalArgsT<uint32_t> EvalArgs;
 
 // COUNT 0: per-lane VGPR accumulators (v_cmp + v_addc); COUNT 1: wave ballots counted on the
 // scalar unit (v_cmp -> s_bcnt1_i32_b64 -> s_add), accumulators live in SGPRs.
@@ -71,32 +76,36 @@ struct EvalAcc {
 // FORM 1: candidate words pinned in VGPRs: three v_bfi_b32 + one v_or_b32 per evaluation;
 // FORM 2: per-row one-hot words eqX (4 ops per row, shared by the candidates) and a chain of four
 //         v_and_or_b32 with the candidate words as the single SGPR operand.
-template <int CC, int VMODE, int COUNT, int FORM>
-__device__ inline void eval_row(uint32_t b0, uint32_t b1, uint32_t g, const EvalArgs &A,
-                                const uint32_t (&nA)[CC], const uint32_t (&nC)[CC], const uint32_t (&nG)[CC],
-                                const uint32_t (&nT)[CC], EvalAcc<CC, COUNT> &acc) {
-    uint32_t gk = g & A.kmask;
+template <int CC, int VMODE, int COUNT, int FORM, typename W>
+__device__ inline void eval_row(W b0, W b1, W g, const EvalArgsT<W> &A,
+                                const W (&nA)[CC], const W (&nC)[CC], const W (&nG)[CC],
+                                const W (&nT)[CC], EvalAcc<CC, COUNT> &acc) {
+    W gk = g & A.kmask;
     // rows outside the universe (SKIP slots and k-mers with more than v gaps, V20:689) get an
-    // all-ones mismatch word: 32 mismatches, counted nowhere
-    if ((int)__popc(gk) > A.v) gk = 0xFFFFFFFFu;
-    uint32_t eA = 0, eC = 0, eG = 0, eT = 0;
+    // all-ones mismatch word: 32 (64) mismatches, counted nowhere
+    if (popcw(gk) > A.v) gk = ~(W)0;
+    W eA = 0, eC = 0, eG = 0, eT = 0;
     if (FORM == 2) { eA = ~(b0 | b1 | gk); eC = b0 & ~b1; eG = b1 & ~b0; eT = b0 & b1; }
 #pragma unroll
     for (int c = 0; c < CC; c++) {
-        uint32_t mm;
+        W mm;
         if (FORM == 2) mm = (eT & nT[c]) | ((eG & nG[c]) | ((eC & nC[c]) | ((eA & nA[c]) | gk)));
-        else mm = bfi(b1, bfi(b0, nT[c], nG[c]), bfi(b0, nC[c], nA[c])) | gk;
+        else mm = bfi<W>(b1, bfi<W>(b0, nT[c], nG[c]), bfi<W>(b0, nC[c], nA[c])) | gk;
         bool pp = mm == 0, ff, rr;
         if (VMODE == 0) {
             ff = rr = pp;
         } else if (VMODE == 1) {
-            uint32_t t;
-            if (FORM == 0) t = mm - 1u;
-            else asm("v_add_u32_e32 %0, -1, %1" : "=v"(t) : "v"(mm));   // no carry-out: keeps `mm == 0` a plain v_cmp
+            W t;
+            if (FORM == 0 || sizeof(W) == 8) t = mm - 1u;
+            else {
+                uint32_t t32;
+                asm("v_add_u32_e32 %0, -1, %1" : "=v"(t32) : "v"((uint32_t)mm));   // no carry-out: keeps `mm == 0` a plain v_cmp
+                t = t32;
+            }
             ff = (mm & (t | A.sF)) == 0;
             rr = (mm & (t | A.sR)) == 0;
         } else {
-            bool le = (int)__popc(mm) <= A.v;
+            bool le = popcw(mm) <= A.v;
             ff = le && (mm & A.sF) == 0;
             rr = le && (mm & A.sR) == 0;
         }
@@ -104,24 +113,25 @@ __device__ inline void eval_row(uint32_t b0, uint32_t b1, uint32_t g, const Eval
     }
 }
 
-struct Raw4 { uint32_t b0[4], b1[4], g[4]; };
-__device__ inline Raw4 load4(const FlyView &V, int r) {
-    Raw4 q;
+template <typename W> struct Raw4 { W b0[4], b1[4], g[4]; };
+template <typename W>
+__device__ inline Raw4<W> load4(const FlyViewT<W> &V, int r) {
+    Raw4<W> q;
 #pragma unroll
     for (int i = 0; i < 4; i++) V.load(r + i, q.b0[i], q.b1[i], q.g[i]);
     return q;
 }
 
-template <int CC, int VMODE, int COUNT, bool PREFETCH, int FORM>
-__global__ __launch_bounds__(kBlock) void eval_kernel(const EvalArgs A) {
+template <int CC, int VMODE, int COUNT, bool PREFETCH, int FORM, typename W = uint32_t>
+__global__ __launch_bounds__(kBlock) void eval_kernel(const EvalArgsT<W> A) {
     __shared__ uint32_t s_acc[3 * CC];
     const EvalItem it = A.items[blockIdx.x];
-    uint32_t nA[CC], nC[CC], nG[CC], nT[CC];
+    W nA[CC], nC[CC], nG[CC], nT[CC];
     EvalAcc<CC, COUNT> acc;
     acc.clear();
 #pragma unroll
     for (int c = 0; c < CC; c++) {
-        uint4 q = A.cand_n[it.cand0 + c];
+        const CandN<W> q = A.cand_n[it.cand0 + c];
         nA[c] = q.x; nC[c] = q.y; nG[c] = q.z; nT[c] = q.w;
         if (FORM == 1) {
             asm volatile("" : "+v"(nA[c]));
@@ -131,27 +141,27 @@ __global__ __launch_bounds__(kBlock) void eval_kernel(const EvalArgs A) {
         }
     }
     if (threadIdx.x < 3 * CC) s_acc[threadIdx.x] = 0;
-    const FlyView V(A.M, A.p0 + it.win, A.k, A.kmask);
+    const FlyViewT<W> V(A.M, A.p0 + it.win, A.k, A.kmask);
     const int r0 = blockIdx.y * A.rows_per_split;
     const int r1 = r0 + A.rows_per_split < A.n_pad ? r0 + A.rows_per_split : A.n_pad;
     // 4 consecutive sequences per lane and iteration, 16-byte loads (n_pad % 4 == 0)
     int r = r0 + threadIdx.x * 4;
-    Raw4 cur;
-    if (PREFETCH && r < r1) cur = load4(V, r);
+    Raw4<W> cur;
+    if (PREFETCH && r < r1) cur = load4<W>(V, r);
 #pragma unroll 1
     while (r < r1) {
         const int rn = r + kBlock * 4;
-        Raw4 now;
+        Raw4<W> now;
         if (PREFETCH) {
             now = cur;
-            if (rn < r1) cur = load4(V, rn);          // next group in flight while this one computes
+            if (rn < r1) cur = load4<W>(V, rn);       // next group in flight while this one computes
         } else {
-            now = load4(V, r);
+            now = load4<W>(V, r);
         }
 #pragma unroll
         for (int i = 0; i < 4; i++) {
-            const uint32_t b0 = now.b0[i], b1 = now.b1[i], g = now.g[i];
-            eval_row<CC, VMODE, COUNT, FORM>(b0, b1, g, A, nA, nC, nG, nT, acc);
+            const W b0 = now.b0[i], b1 = now.b1[i], g = now.g[i];
+            eval_row<CC, VMODE, COUNT, FORM, W>(b0, b1, g, A, nA, nC, nG, nT, acc);
         }
         r = rn;
     }
@@ -159,9 +169,9 @@ __global__ __launch_bounds__(kBlock) void eval_kernel(const EvalArgs A) {
         const int e0 = A.extra_off[it.win], e1 = A.extra_off[it.win + 1];
         for (int eb = e0; eb < e1; eb += kBlock) {   // uniform trip count: COUNT 1 ballots need every lane
             int e = eb + threadIdx.x;
-            uint32_t b0 = 0, b1 = 0, g = 0xFFFFFFFFu;
+            W b0 = 0, b1 = 0, g = ~(W)0;
             if (e < e1) { b0 = A.extra_words[3 * e]; b1 = A.extra_words[3 * e + 1]; g = A.extra_words[3 * e + 2]; }
-            eval_row<CC, VMODE, COUNT, FORM>(b0, b1, g, A, nA, nC, nG, nT, acc);
+            eval_row<CC, VMODE, COUNT, FORM, W>(b0, b1, g, A, nA, nC, nG, nT, acc);
         }
     }
     __syncthreads();
@@ -203,20 +213,22 @@ __global__ __launch_bounds__(kBlock) void eval_kernel(const EvalArgs A) {
 // written here as well (no fill beforehand)
 constexpr int kPatchRun = 1024;
 struct PatchRun { int32_t win, row0; };
-__global__ __launch_bounds__(kBlock) void patch_planes_kernel(const int32_t *__restrict__ off_a, const uint32_t *__restrict__ words_a,
-                                                              const int32_t *__restrict__ off_b, const uint32_t *__restrict__ words_b,
+template <typename W>
+__global__ __launch_bounds__(kBlock) void patch_planes_kernel(const int32_t *__restrict__ off_a, const W *__restrict__ words_a,
+                                                              const int32_t *__restrict__ off_b, const W *__restrict__ words_b,
                                                               const PatchWin *__restrict__ pwin, const PatchRun *__restrict__ runs, int k, int v,
                                                               uint32_t *__restrict__ pplanes, uint32_t *__restrict__ pvalid) {
     const PatchRun run = runs[blockIdx.x];
     const int win = run.win;
     const PatchWin pw = pwin[win];
     const int na = off_a ? off_a[win + 1] - off_a[win] : 0, nb = off_b ? off_b[win + 1] - off_b[win] : 0;
-    const uint32_t kmask = (1u << k) - 1u;
+    const W kmask = kmask_of<W>(k);
+    constexpr int NM = sizeof(W) == 4 ? 2 : 4;                                     // 64 (position, base) slots per register of ballots: k * 4 <= 64 * NM
     const int lane = threadIdx.x & 63;
     const int end = min(run.row0 + kPatchRun, pw.npw * 32);                        // npw is a multiple of 8 words: whole 64-row passes
     for (int r0 = run.row0 + (threadIdx.x >> 6) * 64; r0 < end; r0 += kBlock) {    // uniform per wave
         const int e = r0 + lane;
-        uint32_t b0 = 0, b1 = 0, g = 0xFFFFFFFFu;
+        W b0 = 0, b1 = 0, g = ~(W)0;
         if (e < na) {
             const size_t q = 3 * ((size_t)off_a[win] + e);
             b0 = words_a[q]; b1 = words_a[q + 1]; g = words_a[q + 2];
@@ -224,25 +236,31 @@ __global__ __launch_bounds__(kBlock) void patch_planes_kernel(const int32_t *__r
             const size_t q = 3 * ((size_t)off_b[win] + (e - na));
             b0 = words_b[q]; b1 = words_b[q + 1]; g = words_b[q + 2];
         }
-        const bool ok = e < na + nb && !(g & MP_WIN_SKIP) && (int)__popc(g & kmask) <= v;
+        const bool ok = e < na + nb && !(g & WordTraits<W>::kSkip) && popcw((W)(g & kmask)) <= v;
         const unsigned long long okb = __ballot(ok);
         const int w0 = r0 >> 5;                                                    // r0 % 64 == 0
         if (lane == 0) *reinterpret_cast<uint2 *>(pvalid + pw.voff + w0) = uint2{(uint32_t)okb, (uint32_t)(okb >> 32)};
         // lane (j * 4 + b) keeps the ballot of its (position, base) and stores it: one 8-byte store per lane instead of 4k from lane 0
-        unsigned long long mine = 0, mine2 = 0;
+        unsigned long long mine[NM];
+#pragma unroll
+        for (int q = 0; q < NM; q++) mine[q] = 0;
         for (int j = 0; j < k; j++) {
             const bool base_here = ok && !((g >> j) & 1u);
-            const uint32_t code = ((b0 >> j) & 1u) | (((b1 >> j) & 1u) << 1);
+            const uint32_t code = (uint32_t)((b0 >> j) & 1u) | ((uint32_t)((b1 >> j) & 1u) << 1);
 #pragma unroll
             for (uint32_t b = 0; b < 4; b++) {
                 const unsigned long long bal = __ballot(base_here && code == b);
                 const int slot = j * 4 + (int)b;
-                if (lane == (slot & 63)) { if (slot < 64) mine = bal; else mine2 = bal; }
+                if (lane == (slot & 63)) {
+#pragma unroll
+                    for (int q = 0; q < NM; q++) if ((slot >> 6) == q) mine[q] = bal;
+                }
             }
         }
-        if (lane < k * 4) *reinterpret_cast<uint2 *>(pplanes + pw.poff + (size_t)lane * pw.npw + w0) = uint2{(uint32_t)mine, (uint32_t)(mine >> 32)};
-        if (lane + 64 < k * 4)
-            *reinterpret_cast<uint2 *>(pplanes + pw.poff + (size_t)(lane + 64) * pw.npw + w0) = uint2{(uint32_t)mine2, (uint32_t)(mine2 >> 32)};
+#pragma unroll
+        for (int q = 0; q < NM; q++)
+            if (lane + 64 * q < k * 4)
+                *reinterpret_cast<uint2 *>(pplanes + pw.poff + (size_t)(lane + 64 * q) * pw.npw + w0) = uint2{(uint32_t)mine[q], (uint32_t)(mine[q] >> 32)};
     }
 }
 
@@ -734,10 +752,11 @@ __global__ __launch_bounds__(kBlock) void window_stats_kernel(const StatsArgs A)
 // there are no atomics; works on the window words, i.e. after edge-gap repair, for any v.
 // decision of one (candidate, k-mer) pair for the masks: would the sequence appear in gap_seq_id / the F (R) dict of
 // non_coverage_seq_id (V20:689-698, 1107-1127)?
-__device__ inline void mask_decide(uint32_t b0, uint32_t b1, uint32_t gk, const uint4 q, const EvalArgs &A, bool &bad_f, bool &bad_r) {
-    const bool gap_row = (int)__popc(gk) > A.v;
-    const uint32_t mm = bfi(b1, bfi(b0, q.w, q.z), bfi(b0, q.y, q.x)) | gk;
-    const int d = __popc(mm);
+template <typename W>
+__device__ inline void mask_decide(W b0, W b1, W gk, const CandN<W> q, const EvalArgsT<W> &A, bool &bad_f, bool &bad_r) {
+    const bool gap_row = popcw(gk) > A.v;
+    const W mm = bfi<W>(b1, bfi<W>(b0, q.w, q.z), bfi<W>(b0, q.y, q.x)) | gk;
+    const int d = popcw(mm);
     const bool near = d <= A.v;
     bad_f = gap_row || !(near && (d == 0 || !(mm & A.sF)));
     bad_r = gap_row || !(near && (d == 0 || !(mm & A.sR)));
@@ -745,23 +764,21 @@ __device__ inline void mask_decide(uint32_t b0, uint32_t b1, uint32_t gk, const 
 
 // thread = row of one item's window, 8 candidates: plain column slices straight from the planes (fast_words, no divergence);
 // the repaired / ragged rows of the window are added by mask_patch_kernel from the patch list, IUPAC rows stay 0 (host).
-template <int CC>
-__global__ __launch_bounds__(kBlock) void mask_rows_kernel(const EvalArgs A, int n_rows, unsigned long long *__restrict__ not_f,
+template <int CC, typename W = uint32_t>
+__global__ __launch_bounds__(kBlock) void mask_rows_kernel(const EvalArgsT<W> A, int n_rows, unsigned long long *__restrict__ not_f,
                                                            unsigned long long *__restrict__ not_r) {
     const EvalItem it = A.items[blockIdx.x];
     const int r = blockIdx.y * kBlock + threadIdx.x;             // n_pad is a multiple of kBlock
     const size_t nw = (size_t)A.n_pad / 64, np = (size_t)A.n_pad;
     const int p = A.p0 + it.win;
-    uint32_t b0 = 0, b1 = 0, g = 0;
+    W b0 = 0, b1 = 0, g = 0;
     bool plain = false;
-    if (r < n_rows) {
-        const uint32_t *P = A.M.planes + ((size_t)(p >> 5) * 4) * np + r;
-        plain = fast_words(p, A.k, A.kmask, A.M.rlen[r], P[0], P[np], P[2 * np], P[3 * np], P[4 * np], P[5 * np], P[6 * np], P[7 * np], b0, b1, g);
-    }
+    if (r < n_rows)
+        plain = fast_words<W>(p, A.k, A.kmask, A.M.rlen[r], load_plane_words<W>(A.M.planes + ((size_t)(p >> 5) * 4) * np + r, np), b0, b1, g);
 #pragma unroll
     for (int c = 0; c < CC; c++) {
         bool bad_f, bad_r;
-        mask_decide(b0, b1, g, A.cand_n[it.cand0 + c], A, bad_f, bad_r);
+        mask_decide<W>(b0, b1, g, A.cand_n[it.cand0 + c], A, bad_f, bad_r);
         const unsigned long long wf = __ballot(plain && bad_f), wr = __ballot(plain && bad_r);
         const int oc = A.cand_out[it.cand0 + c];
         if ((threadIdx.x & 63) == 0 && oc >= 0) {
@@ -772,22 +789,22 @@ __global__ __launch_bounds__(kBlock) void mask_rows_kernel(const EvalArgs A, int
 }
 
 // one workgroup per item: the window's slow pairs (patch list: rows and window words from repair_kernel)
-template <int CC>
-__global__ __launch_bounds__(kBlock) void mask_patch_kernel(const EvalArgs A, const int32_t *__restrict__ patch_off,
-                                                            const int32_t *__restrict__ patch_rows, const uint32_t *__restrict__ patch_words,
+template <int CC, typename W = uint32_t>
+__global__ __launch_bounds__(kBlock) void mask_patch_kernel(const EvalArgsT<W> A, const int32_t *__restrict__ patch_off,
+                                                            const int32_t *__restrict__ patch_rows, const W *__restrict__ patch_words,
                                                             unsigned long long *__restrict__ not_f, unsigned long long *__restrict__ not_r) {
     const EvalItem it = A.items[blockIdx.x];
     const size_t nw = (size_t)A.n_pad / 64;
     for (int e = patch_off[it.win] + threadIdx.x; e < patch_off[it.win + 1]; e += kBlock) {
-        const uint32_t b0 = patch_words[3 * (size_t)e], b1 = patch_words[3 * (size_t)e + 1], g = patch_words[3 * (size_t)e + 2];
-        const bool skip = g & MP_WIN_SKIP;                        // IUPAC k-mer (the host owns it) or a too-short row: both bits 0
+        const W b0 = patch_words[3 * (size_t)e], b1 = patch_words[3 * (size_t)e + 1], g = patch_words[3 * (size_t)e + 2];
+        const bool skip = (g & WordTraits<W>::kSkip) != 0;        // IUPAC k-mer (the host owns it) or a too-short row: both bits 0
         const int r = patch_rows[e];
         const unsigned long long bit = 1ull << (r & 63);
         for (int c = 0; c < CC; c++) {
             const int oc = A.cand_out[it.cand0 + c];
             if (oc < 0) continue;
             bool bad_f = false, bad_r = false;
-            if (!skip) mask_decide(b0, b1, g & A.kmask, A.cand_n[it.cand0 + c], A, bad_f, bad_r);
+            if (!skip) mask_decide<W>(b0, b1, g & A.kmask, A.cand_n[it.cand0 + c], A, bad_f, bad_r);
             // the bit-sliced pass left a 1 for every row `excl` flags: the patch rows get their own verdict either way
             if (bad_f) atomicOr(&not_f[(size_t)oc * nw + (size_t)(r >> 6)], bit);
             else atomicAnd(&not_f[(size_t)oc * nw + (size_t)(r >> 6)], ~bit);
@@ -881,9 +898,16 @@ int ensure_patch_planes(mp_ctx *c) {
         c->pp_words = poff; c->pv_words = voff;
         if ((rc = dev_alloc(c, &d_runs, runs.size()))) return rc;
         HIPCK(c, hipMemcpyAsync(d_runs, runs.data(), sizeof(PatchRun) * runs.size(), hipMemcpyHostToDevice, c->stream));
-        hipLaunchKernelGGL(patch_planes_kernel, dim3((unsigned)runs.size()), dim3(kBlock), 0, c->stream,
-                           c->n_patch ? c->patch_off : (const int32_t *)nullptr, c->patch_words,
-                           c->n_extra ? c->extra_off : (const int32_t *)nullptr, c->extra_words, c->pwin, d_runs, c->k, c->v, c->pplanes, c->pvalid);
+        if (c->wide)
+            hipLaunchKernelGGL(patch_planes_kernel<uint64_t>, dim3((unsigned)runs.size()), dim3(kBlock), 0, c->stream,
+                               c->n_patch ? c->patch_off : (const int32_t *)nullptr, reinterpret_cast<const uint64_t *>(c->patch_words),
+                               c->n_extra ? c->extra_off : (const int32_t *)nullptr, reinterpret_cast<const uint64_t *>(c->extra_words), c->pwin, d_runs,
+                               c->k, c->v, c->pplanes, c->pvalid);
+        else
+            hipLaunchKernelGGL(patch_planes_kernel<uint32_t>, dim3((unsigned)runs.size()), dim3(kBlock), 0, c->stream,
+                               c->n_patch ? c->patch_off : (const int32_t *)nullptr, (const uint32_t *)c->patch_words,
+                               c->n_extra ? c->extra_off : (const int32_t *)nullptr, (const uint32_t *)c->extra_words, c->pwin, d_runs, c->k, c->v,
+                               c->pplanes, c->pvalid);
         HIPCK(c, hipGetLastError());
     }
     HIPCK(c, hipStreamSynchronize(c->stream));            // pw and runs are host temporaries
@@ -948,12 +972,59 @@ PatchArgs patch_args(const mp_ctx *c, int GW, int n_items, int unit_threads) {
 
 extern "C" {
 
-int mp_eval_upload(mp_ctx *c, int32_t n_cand, const int32_t *cw, const uint8_t *codes, uint32_t sF, uint32_t sR) {
+// Primers of 32..63 bases: 8 consecutive candidates of a window per item, 64-bit candidate words, the row-per-lane kernels only.
+static int upload_wide(mp_ctx *c, int32_t n_cand, const int32_t *cw, const uint8_t *codes, uint64_t sF, uint64_t sR) {
+    const int k = c->k;
+    const uint64_t kmask = kmask_of<uint64_t>(k);
+    std::vector<EvalItem> items;
+    std::vector<CandN<uint64_t>> cn;
+    std::vector<int32_t> co;
+    for (int i = 0; i < n_cand;) {
+        const int w = cw[i];
+        if (w < 0 || w >= c->n_win || (i && w < cw[i - 1])) return fail(c, MP_ERR_ARG, "candidate windows must be ascending and in range");
+        int j = i;
+        while (j < n_cand && cw[j] == w) j++;
+        for (int b = i; b < j; b += kEvalCC) {
+            items.push_back(EvalItem{w, (int32_t)cn.size()});
+            for (int t = 0; t < kEvalCC; t++) {
+                const int ci = b + t;
+                if (ci >= j) { cn.push_back(CandN<uint64_t>{kmask, kmask, kmask, kmask}); co.push_back(-1); continue; }      // an unused slot matches nothing, reports nowhere
+                CandN<uint64_t> q{0, 0, 0, 0};
+                for (int p = 0; p < k; p++) {
+                    const uint32_t m = codes[(size_t)ci * k + p] & 15u;
+                    if (!(m & 1)) q.x |= 1ull << p;
+                    if (!(m & 2)) q.y |= 1ull << p;
+                    if (!(m & 4)) q.z |= 1ull << p;
+                    if (!(m & 8)) q.w |= 1ull << p;
+                }
+                cn.push_back(q);
+                co.push_back(ci);
+            }
+        }
+        i = j;
+    }
+    c->n_cand = n_cand; c->sF = sF; c->sR = sR;
+    c->n_items = (int)items.size();
+    c->n_padded = (int)cn.size();
+    if (c->n_items == 0) return MP_OK;
+    int rc;
+    if ((rc = dev_alloc(c, &c->items, items.size()))) return rc;
+    if ((rc = dev_alloc(c, &c->cand_n, 2 * cn.size()))) return rc;                   // two uint4 per 64-bit candidate record
+    if ((rc = dev_alloc(c, &c->cand_out, co.size()))) return rc;
+    HIPCK(c, hipMemcpy(c->items, items.data(), sizeof(EvalItem) * items.size(), hipMemcpyHostToDevice));
+    HIPCK(c, hipMemcpy(c->cand_n, cn.data(), sizeof(CandN<uint64_t>) * cn.size(), hipMemcpyHostToDevice));
+    HIPCK(c, hipMemcpy(c->cand_out, co.data(), sizeof(int32_t) * co.size(), hipMemcpyHostToDevice));
+    return MP_OK;
+}
+
+int mp_eval_upload(mp_ctx *c, int32_t n_cand, const int32_t *cw, const uint8_t *codes, uint64_t sF64, uint64_t sR64) {
     if (!c) return MP_ERR_ARG;
     if (!c->excl) return fail(c, MP_ERR_ARG, "no windows built");
     if (n_cand < 0 || (n_cand && (!cw || !codes))) return fail(c, MP_ERR_ARG, "bad arguments");
     HIPCK(c, hipSetDevice(c->dev));
     free_eval(c);
+    if (c->wide) return upload_wide(c, n_cand, cw, codes, sF64, sR64);
+    const uint32_t sF = (uint32_t)sF64, sR = (uint32_t)sR64;      // k <= 31: positions above k never mismatch
     const int k = c->k;
     const uint32_t kmask = (1u << k) - 1u;
     std::vector<EvalItem> items;
@@ -1167,7 +1238,7 @@ int mp_eval_launch(mp_ctx *c, int64_t *device_out) {
         HIPCK(c, hipEventRecord(ev.first, c->stream));
     }
     const char *mode_env = getenv("MP_EVAL_MODE");
-    const bool bits = c->v <= 3 && !(mode_env && !strcmp(mode_env, "rows"));
+    const bool bits = c->v <= 3 && !c->wide && !(mode_env && !strcmp(mode_env, "rows"));      // (the bit-sliced kernels hold 32 positions per item)
     const int vmode = c->v == 0 ? 0 : (c->v == 1 ? 1 : 2);     // predicate specialisation of the row-per-lane code
     if (bits) {
         // bit-sliced pass over the column planes and over the windows' patch planes
@@ -1206,7 +1277,7 @@ int mp_eval_launch(mp_ctx *c, int64_t *device_out) {
 #undef CHAIN_ROW
             unsigned grid;
             const BlockMap bm = block_map(cgw[cshape], c->n_chain, grid);
-            EvalChainArgs ca{c->cols, c->excl, nw, c->p0, c->k, c->v, c->chain_items, c->chain_events, c->cand_out, c->sF, c->sR,
+            EvalChainArgs ca{c->cols, c->excl, nw, c->p0, c->k, c->v, c->chain_items, c->chain_events, c->cand_out, (uint32_t)c->sF, (uint32_t)c->sR,
                              (unsigned long long *)device_out, bm, patch_args(c, cgw[cshape], c->n_chain, 64), nullptr, 0};
             if (c->slide_items > 0) {
                 // sliding evaluation: the patch planes of ALL chain items and the column planes of the items the plan left out run on
@@ -1232,7 +1303,7 @@ int mp_eval_launch(mp_ctx *c, int64_t *device_out) {
                     unsigned rgrid;
                     const BlockMap rbm = block_map(cgw[cshape], c->n_rest, rgrid);
                     PatchArgs none{nullptr, nullptr, nullptr, 0, 0, nullptr, nullptr, 0};
-                    EvalChainArgs ra{c->cols, c->excl, nw, c->p0, c->k, c->v, c->chain_rest, c->chain_events, c->cand_out, c->sF, c->sR,
+                    EvalChainArgs ra{c->cols, c->excl, nw, c->p0, c->k, c->v, c->chain_rest, c->chain_events, c->cand_out, (uint32_t)c->sF, (uint32_t)c->sR,
                                      (unsigned long long *)device_out, rbm, none, nullptr, 0};
                     hipLaunchKernelGGL((c->rest_max_steps > kEvalCC ? lfn : cfn)[c->v][cshape], dim3(rgrid), dim3(kBlock), 0, c->stream, ra);
                 }
@@ -1253,14 +1324,23 @@ int mp_eval_launch(mp_ctx *c, int64_t *device_out) {
         if (n_tab) {
             unsigned grid;
             const BlockMap bm = block_map(2, n_tab, grid);
-            EvalBitsArgs ba{c->cols, c->excl, nw, c->p0, c->k, c->v, c->items, c->cand_symT, c->cand_out, c->sF, c->sR,
+            EvalBitsArgs ba{c->cols, c->excl, nw, c->p0, c->k, c->v, c->items, c->cand_symT, c->cand_out, (uint32_t)c->sF, (uint32_t)c->sR,
                             (unsigned long long *)device_out, bm, c->cand_diff, shape == 0 ? c->table_ids : (const int32_t *)nullptr,
                             patch_args(c, 2, n_tab, 64), nullptr, nullptr, c->n_rows};
             hipLaunchKernelGGL(tfn[c->v][shape == 1 ? 1 : 0], dim3(grid + (unsigned)ba.patch.n_blocks), dim3(kBlock), 0, c->stream, ba);
         }
+    } else if (c->wide) {
+        const EvalArgsT<uint64_t> ea{msa_args(c), c->p0, c->n_pad, c->k, c->items, reinterpret_cast<const CandN<uint64_t> *>(c->cand_n), c->cand_out,
+                                     c->n_extra ? c->extra_off : (const int32_t *)nullptr, reinterpret_cast<const uint64_t *>(c->extra_words), c->sF, c->sR,
+                                     c->v, kmask_of<uint64_t>(c->k), rows, (unsigned long long *)device_out};
+        const dim3 grid((unsigned)c->n_items, (unsigned)split);
+        if (vmode == 0) hipLaunchKernelGGL((eval_kernel<kEvalCC, 0, 1, true, 2, uint64_t>), grid, dim3(kBlock), 0, c->stream, ea);
+        else if (vmode == 1 && !getenv("MP_EVAL_GENERIC_V")) hipLaunchKernelGGL((eval_kernel<kEvalCC, 1, 1, true, 2, uint64_t>), grid, dim3(kBlock), 0, c->stream, ea);
+        else hipLaunchKernelGGL((eval_kernel<kEvalCC, 2, 1, true, 2, uint64_t>), grid, dim3(kBlock), 0, c->stream, ea);
     } else {
-    EvalArgs ea{msa_args(c), c->p0, c->n_pad, c->k, c->items, c->cand_n, c->cand_out, c->n_extra ? c->extra_off : (const int32_t *)nullptr,
-                c->extra_words, c->sF, c->sR, c->v, (1u << c->k) - 1u, rows, (unsigned long long *)device_out};
+    EvalArgs ea{msa_args(c), c->p0, c->n_pad, c->k, c->items, reinterpret_cast<const CandN<uint32_t> *>(c->cand_n), c->cand_out,
+                c->n_extra ? c->extra_off : (const int32_t *)nullptr, c->extra_words, (uint32_t)c->sF, (uint32_t)c->sR, c->v, (1u << c->k) - 1u, rows,
+                (unsigned long long *)device_out};
     int variant = c->eval_variant;
     if (const char *e = getenv("MP_EVAL_VARIANT")) variant = atoi(e);
     if (variant < 0 || variant >= kNumEvalVariants) variant = 0;
@@ -1343,7 +1423,7 @@ int mp_window_stats(mp_ctx *c, int64_t *freq, int64_t *nn) {
     return MP_OK;
 }
 
-int mp_eval_candidates(mp_ctx *c, int32_t n_cand, const int32_t *cw, const uint8_t *codes, uint32_t sF, uint32_t sR,
+int mp_eval_candidates(mp_ctx *c, int32_t n_cand, const int32_t *cw, const uint8_t *codes, uint64_t sF, uint64_t sR,
                        int64_t *out) {
     if (!c) return MP_ERR_ARG;
     int rc = mp_eval_upload(c, n_cand, cw, codes, sF, sR);
@@ -1363,7 +1443,7 @@ int mp_eval_candidates(mp_ctx *c, int32_t n_cand, const int32_t *cw, const uint8
 }
 
 
-int mp_eval_masks_resident(mp_ctx *c, int32_t n_cand, const int32_t *cw, const uint8_t *codes, uint32_t sF, uint32_t sR) {
+int mp_eval_masks_resident(mp_ctx *c, int32_t n_cand, const int32_t *cw, const uint8_t *codes, uint64_t sF, uint64_t sR) {
     if (!c) return MP_ERR_ARG;
     int rc = mp_eval_upload(c, n_cand, cw, codes, sF, sR);
     if (rc) return rc;
@@ -1375,8 +1455,20 @@ int mp_eval_masks_resident(mp_ctx *c, int32_t n_cand, const int32_t *cw, const u
     if ((rc = dev_alloc(c, &c->mask_r, (size_t)n_cand * nw))) return rc;
     c->mask_words = (size_t)n_cand * nw;
     c->n_masks = n_cand;
-    EvalArgs ea{msa_args(c), c->p0, c->n_pad, c->k, c->items, c->cand_n, c->cand_out, nullptr, nullptr, c->sF, c->sR, c->v,
-                (1u << c->k) - 1u, 0, nullptr};
+    if (c->wide) {                                 // primers of 32..63 bases: the row-per-thread kernels on 64-bit words
+        const EvalArgsT<uint64_t> ew{msa_args(c), c->p0, c->n_pad, c->k, c->items, reinterpret_cast<const CandN<uint64_t> *>(c->cand_n), c->cand_out,
+                                     nullptr, nullptr, c->sF, c->sR, c->v, kmask_of<uint64_t>(c->k), 0, nullptr};
+        const dim3 grid((unsigned)c->n_items, (unsigned)(c->n_pad / kBlock));
+        hipLaunchKernelGGL((mask_rows_kernel<kEvalCC, uint64_t>), grid, dim3(kBlock), 0, c->stream, ew, c->n_rows, c->mask_f, c->mask_r);
+        if (c->n_patch)
+            hipLaunchKernelGGL((mask_patch_kernel<kEvalCC, uint64_t>), dim3((unsigned)c->n_items), dim3(kBlock), 0, c->stream, ew, (const int32_t *)c->patch_off,
+                               (const int32_t *)c->patch_rows, reinterpret_cast<const uint64_t *>(c->patch_words), c->mask_f, c->mask_r);
+        HIPCK(c, hipGetLastError());
+        HIPCK(c, hipStreamSynchronize(c->stream));
+        return MP_OK;
+    }
+    EvalArgs ea{msa_args(c), c->p0, c->n_pad, c->k, c->items, reinterpret_cast<const CandN<uint32_t> *>(c->cand_n), c->cand_out, nullptr, nullptr,
+                (uint32_t)c->sF, (uint32_t)c->sR, c->v, (1u << c->k) - 1u, 0, nullptr};
     // the plain rows: bit-sliced on the column planes (the evaluation pass itself, its final words stored instead of counted);
     // MP_MASK_MODE=rows keeps the row-per-thread kernel of rounds 1-2 (0.32 ms against 0.0x ms at 131072 rows x 410 windows)
     const char *mm = getenv("MP_MASK_MODE");
@@ -1389,7 +1481,7 @@ int mp_eval_masks_resident(mp_ctx *c, int32_t n_cand, const int32_t *cw, const u
         unsigned grid;
         const BlockMap bm = make_block_map((int)nw, 2, c->n_items, grid);
         PatchArgs none{nullptr, nullptr, nullptr, 0, 0, nullptr, nullptr, 0};
-        EvalBitsArgs ba{c->cols, c->excl, (int)nw, c->p0, c->k, c->v, c->items, c->cand_symT, c->cand_out, c->sF, c->sR, nullptr, bm, c->cand_diff,
+        EvalBitsArgs ba{c->cols, c->excl, (int)nw, c->p0, c->k, c->v, c->items, c->cand_symT, c->cand_out, (uint32_t)c->sF, (uint32_t)c->sR, nullptr, bm, c->cand_diff,
                         nullptr, none, reinterpret_cast<uint32_t *>(c->mask_f), reinterpret_cast<uint32_t *>(c->mask_r), c->n_rows};
         hipLaunchKernelGGL(mfn[c->v], dim3(grid), dim3(kBlock), 0, c->stream, ba);
     }
@@ -1471,7 +1563,7 @@ int mp_pair_coverage_resident(mp_ctx *c, int64_t n_pairs, const int32_t *pairs, 
     return MP_OK;
 }
 
-int mp_eval_masks(mp_ctx *c, int32_t n_cand, const int32_t *cw, const uint8_t *codes, uint32_t sF, uint32_t sR,
+int mp_eval_masks(mp_ctx *c, int32_t n_cand, const int32_t *cw, const uint8_t *codes, uint64_t sF, uint64_t sR,
                   uint64_t *not_f, uint64_t *not_r) {
     if (!c) return MP_ERR_ARG;
     int rc = mp_eval_masks_resident(c, n_cand, cw, codes, sF, sR);

@@ -240,7 +240,7 @@ int upload_eval_slide(mp_ctx *c, const std::vector<ChainItem> &chains, const std
         in[i] = SlideChainIn{ch.win, ch.cand0, ch.n_steps, ch.ev0, ch.n_ev, {ch.sym[0], ch.sym[1], ch.sym[2], ch.sym[3]}};
     }
     SlidePlan P;
-    if (!build_slide_plan(in, events, cand_out, c->k, c->sF, c->sR, c->p0, n_cols, band, (uint32_t)nw32 * 4u, true, P)) return MP_OK;
+    if (!build_slide_plan(in, events, cand_out, c->k, (uint32_t)c->sF, (uint32_t)c->sR, c->p0, n_cols, band, (uint32_t)nw32 * 4u, true, P)) return MP_OK;
     P.iters.resize(P.iters.size() + 64, 0u);                      // uiter reads 64 words at a time
     int rc;
     if ((rc = dev_alloc(c, &c->slide_bands, P.bands.size()))) return rc;

@@ -6,6 +6,32 @@
 // entropy (V20:602-614), get_optimal_primer_by_viterbi / _by_MM (V20:579-600), refine_by_NN_array (V20:922-1089), the
 // structural part of coverage_stast (V20:860-906) and the replay of its stopping rules on the batched evaluations.
 // All floating-point expressions keep the reference's operand order and libm calls (log(x)/log(2), Python's round()).
+//
+// Compiled twice: as it stands for k <= 32 (keys of 32 symbol nibbles in two 64-bit words, the pipeline's usual -l 18..28), and through
+// hostplan_wide.cpp with MP_PLAN_WIDE = 1 for 33 <= k <= 63 (four words per key), every exported name suffixed _w64.  The entry points
+// of THIS unit look at k (or at the plan's tag) and hand wide work over; a plan is only ever touched by the unit that made it.
+#ifndef MP_PLAN_WIDE
+#define MP_PLAN_WIDE 0
+#endif
+#if MP_PLAN_WIDE
+#define mp_plan mp_plan_w64
+#define mp_plan_error mp_plan_error_w64
+#define mp_plan_destroy mp_plan_destroy_w64
+#define mp_plan_create mp_plan_create_w64
+#define mp_plan_create_segments mp_plan_create_segments_w64
+#define mp_plan_windows mp_plan_windows_w64
+#define mp_plan_sizes mp_plan_sizes_w64
+#define mp_plan_candidates mp_plan_candidates_w64
+#define mp_plan_seeds mp_plan_seeds_w64
+#define mp_plan_chain mp_plan_chain_w64
+#define mp_plan_finish mp_plan_finish_w64
+#define mp_plan_results mp_plan_results_w64
+#define mp_plan_window_table mp_plan_window_table_w64
+#define mp_expand_kmers mp_expand_kmers_w64
+#define mp_expand_kmer_words mp_expand_kmer_words_w64
+#define mp_plan_write_side_files mp_plan_write_side_files_w64
+#define mp_plan_write_side_files_part mp_plan_write_side_files_part_w64
+#endif
 #include "../../include/mprime.h"
 #include "../../include/mprime_host.h"
 
@@ -29,15 +55,25 @@ namespace {
 // ---------------------------------------------------------------------------------------------------------------
 // symbols
 // ---------------------------------------------------------------------------------------------------------------
-struct Key {                    // k symbol codes, one nibble each (position j = nibble j)
-    uint64_t lo = 0, hi = 0;
-    bool operator==(const Key &o) const { return lo == o.lo && hi == o.hi; }
-    uint32_t get(int j) const { return (uint32_t)((j < 16 ? lo >> (4 * j) : hi >> (4 * (j - 16))) & 15u); }
-    void set(int j, uint32_t c) {
-        if (j < 16) lo = (lo & ~(15ull << (4 * j))) | ((uint64_t)c << (4 * j));
-        else hi = (hi & ~(15ull << (4 * (j - 16)))) | ((uint64_t)c << (4 * (j - 16)));
+constexpr int kKeyWords = MP_PLAN_WIDE ? 4 : 2;        // 16 symbol nibbles per word
+constexpr int kMaxK = MP_PLAN_WIDE ? 63 : 32;          // positions a key (and every per-position array below) holds
+typedef uint64_t word_t;                               // a window word as this unit computes with it (read by width, rd_word)
+
+struct Key {                    // k symbol codes, one nibble each (position j = nibble j & 15 of word j >> 4)
+    uint64_t q[kKeyWords] = {};
+    bool operator==(const Key &o) const {
+        bool same = true;
+        for (int i = 0; i < kKeyWords; i++) same &= q[i] == o.q[i];
+        return same;
     }
+    uint32_t get(int j) const { return (uint32_t)((q[j >> 4] >> (4 * (j & 15))) & 15u); }
+    void set(int j, uint32_t c) { q[j >> 4] = (q[j >> 4] & ~(15ull << (4 * (j & 15)))) | ((uint64_t)c << (4 * (j & 15))); }
 };
+
+// window words at the ABI are uint32 while k <= MP_NARROW_K and uint64 above (mprime.h)
+inline word_t rd_word(const void *words, size_t i, int k) {
+    return k > MP_NARROW_K ? ((const uint64_t *)words)[i] : (word_t)((const uint32_t *)words)[i];
+}
 
 // Key of a window k-mer given as window words (b0, b1 = base index bits, g = gap flags; mprime.h): the bits of 16 positions are
 // spread to nibble lanes through a byte table and the one-hot symbol codes are formed for all of them at once.
@@ -52,15 +88,15 @@ struct SpreadTable {
     }
     uint64_t operator()(uint32_t x16) const { return (uint64_t)t[x16 & 255u] | ((uint64_t)t[(x16 >> 8) & 255u] << 32); }
 };
-inline Key key_from_words(uint32_t b0, uint32_t b1, uint32_t g, uint32_t kmask) {
+inline Key key_from_words(word_t b0, word_t b1, word_t g, word_t kmask) {
     static const SpreadTable spread;
-    const uint32_t valid = kmask & ~g;
+    const word_t valid = kmask & ~g;
     Key key;
-    for (int half = 0; half < 2; half++) {
-        const int sh = 16 * half;
-        const uint64_t v = spread((valid >> sh) & 0xFFFFu), s0 = spread((b0 >> sh) & 0xFFFFu), s1 = spread((b1 >> sh) & 0xFFFFu);
-        const uint64_t word = (v & ~s0 & ~s1) | ((v & s0 & ~s1) << 1) | ((v & ~s0 & s1) << 2) | ((v & s0 & s1) << 3);
-        (half ? key.hi : key.lo) = word;
+    for (int part = 0; part < kKeyWords; part++) {
+        const int sh = 16 * part;
+        const uint64_t v = spread((uint32_t)(valid >> sh) & 0xFFFFu), s0 = spread((uint32_t)(b0 >> sh) & 0xFFFFu),
+                       s1 = spread((uint32_t)(b1 >> sh) & 0xFFFFu);
+        key.q[part] = (v & ~s0 & ~s1) | ((v & s0 & ~s1) << 1) | ((v & ~s0 & s1) << 2) | ((v & s0 & s1) << 3);
     }
     return key;
 }
@@ -69,7 +105,11 @@ inline uint64_t mix(uint64_t x) {
     x ^= x >> 33; x *= 0xff51afd7ed558ccdULL; x ^= x >> 33; x *= 0xc4ceb9fe1a85ec53ULL; x ^= x >> 33;
     return x;
 }
-inline uint64_t hash_key(const Key &k) { return mix(k.lo ^ mix(k.hi + 0x9E3779B97F4A7C15ULL)); }
+inline uint64_t hash_key(const Key &k) {
+    uint64_t h = mix(k.q[kKeyWords - 1] + 0x9E3779B97F4A7C15ULL);
+    for (int i = kKeyWords - 2; i >= 0; i--) h = mix(k.q[i] ^ h);
+    return h;
+}
 
 // members of a symbol in the reference's enumeration order (degenerate_base, V20:105-107), as base codes
 struct Members { uint8_t n; uint8_t m[4]; };
@@ -98,7 +138,7 @@ inline int set_size(uint32_t code) { return code == 0 ? 1 : __builtin_popcount(c
 // every expansion in that order.  Returns the number of expansions.
 template <typename F>
 int64_t for_each_expansion(const uint8_t *codes, int k, F &&f) {
-    int idx[32] = {0};
+    int idx[kMaxK + 1] = {0};
     Key cur;
     for (int j = 0; j < k; j++) cur.set(j, kMembers[codes[j]].m[0]);
     int64_t n = 0;
@@ -179,7 +219,7 @@ struct KeyMap {
 };
 
 struct Seed {
-    uint8_t index[32];                       // base index per position
+    uint8_t index[kMaxK + 1];                       // base index per position
     std::vector<Key> chain;                  // chain[0] = the seed
     std::vector<int64_t> cov;                // running perfect coverage (optimal_coverage_init)
     std::vector<uint8_t> stops;              // a structural break rule ends the loop after this member
@@ -207,6 +247,7 @@ struct Window {
 }  // namespace
 
 struct mp_plan {
+    int32_t wide = MP_PLAN_WIDE;             // first member in both builds: which unit owns the plan
     char err[512] = {0};
     mp_plan_params P{};
     std::vector<Window> win;
@@ -214,6 +255,44 @@ struct mp_plan {
     int64_t n_cand = 0;
     bool finished = false;
 };
+
+#if !MP_PLAN_WIDE
+// the wide unit's entry points (hostplan_wide.cpp): same signatures, its own plan type
+struct mp_plan_w64;
+extern "C" {
+const char *mp_plan_error_w64(const mp_plan_w64 *p);
+void mp_plan_destroy_w64(mp_plan_w64 *p);
+int mp_plan_create_w64(const mp_plan_params *params, int64_t n_entries, const int32_t *e_window, const void *e_words, const int64_t *e_count,
+                       const int64_t *e_first, int64_t n_exc, const int32_t *x_window, const int64_t *x_row, const uint8_t *x_codes,
+                       const int64_t *freq, const int64_t *nn, mp_plan_w64 **out);
+int mp_plan_create_segments_w64(const mp_plan_params *params, const int64_t *e_off, const void *e_words, const int32_t *e_count,
+                                const int32_t *e_first, int64_t row_base, int64_t n_exc, const int32_t *x_window, const int64_t *x_row,
+                                const uint8_t *x_codes, const int64_t *freq, const int64_t *nn, mp_plan_w64 **out);
+int mp_plan_windows_w64(const mp_plan_w64 *p, int32_t *status, int64_t *cover_number, int64_t *gap_number, double *cbit, double *tbit);
+int mp_plan_sizes_w64(const mp_plan_w64 *p, int32_t *n_planned, int64_t *n_candidates);
+int mp_plan_candidates_w64(const mp_plan_w64 *p, int32_t *cand_window, uint8_t *cand_codes);
+int mp_plan_seeds_w64(const mp_plan_w64 *p, int32_t w, uint8_t *nm, uint8_t *mm, int32_t *has_mm, int32_t *n_chain_nm, int32_t *n_chain_mm);
+int mp_plan_chain_w64(const mp_plan_w64 *p, int32_t w, int32_t seed, int32_t cap, uint8_t *codes, int64_t *cov, uint8_t *stops, int32_t *n);
+int mp_plan_finish_w64(mp_plan_w64 *p, const int64_t *ev);
+int mp_plan_results_w64(const mp_plan_w64 *p, int32_t *window, double *cbit, double *tbit, uint8_t *primer_codes, int64_t *cov, int64_t *f_mis,
+                        int64_t *r_mis, int32_t *nonsense, int32_t *n_dege, int64_t *cover_number);
+int mp_plan_window_table_w64(const mp_plan_w64 *p, int32_t w, int32_t which, int64_t cap, uint8_t *codes, int64_t *counts, int64_t *first_row,
+                             int64_t *n);
+int mp_expand_kmers_w64(int32_t k, int64_t n, const uint8_t *codes, int64_t cap, uint8_t *out_codes, int64_t *out_src, int64_t *n_out);
+int mp_expand_kmer_words_w64(int32_t k, int64_t n, const uint8_t *codes, int64_t cap, void *out_words, int64_t *out_src, int64_t *n_out);
+int mp_plan_write_side_files_part_w64(const mp_plan_w64 *p, int32_t n_out, const int32_t *out_window, const int64_t *out_pos,
+                                      const uint8_t *primer_codes, uint64_t strictF, uint64_t strictR, const int64_t *dev_off,
+                                      const void *dev_words, int64_t n_dev, const int32_t *labels, int32_t n_rows, int64_t n_exc,
+                                      const int32_t *x_window, const int64_t *x_row, const uint8_t *x_codes, const uint8_t *ids,
+                                      const int64_t *id_off, const char *noncov_path, const char *gap_path, int32_t part);
+}
+// a plan made by the wide unit goes back to it
+#define MP_PLAN_FORWARD(fn, ...) if (p && p->wide) return fn##_w64(reinterpret_cast<const mp_plan_w64 *>(p), ##__VA_ARGS__)
+#define MP_PLAN_FORWARD_MUT(fn, ...) if (p && p->wide) return fn##_w64(reinterpret_cast<mp_plan_w64 *>(p), ##__VA_ARGS__)
+#else
+#define MP_PLAN_FORWARD(fn, ...) (void)0
+#define MP_PLAN_FORWARD_MUT(fn, ...) (void)0
+#endif
 
 namespace {
 
@@ -226,7 +305,7 @@ int pfail(mp_plan *p, int code, const char *fmt, ...) {
 }
 
 struct NNArr {                                // nn[i][a][b], i < k-1
-    int64_t v[31][4][4];
+    int64_t v[kMaxK][4][4];
 };
 
 // sum of cover[] over the expansions of a primer (V20:954-956)
@@ -256,9 +335,9 @@ inline void desc_stable(const int64_t v[4], int order[4]) {
 inline int npos(const int64_t v[4]) { return (v[0] > 0) + (v[1] > 0) + (v[2] > 0) + (v[3] > 0); }
 
 struct Refined {
-    uint8_t P[32];
+    uint8_t P[kMaxK + 1];
     int64_t c2;
-    int64_t cv[31];
+    int64_t cv[kMaxK];
     NNArr nn;
 };
 
@@ -333,19 +412,19 @@ void refine(const Window &w, int k, const uint8_t *primer, int64_t cov, const ui
 
 // everything coverage_stast (V20:860-920) does that does not depend on an evaluation
 int build_chain(const Window &w, Seed &s, int k, const NNArr &NN, double d, int n_max) {
-    uint8_t P[32];
+    uint8_t P[kMaxK + 1];
     Key key;
     for (int j = 0; j < k; j++) { P[j] = (uint8_t)(1u << s.index[j]); key.set(j, P[j]); }
     int32_t slot = w.cover_map.find(key, w.cover);
     int64_t cov = slot < 0 ? 0 : w.cover[(size_t)slot].count;
     NNArr nn = NN;
-    int64_t nn_cov[31];
+    int64_t nn_cov[kMaxK];
     for (int i = 0; i < k - 1; i++) nn_cov[i] = NN.v[i][s.index[i]][s.index[i + 1]];
     s.chain.push_back(key);
     s.cov.push_back(cov);
     s.stops.push_back(0);
     Refined r;
-    for (int guard = 0; guard < 4 * 32 + 8; guard++) {
+    for (int guard = 0; guard < 4 * kMaxK + 8; guard++) {
         refine(w, k, P, cov, s.index, nn_cov, nn, r);
         memcpy(P, r.P, (size_t)k);
         cov = r.c2;
@@ -370,7 +449,7 @@ int build_chain(const Window &w, Seed &s, int k, const NNArr &NN, double d, int 
 // ties go to the lowest base index (numpy argmax takes the first)
 void viterbi(const int64_t *freq /*[4][k]*/, const int64_t *nn /*[k-1][4][4]*/, int k, uint8_t *path) {
     int64_t score[4];
-    uint8_t back[32][4];
+    uint8_t back[kMaxK + 1][4];
     for (int a = 0; a < 4; a++) score[a] = freq[a * k + 0];
     for (int t = 1; t < k; t++) {
         int64_t nxt[4];
@@ -516,9 +595,17 @@ int resolve_threads(int asked, int64_t work_items) {
 
 extern "C" {
 
-const char *mp_plan_error(const mp_plan *p) { return p ? p->err : "mp_plan_create failed"; }
+const char *mp_plan_error(const mp_plan *p) {
+    MP_PLAN_FORWARD(mp_plan_error);
+    return p ? p->err : "mp_plan_create failed";
+}
 
-void mp_plan_destroy(mp_plan *p) { delete p; }
+void mp_plan_destroy(mp_plan *p) {
+#if !MP_PLAN_WIDE
+    if (p && p->wide) { mp_plan_destroy_w64(reinterpret_cast<mp_plan_w64 *>(p)); return; }
+#endif
+    delete p;
+}
 
 // the body of mp_plan_create; allocation failures (here and in the worker threads) leave as MP_ERR_NOMEM, never as exceptions
 // entries either as (e_window, 64-bit counts and global first rows) in any order, or — one rank's read-back as it stands — as window
@@ -527,7 +614,7 @@ struct EntryInput {
     int64_t n;
     const int32_t *window;
     const int64_t *off;
-    const uint32_t *words;
+    const void *words;
     const int64_t *count64, *first64;
     const int32_t *count32, *first32;
     int64_t row_base;
@@ -554,17 +641,25 @@ static int plan_create_guarded(const mp_plan_params *params, const EntryInput &E
     }
 }
 
-int mp_plan_create(const mp_plan_params *params, int64_t n_entries, const int32_t *e_window, const uint32_t *e_words,
+int mp_plan_create(const mp_plan_params *params, int64_t n_entries, const int32_t *e_window, const void *e_words,
                    const int64_t *e_count, const int64_t *e_first, int64_t n_exc, const int32_t *x_window,
                    const int64_t *x_row, const uint8_t *x_codes, const int64_t *freq, const int64_t *nn, mp_plan **out) {
+#if !MP_PLAN_WIDE
+    if (params && params->k > kMaxK)
+        return mp_plan_create_w64(params, n_entries, e_window, e_words, e_count, e_first, n_exc, x_window, x_row, x_codes, freq, nn, (mp_plan_w64 **)out);
+#endif
     if (n_entries < 0 || (n_entries && (!e_window || !e_words || !e_count || !e_first))) return MP_ERR_ARG;
     const EntryInput E{n_entries, e_window, nullptr, e_words, e_count, e_first, nullptr, nullptr, 0};
     return plan_create_guarded(params, E, n_exc, x_window, x_row, x_codes, freq, nn, out);
 }
 
-int mp_plan_create_segments(const mp_plan_params *params, const int64_t *e_off, const uint32_t *e_words, const int32_t *e_count,
+int mp_plan_create_segments(const mp_plan_params *params, const int64_t *e_off, const void *e_words, const int32_t *e_count,
                             const int32_t *e_first, int64_t row_base, int64_t n_exc, const int32_t *x_window, const int64_t *x_row,
                             const uint8_t *x_codes, const int64_t *freq, const int64_t *nn, mp_plan **out) {
+#if !MP_PLAN_WIDE
+    if (params && params->k > kMaxK)
+        return mp_plan_create_segments_w64(params, e_off, e_words, e_count, e_first, row_base, n_exc, x_window, x_row, x_codes, freq, nn, (mp_plan_w64 **)out);
+#endif
     if (!params || !e_off || params->n_windows < 0) return MP_ERR_ARG;
     const int64_t n = e_off[params->n_windows];
     if (n < 0 || (n && (!e_words || !e_count || !e_first))) return MP_ERR_ARG;
@@ -578,8 +673,8 @@ static int plan_create_body(mp_plan *p, const EntryInput &E, int64_t n_exc, cons
     const int k = P.k, W = P.n_windows;
     const int64_t n_entries = E.n;
     const int32_t *e_window = E.window;
-    const uint32_t *e_words = E.words;
-    if (k < 2 || k > 32 || W < 0 || P.v < 0 || P.total_sequences <= 0) return pfail(p, MP_ERR_ARG, "mp_plan_create: bad parameters");
+    const void *e_words = E.words;
+    if (k < 2 || k > kMaxK || W < 0 || P.v < 0 || P.total_sequences <= 0) return pfail(p, MP_ERR_ARG, "mp_plan_create: bad parameters");
     if (n_exc < 0 || (n_exc && (!x_window || !x_row || !x_codes))) return pfail(p, MP_ERR_ARG, "mp_plan_create: bad arguments");
     // counting sort of entries and exceptions by window
     std::vector<int64_t> eoff((size_t)W + 1, 0), xoff((size_t)W + 1, 0);
@@ -611,7 +706,7 @@ static int plan_create_body(mp_plan *p, const EntryInput &E, int64_t n_exc, cons
         for (int64_t i = 0; i < n_exc; i++) xidx[(size_t)cux[(size_t)x_window[i]]++] = i;
     }
     p->win.resize((size_t)W);
-    const uint32_t kmask = k == 32 ? 0xFFFFFFFFu : ((1u << k) - 1u);
+    const word_t kmask = k == 64 ? ~0ull : ((1ull << k) - 1ull);
     const double max_exp = 1 << 22;            // expansions of one exception k-mer the host is willing to enumerate
     std::atomic<int> next{0}, failed{0};       // failed: 0 or the MP_ERR_* code of the first failure
     const int n_thr = resolve_threads(P.n_threads, W);
@@ -623,13 +718,14 @@ static int plan_create_body(mp_plan *p, const EntryInput &E, int64_t n_exc, cons
             sights.clear();
             for (int64_t t = eoff[(size_t)w]; t < eoff[(size_t)w + 1]; t++) {
                 const int64_t i = e_sorted ? t : eidx[(size_t)t];
-                const uint32_t b0 = e_words[i], b1 = e_words[(size_t)n_entries + i], g = e_words[2 * (size_t)n_entries + i] & kmask;
+                const word_t b0 = rd_word(e_words, (size_t)i, k), b1 = rd_word(e_words, (size_t)n_entries + (size_t)i, k),
+                             g = rd_word(e_words, 2 * (size_t)n_entries + (size_t)i, k) & kmask;
                 Sight s;
                 s.key = key_from_words(b0, b1, g, kmask);
                 s.count = E.count(i);
                 s.row = E.first(i);
                 s.sub = 0;
-                s.ngap = __builtin_popcount(g);
+                s.ngap = __builtin_popcountll(g);
                 sights.push_back(s);
             }
             int64_t n_exc_cover = 0, n_exp = 0;
@@ -700,6 +796,7 @@ static int plan_create_body(mp_plan *p, const EntryInput &E, int64_t n_exc, cons
 }
 
 int mp_plan_windows(const mp_plan *p, int32_t *status, int64_t *cover_number, int64_t *gap_number, double *cbit, double *tbit) {
+    MP_PLAN_FORWARD(mp_plan_windows, status, cover_number, gap_number, cbit, tbit);
     if (!p) return MP_ERR_ARG;
     for (size_t w = 0; w < p->win.size(); w++) {
         const Window &x = p->win[w];
@@ -713,6 +810,7 @@ int mp_plan_windows(const mp_plan *p, int32_t *status, int64_t *cover_number, in
 }
 
 int mp_plan_sizes(const mp_plan *p, int32_t *n_planned, int64_t *n_candidates) {
+    MP_PLAN_FORWARD(mp_plan_sizes, n_planned, n_candidates);
     if (!p) return MP_ERR_ARG;
     if (n_planned) *n_planned = (int32_t)p->planned.size();
     if (n_candidates) *n_candidates = p->n_cand;
@@ -720,6 +818,7 @@ int mp_plan_sizes(const mp_plan *p, int32_t *n_planned, int64_t *n_candidates) {
 }
 
 int mp_plan_candidates(const mp_plan *p, int32_t *cand_window, uint8_t *cand_codes) {
+    MP_PLAN_FORWARD(mp_plan_candidates, cand_window, cand_codes);
     if (!p || !cand_window || !cand_codes) return MP_ERR_ARG;
     const int k = p->P.k;
     int64_t c = 0;
@@ -736,6 +835,7 @@ int mp_plan_candidates(const mp_plan *p, int32_t *cand_window, uint8_t *cand_cod
 }
 
 int mp_plan_seeds(const mp_plan *p, int32_t w, uint8_t *nm, uint8_t *mm, int32_t *has_mm, int32_t *n_chain_nm, int32_t *n_chain_mm) {
+    MP_PLAN_FORWARD(mp_plan_seeds, w, nm, mm, has_mm, n_chain_nm, n_chain_mm);
     if (!p || w < 0 || (size_t)w >= p->win.size()) return MP_ERR_ARG;
     const Window &x = p->win[(size_t)w];
     if (x.status != MP_WIN_PLANNED) return MP_ERR_ARG;
@@ -749,6 +849,7 @@ int mp_plan_seeds(const mp_plan *p, int32_t w, uint8_t *nm, uint8_t *mm, int32_t
 }
 
 int mp_plan_chain(const mp_plan *p, int32_t w, int32_t seed, int32_t cap, uint8_t *codes, int64_t *cov, uint8_t *stops, int32_t *n) {
+    MP_PLAN_FORWARD(mp_plan_chain, w, seed, cap, codes, cov, stops, n);
     if (!p || w < 0 || (size_t)w >= p->win.size() || !n) return MP_ERR_ARG;
     const Window &x = p->win[(size_t)w];
     if (x.status != MP_WIN_PLANNED || seed < 0 || seed >= x.n_seeds) return MP_ERR_ARG;
@@ -765,6 +866,7 @@ int mp_plan_chain(const mp_plan *p, int32_t w, int32_t seed, int32_t cap, uint8_
 }
 
 int mp_plan_finish(mp_plan *p, const int64_t *ev) {
+    MP_PLAN_FORWARD_MUT(mp_plan_finish, ev);
     if (!p || !ev) return MP_ERR_ARG;
     const int k = p->P.k;
     for (int32_t w : p->planned) {
@@ -803,7 +905,7 @@ int mp_plan_finish(mp_plan *p, const int64_t *ev) {
         x.cov = ch->cov[(size_t)ch->final_i];
         x.f_mis = ch->F;
         x.r_mis = ch->R;
-        uint8_t codes[32];
+        uint8_t codes[kMaxK + 1];
         x.n_dege = 0;
         for (int j = 0; j < k; j++) { codes[j] = (uint8_t)x.primer.get(j); x.n_dege += set_size(codes[j]) > 1; }
         // nonsense_primer_number (V20:846): expansions that are neither observed k-mers nor the NM seed's phantom key
@@ -819,6 +921,7 @@ int mp_plan_finish(mp_plan *p, const int64_t *ev) {
 
 int mp_plan_results(const mp_plan *p, int32_t *window, double *cbit, double *tbit, uint8_t *primer_codes, int64_t *cov,
                     int64_t *f_mis, int64_t *r_mis, int32_t *nonsense, int32_t *n_dege, int64_t *cover_number) {
+    MP_PLAN_FORWARD(mp_plan_results, window, cbit, tbit, primer_codes, cov, f_mis, r_mis, nonsense, n_dege, cover_number);
     if (!p) return MP_ERR_ARG;
     if (!p->finished) return MP_ERR_ARG;
     const int k = p->P.k;
@@ -842,6 +945,7 @@ int mp_plan_results(const mp_plan *p, int32_t *window, double *cbit, double *tbi
 
 int mp_plan_window_table(const mp_plan *p, int32_t w, int32_t which, int64_t cap, uint8_t *codes, int64_t *counts,
                          int64_t *first_row, int64_t *n) {
+    MP_PLAN_FORWARD(mp_plan_window_table, w, which, cap, codes, counts, first_row, n);
     if (!p || w < 0 || (size_t)w >= p->win.size() || (which != 0 && which != 1) || !n) return MP_ERR_ARG;
     const Window &x = p->win[(size_t)w];
     const std::vector<Entry> &t = which == 0 ? x.cover : x.gap;
@@ -857,7 +961,10 @@ int mp_plan_window_table(const mp_plan *p, int32_t w, int32_t which, int64_t cap
 }
 
 int mp_expand_kmers(int32_t k, int64_t n, const uint8_t *codes, int64_t cap, uint8_t *out_codes, int64_t *out_src, int64_t *n_out) {
-    if (k < 1 || k > 32 || n < 0 || !n_out || (n && !codes)) return MP_ERR_ARG;
+#if !MP_PLAN_WIDE
+    if (k > kMaxK) return mp_expand_kmers_w64(k, n, codes, cap, out_codes, out_src, n_out);
+#endif
+    if (k < 1 || k > kMaxK || n < 0 || !n_out || (n && !codes)) return MP_ERR_ARG;
     double need = 0;
     for (int64_t i = 0; i < n; i++) {
         for (int j = 0; j < k; j++) if (codes[(size_t)i * k + j] > 15) return MP_ERR_ARG;
@@ -876,8 +983,11 @@ int mp_expand_kmers(int32_t k, int64_t n, const uint8_t *codes, int64_t cap, uin
     return MP_OK;
 }
 
-int mp_expand_kmer_words(int32_t k, int64_t n, const uint8_t *codes, int64_t cap, uint32_t *out_words, int64_t *out_src, int64_t *n_out) {
-    if (k < 1 || k > 32 || n < 0 || !n_out || (n && !codes)) return MP_ERR_ARG;
+int mp_expand_kmer_words(int32_t k, int64_t n, const uint8_t *codes, int64_t cap, void *out_words, int64_t *out_src, int64_t *n_out) {
+#if !MP_PLAN_WIDE
+    if (k > kMaxK) return mp_expand_kmer_words_w64(k, n, codes, cap, out_words, out_src, n_out);
+#endif
+    if (k < 1 || k > kMaxK || n < 0 || !n_out || (n && !codes)) return MP_ERR_ARG;
     double need = 0;
     for (int64_t i = 0; i < n; i++) {
         for (int j = 0; j < k; j++) if (codes[(size_t)i * k + j] > 15) return MP_ERR_ARG;
@@ -890,14 +1000,20 @@ int mp_expand_kmer_words(int32_t k, int64_t n, const uint8_t *codes, int64_t cap
     for (int64_t i = 0; i < n; i++)
         for_each_expansion(codes + (size_t)i * k, k, [&](const Key &e) {
             if (out_words) {
-                uint32_t b0 = 0, b1 = 0, g = 0;                       // window words of mprime.h: base index bits and the gap flag
+                word_t b0 = 0, b1 = 0, g = 0;                         // window words of mprime.h: base index bits and the gap flag
                 for (int j = 0; j < k; j++) {
                     const uint32_t c = (uint32_t)e.get(j);
-                    b0 |= (uint32_t)((c & 10u) != 0) << j;            // C or T
-                    b1 |= (uint32_t)((c & 12u) != 0) << j;            // G or T
-                    g |= (uint32_t)(c == 0) << j;
+                    b0 |= (word_t)((c & 10u) != 0) << j;              // C or T
+                    b1 |= (word_t)((c & 12u) != 0) << j;              // G or T
+                    g |= (word_t)(c == 0) << j;
                 }
-                out_words[(size_t)o * 3] = b0; out_words[(size_t)o * 3 + 1] = b1; out_words[(size_t)o * 3 + 2] = g;
+                if (k > MP_NARROW_K) {
+                    uint64_t *ow = (uint64_t *)out_words;
+                    ow[(size_t)o * 3] = b0; ow[(size_t)o * 3 + 1] = b1; ow[(size_t)o * 3 + 2] = g;
+                } else {
+                    uint32_t *ow = (uint32_t *)out_words;
+                    ow[(size_t)o * 3] = (uint32_t)b0; ow[(size_t)o * 3 + 1] = (uint32_t)b1; ow[(size_t)o * 3 + 2] = (uint32_t)g;
+                }
             }
             if (out_src) out_src[o] = i;
             o++;
@@ -982,8 +1098,8 @@ struct KeyHash { size_t operator()(const Key &k) const { return (size_t)hash_key
 }  // namespace
 
 extern "C" int mp_plan_write_side_files(const mp_plan *p, int32_t n_out, const int32_t *out_window, const int64_t *out_pos,
-                                        const uint8_t *primer_codes, uint32_t strictF, uint32_t strictR, const int64_t *dev_off,
-                                        const uint32_t *dev_words, int64_t n_dev, const int32_t *labels, int32_t n_rows, int64_t n_exc,
+                                        const uint8_t *primer_codes, uint64_t strictF, uint64_t strictR, const int64_t *dev_off,
+                                        const void *dev_words, int64_t n_dev, const int32_t *labels, int32_t n_rows, int64_t n_exc,
                                         const int32_t *x_window, const int64_t *x_row, const uint8_t *x_codes, const uint8_t *ids,
                                         const int64_t *id_off, const char *noncov_path, const char *gap_path) {
     return mp_plan_write_side_files_part(p, n_out, out_window, out_pos, primer_codes, strictF, strictR, dev_off, dev_words, n_dev, labels, n_rows,
@@ -991,10 +1107,12 @@ extern "C" int mp_plan_write_side_files(const mp_plan *p, int32_t n_out, const i
 }
 
 extern "C" int mp_plan_write_side_files_part(const mp_plan *p, int32_t n_out, const int32_t *out_window, const int64_t *out_pos,
-                                             const uint8_t *primer_codes, uint32_t strictF, uint32_t strictR, const int64_t *dev_off,
-                                             const uint32_t *dev_words, int64_t n_dev, const int32_t *labels, int32_t n_rows, int64_t n_exc,
+                                             const uint8_t *primer_codes, uint64_t strictF, uint64_t strictR, const int64_t *dev_off,
+                                             const void *dev_words, int64_t n_dev, const int32_t *labels, int32_t n_rows, int64_t n_exc,
                                              const int32_t *x_window, const int64_t *x_row, const uint8_t *x_codes, const uint8_t *ids,
                                              const int64_t *id_off, const char *noncov_path, const char *gap_path, int32_t part) {
+    MP_PLAN_FORWARD(mp_plan_write_side_files_part, n_out, out_window, out_pos, primer_codes, strictF, strictR, dev_off, dev_words, n_dev, labels,
+                    n_rows, n_exc, x_window, x_row, x_codes, ids, id_off, noncov_path, gap_path, part);
     const bool first_part = part & 1, last_part = part & 2;
     if (!first_part && n_out <= 0) return MP_ERR_ARG;                    // a continuation holds at least one window
     if (first_part && !last_part && n_out <= 0) return MP_ERR_ARG;
@@ -1002,7 +1120,7 @@ extern "C" int mp_plan_write_side_files_part(const mp_plan *p, int32_t n_out, co
         return MP_ERR_ARG;
     if (!p->P.keep_tables) return MP_ERR_ARG;
     const int k = p->P.k, v = p->P.v;
-    const uint32_t kmask = k == 32 ? 0xFFFFFFFFu : ((1u << k) - 1u);
+    const word_t kmask = k == 64 ? ~0ull : ((1ull << k) - 1ull);
     mp_plan *pm = const_cast<mp_plan *>(p);                              // the message buffer only
     FILE *fn = fopen(noncov_path, first_part ? "wb" : "ab");
     if (!fn) return pfail(pm, MP_ERR_ARG, "%s: %s", noncov_path, strerror(errno));
@@ -1055,9 +1173,10 @@ extern "C" int mp_plan_write_side_files_part(const mp_plan *p, int32_t n_out, co
             if (lab[r] >= 0 && lab[r] < b - a) rows_of_entry[(size_t)lab[r]].push_back(r);
         std::unordered_map<Key, int32_t, KeyHash> entry_of;             // k-mer -> device entry
         for (int64_t e = a; e < b; e++) {
-            const uint32_t b0 = dev_words[e], b1 = dev_words[(size_t)n_dev + e], g = dev_words[2 * (size_t)n_dev + e] & kmask;
+            const word_t b0 = rd_word(dev_words, (size_t)e, k), b1 = rd_word(dev_words, (size_t)n_dev + (size_t)e, k),
+                         g = rd_word(dev_words, 2 * (size_t)n_dev + (size_t)e, k) & kmask;
             Key key;
-            for (int j = 0; j < k; j++) key.set(j, (g >> j) & 1u ? 0u : 1u << (((b0 >> j) & 1u) | (((b1 >> j) & 1u) << 1)));
+            for (int j = 0; j < k; j++) key.set(j, (g >> j) & 1u ? 0u : 1u << (uint32_t)(((b0 >> j) & 1u) | (((b1 >> j) & 1u) << 1)));
             entry_of.emplace(key, (int32_t)(e - a));
         }
         // exceptions of this window
@@ -1090,15 +1209,15 @@ extern "C" int mp_plan_write_side_files_part(const mp_plan *p, int32_t n_out, co
         snprintf(num, sizeof num, "%lld", (long long)out_pos[oi]);
         on.pad(4); on.put("\""); on.put(num); on.put("\": [\n");
         for (int side = 0; side < 2; side++) {
-            const uint32_t strict = side == 0 ? strictF : strictR;
+            const uint64_t strict = side == 0 ? strictF : strictR;
             on.pad(8);
             bool any = false;
             for (const Entry &e : W.cover) {
-                uint32_t D = 0;
+                uint64_t D = 0;
                 int nd = 0;
                 for (int j = 0; j < k; j++) {
                     const uint32_t c = e.key.get(j);
-                    if (c == 0 || !(pc[j] & c)) { D |= 1u << j; nd++; }
+                    if (c == 0 || !(pc[j] & c)) { D |= 1ull << j; nd++; }
                 }
                 if (nd == 0 || !(nd > v || (D & strict))) continue;
                 on.put(any ? ",\n" : "{\n");
@@ -1117,7 +1236,7 @@ extern "C" int mp_plan_write_side_files_part(const mp_plan *p, int32_t n_out, co
         std::vector<Key> gkeys;
         std::unordered_map<Key, int32_t, KeyHash> seen;
         for (const Entry &e : W.gap) {
-            uint8_t codes[32];
+            uint8_t codes[kMaxK + 1];
             for (int j = 0; j < k; j++) codes[j] = (uint8_t)e.key.get(j);
             for_each_expansion(codes, k, [&](const Key &x) { if (seen.emplace(x, 1).second) gkeys.push_back(x); });
         }

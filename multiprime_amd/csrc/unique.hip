@@ -28,6 +28,10 @@ __device__ inline uint32_t hash3(uint32_t a, uint32_t b, uint32_t c) {
     h = (h ^ (h >> 13)) + c * 0xC2B2AE3Du;
     return h ^ (h >> 16);
 }
+__device__ inline uint32_t hash3(uint64_t a, uint64_t b, uint64_t c) {      // 64-bit window words (k > 31): the high halves fold in first
+    return hash3((uint32_t)a ^ ((uint32_t)(a >> 32) * 0x27D4EB2Fu), (uint32_t)b ^ ((uint32_t)(b >> 32) * 0x165667B1u),
+                 (uint32_t)c ^ ((uint32_t)(c >> 32) * 0x9E3779B1u));
+}
 // three 24-bit multiplies (full rate on gfx950; a 32-bit v_mul_lo is quarter rate and the first version's splitmix hash was a
 // fifth of the kernel's VALU time) over the key's bits 0-23 / 24-47 / 48-63, two folds: on the bench alignment's k-mers the LDS
 // insert needs 1.66 probe rounds per wave and the global table 1.02 probes per key, the same as with two 32-bit multiplies
@@ -398,8 +402,9 @@ __global__ __launch_bounds__(kBlock) void label_kernel(const MsaArgs M, int p0, 
 }
 
 // ---------------------------------------------------------------------------------------------- k >= 22
+template <typename W>
 struct UniqueOut {
-    uint32_t *b0, *b1, *g;
+    W *b0, *b1, *g;
     int32_t *count, *first;
     long long cap;
     unsigned long long *total;   // entries allocated so far (may exceed cap: caller checks)
@@ -409,14 +414,20 @@ struct UniqueOut {
     int32_t *overflow;           // [W] set to 1 when the table did not fit
 };
 
+__device__ inline uint32_t shfl_word(uint32_t x, int lane) { return __shfl(x, lane); }
+__device__ inline uint64_t shfl_word(uint64_t x, int lane) {
+    return (uint64_t)(uint32_t)__shfl((uint32_t)x, lane) | ((uint64_t)(uint32_t)__shfl((uint32_t)(x >> 32), lane) << 32);
+}
+
 // One block per window.  Rows stream through in lanes; equal keys inside a wave are folded with
 // ballots first, then one lane per distinct key updates the table.  A slot stores the row of a representative; key
 // comparison re-derives the representative's window words from the planes.
 // TABLE_IN_LDS = false: same algorithm on a global-memory table (windows with more distinct k-mers
 // than the LDS table holds).
-template <bool TABLE_IN_LDS>
+template <bool TABLE_IN_LDS, typename W>
 __global__ __launch_bounds__(kBlock) void unique_kernel(const MsaArgs M, int p0, int k, const int32_t *__restrict__ win_list, int slots,
-                                                        int limit, uint32_t *__restrict__ gtable, UniqueOut out) {
+                                                        int limit, uint32_t *__restrict__ gtable, UniqueOut<W> out) {
+    constexpr W kSkip = WordTraits<W>::kSkip;
     __shared__ uint32_t s_rep[TABLE_IN_LDS ? kHashSlots : 1];
     __shared__ uint32_t s_cnt[TABLE_IN_LDS ? kHashSlots : 1];
     __shared__ uint32_t s_min[TABLE_IN_LDS ? kHashSlots : 1];
@@ -432,17 +443,17 @@ __global__ __launch_bounds__(kBlock) void unique_kernel(const MsaArgs M, int p0,
     if (threadIdx.x == 0) { s_used = 0; s_over = 0; s_nout = 0; }
     __syncthreads();
     const size_t np = (size_t)n_pad;
-    const FlyView V(M, p0 + w, k, (1u << k) - 1u);
+    const FlyViewT<W> V(M, p0 + w, k, kmask_of<W>(k));
     const int lane = threadIdx.x & 63;
     for (int base = 0; base < n_pad; base += kBlock) {
         int r = base + threadIdx.x;
-        uint32_t b0 = 0, b1 = 0, g = MP_WIN_SKIP;
+        W b0 = 0, b1 = 0, g = kSkip;
         if (r < n_rows) V.load(r, b0, b1, g);
-        bool todo = !(g & MP_WIN_SKIP);
+        bool todo = !(g & kSkip);
         unsigned long long pending = __ballot(todo);
         while (pending) {
             int lead = __ffsll((long long)pending) - 1;
-            uint32_t k0 = __shfl(b0, lead), k1 = __shfl(b1, lead), k2 = __shfl(g, lead);
+            const W k0 = shfl_word(b0, lead), k1 = shfl_word(b1, lead), k2 = shfl_word(g, lead);
             bool same = todo && b0 == k0 && b1 == k1 && g == k2;
             unsigned long long grp = __ballot(same);
             if (lane == lead) {
@@ -454,7 +465,7 @@ __global__ __launch_bounds__(kBlock) void unique_kernel(const MsaArgs M, int p0,
                     if (hit) {
                         if (atomicAdd(&s_used, 1) + 1 > limit) s_over = 1;
                     } else {
-                        uint32_t o0, o1, o2;
+                        W o0, o1, o2;
                         V.load((int)old, o0, o1, o2);
                         hit = o0 == b0 && o1 == b1 && o2 == g;
                     }
@@ -488,7 +499,7 @@ __global__ __launch_bounds__(kBlock) void unique_kernel(const MsaArgs M, int p0,
         int idx = atomicAdd(&s_nout, 1);
         unsigned long long e = base + idx;
         if ((long long)e < out.cap) {
-            uint32_t o0, o1, o2;
+            W o0, o1, o2;
             V.load((int)rr, o0, o1, o2);
             out.b0[e] = o0; out.b1[e] = o1; out.g[e] = o2;
             out.count[e] = (int32_t)cnt[i];
@@ -501,15 +512,15 @@ __global__ __launch_bounds__(kBlock) void unique_kernel(const MsaArgs M, int p0,
     for (int base_r = 0; base_r < n_pad; base_r += kBlock) {
         int r = base_r + threadIdx.x;
         if (r >= n_rows) continue;
-        uint32_t b0, b1, g;
+        W b0, b1, g;
         V.load(r, b0, b1, g);
         int32_t lab = -1;
-        if (!(g & MP_WIN_SKIP)) {
+        if (!(g & kSkip)) {
             uint32_t h = hash3(b0, b1, g) & mask;
             for (int probe = 0; probe < slots; probe++) {
                 uint32_t rr = rep[h];
                 if (rr == kEmpty) break;
-                uint32_t o0, o1, o2;
+                W o0, o1, o2;
                 V.load((int)rr, o0, o1, o2);
                 if (o0 == b0 && o1 == b1 && o2 == g) { lab = (int32_t)cnt[h]; break; }
                 h = (h + 1) & mask;
@@ -522,9 +533,9 @@ __global__ __launch_bounds__(kBlock) void unique_kernel(const MsaArgs M, int p0,
 int alloc_entries(mp_ctx *c, int64_t cap) {
     int rc;
     c->u_cap = cap;
-    if ((rc = dev_alloc(c, &c->u_b0, (size_t)cap))) return rc;
-    if ((rc = dev_alloc(c, &c->u_b1, (size_t)cap))) return rc;
-    if ((rc = dev_alloc(c, &c->u_g, (size_t)cap))) return rc;
+    if ((rc = dev_alloc(c, &c->u_b0, (size_t)cap * wsz(c)))) return rc;
+    if ((rc = dev_alloc(c, &c->u_b1, (size_t)cap * wsz(c)))) return rc;
+    if ((rc = dev_alloc(c, &c->u_g, (size_t)cap * wsz(c)))) return rc;
     if ((rc = dev_alloc(c, &c->u_count, (size_t)cap))) return rc;
     if ((rc = dev_alloc(c, &c->u_first, (size_t)cap))) return rc;
     return MP_OK;
@@ -628,28 +639,29 @@ int unique_packed(mp_ctx *c, int64_t cap, int32_t want_labels, int64_t *n_entrie
     return MP_OK;
 }
 
-// k >= 22: one workgroup per window, representative-row table
-int unique_wide(mp_ctx *c, int64_t cap, int32_t want_labels, int64_t *n_entries) {
-    size_t W = (size_t)c->n_win, np = (size_t)c->n_pad;
+// k >= 22: one workgroup per window, representative-row table (W = the window word type: 64-bit for k > 31)
+template <typename W>
+int unique_rep_rows(mp_ctx *c, int64_t cap, int32_t want_labels, int64_t *n_entries) {
+    const size_t n_w = (size_t)c->n_win, np = (size_t)c->n_pad;
     int rc;
     if ((rc = alloc_entries(c, cap))) return rc;
-    if ((rc = dev_alloc(c, &c->u_over, W))) return rc;
-    if ((rc = dev_alloc(c, &c->u_wcount, W))) return rc;
-    if ((rc = dev_alloc(c, &c->u_wbase, W))) return rc;
+    if ((rc = dev_alloc(c, &c->u_over, n_w))) return rc;
+    if ((rc = dev_alloc(c, &c->u_wcount, n_w))) return rc;
+    if ((rc = dev_alloc(c, &c->u_wbase, n_w))) return rc;
     if ((rc = dev_alloc(c, &c->u_total, 1))) return rc;
-    if (want_labels && (rc = dev_alloc(c, &c->labels, W * np))) return rc;
+    if (want_labels && (rc = dev_alloc(c, &c->labels, n_w * np))) return rc;
     HIPCK(c, hipMemsetAsync(c->u_total, 0, sizeof(unsigned long long), c->stream));
-    UniqueOut uo{c->u_b0, c->u_b1, c->u_g, c->u_count, c->u_first, (long long)cap, c->u_total,
-                 c->u_wbase, c->u_wcount, c->labels, c->u_over};
+    UniqueOut<W> uo{reinterpret_cast<W *>(c->u_b0), reinterpret_cast<W *>(c->u_b1), reinterpret_cast<W *>(c->u_g), c->u_count, c->u_first, (long long)cap,
+                    c->u_total, c->u_wbase, c->u_wcount, c->labels, c->u_over};
     const MsaArgs M = msa_args(c);
-    hipLaunchKernelGGL((unique_kernel<true>), dim3((unsigned)W), dim3(kBlock), 0, c->stream, M, c->p0, c->k, (const int32_t *)nullptr,
+    hipLaunchKernelGGL((unique_kernel<true, W>), dim3((unsigned)n_w), dim3(kBlock), 0, c->stream, M, c->p0, c->k, (const int32_t *)nullptr,
                        kHashSlots, kHashLimit, (uint32_t *)nullptr, uo);
     HIPCK(c, hipGetLastError());
-    std::vector<int32_t> over(W);
-    HIPCK(c, hipMemcpyAsync(over.data(), c->u_over, sizeof(int32_t) * W, hipMemcpyDeviceToHost, c->stream));
+    std::vector<int32_t> over(n_w);
+    HIPCK(c, hipMemcpyAsync(over.data(), c->u_over, sizeof(int32_t) * n_w, hipMemcpyDeviceToHost, c->stream));
     HIPCK(c, hipStreamSynchronize(c->stream));
     std::vector<int32_t> big;
-    for (size_t w = 0; w < W; w++) if (over[w]) big.push_back((int32_t)w);
+    for (size_t w = 0; w < n_w; w++) if (over[w]) big.push_back((int32_t)w);
     if (!big.empty()) {
         // windows with more distinct k-mers than the LDS table holds: same kernel on a global table
         int slots = 1;
@@ -662,7 +674,7 @@ int unique_wide(mp_ctx *c, int64_t cap, int32_t want_labels, int64_t *n_entries)
         for (size_t i = 0; i < big.size(); i += batch) {
             size_t nb = std::min(batch, big.size() - i);
             HIPCK(c, hipMemcpy(d_list, big.data() + i, sizeof(int32_t) * nb, hipMemcpyHostToDevice));
-            hipLaunchKernelGGL((unique_kernel<false>), dim3((unsigned)nb), dim3(kBlock), 0, c->stream, M, c->p0, c->k,
+            hipLaunchKernelGGL((unique_kernel<false, W>), dim3((unsigned)nb), dim3(kBlock), 0, c->stream, M, c->p0, c->k,
                                (const int32_t *)d_list, slots, slots - 32, gtable, uo);
             HIPCK(c, hipGetLastError());
             HIPCK(c, hipStreamSynchronize(c->stream));
@@ -671,10 +683,10 @@ int unique_wide(mp_ctx *c, int64_t cap, int32_t want_labels, int64_t *n_entries)
         dev_free(c, &d_list, batch);
     }
     unsigned long long total = 0;
-    c->h_wbase.resize(W); c->h_wcount.resize(W);
+    c->h_wbase.resize(n_w); c->h_wcount.resize(n_w);
     HIPCK(c, hipMemcpy(&total, c->u_total, sizeof(total), hipMemcpyDeviceToHost));
-    HIPCK(c, hipMemcpy(c->h_wbase.data(), c->u_wbase, sizeof(int64_t) * W, hipMemcpyDeviceToHost));
-    HIPCK(c, hipMemcpy(c->h_wcount.data(), c->u_wcount, sizeof(int32_t) * W, hipMemcpyDeviceToHost));
+    HIPCK(c, hipMemcpy(c->h_wbase.data(), c->u_wbase, sizeof(int64_t) * n_w, hipMemcpyDeviceToHost));
+    HIPCK(c, hipMemcpy(c->h_wcount.data(), c->u_wcount, sizeof(int32_t) * n_w, hipMemcpyDeviceToHost));
     if (n_entries) *n_entries = (int64_t)total;
     if ((long long)total > cap) { c->u_n = 0; return fail(c, MP_ERR_CAPACITY, "unique table needs %llu entries", total); }
     c->u_n = (long long)total;
@@ -702,10 +714,11 @@ int mp_window_unique(mp_ctx *c, int64_t cap, int32_t want_labels, int64_t *n_ent
     if (cap <= 0) return fail(c, MP_ERR_ARG, "cap_entries must be positive");
     HIPCK(c, hipSetDevice(c->dev));
     free_unique(c);
-    return c->p64 ? unique_packed(c, cap, want_labels, n_entries) : unique_wide(c, cap, want_labels, n_entries);
+    if (c->p64) return unique_packed(c, cap, want_labels, n_entries);
+    return c->wide ? unique_rep_rows<uint64_t>(c, cap, want_labels, n_entries) : unique_rep_rows<uint32_t>(c, cap, want_labels, n_entries);
 }
 
-int mp_get_unique(mp_ctx *c, int64_t *win_off, uint32_t *words, int32_t *count, int32_t *first_row) {
+int mp_get_unique(mp_ctx *c, int64_t *win_off, void *words_out, int32_t *count, int32_t *first_row) {
     if (!c) return MP_ERR_ARG;
     if (c->h_wbase.empty()) return fail(c, MP_ERR_ARG, "mp_window_unique has not run");
     HIPCK(c, hipSetDevice(c->dev));
@@ -716,29 +729,31 @@ int mp_get_unique(mp_ctx *c, int64_t *win_off, uint32_t *words, int32_t *count, 
         int64_t o = 0;
         for (size_t w = 0; w < W; w++) { if (c->h_wbase[w] != o) { in_order = false; break; } o += c->h_wcount[w]; }
     }
+    const size_t wb = 4 * wsz(c);                       // bytes per window word
+    uint8_t *words = static_cast<uint8_t *>(words_out);
     if (in_order) {
         Lap lap(c->stream);
         if (n) {
-            HIPCK(c, hipMemcpyAsync(words, c->u_b0, 4 * n, hipMemcpyDeviceToHost, c->stream));
-            HIPCK(c, hipMemcpyAsync(words + n, c->u_b1, 4 * n, hipMemcpyDeviceToHost, c->stream));
-            HIPCK(c, hipMemcpyAsync(words + 2 * n, c->u_g, 4 * n, hipMemcpyDeviceToHost, c->stream));
+            HIPCK(c, hipMemcpyAsync(words, c->u_b0, wb * n, hipMemcpyDeviceToHost, c->stream));
+            HIPCK(c, hipMemcpyAsync(words + wb * n, c->u_b1, wb * n, hipMemcpyDeviceToHost, c->stream));
+            HIPCK(c, hipMemcpyAsync(words + 2 * wb * n, c->u_g, wb * n, hipMemcpyDeviceToHost, c->stream));
             HIPCK(c, hipMemcpyAsync(count, c->u_count, 4 * n, hipMemcpyDeviceToHost, c->stream));
             HIPCK(c, hipMemcpyAsync(first_row, c->u_first, 4 * n, hipMemcpyDeviceToHost, c->stream));
             HIPCK(c, hipStreamSynchronize(c->stream));
         }
-        if (lap.on) fprintf(stderr, "[mprime] get_unique: %zu entries, %.1f MB\n", n, 20.0 * (double)n / 1e6);
+        if (lap.on) fprintf(stderr, "[mprime] get_unique: %zu entries, %.1f MB\n", n, (double)(3 * wb + 8) * (double)n / 1e6);
         lap("get_unique: d2h");
         int64_t o = 0;
         for (size_t w = 0; w < W; w++) { win_off[w] = o; o += c->h_wcount[w]; }
         win_off[W] = o;
         return MP_OK;
     }
-    std::vector<uint32_t> b0(n + 1), b1(n + 1), g(n + 1);
+    std::vector<uint8_t> b0(wb * (n + 1)), b1(wb * (n + 1)), g(wb * (n + 1));
     std::vector<int32_t> cn(n + 1), fr(n + 1);
     if (n) {
-        HIPCK(c, hipMemcpy(b0.data(), c->u_b0, 4 * n, hipMemcpyDeviceToHost));
-        HIPCK(c, hipMemcpy(b1.data(), c->u_b1, 4 * n, hipMemcpyDeviceToHost));
-        HIPCK(c, hipMemcpy(g.data(), c->u_g, 4 * n, hipMemcpyDeviceToHost));
+        HIPCK(c, hipMemcpy(b0.data(), c->u_b0, wb * n, hipMemcpyDeviceToHost));
+        HIPCK(c, hipMemcpy(b1.data(), c->u_b1, wb * n, hipMemcpyDeviceToHost));
+        HIPCK(c, hipMemcpy(g.data(), c->u_g, wb * n, hipMemcpyDeviceToHost));
         HIPCK(c, hipMemcpy(cn.data(), c->u_count, 4 * n, hipMemcpyDeviceToHost));
         HIPCK(c, hipMemcpy(fr.data(), c->u_first, 4 * n, hipMemcpyDeviceToHost));
     }
@@ -747,10 +762,10 @@ int mp_get_unique(mp_ctx *c, int64_t *win_off, uint32_t *words, int32_t *count, 
     for (size_t w = 0; w < W; w++) {
         win_off[w] = o;
         size_t src = (size_t)c->h_wbase[w], m = (size_t)c->h_wcount[w];
+        memcpy(words + wb * (size_t)o, b0.data() + wb * src, wb * m);
+        memcpy(words + wb * (n + (size_t)o), b1.data() + wb * src, wb * m);
+        memcpy(words + wb * (2 * n + (size_t)o), g.data() + wb * src, wb * m);
         for (size_t i = 0; i < m; i++) {
-            words[(size_t)o + i] = b0[src + i];
-            words[n + (size_t)o + i] = b1[src + i];
-            words[2 * n + (size_t)o + i] = g[src + i];
             count[(size_t)o + i] = cn[src + i];
             first_row[(size_t)o + i] = fr[src + i];
         }

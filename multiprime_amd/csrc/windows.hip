@@ -1,5 +1,7 @@
 // windows.hip — part of libmprime_hip.so: hand-written HIP (gfx950 / MI355X, wave64) behind the C ABI of
 // include/mprime.h.  Window scan: which (window, sequence) k-mers are plain column slices, the patch list of the repaired ones, the IUPAC exception list (mp_build_windows).
+#include <type_traits>
+
 #include "common.hpp"
 #include "winwords.hpp"
 
@@ -41,7 +43,11 @@ struct PatchOut {
 constexpr int kCtrStride = 32;            // ints between two windows' global counters: one 128-byte line each
 constexpr int kClsBlock = 1024;          // 16 waves = 1024 rows per workgroup: a window's 16 `excl` words leave as one 128-byte store
 
+// WIDE (primers of 32..63 bases): the same bit tricks on the 96 columns of chunk c .. c + 2 (unsigned __int128).
+template <bool WIDE>
 __global__ __launch_bounds__(kClsBlock) void classify_kernel(const MsaArgs M, int p0, int n_win, int k, int v, PatchOut po) {
+    typedef typename std::conditional<WIDE, unsigned __int128, unsigned long long>::type Cols;      // residue / IUPAC flags of the columns from chunk c on
+    typedef typename std::conditional<WIDE, uint64_t, uint32_t>::type W;
     // ballot words of (window offset, wave): the `excl` array is window-major, so the 32 x 16 words of a workgroup are
     // transposed through LDS and stored 16 consecutive words at a time (a lone 8-byte store per (wave, window) cost
     // 0.8 ms per pass at 131072 x 1000: 2 M scattered partial-line writes)
@@ -53,7 +59,7 @@ __global__ __launch_bounds__(kClsBlock) void classify_kernel(const MsaArgs M, in
     const int n_rows = M.n_rows;
     const int c = (p0 >> 5) + blockIdx.y;                    // chunk of the window starts handled here
     const int o_lo = max(0, p0 - c * 32), o_hi = min(32, p0 + n_win - c * 32);      // start offsets [o_lo, o_hi) are windows
-    const uint32_t kmask = (1u << k) - 1u;
+    const W kmask = kmask_of<W>(k);
     const size_t np = (size_t)M.n_pad;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const bool in_pad = r < M.n_pad, real_row = r < n_rows;
@@ -64,11 +70,17 @@ __global__ __launch_bounds__(kClsBlock) void classify_kernel(const MsaArgs M, in
         const uint32_t loA = P[0], loC = P[np], loG = P[2 * np], loT = P[3 * np];
         const uint32_t hiA = P[4 * np], hiC = P[5 * np], hiG = P[6 * np], hiT = P[7 * np];      // chunk c+1 exists: n_chunks is padded by two
         const uint32_t lo1 = loA | loC, lo2 = loG | loT, hi1 = hiA | hiC, hi2 = hiG | hiT;
-        const unsigned long long N = (unsigned long long)(lo1 | lo2) | ((unsigned long long)(hi1 | hi2) << 32);
-        const unsigned long long Mu = (unsigned long long)((loA & loC) | (loG & loT) | (lo1 & lo2)) |
-                                      ((unsigned long long)((hiA & hiC) | (hiG & hiT) | (hi1 & hi2)) << 32);
+        Cols N = (Cols)((unsigned long long)(lo1 | lo2) | ((unsigned long long)(hi1 | hi2) << 32));
+        Cols Mu = (Cols)((unsigned long long)((loA & loC) | (loG & loT) | (lo1 & lo2)) |
+                         ((unsigned long long)((hiA & hiC) | (hiG & hiT) | (hi1 & hi2)) << 32));
+        if (WIDE) {                                                                     // chunk c+2 exists: n_chunks is padded by two
+            const uint32_t xA = P[8 * np], xC = P[9 * np], xG = P[10 * np], xT = P[11 * np];
+            const uint32_t x1 = xA | xC, x2 = xG | xT;
+            N |= (Cols)(x1 | x2) << 64;
+            Mu |= (Cols)((xA & xC) | (xG & xT) | (x1 & x2)) << 64;
+        }
         // sliding OR over k columns: X_t covers t columns, t the largest power of two <= k; cover(o) = X_t(o) | X_t(o + k - t)
-        auto cover = [k](unsigned long long X) {
+        auto cover = [k](Cols X) {
             int t = 1;
             while (2 * t <= k) { X |= X >> t; t *= 2; }
             return X | (X >> (k - t));
@@ -81,7 +93,7 @@ __global__ __launch_bounds__(kClsBlock) void classify_kernel(const MsaArgs M, in
         flag = ~fast;                                                                   // excl: not a plain slice, or more than v gaps
         if (po.pass == 0)
             for (int o = o_lo; o < o_hi; o++)
-                if ((int)__popc(~(uint32_t)(N >> o) & kmask) > v) flag |= 1u << o;
+                if (popcw((W)(~(W)(N >> o) & kmask)) > v) flag |= 1u << o;
     }
     // The per-window counters are hot: ~5 x 10^5 (wave, window) steps hold a slow pair at 131072 x 1000.  Device-scope
     // atomics on one cache line serialise (~50 ns each, measured: 0.8 ms per pass with a counter per 4 bytes), so a workgroup
@@ -138,37 +150,40 @@ __global__ __launch_bounds__(kClsBlock) void classify_kernel(const MsaArgs M, in
 
 // thread = one slow (window, row) pair: V20:668-687 line by line (winwords.hpp).  Writes the pair's window words (SKIP when the
 // k-mer holds an IUPAC code or the row is too short), appends IUPAC k-mers to the exception list, raises the short-row flag.
+template <typename W>
 __global__ __launch_bounds__(kBlock) void repair_kernel(const MsaArgs M, int p0, int k, int n, const int32_t *__restrict__ rows,
-                                                        const int32_t *__restrict__ wins, uint32_t *__restrict__ words,
+                                                        const int32_t *__restrict__ wins, W *__restrict__ words,
                                                         ExRec *__restrict__ ex, int *__restrict__ ex_count, int *__restrict__ err) {
     const int e = blockIdx.x * kBlock + threadIdx.x;
     if (e >= n) return;
     const int r = rows[e], w = wins[e], p = p0 + w;
-    const uint32_t kmask = (1u << k) - 1u;
+    const W kmask = kmask_of<W>(k);
     const size_t np = (size_t)M.n_pad;
-    const uint32_t *P = M.planes + ((size_t)(p >> 5) * 4) * np + r;
-    uint32_t b0, b1, g;
-    Nib buf;
-    const int rc = slow_words(M, r, p, k, kmask, M.rlen[r], P[0], P[np], P[2 * np], P[3 * np], P[4 * np], P[5 * np], P[6 * np], P[7 * np],
-                              b0, b1, g, buf);
+    const PlaneWords<W> q = load_plane_words<W>(M.planes + ((size_t)(p >> 5) * 4) * np + r, np);
+    W b0, b1, g;
+    NibOf<W> buf;
+    const int rc = slow_words<W>(M, r, p, k, kmask, M.rlen[r], q, b0, b1, g, buf);
     if (rc == 1) {
         const int idx = atomicAdd(ex_count, 1);
-        ex[idx].win = w; ex[idx].row = r; ex[idx].lo = buf.lo; ex[idx].hi = buf.hi;      // capacity = n: cannot overflow
-        b0 = 0; b1 = 0; g = MP_WIN_SKIP | kmask;
+        ex[idx].win = w; ex[idx].row = r;                                               // capacity = n: cannot overflow
+#pragma unroll
+        for (int i = 0; i < 4; i++) ex[idx].q[i] = i < WordTraits<W>::kNibWords ? buf.q[i < WordTraits<W>::kNibWords ? i : 0] : 0ull;
+        b0 = 0; b1 = 0; g = WordTraits<W>::kSkip | kmask;
     } else if (rc == 2) {
         atomicMax(err, 1);
         err[1] = w; err[2] = r;
-        b0 = 0; b1 = 0; g = MP_WIN_SKIP | kmask;
+        b0 = 0; b1 = 0; g = WordTraits<W>::kSkip | kmask;
     }
     words[3 * (size_t)e] = b0; words[3 * (size_t)e + 1] = b1; words[3 * (size_t)e + 2] = g;
 }
 
 // parity / debug: window words of rows [row0, row0 + n) of one window, derived on the fly
-__global__ __launch_bounds__(kBlock) void window_words_kernel(const MsaArgs M, int p, int k, int row0, int n, uint32_t *__restrict__ out) {
+template <typename W>
+__global__ __launch_bounds__(kBlock) void window_words_kernel(const MsaArgs M, int p, int k, int row0, int n, W *__restrict__ out) {
     int i = blockIdx.x * kBlock + threadIdx.x;
     if (i >= n) return;
-    uint32_t b0, b1, g;
-    FlyView(M, p, k, (1u << k) - 1u).load(row0 + i, b0, b1, g);
+    W b0, b1, g;
+    FlyViewT<W>(M, p, k, kmask_of<W>(k)).load(row0 + i, b0, b1, g);
     out[i] = b0; out[(size_t)n + i] = b1; out[2 * (size_t)n + i] = g;
 }
 
@@ -188,6 +203,7 @@ int mp_build_windows(mp_ctx *c, int32_t p0, int32_t n_win, int32_t k, int32_t v,
     free_windows(c);
     lap("build_windows: free");
     c->p0 = p0; c->n_win = n_win; c->k = k; c->v = v;
+    c->wide = k > MP_NARROW_K;            // 64-bit window words (winwords.hpp); wsz() = uint32 units per word
     size_t np = (size_t)c->n_pad;
     int rc;
     // histogram keys: one packed u64 when 3k bits fit (unique.hip), else three u32 words compared through a representative row
@@ -206,7 +222,7 @@ int mp_build_windows(mp_ctx *c, int32_t p0, int32_t n_win, int32_t k, int32_t v,
                              {c->excl, sizeof(unsigned long long) * (size_t)n_win * nw, 0u}, {c->patch_count, sizeof(int32_t) * (size_t)n_win * kCtrStride, 0u}};
     if ((rc = fill_segments(c, init, 5))) return rc;
     lap("build_windows: alloc+memset");
-    hipLaunchKernelGGL(classify_kernel, grid, dim3(kClsBlock), 0, c->stream, M, p0, n_win, k, v,
+    hipLaunchKernelGGL(c->wide ? classify_kernel<true> : classify_kernel<false>, grid, dim3(kClsBlock), 0, c->stream, M, p0, n_win, k, v,
                        PatchOut{0, c->excl, c->patch_count, nullptr, nullptr, nullptr, nullptr});
     HIPCK(c, hipGetLastError());
     lap("build_windows: classify");
@@ -235,7 +251,7 @@ int mp_build_windows(mp_ctx *c, int32_t p0, int32_t n_win, int32_t k, int32_t v,
     lap("build_windows: counts+offsets");
     if (tot) {
         int32_t *d_wins = nullptr;
-        if ((rc = dev_alloc(c, &c->patch_words, (size_t)3 * (size_t)tot))) return rc;
+        if ((rc = dev_alloc(c, &c->patch_words, (size_t)3 * (size_t)tot * wsz(c)))) return rc;
         if ((rc = dev_alloc(c, &c->patch_rows, (size_t)tot))) return rc;
         if ((rc = dev_alloc(c, &d_wins, (size_t)tot))) return rc;
         if ((rc = dev_alloc(c, &c->ex, (size_t)tot))) { dev_free(c, &d_wins, (size_t)tot); return rc; }
@@ -243,10 +259,15 @@ int mp_build_windows(mp_ctx *c, int32_t p0, int32_t n_win, int32_t k, int32_t v,
         hipError_t e = hipMemsetAsync(c->patch_cursor, 0, sizeof(int32_t) * (size_t)n_win * kCtrStride, c->stream);
         int cnt = 0, errv[4] = {0, 0, 0, 0};
         if (e == hipSuccess) {
-            hipLaunchKernelGGL(classify_kernel, grid, dim3(kClsBlock), 0, c->stream, M, p0, n_win, k, v,
+            hipLaunchKernelGGL(c->wide ? classify_kernel<true> : classify_kernel<false>, grid, dim3(kClsBlock), 0, c->stream, M, p0, n_win, k, v,
                                PatchOut{1, c->excl, c->patch_count, c->patch_off, c->patch_cursor, c->patch_rows, d_wins});
-            hipLaunchKernelGGL(repair_kernel, dim3((unsigned)((tot + kBlock - 1) / kBlock)), dim3(kBlock), 0, c->stream, M, p0, k, (int)tot,
-                               (const int32_t *)c->patch_rows, (const int32_t *)d_wins, c->patch_words, c->ex, c->ex_count, c->err_flag);
+            if (c->wide)
+                hipLaunchKernelGGL(repair_kernel<uint64_t>, dim3((unsigned)((tot + kBlock - 1) / kBlock)), dim3(kBlock), 0, c->stream, M, p0, k, (int)tot,
+                                   (const int32_t *)c->patch_rows, (const int32_t *)d_wins, reinterpret_cast<uint64_t *>(c->patch_words), c->ex, c->ex_count,
+                                   c->err_flag);
+            else
+                hipLaunchKernelGGL(repair_kernel<uint32_t>, dim3((unsigned)((tot + kBlock - 1) / kBlock)), dim3(kBlock), 0, c->stream, M, p0, k, (int)tot,
+                                   (const int32_t *)c->patch_rows, (const int32_t *)d_wins, c->patch_words, c->ex, c->ex_count, c->err_flag);
             e = hipGetLastError();
         }
         if (e == hipSuccess) e = hipMemcpyAsync(&cnt, c->ex_count, sizeof(int), hipMemcpyDeviceToHost, c->stream);
@@ -277,16 +298,16 @@ int mp_get_exceptions(mp_ctx *c, int32_t cap, int32_t *ew, int32_t *er, uint8_t 
         const ExRec &e = c->ex_host[(size_t)i];
         ew[i] = e.win; er[i] = e.row;
         for (int j = 0; j < c->k; j++)
-            codes[(size_t)i * c->k + j] = (uint8_t)((j < 16 ? e.lo >> (4 * j) : e.hi >> (4 * (j - 16))) & 15u);
+            codes[(size_t)i * c->k + j] = (uint8_t)((e.q[j >> 4] >> (4 * (j & 15))) & 15u);
     }
     return MP_OK;
 }
 
-int mp_set_extra_rows(mp_ctx *c, int32_t n, const int32_t *win, const uint32_t *words) {
+int mp_set_extra_rows(mp_ctx *c, int32_t n, const int32_t *win, const void *words) {
     if (!c) return MP_ERR_ARG;
     if (!c->excl) return fail(c, MP_ERR_ARG, "no windows built");
     HIPCK(c, hipSetDevice(c->dev));
-    dev_free(c, &c->extra_words, (size_t)3 * c->n_extra);
+    dev_free(c, &c->extra_words, (size_t)3 * c->n_extra * wsz(c));
     c->n_extra = 0;
     std::vector<int32_t> off((size_t)c->n_win + 1, 0);
     for (int i = 0; i < n; i++) {
@@ -300,14 +321,14 @@ int mp_set_extra_rows(mp_ctx *c, int32_t n, const int32_t *win, const uint32_t *
     c->pp_dirty = true; c->qp_dirty = true;
     if (n > 0) {
         int rc;
-        if ((rc = dev_alloc(c, &c->extra_words, (size_t)3 * n))) return rc;
+        if ((rc = dev_alloc(c, &c->extra_words, (size_t)3 * n * wsz(c)))) return rc;
         c->n_extra = n;
-        HIPCK(c, hipMemcpy(c->extra_words, words, sizeof(uint32_t) * 3 * (size_t)n, hipMemcpyHostToDevice));
+        HIPCK(c, hipMemcpy(c->extra_words, words, sizeof(uint32_t) * 3 * (size_t)n * wsz(c), hipMemcpyHostToDevice));
     }
     return MP_OK;
 }
 
-int mp_get_window_words(mp_ctx *c, int32_t w, int32_t row0, int32_t n, uint32_t *out) {
+int mp_get_window_words(mp_ctx *c, int32_t w, int32_t row0, int32_t n, void *out) {
     if (!c) return MP_ERR_ARG;
     if (!c->excl) return fail(c, MP_ERR_ARG, "no windows built");
     if (w < 0 || w >= c->n_win || row0 < 0 || n < 0 || row0 + n > c->n_rows) return fail(c, MP_ERR_ARG, "bad range");
@@ -315,12 +336,16 @@ int mp_get_window_words(mp_ctx *c, int32_t w, int32_t row0, int32_t n, uint32_t 
     if (n == 0) return MP_OK;
     uint32_t *d_out = nullptr;
     int rc;
-    if ((rc = dev_alloc(c, &d_out, (size_t)3 * n))) return rc;
-    hipLaunchKernelGGL(window_words_kernel, dim3((unsigned)((n + kBlock - 1) / kBlock)), dim3(kBlock), 0, c->stream, msa_args(c),
-                       c->p0 + w, c->k, row0, n, d_out);
-    hipError_t e = hipMemcpyAsync(out, d_out, sizeof(uint32_t) * 3 * (size_t)n, hipMemcpyDeviceToHost, c->stream);
+    if ((rc = dev_alloc(c, &d_out, (size_t)3 * n * wsz(c)))) return rc;
+    if (c->wide)
+        hipLaunchKernelGGL(window_words_kernel<uint64_t>, dim3((unsigned)((n + kBlock - 1) / kBlock)), dim3(kBlock), 0, c->stream, msa_args(c),
+                           c->p0 + w, c->k, row0, n, reinterpret_cast<uint64_t *>(d_out));
+    else
+        hipLaunchKernelGGL(window_words_kernel<uint32_t>, dim3((unsigned)((n + kBlock - 1) / kBlock)), dim3(kBlock), 0, c->stream, msa_args(c),
+                           c->p0 + w, c->k, row0, n, d_out);
+    hipError_t e = hipMemcpyAsync(out, d_out, sizeof(uint32_t) * 3 * (size_t)n * wsz(c), hipMemcpyDeviceToHost, c->stream);
     if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
-    dev_free(c, &d_out, (size_t)3 * n);
+    dev_free(c, &d_out, (size_t)3 * n * wsz(c));
     if (e != hipSuccess) return fail(c, MP_ERR_DEVICE, "mp_get_window_words: %s", hipGetErrorString(e));
     return MP_OK;
 }

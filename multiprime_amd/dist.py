@@ -151,6 +151,14 @@ class RowShards:
     def gather_entries(self, e_window, words, count, first_global):
         """Every rank's (window, key words, count, first global row) entries, concatenated.  No merge here: the native
         planning stage merges by key (counts add, the smallest first row wins)."""
+        if np.asarray(words).dtype == np.uint64:                  # primers of more than 31 bases: 64-bit window words, one column each
+            packed = np.empty((len(e_window), 6), np.int64)
+            packed[:, 0] = e_window
+            packed[:, 1:4] = np.asarray(words, np.uint64).view(np.int64).T
+            packed[:, 4] = count
+            packed[:, 5] = first_global
+            g = self.gather_var(packed)
+            return g[:, 0].astype(np.int32), np.ascontiguousarray(g[:, 1:4].T).view(np.uint64), g[:, 4].copy(), g[:, 5].copy()
         packed = np.empty((len(e_window), 5), np.int64)
         packed[:, 0] = e_window
         packed[:, 1] = np.asarray(words[0], np.int64) | (np.asarray(words[1], np.int64) << 32)

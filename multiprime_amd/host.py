@@ -43,9 +43,9 @@ HOST_SYMBOLS = [
     ("mp_plan_finish", C.c_int, [_p, _p]),
     ("mp_plan_results", C.c_int, [_p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p]),
     ("mp_plan_window_table", C.c_int, [_p, C.c_int32, C.c_int32, C.c_int64, _p, _p, _p, C.POINTER(C.c_int64)]),
-    ("mp_plan_write_side_files", C.c_int, [_p, C.c_int32, _p, _p, _p, C.c_uint32, C.c_uint32, _p, _p, C.c_int64, _p, C.c_int32, C.c_int64,
+    ("mp_plan_write_side_files", C.c_int, [_p, C.c_int32, _p, _p, _p, C.c_uint64, C.c_uint64, _p, _p, C.c_int64, _p, C.c_int32, C.c_int64,
                                            _p, _p, _p, _p, _p, C.c_char_p, C.c_char_p]),
-    ("mp_plan_write_side_files_part", C.c_int, [_p, C.c_int32, _p, _p, _p, C.c_uint32, C.c_uint32, _p, _p, C.c_int64, _p, C.c_int32, C.c_int64,
+    ("mp_plan_write_side_files_part", C.c_int, [_p, C.c_int32, _p, _p, _p, C.c_uint64, C.c_uint64, _p, _p, C.c_int64, _p, C.c_int32, C.c_int64,
                                                 _p, _p, _p, _p, _p, C.c_char_p, C.c_char_p, C.c_int32]),
     ("mp_expand_kmer_words", C.c_int, [C.c_int32, C.c_int64, _p, C.c_int64, _p, _p, C.POINTER(C.c_int64)]),
     ("mp_expand_kmers", C.c_int, [C.c_int32, C.c_int64, _p, C.c_int64, _p, _p, C.POINTER(C.c_int64)]),
@@ -171,7 +171,7 @@ def expand_kmers(codes: np.ndarray):
 
 
 def expand_kmer_words(codes: np.ndarray):
-    """(words [m][3] uint32, src [m]): the expansions of expand_kmers as window words (mp_set_extra_rows)."""
+    """(words [m][3] uint32 — uint64 for k > 31 —, src [m]): the expansions of expand_kmers as window words (mp_set_extra_rows)."""
     codes = np.ascontiguousarray(codes, dtype=np.uint8)
     n, k = codes.shape
     d = dll()
@@ -182,7 +182,7 @@ def expand_kmer_words(codes: np.ndarray):
     m = need.value
     if m > 1 << 28:
         raise MprimeError(MP_ERR_CAPACITY, f"IUPAC k-mers expand to {m} concrete k-mers")
-    words = np.empty((max(m, 1), 3), np.uint32)
+    words = np.empty((max(m, 1), 3), np.uint32 if k <= 31 else np.uint64)
     src = np.empty(max(m, 1), np.int64)
     rc = d.mp_expand_kmer_words(k, n, _ptr(codes), m, _ptr(words), _ptr(src), C.byref(need))
     if rc != 0:
@@ -215,7 +215,7 @@ class Plan:
             n = len(e_window)
             e_count = np.ascontiguousarray(e_count, dtype=np.int64)
             e_first = np.ascontiguousarray(e_first, dtype=np.int64)
-        e_words = np.ascontiguousarray(e_words, dtype=np.uint32).reshape(3, n)
+        e_words = np.ascontiguousarray(e_words, dtype=np.uint32 if self.k <= 31 else np.uint64).reshape(3, n)
         assert len(e_count) == n and len(e_first) == n
         x_window = np.ascontiguousarray(x_window, dtype=np.int32)
         x_row = np.ascontiguousarray(x_row, dtype=np.int64)
@@ -316,7 +316,7 @@ class Plan:
         out_pos = np.ascontiguousarray(out_pos, dtype=np.int64)
         primer_codes = np.ascontiguousarray(primer_codes, dtype=np.uint8).reshape(len(out_window), self.k)
         dev_off = np.ascontiguousarray(dev_off, dtype=np.int64)
-        dev_words = np.ascontiguousarray(dev_words, dtype=np.uint32)
+        dev_words = np.ascontiguousarray(dev_words, dtype=np.uint32 if self.k <= 31 else np.uint64)
         n_dev = dev_words.shape[1] if dev_words.ndim == 2 else 0
         labels = np.ascontiguousarray(labels, dtype=np.int32)
         n_rows = labels.shape[1] if labels.ndim == 2 else 0

@@ -98,30 +98,32 @@ def codes_of(seq: str) -> np.ndarray:
 
 
 def words_of_kmers(chars: np.ndarray) -> np.ndarray:
-    """(n,k) ASCII matrix of concrete k-mers over ACGT- -> (n,3) uint32 window words (mprime.h)."""
+    """(n,k) ASCII matrix of concrete k-mers over ACGT- -> (n,3) window words (mprime.h: uint32 for k <= 31, uint64 above)."""
     n, k = chars.shape
-    idx = np.zeros((n, k), np.uint32)
+    wt = np.uint32 if k <= 31 else np.uint64
+    idx = np.zeros((n, k), wt)
     idx[chars == ord("C")] = 1
     idx[chars == ord("G")] = 2
     idx[chars == ord("T")] = 3
-    gap = (chars == ord("-")).astype(np.uint32)
-    sh = np.arange(k, dtype=np.uint32)[None, :]
-    out = np.empty((n, 3), np.uint32)
-    out[:, 0] = np.bitwise_or.reduce((idx & 1) << sh, axis=1)
-    out[:, 1] = np.bitwise_or.reduce((idx >> 1) << sh, axis=1)
+    gap = (chars == ord("-")).astype(wt)
+    sh = np.arange(k, dtype=wt)[None, :]
+    out = np.empty((n, 3), wt)
+    out[:, 0] = np.bitwise_or.reduce((idx & wt(1)) << sh, axis=1)
+    out[:, 1] = np.bitwise_or.reduce((idx >> wt(1)) << sh, axis=1)
     out[:, 2] = np.bitwise_or.reduce(gap << sh, axis=1)
     return out
 
 
 def words_of_codes(codes: np.ndarray) -> np.ndarray:
-    """(n,k) concrete symbol codes (A=1 C=2 G=4 T=8, '-'=0) -> (n,3) uint32 window words (mprime.h)."""
+    """(n,k) concrete symbol codes (A=1 C=2 G=4 T=8, '-'=0) -> (n,3) window words (mprime.h: uint32 for k <= 31, uint64 above)."""
     codes = np.asarray(codes, np.uint8)
     n, k = codes.shape
-    sh = np.arange(k, dtype=np.uint32)[None, :]
-    out = np.empty((n, 3), np.uint32)
-    out[:, 0] = np.bitwise_or.reduce((((codes & 10) != 0).astype(np.uint32)) << sh, axis=1) if n else 0      # C or T: low index bit
-    out[:, 1] = np.bitwise_or.reduce((((codes & 12) != 0).astype(np.uint32)) << sh, axis=1) if n else 0      # G or T: high index bit
-    out[:, 2] = np.bitwise_or.reduce(((codes == 0).astype(np.uint32)) << sh, axis=1) if n else 0
+    wt = np.uint32 if k <= 31 else np.uint64
+    sh = np.arange(k, dtype=wt)[None, :]
+    out = np.empty((n, 3), wt)
+    out[:, 0] = np.bitwise_or.reduce((((codes & 10) != 0).astype(wt)) << sh, axis=1) if n else 0      # C or T: low index bit
+    out[:, 1] = np.bitwise_or.reduce((((codes & 12) != 0).astype(wt)) << sh, axis=1) if n else 0      # G or T: high index bit
+    out[:, 2] = np.bitwise_or.reduce(((codes == 0).astype(wt)) << sh, axis=1) if n else 0
     return out
 
 
@@ -129,11 +131,12 @@ _WORD_LUT = np.frombuffer(b"ACGT----", dtype=np.uint8)      # index = b0 | b1 <<
 
 
 def kmers_of_words(words: np.ndarray, k: int) -> np.ndarray:
-    """(3,n) uint32 window words -> (n,k) ASCII matrix over ACGT-."""
+    """(3,n) window words (uint32, or uint64 for k > 31) -> (n,k) ASCII matrix over ACGT-."""
     n = words.shape[1]
     if n == 0:
         return np.zeros((0, k), np.uint8)
-    bits = [np.unpackbits(np.ascontiguousarray(words[i]).astype("<u4", copy=False).view(np.uint8).reshape(n, 4),
+    wb = 4 if k <= 31 else 8
+    bits = [np.unpackbits(np.ascontiguousarray(words[i]).astype("<u%d" % wb, copy=False).view(np.uint8).reshape(n, wb),
                           axis=1, bitorder="little")[:, :k] for i in range(3)]
     idx = bits[1] << 1
     idx |= bits[0]

@@ -29,25 +29,25 @@ struct mp_ctx {
     /* windows */
     int32_t p0, n_win, k, v;
     char *kmers;      /* [n_win][n_rows][k] characters; kmers[..][0]==0 marks "not stored" (exception) */
-    uint32_t *words;  /* [n_win][3][n_rows] */
+    uint64_t *words;  /* [n_win][3][n_rows]; 64-bit inside for every k, MP_WORD_BYTES(k) at the ABI (rd_word / wr_word) */
     int32_t n_ex, cap_ex;
     int32_t *ex_win, *ex_row;
     char *ex_kmer;    /* [n_ex][k] */
     /* extra rows */
     int32_t n_extra;
     int32_t *extra_win;
-    uint32_t *extra_words;
+    uint64_t *extra_words;
     /* unique */
     int64_t n_ent;
     int64_t *win_off;
-    uint32_t *u_b0, *u_b1, *u_g;
+    uint64_t *u_b0, *u_b1, *u_g;
     int32_t *u_count, *u_first;
     int32_t *labels;  /* [n_win][n_rows] or NULL */
     /* staged candidates */
     int32_t n_cand;
     int32_t *cand_win;
     uint8_t *cand_codes;
-    uint32_t sF, sR;
+    uint64_t sF, sR;
     double eval_ms;
     int32_t eval_n;
     /* "resident" masks of mp_eval_masks_resident: plain host arrays here */
@@ -210,6 +210,17 @@ static int32_t window_kmer(const char *s, int32_t len, int32_t p, int32_t k, cha
     return n;
 }
 
+/* window words at the ABI: uint32 while k <= MP_NARROW_K, uint64 above (mprime.h); SKIP is the word's top bit either way */
+static uint64_t rd_word(const void *p, size_t i, int32_t k) {
+    if (k > MP_NARROW_K) return ((const uint64_t *)p)[i];
+    uint32_t x = ((const uint32_t *)p)[i];
+    return (uint64_t)(x & ~MP_WIN_SKIP) | ((x & MP_WIN_SKIP) ? MP_WIN_SKIP64 : 0);
+}
+static void wr_word(void *p, size_t i, int32_t k, uint64_t x) {
+    if (k > MP_NARROW_K) ((uint64_t *)p)[i] = x;
+    else ((uint32_t *)p)[i] = (uint32_t)(x & 0x7FFFFFFFu) | ((x & MP_WIN_SKIP64) ? MP_WIN_SKIP : 0u);
+}
+
 static int base_index(char ch) { return ch == 'A' ? 0 : ch == 'C' ? 1 : ch == 'G' ? 2 : ch == 'T' ? 3 : -1; }
 
 static uint8_t iupac_code(char ch) {
@@ -232,7 +243,7 @@ int mp_build_windows(mp_ctx *c, int32_t p0, int32_t n_win, int32_t k, int32_t v,
     free_windows(c);
     c->p0 = p0; c->n_win = n_win; c->k = k; c->v = v;
     c->kmers = (char *)calloc((size_t)n_win * N * k, 1);
-    c->words = (uint32_t *)calloc((size_t)n_win * 3 * N, sizeof(uint32_t));
+    c->words = (uint64_t *)calloc((size_t)n_win * 3 * N, sizeof(uint64_t));
     char *scratch = (char *)malloc((size_t)maxlen + 1);
     char buf[2 * MP_MAX_K + 4];
     if (!c->kmers || !c->words || !scratch) { free(scratch); return fail(c, MP_ERR_NOMEM, "out of memory"); }
@@ -240,15 +251,15 @@ int mp_build_windows(mp_ctx *c, int32_t p0, int32_t n_win, int32_t k, int32_t v,
         for (int32_t r = 0; r < N; r++) {
             int32_t n = window_kmer(c->rows[r], c->len[r], p0 + w, k, buf, scratch);
             if (n < k) { free(scratch); return fail(c, MP_ERR_SHORT_WINDOW, "row %d has fewer than %d residues at window %d", r, k, p0 + w); }
-            uint32_t b0 = 0, b1 = 0, g = 0;
+            uint64_t b0 = 0, b1 = 0, g = 0;
             int iupac = 0;
             for (int32_t j = 0; j < k; j++) {
                 int bi = base_index(buf[j]);
-                if (buf[j] == '-') g |= 1u << j;
+                if (buf[j] == '-') g |= 1ull << j;
                 else if (bi < 0) iupac = 1;
-                else { b0 |= (uint32_t)(bi & 1) << j; b1 |= (uint32_t)(bi >> 1) << j; }
+                else { b0 |= (uint64_t)(bi & 1) << j; b1 |= (uint64_t)(bi >> 1) << j; }
             }
-            uint32_t *W = c->words + (size_t)w * 3 * N;
+            uint64_t *W = c->words + (size_t)w * 3 * N;
             if (iupac) {
                 if (c->n_ex == c->cap_ex) {
                     c->cap_ex = c->cap_ex ? 2 * c->cap_ex : 1024;
@@ -259,7 +270,7 @@ int mp_build_windows(mp_ctx *c, int32_t p0, int32_t n_win, int32_t k, int32_t v,
                 c->ex_win[c->n_ex] = w; c->ex_row[c->n_ex] = r;
                 memcpy(c->ex_kmer + (size_t)c->n_ex * k, buf, (size_t)k);
                 c->n_ex++;
-                W[r] = 0; W[N + r] = 0; W[2 * N + r] = MP_WIN_SKIP | ((1u << k) - 1);
+                W[r] = 0; W[N + r] = 0; W[2 * N + r] = MP_WIN_SKIP64 | ((1ull << k) - 1);
             } else {
                 memcpy(c->kmers + ((size_t)w * N + r) * k, buf, (size_t)k);
                 W[r] = b0; W[N + r] = b1; W[2 * N + r] = g;
@@ -281,7 +292,7 @@ int mp_get_exceptions(mp_ctx *c, int32_t cap, int32_t *ew, int32_t *er, uint8_t 
     return MP_OK;
 }
 
-int mp_set_extra_rows(mp_ctx *c, int32_t n, const int32_t *win, const uint32_t *words) {
+int mp_set_extra_rows(mp_ctx *c, int32_t n, const int32_t *win, const void *words) {
     if (!c || !c->words) return c ? fail(c, MP_ERR_ARG, "no windows built") : MP_ERR_ARG;
     free(c->extra_win); free(c->extra_words);
     c->extra_win = NULL; c->extra_words = NULL; c->n_extra = 0;
@@ -290,23 +301,24 @@ int mp_set_extra_rows(mp_ctx *c, int32_t n, const int32_t *win, const uint32_t *
         if (win[i] < 0 || win[i] >= c->n_win || (i && win[i] < win[i - 1])) return fail(c, MP_ERR_ARG, "extra rows must be sorted by window");
     }
     c->extra_win = (int32_t *)malloc(sizeof(int32_t) * n);
-    c->extra_words = (uint32_t *)malloc(sizeof(uint32_t) * 3 * n);
+    c->extra_words = (uint64_t *)malloc(sizeof(uint64_t) * 3 * n);
     memcpy(c->extra_win, win, sizeof(int32_t) * n);
-    memcpy(c->extra_words, words, sizeof(uint32_t) * 3 * n);
+    for (size_t i = 0; i < 3 * (size_t)n; i++) c->extra_words[i] = rd_word(words, i, c->k);
     c->n_extra = n;
     return MP_OK;
 }
 
-int mp_get_window_words(mp_ctx *c, int32_t w, int32_t row0, int32_t n, uint32_t *out) {
+int mp_get_window_words(mp_ctx *c, int32_t w, int32_t row0, int32_t n, void *out) {
     if (!c || !c->words) return c ? fail(c, MP_ERR_ARG, "no windows built") : MP_ERR_ARG;
     if (w < 0 || w >= c->n_win || row0 < 0 || n < 0 || row0 + n > c->n_rows) return fail(c, MP_ERR_ARG, "bad range");
-    const uint32_t *W = c->words + (size_t)w * 3 * c->n_rows;
-    for (int p = 0; p < 3; p++) memcpy(out + (size_t)p * n, W + (size_t)p * c->n_rows + row0, sizeof(uint32_t) * n);
+    const uint64_t *W = c->words + (size_t)w * 3 * c->n_rows;
+    for (int p = 0; p < 3; p++)
+        for (int32_t i = 0; i < n; i++) wr_word(out, (size_t)p * n + i, c->k, W[(size_t)p * c->n_rows + row0 + i]);
     return MP_OK;
 }
 
 /* ---- per-window histogram: V20:689-711 (cover[i] += 1 / gap_sequence[sequence] += 1) -------- */
-typedef struct { uint32_t b0, b1, g; int32_t row; } keyrow;
+typedef struct { uint64_t b0, b1, g; int32_t row; } keyrow;
 
 static int cmp_keyrow(const void *a, const void *b) {
     const keyrow *x = (const keyrow *)a, *y = (const keyrow *)b;
@@ -316,7 +328,7 @@ static int cmp_keyrow(const void *a, const void *b) {
     return x->row < y->row ? -1 : x->row > y->row;
 }
 
-typedef struct { uint32_t b0, b1, g; int32_t count, first; } uent;
+typedef struct { uint64_t b0, b1, g; int32_t count, first; } uent;
 
 static int cmp_first(const void *a, const void *b) {
     const uent *x = (const uent *)a, *y = (const uent *)b;
@@ -336,11 +348,11 @@ int mp_window_unique(mp_ctx *c, int64_t cap, int32_t want_labels, int64_t *n_ent
     if (want_labels) c->labels = (int32_t *)malloc(sizeof(int32_t) * (size_t)W * N);
     int32_t *slot_of_sorted = (int32_t *)malloc(sizeof(int32_t) * (size_t)N);
     for (int32_t w = 0; w < W; w++) {
-        const uint32_t *Wd = c->words + (size_t)w * 3 * N;
+        const uint64_t *Wd = c->words + (size_t)w * 3 * N;
         int32_t m = 0;
         for (int32_t r = 0; r < N; r++) {
             if (c->labels) c->labels[(size_t)w * N + r] = -1;
-            if (Wd[2 * N + r] & MP_WIN_SKIP) continue;
+            if (Wd[2 * N + r] & MP_WIN_SKIP64) continue;
             kr[m].b0 = Wd[r]; kr[m].b1 = Wd[N + r]; kr[m].g = Wd[2 * N + r]; kr[m].row = r; m++;
         }
         qsort(kr, (size_t)m, sizeof(keyrow), cmp_keyrow);
@@ -370,8 +382,8 @@ int mp_window_unique(mp_ctx *c, int64_t cap, int32_t want_labels, int64_t *n_ent
     if (n_entries) *n_entries = n;
     if (n > cap) { free(all); c->n_ent = 0; return fail(c, MP_ERR_CAPACITY, "unique table needs %lld entries", (long long)n); }
     c->n_ent = n;
-    c->u_b0 = (uint32_t *)malloc(sizeof(uint32_t) * (size_t)(n + 1)); c->u_b1 = (uint32_t *)malloc(sizeof(uint32_t) * (size_t)(n + 1));
-    c->u_g = (uint32_t *)malloc(sizeof(uint32_t) * (size_t)(n + 1));
+    c->u_b0 = (uint64_t *)malloc(sizeof(uint64_t) * (size_t)(n + 1)); c->u_b1 = (uint64_t *)malloc(sizeof(uint64_t) * (size_t)(n + 1));
+    c->u_g = (uint64_t *)malloc(sizeof(uint64_t) * (size_t)(n + 1));
     c->u_count = (int32_t *)malloc(sizeof(int32_t) * (size_t)(n + 1)); c->u_first = (int32_t *)malloc(sizeof(int32_t) * (size_t)(n + 1));
     for (int64_t i = 0; i < n; i++) {
         c->u_b0[i] = all[i].b0; c->u_b1[i] = all[i].b1; c->u_g[i] = all[i].g; c->u_count[i] = all[i].count; c->u_first[i] = all[i].first;
@@ -380,13 +392,15 @@ int mp_window_unique(mp_ctx *c, int64_t cap, int32_t want_labels, int64_t *n_ent
     return MP_OK;
 }
 
-int mp_get_unique(mp_ctx *c, int64_t *win_off, uint32_t *words, int32_t *count, int32_t *first_row) {
+int mp_get_unique(mp_ctx *c, int64_t *win_off, void *words, int32_t *count, int32_t *first_row) {
     if (!c || !c->win_off) return c ? fail(c, MP_ERR_ARG, "mp_window_unique has not run") : MP_ERR_ARG;
     int64_t n = c->n_ent;
     memcpy(win_off, c->win_off, sizeof(int64_t) * ((size_t)c->n_win + 1));
-    memcpy(words, c->u_b0, sizeof(uint32_t) * (size_t)n);
-    memcpy(words + n, c->u_b1, sizeof(uint32_t) * (size_t)n);
-    memcpy(words + 2 * n, c->u_g, sizeof(uint32_t) * (size_t)n);
+    for (int64_t i = 0; i < n; i++) {
+        wr_word(words, (size_t)i, c->k, c->u_b0[i]);
+        wr_word(words, (size_t)(n + i), c->k, c->u_b1[i]);
+        wr_word(words, (size_t)(2 * n + i), c->k, c->u_g[i]);
+    }
     memcpy(count, c->u_count, sizeof(int32_t) * (size_t)n);
     memcpy(first_row, c->u_first, sizeof(int32_t) * (size_t)n);
     return MP_OK;
@@ -454,15 +468,15 @@ int mp_window_stats(mp_ctx *c, int64_t *freq, int64_t *nn) {
     return MP_OK;
 }
 
-static void eval_one(const uint8_t *cand, int32_t k, int32_t v, uint32_t sF, uint32_t sR,
+static void eval_one(const uint8_t *cand, int32_t k, int32_t v, uint64_t sF, uint64_t sR,
                      const char *kmer, int64_t *out) {
     int32_t nd = 0, gaps = 0;
-    uint32_t D = 0;
+    uint64_t D = 0;
     for (int32_t j = 0; j < k; j++) {
         if (kmer[j] == '-') gaps++;
         int bi = base_index(kmer[j]);
         int in_set = bi >= 0 && (cand[j] >> bi & 1);
-        if (!in_set) { nd++; D |= 1u << j; }              /* m_dist, V20:231 */
+        if (!in_set) { nd++; D |= 1ull << j; }            /* m_dist, V20:231 */
     }
     if (gaps > v) return;                                  /* not in `cover` (V20:689) */
     if (nd == 0) { out[0]++; return; }                     /* in optimal_primer_set, V20:1105-1106 */
@@ -471,12 +485,12 @@ static void eval_one(const uint8_t *cand, int32_t k, int32_t v, uint32_t sF, uin
     if (!(D & sR)) out[2]++;                               /* V20:1124-1127 */
 }
 
-static void words_to_kmer(uint32_t b0, uint32_t b1, uint32_t g, int32_t k, char *kmer) {
+static void words_to_kmer(uint64_t b0, uint64_t b1, uint64_t g, int32_t k, char *kmer) {
     for (int32_t j = 0; j < k; j++)
         kmer[j] = (g >> j & 1) ? '-' : "ACGT"[(b0 >> j & 1) | (b1 >> j & 1) << 1];
 }
 
-static int eval_all(mp_ctx *c, int32_t n_cand, const int32_t *cw, const uint8_t *codes, uint32_t sF, uint32_t sR, int64_t *out) {
+static int eval_all(mp_ctx *c, int32_t n_cand, const int32_t *cw, const uint8_t *codes, uint64_t sF, uint64_t sR, int64_t *out) {
     int32_t N = c->n_rows, k = c->k;
     char km[MP_MAX_K + 1];
     int32_t e0 = 0;
@@ -500,13 +514,13 @@ static int eval_all(mp_ctx *c, int32_t n_cand, const int32_t *cw, const uint8_t 
 }
 
 int mp_eval_candidates(mp_ctx *c, int32_t n_cand, const int32_t *cw, const uint8_t *codes,
-                       uint32_t sF, uint32_t sR, int64_t *out) {
+                       uint64_t sF, uint64_t sR, int64_t *out) {
     if (!c || !c->words) return c ? fail(c, MP_ERR_ARG, "no windows built") : MP_ERR_ARG;
     if (n_cand < 0 || (n_cand && (!cw || !codes || !out))) return fail(c, MP_ERR_ARG, "bad arguments");
     return eval_all(c, n_cand, cw, codes, sF, sR, out);
 }
 
-int mp_eval_upload(mp_ctx *c, int32_t n_cand, const int32_t *cw, const uint8_t *codes, uint32_t sF, uint32_t sR) {
+int mp_eval_upload(mp_ctx *c, int32_t n_cand, const int32_t *cw, const uint8_t *codes, uint64_t sF, uint64_t sR) {
     if (!c || !c->words) return c ? fail(c, MP_ERR_ARG, "no windows built") : MP_ERR_ARG;
     free(c->cand_win); free(c->cand_codes);
     c->cand_win = (int32_t *)malloc(sizeof(int32_t) * (size_t)(n_cand + 1));
@@ -597,7 +611,7 @@ int mp_comm_allgatherv(mp_ctx *c, const void *send, int64_t n_bytes, const int64
     if (n_bytes) memcpy(recv, send, (size_t)n_bytes);
     return MP_OK;
 }
-int mp_eval_candidates_allreduce(mp_ctx *c, int32_t n_cand, const int32_t *cw, const uint8_t *codes, uint32_t sF, uint32_t sR, int64_t *out) {
+int mp_eval_candidates_allreduce(mp_ctx *c, int32_t n_cand, const int32_t *cw, const uint8_t *codes, uint64_t sF, uint64_t sR, int64_t *out) {
     int rc = one_rank(c);
     if (rc) return rc;
     return mp_eval_candidates(c, n_cand, cw, codes, sF, sR, out);
@@ -760,7 +774,7 @@ int mp_pair_coverage(mp_ctx *c, int32_t n_sets, int32_t n_words, const uint64_t 
 }
 
 /* bitset form of gap_seq_id / non_coverage_seq_id for one candidate per entry (V20:689-698, 1107-1127) */
-int mp_eval_masks(mp_ctx *c, int32_t n_cand, const int32_t *cw, const uint8_t *codes, uint32_t sF, uint32_t sR,
+int mp_eval_masks(mp_ctx *c, int32_t n_cand, const int32_t *cw, const uint8_t *codes, uint64_t sF, uint64_t sR,
                   uint64_t *not_f, uint64_t *not_r) {
     if (!c || !c->words) return c ? fail(c, MP_ERR_ARG, "no windows built") : MP_ERR_ARG;
     if (n_cand < 0 || (n_cand && (!cw || !codes || !not_f || !not_r))) return fail(c, MP_ERR_ARG, "bad arguments");
@@ -792,7 +806,7 @@ int mp_eval_masks(mp_ctx *c, int32_t n_cand, const int32_t *cw, const uint8_t *c
 }
 
 /* (4d) the resident form: the same masks kept in the context, single-bit fix-ups, popcounts of unions */
-int mp_eval_masks_resident(mp_ctx *c, int32_t n_cand, const int32_t *cw, const uint8_t *codes, uint32_t sF, uint32_t sR) {
+int mp_eval_masks_resident(mp_ctx *c, int32_t n_cand, const int32_t *cw, const uint8_t *codes, uint64_t sF, uint64_t sR) {
     if (!c || !c->words) return c ? fail(c, MP_ERR_ARG, "no windows built") : MP_ERR_ARG;
     size_t nw = ((size_t)c->n_rows + 63) / 64;
     free(c->mask_f); free(c->mask_r);

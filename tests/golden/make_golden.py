@@ -70,6 +70,14 @@ FIXTURES = {
     "syn_v3_k27": ("@syn_v2", dict(DEF, l=27, v=3, d=32, s=100, c="1,-2", n=6)),
     "syn_edge": ("@syn_edge", dict(DEF, l=15, v=1, s=50, d=16, f=0.7)),
     "syn_v2_k31": ("@syn_v2", dict(DEF, l=31, v=2, d=64, s=100, c="2,3,-1", n=6)),
+    # primers longer than one 32-bit window word (round 4: -l up to 63)
+    "msa1000_k36_d64": (f"{T}/1000_fasta.msa", dict(CFG2, l=36, d=64, v=1)),
+    "ivc_k45_v2": (f"{T}/variation_effect/IVC/IV_C.msa", dict(DEF, l=45, v=2, d=32, n=6, c="2,3,-1")),
+    "cluster0_k32": (f"{T}/results/Clusters_msa/Cluster_0_20727.tmsa", dict(YAML, l=32, v=1)),
+    "syn_iupac_k33": ("@syn_iupac", dict(DEF, l=33, v=1, s=60, d=24, e=9.0, f=0.5)),
+    "syn_ragged_k40": ("@syn_ragged", dict(DEF, l=40, v=2, s=80)),
+    "syn_edge_k63": ("@syn_edge", dict(DEF, l=63, v=3, s=50, d=16, f=0.4, c="1,2,-1,-3", e=12.0)),
+    "syn_v2_k50": ("@syn_v2", dict(DEF, l=50, v=2, d=64, s=100, c="2,3,-1", n=6, e=10.0, f=0.5)),
 }
 
 

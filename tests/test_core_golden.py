@@ -14,7 +14,10 @@ from multiprime_amd.core import NN_degenerate
 
 FAST = ["syn_iupac", "syn_v2", "syn_ragged", "syn_v3_k27", "syn_edge", "ivc_v0", "ivc_v1", "ivc_v2",
         "msa1000_k18_d64", "msa1000_k20_d64", "msa1000_k22_d64", "msa1000_k18_d10", "msa1000_k30_d64", "msa1000_k31_d64", "syn_v2_k31", "msa1000_c1_f06", "ivc_e30_g"]
-FULL = FAST + ["cluster0_v1", "cluster0_v2", "cluster0_v0_d64", "testfa"]
+# primers of 32..63 bases (64-bit window words; recorded from V20 at -l 32, 33, 36, 40, 45, 50, 63)
+WIDE = ["cluster0_k32", "syn_iupac_k33", "msa1000_k36_d64", "syn_ragged_k40", "ivc_k45_v2", "syn_v2_k50", "syn_edge_k63"]
+FAST = FAST + [n for n in WIDE if n != "cluster0_k32"]
+FULL = FAST + ["cluster0_v1", "cluster0_v2", "cluster0_v0_d64", "testfa", "cluster0_k32"]
 
 
 def canon_noncov(d):

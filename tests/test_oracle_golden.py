@@ -13,7 +13,7 @@ from multiprime_amd import iupac
 from multiprime_amd.core import NN_degenerate
 
 NAMES = ["syn_iupac", "syn_v2", "syn_ragged", "syn_v3_k27", "syn_edge", "ivc_v1", "msa1000_k18_d64", "msa1000_k22_d64", "msa1000_k30_d64", "msa1000_k31_d64", "msa1000_c1_f06", "ivc_e30_g", "cluster0_v0_d64",
-         "cluster0_v2"]
+         "cluster0_v2", "cluster0_k32", "syn_iupac_k33", "msa1000_k36_d64", "syn_ragged_k40", "ivc_k45_v2", "syn_v2_k50", "syn_edge_k63"]
 
 
 def open_fixture(name, lib, tmp_path):
