@@ -17,6 +17,7 @@ from __future__ import annotations
 
 import json
 import os
+import sys
 import time
 from bisect import bisect_left
 
@@ -109,7 +110,7 @@ class Primers_filter(object):
         # written (deep alignments) — the bitset file of `multiPrime-core.py --bitsets`
         self.bitset_file = None
         gap_json, non_json = self.primer_file + ".gap_seq_id_json", self.primer_file + ".non_coverage_seq_id_json"
-        if self.core is not None and self.core.mask_index:
+        if self.core is not None and (self.core.mask_index or self.core.keep_bitsets):      # (no primer at all: an empty index)
             gap_dict, non_cover_dict = None, None
         elif os.path.exists(gap_json) and os.path.exists(non_json):
             with open(gap_json) as g:
@@ -226,6 +227,13 @@ class Primers_filter(object):
         threshold = 1 - self.fraction
         print("Candidata degenerate primer number is: {}".format(len(cand)))
         ID = str(self.outfile)
+        if not cand:
+            # no primer survived the core step's filters: the reference dies here with an IndexError (candidate_primer[-1] of an
+            # empty list, GM:611; tests/golden/chain_k36.json.gz records its exit status 1 and that it writes no file).  Same status,
+            # a message instead of a traceback.
+            print("Error: {} holds no candidate primer; the reference fails on such an input too (IndexError).".format(self.primer_file),
+                  file=sys.stderr)
+            sys.exit(1)
         if int(cand[-1]) - int(cand[0]) < min_len:                                   # GM:611-618
             print("Max PCR product legnth < min len!")
             with open(self.outfile, "w") as fo:

@@ -13,8 +13,10 @@ on eight small seeded synthetic clusters (multiprime_amd.synth, the generator of
 because the reference core takes ~0.1 s per window).  Flags are multiPrime.yaml's.  Stored: the gzipped cluster FASTA files
 and every file the chain wrote, in tests/golden/chain.json.gz.  Environment as SURVEY Appendix A-14.
 
-Usage: python tests/golden/make_golden_chain.py
+Usage: python tests/golden/make_golden_chain.py                                      -> chain.json.gz (-l 18, all eight clusters)
+       python tests/golden/make_golden_chain.py --length 36 --clusters 0,1,3,5,7    -> chain_k36.json.gz (primers longer than one 32-bit word)
 """
+import argparse
 import gzip
 import json
 import os
@@ -49,12 +51,19 @@ def run(cmd, cwd):
 
 
 def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--length", type=int, default=18, help="-l of the core step (multiPrime.yaml: 18)")
+    ap.add_argument("--clusters", default=None, help="comma-separated indices into CLUSTERS (default: all)")
+    args = ap.parse_args()
+    picked = [int(x) for x in args.clusters.split(",")] if args.clusters else list(range(len(CLUSTERS)))
     sys.path.insert(0, REPO)
     from multiprime_amd.synth import synth_block, to_fasta
-    out = {"flags": "multiPrime.yaml", "clusters": [], "files": {}, "stdout": {}}
+    out = {"flags": "multiPrime.yaml" + ("" if args.length == 18 else f" with -l {args.length}"), "primer_length": args.length, "clusters": [], "files": {}, "stdout": {}}
     with tempfile.TemporaryDirectory() as wd:
         names = []
         for i, (n, L, seed, kw) in enumerate(CLUSTERS):
+            if i not in picked:
+                continue
             name = f"Cluster_{i}_{n}"
             names.append(name)
             data = to_fasta(synth_block(0, n, L, seed, block_rows=256, **kw))
@@ -69,7 +78,7 @@ def main():
             fa = os.path.join(wd, name + ".tfa")
             top = os.path.join(wd, name + ".top.primer.out")
             rc1 = run([sys.executable, os.path.join(S, "multiPrime-core.py"), "-i", fa, "-n", "4", "-d", "10", "-v", "1", "-c", "2,3,-1",
-                       "-g", "0.2,0.7", "-s", "150", "-l", "18", "-e", "3.6", "-o", top, "-f", "0.7", "-p", "1"], wd)
+                       "-g", "0.2,0.7", "-s", "150", "-l", str(args.length), "-e", "3.6", "-o", top, "-f", "0.7", "-p", "1"], wd)
             cand = os.path.join(wd, name + ".candidate.primers.txt")
             rc2 = run([sys.executable, os.path.join(S, "get_multiPrime.py"), "-i", top, "-r", fa, "-f", "0.7", "-s", "150,1200",
                        "-g", "0.2,0.7", "-e", "4", "-d", "4", "-a", ADAPTOR, "-m", "0", "-o", cand, "-p", "1"], wd)
@@ -102,7 +111,7 @@ def main():
                 out["files"][fn] = {"json": json.loads(raw)}
             else:
                 out["files"][fn] = {"text": raw.decode().replace(wd, "@WD")}
-    path = os.path.join(HERE, "chain.json.gz")
+    path = os.path.join(HERE, "chain.json.gz" if args.length == 18 else f"chain_k{args.length}.json.gz")
     with open(path, "wb") as f:
         f.write(gzip.compress(json.dumps(out, sort_keys=True).encode(), 9, mtime=0))
     print("wrote", path, os.path.getsize(path), "bytes;", {k: len(v.get("text", "")) for k, v in out["files"].items() if "text" in v})

@@ -57,6 +57,12 @@ CASES = [
     (4, 1000, 120, False, 20, 0, 3),
     (5, 33, 300, True, 28, 3, 10),
     (6, 700, 90, False, 8, 1, 0),
+    # primers of 32..63 bases: 64-bit window words
+    (7, 300, 260, False, 36, 1, 5),
+    (8, 130, 500, True, 45, 2, 0),
+    (9, 500, 200, False, 63, 3, 2),
+    (10, 257, 150, False, 32, 1, 0),
+    (11, 4200, 130, False, 40, 2, 1),
 ]
 
 
@@ -111,7 +117,7 @@ def test_every_abi_output_matches_oracle(hip_lib, oracle_lib, seed, n, L, ragged
     ro = o.eval_candidates(cw, codes, sF, sR)
     assert rh.tolist() == ro.tolist()
     words0 = o.get_window_words(W // 2)
-    ok = (words0[2] & 0x80000000) == 0
+    ok = (words0[2] >> (8 * words0.dtype.itemsize - 1)) == 0            # MP_WIN_SKIP: the top bit of g
     if ok.any():
         kmers = iupac.kmers_of_words(words0[:, ok][:, :40], k)
         cand = iupac.MASK_LUT[kmers]
@@ -254,12 +260,13 @@ def test_candidate_grouping_paths_match_oracle(hip_lib, oracle_lib, monkeypatch,
         assert np.array_equal(got, want), f"counters differ with {env or 'defaults'}"
 
 
-@pytest.mark.parametrize("n,v,ragged", [(77, 0, False), (300, 1, False), (2100, 2, False), (9000, 3, False), (40000, 1, False), (513, 4, False), (6, 1, True), (5, 2, True)])
-def test_coverage_masks_match_oracle(hip_lib, oracle_lib, monkeypatch, n, v, ragged):
+@pytest.mark.parametrize("n,v,ragged,k", [(77, 0, False, 18), (300, 1, False, 18), (2100, 2, False, 18), (9000, 3, False, 18), (40000, 1, False, 18), (513, 4, False, 18),
+                                          (6, 1, True, 18), (5, 2, True, 18), (300, 1, False, 33), (2100, 2, False, 47), (130, 3, True, 40), (700, 5, False, 63)])
+def test_coverage_masks_match_oracle(hip_lib, oracle_lib, monkeypatch, n, v, ragged, k):
     """mp_eval_masks: the bit-sliced form (the evaluation pass storing its final words; v <= 3) and the row-per-thread form
     (MP_MASK_MODE=rows; any v) against the oracle, bit for bit — alignments with edge gaps, ragged ends, IUPAC codes, rows with
     more than v gaps, candidate groups of every kind, row counts off the word boundaries."""
-    L, k, p0 = 110, 18, 3
+    L, p0 = 92 + k, 3
     data, off, _ = fuzz_msa(1234 + n + v, n, L, ragged=ragged, p_gap=0.05, p_iupac=0.004)
     W = L - p0 - k - 2
     rng = np.random.default_rng(n * 3 + v)
@@ -293,7 +300,8 @@ def test_coverage_masks_match_oracle(hip_lib, oracle_lib, monkeypatch, n, v, rag
 
 
 @pytest.mark.parametrize("n,k,v", [(1, 5, 0), (63, 2, 1), (64, 16, 2), (65, 17, 1), (257, 27, 2), (2049, 28, 1),
-                                   (33000, 28, 2), (300, 29, 1), (4100, 30, 3), (33000, 31, 2), (520, 31, 0), (8200, 3, 0), (16500, 21, 1), (700, 20, 3), (40000, 18, 3), (300, 12, 4)])
+                                   (33000, 28, 2), (300, 29, 1), (4100, 30, 3), (33000, 31, 2), (520, 31, 0), (8200, 3, 0), (16500, 21, 1), (700, 20, 3), (40000, 18, 3), (300, 12, 4),
+                                   (300, 32, 1), (2049, 33, 2), (33000, 48, 2), (65, 62, 3), (520, 63, 0), (4100, 63, 4)])
 def test_kernel_shapes_and_extreme_k(hip_lib, oracle_lib, monkeypatch, n, k, v):
     """Row counts around the word / block boundaries and the smallest and largest k, chains of every kind."""
     v = min(v, k - 1)

@@ -36,7 +36,8 @@ def _worker(rank, world, port, name, inp, out, lib_path, write_json=True):
 
 # 1/2/4/8 shards incl. uneven splits: syn_iupac has 60 rows (8 ranks: 7 or 8 rows each), ivc_v1 166 (4 ranks: 41/42)
 @pytest.mark.parametrize("name,world", [("syn_iupac", 2), ("syn_ragged", 3), ("ivc_v1", 2), ("msa1000_k18_d64", 2),
-                                        ("syn_iupac", 8), ("ivc_v1", 4), ("syn_edge", 4), ("msa1000_k18_d64", 8)])
+                                        ("syn_iupac", 8), ("ivc_v1", 4), ("syn_edge", 4), ("msa1000_k18_d64", 8),
+                                        ("syn_iupac_k33", 3), ("syn_ragged_k40", 2), ("syn_edge_k63", 4)])      # 64-bit window words
 def test_sharded_run_matches_reference(name, world, oracle_lib, tmp_path):
     from test_core_golden import check_outputs
     meta = load_gz_json(name + ".trace.json.gz")["meta"]
@@ -77,7 +78,7 @@ def _check_bitsets(name, out):
 
 # without the JSON side files the planning is split by windows across the ranks (candidates gathered, results concatenated)
 @pytest.mark.parametrize("name,world", [("syn_iupac", 2), ("syn_ragged", 3), ("ivc_v1", 4), ("msa1000_k18_d64", 8), ("syn_edge", 5),
-                                        ("cluster0_v2", 3)])
+                                        ("cluster0_v2", 3), ("syn_v2_k50", 3), ("ivc_k45_v2", 2)])
 def test_sharded_run_with_window_split_planning(name, world, oracle_lib, tmp_path):
     meta = load_gz_json(name + ".trace.json.gz")["meta"]
     inp = tmp_path / (name + ".fa")
@@ -184,7 +185,7 @@ def test_comm_exports_of_the_checker_are_a_world_of_one(oracle_lib):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("name,world", [("syn_iupac", 2), ("msa1000_k18_d64", 2), ("syn_ragged", 3)])
+@pytest.mark.parametrize("name,world", [("syn_iupac", 2), ("msa1000_k18_d64", 2), ("syn_ragged", 3), ("syn_ragged_k40", 2), ("syn_iupac_k33", 3)])
 def test_sharded_hip_contexts_match_reference(name, world, hip_lib, tmp_path):
     """Two ranks, each with its own HIP context on the one GPU of the box (gloo carries the collectives): row
     offsets, histogram merging and counter all-reduce on top of the real kernels."""

@@ -41,13 +41,13 @@ ADAPTOR = "TCTTTCCCTACACGACGCTCTTCCGATCT,TGGAGTTCAGACGTGTGCTCTTCCGATCT"
 DEEP_ROWS = 2000        # above this the JSON side files (O(windows x sequences)) give way to device-resident bitsets
 
 
-def cluster_stage(fa, wd, name, library=None, device=0, deep=False, timings=None, phases=None):
+def cluster_stage(fa, wd, name, library=None, device=0, deep=False, timings=None, phases=None, primer_length=18):
     """Rules multiPrime and get_multiPrime for one cluster: {name}.top.primer.out and {name}.candidate.primers.txt in wd.
     Returns (primers written, candidate pairs written)."""
     from multiprime_amd.pairing import Primers_filter
     t0 = time.time()
     top = os.path.join(wd, name + ".top.primer.out")
-    app = NN_degenerate(seq_file=fa, primer_length=18, coverage=0.7, number_of_dege_bases=4, score_of_dege_bases=10,
+    app = NN_degenerate(seq_file=fa, primer_length=primer_length, coverage=0.7, number_of_dege_bases=4, score_of_dege_bases=10,
                         raw_entropy_threshold=3.6, product_len=150, position="2,3,-1", variation=1, distance=4,
                         GC="0.2,0.7", nproc=1, outfile=top, device=device, library=library, write_json=not deep, keep_bitsets=deep)
     app.run()
@@ -63,7 +63,10 @@ def cluster_stage(fa, wd, name, library=None, device=0, deep=False, timings=None
         pf = Primers_filter(ref_file=fa, primer_file=top, outfile=cand, adaptor=ADAPTOR, rep_seq_number=0, distance=4,
                             size="150,1200", position=4, fraction=0.7, diff_Tm=4, core=app if deep else None,
                             library=library, device=device)
-        pf.run()
+        try:
+            pf.run()
+        except SystemExit:              # an empty primer file: the reference's pairing step exits 1 there too and writes nothing
+            pass
     if timings is not None:
         timings["pairing_s"] += time.time() - t0
         for key, val in pf.stats.items():
@@ -130,11 +133,11 @@ def chain_files(wd):
     return out
 
 
-def run_chain(wd, fastas, library=None, device=0, deep_rows=DEEP_ROWS):
+def run_chain(wd, fastas, library=None, device=0, deep_rows=DEEP_ROWS, primer_length=18):
     """The whole chain over {cluster name: (FASTA path, rows)} into wd; returns chain_files(wd)."""
     os.makedirs(wd, exist_ok=True)
     for name, (fa, rows) in fastas.items():
-        cluster_stage(fa, wd, name, library=library, device=device, deep=rows > deep_rows)
+        cluster_stage(fa, wd, name, library=library, device=device, deep=rows > deep_rows, primer_length=primer_length)
     tail_stage(wd, list(fastas), library=library, device=device)
     return chain_files(wd)
 

@@ -25,7 +25,7 @@ ENVS = [{}, {"MP_EVAL_GROUP": "plain"}, {"MP_EVAL_GROUP": "nested"}, {"MP_EVAL_B
         {"MP_EVAL_PROG": "1", "MP_EVAL_CHAIN": "7"}, {"MP_EVAL_PROG": "1", "MP_EVAL_CHAIN": "3"},
         {"MP_EVAL_PROG": "1", "MP_EVAL_CHAIN": "11"}, {"MP_EVAL_PROG": "1", "MP_EVAL_CHAIN": "10"}, {"MP_EVAL_PROG": "1", "MP_EVAL_CHAIN": "12"},
         {"MP_HIST_LDS": "4096"}]
-KEYS = sorted({k for e in ENVS for k in e})
+KEYS = sorted({k for e in ENVS for k in e} | {"MP_EVAL_GENERIC_V"})
 
 
 def main():
@@ -40,7 +40,7 @@ def main():
     n_cases = n_short = n_cand_total = 0
     while time.time() < t_end:
         n = int(rng.choice([1, 7, 63, 64, 65, 200, 257, 1000, 2049, 5000, 9000, 17000, 33000, 70000]))
-        k = int(rng.integers(2, 29))
+        k = int(rng.integers(2, 32)) if rng.random() < 0.7 else int(rng.integers(32, 64))      # 32..63: 64-bit window words, row-per-lane kernels only
         v = int(rng.integers(0, min(4, k)))
         L = int(rng.integers(k + 8, 3 * k + 80))
         p0 = int(rng.integers(0, 6))
@@ -93,7 +93,7 @@ def main():
             sF = int(rng.integers(0, 1 << k))
             sR = int(rng.integers(0, 1 << k))
             want = ctxs[1].eval_candidates(cw, codes, sF, sR)
-            for env in ENVS:
+            for env in (ENVS if k <= 31 else [{}, {"MP_EVAL_GENERIC_V": "1"}]):
                 for key in KEYS:
                     os.environ.pop(key, None)
                 os.environ.update(env)
