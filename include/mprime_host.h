@@ -92,6 +92,14 @@ int mp_plan_create(const mp_plan_params *params, int64_t n_entries, const int32_
 int mp_plan_create_segments(const mp_plan_params *params, const int64_t *e_off, const void *e_words, const int32_t *e_count,
                             const int32_t *e_first, int64_t row_base, int64_t n_exc, const int32_t *x_window, const int64_t *x_row,
                             const uint8_t *x_codes, const int64_t *freq, const int64_t *nn, mp_plan **out);
+/* The same straight from a context whose mp_window_unique has run (one rank, no JSON side files): the histogram entries are read
+ * back in bands of windows while the planning threads already work on the bands that have arrived, instead of one blocking
+ * mp_get_unique followed by mp_plan_create_segments — at 131072 x 1000 the read-back (58 MB) and the planning take about as long as each
+ * other.  *n_entries returns the number of entries.  The plan is the same object, bit for bit (tests compare the two routes). */
+struct mp_ctx;
+int mp_plan_create_streamed(struct mp_ctx *ctx, const mp_plan_params *params, int64_t row_base, int64_t n_exc, const int32_t *x_window,
+                            const int64_t *x_row, const uint8_t *x_codes, const int64_t *freq, const int64_t *nn, int64_t *n_entries,
+                            mp_plan **out);
 void mp_plan_destroy(mp_plan *p);
 const char *mp_plan_error(const mp_plan *p);
 

@@ -235,6 +235,17 @@ class Context:
         self._off = off
         return off, words[:, order], count[order], first[order]
 
+    def window_unique_device(self, cap_entries: int | None = None) -> int:
+        """The histograms only (mp_window_unique without labels): the entries stay on the device for host.Plan(device_context=...),
+        which reads them back beside the planning.  Returns their number."""
+        cap = cap_entries or max(1 << 16, min(self.n_rows * self.n_win, 1 << 24))
+        n = C.c_int64(0)
+        rc = self.d.mp_window_unique(self.h, cap, 0, C.byref(n))
+        if rc == MP_ERR_CAPACITY:
+            rc = self.d.mp_window_unique(self.h, int(n.value), 0, C.byref(n))
+        self._ck(rc)
+        return int(n.value)
+
     def get_labels(self, w: int) -> np.ndarray:
         lab = np.empty(self.n_rows, np.int32)
         self._ck(self.d.mp_get_labels(self.h, w, _ptr(lab)))

@@ -204,10 +204,26 @@ class NN_degenerate(object):
         # (the Python JSON writer of the row-sharded path wants them sorted by first row; the native writer takes them as they come)
         # MP_JSON_WRITER=python keeps the Python writer in a single process too (tests compare the two byte for byte)
         self._native_json = self.write_json and self.comm is None and os.environ.get("MP_JSON_WRITER", "native") != "python"
+        # one rank without JSON side files on the HIP library: the entries never come to Python — the planning stage reads them back
+        # in bands of windows beside its own work (mp_plan_create_streamed; MP_PLAN_STREAM=0 keeps the two blocking calls)
+        streamed = (self.comm is None and not self.write_json and self.lib.backend == "hip" and os.environ.get("MP_PLAN_STREAM", "1") != "0")
+        x_row = ex_r.astype(np.int64) + row_base
+        if streamed:
+            self.ctx.window_unique_device()
+            self.stats["unique_s"] = time.time() - t0
+            t0 = time.time()
+            self._exc = (ex_w, x_row, ex_codes)
+            self._win_split = False
+            self._dev_entries = None
+            plan = host.Plan(k=k, v=v, n_windows=W, total_sequences=self.total_sequence_number, coverage=self.coverage,
+                             entropy_threshold=self.entropy_threshold, max_degeneracy=self.score_of_dege_bases,
+                             max_dege_positions=self.number_of_dege_bases, row_base=row_base, x_window=ex_w, x_row=x_row, x_codes=ex_codes,
+                             freq=self._freq, nn=self._nn, keep_tables=keep, device_context=self.ctx)
+            self.stats["plan_s"] = time.time() - t0
+            return plan
         off, words, count, first = self.ctx.window_unique(want_labels=self.write_json, sort=self.write_json and not self._native_json)
         self.stats["unique_s"] = time.time() - t0
         t0 = time.time()
-        x_row = ex_r.astype(np.int64) + row_base
         self._dev_entries = (off, words)
         if self.comm is None:
             # one rank: the read-back goes to the planning stage as it stands (window segments, 32-bit counts and first rows)

@@ -19,6 +19,7 @@
 #define mp_plan_destroy mp_plan_destroy_w64
 #define mp_plan_create mp_plan_create_w64
 #define mp_plan_create_segments mp_plan_create_segments_w64
+#define mp_plan_create_segments_ready mp_plan_create_segments_ready_w64
 #define mp_plan_windows mp_plan_windows_w64
 #define mp_plan_sizes mp_plan_sizes_w64
 #define mp_plan_candidates mp_plan_candidates_w64
@@ -34,6 +35,7 @@
 #endif
 #include "../../include/mprime.h"
 #include "../../include/mprime_host.h"
+#include "planstream.hpp"
 
 #include <algorithm>
 #include <atomic>
@@ -268,6 +270,9 @@ int mp_plan_create_w64(const mp_plan_params *params, int64_t n_entries, const in
 int mp_plan_create_segments_w64(const mp_plan_params *params, const int64_t *e_off, const void *e_words, const int32_t *e_count,
                                 const int32_t *e_first, int64_t row_base, int64_t n_exc, const int32_t *x_window, const int64_t *x_row,
                                 const uint8_t *x_codes, const int64_t *freq, const int64_t *nn, mp_plan_w64 **out);
+int mp_plan_create_segments_ready_w64(const mp_plan_params *params, const int64_t *e_off, const void *e_words, const int32_t *e_count,
+                                      const int32_t *e_first, int64_t row_base, int64_t n_exc, const int32_t *x_window, const int64_t *x_row,
+                                      const uint8_t *x_codes, const int64_t *freq, const int64_t *nn, const void *ready, mp_plan_w64 **out);
 int mp_plan_windows_w64(const mp_plan_w64 *p, int32_t *status, int64_t *cover_number, int64_t *gap_number, double *cbit, double *tbit);
 int mp_plan_sizes_w64(const mp_plan_w64 *p, int32_t *n_planned, int64_t *n_candidates);
 int mp_plan_candidates_w64(const mp_plan_w64 *p, int32_t *cand_window, uint8_t *cand_codes);
@@ -618,6 +623,7 @@ struct EntryInput {
     const int64_t *count64, *first64;
     const int32_t *count32, *first32;
     int64_t row_base;
+    mp_ready_gate *ready;                     // null, or: the entries of windows below the gate have arrived (mp_plan_create_streamed)
     int64_t count(int64_t i) const { return count64 ? count64[i] : (int64_t)count32[i]; }
     int64_t first(int64_t i) const { return first64 ? first64[i] : (int64_t)first32[i] + row_base; }
 };
@@ -649,21 +655,29 @@ int mp_plan_create(const mp_plan_params *params, int64_t n_entries, const int32_
         return mp_plan_create_w64(params, n_entries, e_window, e_words, e_count, e_first, n_exc, x_window, x_row, x_codes, freq, nn, (mp_plan_w64 **)out);
 #endif
     if (n_entries < 0 || (n_entries && (!e_window || !e_words || !e_count || !e_first))) return MP_ERR_ARG;
-    const EntryInput E{n_entries, e_window, nullptr, e_words, e_count, e_first, nullptr, nullptr, 0};
+    const EntryInput E{n_entries, e_window, nullptr, e_words, e_count, e_first, nullptr, nullptr, 0, nullptr};
     return plan_create_guarded(params, E, n_exc, x_window, x_row, x_codes, freq, nn, out);
 }
 
 int mp_plan_create_segments(const mp_plan_params *params, const int64_t *e_off, const void *e_words, const int32_t *e_count,
                             const int32_t *e_first, int64_t row_base, int64_t n_exc, const int32_t *x_window, const int64_t *x_row,
                             const uint8_t *x_codes, const int64_t *freq, const int64_t *nn, mp_plan **out) {
+    return mp_plan_create_segments_ready(params, e_off, e_words, e_count, e_first, row_base, n_exc, x_window, x_row, x_codes, freq, nn, nullptr, out);
+}
+
+// planstream.hpp: the same with the entries still arriving — windows below the gate `ready` (an mp_ready_gate) are complete
+int mp_plan_create_segments_ready(const mp_plan_params *params, const int64_t *e_off, const void *e_words, const int32_t *e_count,
+                                  const int32_t *e_first, int64_t row_base, int64_t n_exc, const int32_t *x_window, const int64_t *x_row,
+                                  const uint8_t *x_codes, const int64_t *freq, const int64_t *nn, const void *ready, mp_plan **out) {
 #if !MP_PLAN_WIDE
     if (params && params->k > kMaxK)
-        return mp_plan_create_segments_w64(params, e_off, e_words, e_count, e_first, row_base, n_exc, x_window, x_row, x_codes, freq, nn, (mp_plan_w64 **)out);
+        return mp_plan_create_segments_ready_w64(params, e_off, e_words, e_count, e_first, row_base, n_exc, x_window, x_row, x_codes, freq, nn, ready,
+                                                 (mp_plan_w64 **)out);
 #endif
     if (!params || !e_off || params->n_windows < 0) return MP_ERR_ARG;
     const int64_t n = e_off[params->n_windows];
     if (n < 0 || (n && (!e_words || !e_count || !e_first))) return MP_ERR_ARG;
-    const EntryInput E{n, nullptr, e_off, e_words, nullptr, nullptr, e_count, e_first, row_base};
+    const EntryInput E{n, nullptr, e_off, e_words, nullptr, nullptr, e_count, e_first, row_base, static_cast<mp_ready_gate *>(const_cast<void *>(ready))};
     return plan_create_guarded(params, E, n_exc, x_window, x_row, x_codes, freq, nn, out);
 }
 
@@ -715,6 +729,7 @@ static int plan_create_body(mp_plan *p, const EntryInput &E, int64_t n_exc, cons
         for (;;) {
             int w = next.fetch_add(1);
             if (w >= W || failed.load()) break;
+            if (E.ready) E.ready->wait_for(w); // streamed read-back: this window's entries may still be on their way
             sights.clear();
             for (int64_t t = eoff[(size_t)w]; t < eoff[(size_t)w + 1]; t++) {
                 const int64_t i = e_sorted ? t : eidx[(size_t)t];

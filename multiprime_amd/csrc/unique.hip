@@ -12,7 +12,12 @@
 //   10^6 rows.)
 // k >= 22 — unique_kernel: one workgroup per window, LDS table of representative rows; keys are compared by
 //   re-deriving the representative's k-mer.  Same algorithm as round 1, minus the stored window words.
+#include <atomic>
+#include <memory>
+#include <thread>
+
 #include "common.hpp"
+#include "planstream.hpp"
 #include "winwords.hpp"
 
 using namespace mp;
@@ -773,6 +778,80 @@ int mp_get_unique(mp_ctx *c, int64_t *win_off, void *words_out, int32_t *count, 
     }
     win_off[W] = o;
     return MP_OK;
+}
+
+// mprime_host.h: the planning stage fed band by band while the entries come off the device
+int mp_plan_create_streamed(mp_ctx *c, const mp_plan_params *params, int64_t row_base, int64_t n_exc, const int32_t *x_window,
+                            const int64_t *x_row, const uint8_t *x_codes, const int64_t *freq, const int64_t *nn, int64_t *n_entries,
+                            mp_plan **out) {
+    if (!c || !params || !out) return MP_ERR_ARG;
+    *out = nullptr;
+    if (c->h_wbase.empty()) return fail(c, MP_ERR_ARG, "mp_window_unique has not run");
+    if (params->n_windows != c->n_win || params->k != c->k) return fail(c, MP_ERR_ARG, "mp_plan_create_streamed: the parameters are not this context's windows");
+    HIPCK(c, hipSetDevice(c->dev));
+    const size_t n = (size_t)c->u_n, W = (size_t)c->n_win, wb = 4 * wsz(c);
+    if (n_entries) *n_entries = (int64_t)n;
+    std::vector<int64_t> e_off(W + 1);
+    bool in_order = true;
+    {
+        int64_t o = 0;
+        for (size_t w = 0; w < W; w++) { e_off[w] = o; if (c->h_wbase[w] != o) in_order = false; o += c->h_wcount[w]; }
+        e_off[W] = o;
+    }
+    // host buffers nobody has touched yet: their pages are faulted in by the copies, beside the planning
+    std::unique_ptr<uint8_t[]> words(new (std::nothrow) uint8_t[3 * wb * (n + 1)]);
+    std::unique_ptr<int32_t[]> count(new (std::nothrow) int32_t[n + 1]), first(new (std::nothrow) int32_t[n + 1]);
+    if (!words || !count || !first) return fail(c, MP_ERR_NOMEM, "mp_plan_create_streamed: out of host memory");
+    if (!in_order) {
+        // the k >= 22 histograms reserve their segments in completion order: one blocking read-back that lays them out by window
+        int rc = mp_get_unique(c, e_off.data(), words.get(), count.get(), first.get());
+        if (rc) return rc;
+        return mp_plan_create_segments(params, e_off.data(), words.get(), count.get(), first.get(), row_base, n_exc, x_window, x_row, x_codes, freq, nn, out);
+    }
+    mp_ready_gate ready;
+    std::atomic<int> copy_error{0};
+    const bool trace = getenv("MP_TRACE") != nullptr;
+    const auto t_start = std::chrono::steady_clock::now();
+    auto ms_since = [&]() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_start).count(); };
+    std::thread copier([&]() {
+        hipError_t e = hipSetDevice(c->dev);
+        // bands of whole windows, about 1/24 of the entries each (the first ones smaller, so that the planners start early)
+        const size_t target = std::max<size_t>(n / 24, 4096);
+        size_t w0 = 0;
+        int band = 0;
+        while (w0 < W) {
+            size_t w1 = w0 + 1;
+            const size_t want = band < 2 ? target / 4 : target;
+            while (w1 < W && (size_t)(e_off[w1] - e_off[w0]) < want) w1++;
+            const size_t a = (size_t)e_off[w0], m = (size_t)(e_off[w1] - e_off[w0]);
+            if (m && e == hipSuccess) {
+                e = hipMemcpyAsync(words.get() + wb * a, reinterpret_cast<const uint8_t *>(c->u_b0) + wb * a, wb * m, hipMemcpyDeviceToHost, c->stream);
+                if (e == hipSuccess) e = hipMemcpyAsync(words.get() + wb * (n + a), reinterpret_cast<const uint8_t *>(c->u_b1) + wb * a, wb * m, hipMemcpyDeviceToHost, c->stream);
+                if (e == hipSuccess) e = hipMemcpyAsync(words.get() + wb * (2 * n + a), reinterpret_cast<const uint8_t *>(c->u_g) + wb * a, wb * m, hipMemcpyDeviceToHost, c->stream);
+                if (e == hipSuccess) e = hipMemcpyAsync(count.get() + a, c->u_count + a, 4 * m, hipMemcpyDeviceToHost, c->stream);
+                if (e == hipSuccess) e = hipMemcpyAsync(first.get() + a, c->u_first + a, 4 * m, hipMemcpyDeviceToHost, c->stream);
+                if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+            }
+            if (e != hipSuccess) {                       // the planners must not wait for ever: hand them zeroed entries, the result is thrown away
+                copy_error.store((int)e);
+                memset(words.get() + wb * a, 0, wb * m); memset(words.get() + wb * (n + a), 0, wb * m); memset(words.get() + wb * (2 * n + a), 0, wb * m);
+                for (size_t i = a; i < a + m; i++) { count[i] = 1; first[i] = 0; }
+            }
+            ready.raise((int)w1);
+            if (trace && (band < 3 || w1 == W)) fprintf(stderr, "[mprime] plan_streamed: band %d (windows < %zu) there at %.3f ms\n", band, w1, ms_since());
+            w0 = w1;
+            band++;
+        }
+    });
+    int rc = mp_plan_create_segments_ready(params, e_off.data(), words.get(), count.get(), first.get(), row_base, n_exc, x_window, x_row, x_codes, freq, nn,
+                                           &ready, out);
+    if (trace) fprintf(stderr, "[mprime] plan_streamed: planning done at %.3f ms\n", ms_since());
+    copier.join();
+    if (copy_error.load()) {
+        if (*out) { mp_plan_destroy(*out); *out = nullptr; }
+        return fail(c, MP_ERR_DEVICE, "mp_plan_create_streamed: %s", hipGetErrorString((hipError_t)copy_error.load()));
+    }
+    return rc;
 }
 
 int mp_get_labels(mp_ctx *c, int32_t w, int32_t *labels) {

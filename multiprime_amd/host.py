@@ -33,6 +33,7 @@ HOST_SYMBOLS = [
     ("mp_file_count_newlines", C.c_int, [C.c_char_p, C.c_int32, C.POINTER(C.c_int64)]),
     ("mp_plan_create", C.c_int, [C.POINTER(PlanParams), C.c_int64, _p, _p, _p, _p, C.c_int64, _p, _p, _p, _p, _p, C.POINTER(_p)]),
     ("mp_plan_create_segments", C.c_int, [C.POINTER(PlanParams), _p, _p, _p, _p, C.c_int64, C.c_int64, _p, _p, _p, _p, _p, C.POINTER(_p)]),
+    ("mp_plan_create_streamed", C.c_int, [_p, C.POINTER(PlanParams), C.c_int64, C.c_int64, _p, _p, _p, _p, _p, C.POINTER(C.c_int64), C.POINTER(_p)]),
     ("mp_plan_destroy", None, [_p]),
     ("mp_plan_error", C.c_char_p, [_p]),
     ("mp_plan_windows", C.c_int, [_p, _p, _p, _p, _p, _p]),
@@ -194,17 +195,22 @@ class Plan:
     """Per-window planning of one alignment (mp_plan_*)."""
 
     def __init__(self, *, k, v, n_windows, total_sequences, coverage, entropy_threshold, max_degeneracy, max_dege_positions,
-                 e_window=None, e_words, e_count, e_first, x_window, x_row, x_codes, freq, nn, keep_tables=False, n_threads=0,
-                 e_off=None, row_base=0):
+                 e_window=None, e_words=None, e_count=None, e_first=None, x_window, x_row, x_codes, freq, nn, keep_tables=False, n_threads=0,
+                 e_off=None, row_base=0, device_context=None):
         """Entries either with a window per entry (`e_window`, any order: several ranks' tables concatenated; counts and GLOBAL first
         rows as int64) or as ONE rank's read-back as it stands: `e_off` [W+1] window segments, int32 counts and LOCAL first rows plus
-        `row_base` (mp_plan_create_segments: no per-entry window array, no widening copies)."""
+        `row_base` (mp_plan_create_segments: no per-entry window array, no widening copies) — or, with `device_context` (a HIP context
+        whose window_unique has run, ctx.window_unique_device()), not at all: mp_plan_create_streamed reads them back in bands beside the
+        planning."""
         self.d = dll()
         self.k, self.W = int(k), int(n_windows)
         P = PlanParams(int(k), int(v), int(n_windows), int(n_threads), int(total_sequences), float(coverage), float(entropy_threshold),
                        float(max_degeneracy), int(max_dege_positions), int(bool(keep_tables)))
         segments = e_off is not None
-        if segments:
+        streamed = device_context is not None
+        if streamed:
+            n = 0
+        elif segments:
             e_off = np.ascontiguousarray(e_off, dtype=np.int64)
             assert len(e_off) == self.W + 1
             n = int(e_off[-1])
@@ -215,8 +221,9 @@ class Plan:
             n = len(e_window)
             e_count = np.ascontiguousarray(e_count, dtype=np.int64)
             e_first = np.ascontiguousarray(e_first, dtype=np.int64)
-        e_words = np.ascontiguousarray(e_words, dtype=np.uint32 if self.k <= 31 else np.uint64).reshape(3, n)
-        assert len(e_count) == n and len(e_first) == n
+        if not streamed:
+            e_words = np.ascontiguousarray(e_words, dtype=np.uint32 if self.k <= 31 else np.uint64).reshape(3, n)
+            assert len(e_count) == n and len(e_first) == n
         x_window = np.ascontiguousarray(x_window, dtype=np.int32)
         x_row = np.ascontiguousarray(x_row, dtype=np.int64)
         x_codes = np.ascontiguousarray(x_codes, dtype=np.uint8).reshape(len(x_window), self.k)
@@ -224,7 +231,12 @@ class Plan:
         nn = np.ascontiguousarray(nn, dtype=np.int64)
         assert freq.shape == (self.W, 4, self.k) and nn.shape == (self.W, self.k - 1, 4, 4)
         h = _p()
-        if segments:
+        if streamed:
+            ne = C.c_int64(0)
+            rc = self.d.mp_plan_create_streamed(device_context.h, C.byref(P), int(row_base), len(x_window), _ptr(x_window), _ptr(x_row), _ptr(x_codes),
+                                                _ptr(freq), _ptr(nn), C.byref(ne), C.byref(h))
+            self.n_entries = ne.value
+        elif segments:
             rc = self.d.mp_plan_create_segments(C.byref(P), _ptr(e_off), _ptr(e_words), _ptr(e_count), _ptr(e_first), int(row_base), len(x_window),
                                                 _ptr(x_window), _ptr(x_row), _ptr(x_codes), _ptr(freq), _ptr(nn), C.byref(h))
         else:

@@ -78,6 +78,29 @@ def test_hip_path_matches_reference(name, hip_lib, tmp_path):
     check_outputs(name, out)
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", ["syn_iupac", "syn_ragged", "syn_edge", "ivc_v2", "msa1000_k18_d64", "msa1000_k22_d64", "msa1000_k31_d64", "cluster0_v2", "testfa",
+                                  "syn_ragged_k40", "ivc_k45_v2", "syn_edge_k63"])
+def test_streamed_planning_equals_blocking_read_back(name, hip_lib, tmp_path, monkeypatch):
+    """Without JSON side files a single process plans straight from the device (mp_plan_create_streamed: histogram entries read back in
+    bands beside the planning threads; packed keys and the k >= 22 / 64-bit word tables alike).  Same TSV as the reference, and the
+    same plan tables as the two blocking calls (MP_PLAN_STREAM=0), window by window."""
+    want = open(os.path.join(GOLDEN, name + ".tsv"), "rb").read()
+    plans = {}
+    for mode in ("1", "0"):
+        monkeypatch.setenv("MP_PLAN_STREAM", mode)
+        d = tmp_path / mode
+        d.mkdir()
+        app, out = run_fixture(name, hip_lib, d, write_json=False)
+        assert out.read_bytes() == want, f"TSV differs from the reference's with MP_PLAN_STREAM={mode}"
+        assert (app._dev_entries is None) == (mode == "1")
+        st, cn, gn, cb, tb = app.plan.windows()
+        plans[mode] = (st.tolist(), cn.tolist(), gn.tolist(), [repr(x) for x in cb.tolist()], [repr(x) for x in tb.tolist()],
+                       [a.tolist() for a in app.plan.candidates()])
+        app.ctx.close()
+    assert plans["1"] == plans["0"]
+
+
 def _side_bytes(out):
     return (open(str(out) + ".non_coverage_seq_id_json", "rb").read(), open(str(out) + ".gap_seq_id_json", "rb").read())
 

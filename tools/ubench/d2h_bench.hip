@@ -1,0 +1,51 @@
+// d2h_bench.hip — how fast do 58 MB come off the device into host memory of different kinds?  (tools/ubench: measurements behind
+// mp_plan_create_streamed's choice of buffer; hipcc --offload-arch=gfx950 -O2 d2h_bench.hip -o d2h_bench)
+#include <hip/hip_runtime.h>
+#include <sys/mman.h>
+#include <chrono>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+static double now() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
+int main() {
+    const size_t n = 58u << 20;
+    void *d = nullptr;
+    hipMalloc(&d, n);
+    hipMemset(d, 1, n);
+    hipDeviceSynchronize();
+    { void *w = malloc(1 << 20); hipMemcpy(w, d, 1 << 20, hipMemcpyDeviceToHost); free(w); }      // runtime warm-up
+    for (int rep = 0; rep < 2; rep++) {
+        double t0 = now();
+        void *p = malloc(n);
+        hipMemcpy(p, d, n, hipMemcpyDeviceToHost);
+        printf("fresh malloc:            %.2f ms\n", now() - t0);
+        t0 = now();
+        hipMemcpy(p, d, n, hipMemcpyDeviceToHost);
+        printf("touched malloc:          %.2f ms\n", now() - t0);
+        free(p);
+        t0 = now();
+        void *m = mmap(nullptr, n, PROT_READ | PROT_WRITE, MAP_PRIVATE | MAP_ANONYMOUS, -1, 0);
+        madvise(m, n, MADV_HUGEPAGE);
+        hipMemcpy(m, d, n, hipMemcpyDeviceToHost);
+        printf("fresh mmap + hugepage:   %.2f ms\n", now() - t0);
+        munmap(m, n);
+        t0 = now();
+        m = mmap(nullptr, n, PROT_READ | PROT_WRITE, MAP_PRIVATE | MAP_ANONYMOUS | MAP_POPULATE, -1, 0);
+        double t1 = now();
+        hipMemcpy(m, d, n, hipMemcpyDeviceToHost);
+        printf("mmap populate:           %.2f ms populate + %.2f ms copy\n", t1 - t0, now() - t1);
+        munmap(m, n);
+        t0 = now();
+        void *h = nullptr;
+        hipHostMalloc(&h, n, hipHostMallocDefault);
+        t1 = now();
+        hipMemcpy(h, d, n, hipMemcpyDeviceToHost);
+        double t2 = now();
+        hipMemcpy(h, d, n, hipMemcpyDeviceToHost);
+        printf("hipHostMalloc:           %.2f ms alloc + %.2f ms copy (again: %.2f ms)\n", t1 - t0, t2 - t1, now() - t2);
+        t0 = now();
+        hipHostFree(h);
+        printf("hipHostFree:             %.2f ms\n", now() - t0);
+    }
+    return 0;
+}
