@@ -1,5 +1,8 @@
 // api.hip — part of libmprime_hip.so: hand-written HIP (gfx950 / MI355X, wave64) behind the C ABI of
 // include/mprime.h.  Context lifetime and bookkeeping.
+#include <sys/mman.h>
+
+#include <thread>
 #include <vector>
 
 #include "common.hpp"
@@ -35,6 +38,31 @@ int fill_segments(mp_ctx *c, const FillSeg *segs, int n) {
     hipLaunchKernelGGL(fill_kernel, dim3(blocks), dim3(kBlock), 0, c->stream, A);
     HIPCK(c, hipGetLastError());
     return MP_OK;
+}
+
+void *host_map(size_t bytes) {
+    void *p = mmap(nullptr, bytes, PROT_READ | PROT_WRITE, MAP_PRIVATE | MAP_ANONYMOUS, -1, 0);
+    if (p == MAP_FAILED) return nullptr;
+    (void)madvise(p, bytes, MADV_HUGEPAGE);
+    return p;
+}
+void host_unmap(void *p, size_t bytes) { if (p) (void)munmap(p, bytes); }
+
+void prefault_host(void *p, size_t bytes) {
+    constexpr size_t kPage = 4096, kMin = (size_t)4 << 20;
+    if (!p || bytes < kMin || getenv("MP_NO_PREFAULT")) return;
+    unsigned hw = std::thread::hardware_concurrency();
+    const size_t n_thr = std::max<size_t>(1, std::min<size_t>({(size_t)16, (size_t)(hw ? hw : 1), bytes / ((size_t)2 << 20)}));
+    uint8_t *b = static_cast<uint8_t *>(p);
+    auto touch = [=](size_t t) {
+        const size_t lo = bytes * t / n_thr, hi = bytes * (t + 1) / n_thr;
+        for (size_t o = (lo + kPage - 1) / kPage * kPage; o < hi; o += kPage) *reinterpret_cast<volatile uint8_t *>(b + o) = 0;
+        if (lo < hi) *reinterpret_cast<volatile uint8_t *>(b + lo) = 0;
+    };
+    std::vector<std::thread> th;
+    for (size_t t = 1; t < n_thr; t++) th.emplace_back(touch, t);
+    touch(0);
+    for (auto &x : th) x.join();
 }
 
 void free_eval(mp_ctx *c) {
@@ -151,6 +179,7 @@ void mp_destroy(mp_ctx *c) {
     free_comm(c);
     free_msa(c);
     dev_free(c, &c->tmp_out, (size_t)c->tmp_out_n);
+    host_unmap(c->h_stage, c->h_stage_bytes);
     dev_free(c, &c->dm_loss, (size_t)(MP_DIMER_MAX_LEN + 1) * (MP_DIMER_MAX_LEN + 1) * 64);
     dev_free(c, &c->dm_dg, (size_t)(16 + 32 + MP_DIMER_MAX_LEN + 1 + 1));
     for (auto &p : c->ev_busy) { (void)hipEventDestroy(p.first); (void)hipEventDestroy(p.second); }

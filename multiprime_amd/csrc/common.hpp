@@ -205,6 +205,10 @@ struct mp_ctx {
     std::vector<float> ev_samples, ev_last;     // per-launch durations since the last reset / as of the last mp_eval_timing call
     int ev_n = 0;
     int eval_variant = 0;
+    // host staging area of the streamed planning (mp_plan_create_streamed): kept for the context's life — handing 58 MB back to the
+    // kernel and faulting them in again costs more than the copy that fills them
+    uint8_t *h_stage = nullptr;              // host_map() memory
+    size_t h_stage_bytes = 0;
     // row-shard collectives (comm.hip): an RCCL communicator (ncclComm_t) when n_ranks > 1
     void *comm = nullptr;
     int n_ranks = 0, rank = 0;               // n_ranks 0: mp_comm_init has not run
@@ -255,6 +259,16 @@ void dev_free(mp_ctx *c, T **p, size_t n) {
 struct FillSeg { void *p; size_t bytes; uint32_t value; };
 constexpr int kMaxFillSegs = 8;
 int fill_segments(mp_ctx *c, const FillSeg *segs, int n);
+
+// A host buffer that is about to receive a large copy from the device and has never been touched: its pages are faulted in here on
+// several threads (one write per page; the contents are about to be overwritten).  58 MB come off the device in 1.1 ms once the pages
+// exist and in 4.7-6.7 ms when the copy itself has to fault them in one after the other (tools/ubench/d2h_bench.hip) — that, not the
+// transfer, was the read-back time of the histogram entries.  api.hip
+void prefault_host(void *p, size_t bytes);
+// anonymous host memory marked for transparent huge pages (what numpy does for its large arrays): 2 MB faults instead of 4 KB ones —
+// 66 MB are faulted in on 16 threads in ~1.3 ms with it and in ~4.7 ms without.  host_unmap releases it.  api.hip
+void *host_map(size_t bytes);
+void host_unmap(void *p, size_t bytes);
 
 // release the device arrays of one stage (and of every stage that depends on it); api.hip
 void free_eval(mp_ctx *c);

@@ -482,12 +482,24 @@ struct Sight {                 // one sighting of a k-mer inside a window, befor
     int32_t sub, ngap;
 };
 
-// cover / gap_sequence of one window in the reference's dict insertion order (V20:689-711): a key takes the place of
-// its earliest sighting (row, then expansion index inside that row); counts add up.
-void build_tables(Window &w, std::vector<Sight> &sights, int v, int64_t n_exc_cover, int64_t n_exp) {
-    std::vector<Entry> all;
-    all.reserve(sights.size());
+// what a planning thread keeps from window to window: the sightings, the merged table and its map (a deep window's are hundreds of
+// kilobytes — allocated afresh they went through mmap / munmap once per window and thread, and the page faults of 32 threads in one
+// address space were most of the stage's time at 131072 x 1000)
+struct Scratch {
+    std::vector<Sight> sights;
+    std::vector<Entry> all;               // merged, in insertion order
     KeyMap map;
+};
+
+// cover / gap_sequence of one window in the reference's dict insertion order (V20:689-711): a key takes the place of
+// its earliest sighting (row, then expansion index inside that row); counts add up.  The merged table stays in the scratch area
+// (cover entries: ngap <= v, gap entries: the others, both in insertion order); materialize() copies it into the window.
+void build_tables(Window &w, Scratch &S, int v, int64_t n_exc_cover, int64_t n_exp, size_t &n_cover) {
+    std::vector<Sight> &sights = S.sights;
+    std::vector<Entry> &all = S.all;
+    all.clear();
+    all.reserve(sights.size());
+    KeyMap &map = S.map;
     map.reset(sights.size());
     for (const Sight &s : sights) {
         int32_t at = map.find_or_insert(s.key, all, (int32_t)all.size());
@@ -502,12 +514,23 @@ void build_tables(Window &w, std::vector<Sight> &sights, int v, int64_t n_exc_co
         return a.first_row != b.first_row ? a.first_row < b.first_row : a.first_sub < b.first_sub;
     });
     int64_t csum = 0, gsum = 0;
+    n_cover = 0;
     for (const Entry &e : all) {
-        if (e.ngap > v) { w.gap.push_back(e); gsum += e.count; }
-        else { w.cover.push_back(e); csum += e.count; }
+        if (e.ngap > v) gsum += e.count;
+        else { csum += e.count; n_cover++; }
     }
     w.gap_number = gsum;
     w.cover_number = csum - n_exp + n_exc_cover;      // cover_number counts sequences (V20:702), cover counts expansions
+}
+
+// the window's own copies of the tables: `cover` for every window that is planned, both when the caller keeps the tables
+void materialize(Window &w, const Scratch &S, int v, size_t n_cover, bool want_gap) {
+    w.cover.reserve(n_cover);
+    if (want_gap) w.gap.reserve(S.all.size() - n_cover);
+    for (const Entry &e : S.all) {
+        if (e.ngap > v) { if (want_gap) w.gap.push_back(e); }
+        else w.cover.push_back(e);
+    }
 }
 
 // look-ups into `cover` (perfect coverage of a candidate's expansions, nonsense count): only windows past the gates need them
@@ -516,16 +539,18 @@ void build_cover_map(Window &w) {
     for (size_t i = 0; i < w.cover.size(); i++) w.cover_map.find_or_insert(w.cover[i].key, w.cover, (int32_t)i);
 }
 
-// entropy (V20:602-614), same summation order
-void entropy(Window &w) {
+// entropy (V20:602-614), same summation order: the cover entries in insertion order, then the gap entries
+void entropy(Window &w, const std::vector<Entry> &all, int v) {
     const int64_t cn = w.cover_number, gn = w.gap_number, tot = cn + gn;
     double cbit = 0, tbit = 0;
-    for (const Entry &e : w.cover) {
+    for (const Entry &e : all) {
+        if (e.ngap > v) continue;
         double pc = (double)e.count / (double)cn, pt = (double)e.count / (double)tot;
         cbit += pc * py_log2(pc);
         tbit += pt * py_log2(pt);
     }
-    for (const Entry &e : w.gap) {
+    for (const Entry &e : all) {
+        if (e.ngap <= v) continue;
         double pt = (double)e.count / (double)tot;
         tbit += pt * py_log2(pt);
     }
@@ -533,26 +558,34 @@ void entropy(Window &w) {
     w.tbit = py_round2(-tbit);
 }
 
-int plan_window(mp_plan *p, int wi, std::vector<Sight> &sights, int64_t n_exc_cover, int64_t n_exp, const int64_t *freq,
+int plan_window(mp_plan *p, int wi, Scratch &S, int64_t n_exc_cover, int64_t n_exp, const int64_t *freq,
                 const int64_t *nn) {
     const mp_plan_params &P = p->P;
     const int k = P.k;
     Window &w = p->win[(size_t)wi];
-    build_tables(w, sights, P.v, n_exc_cover, n_exp);
+    size_t n_cover = 0;
+    build_tables(w, S, P.v, n_exc_cover, n_exp, n_cover);
+    // a window that stops at a gate keeps its tables only when the caller asked for them (JSON side files, mp_plan_window_table)
+    auto stop = [&](int32_t status) {
+        w.status = status;
+        if (P.keep_tables) materialize(w, S, P.v, n_cover, true);
+        return MP_OK;
+    };
     // gates (V20:713-740)
-    if (py_round2((double)w.gap_number / (double)P.total_sequences) >= (1 - P.coverage)) { w.status = MP_WIN_GAP_GATE; return MP_OK; }
-    if (w.cover.empty()) { w.status = MP_WIN_NO_COVER; return MP_OK; }
-    entropy(w);
-    if (w.tbit > P.entropy_threshold) { w.status = MP_WIN_ENTROPY; return MP_OK; }
+    if (py_round2((double)w.gap_number / (double)P.total_sequences) >= (1 - P.coverage)) return stop(MP_WIN_GAP_GATE);
+    if (n_cover == 0) return stop(MP_WIN_NO_COVER);
+    entropy(w, S.all, P.v);
+    if (w.tbit > P.entropy_threshold) return stop(MP_WIN_ENTROPY);
     int bases = 0;
     for (int a = 0; a < 4; a++) {
         int64_t s = 0;
         for (int j = 0; j < k; j++) s += freq[a * k + j];
         bases += s > 0;
     }
-    if (bases < 4) { w.status = MP_WIN_FEW_BASES; return MP_OK; }                     // V20:736
+    if (bases < 4) return stop(MP_WIN_FEW_BASES);                                       // V20:736
     for (int j = 0; j < k; j++)
-        if (freq[0 * k + j] + freq[1 * k + j] + freq[2 * k + j] + freq[3 * k + j] == 0) { w.status = MP_WIN_GAP_COLUMN; return MP_OK; }
+        if (freq[0 * k + j] + freq[1 * k + j] + freq[2 * k + j] + freq[3 * k + j] == 0) return stop(MP_WIN_GAP_COLUMN);
+    materialize(w, S, P.v, n_cover, P.keep_tables != 0);
     build_cover_map(w);
     NNArr NN;
     memset(&NN, 0, sizeof NN);
@@ -725,7 +758,8 @@ static int plan_create_body(mp_plan *p, const EntryInput &E, int64_t n_exc, cons
     std::atomic<int> next{0}, failed{0};       // failed: 0 or the MP_ERR_* code of the first failure
     const int n_thr = resolve_threads(P.n_threads, W);
     auto work = [&]() {
-        std::vector<Sight> sights;
+        Scratch scratch;
+        std::vector<Sight> &sights = scratch.sights;
         for (;;) {
             int w = next.fetch_add(1);
             if (w >= W || failed.load()) break;
@@ -770,7 +804,7 @@ static int plan_create_body(mp_plan *p, const EntryInput &E, int64_t n_exc, cons
                 }
             }
             if (failed.load()) break;
-            int rc = plan_window(p, w, sights, n_exc_cover, n_exp, freq + (size_t)w * 4 * k, nn + (size_t)w * (k - 1) * 16);
+            int rc = plan_window(p, w, scratch, n_exc_cover, n_exp, freq + (size_t)w * 4 * k, nn + (size_t)w * (k - 1) * 16);
             if (rc != MP_OK) { int zero = 0; failed.compare_exchange_strong(zero, rc); break; }
             if (!P.keep_tables && p->win[(size_t)w].status != MP_WIN_PLANNED) {
                 Window &ww = p->win[(size_t)w];

@@ -739,6 +739,8 @@ int mp_get_unique(mp_ctx *c, int64_t *win_off, void *words_out, int32_t *count, 
     if (in_order) {
         Lap lap(c->stream);
         if (n) {
+            prefault_host(words, 3 * wb * n); prefault_host(count, 4 * n); prefault_host(first_row, 4 * n);
+            lap("get_unique: prefault");
             HIPCK(c, hipMemcpyAsync(words, c->u_b0, wb * n, hipMemcpyDeviceToHost, c->stream));
             HIPCK(c, hipMemcpyAsync(words + wb * n, c->u_b1, wb * n, hipMemcpyDeviceToHost, c->stream));
             HIPCK(c, hipMemcpyAsync(words + 2 * wb * n, c->u_g, wb * n, hipMemcpyDeviceToHost, c->stream));
@@ -788,6 +790,9 @@ int mp_plan_create_streamed(mp_ctx *c, const mp_plan_params *params, int64_t row
     *out = nullptr;
     if (c->h_wbase.empty()) return fail(c, MP_ERR_ARG, "mp_window_unique has not run");
     if (params->n_windows != c->n_win || params->k != c->k) return fail(c, MP_ERR_ARG, "mp_plan_create_streamed: the parameters are not this context's windows");
+    const bool trace = getenv("MP_TRACE") != nullptr;
+    const auto t_start = std::chrono::steady_clock::now();
+    auto ms_since = [&]() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_start).count(); };
     HIPCK(c, hipSetDevice(c->dev));
     const size_t n = (size_t)c->u_n, W = (size_t)c->n_win, wb = 4 * wsz(c);
     if (n_entries) *n_entries = (int64_t)n;
@@ -798,10 +803,22 @@ int mp_plan_create_streamed(mp_ctx *c, const mp_plan_params *params, int64_t row
         for (size_t w = 0; w < W; w++) { e_off[w] = o; if (c->h_wbase[w] != o) in_order = false; o += c->h_wcount[w]; }
         e_off[W] = o;
     }
-    // host buffers nobody has touched yet: their pages are faulted in by the copies, beside the planning
-    std::unique_ptr<uint8_t[]> words(new (std::nothrow) uint8_t[3 * wb * (n + 1)]);
-    std::unique_ptr<int32_t[]> count(new (std::nothrow) int32_t[n + 1]), first(new (std::nothrow) int32_t[n + 1]);
-    if (!words || !count || !first) return fail(c, MP_ERR_NOMEM, "mp_plan_create_streamed: out of host memory");
+    // the context's staging area: words [3][n], counts [n], first rows [n]; grown when a larger table comes along, its pages faulted in
+    // on several threads the first time (common.hpp prefault_host), reused as it stands afterwards
+    const size_t words_bytes = (3 * wb * (n + 1) + 63) / 64 * 64, need = words_bytes + 2 * 4 * (n + 1);
+    if (c->h_stage_bytes < need) {
+        host_unmap(c->h_stage, c->h_stage_bytes);
+        c->h_stage_bytes = 0;
+        const size_t room = (need + need / 8 + ((size_t)2 << 20) - 1) / ((size_t)2 << 20) * ((size_t)2 << 20);
+        c->h_stage = static_cast<uint8_t *>(host_map(room));
+        if (!c->h_stage) return fail(c, MP_ERR_NOMEM, "mp_plan_create_streamed: out of host memory (%zu bytes)", need);
+        c->h_stage_bytes = room;
+        prefault_host(c->h_stage, need);
+    }
+    struct Span { uint8_t *p; uint8_t *get() const { return p; } };
+    struct SpanI { int32_t *p; int32_t *get() const { return p; } int32_t &operator[](size_t i) const { return p[i]; } };
+    const Span words{c->h_stage};
+    const SpanI count{reinterpret_cast<int32_t *>(c->h_stage + words_bytes)}, first{reinterpret_cast<int32_t *>(c->h_stage + words_bytes) + (n + 1)};
     if (!in_order) {
         // the k >= 22 histograms reserve their segments in completion order: one blocking read-back that lays them out by window
         int rc = mp_get_unique(c, e_off.data(), words.get(), count.get(), first.get());
@@ -810,9 +827,7 @@ int mp_plan_create_streamed(mp_ctx *c, const mp_plan_params *params, int64_t row
     }
     mp_ready_gate ready;
     std::atomic<int> copy_error{0};
-    const bool trace = getenv("MP_TRACE") != nullptr;
-    const auto t_start = std::chrono::steady_clock::now();
-    auto ms_since = [&]() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_start).count(); };
+    if (trace) fprintf(stderr, "[mprime] plan_streamed: staging area ready at %.3f ms\n", ms_since());
     std::thread copier([&]() {
         hipError_t e = hipSetDevice(c->dev);
         // bands of whole windows, about 1/24 of the entries each (the first ones smaller, so that the planners start early)
@@ -847,6 +862,7 @@ int mp_plan_create_streamed(mp_ctx *c, const mp_plan_params *params, int64_t row
                                            &ready, out);
     if (trace) fprintf(stderr, "[mprime] plan_streamed: planning done at %.3f ms\n", ms_since());
     copier.join();
+    if (trace) fprintf(stderr, "[mprime] plan_streamed: returning at %.3f ms\n", ms_since());
     if (copy_error.load()) {
         if (*out) { mp_plan_destroy(*out); *out = nullptr; }
         return fail(c, MP_ERR_DEVICE, "mp_plan_create_streamed: %s", hipGetErrorString((hipError_t)copy_error.load()));

@@ -7,6 +7,8 @@ from __future__ import annotations
 
 import ctypes as C
 import os
+import sys
+import time
 
 import numpy as np
 
@@ -233,9 +235,12 @@ class Plan:
         h = _p()
         if streamed:
             ne = C.c_int64(0)
+            t_call = time.time()
             rc = self.d.mp_plan_create_streamed(device_context.h, C.byref(P), int(row_base), len(x_window), _ptr(x_window), _ptr(x_row), _ptr(x_codes),
                                                 _ptr(freq), _ptr(nn), C.byref(ne), C.byref(h))
             self.n_entries = ne.value
+            if os.environ.get("MP_TRACE"):
+                print("[mprime] host.Plan: mp_plan_create_streamed call %.3f ms" % ((time.time() - t_call) * 1e3), file=sys.stderr)
         elif segments:
             rc = self.d.mp_plan_create_segments(C.byref(P), _ptr(e_off), _ptr(e_words), _ptr(e_count), _ptr(e_first), int(row_base), len(x_window),
                                                 _ptr(x_window), _ptr(x_row), _ptr(x_codes), _ptr(freq), _ptr(nn), C.byref(h))
