@@ -487,9 +487,51 @@ struct Sight {                 // one sighting of a k-mer inside a window, befor
 // address space were most of the stage's time at 131072 x 1000)
 struct Scratch {
     std::vector<Sight> sights;
-    std::vector<Entry> all;               // merged, in insertion order
+    std::vector<Entry> all;               // merged, in the order of the first sighting met; `order` lists it in insertion order
+    std::vector<uint32_t> order, order2;
+    std::vector<uint64_t> keys, keys2;
     KeyMap map;
 };
+
+// S.order = the indices of S.all by (first row, expansion index inside that row): a byte-wise radix sort over the bytes in which the
+// keys differ at all (std::sort on the 40-byte entries was most of the stage's time: ~3000 entries per window at 131072 x 1000).
+// Keys are unique (a row holds one k-mer per window; expansions of one exception row differ in the index), so stability is not an issue.
+void sort_insertion_order(Scratch &S) {
+    const size_t n = S.all.size();
+    S.order.resize(n); S.keys.resize(n);
+    uint64_t diff = 0;
+    bool wide_sub = false;
+    for (size_t i = 0; i < n; i++) {
+        const Entry &e = S.all[i];
+        wide_sub |= (uint64_t)e.first_sub >= ((uint64_t)1 << 24) || (uint64_t)e.first_row >= ((uint64_t)1 << 40);
+        S.keys[i] = ((uint64_t)e.first_row << 24) | ((uint64_t)e.first_sub & 0xFFFFFFu);
+        S.order[i] = (uint32_t)i;
+        diff |= S.keys[i] ^ S.keys[0];
+    }
+    if (wide_sub) {                        // beyond the packed key's range (2^40 rows, 2^24 expansions of one k-mer): compare the fields
+        std::sort(S.order.begin(), S.order.end(), [&](uint32_t a, uint32_t b) {
+            const Entry &x = S.all[a], &y = S.all[b];
+            return x.first_row != y.first_row ? x.first_row < y.first_row : x.first_sub < y.first_sub;
+        });
+        return;
+    }
+    if (n < 64) {
+        std::sort(S.order.begin(), S.order.end(), [&](uint32_t a, uint32_t b) { return S.keys[a] < S.keys[b]; });
+        return;
+    }
+    S.order2.resize(n); S.keys2.resize(n);
+    for (int byte = 0; byte < 8; byte++) {
+        if (!((diff >> (8 * byte)) & 0xFFu)) continue;
+        size_t cnt[257] = {0};
+        for (size_t i = 0; i < n; i++) cnt[((S.keys[i] >> (8 * byte)) & 0xFFu) + 1]++;
+        for (int b = 0; b < 256; b++) cnt[b + 1] += cnt[b];
+        for (size_t i = 0; i < n; i++) {
+            const size_t at = cnt[(S.keys[i] >> (8 * byte)) & 0xFFu]++;
+            S.keys2[at] = S.keys[i]; S.order2[at] = S.order[i];
+        }
+        S.keys.swap(S.keys2); S.order.swap(S.order2);
+    }
+}
 
 // cover / gap_sequence of one window in the reference's dict insertion order (V20:689-711): a key takes the place of
 // its earliest sighting (row, then expansion index inside that row); counts add up.  The merged table stays in the scratch area
@@ -510,9 +552,7 @@ void build_tables(Window &w, Scratch &S, int v, int64_t n_exc_cover, int64_t n_e
             if (s.row < e.first_row || (s.row == e.first_row && s.sub < e.first_sub)) { e.first_row = s.row; e.first_sub = s.sub; }
         }
     }
-    std::sort(all.begin(), all.end(), [](const Entry &a, const Entry &b) {
-        return a.first_row != b.first_row ? a.first_row < b.first_row : a.first_sub < b.first_sub;
-    });
+    sort_insertion_order(S);
     int64_t csum = 0, gsum = 0;
     n_cover = 0;
     for (const Entry &e : all) {
@@ -527,7 +567,8 @@ void build_tables(Window &w, Scratch &S, int v, int64_t n_exc_cover, int64_t n_e
 void materialize(Window &w, const Scratch &S, int v, size_t n_cover, bool want_gap) {
     w.cover.reserve(n_cover);
     if (want_gap) w.gap.reserve(S.all.size() - n_cover);
-    for (const Entry &e : S.all) {
+    for (uint32_t i : S.order) {
+        const Entry &e = S.all[i];
         if (e.ngap > v) { if (want_gap) w.gap.push_back(e); }
         else w.cover.push_back(e);
     }
@@ -540,16 +581,19 @@ void build_cover_map(Window &w) {
 }
 
 // entropy (V20:602-614), same summation order: the cover entries in insertion order, then the gap entries
-void entropy(Window &w, const std::vector<Entry> &all, int v) {
+void entropy(Window &w, const Scratch &S, int v) {
+    const std::vector<Entry> &all = S.all;
     const int64_t cn = w.cover_number, gn = w.gap_number, tot = cn + gn;
     double cbit = 0, tbit = 0;
-    for (const Entry &e : all) {
+    for (uint32_t i : S.order) {
+        const Entry &e = all[i];
         if (e.ngap > v) continue;
         double pc = (double)e.count / (double)cn, pt = (double)e.count / (double)tot;
         cbit += pc * py_log2(pc);
         tbit += pt * py_log2(pt);
     }
-    for (const Entry &e : all) {
+    for (uint32_t i : S.order) {
+        const Entry &e = all[i];
         if (e.ngap <= v) continue;
         double pt = (double)e.count / (double)tot;
         tbit += pt * py_log2(pt);
@@ -574,7 +618,7 @@ int plan_window(mp_plan *p, int wi, Scratch &S, int64_t n_exc_cover, int64_t n_e
     // gates (V20:713-740)
     if (py_round2((double)w.gap_number / (double)P.total_sequences) >= (1 - P.coverage)) return stop(MP_WIN_GAP_GATE);
     if (n_cover == 0) return stop(MP_WIN_NO_COVER);
-    entropy(w, S.all, P.v);
+    entropy(w, S, P.v);
     if (w.tbit > P.entropy_threshold) return stop(MP_WIN_ENTROPY);
     int bases = 0;
     for (int a = 0; a < 4; a++) {
