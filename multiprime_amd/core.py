@@ -68,6 +68,9 @@ def _dump_side_file(obj, fh, depth_list):
     fh.write("{\n" + ",\n".join(parts) + "\n}")
 
 
+_TRACE_PY = bool(os.environ.get("MP_TRACE_PY"))
+
+
 class NN_degenerate(object):
     """Drop-in for the reference class of the same name (V20:342-345, 1133-1180)."""
 
@@ -162,6 +165,14 @@ class NN_degenerate(object):
         return self.raw_entropy_threshold * (0.95 if length < 10000 else 0.9)
 
     # ------------------------------------------------------------------ device tables -> native plan
+    def _lap(self, label):
+        """MP_TRACE_PY=1: host-side lap times of run() on stderr (milliseconds since the previous lap)."""
+        if not _TRACE_PY:
+            return
+        now = time.time()
+        print("[core] %-34s %8.3f ms" % (label, (now - getattr(self, "_lap_t", now)) * 1e3), file=sys.stderr)
+        self._lap_t = now
+
     def _plan(self, keep_tables=None):
         """Device stage (windows, statistics, histograms) and the native per-window planning.  Returns the
         host.Plan, or None when the region holds no window."""
@@ -174,6 +185,7 @@ class NN_degenerate(object):
         keep = self.write_json if keep_tables is None else keep_tables
         row_base = self.comm.row0 if self.comm is not None else 0
         t0 = time.time()
+        self._lap("run: start")
         try:
             n_ex = self.ctx.build_windows(p0, W, k, v)
         except MprimeError as e:
@@ -185,13 +197,17 @@ class NN_degenerate(object):
             print("Error: {}. The reference fails on such an alignment too (ValueError in Y_distance); remove sequences with "
                   "fewer than {} residues.".format(str(e).split(": ", 1)[-1], k))
             sys.exit(1)
+        self._lap("build_windows (library)")
         ex_w, ex_r, ex_codes = self.ctx.get_exceptions(n_ex)
+        self._lap("get_exceptions (%d)" % n_ex)
         if n_ex:
             # IUPAC k-mers with <= v gaps join the evaluated universe as their concrete expansions (V20:701-707)
             sel = (ex_codes == 0).sum(axis=1) <= v
             if sel.any():
                 words, src = host.expand_kmer_words(ex_codes[sel])
+                self._lap("expand_kmer_words (%d)" % len(src))
                 self.ctx.set_extra_rows(ex_w[sel][src], words)
+                self._lap("set_extra_rows")
         self.stats["build_windows_s"] = time.time() - t0
         t0 = time.time()
         # state_matrix / trans_matrix of every window (V20:541-577) straight from the column planes; shards add up
@@ -308,14 +324,18 @@ class NN_degenerate(object):
             self.stats["eval_s"] = time.time() - t0
             self.stats["n_candidates"] = n_cand
             t0 = time.time()
+            self._lap("plan + eval")
             plan.finish(ev)                      # replay of the stopping rules, NM / MM choice, nonsense counts
+            self._lap("plan.finish")
             res = plan.results()
             if self._win_split:
                 res = {key: self.comm.gather_var(val) for key, val in res.items()}       # shares in rank order = window order
             primers = iupac.strings_of(iupac.SYMBOL_LUT[res["codes"]])
             # the 3'-end self-dimer test of every window's primer (dimer_check, V20:487-503) in ONE launch:
             # it is the ordered pair (x -> x) of the dimer scan with Loss >= 3 and the two-term deltaG
+            self._lap("results + strings")
             dimer_flag = self._self_dimers(primers)
+            self._lap("self dimers")
             p0 = int(self.start_position)
             wins = res["window"].tolist()
             cbit, tbit = res["cbit"].tolist(), res["tbit"].tolist()
@@ -328,8 +348,11 @@ class NN_degenerate(object):
             # at once: numpy over the symbol-code matrix, value for value what thermo.tm / filters.pre_filter give per primer
             keep = [i for i, d in enumerate(dimer_flag) if not d]                 # V20:749
             kept_codes = res["codes"][keep] if keep else np.zeros((0, k), np.uint8)
+            self._lap("lists")
             tm_all = dict(zip(keep, batchfilters.tm_of_primers(kept_codes)))
+            self._lap("tm_of_primers")
             info_all = dict(zip(keep, batchfilters.information_of_primers(kept_codes, self.GC, self.distance)))
+            self._lap("information_of_primers")
             for i, primer in enumerate(primers):
                 if dimer_flag[i]:
                     continue
@@ -338,6 +361,7 @@ class NN_degenerate(object):
                 rows_out.append([pos, cbit[i], tbit[i], primer, n_dege[i], nonsense[i], cov[i], f_mis[i], r_mis[i], tm_avg, info])
                 if side is not None:
                     non_cov_out[pos], gap_out[pos] = side(wins[i], primer)
+            self._lap("rows_out")
             self.stats["finish_s"] = time.time() - t0
             if self.write_bitsets or self.keep_bitsets:
                 t0 = time.time()
@@ -447,6 +471,7 @@ class NN_degenerate(object):
         t0 = time.time()
         self.ctx.eval_masks_resident(wins, codes, self._sF, self._sR)
         self.stats["bitsets_masks_s"] = time.time() - t0
+        self._lap("bitsets: codes + eval_masks_resident")
         self.mask_index = {int(r[0]): i for i, r in enumerate(rows_out)}
         # rows whose window held an IUPAC code: every expansion must be reached (V20:701-707 puts the id under each
         # expansion's k-mer), gap-type ones are in gap_seq_id.  Vectorised over all (exception, expansion) pairs.
@@ -460,24 +485,25 @@ class NN_degenerate(object):
             sel = (mask_i >= 0) & (r_loc >= 0) & (r_loc < self.ctx.n_rows)
             if sel.any():
                 mask_i, r_loc, xc = mask_i[sel], r_loc[sel], ex_codes[sel]
+                # Verdict of an exception row = the OR over its expansions of "not perfectly matched and (more than v mismatches or a
+                # mismatch at a strict position)" (V20:701-707 puts the id under every expansion's k-mer, V20:1107-1127).  The
+                # expansions need not be listed for that: position j CAN mismatch when it is '-' or when some member of the row's
+                # symbol lies outside the primer's; the expansion that takes a mismatching member wherever there is one has the most
+                # mismatches, so the row is bad when that count exceeds v, or else when a strict position can mismatch at all.
                 gap_type = (xc == 0).sum(axis=1) > v
                 n_x = len(mask_i)
-                bad = np.zeros((n_x, 2), bool)
-                bad[gap_type] = True
-                idx = np.nonzero(~gap_type)[0]
-                if len(idx):
-                    exp, src = host.expand_kmers(xc[idx])                       # [m][k] concrete codes, src -> position in idx
-                    miss = (exp & codes[mask_i[idx]][src]) == 0                 # position not in the primer's symbol ('-' = 0 misses)
-                    nd = miss.sum(axis=1)
-                    pos = np.arange(k)
-                    hit_f = (miss & (((self._sF >> pos) & 1) == 1)).any(axis=1)
-                    hit_r = (miss & (((self._sR >> pos) & 1) == 1)).any(axis=1)
-                    bf = (nd > 0) & ((nd > v) | hit_f)
-                    br = (nd > 0) & ((nd > v) | hit_r)
-                    np.logical_or.at(bad[:, 0], idx[src], bf)
-                    np.logical_or.at(bad[:, 1], idx[src], br)
+                can_miss = (xc == 0) | ((xc & ~codes[mask_i]) != 0)
+                many = can_miss.sum(axis=1) > v
+                pos = np.arange(k)
+                strict_f = ((self._sF >> pos) & 1).astype(bool)
+                strict_r = ((self._sR >> pos) & 1).astype(bool)
+                bad = np.empty((n_x, 2), bool)
+                bad[:, 0] = gap_type | many | (can_miss & strict_f).any(axis=1)
+                bad[:, 1] = gap_type | many | (can_miss & strict_r).any(axis=1)
+                self._lap("bitsets: exception verdicts (%d)" % n_x)
                 self.ctx.masks_set_bits(np.repeat(mask_i, 2), np.repeat(r_loc, 2), np.tile(np.array([0, 1], np.uint8), n_x),
                                         bad.reshape(-1).astype(np.uint8))
+                self._lap("bitsets: masks_set_bits")
 
     def _write_bitsets(self, rows_out):
         """{out}.coverage_bitsets.npz: the resident masks fetched (and, with row shards, gathered bit by bit) into a file —

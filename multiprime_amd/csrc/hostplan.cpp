@@ -962,7 +962,12 @@ int mp_plan_finish(mp_plan *p, const int64_t *ev) {
     MP_PLAN_FORWARD_MUT(mp_plan_finish, ev);
     if (!p || !ev) return MP_ERR_ARG;
     const int k = p->P.k;
-    for (int32_t w : p->planned) {
+    // windows are independent: the replay and the nonsense counts (expansions of every final primer looked up in the window's table)
+    // run on the host's cores; the first perfect-coverage mismatch (in window order) is the one reported
+    std::atomic<size_t> next{0};
+    std::atomic<int64_t> bad_at{-1};
+    auto finish_window = [&](size_t pi) -> bool {
+        const int32_t w = p->planned[pi];
         Window &x = p->win[(size_t)w];
         const int64_t cn = x.cover_number;
         for (int si = 0; si < x.n_seeds; si++) {
@@ -970,10 +975,7 @@ int mp_plan_finish(mp_plan *p, const int64_t *ev) {
             const int64_t base = s.first_cand;
             // the host's running perfect coverage and the device's count are the same quantity
             for (size_t j = 0; j < s.chain.size(); j++)
-                if (ev[3 * (base + (int64_t)j)] != s.cov[j])
-                    return pfail(p, MP_ERR_ARG, "perfect-coverage mismatch between the host chain and the evaluation at window %d "
-                                 "(seed %d, member %zu: host %lld, evaluation %lld)", w, si, j, (long long)s.cov[j],
-                                 (long long)ev[3 * (base + (int64_t)j)]);
+                if (ev[3 * (base + (int64_t)j)] != s.cov[j]) return false;
             // the stopping rules of coverage_stast (V20:881-906)
             int i = 0;
             int64_t F = ev[3 * base + 1], R = ev[3 * base + 2];
@@ -1007,6 +1009,36 @@ int mp_plan_finish(mp_plan *p, const int64_t *ev) {
             if (x.cover_map.find(e, x.cover) < 0 && !(e == x.present)) nonsense++;
         });
         x.nonsense = nonsense;
+        return true;
+    };
+    auto work = [&]() {
+        for (;;) {
+            const size_t pi = next.fetch_add(1);
+            if (pi >= p->planned.size()) break;
+            if (!finish_window(pi)) {
+                int64_t cur = bad_at.load();
+                while ((cur < 0 || (int64_t)pi < cur) && !bad_at.compare_exchange_weak(cur, (int64_t)pi)) {}
+            }
+        }
+    };
+    const int n_thr = resolve_threads(p->P.n_threads, (int64_t)p->planned.size() / 8);
+    if (n_thr <= 1) work();
+    else {
+        std::vector<std::thread> th;
+        for (int t = 0; t < n_thr; t++) th.emplace_back(work);
+        for (auto &t : th) t.join();
+    }
+    if (bad_at.load() >= 0) {
+        const int32_t w = p->planned[(size_t)bad_at.load()];
+        const Window &x = p->win[(size_t)w];
+        for (int si = 0; si < x.n_seeds; si++) {
+            const Seed &s = x.seeds[si];
+            for (size_t j = 0; j < s.chain.size(); j++)
+                if (ev[3 * (s.first_cand + (int64_t)j)] != s.cov[j])
+                    return pfail(p, MP_ERR_ARG, "perfect-coverage mismatch between the host chain and the evaluation at window %d "
+                                 "(seed %d, member %zu: host %lld, evaluation %lld)", w, si, j, (long long)s.cov[j],
+                                 (long long)ev[3 * (s.first_cand + (int64_t)j)]);
+        }
     }
     p->finished = true;
     return MP_OK;
@@ -1053,11 +1085,30 @@ int mp_plan_window_table(const mp_plan *p, int32_t w, int32_t which, int64_t cap
     return MP_OK;
 }
 
-int mp_expand_kmers(int32_t k, int64_t n, const uint8_t *codes, int64_t cap, uint8_t *out_codes, int64_t *out_src, int64_t *n_out) {
-#if !MP_PLAN_WIDE
-    if (k > kMaxK) return mp_expand_kmers_w64(k, n, codes, cap, out_codes, out_src, n_out);
-#endif
-    if (k < 1 || k > kMaxK || n < 0 || !n_out || (n && !codes)) return MP_ERR_ARG;
+extern "C++" {
+// The expansions of many short IUPAC k-mers (the exception list: one or two degenerate positions each): the member lists are walked as a
+// mixed-radix counter over the DEGENERATE positions only (last position fastest — itertools.product order, V20:368-380), every step
+// rewrites the positions that changed and nothing else.  `emit(i, first, changed positions...)` sees each expansion once.
+template <typename Start, typename Change, typename Emit>
+static void walk_expansions(const uint8_t *codes, int k, Start &&start, Change &&change, Emit &&emit) {
+    int dpos[kMaxK + 1], didx[kMaxK + 1], nd = 0;
+    for (int j = 0; j < k; j++)
+        if (kMembers[codes[j]].n > 1) { dpos[nd] = j; didx[nd] = 0; nd++; }
+    start();
+    for (;;) {
+        emit();
+        int t = nd - 1;
+        for (; t >= 0; t--) {
+            const Members &mb = kMembers[codes[dpos[t]]];
+            if (++didx[t] < mb.n) { change(dpos[t], mb.m[didx[t]]); break; }
+            didx[t] = 0;
+            change(dpos[t], mb.m[0]);
+        }
+        if (t < 0) break;
+    }
+}
+
+static int expansion_total(int32_t k, int64_t n, const uint8_t *codes, int64_t cap, int64_t *n_out) {
     double need = 0;
     for (int64_t i = 0; i < n; i++) {
         for (int j = 0; j < k; j++) if (codes[(size_t)i * k + j] > 15) return MP_ERR_ARG;
@@ -1066,13 +1117,30 @@ int mp_expand_kmers(int32_t k, int64_t n, const uint8_t *codes, int64_t cap, uin
     if (need > 9e15) return MP_ERR_CAPACITY;
     *n_out = (int64_t)need;
     if ((int64_t)need > cap) return MP_ERR_CAPACITY;
+    return MP_OK;
+}
+
+}  // extern "C++"
+
+int mp_expand_kmers(int32_t k, int64_t n, const uint8_t *codes, int64_t cap, uint8_t *out_codes, int64_t *out_src, int64_t *n_out) {
+#if !MP_PLAN_WIDE
+    if (k > kMaxK) return mp_expand_kmers_w64(k, n, codes, cap, out_codes, out_src, n_out);
+#endif
+    if (k < 1 || k > kMaxK || n < 0 || !n_out || (n && !codes)) return MP_ERR_ARG;
+    int rc = expansion_total(k, n, codes, cap, n_out);
+    if (rc) return rc;
     int64_t o = 0;
-    for (int64_t i = 0; i < n; i++)
-        for_each_expansion(codes + (size_t)i * k, k, [&](const Key &e) {
-            if (out_codes) for (int j = 0; j < k; j++) out_codes[(size_t)o * k + j] = (uint8_t)e.get(j);
-            if (out_src) out_src[o] = i;
-            o++;
-        });
+    uint8_t cur[kMaxK + 1];
+    for (int64_t i = 0; i < n; i++) {
+        const uint8_t *c = codes + (size_t)i * k;
+        walk_expansions(c, k, [&] { for (int j = 0; j < k; j++) cur[j] = kMembers[c[j]].m[0]; },
+                        [&](int j, uint8_t member) { cur[j] = member; },
+                        [&] {
+                            if (out_codes) memcpy(out_codes + (size_t)o * k, cur, (size_t)k);
+                            if (out_src) out_src[o] = i;
+                            o++;
+                        });
+    }
     return MP_OK;
 }
 
@@ -1081,36 +1149,36 @@ int mp_expand_kmer_words(int32_t k, int64_t n, const uint8_t *codes, int64_t cap
     if (k > kMaxK) return mp_expand_kmer_words_w64(k, n, codes, cap, out_words, out_src, n_out);
 #endif
     if (k < 1 || k > kMaxK || n < 0 || !n_out || (n && !codes)) return MP_ERR_ARG;
-    double need = 0;
-    for (int64_t i = 0; i < n; i++) {
-        for (int j = 0; j < k; j++) if (codes[(size_t)i * k + j] > 15) return MP_ERR_ARG;
-        need += expansions_of(codes + (size_t)i * k, k);
-    }
-    if (need > 9e15) return MP_ERR_CAPACITY;
-    *n_out = (int64_t)need;
-    if ((int64_t)need > cap) return MP_ERR_CAPACITY;
+    int rc = expansion_total(k, n, codes, cap, n_out);
+    if (rc) return rc;
     int64_t o = 0;
-    for (int64_t i = 0; i < n; i++)
-        for_each_expansion(codes + (size_t)i * k, k, [&](const Key &e) {
-            if (out_words) {
-                word_t b0 = 0, b1 = 0, g = 0;                         // window words of mprime.h: base index bits and the gap flag
-                for (int j = 0; j < k; j++) {
-                    const uint32_t c = (uint32_t)e.get(j);
-                    b0 |= (word_t)((c & 10u) != 0) << j;              // C or T
-                    b1 |= (word_t)((c & 12u) != 0) << j;              // G or T
-                    g |= (word_t)(c == 0) << j;
-                }
-                if (k > MP_NARROW_K) {
-                    uint64_t *ow = (uint64_t *)out_words;
-                    ow[(size_t)o * 3] = b0; ow[(size_t)o * 3 + 1] = b1; ow[(size_t)o * 3 + 2] = g;
-                } else {
-                    uint32_t *ow = (uint32_t *)out_words;
-                    ow[(size_t)o * 3] = (uint32_t)b0; ow[(size_t)o * 3 + 1] = (uint32_t)b1; ow[(size_t)o * 3 + 2] = (uint32_t)g;
-                }
-            }
-            if (out_src) out_src[o] = i;
-            o++;
-        });
+    word_t b0 = 0, b1 = 0, g = 0;                                 // window words of mprime.h: base index bits and the gap flag
+    auto put = [&](int j, uint8_t member) {                       // member: a one-hot base code, or 0 = '-'
+        const word_t bit = (word_t)1 << j;
+        b0 &= ~bit; b1 &= ~bit; g &= ~bit;
+        if (member == 0) g |= bit;
+        else {
+            if (member & 10u) b0 |= bit;                          // C or T
+            if (member & 12u) b1 |= bit;                          // G or T
+        }
+    };
+    for (int64_t i = 0; i < n; i++) {
+        const uint8_t *c = codes + (size_t)i * k;
+        walk_expansions(c, k, [&] { b0 = b1 = g = 0; for (int j = 0; j < k; j++) put(j, kMembers[c[j]].m[0]); }, put,
+                        [&] {
+                            if (out_words) {
+                                if (k > MP_NARROW_K) {
+                                    uint64_t *ow = (uint64_t *)out_words;
+                                    ow[(size_t)o * 3] = b0; ow[(size_t)o * 3 + 1] = b1; ow[(size_t)o * 3 + 2] = g;
+                                } else {
+                                    uint32_t *ow = (uint32_t *)out_words;
+                                    ow[(size_t)o * 3] = (uint32_t)b0; ow[(size_t)o * 3 + 1] = (uint32_t)b1; ow[(size_t)o * 3 + 2] = (uint32_t)g;
+                                }
+                            }
+                            if (out_src) out_src[o] = i;
+                            o++;
+                        });
+    }
     return MP_OK;
 }
 

@@ -830,13 +830,15 @@ int mp_plan_create_streamed(mp_ctx *c, const mp_plan_params *params, int64_t row
     if (trace) fprintf(stderr, "[mprime] plan_streamed: staging area ready at %.3f ms\n", ms_since());
     std::thread copier([&]() {
         hipError_t e = hipSetDevice(c->dev);
-        // bands of whole windows, about 1/24 of the entries each (the first ones smaller, so that the planners start early)
-        const size_t target = std::max<size_t>(n / 24, 4096);
+        // bands of whole windows: two small ones so that the planners start early, then a sixth of the entries each — a band is five
+        // copies and every copy through the runtime's staging buffers has ~50 us of its own (24 bands took 6 ms for 58 MB that
+        // cross in 1.1 ms as one piece)
+        const size_t target = std::max<size_t>(n / 6, 65536);
         size_t w0 = 0;
         int band = 0;
         while (w0 < W) {
             size_t w1 = w0 + 1;
-            const size_t want = band < 2 ? target / 4 : target;
+            const size_t want = band < 2 ? target / 8 : target;
             while (w1 < W && (size_t)(e_off[w1] - e_off[w0]) < want) w1++;
             const size_t a = (size_t)e_off[w0], m = (size_t)(e_off[w1] - e_off[w0]);
             if (m && e == hipSuccess) {

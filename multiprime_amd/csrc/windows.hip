@@ -281,8 +281,15 @@ int mp_build_windows(mp_ctx *c, int32_t p0, int32_t n_win, int32_t k, int32_t v,
         c->ex_host.resize((size_t)cnt);
         if (cnt) HIPCK(c, hipMemcpy(c->ex_host.data(), c->ex, sizeof(ExRec) * (size_t)cnt, hipMemcpyDeviceToHost));
         lap("build_windows: ex d2h");
-        std::sort(c->ex_host.begin(), c->ex_host.end(),
-                  [](const ExRec &a, const ExRec &b) { return a.win != b.win ? a.win < b.win : a.row < b.row; });
+        {   // by (window, row): the packed keys are sorted with their positions, the 40-byte records move once
+            std::vector<std::pair<uint64_t, uint32_t>> order((size_t)cnt);
+            for (size_t i = 0; i < (size_t)cnt; i++)
+                order[i] = {((uint64_t)(uint32_t)c->ex_host[i].win << 32) | (uint32_t)c->ex_host[i].row, (uint32_t)i};
+            std::sort(order.begin(), order.end());
+            std::vector<ExRec> sorted((size_t)cnt);
+            for (size_t i = 0; i < (size_t)cnt; i++) sorted[i] = c->ex_host[order[i].second];
+            c->ex_host.swap(sorted);
+        }
         if (n_exc) *n_exc = cnt;
         lap("build_windows: exceptions");
     }
