@@ -179,6 +179,7 @@ void mp_destroy(mp_ctx *c) {
     free_comm(c);
     free_msa(c);
     dev_free(c, &c->tmp_out, (size_t)c->tmp_out_n);
+    if (c->h_stage_pinned) (void)hipHostUnregister(c->h_stage);
     host_unmap(c->h_stage, c->h_stage_bytes);
     dev_free(c, &c->dm_loss, (size_t)(MP_DIMER_MAX_LEN + 1) * (MP_DIMER_MAX_LEN + 1) * 64);
     dev_free(c, &c->dm_dg, (size_t)(16 + 32 + MP_DIMER_MAX_LEN + 1 + 1));

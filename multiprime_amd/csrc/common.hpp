@@ -209,6 +209,7 @@ struct mp_ctx {
     // kernel and faulting them in again costs more than the copy that fills them
     uint8_t *h_stage = nullptr;              // host_map() memory
     size_t h_stage_bytes = 0;
+    bool h_stage_pinned = false;             // registered with the runtime (hipHostRegister): copies into it are plain DMA
     // row-shard collectives (comm.hip): an RCCL communicator (ncclComm_t) when n_ranks > 1
     void *comm = nullptr;
     int n_ranks = 0, rank = 0;               // n_ranks 0: mp_comm_init has not run
@@ -269,6 +270,21 @@ void prefault_host(void *p, size_t bytes);
 // 66 MB are faulted in on 16 threads in ~1.3 ms with it and in ~4.7 ms without.  host_unmap releases it.  api.hip
 void *host_map(size_t bytes);
 void host_unmap(void *p, size_t bytes);
+
+// A large host buffer registered with the runtime for the time of one transfer (hipHostRegister): the copy then is one DMA at the link's
+// rate instead of a walk through the runtime's staging buffers — 58 MB: 0.3 ms to register pages that exist + 1.1 ms to copy, against
+// 3.2-3.4 ms staged (tools/ubench/d2h_bench.hip).  The pages must have been touched (prefault_host, or data already in them); small
+// buffers and a refusal by the runtime leave the staged path in place.  MP_NO_PIN=1 switches it off.
+struct PinScope {
+    void *p = nullptr;
+    PinScope(void *ptr, size_t bytes) {
+        if (ptr && bytes >= ((size_t)4 << 20) && !getenv("MP_NO_PIN") && hipHostRegister(ptr, bytes, hipHostRegisterDefault) == hipSuccess) p = ptr;
+        else (void)hipGetLastError();
+    }
+    ~PinScope() { if (p) (void)hipHostUnregister(p); }
+    PinScope(const PinScope &) = delete;
+    PinScope &operator=(const PinScope &) = delete;
+};
 
 // release the device arrays of one stage (and of every stage that depends on it); api.hip
 void free_eval(mp_ctx *c);

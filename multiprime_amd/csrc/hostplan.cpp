@@ -1021,7 +1021,7 @@ int mp_plan_finish(mp_plan *p, const int64_t *ev) {
             }
         }
     };
-    const int n_thr = resolve_threads(p->P.n_threads, (int64_t)p->planned.size() / 8);
+    const int n_thr = std::min(8, resolve_threads(p->P.n_threads, (int64_t)p->planned.size() / 64));      // (a thread costs ~30 us to start)
     if (n_thr <= 1) work();
     else {
         std::vector<std::thread> th;
@@ -1108,18 +1108,35 @@ static void walk_expansions(const uint8_t *codes, int k, Start &&start, Change &
     }
 }
 
-static int expansion_total(int32_t k, int64_t n, const uint8_t *codes, int64_t cap, int64_t *n_out) {
+// first output slot of every k-mer's expansions (first[n] = their number); MP_ERR_ARG for a bad symbol code, MP_ERR_CAPACITY beyond 9e15
+static int expansion_offsets(int32_t k, int64_t n, const uint8_t *codes, std::vector<int64_t> &first) {
+    first.assign((size_t)n + 1, 0);
     double need = 0;
     for (int64_t i = 0; i < n; i++) {
-        for (int j = 0; j < k; j++) if (codes[(size_t)i * k + j] > 15) return MP_ERR_ARG;
-        need += expansions_of(codes + (size_t)i * k, k);
+        int64_t d = 1;
+        bool big = false;
+        for (int j = 0; j < k; j++) {
+            const uint8_t c = codes[(size_t)i * k + j];
+            if (c > 15) return MP_ERR_ARG;
+            d *= kMembers[c].n;
+            if (d > ((int64_t)1 << 40)) big = true;
+        }
+        need += big ? expansions_of(codes + (size_t)i * k, k) : (double)d;
+        if (need > 9e15) return MP_ERR_CAPACITY;
+        first[(size_t)i + 1] = first[(size_t)i] + d;
     }
-    if (need > 9e15) return MP_ERR_CAPACITY;
-    *n_out = (int64_t)need;
-    if ((int64_t)need > cap) return MP_ERR_CAPACITY;
     return MP_OK;
 }
 
+// run body(i0, i1) over [0, n) on a few threads when there is enough of it (the exception list of a deep alignment: 10^4 .. 10^6 k-mers)
+template <typename Body>
+static void over_kmers(int64_t n, Body &&body) {
+    const int n_thr = n >= 8192 ? std::min(8, resolve_threads(0, n / 4096)) : 1;
+    if (n_thr <= 1) { body((int64_t)0, n); return; }
+    std::vector<std::thread> th;
+    for (int t = 0; t < n_thr; t++) th.emplace_back([&, t] { body(n * t / n_thr, n * (t + 1) / n_thr); });
+    for (auto &x : th) x.join();
+}
 }  // extern "C++"
 
 int mp_expand_kmers(int32_t k, int64_t n, const uint8_t *codes, int64_t cap, uint8_t *out_codes, int64_t *out_src, int64_t *n_out) {
@@ -1127,20 +1144,25 @@ int mp_expand_kmers(int32_t k, int64_t n, const uint8_t *codes, int64_t cap, uin
     if (k > kMaxK) return mp_expand_kmers_w64(k, n, codes, cap, out_codes, out_src, n_out);
 #endif
     if (k < 1 || k > kMaxK || n < 0 || !n_out || (n && !codes)) return MP_ERR_ARG;
-    int rc = expansion_total(k, n, codes, cap, n_out);
+    std::vector<int64_t> first;
+    int rc = expansion_offsets(k, n, codes, first);
     if (rc) return rc;
-    int64_t o = 0;
-    uint8_t cur[kMaxK + 1];
-    for (int64_t i = 0; i < n; i++) {
-        const uint8_t *c = codes + (size_t)i * k;
-        walk_expansions(c, k, [&] { for (int j = 0; j < k; j++) cur[j] = kMembers[c[j]].m[0]; },
-                        [&](int j, uint8_t member) { cur[j] = member; },
-                        [&] {
-                            if (out_codes) memcpy(out_codes + (size_t)o * k, cur, (size_t)k);
-                            if (out_src) out_src[o] = i;
-                            o++;
-                        });
-    }
+    *n_out = first[(size_t)n];
+    if (*n_out > cap) return MP_ERR_CAPACITY;
+    over_kmers(n, [&](int64_t i0, int64_t i1) {
+        uint8_t cur[kMaxK + 1];
+        for (int64_t i = i0; i < i1; i++) {
+            const uint8_t *c = codes + (size_t)i * k;
+            int64_t o = first[(size_t)i];
+            walk_expansions(c, k, [&] { for (int j = 0; j < k; j++) cur[j] = kMembers[c[j]].m[0]; },
+                            [&](int j, uint8_t member) { cur[j] = member; },
+                            [&] {
+                                if (out_codes) memcpy(out_codes + (size_t)o * k, cur, (size_t)k);
+                                if (out_src) out_src[o] = i;
+                                o++;
+                            });
+        }
+    });
     return MP_OK;
 }
 
@@ -1149,9 +1171,12 @@ int mp_expand_kmer_words(int32_t k, int64_t n, const uint8_t *codes, int64_t cap
     if (k > kMaxK) return mp_expand_kmer_words_w64(k, n, codes, cap, out_words, out_src, n_out);
 #endif
     if (k < 1 || k > kMaxK || n < 0 || !n_out || (n && !codes)) return MP_ERR_ARG;
-    int rc = expansion_total(k, n, codes, cap, n_out);
+    std::vector<int64_t> first;
+    int rc = expansion_offsets(k, n, codes, first);
     if (rc) return rc;
-    int64_t o = 0;
+    *n_out = first[(size_t)n];
+    if (*n_out > cap) return MP_ERR_CAPACITY;
+    over_kmers(n, [&](int64_t i0, int64_t i1) {
     word_t b0 = 0, b1 = 0, g = 0;                                 // window words of mprime.h: base index bits and the gap flag
     auto put = [&](int j, uint8_t member) {                       // member: a one-hot base code, or 0 = '-'
         const word_t bit = (word_t)1 << j;
@@ -1162,9 +1187,19 @@ int mp_expand_kmer_words(int32_t k, int64_t n, const uint8_t *codes, int64_t cap
             if (member & 12u) b1 |= bit;                          // G or T
         }
     };
-    for (int64_t i = 0; i < n; i++) {
+    for (int64_t i = i0; i < i1; i++) {
         const uint8_t *c = codes + (size_t)i * k;
-        walk_expansions(c, k, [&] { b0 = b1 = g = 0; for (int j = 0; j < k; j++) put(j, kMembers[c[j]].m[0]); }, put,
+        int64_t o = first[(size_t)i];
+        auto base_words = [&] {                                   // every position at its first member, branch-free
+            b0 = b1 = g = 0;
+            for (int j = 0; j < k; j++) {
+                const uint32_t m0 = kMembers[c[j]].m[0];
+                b0 |= (word_t)(((m0 >> 1) | (m0 >> 3)) & 1u) << j;
+                b1 |= (word_t)(((m0 >> 2) | (m0 >> 3)) & 1u) << j;
+                g |= (word_t)(m0 == 0) << j;
+            }
+        };
+        walk_expansions(c, k, base_words, put,
                         [&] {
                             if (out_words) {
                                 if (k > MP_NARROW_K) {
@@ -1179,6 +1214,7 @@ int mp_expand_kmer_words(int32_t k, int64_t n, const uint8_t *codes, int64_t cap
                             o++;
                         });
     }
+    });
     return MP_OK;
 }
 

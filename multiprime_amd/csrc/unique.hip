@@ -741,12 +741,14 @@ int mp_get_unique(mp_ctx *c, int64_t *win_off, void *words_out, int32_t *count, 
         if (n) {
             prefault_host(words, 3 * wb * n); prefault_host(count, 4 * n); prefault_host(first_row, 4 * n);
             lap("get_unique: prefault");
+            const PinScope pin_w(words, 3 * wb * n), pin_c(count, 4 * n), pin_f(first_row, 4 * n);
+            lap("get_unique: register");
             HIPCK(c, hipMemcpyAsync(words, c->u_b0, wb * n, hipMemcpyDeviceToHost, c->stream));
             HIPCK(c, hipMemcpyAsync(words + wb * n, c->u_b1, wb * n, hipMemcpyDeviceToHost, c->stream));
             HIPCK(c, hipMemcpyAsync(words + 2 * wb * n, c->u_g, wb * n, hipMemcpyDeviceToHost, c->stream));
             HIPCK(c, hipMemcpyAsync(count, c->u_count, 4 * n, hipMemcpyDeviceToHost, c->stream));
             HIPCK(c, hipMemcpyAsync(first_row, c->u_first, 4 * n, hipMemcpyDeviceToHost, c->stream));
-            HIPCK(c, hipStreamSynchronize(c->stream));
+            HIPCK(c, hipStreamSynchronize(c->stream));      // (a failed call above leaves through HIPCK: the scopes unregister on the way out)
         }
         if (lap.on) fprintf(stderr, "[mprime] get_unique: %zu entries, %.1f MB\n", n, (double)(3 * wb + 8) * (double)n / 1e6);
         lap("get_unique: d2h");
@@ -807,13 +809,18 @@ int mp_plan_create_streamed(mp_ctx *c, const mp_plan_params *params, int64_t row
     // on several threads the first time (common.hpp prefault_host), reused as it stands afterwards
     const size_t words_bytes = (3 * wb * (n + 1) + 63) / 64 * 64, need = words_bytes + 2 * 4 * (n + 1);
     if (c->h_stage_bytes < need) {
+        if (c->h_stage_pinned) (void)hipHostUnregister(c->h_stage);
+        c->h_stage_pinned = false;
         host_unmap(c->h_stage, c->h_stage_bytes);
         c->h_stage_bytes = 0;
         const size_t room = (need + need / 8 + ((size_t)2 << 20) - 1) / ((size_t)2 << 20) * ((size_t)2 << 20);
         c->h_stage = static_cast<uint8_t *>(host_map(room));
         if (!c->h_stage) return fail(c, MP_ERR_NOMEM, "mp_plan_create_streamed: out of host memory (%zu bytes)", need);
         c->h_stage_bytes = room;
-        prefault_host(c->h_stage, need);
+        prefault_host(c->h_stage, room);
+        // registered for the context's life: the bands below are DMA copies that take no host thread away from the planning
+        if (!getenv("MP_NO_PIN") && hipHostRegister(c->h_stage, room, hipHostRegisterDefault) == hipSuccess) c->h_stage_pinned = true;
+        else (void)hipGetLastError();
     }
     struct Span { uint8_t *p; uint8_t *get() const { return p; } };
     struct SpanI { int32_t *p; int32_t *get() const { return p; } int32_t &operator[](size_t i) const { return p[i]; } };
@@ -830,10 +837,10 @@ int mp_plan_create_streamed(mp_ctx *c, const mp_plan_params *params, int64_t row
     if (trace) fprintf(stderr, "[mprime] plan_streamed: staging area ready at %.3f ms\n", ms_since());
     std::thread copier([&]() {
         hipError_t e = hipSetDevice(c->dev);
-        // bands of whole windows: two small ones so that the planners start early, then a sixth of the entries each — a band is five
-        // copies and every copy through the runtime's staging buffers has ~50 us of its own (24 bands took 6 ms for 58 MB that
-        // cross in 1.1 ms as one piece)
-        const size_t target = std::max<size_t>(n / 6, 65536);
+        // bands of whole windows: two small ones so that the planners start early, then a sixth (a twelfth when the area is registered)
+        // of the entries each — a band is five copies and every copy through the runtime's staging buffers has ~50 us of its own
+        // (24 bands took 6 ms for 58 MB that cross in 1.1 ms as one piece)
+        const size_t target = std::max<size_t>(n / (c->h_stage_pinned ? 12 : 6), 65536);
         size_t w0 = 0;
         int band = 0;
         while (w0 < W) {
