@@ -277,17 +277,18 @@ class NN_degenerate(object):
         self.stats["plan_s"] = time.time() - t0
         return plan
 
-    def _self_dimers(self, primers):
-        """dimer_check (V20:487-503) for a list of primers: one mp_dimer_pairs launch."""
-        if not primers:
+    def _self_dimers(self, codes):
+        """dimer_check (V20:487-503) for the primers given as an [n][k] matrix of symbol codes: one mp_dimer_pairs launch over the
+        ordered pairs (i -> i)."""
+        n = len(codes)
+        if n == 0:
             return []
-        from .dimer import cached_loss_table, dg_limit, dg_params, encode_primers
-        uniq = list(dict.fromkeys(primers))
-        codes, off = encode_primers(uniq)
-        pairs = np.repeat(np.arange(len(uniq), dtype=np.int32), 2).reshape(-1, 2)
-        flags = self.ctx.dimer_pairs(codes, off, pairs, cached_loss_table(3.0), dg_params(), dg_limit())
-        hit = dict(zip(uniq, (bool(x) for x in flags)))
-        return [hit[p] for p in primers]
+        from .dimer import cached_loss_table, dg_limit, dg_params
+        k = codes.shape[1]
+        off = np.arange(n + 1, dtype=np.int32) * k
+        pairs = np.repeat(np.arange(n, dtype=np.int32), 2).reshape(-1, 2)
+        flags = self.ctx.dimer_pairs(np.ascontiguousarray(codes, np.uint8).reshape(-1), off, pairs, cached_loss_table(3.0), dg_params(), dg_limit())
+        return flags.astype(bool).tolist()
 
     # ------------------------------------------------------------------ driver
     def run(self):
@@ -334,7 +335,7 @@ class NN_degenerate(object):
             # the 3'-end self-dimer test of every window's primer (dimer_check, V20:487-503) in ONE launch:
             # it is the ordered pair (x -> x) of the dimer scan with Loss >= 3 and the two-term deltaG
             self._lap("results + strings")
-            dimer_flag = self._self_dimers(primers)
+            dimer_flag = self._self_dimers(res["codes"])
             self._lap("self dimers")
             p0 = int(self.start_position)
             wins = res["window"].tolist()
