@@ -58,7 +58,7 @@ SHARD_ROWS = 131072            # what one GPU holds of it in the 8-GPU job
 DEFAULT_CEILINGS = {"valu_wave_instr_per_s_per_simd": 8.5e8, "l2_read_GBs": 31559.0, "source": "built-in defaults (profiles/r02_ubench.json missing)"}
 COUNTER_FILES = ("r04_counters.json", "r03_counters.json")
 # sources of the timed kernel (eval_chain_kernel and what it includes): the key of a counter entry
-KERNEL_SOURCES = ("eval.hip", "evalprog.hip", "evalslide.hip", "slidecore.hpp", "slideplan.hpp", "evalslide.hpp", "bitslice.hpp", "common.hpp",
+KERNEL_SOURCES = ("eval.hip", "evalprog.hip", "evalslide.hip", "slidecore.hpp", "slideplan.hpp", "evalslide.hpp", "chainbody.hpp", "bitslice.hpp", "common.hpp",
                   "winwords.hpp", "evalprog.hpp")
 SLIDE_FROM_ROWS = 262145     # evalslide.hip (upload_eval_slide): above 262144 (padded) rows the chains are evaluated by sliding
 PROG_FROM_ROWS = 393216      # eval.hip (mp_eval_upload): the program-driven first-pass kernel, when sliding is switched off
