@@ -62,6 +62,23 @@ def _exact_means(vals, seg):
     return out
 
 
+def _round2(x: np.ndarray) -> np.ndarray:
+    """Python's round(v, 2) of every element: the double nearest to the correctly rounded two-decimal value of v (ties to even on
+    the EXACT binary value).  rint(v * 100) / 100 is that same double whenever v * 100 is not within rounding error of a tie (the
+    quotient of an integer by 100 is correctly rounded, like the decimal string's conversion); the few elements near a tie — and
+    anything not finite or too large for the product to be an integer comparison — go through Python's own round."""
+    x = np.asarray(x, np.float64)
+    with np.errstate(invalid="ignore"):
+        y = x * 100.0
+        r = np.rint(y) / 100.0
+        frac = np.abs(y - np.floor(y))
+    near_tie = ~(np.abs(frac - 0.5) > 1e-6) | ~(np.abs(y) < 4e9)      # (below 2^32 the product is off by < 1e-6)
+    if near_tie.any():
+        idx = np.nonzero(near_tie)[0]
+        r[idx] = [round(v, 2) for v in x[idx].tolist()]
+    return r
+
+
 def tm_of_primers(codes: np.ndarray):
     """[round(mean(Calc_Tm_v2 over the expansions), 2)] per primer (V20:849-852, 282-336)."""
     n, k = codes.shape
@@ -84,7 +101,7 @@ def tm_of_primers(codes: np.ndarray):
     dh = dh * 1000
     ln_c = np.where(sym, thermo._LN_CONC_A, thermo._LN_CONC_B)
     t_raw = 1 / ((1 / (dh / (ds + ln_c))) + thermo.SALT_CORRECTION) - thermo.KELVIN
-    vals = [round(x, 2) for x in t_raw.tolist()]               # thermo.tm rounds every expansion's Tm
+    vals = _round2(t_raw)                                      # thermo.tm rounds every expansion's Tm
     return [round(x, 2) for x in _exact_means(vals, _segments(src, n))]
 
 

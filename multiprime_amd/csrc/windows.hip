@@ -281,13 +281,21 @@ int mp_build_windows(mp_ctx *c, int32_t p0, int32_t n_win, int32_t k, int32_t v,
         c->ex_host.resize((size_t)cnt);
         if (cnt) HIPCK(c, hipMemcpy(c->ex_host.data(), c->ex, sizeof(ExRec) * (size_t)cnt, hipMemcpyDeviceToHost));
         lap("build_windows: ex d2h");
-        {   // by (window, row): the packed keys are sorted with their positions, the 40-byte records move once
-            std::vector<std::pair<uint64_t, uint32_t>> order((size_t)cnt);
-            for (size_t i = 0; i < (size_t)cnt; i++)
-                order[i] = {((uint64_t)(uint32_t)c->ex_host[i].win << 32) | (uint32_t)c->ex_host[i].row, (uint32_t)i};
-            std::sort(order.begin(), order.end());
+        {   // by (window, row): a counting sort over the windows (positions only), then the rows inside each window's short run; the
+            // 40-byte records move once (std::sort on the records: 0.85 ms for 22 666 of them, on packed keys 0.78)
+            std::vector<int32_t> first((size_t)n_win + 1, 0);
+            for (int i = 0; i < cnt; i++) first[(size_t)c->ex_host[(size_t)i].win + 1]++;
+            for (int w = 0; w < n_win; w++) first[(size_t)w + 1] += first[(size_t)w];
+            std::vector<uint32_t> order((size_t)cnt);
+            {
+                std::vector<int32_t> cur(first.begin(), first.end() - 1);
+                for (int i = 0; i < cnt; i++) order[(size_t)cur[(size_t)c->ex_host[(size_t)i].win]++] = (uint32_t)i;
+            }
+            for (int w = 0; w < n_win; w++)
+                std::sort(order.begin() + first[(size_t)w], order.begin() + first[(size_t)w + 1],
+                          [&](uint32_t a, uint32_t b) { return c->ex_host[a].row < c->ex_host[b].row; });
             std::vector<ExRec> sorted((size_t)cnt);
-            for (size_t i = 0; i < (size_t)cnt; i++) sorted[i] = c->ex_host[order[i].second];
+            for (size_t i = 0; i < (size_t)cnt; i++) sorted[i] = c->ex_host[order[i]];
             c->ex_host.swap(sorted);
         }
         if (n_exc) *n_exc = cnt;
