@@ -202,11 +202,16 @@ class NN_degenerate(object):
         self._lap("get_exceptions (%d)" % n_ex)
         if n_ex:
             # IUPAC k-mers with <= v gaps join the evaluated universe as their concrete expansions (V20:701-707)
-            sel = (ex_codes == 0).sum(axis=1) <= v
-            if sel.any():
-                words, src = host.expand_kmer_words(ex_codes[sel])
+            gaps = ex_codes == 0
+            if gaps.any():
+                sel = gaps.sum(axis=1) <= v
+                x_codes, x_win = ex_codes[sel], ex_w[sel]
+            else:                                       # (the usual case: an IUPAC code, no gap in the window)
+                x_codes, x_win = ex_codes, ex_w
+            if len(x_win):
+                words, src = host.expand_kmer_words(x_codes)
                 self._lap("expand_kmer_words (%d)" % len(src))
-                self.ctx.set_extra_rows(ex_w[sel][src], words)
+                self.ctx.set_extra_rows(x_win[src], words)
                 self._lap("set_extra_rows")
         self.stats["build_windows_s"] = time.time() - t0
         t0 = time.time()

@@ -39,6 +39,7 @@
 
 #include <algorithm>
 #include <atomic>
+#include <chrono>
 #include <cmath>
 #include <cerrno>
 #include <cstdarg>
@@ -486,6 +487,7 @@ struct Sight {                 // one sighting of a k-mer inside a window, befor
 // kilobytes — allocated afresh they went through mmap / munmap once per window and thread, and the page faults of 32 threads in one
 // address space were most of the stage's time at 131072 x 1000)
 struct Scratch {
+    double t_sights = 0, t_merge = 0, t_sort = 0, t_gates = 0, t_chain = 0;      // MP_TRACE: seconds this thread spent per phase
     std::vector<Sight> sights;
     std::vector<Entry> all;               // merged, in the order of the first sighting met; `order` lists it in insertion order
     std::vector<uint32_t> order, order2;
@@ -552,7 +554,9 @@ void build_tables(Window &w, Scratch &S, int v, int64_t n_exc_cover, int64_t n_e
             if (s.row < e.first_row || (s.row == e.first_row && s.sub < e.first_sub)) { e.first_row = s.row; e.first_sub = s.sub; }
         }
     }
+    const auto t_a = std::chrono::steady_clock::now();
     sort_insertion_order(S);
+    S.t_sort += std::chrono::duration<double>(std::chrono::steady_clock::now() - t_a).count();
     int64_t csum = 0, gsum = 0;
     n_cover = 0;
     for (const Entry &e : all) {
@@ -608,7 +612,11 @@ int plan_window(mp_plan *p, int wi, Scratch &S, int64_t n_exc_cover, int64_t n_e
     const int k = P.k;
     Window &w = p->win[(size_t)wi];
     size_t n_cover = 0;
+    const auto t_0 = std::chrono::steady_clock::now();
     build_tables(w, S, P.v, n_exc_cover, n_exp, n_cover);
+    const auto t_1 = std::chrono::steady_clock::now();
+    S.t_merge += std::chrono::duration<double>(t_1 - t_0).count();
+    struct Tail { Scratch &S; std::chrono::steady_clock::time_point t; ~Tail() { S.t_gates += std::chrono::duration<double>(std::chrono::steady_clock::now() - t).count(); } } tail{S, t_1};
     // a window that stops at a gate keeps its tables only when the caller asked for them (JSON side files, mp_plan_window_table)
     auto stop = [&](int32_t status) {
         w.status = status;
@@ -801,6 +809,7 @@ static int plan_create_body(mp_plan *p, const EntryInput &E, int64_t n_exc, cons
     const double max_exp = 1 << 22;            // expansions of one exception k-mer the host is willing to enumerate
     std::atomic<int> next{0}, failed{0};       // failed: 0 or the MP_ERR_* code of the first failure
     const int n_thr = resolve_threads(P.n_threads, W);
+    std::atomic<long long> us_sights{0}, us_merge{0}, us_sort{0}, us_rest{0};      // MP_TRACE: thread time per phase
     auto work = [&]() {
         Scratch scratch;
         std::vector<Sight> &sights = scratch.sights;
@@ -808,6 +817,7 @@ static int plan_create_body(mp_plan *p, const EntryInput &E, int64_t n_exc, cons
             int w = next.fetch_add(1);
             if (w >= W || failed.load()) break;
             if (E.ready) E.ready->wait_for(w); // streamed read-back: this window's entries may still be on their way
+            const auto t_w0 = std::chrono::steady_clock::now();
             sights.clear();
             for (int64_t t = eoff[(size_t)w]; t < eoff[(size_t)w + 1]; t++) {
                 const int64_t i = e_sorted ? t : eidx[(size_t)t];
@@ -848,6 +858,7 @@ static int plan_create_body(mp_plan *p, const EntryInput &E, int64_t n_exc, cons
                 }
             }
             if (failed.load()) break;
+            scratch.t_sights += std::chrono::duration<double>(std::chrono::steady_clock::now() - t_w0).count();
             int rc = plan_window(p, w, scratch, n_exc_cover, n_exp, freq + (size_t)w * 4 * k, nn + (size_t)w * (k - 1) * 16);
             if (rc != MP_OK) { int zero = 0; failed.compare_exchange_strong(zero, rc); break; }
             if (!P.keep_tables && p->win[(size_t)w].status != MP_WIN_PLANNED) {
@@ -857,6 +868,8 @@ static int plan_create_body(mp_plan *p, const EntryInput &E, int64_t n_exc, cons
                 std::vector<int32_t>().swap(ww.cover_map.slot);
             }
         }
+        us_sights += (long long)(scratch.t_sights * 1e6); us_merge += (long long)((scratch.t_merge - scratch.t_sort) * 1e6);
+        us_sort += (long long)(scratch.t_sort * 1e6); us_rest += (long long)(scratch.t_gates * 1e6);
     };
     auto worker = [&]() {                      // an exception must not leave a thread (std::terminate) nor cross the C boundary
         try {
@@ -876,6 +889,9 @@ static int plan_create_body(mp_plan *p, const EntryInput &E, int64_t n_exc, cons
         for (auto &t : th) t.join();
     }
     if (failed.load()) return failed.load();
+    if (getenv("MP_TRACE"))
+        fprintf(stderr, "[mprime] plan: %d threads; thread time: sightings %.2f ms, merge %.2f ms, order %.2f ms, gates + chains %.2f ms\n", n_thr,
+                us_sights.load() / 1e3, us_merge.load() / 1e3, us_sort.load() / 1e3, us_rest.load() / 1e3);
     for (int w = 0; w < W; w++) {
         Window &ww = p->win[(size_t)w];
         if (ww.status != MP_WIN_PLANNED) continue;

@@ -179,17 +179,21 @@ def expand_kmer_words(codes: np.ndarray):
     n, k = codes.shape
     d = dll()
     need = C.c_int64(0)
-    rc = d.mp_expand_kmer_words(k, n, _ptr(codes), 0, None, None, C.byref(need))
-    if rc not in (0, MP_ERR_CAPACITY):
+    wt = np.uint32 if k <= 31 else np.uint64
+    # one call when the guess holds (exception k-mers carry one or two IUPAC codes: 2-4 expansions each), else the size, then the call
+    m = 4 * n + 1024
+    for _ in range(2):
+        words = np.empty((max(m, 1), 3), wt)
+        src = np.empty(max(m, 1), np.int64)
+        rc = d.mp_expand_kmer_words(k, n, _ptr(codes), m, _ptr(words), _ptr(src), C.byref(need))
+        if rc != MP_ERR_CAPACITY:
+            break
+        m = need.value
+        if m > 1 << 28:
+            raise MprimeError(MP_ERR_CAPACITY, f"IUPAC k-mers expand to {m} concrete k-mers")
+    if rc != 0:
         raise MprimeError(rc, "mp_expand_kmer_words: bad symbol codes or too many expansions")
     m = need.value
-    if m > 1 << 28:
-        raise MprimeError(MP_ERR_CAPACITY, f"IUPAC k-mers expand to {m} concrete k-mers")
-    words = np.empty((max(m, 1), 3), np.uint32 if k <= 31 else np.uint64)
-    src = np.empty(max(m, 1), np.int64)
-    rc = d.mp_expand_kmer_words(k, n, _ptr(codes), m, _ptr(words), _ptr(src), C.byref(need))
-    if rc != 0:
-        raise MprimeError(rc, "mp_expand_kmer_words")
     return words[:m], src[:m]
 
 
