@@ -87,18 +87,21 @@ def test_streamed_planning_equals_blocking_read_back(name, hip_lib, tmp_path, mo
     same plan tables as the two blocking calls (MP_PLAN_STREAM=0), window by window."""
     want = open(os.path.join(GOLDEN, name + ".tsv"), "rb").read()
     plans = {}
-    for mode in ("1", "0"):
-        monkeypatch.setenv("MP_PLAN_STREAM", mode)
+    for mode in ("1", "0", "1-staged", "0-staged"):
+        monkeypatch.setenv("MP_PLAN_STREAM", mode[0])
+        if mode.endswith("staged"):              # neither registered transfers nor parallel page faults: the runtime's staging path
+            monkeypatch.setenv("MP_NO_PIN", "1")
+            monkeypatch.setenv("MP_NO_PREFAULT", "1")
         d = tmp_path / mode
         d.mkdir()
         app, out = run_fixture(name, hip_lib, d, write_json=False)
         assert out.read_bytes() == want, f"TSV differs from the reference's with MP_PLAN_STREAM={mode}"
-        assert (app._dev_entries is None) == (mode == "1")
+        assert (app._dev_entries is None) == (mode[0] == "1")
         st, cn, gn, cb, tb = app.plan.windows()
         plans[mode] = (st.tolist(), cn.tolist(), gn.tolist(), [repr(x) for x in cb.tolist()], [repr(x) for x in tb.tolist()],
                        [a.tolist() for a in app.plan.candidates()])
         app.ctx.close()
-    assert plans["1"] == plans["0"]
+    assert plans["1"] == plans["0"] == plans["1-staged"] == plans["0-staged"]
 
 
 def _side_bytes(out):
