@@ -161,6 +161,17 @@ int mp_plan_write_side_files_part(const mp_plan *p, int32_t n_out, const int32_t
 /* Expansions of n k-mers of symbol codes (degenerate_seq, V20:368-380) in the reference's order; out_src[i] = index
  * of the k-mer expansion i comes from.  *n_out returns the number needed; MP_ERR_CAPACITY if cap is too small. */
 int mp_expand_kmers(int32_t k, int64_t n, const uint8_t *codes, int64_t cap, uint8_t *out_codes, int64_t *out_src, int64_t *n_out);
+/* (H4) the per-primer numbers of the TSV for all output primers at once (csrc/primerstats.cpp): primer i = codes[i*k .. i*k+k), IUPAC symbol
+ * codes, no gaps, at most 2^22 expansions each.
+ * mp_primer_tm: tm[i] = round(mean over the expansions e of round(Calc_Tm_v2(e), 2), 2) (V20:849-852, 282-336).  `params` holds the
+ *   reference's tables and constants as its own expressions evaluate them (multiprime_amd/thermo.py): dH[cur][prev] (16), dS[cur][prev] (16),
+ *   dH of an end base A,C,G,T (4), dS of an end base (4), the symmetry term of dS, R ln(c) for a self-complementary and for any other
+ *   sequence, the salt correction, 273.15 — 45 doubles.  Python's round() and statistics.mean (exact) are reproduced bit for bit.
+ * mp_primer_filters: gc[i] = round(mean of r3[#G+#C of e], 2) with r3[g] = round(g / k, 3) supplied by the caller (k + 1 doubles,
+ *   V20:401-407), repeat[i] = di_nucleotide (V20:410-416), hairpin[i] = hairpin_check at `distance` (V20:387-398). */
+int mp_primer_tm(int32_t k, int64_t n, const uint8_t *codes, const double *params, double *tm);
+int mp_primer_filters(int32_t k, int64_t n, const uint8_t *codes, const double *r3, int32_t distance, double *gc, uint8_t *repeat, uint8_t *hairpin);
+
 /* The same expansions as window words (b0, b1, g of mprime.h, three per expansion) — what mp_set_extra_rows takes. */
 int mp_expand_kmer_words(int32_t k, int64_t n, const uint8_t *codes, int64_t cap, void *out_words, int64_t *out_src,
                          int64_t *n_out);

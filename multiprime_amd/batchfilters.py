@@ -79,8 +79,28 @@ def _round2(x: np.ndarray) -> np.ndarray:
     return r
 
 
+_TM_PARAMS = np.concatenate([np.asarray(thermo._DH, np.float64).reshape(-1), np.asarray(thermo._DS, np.float64).reshape(-1),
+                             np.asarray([thermo._DH_END[b] for b in "ACGT"], np.float64), np.asarray([thermo._DS_END[b] for b in "ACGT"], np.float64),
+                             np.asarray([thermo._DS_SYMMETRY, thermo._LN_CONC_A, thermo._LN_CONC_B, thermo.SALT_CORRECTION, thermo.KELVIN], np.float64)])
+
+
 def tm_of_primers(codes: np.ndarray):
-    """[round(mean(Calc_Tm_v2 over the expansions), 2)] per primer (V20:849-852, 282-336)."""
+    """[round(mean(Calc_Tm_v2 over the expansions), 2)] per primer (V20:849-852, 282-336): one call of the native host stage
+    (mp_primer_tm, csrc/primerstats.cpp).  tm_of_primers_numpy is the same computation on numpy arrays; tests compare the two and both
+    with the scalar thermo.tm."""
+    codes = np.ascontiguousarray(codes, np.uint8)
+    n, k = codes.shape
+    if n == 0:
+        return []
+    out = np.empty(n, np.float64)
+    rc = host.dll().mp_primer_tm(k, n, host._ptr(codes), host._ptr(_TM_PARAMS), host._ptr(out))
+    if rc != 0:
+        raise host.MprimeError(rc, "mp_primer_tm: a primer holds a gap / unknown symbol or has too many expansions")
+    return out.tolist()
+
+
+def tm_of_primers_numpy(codes: np.ndarray):
+    """tm_of_primers on numpy arrays (rounds 2-3; kept as the cross-check of the native form)."""
     n, k = codes.shape
     if n == 0:
         return []
@@ -153,12 +173,24 @@ def hairpin_of_primers(codes: np.ndarray, distance: int) -> np.ndarray:
     return hit
 
 
-def information_of_primers(codes: np.ndarray, gc_range, distance: int):
-    """filters.pre_filter per primer (primer_pre_filter, V20:507-521): the TSV's "Information" column."""
+def information_of_primers(codes: np.ndarray, gc_range, distance: int, native: bool = True):
+    """filters.pre_filter per primer (primer_pre_filter, V20:507-521): the TSV's "Information" column.  The three inputs — GC fraction,
+    repeat, hairpin — come from one call of the native host stage (mp_primer_filters); native=False takes them from the numpy forms
+    above (the cross-check in tests/test_batchfilters.py)."""
     lo, hi = float(gc_range[0]), float(gc_range[1])
-    gcs = gc_of_primers(codes)
-    rep = repeat_of_primers(codes).tolist()
-    hp = hairpin_of_primers(codes, distance).tolist()
+    codes = np.ascontiguousarray(codes, np.uint8)
+    n, k = codes.shape
+    if native and n:
+        r3 = np.asarray([round(g / k, 3) for g in range(k + 1)], np.float64)
+        gc_a, rep_a, hp_a = np.empty(n, np.float64), np.empty(n, np.uint8), np.empty(n, np.uint8)
+        rc = host.dll().mp_primer_filters(k, n, host._ptr(codes), host._ptr(r3), int(distance), host._ptr(gc_a), host._ptr(rep_a), host._ptr(hp_a))
+        if rc != 0:
+            raise host.MprimeError(rc, "mp_primer_filters: a primer holds a gap / unknown symbol or has too many expansions")
+        gcs, rep, hp = gc_a.tolist(), rep_a.astype(bool).tolist(), hp_a.astype(bool).tolist()
+    else:
+        gcs = gc_of_primers(codes)
+        rep = repeat_of_primers(codes).tolist()
+        hp = hairpin_of_primers(codes, distance).tolist()
     out = []
     for gc, r, h in zip(gcs, rep, hp):
         info = []

@@ -1,0 +1,210 @@
+// primerstats.cpp — part of libmprime_hip.so: the per-primer numbers of the core step's TSV behind include/mprime_host.h (H4) — melting
+// temperature and the "Information" column's inputs of ALL output primers of an alignment in one call.  Plain C++17 on the host (a few
+// hundred primers, a few thousand expansions).  "V20" = scripts/multiPrime-core_V20.py.
+//
+// Everything that decides a digit is done the way the reference's Python does it, so that the TSV stays byte-identical:
+//   * the nearest-neighbour sums are the same left-to-right double additions per expansion (V20:249-261), the closing formula is plain
+//     IEEE arithmetic (V20:328-336; the translation unit is built with -ffp-contract=off), the tables and constants come from the caller
+//     (multiprime_amd/thermo.py evaluates them with the reference's own expressions);
+//   * round(x, 2) is Python's: the double nearest to the correctly rounded two-decimal value of the exact binary x (printf's %.2f is
+//     correctly rounded too; rint(100 x) / 100 is the same double away from a tie and is what runs unless 100 x lies within 1e-6 of one);
+//   * statistics.mean over a primer's expansions is exact: the doubles are integers times one power of two, summed in 128 bits, and the
+//     one division is rounded to nearest-even like Python's int / int.
+#include "../../include/mprime.h"
+#include "../../include/mprime_host.h"
+
+#include <cmath>
+#include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <vector>
+
+namespace {
+
+constexpr int kMaxLen = 64;
+
+// members of a symbol in the reference's enumeration order (degenerate_base, V20:105-107), as base indices A=0 C=1 G=2 T=3
+struct Members { int n; int b[4]; };
+const Members kMembers[16] = {
+    {0, {0, 0, 0, 0}},        // '-' (not a primer symbol)
+    {1, {0, 0, 0, 0}},        // A
+    {1, {1, 0, 0, 0}},        // C
+    {2, {0, 1, 0, 0}},        // M = AC
+    {1, {2, 0, 0, 0}},        // G
+    {2, {0, 2, 0, 0}},        // R = AG
+    {2, {2, 1, 0, 0}},        // S = GC
+    {3, {2, 0, 1, 0}},        // V = GAC
+    {1, {3, 0, 0, 0}},        // T
+    {2, {0, 3, 0, 0}},        // W = AT
+    {2, {1, 3, 0, 0}},        // Y = CT
+    {3, {0, 3, 1, 0}},        // H = ATC
+    {2, {2, 3, 0, 0}},        // K = GT
+    {3, {2, 0, 3, 0}},        // D = GAT
+    {3, {2, 3, 1, 0}},        // B = GTC
+    {4, {0, 3, 2, 1}},        // N = ATGC
+};
+
+double py_round2(double x) {
+    if (!std::isfinite(x)) return x;
+    const double y = x * 100.0;
+    if (std::fabs(y) < 4e9) {                               // below 2^32 the product is off by < 1e-6
+        const double fr = std::fabs(y - std::floor(y));
+        if (std::fabs(fr - 0.5) > 1e-6) return std::rint(y) / 100.0;
+    }
+    char buf[64];
+    snprintf(buf, sizeof buf, "%.2f", x);
+    return strtod(buf, nullptr);
+}
+
+// exact mean of finite doubles: false when the values do not fit the 128-bit sum (the caller falls back to Python's rationals)
+bool exact_mean(const std::vector<double> &v, double &out) {
+    if (v.empty()) return false;
+    int emin = 0;
+    bool any = false;
+    std::vector<int64_t> mant(v.size());
+    std::vector<int> ex(v.size());
+    for (size_t i = 0; i < v.size(); i++) {
+        if (!std::isfinite(v[i])) return false;
+        int e = 0;
+        const double f = std::frexp(v[i], &e);
+        mant[i] = (int64_t)std::ldexp(f, 53);                // exact: |f| < 1
+        ex[i] = e - 53;
+        if (mant[i] != 0 && (!any || ex[i] < emin)) { emin = ex[i]; any = true; }
+    }
+    if (!any) { out = 0.0; return true; }
+    __int128 sum = 0;
+    for (size_t i = 0; i < v.size(); i++) {
+        if (mant[i] == 0) continue;
+        const int sh = ex[i] - emin;
+        if (sh > 40) return false;
+        sum += (__int128)mant[i] << sh;
+    }
+    if (v.size() >= ((size_t)1 << 30)) return false;
+    const bool neg = sum < 0;
+    unsigned __int128 a = neg ? (unsigned __int128)(-sum) : (unsigned __int128)sum;
+    if (a == 0) { out = 0.0; return true; }
+    const uint64_t n = (uint64_t)v.size();
+    auto bitlen = [](unsigned __int128 x) { int b = 0; while (x) { b++; x >>= 1; } return b; };
+    const int la = bitlen(a);
+    int s = 64 + bitlen(n) - la;
+    if (s < 0) s = 0;
+    if (la + s > 126) return false;
+    const unsigned __int128 num = a << s;
+    unsigned __int128 q = num / n;
+    const bool rem = (num % n) != 0;
+    const int lq = bitlen(q);
+    const int drop = lq - 53;
+    if (drop <= 0) return false;                              // (cannot happen: the quotient has at least 63 bits)
+    const unsigned __int128 half = (unsigned __int128)1 << (drop - 1), low = q & (((unsigned __int128)1 << drop) - 1);
+    uint64_t q53 = (uint64_t)(q >> drop);
+    if (low > half || (low == half && (rem || (q53 & 1)))) q53++;
+    const double r = std::ldexp((double)q53, drop - s + emin);
+    out = neg ? -r : r;
+    return true;
+}
+
+// every expansion of codes[0..k): f(base indices) — order does not matter to the callers (they take exact means)
+template <typename F>
+void for_each_expansion(const uint8_t *codes, int k, F &&f) {
+    int idx[kMaxLen] = {0}, cur[kMaxLen];
+    for (int j = 0; j < k; j++) cur[j] = kMembers[codes[j]].b[0];
+    for (;;) {
+        f(cur);
+        int j = k - 1;
+        for (; j >= 0; j--) {
+            const Members &m = kMembers[codes[j]];
+            if (++idx[j] < m.n) { cur[j] = m.b[idx[j]]; break; }
+            idx[j] = 0;
+            cur[j] = m.b[0];
+        }
+        if (j < 0) break;
+    }
+}
+
+bool usable(const uint8_t *codes, int k, double limit) {
+    double d = 1;
+    for (int j = 0; j < k; j++) {
+        if (codes[j] == 0 || codes[j] > 15) return false;
+        d *= kMembers[codes[j]].n;
+    }
+    return d <= limit;
+}
+
+}  // namespace
+
+extern "C" {
+
+// params: [0..16) dH[cur][prev], [16..32) dS[cur][prev], [32..36) dH of an end base, [36..40) dS of an end base, [40] dS symmetry term,
+// [41] R ln(c) of a self-complementary sequence, [42] of any other, [43] salt correction, [44] 273.15
+int mp_primer_tm(int32_t k, int64_t n, const uint8_t *codes, const double *params, double *tm) {
+    if (k < 2 || k > kMaxLen || n < 0 || (n && (!codes || !tm)) || !params) return MP_ERR_ARG;
+    const double *DH = params, *DS = params + 16, *DHE = params + 32, *DSE = params + 36;
+    const double ds_sym = params[40], ln_a = params[41], ln_b = params[42], salt = params[43], kelvin = params[44];
+    std::vector<double> vals;
+    for (int64_t i = 0; i < n; i++) {
+        const uint8_t *c = codes + (size_t)i * k;
+        if (!usable(c, k, 1 << 22)) return MP_ERR_ARG;
+        vals.clear();
+        for_each_expansion(c, k, [&](const int *b) {
+            double dh = 0, ds = 0;
+            for (int t = 1; t < k; t++) { dh += DH[b[t] * 4 + b[t - 1]]; ds += DS[b[t] * 4 + b[t - 1]]; }      // V20:253-256
+            dh += DHE[b[0]] + DHE[b[k - 1]];
+            ds += DSE[b[0]] + DSE[b[k - 1]];
+            bool sym = (k % 2) == 0;                                                                            // V20:237-246
+            for (int t = 0; sym && t < k / 2; t++) sym = b[t] == 3 - b[k / 2 + t];
+            if (sym) ds = ds + ds_sym;
+            dh = dh * 1000;
+            const double ln_c = sym ? ln_a : ln_b;
+            vals.push_back(py_round2(1 / ((1 / (dh / (ds + ln_c))) + salt) - kelvin));                          // V20:336, rounded per expansion
+        });
+        double mean;
+        if (!exact_mean(vals, mean)) return MP_ERR_CAPACITY;
+        tm[i] = py_round2(mean);                                                                                 // V20:852
+    }
+    return MP_OK;
+}
+
+// gc[i] = round(mean over the expansions of r3[number of G/C], 2) with r3[g] = round(g / k, 3) from the caller (V20:401-407);
+// repeat[i] = di_nucleotide (V20:410-416), hairpin[i] = hairpin_check with `distance` (V20:387-398), both as statements about the
+// positions' base sets (an expansion picks one base per position independently)
+int mp_primer_filters(int32_t k, int64_t n, const uint8_t *codes, const double *r3, int32_t distance, double *gc, uint8_t *repeat, uint8_t *hairpin) {
+    if (k < 1 || k > kMaxLen || n < 0 || distance < 0 || (n && (!codes || !gc || !repeat || !hairpin)) || !r3) return MP_ERR_ARG;
+    auto comp = [](uint32_t m) { return ((m & 1u) << 3) | ((m & 2u) << 1) | ((m & 4u) >> 1) | ((m & 8u) >> 3); };
+    std::vector<double> vals;
+    for (int64_t i = 0; i < n; i++) {
+        const uint8_t *M = codes + (size_t)i * k;
+        if (!usable(M, k, 1 << 22)) return MP_ERR_ARG;
+        vals.clear();
+        for_each_expansion(M, k, [&](const int *b) {
+            int g = 0;
+            for (int j = 0; j < k; j++) g += b[j] == 1 || b[j] == 2;
+            vals.push_back(r3[g]);
+        });
+        double mean;
+        if (!exact_mean(vals, mean)) return MP_ERR_CAPACITY;
+        gc[i] = py_round2(mean);
+        bool rep = false;
+        for (int o = 0; o + 3 < k && !rep; o++) rep = (M[o] & M[o + 1] & M[o + 2] & M[o + 3]) != 0;                       // XXXX
+        for (int o = 0; o + 7 < k && !rep; o++) {                                                                          // (XY) x 4, X != Y
+            const uint32_t a = M[o] & M[o + 2] & M[o + 4] & M[o + 6], b = M[o + 1] & M[o + 3] & M[o + 5] & M[o + 7];
+            rep = a != 0 && b != 0 && !(a == b && __builtin_popcount(a) == 1);
+        }
+        for (int o = 0; o + 8 < k && !rep; o++) {                                                                          // (XYZ) x 3, X != Y, Y != Z
+            const uint32_t a = M[o] & M[o + 3] & M[o + 6], b = M[o + 1] & M[o + 4] & M[o + 7], c = M[o + 2] & M[o + 5] & M[o + 8];
+            for (uint32_t y = 1; y < 16 && !rep; y <<= 1) rep = (b & y) != 0 && (a & ~y & 15u) != 0 && (c & ~y & 15u) != 0;
+        }
+        repeat[i] = rep;
+        bool hp = false;
+        for (int s = 0; s <= k - 5 - 5 - distance && !hp; s++)
+            for (int o = s + 5 + distance; o < k - 4 && !hp; o++) {
+                bool ok = true;
+                for (int j = 0; j < 5 && ok; j++) ok = (comp(M[s + 4 - j]) & M[o + j]) != 0;      // RC(stem)[j] = comp(stem[4 - j]) lies in the set at o + j
+                hp = ok;
+            }
+        hairpin[i] = hp;
+    }
+    return MP_OK;
+}
+
+}  // extern "C"

@@ -52,6 +52,8 @@ HOST_SYMBOLS = [
                                                 _p, _p, _p, _p, _p, C.c_char_p, C.c_char_p, C.c_int32]),
     ("mp_expand_kmer_words", C.c_int, [C.c_int32, C.c_int64, _p, C.c_int64, _p, _p, C.POINTER(C.c_int64)]),
     ("mp_expand_kmers", C.c_int, [C.c_int32, C.c_int64, _p, C.c_int64, _p, _p, C.POINTER(C.c_int64)]),
+    ("mp_primer_tm", C.c_int, [C.c_int32, C.c_int64, _p, _p, _p]),
+    ("mp_primer_filters", C.c_int, [C.c_int32, C.c_int64, _p, _p, C.c_int32, _p, _p, _p]),
 ]
 
 _dll = None

@@ -35,15 +35,16 @@ def random_primers(seed, n, k, p_deg):
     return out
 
 
-@pytest.mark.parametrize("k,seed", [(14, 1), (18, 2), (18, 3), (22, 4), (27, 5)])
+@pytest.mark.parametrize("k,seed", [(14, 1), (18, 2), (18, 3), (22, 4), (27, 5), (36, 6), (45, 7), (63, 8)])
 def test_batch_equals_scalar(k, seed):
-    prim = random_primers(seed, 600, k, 0.06)
+    prim = random_primers(seed, 600 if k <= 27 else 150, k, 0.06)
     codes = iupac.MASK_LUT[np.frombuffer("".join(prim).encode(), np.uint8)].reshape(len(prim), k)
     want_tm = []
     for p in prim:
         tms = [thermo.tm(e) for e in iupac.expand(p)]
         want_tm.append(round(iupac.exact_mean(tms), 2))
-    assert batchfilters.tm_of_primers(codes) == want_tm
+    assert batchfilters.tm_of_primers(codes) == want_tm                       # the native host stage (mp_primer_tm)
+    assert batchfilters.tm_of_primers_numpy(codes) == want_tm                 # the same on numpy arrays
     assert batchfilters.gc_of_primers(codes) == [filters.gc_fraction(p) for p in prim]
     want_rep = [filters.has_repeat(p) for p in prim]
     assert batchfilters.repeat_of_primers(codes).tolist() == want_rep and any(want_rep) and not all(want_rep)
@@ -51,8 +52,28 @@ def test_batch_equals_scalar(k, seed):
         want_hp = [filters.has_hairpin(p, d) for p in prim]
         assert batchfilters.hairpin_of_primers(codes, d).tolist() == want_hp
     assert any(filters.has_hairpin(p, 4) for p in prim)
-    got = batchfilters.information_of_primers(codes, ["0.2", "0.7"], 4)
-    assert [str(x) for x in got] == [str(filters.pre_filter(p, ["0.2", "0.7"], 4)) for p in prim]
+    want_info = [str(filters.pre_filter(p, ["0.2", "0.7"], 4)) for p in prim]
+    for native in (True, False):                                              # mp_primer_filters / the numpy forms checked above
+        got = batchfilters.information_of_primers(codes, ["0.2", "0.7"], 4, native=native)
+        assert [str(x) for x in got] == want_info
+        got3 = batchfilters.information_of_primers(codes, ["0.35", "0.55"], 3, native=native)
+        assert [str(x) for x in got3] == [str(filters.pre_filter(p, ["0.35", "0.55"], 3)) for p in prim]
+
+
+def test_native_mean_and_rounding_on_tie_heavy_values():
+    """mp_primer_tm's two exactness devices on their own: primers whose expansions' Tm values average to something close to a
+    two-decimal tie must round like Python (exact mean, then round-half-even on the exact binary value)."""
+    rng = np.random.default_rng(11)
+    k = 16
+    prim = []
+    for _ in range(3000):
+        s = list(rng.choice(list("ACGT"), size=k))
+        for j in rng.choice(k, size=int(rng.integers(1, 4)), replace=False):
+            s[j] = "RYMKSW"[int(rng.integers(0, 6))]                          # 2, 4 or 8 expansions: means land on x.xx5 often
+        prim.append("".join(s))
+    codes = iupac.MASK_LUT[np.frombuffer("".join(prim).encode(), np.uint8)].reshape(len(prim), k)
+    want = [round(iupac.exact_mean([thermo.tm(e) for e in iupac.expand(p)]), 2) for p in prim]
+    assert batchfilters.tm_of_primers(codes) == want
 
 
 def test_segmented_exact_means_equal_statistics_mean():
