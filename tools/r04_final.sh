@@ -21,3 +21,13 @@ timeout 300 python tools/pipeline_scale.py --rows 1048576 > $O/pipeline_scale_1m
 timeout 900 python tools/multi_cluster.py --clusters 16 --max-rows 5000 --check > $O/config5_check.json 2> $O/config5_check.err; echo "config5 check rc=$?"; tail -c 400 $O/config5_check.json
 timeout 300 python tools/soak_parity.py --seconds 150 > $O/soak.txt 2>&1; tail -2 $O/soak.txt
 timeout 200 python tools/soak_primers.py --seconds 60 >> $O/soak.txt 2>&1; tail -1 $O/soak.txt
+# the real step's host side: run() laps at 131072 x 1000, transfer micro-benchmark, batch throughput
+(echo "# NN_degenerate.run() at 131072 x 1000, k=18 (tools/profile_run.py: second run of the process, fresh context): stats in ms, then the laps of the Python side (MP_TRACE_PY) and of the library (MP_TRACE)"
+ for i in 1 2 3; do python tools/profile_run.py 131072 2>&1 | head -1; done
+ echo "# MP_PLAN_STREAM=0 (blocking read-back, then planning)"; MP_PLAN_STREAM=0 python tools/profile_run.py 131072 2>&1 | head -1
+ echo "# MP_NO_PIN=1 MP_NO_PREFAULT=1 MP_PLAN_STREAM=0 (the round-3 transfer path)"; MP_NO_PIN=1 MP_NO_PREFAULT=1 MP_PLAN_STREAM=0 python tools/profile_run.py 131072 2>&1 | head -1
+ echo "# laps"; MP_TRACE_PY=1 MP_TRACE=1 python tools/profile_run.py 131072 2>&1 | grep "^\[core\]\|^\[mprime\]" | tail -48) > $O/run_laps.txt 2>&1
+mkdir -p tools/_build && /opt/rocm/bin/hipcc --offload-arch=gfx950 -O2 -pthread -Wno-unused-value tools/ubench/d2h_bench.hip -o tools/_build/d2h_big 2> /dev/null
+(echo "# tools/ubench/d2h_bench.hip on the MI355X box: 58 MB device -> host into memory of different kinds"; ./tools/_build/d2h_big) > $O/d2h_bench.txt 2>&1
+timeout 600 python tools/batch_bench.py --clusters 64 --rows 500 --workers 4,2x2,2x4 > $O/batch64.txt 2>&1
+timeout 600 python tools/batch_bench.py --clusters 256 --rows 500 --no-per-cluster --workers 4,2x4,3x4 > $O/batch256.txt 2>&1; tail -c 500 $O/batch256.txt

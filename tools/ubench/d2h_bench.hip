@@ -1,5 +1,5 @@
 // d2h_bench.hip — how fast do 58 MB come off the device into host memory of different kinds?  (tools/ubench: measurements behind
-// mp_plan_create_streamed's choice of buffer; hipcc --offload-arch=gfx950 -O2 d2h_bench.hip -o d2h_bench)
+// mp_plan_create_streamed's choice of buffer; hipcc --offload-arch=gfx950 -O2 -pthread tools/ubench/d2h_bench.hip -o tools/_build/d2h_big)
 #include <hip/hip_runtime.h>
 #include <sys/mman.h>
 #include <chrono>
