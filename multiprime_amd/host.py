@@ -69,6 +69,8 @@ def dll():
                                   "the host stage has no Python fallback")
         d = C.CDLL(path)
         for name, res, args in HOST_SYMBOLS:
+            if name == "mp_plan_create_streamed" and not hasattr(d, name):
+                continue                   # a host-only build (MP_HOST_LIB): the entry point that takes a device context lives in unique.hip
             fn = getattr(d, name)
             fn.restype = res
             fn.argtypes = args
