@@ -5,9 +5,11 @@
 //   row's k-mer from the eight plane words that cover the window (winwords.hpp; next iteration's words are already in
 //   flight), the wave folds the k-mer of its first lane (conserved windows put the same k-mer in almost every lane) and
 //   the remaining lanes insert theirs in parallel into an LDS table {key, count, first row} with 64-bit ds_cmpst.  The LDS
-//   table is a write-combining front of the window's table in HBM: when it fills up, and at the end of the slice, its
-//   entries are merged into the global table with 64-bit CAS / add / min atomics — no overflow path, any number of
-//   distinct k-mers per slice.  compact_kernel then lays the occupied slots out as per-window entry segments.
+//   table is a write-combining front of the window's table in HBM: at the end of the slice its entries are merged into the
+//   global table with 64-bit CAS / add / min atomics; a key that finds neither itself nor a free slot within 24 probes of its
+//   hash (more distinct k-mers in a slice than the table takes) goes to the global table directly — any number of distinct
+//   k-mers per slice, and no barrier in the row loop ([r4]; rounds 2-3 met at one per iteration to decide about a mid-way flush:
+//   0.77 -> 0.72 ms).  compact_kernel then lays the occupied slots out as per-window entry segments.
 //   (Round 1 stored a [W][Npad] u64 array of window words first and ran ONE workgroup per window over it: 1.5 s at
 //   10^6 rows.)
 // k >= 22 — unique_kernel: one workgroup per window, LDS table of representative rows; keys are compared by
@@ -130,17 +132,15 @@ __device__ inline void flush_table(const HistArgs &A, int w, unsigned long long 
     }
 }
 
-// SLOTS x 16 bytes of LDS per workgroup decide how many workgroups a CU holds (160 KB: 4 at 2048 slots — the table plus the fill
-// counter is 8 bytes over 32 KB); CHECK = iterations (of 1024 rows) between two fill checks (each costs the workgroup a barrier); the
-// table is flushed above SLOTS - CHECK * 1024 - 128 entries: the next CHECK iterations add at most CHECK * 1024 keys.
+// SLOTS x 16 bytes of LDS per workgroup decide how many workgroups a CU holds (160 KB: 5 at 2048 slots).  kMaxProbe bounds a key's
+// walk through the LDS table: beyond it the key is not there, and if no free slot turned up either it goes to the table in HBM.
 template <int SLOTS, int CHECK>
 __global__ __launch_bounds__(kBlock) void hist_kernel(const HistArgs A) {
-    constexpr int kLdsSlots = SLOTS, kCheckEvery = CHECK, kLdsLimit = SLOTS - CHECK * kBlock * 4 - 128;     // 4 rows per thread and iteration
-    static_assert(kLdsLimit >= 256, "the table must hold a few iterations' keys");
+    constexpr int kLdsSlots = SLOTS, kMaxProbe = 24;
+    (void)CHECK;                                          // (the fill-check period of rounds 2-3; kept in the kernel's name for the profiles)
     __shared__ unsigned long long s_key[kLdsSlots];
     __shared__ uint32_t s_cnt[kLdsSlots];
     __shared__ uint32_t s_min[kLdsSlots];
-    __shared__ int s_used;
     // workgroup b runs on XCD b % 8 and every XCD has its own L2: an XCD owns a band of consecutive windows and walks it
     // window-fastest, so the workgroups resident on it at any time read the same few 32-column chunks of one row slice
     const int xcd = blockIdx.x & 7, q = blockIdx.x >> 3;
@@ -156,7 +156,6 @@ __global__ __launch_bounds__(kBlock) void hist_kernel(const HistArgs A) {
     auto stamp = [&](int i) { if (A.prof && threadIdx.x == 0) A.prof[(size_t)blockIdx.x * 8 + i] = clock64(); };
     stamp(0);
     for (int i = threadIdx.x; i < kLdsSlots; i += kBlock) { s_key[i] = kNoKey; s_cnt[i] = 0; s_min[i] = kEmpty; }
-    if (threadIdx.x == 0) s_used = 0;
     __syncthreads();
     stamp(1);
     const int lane = threadIdx.x & 63;
@@ -184,7 +183,6 @@ __global__ __launch_bounds__(kBlock) void hist_kernel(const HistArgs A) {
     auto hash_rows = [&](const Rows &R, int r4, int iter) {
         const u32x4 (&cw)[8] = R.w;
         const u32x4 len4 = R.len;
-        unsigned long long claims = 0;
         const bool mine = r4 < r1;
         // (1) straight-line: the window words of the thread's four rows (a lane without rows computes on stale registers and is masked
         // by `ok`); per row index u the first live lane's k-mer comes through v_readlane (no LDS round trip) and the lanes that carry
@@ -216,32 +214,28 @@ __global__ __launch_bounds__(kBlock) void hist_kernel(const HistArgs A) {
         for (int u = 0; u < RPT; u++) old[u] = todo[u] ? atomicCAS(&s_key[h[u]], kNoKey, key[u]) : key[u];
 #pragma unroll
         for (int u = 0; u < RPT; u++) {
-            bool claimed = false;
             if (todo[u]) {
                 const uint32_t row = (uint32_t)(r4 + u);
-                if (old[u] == kNoKey) { claimed = true; old[u] = key[u]; }
+                if (old[u] == kNoKey) old[u] = key[u];
                 uint32_t hh = h[u];
-                while (old[u] != key[u]) {
+                // a key sits within kMaxProbe slots of its hash or not in the LDS table at all: when the walk finds neither the key
+                // nor a free slot (a workgroup's rows hold more distinct k-mers than the table takes), the key goes to the window's
+                // table in HBM directly.  No fill count, no check, no barrier in the row loop (round 4; until then the workgroup met at
+                // a barrier every iteration to see whether the table had to be flushed: the waves of a workgroup ran in lock step)
+                for (int probe = 0; old[u] != key[u] && probe < kMaxProbe; probe++) {
                     hh = (hh + 1) & (kLdsSlots - 1);
                     old[u] = atomicCAS(&s_key[hh], kNoKey, key[u]);
-                    if (old[u] == kNoKey) { claimed = true; old[u] = key[u]; }
+                    if (old[u] == kNoKey) old[u] = key[u];
                 }
-                atomicAdd(&s_cnt[hh], cnt[u]);
-                atomicMin(&s_min[hh], row);
-            }
-            claims += __popcll(__ballot(claimed));
-        }
-        // one fill-count update per wave and iteration, not one per claimed slot (they all hit the same LDS word)
-        if (claims && lane == 0) atomicAdd(&s_used, (int)claims);
-        if (iter % kCheckEvery == kCheckEvery - 1) {
-            __syncthreads();
-            if (s_used > kLdsLimit) {                 // uniform: read after the barrier
-                flush();
-                __syncthreads();
-                if (threadIdx.x == 0) s_used = 0;
-                __syncthreads();
+                if (old[u] == key[u]) {
+                    atomicAdd(&s_cnt[hh], cnt[u]);
+                    atomicMin(&s_min[hh], row);
+                } else {
+                    global_insert(A, w, key[u], cnt[u], row);
+                }
             }
         }
+        (void)iter;
     };
     {
         constexpr int kStep = kBlock * RPT;
@@ -259,13 +253,6 @@ __global__ __launch_bounds__(kBlock) void hist_kernel(const HistArgs A) {
     }
     __syncthreads();
     stamp(2);
-    if (threadIdx.x == 0 && A.prof) A.prof[(size_t)blockIdx.x * 8 + 6] = (unsigned long long)s_used;
-    if (s_used > kLdsLimit) {
-        flush();
-        __syncthreads();
-        if (threadIdx.x == 0) s_used = 0;
-        __syncthreads();
-    }
     if (slice == 0 && A.patch_off) {
         // the window's slow pairs (edge-gap repair, ragged end): their k-mers were derived once by repair_kernel (spreading them over
         // the window's slices was tried: every workgroup then pays the section, 764 -> 799 us)
@@ -277,25 +264,20 @@ __global__ __launch_bounds__(kBlock) void hist_kernel(const HistArgs A) {
                 if (!(g & MP_WIN_SKIP)) {
                     const unsigned long long key = (unsigned long long)b0 | ((unsigned long long)b1 << k) | ((unsigned long long)(g & kmask) << (2 * k));
                     uint32_t h = hash64(key) & (kLdsSlots - 1);
-                    for (;;) {
+                    bool placed = false;
+                    for (int probe = 0; probe <= kMaxProbe && !placed; probe++) {
                         unsigned long long old = atomicCAS(&s_key[h], kNoKey, key);
-                        if (old == kNoKey) { atomicAdd(&s_used, 1); old = key; }
-                        if (old == key) { atomicAdd(&s_cnt[h], 1u); atomicMin(&s_min[h], (uint32_t)A.patch_rows[e]); break; }
+                        if (old == kNoKey) old = key;
+                        if (old == key) { atomicAdd(&s_cnt[h], 1u); atomicMin(&s_min[h], (uint32_t)A.patch_rows[e]); placed = true; }
                         h = (h + 1) & (kLdsSlots - 1);
                     }
+                    if (!placed) global_insert(A, w, key, 1u, (uint32_t)A.patch_rows[e]);
                 }
             }
-            __syncthreads();
-            if (s_used > kLdsLimit) {
-                flush();
-                __syncthreads();
-                if (threadIdx.x == 0) s_used = 0;
-                __syncthreads();
-            }
         }
+        __syncthreads();
     }
     stamp(3);
-    if (threadIdx.x == 0 && A.prof) A.prof[(size_t)blockIdx.x * 8 + 7] = (unsigned long long)s_used;
     flush();
     __syncthreads();
     stamp(4);
