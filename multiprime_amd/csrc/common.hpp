@@ -271,20 +271,12 @@ void prefault_host(void *p, size_t bytes);
 void *host_map(size_t bytes);
 void host_unmap(void *p, size_t bytes);
 
-// A large host buffer registered with the runtime for the time of one transfer (hipHostRegister): the copy then is one DMA at the link's
-// rate instead of a walk through the runtime's staging buffers — 58 MB: 0.3 ms to register pages that exist + 1.1 ms to copy, against
-// 3.2-3.4 ms staged (tools/ubench/d2h_bench.hip).  The pages must have been touched (prefault_host, or data already in them); small
-// buffers and a refusal by the runtime leave the staged path in place.  MP_NO_PIN=1 switches it off.
-struct PinScope {
-    void *p = nullptr;
-    PinScope(void *ptr, size_t bytes) {
-        if (ptr && bytes >= ((size_t)4 << 20) && !getenv("MP_NO_PIN") && hipHostRegister(ptr, bytes, hipHostRegisterDefault) == hipSuccess) p = ptr;
-        else (void)hipGetLastError();
-    }
-    ~PinScope() { if (p) (void)hipHostUnregister(p); }
-    PinScope(const PinScope &) = delete;
-    PinScope &operator=(const PinScope &) = delete;
-};
+// Registered memory (hipHostRegister: the copy is one DMA at the link's rate instead of a walk through the runtime's staging buffers —
+// 58 MB: 0.3 ms to register pages that exist + 1.1 ms to copy, against 3.2-3.4 ms staged, tools/ubench/d2h_bench.hip) is used for ONE
+// thing: the library's own staging area of the streamed planning (h_stage: a fresh mapping, registered once, unregistered before it is
+// unmapped).  Registering the CALLER's buffers for the duration of a transfer was tried for the residue bytes and the blocking entry
+// read-back (6.5 -> 3.7 ms, 6.0 -> 4.0 ms) and withdrawn: one run of the GPU suite in four died with SIGABRT inside mp_load_msa at such
+// a registration of memory owned by the Python allocator, without a message — not understood, so not shipped.
 
 // release the device arrays of one stage (and of every stage that depends on it); api.hip
 void free_eval(mp_ctx *c);

@@ -273,8 +273,6 @@ int mp_load_msa(mp_ctx *c, const uint8_t *bytes, const int64_t *row_off, int32_t
     if ((rc = dev_alloc(c, &c->rlen, np))) return rc;
     std::vector<int64_t> off0(n_rows + 1);
     for (int r = 0; r <= n_rows; r++) off0[r] = row_off[r] - row_off[0];
-    // the residue bytes are the one large host-to-device transfer of the step: registered for its duration (common.hpp PinScope)
-    const PinScope pin_bytes(const_cast<uint8_t *>(bytes) + row_off[0], (size_t)total);
     HIPCK(c, hipMemcpyAsync(d_bytes, bytes + row_off[0], (size_t)total, hipMemcpyHostToDevice, c->stream));
     HIPCK(c, hipMemcpyAsync(d_off, off0.data(), sizeof(int64_t) * (n_rows + 1), hipMemcpyHostToDevice, c->stream));
     const FillSeg init[4] = {{c->ung, sizeof(uint32_t) * np * c->ustride, 0u}, {c->rlen, sizeof(int32_t) * np, 0u}, {c->rstrip, sizeof(int32_t) * np, 0u},

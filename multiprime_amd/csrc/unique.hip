@@ -723,14 +723,12 @@ int mp_get_unique(mp_ctx *c, int64_t *win_off, void *words_out, int32_t *count, 
         if (n) {
             prefault_host(words, 3 * wb * n); prefault_host(count, 4 * n); prefault_host(first_row, 4 * n);
             lap("get_unique: prefault");
-            const PinScope pin_w(words, 3 * wb * n), pin_c(count, 4 * n), pin_f(first_row, 4 * n);
-            lap("get_unique: register");
             HIPCK(c, hipMemcpyAsync(words, c->u_b0, wb * n, hipMemcpyDeviceToHost, c->stream));
             HIPCK(c, hipMemcpyAsync(words + wb * n, c->u_b1, wb * n, hipMemcpyDeviceToHost, c->stream));
             HIPCK(c, hipMemcpyAsync(words + 2 * wb * n, c->u_g, wb * n, hipMemcpyDeviceToHost, c->stream));
             HIPCK(c, hipMemcpyAsync(count, c->u_count, 4 * n, hipMemcpyDeviceToHost, c->stream));
             HIPCK(c, hipMemcpyAsync(first_row, c->u_first, 4 * n, hipMemcpyDeviceToHost, c->stream));
-            HIPCK(c, hipStreamSynchronize(c->stream));      // (a failed call above leaves through HIPCK: the scopes unregister on the way out)
+            HIPCK(c, hipStreamSynchronize(c->stream));
         }
         if (lap.on) fprintf(stderr, "[mprime] get_unique: %zu entries, %.1f MB\n", n, (double)(3 * wb + 8) * (double)n / 1e6);
         lap("get_unique: d2h");
@@ -800,8 +798,9 @@ int mp_plan_create_streamed(mp_ctx *c, const mp_plan_params *params, int64_t row
         if (!c->h_stage) return fail(c, MP_ERR_NOMEM, "mp_plan_create_streamed: out of host memory (%zu bytes)", need);
         c->h_stage_bytes = room;
         prefault_host(c->h_stage, room);
-        // registered for the context's life: the bands below are DMA copies that take no host thread away from the planning
-        if (!getenv("MP_NO_PIN") && hipHostRegister(c->h_stage, room, hipHostRegisterDefault) == hipSuccess) c->h_stage_pinned = true;
+        // registered for the context's life when it is large enough to matter: the bands below are then DMA copies that take no host thread
+        // away from the planning (common.hpp on why this is the only registration the library makes)
+        if (room >= ((size_t)8 << 20) && !getenv("MP_NO_PIN") && hipHostRegister(c->h_stage, room, hipHostRegisterDefault) == hipSuccess) c->h_stage_pinned = true;
         else (void)hipGetLastError();
     }
     struct Span { uint8_t *p; uint8_t *get() const { return p; } };
