@@ -3,6 +3,8 @@ product's host modules, so a slip in one of them cannot hide on both sides of a 
 tests/test_oracle_*.py hold it against the fixtures recorded from the unmodified reference (tests/golden/).  Only tests/,
 __graft_entry__.smoke() and bench.py's cpu_baseline leg may import it.
 
+(The file readers of the original are left out: the checker parses records itself, oracle/core_ref.py::parse_records.)
+
 Original header:
 FASTA / alignment input for the core step (host side).
 
@@ -17,23 +19,6 @@ O(bytes) work and runs on the device (mp_load_msa).  The record logic itself is 
 from __future__ import annotations
 
 import numpy as np
-
-
-def read_records(path: str):
-    """Returns (ids, data, row_off): ids in first-appearance order, `data` the concatenated raw residue bytes of all
-    records, row r = data[row_off[r]:row_off[r+1]] — parsed by the native host stage (csrc/fasta.cpp)."""
-    from .host import Fasta
-    fa = Fasta(path)
-    data, row_off = fa.rows()
-    return fa.ids, data, row_off
-
-
-def parse_records(raw: bytes):
-    """Same from a bytes object."""
-    from .host import Fasta
-    fa = Fasta(raw=raw)
-    data, row_off = fa.rows()
-    return fa.ids, data, row_off
 
 
 def region(lead_gap: np.ndarray, rstrip_len: np.ndarray, coverage: float):
