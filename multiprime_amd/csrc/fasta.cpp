@@ -32,9 +32,32 @@ struct Event {                                                   // per line tha
     uint64_t hash;              // of the id token
 };
 
-// str.strip() of a text-mode line, ASCII range: space, \t \n \v \f \r and the separators 0x1c-0x1f (str.isspace is true for
-// them; bytes.strip() would leave them).  Non-ASCII white space (U+0085, U+00A0, ...) is not stripped: INTEGRATION.md.
+// str.strip() of a text-mode line: every character str.isspace() is true for.  ASCII: space, \t \n \v \f \r and the separators
+// 0x1c-0x1f (bytes.strip() would leave those); beyond it ([r4], recorded from the reference's parse_seq: tests/golden/parser_ws.json)
+// U+0085, U+00A0, U+1680, U+2000-200A, U+2028, U+2029, U+202F, U+205F, U+3000 in their UTF-8 forms (the reference reads text mode, UTF-8).
 inline bool is_space(uint8_t c) { return c == ' ' || (c >= 9 && c <= 13) || (c >= 0x1c && c <= 0x1f); }
+inline bool is_space2(uint8_t a, uint8_t b) { return a == 0xC2 && (b == 0x85 || b == 0xA0); }
+inline bool is_space3(uint8_t a, uint8_t b, uint8_t c) {
+    if (a == 0xE1) return b == 0x9A && c == 0x80;                                             // U+1680
+    if (a == 0xE2) return (b == 0x80 && ((c >= 0x80 && c <= 0x8A) || c == 0xA8 || c == 0xA9 || c == 0xAF)) || (b == 0x81 && c == 0x9F);
+    if (a == 0xE3) return b == 0x80 && c == 0x80;                                             // U+3000
+    return false;
+}
+// [a, z) without the white space at either end
+inline void strip_line(const uint8_t *b, int64_t &a, int64_t &z) {
+    for (;;) {
+        if (a < z && is_space(b[a])) a += 1;
+        else if (a + 1 < z && is_space2(b[a], b[a + 1])) a += 2;
+        else if (a + 2 < z && is_space3(b[a], b[a + 1], b[a + 2])) a += 3;
+        else break;
+    }
+    for (;;) {
+        if (z > a && is_space(b[z - 1])) z -= 1;
+        else if (z - 1 > a && is_space2(b[z - 2], b[z - 1])) z -= 2;
+        else if (z - 2 > a && is_space3(b[z - 3], b[z - 2], b[z - 1])) z -= 3;
+        else break;
+    }
+}
 
 inline uint64_t hash_bytes(const uint8_t *p, size_t n) {
     uint64_t h = 0xcbf29ce484222325ULL ^ (n * 0x9E3779B97F4A7C15ULL);
@@ -153,8 +176,7 @@ void scan_chunk(const uint8_t *b, int64_t n, int64_t begin, int64_t end, std::ve
         if (q < n) next = (b[q] == '\r' && q + 1 < n && b[q + 1] == '\n') ? q + 2 : q + 1;
         if (q > p && b[p] == '#') { p = next; continue; }
         int64_t a = p, z = q;
-        while (a < z && is_space(b[a])) a++;
-        while (z > a && is_space(b[z - 1])) z--;
+        strip_line(b, a, z);
         if (q > p && b[p] == '>') {
             // i.strip().split(" ")[0]: the stripped line up to its first blank
             int64_t t = a;

@@ -100,16 +100,19 @@ def parse_records(raw: bytes):
     """parse_seq's record semantics (V20:441-455) in plain Python: the checker of csrc/fasta.cpp."""
     pieces = {}
     cur = None
-    white = b" \t\n\r\x0b\x0c\x1c\x1d\x1e\x1f"      # str.strip() of a text-mode line, ASCII range (bytes.strip() keeps 0x1c-0x1f)
+
+    def strip(line):        # str.strip() as text mode sees the line (UTF-8; bytes that are not stay as they are), back as bytes
+        return line.decode("utf-8", errors="surrogateescape").strip().encode("utf-8", errors="surrogateescape")
+
     for line in raw.splitlines():                   # bytes: \n, \r\n and \r end a line, nothing else (text mode's universal newlines)
         if line.startswith(b"#"):
             continue
         if line.startswith(b">"):
-            cur = line.strip(white).split(b" ")[0]
+            cur = strip(line).split(b" ")[0]
         else:
             if cur is None:
                 raise ValueError("sequence data before the first '>' header")
-            pieces.setdefault(cur, []).append(line.strip(white))
+            pieces.setdefault(cur, []).append(strip(line))
     ids = [k.decode("utf-8", errors="surrogateescape") for k in pieces]
     rows = [b"".join(v) for v in pieces.values()]
     lens = np.fromiter((len(r) for r in rows), dtype=np.int64, count=len(rows))

@@ -81,6 +81,35 @@ def test_fasta_parser_edge_cases(tmp_path):
         host.Fasta(str(tmp_path / "missing.fa"))
 
 
+def test_white_space_at_line_ends_is_stripped_like_the_reference():
+    """tests/golden/parser_ws.json: 45 small files run through the UNMODIFIED reference's parse_seq (make_golden_parser.py) — lines that
+    start / end with every kind of white space str.strip() removes (ASCII, 0x1c-0x1f, U+0085, U+00A0, U+1680, U+2000-200A, U+2028/9, U+202F,
+    U+205F, U+3000), white space inside id tokens, white-space-only lines, '#' behind white space.  The native parser and the checker's
+    restatement give the reference's ids and (after V20:453's per-character mapping) its sequences; where the reference dies (data in front
+    of the first header) both refuse the file."""
+    import json
+    import re
+    from conftest import GOLDEN
+    from oracle.core_ref import parse_records
+    recs = json.load(open(os.path.join(GOLDEN, "parser_ws.json")))
+    assert len(recs) == 45 and sum("error" in r for r in recs) == 20
+    for rec in recs:
+        raw = rec["file_latin1"].encode("latin-1")
+        if "error" in rec:
+            with pytest.raises(ValueError):
+                host.Fasta(raw=raw)
+            with pytest.raises(ValueError):
+                parse_records(raw)
+            continue
+        fa = host.Fasta(raw=raw)
+        data, off = fa.rows()
+        got = [re.sub(b"[^ACGTRYMKSWHBVD]", b"-", data[off[i]:off[i + 1]].tobytes().upper()).decode() for i in range(fa.n_rows)]
+        assert fa.ids == rec["ids"] and got == rec["seqs"], rec["file_latin1"]
+        ids, d2, o2 = parse_records(raw)
+        got2 = [re.sub(b"[^ACGTRYMKSWHBVD]", b"-", d2[o2[i]:o2[i + 1]].tobytes().upper()).decode() for i in range(len(ids))]
+        assert ids == rec["ids"] and got2 == rec["seqs"], rec["file_latin1"]
+
+
 def test_lone_carriage_return_files_parse_in_linear_time():
     """Classic-Mac line ends: the terminator search must not run to the end of the file for every line."""
     import time
