@@ -265,8 +265,11 @@ int mp_pcr_scan(mp_ctx *ctx, const uint8_t *bytes, const int64_t *row_off, int32
 /* (8) k-mismatch primer-site scan — SURVEY §8f-3 ------------------------------------------------ */
 /* Replaces the mapping step of scripts/primer_coverage_validation_by_BWT_V9.py ("BWT": bowtie2 -N m -L 8 -a + samtools
  * + the MD:Z filter of build_dict, BWT:264-300, 241-262) by an exhaustive ungapped scan.  bowtie2 and samtools are absent
- * from this image, so the MAPPER's acceptance rule is a restatement, not a recorded behaviour (unpinned); the
- * MD:Z rule it feeds and everything else the script does are pinned to the reference (tests/golden/validate.json.gz):
+ * from this image, so the mapper cannot be run here; its acceptance rule below is pinned to the reference author's own
+ * bowtie2 run instead (the shipped test_data/results/Core_primers_set/BWT_coverage/ output of rule BWT_validation: 1158
+ * sequences, 485 with a product and 673 without, every decision reproduced — tests/golden/make_golden_bwt.py,
+ * tests/test_validate_bwt.py); the MD:Z rule and everything else the script does are pinned to V9 itself
+ * (tests/golden/validate.json.gz):
  * `bytes`/`row_off` hold the reference sequences (upper-cased by the scan; any character outside ACGT mismatches every
  * base, like bowtie2's N).  Pattern i = pat_codes[pat_off[i] .. pat_off[i+1]) is one CONCRETE primer expansion
  * (codes 1,2,4,8; length 4..MP_PATTERN_MAX_LEN).  For every sequence, start position p and strand s (0: the text reads the

@@ -14,10 +14,14 @@ Same class name (`off_targets`), constructor arguments, flags and output files a
 PARITY: everything around the mapper is pinned to the reference — tests/golden/validate.json.gz holds what the unmodified V9
 class writes for hand-written and seeded SAM input (tests/golden/make_golden_validate.py), this module reproduces it from the
 same SAM text, and the GPU scan is checked end to end against the same stages fed with the SAM lines its hits stand for.  The
-MAPPER ITSELF IS UNPINNED: bowtie2 / samtools are not installed in the authoring image.  It is replaced by its acceptance rule
+MAPPER: bowtie2 / samtools are not installed in the authoring image, so the mapping step is replaced by its acceptance rule
 under default end-to-end scoring — an ungapped alignment with at most floor((0.6 + 0.6 L) / 6) mismatches (minimum score
--0.6 - 0.6 L at 6 per mismatch; `--max-mismatch` overrides), both strands, every site (`-a`).  Against a real bowtie2 run
-expect: no gapped alignments here; sites bowtie2's seed heuristics (-N, -L 8) miss are found here.
+-0.6 - 0.6 L at 6 per mismatch; `--max-mismatch` overrides), both strands, every site (`-a`).  That rule is pinned to the
+reference author's own bowtie2 + samtools run of rule BWT_validation (multiPrime.py:441-457), whose output ships in the reference
+tree: all 1158 sequences whose text is available (485 with a product row, 673 without) are decided identically, and the
+neighbouring rules (budget 0 / 2, 3'-term threshold 0 / 2) are not (tests/golden/make_golden_bwt.py, tests/test_validate_bwt.py).
+Beyond what that run exercises: no gapped alignments here (bowtie2 admits a single 1-base gap at L >= 13: score -8 against a
+minimum of -0.6 - 0.6 L); sites bowtie2's seed heuristics (-N, -L 8) miss are found here.
 
 Orders the reference takes from a Python set (sequences in <out>, names inside a shared term id, unmatched records) are
 deterministic here: first appearance in the forward sites / the primer file / sorted names.

@@ -909,7 +909,8 @@ int mp_pcr_scan(mp_ctx *c, const uint8_t *bytes, const int64_t *row_off, int32_t
 }
 
 /* (8) k-mismatch primer-site scan: the acceptance rule of mprime.h, character by character.  bowtie2 and
- * samtools are not in this image, so this restatement is NOT pinned to recorded reference output ("parity unpinned"). */
+ * samtools are not in this image; the rule is pinned to the bowtie2 run the reference ships (tests/test_validate_bwt.py:
+ * 1158 sequences decided identically). */
 int mp_kmm_scan(mp_ctx *c, const uint8_t *bytes, const int64_t *row_off, int32_t n_rows, int32_t n_pat, const uint8_t *pat_codes,
                 const int32_t *pat_off, int32_t max_mm, int32_t term, int64_t cap, int32_t *hits, int64_t *n_hits) {
     if (!c) return MP_ERR_ARG;

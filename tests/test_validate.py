@@ -2,7 +2,7 @@
 
 Pinned to the reference: everything the script does around the mapper — tests/golden/validate.json.gz holds what the unmodified
 V9 class writes for hand-written and seeded SAM input (make_golden_validate.py); the drop-in must write the same from the same SAM
-text.  Unpinned: the mapper (bowtie2 / samtools are not installed).  For it: the oracle's scan against a brute-force Python
+text.  The mapper's decisions are pinned in tests/test_validate_bwt.py (the reference author's bowtie2 run).  Here: the oracle's scan against a brute-force Python
 statement of the acceptance rule in mprime.h, the HIP kernel against the oracle (`-m gpu`; segment borders, both strands, N / lower
 case, patterns of several lengths), and scan -> sites == SAM lines of the same alignments -> sites, end to end."""
 import os
