@@ -16,11 +16,12 @@ form (`--bucket` steps per collective, dist.StepBuckets) is the side key `ms_per
 
   weak_shard    N = 1 only: the 131072 x 1000 shard one GPU holds in the 8-GPU job (81 MB of planes: lives in the Infinity Cache),
                 timed the same way in this same run (skip with --no-shard) — what the per-GPU kernel time of an N = 8 run should be.
-  roofline      `frac` = the HBM fraction: measured fabric/HBM bytes per launch (`traffic`, rocprofv3 counters) / kernel time /
-                8 TB/s.  Beside it, every fraction that can bind (all <= 1 by construction):
+  roofline      `frac` = `compulsory_frac` = the USEFUL HBM fraction: compulsory bytes of a pass (the packed planes read once, N L 3/8 —
+                SURVEY 8d (ii)) / kernel time / 8 TB/s.  `hbm_frac` = what the kernel actually moved: measured fabric/HBM bytes per
+                launch (`traffic`, rocprofv3 counters) / kernel time / 8 TB/s; `over_fetch` = traffic / compulsory bytes.  Beside them,
+                every fraction that can bind (all <= 1 by construction):
                   valu_frac = VALU wave-instructions per launch / (kernel time x SIMDs x measured issue rate)
                   l2_frac   = bytes returned to registers per launch / (kernel time x 31.4 TB/s = 256 CUs x 64 B/clk)
-                  hbm_frac  = frac
                 `bound` names the largest.  Kernel time is measured live (HIP events on the library's stream); instruction /
                 request / byte counts come from separate rocprofv3 --pmc passes of this same command (tools/collect_counters.py
                 -> profiles/r04_counters.json).  An entry is used only if it was collected for this exact configuration AND
@@ -28,8 +29,13 @@ form (`--bucket` steps per collective, dist.StepBuckets) is the side key `ms_per
                 fractions are dropped (`counters_stale`), never silently reused.  SURVEY §8d's algorithmic figure (3k/8 bytes
                 per evaluation / kernel time / 8 TB/s) is kept as `algorithmic_frac`, labelled: it exceeds 1 (8 nested
                 candidates and 18 overlapping windows share every loaded plane word) and is NOT a roofline fraction.
-  variants      (weak_shard) the same kernel library on less friendly candidate sets: unrelated candidates (no nesting), the
-                symbol-table kernel forced on the nested set, C = 1, and one cold launch (caches flushed, no warm-up).
+  variants      SURVEY 8d's micro-benchmark, at the headline size AND at the shard: the same kernel library on other candidate sets —
+                C = 1, C = 8 unrelated (no nesting), the symbol-table kernel forced on the nested set, C = 64 (eight nested chains
+                per window); at the headline size every variant's counters are checked against the oracle (every 16th window);
+                at the shard also one cold launch (caches flushed, no warm-up).
+  pipeline      the REAL step the kernel belongs to: NN_degenerate(...).run() (the drop-in class, --no-json, bitsets on the device) on
+                the same rows at both sizes, median of 5, phase split, TSV SHA-256 against the checker's (tests/golden/synth_pipeline.json).
+  projected_strong_scaling   ms_per_step (whole workload, one GPU) / weak_shard.ms_per_step: what 8 row shards reach with a free all-reduce.
   cpu_baseline  the plain-C oracle on EVERY host core (threads over row blocks of the whole workload) and on one core (bounded
                 sample); its counters are compared with the GPU's candidate by candidate — `parity_checked` true, or the run
                 exits non-zero.  `python_reference`: the reference's own algorithm (dict of k-mers, numpy score-table
@@ -40,7 +46,9 @@ import argparse
 import hashlib
 import json
 import os
+import shutil
 import sys
+import tempfile
 import threading
 import time
 from concurrent.futures import ThreadPoolExecutor
@@ -56,7 +64,7 @@ FULL_ROWS = 1048576            # BASELINE.json configs[3]: 1M sequences
 SHARD_ROWS = 131072            # what one GPU holds of it in the 8-GPU job
 # measured ceilings (tools/ubench.hip on the same GPU pool, profiles/r02_ubench.json); used when that file is absent
 DEFAULT_CEILINGS = {"valu_wave_instr_per_s_per_simd": 8.5e8, "l2_read_GBs": 31559.0, "source": "built-in defaults (profiles/r02_ubench.json missing)"}
-COUNTER_FILES = ("r04_counters.json", "r03_counters.json")
+COUNTER_FILES = ("r05_counters.json", "r04_counters.json", "r03_counters.json")
 # sources of the timed kernel (eval_chain_kernel and what it includes): the key of a counter entry
 KERNEL_SOURCES = ("eval.hip", "evalprog.hip", "evalslide.hip", "slidecore.hpp", "slideplan.hpp", "evalslide.hpp", "chainbody.hpp", "bitslice.hpp", "common.hpp",
                   "winwords.hpp", "evalprog.hpp")
@@ -252,12 +260,17 @@ def roofline_block(w, per_launch_ms, samples, kern_n, every, mode):
             fr["hbm"] = traffic / kern_s / 1e9 / HBM_PEAK_GBS
     known = {key: val for key, val in fr.items() if val is not None}
     bound = max(known, key=known.get) if known else None
-    # `frac` is the HBM fraction (north_star's bar): counter bytes / kernel time / 8 TB/s; `bound` names the largest of the three
-    achieved = traffic / kern_s / 1e9 if traffic is not None else None
+    # `frac` = the USEFUL HBM fraction: the compulsory bytes of a pass (the packed planes read once, N L 3/8) / kernel time / 8 TB/s —
+    # what an ideal kernel of this formulation would have to move; `hbm_frac` = what the kernel DID move (fabric bytes from the counters) over the
+    # same time and peak (over-fetch = traffic / compulsory_bytes); `bound` names the largest of the counter fractions
+    compulsory = w.n_rows * w.L * 3 / 8.0
+    achieved = compulsory / kern_s / 1e9
     return {"bound": bound, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-            "frac": fr["hbm"], "traffic": traffic,
+            "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+            "compulsory_frac": achieved / HBM_PEAK_GBS, "over_fetch": (traffic / compulsory) if traffic is not None else None,
+            "achieved_counter_GBs": traffic / kern_s / 1e9 if traffic is not None else None,
             "valu_frac": fr["valu"], "l2_frac": fr["l2"], "hbm_frac": fr["hbm"],
-            "compulsory_bytes": w.n_rows * w.L * 3 / 8.0, "compulsory_note": "SURVEY §8d (ii): packed planes read once, N L 3/8 bytes",
+            "compulsory_bytes": compulsory, "compulsory_note": "SURVEY 8d (ii): packed planes read once, N L 3/8 bytes; `achieved` and `frac` are these bytes over the kernel time",
             "algorithmic_frac": alg_bytes / kern_s / 1e9 / HBM_PEAK_GBS,
             "algorithmic_note": "SURVEY 8d figure: 3k/8 bytes per evaluation over the kernel time vs 8 TB/s; exceeds 1 because 8 nested candidates and "
                                 "18 overlapping windows share every loaded plane word — NOT a roofline fraction, kept for comparison with round 1",
@@ -287,14 +300,16 @@ def main():
     ap.add_argument("--cpu-threads", type=int, default=0, help="host threads of the all-core CPU leg (0 = every core)")
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--no-variants", action="store_true")
+    ap.add_argument("--no-pipeline", action="store_true", help="N = 1: skip the `pipeline` block (NN_degenerate.run() on the same rows)")
     ap.add_argument("--no-shard", "--no-full", dest="no_shard", action="store_true",
                     help="N = 1: skip the weak_shard block (the 131072-row shard of the 8-GPU job)")
     ap.add_argument("--bucket", type=int, default=4, help="steps per collective of the bucketed side measurement (N > 1)")
     a = ap.parse_args()
 
+    from multiprime_amd._abi import Library, prefer_staged_copies
+    prefer_staged_copies()          # a program's decision, before the HIP runtime starts: what the drop-in command lines do (the `pipeline` block times their code path)
     import torch
     import torch.distributed as dist
-    from multiprime_amd._abi import Library
 
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -334,13 +349,20 @@ def main():
     # buffer that is reduced with one collective on RCCL's stream while the next bucket's steps evaluate into the other buffer
     # (dist.StepBuckets; xGMI rings are latency-bound at 180 KB per step).
     from multiprime_amd.dist import StepBuckets
+    rotate = os.environ.get("MP_BENCH_ROTATE", "1") != "0"
 
     def timed_region(wl, bucket, n_world):
         sb = StepBuckets(wl.n_cand, bucket, dev, n_world)
 
-        def step():
-            wl.ctx.eval_launch(sb.begin_step().data_ptr())
-            sb.end_step()
+        if rotate:
+            def step():             # the launch that fills a step's block clears the next step's inside its own grid (mp_eval_launch_rotating)
+                out, nxt = sb.begin_rotating()
+                wl.ctx.eval_launch_rotating(out.data_ptr(), nxt.data_ptr())
+                sb.end_step()
+        else:
+            def step():             # MP_BENCH_ROTATE=0: a fill dispatch in front of every evaluation (mp_eval_launch)
+                wl.ctx.eval_launch(sb.begin_step().data_ptr())
+                sb.end_step()
 
         for _ in range(a.warmup):
             step()
@@ -439,10 +461,29 @@ def main():
         if bucketed is not None:
             res["ms_per_step_bucketed"] = bucketed / a.steps * 1e3
             res["bucket"] = a.bucket
-        if world == 1 and not a.no_cpu:
-            n_cpu = a.cpu_rows or rows_per_gpu
-            res["cpu_baseline"] = cpu_baseline(w, w.rows[:n_cpu], a.cpu_threads, gpu_counters if n_cpu == rows_per_gpu else None, a.seed)
-            res["parity_checked"] = res["cpu_baseline"].get("parity_checked")
+        if world == 1:
+            res["step_form"] = ("rotating: the launch that fills a step's counter block clears the next step's inside its own grid (mp_eval_launch_rotating)"
+                                if rotate else "a fill dispatch in front of every evaluation (mp_eval_launch; MP_BENCH_ROTATE=0)")
+            blocks = None
+            if not a.no_cpu:
+                n_cpu = a.cpu_rows or rows_per_gpu
+                blocks = OracleBlocks(w, w.rows[:n_cpu], a.cpu_threads)
+                res["cpu_baseline"] = cpu_baseline(w, blocks, gpu_counters if n_cpu == rows_per_gpu else None, a.seed)
+                res["parity_checked"] = res["cpu_baseline"].get("parity_checked")
+            if not a.no_variants:
+                # SURVEY 8d's micro-benchmark at the headline size: C = 1, unrelated C = 8, nested C = 64, each checked against the oracle
+                res["variants"] = run_variants(w, torch, dev, None, None, a.seed, blocks if blocks is not None and blocks.n == rows_per_gpu else None, cold=False)
+                if any(v.get("parity_checked") is False for v in res["variants"].values()):
+                    res["parity_checked"] = False
+            if blocks is not None:
+                blocks.close()
+                del blocks
+            if not a.no_pipeline:
+                res["pipeline"] = {"what": "the REAL step: the drop-in class NN_degenerate(...).run() (multiprime_amd/core.py; --no-json, coverage bitsets kept on the "
+                                           "device) on the same synthetic rows, a fresh context per repetition, median of 5 after one warm-up; `run_ms` is run() alone, "
+                                           "`construct_ms` the constructor before it (FASTA parse of a file in /dev/shm + mp_load_msa); TSV compared with the CHECKER's "
+                                           "(oracle/core_ref.py over the plain-C oracle, tests/golden/synth_pipeline.json)",
+                                   f"rows_{rows_per_gpu}": pipeline_block(lib, local, w.rows, a)}
     # N = 1: the shard one GPU holds in the 8-GPU job, timed the same way (with the variant measurements)
     if rank == 0 and world == 1 and not a.no_shard and rows_per_gpu != SHARD_ROWS:
         del sb
@@ -452,6 +493,16 @@ def main():
         res["weak_shard"] = weak_shard(lib, local, torch, dev, a, timed_region, every, not a.no_cpu)
         if res["weak_shard"].get("parity_checked") is False:
             res["parity_checked"] = False
+        if "pipeline" in res and "pipeline" in res["weak_shard"]:
+            res["pipeline"][f"rows_{SHARD_ROWS}"] = res["weak_shard"].pop("pipeline")
+        # what row shards over 8 GPUs can reach at best: the whole workload's step over the shard's step (no collective counted)
+        res["projected_strong_scaling"] = {
+            "n_gpus": FULL_ROWS // SHARD_ROWS, "ceiling": res["ms_per_step"] / res["weak_shard"]["ms_per_step"],
+            "ms_per_step_one_gpu": res["ms_per_step"], "ms_per_step_shard": res["weak_shard"]["ms_per_step"],
+            "note": "ms_per_step of the whole workload on one GPU over ms_per_step of the 1/8 shard on one GPU, both measured in this run: the speed-up 8 GPUs "
+                    "reach if the all-reduce of the counters costs nothing (it is overlapped with the next step's kernel: dist.StepBuckets); north_star asks >= 6"}
+    if rank == 0 and world == 1 and any(isinstance(p, dict) and p.get("tsv_equal_oracle") is False for p in res.get("pipeline", {}).values()):
+        res["parity_checked"] = False
     if rank == 0:
         print(json.dumps(res), flush=True)
     if world > 1:
@@ -475,17 +526,23 @@ def weak_shard(lib, local, torch, dev, a, timed_region, every, with_cpu):
     if not a.no_variants:
         src = torch.empty(1 << 28, dtype=torch.float32, device=dev)
         dst = torch.empty_like(src)
-        out["variants"] = run_variants(w, torch, dev, src, dst, a.seed)
+        out["variants"] = run_variants(w, torch, dev, src, dst, a.seed, None)
         del src, dst
     if with_cpu:
-        cb = cpu_baseline(w, w.rows, a.cpu_threads, counters, a.seed, one_core=False, python_leg=False)
+        blocks = OracleBlocks(w, w.rows, a.cpu_threads)
+        cb = cpu_baseline(w, blocks, counters, a.seed, one_core=False, python_leg=False)
+        blocks.close()
         out["cpu_baseline"] = cb
         out["parity_checked"] = cb.get("parity_checked")
+    if not a.no_pipeline:
+        out["pipeline"] = pipeline_block(lib, local, w.rows, a)
     return out
 
 
-def run_variants(w, torch, dev, scratch_a, scratch_b, seed):
-    """The evaluation library on less friendly inputs (every launch timed with HIP events, 20 launches after 3 warm-ups)."""
+def run_variants(w, torch, dev, scratch_a, scratch_b, seed, blocks, cold=True):
+    """The evaluation library on other candidate sets — SURVEY 8d's micro-benchmark: C in {1, 8, 64} per window, nested and not (every
+    launch timed with HIP events, 20 launches after 3 warm-ups).  With `blocks` (the oracle's contexts over the same rows) the counters
+    of every 16th window's candidates are compared with the oracle's."""
     os.environ["MP_EVAL_TIMING_EVERY"] = "1"
     ctx, k, C = w.ctx, w.k, w.C
     total = int(w.universe.sum())
@@ -497,7 +554,14 @@ def run_variants(w, torch, dev, scratch_a, scratch_b, seed):
         t = time_launches(ctx, torch, buf.data_ptr(), 20, 3)
         evals = total * c_per_window
         out[name] = {"evals_per_s": evals / (t["mean_ms"] * 1e-3), "kernel_ms": t["mean_ms"], "kernel_ms_median": t["median_ms"],
-                     "kernel_ms_max": t["max_ms"], "candidates_per_window": c_per_window, "what": note}
+                     "kernel_ms_max": t["max_ms"], "candidates_per_window": c_per_window, "what": note, "eval_mode": eval_mode(w.n_rows, ctx),
+                     "plan": ctx.eval_plan_info()}
+        if blocks is not None:
+            sel = np.nonzero(cand_w % 16 == 0)[0]
+            want, _ = blocks.eval(np.ascontiguousarray(cand_w[sel]), np.ascontiguousarray(cand_codes[sel]))
+            got = buf.cpu().numpy()[sel]
+            out[name]["parity_checked"] = bool(np.array_equal(got, want))
+            out[name]["parity_note"] = f"the {len(sel)} candidates of every 16th window, all three counters, GPU == sum of the oracle's row blocks"
 
     uw, ucodes = make_candidates(w.root_codes, w.p0, w.W, k, C, seed + 1, nested=False)
     measure("unrelated_candidates", uw, ucodes, C, f"{C} candidates per window that are NOT a refinement chain (root + one extra base each): symbol-table kernel")
@@ -505,8 +569,16 @@ def run_variants(w, torch, dev, scratch_a, scratch_b, seed):
     measure("nested_on_table_kernel", w.cw, w.codes, C, "the headline candidates with chain detection off (MP_EVAL_GROUP=plain): symbol-table kernel")
     del os.environ["MP_EVAL_GROUP"]
     measure("c1", w.cw[::C].copy(), w.codes[::C].copy(), 1, "one candidate per window (the root k-mer)")
-    # cold: one launch of the headline set with L2 / Infinity Cache flushed by a 2 GiB device copy, no warm-up
+    # C = 64: eight refinement chains of eight members per window (the root with random extra degeneracy, seeded per chain)
+    chains = [make_candidates(w.root_codes, w.p0, w.W, k, 8, seed + 100 + j)[1].reshape(w.W, 8, k) for j in range(8)]
+    codes64 = np.ascontiguousarray(np.concatenate(chains, axis=1).reshape(w.W * 64, k))
+    measure("nested_c64", np.repeat(np.arange(w.W, dtype=np.int32), 64), codes64, 64,
+            "64 candidates per window: eight nested chains of eight members (SURVEY 8d: C in {1, 8, 64})")
     ctx.eval_upload(w.cw, w.codes, w.sF, w.sR)
+    if not cold:
+        os.environ["MP_EVAL_TIMING_EVERY"] = "4"
+        return out
+    # cold: one launch of the headline set with L2 / Infinity Cache flushed by a 2 GiB device copy, no warm-up
     buf = torch.zeros((w.n_cand, 3), dtype=torch.int64, device=dev)
     colds = []
     for _ in range(3):
@@ -523,60 +595,137 @@ def run_variants(w, torch, dev, scratch_a, scratch_b, seed):
     return out
 
 
-def cpu_baseline(w, rows, n_threads, gpu_counters, seed, one_core=True, python_leg=True):
-    """The oracle (plain-C restatement of the reference) on the host cores: EVERY core over row blocks of the sample (the C call
-    releases the GIL, one oracle context per thread) and one core on a bounded sub-sample.  When the sample is the whole
-    workload its summed counters are compared with the GPU's.  This is the only place bench.py touches oracle/."""
-    from multiprime_amd._abi import Library
-    so = os.path.join(REPO, "oracle", "_build", "libmprime_oracle.so")
-    if not os.path.exists(so):
-        return {"value": None, "unit": "evals/s", "cores": 0, "kind": "port", "sample": "oracle library not built", "parity_checked": None}
-    lib = Library(so)
-    L, p0, W, k, v, C = w.L, w.p0, w.W, w.k, w.v, w.C
-    n = rows.shape[0]
-    cores = os.cpu_count() or 1
-    T = n_threads or cores
-    T = max(1, min(T, n // 256))
-    bounds = [n * t // T for t in range(T + 1)]
-    results = [None] * T
-    universe = [0] * T
+PIPELINE_FLAGS = dict(primer_length=18, coverage=0.8, number_of_dege_bases=4, score_of_dege_bases=10, raw_entropy_threshold=3.6, product_len=150,
+                      position="2,3,-1", variation=1, distance=4, GC="0.2,0.7", nproc=1)     # tools/make_synth_golden.py: the same
 
-    def work(t):
-        blk = rows[bounds[t]:bounds[t + 1]]
-        ora = lib.context(0)
-        ora.load_msa(blk.reshape(-1), np.arange(blk.shape[0] + 1, dtype=np.int64) * L)
-        n_ex = ora.build_windows(p0, W, k, v)
-        expand_exceptions(ora, n_ex, k, v)
-        alln = ora.eval_candidates(np.arange(W, dtype=np.int32), np.full((W, k), 15, np.uint8), 0, 0)
-        universe[t] = int((alln[:, 0] + alln[:, 1]).sum())
+
+def pipeline_block(lib, local, rows, a, reps=5):
+    """NN_degenerate(...).run() — the step the evaluation kernel belongs to — on the workload's own rows: median wall time of `reps`
+    runs after one warm-up (each with a fresh context), the phase split of the median run, and the TSV against the checker's (SHA-256
+    committed by tools/make_synth_golden.py: the checker takes minutes to hours per size on one core)."""
+    from multiprime_amd.core import NN_degenerate
+    from multiprime_amd.synth import to_fasta
+    n, L = rows.shape
+    golden = None
+    for e in (load_json(os.path.join("..", "tests", "golden", "synth_pipeline.json")) or {}).get("entries", []):
+        if (e["rows"], e["cols"], e["seed"]) == (n, L, a.seed):
+            golden = e
+    td = tempfile.mkdtemp(prefix="mp_bench_", dir="/dev/shm" if os.path.isdir("/dev/shm") else None)
+    try:
+        fa, out = os.path.join(td, "syn.fa"), os.path.join(td, "out.tsv")
+        with open(fa, "wb") as f:
+            f.write(to_fasta(rows))
+        runs = []
+        for rep in range(reps + 1):
+            t0 = time.perf_counter()
+            app = NN_degenerate(seq_file=fa, outfile=out, library=lib, device=local, write_json=False, keep_bitsets=True, **PIPELINE_FLAGS)
+            t1 = time.perf_counter()
+            app.run()
+            t2 = time.perf_counter()
+            if rep:                                                   # the first run also warms the process (runtime copy paths, page faults)
+                runs.append((t2 - t1, t1 - t0, {key: val for key, val in app.stats.items() if isinstance(val, (int, float))}))
+            app.ctx.close()
+            del app
+        with open(out, "rb") as f:
+            tsv = f.read()
+    finally:
+        shutil.rmtree(td, ignore_errors=True)
+    runs.sort(key=lambda r: r[0])
+    run_s, construct_s, stats = runs[len(runs) // 2]
+    sha = hashlib.sha256(tsv).hexdigest()
+    return {"rows": n, "cols": L, "run_ms": run_s * 1e3, "run_ms_min": runs[0][0] * 1e3, "run_ms_max": runs[-1][0] * 1e3, "construct_ms": construct_s * 1e3,
+            "repetitions": reps, "phases_ms": {key[:-2]: round(val * 1e3, 3) for key, val in stats.items() if key.endswith("_s")},
+            "windows": stats.get("n_windows"), "windows_past_the_gates": stats.get("windows_planned"), "candidates": stats.get("n_candidates"),
+            "rows_out": stats.get("n_rows"), "tsv_sha256": sha, "oracle_tsv_sha256": golden["tsv_sha256"] if golden else None,
+            "tsv_equal_oracle": (sha == golden["tsv_sha256"]) if golden else None,
+            "oracle_note": (f"checker: {golden['checker']}, {golden['checker_wall_s']} s" if golden else "no committed checker TSV for this size / seed")}
+
+
+class OracleBlocks:
+    """The plain-C oracle (oracle/mprime_oracle.c) on EVERY host core: one oracle context per thread over a block of the sample's
+    rows, built once (untimed, like the GPU's planes); any number of candidate sets are then evaluated on them (the C call releases
+    the GIL) and their counters summed over the blocks.  This and python_reference_leg are the only places bench.py touches oracle/."""
+
+    def __init__(self, w, rows, n_threads):
+        from multiprime_amd._abi import Library
+        so = os.path.join(REPO, "oracle", "_build", "libmprime_oracle.so")
+        self.lib = Library(so) if os.path.exists(so) else None
+        self.w, self.rows, self.n = w, rows, rows.shape[0]
+        self.cores = os.cpu_count() or 1
+        T = n_threads or self.cores
+        self.T = T = max(1, min(T, self.n // 256))
+        self.bounds = [self.n * t // T for t in range(T + 1)]
+        self.ctxs, self.universe = [None] * T, [0] * T
+        if self.lib is None:
+            return
         t0 = time.perf_counter()
-        results[t] = ora.eval_candidates(w.cw, w.codes, w.sF, w.sR)
-        return time.perf_counter() - t0
+        self._threads(self._build)
+        self.build_s = time.perf_counter() - t0
 
-    # all cores: wall time of the evaluation calls only (loading / window building of the oracle contexts is untimed, as on the GPU)
-    spans = [0.0] * T
-    th = [threading.Thread(target=lambda t=t: spans.__setitem__(t, work(t))) for t in range(T)]
-    t0 = time.perf_counter()
-    for x in th:
-        x.start()
-    for x in th:
-        x.join()
-    wall_all = time.perf_counter() - t0
-    evals = sum(universe) * C
-    eval_wall = max(spans)
-    total = np.sum(results, axis=0)
+    def _threads(self, fn):
+        th = [threading.Thread(target=fn, args=(t,)) for t in range(self.T)]
+        for x in th:
+            x.start()
+        for x in th:
+            x.join()
+
+    def _build(self, t):
+        w = self.w
+        blk = self.rows[self.bounds[t]:self.bounds[t + 1]]
+        ora = self.lib.context(0)
+        ora.load_msa(blk.reshape(-1), np.arange(blk.shape[0] + 1, dtype=np.int64) * w.L)
+        n_ex = ora.build_windows(w.p0, w.W, w.k, w.v)
+        expand_exceptions(ora, n_ex, w.k, w.v)
+        alln = ora.eval_candidates(np.arange(w.W, dtype=np.int32), np.full((w.W, w.k), 15, np.uint8), 0, 0)
+        self.universe[t] = alln[:, 0] + alln[:, 1]
+        self.ctxs[t] = ora
+
+    def eval(self, cw, codes):
+        """(counters summed over the row blocks, wall time of the slowest thread's evaluation call)."""
+        res, spans = [None] * self.T, [0.0] * self.T
+
+        def work(t):
+            t0 = time.perf_counter()
+            res[t] = self.ctxs[t].eval_candidates(cw, codes, self.w.sF, self.w.sR)
+            spans[t] = time.perf_counter() - t0
+
+        self._threads(work)
+        return np.sum(res, axis=0), max(spans)
+
+    def universe_total(self, windows=None):
+        u = np.sum(self.universe, axis=0)
+        return int(u.sum() if windows is None else u[windows].sum())
+
+    def close(self):
+        for c in self.ctxs:
+            if c is not None:
+                c.close()
+        self.ctxs = []
+
+
+def cpu_baseline(w, blocks, gpu_counters, seed, one_core=True, python_leg=True):
+    """The oracle on the host cores: EVERY core over row blocks of the sample and one core on a bounded sub-sample.  When the sample
+    is the whole workload its summed counters are compared with the GPU's, candidate by candidate."""
+    if blocks.lib is None:
+        return {"value": None, "unit": "evals/s", "cores": 0, "kind": "port", "sample": "oracle library not built", "parity_checked": None}
+    W, C, n, T = w.W, w.C, blocks.n, blocks.T
+    total, eval_wall = blocks.eval(w.cw, w.codes)
+    evals = blocks.universe_total() * C
     parity = None
     if gpu_counters is not None:
         parity = bool(np.array_equal(total, gpu_counters))
-    out = {"value": evals / eval_wall, "unit": "evals/s", "cores": T, "kind": "port", "host_cores": cores,
-           "sample": f"all {n} sequences, all {W} windows x {C} candidates = {evals} evals on {T} threads (of {cores} host cores) in {eval_wall:.2f} s "
-                     f"(oracle/mprime_oracle.c; {wall_all:.1f} s incl. building the oracle's own tables)",
+    out = {"value": evals / eval_wall, "unit": "evals/s", "cores": T, "kind": "port", "host_cores": blocks.cores,
+           "sample": f"all {n} sequences, all {W} windows x {C} candidates = {evals} evals on {T} threads (of {blocks.cores} host cores) in {eval_wall:.2f} s "
+                     f"(oracle/mprime_oracle.c; its own tables built beforehand in {blocks.build_s:.1f} s, untimed like the GPU's planes)",
            "parity_checked": parity,
-           "parity_note": "per candidate, all three counters, GPU == sum of the oracle's row blocks" if parity is not None else "sample is not the whole workload: no comparison"}
+           "parity_note": "per candidate, all three counters, GPU == sum of the oracle's row blocks" if parity is not None else "sample is not the whole workload: no comparison",
+           "reference_in_kernel_note": "BASELINE.md section 2: the reference itself (V20, one core - its pool is inert) ran 1.8-2.8e5 evals/s inside mis_primer_check and "
+                                       "4.5-7.3e4 evals/s end to end in the authoring container; it cannot run on the GPU box (absent there), `python_reference` restates it"}
     if one_core:            # a bounded sub-sample (first rows)
+        L, p0, k, v = w.L, w.p0, w.k, w.v
         n1 = max(256, min(n, 8192))
-        ora = lib.context(0)
-        ora.load_msa(rows[:n1].reshape(-1), np.arange(n1 + 1, dtype=np.int64) * L)
+        ora = blocks.lib.context(0)
+        ora.load_msa(blocks.rows[:n1].reshape(-1), np.arange(n1 + 1, dtype=np.int64) * L)
         n_ex = ora.build_windows(p0, W, k, v)
         expand_exceptions(ora, n_ex, k, v)
         alln = ora.eval_candidates(np.arange(W, dtype=np.int32), np.full((W, k), 15, np.uint8), 0, 0)
@@ -584,9 +733,10 @@ def cpu_baseline(w, rows, n_threads, gpu_counters, seed, one_core=True, python_l
         t0 = time.perf_counter()
         ora.eval_candidates(w.cw, w.codes, w.sF, w.sR)
         dt1 = time.perf_counter() - t0
+        ora.close()
         out["one_core"] = {"value": ev1 / dt1, "cores": 1, "sample": f"first {n1} sequences, {ev1} evals in {dt1:.2f} s"}
     if python_leg:
-        out["python_reference"] = python_reference_leg(w, lib, seed)
+        out["python_reference"] = python_reference_leg(w, blocks.lib, seed)
     return out
 
 

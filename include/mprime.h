@@ -182,6 +182,14 @@ int mp_pair_coverage_resident(mp_ctx *ctx, int64_t n_pairs, const int32_t *pairs
 int mp_eval_upload(mp_ctx *ctx, int32_t n_cand, const int32_t *cand_window, const uint8_t *cand_codes,
                    uint64_t strictF, uint64_t strictR);
 int mp_eval_launch(mp_ctx *ctx, int64_t *device_out);
+/* The same evaluation for a caller that alternates between counter blocks (one step per alignment or per bucket of a pipelined
+ * all-reduce): mp_eval_launch clears device_out with a dispatch of its own before the evaluation adds to it — 4-5 us on the stream,
+ * a sixth of the evaluation of a 131072-row shard.  Here the CALLER vouches that device_out holds zeros (it was the device_clear of
+ * an earlier rotating launch on this stream, or the caller zeroed it), and device_clear — another [n_cand][3] block, or NULL — is
+ * set to zero by this launch's own workgroups beside their work, ready to be the device_out of the next launch.  Nothing else may be
+ * using device_clear while the launch runs (a collective still reading it on another stream must have been waited for).
+ * device_clear == device_out is an error. */
+int mp_eval_launch_rotating(mp_ctx *ctx, int64_t *device_out, int64_t *device_clear);
 
 /* HIP-event timing of the evaluation kernels themselves (recorded on the context's stream around
  * mp_eval_launch since the last reset): total milliseconds and number of launches timed.  Every

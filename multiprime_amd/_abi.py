@@ -55,6 +55,7 @@ SYMBOLS = [
     ("mp_pair_coverage_resident", C.c_int, [_p, C.c_int64, _p, _p]),
     ("mp_eval_upload", C.c_int, [_p, C.c_int32, _p, _p, C.c_uint64, C.c_uint64]),
     ("mp_eval_launch", C.c_int, [_p, _p]),
+    ("mp_eval_launch_rotating", C.c_int, [_p, _p, _p]),
     ("mp_eval_timing", C.c_int, [_p, C.c_int32, C.POINTER(C.c_double), C.POINTER(C.c_int32)]),
     ("mp_eval_timing_samples", C.c_int, [_p, C.c_int32, _p, C.POINTER(C.c_int32)]),
     ("mp_eval_plan_info", C.c_int, [_p, _p]),
@@ -98,7 +99,12 @@ class Library:
     """A shared library exporting the mprime C ABI."""
 
     def __init__(self, path: str | None = None):
-        # MPRIME_LIBRARY: another build of the same C ABI (a debug build of this library; the ABI checker the tests load)
+        # Without an explicit path the library IS the product's backend: libmprime_hip.so, or another BUILD of it named by
+        # MPRIME_LIBRARY (a debug / sanitizer build).  Whatever it is, it must say mp_backend_name() == "hip": the drop-in commands
+        # never run on the ABI checker by accident of an environment variable.  Test infrastructure that wants the checker behind a
+        # command line (tests/test_cli_multirank.py) has to say so twice: MPRIME_LIBRARY=<checker> AND MPRIME_TEST_CHECKER_BACKEND=1.
+        # Library(path) — what tests and tools do — loads what it is told to.
+        implicit = path is None
         path = path or os.environ.get("MPRIME_LIBRARY") or HIP_LIB
         if not os.path.exists(path):
             raise MprimeError(-2, f"{path} is missing — build it with `python -c 'import __graft_entry__ as g; g.build()'` "
@@ -110,6 +116,9 @@ class Library:
             fn.restype = res
             fn.argtypes = args
         self.backend = self.dll.mp_backend_name().decode()
+        if implicit and self.backend != "hip" and os.environ.get("MPRIME_TEST_CHECKER_BACKEND") != "1":
+            raise MprimeError(-2, f"{path} reports backend {self.backend!r}, not 'hip': the product runs on libmprime_hip.so only "
+                                  "(MPRIME_LIBRARY may name another build of it, not the CPU checker)")
 
     def context(self, device: int = 0) -> "Context":
         return Context(self, device)
@@ -375,6 +384,10 @@ class Context:
 
     def eval_launch(self, out_ptr: int):
         self._ck(self.d.mp_eval_launch(self.h, C.c_void_p(out_ptr)))
+
+    def eval_launch_rotating(self, out_ptr: int, clear_ptr: int = 0):
+        """Evaluate into the zeroed block at out_ptr; the same launch zeroes the block at clear_ptr (0: none) for the next one."""
+        self._ck(self.d.mp_eval_launch_rotating(self.h, C.c_void_p(out_ptr), C.c_void_p(clear_ptr) if clear_ptr else None))
 
     def eval_timing(self, reset: bool = False):
         ms, n = C.c_double(0), C.c_int32(0)

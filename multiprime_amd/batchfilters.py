@@ -62,6 +62,15 @@ def _exact_means(vals, seg):
     return out
 
 
+_ERR_ARG = -1          # MP_ERR_ARG (include/mprime.h)
+
+
+def _no_gap_or_unknown(codes, rc, what):
+    """The one refusal of the native forms that no other form may paper over: a primer with a gap or a symbol outside IUPAC."""
+    if ((codes == 0) | (codes > 15)).any():
+        raise host.MprimeError(rc, what + ": a primer holds a gap / unknown symbol")
+
+
 def _round2(x: np.ndarray) -> np.ndarray:
     """Python's round(v, 2) of every element: the double nearest to the correctly rounded two-decimal value of v (ties to even on
     the EXACT binary value).  rint(v * 100) / 100 is that same double whenever v * 100 is not within rounding error of a tie (the
@@ -94,9 +103,17 @@ def tm_of_primers(codes: np.ndarray):
         return []
     out = np.empty(n, np.float64)
     rc = host.dll().mp_primer_tm(k, n, host._ptr(codes), host._ptr(_TM_PARAMS), host._ptr(out))
-    if rc != 0:
-        raise host.MprimeError(rc, "mp_primer_tm: a primer holds a gap / unknown symbol or has too many expansions")
-    return out.tolist()
+    if rc == 0:
+        return out.tolist()
+    if rc not in (_ERR_ARG, host.MP_ERR_CAPACITY):
+        raise host.MprimeError(rc, "mp_primer_tm")
+    # The native form declines a primer of more than 2^22 expansions (a very high -d) or a mean beyond its 128-bit sum: such a primer
+    # goes through the numpy rows and Python's rationals, as rounds 2-3 did for every primer (the reference enumerates them all too);
+    # the others stay native.  A gap / unknown symbol fails there as well, with the expansion's own message.
+    _no_gap_or_unknown(codes, rc, "mp_primer_tm")
+    if n == 1:
+        return tm_of_primers_numpy(codes)
+    return [tm_of_primers(codes[i:i + 1])[0] for i in range(n)]
 
 
 def tm_of_primers_numpy(codes: np.ndarray):
@@ -184,8 +201,13 @@ def information_of_primers(codes: np.ndarray, gc_range, distance: int, native: b
         r3 = np.asarray([round(g / k, 3) for g in range(k + 1)], np.float64)
         gc_a, rep_a, hp_a = np.empty(n, np.float64), np.empty(n, np.uint8), np.empty(n, np.uint8)
         rc = host.dll().mp_primer_filters(k, n, host._ptr(codes), host._ptr(r3), int(distance), host._ptr(gc_a), host._ptr(rep_a), host._ptr(hp_a))
+        if rc in (_ERR_ARG, host.MP_ERR_CAPACITY):           # as in tm_of_primers: the primers the native form declines take the numpy forms
+            _no_gap_or_unknown(codes, rc, "mp_primer_filters")
+            if n == 1:
+                return information_of_primers(codes, gc_range, distance, native=False)
+            return [information_of_primers(codes[i:i + 1], gc_range, distance)[0] for i in range(n)]
         if rc != 0:
-            raise host.MprimeError(rc, "mp_primer_filters: a primer holds a gap / unknown symbol or has too many expansions")
+            raise host.MprimeError(rc, "mp_primer_filters")
         gcs, rep, hp = gc_a.tolist(), rep_a.astype(bool).tolist(), hp_a.astype(bool).tolist()
     else:
         gcs = gc_of_primers(codes)

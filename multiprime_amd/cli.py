@@ -93,8 +93,7 @@ def _respawn(n, argv):
             skip = True
         elif not tok.startswith("--ngpu="):
             rest.append(tok)
-    script = os.path.abspath(sys.argv[0]) if argv is None else os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))),
-                                                                            "scripts", "multiPrime-core.py")
+    script = _script_and_args(argv)[0]
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
            "--master-port", str(port), script] + rest
     return subprocess.call(cmd)
@@ -115,7 +114,15 @@ def _closing_line(e1, e2):
                                            round(float(e2 - e1), 2)), flush=True)
 
 
-def _run_batch(args, rank, world, device):
+def _script_and_args(argv):
+    """(script, arguments) of this command as a child process would be started: the process's own command line when main() was
+    called without arguments, else the drop-in script with the arguments main() was given (a host program calling main([...]))."""
+    if argv is None:
+        return os.path.abspath(sys.argv[0]), list(sys.argv[1:])
+    return os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "scripts", "multiPrime-core.py"), list(argv)
+
+
+def _run_batch(args, rank, world, device, argv=None):
     pairs = []
     with open(args.batch) as f:
         for line in f:
@@ -134,13 +141,30 @@ def _run_batch(args, rank, world, device):
         # Several PROCESSES on this GPU: the per-cluster Python (filters, TSV rows, array plumbing) holds the interpreter lock, so
         # threads stop scaling at ~60 clusters/s; processes do not share it.  Each child pays its own start-up (0.3-0.4 s, in parallel).
         n = min(args.batch_procs, len(mine))
-        argv = [a for a in sys.argv[1:]]
-        kids = [subprocess.Popen([sys.executable, os.path.abspath(sys.argv[0])] + argv + ["--batch-part", f"{i}/{n}", "--device", str(device)],
+        script, rest = _script_and_args(argv)
+        kids = [subprocess.Popen([sys.executable, script] + rest + ["--batch-part", f"{i}/{n}", "--device", str(device)], stdout=subprocess.PIPE, text=True,
                                  env=dict(os.environ, RANK=str(rank), WORLD_SIZE=str(world), MP_SHARE_DEVICE="1"))
                 for i in range(n)]
+        # a child's lines pass through as they are, except its own summary (tagged "part"): the parent prints ONE summary for the rank
+        sequences, lock = [0], threading.Lock()
+
+        def relay(kid):
+            for line in kid.stdout:
+                if line.startswith('{"batch"') and '"part"' in line:
+                    with lock:
+                        sequences[0] += json.loads(line).get("sequences", 0)
+                else:
+                    sys.stdout.write(line)
+                    sys.stdout.flush()
+
+        th = [threading.Thread(target=relay, args=(k,)) for k in kids]
+        for t in th:
+            t.start()
+        for t in th:
+            t.join()
         codes = [k.wait() for k in kids]
         dt = time.time() - t0
-        print(json.dumps({"batch": args.batch, "rank": rank, "n_ranks": world, "clusters": len(mine), "processes": n,
+        print(json.dumps({"batch": args.batch, "rank": rank, "n_ranks": world, "clusters": len(mine), "sequences": sequences[0], "processes": n,
                           "seconds": round(dt, 3), "clusters_per_s": round(len(mine) / dt, 2) if dt > 0 else None}), flush=True)
         if any(codes):
             raise SystemExit(next(c for c in codes if c))
@@ -191,8 +215,11 @@ def _run_batch(args, rank, world, device):
             raise SystemExit(e.code)
         raise RuntimeError(f"{inp}: {e}") from e
     dt = time.time() - t0
-    print(json.dumps({"batch": args.batch, "rank": rank, "n_ranks": world, "clusters": len(mine), "sequences": rows[0], "workers": workers,
-                      "seconds": round(dt, 3), "clusters_per_s": round(len(mine) / dt, 2) if dt > 0 else None}), flush=True)
+    summary = {"batch": args.batch, "rank": rank, "n_ranks": world, "clusters": len(mine), "sequences": rows[0], "workers": workers,
+               "seconds": round(dt, 3), "clusters_per_s": round(len(mine) / dt, 2) if dt > 0 else None}
+    if args.batch_part:
+        summary["part"] = args.batch_part                # a child of --batch-procs: the parent folds this line into its own
+    print(json.dumps(summary), flush=True)
 
 
 def main(argv=None):
@@ -206,7 +233,7 @@ def main(argv=None):
     base = args.device if args.device is not None else 0
     device = base if world == 1 or os.environ.get("MP_SHARE_DEVICE") == "1" else base + local
     if args.batch is not None:
-        _run_batch(args, rank, world, device)           # clusters are independent: no process group, no collective
+        _run_batch(args, rank, world, device, argv)     # clusters are independent: no process group, no collective
         return
     comm = None
     if world > 1:                                       # one alignment on several GPUs: its rows are sharded

@@ -227,7 +227,8 @@ class NN_degenerate(object):
         self._native_json = self.write_json and self.comm is None and os.environ.get("MP_JSON_WRITER", "native") != "python"
         # one rank without JSON side files on the HIP library: the entries never come to Python — the planning stage reads them back
         # in bands of windows beside its own work (mp_plan_create_streamed; MP_PLAN_STREAM=0 keeps the two blocking calls)
-        streamed = (self.comm is None and not self.write_json and self.lib.backend == "hip" and os.environ.get("MP_PLAN_STREAM", "1") != "0")
+        streamed = (self.comm is None and not self.write_json and self.lib.backend == "hip" and os.environ.get("MP_PLAN_STREAM", "1") != "0"
+                    and host.serves_device_library(self.lib))
         x_row = ex_r.astype(np.int64) + row_base
         if streamed:
             self.ctx.window_unique_device()

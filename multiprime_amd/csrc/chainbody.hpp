@@ -29,7 +29,17 @@ struct EvalChainArgs {
     PatchArgs patch;                   // patch / IUPAC rows: the first patch.n_blocks workgroups run on their planes
     const ChainItem *neg_items;        // the items of the subtracting run (patch.neg_blocks workgroups), n_neg of them
     int n_neg;
+    unsigned long long *clear;         // mp_eval_launch_rotating: the NEXT launch's counter block, zeroed by this launch's grid (may be null)
+    uint32_t n_clear;
 };
+
+// The side job of a rotating launch: the counter block the next launch will add to is set to zero by THIS launch's own workgroups
+// (one store per thread at the bench sizes) instead of by a fill dispatch between two evaluations — a dispatch of its own costs 4-5 us
+// on the stream, a sixth of the evaluation of a 131072-row shard.
+__device__ __forceinline__ void clear_counters(unsigned long long *__restrict__ p, uint32_t n, unsigned bid, unsigned n_blocks) {
+    if (!p) return;
+    for (uint32_t i = bid * kBlock + threadIdx.x; i < n; i += n_blocks * kBlock) p[i] = 0ull;
+}
 
 // One pass of the first candidate over the positions in `rem` whose symbol has NB bases (NB = 4: three or four,
 // all planes loaded and masked).  D positions of loads are requested before the first one is consumed; no other

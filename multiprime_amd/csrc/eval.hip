@@ -347,6 +347,8 @@ struct EvalBitsArgs {
     PatchArgs patch;                   // patch / IUPAC rows: the first patch.n_blocks workgroups run on their planes
     uint32_t *mask_f, *mask_r;         // MASKS form: [candidate][2 nw] "not covered" bit sets instead of counts (mp_eval_masks)
     int n_rows;
+    unsigned long long *clear;         // mp_eval_launch_rotating: the next launch's counter block (chainbody.hpp: clear_counters)
+    uint32_t n_clear;
 };
 
 
@@ -363,6 +365,7 @@ template <int LV, int GW, bool CHAIN, int D, bool MASKS = false>
 __global__ __launch_bounds__(kBlock) void eval_bits_kernel(const EvalBitsArgs A) {
     constexpr int CC = 8;
     __shared__ uint32_t s_part[kBlock / 64][3 * CC / 2];
+    if (!MASKS) clear_counters(A.clear, A.n_clear, blockIdx.x, gridDim.x);
     const bool on_patch = (int)blockIdx.x < A.patch.n_blocks;
     int slice, idx, word0;
     if (on_patch) {                                    // a wave per patch unit: everything below is wave-uniform
@@ -540,6 +543,7 @@ __global__ __launch_bounds__(kBlock) void eval_bits_kernel(const EvalBitsArgs A)
 template <int LV, int GW, int D>
 __global__ __launch_bounds__(kBlock) void eval_chain_kernel(const EvalChainArgs A) {
     __shared__ uint32_t s_part[kBlock / 64][12];
+    clear_counters(A.clear, A.n_clear, blockIdx.x, gridDim.x);
     eval_chain_block<LV, GW, D>(A, s_part, blockIdx.x);
 }
 
@@ -552,6 +556,7 @@ __global__ __launch_bounds__(kBlock) void eval_chain_long_kernel(const EvalChain
     static_assert(GW <= 8, "plane rows are padded to multiples of 8 words");
     constexpr int CC = 8;
     __shared__ uint32_t s_part[kBlock / 64][3 * CC / 2];
+    clear_counters(A.clear, A.n_clear, blockIdx.x, gridDim.x);
     // the patch units come first; a second run of them (sliding evaluation) subtracts the plain slices of the items that slide
     const int patch_blocks = A.patch.n_blocks + A.patch.neg_blocks;
     const bool on_patch = (int)blockIdx.x < patch_blocks;
@@ -1207,19 +1212,27 @@ int mp_eval_upload(mp_ctx *c, int32_t n_cand, const int32_t *cw, const uint8_t *
     return MP_OK;
 }
 
-int mp_eval_launch(mp_ctx *c, int64_t *device_out) {
+// zero_out: the launch clears device_out itself first (mp_eval_launch).  Otherwise the caller vouches for a zeroed device_out
+// (mp_eval_launch_rotating) and `device_clear`, if given, is zeroed by the first evaluation kernel of the step inside its own grid.
+static int eval_launch_impl(mp_ctx *c, int64_t *device_out, int64_t *device_clear, bool zero_out) {
     if (!c) return MP_ERR_ARG;
     if (!c->excl) return fail(c, MP_ERR_ARG, "no windows built");
     if (!device_out) return fail(c, MP_ERR_ARG, "null output");
+    if (device_clear == device_out) return fail(c, MP_ERR_ARG, "the block to clear is the block to fill");
     HIPCK(c, hipSetDevice(c->dev));
     if (c->n_cand == 0) return MP_OK;
+    const size_t n_counters = 3 * (size_t)c->n_cand;
+    auto zero = [&](int64_t *p) {
+        hipLaunchKernelGGL(zero_kernel, dim3((unsigned)((n_counters + 4 * kBlock - 1) / (4 * kBlock))), dim3(kBlock), 0, c->stream,
+                           reinterpret_cast<unsigned long long *>(p), n_counters);
+    };
     // the counters are summed with atomics: they start at zero.  A launch of our own: the runtime's fill kernel takes 6 us per call
     // at this size (profiles/r02_pipeline_kernels.txt), a fifth of the evaluation itself
-    {
-        const size_t n = 3 * (size_t)c->n_cand;
-        hipLaunchKernelGGL(zero_kernel, dim3((unsigned)((n + 4 * kBlock - 1) / (4 * kBlock))), dim3(kBlock), 0, c->stream,
-                           reinterpret_cast<unsigned long long *>(device_out), n);
-    }
+    if (zero_out) zero(device_out);
+    // the rotating form's side job goes to the first kernel of the step that can take it (a kernel that cannot leaves it pending)
+    unsigned long long *pending_clear = reinterpret_cast<unsigned long long *>(device_clear);
+    auto take_clear = [&]() { unsigned long long *p = pending_clear; pending_clear = nullptr; return p; };
+    const uint32_t n_clear = (uint32_t)n_counters;
     // enough blocks to fill 256 CUs several times over, each with at least 1024 sequences
     int max_split = (c->n_pad + 1023) / 1024;
     int want = (4096 + c->n_items - 1) / c->n_items;
@@ -1307,7 +1320,7 @@ int mp_eval_launch(mp_ctx *c, int64_t *device_out) {
                                      (unsigned long long *)device_out, rbm, none, nullptr, 0};
                     hipLaunchKernelGGL((c->rest_max_steps > kEvalCC ? lfn : cfn)[c->v][cshape], dim3(rgrid), dim3(kBlock), 0, c->stream, ra);
                 }
-                int rc = launch_eval_slide(c, (unsigned long long *)device_out, patch_blocks ? &pa2 : nullptr, patch_blocks);
+                int rc = launch_eval_slide(c, (unsigned long long *)device_out, patch_blocks ? &pa2 : nullptr, patch_blocks, take_clear(), n_clear);
                 if (rc) return rc;
             } else {
             if (use_prog) {
@@ -1315,6 +1328,7 @@ int mp_eval_launch(mp_ctx *c, int64_t *device_out) {
                 int rc = launch_eval_prog(c, cshape, bm, ca.patch, grid, (unsigned long long *)device_out);
                 if (rc) return rc;
             } else {
+                ca.clear = take_clear(); ca.n_clear = n_clear;
                 hipLaunchKernelGGL((c->max_steps > kEvalCC ? lfn : cfn)[c->v][cshape], dim3(grid + (unsigned)ca.patch.n_blocks), dim3(kBlock), 0,
                                    c->stream, ca);
             }
@@ -1326,7 +1340,7 @@ int mp_eval_launch(mp_ctx *c, int64_t *device_out) {
             const BlockMap bm = block_map(2, n_tab, grid);
             EvalBitsArgs ba{c->cols, c->excl, nw, c->p0, c->k, c->v, c->items, c->cand_symT, c->cand_out, (uint32_t)c->sF, (uint32_t)c->sR,
                             (unsigned long long *)device_out, bm, c->cand_diff, shape == 0 ? c->table_ids : (const int32_t *)nullptr,
-                            patch_args(c, 2, n_tab, 64), nullptr, nullptr, c->n_rows};
+                            patch_args(c, 2, n_tab, 64), nullptr, nullptr, c->n_rows, take_clear(), n_clear};
             hipLaunchKernelGGL(tfn[c->v][shape == 1 ? 1 : 0], dim3(grid + (unsigned)ba.patch.n_blocks), dim3(kBlock), 0, c->stream, ba);
         }
     } else if (c->wide) {
@@ -1347,6 +1361,7 @@ int mp_eval_launch(mp_ctx *c, int64_t *device_out) {
     hipLaunchKernelGGL(kEvalVariants[variant].fn[getenv("MP_EVAL_GENERIC_V") ? 2 : vmode], dim3((unsigned)c->n_items, (unsigned)split),
                        dim3(kBlock), 0, c->stream, ea);
     }
+    if (pending_clear) zero(device_clear);                  // no kernel of this step could take the side job (row-per-lane / program-driven forms)
     if (timed) {
         HIPCK(c, hipEventRecord(ev.second, c->stream));
         c->ev_busy.push_back(ev);
@@ -1354,6 +1369,10 @@ int mp_eval_launch(mp_ctx *c, int64_t *device_out) {
     HIPCK(c, hipGetLastError());
     return MP_OK;
 }
+
+int mp_eval_launch(mp_ctx *c, int64_t *device_out) { return eval_launch_impl(c, device_out, nullptr, true); }
+
+int mp_eval_launch_rotating(mp_ctx *c, int64_t *device_out, int64_t *device_clear) { return eval_launch_impl(c, device_out, device_clear, false); }
 
 int mp_eval_timing(mp_ctx *c, int32_t reset, double *total_ms, int32_t *n_launches) {
     if (!c) return MP_ERR_ARG;

@@ -38,6 +38,8 @@ struct SlideKernArgs {
     int max_items;                     // items of the largest band (LDS table rows)
     int n_slide_blocks;                // the grid's first workgroups slide; the rest run the step's patch units (chainbody.hpp)
     EvalChainArgs chain;
+    unsigned long long *clear;         // mp_eval_launch_rotating: the next launch's counter block (chainbody.hpp: clear_counters)
+    uint32_t n_clear;
 };
 
 template <int GW>
@@ -142,6 +144,7 @@ struct DevEnv {
 template <int LV, int GW>
 __global__ __launch_bounds__(kBlock) void eval_slide_kernel(const SlideKernArgs K) {
     extern __shared__ __align__(16) uint32_t lds[];
+    clear_counters(K.clear, K.n_clear, blockIdx.x, gridDim.x);
     if ((int)blockIdx.x >= K.n_slide_blocks) {
         // the tail of the grid: the patch-list rows of the same step (their real k-mers added, their plain slices taken back) — no
         // launch of their own, they fill the slots the sliding workgroups leave as they finish
@@ -271,7 +274,8 @@ int upload_eval_slide(mp_ctx *c, const std::vector<ChainItem> &chains, const std
     return MP_OK;
 }
 
-int launch_eval_slide(mp_ctx *c, unsigned long long *device_out, const EvalChainArgs *patch, int patch_blocks) {
+int launch_eval_slide(mp_ctx *c, unsigned long long *device_out, const EvalChainArgs *patch, int patch_blocks, unsigned long long *clear,
+                      uint32_t n_clear) {
 #define SLIDE_ROW(LV) {eval_slide_kernel<LV, 1>, eval_slide_kernel<LV, 2>, eval_slide_kernel<LV, 4>}
     static const SlideFn fn[4][3] = {SLIDE_ROW(1), SLIDE_ROW(2), SLIDE_ROW(3), SLIDE_ROW(4)};
 #undef SLIDE_ROW
@@ -290,6 +294,8 @@ int launch_eval_slide(mp_ctx *c, unsigned long long *device_out, const EvalChain
     K.n_slide_blocks = c->slide_n_bands * K.wc_pad;
     if (patch) K.chain = *patch;
     else { memset(&K.chain, 0, sizeof K.chain); patch_blocks = 0; }
+    K.chain.clear = nullptr; K.chain.n_clear = 0;
+    K.clear = clear; K.n_clear = n_clear;
     const size_t lds = ((size_t)(kBlock / 64) * ((size_t)c->k * 64 * gw + 48) + (size_t)c->slide_max_items * 12) * sizeof(uint32_t);
     if (lds > 160 * 1024) return fail(c, MP_ERR_ARG, "sliding evaluation: a band needs %zu bytes of LDS", lds);
     SlideFn f = fn[c->v][gi];

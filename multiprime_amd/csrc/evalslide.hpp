@@ -12,7 +12,9 @@ int upload_eval_slide(mp_ctx *c, const std::vector<ChainItem> &chains, const std
 struct EvalChainArgs;
 // `patch` (may be null) = the patch units of the same step (eval.hip: positive and subtracting run), `patch_blocks` workgroups of
 // eval_chain_block<LV, 8, 4>: they run as the tail of the sliding kernel's own grid instead of a launch of their own.
-int launch_eval_slide(mp_ctx *c, unsigned long long *device_out, const EvalChainArgs *patch, int patch_blocks);
+// `clear` (may be null): n_clear counters the launch sets to zero beside its work (mp_eval_launch_rotating).
+int launch_eval_slide(mp_ctx *c, unsigned long long *device_out, const EvalChainArgs *patch, int patch_blocks, unsigned long long *clear,
+                      uint32_t n_clear);
 void free_slide(mp_ctx *c);
 
 }  // namespace mp

@@ -57,7 +57,7 @@ double py_round2(double x) {
     return strtod(buf, nullptr);
 }
 
-// exact mean of finite doubles: false when the values do not fit the 128-bit sum (the caller falls back to Python's rationals)
+// exact mean of finite doubles: false when the values do not fit the 128-bit sum (the caller — batchfilters.py — takes such a primer through its numpy form and Python's rationals)
 bool exact_mean(const std::vector<double> &v, double &out) {
     if (v.empty()) return false;
     int emin = 0;

@@ -203,6 +203,10 @@ int mp_build_windows(mp_ctx *c, int32_t p0, int32_t n_win, int32_t k, int32_t v,
     free_windows(c);
     lap("build_windows: free");
     c->p0 = p0; c->n_win = n_win; c->k = k; c->v = v;
+    // free_windows() above released every array whose byte count depends on the word width — mp_device_bytes' accounting (dev_free
+    // takes the count from the CURRENT wsz(c)) is only right if nothing sized with the old width outlives this line
+    if (c->u_b0 || c->u_b1 || c->u_g || c->cand_n || c->patch_words || c->extra_words)
+        return fail(c, MP_ERR_DEVICE, "internal: arrays of the previous word width are still allocated");
     c->wide = k > MP_NARROW_K;            // 64-bit window words (winwords.hpp); wsz() = uint32 units per word
     size_t np = (size_t)c->n_pad;
     int rc;

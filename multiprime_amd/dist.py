@@ -207,29 +207,57 @@ class RowShards:
 
 
 class StepBuckets:
-    """Bucketed, double-buffered all-reduce of per-step counter blocks (bench.py, batch pipelines).
+    """Bucketed all-reduce of per-step counter blocks over a ring of buffers (bench.py, batch pipelines).
 
     `bucket` consecutive steps write into one [bucket][n][3] int64 buffer that is reduced with ONE collective
     (xGMI rings are latency-bound at a few hundred KB), asynchronously on the backend's stream, while the next
-    bucket's steps fill the other buffer.  Every step's block is reduced; `drain()` completes everything."""
+    buckets' steps fill the other buffers.  Every step's block is reduced; `drain()` completes everything.
 
-    def __init__(self, n, bucket, device, world=1, group=None):
+    Two ways to take a step's block:
+      begin_step()      the block; the caller's launch clears it itself (mp_eval_launch)
+      begin_rotating()  (block, next block): the block holds zeros already, and the launch that fills it also clears
+                        the block of the step after it (mp_eval_launch_rotating) — no fill dispatch between two
+                        evaluations.  The next block's buffer must be free of any collective before the launch is
+                        enqueued, so the ring is `depth` = 3 buffers deep when there is a collective (the reduction of
+                        bucket j has the whole of buckets j + 1 and j + 2, less one step, to complete) and 2 otherwise."""
+
+    def __init__(self, n, bucket, device, world=1, group=None, depth=None):
         self.B = max(1, int(bucket))
+        self.D = max(2, int(depth)) if depth else (3 if world > 1 else 2)
         self.world, self.group = world, group
-        self.buf = torch.zeros((2, self.B, n, 3), dtype=torch.int64, device=device)
-        self.works = [None, None]
-        self.i = 0
+        self.buf = torch.zeros((self.D, self.B, n, 3), dtype=torch.int64, device=device)
+        self.works = [None] * self.D
+        self.i = 0                  # steps taken since the start, monotonic (a drain rounds it up to a bucket border)
+        self.base = 0               # self.i at the start of the run the last drain() closed
+        self._run0 = 0
+
+    def _pos(self, i):
+        return (i // self.B) % self.D, i % self.B
+
+    def _free(self, b):
+        if self.works[b] is not None:
+            self.works[b].wait()            # stream-side: the current stream waits for the collective
+            self.works[b] = None
 
     def begin_step(self):
         """The [n][3] block this step writes; waits (stream-side) for the reduction that last used its buffer."""
-        b, slot = (self.i // self.B) & 1, self.i % self.B
-        if slot == 0 and self.works[b] is not None:
-            self.works[b].wait()
-            self.works[b] = None
+        b, slot = self._pos(self.i)
+        if slot == 0:
+            self._free(b)
         return self.buf[b, slot]
 
+    def begin_rotating(self):
+        """(this step's block — zeros —, the next step's block, which this step's launch has to clear)."""
+        b, slot = self._pos(self.i)
+        nb, nslot = self._pos(self.i + 1)
+        if slot == 0:
+            self._free(b)
+        if nslot == 0:
+            self._free(nb)
+        return self.buf[b, slot], self.buf[nb, nslot]
+
     def end_step(self):
-        b, slot = (self.i // self.B) & 1, self.i % self.B
+        b, slot = self._pos(self.i)
         self.i += 1
         if slot == self.B - 1:
             self._flush(b, self.B)
@@ -239,15 +267,19 @@ class StepBuckets:
             self.works[b] = dist.all_reduce(self.buf[b, :n_slots], op=dist.ReduceOp.SUM, group=self.group, async_op=True)
 
     def drain(self):
-        """Reduce the last, partial bucket and wait for everything in flight; the step counter restarts at 0."""
+        """Reduce the last, partial bucket and wait for everything in flight.  The next run starts on a bucket border with a
+        zeroed first block (so it may be a rotating one)."""
         if self.i % self.B:
-            self._flush((self.i // self.B) & 1, self.i % self.B)
-        for b in (0, 1):
-            if self.works[b] is not None:
-                self.works[b].wait()
-                self.works[b] = None
-        self.n_done, self.i = self.i, 0
+            self._flush(self._pos(self.i)[0], self.i % self.B)
+            self.i += self.B - self.i % self.B
+        for b in range(self.D):
+            self._free(b)
+        self.base, self._run0 = self._run0, self.i
+        self.n_done = self.i - self.base
+        b, slot = self._pos(self.i)
+        self.buf[b, slot].zero_()           # what the last rotating launch cleared is the block after ITS step, not this one
 
     def block_of(self, step):
-        """Reduced block of `step` (one of the last 2 * bucket steps before the last drain)."""
-        return self.buf[(step // self.B) & 1, step % self.B]
+        """Reduced block of `step` (0-based inside the run the last drain closed; one of its last (depth - 1) * bucket steps)."""
+        b, slot = self._pos(self.base + step)
+        return self.buf[b, slot]

@@ -78,6 +78,20 @@ def dll():
     return _dll
 
 
+def serves_device_library(lib) -> bool:
+    """True when the host stage loaded here is the SAME build as the device library `lib` and exports the entry point that takes one of
+    its contexts (mp_plan_create_streamed).  MP_HOST_LIB may name a host-only / sanitizer build and MPRIME_LIBRARY another device
+    build: an mp_ctx of one build must never be handed to code of another, so callers then take the blocking route."""
+    d = dll()
+    if not hasattr(d, "mp_plan_create_streamed"):
+        return False
+    mine = os.environ.get("MP_HOST_LIB", HIP_LIB)
+    try:
+        return os.path.samefile(mine, lib.path)
+    except OSError:
+        return False
+
+
 class Fasta:
     """Records of a FASTA / alignment file (parse_seq's record semantics, V20:441-455)."""
 

@@ -159,15 +159,21 @@ class off_targets(object):
         genes = [s[1:] if s.startswith(">") else s for s in fa.ids]          # a mapper names a sequence by its first token
         seqs, names = list(table.reads), table.names()
         # The reference hands every read to bowtie2, which ignores what it cannot align (an empty read from a blank line of the
-        # primer file — V9 get_term keeps it as key "" —, a read with U / I / N left after expansion).  This build does the same:
-        # such reads find nothing, with a warning naming them.  Only when NO read is usable is that an error.  A read beyond the
-        # packed pattern width is reported too ("Limits": use -l to map the 3' term of longer primers).
-        usable = [i for i, seq in enumerate(seqs)
-                  if seq and not (set(seq.upper()) - set("ACGT")) and 4 <= len(seq) <= PATTERN_MAX_LEN]
-        skipped = [names[i] for i in range(len(seqs)) if i not in set(usable)]
+        # primer file — V9 get_term keeps it as key "" —, a read with U / I / N left after expansion, a read shorter than a seed).
+        # This build does the same: such reads find nothing, with a warning naming them; only when NO read is usable is that an
+        # error.  A read BEYOND the packed pattern width is different: bowtie2 would map it, the scan cannot — reporting "no
+        # off-target" for a read that was never looked for would be wrong, so that is a hard error naming the read
+        # ("Limits": use -l to map the 3' term of longer primers).
+        too_long = [names[i] for i, seq in enumerate(seqs) if len(seq) > PATTERN_MAX_LEN]
+        if too_long:
+            raise ValueError("read(s) longer than the scan's {} bases: {} — map the 3' term instead (-l)".format(
+                PATTERN_MAX_LEN, ", ".join(repr(n) for n in too_long[:20]) + (" ..." if len(too_long) > 20 else "")))
+        usable = [i for i, seq in enumerate(seqs) if len(seq) >= 4 and not (set(seq.upper()) - set("ACGT"))]
+        usable_set = set(usable)
+        skipped = [names[i] for i in range(len(seqs)) if i not in usable_set]
         if skipped:
-            print("Warning: {} read(s) not scanned (empty, not ACGT after expansion, or outside 4..{} bases): {}".format(
-                len(skipped), PATTERN_MAX_LEN, ", ".join(repr(n) for n in skipped[:20]) + (" ..." if len(skipped) > 20 else "")),
+            print("Warning: {} read(s) not scanned (empty, shorter than 4 bases, or not ACGT after expansion), as bowtie2 ignores them: {}".format(
+                len(skipped), ", ".join(repr(n) for n in skipped[:20]) + (" ..." if len(skipped) > 20 else "")),
                 file=sys.stderr)
         if not usable:
             raise ValueError(f"no usable read: the scan takes 4..{PATTERN_MAX_LEN} bases of ACGT after expansion")

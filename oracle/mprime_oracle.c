@@ -537,6 +537,23 @@ int mp_eval_launch(mp_ctx *c, int64_t *out) {
     return eval_all(c, c->n_cand, c->cand_win, c->cand_codes, c->sF, c->sR, out);
 }
 
+/* the rotating form (mprime.h): out is taken as zeroed and ADDED to, the other block is cleared */
+int mp_eval_launch_rotating(mp_ctx *c, int64_t *out, int64_t *clear) {
+    if (!c || !c->cand_win) return c ? fail(c, MP_ERR_ARG, "mp_eval_upload has not run") : MP_ERR_ARG;
+    if (!out || clear == out) return fail(c, MP_ERR_ARG, "bad counter blocks");
+    size_t n = 3 * (size_t)c->n_cand;
+    int64_t *tmp = (int64_t *)malloc(sizeof(int64_t) * (n + 1));
+    if (!tmp) return fail(c, MP_ERR_NOMEM, "out of memory");
+    c->eval_n++;
+    int rc = eval_all(c, c->n_cand, c->cand_win, c->cand_codes, c->sF, c->sR, tmp);
+    if (rc == MP_OK) {
+        for (size_t i = 0; i < n; i++) out[i] += tmp[i];
+        if (clear) memset(clear, 0, sizeof(int64_t) * n);
+    }
+    free(tmp);
+    return rc;
+}
+
 int mp_eval_timing(mp_ctx *c, int32_t reset, double *ms, int32_t *n) {
     if (!c) return MP_ERR_ARG;
     if (ms) *ms = c->eval_ms;

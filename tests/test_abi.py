@@ -149,3 +149,16 @@ def test_product_never_reaches_into_the_oracle():
     for path in glob.glob(os.path.join(root, "multiprime_amd", "csrc", "*")):
         if os.path.isfile(path) and path.endswith((".hip", ".cpp", ".hpp")):
             assert "oracle/" not in open(path).read().replace("oracle/core_ref.py", ""), path
+
+
+def test_implicit_loader_refuses_a_backend_that_is_not_hip(oracle_lib, monkeypatch):
+    """Library() without a path is the product's loader: an environment variable must not be able to put the CPU checker behind a
+    drop-in command.  Library(path) — tests, tools — loads what it is told to; the CLI tests say so twice."""
+    from multiprime_amd._abi import Library, MprimeError
+    monkeypatch.setenv("MPRIME_LIBRARY", oracle_lib.path)
+    monkeypatch.delenv("MPRIME_TEST_CHECKER_BACKEND", raising=False)
+    with pytest.raises(MprimeError, match="not 'hip'"):
+        Library()
+    assert Library(oracle_lib.path).backend != "hip"
+    monkeypatch.setenv("MPRIME_TEST_CHECKER_BACKEND", "1")
+    assert Library().path == oracle_lib.path

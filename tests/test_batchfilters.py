@@ -127,3 +127,45 @@ def test_first_stem_hairpins_equal_the_pairing_step_scalar_check():
         want = [Primers_filter.hairpin_check(stub, p) for p in prim]
         codes = iupac.MASK_LUT[np.frombuffer("".join(prim).encode(), np.uint8)].reshape(len(prim), L)
         assert batchfilters.hairpin_first_stem_of_primers(codes, dist).tolist() == want and any(want)
+
+
+def test_primers_the_native_form_declines_take_the_numpy_form(monkeypatch):
+    """mp_primer_tm / mp_primer_filters decline a primer beyond 2^22 expansions (a very high -d) or a mean outside their 128-bit sum
+    (MP_ERR_CAPACITY / MP_ERR_ARG).  The run must not abort there: such a primer goes through the numpy form, the others stay native.
+    A stand-in library declines every primer with three or more degenerate positions; the results must not change."""
+    prim = random_primers(11, 200, 18, 0.1)
+    codes = iupac.MASK_LUT[np.frombuffer("".join(prim).encode(), np.uint8)].reshape(len(prim), 18)
+    want_tm = batchfilters.tm_of_primers(codes)
+    want_info = batchfilters.information_of_primers(codes, ["0.2", "0.7"], 4)
+    real = batchfilters.host.dll()
+    declined = {"tm": 0, "filters": 0}
+
+    def n_degenerate(ptr, n, k):
+        a = np.ctypeslib.as_array((np.ctypeslib.ctypes.c_uint8 * (n * k)).from_address(ptr.value)).reshape(n, k)
+        return (np.bitwise_count(a) > 1).sum(axis=1)
+
+    class Picky:
+        def mp_primer_tm(self, k, n, codes_p, params, out):
+            if (n_degenerate(codes_p, n, k) >= 3).any():
+                declined["tm"] += 1
+                return -4
+            return real.mp_primer_tm(k, n, codes_p, params, out)
+
+        def mp_primer_filters(self, k, n, codes_p, r3, distance, gc, rep, hp):
+            if (n_degenerate(codes_p, n, k) >= 3).any():
+                declined["filters"] += 1
+                return -1
+            return real.mp_primer_filters(k, n, codes_p, r3, distance, gc, rep, hp)
+
+        def __getattr__(self, name):
+            return getattr(real, name)
+
+    monkeypatch.setattr(batchfilters.host, "dll", lambda: Picky())
+    assert batchfilters.tm_of_primers(codes) == want_tm
+    assert [str(x) for x in batchfilters.information_of_primers(codes, ["0.2", "0.7"], 4)] == [str(x) for x in want_info]
+    assert declined["tm"] > 1 and declined["filters"] > 1
+    # a symbol no expansion knows still fails, with the expansion's message
+    bad = codes[:2].copy()
+    bad[1, 3] = 0
+    with pytest.raises(batchfilters.host.MprimeError):
+        batchfilters.tm_of_primers(bad)

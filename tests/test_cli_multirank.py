@@ -22,7 +22,7 @@ def _flags(name):
 
 
 def _env(oracle_lib):
-    env = dict(os.environ, MPRIME_LIBRARY=oracle_lib.path, MP_DIST_BACKEND="gloo", MASTER_ADDR="127.0.0.1")
+    env = dict(os.environ, MPRIME_LIBRARY=oracle_lib.path, MPRIME_TEST_CHECKER_BACKEND="1", MP_DIST_BACKEND="gloo", MASTER_ADDR="127.0.0.1")
     for key in ("RANK", "WORLD_SIZE", "LOCAL_RANK"):
         env.pop(key, None)
     return env
@@ -100,5 +100,9 @@ def test_batch_workers_and_processes_on_one_gpu(oracle_lib, tmp_path):
         for o in outs:
             check_outputs(name, o)
         assert r.stdout.count("Total times") == 5
-        last = [json.loads(line) for line in r.stdout.splitlines() if line.startswith("{")][-1]
+        summaries = [json.loads(line) for line in r.stdout.splitlines() if line.startswith("{")]
+        assert len(summaries) == 1                                      # the children's own summaries are folded into the rank's
+        last = summaries[-1]
         assert last["clusters"] == 5 and (last.get("processes") == 2 if tag == "procs" else last["workers"] == 3)
+        n_seq = sum(1 for line in open(inp) if line.startswith(">"))
+        assert last["sequences"] == 5 * n_seq

@@ -328,3 +328,55 @@ def test_kernel_shapes_and_extreme_k(hip_lib, oracle_lib, monkeypatch, n, k, v):
                     m.setenv(key, val)
                 got = hip.eval_candidates(cw, codes, sF, sR)
             assert np.array_equal(got, want), f"{kind} counters differ with {env or 'defaults'}"
+
+
+@pytest.mark.parametrize("n,v,kind", [(300, 1, "up"), (9000, 1, "mixed"), (40000, 2, "mixed")])
+def test_rotating_launches_match_oracle(hip_lib, oracle_lib, monkeypatch, n, v, kind):
+    """mp_eval_launch_rotating: the launch adds to a block the caller vouches is zero and clears the NEXT launch's block inside
+    its own grid (no fill dispatch between evaluations).  Three blocks in rotation, every kernel that can carry the side job
+    (nested-chain, symbol-table, sliding) and the forms that cannot (row-per-lane, program-driven: a fill launch of their own):
+    every launch's counters equal the oracle's, the cleared block is all zeros, and a block the launch must not touch is intact."""
+    import torch
+    L, k, p0 = 120, 18, 4
+    data, off, _ = fuzz_msa(501 + n + v, n, L, ragged=False, p_gap=0.03, p_iupac=0.002)
+    W = L - p0 - k - 3
+    rng = np.random.default_rng(n * 11 + v)
+    root = np.array([1, 2, 4, 8], np.uint8)[rng.integers(0, 4, size=L)]
+    cw, codes = chain_candidates(rng, root, W, k, kind)
+    sF = sum(1 << y for y in (2, 3) if y < k)
+    sR = sum(1 << y for y in (2, k - 3, k - 2))
+    hip, ora = both(hip_lib, oracle_lib, data, off)
+    for c in (hip, ora):
+        c.build_windows(p0, W, k, v)
+    want = ora.eval_candidates(cw, codes, sF, sR)
+    # the checker's own rotating form: adds to the block, clears the other
+    blk, other = want.copy(), np.full_like(want, 5)
+    ora.eval_upload(cw, codes, sF, sR)
+    ora.eval_launch_rotating(blk.ctypes.data, other.ctypes.data)
+    assert np.array_equal(blk, 2 * want) and not other.any()
+    dev = torch.device("cuda", 0)
+    hip.set_stream(torch.cuda.current_stream().cuda_stream)
+    for env in ({}, {"MP_EVAL_GROUP": "plain"}, {"MP_EVAL_BITS": "1"}, {"MP_EVAL_SLIDE": "1"}, {"MP_EVAL_SLIDE": "1", "MP_SLIDE_GW": "1", "MP_SLIDE_BAND": "5"},
+                {"MP_EVAL_MODE": "rows"}, {"MP_EVAL_PROG": "1"}):
+        with monkeypatch.context() as m:
+            for key, val in env.items():
+                m.setenv(key, val)
+            hip.eval_upload(cw, codes, sF, sR)
+            ring = torch.zeros((3, len(cw), 3), dtype=torch.int64, device=dev)
+            ring[1:] = 7                                         # only block 0 starts zeroed; 1 is cleared by launch 0, 2 by launch 1
+            for step in range(5):
+                a, b, c3 = step % 3, (step + 1) % 3, (step + 2) % 3
+                before = ring[c3].clone()
+                hip.eval_launch_rotating(ring[a].data_ptr(), ring[b].data_ptr())
+                torch.cuda.synchronize()
+                assert np.array_equal(ring[a].cpu().numpy(), want), f"step {step} with {env or 'defaults'}"
+                assert not ring[b].any().item(), f"step {step}: next block not cleared with {env or 'defaults'}"
+                assert torch.equal(ring[c3], before)
+            # no block to clear: the launch only adds (twice into the same block = twice the counts)
+            ring[0].zero_()
+            hip.eval_launch_rotating(ring[0].data_ptr())
+            hip.eval_launch_rotating(ring[0].data_ptr())
+            torch.cuda.synchronize()
+            assert np.array_equal(ring[0].cpu().numpy(), 2 * want)
+    with pytest.raises(Exception):
+        hip.eval_launch_rotating(ring[0].data_ptr(), ring[0].data_ptr())

@@ -199,7 +199,7 @@ def test_sharded_hip_contexts_match_reference(name, world, hip_lib, tmp_path):
     check_outputs(name, out)
 
 
-def _bucket_worker(rank, world, port, steps, bucket, q):
+def _bucket_worker(rank, world, port, steps, bucket, rotating, q):
     sys.path.insert(0, REPO)
     import torch
     import torch.distributed as dist
@@ -210,13 +210,20 @@ def _bucket_worker(rank, world, port, steps, bucket, q):
     try:
         ok = True
         sb = StepBuckets(5, bucket, torch.device("cpu"), world)
-        for round_ in range(2):                               # drain() must leave the object reusable
+        for round_ in range(3):                               # drain() must leave the object reusable
             for i in range(steps):
-                blk = sb.begin_step()
-                blk.copy_(torch.full((5, 3), (rank + 1) * 1000 + i + 100 * round_, dtype=torch.int64))   # "the kernel"
+                val = torch.full((5, 3), (rank + 1) * 1000 + i + 100 * round_, dtype=torch.int64)
+                if rotating:                                  # "the kernel" of mp_eval_launch_rotating: ADDS to its block, clears the next
+                    blk, nxt = sb.begin_rotating()
+                    ok = ok and bool((blk == 0).all()) and blk.data_ptr() != nxt.data_ptr()
+                    blk.add_(val)
+                    nxt.zero_()
+                else:                                         # "the kernel" of mp_eval_launch: clears its block itself
+                    sb.begin_step().copy_(val)
                 sb.end_step()
             sb.drain()
-            for i in range(max(0, steps - bucket), steps):    # at least the last bucket's worth is still in the buffers
+            keep = (sb.D - 1) * bucket                        # the ring still holds at least this many of the run's last steps
+            for i in range(max(0, steps - keep), steps):
                 want = sum((r + 1) * 1000 + i + 100 * round_ for r in range(world))
                 ok = ok and bool((sb.block_of(i) == want).all())
         if rank == 0:
@@ -225,14 +232,16 @@ def _bucket_worker(rank, world, port, steps, bucket, q):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world,steps,bucket", [(2, 9, 4), (2, 8, 4), (3, 5, 1), (2, 3, 8)])
-def test_bucketed_overlapped_allreduce_reduces_every_step(world, steps, bucket):
-    """bench.py's N > 1 exchange (dist.StepBuckets): several steps per collective, two buffers in flight, partial
-    last bucket — every step's block must come out as the sum over the ranks."""
+@pytest.mark.parametrize("rotating", [False, True])
+@pytest.mark.parametrize("world,steps,bucket", [(2, 9, 4), (2, 8, 4), (3, 5, 1), (2, 3, 8), (2, 7, 1)])
+def test_bucketed_overlapped_allreduce_reduces_every_step(world, steps, bucket, rotating):
+    """bench.py's N > 1 exchange (dist.StepBuckets): several steps per collective, a ring of buffers in flight, partial
+    last bucket — every step's block must come out as the sum over the ranks; with rotating launches (the launch that
+    fills a block clears the next step's) every block must be found zeroed."""
     ctx = mp.get_context("spawn")
     q = ctx.SimpleQueue()
     port = 31500 + (os.getpid() % 2000)
-    mp.spawn(_bucket_worker, args=(world, port, steps, bucket, q), nprocs=world, join=True)
+    mp.spawn(_bucket_worker, args=(world, port, steps, bucket, rotating, q), nprocs=world, join=True)
     assert q.get() is True
 
 

@@ -287,17 +287,21 @@ def test_scan_sites_equal_sam_sites_on_the_gpu(seed, hip_lib, tmp_path):
 
 def test_reads_the_scan_cannot_take_are_skipped_by_name(oracle_lib, tmp_path, capsys):
     """The reference hands every read to bowtie2, which ignores what it cannot align: a blank line of the primer file (V9 get_term
-    keeps it as read ""), non-ACGT letters, an over-long read.  Here they are skipped with a warning naming them; only a primer file
-    without ANY usable read is an error."""
+    keeps it as read ""), non-ACGT letters.  Here they are skipped with a warning naming them; only a primer file without ANY
+    usable read is an error.  A read beyond the scan's width is NOT skipped (bowtie2 would have mapped it): a ValueError names it."""
     ref = tmp_path / "ref.fa"
     ref.write_text(">g\n" + "ACGT" * 40 + "\n")
     primers = tmp_path / "p.fa"
     primers.write_text(">long\n" + "ACGT" * 17 + "\n")                          # 68 nt, whole primer: beyond MP_PATTERN_MAX_LEN
     app = off_targets(primer_file=str(primers), term_length=0, reference_file=str(ref), PCR_product_size="50,1200", mismatch_num=1,
                       outfile=str(tmp_path / "o"), term_threshold=4, library=oracle_lib)
-    with pytest.raises(ValueError, match="no usable read"):
+    with pytest.raises(ValueError, match="longer than the scan's 64 bases: 'long_0'"):
         app.run()
-    assert "long_0" in capsys.readouterr().err
+    both = tmp_path / "both.fa"
+    both.write_text(">f\nACGTACGTACGTACGTAC\n>long\n" + "ACGT" * 17 + "\n")       # a usable read beside it does not make the long one skippable
+    with pytest.raises(ValueError, match="long_0"):
+        off_targets(primer_file=str(both), term_length=0, reference_file=str(ref), PCR_product_size="50,1200", mismatch_num=1,
+                    outfile=str(tmp_path / "o"), term_threshold=4, library=oracle_lib).run()
     off_targets(primer_file=str(primers), term_length=20, reference_file=str(ref), PCR_product_size="50,1200", mismatch_num=1,
                 outfile=str(tmp_path / "o"), term_threshold=4, library=oracle_lib).run()      # its 20-base 3' term is fine
     # a blank line and a read with a letter no expansion removes, beside a good primer pair: the run completes, the good pair is found
