@@ -110,34 +110,65 @@ struct DevEnv {
     __device__ __forceinline__ void ring_read(int slot, uint32_t (&o)[GW]) const { ring_get(ring + slot * (64 * GW), o); }
     // The wave's OUT counts of the item's 8 member slots into the workgroup's table: 12 words per item, two 16-bit counts each
     // (registers 0-7: out1 | outF << 16 of slot q; 8-11: outR of slots 2 (q - 8), 2 (q - 8) + 1) — a workgroup covers 4 x 64 x 32 GW
-    // <= 32768 rows, so a field never carries.  Four DPP steps leave every row of 16 lanes with its sum, the rows' last lanes park
-    // theirs, lanes 0-11 add the four rows of their register and hand the packed pair to the table (ds_add, one address per lane:
-    // lanes of one wave never collide — eight lanes adding to ONE address took twice the whole kernel's time).
+    // <= 32768 rows, so a field never carries.
+    // A TRANSPOSING reduction: a step that adds partner lanes also halves the registers — of two registers, half of the lanes go on
+    // with the first and the other half with the second.  DPP masks select whole quads (bank_mask) and rows, so the steps ACROSS the
+    // quads of a row come first: row_ror:4 under bank masks 0x5 / 0xa takes 12 registers to 6 (even quads: the first register's quads
+    // summed in pairs, odd quads: the second's), row_ror:8 under 0x3 / 0xc takes 6 to 3 — quad q of register j then holds, lane by
+    // lane, the row's partial sums of register 4 j + q.  The two steps INSIDE a quad follow on 3 registers instead of 12, and
+    // v_permlane16_swap / v_permlane32_swap (gfx950) fold the four rows the same transposing way: 3 registers -> 1, whose row j (j < 3)
+    // holds the WAVE's total of register 4 j + q in quad q.  12 lanes hand them to the table (ds_add, one address per lane: lanes of
+    // one wave never collide — eight lanes adding to ONE address took twice the whole kernel's time).  31 instructions, no LDS
+    // parking, no wave barrier: round 4 reduced all 12 registers over the row (48 DPP adds), parked the rows' sums in LDS and had 12
+    // lanes add them up (66 instructions and two LDS round trips per item).
+    // The 24 DPP adds are written out: `v_add_u32_dpp dst, a, a ... bank_mask` leaves the quads outside the bank mask as they are, which
+    // is what lets one register take half of its quads' sums from itself and the other half from its partner register in two
+    // instructions (through the builtin — a v_mov_dpp whose result then has to be added — a pair costs three to four).  The order keeps
+    // every DPP read at least two instructions behind the write of its register (the hazard the compiler would otherwise pad with
+    // s_nop; it does not look inside an asm block, hence the s_nop in front: the inputs may come straight out of a VALU instruction).
     __device__ __forceinline__ void commit(int idx, const uint32_t (&accPF)[8], const uint32_t (&accR)[4]) {
-        uint32_t x[12];
-#pragma unroll
-        for (int q = 0; q < 8; q++) x[q] = accPF[q];
-#pragma unroll
-        for (int q = 0; q < 4; q++) x[8 + q] = accR[q];
-#pragma unroll
-        for (int q = 0; q < 12; q++) {
-            x[q] += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x[q], 0xB1, 0xF, 0xF, true);     // quad_perm [1,0,3,2]
-            x[q] += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x[q], 0x4E, 0xF, 0xF, true);     // quad_perm [2,3,0,1]
-            x[q] += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x[q], 0x141, 0xF, 0xF, true);    // row_half_mirror
-            x[q] += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x[q], 0x140, 0xF, 0xF, true);    // row_mirror: every lane = its row's sum
-        }
-        if ((lane & 15) == 15) {
-            u32x4 *row = reinterpret_cast<u32x4 *>(part + (lane >> 4) * 12);
-            row[0] = u32x4{x[0], x[1], x[2], x[3]};
-            row[1] = u32x4{x[4], x[5], x[6], x[7]};
-            row[2] = u32x4{x[8], x[9], x[10], x[11]};
-        }
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-        if (lane < 12) atomicAdd(&tab[idx * 12 + lane], part[lane] + part[12 + lane] + part[24 + lane] + part[36 + lane]);
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();                            // `part` is written again by the next item
+        uint32_t x0 = accPF[0], x1 = accPF[1], x2 = accPF[2], x3 = accPF[3], x4 = accPF[4], x5 = accPF[5], x6 = accPF[6], x7 = accPF[7];
+        uint32_t x8 = accR[0], x9 = accR[1], x10 = accR[2], x11 = accR[3];
+        asm volatile(
+            "s_nop 1\n\t"
+            // across quads, 12 -> 6 registers: the even quads of x[2q] go on with x[2q], the odd quads with x[2q + 1]
+            "v_add_u32_dpp %0, %0, %0 row_ror:4 row_mask:0xf bank_mask:0x5\n\t"
+            "v_add_u32_dpp %2, %2, %2 row_ror:4 row_mask:0xf bank_mask:0x5\n\t"
+            "v_add_u32_dpp %4, %4, %4 row_ror:4 row_mask:0xf bank_mask:0x5\n\t"
+            "v_add_u32_dpp %6, %6, %6 row_ror:4 row_mask:0xf bank_mask:0x5\n\t"
+            "v_add_u32_dpp %8, %8, %8 row_ror:4 row_mask:0xf bank_mask:0x5\n\t"
+            "v_add_u32_dpp %10, %10, %10 row_ror:4 row_mask:0xf bank_mask:0x5\n\t"
+            "v_add_u32_dpp %0, %1, %1 row_ror:4 row_mask:0xf bank_mask:0xa\n\t"
+            "v_add_u32_dpp %2, %3, %3 row_ror:4 row_mask:0xf bank_mask:0xa\n\t"
+            "v_add_u32_dpp %4, %5, %5 row_ror:4 row_mask:0xf bank_mask:0xa\n\t"
+            "v_add_u32_dpp %6, %7, %7 row_ror:4 row_mask:0xf bank_mask:0xa\n\t"
+            "v_add_u32_dpp %8, %9, %9 row_ror:4 row_mask:0xf bank_mask:0xa\n\t"
+            "v_add_u32_dpp %10, %11, %11 row_ror:4 row_mask:0xf bank_mask:0xa\n\t"
+            // 6 -> 3 registers: quads 0, 1 of x[4j] go on with x[4j] (quad 0: all of x[4j], quad 1: all of x[4j + 1]), quads 2, 3 with x[4j + 2]
+            "v_add_u32_dpp %0, %0, %0 row_ror:8 row_mask:0xf bank_mask:0x3\n\t"
+            "v_add_u32_dpp %4, %4, %4 row_ror:8 row_mask:0xf bank_mask:0x3\n\t"
+            "v_add_u32_dpp %8, %8, %8 row_ror:8 row_mask:0xf bank_mask:0x3\n\t"
+            "v_add_u32_dpp %0, %2, %2 row_ror:8 row_mask:0xf bank_mask:0xc\n\t"
+            "v_add_u32_dpp %4, %6, %6 row_ror:8 row_mask:0xf bank_mask:0xc\n\t"
+            "v_add_u32_dpp %8, %10, %10 row_ror:8 row_mask:0xf bank_mask:0xc\n\t"
+            // inside the quads: every lane of quad q = the row's sum of register 4j + q
+            "v_add_u32_dpp %0, %0, %0 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
+            "v_add_u32_dpp %4, %4, %4 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
+            "v_add_u32_dpp %8, %8, %8 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
+            "v_add_u32_dpp %0, %0, %0 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"
+            "v_add_u32_dpp %4, %4, %4 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"
+            "v_add_u32_dpp %8, %8, %8 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"
+            "s_nop 1"
+            : "+v"(x0), "+v"(x1), "+v"(x2), "+v"(x3), "+v"(x4), "+v"(x5), "+v"(x6), "+v"(x7), "+v"(x8), "+v"(x9), "+v"(x10), "+v"(x11));
+        // rows: (z0, z1) -> rows [z0: 0+1, z1: 0+1, z0: 2+3, z1: 2+3]; z2 with itself -> [0+1, 0+1, 2+3, 2+3]; halves -> [z0, z1, z2, z2]
+        typedef unsigned int u32pair __attribute__((ext_vector_type(2)));
+        const u32pair s01 = __builtin_amdgcn_permlane16_swap(x0, x4, false, false);
+        const uint32_t a = s01.x + s01.y;
+        const u32pair s22 = __builtin_amdgcn_permlane16_swap(x8, x8, false, false);
+        const uint32_t b = s22.x + s22.y;
+        const u32pair h = __builtin_amdgcn_permlane32_swap(a, b, false, false);
+        const uint32_t tot = h.x + h.y;
+        if (lane < 48 && (lane & 3) == 0) atomicAdd(&tab[idx * 12 + (lane >> 4) * 4 + ((lane >> 2) & 3)], tot);
     }
 };
 

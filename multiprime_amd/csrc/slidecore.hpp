@@ -199,15 +199,18 @@ SLIDE_HD void slide_item(Env &env, const SlideArgs &A, const typename Env::Rec &
 #pragma unroll
     for (int s = 0; s < 8; s++) {
         if (s > 0) {
-            const bool stF = (flags >> s) & 1u, stR = (flags >> (8 + s)) & 1u;
+            // one more mismatch puts a row OUT when it already has v of them (T[LV - 2]; any row when v = 0) or the position is strict:
+            // DF |= d & (T | strict), with the strict flag of the event as an all-ones / all-zeros scalar — no select, no branch
+            const uint32_t mF = (uint32_t)((int32_t)(flags << (31 - s)) >> 31), mR = (uint32_t)((int32_t)(flags << (23 - s)) >> 31);
 #pragma unroll
             for (int i = 0; i < GW; i++) {
                 const uint32_t d = F.d[s][i];
-                // one more mismatch puts a row OUT when it already has v of them (T[LV - 2]; any row when v = 0) or the position is strict
-                if (LV == 1 || stF) DF[i] |= d;
-                else DF[i] = bop<kSlOrAnd>(DF[i], d, T[LV >= 2 ? LV - 2 : 0][i]);
-                if (LV == 1 || stR) DR[i] |= d;
-                else DR[i] = bop<kSlOrAnd>(DR[i], d, T[LV >= 2 ? LV - 2 : 0][i]);
+                if (LV == 1) { DF[i] |= d; DR[i] |= d; }
+                else {
+                    const uint32_t t = T[LV - 2][i];
+                    DF[i] = bop<kSlOrAnd>(DF[i], d, t | mF);
+                    DR[i] = bop<kSlOrAnd>(DR[i], d, t | mR);
+                }
                 if (LV >= 4) T[2][i] = bop<kSlOrAnd>(T[2][i], T[1][i], d);
                 if (LV >= 3) T[1][i] = bop<kSlOrAnd>(T[1][i], T[0][i], d);
                 T[0][i] |= d;

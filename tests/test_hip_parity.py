@@ -3,6 +3,7 @@ C ABI, on seeded inputs — bit-exact (all outputs are integers / bit masks) —
 size-independent properties at the benchmark's full size."""
 import numpy as np
 import pytest
+import torch  # noqa: F401  (before the HIP library is loaded: torch brings a HIP runtime of its own, and the first one loaded serves the process)
 
 from multiprime_amd import iupac
 from multiprime_amd.synth import synth_block
@@ -336,7 +337,6 @@ def test_rotating_launches_match_oracle(hip_lib, oracle_lib, monkeypatch, n, v, 
     its own grid (no fill dispatch between evaluations).  Three blocks in rotation, every kernel that can carry the side job
     (nested-chain, symbol-table, sliding) and the forms that cannot (row-per-lane, program-driven: a fill launch of their own):
     every launch's counters equal the oracle's, the cleared block is all zeros, and a block the launch must not touch is intact."""
-    import torch
     L, k, p0 = 120, 18, 4
     data, off, _ = fuzz_msa(501 + n + v, n, L, ragged=False, p_gap=0.03, p_iupac=0.002)
     W = L - p0 - k - 3
