@@ -965,7 +965,8 @@ BlockMap make_block_map(int nw, int GW, int n_items, unsigned &grid) {
 // patch units of a launch over n_items items with GW words per thread and unit_threads threads per unit
 PatchArgs patch_args(const mp_ctx *c, int GW, int n_items, int unit_threads) {
     PatchArgs pa{c->pplanes, c->pvalid, c->pwin, 0, 0, nullptr, nullptr, 0};
-    if (c->max_npw > 0 && n_items > 0) {
+    static const bool skip = getenv("MP_EXPERIMENT_SKIP_PATCH") != nullptr;      // TIMING EXPERIMENTS ONLY (tools/): the counts come out wrong
+    if (c->max_npw > 0 && n_items > 0 && !skip) {
         pa.per_item = (c->max_npw + unit_threads * GW - 1) / (unit_threads * GW);
         const long long units = (long long)pa.per_item * n_items, per_block = kBlock / unit_threads;
         pa.n_blocks = (int)(((units + per_block - 1) / per_block + 7) / 8 * 8);

@@ -48,6 +48,7 @@ constexpr int kSlBorrow = slide_lut([](bool ci, bool s, bool br) { return (!ci &
 constexpr int kSlAndNot = slide_lut([](bool a, bool b, bool) { return a && !b; });
 constexpr int kSlOr3 = slide_lut([](bool a, bool b, bool c) { return a || b || c; });
 constexpr int kSlOrAnd = slide_lut([](bool a, bool b, bool c) { return a || (b && c); });                // a | (b & c)
+constexpr int kSlOrAndNot = slide_lut([](bool a, bool b, bool c) { return a || (b && !c); });            // a | (b & ~c)
 constexpr int kSlAndNotNot = slide_lut([](bool a, bool b, bool c) { return a && !b && !c; });
 constexpr int kSlOrNot = slide_lut([](bool a, bool b, bool) { return a || !b; });                         // a | ~b
 constexpr int kSlOrOrNot = slide_lut([](bool a, bool b, bool c) { return a || b || !c; });               // a | b | ~c
@@ -103,7 +104,7 @@ SLIDE_HD void slide_request(Env &env, const typename Env::Rec &rec, SlideFetch<G
 // One item: all eight member slots, straight-line (a slot the item does not have repeats the counts of the one before it — its plane
 // is the all-zero row — and reports to nobody).  SIMPLE (the host's flag; every chain of a refinement run has it): every event plane is
 // the plane of a base beyond the reference — no per-plane masks in the carry-save sum.
-template <int LV, int GW, bool SIMPLE, bool USE_VALID, class Env>
+template <int LV, int GW, bool SIMPLE, bool USE_VALID, bool NO_EXTRA, class Env>
 SLIDE_HD void slide_item(Env &env, const SlideArgs &A, const typename Env::Rec &rec, uint32_t hdr, const SlideCount (&cnt)[GW],
                          const uint32_t (&sv)[kSlideStrict][GW], const SlideFetch<GW> &F, uint32_t (&accPF)[8], uint32_t (&accR)[4]) {
     const int n_extra = (int)((hdr >> 8) & 15u);
@@ -133,8 +134,9 @@ SLIDE_HD void slide_item(Env &env, const SlideArgs &A, const typename Env::Rec &
         r.b4 = c.b4 ^ br;
         c0[i] = r;
     }
-    // corrections that are not events (rare): one plane each, straight onto the count
-    if (n_extra) {
+    // corrections that are not events (rare; a plan of simple items only has none — NO_EXTRA: the loop and the copies of the count
+    // around it are not even compiled): one plane each, straight onto the count
+    if (!NO_EXTRA && n_extra) {
         const uint32_t row0 = env.rec_word(rec, 30);
 #pragma unroll 1
         for (int x = 0; x < n_extra; x++) {
@@ -156,13 +158,13 @@ SLIDE_HD void slide_item(Env &env, const SlideArgs &A, const typename Env::Rec &
     for (int i = 0; i < GW; i++) DF[i] = DR[i] = 0u;
     // strict positions of the most degenerate member: the reference's mismatch word there, minus the rows a SUB plane of that
     // position takes back (they carry a base the member accepts)
+    // (DF |= word & ~(x | ~fF): with no event plane at the position — the usual case — x is nothing and ~fF a launch constant in a
+    // scalar register, so a position costs one instruction per word and set, and the ring's words are never copied)
 #pragma unroll
     for (int q = 0; q < kSlideStrict; q++) {
         if (q >= 4 && A.ns <= 4) break;
         const uint32_t sm = ((q < 4 ? sm_lo : sm_hi) >> (8 * (q & 3))) & 255u;
-        uint32_t v[GW];
-#pragma unroll
-        for (int i = 0; i < GW; i++) v[i] = sv[q][i];
+        const uint32_t nfF = ~(uint32_t)((int32_t)(A.fmask << (31 - q)) >> 31), nfR = ~(uint32_t)((int32_t)(A.rmask << (31 - q)) >> 31);
         if (sm) {
             uint32_t x[GW];
 #pragma unroll
@@ -174,13 +176,16 @@ SLIDE_HD void slide_item(Env &env, const SlideArgs &A, const typename Env::Rec &
                 for (int i = 0; i < GW; i++) x[i] = bop<kSlOrAnd>(x[i], F.d[s][i], m);
             }
 #pragma unroll
-            for (int i = 0; i < GW; i++) v[i] = bop<kSlAndNot>(v[i], x[i], 0u);
-        }
-        const uint32_t fF = (uint32_t)((int32_t)(A.fmask << (31 - q)) >> 31), fR = (uint32_t)((int32_t)(A.rmask << (31 - q)) >> 31);
+            for (int i = 0; i < GW; i++) {
+                DF[i] = bop<kSlOrAndNot>(DF[i], sv[q][i], x[i] | nfF);
+                DR[i] = bop<kSlOrAndNot>(DR[i], sv[q][i], x[i] | nfR);
+            }
+        } else {
 #pragma unroll
-        for (int i = 0; i < GW; i++) {
-            DF[i] = bop<kSlOrAnd>(DF[i], v[i], fF);
-            DR[i] = bop<kSlOrAnd>(DR[i], v[i], fR);
+            for (int i = 0; i < GW; i++) {
+                DF[i] = bop<kSlOrAndNot>(DF[i], sv[q][i], nfF);
+                DR[i] = bop<kSlOrAndNot>(DR[i], sv[q][i], nfR);
+            }
         }
     }
 #pragma unroll
@@ -201,16 +206,32 @@ SLIDE_HD void slide_item(Env &env, const SlideArgs &A, const typename Env::Rec &
         if (s > 0) {
             // one more mismatch puts a row OUT when it already has v of them (T[LV - 2]; any row when v = 0) or the position is strict:
             // DF |= d & (T | strict), with the strict flag of the event as an all-ones / all-zeros scalar — no select, no branch
-            const uint32_t mF = (uint32_t)((int32_t)(flags << (31 - s)) >> 31), mR = (uint32_t)((int32_t)(flags << (23 - s)) >> 31);
+            // (most events are at no strict position: a uniform branch keeps their two masks and two ORs per word out of the way)
+#ifndef SLIDE_WALK_BRANCH
+#define SLIDE_WALK_BRANCH 0
+#endif
+            if (LV >= 2 && (!SLIDE_WALK_BRANCH || ((flags >> s) & 0x101u))) {
+                const uint32_t mF = (uint32_t)((int32_t)(flags << (31 - s)) >> 31), mR = (uint32_t)((int32_t)(flags << (23 - s)) >> 31);
 #pragma unroll
-            for (int i = 0; i < GW; i++) {
-                const uint32_t d = F.d[s][i];
-                if (LV == 1) { DF[i] |= d; DR[i] |= d; }
-                else {
-                    const uint32_t t = T[LV - 2][i];
+                for (int i = 0; i < GW; i++) {
+                    const uint32_t d = F.d[s][i], t = T[LV >= 2 ? LV - 2 : 0][i];
                     DF[i] = bop<kSlOrAnd>(DF[i], d, t | mF);
                     DR[i] = bop<kSlOrAnd>(DR[i], d, t | mR);
                 }
+            } else {
+#pragma unroll
+                for (int i = 0; i < GW; i++) {
+                    const uint32_t d = F.d[s][i];
+                    if (LV == 1) { DF[i] |= d; DR[i] |= d; }
+                    else {
+                        DF[i] = bop<kSlOrAnd>(DF[i], d, T[LV >= 2 ? LV - 2 : 0][i]);
+                        DR[i] = bop<kSlOrAnd>(DR[i], d, T[LV >= 2 ? LV - 2 : 0][i]);
+                    }
+                }
+            }
+#pragma unroll
+            for (int i = 0; i < GW; i++) {
+                const uint32_t d = F.d[s][i];
                 if (LV >= 4) T[2][i] = bop<kSlOrAnd>(T[2][i], T[1][i], d);
                 if (LV >= 3) T[1][i] = bop<kSlOrAnd>(T[1][i], T[0][i], d);
                 T[0][i] |= d;
@@ -226,6 +247,29 @@ SLIDE_HD void slide_item(Env &env, const SlideArgs &A, const typename Env::Rec &
         accPF[s] = nP | (nF << 16);
         if (s & 1) accR[s >> 1] |= nR << 16;
         else accR[s >> 1] = nR;
+    }
+}
+
+// Warm-up of a band: N columns slide in at once — their planes are requested TOGETHER, then counted one after the other (nothing slides
+// out yet, no window is complete: no items).  The two-iterations-ahead pipeline of the main loop hides a column's latency behind the
+// ITEMS of two windows; a warm-up iteration has none, so k - 1 of them one behind the other cost k - 1 half memory round trips — a
+// third of the kernel's time at the 131072-row shard, where every wave of the chip warms up at the same moment
+// (tools/r05_exp2.sh: 17 columns, ~10 us of 29).
+template <int N, int GW, class Env>
+SLIDE_HD void slide_warm_chunk(Env &env, SlideCount (&cnt)[GW], int &slot, int j) {
+    uint32_t w[N][GW];
+#pragma unroll
+    for (int u = 0; u < N; u++) env.fetch(env.iter_word(2 * (j + u)), w[u]);
+#pragma unroll
+    for (int u = 0; u < N; u++) {
+        uint32_t bn[GW];
+#pragma unroll
+        for (int i = 0; i < GW; i++) {
+            bn[i] = ~w[u][i];                                           // rows that do not carry the reference base here
+            slide_updown(cnt[i], bn[i], bn[i]);                         // all of them go up
+        }
+        env.ring_write(slot, bn);
+        slot++;                                                         // (warm-up columns never wrap: fewer than k of them)
     }
 }
 
@@ -261,11 +305,22 @@ SLIDE_HD void slide_band(Env &env, const SlideArgs &A, int band_index) {
     SlideFetch<GW> F0, F1;
     slide_request<GW, USE_VALID>(env, rec0, F0);
     int done = 0;                                                       // items of the band behind us
+    env.load_iters(bd.iter0);
+    // warm-up: an EVEN number j0 of the band's first k - 1 iterations (they have no items and push nothing out) in chunks of 16, 8,
+    // 4, 2 columns in flight; what is left of them (at most one) and everything else runs in the main loop below, from iteration j0.
+    // (k - 1 <= 30 iterations: inside the first 64 iteration words.)
+    int j0 = 0;
+    {
+        const int n_warm = k - 1 < n_iter ? k - 1 : n_iter;
+        while (n_warm - j0 >= 16) { slide_warm_chunk<16, GW>(env, cnt, slot, j0); j0 += 16; }
+        if (n_warm - j0 >= 8) { slide_warm_chunk<8, GW>(env, cnt, slot, j0); j0 += 8; }
+        if (n_warm - j0 >= 4) { slide_warm_chunk<4, GW>(env, cnt, slot, j0); j0 += 4; }
+        if (n_warm - j0 >= 2) { slide_warm_chunk<2, GW>(env, cnt, slot, j0); j0 += 2; }
+    }
     // column pipeline: iteration j's column waits in set j & 1
     uint32_t bA[GW], bB[GW];
-    env.load_iters(bd.iter0);
-    env.fetch(env.iter_word(0), bA);
-    env.fetch(env.iter_word(n_iter > 1 ? 2 : 0), bB);
+    env.fetch(env.iter_word(2 * j0), bA);
+    env.fetch(env.iter_word(n_iter > j0 + 1 ? 2 * j0 + 2 : 2 * j0), bB);
 
     auto item = [&](typename Env::Rec &rec_cur, typename Env::Rec &rec_other, const SlideFetch<GW> &F_cur, SlideFetch<GW> &F_other,
                     const uint32_t (&sv)[kSlideStrict][GW]) __attribute__((always_inline)) {
@@ -275,8 +330,8 @@ SLIDE_HD void slide_band(Env &env, const SlideArgs &A, int band_index) {
         slide_request<GW, USE_VALID>(env, rec_other, F_other);                    // (behind the band's last item: that item's again, unused)
         const uint32_t hdr = env.rec_word(rec, 0);
         uint32_t accPF[8], accR[4];
-        if (ONLY_SIMPLE || (hdr & kSlSimple)) slide_item<LV, GW, true, USE_VALID>(env, A, rec, hdr, cnt, sv, F_cur, accPF, accR);
-        else slide_item<LV, GW, false, USE_VALID>(env, A, rec, hdr, cnt, sv, F_cur, accPF, accR);
+        if (ONLY_SIMPLE || (hdr & kSlSimple)) slide_item<LV, GW, true, USE_VALID, ONLY_SIMPLE>(env, A, rec, hdr, cnt, sv, F_cur, accPF, accR);
+        else slide_item<LV, GW, false, USE_VALID, false>(env, A, rec, hdr, cnt, sv, F_cur, accPF, accR);
         env.commit(done, accPF, accR);
         done++;
     };
@@ -317,12 +372,12 @@ SLIDE_HD void slide_band(Env &env, const SlideArgs &A, int band_index) {
         }
     };
     uint32_t boA[GW], boB[GW];
-    env.ring_read(0, boA);                                              // zeros: the first k columns push nothing out
+    env.ring_read(slot, boA);                                           // zeros: the first k columns push nothing out
 #pragma unroll 1
     for (int base = 0; base < n_iter; base += 30) {                     // 64 iteration words = 32 iterations, two of them look-ahead
         if (base) env.load_iters(bd.iter0 + 2 * base);
         const int n_here = n_iter - base < 30 ? n_iter - base : 30;     // 30 is even: an iteration's parity is that of j
-        int j = 0;
+        int j = base ? 0 : j0;                                          // (j0 is even and at most 30)
 #pragma unroll 1
         for (; j + 1 < n_here; j += 2) {
             iteration(bA, boA, boB, j);
