@@ -40,6 +40,7 @@ struct SlideKernArgs {
     EvalChainArgs chain;
     unsigned long long *clear;         // mp_eval_launch_rotating: the next launch's counter block (chainbody.hpp: clear_counters)
     uint32_t n_clear;
+    unsigned long long *stamps;        // null; MP_EXPERIMENT_STAMPS: [workgroup][8] wall-clock stamps of its phases (tools/slide_stamps.py)
 };
 
 template <int GW>
@@ -56,6 +57,10 @@ struct DevEnv {
     uint32_t live_mask;
 
     __device__ __forceinline__ DevEnv(const SlideKernArgs &k) : K(k) {}
+    // phase stamps of the experiment build-in (one lane per workgroup; a null pointer in every other run: one scalar compare)
+    __device__ __forceinline__ void stamp(int i) const {
+        if (K.stamps && threadIdx.x == 0) K.stamps[(size_t)blockIdx.x * 8 + i] = wall_clock64();
+    }
     __device__ __forceinline__ SlideBand uband(int b) const {
         const SlideBand *p = K.A.bands + b;
         SlideBand r;
@@ -176,11 +181,13 @@ template <int LV, int GW>
 __global__ __launch_bounds__(kBlock) void eval_slide_kernel(const SlideKernArgs K) {
     extern __shared__ __align__(16) uint32_t lds[];
     clear_counters(K.clear, K.n_clear, blockIdx.x, gridDim.x);
+    if (K.stamps && threadIdx.x == 0) K.stamps[(size_t)blockIdx.x * 8] = wall_clock64();
     if ((int)blockIdx.x >= K.n_slide_blocks) {
         // the tail of the grid: the patch-list rows of the same step (their real k-mers added, their plain slices taken back) — no
         // launch of their own, they fill the slots the sliding workgroups leave as they finish
         uint32_t(&s_part)[kBlock / 64][12] = *reinterpret_cast<uint32_t(*)[kBlock / 64][12]>(lds);
         eval_chain_block<LV, 8, 4>(K.chain, s_part, blockIdx.x - (unsigned)K.n_slide_blocks);
+        if (K.stamps && threadIdx.x == 0) K.stamps[(size_t)blockIdx.x * 8 + 7] = wall_clock64();
         return;
     }
     const int slice = (int)(blockIdx.x % (unsigned)K.wc_pad), band = (int)(blockIdx.x / (unsigned)K.wc_pad);
@@ -204,9 +211,12 @@ __global__ __launch_bounds__(kBlock) void eval_slide_kernel(const SlideKernArgs 
     const SlideBand bd = env.uband(band);
     for (int i = (int)threadIdx.x; i < bd.n_items * 12; i += kBlock) tab[i] = 0u;
     __syncthreads();
+    env.stamp(1);
     const bool wave_live = (slice * kBlock + wv * 64) * GW < K.nw32;          // some lane of the wave holds rows
     if (wave_live) slide_band<LV, GW, true, false>(env, K.A, band);
+    env.stamp(4);
     __syncthreads();
+    env.stamp(5);
     // One flush per workgroup and band.  The table holds OUT rows; member t of an item reports its slot's counts turned round:
     // perfect = rows - out1, forward (1..v mismatches, none at a strict position) = out1 - outF, reverse = out1 - outR.
     int live_waves = 0;
@@ -223,6 +233,7 @@ __global__ __launch_bounds__(kBlock) void eval_slide_kernel(const SlideKernArgs 
         const uint32_t val = kind == 0 ? rows - out1 : out1 - (kind == 1 ? outF : outR);
         if (val) atomicAdd(&K.out[(size_t)oc * 3 + kind], (unsigned long long)val);
     }
+    env.stamp(6);
 }
 
 typedef void (*SlideFn)(const SlideKernArgs);
@@ -327,12 +338,27 @@ int launch_eval_slide(mp_ctx *c, unsigned long long *device_out, const EvalChain
     else { memset(&K.chain, 0, sizeof K.chain); patch_blocks = 0; }
     K.chain.clear = nullptr; K.chain.n_clear = 0;
     K.clear = clear; K.n_clear = n_clear;
+    K.stamps = nullptr;
+    const char *stamp_file = getenv("MP_EXPERIMENT_STAMPS");           // tools/slide_stamps.py: the launch is synchronous then
+    const size_t n_stamp = ((size_t)K.n_slide_blocks + (size_t)patch_blocks) * 8;
+    if (stamp_file) {
+        HIPCK(c, hipMalloc(&K.stamps, n_stamp * sizeof(unsigned long long)));
+        HIPCK(c, hipMemsetAsync(K.stamps, 0, n_stamp * sizeof(unsigned long long), c->stream));
+    }
     const size_t lds = ((size_t)(kBlock / 64) * ((size_t)c->k * 64 * gw + 48) + (size_t)c->slide_max_items * 12) * sizeof(uint32_t);
     if (lds > 160 * 1024) return fail(c, MP_ERR_ARG, "sliding evaluation: a band needs %zu bytes of LDS", lds);
     SlideFn f = fn[c->v][gi];
     if (lds > 48 * 1024) HIPCK(c, hipFuncSetAttribute(reinterpret_cast<const void *>(f), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     hipLaunchKernelGGL(f, dim3((unsigned)K.n_slide_blocks + (unsigned)patch_blocks), dim3(kBlock), lds, c->stream, K);
     HIPCK(c, hipGetLastError());
+    if (stamp_file) {
+        std::vector<unsigned long long> h(n_stamp + 2);
+        HIPCK(c, hipStreamSynchronize(c->stream));
+        HIPCK(c, hipMemcpy(h.data() + 2, K.stamps, n_stamp * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+        HIPCK(c, hipFree(K.stamps));
+        h[0] = (unsigned long long)K.n_slide_blocks; h[1] = (unsigned long long)patch_blocks;
+        if (FILE *fo = fopen(stamp_file, "wb")) { fwrite(h.data(), sizeof(unsigned long long), h.size(), fo); fclose(fo); }
+    }
     return MP_OK;
 }
 

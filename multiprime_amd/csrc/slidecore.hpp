@@ -306,6 +306,7 @@ SLIDE_HD void slide_band(Env &env, const SlideArgs &A, int band_index) {
     slide_request<GW, USE_VALID>(env, rec0, F0);
     int done = 0;                                                       // items of the band behind us
     env.load_iters(bd.iter0);
+    env.stamp(2);
     // warm-up: an EVEN number j0 of the band's first k - 1 iterations (they have no items and push nothing out) in chunks of 16, 8,
     // 4, 2 columns in flight; what is left of them (at most one) and everything else runs in the main loop below, from iteration j0.
     // (k - 1 <= 30 iterations: inside the first 64 iteration words.)
@@ -317,6 +318,7 @@ SLIDE_HD void slide_band(Env &env, const SlideArgs &A, int band_index) {
         if (n_warm - j0 >= 4) { slide_warm_chunk<4, GW>(env, cnt, slot, j0); j0 += 4; }
         if (n_warm - j0 >= 2) { slide_warm_chunk<2, GW>(env, cnt, slot, j0); j0 += 2; }
     }
+    env.stamp(3);
     // column pipeline: iteration j's column waits in set j & 1
     uint32_t bA[GW], bB[GW];
     env.fetch(env.iter_word(2 * j0), bA);
