@@ -51,7 +51,6 @@ struct DevEnv {
     uint32_t row_bytes;
     bool live;
     uint32_t *ring;                    // this lane's GW words of slot 0; slots are 64 * GW words apart
-    uint32_t *part;                    // the wave's 4 x 12 words for its rows' packed sums
     uint32_t *tab;                     // the workgroup's counters [item of the band][12]
     uint32_t itv;                      // 64 iteration words, one per lane
     uint32_t live_mask;
@@ -194,11 +193,10 @@ __global__ __launch_bounds__(kBlock) void eval_slide_kernel(const SlideKernArgs 
     if (slice >= K.wc) return;
     const int wv = (int)(threadIdx.x >> 6), lane = (int)(threadIdx.x & 63);
     const int ring_words = K.A.k * 64 * GW;
-    uint32_t *tab = lds + (kBlock / 64) * ring_words + (kBlock / 64) * 48;
+    uint32_t *tab = lds + (kBlock / 64) * ring_words;
     DevEnv<GW> env(K);
     env.lane = lane;
     env.ring = lds + wv * ring_words + lane * GW;
-    env.part = lds + (kBlock / 64) * ring_words + wv * 48;
     env.tab = tab;
     env.itv = 0u;
     const int word0 = (slice * kBlock + (int)threadIdx.x) * GW;
@@ -222,16 +220,31 @@ __global__ __launch_bounds__(kBlock) void eval_slide_kernel(const SlideKernArgs 
     int live_waves = 0;
     for (int w = 0; w < kBlock / 64; w++) live_waves += (slice * kBlock + w * 64) * GW < K.nw32 ? 1 : 0;
     const uint32_t rows = (uint32_t)live_waves * 64u * 32u * GW;
-    for (int i = (int)threadIdx.x; i < bd.n_items * 24; i += kBlock) {
-        const int item = i / 24, r = i % 24, t = r / 3, kind = r % 3;                  // 0 perfect, 1 forward, 2 reverse
-        const uint32_t *rec = K.A.recs + (size_t)(bd.item0 + item) * kSlideRec;
-        const int oc = (int)rec[8 + t];
-        if (oc < 0) continue;
-        const int slot = (int)((rec[26] >> (4 * t)) & 15u);
-        const uint32_t *row = tab + item * 12;
-        const uint32_t out1 = row[slot] & 0xFFFFu, outF = row[slot] >> 16, outR = (row[8 + (slot >> 1)] >> (16 * (slot & 1))) & 0xFFFFu;
-        const uint32_t val = kind == 0 ? rows - out1 : out1 - (kind == 1 ? outF : outR);
-        if (val) atomicAdd(&K.out[(size_t)oc * 3 + kind], (unsigned long long)val);
+    // A thread's entries are kBlock apart; what it needs of their records (the candidate a member slot reports to, the slot map) is
+    // requested for four entries at once — one memory round trip per four instead of one per entry: this flush is the last thing the
+    // kernel's last workgroups do, nothing hides it (6.5 us per workgroup at 60 items a band before, tools/slide_stamps.py).
+    const int n_entries = bd.n_items * 24;
+    for (int i0 = (int)threadIdx.x; i0 < n_entries; i0 += 4 * kBlock) {
+        int oc[4];
+        uint32_t map[4];
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            const int i = i0 + u * kBlock, ic = i < n_entries ? i : (int)threadIdx.x;      // (past the end: the thread's first entry again, unused)
+            const uint32_t *rec = K.A.recs + (size_t)(bd.item0 + ic / 24) * kSlideRec;
+            oc[u] = (int)rec[8 + (ic % 24) / 3];
+            map[u] = rec[26];
+        }
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            const int i = i0 + u * kBlock;
+            if (i >= n_entries || oc[u] < 0) continue;
+            const int item = i / 24, r = i % 24, t = r / 3, kind = r % 3;              // 0 perfect, 1 forward, 2 reverse
+            const int slot = (int)((map[u] >> (4 * t)) & 15u);
+            const uint32_t *row = tab + item * 12;
+            const uint32_t out1 = row[slot] & 0xFFFFu, outF = row[slot] >> 16, outR = (row[8 + (slot >> 1)] >> (16 * (slot & 1))) & 0xFFFFu;
+            const uint32_t val = kind == 0 ? rows - out1 : out1 - (kind == 1 ? outF : outR);
+            if (val) atomicAdd(&K.out[(size_t)oc[u] * 3 + kind], (unsigned long long)val);
+        }
     }
     env.stamp(6);
 }
@@ -345,7 +358,7 @@ int launch_eval_slide(mp_ctx *c, unsigned long long *device_out, const EvalChain
         HIPCK(c, hipMalloc(&K.stamps, n_stamp * sizeof(unsigned long long)));
         HIPCK(c, hipMemsetAsync(K.stamps, 0, n_stamp * sizeof(unsigned long long), c->stream));
     }
-    const size_t lds = ((size_t)(kBlock / 64) * ((size_t)c->k * 64 * gw + 48) + (size_t)c->slide_max_items * 12) * sizeof(uint32_t);
+    const size_t lds = ((size_t)(kBlock / 64) * ((size_t)c->k * 64 * gw) + (size_t)c->slide_max_items * 12) * sizeof(uint32_t);
     if (lds > 160 * 1024) return fail(c, MP_ERR_ARG, "sliding evaluation: a band needs %zu bytes of LDS", lds);
     SlideFn f = fn[c->v][gi];
     if (lds > 48 * 1024) HIPCK(c, hipFuncSetAttribute(reinterpret_cast<const void *>(f), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
