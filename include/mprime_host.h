@@ -172,6 +172,14 @@ int mp_expand_kmers(int32_t k, int64_t n, const uint8_t *codes, int64_t cap, uin
 int mp_primer_tm(int32_t k, int64_t n, const uint8_t *codes, const double *params, double *tm);
 int mp_primer_filters(int32_t k, int64_t n, const uint8_t *codes, const double *r3, int32_t distance, double *gc, uint8_t *repeat, uint8_t *hairpin);
 
+/* (H5) coverage-bitset verdicts of the rows whose window held an IUPAC code (the hand-off to the pairing stage; V20:701-707 files
+ * the row's id under every expansion's k-mer, V20:1107-1127 decides per k-mer).  Exception i: the row's symbol codes xc[i*k .. i*k+k) (0 = '-')
+ * against output primer primer_of[i] (codes primers[p*k .. p*k+k), p < n_primers).  bad[2i] / bad[2i+1] = 1 when the forward / reverse primer
+ * does NOT reach the row: more than v gaps, more than v positions that can mismatch (a gap, or a member of the row's symbol outside the
+ * primer's), or a strict position (bit j of strictF / strictR) that can mismatch.  A few host threads from 16384 exceptions up. */
+int mp_exception_verdicts(int32_t k, int32_t v, int64_t n, const uint8_t *xc, const int64_t *primer_of, int64_t n_primers, const uint8_t *primers,
+                          uint64_t strictF, uint64_t strictR, uint8_t *bad);
+
 /* The same expansions as window words (b0, b1, g of mprime.h, three per expansion) — what mp_set_extra_rows takes. */
 int mp_expand_kmer_words(int32_t k, int64_t n, const uint8_t *codes, int64_t cap, void *out_words, int64_t *out_src,
                          int64_t *n_out);

@@ -198,22 +198,62 @@ class NN_degenerate(object):
                   "fewer than {} residues.".format(str(e).split(": ", 1)[-1], k))
             sys.exit(1)
         self._lap("build_windows (library)")
-        ex_w, ex_r, ex_codes = self.ctx.get_exceptions(n_ex)
-        self._lap("get_exceptions (%d)" % n_ex)
-        if n_ex:
-            # IUPAC k-mers with <= v gaps join the evaluated universe as their concrete expansions (V20:701-707)
-            gaps = ex_codes == 0
-            if gaps.any():
-                sel = gaps.sum(axis=1) <= v
-                x_codes, x_win = ex_codes[sel], ex_w[sel]
-            else:                                       # (the usual case: an IUPAC code, no gap in the window)
-                x_codes, x_win = ex_codes, ex_w
-            if len(x_win):
-                words, src = host.expand_kmer_words(x_codes)
-                self._lap("expand_kmer_words (%d)" % len(src))
-                self.ctx.set_extra_rows(x_win[src], words)
-                self._lap("set_extra_rows")
-        self.stats["build_windows_s"] = time.time() - t0
+        # one rank without JSON side files on the HIP library: the histogram entries never come to Python — the planning stage reads them
+        # back in bands of windows beside its own work (mp_plan_create_streamed; MP_PLAN_STREAM=0 keeps the two blocking calls)
+        streamed = (self.comm is None and not self.write_json and self.lib.backend == "hip" and os.environ.get("MP_PLAN_STREAM", "1") != "0"
+                    and host.serves_device_library(self.lib))
+
+        def exceptions_on_the_host():
+            """The window k-mers that hold an IUPAC code, and the concrete expansions of those with <= v gaps (V20:701-707) as window words:
+            pure host work on the list mp_build_windows left in the context."""
+            ex_w, ex_r, ex_codes = self.ctx.get_exceptions(n_ex)
+            extra = None
+            if n_ex:
+                gaps = ex_codes == 0
+                if gaps.any():
+                    sel = gaps.sum(axis=1) <= v
+                    x_codes, x_win = ex_codes[sel], ex_w[sel]
+                else:                                       # (the usual case: an IUPAC code, no gap in the window)
+                    x_codes, x_win = ex_codes, ex_w
+                if len(x_win):
+                    words, src = host.expand_kmer_words(x_codes)
+                    extra = (x_win[src], words)
+            return ex_w, ex_r, ex_codes, extra
+
+        early_unique = False
+        if streamed and n_ex >= 2048:
+            # The per-window histograms (mp_window_unique_device: ~0.7 ms of kernels at 131072 rows, 6 ms at 10^6) do not depend on the
+            # exception list, and unpacking / expanding that list (1.6 ms / ~5 ms) does not touch the device: the device call runs on this
+            # thread (ctypes drops the interpreter lock) while a helper thread does the host work.  Only mp_set_extra_rows — which does
+            # touch the context — waits for both.
+            box = {}
+
+            def helper_main():
+                try:
+                    box["r"] = exceptions_on_the_host()
+                except BaseException as e:                  # re-raised on the calling thread below
+                    box["error"] = e
+
+            helper = threading.Thread(target=helper_main)
+            helper.start()
+            t_u = time.time()
+            try:
+                self.ctx.window_unique_device()
+            finally:
+                helper.join()
+            self.stats["unique_s"] = time.time() - t_u
+            early_unique = True
+            if "error" in box:
+                raise box["error"]
+            ex_w, ex_r, ex_codes, extra = box["r"]
+            self._lap("histograms || exception list (%d)" % n_ex)
+        else:
+            ex_w, ex_r, ex_codes, extra = exceptions_on_the_host()
+            self._lap("get_exceptions + expand_kmer_words (%d)" % n_ex)
+        if extra is not None:
+            self.ctx.set_extra_rows(*extra)
+            self._lap("set_extra_rows")
+        self.stats["build_windows_s"] = time.time() - t0 - (self.stats["unique_s"] if early_unique else 0.0)
         t0 = time.time()
         # state_matrix / trans_matrix of every window (V20:541-577) straight from the column planes; shards add up
         self._freq, self._nn = self.ctx.window_stats()
@@ -225,14 +265,11 @@ class NN_degenerate(object):
         # (the Python JSON writer of the row-sharded path wants them sorted by first row; the native writer takes them as they come)
         # MP_JSON_WRITER=python keeps the Python writer in a single process too (tests compare the two byte for byte)
         self._native_json = self.write_json and self.comm is None and os.environ.get("MP_JSON_WRITER", "native") != "python"
-        # one rank without JSON side files on the HIP library: the entries never come to Python — the planning stage reads them back
-        # in bands of windows beside its own work (mp_plan_create_streamed; MP_PLAN_STREAM=0 keeps the two blocking calls)
-        streamed = (self.comm is None and not self.write_json and self.lib.backend == "hip" and os.environ.get("MP_PLAN_STREAM", "1") != "0"
-                    and host.serves_device_library(self.lib))
         x_row = ex_r.astype(np.int64) + row_base
         if streamed:
-            self.ctx.window_unique_device()
-            self.stats["unique_s"] = time.time() - t0
+            if not early_unique:
+                self.ctx.window_unique_device()
+                self.stats["unique_s"] = time.time() - t0
             t0 = time.time()
             self._exc = (ex_w, x_row, ex_codes)
             self._win_split = False
@@ -497,16 +534,8 @@ class NN_degenerate(object):
                 # expansions need not be listed for that: position j CAN mismatch when it is '-' or when some member of the row's
                 # symbol lies outside the primer's; the expansion that takes a mismatching member wherever there is one has the most
                 # mismatches, so the row is bad when that count exceeds v, or else when a strict position can mismatch at all.
-                gap_type = (xc == 0).sum(axis=1) > v
                 n_x = len(mask_i)
-                can_miss = (xc == 0) | ((xc & ~codes[mask_i]) != 0)
-                many = can_miss.sum(axis=1) > v
-                pos = np.arange(k)
-                strict_f = ((self._sF >> pos) & 1).astype(bool)
-                strict_r = ((self._sR >> pos) & 1).astype(bool)
-                bad = np.empty((n_x, 2), bool)
-                bad[:, 0] = gap_type | many | (can_miss & strict_f).any(axis=1)
-                bad[:, 1] = gap_type | many | (can_miss & strict_r).any(axis=1)
+                bad = host.exception_verdicts(xc, mask_i, codes, v, self._sF, self._sR)         # native, a few threads (mp_exception_verdicts)
                 self._lap("bitsets: exception verdicts (%d)" % n_x)
                 self.ctx.masks_set_bits(np.repeat(mask_i, 2), np.repeat(r_loc, 2), np.tile(np.array([0, 1], np.uint8), n_x),
                                         bad.reshape(-1).astype(np.uint8))

@@ -808,7 +808,11 @@ static int plan_create_body(mp_plan *p, const EntryInput &E, int64_t n_exc, cons
     const word_t kmask = k == 64 ? ~0ull : ((1ull << k) - 1ull);
     const double max_exp = 1 << 22;            // expansions of one exception k-mer the host is willing to enumerate
     std::atomic<int> next{0}, failed{0};       // failed: 0 or the MP_ERR_* code of the first failure
-    const int n_thr = resolve_threads(P.n_threads, W);
+    // 32 threads by default; 64 from 8 M entries up (10^6 rows: planning done at 7.5 instead of 10.5 ms; at 131072 rows — 2.9 M entries —
+    // more than 32 only adds thread starts and contention: 4.8 ms with 32 or 48, 5.2 with 64, 7.0 with 128; tools/r05_threads.sh)
+    int n_thr = resolve_threads(P.n_threads, W);
+    if (P.n_threads <= 0 && !getenv("MP_HOST_THREADS") && n_entries >= ((int64_t)8 << 20))
+        n_thr = (int)std::min<int64_t>(W, std::max(n_thr, std::min(64, (int)std::thread::hardware_concurrency())));
     std::atomic<long long> us_sights{0}, us_merge{0}, us_sort{0}, us_rest{0};      // MP_TRACE: thread time per phase
     auto work = [&]() {
         Scratch scratch;
@@ -1125,33 +1129,42 @@ static void walk_expansions(const uint8_t *codes, int k, Start &&start, Change &
 }
 
 // first output slot of every k-mer's expansions (first[n] = their number); MP_ERR_ARG for a bad symbol code, MP_ERR_CAPACITY beyond 9e15
-static int expansion_offsets(int32_t k, int64_t n, const uint8_t *codes, std::vector<int64_t> &first) {
-    first.assign((size_t)n + 1, 0);
-    double need = 0;
-    for (int64_t i = 0; i < n; i++) {
-        int64_t d = 1;
-        bool big = false;
-        for (int j = 0; j < k; j++) {
-            const uint8_t c = codes[(size_t)i * k + j];
-            if (c > 15) return MP_ERR_ARG;
-            d *= kMembers[c].n;
-            if (d > ((int64_t)1 << 40)) big = true;
-        }
-        need += big ? expansions_of(codes + (size_t)i * k, k) : (double)d;
-        if (need > 9e15) return MP_ERR_CAPACITY;
-        first[(size_t)i + 1] = first[(size_t)i] + d;
-    }
-    return MP_OK;
-}
-
 // run body(i0, i1) over [0, n) on a few threads when there is enough of it (the exception list of a deep alignment: 10^4 .. 10^6 k-mers)
 template <typename Body>
 static void over_kmers(int64_t n, Body &&body) {
-    const int n_thr = n >= 8192 ? std::min(8, resolve_threads(0, n / 4096)) : 1;
+    const int n_thr = n >= 8192 ? std::min(16, resolve_threads(0, n / 4096)) : 1;
     if (n_thr <= 1) { body((int64_t)0, n); return; }
     std::vector<std::thread> th;
     for (int t = 0; t < n_thr; t++) th.emplace_back([&, t] { body(n * t / n_thr, n * (t + 1) / n_thr); });
     for (auto &x : th) x.join();
+}
+
+static int expansion_offsets(int32_t k, int64_t n, const uint8_t *codes, std::vector<int64_t> &first) {
+    first.assign((size_t)n + 1, 0);
+    // the degeneracy of every k-mer on the threads (first[i + 1] for now), the running sum behind them
+    std::atomic<int> bad{0};
+    std::vector<uint8_t> big((size_t)n, 0);
+    over_kmers(n, [&](int64_t i0, int64_t i1) {
+        for (int64_t i = i0; i < i1; i++) {
+            int64_t d = 1;
+            for (int j = 0; j < k; j++) {
+                const uint8_t c = codes[(size_t)i * k + j];
+                if (c > 15) { bad.store(1); return; }
+                d *= kMembers[c].n;
+                if (d > ((int64_t)1 << 40)) big[(size_t)i] = 1;                   // counted as a double below ...
+                if (d > ((int64_t)1 << 60)) d = (int64_t)1 << 60;                 // ... and beyond 2^60 the call fails there anyway (> 9e15)
+            }
+            first[(size_t)i + 1] = d;
+        }
+    });
+    if (bad.load()) return MP_ERR_ARG;
+    double need = 0;
+    for (int64_t i = 0; i < n; i++) {
+        need += big[(size_t)i] ? expansions_of(codes + (size_t)i * k, k) : (double)first[(size_t)i + 1];
+        if (need > 9e15) return MP_ERR_CAPACITY;
+        first[(size_t)i + 1] += first[(size_t)i];
+    }
+    return MP_OK;
 }
 }  // extern "C++"
 

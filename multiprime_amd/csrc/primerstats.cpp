@@ -18,6 +18,8 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <algorithm>
+#include <thread>
 #include <vector>
 
 namespace {
@@ -204,6 +206,41 @@ int mp_primer_filters(int32_t k, int64_t n, const uint8_t *codes, const double *
             }
         hairpin[i] = hp;
     }
+    return MP_OK;
+}
+
+// (H5) the coverage-bitset verdicts of the rows whose window held an IUPAC code (V20:701-707 puts the row's id under EVERY expansion's
+// k-mer, V20:1107-1127 decides per k-mer): the row is NOT reached when some expansion is neither matched perfectly nor admissible.  The
+// expansions need not be listed: position j CAN mismatch when the row has '-' there or some member of its symbol lies outside the
+// primer's; the expansion that takes a mismatching member wherever there is one has the most mismatches, so the row is bad when that
+// count exceeds v, or else when a strict position can mismatch at all; a row with more than v gaps is in gap_seq_id: bad for both.
+int mp_exception_verdicts(int32_t k, int32_t v, int64_t n, const uint8_t *xc, const int64_t *primer_of, int64_t n_primers, const uint8_t *primers,
+                          uint64_t strictF, uint64_t strictR, uint8_t *bad) {
+    if (k < 1 || k > kMaxLen || v < 0 || n < 0 || (n && (!xc || !primer_of || !primers || !bad))) return MP_ERR_ARG;
+    for (int64_t i = 0; i < n; i++)
+        if (primer_of[i] < 0 || primer_of[i] >= n_primers) return MP_ERR_ARG;
+    auto body = [&](int64_t i0, int64_t i1) {
+        for (int64_t i = i0; i < i1; i++) {
+            const uint8_t *row = xc + (size_t)i * k, *pr = primers + (size_t)primer_of[i] * k;
+            int gaps = 0, miss = 0;
+            uint64_t can = 0;
+            for (int j = 0; j < k; j++) {
+                const bool gap = row[j] == 0, m = gap || (row[j] & ~pr[j] & 15u) != 0;
+                gaps += gap;
+                miss += m;
+                can |= (uint64_t)m << j;
+            }
+            const bool both = gaps > v || miss > v;
+            bad[2 * i] = both || (can & strictF) != 0;
+            bad[2 * i + 1] = both || (can & strictR) != 0;
+        }
+    };
+    int n_thr = n >= 16384 ? (int)std::min<int64_t>(16, std::min<int64_t>((int64_t)std::max(1u, std::thread::hardware_concurrency()), n / 8192)) : 1;
+    if (const char *e = getenv("MP_HOST_THREADS")) n_thr = std::max(1, std::min(n_thr, atoi(e)));
+    if (n_thr <= 1) { body(0, n); return MP_OK; }
+    std::vector<std::thread> th;
+    for (int t = 0; t < n_thr; t++) th.emplace_back([&, t] { body(n * t / n_thr, n * (t + 1) / n_thr); });
+    for (auto &x : th) x.join();
     return MP_OK;
 }
 

@@ -561,6 +561,11 @@ int unique_packed(mp_ctx *c, int64_t cap, int32_t want_labels, int64_t *n_entrie
                    c->n_patch ? c->patch_off : (const int32_t *)nullptr, c->patch_rows, c->patch_words, nullptr};
         // enough workgroups to fill 256 CUs several times over, slices of at least 4096 rows
         int n_slices = (int)std::max<size_t>(1, std::min<size_t>((np + 4095) / 4096, (8192 + W - 1) / W));
+        // ... and slices of at most 24576 rows: an XCD's resident workgroups walk a band of ~120 consecutive windows of ONE slice, i.e. the
+        // plane words of four or five 32-column chunks of that slice — 16 bytes per row and chunk, which have to stay in the XCD's 4 MB of
+        // L2 to be read from HBM once instead of once per window (10^6 rows: 9 slices of 116 k rows 9.5 ms, 48 slices 5.8 ms; 131072
+        // rows: 9 slices of 14.6 k rows 0.71 ms, more slices only add table flushes — tools/r05_hist.sh)
+        n_slices = (int)std::max<size_t>((size_t)n_slices, (np + 24575) / 24576);
         if (const char *e = getenv("MP_HIST_SLICES")) n_slices = std::max(1, atoi(e));
         A.rows_per_block = (int)(((np + n_slices - 1) / n_slices + kBlock - 1) / kBlock * kBlock);
         A.n_slices = (int)((np + A.rows_per_block - 1) / A.rows_per_block);

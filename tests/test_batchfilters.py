@@ -169,3 +169,32 @@ def test_primers_the_native_form_declines_take_the_numpy_form(monkeypatch):
     bad[1, 3] = 0
     with pytest.raises(batchfilters.host.MprimeError):
         batchfilters.tm_of_primers(bad)
+
+
+def test_native_exception_verdicts_equal_the_numpy_statement():
+    """mp_exception_verdicts (csrc/primerstats.cpp, threads from 16384 rows up) against the vectorised statement it replaced in
+    core._resident_bitsets: gap-type rows, rows with more than v positions that can mismatch, strict positions that can."""
+    from multiprime_amd import host
+    rng = np.random.default_rng(5)
+    for k, v, n in ((18, 1, 50000), (18, 0, 700), (27, 3, 20000), (45, 2, 3000)):
+        one_hot = np.array([1, 2, 4, 8], np.uint8)
+        primers = np.where(rng.random((37, k)) < 0.8, one_hot[rng.integers(0, 4, size=(37, k))], rng.integers(1, 16, size=(37, k))).astype(np.uint8)
+        of = rng.integers(0, len(primers), size=n)
+        xc = (primers[of] & (~primers[of] + 1)).astype(np.uint8)                # a row that matches its primer: the lowest member everywhere
+        which = rng.random((n, k))
+        hit = which < 0.03                                                      # ... then a few other symbols, IUPAC codes and gaps
+        xc[hit] = rng.integers(1, 16, size=int(hit.sum())).astype(np.uint8)
+        xc[which > 0.99] = 0
+        sF = sum(1 << int(y) for y in rng.choice(k, 3, replace=False))
+        sR = sum(1 << int(y) for y in rng.choice(k, 3, replace=False))
+        got = host.exception_verdicts(xc, of, primers, v, sF, sR)
+        gap_type = (xc == 0).sum(axis=1) > v
+        can_miss = (xc == 0) | ((xc & ~primers[of]) != 0)
+        many = can_miss.sum(axis=1) > v
+        pos = np.arange(k)
+        want = np.empty((n, 2), bool)
+        want[:, 0] = gap_type | many | (can_miss & ((sF >> pos) & 1).astype(bool)).any(axis=1)
+        want[:, 1] = gap_type | many | (can_miss & ((sR >> pos) & 1).astype(bool)).any(axis=1)
+        assert np.array_equal(got, want) and want.any() and not want.all()
+    with pytest.raises(host.MprimeError):
+        host.exception_verdicts(xc, of + 1000, primers, v, sF, sR)
