@@ -301,7 +301,9 @@ int mp_kmm_scan(mp_ctx *ctx, const uint8_t *bytes, const int64_t *row_off, int32
  *     rank 0: mp_comm_unique_id(id)  ->  id to every rank (MPI_Bcast, a socket, a file — the host's business)
  *     all:    mp_comm_init(ctx, n_ranks, rank, id)                 (collective: every rank calls it)
  *     all:    mp_eval_candidates_allreduce(...) instead of mp_eval_candidates; mp_comm_allreduce_host_i64 on the
- *             mp_window_stats tables; mp_comm_allgather_i64 + mp_comm_allgatherv for the tables
+ *             mp_window_stats tables; mp_comm_allgather_i64 + mp_comm_allgatherv for the tables every rank needs in full,
+ *             mp_comm_alltoall_counts + mp_comm_alltoallv for the tables with one consumer per row (histogram entries -> the rank
+ *             that plans the window)
  * n_ranks = 1 is valid without RCCL (every collective is the identity).  Collectives are enqueued on the context's stream
  * (mp_set_stream) straight behind the kernels; the *_host_* / gather forms return when the result is in the caller's buffer.
  * Every rank must issue the same collectives in the same order.  The checker library implements n_ranks = 1 only. */
@@ -321,6 +323,14 @@ int mp_comm_allreduce_host_i64(mp_ctx *ctx, int64_t *host_buf, int64_t n);
 int mp_comm_allgather_i64(mp_ctx *ctx, int64_t value, int64_t *out);
 /* recv = rank 0's bytes, rank 1's bytes, ...; counts[r] = bytes of rank r (counts[rank] == n_bytes); host buffers */
 int mp_comm_allgatherv(mp_ctx *ctx, const void *send, int64_t n_bytes, const int64_t *counts, void *recv);
+/* Personalised exchange (all-to-all-v) of host byte arrays: `send` holds, in rank order, send_counts[r] bytes for every rank r.
+ * mp_comm_alltoall_counts tells every rank what it will receive (recv_counts[r] = what rank r sends to this rank: one all-gather of the
+ * n_ranks x n_ranks count matrix); mp_comm_alltoallv then moves the bytes (ncclAllToAllv, or grouped ncclSend / ncclRecv where the
+ * library lacks it): recv = rank 0's bytes for this rank, rank 1's, ...  Used where a table has ONE consumer per row — the histogram
+ * entries of a window go to the rank that plans the window — so that a rank receives what it needs instead of everybody's everything
+ * (the all-gather above: n_ranks times the bytes). */
+int mp_comm_alltoall_counts(mp_ctx *ctx, const int64_t *send_counts, int64_t *recv_counts);
+int mp_comm_alltoallv(mp_ctx *ctx, const void *send, const int64_t *send_counts, void *recv, const int64_t *recv_counts);
 /* mp_eval_candidates over this rank's rows + the all-reduce of the counters on the same stream: out = the global counts */
 int mp_eval_candidates_allreduce(mp_ctx *ctx, int32_t n_cand, const int32_t *cand_window, const uint8_t *cand_codes,
                                  uint64_t strictF, uint64_t strictR, int64_t *out);

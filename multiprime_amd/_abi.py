@@ -73,6 +73,8 @@ SYMBOLS = [
     ("mp_comm_allreduce_host_i64", C.c_int, [_p, _p, C.c_int64]),
     ("mp_comm_allgather_i64", C.c_int, [_p, C.c_int64, _p]),
     ("mp_comm_allgatherv", C.c_int, [_p, _p, C.c_int64, _p, _p]),
+    ("mp_comm_alltoall_counts", C.c_int, [_p, _p, _p]),
+    ("mp_comm_alltoallv", C.c_int, [_p, _p, _p, _p, _p]),
     ("mp_eval_candidates_allreduce", C.c_int, [_p, C.c_int32, _p, _p, C.c_uint64, C.c_uint64, _p]),
     ("mp_device_bytes", C.c_int, [_p, C.POINTER(C.c_int64)]),
 ]
@@ -328,6 +330,18 @@ class Context:
         self._ck(self.d.mp_comm_allgatherv(self.h, _ptr(payload) if payload.size else None, payload.size, _ptr(counts),
                                            _ptr(out) if out.size else None))
         return out, counts
+
+    def comm_exchange_bytes(self, payload: np.ndarray, send_counts):
+        """Personalised exchange: `payload` holds send_counts[r] bytes for every rank r, in rank order.  Returns (the bytes this rank
+        receives, source rank by source rank; their counts)."""
+        payload = np.ascontiguousarray(payload, dtype=np.uint8)
+        send_counts = np.ascontiguousarray(send_counts, dtype=np.int64)
+        recv_counts = np.zeros(len(send_counts), np.int64)
+        self._ck(self.d.mp_comm_alltoall_counts(self.h, _ptr(send_counts), _ptr(recv_counts)))
+        out = np.empty(int(recv_counts.sum()), np.uint8)
+        self._ck(self.d.mp_comm_alltoallv(self.h, _ptr(payload) if payload.size else None, _ptr(send_counts),
+                                          _ptr(out) if out.size else None, _ptr(recv_counts)))
+        return out, recv_counts
 
     def eval_candidates_allreduce(self, cand_window, cand_codes, strictF: int, strictR: int) -> np.ndarray:
         cand_window = np.ascontiguousarray(cand_window, dtype=np.int32)

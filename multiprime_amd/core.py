@@ -258,7 +258,7 @@ class NN_degenerate(object):
         # state_matrix / trans_matrix of every window (V20:541-577) straight from the column planes; shards add up
         self._freq, self._nn = self.ctx.window_stats()
         if self.comm is not None:
-            self._freq, self._nn = self.comm.sum_int64(self._freq), self.comm.sum_int64(self._nn)
+            self._freq, self._nn = self.comm.sum_many_int64([self._freq, self._nn])           # one all-reduce for both tables
         self.stats["stats_s"] = time.time() - t0
         t0 = time.time()
         # per-window histograms; sorted by first row only when the id lists of the JSON files need the labels
@@ -297,21 +297,23 @@ class NN_degenerate(object):
             return plan
         e_window = np.repeat(np.arange(W, dtype=np.int32), np.diff(off))
         e_first = first.astype(np.int64) + row_base
-        if self.comm is not None:
-            e_window, words, count, e_first = self.comm.gather_entries(e_window, words, count, e_first)
-            ex_w, x_row, ex_codes = self.comm.gather_exceptions(ex_w, x_row, ex_codes, k)
-        self._exc = (ex_w, x_row, ex_codes)
-        # Row shards without JSON side files split the planning by WINDOWS: every rank holds the merged histograms of all windows
-        # (one all-gather) but plans only its contiguous share of them; the candidates are gathered, evaluated by everyone on their
-        # own rows, and the results of the shares are concatenated (run()).  The JSON writers need every window's ordered table
-        # on rank 0, so with them the planning stays replicated (it is O(windows x sequences) output anyway).
+        # Row shards without JSON side files split the planning by WINDOWS: every rank plans a contiguous share of them and needs the
+        # histogram entries and exceptions of THOSE windows only, from every rank's rows — a personalised exchange (all-to-all-v: a rank
+        # receives about what it holds itself; round 4 all-gathered every table to every rank, world x the bytes, and threw most of it
+        # away).  The candidates are then gathered, evaluated by everyone on their own rows, and the results of the shares are
+        # concatenated (run()).  The JSON writers need every window's ordered table on rank 0, so with them the planning stays
+        # replicated on all-gathered tables (it is O(windows x sequences) output anyway).
         self._win_split = self.comm is not None and not self.write_json and not keep
         if self._win_split:
-            lo, hi = self.comm.window_range(W)
-            sel = (e_window >= lo) & (e_window < hi)
-            e_window, words, count, e_first = e_window[sel], np.ascontiguousarray(words[:, sel]), count[sel], e_first[sel]
-            xs = (ex_w >= lo) & (ex_w < hi)
-            ex_w, x_row, ex_codes = ex_w[xs], x_row[xs], ex_codes[xs]
+            e_window, words, count, e_first = self.comm.entries_to_window_owners(W, e_window, words, count, e_first)
+            ex_local = (ex_w, x_row, ex_codes)
+            ex_w, x_row, ex_codes = self.comm.exceptions_to_window_owners(W, ex_w, x_row, ex_codes, k)
+            self._exc = ex_local                                 # this rank's own rows: what its coverage bitsets need
+        else:
+            if self.comm is not None:
+                e_window, words, count, e_first = self.comm.gather_entries(e_window, words, count, e_first)
+                ex_w, x_row, ex_codes = self.comm.gather_exceptions(ex_w, x_row, ex_codes, k)
+            self._exc = (ex_w, x_row, ex_codes)
         plan = host.Plan(k=k, v=v, n_windows=W, total_sequences=self.total_sequence_number, coverage=self.coverage,
                          entropy_threshold=self.entropy_threshold, max_degeneracy=self.score_of_dege_bases,
                          max_dege_positions=self.number_of_dege_bases, e_window=e_window, e_words=words, e_count=count,
@@ -350,14 +352,15 @@ class NN_degenerate(object):
                 # every rank planned its share of the windows: all candidates (rank order = window order) go to everyone, each
                 # rank counts them on its rows, one all-reduce; a rank replays the stopping rules on its own slice
                 mine = len(cand_w)
-                counts = self.comm.gather_var(np.asarray([mine], np.int64))
-                first = int(counts[: self.comm.rank].sum())
-                all_w, all_codes = self.comm.gather_var(cand_w), self.comm.gather_var(codes)
+                # candidate windows, their codes and the shares' window counts travel together (one pair of collectives)
+                (all_w, all_codes, planned), per_rank = self.comm.gather_many(
+                    [cand_w, codes.reshape(mine, k), np.asarray([plan.n_planned], np.int64)], with_counts=True)
+                first = int(per_rank[: self.comm.rank, 0].sum())
                 n_cand = len(all_w)
                 ev_all = (self.comm.eval_allreduce(self.ctx, all_w, all_codes, self._sF, self._sR) if n_cand
                           else np.zeros((0, 3), np.int64))
                 ev = np.ascontiguousarray(ev_all[first:first + mine])
-                self.stats["windows_planned"] = int(self.comm.gather_var(np.asarray([plan.n_planned], np.int64)).sum())
+                self.stats["windows_planned"] = int(planned.sum())
             elif n_cand:
                 if self.comm is not None:
                     ev = self.comm.eval_allreduce(self.ctx, cand_w, codes, self._sF, self._sR)
@@ -373,7 +376,8 @@ class NN_degenerate(object):
             self._lap("plan.finish")
             res = plan.results()
             if self._win_split:
-                res = {key: self.comm.gather_var(val) for key, val in res.items()}       # shares in rank order = window order
+                keys = list(res)                                                          # shares in rank order = window order;
+                res = dict(zip(keys, self.comm.gather_many([res[key] for key in keys])))  # all columns in one pair of collectives
             primers = iupac.strings_of(iupac.SYMBOL_LUT[res["codes"]])
             # the 3'-end self-dimer test of every window's primer (dimer_check, V20:487-503) in ONE launch:
             # it is the ordered pair (x -> x) of the dimer scan with Loss >= 3 and the two-term deltaG

@@ -17,6 +17,7 @@
 
 #include <mutex>
 #include <string>
+#include <vector>
 
 using namespace mp;
 
@@ -29,6 +30,12 @@ struct Rccl {
     ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
     ncclResult_t (*AllReduce)(const void *, void *, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t) = nullptr;
     ncclResult_t (*AllGather)(const void *, void *, size_t, ncclDataType_t, ncclComm_t, hipStream_t) = nullptr;
+    // optional: the personalised exchange in one call (an RCCL extension), else grouped point-to-point calls
+    ncclResult_t (*AllToAllv)(const void *, const size_t[], const size_t[], void *, const size_t[], const size_t[], ncclDataType_t, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*Send)(const void *, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*Recv)(void *, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*GroupStart)() = nullptr;
+    ncclResult_t (*GroupEnd)() = nullptr;
     const char *(*GetErrorString)(ncclResult_t) = nullptr;
     ncclResult_t (*CommCount)(const ncclComm_t, int *) = nullptr;          // optional (mp_comm_describe)
     ncclResult_t (*CommUserRank)(const ncclComm_t, int *) = nullptr;
@@ -75,6 +82,11 @@ Rccl &rccl() {
         r.AllReduce = reinterpret_cast<decltype(r.AllReduce)>(sym("ncclAllReduce"));
         r.AllGather = reinterpret_cast<decltype(r.AllGather)>(sym("ncclAllGather"));
         r.GetErrorString = reinterpret_cast<decltype(r.GetErrorString)>(sym("ncclGetErrorString"));
+        r.AllToAllv = reinterpret_cast<decltype(r.AllToAllv)>(dlsym(r.lib, "ncclAllToAllv"));
+        r.Send = reinterpret_cast<decltype(r.Send)>(dlsym(r.lib, "ncclSend"));
+        r.Recv = reinterpret_cast<decltype(r.Recv)>(dlsym(r.lib, "ncclRecv"));
+        r.GroupStart = reinterpret_cast<decltype(r.GroupStart)>(dlsym(r.lib, "ncclGroupStart"));
+        r.GroupEnd = reinterpret_cast<decltype(r.GroupEnd)>(dlsym(r.lib, "ncclGroupEnd"));
         r.CommCount = reinterpret_cast<decltype(r.CommCount)>(dlsym(r.lib, "ncclCommCount"));
         r.CommUserRank = reinterpret_cast<decltype(r.CommUserRank)>(dlsym(r.lib, "ncclCommUserRank"));
         Dl_info where;
@@ -246,6 +258,80 @@ int mp_comm_allgatherv(mp_ctx *c, const void *send, int64_t n_bytes, const int64
     for (size_t r = 0; r < R; r++) {
         if (counts[r]) HIPCK(c, hipMemcpyAsync(static_cast<uint8_t *>(recv) + at, d + slot * r, (size_t)counts[r], hipMemcpyDeviceToHost, c->stream));
         at += (size_t)counts[r];
+    }
+    HIPCK(c, hipStreamSynchronize(c->stream));
+    return MP_OK;
+}
+
+int mp_comm_alltoall_counts(mp_ctx *c, const int64_t *send_counts, int64_t *recv_counts) {
+    int rc = need_comm(c);
+    if (rc) return rc;
+    if (!send_counts || !recv_counts) return fail(c, MP_ERR_ARG, "mp_comm_alltoall_counts: null argument");
+    for (int r = 0; r < c->n_ranks; r++)
+        if (send_counts[r] < 0) return fail(c, MP_ERR_ARG, "mp_comm_alltoall_counts: negative count");
+    if (!c->comm) { recv_counts[0] = send_counts[0]; return MP_OK; }
+    HIPCK(c, hipSetDevice(c->dev));
+    // every rank's row of counts to everyone (R x R int64: bytes), this rank's column is what it receives
+    const size_t R = (size_t)c->n_ranks;
+    if ((rc = scratch(c, (R * R + R) * 8))) return rc;
+    int64_t *d = reinterpret_cast<int64_t *>(c->comm_scratch);
+    HIPCK(c, hipMemcpyAsync(d + R * R, send_counts, R * 8, hipMemcpyHostToDevice, c->stream));
+    NCCLCK(c, rccl().AllGather(d + R * R, d, R, ncclInt64, reinterpret_cast<ncclComm_t>(c->comm), c->stream));
+    std::vector<int64_t> all(R * R);
+    HIPCK(c, hipMemcpyAsync(all.data(), d, R * R * 8, hipMemcpyDeviceToHost, c->stream));
+    HIPCK(c, hipStreamSynchronize(c->stream));
+    for (size_t r = 0; r < R; r++) recv_counts[r] = all[r * R + (size_t)c->rank];
+    return MP_OK;
+}
+
+int mp_comm_alltoallv(mp_ctx *c, const void *send, const int64_t *send_counts, void *recv, const int64_t *recv_counts) {
+    int rc = need_comm(c);
+    if (rc) return rc;
+    if (!send_counts || !recv_counts) return fail(c, MP_ERR_ARG, "mp_comm_alltoallv: null counts");
+    const size_t R = (size_t)c->n_ranks;
+    // 16-byte granules per piece on the device (the pieces of one rank are laid out one after the other, padded)
+    std::vector<size_t> s_cnt(R), s_dis(R), r_cnt(R), r_dis(R);
+    size_t s_tot = 0, r_tot = 0, s_bytes = 0, r_bytes = 0;
+    for (size_t r = 0; r < R; r++) {
+        if (send_counts[r] < 0 || recv_counts[r] < 0) return fail(c, MP_ERR_ARG, "mp_comm_alltoallv: negative count");
+        s_cnt[r] = (size_t)send_counts[r]; s_dis[r] = s_tot; s_tot += (s_cnt[r] + 15) / 16 * 16; s_bytes += s_cnt[r];
+        r_cnt[r] = (size_t)recv_counts[r]; r_dis[r] = r_tot; r_tot += (r_cnt[r] + 15) / 16 * 16; r_bytes += r_cnt[r];
+    }
+    if ((s_bytes && !send) || (r_bytes && !recv)) return fail(c, MP_ERR_ARG, "mp_comm_alltoallv: null buffer");
+    if (!c->comm) {
+        if (recv_counts[0] != send_counts[0]) return fail(c, MP_ERR_ARG, "mp_comm_alltoallv: a world of one receives what it sends");
+        if (s_bytes) memcpy(recv, send, s_bytes);
+        return MP_OK;
+    }
+    HIPCK(c, hipSetDevice(c->dev));
+    Rccl &L = rccl();
+    if (!L.AllToAllv && !(L.Send && L.Recv && L.GroupStart && L.GroupEnd)) return fail(c, MP_ERR_DEVICE, "mp_comm_alltoallv: this librccl has neither ncclAllToAllv nor ncclSend / ncclRecv");
+    if ((rc = scratch(c, s_tot + r_tot + 32))) return rc;
+    uint8_t *ds = c->comm_scratch, *dr = c->comm_scratch + (s_tot + 15) / 16 * 16;
+    {
+        size_t at = 0;
+        for (size_t r = 0; r < R; r++) {
+            if (s_cnt[r]) HIPCK(c, hipMemcpyAsync(ds + s_dis[r], static_cast<const uint8_t *>(send) + at, s_cnt[r], hipMemcpyHostToDevice, c->stream));
+            at += s_cnt[r];
+        }
+    }
+    ncclComm_t comm = reinterpret_cast<ncclComm_t>(c->comm);
+    if (L.AllToAllv) {
+        NCCLCK(c, L.AllToAllv(ds, s_cnt.data(), s_dis.data(), dr, r_cnt.data(), r_dis.data(), ncclUint8, comm, c->stream));
+    } else {
+        NCCLCK(c, L.GroupStart());
+        for (size_t r = 0; r < R; r++) {
+            if (s_cnt[r]) NCCLCK(c, L.Send(ds + s_dis[r], s_cnt[r], ncclUint8, (int)r, comm, c->stream));
+            if (r_cnt[r]) NCCLCK(c, L.Recv(dr + r_dis[r], r_cnt[r], ncclUint8, (int)r, comm, c->stream));
+        }
+        NCCLCK(c, L.GroupEnd());
+    }
+    {
+        size_t at = 0;
+        for (size_t r = 0; r < R; r++) {
+            if (r_cnt[r]) HIPCK(c, hipMemcpyAsync(static_cast<uint8_t *>(recv) + at, dr + r_dis[r], r_cnt[r], hipMemcpyDeviceToHost, c->stream));
+            at += r_cnt[r];
+        }
     }
     HIPCK(c, hipStreamSynchronize(c->stream));
     return MP_OK;

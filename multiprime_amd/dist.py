@@ -41,6 +41,15 @@ class RowShards:
         self.n_total = 0
         self.global_labels = None
         self.native = None          # the context whose RCCL communicator carries the collectives (attach)
+        self.traffic = []           # (what, bytes sent, bytes received) per collective of this alignment; MP_TRACE prints them
+        self.tables = {}            # what -> bytes of this rank's own table that went into a personalised exchange
+
+    def _account(self, what, sent, received):
+        import os
+        import sys
+        self.traffic.append((what, int(sent), int(received)))
+        if os.environ.get("MP_TRACE"):
+            print("[dist] rank %d %-28s sent %12d B  received %12d B" % (self.rank, what, sent, received), file=sys.stderr)
 
     def attach(self, ctx):
         """Collectives through the library's own communicator when this is a GPU run of the HIP library.  MP_NATIVE_COMM=0 keeps
@@ -104,6 +113,7 @@ class RowShards:
         if self.native is not None:
             flat, counts = self.native.comm_gather_bytes(arr.reshape(-1).view(np.uint8), self.world)
             n = int(counts.sum()) // max(row_bytes, 1)
+            self._account("all-gather", arr.nbytes, int(counts.sum()))
             return np.moveaxis(flat.view(dt).reshape((n,) + tail), 0, axis)
         dev = self._device()
         n_local = torch.tensor([arr.shape[0]], dtype=torch.int64, device=dev)
@@ -118,7 +128,54 @@ class RowShards:
         parts = [torch.empty(cap, dtype=torch.uint8, device=dev) for _ in range(self.world)]
         dist.all_gather(parts, payload, group=self.group)
         out = [p[: n * row_bytes].cpu().numpy().view(dt).reshape((n,) + tail) for p, n in zip(parts, sizes)]
+        self._account("all-gather", arr.nbytes, sum(sizes) * row_bytes)
         return np.moveaxis(np.concatenate(out, axis=0), 0, axis)
+
+    def gather_many(self, arrays, with_counts=False):
+        """gather_var of several arrays (rows along axis 0, any dtypes) with ONE pair of collectives for all of them: the per-rank row
+        counts as a small matrix, the payloads as one byte string.  Returns the concatenations in rank order (and, with_counts, the
+        [world][n_arrays] row counts)."""
+        arrays = [np.ascontiguousarray(a) for a in arrays]
+        if not arrays:
+            return ([], np.zeros((self.world, 0), np.int64)) if with_counts else []
+        rows = np.asarray([len(a) for a in arrays], np.int64).reshape(1, -1)
+        all_rows = self.gather_var(rows)                                              # [world][n_arrays]
+        payload = np.concatenate([a.reshape(-1).view(np.uint8) for a in arrays]) if any(a.size for a in arrays) else np.zeros(0, np.uint8)
+        blob = self.gather_var(payload)
+        out, at = [[] for _ in arrays], 0
+        for r in range(self.world):
+            for i, a in enumerate(arrays):
+                tail = a.shape[1:]
+                nb = int(all_rows[r, i]) * int(np.prod(tail, dtype=np.int64)) * a.dtype.itemsize
+                out[i].append(blob[at:at + nb].view(a.dtype).reshape((int(all_rows[r, i]),) + tail))
+                at += nb
+        cat = [np.concatenate(parts, axis=0) for parts in out]
+        return (cat, all_rows) if with_counts else cat
+
+    def exchange_rows(self, arr, counts, what="exchange"):
+        """Personalised exchange (all-to-all-v): `arr`'s rows are grouped by destination — counts[r] rows for rank r, in rank order.
+        Returns the rows this rank receives, source rank by source rank.  A rank receives only what is meant for it; the all-gather
+        of the same table would hand every rank all of it (world x the bytes)."""
+        arr = np.ascontiguousarray(arr)
+        tail, dt = arr.shape[1:], arr.dtype
+        row_bytes = int(np.prod(tail, dtype=np.int64)) * dt.itemsize
+        counts = np.asarray(counts, np.int64)
+        assert len(counts) == self.world and int(counts.sum()) == len(arr)
+        self.tables[what] = arr.nbytes
+        if self.native is not None:
+            flat, got = self.native.comm_exchange_bytes(arr.reshape(-1).view(np.uint8), counts * row_bytes)
+            self._account(what, arr.nbytes - int(counts[self.rank]) * row_bytes, int(got.sum()) - int(got[self.rank]))
+            return flat.view(dt).reshape((int(got.sum()) // max(row_bytes, 1),) + tail)
+        dev = self._device()
+        send_n = torch.from_numpy(counts.copy()).to(dev)
+        recv_n = torch.empty(self.world, dtype=torch.int64, device=dev)
+        dist.all_to_all_single(recv_n, send_n, group=self.group)
+        recv_rows = [int(x) for x in recv_n.cpu().tolist()]
+        send = torch.from_numpy(arr.reshape(-1).view(np.uint8).copy()).to(dev) if arr.size else torch.zeros(0, dtype=torch.uint8, device=dev)
+        recv = torch.empty(sum(recv_rows) * row_bytes, dtype=torch.uint8, device=dev)
+        dist.all_to_all_single(recv, send, [n * row_bytes for n in recv_rows], [int(n) * row_bytes for n in counts.tolist()], group=self.group)
+        self._account(what, arr.nbytes - int(counts[self.rank]) * row_bytes, (sum(recv_rows) - recv_rows[self.rank]) * row_bytes)
+        return recv.cpu().numpy().view(dt).reshape((sum(recv_rows),) + tail)
 
     def gather_columns(self, arr):
         """[m][n_local] per rank -> [m][n_total] (columns = rows of the alignment)."""
@@ -149,25 +206,57 @@ class RowShards:
 
     # -- histograms and exceptions ---------------------------------------------------------------
     def gather_entries(self, e_window, words, count, first_global):
-        """Every rank's (window, key words, count, first global row) entries, concatenated.  No merge here: the native
-        planning stage merges by key (counts add, the smallest first row wins)."""
+        """Every rank's (window, key words, count, first global row) entries, concatenated — for the REPLICATED planning (JSON side
+        files: rank 0 needs every window's table).  No merge here: the native planning stage merges by key (counts add, the smallest
+        first row wins).  The window-split planning uses entries_to_window_owners instead."""
+        return self._unpack_entries(self.gather_var(self._pack_entries(e_window, words, count, first_global)))
+
+    @staticmethod
+    def _pack_entries(e_window, words, count, first_global):
         if np.asarray(words).dtype == np.uint64:                  # primers of more than 31 bases: 64-bit window words, one column each
             packed = np.empty((len(e_window), 6), np.int64)
             packed[:, 0] = e_window
             packed[:, 1:4] = np.asarray(words, np.uint64).view(np.int64).T
             packed[:, 4] = count
             packed[:, 5] = first_global
-            g = self.gather_var(packed)
-            return g[:, 0].astype(np.int32), np.ascontiguousarray(g[:, 1:4].T).view(np.uint64), g[:, 4].copy(), g[:, 5].copy()
+            return packed
         packed = np.empty((len(e_window), 5), np.int64)
         packed[:, 0] = e_window
         packed[:, 1] = np.asarray(words[0], np.int64) | (np.asarray(words[1], np.int64) << 32)
         packed[:, 2] = np.asarray(words[2], np.int64)
         packed[:, 3] = count
         packed[:, 4] = first_global
-        g = self.gather_var(packed)
+        return packed
+
+    @staticmethod
+    def _unpack_entries(g):
+        if g.shape[1] == 6:
+            return g[:, 0].astype(np.int32), np.ascontiguousarray(g[:, 1:4].T).view(np.uint64), g[:, 4].copy(), g[:, 5].copy()
         w = np.stack([(g[:, 1] & 0xFFFFFFFF).astype(np.uint32), (g[:, 1] >> 32).astype(np.uint32), g[:, 2].astype(np.uint32)])
         return g[:, 0].astype(np.int32), w, g[:, 3].copy(), g[:, 4].copy()
+
+    def entries_to_window_owners(self, n_windows, e_window, words, count, first_global):
+        """The planning is split by windows (window_range): every entry goes to the ONE rank that plans its window — a personalised
+        exchange instead of gather_entries' all-gather, which moved world x the bytes for every rank to throw most of them away.
+        `e_window` is ascending (window segments), so a destination's entries are one contiguous run."""
+        starts = self.bounds(n_windows)
+        cuts = np.searchsorted(np.asarray(e_window), np.asarray(starts), side="left")
+        g = self.exchange_rows(self._pack_entries(e_window, words, count, first_global), np.diff(cuts), what="histogram entries")
+        return self._unpack_entries(g)
+
+    def exceptions_to_window_owners(self, n_windows, ex_w, x_row, ex_codes, k):
+        """The IUPAC exception list the same way (one byte row per exception: window, row, codes)."""
+        starts = self.bounds(n_windows)
+        order = np.argsort(np.asarray(ex_w), kind="stable")                          # (the library hands them over by window already)
+        ex_w, x_row, ex_codes = np.asarray(ex_w)[order], np.asarray(x_row)[order], np.asarray(ex_codes, np.uint8).reshape(len(order), k)[order]
+        rec = np.empty((len(ex_w), 12 + k), np.uint8)
+        rec[:, 0:4] = np.ascontiguousarray(ex_w, np.int32).view(np.uint8).reshape(-1, 4)
+        rec[:, 4:12] = np.ascontiguousarray(x_row, np.int64).view(np.uint8).reshape(-1, 8)
+        rec[:, 12:] = ex_codes
+        cuts = np.searchsorted(ex_w, np.asarray(starts), side="left")
+        g = self.exchange_rows(rec, np.diff(cuts), what="exception list")
+        return (np.ascontiguousarray(g[:, 0:4]).view(np.int32).reshape(-1), np.ascontiguousarray(g[:, 4:12]).view(np.int64).reshape(-1),
+                np.ascontiguousarray(g[:, 12:]))
 
     def gather_exceptions(self, ex_w, x_row, ex_codes, k):
         head = np.empty((len(ex_w), 2), np.int64)
@@ -178,8 +267,21 @@ class RowShards:
         return g[:, 0].astype(np.int32), g[:, 1].copy(), codes
 
     # -- evaluation ----------------------------------------------------------------------------
+    def sum_many_int64(self, arrays):
+        """sum_int64 of several arrays with ONE all-reduce (the per-window base and pair statistics travel together)."""
+        shapes = [np.shape(a) for a in arrays]
+        flat = np.concatenate([np.asarray(a, np.int64).reshape(-1) for a in arrays]) if arrays else np.zeros(0, np.int64)
+        tot = self.sum_int64(flat)
+        out, at = [], 0
+        for sh in shapes:
+            n = int(np.prod(sh, dtype=np.int64))
+            out.append(tot[at:at + n].reshape(sh))
+            at += n
+        return out
+
     def sum_int64(self, a):
         """Element-wise sum over the ranks of an int64 array every rank holds (per-window statistics)."""
+        self._account("all-reduce", np.asarray(a).size * 8, np.asarray(a).size * 8)
         if self.native is not None:
             return self.native.comm_sum(a).reshape(np.shape(a))
         t = torch.from_numpy(np.ascontiguousarray(a, dtype=np.int64))

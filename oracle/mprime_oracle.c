@@ -628,6 +628,21 @@ int mp_comm_allgatherv(mp_ctx *c, const void *send, int64_t n_bytes, const int64
     if (n_bytes) memcpy(recv, send, (size_t)n_bytes);
     return MP_OK;
 }
+int mp_comm_alltoall_counts(mp_ctx *c, const int64_t *send_counts, int64_t *recv_counts) {
+    int rc = one_rank(c);
+    if (rc) return rc;
+    if (!send_counts || !recv_counts || send_counts[0] < 0) return fail(c, MP_ERR_ARG, "mp_comm_alltoall_counts: bad arguments");
+    recv_counts[0] = send_counts[0];
+    return MP_OK;
+}
+int mp_comm_alltoallv(mp_ctx *c, const void *send, const int64_t *send_counts, void *recv, const int64_t *recv_counts) {
+    int rc = one_rank(c);
+    if (rc) return rc;
+    if (!send_counts || !recv_counts || send_counts[0] < 0 || recv_counts[0] != send_counts[0] || (send_counts[0] && (!send || !recv)))
+        return fail(c, MP_ERR_ARG, "mp_comm_alltoallv: bad arguments");
+    if (send_counts[0]) memcpy(recv, send, (size_t)send_counts[0]);
+    return MP_OK;
+}
 int mp_eval_candidates_allreduce(mp_ctx *c, int32_t n_cand, const int32_t *cw, const uint8_t *codes, uint64_t sF, uint64_t sR, int64_t *out) {
     int rc = one_rank(c);
     if (rc) return rc;

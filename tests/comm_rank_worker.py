@@ -42,6 +42,17 @@ def main():
             assert counts.tolist() == lens, (counts.tolist(), lens)
             want = np.concatenate([payload_of(r, lens[r]) for r in range(world)]) if sum(lens) else np.zeros(0, np.uint8)
             assert got.shape == want.shape and np.array_equal(got, want), ("gather", lens)
+        # 1b. the personalised exchange (mp_comm_alltoall_counts + mp_comm_alltoallv): piece (src -> dst) is a seeded pattern of
+        # spec["exchanges"][i][src][dst] bytes — empty pieces, one byte, skewed, beyond one transport chunk
+        def piece(src, dst, n):
+            return np.random.default_rng([79, src, dst]).integers(0, 256, size=n, dtype=np.uint8)
+        for M in spec["exchanges"]:
+            mine = [piece(rank, d, M[rank][d]) for d in range(world)]
+            got, counts = ctx.comm_exchange_bytes(np.concatenate(mine) if sum(M[rank]) else np.zeros(0, np.uint8), M[rank])
+            assert counts.tolist() == [M[s][rank] for s in range(world)], (counts.tolist(), M)
+            want = [piece(s, rank, M[s][rank]) for s in range(world)]
+            want = np.concatenate(want) if sum(len(x) for x in want) else np.zeros(0, np.uint8)
+            assert got.shape == want.shape and np.array_equal(got, want), ("exchange", M)
         # 2. host all-reduce (mp_comm_allreduce_host_i64): per-window statistics travel this way
         for n in spec["sums"]:
             mine = np.random.default_rng([78, rank]).integers(-2 ** 40, 2 ** 40, size=n, dtype=np.int64)

@@ -197,6 +197,41 @@ ncclResult_t ncclAllGather(const void *send, void *recv, size_t sendcount, ncclD
     return ncclSuccess;
 }
 
+// the personalised exchange (an RCCL extension comm.hip prefers to grouped ncclSend / ncclRecv): first every rank's row of counts, then
+// n_ranks rounds — in round j rank r's piece for rank (r + j) % n goes through r's slot, in as many chunks as the longest piece of the
+// round needs (every rank knows the whole count matrix, so all of them pass the same barriers)
+ncclResult_t ncclAllToAllv(const void *send, const size_t sendcounts[], const size_t sdispls[], void *recv, const size_t recvcounts[],
+                           const size_t rdispls[], ncclDataType_t dt, ncclComm_t c, hipStream_t stream) {
+    const size_t es = dtype_size(dt);
+    if (!c || es == 0 || !sendcounts || !sdispls || !recvcounts || !rdispls) return ncclInvalidArgument;
+    if (hipStreamSynchronize(stream) != hipSuccess) return ncclUnhandledCudaError;
+    const int R = c->n_ranks, me = c->rank;
+    std::vector<size_t> M((size_t)R * R);
+    memcpy(c->slot(me), sendcounts, sizeof(size_t) * (size_t)R);
+    if (!c->barrier()) return ncclSystemError;
+    for (int r = 0; r < R; r++) memcpy(&M[(size_t)r * R], c->slot(r), sizeof(size_t) * (size_t)R);
+    if (!c->barrier()) return ncclSystemError;
+    for (int r = 0; r < R; r++)
+        if (M[(size_t)r * R + me] != recvcounts[r]) return ncclInvalidArgument;           // what I expect is what they send
+    for (int j = 0; j < R; j++) {
+        const int dst = (me + j) % R, src = (me - j + R) % R;
+        size_t longest = 0;
+        for (int r = 0; r < R; r++) longest = std::max(longest, M[(size_t)r * R + (size_t)((r + j) % R)] * es);
+        const size_t mine = sendcounts[dst] * es, theirs = recvcounts[src] * es;
+        for (size_t at = 0; at < longest; at += kSlot) {
+            const size_t n_out = at < mine ? std::min(kSlot, mine - at) : 0, n_in = at < theirs ? std::min(kSlot, theirs - at) : 0;
+            ncclResult_t rc = exchange(c, static_cast<const uint8_t *>(send) + sdispls[dst] * es + at, n_out, [&] {
+                if (n_in && hipMemcpy(static_cast<uint8_t *>(recv) + rdispls[src] * es + at, c->slot(src), n_in, hipMemcpyHostToDevice) != hipSuccess)
+                    return ncclUnhandledCudaError;
+                return ncclSuccess;
+            });
+            if (rc != ncclSuccess) return rc;
+        }
+    }
+    if (me == 0) c->hdr->calls.fetch_add(1);
+    return ncclSuccess;
+}
+
 ncclResult_t ncclCommCount(const ncclComm_t c, int *n) { if (!c || !n) return ncclInvalidArgument; *n = c->hdr->attached.load(); return ncclSuccess; }
 ncclResult_t ncclCommUserRank(const ncclComm_t c, int *r) { if (!c || !r) return ncclInvalidArgument; *r = c->rank; return ncclSuccess; }
 

@@ -59,7 +59,12 @@ def test_collectives_of_the_abi_with_several_ranks_on_one_gpu(world, hip_lib, tm
     _eval_case(hip_lib, wd)
     big = (8 << 20) + 12345                                           # beyond one 8 MiB transport chunk of the stand-in
     gathers = [[0] * world, [1] + [0] * (world - 1), [17, 4096, 5][:world], [big] + [3] * (world - 1), [0] * (world - 1) + [70001]]
-    json.dump({"gathers": gathers, "sums": [0, 1, 1000, (1 << 20) + 7]}, open(os.path.join(wd, "spec.json"), "w"))
+    rng = np.random.default_rng(world)
+    exchanges = [[[0] * world for _ in range(world)],
+                 [[int(s == 0 and d == world - 1) for d in range(world)] for s in range(world)],               # one byte, one pair
+                 [[int(x) for x in rng.integers(0, 5000, size=world)] for _ in range(world)],
+                 [[(big if (s, d) == (0, 1 % world) else 7 * (s + 1) + d) for d in range(world)] for s in range(world)]]
+    json.dump({"gathers": gathers, "sums": [0, 1, 1000, (1 << 20) + 7], "exchanges": exchanges}, open(os.path.join(wd, "spec.json"), "w"))
     env = dict(os.environ, MP_RCCL_LIBRARY=STUB)
     # the id comes from the library's own export, as a host would draw it on rank 0
     uid = subprocess.check_output([sys.executable, "-c",
@@ -100,8 +105,56 @@ def _core_worker(rank, world, port, name, inp, out, write_json):
         assert seen[0] == world and seen[1] == rank and seen[2].endswith("librccl_stub.so"), seen
         app.run()
         assert app._win_split == (not write_json)
+        from test_multirank import check_traffic
+        check_traffic(app, world)                     # window-split: the tables reach the window owners by mp_comm_alltoallv
     finally:
         dist.destroy_process_group()
+
+
+def _synthetic_worker(rank, world, port, inp, out):
+    """Row shards of a synthetic alignment (rows and variation spread evenly): what a rank receives of the histogram entries is about
+    what it holds itself."""
+    sys.path.insert(0, REPO)
+    os.environ["MP_RCCL_LIBRARY"] = STUB
+    os.environ["MP_NATIVE_COMM"] = "force"
+    import torch.distributed as dist
+    from multiprime_amd._abi import Library
+    from multiprime_amd.core import NN_degenerate
+    from multiprime_amd.dist import RowShards
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        comm = RowShards()
+        app = NN_degenerate(seq_file=inp, primer_length=18, coverage=0.8, number_of_dege_bases=4, score_of_dege_bases=10, raw_entropy_threshold=3.6,
+                            product_len=150, position="2,3,-1", variation=1, distance=4, GC="0.2,0.7", nproc=1, outfile=out, library=Library(),
+                            comm=comm, write_json=False)
+        app.run()
+        assert app._win_split and comm.native is not None
+        (sent, received), = [(s, r) for w, s, r in comm.traffic if w == "histogram entries"]
+        own = comm.tables["histogram entries"]
+        assert received <= 1.2 * own, (sent, received, own)          # the all-gather delivered (world - 1) x own
+        assert received >= 0.5 * own * (world - 1) / world
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("world", [2, 3])
+def test_window_owners_receive_about_their_own_share(world, tmp_path):
+    """The bench's synthetic alignment (16384 rows) on `world` row shards through the library's communicator: TSV == the checker's
+    committed hash, and the personalised exchange hands a rank <= 1.2 x the entries it holds itself."""
+    import hashlib
+    import torch.multiprocessing as mp
+    from multiprime_amd.synth import synth_block, to_fasta
+    db = json.load(open(os.path.join(REPO, "tests", "golden", "synth_pipeline.json")))
+    entry = next(e for e in db["entries"] if e["rows"] == 16384)
+    inp = tmp_path / "syn.fa"
+    inp.write_bytes(to_fasta(synth_block(0, 16384, entry["cols"], entry["seed"])))
+    out = tmp_path / "syn.tsv"
+    port = 30700 + (os.getpid() % 2000)
+    mp.spawn(_synthetic_worker, args=(world, port, str(inp), str(out)), nprocs=world, join=True)
+    assert hashlib.sha256(out.read_bytes()).hexdigest() == entry["tsv_sha256"]
 
 
 @pytest.mark.gpu

@@ -30,8 +30,33 @@ def _worker(rank, world, port, name, inp, out, lib_path, write_json=True):
                             outfile=out, library=Library(lib_path), comm=RowShards(), write_bitsets=True, write_json=write_json)
         app.run()
         assert app._win_split == (not write_json)
+        check_traffic(app, world)
     finally:
         dist.destroy_process_group()
+
+
+def check_traffic(app, world):
+    """Window-split planning: the histogram entries and the exception list reach the rank that plans the window by a personalised
+    exchange — a rank receives the entries of ITS windows (about 1 / world of the others' tables; the all-gather delivered all of
+    them); every table moves in ONE collective and the small ones travel together.  Replicated planning (JSON side files) keeps the
+    all-gathers.  (tests/test_comm_ranks.py makes the 1.2 x statement on the evenly spread synthetic alignment, through RCCL's ABI.)"""
+    t = app.comm.traffic
+    kinds = [what for what, _, _ in t]
+    if not app._win_split:
+        assert "histogram entries" not in kinds and kinds.count("all-gather") >= 4
+        return
+    assert kinds.count("histogram entries") == 1 and kinds.count("exception list") == 1, kinds
+    assert kinds.count("all-reduce") <= 3, kinds             # the region's two row histograms, the two statistics tables together (+ the counters')
+    import numpy as np
+    for what in ("histogram entries", "exception list"):
+        (sent, received), = [(s, r) for w, s, r in t if w == what]
+        own = np.asarray([app.comm.tables[what]], np.int64)
+        others = int(app.comm.gather_var(own).sum()) - int(own[0])      # what an all-gather of the table would have delivered here
+        # an even spread delivers others / world; real alignments are skewed (variable regions hold more distinct k-mers)
+        assert received <= (0.75 if world == 2 else 0.6) * others + 4096, (what, sent, received, others)
+        assert sent <= int(own[0])
+    # everything else: the row attributes of the region, two small gathers per fused group (candidates, results, bitsets)
+    assert kinds.count("all-gather") <= 14, kinds
 
 
 # 1/2/4/8 shards (SURVEY §4-iv) incl. uneven splits: syn_iupac has 60 rows (8 ranks: 7 or 8 rows each), ivc_v1 166 (4 ranks: 41/42)
