@@ -91,6 +91,34 @@ def prefer_staged_copies():
         os.environ.setdefault("GPU_PINNED_MIN_XFER_SIZE", "256")
 
 
+def one_hip_runtime():
+    """One HIP runtime per process.  torch ships its own libamdhip64 / libhsa-runtime64 (torch/lib); libmprime_hip.so is linked against
+    the system's (/opt/rocm).  The file names differ but the SONAMEs agree, so whichever is loaded FIRST serves both — and when this
+    library comes first and torch second, the loader finds torch's copy by its run path and the process ends up with two HIP and two
+    HSA runtimes on one GPU: torch then reports "No HIP GPUs are available" (tools/maps_check.py), and what else two runtimes do to
+    each other's registered memory is anybody's guess (the unexplained SIGABRT of round 4 is a candidate).  So before
+    the HIP library is opened in a process where torch is installed but not imported yet, torch's runtime is opened first — exactly the
+    state of a process that imported torch first (bench.py, the GPU suite).  MP_KEEP_SYSTEM_HIP=1 leaves the order to the caller."""
+    import importlib.util
+    import sys
+    if "torch" in sys.modules or os.environ.get("MP_KEEP_SYSTEM_HIP") == "1":
+        return
+    try:
+        spec = importlib.util.find_spec("torch")
+    except (ImportError, ValueError):
+        return
+    if spec is None or not spec.submodule_search_locations:
+        return
+    libdir = os.path.join(list(spec.submodule_search_locations)[0], "lib")
+    for name in ("libhsa-runtime64.so", "libamdhip64.so"):
+        path = os.path.join(libdir, name)
+        if os.path.exists(path):
+            try:
+                C.CDLL(path, mode=C.RTLD_GLOBAL)
+            except OSError:
+                return
+
+
 class MprimeError(RuntimeError):
     def __init__(self, code, msg):
         super().__init__(f"mprime error {code}: {msg}")
@@ -112,6 +140,8 @@ class Library:
             raise MprimeError(-2, f"{path} is missing — build it with `python -c 'import __graft_entry__ as g; g.build()'` "
                                   "(hipcc --offload-arch=gfx950); there is no CPU fallback")
         self.path = path
+        if os.path.basename(path).startswith("libmprime_hip"):
+            one_hip_runtime()
         self.dll = C.CDLL(path)
         for name, res, args in SYMBOLS:
             fn = getattr(self.dll, name)     # AttributeError = ABI symbol missing

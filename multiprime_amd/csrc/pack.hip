@@ -273,6 +273,14 @@ int mp_load_msa(mp_ctx *c, const uint8_t *bytes, const int64_t *row_off, int32_t
     if ((rc = dev_alloc(c, &c->rlen, np))) return rc;
     std::vector<int64_t> off0(n_rows + 1);
     for (int r = 0; r <= n_rows; r++) off0[r] = row_off[r] - row_off[0];
+    // MP_EXPERIMENT_PIN_LOAD (tools/load_stress.py only): round 4's registration of the CALLER's residue bytes for the duration of this
+    // transfer — withdrawn after an unexplained SIGABRT in one GPU-suite run of four; kept behind the switch so that the stress tool
+    // exercises exactly that code path
+    struct PinForLoad {
+        void *p = nullptr;
+        PinForLoad(void *ptr, size_t n) { if (getenv("MP_EXPERIMENT_PIN_LOAD") && n >= ((size_t)4 << 20) && hipHostRegister(ptr, n, hipHostRegisterDefault) == hipSuccess) p = ptr; else (void)hipGetLastError(); }
+        ~PinForLoad() { if (p) { (void)hipStreamSynchronize(nullptr); (void)hipHostUnregister(p); } }
+    } pin_for_load(getenv("MP_EXPERIMENT_PIN_LOAD") ? const_cast<uint8_t *>(bytes) + row_off[0] : nullptr, (size_t)total);
     HIPCK(c, hipMemcpyAsync(d_bytes, bytes + row_off[0], (size_t)total, hipMemcpyHostToDevice, c->stream));
     HIPCK(c, hipMemcpyAsync(d_off, off0.data(), sizeof(int64_t) * (n_rows + 1), hipMemcpyHostToDevice, c->stream));
     const FillSeg init[4] = {{c->ung, sizeof(uint32_t) * np * c->ustride, 0u}, {c->rlen, sizeof(int32_t) * np, 0u}, {c->rstrip, sizeof(int32_t) * np, 0u},

@@ -68,6 +68,9 @@ def dll():
         if not os.path.exists(path):
             raise MprimeError(-2, f"{HIP_LIB} is missing — build it with `python -c 'import __graft_entry__ as g; g.build()'`; "
                                   "the host stage has no Python fallback")
+        if os.path.basename(path).startswith("libmprime_hip"):
+            from ._abi import one_hip_runtime
+            one_hip_runtime()
         d = C.CDLL(path)
         for name, res, args in HOST_SYMBOLS:
             if name == "mp_plan_create_streamed" and not hasattr(d, name):
