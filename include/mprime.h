@@ -122,6 +122,19 @@ int mp_get_window_words(mp_ctx *ctx, int32_t w, int32_t row0, int32_t n, void *o
  * host can rebuild the id lists (non_gap_seq_id / gap_seq_id, V20:698,707). */
 int mp_window_unique(mp_ctx *ctx, int64_t cap_entries, int32_t want_labels, int64_t *n_entries);
 
+/* The entropy gate of V20:723 decided on the device where that is certain.  More than half of the windows of a deep alignment end at
+ * `Entropy of total (bit) > threshold` — after the host has read back, decoded, merged and ordered all their entries, and they are the
+ * windows with the most entries.  mp_set_entropy_gate(threshold > 0) arms the gate for the following mp_window_unique calls WITHOUT labels
+ * (0 disarms it): the call then takes the entropy of every window's table on the device and rejects the windows that exceed
+ * threshold + 0.005 (the rounding to two decimals) by more than a bound on what the table cannot see — the rows holding an IUPAC code,
+ * which the host adds with their expansions: total-variation distance theta = E / (T + E) between the two distributions, hence at most
+ * theta log2(T + E) + h2(theta) between their entropies.  A rejected window has no entries (win_off[w] == win_off[w + 1]);
+ * mp_plan_create_streamed reports it as MP_WIN_ENTROPY_DEVICE without planning it; every other window is decided by the host exactly as
+ * before, so the planned windows and everything derived from them are unchanged.  mp_entropy_gate_result: how many windows the last
+ * mp_window_unique rejected, and which (rejected[n_windows], may be NULL).  The checker accepts the calls and never rejects. */
+int mp_set_entropy_gate(mp_ctx *ctx, double threshold);
+int mp_entropy_gate_result(mp_ctx *ctx, int32_t *n_rejected, uint8_t *rejected);
+
 /* Entries of window w are [win_off[w], win_off[w+1]); order inside a window is unspecified.
  * words: b0 at [0,n), b1 at [n,2n), g at [2n,3n) with n = total entries. */
 int mp_get_unique(mp_ctx *ctx, int64_t *win_off, void *words, int32_t *count, int32_t *first_row);

@@ -73,6 +73,9 @@ typedef struct mp_plan_params {
 #define MP_WIN_ENTROPY 3         /* tBit > threshold                                (V20:723) */
 #define MP_WIN_FEW_BASES 4       /* fewer than 4 bases in the frequency matrix      (V20:736) */
 #define MP_WIN_GAP_COLUMN 5      /* an all-gap column                               (V20:738) */
+#define MP_WIN_ENTROPY_DEVICE 6  /* tBit > threshold for certain, decided on the device from the window's histogram table before its entries
+                                    were read back (mp_set_entropy_gate, mprime.h): the host would have stopped at V20:723 or at one of the two
+                                    gates in front of it (gap fraction, empty cover); no entropy value is computed */
 
 /* Builds, for every window, the insertion-ordered cover / gap_sequence tables from
  *   - histogram entries (any order, duplicates allowed: entries of several row shards are merged by key — counts

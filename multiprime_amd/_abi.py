@@ -44,6 +44,8 @@ SYMBOLS = [
     ("mp_get_window_words", C.c_int, [_p, C.c_int32, C.c_int32, C.c_int32, _p]),
     ("mp_window_stats", C.c_int, [_p, _p, _p]),
     ("mp_window_unique", C.c_int, [_p, C.c_int64, C.c_int32, C.POINTER(C.c_int64)]),
+    ("mp_set_entropy_gate", C.c_int, [_p, C.c_double]),
+    ("mp_entropy_gate_result", C.c_int, [_p, C.POINTER(C.c_int32), _p]),
     ("mp_get_unique", C.c_int, [_p, _p, _p, _p, _p]),
     ("mp_get_labels", C.c_int, [_p, C.c_int32, _p]),
     ("mp_get_labels_many", C.c_int, [_p, C.c_int32, _p, _p]),
@@ -286,6 +288,17 @@ class Context:
             rc = self.d.mp_window_unique(self.h, int(n.value), 0, C.byref(n))
         self._ck(rc)
         return int(n.value)
+
+    def set_entropy_gate(self, threshold: float):
+        """Arm (threshold > 0) or disarm (0) the entropy gate on the device for the following window_unique_device calls."""
+        self._ck(self.d.mp_set_entropy_gate(self.h, float(threshold)))
+
+    def entropy_gate_result(self):
+        """(number of windows the last histogram call rejected on the device, bool [n_win] which)."""
+        n = C.c_int32(0)
+        which = np.zeros(max(self.n_win, 1), np.uint8)
+        self._ck(self.d.mp_entropy_gate_result(self.h, C.byref(n), _ptr(which)))
+        return int(n.value), which[: self.n_win].astype(bool)
 
     def get_labels(self, w: int) -> np.ndarray:
         lab = np.empty(self.n_rows, np.int32)

@@ -173,6 +173,11 @@ class NN_degenerate(object):
         print("[core] %-34s %8.3f ms" % (label, (now - getattr(self, "_lap_t", now)) * 1e3), file=sys.stderr)
         self._lap_t = now
 
+    def _arm_device_gate(self):
+        """The streamed planning lets the device reject the windows whose entropy exceeds the threshold for certain (mp_set_entropy_gate):
+        their entries are neither read back nor planned.  MP_DEVICE_GATE=0 leaves every window to the host."""
+        self.ctx.set_entropy_gate(self.entropy_threshold if os.environ.get("MP_DEVICE_GATE", "1") != "0" else 0)
+
     def _plan(self, keep_tables=None):
         """Device stage (windows, statistics, histograms) and the native per-window planning.  Returns the
         host.Plan, or None when the region holds no window."""
@@ -238,6 +243,7 @@ class NN_degenerate(object):
             helper.start()
             t_u = time.time()
             try:
+                self._arm_device_gate()
                 self.ctx.window_unique_device()
             finally:
                 helper.join()
@@ -268,8 +274,11 @@ class NN_degenerate(object):
         x_row = ex_r.astype(np.int64) + row_base
         if streamed:
             if not early_unique:
+                self._arm_device_gate()
                 self.ctx.window_unique_device()
                 self.stats["unique_s"] = time.time() - t0
+            self.ctx.set_entropy_gate(0)
+            self.stats["windows_device_gated"] = self.ctx.entropy_gate_result()[0]
             t0 = time.time()
             self._exc = (ex_w, x_row, ex_codes)
             self._win_split = False

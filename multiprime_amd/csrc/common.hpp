@@ -162,6 +162,10 @@ struct mp_ctx {
     unsigned long long *u_total = nullptr;
     std::vector<int64_t> h_wbase;
     std::vector<int32_t> h_wcount;
+    // the entropy gate on the device (mp_set_entropy_gate): armed threshold (0: off), and after the histograms which windows it
+    // rejected — their entries are neither compacted nor read back nor planned (mp_plan_create_streamed)
+    double gate_threshold = 0;
+    std::vector<uint8_t> h_wskip;
     // dimer tables (Loss decisions, deltaG constants): cached across calls, re-uploaded only when the contents change
     uint8_t *dm_loss = nullptr;
     double *dm_dg = nullptr;

@@ -273,7 +273,8 @@ int mp_plan_create_segments_w64(const mp_plan_params *params, const int64_t *e_o
                                 const uint8_t *x_codes, const int64_t *freq, const int64_t *nn, mp_plan_w64 **out);
 int mp_plan_create_segments_ready_w64(const mp_plan_params *params, const int64_t *e_off, const void *e_words, const int32_t *e_count,
                                       const int32_t *e_first, int64_t row_base, int64_t n_exc, const int32_t *x_window, const int64_t *x_row,
-                                      const uint8_t *x_codes, const int64_t *freq, const int64_t *nn, const void *ready, mp_plan_w64 **out);
+                                      const uint8_t *x_codes, const int64_t *freq, const int64_t *nn, const void *ready, const uint8_t *skip,
+                                      mp_plan_w64 **out);
 int mp_plan_windows_w64(const mp_plan_w64 *p, int32_t *status, int64_t *cover_number, int64_t *gap_number, double *cbit, double *tbit);
 int mp_plan_sizes_w64(const mp_plan_w64 *p, int32_t *n_planned, int64_t *n_candidates);
 int mp_plan_candidates_w64(const mp_plan_w64 *p, int32_t *cand_window, uint8_t *cand_codes);
@@ -709,6 +710,7 @@ struct EntryInput {
     const int32_t *count32, *first32;
     int64_t row_base;
     mp_ready_gate *ready;                     // null, or: the entries of windows below the gate have arrived (mp_plan_create_streamed)
+    const uint8_t *skip;                      // null, or: windows the entropy gate rejected on the device (no entries, not planned)
     int64_t count(int64_t i) const { return count64 ? count64[i] : (int64_t)count32[i]; }
     int64_t first(int64_t i) const { return first64 ? first64[i] : (int64_t)first32[i] + row_base; }
 };
@@ -740,29 +742,30 @@ int mp_plan_create(const mp_plan_params *params, int64_t n_entries, const int32_
         return mp_plan_create_w64(params, n_entries, e_window, e_words, e_count, e_first, n_exc, x_window, x_row, x_codes, freq, nn, (mp_plan_w64 **)out);
 #endif
     if (n_entries < 0 || (n_entries && (!e_window || !e_words || !e_count || !e_first))) return MP_ERR_ARG;
-    const EntryInput E{n_entries, e_window, nullptr, e_words, e_count, e_first, nullptr, nullptr, 0, nullptr};
+    const EntryInput E{n_entries, e_window, nullptr, e_words, e_count, e_first, nullptr, nullptr, 0, nullptr, nullptr};
     return plan_create_guarded(params, E, n_exc, x_window, x_row, x_codes, freq, nn, out);
 }
 
 int mp_plan_create_segments(const mp_plan_params *params, const int64_t *e_off, const void *e_words, const int32_t *e_count,
                             const int32_t *e_first, int64_t row_base, int64_t n_exc, const int32_t *x_window, const int64_t *x_row,
                             const uint8_t *x_codes, const int64_t *freq, const int64_t *nn, mp_plan **out) {
-    return mp_plan_create_segments_ready(params, e_off, e_words, e_count, e_first, row_base, n_exc, x_window, x_row, x_codes, freq, nn, nullptr, out);
+    return mp_plan_create_segments_ready(params, e_off, e_words, e_count, e_first, row_base, n_exc, x_window, x_row, x_codes, freq, nn, nullptr, nullptr, out);
 }
 
 // planstream.hpp: the same with the entries still arriving — windows below the gate `ready` (an mp_ready_gate) are complete
 int mp_plan_create_segments_ready(const mp_plan_params *params, const int64_t *e_off, const void *e_words, const int32_t *e_count,
                                   const int32_t *e_first, int64_t row_base, int64_t n_exc, const int32_t *x_window, const int64_t *x_row,
-                                  const uint8_t *x_codes, const int64_t *freq, const int64_t *nn, const void *ready, mp_plan **out) {
+                                  const uint8_t *x_codes, const int64_t *freq, const int64_t *nn, const void *ready, const uint8_t *skip,
+                                  mp_plan **out) {
 #if !MP_PLAN_WIDE
     if (params && params->k > kMaxK)
         return mp_plan_create_segments_ready_w64(params, e_off, e_words, e_count, e_first, row_base, n_exc, x_window, x_row, x_codes, freq, nn, ready,
-                                                 (mp_plan_w64 **)out);
+                                                 skip, (mp_plan_w64 **)out);
 #endif
     if (!params || !e_off || params->n_windows < 0) return MP_ERR_ARG;
     const int64_t n = e_off[params->n_windows];
     if (n < 0 || (n && (!e_words || !e_count || !e_first))) return MP_ERR_ARG;
-    const EntryInput E{n, nullptr, e_off, e_words, nullptr, nullptr, e_count, e_first, row_base, static_cast<mp_ready_gate *>(const_cast<void *>(ready))};
+    const EntryInput E{n, nullptr, e_off, e_words, nullptr, nullptr, e_count, e_first, row_base, static_cast<mp_ready_gate *>(const_cast<void *>(ready)), skip};
     return plan_create_guarded(params, E, n_exc, x_window, x_row, x_codes, freq, nn, out);
 }
 
@@ -820,6 +823,7 @@ static int plan_create_body(mp_plan *p, const EntryInput &E, int64_t n_exc, cons
         for (;;) {
             int w = next.fetch_add(1);
             if (w >= W || failed.load()) break;
+            if (E.skip && E.skip[w]) { p->win[(size_t)w].status = MP_WIN_ENTROPY_DEVICE; continue; }      // rejected on the device: nothing to plan
             if (E.ready) E.ready->wait_for(w); // streamed read-back: this window's entries may still be on their way
             const auto t_w0 = std::chrono::steady_clock::now();
             sights.clear();

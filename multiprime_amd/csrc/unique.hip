@@ -310,6 +310,30 @@ __global__ __launch_bounds__(kBlock) void count_kernel(const unsigned long long 
     if (threadIdx.x == 0) used[w] = s_n;
 }
 
+// The entropy gate's sums over a window's table (mp_set_entropy_gate): T = sum of the counts, S = sum of c log2 c — the entropy of the
+// window's k-mer distribution is log2 T - S / T whatever the order of the terms.  One workgroup per window.
+__global__ __launch_bounds__(kBlock) void gate_kernel(const unsigned long long *__restrict__ g_key, const uint32_t *__restrict__ g_cnt, int g_slots,
+                                                      double *__restrict__ sums) {
+    __shared__ double s_t[kBlock / 64], s_s[kBlock / 64];
+    const int w = blockIdx.x;
+    double t = 0, s = 0;
+    for (int i = threadIdx.x; i < g_slots; i += kBlock) {
+        const size_t at = (size_t)w * g_slots + i;
+        if (g_key[at] == kNoKey) continue;
+        const double c = (double)g_cnt[at];
+        t += c;
+        s += c * log2(c);
+    }
+    for (int sft = 32; sft >= 1; sft >>= 1) { t += __shfl_xor(t, sft); s += __shfl_xor(s, sft); }
+    if ((threadIdx.x & 63) == 0) { s_t[threadIdx.x >> 6] = t; s_s[threadIdx.x >> 6] = s; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double tt = 0, ss = 0;
+        for (int i = 0; i < kBlock / 64; i++) { tt += s_t[i]; ss += s_s[i]; }
+        sums[2 * w] = tt; sums[2 * w + 1] = ss;
+    }
+}
+
 // occupied slots -> entries of the window's segment (order inside a window is unspecified).  One workgroup per window
 // walks the window's table with a running count in LDS: no global atomics (a returning atomic per wave on ~1000 hot
 // addresses made the first version 0.7 ms at 131072 x 1000 for 128 MB of reads).
@@ -318,6 +342,7 @@ __global__ __launch_bounds__(kBlock) void compact_kernel(const CompactArgs A) {
     __shared__ int s_part[U * NWV];
     __shared__ int s_base;
     const int w = blockIdx.x;
+    if (A.win_base[w] < 0) return;                            // a window the entropy gate rejected on the device: no entries leave it
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     if (threadIdx.x == 0) s_base = 0;
     __syncthreads();
@@ -605,14 +630,63 @@ int unique_packed(mp_ctx *c, int64_t cap, int32_t want_labels, int64_t *n_entrie
         if (attempt == 7 || (size_t)slots * 8 > ((size_t)1 << 28)) return fail(c, MP_ERR_NOMEM, "histogram tables do not converge");
         slots *= 8;
     }
+    // The entropy gate on the device (armed by mp_set_entropy_gate, no labels wanted): V20:723 rejects a window whose "Entropy of total",
+    // rounded to two decimals, exceeds the threshold — and more than half of the windows of a deep alignment end there, after the host has
+    // decoded, merged and ordered all their entries (they are the windows with the MOST entries).  The tables hold what the host would
+    // sum, except the rows with an IUPAC code (E of them, counted with their expansions): the true distribution differs from the
+    // table's by a total-variation distance of at most theta = E / (T + E), so the two entropies differ by at most
+    // theta log2(T + E) + h2(theta) (Fannes-Audenaert), and rounding moves the value by at most 0.005.  A window whose table entropy
+    // clears threshold + 0.005 by more than that bound is rejected here, for certain; every other window goes to the host as before,
+    // which decides exactly.  A rejected window's entries are not compacted, not read back, not planned.
+    c->h_wskip.clear();
+    if (c->gate_threshold > 0 && !want_labels && !getenv("MP_NO_DEVICE_GATE")) {
+        double *d_sums = nullptr;
+        if ((rc = dev_alloc(c, &d_sums, 2 * W))) return rc;
+        hipLaunchKernelGGL(gate_kernel, dim3((unsigned)W), dim3(kBlock), 0, c->stream, (const unsigned long long *)c->g_key, (const uint32_t *)c->g_cnt, slots, d_sums);
+        std::vector<double> sums(2 * W);
+        hipError_t e = hipGetLastError();
+        if (e == hipSuccess) e = hipMemcpyAsync(sums.data(), d_sums, sizeof(double) * 2 * W, hipMemcpyDeviceToHost, c->stream);
+        if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+        dev_free(c, &d_sums, 2 * W);
+        if (e != hipSuccess) return fail(c, MP_ERR_DEVICE, "entropy gate: %s", hipGetErrorString(e));
+        // E per window: an exception row with more than v gaps is one gap_sequence entry, any other counts once per expansion (V20:689-707)
+        std::vector<double> extra(W, 0.0);
+        static const int kSetSize[16] = {1, 1, 1, 2, 1, 2, 2, 3, 1, 2, 2, 3, 2, 3, 3, 4};
+        for (const ExRec &x : c->ex_host) {
+            int gaps = 0;
+            double n_exp = 1;
+            for (int j = 0; j < c->k; j++) {
+                const uint32_t code = (uint32_t)((x.q[j >> 4] >> (4 * (j & 15))) & 15u);
+                gaps += code == 0;
+                n_exp *= kSetSize[code];
+            }
+            if (x.win >= 0 && (size_t)x.win < W) extra[(size_t)x.win] += gaps > c->v ? 1.0 : n_exp;
+        }
+        c->h_wskip.assign(W, 0);
+        size_t n_skip = 0;
+        for (size_t w = 0; w < W; w++) {
+            const double T = sums[2 * w], S = sums[2 * w + 1], E = extra[w];
+            if (!(T > 0)) continue;
+            const double H = std::log2(T) - S / T, theta = E / (T + E);
+            const double h2 = theta > 0 && theta < 1 ? -theta * std::log2(theta) - (1 - theta) * std::log2(1 - theta) : 0.0;
+            const double bound = theta * std::log2(T + E) + h2 + 1e-6;
+            if (H - bound > c->gate_threshold + 0.005) { c->h_wskip[w] = 1; used[w] = 0; n_skip++; }
+        }
+        if (getenv("MP_TRACE")) fprintf(stderr, "[mprime] unique: entropy gate on the device rejected %zu of %zu windows\n", n_skip, W);
+        lap("unique: entropy gate");
+    }
     c->h_wbase.resize(W); c->h_wcount.resize(W);
     int64_t total = 0;
-    for (size_t w = 0; w < W; w++) { c->h_wbase[w] = total; c->h_wcount[w] = used[w]; total += used[w]; }
+    std::vector<int64_t> dev_base(W);
+    for (size_t w = 0; w < W; w++) {
+        c->h_wbase[w] = total; c->h_wcount[w] = used[w]; total += used[w];
+        dev_base[w] = !c->h_wskip.empty() && c->h_wskip[w] ? -1 : c->h_wbase[w];
+    }
     if (n_entries) *n_entries = total;
     if (total > cap) { c->u_n = 0; return fail(c, MP_ERR_CAPACITY, "unique table needs %lld entries", (long long)total); }
     if ((rc = alloc_entries(c, std::max<int64_t>(total, 1)))) return rc;
     if ((rc = dev_alloc(c, &d_cursor, W))) return rc;
-    HIPCK(c, hipMemcpyAsync(c->u_wbase, c->h_wbase.data(), sizeof(int64_t) * W, hipMemcpyHostToDevice, c->stream));
+    HIPCK(c, hipMemcpy(c->u_wbase, dev_base.data(), sizeof(int64_t) * W, hipMemcpyHostToDevice));
     HIPCK(c, hipMemsetAsync(d_cursor, 0, sizeof(int32_t) * W, c->stream));
     CompactArgs CA{c->g_key, c->g_cnt, c->g_min, c->g_idx, c->g_slots, c->k, c->u_wbase, d_cursor,
                    c->u_b0, c->u_b1, c->u_g, c->u_count, c->u_first, (long long)c->u_cap};
@@ -706,8 +780,25 @@ int mp_window_unique(mp_ctx *c, int64_t cap, int32_t want_labels, int64_t *n_ent
     if (cap <= 0) return fail(c, MP_ERR_ARG, "cap_entries must be positive");
     HIPCK(c, hipSetDevice(c->dev));
     free_unique(c);
+    c->h_wskip.clear();
     if (c->p64) return unique_packed(c, cap, want_labels, n_entries);
     return c->wide ? unique_rep_rows<uint64_t>(c, cap, want_labels, n_entries) : unique_rep_rows<uint32_t>(c, cap, want_labels, n_entries);
+}
+
+int mp_set_entropy_gate(mp_ctx *c, double threshold) {
+    if (!c) return MP_ERR_ARG;
+    if (!(threshold >= 0)) return fail(c, MP_ERR_ARG, "mp_set_entropy_gate: the threshold must be >= 0 (0 switches the gate off)");
+    c->gate_threshold = threshold;
+    return MP_OK;
+}
+
+int mp_entropy_gate_result(mp_ctx *c, int32_t *n_rejected, uint8_t *rejected) {
+    if (!c) return MP_ERR_ARG;
+    int32_t n = 0;
+    for (size_t w = 0; w < c->h_wskip.size(); w++) { n += c->h_wskip[w]; if (rejected) rejected[w] = c->h_wskip[w]; }
+    if (rejected && c->h_wskip.empty()) memset(rejected, 0, (size_t)c->n_win);
+    if (n_rejected) *n_rejected = n;
+    return MP_OK;
 }
 
 int mp_get_unique(mp_ctx *c, int64_t *win_off, void *words_out, int32_t *count, int32_t *first_row) {
@@ -854,7 +945,7 @@ int mp_plan_create_streamed(mp_ctx *c, const mp_plan_params *params, int64_t row
         }
     });
     int rc = mp_plan_create_segments_ready(params, e_off.data(), words.get(), count.get(), first.get(), row_base, n_exc, x_window, x_row, x_codes, freq, nn,
-                                           &ready, out);
+                                           &ready, c->h_wskip.empty() ? nullptr : c->h_wskip.data(), out);
     if (trace) fprintf(stderr, "[mprime] plan_streamed: planning done at %.3f ms\n", ms_since());
     copier.join();
     if (trace) fprintf(stderr, "[mprime] plan_streamed: returning at %.3f ms\n", ms_since());

@@ -392,6 +392,19 @@ int mp_window_unique(mp_ctx *c, int64_t cap, int32_t want_labels, int64_t *n_ent
     return MP_OK;
 }
 
+/* the device-side entropy gate (mprime.h): the checker never rejects a window itself */
+int mp_set_entropy_gate(mp_ctx *c, double threshold) {
+    if (!c) return MP_ERR_ARG;
+    if (!(threshold >= 0)) return fail(c, MP_ERR_ARG, "mp_set_entropy_gate: the threshold must be >= 0");
+    return MP_OK;
+}
+int mp_entropy_gate_result(mp_ctx *c, int32_t *n_rejected, uint8_t *rejected) {
+    if (!c) return MP_ERR_ARG;
+    if (n_rejected) *n_rejected = 0;
+    if (rejected && c->n_win > 0) memset(rejected, 0, (size_t)c->n_win);
+    return MP_OK;
+}
+
 int mp_get_unique(mp_ctx *c, int64_t *win_off, void *words, int32_t *count, int32_t *first_row) {
     if (!c || !c->win_off) return c ? fail(c, MP_ERR_ARG, "mp_window_unique has not run") : MP_ERR_ARG;
     int64_t n = c->n_ent;

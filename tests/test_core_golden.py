@@ -86,9 +86,12 @@ def test_streamed_planning_equals_blocking_read_back(name, hip_lib, tmp_path, mo
     bands beside the planning threads; packed keys and the k >= 22 / 64-bit word tables alike).  Same TSV as the reference, and the
     same plan tables as the two blocking calls (MP_PLAN_STREAM=0), window by window."""
     want = open(os.path.join(GOLDEN, name + ".tsv"), "rb").read()
-    plans = {}
-    for mode in ("1", "0", "1-staged", "0-staged"):
+    plans, gated = {}, {}
+    for mode in ("1", "0", "1-staged", "0-staged", "1-gate"):
         monkeypatch.setenv("MP_PLAN_STREAM", mode[0])
+        # "1-gate": the entropy gate decided on the device where that is certain (the default of the streamed route); the other modes
+        # leave every window to the host, so that the two routes can be compared window by window
+        monkeypatch.setenv("MP_DEVICE_GATE", "1" if mode == "1-gate" else "0")
         if mode.endswith("staged"):              # neither registered transfers nor parallel page faults: the runtime's staging path
             monkeypatch.setenv("MP_NO_PIN", "1")
             monkeypatch.setenv("MP_NO_PREFAULT", "1")
@@ -100,8 +103,23 @@ def test_streamed_planning_equals_blocking_read_back(name, hip_lib, tmp_path, mo
         st, cn, gn, cb, tb = app.plan.windows()
         plans[mode] = (st.tolist(), cn.tolist(), gn.tolist(), [repr(x) for x in cb.tolist()], [repr(x) for x in tb.tolist()],
                        [a.tolist() for a in app.plan.candidates()])
+        gated[mode] = app.stats.get("windows_device_gated", 0)
         app.ctx.close()
     assert plans["1"] == plans["0"] == plans["1-staged"] == plans["0-staged"]
+    assert gated["1"] == 0
+    # with the gate on the device: a window it rejected is one the host rejects at the entropy gate (status 3) or at one of the two gates
+    # in front of it (gap fraction, empty cover: V20:713-723 in that order), every other window and every candidate is the same
+    g, h = plans["1-gate"], plans["1"]
+    n_dev = 0
+    for w, (sg, sh) in enumerate(zip(g[0], h[0])):
+        if sg == 6:                              # MP_WIN_ENTROPY_DEVICE
+            assert sh in (1, 2, 3), (w, sh)
+            n_dev += 1
+        else:
+            assert (sg, g[1][w], g[2][w], g[3][w], g[4][w]) == (sh, h[1][w], h[2][w], h[3][w], h[4][w]), w
+    assert g[5] == h[5] and n_dev == gated["1-gate"]
+    if name == "msa1000_k18_d64":            # (1000 sequences: most of the windows the host rejects are beyond the bound; 166 of ivc_v2: none)
+        assert n_dev > 50, "the device gate rejected next to nothing on an alignment where the host rejects hundreds of windows"
 
 
 def _side_bytes(out):
