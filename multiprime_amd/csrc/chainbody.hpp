@@ -219,4 +219,88 @@ __device__ __forceinline__ void eval_chain_block(const EvalChainArgs &A, uint32_
     else block_commit<GW>(accP, accF, accR, s_part, A.cand_out + it.cand0, A.out);
 }
 
+// One PATCH UNIT per wave with ONE word per lane (64 words = 2048 rows of a window's patch planes) — the form the sliding launch runs
+// its patch units in.  A unit of eval_chain_block<LV, 8, 4> took ~10 us at the 131072-row shard whatever little it had to do (23 words
+// of patch rows, 3 lanes of 64 busy): its walk fetches an event word, then that event's plane, one event after the other — fourteen
+// dependent memory round trips — and those units are the tail of the launch, nothing hides them (tools/slide_stamps.py: slide
+// workgroups done at 25 us, patch units until 30).  Here everything a unit needs is requested in three rounds: the item, then its
+// event words (one per lane, read back with v_readlane) together with the first-pass planes (16 positions in flight), then ALL event
+// planes at once into the wave's stash in LDS (kPatchEvents of them; a chain with more events falls back to one-ahead fetches from
+// there on); the walk then reads the stash.  `stash`: 64 x kPatchEvents words of LDS of this wave; `row`: its 12 words for the sums.
+constexpr int kPatchEvents = 16;
+template <int LV>
+__device__ __forceinline__ void eval_patch_wave(const EvalChainArgs &A, uint32_t *row, uint32_t *stash, const unsigned unit, const bool negative) {
+    constexpr int CC = 8, GW = 1;
+    const int lane = (int)(threadIdx.x & 63);
+    const int item = __builtin_amdgcn_readfirstlane((int)(unit / (unsigned)A.patch.per_item)), slice = __builtin_amdgcn_readfirstlane((int)(unit % (unsigned)A.patch.per_item));
+    if (item >= (negative ? A.n_neg : A.map.n_items)) return;
+    const int word0 = slice * 64 + lane;
+    const ChainItem it = negative ? A.neg_items[item] : A.items[item];
+    const WordTile T = negative ? plain_tile(A.patch, it.win, word0) : patch_tile(A.patch, it.win, word0);
+    if (slice * 64 >= (int)T.stride) return;                               // nothing of this window's patch planes left for the wave
+    const size_t nw32 = T.stride;
+    const uint32_t *Pw = T.planes;
+    const uint32_t *ev = A.events + it.ev0;
+    const int n_ev = __builtin_amdgcn_readfirstlane((int)it.n_ev), n_steps = __builtin_amdgcn_readfirstlane((int)it.n_steps);
+    // round 2: the event words (lane e holds event e) ...
+    const uint32_t evv = lane < n_ev ? ev[lane] : 0u;
+    uint32_t acc[CC];
+#pragma unroll
+    for (int c = 0; c < CC; c++) acc[c] = 0;
+    // (a lane past the window's patch words computes on word 0 of the planes — inside the allocation — and is masked at the counts)
+    const uint32_t *Pl = T.live ? Pw : Pw - (word0 - slice * 64) ;
+    uint32_t t1[GW] = {0}, t2[GW] = {0}, t3[GW] = {0}, t4[GW] = {0}, sf[GW] = {0}, sr[GW] = {0};
+    const unsigned long long sy_lo = it.sym[0] | ((unsigned long long)it.sym[1] << 32);
+    const unsigned long long sy_hi = it.sym[2] | ((unsigned long long)it.sym[3] << 32);
+    // ... and the first candidate over all k positions, 16 / 8 / 4 positions in flight
+    chain_first_pass<LV, GW, 16, 1>(it.pos1, Pl, nw32, sy_lo, sy_hi, A.sF, A.sR, t1, t2, t3, t4, sf, sr);
+    chain_first_pass<LV, GW, 8, 2>(it.pos2, Pl, nw32, sy_lo, sy_hi, A.sF, A.sR, t1, t2, t3, t4, sf, sr);
+    chain_first_pass<LV, GW, 4, 4>(it.pos4, Pl, nw32, sy_lo, sy_hi, A.sF, A.sR, t1, t2, t3, t4, sf, sr);
+    const uint32_t valid = T.live ? (T.mask[0] ^ T.mask_flip) : 0u;
+    // round 3: every event plane at once (an event the item does not have repeats its last one)
+    auto plane_of = [&](uint32_t evw) { return Pl + ((size_t)(evw & 255u) * 4 + (size_t)__builtin_ctz(((evw >> 8) & 15u) | 16u)) * nw32; };
+    {
+        uint32_t pl[kPatchEvents];
+#pragma unroll
+        for (int u = 0; u < kPatchEvents; u++) {
+            const int e = n_ev ? (u < n_ev ? u : n_ev - 1) : 0;
+            const uint32_t evw = n_ev ? (uint32_t)__builtin_amdgcn_readlane((int)evv, e) : (1u << 8);
+            pl[u] = plane_of(evw)[0];
+        }
+#pragma unroll
+        for (int u = 0; u < kPatchEvents; u++) stash[u * 64 + lane] = pl[u];           // (a lane reads back its own words only: no barrier)
+    }
+    // the walk down the chain: the events of step s, then member s is counted (as in eval_chain_block)
+    int e = 0;
+#pragma unroll
+    for (int s = 0; s < CC; s++) {
+        if (s >= n_steps) break;
+        if (s > 0) {
+#pragma unroll 1
+            while (e < n_ev) {
+                const uint32_t evw = e < 64 ? (uint32_t)__builtin_amdgcn_readlane((int)evv, e) : ev[e];
+                if ((int)(evw >> 16) != s) break;
+                const uint32_t cur = e < kPatchEvents ? stash[e * 64 + lane] : plane_of(evw)[0];
+                const uint32_t j = evw & 255u;
+                count_plane<LV>(t1[0], t2[0], t3[0], t4[0], cur);
+                if (((A.sF | A.sR) >> j) & 1u) {
+                    const uint32_t fF = ((A.sF >> j) & 1u) ? 0xFFFFFFFFu : 0u, fR = ((A.sR >> j) & 1u) ? 0xFFFFFFFFu : 0u;
+                    sf[0] = __builtin_amdgcn_bitop3_b32(sf[0], cur, fF, kLutOrAnd);
+                    sr[0] = __builtin_amdgcn_bitop3_b32(sr[0], cur, fR, kLutOrAnd);
+                }
+                e++;
+            }
+        }
+        const uint32_t far = LV == 1 ? t1[0] : (LV == 2 ? t2[0] : (LV == 3 ? t3[0] : t4[0]));
+        const uint32_t nP = (uint32_t)__popc(valid & ~t1[0]);
+        const uint32_t nF = (uint32_t)__popc(__builtin_amdgcn_bitop3_b32(valid, far, sf[0], kLutAndNotNot));
+        const uint32_t nR = (uint32_t)__popc(__builtin_amdgcn_bitop3_b32(valid, far, sr[0], kLutAndNotNot));
+        acc[s] = nP | (nF << 10) | (nR << 20);
+    }
+    uint32_t accP[CC], accF[CC], accR[CC];
+#pragma unroll
+    for (int c = 0; c < CC; c++) { accP[c] = acc[c] & 1023u; accF[c] = (acc[c] >> 10) & 1023u; accR[c] = acc[c] >> 20; }
+    wave_commit<GW>(accP, accF, accR, row, A.cand_out + it.cand0, A.out, negative);
+}
+
 }  // namespace mp

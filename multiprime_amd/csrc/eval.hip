@@ -1299,16 +1299,19 @@ static int eval_launch_impl(mp_ctx *c, int64_t *device_out, int64_t *device_clea
                 // (the sliding kernel counts every row of a window as a plain column slice: the patch planes add the patch-list rows'
                 // real k-mers, their plain-slice planes take the plain counts back — the exclusion words are not read at all)
                 EvalChainArgs pa2 = ca;
-                int patch_blocks = 0;
+                int patch_blocks = 0, pgw = 8;
                 if (ca.patch.n_blocks) {
                     { int rc = ensure_plain_planes(c); if (rc) return rc; }
-                    // patch units are laid out for 8 words per thread (the shape the sliding launch runs them in)
-                    pa2.patch = patch_args(c, 8, c->n_chain, 64);
-                    const PatchArgs neg = patch_args(c, 8, c->slide_items, 64);
+                    // chains of more than 8 members: the long-chain kernel, a launch of its own, units of 8 words per thread; else the
+                    // units are the tail of the sliding launch, one word per lane (chainbody.hpp: eval_patch_wave)
+                    const bool long_chains = c->max_steps > kEvalCC;
+                    pgw = long_chains || c->max_npw > 64 ? 8 : 1;
+                    pa2.patch = patch_args(c, pgw, c->n_chain, 64);
+                    const PatchArgs neg = patch_args(c, pgw, c->slide_items, 64);
                     pa2.patch.qplanes = c->qplanes; pa2.patch.qvalid = c->qvalid; pa2.patch.neg_blocks = neg.n_blocks;
                     pa2.neg_items = c->chain_slid; pa2.n_neg = c->slide_items;
                     patch_blocks = pa2.patch.n_blocks + neg.n_blocks;
-                    if (c->max_steps > kEvalCC) {                 // chains of more than 8 members: the long-chain kernel, a launch of its own
+                    if (long_chains) {
                         hipLaunchKernelGGL(lfn[c->v][7], dim3((unsigned)patch_blocks), dim3(kBlock), 0, c->stream, pa2);
                         patch_blocks = 0;
                     }
@@ -1321,7 +1324,7 @@ static int eval_launch_impl(mp_ctx *c, int64_t *device_out, int64_t *device_clea
                                      (unsigned long long *)device_out, rbm, none, nullptr, 0};
                     hipLaunchKernelGGL((c->rest_max_steps > kEvalCC ? lfn : cfn)[c->v][cshape], dim3(rgrid), dim3(kBlock), 0, c->stream, ra);
                 }
-                int rc = launch_eval_slide(c, (unsigned long long *)device_out, patch_blocks ? &pa2 : nullptr, patch_blocks, take_clear(), n_clear);
+                int rc = launch_eval_slide(c, (unsigned long long *)device_out, patch_blocks ? &pa2 : nullptr, patch_blocks, pgw, take_clear(), n_clear);
                 if (rc) return rc;
             } else {
             if (use_prog) {

@@ -40,6 +40,7 @@ struct SlideKernArgs {
     EvalChainArgs chain;
     unsigned long long *clear;         // mp_eval_launch_rotating: the next launch's counter block (chainbody.hpp: clear_counters)
     uint32_t n_clear;
+    int patch_words;                   // words per lane of the patch units in the grid's tail: 1 (eval_patch_wave) or 8 (eval_chain_block<LV, 8, 4>)
     unsigned long long *stamps;        // null; MP_EXPERIMENT_STAMPS: [workgroup][8] wall-clock stamps of its phases (tools/slide_stamps.py)
 };
 
@@ -184,8 +185,20 @@ __global__ __launch_bounds__(kBlock) void eval_slide_kernel(const SlideKernArgs 
     if ((int)blockIdx.x >= K.n_slide_blocks) {
         // the tail of the grid: the patch-list rows of the same step (their real k-mers added, their plain slices taken back) — no
         // launch of their own, they fill the slots the sliding workgroups leave as they finish
-        uint32_t(&s_part)[kBlock / 64][12] = *reinterpret_cast<uint32_t(*)[kBlock / 64][12]>(lds);
-        eval_chain_block<LV, 8, 4>(K.chain, s_part, blockIdx.x - (unsigned)K.n_slide_blocks);
+        // (a wave per unit, one word per lane: chainbody.hpp eval_patch_wave; the first patch.n_blocks workgroups add the patch rows' real
+        // k-mers, the following patch.neg_blocks take their plain slices back)
+        // ... when a window's patch rows fit one such unit (up to 2048 of them: the shallow alignments, where these units are the launch's
+        // tail); deeper ones keep the units of 8 words per lane — a third of the waves, and the tail hides behind the sliding workgroups
+        // that finish last (10^6 rows: 0.165 ms per step with them, 0.176 with three one-word units per window)
+        const unsigned pb = blockIdx.x - (unsigned)K.n_slide_blocks, wv = threadIdx.x >> 6;
+        if (K.patch_words == 1) {
+            const bool negative = (int)pb >= K.chain.patch.n_blocks;
+            const unsigned unit = (pb - (negative ? (unsigned)K.chain.patch.n_blocks : 0u)) * (kBlock / 64) + wv;
+            eval_patch_wave<LV>(K.chain, lds + wv * 12, lds + 64 + wv * (64 * kPatchEvents), unit, negative);
+        } else {
+            uint32_t(&s_part)[kBlock / 64][12] = *reinterpret_cast<uint32_t(*)[kBlock / 64][12]>(lds);
+            eval_chain_block<LV, 8, 4>(K.chain, s_part, pb);
+        }
         if (K.stamps && threadIdx.x == 0) K.stamps[(size_t)blockIdx.x * 8 + 7] = wall_clock64();
         return;
     }
@@ -329,8 +342,8 @@ int upload_eval_slide(mp_ctx *c, const std::vector<ChainItem> &chains, const std
     return MP_OK;
 }
 
-int launch_eval_slide(mp_ctx *c, unsigned long long *device_out, const EvalChainArgs *patch, int patch_blocks, unsigned long long *clear,
-                      uint32_t n_clear) {
+int launch_eval_slide(mp_ctx *c, unsigned long long *device_out, const EvalChainArgs *patch, int patch_blocks, int patch_words,
+                      unsigned long long *clear, uint32_t n_clear) {
 #define SLIDE_ROW(LV) {eval_slide_kernel<LV, 1>, eval_slide_kernel<LV, 2>, eval_slide_kernel<LV, 4>}
     static const SlideFn fn[4][3] = {SLIDE_ROW(1), SLIDE_ROW(2), SLIDE_ROW(3), SLIDE_ROW(4)};
 #undef SLIDE_ROW
@@ -351,6 +364,7 @@ int launch_eval_slide(mp_ctx *c, unsigned long long *device_out, const EvalChain
     else { memset(&K.chain, 0, sizeof K.chain); patch_blocks = 0; }
     K.chain.clear = nullptr; K.chain.n_clear = 0;
     K.clear = clear; K.n_clear = n_clear;
+    K.patch_words = patch_words;
     K.stamps = nullptr;
     const char *stamp_file = getenv("MP_EXPERIMENT_STAMPS");           // tools/slide_stamps.py: the launch is synchronous then
     const size_t n_stamp = ((size_t)K.n_slide_blocks + (size_t)patch_blocks) * 8;
@@ -358,7 +372,8 @@ int launch_eval_slide(mp_ctx *c, unsigned long long *device_out, const EvalChain
         HIPCK(c, hipMalloc(&K.stamps, n_stamp * sizeof(unsigned long long)));
         HIPCK(c, hipMemsetAsync(K.stamps, 0, n_stamp * sizeof(unsigned long long), c->stream));
     }
-    const size_t lds = ((size_t)(kBlock / 64) * ((size_t)c->k * 64 * gw) + (size_t)c->slide_max_items * 12) * sizeof(uint32_t);
+    size_t lds = ((size_t)(kBlock / 64) * ((size_t)c->k * 64 * gw) + (size_t)c->slide_max_items * 12) * sizeof(uint32_t);
+    if (patch_blocks) lds = std::max(lds, (size_t)(64 + (kBlock / 64) * 64 * kPatchEvents) * sizeof(uint32_t));      // the patch units' rows and stashes
     if (lds > 160 * 1024) return fail(c, MP_ERR_ARG, "sliding evaluation: a band needs %zu bytes of LDS", lds);
     SlideFn f = fn[c->v][gi];
     if (lds > 48 * 1024) HIPCK(c, hipFuncSetAttribute(reinterpret_cast<const void *>(f), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));

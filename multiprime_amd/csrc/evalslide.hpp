@@ -13,8 +13,9 @@ struct EvalChainArgs;
 // `patch` (may be null) = the patch units of the same step (eval.hip: positive and subtracting run), `patch_blocks` workgroups of
 // eval_chain_block<LV, 8, 4>: they run as the tail of the sliding kernel's own grid instead of a launch of their own.
 // `clear` (may be null): n_clear counters the launch sets to zero beside its work (mp_eval_launch_rotating).
-int launch_eval_slide(mp_ctx *c, unsigned long long *device_out, const EvalChainArgs *patch, int patch_blocks, unsigned long long *clear,
-                      uint32_t n_clear);
+// `patch_words`: the shape the patch units were laid out for (patch_args): 1 or 8 words per lane.
+int launch_eval_slide(mp_ctx *c, unsigned long long *device_out, const EvalChainArgs *patch, int patch_blocks, int patch_words,
+                      unsigned long long *clear, uint32_t n_clear);
 void free_slide(mp_ctx *c);
 
 }  // namespace mp
