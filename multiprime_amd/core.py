@@ -173,10 +173,12 @@ class NN_degenerate(object):
         print("[core] %-34s %8.3f ms" % (label, (now - getattr(self, "_lap_t", now)) * 1e3), file=sys.stderr)
         self._lap_t = now
 
-    def _arm_device_gate(self):
+    def _arm_device_gate(self, keep_tables=False):
         """The streamed planning lets the device reject the windows whose entropy exceeds the threshold for certain (mp_set_entropy_gate):
-        their entries are neither read back nor planned.  MP_DEVICE_GATE=0 leaves every window to the host."""
-        self.ctx.set_entropy_gate(self.entropy_threshold if os.environ.get("MP_DEVICE_GATE", "1") != "0" else 0)
+        their entries are neither read back nor planned.  Not when the caller wants every window's tables kept (a rejected window
+        has none); MP_DEVICE_GATE=0 leaves every window to the host."""
+        on = os.environ.get("MP_DEVICE_GATE", "1") != "0" and not keep_tables
+        self.ctx.set_entropy_gate(self.entropy_threshold if on else 0)
 
     def _plan(self, keep_tables=None):
         """Device stage (windows, statistics, histograms) and the native per-window planning.  Returns the
@@ -243,7 +245,7 @@ class NN_degenerate(object):
             helper.start()
             t_u = time.time()
             try:
-                self._arm_device_gate()
+                self._arm_device_gate(keep)
                 self.ctx.window_unique_device()
             finally:
                 helper.join()
@@ -274,7 +276,7 @@ class NN_degenerate(object):
         x_row = ex_r.astype(np.int64) + row_base
         if streamed:
             if not early_unique:
-                self._arm_device_gate()
+                self._arm_device_gate(keep)
                 self.ctx.window_unique_device()
                 self.stats["unique_s"] = time.time() - t0
             self.ctx.set_entropy_gate(0)
