@@ -72,11 +72,23 @@ struct DevEnv {
     // iteration words arrive 64 at a time, one per lane (the array is padded by 64 words)
     __device__ __forceinline__ void load_iters(int idx) { itv = K.A.iters[(size_t)idx + (size_t)lane]; }
     __device__ __forceinline__ uint32_t iter_word(int j) const { return (uint32_t)__builtin_amdgcn_readlane((int)itv, j); }
-    // an item's record: its 32 words, one per lane of a register; a word leaves with one v_readlane
-    typedef uint32_t Rec;
-    __device__ __forceinline__ Rec load_rec(int item) const { return K.A.recs[(size_t)item * kSlideRec + (size_t)(lane & 31)]; }
-    __device__ __forceinline__ uint32_t rec_word(Rec r, int q) const { return (uint32_t)__builtin_amdgcn_readlane((int)r, q); }
-    __device__ __forceinline__ uint32_t rec_word_dyn(Rec r, int q) const { return (uint32_t)__builtin_amdgcn_readlane((int)r, q); }
+    // an item's record: the words the band routine reads arrive through SCALAR loads (the address is wave-uniform; the records are
+    // read-only: constant address space) — round 4 loaded the 32 words one per lane and took each out with a v_readlane: 13 vector
+    // instructions per item on a kernel that is bound by vector-instruction issue
+    typedef const uint32_t __attribute__((address_space(4))) * ConstWords;
+    struct Rec { uint32_t w[8], sm_lo, sm_hi, flags; ConstWords p; };
+    __device__ __forceinline__ Rec load_rec(int item) const {
+        Rec r;
+        r.p = (ConstWords)(K.A.recs + (size_t)__builtin_amdgcn_readfirstlane(item) * kSlideRec);
+#pragma unroll
+        for (int q = 0; q < 8; q++) r.w[q] = r.p[q];
+        r.sm_lo = r.p[24]; r.sm_hi = r.p[25]; r.flags = r.p[28];
+        return r;
+    }
+    __device__ __forceinline__ uint32_t rec_word(const Rec &r, int q) const {          // q is a constant after inlining
+        return q < 8 ? r.w[q] : (q == 24 ? r.sm_lo : (q == 25 ? r.sm_hi : (q == 28 ? r.flags : r.p[q])));
+    }
+    __device__ __forceinline__ uint32_t rec_word_dyn(const Rec &r, int q) const { return r.p[q]; }
     __device__ __forceinline__ void load(__amdgpu_buffer_rsrc_t rs, int soff, uint32_t (&d)[GW]) const {
         if constexpr (GW == 4) {
             const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rs, voff, soff, 0);

@@ -210,7 +210,27 @@ SLIDE_HD void slide_item(Env &env, const SlideArgs &A, const typename Env::Rec &
 #ifndef SLIDE_WALK_BRANCH
 #define SLIDE_WALK_BRANCH 0
 #endif
-            if (LV >= 2 && (!SLIDE_WALK_BRANCH || ((flags >> s) & 0x101u))) {
+            if (SLIDE_WALK_BRANCH == 2) {
+                // the count-based update for every event; an event at a strict position (the minority: a uniform branch) puts its rows out
+                // whatever their count — two more instructions per word for those events only, no masks for the others
+#pragma unroll
+                for (int i = 0; i < GW; i++) {
+                    const uint32_t d = F.d[s][i];
+                    if (LV == 1) { DF[i] |= d; DR[i] |= d; }
+                    else {
+                        DF[i] = bop<kSlOrAnd>(DF[i], d, T[LV >= 2 ? LV - 2 : 0][i]);
+                        DR[i] = bop<kSlOrAnd>(DR[i], d, T[LV >= 2 ? LV - 2 : 0][i]);
+                    }
+                }
+                if (LV >= 2 && ((flags >> s) & 0x101u)) {
+                    const uint32_t mF = (uint32_t)((int32_t)(flags << (31 - s)) >> 31), mR = (uint32_t)((int32_t)(flags << (23 - s)) >> 31);
+#pragma unroll
+                    for (int i = 0; i < GW; i++) {
+                        DF[i] = bop<kSlOrAnd>(DF[i], F.d[s][i], mF);
+                        DR[i] = bop<kSlOrAnd>(DR[i], F.d[s][i], mR);
+                    }
+                }
+            } else if (LV >= 2 && (!SLIDE_WALK_BRANCH || ((flags >> s) & 0x101u))) {
                 const uint32_t mF = (uint32_t)((int32_t)(flags << (31 - s)) >> 31), mR = (uint32_t)((int32_t)(flags << (23 - s)) >> 31);
 #pragma unroll
                 for (int i = 0; i < GW; i++) {
