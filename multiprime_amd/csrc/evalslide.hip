@@ -189,8 +189,11 @@ struct DevEnv {
     }
 };
 
+#ifndef SLIDE_MIN_WAVES
+#define SLIDE_MIN_WAVES 1
+#endif
 template <int LV, int GW>
-__global__ __launch_bounds__(kBlock) void eval_slide_kernel(const SlideKernArgs K) {
+__global__ __launch_bounds__(kBlock, GW == 4 ? 1 : SLIDE_MIN_WAVES) void eval_slide_kernel(const SlideKernArgs K) {
     extern __shared__ __align__(16) uint32_t lds[];
     clear_counters(K.clear, K.n_clear, blockIdx.x, gridDim.x);
     if (K.stamps && threadIdx.x == 0) K.stamps[(size_t)blockIdx.x * 8] = wall_clock64();

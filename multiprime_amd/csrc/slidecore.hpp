@@ -61,6 +61,16 @@ SLIDE_HD int slide_popc(uint32_t x) {
 #endif
 }
 
+// keeps a value's computation where it is written: the compiler otherwise sinks the popcounts of a member slot behind the branches of the
+// later events and carries the slot's three sets along until then (48 more registers at two words per lane)
+SLIDE_HD void slide_pin(uint32_t &x) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    asm volatile("" : "+v"(x));
+#else
+    (void)x;
+#endif
+}
+
 // 5-bit bit-sliced counters (k <= 31 columns): c += up - down for two disjoint one-bit planes given as (changed, direction):
 // x = rows that change, dir = rows that go UP among them (rows of x outside dir go down).  10 instructions per word.
 struct SlideCount { uint32_t b0, b1, b2, b3, b4; };
@@ -208,7 +218,7 @@ SLIDE_HD void slide_item(Env &env, const SlideArgs &A, const typename Env::Rec &
             // DF |= d & (T | strict), with the strict flag of the event as an all-ones / all-zeros scalar — no select, no branch
             // (most events are at no strict position: a uniform branch keeps their two masks and two ORs per word out of the way)
 #ifndef SLIDE_WALK_BRANCH
-#define SLIDE_WALK_BRANCH 0
+#define SLIDE_WALK_BRANCH 2
 #endif
             if (SLIDE_WALK_BRANCH == 2) {
                 // the count-based update for every event; an event at a strict position (the minority: a uniform branch) puts its rows out
@@ -267,6 +277,7 @@ SLIDE_HD void slide_item(Env &env, const SlideArgs &A, const typename Env::Rec &
         accPF[s] = nP | (nF << 16);
         if (s & 1) accR[s >> 1] |= nR << 16;
         else accR[s >> 1] = nR;
+        if (SLIDE_WALK_BRANCH) { slide_pin(accPF[s]); slide_pin(accR[s >> 1]); }
     }
 }
 
