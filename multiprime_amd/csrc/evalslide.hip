@@ -58,6 +58,17 @@ struct DevEnv {
 
     __device__ __forceinline__ DevEnv(const SlideKernArgs &k) : K(k) {}
     // phase stamps of the experiment build-in (one lane per workgroup; a null pointer in every other run: one scalar compare)
+    // issue priority by progress through the band (0 = a quarter or more still to do ... ): the SIMD issues its OLDEST wave first, so the
+    // first workgroup of a CU runs ahead and its last one finishes alone, with nobody to fill the stalls of its own loads (tools/slide_stamps.py:
+    // 84 / 103 / 126 / 148 us).  A wave that is ahead steps down, the ones behind catch up, and a CU's workgroups end together.
+    __device__ __forceinline__ void progress(int quarter) const {
+#ifndef SLIDE_NO_PRIO
+        if (quarter <= 0) __builtin_amdgcn_s_setprio(3);
+        else if (quarter == 1) __builtin_amdgcn_s_setprio(2);
+        else if (quarter == 2) __builtin_amdgcn_s_setprio(1);
+        else __builtin_amdgcn_s_setprio(0);
+#endif
+    }
     __device__ __forceinline__ void stamp(int i) const {
         if (K.stamps && threadIdx.x == 0) K.stamps[(size_t)blockIdx.x * 8 + i] = wall_clock64();
     }
@@ -206,6 +217,10 @@ __global__ __launch_bounds__(kBlock, GW == 4 ? 1 : SLIDE_MIN_WAVES) void eval_sl
         // tail); deeper ones keep the units of 8 words per lane — a third of the waves, and the tail hides behind the sliding workgroups
         // that finish last (10^6 rows: 0.165 ms per step with them, 0.176 with three one-word units per window)
         const unsigned pb = blockIdx.x - (unsigned)K.n_slide_blocks, wv = threadIdx.x >> 6;
+#ifndef SLIDE_PATCH_PRIO
+#define SLIDE_PATCH_PRIO 3
+#endif
+        __builtin_amdgcn_s_setprio(SLIDE_PATCH_PRIO);                  // short and late: as the youngest waves of a busy CU they would wait for everybody
         if (K.patch_words == 1) {
             const bool negative = (int)pb >= K.chain.patch.n_blocks;
             const unsigned unit = (pb - (negative ? (unsigned)K.chain.patch.n_blocks : 0u)) * (kBlock / 64) + wv;

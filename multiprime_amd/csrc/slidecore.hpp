@@ -310,6 +310,7 @@ SLIDE_HD void slide_warm_chunk(Env &env, SlideCount (&cnt)[GW], int &slot, int j
 //   fetch(plane_row x row_scale, d)    the lane's words of column plane row `plane_row` (= column * 4 + base)
 //   valid_of(window x row_scale, v)    rows the column-plane pass may count for this window
 //   ring_zero(k); ring_write(slot, in); ring_read(slot, out)
+//   progress(quarter)                  quarters of the band behind the wave (a hint for the issue priority)
 //   commit(item_in_band, accPF, accR)  the lane's OUT counts of the item's 8 member slots (layout: slide_item)
 // Software pipeline: the column sliding in is requested two iterations ahead, an item's record two items ahead, its planes one item
 // ahead — a wave has few neighbours on its SIMD (the ring takes LDS), so it hides its own latencies.  The two register sets of each
@@ -398,12 +399,26 @@ SLIDE_HD void slide_band(Env &env, const SlideArgs &A, int band_index) {
                 for (int i = 0; i < GW; i++) sv[q][i] = 0u;
             }
         }
+        // items in pairs: inside the loop the two register sets have fixed roles (a loop over single items that picks the set by parity
+        // ends in one copy of the code that moves the freshly loaded set into place: 14 moves and a wait for the youngest load per item)
+        int ii = 0;
+        if (done & 1) { item(rec1, rec0, F1, F0, sv); ii = 1; }
 #pragma unroll 1
-        for (int ii = 0; ii < n_items; ii++) {
-            if (done & 1) item(rec1, rec0, F1, F0, sv);
-            else item(rec0, rec1, F0, F1, sv);
+        for (; ii + 1 < n_items; ii += 2) {
+            item(rec0, rec1, F0, F1, sv);
+            item(rec1, rec0, F1, F0, sv);
         }
+        if (ii < n_items) item(rec0, rec1, F0, F1, sv);
     };
+    // quarters of the band's windows behind the wave (the warm-up columns are nobody's progress: every wave has them).  Long bands only:
+    // with the 8-window bands of a 131072-row shard the workgroups of a CU ending together only delays the patch units that wait for
+    // their slots (tools/r05_prio.sh, profiles/r05_exp_prio.txt: 0.0334 against 0.0312 ms)
+#ifndef SLIDE_PRIO_MIN_WIN
+#define SLIDE_PRIO_MIN_WIN 32
+#endif
+    const int quarter_len = bd.n_win < SLIDE_PRIO_MIN_WIN ? 1 << 20 : ((bd.n_win + 3) / 4 > 2 ? (bd.n_win + 3) / 4 : 2);
+    int quarter = 0, next_quarter = k - 1 + quarter_len;
+    env.progress(0);
     uint32_t boA[GW], boB[GW];
     env.ring_read(slot, boA);                                           // zeros: the first k columns push nothing out
 #pragma unroll 1
@@ -413,11 +428,13 @@ SLIDE_HD void slide_band(Env &env, const SlideArgs &A, int band_index) {
         int j = base ? 0 : j0;                                          // (j0 is even and at most 30)
 #pragma unroll 1
         for (; j + 1 < n_here; j += 2) {
+            if (base + j >= next_quarter) { env.progress(++quarter); next_quarter += quarter_len; }
             iteration(bA, boA, boB, j);
             iteration(bB, boB, boA, j + 1);
         }
         if (j < n_here) iteration(bA, boA, boB, j);                     // (an odd tail ends the band)
     }
+    env.progress(3);
 }
 
 }  // namespace mp

@@ -48,6 +48,7 @@ struct HostEnv {
         for (int i = 0; i < GW; i++) v[i] = word0 + i < C.nw32 ? C.valid[(size_t)win * C.nw32 + (size_t)(word0 + i)] : 0u;
     }
     void stamp(int) const {}
+    void progress(int) const {}
     void ring_zero(int k) { for (int i = 0; i < k * GW; i++) ring[(size_t)i] = 0u; }
     void ring_write(int slot, const uint32_t (&in)[GW]) {
         for (int i = 0; i < GW; i++) ring[(size_t)slot * GW + i] = in[i];
