@@ -15,6 +15,12 @@
 #define SLIDE_HD inline
 #endif
 
+// the side of a wave-uniform branch that is laid out out of line: a taken branch costs a wave a refill of its instruction buffer, the
+// fall-through nothing — the usual case goes straight on
+#ifndef SLIDE_UNLIKELY
+#define SLIDE_UNLIKELY(x) __builtin_expect(!!(x), 0)
+#endif
+
 namespace mp {
 
 // D = f(a, b, c) bit by bit, f given by its truth table (bit (a << 2 | b << 1 | c) of LUT): one v_bitop3_b32 on gfx950
@@ -175,7 +181,7 @@ SLIDE_HD void slide_item(Env &env, const SlideArgs &A, const typename Env::Rec &
         if (q >= 4 && A.ns <= 4) break;
         const uint32_t sm = ((q < 4 ? sm_lo : sm_hi) >> (8 * (q & 3))) & 255u;
         const uint32_t nfF = ~(uint32_t)((int32_t)(A.fmask << (31 - q)) >> 31), nfR = ~(uint32_t)((int32_t)(A.rmask << (31 - q)) >> 31);
-        if (sm) {
+        if (SLIDE_UNLIKELY(sm != 0u)) {
             uint32_t x[GW];
 #pragma unroll
             for (int i = 0; i < GW; i++) x[i] = 0u;
@@ -232,7 +238,7 @@ SLIDE_HD void slide_item(Env &env, const SlideArgs &A, const typename Env::Rec &
                         DR[i] = bop<kSlOrAnd>(DR[i], d, T[LV >= 2 ? LV - 2 : 0][i]);
                     }
                 }
-                if (LV >= 2 && ((flags >> s) & 0x101u)) {
+                if (LV >= 2 && SLIDE_UNLIKELY(((flags >> s) & 0x101u) != 0u)) {
                     const uint32_t mF = (uint32_t)((int32_t)(flags << (31 - s)) >> 31), mR = (uint32_t)((int32_t)(flags << (23 - s)) >> 31);
 #pragma unroll
                     for (int i = 0; i < GW; i++) {
