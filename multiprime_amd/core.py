@@ -408,6 +408,14 @@ class NN_degenerate(object):
             keep = [i for i, d in enumerate(dimer_flag) if not d]                 # V20:749
             kept_codes = res["codes"][keep] if keep else np.zeros((0, k), np.uint8)
             self._lap("lists")
+            # the coverage bitsets of the output rows (a launch, the verdicts of the IUPAC rows on host threads, a patch launch: all native,
+            # no interpreter lock held) run beside the Tm / Information columns and the TSV — the output rows are known from here on.
+            # One process only, and only when nothing else of this thread touches the context meanwhile (the Python side-file builder does).
+            bitsets = None
+            if self.write_bitsets or self.keep_bitsets:
+                out_wins = np.asarray([wins[i] for i in keep], np.int32)
+                out_pos = [p0 + wins[i] for i in keep]
+                bitsets = _Beside(self._resident_bitsets, out_wins, kept_codes, out_pos, beside=self.comm is None and side is None)
             tm_all = dict(zip(keep, batchfilters.tm_of_primers(kept_codes)))
             self._lap("tm_of_primers")
             info_all = dict(zip(keep, batchfilters.information_of_primers(kept_codes, self.GC, self.distance)))
@@ -422,16 +430,18 @@ class NN_degenerate(object):
                     non_cov_out[pos], gap_out[pos] = side(wins[i], primer)
             self._lap("rows_out")
             self.stats["finish_s"] = time.time() - t0
-            if self.write_bitsets or self.keep_bitsets:
-                t0 = time.time()
-                self._resident_bitsets(rows_out)
+            if bitsets is not None and (self.write_json or self.write_bitsets):
+                bitsets.join()                               # the side files and the bitset file read the context
                 if self.write_bitsets:
+                    t0 = time.time()
                     self._write_bitsets(rows_out)
-                self.stats["bitsets_s"] = time.time() - t0
+                    self.stats["bitsets_s"] += time.time() - t0
         if self.comm is None or self.comm.rank == 0:
             t0 = time.time()
             self._write(rows_out, non_cov_out, gap_out)
             self.stats["write_s"] = time.time() - t0
+        if plan is not None and bitsets is not None:
+            bitsets.join()
         self.stats["run_s"] = time.time() - t_run
         self.stats["n_windows"] = self.n_windows
         self.stats["n_rows"] = len(rows_out)
@@ -516,22 +526,19 @@ class NN_degenerate(object):
 
         return build
 
-    def _resident_bitsets(self, rows_out):
+    def _resident_bitsets(self, wins, codes, positions):
         """Per output window, which sequences a forward / reverse primer there does NOT reach — exactly the union the
         pairing stage takes of gap_seq_id and non_coverage_seq_id (get_multiPrime_V8.py:560-567) — as bits, one per
         sequence, computed by one mp_eval_masks_resident launch and LEFT ON THE DEVICE (mask i = output row i);
         the rows whose window held an IUPAC code are decided here on the host and patched in (mp_masks_set_bits)."""
         k, v = self.primer_length, self.variation
-        p0 = int(self.start_position)
-        n_out = len(rows_out)
-        wins = np.asarray([int(r[0]) - p0 for r in rows_out], np.int32)
-        codes = (iupac.MASK_LUT[np.frombuffer("".join(r[3] for r in rows_out).encode(), np.uint8)].reshape(n_out, k)
-                 if n_out else np.zeros((0, k), np.uint8))
-        t0 = time.time()
+        n_out = len(positions)
+        codes = np.ascontiguousarray(codes, np.uint8).reshape(n_out, k)      # the output primers as 4-bit base sets (what MASK_LUT gives of their strings)
+        t_all = t0 = time.time()
         self.ctx.eval_masks_resident(wins, codes, self._sF, self._sR)
         self.stats["bitsets_masks_s"] = time.time() - t0
-        self._lap("bitsets: codes + eval_masks_resident")
-        self.mask_index = {int(r[0]): i for i, r in enumerate(rows_out)}
+        self._lap("bitsets: eval_masks_resident")
+        self.mask_index = {int(pos): i for i, pos in enumerate(positions)}
         # rows whose window held an IUPAC code: every expansion must be reached (V20:701-707 puts the id under each
         # expansion's k-mer), gap-type ones are in gap_seq_id.  Vectorised over all (exception, expansion) pairs.
         ex_w, x_row, ex_codes = self._exc
@@ -555,6 +562,7 @@ class NN_degenerate(object):
                 self.ctx.masks_set_bits(np.repeat(mask_i, 2), np.repeat(r_loc, 2), np.tile(np.array([0, 1], np.uint8), n_x),
                                         bad.reshape(-1).astype(np.uint8))
                 self._lap("bitsets: masks_set_bits")
+        self.stats["bitsets_s"] = time.time() - t_all
 
     def _write_bitsets(self, rows_out):
         """{out}.coverage_bitsets.npz: the resident masks fetched (and, with row shards, gathered bit by bit) into a file —
@@ -617,6 +625,34 @@ class NN_degenerate(object):
                 _dump_side_file(non_cov_out, fj, True)
             with open(self.outfile + ".gap_seq_id_json", "w") as fg:               # V20:1175-1176
                 _dump_side_file(gap_out, fg, False)
+
+
+class _Beside:
+    """fn(*args) on a helper thread (beside=True) or at once; join() waits and hands an exception of the helper to the caller."""
+
+    def __init__(self, fn, *args, beside=True):
+        self._error = None
+        self._thread = None
+        if not beside:
+            fn(*args)
+            return
+
+        def main():
+            try:
+                fn(*args)
+            except BaseException as e:          # noqa: BLE001 — re-raised on the calling thread
+                self._error = e
+
+        self._thread = threading.Thread(target=main)
+        self._thread.start()
+
+    def join(self):
+        if self._thread is not None:
+            self._thread.join()
+            self._thread = None
+        if self._error is not None:
+            e, self._error = self._error, None
+            raise e
 
 
 def bitset_ids(z):

@@ -135,6 +135,55 @@ void free_msa(mp_ctx *c) {
 
 }  // namespace mp
 
+namespace mp {
+
+constexpr size_t kPoolBlocks = 96, kPoolBytes = (size_t)3 << 30, kPoolBlockMax = (size_t)1 << 30;
+
+static bool pool_enabled(mp_ctx *c) {
+    if (c->pool_on < 0) {
+        const char *e = getenv("MP_DEVICE_POOL");
+        c->pool_on = e && atoi(e) == 0 ? 0 : 1;
+    }
+    return c->pool_on == 1;
+}
+
+void *pool_take(mp_ctx *c, size_t bytes) {
+    std::lock_guard<std::mutex> g(c->pool_mu);
+    if (!pool_enabled(c)) return nullptr;
+    for (size_t i = c->pool.size(); i-- > 0;)               // the youngest block of the size: the likeliest to be in a cache still
+        if (c->pool[i].bytes == bytes) {
+            void *p = c->pool[i].p;
+            c->pool.erase(c->pool.begin() + (long)i);
+            c->pool_bytes -= bytes;
+            c->pool_hits++;
+            return p;
+        }
+    c->pool_misses++;
+    return nullptr;
+}
+
+bool pool_give(mp_ctx *c, void *p, size_t bytes) {
+    std::lock_guard<std::mutex> g(c->pool_mu);
+    if (!pool_enabled(c) || bytes > kPoolBlockMax) return false;
+    while (!c->pool.empty() && (c->pool.size() >= kPoolBlocks || c->pool_bytes + bytes > kPoolBytes)) {
+        (void)hipFree(c->pool.front().p);
+        c->pool_bytes -= c->pool.front().bytes;
+        c->pool.erase(c->pool.begin());
+    }
+    c->pool.push_back({p, bytes});
+    c->pool_bytes += bytes;
+    return true;
+}
+
+void pool_drain(mp_ctx *c) {
+    std::lock_guard<std::mutex> g(c->pool_mu);
+    for (auto &b : c->pool) (void)hipFree(b.p);
+    c->pool.clear();
+    c->pool_bytes = 0;
+}
+
+}  // namespace mp
+
 using namespace mp;
 
 // Copies between the device and ordinary (pageable) host memory: from a minimum size on, the HIP runtime page-locks the user's
@@ -179,17 +228,27 @@ void mp_destroy(mp_ctx *c) {
     free_comm(c);
     free_msa(c);
     dev_free(c, &c->tmp_out, (size_t)c->tmp_out_n);
+    dev_free(c, &c->stats_buf, c->stats_buf_n);
+    if (getenv("MP_TRACE")) fprintf(stderr, "[mprime] device blocks: %lld reused, %lld from the runtime, %zu waiting (%.1f MB)\n", c->pool_hits, c->pool_misses,
+                                    c->pool.size(), c->pool_bytes / 1048576.0);
     if (c->h_stage_pinned) (void)hipHostUnregister(c->h_stage);
     host_unmap(c->h_stage, c->h_stage_bytes);
     dev_free(c, &c->dm_loss, (size_t)(MP_DIMER_MAX_LEN + 1) * (MP_DIMER_MAX_LEN + 1) * 64);
     dev_free(c, &c->dm_dg, (size_t)(16 + 32 + MP_DIMER_MAX_LEN + 1 + 1));
     for (auto &p : c->ev_busy) { (void)hipEventDestroy(p.first); (void)hipEventDestroy(p.second); }
     for (auto &p : c->ev_free) { (void)hipEventDestroy(p.first); (void)hipEventDestroy(p.second); }
+    pool_drain(c);                                       // (last: the frees above went through the pool)
     delete c;
 }
 
 int mp_set_stream(mp_ctx *c, void *s) {
     if (!c) return MP_ERR_ARG;
+    if (c->stream != (hipStream_t)s) {
+        // device blocks change hands between stages without a wait (common.hpp: the pool) because everything is ordered on ONE stream:
+        // what the old stream still has in flight is finished before the new one takes over
+        HIPCK(c, hipSetDevice(c->dev));
+        HIPCK(c, hipStreamSynchronize(c->stream));
+    }
     c->stream = (hipStream_t)s;
     return MP_OK;
 }

@@ -27,6 +27,7 @@
 #include <cstring>
 #include <numeric>
 #include <chrono>
+#include <mutex>
 #include <vector>
 
 namespace mp {
@@ -204,6 +205,14 @@ struct mp_ctx {
     uint64_t sF = 0, sR = 0;
     unsigned long long *tmp_out = nullptr;
     int tmp_out_n = 0;
+    struct PoolBlock { void *p; size_t bytes; };
+    std::vector<PoolBlock> pool;                 // released device blocks, oldest first (pool_take / pool_give, api.hip)
+    size_t pool_bytes = 0;
+    long long pool_hits = 0, pool_misses = 0;
+    int pool_on = -1;                            // -1: MP_DEVICE_POOL not read yet
+    std::mutex pool_mu;
+    unsigned long long *stats_buf = nullptr;     // mp_window_stats: counters of the last call's size, kept (a hipMalloc + hipFree pair per call otherwise)
+    size_t stats_buf_n = 0;
     std::vector<std::pair<hipEvent_t, hipEvent_t>> ev_busy, ev_free;
     double ev_ms = 0;
     std::vector<float> ev_samples, ev_last;     // per-launch durations since the last reset / as of the last mp_eval_timing call
@@ -240,11 +249,31 @@ inline int fail(mp_ctx *c, int code, const char *fmt, ...) {
         if (e_ != hipSuccess) return fail((c), MP_ERR_DEVICE, "%s: %s", #call, hipGetErrorString(e_));  \
     } while (0)
 
+// Device blocks a stage has released wait in the context for the next request of exactly their size (api.hip): a core step allocates
+// and frees ~40 blocks, hipMalloc costs 20-100 us and hipFree waits for the device on top — and a worker that runs one alignment after
+// the other (or a bench that repeats one) asks for the same sizes again.  Everything the library launches is ordered on the context's
+// stream or synchronised before a block is released, so a block can change hands without the wait hipFree implied.  At most
+// kPoolBlocks blocks / kPoolBytes bytes wait (the oldest go back to the runtime first); mp_destroy and a failed hipMalloc empty the
+// pool; MP_DEVICE_POOL=0 switches it off.
+void *pool_take(mp_ctx *c, size_t bytes);               // a waiting block of exactly `bytes`, or null
+bool pool_give(mp_ctx *c, void *p, size_t bytes);        // false: not taken (the caller frees it)
+void pool_drain(mp_ctx *c);
+
 template <typename T>
 int dev_alloc(mp_ctx *c, T **p, size_t n) {
     *p = nullptr;
     if (n == 0) n = 1;
+    if (void *q = pool_take(c, n * sizeof(T))) {
+        *p = (T *)q;
+        c->bytes += (int64_t)(n * sizeof(T));
+        return MP_OK;
+    }
     hipError_t e = hipMalloc((void **)p, n * sizeof(T));
+    if (e != hipSuccess) {                       // (what waits in the pool may be what is missing)
+        (void)hipGetLastError();
+        pool_drain(c);
+        e = hipMalloc((void **)p, n * sizeof(T));
+    }
     if (e != hipSuccess) return fail(c, MP_ERR_NOMEM, "hipMalloc(%zu bytes): %s", n * sizeof(T), hipGetErrorString(e));
     c->bytes += (int64_t)(n * sizeof(T));
     return MP_OK;
@@ -253,8 +282,9 @@ int dev_alloc(mp_ctx *c, T **p, size_t n) {
 template <typename T>
 void dev_free(mp_ctx *c, T **p, size_t n) {
     if (*p) {
-        (void)hipFree(*p);
-        c->bytes -= (int64_t)((n ? n : 1) * sizeof(T));
+        const size_t bytes = (n ? n : 1) * sizeof(T);
+        if (!pool_give(c, (void *)*p, bytes)) (void)hipFree(*p);
+        c->bytes -= (int64_t)bytes;
         *p = nullptr;
     }
 }

@@ -1418,9 +1418,14 @@ int mp_window_stats(mp_ctx *c, int64_t *freq, int64_t *nn) {
     HIPCK(c, hipSetDevice(c->dev));
     const size_t W = (size_t)c->n_win, k = (size_t)c->k;
     const size_t n_f = W * 4 * k, n_t = W * (k - 1) * 16;
-    unsigned long long *d = nullptr;
     int rc;
-    if ((rc = dev_alloc(c, &d, n_f + n_t))) return rc;
+    if (c->stats_buf_n < n_f + n_t) {
+        dev_free(c, &c->stats_buf, c->stats_buf_n);
+        c->stats_buf_n = 0;
+        if ((rc = dev_alloc(c, &c->stats_buf, n_f + n_t))) return rc;
+        c->stats_buf_n = n_f + n_t;
+    }
+    unsigned long long *d = c->stats_buf;
     HIPCK(c, hipMemsetAsync(d, 0, sizeof(unsigned long long) * (n_f + n_t), c->stream));
     const int nw = c->n_pad / 64;
     // words per thread: 4 from 32768 rows up (8: 0.64 ms against 0.34 at 131072 x 1000 — half the waves, 2: 0.36)
@@ -1432,7 +1437,7 @@ int mp_window_stats(mp_ctx *c, int64_t *freq, int64_t *nn) {
     const int bands = m.ny_pad >= 8 ? 1 : 8 / m.ny_pad;
     m.per_band = (c->n_win + bands - 1) / bands;
     const unsigned grid = m.ny_pad >= 8 ? (unsigned)((size_t)c->n_win * m.ny_pad) : (unsigned)(8 * (size_t)m.per_band);
-    if ((rc = ensure_patch_planes(c))) { dev_free(c, &d, n_f + n_t); return rc; }
+    if ((rc = ensure_patch_planes(c))) return rc;
     StatsArgs sa{c->cols, c->excl, nw, c->p0, c->k, c->v, m, d, d + n_f, patch_args(c, GW, c->n_win, kBlock)};
     const dim3 full(grid + (unsigned)sa.patch.n_blocks);
     if (GW == 4) hipLaunchKernelGGL(window_stats_kernel<4>, full, dim3(kBlock), 0, c->stream, sa);
@@ -1442,7 +1447,6 @@ int mp_window_stats(mp_ctx *c, int64_t *freq, int64_t *nn) {
     HIPCK(c, hipMemcpyAsync(freq, d, sizeof(int64_t) * n_f, hipMemcpyDeviceToHost, c->stream));
     HIPCK(c, hipMemcpyAsync(nn, d + n_f, sizeof(int64_t) * n_t, hipMemcpyDeviceToHost, c->stream));
     HIPCK(c, hipStreamSynchronize(c->stream));
-    dev_free(c, &d, n_f + n_t);
     return MP_OK;
 }
 
