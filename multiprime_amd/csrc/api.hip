@@ -6,6 +6,7 @@
 #include <vector>
 
 #include "common.hpp"
+#include "workers.hpp"
 
 namespace mp {
 
@@ -59,10 +60,7 @@ void prefault_host(void *p, size_t bytes) {
         for (size_t o = (lo + kPage - 1) / kPage * kPage; o < hi; o += kPage) *reinterpret_cast<volatile uint8_t *>(b + o) = 0;
         if (lo < hi) *reinterpret_cast<volatile uint8_t *>(b + lo) = 0;
     };
-    std::vector<std::thread> th;
-    for (size_t t = 1; t < n_thr; t++) th.emplace_back(touch, t);
-    touch(0);
-    for (auto &x : th) x.join();
+    mp::run_on_threads((int)n_thr, [&](int t) { touch((size_t)t); });
 }
 
 void free_eval(mp_ctx *c) {

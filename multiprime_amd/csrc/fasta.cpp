@@ -5,6 +5,7 @@
 // the ids in first-appearance order and makes a repeated id continue its first record (defaultdict(str)).
 // The per-character mapping of V20:453 is NOT done here — that is device work (pack_kernel, mp_load_msa).
 #include "../../include/mprime.h"
+#include "workers.hpp"
 #include "../../include/mprime_host.h"
 
 #include <fcntl.h>
@@ -200,9 +201,7 @@ int parse(mp_fasta *f) {
     Trace tr;
     if (T == 1) scan_chunk(b, n, 0, n, ev[0]);
     else {
-        std::vector<std::thread> th;
-        for (int t = 0; t < T; t++) th.emplace_back([&, t]() { scan_chunk(b, n, cut[(size_t)t], cut[(size_t)t + 1], ev[(size_t)t]); });
-        for (auto &x : th) x.join();
+        mp::run_on_threads(T, [&](int t) { scan_chunk(b, n, cut[(size_t)t], cut[(size_t)t + 1], ev[(size_t)t]); });
     }
     tr.lap("scan");
     // serial join: ids in first-appearance order, a repeated id continues its first record
@@ -361,9 +360,7 @@ int mp_fasta_parse_file(const char *path, int32_t n_threads, mp_fasta **out) {
         };
         if (T == 1) rd(0);
         else {
-            std::vector<std::thread> th;
-            for (int t = 0; t < T; t++) th.emplace_back(rd, t);
-            for (auto &x : th) x.join();
+            mp::run_on_threads(T, rd);
         }
         for (int x : bad) if (x) { close(fd); return ffail(f, MP_ERR_ARG, "%s: short read", path); }
     }
@@ -423,9 +420,7 @@ int mp_file_count_newlines(const char *path, int32_t n_threads, int64_t *count) 
     };
     if (T == 1) run(0);
     else {
-        std::vector<std::thread> th;
-        for (int t = 0; t < T; t++) th.emplace_back(run, t);
-        for (auto &x : th) x.join();
+        mp::run_on_threads(T, run);
     }
     close(fd);
     for (int x : bad) if (x) return MP_ERR_ARG;
@@ -460,9 +455,7 @@ int mp_fasta_rows(const mp_fasta *f, uint8_t *data, int64_t *row_off) {
     };
     if (T == 1) copy(0);
     else {
-        std::vector<std::thread> th;
-        for (int t = 0; t < T; t++) th.emplace_back(copy, t);
-        for (auto &x : th) x.join();
+        mp::run_on_threads(T, copy);
     }
     return MP_OK;
 }

@@ -34,6 +34,7 @@
 #define mp_plan_write_side_files_part mp_plan_write_side_files_part_w64
 #endif
 #include "../../include/mprime.h"
+#include "workers.hpp"
 #include "../../include/mprime_host.h"
 #include "planstream.hpp"
 
@@ -892,9 +893,7 @@ static int plan_create_body(mp_plan *p, const EntryInput &E, int64_t n_exc, cons
     };
     if (n_thr <= 1) worker();
     else {
-        std::vector<std::thread> th;
-        for (int t = 0; t < n_thr; t++) th.emplace_back(worker);
-        for (auto &t : th) t.join();
+        mp::run_on_threads(n_thr, [&](int) { worker(); });
     }
     if (failed.load()) return failed.load();
     if (getenv("MP_TRACE"))
@@ -1048,9 +1047,7 @@ int mp_plan_finish(mp_plan *p, const int64_t *ev) {
     const int n_thr = std::min(8, resolve_threads(p->P.n_threads, (int64_t)p->planned.size() / 64));      // (a thread costs ~30 us to start)
     if (n_thr <= 1) work();
     else {
-        std::vector<std::thread> th;
-        for (int t = 0; t < n_thr; t++) th.emplace_back(work);
-        for (auto &t : th) t.join();
+        mp::run_on_threads(n_thr, [&](int) { work(); });
     }
     if (bad_at.load() >= 0) {
         const int32_t w = p->planned[(size_t)bad_at.load()];
@@ -1138,9 +1135,7 @@ template <typename Body>
 static void over_kmers(int64_t n, Body &&body) {
     const int n_thr = n >= 8192 ? std::min(16, resolve_threads(0, n / 4096)) : 1;
     if (n_thr <= 1) { body((int64_t)0, n); return; }
-    std::vector<std::thread> th;
-    for (int t = 0; t < n_thr; t++) th.emplace_back([&, t] { body(n * t / n_thr, n * (t + 1) / n_thr); });
-    for (auto &x : th) x.join();
+    mp::run_on_threads(n_thr, [&](int t) { body(n * t / n_thr, n * (t + 1) / n_thr); });
 }
 
 static int expansion_offsets(int32_t k, int64_t n, const uint8_t *codes, std::vector<int64_t> &first) {
@@ -1486,9 +1481,7 @@ extern "C" int mp_plan_write_side_files_part(const mp_plan *p, int32_t n_out, co
     };
     if (n_threads == 1) format_run(0);
     else {
-        std::vector<std::thread> th;
-        for (int t = 0; t < n_threads; t++) th.emplace_back(format_run, t);
-        for (auto &x : th) x.join();
+        mp::run_on_threads(n_threads, format_run);
     }
     if (oom) { fclose(fn); fclose(fg); return pfail(pm, MP_ERR_NOMEM, "mp_plan_write_side_files: out of memory"); }
     // a continuation starts with the separator the previous part left out

@@ -11,6 +11,7 @@
 //   * statistics.mean over a primer's expansions is exact: the doubles are integers times one power of two, summed in 128 bits, and the
 //     one division is rounded to nearest-even like Python's int / int.
 #include "../../include/mprime.h"
+#include "workers.hpp"
 #include "../../include/mprime_host.h"
 
 #include <cmath>
@@ -238,9 +239,7 @@ int mp_exception_verdicts(int32_t k, int32_t v, int64_t n, const uint8_t *xc, co
     int n_thr = n >= 16384 ? (int)std::min<int64_t>(16, std::min<int64_t>((int64_t)std::max(1u, std::thread::hardware_concurrency()), n / 8192)) : 1;
     if (const char *e = getenv("MP_HOST_THREADS")) n_thr = std::max(1, std::min(n_thr, atoi(e)));
     if (n_thr <= 1) { body(0, n); return MP_OK; }
-    std::vector<std::thread> th;
-    for (int t = 0; t < n_thr; t++) th.emplace_back([&, t] { body(n * t / n_thr, n * (t + 1) / n_thr); });
-    for (auto &x : th) x.join();
+    mp::run_on_threads(n_thr, [&](int t) { body(n * t / n_thr, n * (t + 1) / n_thr); });
     return MP_OK;
 }
 

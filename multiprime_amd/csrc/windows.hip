@@ -3,6 +3,7 @@
 #include <type_traits>
 
 #include "common.hpp"
+#include "workers.hpp"
 #include <thread>
 #include "winwords.hpp"
 
@@ -308,13 +309,11 @@ int mp_build_windows(mp_ctx *c, int32_t p0, int32_t n_win, int32_t k, int32_t v,
             const int n_thr = cnt >= 16384 ? std::max(1, std::min({16, (int)std::thread::hardware_concurrency(), cnt / 8192})) : 1;
             if (n_thr <= 1) part(0, n_win);
             else {
-                std::vector<std::thread> th;
-                for (int t = 0; t < n_thr; t++) {            // window ranges of about equal record counts
+                mp::run_on_threads(n_thr, [&](int t) {            // window ranges of about equal record counts
                     const int w0 = (int)(std::lower_bound(first.begin(), first.end(), (int32_t)((long long)cnt * t / n_thr)) - first.begin());
                     const int w1 = t + 1 == n_thr ? n_win : (int)(std::lower_bound(first.begin(), first.end(), (int32_t)((long long)cnt * (t + 1) / n_thr)) - first.begin());
-                    th.emplace_back(part, std::min(w0, n_win), std::min(w1, n_win));
-                }
-                for (auto &x : th) x.join();
+                    part(std::min(w0, n_win), std::min(w1, n_win));
+                });
             }
             c->ex_host.swap(sorted);
         }
@@ -340,9 +339,7 @@ int mp_get_exceptions(mp_ctx *c, int32_t cap, int32_t *ew, int32_t *er, uint8_t 
     const int n_thr = n >= 16384 ? std::max(1, std::min({16, (int)std::thread::hardware_concurrency(), n / 8192})) : 1;
     if (n_thr <= 1) part(0, n);
     else {
-        std::vector<std::thread> th;
-        for (int t = 0; t < n_thr; t++) th.emplace_back(part, (int)((long long)n * t / n_thr), (int)((long long)n * (t + 1) / n_thr));
-        for (auto &x : th) x.join();
+        mp::run_on_threads(n_thr, [&](int t) { part((int)((long long)n * t / n_thr), (int)((long long)n * (t + 1) / n_thr)); });
     }
     return MP_OK;
 }
