@@ -812,11 +812,12 @@ static int plan_create_body(mp_plan *p, const EntryInput &E, int64_t n_exc, cons
     const word_t kmask = k == 64 ? ~0ull : ((1ull << k) - 1ull);
     const double max_exp = 1 << 22;            // expansions of one exception k-mer the host is willing to enumerate
     std::atomic<int> next{0}, failed{0};       // failed: 0 or the MP_ERR_* code of the first failure
-    // 32 threads by default; 64 from 8 M entries up (10^6 rows: planning done at 7.5 instead of 10.5 ms; at 131072 rows — 2.9 M entries —
-    // more than 32 only adds thread starts and contention: 4.8 ms with 32 or 48, 5.2 with 64, 7.0 with 128; tools/r05_threads.sh)
+    // 32 threads by default; 96 from 2 M entries up — the entries that reach the host once the device's entropy gate has kept the
+    // heaviest windows (10^6 rows: planning 4.3 ms with 32 threads, 3.0-3.7 with 64, 2.85 with 96; at 131072 rows — under 1 M entries —
+    // more than 32 gain nothing: profiles/r05_exp_threads2.txt, tools/r05_threads2.sh; the threads are kept, workers.hpp)
     int n_thr = resolve_threads(P.n_threads, W);
-    if (P.n_threads <= 0 && !getenv("MP_HOST_THREADS") && n_entries >= ((int64_t)8 << 20))
-        n_thr = (int)std::min<int64_t>(W, std::max(n_thr, std::min(64, (int)std::thread::hardware_concurrency())));
+    if (P.n_threads <= 0 && !getenv("MP_HOST_THREADS") && n_entries >= ((int64_t)2 << 20))
+        n_thr = (int)std::min<int64_t>(W, std::max(n_thr, std::min(96, (int)std::thread::hardware_concurrency())));
     std::atomic<long long> us_sights{0}, us_merge{0}, us_sort{0}, us_rest{0};      // MP_TRACE: thread time per phase
     auto work = [&]() {
         Scratch scratch;
