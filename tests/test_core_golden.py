@@ -78,6 +78,36 @@ def test_hip_path_matches_reference(name, hip_lib, tmp_path):
     check_outputs(name, out)
 
 
+def test_one_context_for_many_alignments_on_the_checker(oracle_lib, tmp_path):
+    """The same control flow (a context kept across alignments of different shapes) without a GPU."""
+    ctx = None
+    for name in ("msa1000_k18_d64", "syn_iupac", "msa1000_k18_d64", "syn_edge"):
+        d = tmp_path / name
+        d.mkdir(exist_ok=True)
+        app, out = run_fixture(name, oracle_lib, d, context=ctx)
+        ctx = app.ctx
+        check_outputs(name, out)
+    ctx.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("pool", ["1", "0"])
+def test_one_context_for_many_alignments(pool, hip_lib, tmp_path, monkeypatch):
+    """A --batch worker keeps ONE context across alignments: every stage then receives device blocks a stage of the alignment before
+    released (the context's pool, csrc/common.hpp — no hipFree in between, so nothing waits for the device either).  Alignments of different
+    shapes one after the other, twice round, each with the reference's bytes; MP_DEVICE_POOL=0 beside it."""
+    monkeypatch.setenv("MP_DEVICE_POOL", pool)
+    ctx = None
+    for rnd in range(2):
+        for name in ("msa1000_k18_d64", "syn_iupac", "cluster0_v2", "msa1000_k18_d64", "syn_edge", "ivc_v2"):
+            d = tmp_path / ("%d_%s" % (rnd, name))
+            d.mkdir(exist_ok=True)
+            app, out = run_fixture(name, hip_lib, d, context=ctx)
+            ctx = app.ctx
+            check_outputs(name, out)
+    ctx.close()
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize("name", ["syn_iupac", "syn_ragged", "syn_edge", "ivc_v2", "msa1000_k18_d64", "msa1000_k22_d64", "msa1000_k31_d64", "cluster0_v2", "testfa",
                                   "syn_ragged_k40", "ivc_k45_v2", "syn_edge_k63"])
