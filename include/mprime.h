@@ -64,7 +64,10 @@ const char *mp_last_error(const mp_ctx *ctx);
 const char *mp_backend_name(void);
 /* Launch every kernel of this context on `hip_stream` (a hipStream_t; NULL = the default
  * stream).  bench.py passes torch's current stream so that torch.cuda events and RCCL
- * collectives order with the kernels. */
+ * collectives order with the kernels.  A context works on ONE stream at a time: its stages hand
+ * device blocks to each other without waiting for the device (a released block waits in the
+ * context for the next request of its size), which is safe because everything is ordered on that
+ * stream — so a change of stream first waits for what the old one still has in flight. */
 int mp_set_stream(mp_ctx *ctx, void *hip_stream);
 
 /* (1) alignment -> device ----------------------------------------------------------------- */
