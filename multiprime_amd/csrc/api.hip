@@ -173,6 +173,22 @@ bool pool_give(mp_ctx *c, void *p, size_t bytes) {
     return true;
 }
 
+void pool_note(mp_ctx *c, void *p, size_t bytes) {
+    std::lock_guard<std::mutex> g(c->pool_mu);
+    c->pool_live[p] = bytes;
+}
+
+size_t pool_forget(mp_ctx *c, void *p, size_t claimed) {
+    std::lock_guard<std::mutex> g(c->pool_mu);
+    auto it = c->pool_live.find(p);
+    if (it == c->pool_live.end()) return 0;
+    const size_t real = it->second;
+    c->pool_live.erase(it);
+    if (real != claimed && getenv("MP_TRACE"))
+        fprintf(stderr, "[mprime] dev_free: a block of %zu bytes released as %zu bytes\n", real, claimed);
+    return real;
+}
+
 void pool_drain(mp_ctx *c) {
     std::lock_guard<std::mutex> g(c->pool_mu);
     for (auto &b : c->pool) (void)hipFree(b.p);

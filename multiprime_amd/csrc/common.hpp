@@ -28,6 +28,7 @@
 #include <numeric>
 #include <chrono>
 #include <mutex>
+#include <unordered_map>
 #include <vector>
 
 namespace mp {
@@ -206,6 +207,7 @@ struct mp_ctx {
     unsigned long long *tmp_out = nullptr;
     int tmp_out_n = 0;
     struct PoolBlock { void *p; size_t bytes; };
+    std::unordered_map<void *, size_t> pool_live; // blocks of dev_alloc that are out: the size they were requested with
     std::vector<PoolBlock> pool;                 // released device blocks, oldest first (pool_take / pool_give, api.hip)
     size_t pool_bytes = 0;
     long long pool_hits = 0, pool_misses = 0;
@@ -258,6 +260,10 @@ inline int fail(mp_ctx *c, int code, const char *fmt, ...) {
 void *pool_take(mp_ctx *c, size_t bytes);               // a waiting block of exactly `bytes`, or null
 bool pool_give(mp_ctx *c, void *p, size_t bytes);        // false: not taken (the caller frees it)
 void pool_drain(mp_ctx *c);
+// the size a block was REQUESTED with is kept by the context (a block goes back into the pool under that size, whatever count the
+// releasing call site passes: a site that got its count wrong used to skew mp_device_bytes — with the pool it would hand out a short block)
+void pool_note(mp_ctx *c, void *p, size_t bytes);
+size_t pool_forget(mp_ctx *c, void *p, size_t claimed);  // the recorded size (0: not a block of dev_alloc); a differing claim is reported under MP_TRACE
 
 template <typename T>
 int dev_alloc(mp_ctx *c, T **p, size_t n) {
@@ -265,6 +271,7 @@ int dev_alloc(mp_ctx *c, T **p, size_t n) {
     if (n == 0) n = 1;
     if (void *q = pool_take(c, n * sizeof(T))) {
         *p = (T *)q;
+        pool_note(c, q, n * sizeof(T));
         c->bytes += (int64_t)(n * sizeof(T));
         return MP_OK;
     }
@@ -275,6 +282,7 @@ int dev_alloc(mp_ctx *c, T **p, size_t n) {
         e = hipMalloc((void **)p, n * sizeof(T));
     }
     if (e != hipSuccess) return fail(c, MP_ERR_NOMEM, "hipMalloc(%zu bytes): %s", n * sizeof(T), hipGetErrorString(e));
+    pool_note(c, (void *)*p, n * sizeof(T));
     c->bytes += (int64_t)(n * sizeof(T));
     return MP_OK;
 }
@@ -282,9 +290,9 @@ int dev_alloc(mp_ctx *c, T **p, size_t n) {
 template <typename T>
 void dev_free(mp_ctx *c, T **p, size_t n) {
     if (*p) {
-        const size_t bytes = (n ? n : 1) * sizeof(T);
-        if (!pool_give(c, (void *)*p, bytes)) (void)hipFree(*p);
-        c->bytes -= (int64_t)bytes;
+        const size_t claimed = (n ? n : 1) * sizeof(T), real = pool_forget(c, (void *)*p, claimed);
+        if (!real || !pool_give(c, (void *)*p, real)) (void)hipFree(*p);
+        c->bytes -= (int64_t)(real ? real : claimed);
         *p = nullptr;
     }
 }

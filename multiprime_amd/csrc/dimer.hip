@@ -821,7 +821,13 @@ struct Scratch {
     }
     ~Scratch() {
         for (auto &b : bufs)
-            if (*b.first) { (void)hipFree(*b.first); c->bytes -= (int64_t)b.second; *b.first = nullptr; }
+            if (*b.first) {                          // (dev_free without the type)
+                void *q = *b.first;
+                const size_t real = pool_forget(c, q, b.second);
+                if (!real || !pool_give(c, q, real)) (void)hipFree(q);
+                c->bytes -= (int64_t)(real ? real : b.second);
+                *b.first = nullptr;
+            }
     }
 };
 
