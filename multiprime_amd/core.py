@@ -393,18 +393,26 @@ class NN_degenerate(object):
             # the 3'-end self-dimer test of every window's primer (dimer_check, V20:487-503) in ONE launch:
             # it is the ordered pair (x -> x) of the dimer scan with Loss >= 3 and the two-term deltaG
             self._lap("results + strings")
-            dimer_flag = self._self_dimers(res["codes"])
-            self._lap("self dimers")
+            # (the launch and its read-back on a helper thread — one process only: the call holds no interpreter lock — while this thread
+            # turns the result columns into lists)
+            dimer_out = []
+            dimers = _Beside(lambda: dimer_out.append(self._self_dimers(res["codes"])), beside=self.comm is None)
             p0 = int(self.start_position)
             wins = res["window"].tolist()
             cbit, tbit = res["cbit"].tolist(), res["tbit"].tolist()
             cov, f_mis, r_mis = res["cov"].tolist(), res["f_mis"].tolist(), res["r_mis"].tolist()
             nonsense, n_dege = res["nonsense"].tolist(), res["n_dege"].tolist()
+            # Tm (V20:849-852, 282-336) and the "Information" column (primer_pre_filter, V20:507-521, V20:911) of every primer at once,
+            # value for value what thermo.tm / filters.pre_filter give per primer — of ALL windows' primers, the few a self-dimer
+            # removes included: the numbers do not depend on the flags, and the flags are still on their way
+            tm_list = batchfilters.tm_of_primers(res["codes"])
+            info_list = batchfilters.information_of_primers(res["codes"], self.GC, self.distance)
+            dimers.join()
+            dimer_flag = dimer_out[0]
+            self._lap("self dimers || lists, Tm, Information")
             # JSON side files: written natively for a single process (mp_plan_write_side_files); row shards gather id lists per
             # output window and use the Python writer below
             side = self._side_file_builder() if self.write_json and not self._native_json else None
-            # Tm (V20:849-852, 282-336) and the "Information" column (primer_pre_filter, V20:507-521, V20:911) of every primer
-            # at once: numpy over the symbol-code matrix, value for value what thermo.tm / filters.pre_filter give per primer
             keep = [i for i, d in enumerate(dimer_flag) if not d]                 # V20:749
             kept_codes = res["codes"][keep] if keep else np.zeros((0, k), np.uint8)
             self._lap("lists")
@@ -416,14 +424,10 @@ class NN_degenerate(object):
                 out_wins = np.asarray([wins[i] for i in keep], np.int32)
                 out_pos = [p0 + wins[i] for i in keep]
                 bitsets = _Beside(self._resident_bitsets, out_wins, kept_codes, out_pos, beside=self.comm is None and side is None)
-            tm_all = dict(zip(keep, batchfilters.tm_of_primers(kept_codes)))
-            self._lap("tm_of_primers")
-            info_all = dict(zip(keep, batchfilters.information_of_primers(kept_codes, self.GC, self.distance)))
-            self._lap("information_of_primers")
             for i, primer in enumerate(primers):
                 if dimer_flag[i]:
                     continue
-                tm_avg, info = tm_all[i], info_all[i]
+                tm_avg, info = tm_list[i], info_list[i]
                 pos = p0 + wins[i]
                 rows_out.append([pos, cbit[i], tbit[i], primer, n_dege[i], nonsense[i], cov[i], f_mis[i], r_mis[i], tm_avg, info])
                 if side is not None:
