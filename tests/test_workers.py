@@ -85,3 +85,24 @@ def test_switch_off():
     env = dict(os.environ, MP_HOST_POOL="0")
     out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=300)
     assert out.returncode == 0 and "ok" in out.stdout, out.stderr
+
+
+def test_beside_hands_the_helpers_exception_to_the_caller():
+    """core._Beside (the core step's helper threads: coverage bitsets, self-dimer launch): join() re-raises on the calling thread."""
+    import pytest
+    from multiprime_amd.core import _Beside
+
+    def boom(x):
+        raise ValueError("from the helper: %d" % x)
+
+    for beside in (True,):
+        b = _Beside(boom, 7, beside=beside)
+        with pytest.raises(ValueError, match="from the helper: 7"):
+            b.join()
+        b.join()                                           # the error is handed over once
+    with pytest.raises(ValueError):
+        _Beside(boom, 7, beside=False)                       # not beside: raised where it happens
+    seen = []
+    ok = _Beside(seen.append, 3)
+    ok.join()
+    assert seen == [3]
