@@ -472,7 +472,10 @@ def main():
                 res["parity_checked"] = res["cpu_baseline"].get("parity_checked")
             if not a.no_variants:
                 # SURVEY 8d's micro-benchmark at the headline size: C = 1, unrelated C = 8, nested C = 64, each checked against the oracle
-                res["variants"] = run_variants(w, torch, dev, None, None, a.seed, blocks if blocks is not None and blocks.n == rows_per_gpu else None, cold=False)
+                try:
+                    res["variants"] = run_variants(w, torch, dev, None, None, a.seed, blocks if blocks is not None and blocks.n == rows_per_gpu else None, cold=False)
+                except Exception as e:          # noqa: BLE001 — a side measurement must not take the headline line with it
+                    res["variants"] = {"error": {"error": f"{type(e).__name__}: {e}"}}
                 if any(v.get("parity_checked") is False for v in res["variants"].values()):
                     res["parity_checked"] = False
             if blocks is not None:
@@ -490,17 +493,21 @@ def main():
         w.ctx = ctx = None
         w.rows = None
         torch.cuda.empty_cache()
-        res["weak_shard"] = weak_shard(lib, local, torch, dev, a, timed_region, every, not a.no_cpu)
+        try:
+            res["weak_shard"] = weak_shard(lib, local, torch, dev, a, timed_region, every, not a.no_cpu)
+        except Exception as e:                  # noqa: BLE001 — as above
+            res["weak_shard"] = {"error": f"{type(e).__name__}: {e}"}
         if res["weak_shard"].get("parity_checked") is False:
             res["parity_checked"] = False
         if "pipeline" in res and "pipeline" in res["weak_shard"]:
             res["pipeline"][f"rows_{SHARD_ROWS}"] = res["weak_shard"].pop("pipeline")
         # what row shards over 8 GPUs can reach at best: the whole workload's step over the shard's step (no collective counted)
-        res["projected_strong_scaling"] = {
-            "n_gpus": FULL_ROWS // SHARD_ROWS, "ceiling": res["ms_per_step"] / res["weak_shard"]["ms_per_step"],
-            "ms_per_step_one_gpu": res["ms_per_step"], "ms_per_step_shard": res["weak_shard"]["ms_per_step"],
-            "note": "ms_per_step of the whole workload on one GPU over ms_per_step of the 1/8 shard on one GPU, both measured in this run: the speed-up 8 GPUs "
-                    "reach if the all-reduce of the counters costs nothing (it is overlapped with the next step's kernel: dist.StepBuckets); north_star asks >= 6"}
+        if "ms_per_step" in res["weak_shard"]:
+            res["projected_strong_scaling"] = {
+                "n_gpus": FULL_ROWS // SHARD_ROWS, "ceiling": res["ms_per_step"] / res["weak_shard"]["ms_per_step"],
+                "ms_per_step_one_gpu": res["ms_per_step"], "ms_per_step_shard": res["weak_shard"]["ms_per_step"],
+                "note": "ms_per_step of the whole workload on one GPU over ms_per_step of the 1/8 shard on one GPU, both measured in this run: the speed-up 8 GPUs "
+                        "reach if the all-reduce of the counters costs nothing (it is overlapped with the next step's kernel: dist.StepBuckets); north_star asks >= 6"}
     if rank == 0 and world == 1 and any(isinstance(p, dict) and p.get("tsv_equal_oracle") is False for p in res.get("pipeline", {}).values()):
         res["parity_checked"] = False
     if rank == 0:
@@ -600,6 +607,14 @@ PIPELINE_FLAGS = dict(primer_length=18, coverage=0.8, number_of_dege_bases=4, sc
 
 
 def pipeline_block(lib, local, rows, a, reps=5):
+    """pipeline_block_unguarded, or {"error": ...}: a side measurement must not take the headline line with it."""
+    try:
+        return pipeline_block_unguarded(lib, local, rows, a, reps)
+    except (Exception, SystemExit) as e:          # noqa: BLE001 — reported in the line
+        return {"rows": int(rows.shape[0]), "cols": int(rows.shape[1]), "error": f"{type(e).__name__}: {e}"}
+
+
+def pipeline_block_unguarded(lib, local, rows, a, reps=5):
     """NN_degenerate(...).run() — the step the evaluation kernel belongs to — on the workload's own rows: median wall time of `reps`
     runs after one warm-up (each with a fresh context), the phase split of the median run, and the TSV against the checker's (SHA-256
     committed by tools/make_synth_golden.py: the checker takes minutes to hours per size on one core)."""
@@ -610,7 +625,11 @@ def pipeline_block(lib, local, rows, a, reps=5):
     for e in (load_json(os.path.join("..", "tests", "golden", "synth_pipeline.json")) or {}).get("entries", []):
         if (e["rows"], e["cols"], e["seed"]) == (n, L, a.seed):
             golden = e
-    td = tempfile.mkdtemp(prefix="mp_bench_", dir="/dev/shm" if os.path.isdir("/dev/shm") else None)
+    # the FASTA (rows x (cols + ~12) bytes: 1 GB at config 4) goes to memory-backed storage when that has room for it, else to the default
+    # temporary directory
+    need = int(n) * (int(L) + 16) * 2
+    shm = "/dev/shm" if os.path.isdir("/dev/shm") and shutil.disk_usage("/dev/shm").free > need else None
+    td = tempfile.mkdtemp(prefix="mp_bench_", dir=shm)
     try:
         fa, out = os.path.join(td, "syn.fa"), os.path.join(td, "out.tsv")
         with open(fa, "wb") as f:
