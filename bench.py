@@ -446,7 +446,7 @@ def main():
             "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
             "ms_per_step": elapsed / a.steps * 1e3,
             "higher_is_better": True, "scaling": "strong" if strong else "weak", "vs_baseline": None,
-            "dtype": "u32 bit-planes", "data": "synthetic",
+            "dtype": "u32", "data": "synthetic",
             "config": {"workload": f"{w.describe()} per GPU x {world} GPU(s) = {whole} (SURVEY 8d input 4; synthetic 1M x 1 kb, row shards)",
                        "rows_per_gpu": rows_per_gpu, "rows_total": world * rows_per_gpu, "cols": L, "k": k, "variation": a.v,
                        "candidates_per_window": C, "windows": w.W, "evals_per_step_per_gpu": w.evals, "iupac_extra_rows": w.n_extra,
@@ -511,12 +511,92 @@ def main():
     if rank == 0 and world == 1 and any(isinstance(p, dict) and p.get("tsv_equal_oracle") is False for p in res.get("pipeline", {}).values()):
         res["parity_checked"] = False
     if rank == 0:
-        print(json.dumps(res), flush=True)
+        emit(res)
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
     if rank == 0 and res.get("parity_checked") is False:
         raise SystemExit("bench.py: GPU counters differ from the CPU oracle's")
+
+
+HEADLINE_LIMIT = 4096        # bytes of the final stdout line: the driver keeps a tail of stdout and parses its last line
+
+
+def _sig(x, digits=6):
+    """Floats of the headline at `digits` significant digits (the detail file keeps full precision)."""
+    if isinstance(x, float):
+        return float(f"{x:.{digits}g}")
+    if isinstance(x, dict):
+        return {key: _sig(val, digits) for key, val in x.items()}
+    if isinstance(x, (list, tuple)):
+        return [_sig(val, digits) for val in x]
+    return x
+
+
+def headline(res):
+    """The ONE line the driver parses: the contract's keys, `roofline` and `cpu_baseline` of the headline kernel, the parity verdict and
+    the projected scaling ceiling — no notes, no tables, no nested side measurements (those go to bench_detail.json and to an
+    earlier, prefixed stdout line).  Always shorter than HEADLINE_LIMIT (tests/test_bench_line.py)."""
+    top = ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data",
+           "parity_checked", "ms_per_step_bucketed", "bucket")
+    out = {key: res[key] for key in top if key in res}
+    cfg = res.get("config", {})
+    out["config"] = {key: cfg[key] for key in ("workload", "rows_per_gpu", "rows_total", "cols", "k", "variation", "candidates_per_window", "windows",
+                                               "evals_per_step_per_gpu", "parallelism") if key in cfg}
+    out["config"]["workload"] = str(out["config"].get("workload", ""))[:240]
+    rf = res.get("roofline") or {}
+    # `bound` of the contract is the roofline `peak` belongs to (HBM; integer bit-mask work has no MFMA roofline); `limiter` is the
+    # largest of the measured fractions (valu / l2 / hbm), i.e. what actually binds the kernel
+    out["roofline"] = {"bound": "hbm", "achieved": rf.get("achieved"), "peak": rf.get("peak"), "unit": rf.get("unit"), "frac": rf.get("frac"),
+                       "traffic": rf.get("traffic"), "hbm_frac": rf.get("hbm_frac"), "over_fetch": rf.get("over_fetch"),
+                       "valu_frac": rf.get("valu_frac"), "l2_frac": rf.get("l2_frac"), "limiter": rf.get("bound"),
+                       "algorithmic_frac": rf.get("algorithmic_frac"), "compulsory_bytes": rf.get("compulsory_bytes"),
+                       "kernel": str(rf.get("kernel", "")).split(" (")[0], "kernel_ms": rf.get("kernel_ms"),
+                       "counters_stale": rf.get("counters_stale")}
+    cb = res.get("cpu_baseline")
+    if cb:
+        out["cpu_baseline"] = {"value": cb.get("value"), "unit": cb.get("unit"), "cores": cb.get("cores"), "kind": cb.get("kind"),
+                               "sample": str(cb.get("sample", ""))[:200], "parity_checked": cb.get("parity_checked")}
+        if isinstance(cb.get("one_core"), dict):
+            out["cpu_baseline"]["one_core_value"] = cb["one_core"].get("value")
+    ps = res.get("projected_strong_scaling")
+    if ps:
+        out["projected_strong_scaling"] = {key: ps[key] for key in ("n_gpus", "ceiling", "shape", "ms_per_step_one_gpu", "ms_per_step_shard") if key in ps}
+    pl = res.get("pipeline") or {}
+    runs = {key: {"run_ms": val.get("run_ms"), "construct_ms": val.get("construct_ms"), "tsv_equal_oracle": val.get("tsv_equal_oracle")}
+            for key, val in pl.items() if isinstance(val, dict) and "run_ms" in val}
+    if runs:
+        out["pipeline"] = runs
+    if "comm" in res:
+        out["comm"] = {key: res["comm"][key] for key in ("backend", "rccl_ranks_seen", "sum_of_ones") if key in res["comm"]}
+    if "step_time_ranks_ms" in res:
+        out["step_time_ranks_ms"] = res["step_time_ranks_ms"]
+    out["detail"] = "bench_detail.json"
+    out = _sig(out)
+    line = json.dumps(out, separators=(",", ":"))
+    for drop in ("pipeline", "comm", "step_time_ranks_ms", "projected_strong_scaling"):       # never reached with the fields above; the limit holds regardless
+        if len(line) < HEADLINE_LIMIT:
+            break
+        out.pop(drop, None)
+        line = json.dumps(out, separators=(",", ":"))
+    if len(line) >= HEADLINE_LIMIT:
+        raise SystemExit(f"bench.py: headline line of {len(line)} bytes")
+    return line
+
+
+def emit(res):
+    """Everything measured -> bench_detail.json beside this file (and gpurun_out/ when that exists) and ONE earlier stdout line prefixed
+    `bench_detail: ` (not a JSON line by itself); then the headline as the LAST stdout line."""
+    detail = json.dumps(res)
+    for d in (REPO, os.path.join(REPO, "gpurun_out")):
+        if os.path.isdir(d):
+            try:
+                with open(os.path.join(d, "bench_detail.json"), "w") as f:
+                    f.write(detail + "\n")
+            except OSError:
+                pass
+    print("bench_detail: " + detail, flush=True)
+    print(headline(res), flush=True)
 
 
 def weak_shard(lib, local, torch, dev, a, timed_region, every, with_cpu):
