@@ -132,9 +132,8 @@ class Library:
 
     def __init__(self, path: str | None = None):
         # Without an explicit path the library IS the product's backend: libmprime_hip.so, or another BUILD of it named by
-        # MPRIME_LIBRARY (a debug / sanitizer build).  Whatever it is, it must say mp_backend_name() == "hip": the drop-in commands
-        # never run on the ABI checker by accident of an environment variable.  Test infrastructure that wants the checker behind a
-        # command line (tests/test_cli_multirank.py) has to say so twice: MPRIME_LIBRARY=<checker> AND MPRIME_TEST_CHECKER_BACKEND=1.
+        # MPRIME_LIBRARY (a debug / sanitizer build).  Whatever it is, it must say mp_backend_name() == "hip": no environment variable
+        # can put the ABI checker behind a drop-in command (the CPU-only CLI tests patch this class from tests/checker_shim/).
         # Library(path) — what tests and tools do — loads what it is told to.
         implicit = path is None
         path = path or os.environ.get("MPRIME_LIBRARY") or HIP_LIB
@@ -150,7 +149,7 @@ class Library:
             fn.restype = res
             fn.argtypes = args
         self.backend = self.dll.mp_backend_name().decode()
-        if implicit and self.backend != "hip" and os.environ.get("MPRIME_TEST_CHECKER_BACKEND") != "1":
+        if implicit and self.backend != "hip":
             raise MprimeError(-2, f"{path} reports backend {self.backend!r}, not 'hip': the product runs on libmprime_hip.so only "
                                   "(MPRIME_LIBRARY may name another build of it, not the CPU checker)")
 

@@ -152,13 +152,18 @@ def test_product_never_reaches_into_the_oracle():
 
 
 def test_implicit_loader_refuses_a_backend_that_is_not_hip(oracle_lib, monkeypatch):
-    """Library() without a path is the product's loader: an environment variable must not be able to put the CPU checker behind a
-    drop-in command.  Library(path) — tests, tools — loads what it is told to; the CLI tests say so twice."""
+    """Library() without a path is the product's loader: no environment variable can put the CPU checker behind a drop-in command.
+    Library(path) — tests, tools — loads what it is told to; the CLI tests patch the class from tests/checker_shim/."""
     from multiprime_amd._abi import Library, MprimeError
     monkeypatch.setenv("MPRIME_LIBRARY", oracle_lib.path)
-    monkeypatch.delenv("MPRIME_TEST_CHECKER_BACKEND", raising=False)
+    monkeypatch.setenv("MPRIME_TEST_CHECKER_BACKEND", "1")          # the round-5 hook: gone
+    monkeypatch.setenv("MP_TEST_CHECKER_SO", oracle_lib.path)       # read by the tests' shim only, never by the package
     with pytest.raises(MprimeError, match="not 'hip'"):
         Library()
     assert Library(oracle_lib.path).backend != "hip"
-    monkeypatch.setenv("MPRIME_TEST_CHECKER_BACKEND", "1")
-    assert Library().path == oracle_lib.path
+    import multiprime_amd
+    for root, _, files in os.walk(os.path.dirname(multiprime_amd.__file__)):
+        for name in files:
+            if name.endswith((".py", ".hip", ".cpp", ".hpp")):
+                text = open(os.path.join(root, name)).read()
+                assert "MPRIME_TEST_CHECKER_BACKEND" not in text and "MP_TEST_CHECKER_SO" not in text, name

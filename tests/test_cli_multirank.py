@@ -1,6 +1,6 @@
 """The drop-in command itself on several ranks (CPU, gloo): `scripts/multiPrime-core.py` under torch.distributed.run shards the
 rows of ONE alignment (rank 0 writes, bytes equal the reference's files), `--ngpu N` launches the ranks itself, and `--batch`
-spreads CLUSTERS over the ranks without a collective.  The device calls go to the ABI checker (MPRIME_LIBRARY), as in
+spreads CLUSTERS over the ranks without a collective.  The device calls go to the ABI checker (tests/checker_shim), as in
 test_multirank.py; the command line, the launcher glue and the collectives are the product's."""
 import json
 import os
@@ -22,7 +22,12 @@ def _flags(name):
 
 
 def _env(oracle_lib):
-    env = dict(os.environ, MPRIME_LIBRARY=oracle_lib.path, MPRIME_TEST_CHECKER_BACKEND="1", MP_DIST_BACKEND="gloo", MASTER_ADDR="127.0.0.1")
+    # the children's device calls go to the checker: tests/checker_shim/sitecustomize.py patches the loader's default path in the child
+    # (the product loader itself has no switch that admits a non-HIP backend)
+    shim = os.path.join(REPO, "tests", "checker_shim")
+    env = dict(os.environ, MP_TEST_CHECKER_SO=oracle_lib.path, MP_DIST_BACKEND="gloo", MASTER_ADDR="127.0.0.1",
+               PYTHONPATH=os.pathsep.join([shim] + [p for p in os.environ.get("PYTHONPATH", "").split(os.pathsep) if p]))
+    env.pop("MPRIME_LIBRARY", None)
     for key in ("RANK", "WORLD_SIZE", "LOCAL_RANK"):
         env.pop(key, None)
     return env
