@@ -348,6 +348,22 @@ class NN_degenerate(object):
 
     # ------------------------------------------------------------------ driver
     def run(self):
+        """V20:1133-1180.  Helper threads of a run (self-dimer launch, coverage bitsets) use the context: whatever way this call ends,
+        they have ended before it returns — a caller's `finally: ctx.close()` must never destroy a context a helper still works on."""
+        self._helpers = []
+        try:
+            return self._run()
+        finally:
+            for helper in self._helpers:
+                helper.wait_quietly()
+            self._helpers = []
+
+    def _beside(self, fn, *args, beside=True):
+        helper = _Beside(fn, *args, beside=beside)
+        self._helpers.append(helper)
+        return helper
+
+    def _run(self):
         k = self.primer_length
         t_run = time.time()
         plan = self._plan()
@@ -396,7 +412,7 @@ class NN_degenerate(object):
             # (the launch and its read-back on a helper thread — one process only: the call holds no interpreter lock — while this thread
             # turns the result columns into lists)
             dimer_out = []
-            dimers = _Beside(lambda: dimer_out.append(self._self_dimers(res["codes"])), beside=self.comm is None)
+            dimers = self._beside(lambda: dimer_out.append(self._self_dimers(res["codes"])), beside=self.comm is None)
             p0 = int(self.start_position)
             wins = res["window"].tolist()
             cbit, tbit = res["cbit"].tolist(), res["tbit"].tolist()
@@ -423,7 +439,7 @@ class NN_degenerate(object):
             if self.write_bitsets or self.keep_bitsets:
                 out_wins = np.asarray([wins[i] for i in keep], np.int32)
                 out_pos = [p0 + wins[i] for i in keep]
-                bitsets = _Beside(self._resident_bitsets, out_wins, kept_codes, out_pos, beside=self.comm is None and side is None)
+                bitsets = self._beside(self._resident_bitsets, out_wins, kept_codes, out_pos, beside=self.comm is None and side is None)
             for i, primer in enumerate(primers):
                 if dimer_flag[i]:
                     continue
@@ -657,6 +673,13 @@ class _Beside:
         if self._error is not None:
             e, self._error = self._error, None
             raise e
+
+    def wait_quietly(self):
+        """The helper has ended when this returns; its error, if any, is dropped (the caller is already leaving with its own)."""
+        if self._thread is not None:
+            self._thread.join()
+            self._thread = None
+        self._error = None
 
 
 def bitset_ids(z):

@@ -1,6 +1,7 @@
 // api.hip — part of libmprime_hip.so: hand-written HIP (gfx950 / MI355X, wave64) behind the C ABI of
 // include/mprime.h.  Context lifetime and bookkeeping.
 #include <sys/mman.h>
+#include <algorithm>
 
 #include <thread>
 #include <vector>
@@ -145,30 +146,66 @@ static bool pool_enabled(mp_ctx *c) {
     return c->pool_on == 1;
 }
 
+// live contexts of the process (pool_register): a failed allocation drains all their pools, and contexts on one device share kPoolBytes
+static std::mutex g_ctx_mu;
+static std::vector<mp_ctx *> g_ctxs;
+
+void pool_register(mp_ctx *c, bool alive) {
+    std::lock_guard<std::mutex> g(g_ctx_mu);
+    if (alive) g_ctxs.push_back(c);
+    else g_ctxs.erase(std::remove(g_ctxs.begin(), g_ctxs.end(), c), g_ctxs.end());
+}
+
+static size_t pool_byte_limit(const mp_ctx *c) {
+    std::lock_guard<std::mutex> g(g_ctx_mu);
+    size_t same = 0;
+    for (const mp_ctx *o : g_ctxs) same += o->dev == c->dev;
+    return kPoolBytes / std::max<size_t>(same, 1);
+}
+
 void *pool_take(mp_ctx *c, size_t bytes) {
-    std::lock_guard<std::mutex> g(c->pool_mu);
-    if (!pool_enabled(c)) return nullptr;
-    for (size_t i = c->pool.size(); i-- > 0;)               // the youngest block of the size: the likeliest to be in a cache still
-        if (c->pool[i].bytes == bytes) {
-            void *p = c->pool[i].p;
-            c->pool.erase(c->pool.begin() + (long)i);
-            c->pool_bytes -= bytes;
-            c->pool_hits++;
-            return p;
-        }
-    c->pool_misses++;
-    return nullptr;
+    void *p = nullptr;
+    hipEvent_t ev = nullptr;
+    {
+        std::lock_guard<std::mutex> g(c->pool_mu);
+        if (!pool_enabled(c)) return nullptr;
+        for (size_t i = c->pool.size(); i-- > 0;)               // the youngest block of the size: the likeliest to be in a cache still
+            if (c->pool[i].bytes == bytes) {
+                p = c->pool[i].p;
+                ev = c->pool[i].released;
+                c->pool.erase(c->pool.begin() + (long)i);
+                c->pool_bytes -= bytes;
+                c->pool_hits++;
+                break;
+            }
+        if (!p) { c->pool_misses++; return nullptr; }
+    }
+    // whatever the context's stream had queued when the block was released has finished before the block is used again — by a kernel
+    // on that stream (already ordered), by a blocking copy on the null stream or by a caller's non-blocking stream (not ordered otherwise)
+    if (ev) {
+        (void)hipEventSynchronize(ev);
+        std::lock_guard<std::mutex> g(c->pool_mu);
+        c->pool_events.push_back(ev);
+    }
+    return p;
 }
 
 bool pool_give(mp_ctx *c, void *p, size_t bytes) {
+    if (bytes > kPoolBlockMax) return false;
+    const size_t limit = pool_byte_limit(c);
     std::lock_guard<std::mutex> g(c->pool_mu);
-    if (!pool_enabled(c) || bytes > kPoolBlockMax) return false;
-    while (!c->pool.empty() && (c->pool.size() >= kPoolBlocks || c->pool_bytes + bytes > kPoolBytes)) {
-        (void)hipFree(c->pool.front().p);
+    if (!pool_enabled(c) || bytes > limit) return false;
+    while (!c->pool.empty() && (c->pool.size() >= kPoolBlocks || c->pool_bytes + bytes > limit)) {
+        (void)hipFree(c->pool.front().p);                   // (hipFree waits for the device itself)
+        if (c->pool.front().released) c->pool_events.push_back(c->pool.front().released);
         c->pool_bytes -= c->pool.front().bytes;
         c->pool.erase(c->pool.begin());
     }
-    c->pool.push_back({p, bytes});
+    hipEvent_t ev = nullptr;
+    if (!c->pool_events.empty()) { ev = c->pool_events.back(); c->pool_events.pop_back(); }
+    else if (hipEventCreateWithFlags(&ev, hipEventDisableTiming) != hipSuccess) { (void)hipGetLastError(); return false; }
+    if (hipEventRecord(ev, c->stream) != hipSuccess) { (void)hipGetLastError(); c->pool_events.push_back(ev); return false; }
+    c->pool.push_back({p, bytes, ev});
     c->pool_bytes += bytes;
     return true;
 }
@@ -191,9 +228,14 @@ size_t pool_forget(mp_ctx *c, void *p, size_t claimed) {
 
 void pool_drain(mp_ctx *c) {
     std::lock_guard<std::mutex> g(c->pool_mu);
-    for (auto &b : c->pool) (void)hipFree(b.p);
+    for (auto &b : c->pool) { (void)hipFree(b.p); if (b.released) c->pool_events.push_back(b.released); }
     c->pool.clear();
     c->pool_bytes = 0;
+}
+
+void pool_drain_all() {
+    std::lock_guard<std::mutex> g(g_ctx_mu);
+    for (mp_ctx *o : g_ctxs) pool_drain(o);
 }
 
 }  // namespace mp
@@ -231,6 +273,7 @@ int mp_create(int device, mp_ctx **out) {
             (void)hipFree(d);
         }
     }
+    pool_register(c, true);
     *out = c;
     return MP_OK;
 }
@@ -252,6 +295,8 @@ void mp_destroy(mp_ctx *c) {
     for (auto &p : c->ev_busy) { (void)hipEventDestroy(p.first); (void)hipEventDestroy(p.second); }
     for (auto &p : c->ev_free) { (void)hipEventDestroy(p.first); (void)hipEventDestroy(p.second); }
     pool_drain(c);                                       // (last: the frees above went through the pool)
+    for (hipEvent_t ev : c->pool_events) (void)hipEventDestroy(ev);
+    pool_register(c, false);
     delete c;
 }
 

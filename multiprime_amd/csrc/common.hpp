@@ -206,7 +206,8 @@ struct mp_ctx {
     uint64_t sF = 0, sR = 0;
     unsigned long long *tmp_out = nullptr;
     int tmp_out_n = 0;
-    struct PoolBlock { void *p; size_t bytes; };
+    struct PoolBlock { void *p; size_t bytes; hipEvent_t released; };     // `released`: recorded on the context's stream when the block came back
+    std::vector<hipEvent_t> pool_events;         // events of blocks that were handed out again (reused by the next release)
     std::unordered_map<void *, size_t> pool_live; // blocks of dev_alloc that are out: the size they were requested with
     std::vector<PoolBlock> pool;                 // released device blocks, oldest first (pool_take / pool_give, api.hip)
     size_t pool_bytes = 0;
@@ -254,12 +255,18 @@ inline int fail(mp_ctx *c, int code, const char *fmt, ...) {
 // Device blocks a stage has released wait in the context for the next request of exactly their size (api.hip): a core step allocates
 // and frees ~40 blocks, hipMalloc costs 20-100 us and hipFree waits for the device on top — and a worker that runs one alignment after
 // the other (or a bench that repeats one) asks for the same sizes again.  Everything the library launches is ordered on the context's
-// stream or synchronised before a block is released, so a block can change hands without the wait hipFree implied.  At most
-// kPoolBlocks blocks / kPoolBytes bytes wait (the oldest go back to the runtime first); mp_destroy and a failed hipMalloc empty the
-// pool; MP_DEVICE_POOL=0 switches it off.
+// stream or synchronised before a block is released, so a block can change hands without the wait hipFree implied.  [r6, advisor] That
+// held only for users ON the context's stream: a blocking copy on the null stream into a recycled block is not ordered against a
+// non-blocking stream the caller passed through mp_set_stream.  A released block now carries an event recorded on the context's stream
+// and whoever takes it waits for that event first (the host waits: after it, a copy or kernel on ANY stream may touch the block).  At
+// most kPoolBlocks blocks / kPoolBytes bytes wait per context — the byte limit is divided by the number of live contexts on the device
+// (eight --batch-workers contexts used to hold 3 GB each) — the oldest go back to the runtime first; mp_destroy empties the pool, a
+// failed hipMalloc empties the pools of EVERY context of the process (pool_drain_all); MP_DEVICE_POOL=0 switches it off.
 void *pool_take(mp_ctx *c, size_t bytes);               // a waiting block of exactly `bytes`, or null
 bool pool_give(mp_ctx *c, void *p, size_t bytes);        // false: not taken (the caller frees it)
 void pool_drain(mp_ctx *c);
+void pool_drain_all();                                  // every live context of the process (a failed hipMalloc: what waits anywhere may be what is missing)
+void pool_register(mp_ctx *c, bool alive);              // mp_create / mp_destroy
 // the size a block was REQUESTED with is kept by the context (a block goes back into the pool under that size, whatever count the
 // releasing call site passes: a site that got its count wrong used to skew mp_device_bytes — with the pool it would hand out a short block)
 void pool_note(mp_ctx *c, void *p, size_t bytes);
@@ -278,7 +285,7 @@ int dev_alloc(mp_ctx *c, T **p, size_t n) {
     hipError_t e = hipMalloc((void **)p, n * sizeof(T));
     if (e != hipSuccess) {                       // (what waits in the pool may be what is missing)
         (void)hipGetLastError();
-        pool_drain(c);
+        pool_drain_all();
         e = hipMalloc((void **)p, n * sizeof(T));
     }
     if (e != hipSuccess) return fail(c, MP_ERR_NOMEM, "hipMalloc(%zu bytes): %s", n * sizeof(T), hipGetErrorString(e));
