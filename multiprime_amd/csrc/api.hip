@@ -91,6 +91,7 @@ void free_unique(mp_ctx *c) {
     dev_free(c, &c->u_total, 1);
     dev_free(c, &c->g_key, W * (size_t)c->g_slots); dev_free(c, &c->g_cnt, W * (size_t)c->g_slots);
     dev_free(c, &c->g_min, W * (size_t)c->g_slots); dev_free(c, &c->g_idx, W * (size_t)c->g_slots);
+    dev_free(c, &c->g_gap, W * (size_t)c->g_slots);
     c->g_slots = 0;
     c->u_cap = c->u_n = 0;
     c->h_wbase.clear(); c->h_wcount.clear();

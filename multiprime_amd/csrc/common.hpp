@@ -155,6 +155,7 @@ struct mp_ctx {
     // unique: global hash tables [W][g_slots] (k <= 21) behind the per-workgroup LDS tables
     unsigned long long *g_key = nullptr;
     uint32_t *g_cnt = nullptr, *g_min = nullptr;
+    uint32_t *g_gap = nullptr;               // k = 22..31: gap words of the keys that carry a gap (unique.hip)
     int32_t *g_idx = nullptr;                // dense index of a slot's entry inside its window (labels)
     int g_slots = 0;
     long long u_cap = 0, u_n = 0;

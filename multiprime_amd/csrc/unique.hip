@@ -20,6 +20,7 @@
 
 #include "common.hpp"
 #include "planstream.hpp"
+#include "workers.hpp"
 #include "winwords.hpp"
 
 using namespace mp;
@@ -50,15 +51,34 @@ __device__ inline uint32_t hash64(unsigned long long x) {
 }
 
 constexpr unsigned long long kNoKey = ~0ull;
+constexpr uint32_t kNoGap = 0xFFFFFFFFu;  // a slot's gap word before the first flagged key claims it (a gap word has k <= 31 bits)
+constexpr unsigned long long kGapFlag = 1ull << 62;
 constexpr int kLdsSlots = 2048;           // 32 KB of LDS per workgroup -> 4-5 workgroups per CU
-constexpr int kCheckEvery = 4;            // iterations between two fill checks (each costs the workgroup a barrier)
-constexpr int kLdsLimit = kLdsSlots - kCheckEvery * kBlock - 128;      // flush above this: the next kCheckEvery iterations add at most that many keys
+
+// Key forms.  k <= 21 (WIDE = false): the 3k bits b0 | b1 << k | g << 2k ARE the key.  k = 22..31 (WIDE = true, round 6): the key is the
+// 2k base bits b0 | b1 << k (<= 62 bits) plus, for the few rows with a gap inside the window, bit 62 and the gap word g in a u32 BESIDE
+// the slot: a slot is claimed in two steps — 64-bit CAS on the key word, then, for a flagged key only, a 32-bit CAS of the gap word from
+// kNoGap.  Whoever sets the gap word owns the slot; a flagged key that finds another gap word there treats the slot as taken by another
+// key and probes on.  Probe sequences are deterministic and slots are never released, so every (key, gap) lives in exactly one slot.
+// A gap position carries b0 = b1 = 0 (fast_from_slices), so (key bits, g) determines the k-mer.  Unflagged keys — 96 % of the rows —
+// never touch the gap words: their cost is that of the narrow form.
+template <bool WIDE>
+__device__ inline void make_key(uint32_t b0, uint32_t b1, uint32_t g, int k, unsigned long long &key, uint32_t &gap) {
+    if (WIDE) {
+        key = (unsigned long long)b0 | ((unsigned long long)b1 << k) | (g ? kGapFlag : 0ull);
+        gap = g;
+    } else {
+        key = (unsigned long long)b0 | ((unsigned long long)b1 << k) | ((unsigned long long)g << (2 * k));
+        gap = 0;
+    }
+}
 
 struct HistArgs {
     MsaArgs M;
     int p0, k, n_win, rows_per_block, n_slices, win_per_xcd;
     unsigned long long *g_key;            // [W][g_slots]
     uint32_t *g_cnt, *g_min;
+    uint32_t *g_gap;                      // [W][g_slots] gap words of flagged keys (WIDE), else null
     int g_slots;
     int32_t *g_over;                      // [W] 1 = the global table of the window is too small
     const int32_t *patch_off;             // [W+1] slow pairs of every window (mp_build_windows): rows and window words
@@ -67,48 +87,81 @@ struct HistArgs {
     unsigned long long *prof;             // MP_HIST_PROF: [workgroup][8] shader-clock stamps of hist_kernel's phases (null: none)
 };
 
+// the scope of the atomics on the windows' tables in HBM (experiment knob: __HIP_MEMORY_SCOPE_WORKGROUP executes them in the XCD's L2)
+#ifndef MP_HIST_SCOPE
+#define MP_HIST_SCOPE __HIP_MEMORY_SCOPE_AGENT
+#endif
+__device__ inline unsigned long long g_cas(unsigned long long *p, unsigned long long expect, unsigned long long val) {
+    __hip_atomic_compare_exchange_strong(p, &expect, val, __ATOMIC_RELAXED, __ATOMIC_RELAXED, MP_HIST_SCOPE);
+    return expect;
+}
+__device__ inline uint32_t g_cas(uint32_t *p, uint32_t expect, uint32_t val) {
+    __hip_atomic_compare_exchange_strong(p, &expect, val, __ATOMIC_RELAXED, __ATOMIC_RELAXED, MP_HIST_SCOPE);
+    return expect;
+}
+__device__ inline void g_add(uint32_t *p, uint32_t v) { (void)__hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, MP_HIST_SCOPE); }
+__device__ inline void g_min(uint32_t *p, uint32_t v) { (void)__hip_atomic_fetch_min(p, v, __ATOMIC_RELAXED, MP_HIST_SCOPE); }
+
+// does slot h (whose key word answered `old` to the claim of `key`, with kNoKey already replaced by key) hold (key, gap)?
+template <bool WIDE>
+__device__ inline bool slot_holds(unsigned long long old, unsigned long long key, uint32_t *gap_words, size_t h, uint32_t gap) {
+    if (old != key) return false;
+    if (!WIDE || !(key & kGapFlag)) return true;
+    const uint32_t og = atomicCAS(&gap_words[h], kNoGap, gap);
+    return og == kNoGap || og == gap;
+}
+
 // merge one (key, count, first row) into the window's global table, probing from slot h
-__device__ inline void global_insert_from(const HistArgs &A, int w, unsigned long long key, uint32_t cnt, uint32_t row, uint32_t h, int probe0) {
+template <bool WIDE>
+__device__ inline void global_insert_from(const HistArgs &A, int w, unsigned long long key, uint32_t gap, uint32_t cnt, uint32_t row, uint32_t h, int probe0) {
     const uint32_t mask = (uint32_t)A.g_slots - 1u;
-    unsigned long long *K = A.g_key + (size_t)w * A.g_slots;
+    const size_t base = (size_t)w * A.g_slots;
+    unsigned long long *K = A.g_key + base;
     for (int probe = probe0; probe < A.g_slots; probe++) {
         unsigned long long old = K[h];
         if (old == kNoKey) {
-            old = atomicCAS(&K[h], kNoKey, key);
-            if (old == kNoKey) old = key;                 // claimed (occupied slots are counted afterwards, count_kernel)
+            old = g_cas(&K[h], kNoKey, key);
+            if (old == kNoKey) old = key;                 // claimed (occupied slots are counted afterwards, table_sums_kernel)
         }
-        if (old == key) {
-            atomicAdd(&A.g_cnt[(size_t)w * A.g_slots + h], cnt);
-            atomicMin(&A.g_min[(size_t)w * A.g_slots + h], row);
+        if (slot_holds<WIDE>(old, key, A.g_gap, base + h, gap)) {
+            g_add(&A.g_cnt[base + h], cnt);
+            g_min(&A.g_min[base + h], row);
             return;
         }
         h = (h + 1) & mask;
     }
     A.g_over[w] = 1;
 }
-__device__ inline void global_insert(const HistArgs &A, int w, unsigned long long key, uint32_t cnt, uint32_t row) {
-    global_insert_from(A, w, key, cnt, row, hash64(key) & ((uint32_t)A.g_slots - 1u), 0);
+template <bool WIDE>
+__device__ inline void global_insert(const HistArgs &A, int w, unsigned long long key, uint32_t gap, uint32_t cnt, uint32_t row) {
+    global_insert_from<WIDE>(A, w, key, gap, cnt, row, hash64(key) & ((uint32_t)A.g_slots - 1u), 0);
 }
 
 // The workgroup's LDS table into the window's global table.  A thread owns SLOTS / kBlock slots and takes them through the merge four
 // at a time: their first-probe reads together, then the claims, then the (unreturned) count / first-row atomics — two global round
 // trips per four slots instead of two or three per occupied slot one after the other (the flush is a third of a workgroup's life and
 // all of it is global latency); a slot whose first probe meets another key walks on alone.
-template <int SLOTS>
-__device__ inline void flush_table(const HistArgs &A, int w, unsigned long long *s_key, uint32_t *s_cnt, uint32_t *s_min) {
-    constexpr int S = 4;
+template <int SLOTS, bool WIDE>
+__device__ inline void flush_table(const HistArgs &A, int w, unsigned long long *s_key, uint32_t *s_cnt, uint32_t *s_min, uint32_t *s_gap) {
+#ifndef MP_HIST_FLUSH_S
+#define MP_HIST_FLUSH_S 4
+#endif
+    constexpr int S = MP_HIST_FLUSH_S;
     static_assert(SLOTS % (S * kBlock) == 0, "whole groups of slots per thread");
     const uint32_t mask = (uint32_t)A.g_slots - 1u;
-    unsigned long long *K = A.g_key + (size_t)w * A.g_slots;
+    const size_t base = (size_t)w * A.g_slots;
+    unsigned long long *K = A.g_key + base;
 #pragma unroll 1
     for (int i0 = threadIdx.x; i0 < SLOTS; i0 += S * kBlock) {
         unsigned long long key[S], old[S];
-        uint32_t cnt[S], mn[S], h[S];
+        uint32_t cnt[S], mn[S], h[S], gap[S];
 #pragma unroll
         for (int u = 0; u < S; u++) {
             const int i = i0 + u * kBlock;
             key[u] = s_key[i]; cnt[u] = s_cnt[i]; mn[u] = s_min[i];
             s_key[i] = kNoKey; s_cnt[i] = 0; s_min[i] = kEmpty;
+            gap[u] = 0;
+            if (WIDE) { gap[u] = s_gap[i]; s_gap[i] = kNoGap; }
             h[u] = hash64(key[u]) & mask;
         }
 #pragma unroll
@@ -116,31 +169,42 @@ __device__ inline void flush_table(const HistArgs &A, int w, unsigned long long 
 #pragma unroll
         for (int u = 0; u < S; u++)
             if (key[u] != kNoKey && old[u] == kNoKey) {
-                old[u] = atomicCAS(&K[h[u]], kNoKey, key[u]);
+                old[u] = g_cas(&K[h[u]], kNoKey, key[u]);
                 if (old[u] == kNoKey) old[u] = key[u];
             }
 #pragma unroll
         for (int u = 0; u < S; u++)
             if (key[u] != kNoKey) {
-                if (old[u] == key[u]) {
-                    atomicAdd(&A.g_cnt[(size_t)w * A.g_slots + h[u]], cnt[u]);
-                    atomicMin(&A.g_min[(size_t)w * A.g_slots + h[u]], mn[u]);
+                if (slot_holds<WIDE>(old[u], key[u], A.g_gap, base + h[u], gap[u])) {
+                    g_add(&A.g_cnt[base + h[u]], cnt[u]);
+                    g_min(&A.g_min[base + h[u]], mn[u]);
                 } else {
-                    global_insert_from(A, w, key[u], cnt[u], mn[u], (h[u] + 1) & mask, 1);
+                    global_insert_from<WIDE>(A, w, key[u], gap[u], cnt[u], mn[u], (h[u] + 1) & mask, 1);
                 }
             }
     }
 }
 
-// SLOTS x 16 bytes of LDS per workgroup decide how many workgroups a CU holds (160 KB: 5 at 2048 slots).  kMaxProbe bounds a key's
-// walk through the LDS table: beyond it the key is not there, and if no free slot turned up either it goes to the table in HBM.
-template <int SLOTS, int CHECK>
+__device__ inline unsigned long long readlane64(unsigned long long x, int lane) {
+    return (unsigned long long)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)x, lane) |
+           ((unsigned long long)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(x >> 32), lane) << 32);
+}
+__device__ inline unsigned long long uniform64(unsigned long long x) {
+    return (unsigned long long)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)x) |
+           ((unsigned long long)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(x >> 32)) << 32);
+}
+
+// SLOTS x 16 (20 with gap words) bytes of LDS per workgroup decide how many workgroups a CU holds (160 KB: 5 at 2048 slots).  kMaxProbe
+// bounds a key's walk through the LDS table: beyond it the key is not there, and if no free slot turned up either it goes to the table
+// in HBM.  FOLDS: rounds of wave-level folding in front of the LDS table (below).
+template <int SLOTS, bool WIDE, int FOLDS>
 __global__ __launch_bounds__(kBlock) void hist_kernel(const HistArgs A) {
     constexpr int kLdsSlots = SLOTS, kMaxProbe = 24;
-    (void)CHECK;                                          // (the fill-check period of rounds 2-3; kept in the kernel's name for the profiles)
     __shared__ unsigned long long s_key[kLdsSlots];
     __shared__ uint32_t s_cnt[kLdsSlots];
     __shared__ uint32_t s_min[kLdsSlots];
+    __shared__ uint32_t s_gap[WIDE ? kLdsSlots : 1];
+    __shared__ int s_used, s_flag;                        // slots claimed since the last flush; the workgroup's decision to flush
     // workgroup b runs on XCD b % 8 and every XCD has its own L2: an XCD owns a band of consecutive windows and walks it
     // window-fastest, so the workgroups resident on it at any time read the same few 32-column chunks of one row slice
     const int xcd = blockIdx.x & 7, q = blockIdx.x >> 3;
@@ -155,12 +219,16 @@ __global__ __launch_bounds__(kBlock) void hist_kernel(const HistArgs A) {
     const int r1 = min(r0 + A.rows_per_block, A.M.n_pad);
     auto stamp = [&](int i) { if (A.prof && threadIdx.x == 0) A.prof[(size_t)blockIdx.x * 8 + i] = clock64(); };
     stamp(0);
-    for (int i = threadIdx.x; i < kLdsSlots; i += kBlock) { s_key[i] = kNoKey; s_cnt[i] = 0; s_min[i] = kEmpty; }
+    for (int i = threadIdx.x; i < kLdsSlots; i += kBlock) {
+        s_key[i] = kNoKey; s_cnt[i] = 0; s_min[i] = kEmpty;
+        if (WIDE) s_gap[i] = kNoGap;
+    }
+    if (threadIdx.x == 0) { s_used = 0; s_flag = 0; }
     __syncthreads();
     stamp(1);
     const int lane = threadIdx.x & 63;
     const uint32_t *P = A.M.planes + ((size_t)(p >> 5) * 4) * np;
-    auto flush = [&]() { flush_table<SLOTS>(A, w, s_key, s_cnt, s_min); };
+    auto flush = [&]() { flush_table<SLOTS, WIDE>(A, w, s_key, s_cnt, s_min, s_gap); };
     // A thread takes FOUR consecutive rows per iteration: the eight plane words of the four rows arrive as eight 16-byte buffer loads
     // (row byte offset in a vector register, plane offset in a scalar one).  One-word loads are what round 2 used: a CU returns them at
     // 20 B/clk (`ubench`: 11 TB/s over the chip, against 31 TB/s for 16-byte loads), and 18.8 M of them per launch were half the
@@ -180,31 +248,61 @@ __global__ __launch_bounds__(kBlock) void hist_kernel(const HistArgs A) {
             R.len = __builtin_amdgcn_raw_buffer_load_b128(lrs, r4 * 4, 0, 0);
         }
     };
-    auto hash_rows = [&](const Rows &R, int r4, int iter) {
+    // The wave's running consensus: the k-mer that led the largest group so far (wave-uniform, scalar registers).  [r6] What bound this
+    // kernel was not instruction issue (VALU 24 % busy) but the LDS unit serialising atomics on ONE address: rounds 2-5 folded only the
+    // k-mer of a step's FIRST live lane, and whenever that lane did not carry the window's consensus (43 % of the steps on the bench
+    // alignment) ~36 lanes sent a CAS, an add and a min to the same slot, one after the other.  Now a step folds the lanes that carry
+    // the running consensus (no readlane needed), then FOLDS more groups led by the first lane still pending; only what is left — lanes
+    // with mostly distinct k-mers — goes to the table one lane at a time.
+#ifndef MP_HIST_CONS_CARRY
+#define MP_HIST_CONS_CARRY 0          // 1: the consensus is handed from row index to row index inside a step (serialises the four chains)
+#endif
+    unsigned long long cons = kNoKey;
+    auto hash_rows = [&](const Rows &R, int r4) {
+        const unsigned long long cons_in = cons;
+        (void)cons_in;
         const u32x4 (&cw)[8] = R.w;
         const u32x4 len4 = R.len;
         const bool mine = r4 < r1;
         // (1) straight-line: the window words of the thread's four rows (a lane without rows computes on stale registers and is masked
-        // by `ok`); per row index u the first live lane's k-mer comes through v_readlane (no LDS round trip) and the lanes that carry
-        // it fold into that lane
+        // by `ok`); group leaders (the lowest lane of a group = its lowest row) carry the group's count
         unsigned long long key[RPT];
-        uint32_t cnt[RPT], h[RPT];
+        uint32_t cnt[RPT], h[RPT], gap[RPT];
         bool todo[RPT];
+        uint32_t claims = 0;                                  // slots this lane claimed in this step (<= RPT)
 #pragma unroll
         for (int u = 0; u < RPT; u++) {
             uint32_t b0, b1, g;
             // plain column slices only: the repaired / IUPAC / ragged rows of the window come from the patch list below
             const bool plain = fast_words(p, k, kmask, (int)len4[u], cw[0][u], cw[1][u], cw[2][u], cw[3][u], cw[4][u], cw[5][u], cw[6][u], cw[7][u], b0, b1, g);
             const bool ok = plain & mine & (r4 + u < A.M.n_rows);
-            key[u] = (unsigned long long)b0 | ((unsigned long long)b1 << k) | ((unsigned long long)g << (2 * k));
-            const unsigned long long pending = __ballot(ok);
-            const int lead = __builtin_amdgcn_readfirstlane(pending ? __ffsll((long long)pending) - 1 : 0);
-            const unsigned long long k0 = (unsigned long long)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)key[u], lead) |
-                                          ((unsigned long long)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(key[u] >> 32), lead) << 32);
-            const bool same = ok & (key[u] == k0);
-            const unsigned long long grp = __ballot(same);             // (every lane votes: not inside the conditional below)
-            cnt[u] = lane == lead ? (uint32_t)__popcll(grp) : 1u;
-            todo[u] = ok & (!same | (lane == lead));
+            make_key<WIDE>(b0, b1, g, k, key[u], gap[u]);
+            unsigned long long pending = __ballot(ok);
+            const unsigned long long cref = MP_HIST_CONS_CARRY ? cons : cons_in;   // (the four row indices of a step are independent chains)
+            const bool s0 = ok & (key[u] == cref);                      // (a flagged key never equals the consensus: it is adopted unflagged only)
+            const unsigned long long g0 = __ballot(s0);
+            pending &= ~g0;
+            const int lead0 = g0 ? __ffsll((long long)g0) - 1 : -1;
+            uint32_t c = 1u;
+            bool go = false;
+            if (lane == lead0) { c = (uint32_t)__popcll(g0); go = true; }
+            int best_n = (int)__popcll(g0);
+            unsigned long long best_key = cref;
+#pragma unroll
+            for (int f = 0; f < FOLDS; f++) {
+                const int lead = pending ? __ffsll((long long)pending) - 1 : 0;
+                const unsigned long long kf = readlane64(key[u], lead);
+                bool same = ((pending >> lane) & 1ull) && key[u] == kf;
+                if (WIDE) same = same && gap[u] == (uint32_t)__builtin_amdgcn_readlane((int)gap[u], lead);
+                const unsigned long long grp = __ballot(same);             // (every lane votes: not inside a conditional)
+                pending &= ~grp;
+                const int n = (int)__popcll(grp);
+                if (lane == lead && n) { c = (uint32_t)n; go = true; }
+                if (n > best_n && !(WIDE && (kf & kGapFlag))) { best_n = n; best_key = kf; }
+            }
+            if (MP_HIST_CONS_CARRY || u == 0) cons = best_key;
+            cnt[u] = c;
+            todo[u] = go | (bool)((pending >> lane) & 1ull);
             h[u] = hash64(key[u]) & (kLdsSlots - 1);
         }
         // (2) the first probes of all four rows leave together (four LDS round trips overlap instead of following each other); a row
@@ -216,39 +314,63 @@ __global__ __launch_bounds__(kBlock) void hist_kernel(const HistArgs A) {
         for (int u = 0; u < RPT; u++) {
             if (todo[u]) {
                 const uint32_t row = (uint32_t)(r4 + u);
-                if (old[u] == kNoKey) old[u] = key[u];
+                if (old[u] == kNoKey) { old[u] = key[u]; claims++; }
                 uint32_t hh = h[u];
                 // a key sits within kMaxProbe slots of its hash or not in the LDS table at all: when the walk finds neither the key
                 // nor a free slot (a workgroup's rows hold more distinct k-mers than the table takes), the key goes to the window's
                 // table in HBM directly.  No fill count, no check, no barrier in the row loop (round 4; until then the workgroup met at
                 // a barrier every iteration to see whether the table had to be flushed: the waves of a workgroup ran in lock step)
-                for (int probe = 0; old[u] != key[u] && probe < kMaxProbe; probe++) {
+                bool here = slot_holds<WIDE>(old[u], key[u], s_gap, hh, gap[u]);
+                for (int probe = 0; !here && probe < kMaxProbe; probe++) {
                     hh = (hh + 1) & (kLdsSlots - 1);
                     old[u] = atomicCAS(&s_key[hh], kNoKey, key[u]);
-                    if (old[u] == kNoKey) old[u] = key[u];
+                    if (old[u] == kNoKey) { old[u] = key[u]; claims++; }
+                    here = slot_holds<WIDE>(old[u], key[u], s_gap, hh, gap[u]);
                 }
-                if (old[u] == key[u]) {
+                if (here) {
                     atomicAdd(&s_cnt[hh], cnt[u]);
                     atomicMin(&s_min[hh], row);
                 } else {
-                    global_insert(A, w, key[u], cnt[u], row);
+                    global_insert<WIDE>(A, w, key[u], gap[u], cnt[u], row);
                 }
             }
         }
-        (void)iter;
+        // the wave's claims of this step (three ballots: a lane claims at most RPT = 4 slots) -> the workgroup's fill count
+        const int n_claimed = (int)__popcll(__ballot(claims & 1u)) + 2 * (int)__popcll(__ballot(claims & 2u)) + 4 * (int)__popcll(__ballot(claims & 4u));
+        if (lane == 0 && n_claimed) atomicAdd(&s_used, n_claimed);
+    };
+    // [r6] The table is flushed MID-SLICE once it is more than kFlushAt full (checked every second step: two barriers per 2048 rows).
+    // Rounds 4-5 never flushed before the end of the slice and let a key that found no free slot within kMaxProbe probes go to the table
+    // in HBM itself: at 10^6 rows a 24576-row slice of a variable window holds ~3500 distinct k-mers, the 2048 slots were full after a
+    // third of the slice, and from then on EVERY new k-mer walked 24 slots (24 returning LDS atomics, one after the other) before its
+    // lane-at-a-time insert into HBM — the windows the entropy gate rejects were the slowest, and the k = 22 histograms took twice the
+    // time of the k = 18 ones.  The batched flush moves an entry for ~30 cycles of the workgroup; a lane's own walk and insert cost ~10x.
+#ifndef MP_HIST_FLUSH_16THS
+#define MP_HIST_FLUSH_16THS 7
+#endif
+    constexpr int kFlushAt = SLOTS * MP_HIST_FLUSH_16THS / 16;
+    auto maybe_flush = [&]() {
+        __syncthreads();
+        if (threadIdx.x == 0) s_flag = s_used > kFlushAt;
+        __syncthreads();
+        if (s_flag) {
+            flush();
+            if (threadIdx.x == 0) s_used = 0;
+            __syncthreads();
+        }
     };
     {
         constexpr int kStep = kBlock * RPT;
         Rows Ra, Rb;
         const int t4 = (int)threadIdx.x * RPT;
         fetch(Ra, r0 + t4);
-        int iter = 0;
-        for (int base = r0; base < r1; base += 2 * kStep, iter += 2) {      // uniform trip count: the barriers inside are reached by all
+        for (int base = r0; base < r1; base += 2 * kStep) {
             fetch(Rb, base + kStep + t4);
-            hash_rows(Ra, base + t4, iter);
+            hash_rows(Ra, base + t4);
             if (base + kStep >= r1) break;
             fetch(Ra, base + 2 * kStep + t4);
-            hash_rows(Rb, base + kStep + t4, iter + 1);
+            hash_rows(Rb, base + kStep + t4);
+            if (base + 2 * kStep < r1) maybe_flush();
         }
     }
     __syncthreads();
@@ -262,18 +384,269 @@ __global__ __launch_bounds__(kBlock) void hist_kernel(const HistArgs A) {
             if (e < e1) {
                 const uint32_t b0 = A.patch_words[3 * (size_t)e], b1 = A.patch_words[3 * (size_t)e + 1], g = A.patch_words[3 * (size_t)e + 2];
                 if (!(g & MP_WIN_SKIP)) {
-                    const unsigned long long key = (unsigned long long)b0 | ((unsigned long long)b1 << k) | ((unsigned long long)(g & kmask) << (2 * k));
+                    unsigned long long key;
+                    uint32_t gap;
+                    make_key<WIDE>(b0, b1, g & kmask, k, key, gap);
                     uint32_t h = hash64(key) & (kLdsSlots - 1);
                     bool placed = false;
                     for (int probe = 0; probe <= kMaxProbe && !placed; probe++) {
                         unsigned long long old = atomicCAS(&s_key[h], kNoKey, key);
                         if (old == kNoKey) old = key;
-                        if (old == key) { atomicAdd(&s_cnt[h], 1u); atomicMin(&s_min[h], (uint32_t)A.patch_rows[e]); placed = true; }
+                        if (slot_holds<WIDE>(old, key, s_gap, h, gap)) { atomicAdd(&s_cnt[h], 1u); atomicMin(&s_min[h], (uint32_t)A.patch_rows[e]); placed = true; }
                         h = (h + 1) & (kLdsSlots - 1);
                     }
-                    if (!placed) global_insert(A, w, key, 1u, (uint32_t)A.patch_rows[e]);
+                    if (!placed) global_insert<WIDE>(A, w, key, gap, 1u, (uint32_t)A.patch_rows[e]);
                 }
             }
+        }
+        __syncthreads();
+    }
+    stamp(3);
+    flush();
+    __syncthreads();
+    stamp(4);
+}
+
+
+// ---------------------------------------------------------------------------------------------------------------------------------
+// hist2_kernel [r6] — the same (window, slice of rows) decomposition, the same tables, a different row loop.
+//
+// What bound hist_kernel was never found in a unit being busy (rocprofv3 at 10^6 rows: vector ALU 24 %, LDS array 21 %, scalar 33 %,
+// 6.4 TB/s through the vector memory path): a wave spent ~2100 cycles per 64 rows WAITING — every step ended in returning LDS atomics
+// (64-bit compare-and-swap, a divergent probe walk behind it, add, min) for the ~27 lanes whose k-mer is not the consensus, and four
+// waves per SIMD cannot hide that.  Folding more groups, batching the flush, flushing mid-slice: all within noise (profiles/
+// r06_hist_experiments.txt).  So the row loop no longer ends in a returning atomic at all:
+//   * a wave fixes a REFERENCE k-mer (the first k-mer a fifth of a step's lanes share — the window's consensus) in scalar registers;
+//   * lanes that carry it are counted with one ballot and a scalar add (57 % of the rows of the bench alignment);
+//   * lanes that differ from it in exactly ONE position (30 %) bump a dense counter [position][symbol] of their wave in LDS with a
+//     non-returning add and min — 8 k counters instead of a hash table for the ~54 single-substitution variants that make up most
+//     of the non-consensus rows;
+//   * the rest (12 %) append (k-mer, row) to a ring of their wave in LDS (position = scalar tail + lane rank: no atomic), and whenever
+//     the ring holds 64 entries the wave inserts them into the workgroup's hash table with ALL lanes busy — the returning
+//     compare-and-swap chain is paid once per 64 such rows instead of once per step.
+// At the end of the slice a wave's reference count, dense counters and ring leftovers go through the same insert; the hash table is
+// flushed into the window's table in HBM as before (and mid-slice when it fills up).
+// ---------------------------------------------------------------------------------------------------------------------------------
+template <int SLOTS, bool WIDE>
+__global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(4))) void hist2_kernel(const HistArgs A) {
+    constexpr int kMaxProbe = 24, NW = kBlock / 64, QCAP = 256, ND = 256;     // (two row indices append at most 2 x 64 entries to the 63 that may wait)
+    __shared__ unsigned long long s_key[SLOTS];
+    __shared__ uint32_t s_cnt[SLOTS];
+    __shared__ uint32_t s_min[SLOTS];
+    __shared__ uint32_t s_gap[WIDE ? SLOTS : 1];
+    __shared__ uint32_t d_cnt[NW][ND], d_min[NW][ND];         // per wave: [position * 8 + symbol] of the single-difference k-mers
+    __shared__ unsigned long long q_key[NW][QCAP];            // per wave: ring of the other k-mers waiting for a dense insert
+    __shared__ uint32_t q_row[NW][QCAP];
+    __shared__ uint32_t q_gap[WIDE ? NW : 1][QCAP];
+    __shared__ int s_used, s_flag;
+    const int xcd = blockIdx.x & 7, q = blockIdx.x >> 3;
+    const int wl = q % A.win_per_xcd, slice = q / A.win_per_xcd;
+    const int w = xcd * A.win_per_xcd + wl;
+    if (w >= A.n_win || slice >= A.n_slices) return;
+    const int k = A.k;
+    const uint32_t kmask = (1u << k) - 1u;
+    const int p = A.p0 + w;
+    const size_t np = (size_t)A.M.n_pad;
+    const int r0 = slice * A.rows_per_block;
+    const int r1 = min(r0 + A.rows_per_block, A.M.n_pad);
+    auto stamp = [&](int i) { if (A.prof && threadIdx.x == 0) A.prof[(size_t)blockIdx.x * 8 + i] = clock64(); };
+    stamp(0);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    for (int i = threadIdx.x; i < SLOTS; i += kBlock) {
+        s_key[i] = kNoKey; s_cnt[i] = 0; s_min[i] = kEmpty;
+        if (WIDE) s_gap[i] = kNoGap;
+    }
+    for (int i = lane; i < ND; i += 64) { d_cnt[wave][i] = 0; d_min[wave][i] = kEmpty; }
+    if (threadIdx.x == 0) { s_used = 0; s_flag = 0; }
+    __syncthreads();
+    stamp(1);
+    const uint32_t *P = A.M.planes + ((size_t)(p >> 5) * 4) * np;
+    constexpr int RPT = 4;
+    typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+    const __amdgpu_buffer_rsrc_t prs = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint32_t *>(P), 0, 0x7FFFFFFF, 0x00020000);
+    const __amdgpu_buffer_rsrc_t lrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<int32_t *>(A.M.rlen), 0, 0x7FFFFFFF, 0x00020000);
+    const int plane_bytes = (int)(np * 4);
+    struct Rows { u32x4 w[8], len; };
+    auto fetch = [&](Rows &R, int r4) {
+        if (r4 < r1) {
+#pragma unroll
+            for (int j = 0; j < 8; j++) R.w[j] = __builtin_amdgcn_raw_buffer_load_b128(prs, r4 * 4, j * plane_bytes, 0);
+            R.len = __builtin_amdgcn_raw_buffer_load_b128(lrs, r4 * 4, 0, 0);
+        }
+    };
+    // one (k-mer, count, first row) of every lane with `go` into the workgroup's table (or, when that is full around its hash, into
+    // the window's table in HBM); returns 1 when the lane claimed a slot
+    auto insert = [&](bool go, unsigned long long key, uint32_t gap, uint32_t cnt, uint32_t row) -> uint32_t {
+        uint32_t claimed = 0;
+        if (go) {
+            uint32_t hh = hash64(key) & (SLOTS - 1);
+            unsigned long long old = atomicCAS(&s_key[hh], kNoKey, key);
+            if (old == kNoKey) { old = key; claimed = 1; }
+            bool here = slot_holds<WIDE>(old, key, s_gap, hh, gap);
+            for (int probe = 0; !here && probe < kMaxProbe; probe++) {
+                hh = (hh + 1) & (SLOTS - 1);
+                old = atomicCAS(&s_key[hh], kNoKey, key);
+                if (old == kNoKey) { old = key; claimed = 1; }
+                here = slot_holds<WIDE>(old, key, s_gap, hh, gap);
+            }
+            if (here) {
+                atomicAdd(&s_cnt[hh], cnt);
+                atomicMin(&s_min[hh], row);
+            } else {
+                global_insert<WIDE>(A, w, key, gap, cnt, row);
+            }
+        }
+        return claimed;
+    };
+    auto note_claims = [&](uint32_t claimed) {                 // (uniform control flow: every lane of the wave comes by)
+        const int n = (int)__popcll(__ballot(claimed != 0));
+        if (lane == 0 && n) atomicAdd(&s_used, n);
+    };
+    // wave-uniform state (scalar registers)
+    bool have_ref = false;
+    uint32_t rb0 = 0, rb1 = 0, rg = 0;                        // the reference k-mer
+    uint32_t n_ref = 0, first_ref = kEmpty;                   // rows that carry it, the first of them
+    uint32_t q_head = 0, q_tail = 0;                          // the wave's ring: entries [q_head, q_tail) modulo QCAP
+    auto drain = [&](uint32_t n) {                            // the first n <= 64 ring entries into the table
+        const uint32_t pos = (q_head + (uint32_t)lane) & (QCAP - 1);
+        const bool go = (uint32_t)lane < n;
+        const unsigned long long key = q_key[wave][pos];
+        const uint32_t row = q_row[wave][pos];
+        const uint32_t gap = WIDE ? q_gap[WIDE ? wave : 0][pos] : 0u;
+        note_claims(insert(go, key, gap, 1u, row));
+        q_head += n;
+    };
+    auto hash_rows = [&](const Rows &R, int base) {
+        const int r4 = base + (int)threadIdx.x * RPT;
+        const u32x4 (&cw)[8] = R.w;
+#ifdef MP_HIST_EXP_LOADONLY                                  // experiment: the loads alone (every word used once, nothing counted)
+        {
+            uint32_t x = R.len[0];
+#pragma unroll
+            for (int j = 0; j < 8; j++) x ^= R.w[j][0] ^ R.w[j][1] ^ R.w[j][2] ^ R.w[j][3];
+            if (x == 0x12345678u && r4 < r1) n_ref++;
+            return;
+        }
+#endif
+        const u32x4 len4 = R.len;
+        const bool mine = r4 < r1;
+#pragma unroll
+        for (int u = 0; u < RPT; u++) {
+            uint32_t b0, b1, g;
+            const bool plain = fast_words(p, k, kmask, (int)len4[u], cw[0][u], cw[1][u], cw[2][u], cw[3][u], cw[4][u], cw[5][u], cw[6][u], cw[7][u], b0, b1, g);
+            const bool ok = plain & mine & (r4 + u < A.M.n_rows);
+            const uint32_t row = (uint32_t)(r4 + u);
+            if (!have_ref) {                                   // (uniform) adopt the first k-mer that 12 lanes of a step share
+                const unsigned long long okm = __ballot(ok);
+                if (okm) {
+                    const int lead = __ffsll((long long)okm) - 1;
+                    const uint32_t l0 = (uint32_t)__builtin_amdgcn_readlane((int)b0, lead), l1 = (uint32_t)__builtin_amdgcn_readlane((int)b1, lead),
+                                   lg = (uint32_t)__builtin_amdgcn_readlane((int)g, lead);
+                    const unsigned long long same = __ballot(ok && b0 == l0 && b1 == l1 && g == lg);
+                    if (__popcll(same) >= 12) { have_ref = true; rb0 = l0; rb1 = l1; rg = lg; }
+                }
+            }
+            const uint32_t d = (b0 ^ rb0) | (b1 ^ rb1) | (g ^ rg);
+            const bool is_ref = ok && have_ref && d == 0;
+            const bool is_one = ok && have_ref && d != 0 && (d & (d - 1u)) == 0;
+            const unsigned long long m_ref = __ballot(is_ref);
+            if (m_ref) {
+                n_ref += (uint32_t)__popcll(m_ref);
+                const uint32_t cand = (uint32_t)(base + ((wave * 64 + (__ffsll((long long)m_ref) - 1)) * RPT) + u);
+                first_ref = cand < first_ref ? cand : first_ref;
+            }
+            if (is_one) {
+                const int j = __ffs((int)d) - 1;
+                const uint32_t sym = ((b0 >> j) & 1u) | (((b1 >> j) & 1u) << 1) | (((g >> j) & 1u) << 2);
+                atomicAdd(&d_cnt[wave][j * 8 + (int)sym], 1u);
+                atomicMin(&d_min[wave][j * 8 + (int)sym], row);
+            }
+            const bool other = ok && !is_ref && !is_one;
+            const unsigned long long m_oth = __ballot(other);
+            if (m_oth) {
+                if (other) {
+                    const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(m_oth >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m_oth, 0u));
+                    const uint32_t pos = (q_tail + rank) & (QCAP - 1);
+                    unsigned long long key;
+                    uint32_t gap;
+                    make_key<WIDE>(b0, b1, g, k, key, gap);
+                    q_key[wave][pos] = key;
+                    q_row[wave][pos] = row;
+                    if (WIDE) q_gap[WIDE ? wave : 0][pos] = gap;
+                }
+                q_tail += (uint32_t)__popcll(m_oth);
+            }
+            if (u & 1) {
+#pragma unroll 1
+                while (q_tail - q_head >= 64u) drain(64u);
+            }
+        }
+    };
+#ifndef MP_HIST2_FLUSH_16THS
+#define MP_HIST2_FLUSH_16THS 9
+#endif
+    constexpr int kFlushAt = SLOTS * MP_HIST2_FLUSH_16THS / 16;
+#ifdef MP_HIST_EXP_NOFLUSH                                   // experiment: nothing leaves the workgroup
+    auto flush = [&]() { for (int i = threadIdx.x; i < SLOTS; i += kBlock) { s_key[i] = kNoKey; s_cnt[i] = 0; s_min[i] = kEmpty; } };
+#else
+    auto flush = [&]() { flush_table<SLOTS, WIDE>(A, w, s_key, s_cnt, s_min, s_gap); };
+#endif
+    auto maybe_flush = [&]() {
+        __syncthreads();
+        if (threadIdx.x == 0) s_flag = s_used > kFlushAt;
+        __syncthreads();
+        if (s_flag) {
+            flush();
+            if (threadIdx.x == 0) s_used = 0;
+            __syncthreads();
+        }
+    };
+    {
+        constexpr int kStep = kBlock * RPT;
+        Rows Ra, Rb;
+        const int t4 = (int)threadIdx.x * RPT;
+        fetch(Ra, r0 + t4);
+        for (int base = r0; base < r1; base += 2 * kStep) {
+            fetch(Rb, base + kStep + t4);
+            hash_rows(Ra, base);
+            if (base + kStep >= r1) break;
+            fetch(Ra, base + 2 * kStep + t4);
+            hash_rows(Rb, base + kStep);
+            if (base + 2 * kStep < r1) maybe_flush();
+        }
+    }
+    // the wave's leftovers: ring, reference count, dense counters — all through the same insert
+    if (q_tail != q_head) drain(q_tail - q_head);
+    {
+        unsigned long long key;
+        uint32_t gap;
+        make_key<WIDE>(rb0, rb1, rg, k, key, gap);
+        note_claims(insert(lane == 0 && n_ref != 0, key, gap, n_ref, first_ref));
+        for (int i0 = 0; i0 < 8 * k; i0 += 64) {
+            const int i = i0 + lane;
+            const uint32_t c = i < 8 * k ? d_cnt[wave][i] : 0u;
+            const uint32_t mn = i < 8 * k ? d_min[wave][i] : kEmpty;
+            const int j = i >> 3;
+            const uint32_t sym = (uint32_t)i & 7u, bit = 1u << (j & 31);
+            const uint32_t e0 = (rb0 & ~bit) | ((sym & 1u) ? bit : 0u), e1 = (rb1 & ~bit) | ((sym & 2u) ? bit : 0u), eg = (rg & ~bit) | ((sym & 4u) ? bit : 0u);
+            make_key<WIDE>(e0, e1, eg, k, key, gap);
+            note_claims(insert(c != 0, key, gap, c, mn));
+        }
+    }
+    __syncthreads();
+    stamp(2);
+    if (slice == 0 && A.patch_off) {
+        const int e0 = A.patch_off[w], e1 = A.patch_off[w + 1];
+        for (int eb = e0; eb < e1; eb += kBlock) {
+            const int e = eb + threadIdx.x;
+            bool go = false;
+            unsigned long long key = 0;
+            uint32_t gap = 0, row = 0;
+            if (e < e1) {
+                const uint32_t b0 = A.patch_words[3 * (size_t)e], b1 = A.patch_words[3 * (size_t)e + 1], g = A.patch_words[3 * (size_t)e + 2];
+                if (!(g & MP_WIN_SKIP)) { make_key<WIDE>(b0, b1, g & kmask, k, key, gap); row = (uint32_t)A.patch_rows[e]; go = true; }
+            }
+            (void)insert(go, key, gap, 1u, row);
         }
         __syncthreads();
     }
@@ -287,6 +660,7 @@ __global__ __launch_bounds__(kBlock) void hist_kernel(const HistArgs A) {
 struct CompactArgs {
     const unsigned long long *g_key;
     const uint32_t *g_cnt, *g_min;
+    const uint32_t *g_gap;        // gap words of flagged keys (k = 22..31), else null
     int32_t *g_idx;
     int g_slots, k;
     const int64_t *win_base;      // [W] first entry of the window's segment
@@ -296,41 +670,46 @@ struct CompactArgs {
     long long cap;
 };
 
-// occupied slots per window (a counter bumped at every claim would be ~2 x 10^6 atomics on 31 cache lines)
-__global__ __launch_bounds__(kBlock) void count_kernel(const unsigned long long *__restrict__ g_key, int g_slots, int32_t *__restrict__ used) {
-    __shared__ int s_n;
-    const int w = blockIdx.x;
-    if (threadIdx.x == 0) s_n = 0;
-    __syncthreads();
-    int n = 0;
-    for (int i = threadIdx.x; i < g_slots; i += kBlock) n += g_key[(size_t)w * g_slots + i] != kNoKey;
-    for (int sft = 32; sft >= 1; sft >>= 1) n += __shfl_xor(n, sft);
-    if ((threadIdx.x & 63) == 0) atomicAdd(&s_n, n);
-    __syncthreads();
-    if (threadIdx.x == 0) used[w] = s_n;
-}
-
-// The entropy gate's sums over a window's table (mp_set_entropy_gate): T = sum of the counts, S = sum of c log2 c — the entropy of the
-// window's k-mer distribution is log2 T - S / T whatever the order of the terms.  One workgroup per window.
-__global__ __launch_bounds__(kBlock) void gate_kernel(const unsigned long long *__restrict__ g_key, const uint32_t *__restrict__ g_cnt, int g_slots,
-                                                      double *__restrict__ sums) {
+// One pass over the tables for everything the host wants to know before it lays out the entries: the occupied slots of every window (a
+// counter bumped at every claim would be ~2 x 10^6 atomics on 31 cache lines) and the entropy gate's sums (mp_set_entropy_gate):
+// T = sum of the counts, S = sum of c log2 c — the entropy of the window's k-mer distribution is log2 T - S / T whatever the order of the
+// terms.  [r6] Rounds 2-5 ran two kernels of ONE workgroup per window, one slot per thread and trip (count_kernel, gate_kernel: 0.32 +
+// 3.3 ms at 10^6 rows, two read-backs); now a window's table is cut into `parts` pieces (grid = windows x parts), a thread has eight
+// slots in flight, and the per-piece partial sums (int count, two doubles) are added up on the host: one launch, one read-back.
+struct TableSums { double t, s; int32_t used, pad; };
+__global__ __launch_bounds__(kBlock) void table_sums_kernel(const unsigned long long *__restrict__ g_key, const uint32_t *__restrict__ g_cnt, int g_slots,
+                                                            int parts, int want_sums, TableSums *__restrict__ out) {
+    constexpr int U = 8;
     __shared__ double s_t[kBlock / 64], s_s[kBlock / 64];
-    const int w = blockIdx.x;
-    double t = 0, s = 0;
-    for (int i = threadIdx.x; i < g_slots; i += kBlock) {
-        const size_t at = (size_t)w * g_slots + i;
-        if (g_key[at] == kNoKey) continue;
-        const double c = (double)g_cnt[at];
-        t += c;
-        s += c * log2(c);
+    __shared__ int s_n[kBlock / 64];
+    const int w = blockIdx.x / parts, part = blockIdx.x % parts;
+    const int per = g_slots / parts;                          // g_slots and parts are powers of two, per >= kBlock
+    const size_t base = (size_t)w * g_slots + (size_t)part * per;
+    double t = 0, sum = 0;
+    int n = 0;
+    for (int i0 = threadIdx.x; i0 < per; i0 += U * kBlock) {
+        unsigned long long key[U];
+#pragma unroll
+        for (int u = 0; u < U; u++) key[u] = i0 + u * kBlock < per ? g_key[base + i0 + u * kBlock] : kNoKey;
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+            if (key[u] == kNoKey) continue;
+            n++;
+            if (want_sums) {
+                const double c = (double)g_cnt[base + i0 + u * kBlock];
+                t += c;
+                sum += c * log2(c);
+            }
+        }
     }
-    for (int sft = 32; sft >= 1; sft >>= 1) { t += __shfl_xor(t, sft); s += __shfl_xor(s, sft); }
-    if ((threadIdx.x & 63) == 0) { s_t[threadIdx.x >> 6] = t; s_s[threadIdx.x >> 6] = s; }
+    for (int sft = 32; sft >= 1; sft >>= 1) { t += __shfl_xor(t, sft); sum += __shfl_xor(sum, sft); n += __shfl_xor(n, sft); }
+    if ((threadIdx.x & 63) == 0) { s_t[threadIdx.x >> 6] = t; s_s[threadIdx.x >> 6] = sum; s_n[threadIdx.x >> 6] = n; }
     __syncthreads();
     if (threadIdx.x == 0) {
         double tt = 0, ss = 0;
-        for (int i = 0; i < kBlock / 64; i++) { tt += s_t[i]; ss += s_s[i]; }
-        sums[2 * w] = tt; sums[2 * w + 1] = ss;
+        int nn = 0;
+        for (int i = 0; i < kBlock / 64; i++) { tt += s_t[i]; ss += s_s[i]; nn += s_n[i]; }
+        out[blockIdx.x] = TableSums{tt, ss, nn, 0};
     }
 }
 
@@ -377,7 +756,7 @@ __global__ __launch_bounds__(kBlock) void compact_kernel(const CompactArgs A) {
             if (e < A.cap) {
                 A.b0[e] = (uint32_t)key[u] & kmask;
                 A.b1[e] = (uint32_t)(key[u] >> A.k) & kmask;
-                A.g[e] = (uint32_t)(key[u] >> (2 * A.k)) & kmask;
+                A.g[e] = A.g_gap ? ((key[u] & kGapFlag) ? A.g_gap[s] : 0u) : (uint32_t)(key[u] >> (2 * A.k)) & kmask;
                 A.count[e] = (int32_t)A.g_cnt[s];
                 A.first[e] = (int32_t)A.g_min[s];
             }
@@ -390,7 +769,8 @@ __global__ __launch_bounds__(kBlock) void compact_kernel(const CompactArgs A) {
 
 // per-row labels (index of the row's entry inside its window, -1 = not in the histogram): JSON side files only
 __global__ __launch_bounds__(kBlock) void label_kernel(const MsaArgs M, int p0, int k, const unsigned long long *__restrict__ g_key,
-                                                       const int32_t *__restrict__ g_idx, int g_slots, int32_t *__restrict__ labels) {
+                                                       const uint32_t *__restrict__ g_gap, const int32_t *__restrict__ g_idx, int g_slots,
+                                                       int32_t *__restrict__ labels) {
     const int per_win = M.n_pad / kBlock;
     const int w = blockIdx.x / per_win;
     const int r = (blockIdx.x % per_win) * kBlock + threadIdx.x;
@@ -400,12 +780,15 @@ __global__ __launch_bounds__(kBlock) void label_kernel(const MsaArgs M, int p0, 
     FlyView(M, p0 + w, k, kmask).load(r, b0, b1, g);
     int32_t lab = -1;
     if (!(g & MP_WIN_SKIP)) {
-        const unsigned long long key = (unsigned long long)b0 | ((unsigned long long)b1 << k) | ((unsigned long long)(g & kmask) << (2 * k));
+        unsigned long long key;
+        uint32_t gap;
+        if (g_gap) make_key<true>(b0, b1, g & kmask, k, key, gap);
+        else make_key<false>(b0, b1, g & kmask, k, key, gap);
         const uint32_t mask = (uint32_t)g_slots - 1u;
         uint32_t h = hash64(key) & mask;
         for (int probe = 0; probe < g_slots; probe++) {
             const unsigned long long o = g_key[(size_t)w * g_slots + h];
-            if (o == key) { lab = g_idx[(size_t)w * g_slots + h]; break; }
+            if (o == key && (!g_gap || !(key & kGapFlag) || g_gap[(size_t)w * g_slots + h] == gap)) { lab = g_idx[(size_t)w * g_slots + h]; break; }
             if (o == kNoKey) break;
             h = (h + 1) & mask;
         }
@@ -553,23 +936,54 @@ int alloc_entries(mp_ctx *c, int64_t cap) {
     return MP_OK;
 }
 
-// k <= 21: LDS-combined global hash tables straight from the planes
+// k <= 31: LDS-combined global hash tables straight from the planes (k <= 21: the key is the 3k bits; k = 22..31: 2k bits + gap word)
 int unique_packed(mp_ctx *c, int64_t cap, int32_t want_labels, int64_t *n_entries) {
     const size_t W = (size_t)c->n_win, np = (size_t)c->n_pad;
+    const bool wide_key = !c->p64;
     int rc;
     Lap lap(c->stream);
     if ((rc = dev_alloc(c, &c->u_over, W))) return rc;
     if ((rc = dev_alloc(c, &c->u_wcount, W))) return rc;
     if ((rc = dev_alloc(c, &c->u_wbase, W))) return rc;
     int32_t *d_cursor = nullptr;
-    // a table holds every distinct k-mer of a window; first try: twice the rows, capped at max(16384, rows / 8) slots —
-    // 24 bytes per slot, 3 GB for 982 windows of 10^6 rows, where the deepest windows hold > 14000 distinct k-mers and the
-    // 16384-slot first try used to be thrown away (0.32 s of a second pass)
+    // a table holds every distinct k-mer of a window; first try: twice the rows, capped at max(16384, rows / 16) slots (the deepest
+    // windows of the 10^6-row bench alignment hold ~14000 distinct k-mers; [r6] rounds 2-5 capped at rows / 8: every pass over the
+    // tables — fill, sums, compaction — is proportional to the slots, 2.6 GB of them at 10^6 rows)
     int slots = kBlock, cap_slots = 16384;
-    while (cap_slots < c->n_rows / 8) cap_slots <<= 1;
+    while (cap_slots < c->n_rows / 16) cap_slots <<= 1;
     while (slots < 2 * c->n_rows + 64 && slots < cap_slots) slots <<= 1;
     if (const char *e = getenv("MP_HIST_SLOTS")) { int s = atoi(e); if (s >= kBlock && (s & (s - 1)) == 0) slots = s; }
+    const bool gate = c->gate_threshold > 0 && !want_labels && !getenv("MP_NO_DEVICE_GATE");
     std::vector<int32_t> used(W), over(W);
+    std::vector<double> sums(2 * W, 0.0);
+    // E per window for the gate (below): an exception row with more than v gaps is one gap_sequence entry, any other counts once per
+    // expansion (V20:689-707).  Host work that needs nothing from the device: it runs while the histogram kernel does.
+    std::vector<double> extra;
+    auto count_extra = [&]() {
+        extra.assign(W, 0.0);
+        static const int kSetSize[16] = {1, 1, 1, 2, 1, 2, 2, 3, 1, 2, 2, 3, 2, 3, 3, 4};
+        const size_t n_ex = c->ex_host.size();
+        const int T = (int)std::max<size_t>(1, std::min<size_t>(8, n_ex / 8192));
+        std::vector<std::vector<double>> part((size_t)T);
+        const int k = c->k, v = c->v;
+        run_on_threads(T, [&](int t) {
+            std::vector<double> &mine = part[(size_t)t];
+            mine.assign(W, 0.0);
+            for (size_t i = n_ex * (size_t)t / (size_t)T, i1 = n_ex * (size_t)(t + 1) / (size_t)T; i < i1; i++) {
+                const ExRec &x = c->ex_host[i];
+                int gaps = 0;
+                double n_exp = 1;
+                for (int j = 0; j < k; j++) {
+                    const uint32_t code = (uint32_t)((x.q[j >> 4] >> (4 * (j & 15))) & 15u);
+                    gaps += code == 0;
+                    n_exp *= kSetSize[code];
+                }
+                if (x.win >= 0 && (size_t)x.win < W) mine[(size_t)x.win] += gaps > v ? 1.0 : n_exp;
+            }
+        });
+        for (int t = 0; t < T; t++)
+            for (size_t w = 0; w < W; w++) extra[w] += part[(size_t)t][w];
+    };
     for (int attempt = 0; attempt < 8; attempt++) {
         const size_t n = W * (size_t)slots;
         c->g_slots = slots;
@@ -577,12 +991,13 @@ int unique_packed(mp_ctx *c, int64_t cap, int32_t want_labels, int64_t *n_entrie
         if ((rc = dev_alloc(c, &c->g_cnt, n))) return rc;
         if ((rc = dev_alloc(c, &c->g_min, n))) return rc;
         if ((rc = dev_alloc(c, &c->g_idx, n))) return rc;
-        const FillSeg init[5] = {{c->g_key, sizeof(unsigned long long) * n, 0xFFFFFFFFu}, {c->g_cnt, sizeof(uint32_t) * n, 0u}, {c->g_min, sizeof(uint32_t) * n, 0xFFFFFFFFu},
-                                 {c->u_wcount, sizeof(int32_t) * W, 0u}, {c->u_over, sizeof(int32_t) * W, 0u}};
+        if (wide_key && (rc = dev_alloc(c, &c->g_gap, n))) return rc;
+        const FillSeg init[6] = {{c->g_key, sizeof(unsigned long long) * n, 0xFFFFFFFFu}, {c->g_cnt, sizeof(uint32_t) * n, 0u}, {c->g_min, sizeof(uint32_t) * n, 0xFFFFFFFFu},
+                                 {c->u_wcount, sizeof(int32_t) * W, 0u}, {c->u_over, sizeof(int32_t) * W, 0u}, {c->g_gap, sizeof(uint32_t) * n, 0xFFFFFFFFu}};
         lap("unique: table alloc");
-        if ((rc = fill_segments(c, init, 5))) return rc;
+        if ((rc = fill_segments(c, init, wide_key ? 6 : 5))) return rc;
         lap("unique: table fill");
-        HistArgs A{msa_args(c), c->p0, c->k, c->n_win, 0, 0, 0, c->g_key, c->g_cnt, c->g_min, slots, c->u_over,
+        HistArgs A{msa_args(c), c->p0, c->k, c->n_win, 0, 0, 0, c->g_key, c->g_cnt, c->g_min, c->g_gap, slots, c->u_over,
                    c->n_patch ? c->patch_off : (const int32_t *)nullptr, c->patch_rows, c->patch_words, nullptr};
         // enough workgroups to fill 256 CUs several times over, slices of at least 4096 rows
         int n_slices = (int)std::max<size_t>(1, std::min<size_t>((np + 4095) / 4096, (8192 + W - 1) / W));
@@ -602,10 +1017,19 @@ int unique_packed(mp_ctx *c, int64_t cap, int32_t want_labels, int64_t *n_entrie
                 HIPCK(c, hipMalloc((void **)&A.prof, (size_t)blocks * 64));
                 HIPCK(c, hipMemsetAsync(A.prof, 0, (size_t)blocks * 64, c->stream));
             }
-            int lds_slots = 2048;
-            if (const char *e = getenv("MP_HIST_LDS")) lds_slots = atoi(e);
-            if (lds_slots == 4096) hipLaunchKernelGGL((hist_kernel<4096, 2>), dim3(blocks), dim3(kBlock), 0, c->stream, A);
-            else hipLaunchKernelGGL((hist_kernel<2048, 1>), dim3(blocks), dim3(kBlock), 0, c->stream, A);
+            int folds = 2;                                        // MP_HIST_FOLDS: A/B of the wave-level folding (0 = consensus only)
+            if (const char *e = getenv("MP_HIST_FOLDS")) folds = atoi(e);
+            if (!(getenv("MP_HIST_V1") && getenv("MP_HIST_V1")[0] == '1')) {                          // [r6] reference count + dense single-difference counters + dense inserts
+                if (wide_key) hipLaunchKernelGGL((hist2_kernel<1024, true>), dim3(blocks), dim3(kBlock), 0, c->stream, A);
+                else hipLaunchKernelGGL((hist2_kernel<1024, false>), dim3(blocks), dim3(kBlock), 0, c->stream, A);
+            } else if (wide_key) {
+                if (folds <= 1) hipLaunchKernelGGL((hist_kernel<2048, true, 1>), dim3(blocks), dim3(kBlock), 0, c->stream, A);
+                else hipLaunchKernelGGL((hist_kernel<2048, true, 2>), dim3(blocks), dim3(kBlock), 0, c->stream, A);
+            } else {
+                if (folds <= 1) hipLaunchKernelGGL((hist_kernel<2048, false, 1>), dim3(blocks), dim3(kBlock), 0, c->stream, A);
+                else if (folds == 2) hipLaunchKernelGGL((hist_kernel<2048, false, 2>), dim3(blocks), dim3(kBlock), 0, c->stream, A);
+                else hipLaunchKernelGGL((hist_kernel<2048, false, 3>), dim3(blocks), dim3(kBlock), 0, c->stream, A);
+            }
             if (prof_path) {
                 std::vector<unsigned long long> h((size_t)blocks * 8);
                 HIPCK(c, hipStreamSynchronize(c->stream));
@@ -615,53 +1039,52 @@ int unique_packed(mp_ctx *c, int64_t cap, int32_t want_labels, int64_t *n_entrie
                 if (FILE *f = fopen(prof_path, "wb")) { fwrite(h.data(), 8, h.size(), f); fclose(f); }
             }
         }
-        lap("unique: histogram");
-        hipLaunchKernelGGL(count_kernel, dim3((unsigned)W), dim3(kBlock), 0, c->stream, (const unsigned long long *)c->g_key, slots, c->u_wcount);
         HIPCK(c, hipGetLastError());
-        HIPCK(c, hipMemcpyAsync(used.data(), c->u_wcount, sizeof(int32_t) * W, hipMemcpyDeviceToHost, c->stream));
-        HIPCK(c, hipMemcpyAsync(over.data(), c->u_over, sizeof(int32_t) * W, hipMemcpyDeviceToHost, c->stream));
-        HIPCK(c, hipStreamSynchronize(c->stream));
-        lap("unique: count + d2h");
+        // occupied slots and the gate's sums in one pass over the tables, one read-back
+        int parts = 1;
+        while (parts < 16 && slots / (parts * 2) >= 8 * kBlock) parts <<= 1;
+        TableSums *d_sums = nullptr;
+        if ((rc = dev_alloc(c, &d_sums, W * (size_t)parts))) return rc;
+        hipLaunchKernelGGL(table_sums_kernel, dim3((unsigned)(W * (size_t)parts)), dim3(kBlock), 0, c->stream, (const unsigned long long *)c->g_key,
+                           (const uint32_t *)c->g_cnt, slots, parts, gate ? 1 : 0, d_sums);
+        std::vector<TableSums> hs(W * (size_t)parts);
+        hipError_t e = hipGetLastError();
+        if (e == hipSuccess) e = hipMemcpyAsync(hs.data(), d_sums, sizeof(TableSums) * hs.size(), hipMemcpyDeviceToHost, c->stream);
+        if (e == hipSuccess) e = hipMemcpyAsync(over.data(), c->u_over, sizeof(int32_t) * W, hipMemcpyDeviceToHost, c->stream);
+        if (gate && extra.empty()) count_extra();              // (host work beside the kernels)
+        if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+        dev_free(c, &d_sums, W * (size_t)parts);
+        if (e != hipSuccess) return fail(c, MP_ERR_DEVICE, "histogram tables: %s", hipGetErrorString(e));
+        lap("unique: histogram + sums + d2h");
         bool any_over = false;
-        for (size_t w = 0; w < W; w++) any_over |= over[w] != 0 || used[w] > slots - slots / 8;
+        for (size_t w = 0; w < W; w++) {
+            int32_t u = 0;
+            double t = 0, sum = 0;
+            for (int q = 0; q < parts; q++) { const TableSums &x = hs[w * (size_t)parts + (size_t)q]; u += x.used; t += x.t; sum += x.s; }
+            used[w] = u; sums[2 * w] = t; sums[2 * w + 1] = sum;
+            any_over |= over[w] != 0 || u > slots - slots / 8;
+        }
         if (!any_over) break;
         // a window has (nearly) as many distinct k-mers as slots: start over with tables 8x the size (rare: random input)
-        dev_free(c, &c->g_key, n); dev_free(c, &c->g_cnt, n); dev_free(c, &c->g_min, n); dev_free(c, &c->g_idx, n);
+        dev_free(c, &c->g_key, n); dev_free(c, &c->g_cnt, n); dev_free(c, &c->g_min, n); dev_free(c, &c->g_idx, n); dev_free(c, &c->g_gap, n);
         if (attempt == 7 || (size_t)slots * 8 > ((size_t)1 << 28)) return fail(c, MP_ERR_NOMEM, "histogram tables do not converge");
         slots *= 8;
     }
     // The entropy gate on the device (armed by mp_set_entropy_gate, no labels wanted): V20:723 rejects a window whose "Entropy of total",
     // rounded to two decimals, exceeds the threshold — and more than half of the windows of a deep alignment end there, after the host has
     // decoded, merged and ordered all their entries (they are the windows with the MOST entries).  The tables hold what the host would
-    // sum, except the rows with an IUPAC code (E of them, counted with their expansions): the true distribution differs from the
-    // table's by a total-variation distance of at most theta = E / (T + E), so the two entropies differ by at most
-    // theta log2(T + E) + h2(theta) (Fannes-Audenaert), and rounding moves the value by at most 0.005.  A window whose table entropy
-    // clears threshold + 0.005 by more than that bound is rejected here, for certain; every other window goes to the host as before,
-    // which decides exactly.  A rejected window's entries are not compacted, not read back, not planned.
+    // sum, except the rows with an IUPAC code: X such rows add E >= X unit masses (one per expansion; V20:689-707).  The host's tBit
+    // (V20:602-614) divides every count by N = cover_number + gap_sequence_number — ROWS, N = T + X — while the masses sum to
+    // M = T + E >= N: with q the normalised distribution of the masses and r = M / N, tBit = -sum (c / N) log2(c / N) = r (H(q) - log2 r).
+    // (a) H(q) is within theta log2(T + E) + h2(theta), theta = E / (T + E), of the table's entropy H = log2 T - S / T (q = (1 - theta) p
+    // + theta e: total-variation distance <= theta; Fannes-Audenaert), 1e-6 covers the floating-point order.  (b) [r6, advisor] r is in
+    // [1, (T + E) / T]; f(r) = r (H - log2 r) is concave in r, so over that interval it is at least min(f(1), f(r_max)), and it rises
+    // with H.  Hence tBit >= min(Hlow, r_max (Hlow - log2 r_max)) with Hlow = H - bound; rounding moves tBit by at most 0.005.  A window
+    // whose lower bound clears threshold + 0.005 is rejected here, for certain (tests/test_gate_bound.py compares with the exact host
+    // value on IUPAC-heavy windows); every other window goes to the host as before, which decides exactly.  A rejected window's entries
+    // are not compacted, not read back, not planned.
     c->h_wskip.clear();
-    if (c->gate_threshold > 0 && !want_labels && !getenv("MP_NO_DEVICE_GATE")) {
-        double *d_sums = nullptr;
-        if ((rc = dev_alloc(c, &d_sums, 2 * W))) return rc;
-        hipLaunchKernelGGL(gate_kernel, dim3((unsigned)W), dim3(kBlock), 0, c->stream, (const unsigned long long *)c->g_key, (const uint32_t *)c->g_cnt, slots, d_sums);
-        std::vector<double> sums(2 * W);
-        hipError_t e = hipGetLastError();
-        if (e == hipSuccess) e = hipMemcpyAsync(sums.data(), d_sums, sizeof(double) * 2 * W, hipMemcpyDeviceToHost, c->stream);
-        if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
-        dev_free(c, &d_sums, 2 * W);
-        if (e != hipSuccess) return fail(c, MP_ERR_DEVICE, "entropy gate: %s", hipGetErrorString(e));
-        // E per window: an exception row with more than v gaps is one gap_sequence entry, any other counts once per expansion (V20:689-707)
-        std::vector<double> extra(W, 0.0);
-        static const int kSetSize[16] = {1, 1, 1, 2, 1, 2, 2, 3, 1, 2, 2, 3, 2, 3, 3, 4};
-        for (const ExRec &x : c->ex_host) {
-            int gaps = 0;
-            double n_exp = 1;
-            for (int j = 0; j < c->k; j++) {
-                const uint32_t code = (uint32_t)((x.q[j >> 4] >> (4 * (j & 15))) & 15u);
-                gaps += code == 0;
-                n_exp *= kSetSize[code];
-            }
-            if (x.win >= 0 && (size_t)x.win < W) extra[(size_t)x.win] += gaps > c->v ? 1.0 : n_exp;
-        }
+    if (gate) {
         c->h_wskip.assign(W, 0);
         size_t n_skip = 0;
         for (size_t w = 0; w < W; w++) {
@@ -670,10 +1093,12 @@ int unique_packed(mp_ctx *c, int64_t cap, int32_t want_labels, int64_t *n_entrie
             const double H = std::log2(T) - S / T, theta = E / (T + E);
             const double h2 = theta > 0 && theta < 1 ? -theta * std::log2(theta) - (1 - theta) * std::log2(1 - theta) : 0.0;
             const double bound = theta * std::log2(T + E) + h2 + 1e-6;
-            if (H - bound > c->gate_threshold + 0.005) { c->h_wskip[w] = 1; used[w] = 0; n_skip++; }
+            const double Hq = H - bound, r_max = (T + E) / T;
+            const double low = std::min(Hq, r_max * (Hq - std::log2(r_max)));
+            if (low > c->gate_threshold + 0.005) { c->h_wskip[w] = 1; used[w] = 0; n_skip++; }
         }
         if (getenv("MP_TRACE")) fprintf(stderr, "[mprime] unique: entropy gate on the device rejected %zu of %zu windows\n", n_skip, W);
-        lap("unique: entropy gate");
+        lap("unique: entropy gate (host part)");
     }
     c->h_wbase.resize(W); c->h_wcount.resize(W);
     int64_t total = 0;
@@ -686,16 +1111,16 @@ int unique_packed(mp_ctx *c, int64_t cap, int32_t want_labels, int64_t *n_entrie
     if (total > cap) { c->u_n = 0; return fail(c, MP_ERR_CAPACITY, "unique table needs %lld entries", (long long)total); }
     if ((rc = alloc_entries(c, std::max<int64_t>(total, 1)))) return rc;
     if ((rc = dev_alloc(c, &d_cursor, W))) return rc;
-    HIPCK(c, hipMemcpy(c->u_wbase, dev_base.data(), sizeof(int64_t) * W, hipMemcpyHostToDevice));
+    HIPCK(c, hipMemcpyAsync(c->u_wbase, dev_base.data(), sizeof(int64_t) * W, hipMemcpyHostToDevice, c->stream));
     HIPCK(c, hipMemsetAsync(d_cursor, 0, sizeof(int32_t) * W, c->stream));
-    CompactArgs CA{c->g_key, c->g_cnt, c->g_min, c->g_idx, c->g_slots, c->k, c->u_wbase, d_cursor,
+    CompactArgs CA{c->g_key, c->g_cnt, c->g_min, c->g_gap, c->g_idx, c->g_slots, c->k, c->u_wbase, d_cursor,
                    c->u_b0, c->u_b1, c->u_g, c->u_count, c->u_first, (long long)c->u_cap};
     hipLaunchKernelGGL(compact_kernel, dim3((unsigned)W), dim3(kBlock), 0, c->stream, CA);
     HIPCK(c, hipGetLastError());
     if (want_labels) {
         if ((rc = dev_alloc(c, &c->labels, W * np))) return rc;
         hipLaunchKernelGGL(label_kernel, dim3((unsigned)((np / kBlock) * W)), dim3(kBlock), 0, c->stream, msa_args(c), c->p0, c->k,
-                           (const unsigned long long *)c->g_key, (const int32_t *)c->g_idx, c->g_slots, c->labels);
+                           (const unsigned long long *)c->g_key, (const uint32_t *)c->g_gap, (const int32_t *)c->g_idx, c->g_slots, c->labels);
         HIPCK(c, hipGetLastError());
     }
     HIPCK(c, hipStreamSynchronize(c->stream));
@@ -781,7 +1206,7 @@ int mp_window_unique(mp_ctx *c, int64_t cap, int32_t want_labels, int64_t *n_ent
     HIPCK(c, hipSetDevice(c->dev));
     free_unique(c);
     c->h_wskip.clear();
-    if (c->p64) return unique_packed(c, cap, want_labels, n_entries);
+    if (!c->wide && !getenv("MP_HIST_REP_ROWS")) return unique_packed(c, cap, want_labels, n_entries);     // k <= 31
     return c->wide ? unique_rep_rows<uint64_t>(c, cap, want_labels, n_entries) : unique_rep_rows<uint32_t>(c, cap, want_labels, n_entries);
 }
 

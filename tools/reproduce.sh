@@ -1,0 +1,49 @@
+#!/bin/bash
+# One entry point for every measurement that ends up under profiles/ (round 6 on; the per-round r04_*/r05_* command logs are gone).
+#   tools/reproduce.sh <target> [args]      — run ON the GPU box (through gpurun), writes under gpurun_out/r06/<target>/
+# targets: see the case statement; each names the profiles/ file(s) it produces.
+set -u
+T=${1:?target}; shift || true
+O=gpurun_out/r06/$T
+mkdir -p $O
+cd /tmp && export TMPDIR=/tmp && cd - > /dev/null
+laps() {   # laps <rows> <k>: stats line + library / Python laps of the second run() of a process
+  MP_TRACE_PY=1 MP_TRACE=1 python tools/profile_run.py $1 $2 2>&1 | grep "^{\|^\[core\]\|^\[mprime\]" | tail -48
+}
+case $T in
+hist_tests)      # the histogram paths + the suites that go through them
+  timeout 1500 python -m pytest tests/test_hist_paths.py tests/test_hip_parity.py tests/test_core_golden.py -x -q -m gpu 2>&1 | tail -15 | tee $O/pytest.txt ;;
+hist_ab)         # profiles/r06_hist_folds.txt: wave-level folding rounds of hist_kernel, k = 18 / 22, both depths
+  for rows in 131072 1048576; do for k in 18 22; do for f in 1 2 3; do
+    echo "# rows $rows k $k MP_HIST_FOLDS=$f"
+    MP_HIST_FOLDS=$f MP_TRACE=1 python tools/profile_run.py $rows $k 2>&1 | grep "unique:\|^{" | tail -8
+  done; done; done 2>&1 | tee $O/hist_folds.txt ;;
+run_laps)        # profiles/r06_run_laps.txt
+  (for rows in 131072 1048576; do for k in 18 22; do echo "# rows $rows k $k"; laps $rows $k; done; done) 2>&1 | tee $O/run_laps.txt ;;
+hist_where)      # where hist_kernel's time goes: phase stamps of every workgroup, kernel trace of the core step, LDS / wait counters
+  for rows in 131072 1048576; do
+    echo "# rows $rows: MP_HIST_PROF stamps"
+    MP_HIST_PROF=$O/stamps_$rows.bin python tools/pipeline_scale.py --rows $rows > /dev/null 2>&1; python tools/hist_prof.py $O/stamps_$rows.bin
+    echo "# rows $rows: rocprofv3 --kernel-trace --stats of the core step"
+    rocprofv3 --kernel-trace --stats -d $O/prof_$rows/trace -o t -- python tools/pipeline_scale.py --rows $rows > /dev/null 2>&1
+    python tools/summarize_profile.py $O/prof_$rows 2>/dev/null | head -30
+    echo "# rows $rows: counters of hist_kernel"
+    python tools/pmc_kernel.py --kernel hist_kernel --rows $rows --out $O/pmc_$rows
+  done 2>&1 | tee $O/hist_where.txt ;;
+hist_variants)   # A/B of compile-time knobs of unique.hip: tools/build_variant.sh <tag> unique.hip -D... beforehand, tags as arguments ("product" = the shipped build)
+  for round in 1 2; do for v in "$@"; do for rows in 131072 1048576; do
+    if [ $v = product ]; then unset MPRIME_LIBRARY MP_HOST_LIB; else export MPRIME_LIBRARY=$PWD/tools/_build/libmprime_hip_$v.so MP_HOST_LIB=$PWD/tools/_build/libmprime_hip_$v.so; fi
+    echo "# $v rows $rows"; MP_TRACE=1 python tools/profile_run.py $rows 18 2>&1 | grep "histogram + sums\|^{" | tail -2
+  done; done; done 2>&1 | tee $O/hist_variants.txt ;;
+hist_v1v2)       # hist2_kernel (default) against hist_kernel (MP_HIST_V1=1), k = 18 / 22, both depths
+  for round in 1 2; do for rows in 131072 1048576; do for k in 18 22; do for v1 in "" 1; do
+    echo "# rows $rows k $k MP_HIST_V1=$v1"; MP_HIST_V1=$v1 MP_TRACE=1 python tools/profile_run.py $rows $k 2>&1 | grep "histogram + sums\|^{" | tail -2
+  done; done; done; done 2>&1 | tee $O/hist_v1v2.txt ;;
+hist_exp)        # experiment builds of unique.hip (results are WRONG: timing only): kernel time of hist2_kernel under rocprofv3, tags as arguments
+  for v in "$@"; do for rows in 131072 1048576; do
+    if [ $v = product ]; then unset MPRIME_LIBRARY MP_HOST_LIB; else export MPRIME_LIBRARY=$PWD/tools/_build/libmprime_hip_$v.so MP_HOST_LIB=$PWD/tools/_build/libmprime_hip_$v.so; fi
+    rm -rf $O/t_${v}_$rows; rocprofv3 --kernel-trace --stats -d $O/t_${v}_$rows/trace -o t -- python tools/hist_only.py $rows 18 > /dev/null 2>&1
+    echo "# $v rows $rows"; python tools/summarize_profile.py $O/t_${v}_$rows 2>/dev/null | grep "hist\|table_sums\|compact"
+  done; done 2>&1 | tee $O/hist_exp.txt ;;
+*) echo "unknown target $T"; exit 2 ;;
+esac
