@@ -301,6 +301,7 @@ def main():
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--no-variants", action="store_true")
     ap.add_argument("--no-pipeline", action="store_true", help="N = 1: skip the `pipeline` block (NN_degenerate.run() on the same rows)")
+    ap.add_argument("--no-side", action="store_true", help="N = 1: skip the `side_steps` block (dimer scan, in-silico PCR, k-mismatch scan: tools/side_bench.py)")
     ap.add_argument("--no-shard", "--no-full", dest="no_shard", action="store_true",
                     help="N = 1: skip the weak_shard block (the 131072-row shard of the 8-GPU job)")
     ap.add_argument("--bucket", type=int, default=4, help="steps per collective of the bucketed side measurement (N > 1)")
@@ -510,6 +511,16 @@ def main():
                         "reach if the all-reduce of the counters costs nothing (it is overlapped with the next step's kernel: dist.StepBuckets); north_star asks >= 6"}
     if rank == 0 and world == 1 and any(isinstance(p, dict) and p.get("tsv_equal_oracle") is False for p in res.get("pipeline", {}).values()):
         res["parity_checked"] = False
+    # N = 1: the steps either side of the core step, each with its checker leg — detail file only
+    if rank == 0 and world == 1 and not a.no_side:
+        try:
+            sys.path.insert(0, os.path.join(REPO, "tools"))
+            import side_bench
+            res["side_steps"] = side_bench.run(lib, local)
+            if any(isinstance(b, dict) and b.get("parity_checked") is False for b in res["side_steps"].values()):
+                res["parity_checked"] = False
+        except Exception as e:                  # noqa: BLE001 — a side measurement must not take the headline line with it
+            res["side_steps"] = {"error": f"{type(e).__name__}: {e}"}
     if rank == 0:
         emit(res)
     if world > 1:

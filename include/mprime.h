@@ -308,6 +308,26 @@ int mp_kmm_scan(mp_ctx *ctx, const uint8_t *bytes, const int64_t *row_off, int32
                 const uint8_t *pat_codes, const int32_t *pat_off, int32_t max_mismatch, int32_t term, int64_t cap_hits,
                 int32_t *hits, int64_t *n_hits);
 
+/* (8b) the resident sequence store shared by the scans of (7) and (8) — SURVEY §8f-4 ----------------------------------------- */
+/* The steps either side of the core step read the SAME unaligned sequence database more than once: extract_PCR_product_V1.py:189-216
+ * searches it for every primer pair, primer_coverage_validation_by_BWT_V9.py:264-300 maps every primer set against it.  mp_pcr_scan
+ * and mp_kmm_scan take the database as ASCII bytes per call (1 byte per base over PCIe and through the kernel's packing loop, every
+ * time).  mp_seq_load uploads it ONCE into the context and packs it on the device: per sequence, 64-bit words of 32 bases — a CODE
+ * word (2 bits per base, A0 C1 G2 T3, case folded) and a FLAG word (bit 2j: base j is not A/C/G/T in either case, or lies past the
+ * end of the sequence; bit 2j+1: base j is a lower-case letter) — 4 bits per base, everything both scans need: the PCR search is
+ * case sensitive as the reference's re.search is (a lower-case base matches no expansion: it tests both flag bits), the k-mismatch
+ * scan upper-cases as bowtie2 does (it tests bit 2j only).  The bytes stay in HBM beside the words for the rare fall-backs that walk
+ * characters (a pair table of more than 4096 expansions, a sequence whose occurrence list overflows).  The *_resident scans are
+ * mp_pcr_scan / mp_kmm_scan on the stored database: same arguments minus the text, same results bit for bit.  One store per context;
+ * a second mp_seq_load replaces it, mp_seq_free / mp_destroy release it. */
+int mp_seq_load(mp_ctx *ctx, const uint8_t *bytes, const int64_t *row_off, int32_t n_rows);
+int mp_seq_free(mp_ctx *ctx);
+/* n_rows of the store, its bases, and the bytes it holds on the device (words + characters + offsets) */
+int mp_seq_info(mp_ctx *ctx, int32_t *n_rows, int64_t *n_bases, int64_t *device_bytes);
+int mp_pcr_scan_resident(mp_ctx *ctx, int32_t n_pairs, const uint8_t *codes, const int32_t *off, int32_t *out);
+int mp_kmm_scan_resident(mp_ctx *ctx, int32_t n_patterns, const uint8_t *pat_codes, const int32_t *pat_off, int32_t max_mismatch,
+                         int32_t term, int64_t cap_hits, int32_t *hits, int64_t *n_hits);
+
 /* (9) row shards over several GPUs — SURVEY §8e --------------------------------------------------------------------------- */
 /* The reference is one process (its -p pool is inert, V20:1143).  Here every O(N) quantity of the path is a sum over sequences,
  * so N processes (one per GPU) each load a contiguous block of the alignment's rows (mp_reserve_columns + mp_load_msa), build

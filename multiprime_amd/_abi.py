@@ -67,6 +67,11 @@ SYMBOLS = [
     ("mp_pair_coverage", C.c_int, [_p, C.c_int32, C.c_int32, _p, _p, C.c_int64, _p, _p]),
     ("mp_pcr_scan", C.c_int, [_p, _p, _p, C.c_int32, C.c_int32, _p, _p, _p]),
     ("mp_kmm_scan", C.c_int, [_p, _p, _p, C.c_int32, C.c_int32, _p, _p, C.c_int32, C.c_int32, C.c_int64, _p, C.POINTER(C.c_int64)]),
+    ("mp_seq_load", C.c_int, [_p, _p, _p, C.c_int32]),
+    ("mp_seq_free", C.c_int, [_p]),
+    ("mp_seq_info", C.c_int, [_p, C.POINTER(C.c_int32), C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),
+    ("mp_pcr_scan_resident", C.c_int, [_p, C.c_int32, _p, _p, _p]),
+    ("mp_kmm_scan_resident", C.c_int, [_p, C.c_int32, _p, _p, C.c_int32, C.c_int32, C.c_int64, _p, C.POINTER(C.c_int64)]),
     ("mp_comm_unique_id", C.c_int, [_p]),
     ("mp_comm_init", C.c_int, [_p, C.c_int32, C.c_int32, _p]),
     ("mp_comm_destroy", C.c_int, [_p]),
@@ -536,6 +541,45 @@ class Context:
             n = C.c_int64(0)
             self._ck(self.d.mp_kmm_scan(self.h, _ptr(data), _ptr(row_off), len(row_off) - 1, len(pat_off) - 1, _ptr(pat_codes),
                                         _ptr(pat_off), int(max_mismatch), int(term), cap, _ptr(hits), C.byref(n)))
+            if n.value <= cap:
+                h = hits[: n.value]
+                return h[np.lexsort((h[:, 3], h[:, 2], h[:, 1], h[:, 0]))] if len(h) else h
+            cap = int(n.value)
+
+    # (8b) the resident sequence store
+    def seq_load(self, data, row_off):
+        """The unaligned database of the PCR / k-mismatch scans, uploaded and packed once (mp_seq_load); the *_resident scans use it."""
+        data = np.ascontiguousarray(data, dtype=np.uint8)
+        row_off = np.ascontiguousarray(row_off, dtype=np.int64)
+        self._ck(self.d.mp_seq_load(self.h, _ptr(data) if len(data) else None, _ptr(row_off), len(row_off) - 1))
+
+    def seq_free(self):
+        self._ck(self.d.mp_seq_free(self.h))
+
+    def seq_info(self):
+        """(sequences, bases, bytes on the device) of the store."""
+        n, b, d = C.c_int32(0), C.c_int64(0), C.c_int64(0)
+        self._ck(self.d.mp_seq_info(self.h, C.byref(n), C.byref(b), C.byref(d)))
+        return n.value, b.value, d.value
+
+    def pcr_scan_resident(self, codes, off) -> np.ndarray:
+        """pcr_scan on the stored database."""
+        codes = np.ascontiguousarray(codes, dtype=np.uint8)
+        off = np.ascontiguousarray(off, dtype=np.int32)
+        n_rows, n_pairs = self.seq_info()[0], (len(off) - 1) // 2
+        out = np.full((max(n_pairs, 1), max(n_rows, 1), 4), -1, np.int32)
+        self._ck(self.d.mp_pcr_scan_resident(self.h, n_pairs, _ptr(codes), _ptr(off), _ptr(out)))
+        return out[:n_pairs, :n_rows]
+
+    def kmm_scan_resident(self, pat_codes, pat_off, max_mismatch: int, term: int, cap: int = 1 << 20) -> np.ndarray:
+        """kmm_scan on the stored database."""
+        pat_codes = np.ascontiguousarray(pat_codes, dtype=np.uint8)
+        pat_off = np.ascontiguousarray(pat_off, dtype=np.int32)
+        while True:
+            hits = np.empty((max(cap, 1), 4), np.int32)
+            n = C.c_int64(0)
+            self._ck(self.d.mp_kmm_scan_resident(self.h, len(pat_off) - 1, _ptr(pat_codes), _ptr(pat_off), int(max_mismatch), int(term), cap,
+                                                 _ptr(hits), C.byref(n)))
             if n.value <= cap:
                 h = hits[: n.value]
                 return h[np.lexsort((h[:, 3], h[:, 2], h[:, 1], h[:, 0]))] if len(h) else h

@@ -285,6 +285,7 @@ void mp_destroy(mp_ctx *c) {
     (void)hipDeviceSynchronize();
     free_comm(c);
     free_msa(c);
+    free_seq(c);
     dev_free(c, &c->tmp_out, (size_t)c->tmp_out_n);
     dev_free(c, &c->stats_buf, c->stats_buf_n);
     if (getenv("MP_TRACE")) fprintf(stderr, "[mprime] device blocks: %lld reused, %lld from the runtime, %zu waiting (%.1f MB)\n", c->pool_hits, c->pool_misses,

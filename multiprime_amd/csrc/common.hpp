@@ -227,6 +227,14 @@ struct mp_ctx {
     uint8_t *h_stage = nullptr;              // host_map() memory
     size_t h_stage_bytes = 0;
     bool h_stage_pinned = false;             // registered with the runtime (hipHostRegister): copies into it are plain DMA
+    // the resident sequence store (mp_seq_load, scan.hip): the unaligned database of the PCR / k-mismatch scans
+    uint8_t *sq_bytes = nullptr;             // the characters as loaded (fall-back paths only)
+    int64_t *sq_roff = nullptr;              // [sq_n + 1] byte offsets
+    unsigned long long *sq_code = nullptr, *sq_flag = nullptr;   // [sq_words] 32 bases per word: 2-bit codes / {not ACGT, lower case} flags
+    int64_t *sq_woff = nullptr;              // [sq_n + 1] word offsets
+    int32_t sq_n = 0;
+    size_t sq_total = 0, sq_words = 0;
+    std::vector<int64_t> sq_roff_host;
     // row-shard collectives (comm.hip): an RCCL communicator (ncclComm_t) when n_ranks > 1
     void *comm = nullptr;
     int n_ranks = 0, rank = 0;               // n_ranks 0: mp_comm_init has not run
@@ -333,6 +341,7 @@ void free_eval(mp_ctx *c);
 void free_slide(mp_ctx *c);
 void free_comm(mp_ctx *c);
 void free_unique(mp_ctx *c);
+void free_seq(mp_ctx *c);        // scan.hip
 void free_windows(mp_ctx *c);
 void free_msa(mp_ctx *c);
 // per-translation-unit device constants (called by mp_create on the context's device)

@@ -642,16 +642,35 @@ __device__ inline int pcr_first(const uint32_t *__restrict__ s_pos, const uint16
     return best == 0x7fffffff ? -1 : best;
 }
 
-template <int NW>
+// RES: the packed segment comes from the context's resident store (mp_seq_load, scan.hip) instead of the packing loop over characters;
+// the characters are only touched by the overflow fall-back at the end
+template <int NW, bool RES>
 __global__ __launch_bounds__(kBlock) void pcr_block_kernel(const uint8_t *__restrict__ bytes, const int64_t *__restrict__ row_off, int n_rows,
+                                                           const unsigned long long *__restrict__ st_code, const unsigned long long *__restrict__ st_flag,
+                                                           const int64_t *__restrict__ st_woff,
                                                            const PcrPat<NW> *__restrict__ pats, int n_pats, const PcrPair *__restrict__ pairs,
                                                            int n_pairs, const uint8_t *__restrict__ codes, const int32_t *__restrict__ off,
-                                                           int32_t *__restrict__ out) {
+                                                           int32_t *__restrict__ out, int prefilter) {
     constexpr int kPcrSegWords = kPcrSeg / 32 + 1 + NW;
     __shared__ unsigned long long s_b[kPcrSegWords], s_n[kPcrSegWords];
     __shared__ uint32_t s_pos[kPcrHits];
     __shared__ uint16_t s_pat[kPcrHits];
     __shared__ int s_nh;
+    // [r6] prefilter (every pattern has >= 8 bases): one bit per 8-base prefix that SOME pattern starts with (65536 bits); a position
+    // whose first 8 bases are all upper-case A/C/G/T and whose prefix bit is set is queued, and only the queued positions — a few per
+    // cent — are compared with the pattern table, one position per lane.  Without it every position paid ~6 instructions for each of
+    // the up to 4096 patterns: 3.3 ms for 20 727 sequences x 64 pairs, integer-VALU bound.
+    __shared__ uint32_t s_bits[2048];
+    __shared__ uint16_t s_q[kPcrSeg];
+    __shared__ int s_nq;
+    if (prefilter) {
+        for (int i = threadIdx.x; i < 2048; i += kBlock) s_bits[i] = 0;
+        __syncthreads();
+        for (int i = threadIdx.x; i < n_pats; i += kBlock) {
+            const uint32_t pfx = (uint32_t)pats[i].word[0] & 0xFFFFu;
+            atomicOr(&s_bits[pfx >> 5], 1u << (pfx & 31));
+        }
+    }
     const int row = blockIdx.x;
     const uint8_t *s = bytes + row_off[row];
     const int len = (int)(row_off[row + 1] - row_off[row]);
@@ -659,9 +678,20 @@ __global__ __launch_bounds__(kBlock) void pcr_block_kernel(const uint8_t *__rest
     const unsigned long long kOdd = 0x5555555555555555ull;
     for (int base = 0; base < len; base += kPcrSeg) {
         __syncthreads();
+        if (threadIdx.x == 0) s_nq = 0;
         for (int w = threadIdx.x; w < kPcrSegWords; w += kBlock) {
             unsigned long long b = 0, n = 0;
             const int p0 = base + w * 32;
+            if (RES) {
+                const long long gw = base / 32 + w, nwords = st_woff[row + 1] - st_woff[row];
+                if (gw < nwords) {                   // the search is case sensitive: a lower-case base matches nothing either
+                    const unsigned long long f = st_flag[st_woff[row] + gw];
+                    b = st_code[st_woff[row] + gw]; n = (f | (f >> 1)) & kOdd;
+                    b &= ~(n | (n << 1));            // (the packing loop leaves code 0 where nothing matches)
+                } else n = kOdd;
+                s_b[w] = b; s_n[w] = n;
+                continue;
+            }
             for (int j = 0; j < 32; j++) {
                 const int p = p0 + j;
                 const int c = p < len ? pcr_base(s[p]) : -1;
@@ -671,7 +701,20 @@ __global__ __launch_bounds__(kBlock) void pcr_block_kernel(const uint8_t *__rest
             s_b[w] = b; s_n[w] = n;
         }
         __syncthreads();
-        for (int q = threadIdx.x; q < kPcrSeg; q += kBlock) {
+        if (prefilter) {
+            for (int q = threadIdx.x; q < kPcrSeg; q += kBlock) {
+                if (base + q >= len) break;
+                const int w = q >> 5, sh = (q & 31) * 2;
+                unsigned long long w0 = s_b[w] >> sh, n0 = s_n[w] >> sh;
+                if (sh) { w0 |= s_b[w + 1] << (64 - sh); n0 |= s_n[w + 1] << (64 - sh); }
+                const uint32_t pfx = (uint32_t)w0 & 0xFFFFu;
+                if (((uint32_t)n0 & 0xFFFFu) == 0 && ((s_bits[pfx >> 5] >> (pfx & 31)) & 1u)) s_q[atomicAdd(&s_nq, 1)] = (uint16_t)q;
+            }
+            __syncthreads();
+        }
+        const int n_todo = prefilter ? s_nq : kPcrSeg;
+        for (int qi = threadIdx.x; qi < n_todo; qi += kBlock) {
+            const int q = prefilter ? (int)s_q[qi] : qi;
             const int p = base + q;
             if (p >= len) break;
             const int w = q >> 5, sh = (q & 31) * 2;
@@ -982,29 +1025,17 @@ int mp_pair_coverage(mp_ctx *c, int32_t n_sets, int32_t n_words, const uint64_t 
 }
 
 
-int mp_pcr_scan(mp_ctx *c, const uint8_t *bytes, const int64_t *row_off, int32_t n_rows, int32_t n_pairs,
-                const uint8_t *codes, const int32_t *off, int32_t *out) {
-    if (!c) return MP_ERR_ARG;
-    if (n_rows < 0 || n_pairs < 0 || (n_rows && (!bytes || !row_off)) || (n_pairs && (!codes || !off)) || (n_rows && n_pairs && !out))
-        return fail(c, MP_ERR_ARG, "mp_pcr_scan: bad arguments");
-    HIPCK(c, hipSetDevice(c->dev));
-    if (n_rows == 0 || n_pairs == 0) return MP_OK;
+// the search on device text: the bytes of this call, or the context's resident store (st_code set)
+static int pcr_scan_device(mp_ctx *c, const uint8_t *d_bytes, const int64_t *d_roff, const unsigned long long *st_code, const unsigned long long *st_flag,
+                           const int64_t *st_woff, int32_t n_rows, int32_t n_pairs, const uint8_t *codes, const int32_t *off, int32_t *out) {
     int rc;
     if ((rc = check_primers(c, 2 * n_pairs, codes, off, MP_PATTERN_MAX_LEN))) return rc;
-    const size_t total = (size_t)(row_off[n_rows] - row_off[0]), ncodes = (size_t)off[2 * n_pairs];
+    const size_t ncodes = (size_t)off[2 * n_pairs];
     const size_t nout = (size_t)n_pairs * (size_t)n_rows * 4;
-    uint8_t *d_bytes = nullptr, *d_codes = nullptr;
-    int64_t *d_roff = nullptr;
+    Scratch sc(c);
+    uint8_t *d_codes = nullptr;
     int32_t *d_off = nullptr, *d_out = nullptr;
-    if ((rc = dev_alloc(c, &d_bytes, total + 16))) return rc;
-    if ((rc = dev_alloc(c, &d_roff, (size_t)n_rows + 1))) return rc;
-    if ((rc = dev_alloc(c, &d_codes, ncodes))) return rc;
-    if ((rc = dev_alloc(c, &d_off, (size_t)2 * n_pairs + 1))) return rc;
-    if ((rc = dev_alloc(c, &d_out, nout))) return rc;
-    std::vector<int64_t> roff((size_t)n_rows + 1);
-    for (int32_t r = 0; r <= n_rows; r++) roff[(size_t)r] = row_off[r] - row_off[0];
-    HIPCK(c, hipMemcpyAsync(d_bytes, bytes + row_off[0], total, hipMemcpyHostToDevice, c->stream));
-    HIPCK(c, hipMemcpyAsync(d_roff, roff.data(), sizeof(int64_t) * roff.size(), hipMemcpyHostToDevice, c->stream));
+    if ((rc = sc.alloc(&d_codes, ncodes)) || (rc = sc.alloc(&d_off, (size_t)2 * n_pairs + 1)) || (rc = sc.alloc(&d_out, nout))) return rc;
     HIPCK(c, hipMemcpyAsync(d_codes, codes, ncodes, hipMemcpyHostToDevice, c->stream));
     HIPCK(c, hipMemcpyAsync(d_off, off, sizeof(int32_t) * ((size_t)2 * n_pairs + 1), hipMemcpyHostToDevice, c->stream));
     // pattern table of the block-per-sequence kernel: every forward expansion and RC(reverse expansion), in expansion order
@@ -1050,21 +1081,19 @@ int mp_pcr_scan(mp_ctx *c, const uint8_t *bytes, const int64_t *row_off, int32_t
     const size_t pat_bytes = two_words ? sizeof(PcrPat<2>) * pats.size() : sizeof(PcrPat<1>) * narrow.size();
     uint8_t *d_pats = nullptr;
     PcrPair *d_prs = nullptr;
-    if (fits) {
-        if ((rc = dev_alloc(c, &d_pats, pat_bytes)) || (rc = dev_alloc(c, &d_prs, prs.size()))) {
-            dev_free(c, &d_pats, pat_bytes); dev_free(c, &d_prs, prs.size());
-            fits = false;
-        }
-    }
+    if (fits && ((rc = sc.alloc(&d_pats, pat_bytes)) || (rc = sc.alloc(&d_prs, prs.size())))) fits = false;
     if (fits) {
         HIPCK(c, hipMemcpyAsync(d_pats, two_words ? (const void *)pats.data() : (const void *)narrow.data(), pat_bytes, hipMemcpyHostToDevice, c->stream));
         HIPCK(c, hipMemcpyAsync(d_prs, prs.data(), sizeof(PcrPair) * prs.size(), hipMemcpyHostToDevice, c->stream));
-        if (two_words)
-            hipLaunchKernelGGL(pcr_block_kernel<2>, dim3((unsigned)n_rows), dim3(kBlock), 0, c->stream, d_bytes, d_roff, n_rows,
-                               reinterpret_cast<const PcrPat<2> *>(d_pats), (int)pats.size(), (const PcrPair *)d_prs, n_pairs, d_codes, d_off, d_out);
-        else
-            hipLaunchKernelGGL(pcr_block_kernel<1>, dim3((unsigned)n_rows), dim3(kBlock), 0, c->stream, d_bytes, d_roff, n_rows,
-                               reinterpret_cast<const PcrPat<1> *>(d_pats), (int)narrow.size(), (const PcrPair *)d_prs, n_pairs, d_codes, d_off, d_out);
+        int shortest = MP_PATTERN_MAX_LEN;
+        for (int32_t q = 0; q < 2 * n_pairs; q++) shortest = std::min(shortest, off[q + 1] - off[q]);
+        const int prefilter = shortest >= 8 && !getenv("MP_PCR_NO_PREFILTER") ? 1 : 0;
+#define MP_PCR_LAUNCH(NW, RES, NP)                                                                                                             \
+    hipLaunchKernelGGL((pcr_block_kernel<NW, RES>), dim3((unsigned)n_rows), dim3(kBlock), 0, c->stream, d_bytes, d_roff, n_rows, st_code, st_flag, \
+                       st_woff, reinterpret_cast<const PcrPat<NW> *>(d_pats), (int)(NP), (const PcrPair *)d_prs, n_pairs, d_codes, d_off, d_out, prefilter)
+        if (st_code) { if (two_words) MP_PCR_LAUNCH(2, true, pats.size()); else MP_PCR_LAUNCH(1, true, narrow.size()); }
+        else { if (two_words) MP_PCR_LAUNCH(2, false, pats.size()); else MP_PCR_LAUNCH(1, false, narrow.size()); }
+#undef MP_PCR_LAUNCH
     } else if (two_words) {
         hipLaunchKernelGGL(pcr_kernel<true>, dim3((unsigned)((n_rows + kBlock - 1) / kBlock), (unsigned)n_pairs), dim3(kBlock), 0, c->stream,
                            d_bytes, d_roff, n_rows, d_codes, d_off, d_out);
@@ -1075,10 +1104,37 @@ int mp_pcr_scan(mp_ctx *c, const uint8_t *bytes, const int64_t *row_off, int32_t
     HIPCK(c, hipGetLastError());
     HIPCK(c, hipMemcpyAsync(out, d_out, sizeof(int32_t) * nout, hipMemcpyDeviceToHost, c->stream));
     HIPCK(c, hipStreamSynchronize(c->stream));
-    dev_free(c, &d_bytes, total + 16); dev_free(c, &d_roff, (size_t)n_rows + 1); dev_free(c, &d_codes, ncodes);
-    dev_free(c, &d_off, (size_t)2 * n_pairs + 1); dev_free(c, &d_out, nout);
-    dev_free(c, &d_pats, pat_bytes); dev_free(c, &d_prs, prs.size());
     return MP_OK;
+}
+
+int mp_pcr_scan(mp_ctx *c, const uint8_t *bytes, const int64_t *row_off, int32_t n_rows, int32_t n_pairs,
+                const uint8_t *codes, const int32_t *off, int32_t *out) {
+    if (!c) return MP_ERR_ARG;
+    if (n_rows < 0 || n_pairs < 0 || (n_rows && (!bytes || !row_off)) || (n_pairs && (!codes || !off)) || (n_rows && n_pairs && !out))
+        return fail(c, MP_ERR_ARG, "mp_pcr_scan: bad arguments");
+    HIPCK(c, hipSetDevice(c->dev));
+    if (n_rows == 0 || n_pairs == 0) return MP_OK;
+    const size_t total = (size_t)(row_off[n_rows] - row_off[0]);
+    Scratch sc(c);
+    uint8_t *d_bytes = nullptr;
+    int64_t *d_roff = nullptr;
+    int rc;
+    if ((rc = sc.alloc(&d_bytes, total + 16)) || (rc = sc.alloc(&d_roff, (size_t)n_rows + 1))) return rc;
+    std::vector<int64_t> roff((size_t)n_rows + 1);
+    for (int32_t r = 0; r <= n_rows; r++) roff[(size_t)r] = row_off[r] - row_off[0];
+    HIPCK(c, hipMemcpyAsync(d_bytes, bytes + row_off[0], total, hipMemcpyHostToDevice, c->stream));
+    HIPCK(c, hipMemcpyAsync(d_roff, roff.data(), sizeof(int64_t) * roff.size(), hipMemcpyHostToDevice, c->stream));
+    rc = pcr_scan_device(c, d_bytes, d_roff, nullptr, nullptr, nullptr, n_rows, n_pairs, codes, off, out);
+    (void)hipStreamSynchronize(c->stream);               // (roff leaves scope)
+    return rc;
+}
+
+int mp_pcr_scan_resident(mp_ctx *c, int32_t n_pairs, const uint8_t *codes, const int32_t *off, int32_t *out) {
+    if (!c) return MP_ERR_ARG;
+    if (n_pairs < 0 || (n_pairs && (!codes || !off)) || (c->sq_n && n_pairs && !out)) return fail(c, MP_ERR_ARG, "mp_pcr_scan_resident: bad arguments");
+    HIPCK(c, hipSetDevice(c->dev));
+    if (c->sq_n == 0 || n_pairs == 0) return MP_OK;
+    return pcr_scan_device(c, c->sq_bytes, c->sq_roff, c->sq_code, c->sq_flag, c->sq_woff, c->sq_n, n_pairs, codes, off, out);
 }
 
 }  // extern "C"

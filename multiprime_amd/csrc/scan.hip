@@ -26,8 +26,12 @@ struct KmmPat {
     int32_t len, id, strand, never;   // never: term > len — the trailing match run cannot reach the threshold
 };
 
-template <int NW>
+// RES: the text comes from the context's resident store (mp_seq_load: `code` / `flag` words at word offsets `woff`) — a segment is
+// kSegWords coalesced 8-byte loads per plane instead of 32 byte loads and ~130 instructions per word
+template <int NW, bool RES>
 __global__ __launch_bounds__(kBlock) void kmm_kernel(const uint8_t *__restrict__ bytes, const int64_t *__restrict__ row_off,
+                                                     const unsigned long long *__restrict__ code, const unsigned long long *__restrict__ flag,
+                                                     const int64_t *__restrict__ woff,
                                                      const int32_t *__restrict__ blk_row, const int32_t *__restrict__ blk_seg,
                                                      const KmmPat<NW> *__restrict__ pats, int n_pats, int max_mm, long long cap,
                                                      int32_t *__restrict__ hits, unsigned long long *__restrict__ n_hits) {
@@ -42,6 +46,13 @@ __global__ __launch_bounds__(kBlock) void kmm_kernel(const uint8_t *__restrict__
     for (int w = threadIdx.x; w < kSegWords; w += kBlock) {
         unsigned long long b = 0, n = 0;
         const long long p0 = base + (long long)w * 32;
+        if (RES) {
+            const long long gw = base / 32 + w, nwords = woff[row + 1] - woff[row];
+            if (gw < nwords) { b = code[woff[row] + gw]; n = flag[woff[row] + gw] & 0x5555555555555555ull; }     // (the scan upper-cases: bit 2j alone)
+            else n = 0x5555555555555555ull;
+            s_b[w] = b; s_n[w] = n;
+            continue;
+        }
         for (int j = 0; j < 32; j++) {
             const long long p = p0 + j;
             unsigned long long code = 0, bad = 1;
@@ -116,19 +127,39 @@ void kmm_patterns(int32_t n_pat, const uint8_t *pat_codes, const int32_t *pat_of
     }
 }
 
-}  // namespace
+// pack the characters of the store into words (one thread per word; once per mp_seq_load)
+__global__ __launch_bounds__(kBlock) void seq_pack_kernel(const uint8_t *__restrict__ bytes, const int64_t *__restrict__ row_off,
+                                                          const int64_t *__restrict__ woff, int n_rows, unsigned long long *__restrict__ code,
+                                                          unsigned long long *__restrict__ flag) {
+    const int row = blockIdx.x;
+    if (row >= n_rows) return;
+    const uint8_t *s = bytes + row_off[row];
+    const long long len = row_off[row + 1] - row_off[row], nw = woff[row + 1] - woff[row];
+    for (long long w = threadIdx.x; w < nw; w += kBlock) {
+        unsigned long long b = 0, f = 0;
+        for (int j = 0; j < 32; j++) {
+            const long long p = w * 32 + j;
+            unsigned long long c = 0, bad = 1, low = 0;
+            if (p < len) {
+                uint8_t ch = s[p];
+                if (ch >= 'a' && ch <= 'z') { ch -= 32; low = 1; }
+                if (ch == 'A') { c = 0; bad = 0; }
+                else if (ch == 'C') { c = 1; bad = 0; }
+                else if (ch == 'G') { c = 2; bad = 0; }
+                else if (ch == 'T') { c = 3; bad = 0; }
+            }
+            b |= c << (2 * j);
+            f |= (bad | (low << 1)) << (2 * j);
+        }
+        code[woff[row] + w] = b;
+        flag[woff[row] + w] = f;
+    }
+}
 
-extern "C" {
-
-int mp_kmm_scan(mp_ctx *c, const uint8_t *bytes, const int64_t *row_off, int32_t n_rows, int32_t n_pat, const uint8_t *pat_codes,
-                const int32_t *pat_off, int32_t max_mm, int32_t term, int64_t cap, int32_t *hits, int64_t *n_hits) {
-    if (!c) return MP_ERR_ARG;
-    if (n_rows < 0 || n_pat < 0 || !n_hits || cap < 0 || (cap && !hits) || (n_rows && (!bytes || !row_off)) ||
-        (n_pat && (!pat_codes || !pat_off)) || max_mm < 0 || term < 0)
-        return fail(c, MP_ERR_ARG, "mp_kmm_scan: bad arguments");
-    HIPCK(c, hipSetDevice(c->dev));
-    *n_hits = 0;
-    if (n_rows == 0 || n_pat == 0) return MP_OK;
+// the scan itself on device text (bytes of this call, or the resident store when `code` is set)
+int kmm_scan_device(mp_ctx *c, const uint8_t *d_bytes, const int64_t *d_roff, const unsigned long long *code, const unsigned long long *flag,
+                    const int64_t *d_woff, const int64_t *roff_host, int32_t n_rows, int32_t n_pat, const uint8_t *pat_codes, const int32_t *pat_off,
+                    int32_t max_mm, int32_t term, int64_t cap, int32_t *hits, int64_t *n_hits) {
     int longest = 0;
     for (int32_t i = 0; i < n_pat; i++) {
         const int len = pat_off[i + 1] - pat_off[i];
@@ -149,42 +180,34 @@ int mp_kmm_scan(mp_ctx *c, const uint8_t *bytes, const int64_t *row_off, int32_t
     const void *pat_src = two_words ? (const void *)pats2.data() : (const void *)pats1.data();
     std::vector<int32_t> blk_row, blk_seg;
     for (int32_t r = 0; r < n_rows; r++) {
-        const int64_t len = row_off[r + 1] - row_off[r];
+        const int64_t len = roff_host[r + 1] - roff_host[r];
         if (len < 0 || len > 0x7fffffffLL) return fail(c, MP_ERR_ARG, "sequence %d has bad length", r);
         for (int64_t sgm = 0; sgm * kSeg < len; sgm++) { blk_row.push_back(r); blk_seg.push_back((int32_t)sgm); }
     }
     if (blk_row.empty()) return MP_OK;
-    const size_t total = (size_t)(row_off[n_rows] - row_off[0]), nb = blk_row.size();
-    uint8_t *d_bytes = nullptr;
-    int64_t *d_roff = nullptr;
+    const size_t nb = blk_row.size();
     int32_t *d_brow = nullptr, *d_bseg = nullptr, *d_hits = nullptr;
     uint8_t *d_pats = nullptr;
     unsigned long long *d_n = nullptr;
     const size_t hcap = (size_t)std::max<int64_t>(cap, 1) * 4;
     int rc = MP_OK;
     auto cleanup = [&]() {
-        dev_free(c, &d_bytes, total + 16); dev_free(c, &d_roff, (size_t)n_rows + 1); dev_free(c, &d_brow, nb); dev_free(c, &d_bseg, nb);
-        dev_free(c, &d_hits, hcap); dev_free(c, &d_pats, pat_bytes); dev_free(c, &d_n, 1);
+        dev_free(c, &d_brow, nb); dev_free(c, &d_bseg, nb); dev_free(c, &d_hits, hcap); dev_free(c, &d_pats, pat_bytes); dev_free(c, &d_n, 1);
     };
-    std::vector<int64_t> roff((size_t)n_rows + 1);
-    for (int32_t r = 0; r <= n_rows; r++) roff[(size_t)r] = row_off[r] - row_off[0];
     hipError_t e = hipSuccess;
-    if ((rc = dev_alloc(c, &d_bytes, total + 16)) || (rc = dev_alloc(c, &d_roff, (size_t)n_rows + 1)) || (rc = dev_alloc(c, &d_brow, nb)) ||
-        (rc = dev_alloc(c, &d_bseg, nb)) || (rc = dev_alloc(c, &d_hits, hcap)) || (rc = dev_alloc(c, &d_pats, pat_bytes)) ||
-        (rc = dev_alloc(c, &d_n, 1))) { cleanup(); return rc; }
-    if (e == hipSuccess) e = hipMemcpyAsync(d_bytes, bytes + row_off[0], total, hipMemcpyHostToDevice, c->stream);
-    if (e == hipSuccess) e = hipMemcpyAsync(d_roff, roff.data(), sizeof(int64_t) * roff.size(), hipMemcpyHostToDevice, c->stream);
+    if ((rc = dev_alloc(c, &d_brow, nb)) || (rc = dev_alloc(c, &d_bseg, nb)) || (rc = dev_alloc(c, &d_hits, hcap)) ||
+        (rc = dev_alloc(c, &d_pats, pat_bytes)) || (rc = dev_alloc(c, &d_n, 1))) { cleanup(); return rc; }
     if (e == hipSuccess) e = hipMemcpyAsync(d_brow, blk_row.data(), sizeof(int32_t) * nb, hipMemcpyHostToDevice, c->stream);
     if (e == hipSuccess) e = hipMemcpyAsync(d_bseg, blk_seg.data(), sizeof(int32_t) * nb, hipMemcpyHostToDevice, c->stream);
     if (e == hipSuccess) e = hipMemcpyAsync(d_pats, pat_src, pat_bytes, hipMemcpyHostToDevice, c->stream);
     if (e == hipSuccess) e = hipMemsetAsync(d_n, 0, sizeof(unsigned long long), c->stream);
     if (e == hipSuccess) {
-        if (two_words)
-            hipLaunchKernelGGL(kmm_kernel<2>, dim3((unsigned)nb), dim3(kBlock), 0, c->stream, d_bytes, d_roff, d_brow, d_bseg,
-                               reinterpret_cast<const KmmPat<2> *>(d_pats), (int)n_entries, (int)max_mm, (long long)cap, d_hits, d_n);
-        else
-            hipLaunchKernelGGL(kmm_kernel<1>, dim3((unsigned)nb), dim3(kBlock), 0, c->stream, d_bytes, d_roff, d_brow, d_bseg,
-                               reinterpret_cast<const KmmPat<1> *>(d_pats), (int)n_entries, (int)max_mm, (long long)cap, d_hits, d_n);
+#define MP_KMM_LAUNCH(NW, RES)                                                                                                               \
+    hipLaunchKernelGGL((kmm_kernel<NW, RES>), dim3((unsigned)nb), dim3(kBlock), 0, c->stream, d_bytes, d_roff, code, flag, d_woff, d_brow, \
+                       d_bseg, reinterpret_cast<const KmmPat<NW> *>(d_pats), (int)n_entries, (int)max_mm, (long long)cap, d_hits, d_n)
+        if (code) { if (two_words) MP_KMM_LAUNCH(2, true); else MP_KMM_LAUNCH(1, true); }
+        else { if (two_words) MP_KMM_LAUNCH(2, false); else MP_KMM_LAUNCH(1, false); }
+#undef MP_KMM_LAUNCH
         e = hipGetLastError();
     }
     unsigned long long n = 0;
@@ -192,12 +215,115 @@ int mp_kmm_scan(mp_ctx *c, const uint8_t *bytes, const int64_t *row_off, int32_t
     if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
     if (e == hipSuccess && cap) {
         const size_t got = (size_t)std::min<unsigned long long>(n, (unsigned long long)cap);
-        if (got) e = hipMemcpy(hits, d_hits, sizeof(int32_t) * 4 * got, hipMemcpyDeviceToHost);
+        if (got) e = hipMemcpyAsync(hits, d_hits, sizeof(int32_t) * 4 * got, hipMemcpyDeviceToHost, c->stream);
+        if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
     }
     cleanup();
     if (e != hipSuccess) return fail(c, MP_ERR_DEVICE, "mp_kmm_scan: %s", hipGetErrorString(e));
     *n_hits = (int64_t)n;
     return MP_OK;
+}
+
+}  // namespace
+
+namespace mp {
+void free_seq(mp_ctx *c) {
+    dev_free(c, &c->sq_bytes, c->sq_total + 16); dev_free(c, &c->sq_roff, (size_t)c->sq_n + 1);
+    dev_free(c, &c->sq_code, c->sq_words); dev_free(c, &c->sq_flag, c->sq_words); dev_free(c, &c->sq_woff, (size_t)c->sq_n + 1);
+    c->sq_n = 0; c->sq_total = c->sq_words = 0;
+    c->sq_roff_host.clear();
+}
+}  // namespace mp
+
+extern "C" {
+
+int mp_seq_load(mp_ctx *c, const uint8_t *bytes, const int64_t *row_off, int32_t n_rows) {
+    if (!c) return MP_ERR_ARG;
+    if (n_rows < 0 || (n_rows && (!bytes || !row_off))) return fail(c, MP_ERR_ARG, "mp_seq_load: bad arguments");
+    HIPCK(c, hipSetDevice(c->dev));
+    free_seq(c);
+    if (n_rows == 0) return MP_OK;
+    std::vector<int64_t> roff((size_t)n_rows + 1), woff((size_t)n_rows + 1);
+    woff[0] = 0;
+    for (int32_t r = 0; r <= n_rows; r++) roff[(size_t)r] = row_off[r] - row_off[0];
+    for (int32_t r = 0; r < n_rows; r++) {
+        const int64_t len = roff[(size_t)r + 1] - roff[(size_t)r];
+        if (len < 0 || len > 0x7fffffffLL) return fail(c, MP_ERR_ARG, "sequence %d has bad length", r);
+        woff[(size_t)r + 1] = woff[(size_t)r] + (len + 31) / 32;
+    }
+    const size_t total = (size_t)roff[(size_t)n_rows], words = (size_t)woff[(size_t)n_rows];
+    int rc;
+    c->sq_n = n_rows; c->sq_total = total; c->sq_words = words;
+    if ((rc = dev_alloc(c, &c->sq_bytes, total + 16)) || (rc = dev_alloc(c, &c->sq_roff, (size_t)n_rows + 1)) || (rc = dev_alloc(c, &c->sq_code, words)) ||
+        (rc = dev_alloc(c, &c->sq_flag, words)) || (rc = dev_alloc(c, &c->sq_woff, (size_t)n_rows + 1))) { free_seq(c); return rc; }
+    hipError_t e = hipSuccess;
+    if (total) e = hipMemcpyAsync(c->sq_bytes, bytes + row_off[0], total, hipMemcpyHostToDevice, c->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(c->sq_roff, roff.data(), sizeof(int64_t) * roff.size(), hipMemcpyHostToDevice, c->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(c->sq_woff, woff.data(), sizeof(int64_t) * woff.size(), hipMemcpyHostToDevice, c->stream);
+    if (e == hipSuccess) {
+        hipLaunchKernelGGL(seq_pack_kernel, dim3((unsigned)n_rows), dim3(kBlock), 0, c->stream, (const uint8_t *)c->sq_bytes, (const int64_t *)c->sq_roff,
+                           (const int64_t *)c->sq_woff, (int)n_rows, c->sq_code, c->sq_flag);
+        e = hipGetLastError();
+    }
+    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);            // (the host vectors above leave scope)
+    if (e != hipSuccess) { free_seq(c); return fail(c, MP_ERR_DEVICE, "mp_seq_load: %s", hipGetErrorString(e)); }
+    c->sq_roff_host = std::move(roff);
+    return MP_OK;
+}
+
+int mp_seq_free(mp_ctx *c) {
+    if (!c) return MP_ERR_ARG;
+    HIPCK(c, hipSetDevice(c->dev));
+    free_seq(c);
+    return MP_OK;
+}
+
+int mp_seq_info(mp_ctx *c, int32_t *n_rows, int64_t *n_bases, int64_t *device_bytes) {
+    if (!c) return MP_ERR_ARG;
+    if (n_rows) *n_rows = c->sq_n;
+    if (n_bases) *n_bases = (int64_t)c->sq_total;
+    if (device_bytes) *device_bytes = c->sq_n ? (int64_t)(c->sq_total + 16 + 16 * c->sq_words + 16 * ((size_t)c->sq_n + 1)) : 0;
+    return MP_OK;
+}
+
+int mp_kmm_scan(mp_ctx *c, const uint8_t *bytes, const int64_t *row_off, int32_t n_rows, int32_t n_pat, const uint8_t *pat_codes,
+                const int32_t *pat_off, int32_t max_mm, int32_t term, int64_t cap, int32_t *hits, int64_t *n_hits) {
+    if (!c) return MP_ERR_ARG;
+    if (n_rows < 0 || n_pat < 0 || !n_hits || cap < 0 || (cap && !hits) || (n_rows && (!bytes || !row_off)) ||
+        (n_pat && (!pat_codes || !pat_off)) || max_mm < 0 || term < 0)
+        return fail(c, MP_ERR_ARG, "mp_kmm_scan: bad arguments");
+    HIPCK(c, hipSetDevice(c->dev));
+    *n_hits = 0;
+    if (n_rows == 0 || n_pat == 0) return MP_OK;
+    const size_t total = (size_t)(row_off[n_rows] - row_off[0]);
+    std::vector<int64_t> roff((size_t)n_rows + 1);
+    for (int32_t r = 0; r <= n_rows; r++) roff[(size_t)r] = row_off[r] - row_off[0];
+    uint8_t *d_bytes = nullptr;
+    int64_t *d_roff = nullptr;
+    int rc;
+    if ((rc = dev_alloc(c, &d_bytes, total + 16)) || (rc = dev_alloc(c, &d_roff, (size_t)n_rows + 1))) {
+        dev_free(c, &d_bytes, total + 16); dev_free(c, &d_roff, (size_t)n_rows + 1);
+        return rc;
+    }
+    hipError_t e = hipMemcpyAsync(d_bytes, bytes + row_off[0], total, hipMemcpyHostToDevice, c->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(d_roff, roff.data(), sizeof(int64_t) * roff.size(), hipMemcpyHostToDevice, c->stream);
+    rc = e == hipSuccess ? kmm_scan_device(c, d_bytes, d_roff, nullptr, nullptr, nullptr, roff.data(), n_rows, n_pat, pat_codes, pat_off, max_mm, term, cap, hits, n_hits)
+                         : fail(c, MP_ERR_DEVICE, "mp_kmm_scan: %s", hipGetErrorString(e));
+    (void)hipStreamSynchronize(c->stream);
+    dev_free(c, &d_bytes, total + 16); dev_free(c, &d_roff, (size_t)n_rows + 1);
+    return rc;
+}
+
+int mp_kmm_scan_resident(mp_ctx *c, int32_t n_pat, const uint8_t *pat_codes, const int32_t *pat_off, int32_t max_mm, int32_t term, int64_t cap,
+                         int32_t *hits, int64_t *n_hits) {
+    if (!c) return MP_ERR_ARG;
+    if (n_pat < 0 || !n_hits || cap < 0 || (cap && !hits) || (n_pat && (!pat_codes || !pat_off)) || max_mm < 0 || term < 0)
+        return fail(c, MP_ERR_ARG, "mp_kmm_scan_resident: bad arguments");
+    HIPCK(c, hipSetDevice(c->dev));
+    *n_hits = 0;
+    if (c->sq_n == 0 || n_pat == 0) return MP_OK;
+    return kmm_scan_device(c, c->sq_bytes, c->sq_roff, c->sq_code, c->sq_flag, c->sq_woff, c->sq_roff_host.data(), c->sq_n, n_pat, pat_codes, pat_off,
+                           max_mm, term, cap, hits, n_hits);
 }
 
 }  // extern "C"

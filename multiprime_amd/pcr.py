@@ -92,7 +92,13 @@ class Product(object):
         flat = [s for n in names for s in self.primers[n]]
         codes, off = encode_primers(flat, PATTERN_MAX_LEN) if flat else (np.zeros(0, np.uint8), np.zeros(1, np.int32))
         t0 = time.time()
-        hits = self.ctx.pcr_scan(data, row_off, codes, off) if names and bodies else np.full((len(names), len(bodies), 4), -1, np.int32)   # -1 = no amplicon (0 would read "expansion 0 at position 0")
+        if names and bodies:
+            # the database is uploaded and packed once (mp_seq_load) and stays in the context: a caller that hands its context on (a
+            # validation step on the same reference) scans the stored words again instead of sending the text a second time
+            self.ctx.seq_load(data, row_off)
+            hits = self.ctx.pcr_scan_resident(codes, off)
+        else:
+            hits = np.full((len(names), len(bodies), 4), -1, np.int32)   # -1 = no amplicon (0 would read "expansion 0 at position 0")
         self.stats["scan_s"] = time.time() - t0
         product_ids = set()
         stripped = [line.strip() for line in seqs]                                     # what a non-target record prints (PCR:211)

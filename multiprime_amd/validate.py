@@ -181,6 +181,9 @@ class off_targets(object):
         ctx = lib.context(self._device)
         found = []
         try:
+            # the database goes to the device ONCE, packed (mp_seq_load: 4 bits per base beside the characters); every mismatch budget
+            # scans the stored words (rounds 2-5 sent the ASCII text with every call)
+            ctx.seq_load(data, row_off)
             budgets = {}
             for i in usable:
                 budgets.setdefault(self.max_mismatch if self.max_mismatch is not None else bowtie2_mismatch_budget(len(seqs[i])), []).append(i)
@@ -188,7 +191,7 @@ class off_targets(object):
                 codes = iupac.MASK_LUT[np.frombuffer("".join(seqs[i].upper() for i in members).encode(), np.uint8)]
                 off = np.zeros(len(members) + 1, np.int32)
                 np.cumsum([len(seqs[i]) for i in members], out=off[1:])
-                h = ctx.kmm_scan(data, row_off, codes, off, budget, self.term_threshold)
+                h = ctx.kmm_scan_resident(codes, off, budget, self.term_threshold)
                 if len(h):
                     h = h.copy()
                     h[:, 2] = np.asarray(members, np.int32)[h[:, 2]]

@@ -53,6 +53,10 @@ struct mp_ctx {
     /* "resident" masks of mp_eval_masks_resident: plain host arrays here */
     uint64_t *mask_f, *mask_r;
     int32_t n_masks;
+    /* mp_seq_load: the checker keeps the characters; its "resident" scans are the byte scans on them */
+    uint8_t *sq_bytes;
+    int64_t *sq_off;
+    int32_t sq_n;
 };
 
 static int fail(mp_ctx *c, int code, const char *fmt, ...) {
@@ -96,6 +100,7 @@ void mp_destroy(mp_ctx *c) {
     free_windows(c); free_rows(c);
     free(c->cand_win); free(c->cand_codes);
     free(c->mask_f); free(c->mask_r);
+    free(c->sq_bytes); free(c->sq_off);
     free(c);
 }
 
@@ -999,4 +1004,45 @@ int mp_kmm_scan(mp_ctx *c, const uint8_t *bytes, const int64_t *row_off, int32_t
     }
     *n_hits = n;
     return MP_OK;
+}
+
+/* (8b) the resident sequence store: the checker keeps the characters and runs the byte scans of (7) / (8) on them */
+int mp_seq_free(mp_ctx *c) {
+    if (!c) return MP_ERR_ARG;
+    free(c->sq_bytes); free(c->sq_off);
+    c->sq_bytes = NULL; c->sq_off = NULL; c->sq_n = 0;
+    return MP_OK;
+}
+int mp_seq_load(mp_ctx *c, const uint8_t *bytes, const int64_t *row_off, int32_t n_rows) {
+    if (!c) return MP_ERR_ARG;
+    if (n_rows < 0 || (n_rows && (!bytes || !row_off))) return fail(c, MP_ERR_ARG, "mp_seq_load: bad arguments");
+    mp_seq_free(c);
+    if (n_rows == 0) return MP_OK;
+    int64_t total = row_off[n_rows] - row_off[0];
+    c->sq_bytes = malloc((size_t)total + 1);
+    c->sq_off = malloc(sizeof(int64_t) * ((size_t)n_rows + 1));
+    if (!c->sq_bytes || !c->sq_off) { mp_seq_free(c); return fail(c, MP_ERR_NOMEM, "mp_seq_load: out of memory"); }
+    memcpy(c->sq_bytes, bytes + row_off[0], (size_t)total);
+    for (int32_t r = 0; r <= n_rows; r++) c->sq_off[r] = row_off[r] - row_off[0];
+    c->sq_n = n_rows;
+    return MP_OK;
+}
+int mp_seq_info(mp_ctx *c, int32_t *n_rows, int64_t *n_bases, int64_t *device_bytes) {
+    if (!c) return MP_ERR_ARG;
+    if (n_rows) *n_rows = c->sq_n;
+    if (n_bases) *n_bases = c->sq_n ? c->sq_off[c->sq_n] : 0;
+    if (device_bytes) *device_bytes = 0;
+    return MP_OK;
+}
+int mp_pcr_scan_resident(mp_ctx *c, int32_t n_pairs, const uint8_t *codes, const int32_t *off, int32_t *out) {
+    if (!c) return MP_ERR_ARG;
+    if (c->sq_n == 0 || n_pairs == 0) return MP_OK;
+    return mp_pcr_scan(c, c->sq_bytes, c->sq_off, c->sq_n, n_pairs, codes, off, out);
+}
+int mp_kmm_scan_resident(mp_ctx *c, int32_t n_pat, const uint8_t *pat_codes, const int32_t *pat_off, int32_t max_mm, int32_t term, int64_t cap,
+                         int32_t *hits, int64_t *n_hits) {
+    if (!c || !n_hits) return MP_ERR_ARG;
+    *n_hits = 0;
+    if (c->sq_n == 0 || n_pat == 0) return MP_OK;
+    return mp_kmm_scan(c, c->sq_bytes, c->sq_off, c->sq_n, n_pat, pat_codes, pat_off, max_mm, term, cap, hits, n_hits);
 }

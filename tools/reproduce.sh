@@ -45,5 +45,16 @@ hist_exp)        # experiment builds of unique.hip (results are WRONG: timing on
     rm -rf $O/t_${v}_$rows; rocprofv3 --kernel-trace --stats -d $O/t_${v}_$rows/trace -o t -- python tools/hist_only.py $rows 18 > /dev/null 2>&1
     echo "# $v rows $rows"; python tools/summarize_profile.py $O/t_${v}_$rows 2>/dev/null | grep "hist\|table_sums\|compact"
   done; done 2>&1 | tee $O/hist_exp.txt ;;
+side)            # rows D / M, f-2, f-3, f-4: tests of the resident store, the side blocks of bench.py, kernel trace of the same calls
+  timeout 900 python -m pytest tests/test_seq_store.py tests/test_pcr.py tests/test_validate.py tests/test_validate_bwt.py tests/test_dimer.py -x -q -m gpu 2>&1 | tail -4 | tee $O/pytest.txt
+  timeout 900 python tools/side_bench.py > $O/side_bench.json 2> $O/side_bench.err; tail -c 600 $O/side_bench.err; python -c "
+import json; d = json.load(open('$O/side_bench.json'))
+for k, v in d.items():
+    print(k, {a: (round(b, 3) if isinstance(b, float) else b) for a, b in v.items() if not isinstance(b, (dict, str))})
+    for a, b in v.items():
+        if isinstance(b, dict): print('   ', a, {x: (float('%.4g' % y) if isinstance(y, float) else y) for x, y in b.items() if x != 'sample'})
+"
+  rocprofv3 --kernel-trace --stats -d $O/prof/trace -o t -- python tools/side_bench.py > /dev/null 2>&1
+  python tools/summarize_profile.py $O/prof 2>/dev/null | head -24 | tee $O/side_kernels.txt ;;
 *) echo "unknown target $T"; exit 2 ;;
 esac
