@@ -35,7 +35,9 @@ form (`--bucket` steps per collective, dist.StepBuckets) is the side key `ms_per
                 at the shard also one cold launch (caches flushed, no warm-up).
   pipeline      the REAL step the kernel belongs to: NN_degenerate(...).run() (the drop-in class, --no-json, bitsets on the device) on
                 the same rows at both sizes, median of 5, phase split, TSV SHA-256 against the checker's (tests/golden/synth_pipeline.json).
-  projected_strong_scaling   ms_per_step (whole workload, one GPU) / weak_shard.ms_per_step: what 8 row shards reach with a free all-reduce.
+  shard_shapes  N = 1 only: one rank's share under the 2-D shapes 4x2, 2x4, 1x8 (row shards x window groups, dist.ShardGrid), timed and checked the same way.
+  projected_strong_scaling   ms_per_step (whole workload, one GPU) / the best ms_per_step of one rank's share over the shapes 8x1 (`weak_shard`), 4x2, 2x4, 1x8:
+                what 8 GPUs reach with a free all-reduce.
   cpu_baseline  the plain-C oracle on EVERY host core (threads over row blocks of the whole workload) and on one core (bounded
                 sample); its counters are compared with the GPU's candidate by candidate — `parity_checked` true, or the run
                 exits non-zero.  `python_reference`: the reference's own algorithm (dict of k-mers, numpy score-table
@@ -68,6 +70,7 @@ COUNTER_FILES = ("r05_counters.json", "r04_counters.json", "r03_counters.json")
 # sources of the timed kernel (eval_chain_kernel and what it includes): the key of a counter entry
 KERNEL_SOURCES = ("eval.hip", "evalprog.hip", "evalslide.hip", "slidecore.hpp", "slideplan.hpp", "evalslide.hpp", "chainbody.hpp", "bitslice.hpp", "common.hpp",
                   "winwords.hpp", "evalprog.hpp")
+CONFIG4_CHECKSUM = [4933256386, 2131385189, 2001280469]      # counter_checksum of the default workload (N = 1, oracle-checked: profiles/r04_bench.json on)
 SLIDE_FROM_ROWS = 262145     # evalslide.hip (upload_eval_slide): above 262144 (padded) rows the chains are evaluated by sliding
 PROG_FROM_ROWS = 393216      # eval.hip (mp_eval_upload): the program-driven first-pass kernel, when sliding is switched off
 
@@ -211,20 +214,27 @@ def time_launches(ctx, torch, out_ptr, n, warm):
 class Workload:
     """The evaluation workload on `n_rows` sequences starting at global row `row0`, resident on the device."""
 
-    def __init__(self, lib, local, torch, row0, n_rows, a):
+    def __init__(self, lib, local, torch, row0, n_rows, a, win_part=(0, 1), rows=None):
+        """`win_part` = (g, G): the g-th of G contiguous groups of the windows (2-D shards: rows x windows, dist.ShardGrid);
+        `rows`: the synthetic rows when the caller holds them already."""
         t0 = time.time()
         self.k, self.v, self.C, self.L, self.n_rows = a.k, a.v, a.cands, a.cols, n_rows
         self.ctx = lib.context(local)
         self.ctx.set_stream(torch.cuda.current_stream().cuda_stream)
-        self.rows = synth_rows(row0, n_rows, self.L, a.seed)
+        self.rows = rows if rows is not None else synth_rows(row0, n_rows, self.L, a.seed)
         self.ctx.load_msa(self.rows.reshape(-1), np.arange(n_rows + 1, dtype=np.int64) * self.L)
         k = self.k
-        self.p0, self.W = 16, self.L - 32 - k                       # same windows on every rank
+        w_all = self.L - 32 - k                                     # the same windows on every rank of a row group ...
+        g, G = win_part                                             # ... cut into G contiguous groups along the window axis
+        lo, hi = w_all * g // G, w_all * (g + 1) // G
+        self.p0, self.W, self.win_part = 16 + lo, hi - lo, (g, G)
         n_ex = self.ctx.build_windows(self.p0, self.W, k, self.v)
         self.n_extra = expand_exceptions(self.ctx, n_ex, k, self.v)
         from multiprime_amd.synth import synth_root
         self.root_codes = np.array([1, 2, 4, 8], np.uint8)[synth_root(self.L, a.seed)]
-        self.cw, self.codes = make_candidates(self.root_codes, self.p0, self.W, k, self.C, a.seed)
+        # the candidates of ALL windows (seeded per window set), this group's slice of them: the same candidate for a window whatever the shape
+        _, codes_all = make_candidates(self.root_codes, 16, w_all, k, self.C, a.seed)
+        self.cw, self.codes = np.repeat(np.arange(self.W, dtype=np.int32), self.C), np.ascontiguousarray(codes_all[lo * self.C:hi * self.C])
         f_set, r_set = {2, 3, k}, {2, k - 3, k - 2}                 # -c 2,3,-1 (multiPrime.yaml), get_Y V20:1091
         self.sF = sum(1 << y for y in f_set if 0 <= y < k)
         self.sR = sum(1 << y for y in r_set if 0 <= y < k)
@@ -238,7 +248,8 @@ class Workload:
         self.setup_s = time.time() - t0
 
     def describe(self):
-        return (f"synthetic MSA {self.n_rows} x {self.L}, k={self.k}, v={self.v}, {self.C} candidates/window, {self.W} windows, "
+        part = "" if self.win_part[1] == 1 else f" (window group {self.win_part[0] + 1} of {self.win_part[1]})"
+        return (f"synthetic MSA {self.n_rows} x {self.L}, k={self.k}, v={self.v}, {self.C} candidates/window, {self.W} windows{part}, "
                 f"strict -c 2,3,-1")
 
 
@@ -301,9 +312,13 @@ def main():
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--no-variants", action="store_true")
     ap.add_argument("--no-pipeline", action="store_true", help="N = 1: skip the `pipeline` block (NN_degenerate.run() on the same rows)")
+    ap.add_argument("--no-shapes", action="store_true", help="N = 1: skip the `shard_shapes` block (one rank's share of the 2-D shards 4x2, 2x4, 1x8)")
     ap.add_argument("--no-side", action="store_true", help="N = 1: skip the `side_steps` block (dimer scan, in-silico PCR, k-mismatch scan: tools/side_bench.py)")
     ap.add_argument("--no-shard", "--no-full", dest="no_shard", action="store_true",
                     help="N = 1: skip the weak_shard block (the 131072-row shard of the 8-GPU job)")
+    ap.add_argument("--shape", default=None, metavar="RxG|auto", help="N > 1: R row shards x G window groups (R x G = N); default auto = as many window "
+                    "groups as the device memory allows (dist.ShardGrid.best_shape); Nx1 = row shards only")
+    ap.add_argument("--share", default=None, metavar="RxG", help="N = 1 experiment: time one rank's share of an R x G job instead of the whole workload")
     ap.add_argument("--bucket", type=int, default=4, help="steps per collective of the bucketed side measurement (N > 1)")
     a = ap.parse_args()
 
@@ -320,9 +335,22 @@ def main():
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the product has no CPU path")
     strong = a.rows == 0
-    if strong and FULL_ROWS % world:
-        raise SystemExit(f"config 4 ({FULL_ROWS} rows) does not split evenly over {world} GPUs: pass --rows")
-    rows_per_gpu = FULL_ROWS // world if strong else a.rows
+    # N > 1: the shape of the job — R row shards x G window groups (multiprime_amd.dist.ShardGrid): rank r holds row shard r // G and evaluates
+    # window group r % G; the counters' all-reduce runs inside a row group (the R ranks with the same r % G).  Default: as many window groups as
+    # the device memory allows (config 4: 1 x N — every GPU holds every row, 5 GB, and there is nothing to reduce); --shape Nx1 = row shards only.
+    from multiprime_amd.dist import ShardGrid
+    R, G = (ShardGrid.best_shape(world, FULL_ROWS if strong else a.rows * world, a.cols) if a.shape in (None, "auto") else ShardGrid.parse(a.shape, world))
+    if not strong:
+        R, G = world, 1                                 # --rows fixes the rows per GPU: row shards
+    if strong and FULL_ROWS % R:
+        raise SystemExit(f"config 4 ({FULL_ROWS} rows) does not split evenly into {R} row shards")
+    ri, gi = divmod(rank, G)
+    rows_per_gpu = FULL_ROWS // R if strong else a.rows
+    if a.share:                                         # N = 1 experiments: the main workload is ONE rank's share of an R x G job (tools/reproduce.sh share_sweep)
+        if world != 1:
+            raise SystemExit("--share is a one-GPU experiment")
+        sR, sG = (int(x) for x in a.share.lower().split("x"))
+        rows_per_gpu, G, strong = FULL_ROWS // sR, sG, False
     # MP_BENCH_BACKEND=gloo (testing only): several ranks on whatever GPUs the box has, collectives through the host —
     # exercises the N > 1 control flow of this file on a 1-GPU box; RCCL itself refuses two ranks on one device
     backend = os.environ.get("MP_BENCH_BACKEND", "nccl")
@@ -342,8 +370,14 @@ def main():
     # roofline); a pair idles the stream for ~6 us, so the timed region samples one launch in four
     every = int(os.environ.setdefault("MP_EVAL_TIMING_EVERY", "4"))
     lib = Library()                                   # the HIP library or an error: no fallback
-    w = Workload(lib, local, torch, rank * rows_per_gpu, rows_per_gpu, a)
+    w = Workload(lib, local, torch, ri * rows_per_gpu, rows_per_gpu, a, win_part=(gi, G))
     ctx, n_cand = w.ctx, w.n_cand
+    row_group = None                                    # the ranks this rank's counters are summed with: its row group
+    if world > 1 and G > 1 and R > 1:
+        for g in range(G):                              # (every rank creates every group, in the same order)
+            grp = dist.new_group([r * G + g for r in range(R)])
+            if g == gi:
+                row_group = grp
 
     # N > 1: the counters of every step are all-reduced over RCCL inside the timed region.  Headline: ONE collective per step
     # (what the drop-in pipeline does per alignment).  Side key: `--bucket` consecutive steps write into one [bucket][n_cand][3]
@@ -352,8 +386,9 @@ def main():
     from multiprime_amd.dist import StepBuckets
     rotate = os.environ.get("MP_BENCH_ROTATE", "1") != "0"
 
-    def timed_region(wl, bucket, n_world):
-        sb = StepBuckets(wl.n_cand, bucket, dev, n_world)
+    def timed_region(wl, bucket, n_world, n_reduce=None, group=None):
+        """`n_world` ranks take part in the barriers and the max over ranks; `n_reduce` of them (a row group) in the counters' all-reduce."""
+        sb = StepBuckets(wl.n_cand, bucket, dev, n_world if n_reduce is None else n_reduce, group)
 
         if rotate:
             def step():             # the launch that fills a step's block clears the next step's inside its own grid (mp_eval_launch_rotating)
@@ -389,18 +424,24 @@ def main():
             dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         return float(tt[0].item()), kern_ms, kern_n, samples, sb, (-float(tt[1].item()), float(tt[0].item()))
 
-    elapsed, kern_ms, kern_n, samples, sb, spread = timed_region(w, 1, world)
+    elapsed, kern_ms, kern_n, samples, sb, spread = timed_region(w, 1, world, R, row_group)
     gpu_counters = sb.block_of(a.steps - 1).cpu().numpy().copy()       # [n_cand][3], summed over ranks when N > 1
     bucketed = None
     if world > 1 and a.bucket > 1:
-        e1, *_ = timed_region(w, a.bucket, world)
+        e1, *_ = timed_region(w, a.bucket, world, R, row_group)
         bucketed = e1
 
     ev = torch.tensor([w.evals], dtype=torch.int64, device=dev)
     if world > 1:
         dist.all_reduce(ev, op=dist.ReduceOp.SUM)
     evals_total = int(ev.item())
-    checksum = gpu_counters.sum(axis=0).tolist()
+    # the counters of every candidate summed: over the window groups (their leaders, row shard 0, hold a group's reduced counters) this is the
+    # checksum of the whole workload — at N = 1 it comes out of the run whose counters are compared with the oracle's one by one, so a
+    # committed value lets an N > 1 run (no oracle leg there) say whether ITS counters are the same
+    cs = torch.tensor(gpu_counters.sum(axis=0) if ri == 0 else np.zeros(3, np.int64), dtype=torch.int64, device=dev)
+    if world > 1:
+        dist.all_reduce(cs, op=dist.ReduceOp.SUM)
+    checksum = [int(x) for x in cs.tolist()]
 
     # what the communicator itself says (N > 1): the ranks RCCL saw, through a communicator of the library's own
     comm_info = None
@@ -448,14 +489,20 @@ def main():
             "ms_per_step": elapsed / a.steps * 1e3,
             "higher_is_better": True, "scaling": "strong" if strong else "weak", "vs_baseline": None,
             "dtype": "u32", "data": "synthetic",
-            "config": {"workload": f"{w.describe()} per GPU x {world} GPU(s) = {whole} (SURVEY 8d input 4; synthetic 1M x 1 kb, row shards)",
-                       "rows_per_gpu": rows_per_gpu, "rows_total": world * rows_per_gpu, "cols": L, "k": k, "variation": a.v,
+            "config": {"workload": f"{w.describe()} per GPU x {world} GPU(s) = {whole} (SURVEY 8d input 4; synthetic 1M x 1 kb; shape {R}x{G}: row shards x window groups)",
+                       "rows_per_gpu": rows_per_gpu, "rows_total": R * rows_per_gpu, "cols": L, "k": k, "variation": a.v,
                        "candidates_per_window": C, "windows": w.W, "evals_per_step_per_gpu": w.evals, "iupac_extra_rows": w.n_extra,
-                       "parallelism": (f"row shards x{world}, one RCCL all-reduce of the [{n_cand}x3] int64 counters per step" if world > 1
-                                       else "one GPU holds every row")},
+                       "shape": f"{R}x{G}",
+                       "parallelism": ("one GPU holds every row" if world == 1 else
+                                       f"{G} window groups x 1 row shard: every GPU holds every row and evaluates 1/{G} of the windows, no collective" if R == 1 else
+                                       f"{R} row shards x {G} window group(s): one RCCL all-reduce of the [{n_cand}x3] int64 counters per step inside a row group of {R} ranks")},
             "roofline": roofline_block(w, per_launch_ms, samples, kern_n, every, mode),
             "measured_copy_GBs": copy_gbs, "setup_s": w.setup_s, "device_bytes": ctx.device_bytes(), "counter_checksum": checksum,
         }
+        default_workload = strong and (a.k, a.v, a.cands, a.cols, a.seed) == (18, 1, 8, 1000, 20250303)
+        if world > 1 and default_workload:
+            res["parity_checked"] = checksum == CONFIG4_CHECKSUM
+            res["parity_note"] = "the sum of all candidates' counters equals the N = 1 run's, whose counters were compared with the oracle's one by one"
         if world > 1:
             res["step_time_ranks_ms"] = {"min": spread[0] / a.steps * 1e3, "max": spread[1] / a.steps * 1e3}
             res["comm"] = comm_info
@@ -492,7 +539,7 @@ def main():
     if rank == 0 and world == 1 and not a.no_shard and rows_per_gpu != SHARD_ROWS:
         del sb
         w.ctx = ctx = None
-        w.rows = None
+        rows_full, w.rows = w.rows, None
         torch.cuda.empty_cache()
         try:
             res["weak_shard"] = weak_shard(lib, local, torch, dev, a, timed_region, every, not a.no_cpu)
@@ -507,8 +554,23 @@ def main():
             res["projected_strong_scaling"] = {
                 "n_gpus": FULL_ROWS // SHARD_ROWS, "ceiling": res["ms_per_step"] / res["weak_shard"]["ms_per_step"],
                 "ms_per_step_one_gpu": res["ms_per_step"], "ms_per_step_shard": res["weak_shard"]["ms_per_step"],
+                "shape": "8x1",
                 "note": "ms_per_step of the whole workload on one GPU over ms_per_step of the 1/8 shard on one GPU, both measured in this run: the speed-up 8 GPUs "
                         "reach if the all-reduce of the counters costs nothing (it is overlapped with the next step's kernel: dist.StepBuckets); north_star asks >= 6"}
+        # ... and what the 2-D shards reach (dist.ShardGrid: R row shards x G window groups, the alignment's rows replicated along the window axis,
+        # the all-reduce inside a row group only): the share of ONE rank of every shape, on this GPU, in this run, checked against the oracle
+        if not a.no_shapes and rows_per_gpu == FULL_ROWS:
+            try:
+                res["shard_shapes"] = shard_shapes(lib, local, torch, a, timed_region, rows_full, not a.no_cpu)
+                best = min((s for s in res["shard_shapes"].values() if isinstance(s, dict) and "ms_per_step" in s), key=lambda s: s["ms_per_step"], default=None)
+                ps = res.get("projected_strong_scaling")
+                if best is not None and ps is not None and best["ms_per_step"] < ps["ms_per_step_shard"]:
+                    ps.update({"ceiling": res["ms_per_step"] / best["ms_per_step"], "ms_per_step_shard": best["ms_per_step"], "shape": best["shape"]})
+                if any(isinstance(s, dict) and s.get("parity_checked") is False for s in res["shard_shapes"].values()):
+                    res["parity_checked"] = False
+            except Exception as e:              # noqa: BLE001 — as above
+                res["shard_shapes"] = {"error": f"{type(e).__name__}: {e}"}
+        del rows_full
     if rank == 0 and world == 1 and any(isinstance(p, dict) and p.get("tsv_equal_oracle") is False for p in res.get("pipeline", {}).values()):
         res["parity_checked"] = False
     # N = 1: the steps either side of the core step, each with its checker leg — detail file only
@@ -553,7 +615,7 @@ def headline(res):
     out = {key: res[key] for key in top if key in res}
     cfg = res.get("config", {})
     out["config"] = {key: cfg[key] for key in ("workload", "rows_per_gpu", "rows_total", "cols", "k", "variation", "candidates_per_window", "windows",
-                                               "evals_per_step_per_gpu", "parallelism") if key in cfg}
+                                               "evals_per_step_per_gpu", "shape", "parallelism") if key in cfg}
     out["config"]["workload"] = str(out["config"].get("workload", ""))[:240]
     rf = res.get("roofline") or {}
     # `bound` of the contract is the roofline `peak` belongs to (HBM; integer bit-mask work has no MFMA roofline); `limiter` is the
@@ -634,6 +696,34 @@ def weak_shard(lib, local, torch, dev, a, timed_region, every, with_cpu):
         out["parity_checked"] = cb.get("parity_checked")
     if not a.no_pipeline:
         out["pipeline"] = pipeline_block(lib, local, w.rows, a)
+    return out
+
+
+def shard_shapes(lib, local, torch, a, timed_region, rows_full, with_cpu, n_gpus=8):
+    """One rank's share of config 4 under every 2-D shape R x G of `n_gpus` ranks (R contiguous row shards x G contiguous window groups;
+    8x1 is `weak_shard`): rows [0, 1048576 / R) x window group 0 of G, timed like the headline, counters against the oracle on the same
+    rows and windows.  The all-reduce of a shape runs inside a row group (R ranks, [n_candidates / G x 3] counters) and is not counted,
+    as in projected_strong_scaling."""
+    out = {}
+    for R in (4, 2, 1):
+        G = n_gpus // R
+        n = FULL_ROWS // R
+        w = Workload(lib, local, torch, 0, n, a, win_part=(0, G), rows=rows_full[:n])
+        elapsed, kern_ms, kern_n, samples, sb, _ = timed_region(w, 1, 1)
+        counters = sb.block_of(a.steps - 1).cpu().numpy().copy()
+        blk = {"shape": f"{R}x{G}", "rows": n, "windows": w.W, "ms_per_step": elapsed / a.steps * 1e3, "kernel_ms": kern_ms / max(kern_n, 1),
+               "evals_per_step": w.evals, "eval_mode": eval_mode(w.n_rows, w.ctx), "device_bytes": w.ctx.device_bytes(),
+               "allreduce_ranks": R, "allreduce_bytes": int(w.n_cand) * 24}
+        if with_cpu:
+            blocks = OracleBlocks(w, w.rows, a.cpu_threads)
+            want, _ = blocks.eval(w.cw, w.codes)
+            blocks.close()
+            blk["parity_checked"] = bool(np.array_equal(want, counters))
+        out[blk["shape"]] = blk
+        del sb
+        w.ctx.close()
+        w.ctx = None
+        torch.cuda.empty_cache()
     return out
 
 

@@ -55,6 +55,9 @@ def parse_args(argv=None):
     p.add_argument("-a", "--away", type=int, default=4, metavar="<int>", help="Hairpin: minimal distance of paired bases. Default: 4.")
     p.add_argument("-o", "--out", type=str, default=None, metavar="<file>", help="output file")
     p.add_argument("--device", type=int, default=None, help="GPU ordinal (default 0); with several ranks: the ordinal of local rank 0, rank r opens D + r")
+    p.add_argument("--grid", default=None, metavar="RxG|auto",
+                   help="with several ranks: R row shards x G window groups instead of row shards only (R x G = ranks); auto = as many "
+                        "window groups as fit the device memory")
     p.add_argument("--ngpu", type=int, default=1, help="GPUs of this node to use: re-launches this command as that many ranks")
     p.add_argument("--batch", type=str, default=None, metavar="<file>",
                    help="file of `input<TAB>output` lines: all of them in one process per GPU with this command's flags")
@@ -99,13 +102,13 @@ def _respawn(n, argv):
     return subprocess.call(cmd)
 
 
-def _core(args, inp, out, device, comm, context=None):
+def _core(args, inp, out, device, comm, context=None, grid=None):
     from .core import NN_degenerate
     return NN_degenerate(seq_file=inp, primer_length=args.plen, coverage=args.fraction,
                          number_of_dege_bases=args.dnum, score_of_dege_bases=args.degeneracy,
                          raw_entropy_threshold=args.entropy, product_len=args.size, position=args.coordinate,
                          variation=args.variation, distance=args.away, GC=args.gc, nproc=args.proc, outfile=out,
-                         device=device, comm=comm, write_json=not args.no_json, write_bitsets=args.bitsets, context=context)
+                         device=device, comm=comm, write_json=not args.no_json, write_bitsets=args.bitsets, context=context, grid=grid)
 
 
 def _closing_line(e1, e2):
@@ -235,7 +238,7 @@ def main(argv=None):
     if args.batch is not None:
         _run_batch(args, rank, world, device, argv)     # clusters are independent: no process group, no collective
         return
-    comm = None
+    comm = grid = None
     if world > 1:                                       # one alignment on several GPUs: its rows are sharded
         import torch
         import torch.distributed as dist
@@ -248,9 +251,19 @@ def main(argv=None):
         else:
             dist.init_process_group(backend)
         comm = RowShards()
+        # --grid RxG: R row shards x G window groups (dist.ShardGrid); "auto": as many window groups as the device memory allows —
+        # a window group of one row shard has no collective at all
+        if args.grid:
+            from .dist import ShardGrid
+            if args.grid == "auto":                            # the file's bytes stand for rows x columns
+                shape = ShardGrid.best_shape(world, os.path.getsize(args.input), 1)
+            else:
+                shape = ShardGrid.parse(args.grid, world)
+            if shape[1] > 1:
+                grid, comm = ShardGrid(*shape), None
     e1 = time.time()
     try:
-        app = _core(args, args.input, args.out, device, comm)
+        app = _core(args, args.input, args.out, device, comm, grid=grid)
         app.run()
     finally:
         if comm is not None:

@@ -77,7 +77,7 @@ class NN_degenerate(object):
     def __init__(self, seq_file, primer_length=18, coverage=0.8, number_of_dege_bases=18, score_of_dege_bases=1000,
                  product_len=250, position="2,-1", variation=2, raw_entropy_threshold=3.6, distance=4, GC="0.4,0.6",
                  nproc=10, outfile="", *, library: Library | None = None, device: int = 0, comm=None,
-                 write_json: bool = True, write_bitsets: bool = False, keep_bitsets: bool = False, context=None):
+                 write_json: bool = True, write_bitsets: bool = False, keep_bitsets: bool = False, context=None, grid=None):
         self.primer_length = int(primer_length)
         self.coverage = coverage
         self.number_of_dege_bases = number_of_dege_bases
@@ -95,6 +95,16 @@ class NN_degenerate(object):
         self.keep_bitsets = keep_bitsets        # leave those bitsets on the device for a pairing stage in this process (pairing.Primers_filter(core=...))
         self.mask_index = {}
         self.comm = comm                        # multiprime_amd.dist.RowShards or None
+        # multiprime_amd.dist.ShardGrid: R row shards x G window groups — this rank's row group is the RowShards (or None: one row shard),
+        # this rank's window group a contiguous share of the windows; the group leaders' rows are gathered on rank 0 (run)
+        self.grid = grid
+        if grid is not None:
+            if comm is not None:
+                raise ValueError("pass either comm (row shards) or grid (row shards x window groups)")
+            if (write_bitsets or keep_bitsets) and grid.G > 1:
+                raise ValueError("coverage bitsets span every window: not with window groups (grid.G > 1)")
+            self.comm = comm = grid.comm
+        self._win_part = grid.window_part() if grid is not None else (0, 1)
         k = self.primer_length
         if not 2 <= k <= 63:
             # the reference has no such limit; documented in INTEGRATION.md (one k-mer = one machine word per plane, MP_MAX_K)
@@ -184,8 +194,11 @@ class NN_degenerate(object):
         """Device stage (windows, statistics, histograms) and the native per-window planning.  Returns the
         host.Plan, or None when the region holds no window."""
         k, v = self.primer_length, self.variation
-        p0 = int(self.start_position)
-        W = int(self.stop_position - self.start_position - k)
+        w_all = int(self.stop_position - self.start_position - k)              # windows = range(start, stop - k), V20:1141 ...
+        g, G = self._win_part                                                   # ... of which this rank's window group takes a contiguous share
+        lo, hi = (max(w_all, 0) * g // G, max(w_all, 0) * (g + 1) // G) if G > 1 else (0, w_all)
+        self._p0 = p0 = int(self.start_position) + lo
+        W = hi - lo
         self.n_windows = W
         if W <= 0:
             return None
@@ -272,7 +285,8 @@ class NN_degenerate(object):
         # per-window histograms; sorted by first row only when the id lists of the JSON files need the labels
         # (the Python JSON writer of the row-sharded path wants them sorted by first row; the native writer takes them as they come)
         # MP_JSON_WRITER=python keeps the Python writer in a single process too (tests compare the two byte for byte)
-        self._native_json = self.write_json and self.comm is None and os.environ.get("MP_JSON_WRITER", "native") != "python"
+        self._native_json = (self.write_json and self.comm is None and self._win_part[1] == 1 and
+                             os.environ.get("MP_JSON_WRITER", "native") != "python")
         x_row = ex_r.astype(np.int64) + row_base
         if streamed:
             if not early_unique:
@@ -413,7 +427,7 @@ class NN_degenerate(object):
             # turns the result columns into lists)
             dimer_out = []
             dimers = self._beside(lambda: dimer_out.append(self._self_dimers(res["codes"])), beside=self.comm is None)
-            p0 = int(self.start_position)
+            p0 = self._p0
             wins = res["window"].tolist()
             cbit, tbit = res["cbit"].tolist(), res["tbit"].tolist()
             cov, f_mis, r_mis = res["cov"].tolist(), res["f_mis"].tolist(), res["r_mis"].tolist()
@@ -456,7 +470,19 @@ class NN_degenerate(object):
                     t0 = time.time()
                     self._write_bitsets(rows_out)
                     self.stats["bitsets_s"] += time.time() - t0
-        if self.comm is None or self.comm.rank == 0:
+        if self.grid is not None and self.grid.G > 1:
+            # window groups: the leaders' rows (window order = group order) and side-file entries meet on rank 0, which writes
+            parts = self.grid.gather_outputs((rows_out, non_cov_out, gap_out))
+            if parts is not None:
+                rows_out, non_cov_out, gap_out = [], {}, {}
+                for part_rows, part_nc, part_gap in parts:
+                    rows_out += part_rows
+                    non_cov_out.update(part_nc)
+                    gap_out.update(part_gap)
+                t0 = time.time()
+                self._write(rows_out, non_cov_out, gap_out)
+                self.stats["write_s"] = time.time() - t0
+        elif self.comm is None or self.comm.rank == 0:
             t0 = time.time()
             self._write(rows_out, non_cov_out, gap_out)
             self.stats["write_s"] = time.time() - t0
@@ -620,7 +646,7 @@ class NN_degenerate(object):
                 fo.write("\t".join(map(str, row)) + "\n")
         if self.write_json and getattr(self, "_native_json", False) and self.plan is not None:
             k = self.primer_length
-            p0 = int(self.start_position)
+            p0 = self._p0
             wins = np.asarray([int(r[0]) - p0 for r in rows_out], np.int32)
             codes = (iupac.MASK_LUT[np.frombuffer("".join(r[3] for r in rows_out).encode(), np.uint8)].reshape(len(rows_out), k)
                      if rows_out else np.zeros((0, k), np.uint8))

@@ -308,6 +308,74 @@ class RowShards:
         return out.numpy()
 
 
+class ShardGrid:
+    """R row shards x G window groups of the `world` ranks of one job ("windows are independent, so an alternative / extra
+    axis is window-sharding").  Rank r is row shard r // G of window group r % G: it loads the rows of ITS row shard (the alignment is
+    replicated along the window axis) and works on ITS contiguous share of the windows only.  The G window groups are independent
+    jobs of R ranks each — every collective of RowShards runs inside a row group (R ranks: ranks with the same r % G), over
+    1 / G of the windows' tables and counters — and the leaders of the groups (row shard 0: ranks 0 .. G - 1) hand their output
+    rows to rank 0.  R = world, G = 1 is the plain row sharding; R = 1, G = world needs no collective at all.
+
+    Shape: `best_shape` — bench.py's `shard_shapes` block measures one rank's share of config 4 under 8x1, 4x2, 2x4 and 1x8 on one
+    GPU (round 6: 32.3 / 30.9 / 30.9 / 27.8 us per step); window groups win whenever a GPU can hold every row, because a group
+    of one row shard has no all-reduce to wait for and the sliding kernel keeps its long row slices."""
+
+    def __init__(self, R, G):
+        if not dist.is_initialized():
+            raise RuntimeError("torch.distributed is not initialised")
+        world = dist.get_world_size()
+        if R < 1 or G < 1 or R * G != world:
+            raise ValueError(f"grid {R}x{G} does not cover {world} ranks")
+        self.R, self.G, self.world = R, G, world
+        self.rank = dist.get_rank()
+        self.ri, self.gi = divmod(self.rank, G)
+        self.row_group = None
+        if R > 1 and G > 1:
+            for g in range(G):                                  # every rank creates every group, in the same order
+                grp = dist.new_group([r * G + g for r in range(R)])
+                if g == self.gi:
+                    self.row_group = grp
+        # the RowShards of this rank's row group (None: a group of one rank computes alone)
+        self.comm = RowShards(group=self.row_group) if R > 1 else None
+
+    @staticmethod
+    def best_shape(world, n_rows, n_cols, replica_budget_bytes=None):
+        """(R, G): as many window groups as the device memory allows — a rank of shape R x G holds n_rows / R rows at ~6 bytes per
+        cell (planes, column planes, window tables: DESIGN.md section 3 measures 5.1 GB for 10^6 x 1000)."""
+        import os
+        budget = replica_budget_bytes if replica_budget_bytes is not None else int(float(os.environ.get("MP_GRID_REPLICA_GB", "96")) * (1 << 30))
+        for G in sorted((g for g in range(1, world + 1) if world % g == 0), reverse=True):
+            R = world // G
+            if (n_rows + R - 1) // R * n_cols * 6 <= budget:
+                return R, G
+        return world, 1
+
+    @staticmethod
+    def parse(text, world):
+        """'RxG' -> (R, G), checked against the world size."""
+        try:
+            R, G = (int(x) for x in text.lower().split("x"))
+        except ValueError:
+            raise ValueError(f"grid {text!r}: expected RxG, e.g. 2x4") from None
+        if R < 1 or G < 1 or R * G != world:
+            raise ValueError(f"grid {text!r} does not cover {world} ranks")
+        return R, G
+
+    @property
+    def leader(self):
+        return self.ri == 0
+
+    def window_part(self):
+        return self.gi, self.G
+
+    def gather_outputs(self, payload):
+        """The leaders' payloads in window-group order on rank 0 (None elsewhere).  A handful of output rows and, with the JSON side
+        files, their id lists: pickled objects (gather_object), once per alignment."""
+        box = [None] * self.world if self.rank == 0 else None
+        dist.gather_object(payload if self.leader else None, box, dst=0)
+        return [box[g] for g in range(self.G)] if self.rank == 0 else None
+
+
 class StepBuckets:
     """Bucketed all-reduce of per-step counter blocks over a ring of buffers (bench.py, batch pipelines).
 

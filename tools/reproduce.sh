@@ -56,5 +56,29 @@ for k, v in d.items():
 "
   rocprofv3 --kernel-trace --stats -d $O/prof/trace -o t -- python tools/side_bench.py > /dev/null 2>&1
   python tools/summarize_profile.py $O/prof 2>/dev/null | head -24 | tee $O/side_kernels.txt ;;
+shapes)          # bench.py's shard_shapes block alone (headline + 8x1 shard + 4x2 / 2x4 / 1x8), no side measurements
+  timeout 1200 python bench.py --steps 40 --warmup 5 --no-variants --no-pipeline --no-side "$@" > $O/bench.txt 2> $O/bench.err; tail -c 400 $O/bench.err; tail -1 $O/bench.txt
+  python -c "
+import json
+d = json.load(open('bench_detail.json'))
+for k, v in d.get('shard_shapes', {}).items(): print(k, v)
+print('8x1', d['weak_shard']['ms_per_step'], d.get('projected_strong_scaling'))
+" | tee $O/shapes.txt ;;
+bench_ranks)     # bench.py's N > 1 control flow on the ONE GPU of a test box: ranks over gloo (RCCL refuses two ranks on one device), every shape
+  for spec in "2 1x2" "2 2x1" "4 2x2" "4 1x4" "4 auto"; do set -- $spec
+    echo "# N=$1 --shape $2"
+    MP_BENCH_BACKEND=gloo timeout 900 python -m torch.distributed.run --nnodes=1 --nproc-per-node $1 --master-addr 127.0.0.1 --master-port 29533 \
+      bench.py --gpus $1 --steps 10 --warmup 2 --shape $2 2> $O/err_$1_$2.txt | tail -1 | python -c "
+import json, sys
+d = json.loads(sys.stdin.read())
+print({k: d[k] for k in ('n_gpus', 'ms_per_step', 'value', 'parity_checked')}, d['config']['shape'], d['config']['parallelism'])"
+  done 2>&1 | tee $O/bench_ranks.txt ;;
+share_sweep)     # profiles/r06_share_sweep.txt: one rank's share of the 1x8 / 2x4 / 8x1 job under band lengths and row words per lane of the sliding kernel
+  for share in 1x8 2x4 8x1; do for gw in 1 2 4; do for band in 0 4 6 8 10 12 15 20 30; do
+    if [ $band = 0 ]; then unset MP_SLIDE_BAND; else export MP_SLIDE_BAND=$band; fi
+    MP_EVAL_SLIDE=1 MP_SLIDE_GW=$gw timeout 300 python bench.py --steps 60 --warmup 5 --share $share --no-variants --no-pipeline --no-side --no-shard --no-cpu 2>/dev/null | tail -1 | python -c "
+import json, sys
+d = json.loads(sys.stdin.read()); print('share $share gw $gw band $band ms_per_step %.5f kernel_ms %.5f' % (d['ms_per_step'], d['roofline']['kernel_ms']))"
+  done; done; done 2>&1 | tee $O/share_sweep.txt ;;
 *) echo "unknown target $T"; exit 2 ;;
 esac
