@@ -385,12 +385,18 @@ def main():
     # (dist.StepBuckets; xGMI rings are latency-bound at 180 KB per step).
     from multiprime_amd.dist import StepBuckets
     rotate = os.environ.get("MP_BENCH_ROTATE", "1") != "0"
+    two_streams = os.environ.get("MP_BENCH_STREAMS", "1") == "2"
 
     def timed_region(wl, bucket, n_world, n_reduce=None, group=None):
         """`n_world` ranks take part in the barriers and the max over ranks; `n_reduce` of them (a row group) in the counters' all-reduce."""
         sb = StepBuckets(wl.n_cand, bucket, dev, n_world if n_reduce is None else n_reduce, group)
 
-        if rotate:
+        if two_streams and sb.world == 1:
+            def step():             # steps alternate between the context's two streams and between two counter blocks (mp_eval_launch_alt)
+                blk = sb.begin_step()
+                (wl.ctx.eval_launch if sb.i % 2 == 0 else wl.ctx.eval_launch_alt)(blk.data_ptr())
+                sb.end_step()
+        elif rotate:
             def step():             # the launch that fills a step's block clears the next step's inside its own grid (mp_eval_launch_rotating)
                 out, nxt = sb.begin_rotating()
                 wl.ctx.eval_launch_rotating(out.data_ptr(), nxt.data_ptr())

@@ -206,6 +206,16 @@ int mp_eval_launch(mp_ctx *ctx, int64_t *device_out);
  * using device_clear while the launch runs (a collective still reading it on another stream must have been waited for).
  * device_clear == device_out is an error. */
 int mp_eval_launch_rotating(mp_ctx *ctx, int64_t *device_out, int64_t *device_clear);
+/* mp_eval_launch on the context's SECOND stream (created on first use): a caller with a queue of independent evaluations of one
+ * staged candidate set — steps of a benchmark, alignments of a batch that share their candidates' windows — alternates between
+ * mp_eval_launch and this call, and consecutive launches overlap where they do not use the chip: the next kernel's dispatch, its
+ * workgroups' first misses and warm-up columns run while the last workgroups of the kernel before it finish, and the clearing
+ * dispatch of one block runs beside the evaluation into the other (a launch of a 1/8 share of config 4 is 17 us of window work in
+ * a 27 us kernel).  The two launches in flight must write different counter blocks.  The first launch after mp_eval_upload has to be
+ * an mp_eval_launch (it builds what the staged set needs once); results are complete when BOTH streams are (mp_eval_sync, or the
+ * caller's device-wide synchronisation). */
+int mp_eval_launch_alt(mp_ctx *ctx, int64_t *device_out);
+int mp_eval_sync(mp_ctx *ctx);
 
 /* HIP-event timing of the evaluation kernels themselves (recorded on the context's stream around
  * mp_eval_launch since the last reset): total milliseconds and number of launches timed.  Every

@@ -58,6 +58,8 @@ SYMBOLS = [
     ("mp_eval_upload", C.c_int, [_p, C.c_int32, _p, _p, C.c_uint64, C.c_uint64]),
     ("mp_eval_launch", C.c_int, [_p, _p]),
     ("mp_eval_launch_rotating", C.c_int, [_p, _p, _p]),
+    ("mp_eval_launch_alt", C.c_int, [_p, _p]),
+    ("mp_eval_sync", C.c_int, [_p]),
     ("mp_eval_timing", C.c_int, [_p, C.c_int32, C.POINTER(C.c_double), C.POINTER(C.c_int32)]),
     ("mp_eval_timing_samples", C.c_int, [_p, C.c_int32, _p, C.POINTER(C.c_int32)]),
     ("mp_eval_plan_info", C.c_int, [_p, _p]),
@@ -449,6 +451,13 @@ class Context:
     def eval_launch_rotating(self, out_ptr: int, clear_ptr: int = 0):
         """Evaluate into the zeroed block at out_ptr; the same launch zeroes the block at clear_ptr (0: none) for the next one."""
         self._ck(self.d.mp_eval_launch_rotating(self.h, C.c_void_p(out_ptr), C.c_void_p(clear_ptr) if clear_ptr else None))
+
+    def eval_launch_alt(self, out_ptr: int):
+        """eval_launch on the context's second stream (mp_eval_launch_alt): alternate with eval_launch, different counter blocks."""
+        self._ck(self.d.mp_eval_launch_alt(self.h, C.c_void_p(out_ptr)))
+
+    def eval_sync(self):
+        self._ck(self.d.mp_eval_sync(self.h))
 
     def eval_timing(self, reset: bool = False):
         ms, n = C.c_double(0), C.c_int32(0)

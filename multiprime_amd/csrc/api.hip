@@ -283,6 +283,7 @@ void mp_destroy(mp_ctx *c) {
     if (!c) return;
     (void)hipSetDevice(c->dev);
     (void)hipDeviceSynchronize();
+    if (c->alt_stream) (void)hipStreamDestroy(c->alt_stream);
     free_comm(c);
     free_msa(c);
     free_seq(c);

@@ -119,6 +119,7 @@ struct mp_ctx {
     char err[512] = {0};
     int dev = 0;
     hipStream_t stream = nullptr;
+    hipStream_t alt_stream = nullptr;        // mp_eval_launch_alt: the library's own second stream (eval.hip)
     int64_t bytes = 0;
     // alignment
     int n_rows = 0, n_pad = 0, n_chunks = 0, max_len = 0, ustride = 0;

@@ -1378,6 +1378,30 @@ int mp_eval_launch(mp_ctx *c, int64_t *device_out) { return eval_launch_impl(c, 
 
 int mp_eval_launch_rotating(mp_ctx *c, int64_t *device_out, int64_t *device_clear) { return eval_launch_impl(c, device_out, device_clear, false); }
 
+int mp_eval_launch_alt(mp_ctx *c, int64_t *device_out) {
+    if (!c) return MP_ERR_ARG;
+    HIPCK(c, hipSetDevice(c->dev));
+    if (c->pp_dirty || (c->slide_items > 0 && c->qp_dirty && c->n_patch))
+        return fail(c, MP_ERR_ARG, "mp_eval_launch_alt: the first launch of a staged candidate set has to be mp_eval_launch");
+    if (!c->alt_stream) {
+        HIPCK(c, hipStreamSynchronize(c->stream));            // whatever the first launches built is there before the second stream exists
+        HIPCK(c, hipStreamCreateWithFlags(&c->alt_stream, hipStreamNonBlocking));
+    }
+    hipStream_t keep = c->stream;
+    c->stream = c->alt_stream;                                // (everything a launch enqueues goes to the context's stream)
+    const int rc = eval_launch_impl(c, device_out, nullptr, true);
+    c->stream = keep;
+    return rc;
+}
+
+int mp_eval_sync(mp_ctx *c) {
+    if (!c) return MP_ERR_ARG;
+    HIPCK(c, hipSetDevice(c->dev));
+    HIPCK(c, hipStreamSynchronize(c->stream));
+    if (c->alt_stream) HIPCK(c, hipStreamSynchronize(c->alt_stream));
+    return MP_OK;
+}
+
 int mp_eval_timing(mp_ctx *c, int32_t reset, double *total_ms, int32_t *n_launches) {
     if (!c) return MP_ERR_ARG;
     HIPCK(c, hipSetDevice(c->dev));

@@ -555,6 +555,9 @@ int mp_eval_launch(mp_ctx *c, int64_t *out) {
     return eval_all(c, c->n_cand, c->cand_win, c->cand_codes, c->sF, c->sR, out);
 }
 
+int mp_eval_launch_alt(mp_ctx *c, int64_t *out) { return mp_eval_launch(c, out); }      /* (one "stream": the calling thread) */
+int mp_eval_sync(mp_ctx *c) { return c ? MP_OK : MP_ERR_ARG; }
+
 /* the rotating form (mprime.h): out is taken as zeroed and ADDED to, the other block is cleared */
 int mp_eval_launch_rotating(mp_ctx *c, int64_t *out, int64_t *clear) {
     if (!c || !c->cand_win) return c ? fail(c, MP_ERR_ARG, "mp_eval_upload has not run") : MP_ERR_ARG;

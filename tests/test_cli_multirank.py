@@ -111,3 +111,15 @@ def test_batch_workers_and_processes_on_one_gpu(oracle_lib, tmp_path):
         assert last["clusters"] == 5 and (last.get("processes") == 2 if tag == "procs" else last["workers"] == 3)
         n_seq = sum(1 for line in open(inp) if line.startswith(">"))
         assert last["sequences"] == 5 * n_seq
+
+
+@pytest.mark.parametrize("grid,world", [("2x2", 4), ("auto", 3)])
+def test_grid_flag_splits_rows_and_windows(grid, world, oracle_lib, tmp_path):
+    """--grid RxG: R row shards x G window groups (dist.ShardGrid); auto = window groups only when the alignment fits a device."""
+    name = "ivc_v1"
+    inp, out = _input(name, tmp_path), tmp_path / (name + ".out")
+    r = subprocess.run([sys.executable, SCRIPT, "-i", str(inp), "-o", str(out), "--ngpu", str(world), "--grid", grid] + _flags(name),
+                       env=_env(oracle_lib), capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert r.stdout.count("Total times") == 1
+    check_outputs(name, out)

@@ -80,5 +80,11 @@ share_sweep)     # profiles/r06_share_sweep.txt: one rank's share of the 1x8 / 2
 import json, sys
 d = json.loads(sys.stdin.read()); print('share $share gw $gw band $band ms_per_step %.5f kernel_ms %.5f' % (d['ms_per_step'], d['roofline']['kernel_ms']))"
   done; done; done 2>&1 | tee $O/share_sweep.txt ;;
+streams)         # one stream (rotating launches) against two (mp_eval_launch_alt): the whole workload and one rank's shares
+  for share in "" 1x8 2x4 8x1; do for st in 1 2; do for rep in 1 2; do
+    MP_BENCH_STREAMS=$st timeout 300 python bench.py --steps 80 --warmup 6 ${share:+--share $share} --no-variants --no-pipeline --no-side --no-shard --no-cpu 2>/dev/null | tail -1 | python -c "
+import json, sys
+d = json.loads(sys.stdin.read()); print('share ${share:-1x1} streams $st ms_per_step %.5f kernel_ms %.5f' % (d['ms_per_step'], d['roofline']['kernel_ms']))"
+  done; done; done 2>&1 | tee $O/streams.txt ;;
 *) echo "unknown target $T"; exit 2 ;;
 esac
