@@ -66,7 +66,7 @@ FULL_ROWS = 1048576            # BASELINE.json configs[3]: 1M sequences
 SHARD_ROWS = 131072            # what one GPU holds of it in the 8-GPU job
 # measured ceilings (tools/ubench.hip on the same GPU pool, profiles/r02_ubench.json); used when that file is absent
 DEFAULT_CEILINGS = {"valu_wave_instr_per_s_per_simd": 8.5e8, "l2_read_GBs": 31559.0, "source": "built-in defaults (profiles/r02_ubench.json missing)"}
-COUNTER_FILES = ("r05_counters.json", "r04_counters.json", "r03_counters.json")
+COUNTER_FILES = ("r06_counters.json", "r05_counters.json", "r04_counters.json", "r03_counters.json")
 # sources of the timed kernel (eval_chain_kernel and what it includes): the key of a counter entry
 KERNEL_SOURCES = ("eval.hip", "evalprog.hip", "evalslide.hip", "slidecore.hpp", "slideplan.hpp", "evalslide.hpp", "chainbody.hpp", "bitslice.hpp", "common.hpp",
                   "winwords.hpp", "evalprog.hpp")
@@ -385,13 +385,24 @@ def main():
     # (dist.StepBuckets; xGMI rings are latency-bound at 180 KB per step).
     from multiprime_amd.dist import StepBuckets
     rotate = os.environ.get("MP_BENCH_ROTATE", "1") != "0"
-    two_streams = os.environ.get("MP_BENCH_STREAMS", "1") == "2"
+    # Steps are independent evaluations of one staged candidate set into alternating counter blocks.  Where no collective follows a step
+    # (one GPU, or window groups of one row shard) they are issued alternately on the context's TWO streams (mp_eval_launch /
+    # mp_eval_launch_alt): the next kernel's dispatch, first misses and warm-up columns overlap the last workgroups of the one before it —
+    # worth 2 % on the whole workload and 30 % on a 1/8 share, whose 27 us kernel holds 17 us of window work (profiles/r06_streams.txt).
+    # MP_BENCH_STREAMS=1 issues them on one stream (rotating launches), as rounds 1-5 did; the roofline's kernel time ALWAYS comes from
+    # such a pass (a launch alone on the chip), reported beside the headline as `ms_per_step_one_stream`.
+    two_streams = os.environ.get("MP_BENCH_STREAMS", "2") == "2"
 
-    def timed_region(wl, bucket, n_world, n_reduce=None, group=None):
-        """`n_world` ranks take part in the barriers and the max over ranks; `n_reduce` of them (a row group) in the counters' all-reduce."""
+    def timed_region(wl, bucket, n_world, n_reduce=None, group=None, streams=None, steps=None):
+        """`n_world` ranks take part in the barriers and the max over ranks; `n_reduce` of them (a row group) in the counters' all-reduce.
+        Returns (..., streams used)."""
         sb = StepBuckets(wl.n_cand, bucket, dev, n_world if n_reduce is None else n_reduce, group)
+        use2 = (two_streams if streams is None else streams == 2) and sb.world == 1
+        keep_every = os.environ.get("MP_EVAL_TIMING_EVERY")
+        if use2:
+            os.environ["MP_EVAL_TIMING_EVERY"] = "0"            # (an event pair between two overlapping kernels measures neither)
 
-        if two_streams and sb.world == 1:
+        if use2:
             def step():             # steps alternate between the context's two streams and between two counter blocks (mp_eval_launch_alt)
                 blk = sb.begin_step()
                 (wl.ctx.eval_launch if sb.i % 2 == 0 else wl.ctx.eval_launch_alt)(blk.data_ptr())
@@ -415,7 +426,7 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
         t0 = time.perf_counter()
-        for _ in range(a.steps):
+        for _ in range(a.steps if steps is None else steps):
             step()
         sb.drain()
         torch.cuda.synchronize()
@@ -425,16 +436,37 @@ def main():
         dt = time.perf_counter() - t0
         kern_ms, kern_n = wl.ctx.eval_timing(reset=True)
         samples = np.sort(wl.ctx.eval_timing_samples())
+        if keep_every is None:
+            os.environ.pop("MP_EVAL_TIMING_EVERY", None)
+        else:
+            os.environ["MP_EVAL_TIMING_EVERY"] = keep_every
         tt = torch.tensor([dt, -dt], dtype=torch.float64, device=dev)
         if n_world > 1:
             dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        return float(tt[0].item()), kern_ms, kern_n, samples, sb, (-float(tt[1].item()), float(tt[0].item()))
+        return float(tt[0].item()), kern_ms, kern_n, samples, sb, (-float(tt[1].item()), float(tt[0].item())), 2 if use2 else 1
 
-    elapsed, kern_ms, kern_n, samples, sb, spread = timed_region(w, 1, world, R, row_group)
+    def timed_pair(wl, n_world, n_reduce=None, group=None):
+        """The headline's timed region and, when that overlapped its steps on two streams, a second one on ONE stream for the kernel's own
+        duration (HIP events around single launches: the roofline's kernel time) — (elapsed, kernel ms, launches timed, samples, buckets,
+        spread, streams of the first region, ms per step on one stream)."""
+        pick = None
+        if n_world == 1 and two_streams and "MP_BENCH_STREAMS" not in os.environ:
+            # one GPU: the launch strategy is chosen by a short trial of both (a kernel that fills the chip for 140 us gains nothing from a
+            # second stream and may lose to it; a 27 us share gains 30 %) — like any launch parameter, and reported as `steps_in_flight`
+            trial = {st: min(timed_region(wl, 1, 1, streams=st, steps=12)[0] for _ in range(2)) for st in (1, 2)}
+            pick = min(trial, key=trial.get)
+        elapsed, kern_ms, kern_n, samples, sb, spread, used = timed_region(wl, 1, n_world, n_reduce, group, streams=pick)
+        one_ms = elapsed / a.steps * 1e3
+        if used == 2:
+            e1, kern_ms, kern_n, samples, _, _, _ = timed_region(wl, 1, 1, streams=1)
+            one_ms = e1 / a.steps * 1e3
+        return elapsed, kern_ms, kern_n, samples, sb, spread, used, one_ms
+
+    elapsed, kern_ms, kern_n, samples, sb, spread, streams_used, one_stream_ms = timed_pair(w, world, R, row_group)
     gpu_counters = sb.block_of(a.steps - 1).cpu().numpy().copy()       # [n_cand][3], summed over ranks when N > 1
     bucketed = None
     if world > 1 and a.bucket > 1:
-        e1, *_ = timed_region(w, a.bucket, world, R, row_group)
+        e1, *_ = timed_region(w, a.bucket, world, R, row_group, streams=1)
         bucketed = e1
 
     ev = torch.tensor([w.evals], dtype=torch.int64, device=dev)
@@ -493,6 +525,7 @@ def main():
             "unit": "evals/s",
             "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
             "ms_per_step": elapsed / a.steps * 1e3,
+            "steps_in_flight": streams_used, "ms_per_step_one_stream": one_stream_ms,
             "higher_is_better": True, "scaling": "strong" if strong else "weak", "vs_baseline": None,
             "dtype": "u32", "data": "synthetic",
             "config": {"workload": f"{w.describe()} per GPU x {world} GPU(s) = {whole} (SURVEY 8d input 4; synthetic 1M x 1 kb; shape {R}x{G}: row shards x window groups)",
@@ -548,7 +581,7 @@ def main():
         rows_full, w.rows = w.rows, None
         torch.cuda.empty_cache()
         try:
-            res["weak_shard"] = weak_shard(lib, local, torch, dev, a, timed_region, every, not a.no_cpu)
+            res["weak_shard"] = weak_shard(lib, local, torch, dev, a, timed_pair, every, not a.no_cpu)
         except Exception as e:                  # noqa: BLE001 — as above
             res["weak_shard"] = {"error": f"{type(e).__name__}: {e}"}
         if res["weak_shard"].get("parity_checked") is False:
@@ -561,17 +594,21 @@ def main():
                 "n_gpus": FULL_ROWS // SHARD_ROWS, "ceiling": res["ms_per_step"] / res["weak_shard"]["ms_per_step"],
                 "ms_per_step_one_gpu": res["ms_per_step"], "ms_per_step_shard": res["weak_shard"]["ms_per_step"],
                 "shape": "8x1",
-                "note": "ms_per_step of the whole workload on one GPU over ms_per_step of the 1/8 shard on one GPU, both measured in this run: the speed-up 8 GPUs "
-                        "reach if the all-reduce of the counters costs nothing (it is overlapped with the next step's kernel: dist.StepBuckets); north_star asks >= 6"}
+                "ceiling_one_stream": res["ms_per_step_one_stream"] / res["weak_shard"]["ms_per_step_one_stream"],
+                "note": "ms_per_step of the whole workload on one GPU over ms_per_step of one rank's share of the 8-GPU job on one GPU, both measured in this run "
+                        "the same way (steps on two streams; `ceiling_one_stream`: both on one stream): the speed-up 8 GPUs reach when the exchange of the counters "
+                        "costs nothing — true by construction for window groups of one row shard (shape 1x8: no collective), overlapped with the next step's "
+                        "kernel for row shards (dist.StepBuckets); north_star asks >= 6"}
         # ... and what the 2-D shards reach (dist.ShardGrid: R row shards x G window groups, the alignment's rows replicated along the window axis,
         # the all-reduce inside a row group only): the share of ONE rank of every shape, on this GPU, in this run, checked against the oracle
         if not a.no_shapes and rows_per_gpu == FULL_ROWS:
             try:
-                res["shard_shapes"] = shard_shapes(lib, local, torch, a, timed_region, rows_full, not a.no_cpu)
+                res["shard_shapes"] = shard_shapes(lib, local, torch, a, timed_pair, rows_full, not a.no_cpu)
                 best = min((s for s in res["shard_shapes"].values() if isinstance(s, dict) and "ms_per_step" in s), key=lambda s: s["ms_per_step"], default=None)
                 ps = res.get("projected_strong_scaling")
                 if best is not None and ps is not None and best["ms_per_step"] < ps["ms_per_step_shard"]:
-                    ps.update({"ceiling": res["ms_per_step"] / best["ms_per_step"], "ms_per_step_shard": best["ms_per_step"], "shape": best["shape"]})
+                    ps.update({"ceiling": res["ms_per_step"] / best["ms_per_step"], "ms_per_step_shard": best["ms_per_step"], "shape": best["shape"],
+                               "ceiling_one_stream": res["ms_per_step_one_stream"] / best["ms_per_step_one_stream"]})
                 if any(isinstance(s, dict) and s.get("parity_checked") is False for s in res["shard_shapes"].values()):
                     res["parity_checked"] = False
             except Exception as e:              # noqa: BLE001 — as above
@@ -617,7 +654,7 @@ def headline(res):
     the projected scaling ceiling — no notes, no tables, no nested side measurements (those go to bench_detail.json and to an
     earlier, prefixed stdout line).  Always shorter than HEADLINE_LIMIT (tests/test_bench_line.py)."""
     top = ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data",
-           "parity_checked", "ms_per_step_bucketed", "bucket")
+           "parity_checked", "ms_per_step_bucketed", "bucket", "steps_in_flight", "ms_per_step_one_stream")
     out = {key: res[key] for key in top if key in res}
     cfg = res.get("config", {})
     out["config"] = {key: cfg[key] for key in ("workload", "rows_per_gpu", "rows_total", "cols", "k", "variation", "candidates_per_window", "windows",
@@ -630,7 +667,7 @@ def headline(res):
                        "traffic": rf.get("traffic"), "hbm_frac": rf.get("hbm_frac"), "over_fetch": rf.get("over_fetch"),
                        "valu_frac": rf.get("valu_frac"), "l2_frac": rf.get("l2_frac"), "limiter": rf.get("bound"),
                        "algorithmic_frac": rf.get("algorithmic_frac"), "compulsory_bytes": rf.get("compulsory_bytes"),
-                       "kernel": str(rf.get("kernel", "")).split(" (")[0], "kernel_ms": rf.get("kernel_ms"),
+                       "kernel": str(rf.get("kernel", "")).split(" (")[0], "eval_mode": rf.get("eval_mode"), "kernel_ms": rf.get("kernel_ms"),
                        "counters_stale": rf.get("counters_stale")}
     cb = res.get("cpu_baseline")
     if cb:
@@ -640,7 +677,8 @@ def headline(res):
             out["cpu_baseline"]["one_core_value"] = cb["one_core"].get("value")
     ps = res.get("projected_strong_scaling")
     if ps:
-        out["projected_strong_scaling"] = {key: ps[key] for key in ("n_gpus", "ceiling", "shape", "ms_per_step_one_gpu", "ms_per_step_shard") if key in ps}
+        out["projected_strong_scaling"] = {key: ps[key] for key in ("n_gpus", "ceiling", "shape", "ms_per_step_one_gpu", "ms_per_step_shard",
+                                                                    "ceiling_one_stream") if key in ps}
     pl = res.get("pipeline") or {}
     runs = {key: {"run_ms": val.get("run_ms"), "construct_ms": val.get("construct_ms"), "tsv_equal_oracle": val.get("tsv_equal_oracle")}
             for key, val in pl.items() if isinstance(val, dict) and "run_ms" in val}
@@ -678,14 +716,15 @@ def emit(res):
     print(headline(res), flush=True)
 
 
-def weak_shard(lib, local, torch, dev, a, timed_region, every, with_cpu):
+def weak_shard(lib, local, torch, dev, a, timed_pair, every, with_cpu):
     """The 131072 x 1000 shard one GPU holds when config 4 is spread over 8 GPUs: the same steps, timed the same way, on one GPU."""
     w = Workload(lib, local, torch, 0, SHARD_ROWS, a)
-    elapsed, kern_ms, kern_n, samples, sb, _ = timed_region(w, 1, 1)
+    elapsed, kern_ms, kern_n, samples, sb, _, used, one_ms = timed_pair(w, 1)
     counters = sb.block_of(a.steps - 1).cpu().numpy().copy()
     per_launch_ms = kern_ms / max(kern_n, 1)
     out = {"workload": w.describe() + " on ONE GPU (the per-GPU shard of BASELINE configs[3] at N = 8; planes 81 MB: inside the Infinity Cache)",
            "value": w.evals * a.steps / elapsed, "unit": "evals/s", "ms_per_step": elapsed / a.steps * 1e3, "steps": a.steps,
+           "steps_in_flight": used, "ms_per_step_one_stream": one_ms,
            "evals_per_step": w.evals, "iupac_extra_rows": w.n_extra, "setup_s": w.setup_s, "device_bytes": w.ctx.device_bytes(),
            "roofline": roofline_block(w, per_launch_ms, samples, kern_n, every, eval_mode(w.n_rows, w.ctx)),
            "counter_checksum": counters.sum(axis=0).tolist()}
@@ -705,7 +744,7 @@ def weak_shard(lib, local, torch, dev, a, timed_region, every, with_cpu):
     return out
 
 
-def shard_shapes(lib, local, torch, a, timed_region, rows_full, with_cpu, n_gpus=8):
+def shard_shapes(lib, local, torch, a, timed_pair, rows_full, with_cpu, n_gpus=8):
     """One rank's share of config 4 under every 2-D shape R x G of `n_gpus` ranks (R contiguous row shards x G contiguous window groups;
     8x1 is `weak_shard`): rows [0, 1048576 / R) x window group 0 of G, timed like the headline, counters against the oracle on the same
     rows and windows.  The all-reduce of a shape runs inside a row group (R ranks, [n_candidates / G x 3] counters) and is not counted,
@@ -715,9 +754,10 @@ def shard_shapes(lib, local, torch, a, timed_region, rows_full, with_cpu, n_gpus
         G = n_gpus // R
         n = FULL_ROWS // R
         w = Workload(lib, local, torch, 0, n, a, win_part=(0, G), rows=rows_full[:n])
-        elapsed, kern_ms, kern_n, samples, sb, _ = timed_region(w, 1, 1)
+        elapsed, kern_ms, kern_n, samples, sb, _, used, one_ms = timed_pair(w, 1)
         counters = sb.block_of(a.steps - 1).cpu().numpy().copy()
-        blk = {"shape": f"{R}x{G}", "rows": n, "windows": w.W, "ms_per_step": elapsed / a.steps * 1e3, "kernel_ms": kern_ms / max(kern_n, 1),
+        blk = {"shape": f"{R}x{G}", "rows": n, "windows": w.W, "ms_per_step": elapsed / a.steps * 1e3, "steps_in_flight": used,
+               "ms_per_step_one_stream": one_ms, "kernel_ms": kern_ms / max(kern_n, 1),
                "evals_per_step": w.evals, "eval_mode": eval_mode(w.n_rows, w.ctx), "device_bytes": w.ctx.device_bytes(),
                "allreduce_ranks": R, "allreduce_bytes": int(w.n_cand) * 24}
         if with_cpu:

@@ -30,7 +30,8 @@ PASSES = {
 
 def run(cmd, log):
     with open(log, "w") as f, open(log + ".err", "w") as e:
-        return subprocess.call(cmd, stdout=f, stderr=e, cwd="/tmp", env=dict(os.environ, TMPDIR="/tmp"), timeout=600)
+        # (MP_BENCH_STREAMS=1: one launch at a time on the chip — a kernel's duration and counters are its own)
+        return subprocess.call(cmd, stdout=f, stderr=e, cwd="/tmp", env=dict(os.environ, TMPDIR="/tmp", MP_BENCH_STREAMS="1"), timeout=600)
 
 
 def per_kernel(dbfile):
@@ -54,7 +55,7 @@ def main():
     a = ap.parse_args()
     a.out = os.path.abspath(a.out)                 # rocprofv3 runs from /tmp
     os.makedirs(a.out, exist_ok=True)
-    bench = [sys.executable, os.path.join(REPO, "bench.py"), "--rows", str(a.rows), "--no-cpu", "--no-variants", "--no-full", "--no-pipeline"] + a.bench_args.split()
+    bench = [sys.executable, os.path.join(REPO, "bench.py"), "--rows", str(a.rows), "--no-cpu", "--no-variants", "--no-full", "--no-pipeline", "--no-side", "--no-shapes"] + a.bench_args.split()
     # kernel trace of the bench command itself
     run(["rocprofv3", "--kernel-trace", "--stats", "-d", os.path.join(a.out, "trace"), "-o", "bench", "--"] + bench + ["--steps", "20", "--warmup", "3"],
         os.path.join(a.out, "trace_bench.json"))
