@@ -78,6 +78,9 @@ void free_eval(mp_ctx *c) {
     dev_free(c, &c->chain_items, (size_t)c->n_chain);
     if (c->n_chain) dev_free(c, &c->chain_events, (size_t)c->n_events + 1);
     dev_free(c, &c->table_ids, (size_t)c->n_table);
+    if (c->x_items) { void *q = c->x_items; const size_t real = pool_forget(c, q, 0); if (!real || !pool_give(c, q, real)) (void)hipFree(q); c->bytes -= (int64_t)real; c->x_items = nullptr; }
+    dev_free(c, &c->x_events, (size_t)c->x_n_events + 1); dev_free(c, &c->x_cand_out, (size_t)c->x_n * 8);
+    c->x_n = c->x_n_events = 0;
     c->n_chain = c->n_table = c->n_events = 0;
     c->n_items = c->n_padded = c->n_cand = 0;
 }

@@ -185,6 +185,11 @@ struct mp_ctx {
     uint4 *cand_n = nullptr;
     uint32_t *cand_symT = nullptr, *cand_diff = nullptr, *chain_events = nullptr;
     mp::ChainItem *chain_items = nullptr;
+    // eval_chain_x_kernel (evalx.hpp): chain items of primers of 32..63 bases / of v = 4, 5 — beside the row-per-lane arrays above
+    void *x_items = nullptr;
+    uint32_t *x_events = nullptr;
+    int32_t *x_cand_out = nullptr;
+    int x_n = 0, x_n_events = 0;
     int32_t *table_ids = nullptr;
     int n_chain = 0, n_table = 0, n_events = 0, max_steps = 0;     // max_steps: members of the longest chain item
     // host copies of the staged chain items (evalslide.hip builds its plan from them)

@@ -11,6 +11,7 @@
 #include "evalprog.hpp"
 #include "evalslide.hpp"
 #include "chainbody.hpp"
+#include "evalx.hpp"
 
 using namespace mp;
 
@@ -976,6 +977,98 @@ PatchArgs patch_args(const mp_ctx *c, int GW, int n_items, int unit_threads) {
 
 }  // namespace
 
+// [r6] The chain items of eval_chain_x_kernel (evalx.hpp) for a staged candidate set of primers of 32..63 bases or of v = 4, 5: every
+// maximal run of at most 8 consecutive candidates of a window that is nested in one direction (a refinement chain read either way) is
+// one item — a single candidate is a run of one: its first pass alone is ~80 times cheaper than the row-per-lane comparison.  Built
+// BESIDE the row-per-lane arrays (the coverage masks and MP_EVAL_MODE=rows still use those); not built when a candidate holds an empty
+// symbol (it matches nothing: the row-per-lane form handles that).
+static int upload_x(mp_ctx *c, int32_t n_cand, const int32_t *cw, const uint8_t *codes) {
+    c->x_n = 0;
+    if (c->v > 5 || c->k > 63 || getenv("MP_EVAL_NO_X")) return MP_OK;
+    const int k = c->k;
+    auto sym_at = [&](int ci, int p) { return (uint32_t)(codes[(size_t)ci * k + p] & 15u); };
+    for (int ci = 0; ci < n_cand; ci++)
+        for (int p = 0; p < k; p++)
+            if (!sym_at(ci, p)) return MP_OK;
+    std::vector<ChainItemX> items;
+    std::vector<uint32_t> events;
+    std::vector<int32_t> co;
+    std::vector<int> order;
+    for (int i = 0; i < n_cand;) {
+        const int w = cw[i];
+        int j = i;
+        while (j < n_cand && cw[j] == w) j++;
+        for (int b = i; b < j;) {
+            int e = b + 1, dir = 3;
+            while (e < j && e - b < kEvalCC) {
+                int rel = 3;
+                for (int p = 0; p < k; p++) {
+                    const uint32_t x = sym_at(e - 1, p), y = sym_at(e, p);
+                    if (x & ~y) rel &= ~1;           // not "previous within next"
+                    if (y & ~x) rel &= ~2;           // not "next within previous"
+                }
+                if (!(dir & rel)) break;
+                dir &= rel; e++;
+            }
+            order.clear();
+            if ((dir & 2) == 0) for (int ci = e - 1; ci >= b; ci--) order.push_back(ci);      // ascending run: most degenerate member last
+            else for (int ci = b; ci < e; ci++) order.push_back(ci);
+            ChainItemX ch{};
+            ch.win = w; ch.cand0 = (int32_t)co.size(); ch.n_steps = (int32_t)order.size(); ch.ev0 = (int32_t)events.size();
+            for (int p = 0; p < k; p++) {
+                const uint32_t sy = sym_at(order[0], p);
+                ch.sym[p >> 3] |= sy << (4 * (p & 7));
+                const int nb = __builtin_popcount(sy);
+                (nb == 1 ? ch.pos1 : (nb == 2 ? ch.pos2 : ch.pos4)) |= 1ull << p;
+            }
+            for (size_t t = 1; t < order.size(); t++)
+                for (int p = 0; p < k; p++) {
+                    const uint32_t lost = sym_at(order[t - 1], p) & ~sym_at(order[t], p);
+                    for (uint32_t bit = 1; bit < 16; bit <<= 1)
+                        if (lost & bit) events.push_back((uint32_t)p | (bit << 8) | ((uint32_t)t << 16));
+                }
+            ch.n_ev = (int32_t)events.size() - ch.ev0;
+            items.push_back(ch);
+            for (int t = 0; t < kEvalCC; t++) co.push_back(t < (int)order.size() ? order[(size_t)t] : -1);
+            b = e;
+        }
+        i = j;
+    }
+    if (items.empty()) return MP_OK;
+    int rc;
+    ChainItemX *d_items = nullptr;
+    if ((rc = dev_alloc(c, &d_items, items.size()))) return rc;
+    c->x_items = d_items;
+    c->x_n = (int)items.size(); c->x_n_events = (int)events.size();
+    if ((rc = dev_alloc(c, &c->x_events, events.size() + 1))) return rc;
+    if ((rc = dev_alloc(c, &c->x_cand_out, co.size()))) return rc;
+    HIPCK(c, hipMemcpyAsync(d_items, items.data(), sizeof(ChainItemX) * items.size(), hipMemcpyHostToDevice, c->stream));
+    if (!events.empty()) HIPCK(c, hipMemcpyAsync(c->x_events, events.data(), sizeof(uint32_t) * events.size(), hipMemcpyHostToDevice, c->stream));
+    HIPCK(c, hipMemcpyAsync(c->x_cand_out, co.data(), sizeof(int32_t) * co.size(), hipMemcpyHostToDevice, c->stream));
+    HIPCK(c, hipStreamSynchronize(c->stream));
+    return MP_OK;
+}
+
+typedef void (*EvalXFn)(const EvalXArgs);
+static int launch_eval_x(mp_ctx *c, unsigned long long *out) {
+    { int rc = ensure_patch_planes(c); if (rc) return rc; }
+    const int nw = c->n_pad / 64, nw32 = 2 * nw;
+    // words per thread x positions in flight by depth (as eval_chain_kernel chooses them); five and six counter levels: at most 4 words
+#define X_ROW(LV) {eval_chain_x_kernel<LV, 1, 6>, eval_chain_x_kernel<LV, 2, 6>, eval_chain_x_kernel<LV, 4, 3>, eval_chain_x_kernel<LV, (LV <= 4 ? 8 : 4), (LV <= 4 ? 2 : 3)>}
+    static const EvalXFn fn[6][4] = {X_ROW(1), X_ROW(2), X_ROW(3), X_ROW(4), X_ROW(5), X_ROW(6)};
+#undef X_ROW
+    int shape = nw32 >= 4 * kBlock ? 3 : (nw32 >= 2 * kBlock ? 2 : (nw32 >= kBlock ? 1 : 0));
+    if (const char *e = getenv("MP_EVAL_X_SHAPE")) { const int sh = atoi(e); if (sh >= 0 && sh < 4) shape = sh; }
+    static const int gw_of[4] = {1, 2, 4, 8};
+    const int GW = shape == 3 && c->v >= 4 ? 4 : gw_of[shape];
+    unsigned grid;
+    const BlockMap bm = make_block_map(nw, GW, c->x_n, grid);
+    EvalXArgs xa{c->cols, c->excl, nw, c->p0, c->k, c->v, reinterpret_cast<const ChainItemX *>(c->x_items), c->x_events, c->x_cand_out, c->sF, c->sR, out, bm,
+                 patch_args(c, GW, c->x_n, 64)};
+    hipLaunchKernelGGL(fn[c->v][shape], dim3(grid + (unsigned)xa.patch.n_blocks), dim3(kBlock), 0, c->stream, xa);
+    return MP_OK;
+}
+
 extern "C" {
 
 // Primers of 32..63 bases: 8 consecutive candidates of a window per item, 64-bit candidate words, the row-per-lane kernels only.
@@ -1020,7 +1113,7 @@ static int upload_wide(mp_ctx *c, int32_t n_cand, const int32_t *cw, const uint8
     HIPCK(c, hipMemcpy(c->items, items.data(), sizeof(EvalItem) * items.size(), hipMemcpyHostToDevice));
     HIPCK(c, hipMemcpy(c->cand_n, cn.data(), sizeof(CandN<uint64_t>) * cn.size(), hipMemcpyHostToDevice));
     HIPCK(c, hipMemcpy(c->cand_out, co.data(), sizeof(int32_t) * co.size(), hipMemcpyHostToDevice));
-    return MP_OK;
+    return upload_x(c, n_cand, cw, codes);           // [r6] the bit-sliced chain items beside the row-per-lane arrays
 }
 
 int mp_eval_upload(mp_ctx *c, int32_t n_cand, const int32_t *cw, const uint8_t *codes, uint64_t sF64, uint64_t sR64) {
@@ -1210,6 +1303,7 @@ int mp_eval_upload(mp_ctx *c, int32_t n_cand, const int32_t *cw, const uint8_t *
     HIPCK(c, hipMemcpy(c->items, items.data(), sizeof(EvalItem) * items.size(), hipMemcpyHostToDevice));
     HIPCK(c, hipMemcpy(c->cand_n, cn.data(), sizeof(uint4) * cn.size(), hipMemcpyHostToDevice));
     HIPCK(c, hipMemcpy(c->cand_out, co.data(), sizeof(int32_t) * co.size(), hipMemcpyHostToDevice));
+    if (c->v > 3) return upload_x(c, n_cand, cw, codes);     // [r6] v = 4, 5: the four-level kernels above do not count that far
     return MP_OK;
 }
 
@@ -1253,8 +1347,12 @@ static int eval_launch_impl(mp_ctx *c, int64_t *device_out, int64_t *device_clea
     }
     const char *mode_env = getenv("MP_EVAL_MODE");
     const bool bits = c->v <= 3 && !c->wide && !(mode_env && !strcmp(mode_env, "rows"));      // (the bit-sliced kernels hold 32 positions per item)
+    const bool xbits = !bits && c->x_n > 0 && !(mode_env && !strcmp(mode_env, "rows"));       // [r6] 32..63 positions / v = 4, 5: eval_chain_x_kernel
     const int vmode = c->v == 0 ? 0 : (c->v == 1 ? 1 : 2);     // predicate specialisation of the row-per-lane code
-    if (bits) {
+    if (xbits) {
+        const int rc = launch_eval_x(c, (unsigned long long *)device_out);
+        if (rc) return rc;
+    } else if (bits) {
         // bit-sliced pass over the column planes and over the windows' patch planes
         // MP_EVAL_BITS: 0 (default) = nested-chain kernel on the nested items + symbol-table kernel (with the shared-
         // position shortcut) on the others; 1 = symbol-table kernel on every item, no shortcut; 2 = the same with it

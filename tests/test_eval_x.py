@@ -1,0 +1,90 @@
+"""eval_chain_x_kernel (csrc/evalx.hpp, round 6): the bit-sliced nested-chain evaluation for primers of 32..63 bases and for v = 4, 5
+— every staged candidate set of those cases — against the oracle, and against the row-per-lane kernels it replaces (MP_EVAL_NO_X):
+refinement chains read in either direction, runs longer than 8 members (cut into several items), unrelated candidates (runs of
+one), strict positions beyond bit 31, IUPAC / edge-gap / ragged rows (patch planes), every words-per-thread shape."""
+import numpy as np
+import pytest
+import torch  # noqa: F401
+
+from multiprime_amd import iupac
+from test_hip_parity import both, fuzz_msa
+
+pytestmark = pytest.mark.gpu
+
+
+def chain_candidates(rng, rows_ascii, p0, W, k, per_window):
+    """Per window: a refinement chain from a real k-mer of some row (more degenerate member by member), listed upwards or downwards,
+    then unrelated candidates up to `per_window`."""
+    cw, codes = [], []
+    n, L = rows_ascii.shape
+    for w in range(W):
+        src = rows_ascii[int(rng.integers(0, n)), p0 + w:p0 + w + k]
+        base = iupac.MASK_LUT[src].copy()
+        base[(base == 0) | (base > 8) | ((base & (base - 1)) != 0)] = 1            # gaps / IUPAC codes of the source row -> A
+        chain = [base.copy()]
+        for _ in range(int(rng.integers(1, 12))):
+            nxt = chain[-1].copy()
+            nxt[int(rng.integers(0, k))] |= np.uint8(1 << int(rng.integers(0, 4)))
+            chain.append(nxt)
+        if rng.random() < 0.5:
+            chain.reverse()
+        cand = chain[:per_window]
+        while len(cand) < per_window:
+            r = np.array([1, 2, 4, 8], np.uint8)[rng.integers(0, 4, size=k)]
+            r[int(rng.integers(0, k))] = np.uint8(rng.integers(1, 16))
+            cand.append(r)
+        for c in cand:
+            cw.append(w)
+            codes.append(c)
+    return np.asarray(cw, np.int32), np.asarray(codes, np.uint8)
+
+
+CASES = [  # seed, n, L, ragged, k, v
+    (1, 300, 150, False, 36, 1), (2, 257, 170, False, 45, 2), (3, 9000, 110, False, 63, 3), (4, 1000, 120, False, 32, 0),
+    (5, 20000, 100, False, 40, 4), (6, 700, 140, False, 50, 5), (7, 300, 120, False, 18, 4), (8, 40000, 80, False, 22, 5),
+    (9, 4200, 100, False, 31, 4), (10, 12000, 100, False, 33, 5),
+]
+
+
+@pytest.mark.parametrize("seed,n,L,ragged,k,v", CASES)
+def test_chain_x_kernel_equals_oracle_and_row_kernels(hip_lib, oracle_lib, monkeypatch, seed, n, L, ragged, k, v):
+    data, off, maxlen = fuzz_msa(seed, n, L, ragged, p_iupac=0.002)
+    h, o = both(hip_lib, oracle_lib, data, off)
+    try:
+        W = (int(np.sort(np.diff(off))[n // 4]) if ragged else maxlen) - k - 2
+        assert h.build_windows(2, W, k, v) == o.build_windows(2, W, k, v)
+        # IUPAC rows expanded by the host, as the product does it
+        ne = h.build_windows(2, W, k, v)
+        ew, er, ec = h.get_exceptions(ne)
+        raw = iupac.strings_of(iupac.SYMBOL_LUT[ec]) if ne else []
+        xw, xk = [], []
+        for w_, s in zip(ew.tolist(), raw):
+            if s.count("-") <= v and iupac.degeneracy(s) <= 16:
+                for e in iupac.expand(s):
+                    xw.append(w_)
+                    xk.append(e)
+        if xw:
+            words = iupac.words_of_kmers(np.frombuffer("".join(xk).encode(), np.uint8).reshape(len(xk), k))
+            for c in (h, o):
+                c.set_extra_rows(np.asarray(xw, np.int32), words)
+        rng = np.random.default_rng(seed)
+        rows_ascii = np.zeros((n, maxlen), np.uint8) + ord("-")
+        for r in range(min(n, 400)):
+            rows_ascii[r, : off[r + 1] - off[r]] = data[off[r]:off[r + 1]]
+        rows_ascii = rows_ascii[: min(n, 400)]
+        cw, codes = chain_candidates(rng, rows_ascii, 2, W, k, 11)
+        sF = (1 << 1) | (1 << (k - 1)) | (1 << (k // 2))
+        sR = (0b11 << (k - 3)) | 1
+        want = o.eval_candidates(cw, codes, sF, sR)
+        got = h.eval_candidates(cw, codes, sF, sR)
+        assert np.array_equal(got, want)
+        assert want[:, 0].sum() > 0 and (v == 0 or (want[:, 1] + want[:, 2]).sum() > 0)          # every counter moved
+        monkeypatch.setenv("MP_EVAL_NO_X", "1")
+        assert np.array_equal(h.eval_candidates(cw, codes, sF, sR), want)              # the row-per-lane kernels: the round-5 path
+        monkeypatch.delenv("MP_EVAL_NO_X")
+        for shape in ("0", "1", "2", "3"):
+            monkeypatch.setenv("MP_EVAL_X_SHAPE", shape)
+            assert np.array_equal(h.eval_candidates(cw, codes, sF, sR), want), shape
+    finally:
+        h.close()
+        o.close()
