@@ -313,6 +313,7 @@ def main():
     ap.add_argument("--no-variants", action="store_true")
     ap.add_argument("--no-pipeline", action="store_true", help="N = 1: skip the `pipeline` block (NN_degenerate.run() on the same rows)")
     ap.add_argument("--no-shapes", action="store_true", help="N = 1: skip the `shard_shapes` block (one rank's share of the 2-D shards 4x2, 2x4, 1x8)")
+    ap.add_argument("--no-ksweep", action="store_true", help="N = 1: skip the `k_sweep` block (the headline workload at k = 20, 22, 36)")
     ap.add_argument("--no-side", action="store_true", help="N = 1: skip the `side_steps` block (dimer scan, in-silico PCR, k-mismatch scan: tools/side_bench.py)")
     ap.add_argument("--no-shard", "--no-full", dest="no_shard", action="store_true",
                     help="N = 1: skip the weak_shard block (the 131072-row shard of the 8-GPU job)")
@@ -613,6 +614,14 @@ def main():
                     res["parity_checked"] = False
             except Exception as e:              # noqa: BLE001 — as above
                 res["shard_shapes"] = {"error": f"{type(e).__name__}: {e}"}
+        # the same rows at other primer lengths (k = 20, 22: BASELINE configs[1]; 36: 64-bit window words)
+        if not a.no_ksweep and rows_per_gpu == FULL_ROWS and a.k == 18:
+            try:
+                res["k_sweep"] = k_sweep(lib, local, torch, dev, a, rows_full, not a.no_cpu)
+                if any(isinstance(b, dict) and b.get("parity_checked") is False for b in res["k_sweep"].values()):
+                    res["parity_checked"] = False
+            except Exception as e:              # noqa: BLE001 — as above
+                res["k_sweep"] = {"error": f"{type(e).__name__}: {e}"}
         del rows_full
     if rank == 0 and world == 1 and any(isinstance(p, dict) and p.get("tsv_equal_oracle") is False for p in res.get("pipeline", {}).values()):
         res["parity_checked"] = False
@@ -773,6 +782,40 @@ def shard_shapes(lib, local, torch, a, timed_pair, rows_full, with_cpu, n_gpus=8
     return out
 
 
+def k_sweep(lib, local, torch, dev, a, rows_full, with_cpu, ks=(20, 22, 36)):
+    """The headline workload at other primer lengths (BASELINE configs[1] names k = 18-22; the reference takes any -l, V20:64-65): the
+    same rows, 8 nested candidates per window, every launch timed with HIP events (20 after 3 warm-ups); counters of every 16th
+    window against the oracle.  k = 36 runs on eval_chain_x_kernel (64-bit window words)."""
+    import argparse
+    out = {}
+    keep = os.environ.get("MP_EVAL_TIMING_EVERY")
+    os.environ["MP_EVAL_TIMING_EVERY"] = "1"
+    for kk in ks:
+        ak = argparse.Namespace(**{**vars(a), "k": kk})
+        w = Workload(lib, local, torch, 0, rows_full.shape[0], ak, rows=rows_full)
+        buf = torch.zeros((w.n_cand, 3), dtype=torch.int64, device=dev)
+        t = time_launches(w.ctx, torch, buf.data_ptr(), 20, 3)
+        blk = {"k": kk, "windows": w.W, "evals_per_step": w.evals, "kernel_ms": t["mean_ms"], "kernel_ms_median": t["median_ms"],
+               "evals_per_s": w.evals / (t["mean_ms"] * 1e-3), "eval_mode": "chain_x" if kk > 31 else eval_mode(w.n_rows, w.ctx),
+               "compulsory_frac": w.n_rows * w.L * 3 / 8.0 / (t["mean_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS}
+        if with_cpu:
+            blocks = OracleBlocks(w, w.rows, a.cpu_threads)
+            sel = np.nonzero(w.cw % 16 == 0)[0]
+            want, _ = blocks.eval(np.ascontiguousarray(w.cw[sel]), np.ascontiguousarray(w.codes[sel]))
+            blocks.close()
+            blk["parity_checked"] = bool(np.array_equal(buf.cpu().numpy()[sel], want))
+        out[f"k_{kk}"] = blk
+        w.ctx.close()
+        w.ctx = None
+        del buf
+        torch.cuda.empty_cache()
+    if keep is None:
+        os.environ.pop("MP_EVAL_TIMING_EVERY", None)
+    else:
+        os.environ["MP_EVAL_TIMING_EVERY"] = keep
+    return out
+
+
 def run_variants(w, torch, dev, scratch_a, scratch_b, seed, blocks, cold=True):
     """The evaluation library on other candidate sets — SURVEY 8d's micro-benchmark: C in {1, 8, 64} per window, nested and not (every
     launch timed with HIP events, 20 launches after 3 warm-ups).  With `blocks` (the oracle's contexts over the same rows) the counters
@@ -880,13 +923,16 @@ def pipeline_block_unguarded(lib, local, rows, a, reps=5):
         shutil.rmtree(td, ignore_errors=True)
     runs.sort(key=lambda r: r[0])
     run_s, construct_s, stats = runs[len(runs) // 2]
+    kern = (load_json("r06_pipeline_kernels.json") or {}).get(f"rows_{n}")
     sha = hashlib.sha256(tsv).hexdigest()
     return {"rows": n, "cols": L, "run_ms": run_s * 1e3, "run_ms_min": runs[0][0] * 1e3, "run_ms_max": runs[-1][0] * 1e3, "construct_ms": construct_s * 1e3,
             "repetitions": reps, "phases_ms": {key[:-2]: round(val * 1e3, 3) for key, val in stats.items() if key.endswith("_s")},
             "windows": stats.get("n_windows"), "windows_past_the_gates": stats.get("windows_planned"), "candidates": stats.get("n_candidates"),
             "rows_out": stats.get("n_rows"), "tsv_sha256": sha, "oracle_tsv_sha256": golden["tsv_sha256"] if golden else None,
             "tsv_equal_oracle": (sha == golden["tsv_sha256"]) if golden else None,
-            "oracle_note": (f"checker: {golden['checker']}, {golden['checker_wall_s']} s" if golden else "no committed checker TSV for this size / seed")}
+            "oracle_note": (f"checker: {golden['checker']}, {golden['checker_wall_s']} s" if golden else "no committed checker TSV for this size / seed"),
+            "kernels": kern["kernels"] if kern else None,
+            "kernels_note": (kern["what"] + " — collected by tools/reproduce.sh pipeline_kernels, not in this run") if kern else "profiles/r06_pipeline_kernels.json absent"}
 
 
 class OracleBlocks:

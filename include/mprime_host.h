@@ -43,6 +43,16 @@ int mp_fasta_sizes(const mp_fasta *f, int32_t *n_rows, int64_t *n_residue_bytes,
 int mp_fasta_rows(const mp_fasta *f, uint8_t *data, int64_t *row_off);
 /* ids back to back, id r = ids[id_off[r] .. id_off[r+1]) (raw bytes of the file) */
 int mp_fasta_ids(const mp_fasta *f, uint8_t *ids, int64_t *id_off);
+/* Residue bytes [byte0, byte1) of the rows laid end to end — mp_fasta_rows' data[byte0 .. byte1) — into dst, on n_threads threads
+ * (0: the parser's).  The streamed load below is built on it. */
+int mp_fasta_gather(const mp_fasta *f, int64_t byte0, int64_t byte1, uint8_t *dst, int32_t n_threads);
+/* mp_load_msa(ctx, mp_fasta_rows(f)) without the intermediate copy [r6]: the records' residue bytes go from the parsed file straight
+ * into a ring of transfer buffers the context keeps registered with the runtime (3 x 32 MB), chunk by chunk on the host's threads,
+ * while the chunk before is on its way to the device by DMA — a 1 GB alignment used to be copied into a caller-owned array first
+ * (1 GB of fresh pages), then crossed through the runtime's own staging buffers.  Same device state as mp_load_msa afterwards.
+ * Product library only (it takes a device context); struct mp_ctx is the context of mprime.h. */
+struct mp_ctx;
+int mp_load_msa_fasta(struct mp_ctx *ctx, const mp_fasta *f);
 /* Newlines of a file as Python's text mode counts them (\n, \r\n as one, a lone \r), on n_threads threads (0 = as many as pay
  * off) — get_multiPrime / get_degePrimer take "newlines / 2" of the whole input as the number of sequences
  * (get_multiPrime_V8.py:348-357, get_degePrimer_V6.py:260-271): a full pass over files of a gigabyte and more. */

@@ -136,7 +136,10 @@ class NN_degenerate(object):
             self.total_sequence_number = fa.n_rows
             if fa.n_rows == 0:
                 raise ValueError("no sequence records in " + str(seq_file))
-            data, row_off = fa.rows()
+            # one process, the product library on both sides: the residue bytes go from the parsed file straight to the device
+            # (mp_load_msa_fasta) — no 1 GB intermediate array for a 10^6-row alignment; row shards cut their rows out of it first
+            streamed_load = comm is None and os.environ.get("MP_LOAD_STREAM", "1") != "0"
+            data, row_off = (None, fa.row_offsets()) if streamed_load else fa.rows()
         finally:
             starter.join()
         if "error" in made:
@@ -150,7 +153,12 @@ class NN_degenerate(object):
         if comm is not None:
             self.ctx.reserve_columns(width)                            # windows span the whole alignment, not this shard's rows
             data, row_off = comm.take_shard(data, row_off)
-        self.ctx.load_msa(data, row_off)
+        if data is None and host.serves_device_library(self.lib) and hasattr(host.dll(), "mp_load_msa_fasta"):
+            fa.load_into(self.ctx)
+        else:
+            if data is None:
+                data, row_off = fa.rows()
+            self.ctx.load_msa(data, row_off)
         # seq_attribute (V20:617-640) takes one order statistic of the rows' leading-gap lengths and one of their right-stripped
         # lengths: histograms of both leave the device (8 KB instead of 8 bytes per row), shards add theirs
         lead_h, rstrip_h = self.ctx.row_histograms(width + 1)

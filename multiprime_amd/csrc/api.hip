@@ -294,6 +294,11 @@ void mp_destroy(mp_ctx *c) {
     dev_free(c, &c->stats_buf, c->stats_buf_n);
     if (getenv("MP_TRACE")) fprintf(stderr, "[mprime] device blocks: %lld reused, %lld from the runtime, %zu waiting (%.1f MB)\n", c->pool_hits, c->pool_misses,
                                     c->pool.size(), c->pool_bytes / 1048576.0);
+    if (c->h_ring) {
+        if (c->h_ring_pinned) (void)hipHostUnregister(c->h_ring);
+        host_unmap(c->h_ring, (size_t)96 << 20);
+        for (hipEvent_t ev : c->h_ring_ev) if (ev) (void)hipEventDestroy(ev);
+    }
     if (c->h_stage_pinned) (void)hipHostUnregister(c->h_stage);
     host_unmap(c->h_stage, c->h_stage_bytes);
     dev_free(c, &c->dm_loss, (size_t)(MP_DIMER_MAX_LEN + 1) * (MP_DIMER_MAX_LEN + 1) * 64);

@@ -233,6 +233,9 @@ struct mp_ctx {
     uint8_t *h_stage = nullptr;              // host_map() memory
     size_t h_stage_bytes = 0;
     bool h_stage_pinned = false;             // registered with the runtime (hipHostRegister): copies into it are plain DMA
+    uint8_t *h_ring = nullptr;               // mp_load_msa_fasta: 3 x 32 MB transfer buffers (host_map, registered), kept for the context's life
+    bool h_ring_pinned = false;
+    hipEvent_t h_ring_ev[3] = {nullptr, nullptr, nullptr};
     // the resident sequence store (mp_seq_load, scan.hip): the unaligned database of the PCR / k-mismatch scans
     uint8_t *sq_bytes = nullptr;             // the characters as loaded (fall-back paths only)
     int64_t *sq_roff = nullptr;              // [sq_n + 1] byte offsets

@@ -460,6 +460,34 @@ int mp_fasta_rows(const mp_fasta *f, uint8_t *data, int64_t *row_off) {
     return MP_OK;
 }
 
+// residue bytes [byte0, byte1) of the rows laid end to end (what mp_fasta_rows writes at data[byte0 .. byte1)), on n_threads threads:
+// the streamed load (mp_load_msa_fasta, pack.hip) fills its transfer buffers with it chunk by chunk
+int mp_fasta_gather(const mp_fasta *f, int64_t byte0, int64_t byte1, uint8_t *dst, int32_t n_threads) {
+    if (!f || !dst) return MP_ERR_ARG;
+    const size_t R = f->id_off_src.size();
+    if (R == 0 || byte1 <= byte0) return MP_OK;
+    if (byte0 < 0 || byte1 > f->row_off[R]) return MP_ERR_ARG;
+    // rows that overlap the range
+    const size_t ra = (size_t)(std::upper_bound(f->row_off.begin(), f->row_off.end(), byte0) - f->row_off.begin()) - 1;
+    const size_t rb = (size_t)(std::lower_bound(f->row_off.begin(), f->row_off.end(), byte1) - f->row_off.begin());      // rows [ra, rb)
+    const int T = std::max(1, std::min<int>(n_threads > 0 ? n_threads : f->n_threads, (int)((byte1 - byte0) / (1 << 20) + 1)));
+    auto copy = [&](int t) {
+        const size_t r0 = ra + (rb - ra) * (size_t)t / (size_t)T, r1 = ra + (rb - ra) * ((size_t)t + 1) / (size_t)T;
+        for (size_t r = r0; r < r1; r++) {
+            int64_t at = f->row_off[r];                            // position of the segment's first byte in the concatenation
+            for (int64_t i = f->row_seg[r]; i < f->row_seg[r + 1]; i++) {
+                const Seg &s = f->segs[(size_t)i];
+                const int64_t a = std::max(at, byte0), b = std::min<int64_t>(at + s.len, byte1);
+                if (b > a) memcpy(dst + (a - byte0), f->buf + s.off + (a - at), (size_t)(b - a));
+                at += s.len;
+            }
+        }
+    };
+    if (T == 1) copy(0);
+    else mp::run_on_threads(T, copy);
+    return MP_OK;
+}
+
 int mp_fasta_ids(const mp_fasta *f, uint8_t *ids, int64_t *id_off) {
     if (!f || !id_off) return MP_ERR_ARG;
     const size_t R = f->id_off_src.size();

@@ -1,6 +1,7 @@
 // pack.hip — part of libmprime_hip.so: hand-written HIP (gfx950 / MI355X, wave64) behind the C ABI of
 // include/mprime.h.  Alignment -> bit planes: pack, row scan, gap-free strings, column planes (mp_load_msa).
 #include "common.hpp"
+#include "../../include/mprime_host.h"
 
 using namespace mp;
 
@@ -239,9 +240,12 @@ int mp_reserve_columns(mp_ctx *c, int32_t n_columns) {
     return MP_OK;
 }
 
-int mp_load_msa(mp_ctx *c, const uint8_t *bytes, const int64_t *row_off, int32_t n_rows) {
-    if (!c) return MP_ERR_ARG;
-    if (!bytes || !row_off || n_rows <= 0) return fail(c, MP_ERR_ARG, "mp_load_msa: bad arguments");
+}  // extern "C"
+
+namespace {
+// the device side of a load: allocations, the residue bytes (brought by `upload`), the packing kernels
+template <typename Upload>
+int load_msa_impl(mp_ctx *c, const int64_t *row_off, int32_t n_rows, Upload &&upload) {
     HIPCK(c, hipSetDevice(c->dev));
     free_msa(c);
     int64_t max_len = 0;
@@ -273,19 +277,11 @@ int mp_load_msa(mp_ctx *c, const uint8_t *bytes, const int64_t *row_off, int32_t
     if ((rc = dev_alloc(c, &c->rlen, np))) return rc;
     std::vector<int64_t> off0(n_rows + 1);
     for (int r = 0; r <= n_rows; r++) off0[r] = row_off[r] - row_off[0];
-    // MP_EXPERIMENT_PIN_LOAD (tools/load_stress.py only): round 4's registration of the CALLER's residue bytes for the duration of this
-    // transfer — withdrawn after an unexplained SIGABRT in one GPU-suite run of four; kept behind the switch so that the stress tool
-    // exercises exactly that code path
-    struct PinForLoad {
-        void *p = nullptr;
-        PinForLoad(void *ptr, size_t n) { if (getenv("MP_EXPERIMENT_PIN_LOAD") && n >= ((size_t)4 << 20) && hipHostRegister(ptr, n, hipHostRegisterDefault) == hipSuccess) p = ptr; else (void)hipGetLastError(); }
-        ~PinForLoad() { if (p) { (void)hipStreamSynchronize(nullptr); (void)hipHostUnregister(p); } }
-    } pin_for_load(getenv("MP_EXPERIMENT_PIN_LOAD") ? const_cast<uint8_t *>(bytes) + row_off[0] : nullptr, (size_t)total);
-    HIPCK(c, hipMemcpyAsync(d_bytes, bytes + row_off[0], (size_t)total, hipMemcpyHostToDevice, c->stream));
     HIPCK(c, hipMemcpyAsync(d_off, off0.data(), sizeof(int64_t) * (n_rows + 1), hipMemcpyHostToDevice, c->stream));
     const FillSeg init[4] = {{c->ung, sizeof(uint32_t) * np * c->ustride, 0u}, {c->rlen, sizeof(int32_t) * np, 0u}, {c->rstrip, sizeof(int32_t) * np, 0u},
                              {c->cols + (size_t)c->n_chunks * 32 * 4 * (np / 64), sizeof(unsigned long long) * (np / 64), 0u}};
     if ((rc = fill_segments(c, init, 4))) return rc;
+    if ((rc = upload(d_bytes, total))) return rc;
     hipLaunchKernelGGL(pack_kernel, dim3((unsigned)(c->n_pad / kBlock), (unsigned)((c->n_chunks + kPackChunks - 1) / kPackChunks)), dim3(kBlock), 0,
                        c->stream, d_bytes, d_off, n_rows, c->n_pad, c->n_chunks, c->planes);
     hipLaunchKernelGGL(row_scan_kernel, dim3((unsigned)(c->n_pad / kBlock), (unsigned)kScanSegs), dim3(kBlock), 0, c->stream, c->planes, d_off, n_rows,
@@ -297,6 +293,63 @@ int mp_load_msa(mp_ctx *c, const uint8_t *bytes, const int64_t *row_off, int32_t
     dev_free(c, &d_bytes, (size_t)total + 64);
     dev_free(c, &d_off, (size_t)n_rows + 1);
     return MP_OK;
+}
+}  // namespace
+
+extern "C" {
+
+int mp_load_msa(mp_ctx *c, const uint8_t *bytes, const int64_t *row_off, int32_t n_rows) {
+    if (!c) return MP_ERR_ARG;
+    if (!bytes || !row_off || n_rows <= 0) return fail(c, MP_ERR_ARG, "mp_load_msa: bad arguments");
+    return load_msa_impl(c, row_off, n_rows, [&](uint8_t *d_bytes, int64_t total) -> int {
+        // MP_EXPERIMENT_PIN_LOAD (tools/load_stress.py only): round 4's registration of the CALLER's residue bytes for the duration of this
+        // transfer — withdrawn after an unexplained SIGABRT in one GPU-suite run of four; kept behind the switch so that the stress tool
+        // exercises exactly that code path
+        struct PinForLoad {
+            void *p = nullptr;
+            PinForLoad(void *ptr, size_t n) { if (getenv("MP_EXPERIMENT_PIN_LOAD") && n >= ((size_t)4 << 20) && hipHostRegister(ptr, n, hipHostRegisterDefault) == hipSuccess) p = ptr; else (void)hipGetLastError(); }
+            ~PinForLoad() { if (p) { (void)hipStreamSynchronize(nullptr); (void)hipHostUnregister(p); } }
+        } pin_for_load(getenv("MP_EXPERIMENT_PIN_LOAD") ? const_cast<uint8_t *>(bytes) + row_off[0] : nullptr, (size_t)total);
+        HIPCK(c, hipMemcpyAsync(d_bytes, bytes + row_off[0], (size_t)total, hipMemcpyHostToDevice, c->stream));
+        HIPCK(c, hipStreamSynchronize(c->stream));          // (a registration ends with this scope)
+        return MP_OK;
+    });
+}
+
+// mprime_host.h: the residue bytes straight from the parsed file through the context's ring of registered transfer buffers
+int mp_load_msa_fasta(mp_ctx *c, const mp_fasta *f) {
+    if (!c) return MP_ERR_ARG;
+    if (!f) return fail(c, MP_ERR_ARG, "mp_load_msa_fasta: no parsed file");
+    int32_t n_rows = 0;
+    int64_t n_bytes = 0, n_ids = 0;
+    if (mp_fasta_sizes(f, &n_rows, &n_bytes, &n_ids) != MP_OK || n_rows <= 0) return fail(c, MP_ERR_ARG, "mp_load_msa_fasta: no sequence records");
+    std::vector<int64_t> row_off((size_t)n_rows + 1);
+    if (mp_fasta_rows(f, nullptr, row_off.data()) != MP_OK) return fail(c, MP_ERR_ARG, "mp_load_msa_fasta: mp_fasta_rows");
+    constexpr size_t kSlot = (size_t)32 << 20;
+    constexpr int kSlots = 3;
+    return load_msa_impl(c, row_off.data(), n_rows, [&](uint8_t *d_bytes, int64_t total) -> int {
+        HIPCK(c, hipSetDevice(c->dev));
+        if (!c->h_ring) {
+            c->h_ring = static_cast<uint8_t *>(host_map(kSlot * kSlots));
+            if (!c->h_ring) return fail(c, MP_ERR_NOMEM, "mp_load_msa_fasta: out of host memory");
+            prefault_host(c->h_ring, kSlot * kSlots);
+            if (!getenv("MP_NO_PIN") && hipHostRegister(c->h_ring, kSlot * kSlots, hipHostRegisterDefault) == hipSuccess) c->h_ring_pinned = true;
+            else (void)hipGetLastError();
+            for (int i = 0; i < kSlots; i++) HIPCK(c, hipEventCreateWithFlags(&c->h_ring_ev[i], hipEventDisableTiming));
+        }
+        int slot = 0;
+        bool used[kSlots] = {false, false, false};
+        for (int64_t at = 0; at < total; at += (int64_t)kSlot, slot = (slot + 1) % kSlots) {
+            const int64_t n = std::min<int64_t>((int64_t)kSlot, total - at);
+            if (used[slot]) HIPCK(c, hipEventSynchronize(c->h_ring_ev[slot]));       // the copy that last read this slot has finished
+            uint8_t *buf = c->h_ring + (size_t)slot * kSlot;
+            if (mp_fasta_gather(f, at, at + n, buf, 0) != MP_OK) return fail(c, MP_ERR_ARG, "mp_load_msa_fasta: gather");
+            HIPCK(c, hipMemcpyAsync(d_bytes + at, buf, (size_t)n, hipMemcpyHostToDevice, c->stream));
+            HIPCK(c, hipEventRecord(c->h_ring_ev[slot], c->stream));
+            used[slot] = true;
+        }
+        return MP_OK;
+    });
 }
 
 int mp_row_attributes(mp_ctx *c, int32_t *lead, int32_t *rstrip, int32_t *rowlen) {

@@ -31,6 +31,8 @@ HOST_SYMBOLS = [
     ("mp_fasta_error", C.c_char_p, [_p]),
     ("mp_fasta_sizes", C.c_int, [_p, C.POINTER(C.c_int32), C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),
     ("mp_fasta_rows", C.c_int, [_p, _p, _p]),
+    ("mp_fasta_gather", C.c_int, [_p, C.c_int64, C.c_int64, _p, C.c_int32]),
+    ("mp_load_msa_fasta", C.c_int, [_p, _p]),
     ("mp_fasta_ids", C.c_int, [_p, _p, _p]),
     ("mp_file_count_newlines", C.c_int, [C.c_char_p, C.c_int32, C.POINTER(C.c_int64)]),
     ("mp_plan_create", C.c_int, [C.POINTER(PlanParams), C.c_int64, _p, _p, _p, _p, C.c_int64, _p, _p, _p, _p, _p, C.POINTER(_p)]),
@@ -73,7 +75,7 @@ def dll():
             one_hip_runtime()
         d = C.CDLL(path)
         for name, res, args in HOST_SYMBOLS:
-            if name == "mp_plan_create_streamed" and not hasattr(d, name):
+            if name in ("mp_plan_create_streamed", "mp_load_msa_fasta") and not hasattr(d, name):
                 continue                   # a host-only build (MP_HOST_LIB): the entry point that takes a device context lives in unique.hip
             fn = getattr(d, name)
             fn.restype = res
@@ -129,6 +131,22 @@ class Fasta:
         if rc != 0:
             raise MprimeError(rc, "mp_fasta_rows")
         return data[: self.n_bytes], off
+
+    def row_offsets(self):
+        """row_off alone (no residue bytes are copied)."""
+        off = np.empty(self.n_rows + 1, np.int64)
+        rc = self.d.mp_fasta_rows(self.h, None, _ptr(off))
+        if rc != 0:
+            raise MprimeError(rc, "mp_fasta_rows")
+        return off
+
+    def load_into(self, ctx):
+        """mp_load_msa_fasta: the records' residue bytes from the parsed file straight through the context's registered transfer
+        buffers to the device (no intermediate array).  The caller checked serves_device_library(ctx.lib)."""
+        rc = self.d.mp_load_msa_fasta(ctx.h, self.h)
+        if rc != 0:
+            raise MprimeError(rc, ctx.d.mp_last_error(ctx.h).decode())
+        ctx.n_rows = self.n_rows
 
     def ids_raw(self):
         """(bytes as a uint8 array, offsets): the ids as they stand in the file, id r = bytes[off[r]:off[r+1]]."""

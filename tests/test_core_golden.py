@@ -78,6 +78,23 @@ def test_hip_path_matches_reference(name, hip_lib, tmp_path):
     check_outputs(name, out)
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", ["syn_edge", "syn_ragged", "msa1000_k18_d64", "testfa"])
+def test_streamed_load_equals_the_array_load(name, hip_lib, tmp_path, monkeypatch):
+    """mp_load_msa_fasta (residue bytes from the parsed file through the context's registered transfer buffers: the default of a single
+    process) against mp_load_msa of the rows array (MP_LOAD_STREAM=0), and without registered buffers (MP_NO_PIN): the reference's files."""
+    for mode, env in (("stream", {}), ("array", {"MP_LOAD_STREAM": "0"}), ("unpinned", {"MP_NO_PIN": "1"})):
+        for key in ("MP_LOAD_STREAM", "MP_NO_PIN"):
+            monkeypatch.delenv(key, raising=False)
+        for key, val in env.items():
+            monkeypatch.setenv(key, val)
+        d = tmp_path / mode
+        d.mkdir()
+        app, out = run_fixture(name, hip_lib, d)
+        check_outputs(name, out)
+        app.ctx.close()
+
+
 def test_one_context_for_many_alignments_on_the_checker(oracle_lib, tmp_path):
     """The same control flow (a context kept across alignments of different shapes) without a GPU."""
     ctx = None

@@ -372,3 +372,28 @@ def test_expansions_as_window_words_equal_the_code_path():
     exp, src = host.expand_kmers(codes)
     words, src2 = host.expand_kmer_words(codes)
     assert np.array_equal(src, src2) and np.array_equal(iupac.words_of_codes(exp), words)
+
+
+def test_fasta_gather_equals_the_rows_array():
+    """mp_fasta_gather (the streamed load's source): any byte range of the rows laid end to end, on any number of threads — multi-line
+    records, CRLF, repeated ids, empty records."""
+    import ctypes as C
+    import numpy as np
+    from multiprime_amd import host
+    rng = np.random.default_rng(5)
+    recs = []
+    for i in range(300):
+        L = int(rng.integers(0, 400))
+        body = bytes(rng.choice(np.frombuffer(b"ACGT-N", np.uint8), size=L))
+        width = int(rng.integers(20, 80))
+        lines = [body[a:a + width] for a in range(0, L, width)] or [b""]
+        recs.append(b">s%03d\n" % (i % 280) + (b"\r\n" if i % 3 == 0 else b"\n").join(lines) + b"\n")
+    fa = host.Fasta(raw=b"".join(recs))
+    data, off = fa.rows()
+    assert np.array_equal(fa.row_offsets(), off)
+    total = int(off[-1])
+    for a, b, T in [(0, total, 0), (0, total, 1), (5, total - 7, 3), (int(off[17]) + 3, int(off[18]) - 1, 2), (total // 3, total // 3 + 1, 1),
+                    (int(off[40]), int(off[95]), 5), (total, total, 1)]:
+        out = np.full(max(b - a, 1), 255, np.uint8)
+        rc = host.dll().mp_fasta_gather(fa.h, a, b, out.ctypes.data_as(C.c_void_p), T)
+        assert rc == 0 and np.array_equal(out[: b - a], data[a:b]), (a, b, T)

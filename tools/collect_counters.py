@@ -55,7 +55,7 @@ def main():
     a = ap.parse_args()
     a.out = os.path.abspath(a.out)                 # rocprofv3 runs from /tmp
     os.makedirs(a.out, exist_ok=True)
-    bench = [sys.executable, os.path.join(REPO, "bench.py"), "--rows", str(a.rows), "--no-cpu", "--no-variants", "--no-full", "--no-pipeline", "--no-side", "--no-shapes"] + a.bench_args.split()
+    bench = [sys.executable, os.path.join(REPO, "bench.py"), "--rows", str(a.rows), "--no-cpu", "--no-variants", "--no-full", "--no-pipeline", "--no-side", "--no-shapes", "--no-ksweep"] + a.bench_args.split()
     # kernel trace of the bench command itself
     run(["rocprofv3", "--kernel-trace", "--stats", "-d", os.path.join(a.out, "trace"), "-o", "bench", "--"] + bench + ["--steps", "20", "--warmup", "3"],
         os.path.join(a.out, "trace_bench.json"))

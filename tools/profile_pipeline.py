@@ -15,6 +15,8 @@ REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 ap = argparse.ArgumentParser()
 ap.add_argument("--rows", type=int, default=131072)
 ap.add_argument("--out", default=os.path.join(REPO, "gpurun_out", "r02", "prof_pipe"))
+ap.add_argument("--json", default="", help="also write the per-kernel rows {kernel, calls, avg_us, bytes_compulsory, frac} to this file (merged by rows: "
+                                             "bench.py's pipeline block reads profiles/r06_pipeline_kernels.json)")
 a = ap.parse_args()
 out = os.path.abspath(a.out)
 os.makedirs(out, exist_ok=True)
@@ -54,3 +56,42 @@ if tdb:
         ratio = c.get("SQ_WAIT_INST_ANY", 0) / c["SQ_BUSY_CYCLES"] if c.get("SQ_BUSY_CYCLES") else 0
         print(f"{short(name):44s} {calls:5d} {total:10.1f} {avg:9.1f} {c.get('SQ_INSTS_VALU', 0):11.0f} {c.get('SQ_INSTS_SALU', 0):11.0f} "
               f"{c.get('SQ_INSTS_VMEM_RD', 0):9.0f} {c.get('SQ_INSTS_LDS', 0):9.0f} {c.get('SQ_WAVES', 0):8.0f} {ratio:14.2f} {vf:9.3f}")
+
+
+# ---- per-kernel rows with the bytes an ideal kernel of the formulation must move (N rows x L = 1000 columns, W windows of k = 18) -------------
+if a.json and tdb:
+    N, L, k = float(a.rows), 1000.0, 18
+    W = L - k - 36                                   # windows of the primer region on the synthetic alignment (982 at the bench sizes: region 18..1000)
+    slots = 16384.0
+    while slots < N / 16:
+        slots *= 2
+    model = [   # (kernel-name prefix, bytes per call, what)
+        ("pack_kernel", N * L * 1.5, "characters in, 4 one-bit planes out"),
+        ("row_scan_kernel", N * L * (0.5 + 0.125 + 0.5), "planes in; prefix counts and gap-free nibbles out"),
+        ("colplane_kernel", N * L * 1.0, "planes in, column planes out"),
+        ("classify_kernel", N * L * 0.5 + W * N / 8, "planes in, exclusion words out (per pass)"),
+        ("hist", N * L * 3 / 8, "SURVEY 8d (ii): the packed planes once (every window re-reads its 8 plane words: 36 B per row and window through L2)"),
+        ("table_sums_kernel", W * slots * 12, "every slot's key and count once"),
+        ("compact_kernel", W * 0.45 * slots * 16, "the tables of the windows the gate leaves (~45 %) once"),
+        ("window_stats_kernel", N * L * 0.5 + W * N / 8, "column planes and exclusion words once"),
+        ("eval_slide_kernel", N * L * 3 / 8, "SURVEY 8d (ii)"), ("eval_chain_kernel", N * L * 3 / 8, "SURVEY 8d (ii)"), ("eval_bits_kernel", N * L * 3 / 8, "SURVEY 8d (ii)"),
+    ]
+    rows = []
+    for name, calls, total, avg in sqlite3.connect(tdb[0]).execute("select name,total_calls,total_duration,average from top_kernels order by total_duration desc"):
+        sn = short(name)
+        m = next((x for x in model if sn.startswith(x[0]) or (" " + x[0]) in sn or sn.split("<")[0].endswith(x[0])), None)
+        row = {"kernel": sn, "calls": calls, "avg_us": avg, "total_us": total}
+        if m:
+            row.update({"bytes_compulsory": m[1], "frac": m[1] / (avg * 1e-6) / 8e12, "bytes_model": m[2]})
+        c = pmc.get(name, {})
+        if c.get("SQ_INSTS_VALU"):
+            row["valu_frac"] = c["SQ_INSTS_VALU"] / (avg * 1e-6 * 1024 * ceil)
+        rows.append(row)
+    try:
+        with open(a.json) as f:
+            db = json.load(f)
+    except (OSError, ValueError):
+        db = {}
+    db[f"rows_{a.rows}"] = {"what": "rocprofv3 --kernel-trace of the whole core step (tools/pipeline_scale.py); frac = bytes_compulsory / avg duration / 8 TB/s", "kernels": rows}
+    with open(a.json, "w") as f:
+        json.dump(db, f, indent=1)

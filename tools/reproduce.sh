@@ -57,7 +57,7 @@ for k, v in d.items():
   rocprofv3 --kernel-trace --stats -d $O/prof/trace -o t -- python tools/side_bench.py > /dev/null 2>&1
   python tools/summarize_profile.py $O/prof 2>/dev/null | head -24 | tee $O/side_kernels.txt ;;
 shapes)          # bench.py's shard_shapes block alone (headline + 8x1 shard + 4x2 / 2x4 / 1x8), no side measurements
-  timeout 1200 python bench.py --steps 40 --warmup 5 --no-variants --no-pipeline --no-side "$@" > $O/bench.txt 2> $O/bench.err; tail -c 400 $O/bench.err; tail -1 $O/bench.txt
+  timeout 1200 python bench.py --steps 40 --warmup 5 --no-variants --no-pipeline --no-side --no-ksweep "$@" > $O/bench.txt 2> $O/bench.err; tail -c 400 $O/bench.err; tail -1 $O/bench.txt
   python -c "
 import json
 d = json.load(open('bench_detail.json'))
@@ -76,15 +76,32 @@ print({k: d[k] for k in ('n_gpus', 'ms_per_step', 'value', 'parity_checked')}, d
 share_sweep)     # profiles/r06_share_sweep.txt: one rank's share of the 1x8 / 2x4 / 8x1 job under band lengths and row words per lane of the sliding kernel
   for share in 1x8 2x4 8x1; do for gw in 1 2 4; do for band in 0 4 6 8 10 12 15 20 30; do
     if [ $band = 0 ]; then unset MP_SLIDE_BAND; else export MP_SLIDE_BAND=$band; fi
-    MP_EVAL_SLIDE=1 MP_SLIDE_GW=$gw timeout 300 python bench.py --steps 60 --warmup 5 --share $share --no-variants --no-pipeline --no-side --no-shard --no-cpu 2>/dev/null | tail -1 | python -c "
+    MP_EVAL_SLIDE=1 MP_SLIDE_GW=$gw timeout 300 python bench.py --steps 60 --warmup 5 --share $share --no-variants --no-pipeline --no-side --no-ksweep --no-shard --no-cpu 2>/dev/null | tail -1 | python -c "
 import json, sys
 d = json.loads(sys.stdin.read()); print('share $share gw $gw band $band ms_per_step %.5f kernel_ms %.5f' % (d['ms_per_step'], d['roofline']['kernel_ms']))"
   done; done; done 2>&1 | tee $O/share_sweep.txt ;;
 streams)         # one stream (rotating launches) against two (mp_eval_launch_alt): the whole workload and one rank's shares
   for share in "" 1x8 2x4 8x1; do for st in 1 2; do for rep in 1 2; do
-    MP_BENCH_STREAMS=$st timeout 300 python bench.py --steps 80 --warmup 6 ${share:+--share $share} --no-variants --no-pipeline --no-side --no-shard --no-cpu 2>/dev/null | tail -1 | python -c "
+    MP_BENCH_STREAMS=$st timeout 300 python bench.py --steps 80 --warmup 6 ${share:+--share $share} --no-variants --no-pipeline --no-side --no-ksweep --no-shard --no-cpu 2>/dev/null | tail -1 | python -c "
 import json, sys
 d = json.loads(sys.stdin.read()); print('share ${share:-1x1} streams $st ms_per_step %.5f kernel_ms %.5f' % (d['ms_per_step'], d['roofline']['kernel_ms']))"
   done; done; done 2>&1 | tee $O/streams.txt ;;
+bench_default)   # profiles/r06_bench.json + r06_bench_detail.json: `python bench.py` with the driver's flags, wall time, the blocks of the detail file in short
+  SECONDS=0; python bench.py --gpus 1 --steps 20 --warmup 5 > $O/bench.txt 2> $O/bench.err; echo "rc=$? wall=${SECONDS}s"; tail -c 300 $O/bench.err
+  tail -1 $O/bench.txt > $O/bench.json; cp bench_detail.json $O/bench_detail.json; wc -c $O/bench.json; cat $O/bench.json
+  python -c "
+import json
+d = json.load(open('bench_detail.json'))
+print('k_sweep', json.dumps(d.get('k_sweep'))[:1800])
+print('pipeline', {k: (v.get('run_ms'), v.get('construct_ms'), v.get('tsv_equal_oracle')) for k, v in d['pipeline'].items() if isinstance(v, dict)})
+for k, v in d['pipeline'].items():
+    if isinstance(v, dict): print('phases', k, v.get('phases_ms'))
+print('side', {k: (v.get('parity_checked') if isinstance(v, dict) else v) for k, v in d['side_steps'].items()})
+print('shapes', {k: (v.get('ms_per_step'), v.get('parity_checked')) for k, v in d.get('shard_shapes', {}).items() if isinstance(v, dict)})
+print('variants', {k: (v.get('evals_per_s'), v.get('parity_checked')) for k, v in d.get('variants', {}).items() if isinstance(v, dict)})
+" | tee $O/blocks.txt ;;
+pipeline_kernels) # profiles/r06_pipeline_kernels.txt + .json: every kernel of the core step at both depths (trace + one SQ counter pass), bytes model, frac
+  rm -f $O/pipeline_kernels.json
+  for rows in 131072 1048576; do python tools/profile_pipeline.py --rows $rows --out $O/prof_$rows --json $O/pipeline_kernels.json; echo; done 2>&1 | tee $O/pipeline_kernels.txt ;;
 *) echo "unknown target $T"; exit 2 ;;
 esac
