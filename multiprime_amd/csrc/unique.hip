@@ -429,7 +429,9 @@ __global__ __launch_bounds__(kBlock) void hist_kernel(const HistArgs A) {
 // ---------------------------------------------------------------------------------------------------------------------------------
 template <int SLOTS, bool WIDE>
 __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(4))) void hist2_kernel(const HistArgs A) {
-    constexpr int kMaxProbe = 24, NW = kBlock / 64, QCAP = 256, ND = 256;     // (two row indices append at most 2 x 64 entries to the 63 that may wait)
+    // the ring holds what may wait (63) plus what one / two row indices append before the next drain: the wide-key form drains after every
+    // row index (128 entries: 36 KB of LDS per workgroup, four per CU), the narrow one after every second
+    constexpr int kMaxProbe = 24, NW = kBlock / 64, QCAP = WIDE ? 128 : 256, ND = 256;
     __shared__ unsigned long long s_key[SLOTS];
     __shared__ uint32_t s_cnt[SLOTS];
     __shared__ uint32_t s_min[SLOTS];
@@ -576,10 +578,13 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(4))) voi
                 }
                 q_tail += (uint32_t)__popcll(m_oth);
             }
-            if (u & 1) {
+            if (WIDE || (u & 1)) {
 #pragma unroll 1
                 while (q_tail - q_head >= 64u) drain(64u);
             }
+#ifndef MP_HIST2_NO_SCHED_BARRIER
+            __builtin_amdgcn_sched_barrier(0);                // one row index after the other: interleaving the four keeps four k-mers' worth of registers alive
+#endif
         }
     };
 #ifndef MP_HIST2_FLUSH_16THS
@@ -601,7 +606,20 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(4))) voi
             __syncthreads();
         }
     };
-    {
+#ifndef MP_HIST2_WIDE_SINGLE
+#define MP_HIST2_WIDE_SINGLE 1        // the wide-key form takes one register set (its gap words cost it a wave per SIMD otherwise: 162 -> 128 VGPRs)
+#endif
+    if (WIDE && MP_HIST2_WIDE_SINGLE) {
+        constexpr int kStep = kBlock * RPT;
+        Rows Ra;
+        const int t4 = (int)threadIdx.x * RPT;
+        int it = 0;
+        for (int base = r0; base < r1; base += kStep, it++) {
+            fetch(Ra, base + t4);
+            hash_rows(Ra, base);
+            if ((it & 1) && base + kStep < r1) maybe_flush();
+        }
+    } else {
         constexpr int kStep = kBlock * RPT;
         Rows Ra, Rb;
         const int t4 = (int)threadIdx.x * RPT;
