@@ -119,13 +119,32 @@ def one_hip_runtime():
     if spec is None or not spec.submodule_search_locations:
         return
     libdir = os.path.join(list(spec.submodule_search_locations)[0], "lib")
+    loaded = []
     for name in ("libhsa-runtime64.so", "libamdhip64.so"):
         path = os.path.join(libdir, name)
         if os.path.exists(path):
             try:
-                C.CDLL(path, mode=C.RTLD_GLOBAL)
-            except OSError:
+                loaded.append((name, C.CDLL(path, mode=C.RTLD_GLOBAL)))
+            except OSError as e:
+                # [r6, advisor] a half-loaded pair (torch's HSA, the system's HIP) is the mixed state this function exists to prevent
+                if loaded:
+                    raise MprimeError(-2, f"torch's {loaded[0][0]} is loaded but its {name} is not ({e}): refusing to run on a mixed pair of HIP "
+                                          "runtimes (MP_KEEP_SYSTEM_HIP=1 skips this step)") from None
                 return
+    # the runtime that now serves the process against the one libmprime_hip.so was built with (hipcc of /opt/rocm): a different MAJOR is refused
+    if len(loaded) == 2:
+        ver = C.c_int(0)
+        try:
+            if loaded[1][1].hipRuntimeGetVersion(C.byref(ver)) == 0:
+                major = ver.value // 10000000
+                built = int(os.environ.get("MP_BUILT_HIP_MAJOR", "7"))
+                if os.environ.get("MP_TRACE"):
+                    print(f"[mprime] HIP runtime bound: torch's ({libdir}), version {ver.value}; library built with HIP {built}.x", file=sys.stderr)
+                if major != built:
+                    raise MprimeError(-2, f"torch's HIP runtime is version {ver.value} (major {major}), libmprime_hip.so was built with HIP {built}.x: "
+                                          "set MP_KEEP_SYSTEM_HIP=1 to run on the system's runtime instead")
+        except AttributeError:
+            pass
 
 
 class MprimeError(RuntimeError):

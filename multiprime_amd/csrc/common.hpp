@@ -119,6 +119,8 @@ struct mp_ctx {
     char err[512] = {0};
     int dev = 0;
     hipStream_t stream = nullptr;
+    const void *rot_block = nullptr;         // mp_eval_launch_rotating: the block the last rotating launch cleared, and for how many counters
+    size_t rot_cleared = 0;
     hipStream_t alt_stream = nullptr;        // mp_eval_launch_alt: the library's own second stream (eval.hip)
     int64_t bytes = 0;
     // alignment

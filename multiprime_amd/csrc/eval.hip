@@ -1324,6 +1324,12 @@ static int eval_launch_impl(mp_ctx *c, int64_t *device_out, int64_t *device_clea
     // the counters are summed with atomics: they start at zero.  A launch of our own: the runtime's fill kernel takes 6 us per call
     // at this size (profiles/r02_pipeline_kernels.txt), a fifth of the evaluation itself
     if (zero_out) zero(device_out);
+    // [r6, advisor] a rotating launch clears 3 x n_cand counters of the block it is handed — the size of ITS staged set.  When that block comes
+    // back as device_out under a larger set, its tail was never cleared: refuse instead of adding to stale counts.
+    if (!zero_out && device_out == c->rot_block && n_counters > c->rot_cleared)
+        return fail(c, MP_ERR_ARG, "mp_eval_launch_rotating: this block was cleared for %zu counters by the launch before, the staged set needs %zu",
+                    c->rot_cleared, n_counters);
+    if (!zero_out) { c->rot_block = device_clear; c->rot_cleared = device_clear ? n_counters : 0; }
     // the rotating form's side job goes to the first kernel of the step that can take it (a kernel that cannot leaves it pending)
     unsigned long long *pending_clear = reinterpret_cast<unsigned long long *>(device_clear);
     auto take_clear = [&]() { unsigned long long *p = pending_clear; pending_clear = nullptr; return p; };

@@ -438,14 +438,16 @@ class StepBuckets:
 
     def drain(self):
         """Reduce the last, partial bucket and wait for everything in flight.  The next run starts on a bucket border with a
-        zeroed first block (so it may be a rotating one)."""
+        zeroed first block (so it may be a rotating one).  `n_done` = the steps really taken in the run this call closes (the slots
+        that pad a partial bucket are not steps)."""
+        taken = self.i
         if self.i % self.B:
             self._flush(self._pos(self.i)[0], self.i % self.B)
             self.i += self.B - self.i % self.B
         for b in range(self.D):
             self._free(b)
         self.base, self._run0 = self._run0, self.i
-        self.n_done = self.i - self.base
+        self.n_done = taken - self.base
         b, slot = self._pos(self.i)
         self.buf[b, slot].zero_()           # what the last rotating launch cleared is the block after ITS step, not this one
 
