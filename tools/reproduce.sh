@@ -103,5 +103,21 @@ print('variants', {k: (v.get('evals_per_s'), v.get('parity_checked')) for k, v i
 pipeline_kernels) # profiles/r06_pipeline_kernels.txt + .json: every kernel of the core step at both depths (trace + one SQ counter pass), bytes model, frac
   rm -f $O/pipeline_kernels.json
   for rows in 131072 1048576; do python tools/profile_pipeline.py --rows $rows --out $O/prof_$rows --json $O/pipeline_kernels.json; echo; done 2>&1 | tee $O/pipeline_kernels.txt ;;
+final)           # everything the round's profiles/ files come from, in the order their consumers need them (copy gpurun_out/r06/final/* to profiles/r06_*)
+  timeout 2400 python -m pytest tests -q -m gpu -x > $O/pytest_gpu.log 2>&1; echo "pytest rc=$?"; tail -3 $O/pytest_gpu.log
+  python -c "import __graft_entry__ as g; g.smoke()" > $O/smoke.txt 2>&1; tail -2 $O/smoke.txt
+  rm -f $O/pipeline_kernels.json
+  for rows in 131072 1048576; do python tools/profile_pipeline.py --rows $rows --out $O/prof_pipe_$rows --json $O/pipeline_kernels.json; echo; done > $O/pipeline_kernels.txt 2>&1
+  cp $O/pipeline_kernels.json profiles/r06_pipeline_kernels.json
+  timeout 900 python tools/collect_counters.py --rows 1048576 --out $O/prof_1m > $O/collect_1m.log 2>&1
+  timeout 600 python tools/collect_counters.py --rows 131072 --out $O/prof_131k --merge $O/prof_1m/counters.json > $O/collect_131k.log 2>&1
+  cp $O/prof_131k/counters.json profiles/r06_counters.json; cp $O/prof_131k/counters.json $O/counters.json
+  cp $O/prof_1m/summary.txt $O/bench_eval_1m.txt 2>/dev/null; cp $O/prof_131k/summary.txt $O/bench_eval.txt 2>/dev/null
+  rocprofv3 --kernel-trace --stats -d $O/prof_side/trace -o t -- python tools/side_bench.py > /dev/null 2>&1
+  python tools/summarize_profile.py $O/prof_side 2>/dev/null | head -24 > $O/side_kernels.txt
+  SECONDS=0; python bench.py --gpus 1 --steps 20 --warmup 5 > $O/bench.txt 2> $O/bench.err; echo "bench rc=$? wall=${SECONDS}s"
+  tail -1 $O/bench.txt > $O/bench.json; cp bench_detail.json $O/bench_detail.json; wc -c $O/bench.json; cat $O/bench.json
+  (for rows in 131072 1048576; do for k in 18 22; do echo "# rows $rows k $k"; laps $rows $k; done; done) > $O/run_laps.txt 2>&1
+  du -sh $O; rm -rf $O/prof_pipe_* $O/prof_1m/pmc_* $O/prof_131k/pmc_* $O/prof_1m/cal_* $O/prof_131k/cal_* $O/prof_side ;;
 *) echo "unknown target $T"; exit 2 ;;
 esac
