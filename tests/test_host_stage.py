@@ -397,3 +397,48 @@ def test_fasta_gather_equals_the_rows_array():
         out = np.full(max(b - a, 1), 255, np.uint8)
         rc = host.dll().mp_fasta_gather(fa.h, a, b, out.ctypes.data_as(C.c_void_p), T)
         assert rc == 0 and np.array_equal(out[: b - a], data[a:b]), (a, b, T)
+
+
+def test_parallel_join_equals_serial_join(monkeypatch):
+    """The parser's join on all threads (no id repeated: the common file) against the serial join (MP_HOST_SERIAL_JOIN), and its
+    fall-backs: a repeated id (first-appearance order, the record continues), headers without lines, blank lines, comments, CRLF / lone
+    CR, a record longer than a chunk, sequence data before the first header (the serial join's error)."""
+    import numpy as np
+    from multiprime_amd import host
+    rng = np.random.default_rng(11)
+
+    def make(n, repeat, long_record=False):
+        out = []
+        for i in range(n):
+            ident = b"s%04d" % (i if not (repeat and i % 17 == 5) else i - 3)
+            lines = [bytes(rng.choice(np.frombuffer(b"ACGT-", np.uint8), size=int(rng.integers(0, 90)))) for _ in range(int(rng.integers(0, 4)))]
+            if long_record and i == n // 2:
+                lines = [b"ACGT" * 20] * 400
+            if i % 23 == 0:
+                lines.insert(0, b"# a comment")
+            if i % 29 == 0:
+                lines.append(b"")
+            nl = (b"\n", b"\r\n", b"\r")[i % 3]
+            out.append(b">" + ident + b" description" + nl + b"".join(x + nl for x in lines))
+        return b"".join(out)
+
+    def parsed(raw):
+        fa = host.Fasta(raw=raw)
+        data, off = fa.rows()
+        res = (fa.ids, off.tolist(), data.tobytes())
+        fa.close()
+        return res
+
+    for threads in ("2", "7", "13"):
+        for repeat, long_record in ((False, False), (True, False), (False, True)):
+            raw = make(500, repeat, long_record)
+            monkeypatch.setenv("MP_HOST_THREADS", threads)
+            monkeypatch.delenv("MP_HOST_SERIAL_JOIN", raising=False)
+            fast = parsed(raw)
+            monkeypatch.setenv("MP_HOST_SERIAL_JOIN", "1")
+            assert parsed(raw) == fast, (threads, repeat, long_record)
+    monkeypatch.delenv("MP_HOST_SERIAL_JOIN", raising=False)
+    monkeypatch.setenv("MP_HOST_THREADS", "5")
+    import pytest
+    with pytest.raises(ValueError, match="before the first"):
+        host.Fasta(raw=b"ACGT\n" + make(50, False))
