@@ -243,10 +243,26 @@ bool join_parallel(mp_fasta *f, const std::vector<std::vector<Event>> &ev_all, s
     f->id_len.assign(R, 0);
     std::vector<uint64_t> id_hash(R);
     raw.assign(S, Seg{0, 0, 0});
+    // ... with each record's first segment (row_seg) and, chunk by chunk, the residues before it (row_off: completed below)
+    f->row_seg.assign(R + 1, 0);
+    f->row_off.assign(R + 1, 0);
+    std::vector<int64_t> chunk_bytes((size_t)T + 1, 0);
     mp::run_on_threads(T, [&](int t) {
-        int64_t r = n_rec[(size_t)t] - 1, g = n_seg[(size_t)t];
-        walk(t, [&](const Event &h) { r++; f->id_off_src[(size_t)r] = h.off; f->id_len[(size_t)r] = h.len; id_hash[(size_t)r] = h.hash; },
-             [&](const Event &e) { raw[(size_t)g++] = Seg{e.off, e.len, (int32_t)r}; });
+        int64_t r = n_rec[(size_t)t] - 1, g = n_seg[(size_t)t], bytes = 0;
+        walk(t, [&](const Event &h) {
+                 r++;
+                 f->id_off_src[(size_t)r] = h.off; f->id_len[(size_t)r] = h.len; id_hash[(size_t)r] = h.hash;
+                 f->row_seg[(size_t)r] = g; f->row_off[(size_t)r] = bytes;
+             },
+             [&](const Event &e) { raw[(size_t)g++] = Seg{e.off, e.len, (int32_t)r}; bytes += e.len; });
+        chunk_bytes[(size_t)t + 1] = bytes;
+    });
+    for (int t = 0; t < T; t++) chunk_bytes[(size_t)t + 1] += chunk_bytes[(size_t)t];
+    f->row_seg[R] = (int64_t)S;
+    f->row_off[R] = chunk_bytes[(size_t)T];
+    mp::run_on_threads(T, [&](int t) {
+        const int64_t add = chunk_bytes[(size_t)t];
+        if (add) for (int64_t r = n_rec[(size_t)t]; r < n_rec[(size_t)t + 1]; r++) f->row_off[(size_t)r] += add;
     });
     // is any id repeated?
     size_t cap = 16;
@@ -273,9 +289,11 @@ bool join_parallel(mp_fasta *f, const std::vector<std::vector<Event>> &ev_all, s
         }
     });
     if (repeated.load()) {
-        f->id_off_src.clear(); f->id_len.clear(); raw.clear();
+        f->id_off_src.clear(); f->id_len.clear(); f->row_seg.clear(); f->row_off.clear(); raw.clear();
         return false;
     }
+    f->id_bytes = 0;
+    for (size_t r = 0; r < R; r++) f->id_bytes += f->id_len[r];
     return true;
 }
 
@@ -345,25 +363,29 @@ int parse(mp_fasta *f) {
     }
     tr.lap("join");
     const size_t R = f->id_off_src.size();
-    // group the segments by row (stable: file order inside a row); already grouped when no id repeats out of order
-    f->row_seg.assign(R + 1, 0);
-    for (const Seg &s : raw) f->row_seg[(size_t)s.row + 1]++;
-    for (size_t r = 0; r < R; r++) f->row_seg[r + 1] += f->row_seg[r];
-    bool sorted = true;
-    for (size_t i = 1; i < raw.size(); i++) if (raw[i].row < raw[i - 1].row) { sorted = false; break; }
-    if (sorted) f->segs.swap(raw);
-    else {
-        f->segs.resize(raw.size());
-        std::vector<int64_t> at(f->row_seg.begin(), f->row_seg.end() - 1);
-        for (const Seg &s : raw) f->segs[(size_t)at[(size_t)s.row]++] = s;
-    }
-    f->row_off.assign(R + 1, 0);
-    f->id_bytes = 0;
-    for (size_t r = 0; r < R; r++) {
-        int64_t len = 0;
-        for (int64_t i = f->row_seg[r]; i < f->row_seg[r + 1]; i++) len += f->segs[(size_t)i].len;
-        f->row_off[r + 1] = f->row_off[r] + len;
-        f->id_bytes += f->id_len[r];
+    if (fast) {
+        f->segs.swap(raw);                              // in file order = grouped by row; row_seg / row_off / id_bytes came with the join
+    } else {
+        // group the segments by row (stable: file order inside a row); already grouped when no id repeats out of order
+        f->row_seg.assign(R + 1, 0);
+        for (const Seg &s : raw) f->row_seg[(size_t)s.row + 1]++;
+        for (size_t r = 0; r < R; r++) f->row_seg[r + 1] += f->row_seg[r];
+        bool sorted = true;
+        for (size_t i = 1; i < raw.size(); i++) if (raw[i].row < raw[i - 1].row) { sorted = false; break; }
+        if (sorted) f->segs.swap(raw);
+        else {
+            f->segs.resize(raw.size());
+            std::vector<int64_t> at(f->row_seg.begin(), f->row_seg.end() - 1);
+            for (const Seg &s : raw) f->segs[(size_t)at[(size_t)s.row]++] = s;
+        }
+        f->row_off.assign(R + 1, 0);
+        f->id_bytes = 0;
+        for (size_t r = 0; r < R; r++) {
+            int64_t len = 0;
+            for (int64_t i = f->row_seg[r]; i < f->row_seg[r + 1]; i++) len += f->segs[(size_t)i].len;
+            f->row_off[r + 1] = f->row_off[r] + len;
+            f->id_bytes += f->id_len[r];
+        }
     }
     tr.lap("group");
     if (R > 0x7fffffffULL - 1) return ffail(f, MP_ERR_ARG, "too many records");
