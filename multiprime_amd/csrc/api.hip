@@ -65,6 +65,9 @@ void prefault_host(void *p, size_t bytes) {
 }
 
 void free_eval(mp_ctx *c) {
+    // [r6] launches on the context's second stream (mp_eval_launch_alt) read what is released below, and the pool's "released" events are
+    // recorded on the FIRST stream: whatever the second one still runs has finished before any of it changes hands
+    if (c->alt_stream) (void)hipStreamSynchronize(c->alt_stream);
     free_slide(c);
     c->h_chains.clear(); c->h_events.clear(); c->h_cand_out.clear();
     dev_free(c, &c->chain_prog, c->chain_prog_n);
