@@ -99,8 +99,33 @@ __device__ inline uint32_t g_cas(uint32_t *p, uint32_t expect, uint32_t val) {
     __hip_atomic_compare_exchange_strong(p, &expect, val, __ATOMIC_RELAXED, __ATOMIC_RELAXED, MP_HIST_SCOPE);
     return expect;
 }
+// MP_HIST_CM64 (experiment, tools/build_variant.sh): count and first row of a slot in ONE 64-bit word (count << 32 | ~first row: zero = empty),
+// updated by a compare-and-swap loop — one atomic operation on the table in HBM where add + min are two
+#ifndef MP_HIST_CM64
+#define MP_HIST_CM64 0
+#endif
+__device__ inline void g_count_min(uint32_t *cnt_base, uint32_t *min_base, size_t at, uint32_t cnt, uint32_t row, bool fresh);
 __device__ inline void g_add(uint32_t *p, uint32_t v) { (void)__hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, MP_HIST_SCOPE); }
 __device__ inline void g_min(uint32_t *p, uint32_t v) { (void)__hip_atomic_fetch_min(p, v, __ATOMIC_RELAXED, MP_HIST_SCOPE); }
+
+__device__ inline void g_count_min(uint32_t *cnt_base, uint32_t *min_base, size_t at, uint32_t cnt, uint32_t row, bool fresh) {
+#if MP_HIST_CM64
+    unsigned long long *cm = reinterpret_cast<unsigned long long *>(cnt_base) + at;
+    unsigned long long old = fresh ? 0ull : *cm;
+    for (;;) {
+        const uint32_t lo = (uint32_t)old, nr = ~row;
+        const unsigned long long neu = ((unsigned long long)((uint32_t)(old >> 32) + cnt) << 32) | (unsigned long long)(lo > nr ? lo : nr);
+        const unsigned long long got = g_cas(cm, old, neu);
+        if (got == old) break;
+        old = got;
+    }
+    (void)min_base;
+#else
+    (void)fresh;
+    g_add(cnt_base + at, cnt);
+    g_min(min_base + at, row);
+#endif
+}
 
 // does slot h (whose key word answered `old` to the claim of `key`, with kNoKey already replaced by key) hold (key, gap)?
 template <bool WIDE>
@@ -119,13 +144,13 @@ __device__ inline void global_insert_from(const HistArgs &A, int w, unsigned lon
     unsigned long long *K = A.g_key + base;
     for (int probe = probe0; probe < A.g_slots; probe++) {
         unsigned long long old = K[h];
+        bool fresh = false;
         if (old == kNoKey) {
             old = g_cas(&K[h], kNoKey, key);
-            if (old == kNoKey) old = key;                 // claimed (occupied slots are counted afterwards, table_sums_kernel)
+            if (old == kNoKey) { old = key; fresh = true; }     // claimed (occupied slots are counted afterwards, table_sums_kernel)
         }
         if (slot_holds<WIDE>(old, key, A.g_gap, base + h, gap)) {
-            g_add(&A.g_cnt[base + h], cnt);
-            g_min(&A.g_min[base + h], row);
+            g_count_min(A.g_cnt, A.g_min, base + h, cnt, row, fresh);
             return;
         }
         h = (h + 1) & mask;
@@ -166,18 +191,20 @@ __device__ inline void flush_table(const HistArgs &A, int w, unsigned long long 
         }
 #pragma unroll
         for (int u = 0; u < S; u++) old[u] = key[u] != kNoKey ? K[h[u]] : 0ull;
+        bool fresh[S];
 #pragma unroll
-        for (int u = 0; u < S; u++)
+        for (int u = 0; u < S; u++) {
+            fresh[u] = false;
             if (key[u] != kNoKey && old[u] == kNoKey) {
                 old[u] = g_cas(&K[h[u]], kNoKey, key[u]);
-                if (old[u] == kNoKey) old[u] = key[u];
+                if (old[u] == kNoKey) { old[u] = key[u]; fresh[u] = true; }
             }
+        }
 #pragma unroll
         for (int u = 0; u < S; u++)
             if (key[u] != kNoKey) {
                 if (slot_holds<WIDE>(old[u], key[u], A.g_gap, base + h[u], gap[u])) {
-                    g_add(&A.g_cnt[base + h[u]], cnt[u]);
-                    g_min(&A.g_min[base + h[u]], mn[u]);
+                    g_count_min(A.g_cnt, A.g_min, base + h[u], cnt[u], mn[u], fresh[u]);
                 } else {
                     global_insert_from<WIDE>(A, w, key[u], gap[u], cnt[u], mn[u], (h[u] + 1) & mask, 1);
                 }
@@ -714,7 +741,11 @@ __global__ __launch_bounds__(kBlock) void table_sums_kernel(const unsigned long 
             if (key[u] == kNoKey) continue;
             n++;
             if (want_sums) {
+#if MP_HIST_CM64
+                const double c = (double)(uint32_t)(reinterpret_cast<const unsigned long long *>(g_cnt)[base + i0 + u * kBlock] >> 32);
+#else
                 const double c = (double)g_cnt[base + i0 + u * kBlock];
+#endif
                 t += c;
                 sum += c * log2(c);
             }
@@ -775,8 +806,14 @@ __global__ __launch_bounds__(kBlock) void compact_kernel(const CompactArgs A) {
                 A.b0[e] = (uint32_t)key[u] & kmask;
                 A.b1[e] = (uint32_t)(key[u] >> A.k) & kmask;
                 A.g[e] = A.g_gap ? ((key[u] & kGapFlag) ? A.g_gap[s] : 0u) : (uint32_t)(key[u] >> (2 * A.k)) & kmask;
+#if MP_HIST_CM64
+                const unsigned long long cm = reinterpret_cast<const unsigned long long *>(A.g_cnt)[s];
+                A.count[e] = (int32_t)(uint32_t)(cm >> 32);
+                A.first[e] = (int32_t)~(uint32_t)cm;
+#else
                 A.count[e] = (int32_t)A.g_cnt[s];
                 A.first[e] = (int32_t)A.g_min[s];
+#endif
             }
         }
         __syncthreads();
@@ -1006,11 +1043,11 @@ int unique_packed(mp_ctx *c, int64_t cap, int32_t want_labels, int64_t *n_entrie
         const size_t n = W * (size_t)slots;
         c->g_slots = slots;
         if ((rc = dev_alloc(c, &c->g_key, n))) return rc;
-        if ((rc = dev_alloc(c, &c->g_cnt, n))) return rc;
-        if ((rc = dev_alloc(c, &c->g_min, n))) return rc;
+        if ((rc = dev_alloc(c, &c->g_cnt, MP_HIST_CM64 ? 2 * n : n))) return rc;       // (MP_HIST_CM64: one u64 per slot, no first-row array)
+        if ((rc = dev_alloc(c, &c->g_min, MP_HIST_CM64 ? 1 : n))) return rc;
         if ((rc = dev_alloc(c, &c->g_idx, n))) return rc;
         if (wide_key && (rc = dev_alloc(c, &c->g_gap, n))) return rc;
-        const FillSeg init[6] = {{c->g_key, sizeof(unsigned long long) * n, 0xFFFFFFFFu}, {c->g_cnt, sizeof(uint32_t) * n, 0u}, {c->g_min, sizeof(uint32_t) * n, 0xFFFFFFFFu},
+        const FillSeg init[6] = {{c->g_key, sizeof(unsigned long long) * n, 0xFFFFFFFFu}, {c->g_cnt, sizeof(uint32_t) * (MP_HIST_CM64 ? 2 * n : n), 0u}, {c->g_min, sizeof(uint32_t) * (MP_HIST_CM64 ? 1 : n), 0xFFFFFFFFu},
                                  {c->u_wcount, sizeof(int32_t) * W, 0u}, {c->u_over, sizeof(int32_t) * W, 0u}, {c->g_gap, sizeof(uint32_t) * n, 0xFFFFFFFFu}};
         lap("unique: table alloc");
         if ((rc = fill_segments(c, init, wide_key ? 6 : 5))) return rc;
@@ -1084,7 +1121,7 @@ int unique_packed(mp_ctx *c, int64_t cap, int32_t want_labels, int64_t *n_entrie
         }
         if (!any_over) break;
         // a window has (nearly) as many distinct k-mers as slots: start over with tables 8x the size (rare: random input)
-        dev_free(c, &c->g_key, n); dev_free(c, &c->g_cnt, n); dev_free(c, &c->g_min, n); dev_free(c, &c->g_idx, n); dev_free(c, &c->g_gap, n);
+        dev_free(c, &c->g_key, n); dev_free(c, &c->g_cnt, MP_HIST_CM64 ? 2 * n : n); dev_free(c, &c->g_min, MP_HIST_CM64 ? 1 : n); dev_free(c, &c->g_idx, n); dev_free(c, &c->g_gap, n);
         if (attempt == 7 || (size_t)slots * 8 > ((size_t)1 << 28)) return fail(c, MP_ERR_NOMEM, "histogram tables do not converge");
         slots *= 8;
     }
