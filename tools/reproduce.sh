@@ -119,5 +119,7 @@ final)           # everything the round's profiles/ files come from, in the orde
   tail -1 $O/bench.txt > $O/bench.json; cp bench_detail.json $O/bench_detail.json; wc -c $O/bench.json; cat $O/bench.json
   (for rows in 131072 1048576; do for k in 18 22; do echo "# rows $rows k $k"; laps $rows $k; done; done) > $O/run_laps.txt 2>&1
   du -sh $O; rm -rf $O/prof_pipe_* $O/prof_1m/pmc_* $O/prof_131k/pmc_* $O/prof_1m/cal_* $O/prof_131k/cal_* $O/prof_side ;;
+soak)            # profiles/r06_soak.txt: randomised HIP-vs-oracle soaks through every kernel setting (incl. hist2 / hist / rep-rows, eval_chain_x shapes, v <= 5)
+  (timeout 500 python tools/soak_parity.py --seconds ${1:-240} --seed 61; timeout 200 python tools/soak_parity.py --seconds 60 --seed 62; timeout 200 python tools/soak_primers.py --seconds 45) 2>&1 | tee $O/soak.txt ;;
 *) echo "unknown target $T"; exit 2 ;;
 esac

@@ -25,7 +25,12 @@ ENVS = [{}, {"MP_EVAL_GROUP": "plain"}, {"MP_EVAL_GROUP": "nested"}, {"MP_EVAL_B
         {"MP_EVAL_PROG": "1", "MP_EVAL_CHAIN": "7"}, {"MP_EVAL_PROG": "1", "MP_EVAL_CHAIN": "3"},
         {"MP_EVAL_PROG": "1", "MP_EVAL_CHAIN": "11"}, {"MP_EVAL_PROG": "1", "MP_EVAL_CHAIN": "10"}, {"MP_EVAL_PROG": "1", "MP_EVAL_CHAIN": "12"},
         {"MP_HIST_LDS": "4096"}]
-KEYS = sorted({k for e in ENVS for k in e} | {"MP_EVAL_GENERIC_V"})
+# [r6] primers of 32..63 bases / v = 4, 5: eval_chain_x_kernel in its four shapes, and the row-per-lane kernels it replaces
+ENVS_X = [{}, {"MP_EVAL_X_SHAPE": "0"}, {"MP_EVAL_X_SHAPE": "1"}, {"MP_EVAL_X_SHAPE": "2"}, {"MP_EVAL_X_SHAPE": "3"}, {"MP_EVAL_NO_X": "1"},
+          {"MP_EVAL_NO_X": "1", "MP_EVAL_GENERIC_V": "1"}]
+# [r6] histogram paths: hist2_kernel (default), the round-5 row loop, the one-workgroup-per-window kernel
+ENVS_HIST = [{}, {"MP_HIST_V1": "1"}, {"MP_HIST_V1": "1", "MP_HIST_FOLDS": "3"}, {"MP_HIST_REP_ROWS": "1"}]
+KEYS = sorted({k for e in ENVS + ENVS_X + ENVS_HIST for k in e} | {"MP_EVAL_GENERIC_V"})
 
 
 def main():
@@ -41,7 +46,7 @@ def main():
     while time.time() < t_end:
         n = int(rng.choice([1, 7, 63, 64, 65, 200, 257, 1000, 2049, 5000, 9000, 17000, 33000, 70000]))
         k = int(rng.integers(2, 32)) if rng.random() < 0.7 else int(rng.integers(32, 64))      # 32..63: 64-bit window words, row-per-lane kernels only
-        v = int(rng.integers(0, min(4, k)))
+        v = int(rng.integers(0, min(6, k)))                        # [r6] v = 4, 5: six counter levels
         L = int(rng.integers(k + 8, 3 * k + 80))
         p0 = int(rng.integers(0, 6))
         ragged = bool(rng.random() < 0.3) and n > 10
@@ -86,14 +91,21 @@ def main():
                     c.set_extra_rows(np.asarray(xw, np.int32), words)
             for x, y in zip(ctxs[0].window_stats(), ctxs[1].window_stats()):
                 assert np.array_equal(x, y), "window_stats"
-            for x, y in zip(ctxs[0].window_unique(), ctxs[1].window_unique()):
-                assert np.array_equal(x, y), "window_unique"
+            want_u = ctxs[1].window_unique()
+            for env in (ENVS_HIST if k <= 31 else [{}]):
+                for key in KEYS:
+                    os.environ.pop(key, None)
+                os.environ.update(env)
+                for x, y in zip(ctxs[0].window_unique(), want_u):
+                    assert np.array_equal(x, y), ("window_unique", env)
+            for key in KEYS:
+                os.environ.pop(key, None)
             root = np.array([1, 2, 4, 8], np.uint8)[rng.integers(0, 4, size=maxlen + k)]
             cw, codes = chain_candidates(rng, root, W, k, str(rng.choice(["up", "down", "mixed"])))
             sF = int(rng.integers(0, 1 << k))
             sR = int(rng.integers(0, 1 << k))
             want = ctxs[1].eval_candidates(cw, codes, sF, sR)
-            for env in (ENVS if k <= 31 else [{}, {"MP_EVAL_GENERIC_V": "1"}]):
+            for env in (ENVS if k <= 31 and v <= 3 else ENVS_X):
                 for key in KEYS:
                     os.environ.pop(key, None)
                 os.environ.update(env)
@@ -113,7 +125,7 @@ def main():
             for c in ctxs:
                 c.close()
     print(json.dumps({"cases": n_cases, "short_window_errors_on_both": n_short, "candidates": n_cand_total,
-                      "settings_per_case": len(ENVS), "seconds": a.seconds, "seed": a.seed}))
+                      "settings_per_case": len(ENVS), "settings_wide_or_v45": len(ENVS_X), "histogram_settings": len(ENVS_HIST), "seconds": a.seconds, "seed": a.seed}))
 
 
 if __name__ == "__main__":
