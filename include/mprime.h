@@ -155,6 +155,11 @@ int mp_get_labels_many(mp_ctx *ctx, int32_t n, const int32_t *windows, int32_t *
  *                    not counted, V20:569-575)
  * Host arrays, int64: freq [n_windows][4][k], nn [n_windows][k-1][4][4]. */
 int mp_window_stats(mp_ctx *ctx, int64_t *freq, int64_t *nn);
+/* [r6] mp_window_stats in two halves: begin launches the kernel and the read-back of its counters on the context's second stream and
+ * returns at once, end waits and fills freq / nn.  mp_plan_create_streamed (mprime_host.h) calls end itself when a begin is pending: its
+ * read-back of the histogram entries then runs beside the statistics kernel.  One begin at a time. */
+int mp_window_stats_begin(mp_ctx *ctx);
+int mp_window_stats_end(mp_ctx *ctx, int64_t *freq, int64_t *nn);
 
 /* (4) candidate x sequence coverage evaluation ---------------------------------------------- */
 /* Replaces mis_primer_check + Y_distance (V20:1103-1130, 229-233), evaluated per sequence

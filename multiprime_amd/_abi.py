@@ -58,6 +58,8 @@ SYMBOLS = [
     ("mp_eval_upload", C.c_int, [_p, C.c_int32, _p, _p, C.c_uint64, C.c_uint64]),
     ("mp_eval_launch", C.c_int, [_p, _p]),
     ("mp_eval_launch_rotating", C.c_int, [_p, _p, _p]),
+    ("mp_window_stats_begin", C.c_int, [_p]),
+    ("mp_window_stats_end", C.c_int, [_p, _p, _p]),
     ("mp_eval_launch_alt", C.c_int, [_p, _p]),
     ("mp_eval_sync", C.c_int, [_p]),
     ("mp_eval_timing", C.c_int, [_p, C.c_int32, C.POINTER(C.c_double), C.POINTER(C.c_int32)]),
@@ -349,6 +351,18 @@ class Context:
         nn = np.zeros((self.n_win, self.k - 1, 4, 4), np.int64)
         self._ck(self.d.mp_window_stats(self.h, _ptr(freq), _ptr(nn)))
         return freq, nn
+
+    def window_stats_begin(self):
+        """window_stats in two halves (mp_window_stats_begin): the kernel and the read-back of its counters start on the context's second
+        stream; returns the (freq, nn) arrays the counters will land in — valid after window_stats_end(freq, nn), or after a
+        host.Plan(device_context=...) built with them (mp_plan_create_streamed ends a pending begin itself)."""
+        freq = np.zeros((self.n_win, 4, self.k), np.int64)
+        nn = np.zeros((self.n_win, self.k - 1, 4, 4), np.int64)
+        self._ck(self.d.mp_window_stats_begin(self.h))
+        return freq, nn
+
+    def window_stats_end(self, freq, nn):
+        self._ck(self.d.mp_window_stats_end(self.h, _ptr(freq), _ptr(nn)))
 
     def eval_candidates(self, cand_window, cand_codes, strictF: int, strictR: int) -> np.ndarray:
         cand_window = np.ascontiguousarray(cand_window, dtype=np.int32)

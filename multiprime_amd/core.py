@@ -284,8 +284,14 @@ class NN_degenerate(object):
             self._lap("set_extra_rows")
         self.stats["build_windows_s"] = time.time() - t0 - (self.stats["unique_s"] if early_unique else 0.0)
         t0 = time.time()
-        # state_matrix / trans_matrix of every window (V20:541-577) straight from the column planes; shards add up
-        self._freq, self._nn = self.ctx.window_stats()
+        # state_matrix / trans_matrix of every window (V20:541-577) straight from the column planes; shards add up.  The streamed planning
+        # of a single process starts the kernel only (mp_window_stats_begin, second stream): its read-back of the histogram entries runs
+        # beside it, and mp_plan_create_streamed collects the counters before a planner reads one
+        stats_beside = streamed and self.comm is None and os.environ.get("MP_STATS_BESIDE", "1") != "0"
+        if stats_beside:
+            self._freq, self._nn = self.ctx.window_stats_begin()
+        else:
+            self._freq, self._nn = self.ctx.window_stats()
         if self.comm is not None:
             self._freq, self._nn = self.comm.sum_many_int64([self._freq, self._nn])           # one all-reduce for both tables
         self.stats["stats_s"] = time.time() - t0

@@ -297,6 +297,8 @@ void mp_destroy(mp_ctx *c) {
     dev_free(c, &c->stats_buf, c->stats_buf_n);
     if (getenv("MP_TRACE")) fprintf(stderr, "[mprime] device blocks: %lld reused, %lld from the runtime, %zu waiting (%.1f MB)\n", c->pool_hits, c->pool_misses,
                                     c->pool.size(), c->pool_bytes / 1048576.0);
+    if (c->h_stats) { if (c->h_stats_pinned) (void)hipHostUnregister(c->h_stats); host_unmap(c->h_stats, c->h_stats_bytes); }
+    if (c->stats_ev) (void)hipEventDestroy(c->stats_ev);
     if (c->h_ring) {
         if (c->h_ring_pinned) (void)hipHostUnregister(c->h_ring);
         host_unmap(c->h_ring, (size_t)96 << 20);

@@ -235,6 +235,10 @@ struct mp_ctx {
     uint8_t *h_stage = nullptr;              // host_map() memory
     size_t h_stage_bytes = 0;
     bool h_stage_pinned = false;             // registered with the runtime (hipHostRegister): copies into it are plain DMA
+    uint8_t *h_stats = nullptr;              // mp_window_stats_begin: the counters' landing buffer (host_map, registered)
+    size_t h_stats_bytes = 0, stats_pending_f = 0, stats_pending_t = 0;       // pending: counters of a begin nobody has ended yet
+    bool h_stats_pinned = false;
+    hipEvent_t stats_ev = nullptr;
     uint8_t *h_ring = nullptr;               // mp_load_msa_fasta: 3 x 32 MB transfer buffers (host_map, registered), kept for the context's life
     bool h_ring_pinned = false;
     hipEvent_t h_ring_ev[3] = {nullptr, nullptr, nullptr};

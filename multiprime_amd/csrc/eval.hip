@@ -1539,13 +1539,10 @@ int mp_eval_timing_samples(mp_ctx *c, int32_t cap, float *ms, int32_t *n) {
     return MP_OK;
 }
 
-int mp_window_stats(mp_ctx *c, int64_t *freq, int64_t *nn) {
-    if (!c) return MP_ERR_ARG;
-    if (!c->excl) return fail(c, MP_ERR_ARG, "no windows built");
-    if (!freq || !nn) return fail(c, MP_ERR_ARG, "null output");
-    HIPCK(c, hipSetDevice(c->dev));
+// the statistics launch on the context's current stream into stats_buf (n_f frequency + n_t pair counters)
+static int window_stats_launch(mp_ctx *c, size_t &n_f, size_t &n_t) {
     const size_t W = (size_t)c->n_win, k = (size_t)c->k;
-    const size_t n_f = W * 4 * k, n_t = W * (k - 1) * 16;
+    n_f = W * 4 * k; n_t = W * (k - 1) * 16;
     int rc;
     if (c->stats_buf_n < n_f + n_t) {
         dev_free(c, &c->stats_buf, c->stats_buf_n);
@@ -1565,16 +1562,82 @@ int mp_window_stats(mp_ctx *c, int64_t *freq, int64_t *nn) {
     const int bands = m.ny_pad >= 8 ? 1 : 8 / m.ny_pad;
     m.per_band = (c->n_win + bands - 1) / bands;
     const unsigned grid = m.ny_pad >= 8 ? (unsigned)((size_t)c->n_win * m.ny_pad) : (unsigned)(8 * (size_t)m.per_band);
-    if ((rc = ensure_patch_planes(c))) return rc;
     StatsArgs sa{c->cols, c->excl, nw, c->p0, c->k, c->v, m, d, d + n_f, patch_args(c, GW, c->n_win, kBlock)};
     const dim3 full(grid + (unsigned)sa.patch.n_blocks);
     if (GW == 4) hipLaunchKernelGGL(window_stats_kernel<4>, full, dim3(kBlock), 0, c->stream, sa);
     else if (GW == 2) hipLaunchKernelGGL(window_stats_kernel<2>, full, dim3(kBlock), 0, c->stream, sa);
     else hipLaunchKernelGGL(window_stats_kernel<1>, full, dim3(kBlock), 0, c->stream, sa);
     HIPCK(c, hipGetLastError());
+    return MP_OK;
+}
+
+int mp_window_stats(mp_ctx *c, int64_t *freq, int64_t *nn) {
+    if (!c) return MP_ERR_ARG;
+    if (!c->excl) return fail(c, MP_ERR_ARG, "no windows built");
+    if (!freq || !nn) return fail(c, MP_ERR_ARG, "null output");
+    HIPCK(c, hipSetDevice(c->dev));
+    int rc;
+    if ((rc = ensure_patch_planes(c))) return rc;
+    size_t n_f = 0, n_t = 0;
+    if ((rc = window_stats_launch(c, n_f, n_t))) return rc;
+    unsigned long long *d = c->stats_buf;
     HIPCK(c, hipMemcpyAsync(freq, d, sizeof(int64_t) * n_f, hipMemcpyDeviceToHost, c->stream));
     HIPCK(c, hipMemcpyAsync(nn, d + n_f, sizeof(int64_t) * n_t, hipMemcpyDeviceToHost, c->stream));
     HIPCK(c, hipStreamSynchronize(c->stream));
+    return MP_OK;
+}
+
+// [r6] The same in two halves, for a caller that has something else to put on the device's copy engines meanwhile — the streamed planning
+// (mp_plan_create_streamed) reads 50-100 MB of histogram entries back while the statistics kernel (2.8 ms at 10^6 rows) runs: begin
+// launches the kernel and the read-back of its counters into a registered buffer of the context on the SECOND stream and returns at once;
+// end waits for them and hands the counters over.  mp_plan_create_streamed calls end itself (before its planners read a counter) when a
+// begin is pending and is given the arrays the counters belong in.
+int mp_window_stats_begin(mp_ctx *c) {
+    if (!c) return MP_ERR_ARG;
+    if (!c->excl) return fail(c, MP_ERR_ARG, "no windows built");
+    HIPCK(c, hipSetDevice(c->dev));
+    int rc;
+    if ((rc = ensure_patch_planes(c))) return rc;                      // (on the first stream)
+    if (!c->alt_stream) HIPCK(c, hipStreamCreateWithFlags(&c->alt_stream, hipStreamNonBlocking));
+    if (!c->stats_ev) HIPCK(c, hipEventCreateWithFlags(&c->stats_ev, hipEventDisableTiming));
+    // the second stream starts behind everything the first has queued so far (planes, windows, patch planes)
+    HIPCK(c, hipEventRecord(c->stats_ev, c->stream));
+    HIPCK(c, hipStreamWaitEvent(c->alt_stream, c->stats_ev, 0));
+    const size_t W = (size_t)c->n_win, k = (size_t)c->k, n = W * 4 * k + W * (k - 1) * 16, bytes = sizeof(int64_t) * n;
+    if (c->h_stats_bytes < bytes) {
+        if (c->h_stats) { if (c->h_stats_pinned) (void)hipHostUnregister(c->h_stats); host_unmap(c->h_stats, c->h_stats_bytes); }
+        c->h_stats_pinned = false; c->h_stats_bytes = 0;
+        const size_t room = (bytes + ((size_t)2 << 20) - 1) / ((size_t)2 << 20) * ((size_t)2 << 20);
+        c->h_stats = static_cast<uint8_t *>(host_map(room));
+        if (!c->h_stats) return fail(c, MP_ERR_NOMEM, "mp_window_stats_begin: out of host memory");
+        c->h_stats_bytes = room;
+        prefault_host(c->h_stats, room);
+        if (!getenv("MP_NO_PIN") && hipHostRegister(c->h_stats, room, hipHostRegisterDefault) == hipSuccess) c->h_stats_pinned = true;
+        else (void)hipGetLastError();
+    }
+    hipStream_t keep = c->stream;
+    c->stream = c->alt_stream;
+    size_t n_f = 0, n_t = 0;
+    rc = window_stats_launch(c, n_f, n_t);
+    hipError_t e = hipSuccess;
+    if (rc == MP_OK) e = hipMemcpyAsync(c->h_stats, c->stats_buf, bytes, hipMemcpyDeviceToHost, c->stream);
+    if (rc == MP_OK && e == hipSuccess) e = hipEventRecord(c->stats_ev, c->stream);
+    c->stream = keep;
+    if (rc) return rc;
+    if (e != hipSuccess) return fail(c, MP_ERR_DEVICE, "mp_window_stats_begin: %s", hipGetErrorString(e));
+    c->stats_pending_f = n_f; c->stats_pending_t = n_t;
+    return MP_OK;
+}
+
+int mp_window_stats_end(mp_ctx *c, int64_t *freq, int64_t *nn) {
+    if (!c) return MP_ERR_ARG;
+    if (!c->stats_pending_f) return fail(c, MP_ERR_ARG, "mp_window_stats_end: no mp_window_stats_begin is pending");
+    if (!freq || !nn) return fail(c, MP_ERR_ARG, "null output");
+    HIPCK(c, hipSetDevice(c->dev));
+    HIPCK(c, hipEventSynchronize(c->stats_ev));
+    memcpy(freq, c->h_stats, sizeof(int64_t) * c->stats_pending_f);
+    memcpy(nn, c->h_stats + sizeof(int64_t) * c->stats_pending_f, sizeof(int64_t) * c->stats_pending_t);
+    c->stats_pending_f = c->stats_pending_t = 0;
     return MP_OK;
 }
 

@@ -1242,6 +1242,21 @@ int unique_rep_rows(mp_ctx *c, int64_t cap, int32_t want_labels, int64_t *n_entr
 }  // namespace
 
 namespace {
+// [r6] A band of histogram entries into the registered staging area of the host BY A KERNEL (stores over the link): its five pieces —
+// three word arrays, counts, first rows — in one launch.  The copy engine charges ~50-70 us per hipMemcpyAsync whatever its size; 14 bands
+// x 5 arrays were 70 copies of ~0.7 MB, 5 ms for 49 MB that cross the link in ~1.5.
+struct D2hSeg { const uint32_t *src; uint32_t *dst; unsigned long long n; };       // n 32-bit words
+struct D2hArgs { D2hSeg seg[5]; };
+__global__ __launch_bounds__(kBlock) void d2h_band_kernel(const D2hArgs A) {
+    const unsigned long long stride = (unsigned long long)gridDim.x * kBlock;
+#pragma unroll
+    for (int q = 0; q < 5; q++) {
+        const uint32_t *__restrict__ src = A.seg[q].src;
+        uint32_t *__restrict__ dst = A.seg[q].dst;
+        for (unsigned long long i = (unsigned long long)blockIdx.x * kBlock + threadIdx.x; i < A.seg[q].n; i += stride) dst[i] = src[i];
+    }
+}
+
 __global__ __launch_bounds__(kBlock) void gather_labels_kernel(const int32_t *__restrict__ labels, const int32_t *__restrict__ windows, int n,
                                                                int n_rows, int n_pad, int32_t *__restrict__ out) {
     const long long total = (long long)n * n_rows;
@@ -1383,8 +1398,12 @@ int mp_plan_create_streamed(mp_ctx *c, const mp_plan_params *params, int64_t row
     struct SpanI { int32_t *p; int32_t *get() const { return p; } int32_t &operator[](size_t i) const { return p[i]; } };
     const Span words{c->h_stage};
     const SpanI count{reinterpret_cast<int32_t *>(c->h_stage + words_bytes)}, first{reinterpret_cast<int32_t *>(c->h_stage + words_bytes) + (n + 1)};
+    if (!in_order && c->stats_pending_f) {             // (no band copies to hide the statistics behind on this route)
+        int rc = mp_window_stats_end(c, const_cast<int64_t *>(freq), const_cast<int64_t *>(nn));
+        if (rc) return rc;
+    }
     if (!in_order) {
-        // the k >= 22 histograms reserve their segments in completion order: one blocking read-back that lays them out by window
+        // the k >= 32 histograms reserve their segments in completion order: one blocking read-back that lays them out by window
         int rc = mp_get_unique(c, e_off.data(), words.get(), count.get(), first.get());
         if (rc) return rc;
         return mp_plan_create_segments(params, e_off.data(), words.get(), count.get(), first.get(), row_base, n_exc, x_window, x_row, x_codes, freq, nn, out);
@@ -1394,40 +1413,87 @@ int mp_plan_create_streamed(mp_ctx *c, const mp_plan_params *params, int64_t row
     if (trace) fprintf(stderr, "[mprime] plan_streamed: staging area ready at %.3f ms\n", ms_since());
     std::thread copier([&]() {
         hipError_t e = hipSetDevice(c->dev);
+        bool stats_owed = c->stats_pending_f != 0;     // [r6] mp_window_stats_begin is pending: its counters land in freq / nn before a planner may read them
         // bands of whole windows: two small ones so that the planners start early, then a sixth (a twelfth when the area is registered)
         // of the entries each — a band is five copies and every copy through the runtime's staging buffers has ~50 us of its own
         // (24 bands took 6 ms for 58 MB that cross in 1.1 ms as one piece)
         const size_t target = std::max<size_t>(n / (c->h_stage_pinned ? 12 : 6), 65536);
-        size_t w0 = 0;
-        int band = 0;
-        while (w0 < W) {
+        // [r6] with a registered staging area every copy is a DMA the runtime only queues: ALL bands' copies are queued up front, an event
+        // behind each band, and this thread then waits for the events in turn — the copy engine runs back to back (rounds 4-5 queued a band,
+        // waited for it, queued the next: ~0.1 ms of idle engine between the 14 bands).  Unregistered (staged) copies keep that order: each
+        // of them blocks in the runtime anyway.
+        struct Band { size_t w1, a, m; hipEvent_t ev; };
+        std::vector<Band> bands;
+        for (size_t w0 = 0; w0 < W;) {
             size_t w1 = w0 + 1;
-            const size_t want = band < 2 ? target / 8 : target;
+            const size_t want = bands.size() < 2 ? target / 8 : target;
             while (w1 < W && (size_t)(e_off[w1] - e_off[w0]) < want) w1++;
-            const size_t a = (size_t)e_off[w0], m = (size_t)(e_off[w1] - e_off[w0]);
-            if (m && e == hipSuccess) {
-                e = hipMemcpyAsync(words.get() + wb * a, reinterpret_cast<const uint8_t *>(c->u_b0) + wb * a, wb * m, hipMemcpyDeviceToHost, c->stream);
-                if (e == hipSuccess) e = hipMemcpyAsync(words.get() + wb * (n + a), reinterpret_cast<const uint8_t *>(c->u_b1) + wb * a, wb * m, hipMemcpyDeviceToHost, c->stream);
-                if (e == hipSuccess) e = hipMemcpyAsync(words.get() + wb * (2 * n + a), reinterpret_cast<const uint8_t *>(c->u_g) + wb * a, wb * m, hipMemcpyDeviceToHost, c->stream);
-                if (e == hipSuccess) e = hipMemcpyAsync(count.get() + a, c->u_count + a, 4 * m, hipMemcpyDeviceToHost, c->stream);
-                if (e == hipSuccess) e = hipMemcpyAsync(first.get() + a, c->u_first + a, 4 * m, hipMemcpyDeviceToHost, c->stream);
-                if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+            bands.push_back(Band{w1, (size_t)e_off[w0], (size_t)(e_off[w1] - e_off[w0]), nullptr});
+            w0 = w1;
+        }
+        // the staging area as the device sees it (registered memory is mapped): the band kernel stores straight into it
+        uint8_t *dev_stage = nullptr;
+        // (measured equal to the copy engine within the noise of a box — 10^6 rows, 49 MB: planning 5.1-6.9 ms against 4.9-5.6 — so it is opt-in:
+        // MP_PLAN_D2H_KERNEL=1; what slows the read-back at that depth is the host side, 96 planning threads on the same memory)
+        if (c->h_stage_pinned && getenv("MP_PLAN_D2H_KERNEL") && hipHostGetDevicePointer((void **)&dev_stage, c->h_stage, 0) != hipSuccess) { (void)hipGetLastError(); dev_stage = nullptr; }
+        auto queue_band = [&](Band &B) {
+            const size_t a = B.a, m = B.m;
+            if (!m || e != hipSuccess) return;
+            if (dev_stage) {
+                const size_t ww = wb / 4;                                  // 32-bit units per window word
+                auto at = [&](const void *host) { return reinterpret_cast<uint32_t *>(dev_stage + (static_cast<const uint8_t *>(host) - c->h_stage)); };
+                D2hArgs A;
+                A.seg[0] = D2hSeg{reinterpret_cast<const uint32_t *>(c->u_b0) + ww * a, at(words.get() + wb * a), (unsigned long long)(ww * m)};
+                A.seg[1] = D2hSeg{reinterpret_cast<const uint32_t *>(c->u_b1) + ww * a, at(words.get() + wb * (n + a)), (unsigned long long)(ww * m)};
+                A.seg[2] = D2hSeg{reinterpret_cast<const uint32_t *>(c->u_g) + ww * a, at(words.get() + wb * (2 * n + a)), (unsigned long long)(ww * m)};
+                A.seg[3] = D2hSeg{reinterpret_cast<const uint32_t *>(c->u_count) + a, at(count.get() + a), (unsigned long long)m};
+                A.seg[4] = D2hSeg{reinterpret_cast<const uint32_t *>(c->u_first) + a, at(first.get() + a), (unsigned long long)m};
+                const unsigned blocks = (unsigned)std::min<size_t>((ww * m + kBlock - 1) / kBlock, 2048);
+                hipLaunchKernelGGL(d2h_band_kernel, dim3(std::max(1u, blocks)), dim3(kBlock), 0, c->stream, A);
+                e = hipGetLastError();
+                return;
             }
+            e = hipMemcpyAsync(words.get() + wb * a, reinterpret_cast<const uint8_t *>(c->u_b0) + wb * a, wb * m, hipMemcpyDeviceToHost, c->stream);
+            if (e == hipSuccess) e = hipMemcpyAsync(words.get() + wb * (n + a), reinterpret_cast<const uint8_t *>(c->u_b1) + wb * a, wb * m, hipMemcpyDeviceToHost, c->stream);
+            if (e == hipSuccess) e = hipMemcpyAsync(words.get() + wb * (2 * n + a), reinterpret_cast<const uint8_t *>(c->u_g) + wb * a, wb * m, hipMemcpyDeviceToHost, c->stream);
+            if (e == hipSuccess) e = hipMemcpyAsync(count.get() + a, c->u_count + a, 4 * m, hipMemcpyDeviceToHost, c->stream);
+            if (e == hipSuccess) e = hipMemcpyAsync(first.get() + a, c->u_first + a, 4 * m, hipMemcpyDeviceToHost, c->stream);
+        };
+        const bool ahead = c->h_stage_pinned && !getenv("MP_PLAN_NO_AHEAD");
+        if (ahead)
+            for (Band &B : bands) {
+                queue_band(B);
+                if (e == hipSuccess) e = hipEventCreateWithFlags(&B.ev, hipEventDisableTiming);
+                if (e == hipSuccess) e = hipEventRecord(B.ev, c->stream);
+            }
+        int band = 0;
+        for (Band &B : bands) {
+            if (ahead) { if (e == hipSuccess && B.ev) e = hipEventSynchronize(B.ev); }
+            else { queue_band(B); if (e == hipSuccess) e = hipStreamSynchronize(c->stream); }
+            const size_t a = B.a, m = B.m, w1 = B.w1;
             if (e != hipSuccess) {                       // the planners must not wait for ever: hand them zeroed entries, the result is thrown away
                 copy_error.store((int)e);
                 memset(words.get() + wb * a, 0, wb * m); memset(words.get() + wb * (n + a), 0, wb * m); memset(words.get() + wb * (2 * n + a), 0, wb * m);
                 for (size_t i = a; i < a + m; i++) { count[i] = 1; first[i] = 0; }
             }
+            if (stats_owed) {
+                stats_owed = false;
+                if (mp_window_stats_end(c, const_cast<int64_t *>(freq), const_cast<int64_t *>(nn)) != MP_OK) copy_error.store((int)hipErrorUnknown);
+                if (trace) fprintf(stderr, "[mprime] plan_streamed: window statistics there at %.3f ms\n", ms_since());
+            }
             ready.raise((int)w1);
             if (trace && (band < 3 || w1 == W)) fprintf(stderr, "[mprime] plan_streamed: band %d (windows < %zu) there at %.3f ms\n", band, w1, ms_since());
-            w0 = w1;
             band++;
         }
+        if (e != hipSuccess) (void)hipStreamSynchronize(c->stream);      // (queued copies must not outlive the buffers)
+        for (Band &B : bands) if (B.ev) (void)hipEventDestroy(B.ev);
+        if (trace) fprintf(stderr, "[mprime] plan_streamed: %zu entries, %.1f MB in %zu bands\n", n, (double)(3 * wb + 8) * (double)n / 1e6, bands.size());
     });
     int rc = mp_plan_create_segments_ready(params, e_off.data(), words.get(), count.get(), first.get(), row_base, n_exc, x_window, x_row, x_codes, freq, nn,
                                            &ready, c->h_wskip.empty() ? nullptr : c->h_wskip.data(), out);
     if (trace) fprintf(stderr, "[mprime] plan_streamed: planning done at %.3f ms\n", ms_since());
     copier.join();
+    if (c->stats_pending_f) (void)mp_window_stats_end(c, const_cast<int64_t *>(freq), const_cast<int64_t *>(nn));      // (no window at all: nobody asked)
     if (trace) fprintf(stderr, "[mprime] plan_streamed: returning at %.3f ms\n", ms_since());
     if (copy_error.load()) {
         if (*out) { mp_plan_destroy(*out); *out = nullptr; }

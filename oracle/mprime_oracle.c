@@ -555,6 +555,8 @@ int mp_eval_launch(mp_ctx *c, int64_t *out) {
     return eval_all(c, c->n_cand, c->cand_win, c->cand_codes, c->sF, c->sR, out);
 }
 
+int mp_window_stats_begin(mp_ctx *c) { return c ? MP_OK : MP_ERR_ARG; }                  /* (nothing runs beside anything here) */
+int mp_window_stats_end(mp_ctx *c, int64_t *freq, int64_t *nn) { return mp_window_stats(c, freq, nn); }
 int mp_eval_launch_alt(mp_ctx *c, int64_t *out) { return mp_eval_launch(c, out); }      /* (one "stream": the calling thread) */
 int mp_eval_sync(mp_ctx *c) { return c ? MP_OK : MP_ERR_ARG; }
 
