@@ -121,5 +121,7 @@ final)           # everything the round's profiles/ files come from, in the orde
   du -sh $O; rm -rf $O/prof_pipe_* $O/prof_1m/pmc_* $O/prof_131k/pmc_* $O/prof_1m/cal_* $O/prof_131k/cal_* $O/prof_side ;;
 soak)            # profiles/r06_soak.txt: randomised HIP-vs-oracle soaks through every kernel setting (incl. hist2 / hist / rep-rows, eval_chain_x shapes, v <= 5)
   (timeout 500 python tools/soak_parity.py --seconds ${1:-240} --seed 61; timeout 200 python tools/soak_parity.py --seconds 60 --seed 62; timeout 200 python tools/soak_primers.py --seconds 45) 2>&1 | tee $O/soak.txt ;;
+side_counters)   # profiles/r06_side_kernels.json (+ .txt): kernel trace and FETCH_SIZE / WRITE_SIZE passes of tools/side_bench.py, per kernel
+  python tools/side_counters.py --out $O 2>&1 | tee $O/side_kernels_counters.txt ;;
 *) echo "unknown target $T"; exit 2 ;;
 esac
