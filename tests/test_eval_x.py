@@ -88,3 +88,49 @@ def test_chain_x_kernel_equals_oracle_and_row_kernels(hip_lib, oracle_lib, monke
     finally:
         h.close()
         o.close()
+
+
+@pytest.mark.parametrize("n,k,v", [(5000, 18, 1), (300000, 18, 1), (20000, 36, 2)])
+def test_launches_on_the_second_stream_equal_the_first(hip_lib, oracle_lib, n, k, v):
+    """mp_eval_launch_alt: evaluations of one staged set alternately on the context's two streams into different counter blocks, twice
+    each — every block equals the oracle's counters; the first launch of a staged set must be mp_eval_launch; mp_window_stats_begin /
+    _end (the second stream's other user) give mp_window_stats' tables."""
+    from multiprime_amd._abi import MprimeError
+    data, off, maxlen = fuzz_msa(40 + k, min(n, 20000), 90, False, p_iupac=0.0)
+    if n > 20000:                                                   # deep: the sliding kernel's size
+        reps = n // 20000
+        rows = data.reshape(-1, 90)
+        data = np.tile(rows, (reps, 1)).reshape(-1)
+        off = np.arange(reps * rows.shape[0] + 1, dtype=np.int64) * 90
+    h, o = both(hip_lib, oracle_lib, data, off)
+    try:
+        W = maxlen - k - 2
+        assert h.build_windows(2, W, k, v) == o.build_windows(2, W, k, v)
+        rng = np.random.default_rng(k)
+        rows_ascii = data[: 400 * 90].reshape(400, 90)
+        cw, codes = chain_candidates(rng, rows_ascii, 2, W, k, 8)
+        sF, sR = (1 << 2) | (1 << 3), (1 << (k - 2)) | (1 << 2)
+        want = o.eval_candidates(cw, codes, sF, sR)
+        h.set_stream(torch.cuda.current_stream().cuda_stream)
+        h.eval_upload(cw, codes, sF, sR)
+        blocks = torch.zeros((4, len(cw), 3), dtype=torch.int64, device="cuda")
+        with pytest.raises(MprimeError, match="first launch"):      # nothing has built the windows' patch planes yet: that is the first stream's job
+            h.eval_launch_alt(blocks[1].data_ptr())
+        fw, nw_ = o.window_stats()
+        f0, n0 = h.window_stats_begin()
+        h.window_stats_end(f0, n0)
+        assert np.array_equal(f0, fw) and np.array_equal(n0, nw_)
+        h.eval_launch(blocks[0].data_ptr())
+        h.eval_launch_alt(blocks[1].data_ptr())
+        h.eval_launch(blocks[2].data_ptr())
+        h.eval_launch_alt(blocks[3].data_ptr())
+        h.eval_launch(blocks[0].data_ptr())                        # a block is cleared by the launch that fills it
+        h.eval_launch_alt(blocks[1].data_ptr())
+        h.eval_sync()
+        torch.cuda.synchronize()
+        got = blocks.cpu().numpy()
+        for i in range(4):
+            assert np.array_equal(got[i], want), i
+    finally:
+        h.close()
+        o.close()
