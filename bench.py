@@ -62,8 +62,11 @@ sys.path.insert(0, REPO)
 sys.path.insert(0, os.path.join(REPO, "tools"))
 # the workload, the roofline arithmetic (tools/bench_common.py) and the side measurements that fill bench_detail.json (tools/bench_blocks.py);
 # this file keeps the contract: the timed region and the one line the driver parses
-from bench_common import (CONFIG4_CHECKSUM, FULL_ROWS, SHARD_ROWS, Workload, eval_mode, kernel_source_hash, roofline_block)  # noqa: E402,F401
-from bench_blocks import OracleBlocks, cpu_baseline, k_sweep, pipeline_block, run_variants, shard_shapes, weak_shard  # noqa: E402
+# (the names tests/ and tools/ use through `import bench` stay importable from here)
+from bench_common import (CONFIG4_CHECKSUM, FULL_ROWS, SHARD_ROWS, Workload, eval_mode, expand_exceptions, kernel_source_hash, load_json,  # noqa: E402,F401
+                          make_candidates, roofline_block, synth_rows, time_launches)
+from bench_blocks import (OracleBlocks, cpu_baseline, k_sweep, pipeline_block, python_reference_leg, run_variants, shard_shapes,  # noqa: E402,F401
+                          weak_shard)
 
 
 def main():
