@@ -2,8 +2,9 @@
 # Multi-GPU measurement in one go, for the day an 8-GPU MI355X node is at hand (none was in rounds 1-4: no scaling curve has been
 # measured).  Run from the repository root on the node:
 #   tools/scale_run.sh [out_dir]
-# 1. bench.py at N = 1, 2, 4, 8 — config 4 (1 048 576 x 1000) split over the GPUs (strong scaling), one RCCL all-reduce per step;
-#    each line carries `comm.rccl_ranks_seen` (what the library's own communicator reports) and the per-rank step time min / max.
+# 1. bench.py at N = 1, 2, 4, 8 — config 4 (1 048 576 x 1000) split over the GPUs (strong scaling; [r6] default shape 1 x N: window groups, every GPU
+#    holds every row, no collective — add `--shape Nx1` for row shards with one RCCL all-reduce per step); each line carries
+#    `comm.rccl_ranks_seen` (what the library's own communicator reports), the per-rank step time min / max and `parity_checked` (checksum == N = 1).
 # 2. config 5: the 64-cluster chain (tools/multi_cluster.py), clusters spread over 8 ranks, with --check on 16 smaller clusters.
 # 3. the drop-in CLI on one deep alignment, rows sharded over 8 GPUs (--ngpu 8), against the one-GPU run: files must be identical.
 set -u
