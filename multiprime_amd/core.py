@@ -595,33 +595,40 @@ class NN_degenerate(object):
         n_out = len(positions)
         codes = np.ascontiguousarray(codes, np.uint8).reshape(n_out, k)      # the output primers as 4-bit base sets (what MASK_LUT gives of their strings)
         t_all = t0 = time.time()
-        self.ctx.eval_masks_resident(wins, codes, self._sF, self._sR)
+        # the launch (a device call: no interpreter lock held) on a thread of its own, the IUPAC rows' verdicts (native host code) on this one:
+        # the two meet at mp_masks_set_bits  [r6: they ran one after the other, 1.2-1.5 + 2.3 ms at 10^6 rows]
+        launch = _Beside(self.ctx.eval_masks_resident, wins, codes, self._sF, self._sR, beside=self.comm is None)
+        try:
+            self.mask_index = {int(pos): i for i, pos in enumerate(positions)}
+            # rows whose window held an IUPAC code: every expansion must be reached (V20:701-707 puts the id under each
+            # expansion's k-mer), gap-type ones are in gap_seq_id.  Vectorised over all (exception, expansion) pairs.
+            ex_w, x_row, ex_codes = self._exc
+            patch = None
+            if len(ex_w) and n_out:
+                row0 = self.comm.row0 if self.comm is not None else 0
+                slot_of = np.full(self.n_windows, -1, np.int64)
+                slot_of[wins] = np.arange(n_out)
+                mask_i = slot_of[ex_w]
+                r_loc = x_row - row0
+                sel = (mask_i >= 0) & (r_loc >= 0) & (r_loc < self.ctx.n_rows)
+                if sel.any():
+                    mask_i, r_loc, xc = mask_i[sel], r_loc[sel], ex_codes[sel]
+                    # Verdict of an exception row = the OR over its expansions of "not perfectly matched and (more than v mismatches or a
+                    # mismatch at a strict position)" (V20:701-707 puts the id under every expansion's k-mer, V20:1107-1127).  The
+                    # expansions need not be listed for that: position j CAN mismatch when it is '-' or when some member of the row's
+                    # symbol lies outside the primer's; the expansion that takes a mismatching member wherever there is one has the most
+                    # mismatches, so the row is bad when that count exceeds v, or else when a strict position can mismatch at all.
+                    n_x = len(mask_i)
+                    bad = host.exception_verdicts(xc, mask_i, codes, v, self._sF, self._sR)         # native, a few threads (mp_exception_verdicts)
+                    self._lap("bitsets: exception verdicts (%d)" % n_x)
+                    patch = (np.repeat(mask_i, 2), np.repeat(r_loc, 2), np.tile(np.array([0, 1], np.uint8), n_x), bad.reshape(-1).astype(np.uint8))
+        finally:
+            launch.wait_quietly() if sys.exc_info()[0] is not None else launch.join()
         self.stats["bitsets_masks_s"] = time.time() - t0
-        self._lap("bitsets: eval_masks_resident")
-        self.mask_index = {int(pos): i for i, pos in enumerate(positions)}
-        # rows whose window held an IUPAC code: every expansion must be reached (V20:701-707 puts the id under each
-        # expansion's k-mer), gap-type ones are in gap_seq_id.  Vectorised over all (exception, expansion) pairs.
-        ex_w, x_row, ex_codes = self._exc
-        if len(ex_w) and n_out:
-            row0 = self.comm.row0 if self.comm is not None else 0
-            slot_of = np.full(self.n_windows, -1, np.int64)
-            slot_of[wins] = np.arange(n_out)
-            mask_i = slot_of[ex_w]
-            r_loc = x_row - row0
-            sel = (mask_i >= 0) & (r_loc >= 0) & (r_loc < self.ctx.n_rows)
-            if sel.any():
-                mask_i, r_loc, xc = mask_i[sel], r_loc[sel], ex_codes[sel]
-                # Verdict of an exception row = the OR over its expansions of "not perfectly matched and (more than v mismatches or a
-                # mismatch at a strict position)" (V20:701-707 puts the id under every expansion's k-mer, V20:1107-1127).  The
-                # expansions need not be listed for that: position j CAN mismatch when it is '-' or when some member of the row's
-                # symbol lies outside the primer's; the expansion that takes a mismatching member wherever there is one has the most
-                # mismatches, so the row is bad when that count exceeds v, or else when a strict position can mismatch at all.
-                n_x = len(mask_i)
-                bad = host.exception_verdicts(xc, mask_i, codes, v, self._sF, self._sR)         # native, a few threads (mp_exception_verdicts)
-                self._lap("bitsets: exception verdicts (%d)" % n_x)
-                self.ctx.masks_set_bits(np.repeat(mask_i, 2), np.repeat(r_loc, 2), np.tile(np.array([0, 1], np.uint8), n_x),
-                                        bad.reshape(-1).astype(np.uint8))
-                self._lap("bitsets: masks_set_bits")
+        self._lap("bitsets: eval_masks_resident (beside the verdicts)")
+        if patch is not None:
+            self.ctx.masks_set_bits(*patch)
+            self._lap("bitsets: masks_set_bits")
         self.stats["bitsets_s"] = time.time() - t_all
 
     def _write_bitsets(self, rows_out):
