@@ -193,9 +193,25 @@ int mp_primer_filters(int32_t k, int64_t n, const uint8_t *codes, const double *
 int mp_exception_verdicts(int32_t k, int32_t v, int64_t n, const uint8_t *xc, const int64_t *primer_of, int64_t n_primers, const uint8_t *primers,
                           uint64_t strictF, uint64_t strictR, uint8_t *bad);
 
+/* (H5b) the verdicts of (H5) as the assignments mp_masks_set_bits (mprime.h) takes, the selection included (core.py _resident_bitsets: the
+ * numpy selection + repeat / tile around mp_exception_verdicts cost 2.5 ms at 10^6 rows beside 0.1 ms of verdicts).  Of the n exception rows
+ * (window x_window[i] < n_windows, global row x_row[i], codes xc[i*k ..)) those with slot_of[x_window[i]] >= 0 (the window's output row; its
+ * primer is primers[slot*k ..), slot < n_primers) and row0 <= x_row[i] < row0 + n_rows give two assignments each, in exception order:
+ * cand = slot, row = x_row[i] - row0, which = 0 / 1 (forward / reverse), value = the verdict.  The four outputs hold 2n entries;
+ * *n_out = entries written. */
+int mp_exception_assignments(int32_t k, int32_t v, int64_t n, const int32_t *x_window, const int64_t *x_row, const uint8_t *xc, int32_t n_windows,
+                             const int32_t *slot_of, int64_t row0, int64_t n_rows, int64_t n_primers, const uint8_t *primers, uint64_t strictF,
+                             uint64_t strictR, int32_t *cand, int32_t *row, uint8_t *which, uint8_t *value, int64_t *n_out);
+
 /* The same expansions as window words (b0, b1, g of mprime.h, three per expansion) — what mp_set_extra_rows takes. */
 int mp_expand_kmer_words(int32_t k, int64_t n, const uint8_t *codes, int64_t cap, void *out_words, int64_t *out_src,
                          int64_t *n_out);
+/* [r6] The same for the exception list of mp_get_exceptions as it stands: rows with more than v gaps (code 0) are dropped — they are
+ * gap_sequence entries, not k-mers (V20:689-707) —, every expansion comes with its row's window x_window[i] instead of the row index:
+ * (out_window, out_words) is what mp_set_extra_rows takes (core.py did the selection and the indexing in numpy: 4.7 ms of a helper
+ * thread's 8 at 10^6 rows).  MP_ERR_CAPACITY with *n_out = the expansions there are when cap is too small. */
+int mp_expand_exception_words(int32_t k, int32_t v, int64_t n, const int32_t *x_window, const uint8_t *codes, int64_t cap, void *out_words,
+                              int32_t *out_window, int64_t *n_out);
 
 #ifdef __cplusplus
 }

@@ -230,22 +230,22 @@ class NN_degenerate(object):
         # back in bands of windows beside its own work (mp_plan_create_streamed; MP_PLAN_STREAM=0 keeps the two blocking calls)
         streamed = (self.comm is None and not self.write_json and self.lib.backend == "hip" and os.environ.get("MP_PLAN_STREAM", "1") != "0"
                     and host.serves_device_library(self.lib))
-
         def exceptions_on_the_host():
             """The window k-mers that hold an IUPAC code, and the concrete expansions of those with <= v gaps (V20:701-707) as window words:
             pure host work on the list mp_build_windows left in the context."""
+            t_h = [time.time()]
             ex_w, ex_r, ex_codes = self.ctx.get_exceptions(n_ex)
+            t_h.append(time.time())
             extra = None
             if n_ex:
-                gaps = ex_codes == 0
-                if gaps.any():
-                    sel = gaps.sum(axis=1) <= v
-                    x_codes, x_win = ex_codes[sel], ex_w[sel]
-                else:                                       # (the usual case: an IUPAC code, no gap in the window)
-                    x_codes, x_win = ex_codes, ex_w
+                # rows with more than v gaps are gap_sequence entries, the others expand (selection, expansion and the windows of the
+                # expansions in one native call  [r6: the numpy selection around mp_expand_kmer_words took 4.4 ms of this thread's 8 at 10^6 rows])
+                x_win, words = host.expand_exception_words(ex_w, ex_codes, v)
                 if len(x_win):
-                    words, src = host.expand_kmer_words(x_codes)
-                    extra = (x_win[src], words)
+                    extra = (x_win, words)
+            if _TRACE_PY:
+                t_h.append(time.time())
+                print("[core] exception list: " + " ".join("%.3f" % ((b - a) * 1e3) for a, b in zip(t_h, t_h[1:])) + " ms (get, expand)", file=sys.stderr)
             return ex_w, ex_r, ex_codes, extra
 
         early_unique = False
@@ -287,6 +287,8 @@ class NN_degenerate(object):
         # state_matrix / trans_matrix of every window (V20:541-577) straight from the column planes; shards add up.  The streamed planning
         # of a single process starts the kernel only (mp_window_stats_begin, second stream): its read-back of the histogram entries runs
         # beside it, and mp_plan_create_streamed collects the counters before a planner reads one
+        # ([r6] tried: the column planes' half of the kernel queued right after mp_build_windows, beside the histograms — the planners start
+        # 1.3 ms earlier, the histogram kernels end 1.7 ms later and the bands arrive later: no gain, not kept)
         stats_beside = streamed and self.comm is None and os.environ.get("MP_STATS_BESIDE", "1") != "0"
         if stats_beside:
             self._freq, self._nn = self.ctx.window_stats_begin()
@@ -605,23 +607,20 @@ class NN_degenerate(object):
             ex_w, x_row, ex_codes = self._exc
             patch = None
             if len(ex_w) and n_out:
+                # Verdict of an exception row = the OR over its expansions of "not perfectly matched and (more than v mismatches or a
+                # mismatch at a strict position)" (V20:701-707 puts the id under every expansion's k-mer, V20:1107-1127).  The
+                # expansions need not be listed for that: position j CAN mismatch when it is '-' or when some member of the row's
+                # symbol lies outside the primer's; the expansion that takes a mismatching member wherever there is one has the most
+                # mismatches, so the row is bad when that count exceeds v, or else when a strict position can mismatch at all.
+                # Selection (output windows, this shard's rows), verdicts and the assignment layout in one native call  [r6: the numpy
+                # selection and repeat / tile around the verdicts took 2.5 ms at 10^6 rows]
                 row0 = self.comm.row0 if self.comm is not None else 0
-                slot_of = np.full(self.n_windows, -1, np.int64)
-                slot_of[wins] = np.arange(n_out)
-                mask_i = slot_of[ex_w]
-                r_loc = x_row - row0
-                sel = (mask_i >= 0) & (r_loc >= 0) & (r_loc < self.ctx.n_rows)
-                if sel.any():
-                    mask_i, r_loc, xc = mask_i[sel], r_loc[sel], ex_codes[sel]
-                    # Verdict of an exception row = the OR over its expansions of "not perfectly matched and (more than v mismatches or a
-                    # mismatch at a strict position)" (V20:701-707 puts the id under every expansion's k-mer, V20:1107-1127).  The
-                    # expansions need not be listed for that: position j CAN mismatch when it is '-' or when some member of the row's
-                    # symbol lies outside the primer's; the expansion that takes a mismatching member wherever there is one has the most
-                    # mismatches, so the row is bad when that count exceeds v, or else when a strict position can mismatch at all.
-                    n_x = len(mask_i)
-                    bad = host.exception_verdicts(xc, mask_i, codes, v, self._sF, self._sR)         # native, a few threads (mp_exception_verdicts)
-                    self._lap("bitsets: exception verdicts (%d)" % n_x)
-                    patch = (np.repeat(mask_i, 2), np.repeat(r_loc, 2), np.tile(np.array([0, 1], np.uint8), n_x), bad.reshape(-1).astype(np.uint8))
+                slot_of = np.full(self.n_windows, -1, np.int32)
+                slot_of[wins] = np.arange(n_out, dtype=np.int32)
+                got = host.exception_assignments(ex_w, x_row, ex_codes, slot_of, row0, self.ctx.n_rows, codes, v, self._sF, self._sR)
+                self._lap("bitsets: exception verdicts (%d)" % (len(got[0]) // 2))
+                if len(got[0]):
+                    patch = got
         finally:
             launch.wait_quietly() if sys.exc_info()[0] is not None else launch.join()
         self.stats["bitsets_masks_s"] = time.time() - t0

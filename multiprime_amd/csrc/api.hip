@@ -104,6 +104,10 @@ void free_unique(mp_ctx *c) {
 }
 
 void free_windows(mp_ctx *c) {
+    {   // (exception records nobody collected go with their windows)
+        std::lock_guard<std::mutex> lock(c->ex_mu);
+        c->ex_pending = 0;
+    }
     free_eval(c);
     dev_free(c, &c->mask_f, c->mask_words); dev_free(c, &c->mask_r, c->mask_words);
     c->mask_words = 0; c->n_masks = 0;
@@ -290,6 +294,8 @@ void mp_destroy(mp_ctx *c) {
     (void)hipSetDevice(c->dev);
     (void)hipDeviceSynchronize();
     if (c->alt_stream) (void)hipStreamDestroy(c->alt_stream);
+    if (c->ex_stream) (void)hipStreamDestroy(c->ex_stream);
+    if (c->h_ex) { if (c->h_ex_pinned) (void)hipHostUnregister(c->h_ex); host_unmap(c->h_ex, c->h_ex_bytes); }
     free_comm(c);
     free_msa(c);
     free_seq(c);

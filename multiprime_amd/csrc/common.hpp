@@ -141,7 +141,16 @@ struct mp_ctx {
     mp::ExRec *ex = nullptr;
     int ex_cap = 0;
     int *ex_count = nullptr, *err_flag = nullptr;
-    std::vector<mp::ExRec> ex_host;
+    std::vector<mp::ExRec> ex_host;          // sorted by (window, row); complete only after ex_fetch()
+    // [r6] the records leave the device BESIDE the histogram launch: mp_build_windows only notes how many there are; whoever needs ex_host
+    // first — mp_get_exceptions on the caller's helper thread, the device gate's per-window counts (unique.hip) — copies them into h_ex
+    // (host_map, registered) on ex_stream and sorts: ex_fetch(), one at a time under ex_mu
+    uint8_t *h_ex = nullptr;
+    size_t h_ex_bytes = 0;
+    bool h_ex_pinned = false;
+    hipStream_t ex_stream = nullptr;
+    int ex_pending = 0;                      // records on the device (c->ex), not yet in ex_host
+    std::mutex ex_mu;
     int32_t *extra_off = nullptr;
     uint32_t *extra_words = nullptr;
     int n_extra = 0;
@@ -352,6 +361,7 @@ void host_unmap(void *p, size_t bytes);
 // a registration of memory owned by the Python allocator, without a message — not understood, so not shipped.
 
 // release the device arrays of one stage (and of every stage that depends on it); api.hip
+int ex_fetch(mp_ctx *c);         // windows.hip: ex_host complete (see mp_ctx::ex_pending)
 void free_eval(mp_ctx *c);
 void free_slide(mp_ctx *c);
 void free_comm(mp_ctx *c);

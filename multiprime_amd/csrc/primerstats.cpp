@@ -22,6 +22,7 @@
 #include <algorithm>
 #include <thread>
 #include <vector>
+#include <vector>
 
 namespace {
 
@@ -240,6 +241,88 @@ int mp_exception_verdicts(int32_t k, int32_t v, int64_t n, const uint8_t *xc, co
     if (const char *e = getenv("MP_HOST_THREADS")) n_thr = std::max(1, std::min(n_thr, atoi(e)));
     if (n_thr <= 1) { body(0, n); return MP_OK; }
     mp::run_on_threads(n_thr, [&](int t) { body(n * t / n_thr, n * (t + 1) / n_thr); });
+    return MP_OK;
+}
+
+// (H4b) mp_expand_kmer_words for the exception list as it comes from mp_get_exceptions: the rows with more than v gaps dropped (V20:701-707
+// expands only k-mers that stay in the universe), every expansion with its row's WINDOW — what mp_set_extra_rows takes.
+int mp_expand_exception_words(int32_t k, int32_t v, int64_t n, const int32_t *x_window, const uint8_t *codes, int64_t cap, void *out_words,
+                              int32_t *out_window, int64_t *n_out) {
+    if (k < 1 || k > kMaxLen || v < 0 || n < 0 || cap < 0 || !n_out || (n && (!x_window || !codes)) || (cap && (!out_words || !out_window))) return MP_ERR_ARG;
+    *n_out = 0;
+    std::vector<int64_t> keep;
+    keep.reserve((size_t)n);
+    for (int64_t i = 0; i < n; i++) {
+        const uint8_t *r = codes + (size_t)i * k;
+        int gaps = 0;
+        for (int j = 0; j < k; j++) gaps += r[j] == 0;
+        if (gaps <= v) keep.push_back(i);
+    }
+    const int64_t m = (int64_t)keep.size();
+    std::vector<uint8_t> some;
+    const uint8_t *sel = codes;
+    if (m != n) {
+        some.resize((size_t)m * k);
+        for (int64_t i = 0; i < m; i++) memcpy(some.data() + (size_t)i * k, codes + (size_t)keep[(size_t)i] * k, (size_t)k);
+        sel = some.data();
+    }
+    std::vector<int64_t> src((size_t)std::max<int64_t>(cap, 1));
+    const int rc = mp_expand_kmer_words(k, m, sel, cap, out_words, src.data(), n_out);
+    if (rc) return rc;                                           // (MP_ERR_CAPACITY: *n_out holds the expansions there are)
+    for (int64_t o = 0; o < *n_out; o++) out_window[o] = x_window[keep[(size_t)src[(size_t)o]]];
+    return MP_OK;
+}
+
+// (H5b) the same verdicts as assignments for mp_masks_set_bits, the selection included: of the n exception rows those whose window is an output
+// window (slot_of[window] >= 0) and whose row lies in [row0, row0 + n_rows) give two assignments each, in exception order — (output row, local
+// row, 0, forward verdict), (…, 1, reverse verdict).  Two passes over contiguous shares of the list (count, then write behind the shares before).
+int mp_exception_assignments(int32_t k, int32_t v, int64_t n, const int32_t *x_window, const int64_t *x_row, const uint8_t *xc, int32_t n_windows,
+                             const int32_t *slot_of, int64_t row0, int64_t n_rows, int64_t n_primers, const uint8_t *primers, uint64_t strictF,
+                             uint64_t strictR, int32_t *cand, int32_t *row, uint8_t *which, uint8_t *value, int64_t *n_out) {
+    if (k < 1 || k > kMaxLen || v < 0 || n < 0 || n_windows < 0 || n_rows < 0 || n_rows > 0x7fffffffLL || !n_out ||
+        (n && (!x_window || !x_row || !xc || !slot_of || !primers || !cand || !row || !which || !value)))
+        return MP_ERR_ARG;
+    *n_out = 0;
+    for (int32_t w = 0; w < n_windows; w++)
+        if (slot_of[w] >= n_primers) return MP_ERR_ARG;
+    for (int64_t i = 0; i < n; i++)
+        if (x_window[i] < 0 || x_window[i] >= n_windows) return MP_ERR_ARG;
+    auto taken = [&](int64_t i) { return slot_of[x_window[i]] >= 0 && x_row[i] >= row0 && x_row[i] - row0 < n_rows; };
+    int n_thr = n >= 16384 ? (int)std::min<int64_t>(16, std::min<int64_t>((int64_t)std::max(1u, std::thread::hardware_concurrency()), n / 8192)) : 1;
+    if (const char *e = getenv("MP_HOST_THREADS")) n_thr = std::max(1, std::min(n_thr, atoi(e)));
+    std::vector<int64_t> first((size_t)n_thr + 1, 0);
+    auto share = [&](int t, bool write) {
+        int64_t o = first[(size_t)t], found = 0;
+        for (int64_t i = n * t / n_thr, i1 = n * (t + 1) / n_thr; i < i1; i++) {
+            if (!taken(i)) continue;
+            found++;
+            if (!write) continue;
+            const int32_t slot = slot_of[x_window[i]];
+            const uint8_t *r = xc + (size_t)i * k, *pr = primers + (size_t)slot * k;
+            int gaps = 0, miss = 0;
+            uint64_t can = 0;
+            for (int j = 0; j < k; j++) {
+                const bool gap = r[j] == 0, m = gap || (r[j] & ~pr[j] & 15u) != 0;
+                gaps += gap;
+                miss += m;
+                can |= (uint64_t)m << j;
+            }
+            const bool both = gaps > v || miss > v;
+            cand[2 * o] = slot; cand[2 * o + 1] = slot;
+            row[2 * o] = row[2 * o + 1] = (int32_t)(x_row[i] - row0);
+            which[2 * o] = 0; which[2 * o + 1] = 1;
+            value[2 * o] = both || (can & strictF) != 0;
+            value[2 * o + 1] = both || (can & strictR) != 0;
+            o++;
+        }
+        if (!write) first[(size_t)t + 1] = found;
+    };
+    if (n_thr <= 1) share(0, false);
+    else mp::run_on_threads(n_thr, [&](int t) { share(t, false); });
+    for (int t = 0; t < n_thr; t++) first[(size_t)t + 1] += first[(size_t)t];
+    if (n_thr <= 1) share(0, true);
+    else mp::run_on_threads(n_thr, [&](int t) { share(t, true); });
+    *n_out = 2 * first[(size_t)n_thr];
     return MP_OK;
 }
 

@@ -1014,8 +1014,10 @@ int unique_packed(mp_ctx *c, int64_t cap, int32_t want_labels, int64_t *n_entrie
     // E per window for the gate (below): an exception row with more than v gaps is one gap_sequence entry, any other counts once per
     // expansion (V20:689-707).  Host work that needs nothing from the device: it runs while the histogram kernel does.
     std::vector<double> extra;
+    int extra_rc = MP_OK;
     auto count_extra = [&]() {
         extra.assign(W, 0.0);
+        if ((extra_rc = ex_fetch(c))) return;                   // (the records may still be on their way: windows.hip)
         static const int kSetSize[16] = {1, 1, 1, 2, 1, 2, 2, 3, 1, 2, 2, 3, 2, 3, 3, 4};
         const size_t n_ex = c->ex_host.size();
         const int T = (int)std::max<size_t>(1, std::min<size_t>(8, n_ex / 8192));
@@ -1110,6 +1112,7 @@ int unique_packed(mp_ctx *c, int64_t cap, int32_t want_labels, int64_t *n_entrie
         if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
         dev_free(c, &d_sums, W * (size_t)parts);
         if (e != hipSuccess) return fail(c, MP_ERR_DEVICE, "histogram tables: %s", hipGetErrorString(e));
+        if (extra_rc) return extra_rc;
         lap("unique: histogram + sums + d2h");
         bool any_over = false;
         for (size_t w = 0; w < W; w++) {

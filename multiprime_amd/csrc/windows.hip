@@ -192,6 +192,76 @@ __global__ __launch_bounds__(kBlock) void window_words_kernel(const MsaArgs M, i
 
 }  // namespace
 
+namespace mp {
+
+// The exception records of mp_build_windows on the host, by (window, row): waits for the copy the build queued, then a counting sort over
+// the windows (positions only) and the rows inside each window's short run; the 40-byte records move once (std::sort on the records:
+// 0.85 ms for 22 666 of them, on packed keys 0.78).  Thread-safe: the caller's helper thread and the histogram's host part both ask.
+int ex_fetch(mp_ctx *c) {
+    std::lock_guard<std::mutex> lock(c->ex_mu);
+    if (!c->ex_pending) return MP_OK;
+    const auto t0 = std::chrono::steady_clock::now();
+    const int cnt = c->ex_pending, n_win = c->n_win;
+    c->ex_pending = 0;
+    c->ex_host.clear();
+    const size_t bytes = sizeof(ExRec) * (size_t)cnt;
+    hipError_t e = hipSetDevice(c->dev);
+    if (e == hipSuccess && c->h_ex_bytes < bytes) {
+        if (c->h_ex) { if (c->h_ex_pinned) (void)hipHostUnregister(c->h_ex); host_unmap(c->h_ex, c->h_ex_bytes); }
+        c->h_ex_pinned = false; c->h_ex_bytes = 0;
+        const size_t room = (bytes + bytes / 4 + ((size_t)2 << 20) - 1) / ((size_t)2 << 20) * ((size_t)2 << 20);
+        c->h_ex = static_cast<uint8_t *>(host_map(room));
+        if (!c->h_ex) return fail(c, MP_ERR_NOMEM, "exception records: out of host memory (%zu bytes)", room);
+        c->h_ex_bytes = room;
+        prefault_host(c->h_ex, room);
+        if (!getenv("MP_NO_PIN") && hipHostRegister(c->h_ex, room, hipHostRegisterDefault) == hipSuccess) c->h_ex_pinned = true;
+        else (void)hipGetLastError();
+    }
+    // a stream of the library's own: the first one is busy with the histograms, and mp_build_windows waited for the kernels that wrote the records
+    if (e == hipSuccess && !c->ex_stream) e = hipStreamCreateWithFlags(&c->ex_stream, hipStreamNonBlocking);
+    if (e == hipSuccess) e = hipMemcpyAsync(c->h_ex, c->ex, bytes, hipMemcpyDeviceToHost, c->ex_stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(c->ex_stream);
+    if (e != hipSuccess) return fail(c, MP_ERR_DEVICE, "exception records: %s", hipGetErrorString(e));
+    const auto t1 = std::chrono::steady_clock::now();
+    const ExRec *rec = reinterpret_cast<const ExRec *>(c->h_ex);
+    for (int i = 0; i < cnt; i++)
+        if (rec[i].win < 0 || rec[i].win >= n_win) return fail(c, MP_ERR_DEVICE, "exception record %d names window %d", i, rec[i].win);
+    std::vector<int32_t> first((size_t)n_win + 1, 0);
+    for (int i = 0; i < cnt; i++) first[(size_t)rec[i].win + 1]++;
+    for (int w = 0; w < n_win; w++) first[(size_t)w + 1] += first[(size_t)w];
+    std::vector<uint32_t> order((size_t)cnt);
+    {
+        std::vector<int32_t> cur(first.begin(), first.end() - 1);
+        for (int i = 0; i < cnt; i++) order[(size_t)cur[(size_t)rec[i].win]++] = (uint32_t)i;
+    }
+    // (10^6 rows with IUPAC codes at 1e-5: 1.8e5 records, 7 MB — the sorts of the windows' runs and the one move of the records
+    // are spread over a few threads, each with a contiguous range of windows: 4.8 -> ~1 ms)
+    std::vector<ExRec> sorted((size_t)cnt);
+    auto part = [&](int w0, int w1) {
+        for (int w = w0; w < w1; w++)
+            std::sort(order.begin() + first[(size_t)w], order.begin() + first[(size_t)w + 1], [&](uint32_t a, uint32_t b) { return rec[a].row < rec[b].row; });
+        for (size_t i = (size_t)first[(size_t)w0]; i < (size_t)first[(size_t)w1]; i++) sorted[i] = rec[order[i]];
+    };
+    const int n_thr = cnt >= 16384 ? std::max(1, std::min({16, (int)std::thread::hardware_concurrency(), cnt / 8192})) : 1;
+    if (n_thr <= 1) part(0, n_win);
+    else {
+        run_on_threads(n_thr, [&](int t) {            // window ranges of about equal record counts
+            const int w0 = (int)(std::lower_bound(first.begin(), first.end(), (int32_t)((long long)cnt * t / n_thr)) - first.begin());
+            const int w1 = t + 1 == n_thr ? n_win : (int)(std::lower_bound(first.begin(), first.end(), (int32_t)((long long)cnt * (t + 1) / n_thr)) - first.begin());
+            part(std::min(w0, n_win), std::min(w1, n_win));
+        });
+    }
+    c->ex_host.swap(sorted);
+    if (getenv("MP_TRACE")) {
+        const auto t2 = std::chrono::steady_clock::now();
+        fprintf(stderr, "[mprime] exceptions: %d records; copied in %.3f ms, sorted in %.3f ms\n", cnt,
+                std::chrono::duration<double, std::milli>(t1 - t0).count(), std::chrono::duration<double, std::milli>(t2 - t1).count());
+    }
+    return MP_OK;
+}
+
+}  // namespace mp
+
 extern "C" {
 
 int mp_build_windows(mp_ctx *c, int32_t p0, int32_t n_win, int32_t k, int32_t v, int32_t *n_exc) {
@@ -281,44 +351,17 @@ int mp_build_windows(mp_ctx *c, int32_t p0, int32_t n_win, int32_t k, int32_t v,
         if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
         lap("build_windows: list+repair");
         dev_free(c, &d_wins, (size_t)tot);
+        lap("build_windows: scratch released");
         if (e != hipSuccess) return fail(c, MP_ERR_DEVICE, "mp_build_windows: %s", hipGetErrorString(e));
         if (errv[0])
             return fail(c, MP_ERR_SHORT_WINDOW, "row %d has fewer than %d residues at window %d", errv[2], k, p0 + errv[1]);
-        c->ex_host.resize((size_t)cnt);
-        if (cnt) HIPCK(c, hipMemcpy(c->ex_host.data(), c->ex, sizeof(ExRec) * (size_t)cnt, hipMemcpyDeviceToHost));
-        lap("build_windows: ex d2h");
-        {   // by (window, row): a counting sort over the windows (positions only), then the rows inside each window's short run; the
-            // 40-byte records move once (std::sort on the records: 0.85 ms for 22 666 of them, on packed keys 0.78)
-            std::vector<int32_t> first((size_t)n_win + 1, 0);
-            for (int i = 0; i < cnt; i++) first[(size_t)c->ex_host[(size_t)i].win + 1]++;
-            for (int w = 0; w < n_win; w++) first[(size_t)w + 1] += first[(size_t)w];
-            std::vector<uint32_t> order((size_t)cnt);
-            {
-                std::vector<int32_t> cur(first.begin(), first.end() - 1);
-                for (int i = 0; i < cnt; i++) order[(size_t)cur[(size_t)c->ex_host[(size_t)i].win]++] = (uint32_t)i;
-            }
-            // (10^6 rows with IUPAC codes at 1e-5: 1.8e5 records, 7 MB — the sorts of the windows' runs and the one move of the records
-            // are spread over a few threads, each with a contiguous range of windows: 4.8 -> ~1 ms)
-            std::vector<ExRec> sorted((size_t)cnt);
-            auto part = [&](int w0, int w1) {
-                for (int w = w0; w < w1; w++)
-                    std::sort(order.begin() + first[(size_t)w], order.begin() + first[(size_t)w + 1],
-                              [&](uint32_t a, uint32_t b) { return c->ex_host[a].row < c->ex_host[b].row; });
-                for (size_t i = (size_t)first[(size_t)w0]; i < (size_t)first[(size_t)w1]; i++) sorted[i] = c->ex_host[order[i]];
-            };
-            const int n_thr = cnt >= 16384 ? std::max(1, std::min({16, (int)std::thread::hardware_concurrency(), cnt / 8192})) : 1;
-            if (n_thr <= 1) part(0, n_win);
-            else {
-                mp::run_on_threads(n_thr, [&](int t) {            // window ranges of about equal record counts
-                    const int w0 = (int)(std::lower_bound(first.begin(), first.end(), (int32_t)((long long)cnt * t / n_thr)) - first.begin());
-                    const int w1 = t + 1 == n_thr ? n_win : (int)(std::lower_bound(first.begin(), first.end(), (int32_t)((long long)cnt * (t + 1) / n_thr)) - first.begin());
-                    part(std::min(w0, n_win), std::min(w1, n_win));
-                });
-            }
-            c->ex_host.swap(sorted);
+        // the records (40 bytes each) stay on the device until someone asks: ex_fetch() — the caller's helper thread (mp_get_exceptions) or
+        // the histogram's host part, both beside the histogram kernels instead of in front of them
+        {
+            std::lock_guard<std::mutex> lock(c->ex_mu);
+            c->ex_pending = cnt;
         }
         if (n_exc) *n_exc = cnt;
-        lap("build_windows: exceptions");
     }
     return MP_OK;
 }
@@ -326,6 +369,7 @@ int mp_build_windows(mp_ctx *c, int32_t p0, int32_t n_win, int32_t k, int32_t v,
 int mp_get_exceptions(mp_ctx *c, int32_t cap, int32_t *ew, int32_t *er, uint8_t *codes) {
     if (!c) return MP_ERR_ARG;
     if (!c->excl) return fail(c, MP_ERR_ARG, "no windows built");
+    if (int rc = ex_fetch(c)) return rc;
     int n = (int)c->ex_host.size();
     if (cap < n) return fail(c, MP_ERR_CAPACITY, "exception buffer too small: need %d", n);
     auto part = [&](int i0, int i1) {

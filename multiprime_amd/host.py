@@ -57,6 +57,9 @@ HOST_SYMBOLS = [
     ("mp_primer_tm", C.c_int, [C.c_int32, C.c_int64, _p, _p, _p]),
     ("mp_primer_filters", C.c_int, [C.c_int32, C.c_int64, _p, _p, C.c_int32, _p, _p, _p]),
     ("mp_exception_verdicts", C.c_int, [C.c_int32, C.c_int32, C.c_int64, _p, _p, C.c_int64, _p, C.c_uint64, C.c_uint64, _p]),
+    ("mp_expand_exception_words", C.c_int, [C.c_int32, C.c_int32, C.c_int64, _p, _p, C.c_int64, _p, _p, _p]),
+    ("mp_exception_assignments", C.c_int, [C.c_int32, C.c_int32, C.c_int64, _p, _p, _p, C.c_int32, _p, C.c_int64, C.c_int64, C.c_int64, _p, C.c_uint64,
+                                           C.c_uint64, _p, _p, _p, _p, _p]),
 ]
 
 _dll = None
@@ -206,6 +209,29 @@ def exception_verdicts(xc: np.ndarray, primer_of: np.ndarray, primers: np.ndarra
     return bad.view(bool)
 
 
+def exception_assignments(x_window, x_row, xc, slot_of, row0: int, n_rows: int, primers, v: int, strictF: int, strictR: int):
+    """(cand, row, which, value) for Context.masks_set_bits: the verdicts of the exception rows whose window is an output window
+    (slot_of[window] >= 0) and whose row lies in [row0, row0 + n_rows) — selection, verdicts and layout in one native call
+    (mp_exception_assignments)."""
+    x_window = np.ascontiguousarray(x_window, np.int32)
+    x_row = np.ascontiguousarray(x_row, np.int64)
+    xc = np.ascontiguousarray(xc, np.uint8)
+    slot_of = np.ascontiguousarray(slot_of, np.int32)
+    primers = np.ascontiguousarray(primers, np.uint8)
+    n = len(x_window)
+    k = xc.shape[1] if xc.ndim == 2 else (primers.shape[1] if primers.ndim == 2 else 1)
+    cand, row = np.empty(2 * n, np.int32), np.empty(2 * n, np.int32)
+    which, value = np.empty(2 * n, np.uint8), np.empty(2 * n, np.uint8)
+    n_out = C.c_int64(0)
+    rc = dll().mp_exception_assignments(k, int(v), n, _ptr(x_window), _ptr(x_row), _ptr(xc), len(slot_of), _ptr(slot_of), int(row0), int(n_rows),
+                                        len(primers), _ptr(primers), int(strictF), int(strictR), _ptr(cand), _ptr(row), _ptr(which), _ptr(value),
+                                        C.byref(n_out))
+    if rc != 0:
+        raise MprimeError(rc, "mp_exception_assignments: bad arguments")
+    m = n_out.value
+    return cand[:m], row[:m], which[:m], value[:m]
+
+
 def expand_kmers(codes: np.ndarray):
     """(expansions [m][k], src [m]): degenerate_seq (V20:368-380) of every k-mer of symbol codes, reference order."""
     codes = np.ascontiguousarray(codes, dtype=np.uint8)
@@ -248,6 +274,31 @@ def expand_kmer_words(codes: np.ndarray):
         raise MprimeError(rc, "mp_expand_kmer_words: bad symbol codes or too many expansions")
     m = need.value
     return words[:m], src[:m]
+
+
+def expand_exception_words(x_window: np.ndarray, codes: np.ndarray, v: int):
+    """(windows [m] int32, words [m][3]): the expansions of the exception k-mers with at most v gaps, each with its row's window — the
+    arguments of Context.set_extra_rows (mp_expand_exception_words)."""
+    codes = np.ascontiguousarray(codes, dtype=np.uint8)
+    x_window = np.ascontiguousarray(x_window, dtype=np.int32)
+    n, k = codes.shape
+    d = dll()
+    need = C.c_int64(0)
+    wt = np.uint32 if k <= 31 else np.uint64
+    m = 4 * n + 1024
+    for _ in range(2):
+        words = np.empty((max(m, 1), 3), wt)
+        win = np.empty(max(m, 1), np.int32)
+        rc = d.mp_expand_exception_words(k, int(v), n, _ptr(x_window), _ptr(codes), m, _ptr(words), _ptr(win), C.byref(need))
+        if rc != MP_ERR_CAPACITY:
+            break
+        m = need.value
+        if m > 1 << 28:
+            raise MprimeError(MP_ERR_CAPACITY, f"IUPAC k-mers expand to {m} concrete k-mers")
+    if rc != 0:
+        raise MprimeError(rc, "mp_expand_exception_words: bad symbol codes or too many expansions")
+    m = need.value
+    return win[:m], words[:m]
 
 
 class Plan:

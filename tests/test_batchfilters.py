@@ -198,3 +198,39 @@ def test_native_exception_verdicts_equal_the_numpy_statement():
         assert np.array_equal(got, want) and want.any() and not want.all()
     with pytest.raises(host.MprimeError):
         host.exception_verdicts(xc, of + 1000, primers, v, sF, sR)
+
+
+def test_native_exception_assignments_equal_selection_plus_verdicts():
+    """mp_exception_assignments (selection of output windows and of the shard's rows + verdicts + the layout mp_masks_set_bits takes, on
+    several threads from 16384 rows up) against the numpy selection around mp_exception_verdicts that core._resident_bitsets used."""
+    from multiprime_amd import host
+    rng = np.random.default_rng(11)
+    for k, v, n, n_win, row0, n_rows in ((18, 1, 60000, 400, 0, 5000), (18, 0, 900, 50, 1000, 700), (18, 1, 0, 10, 0, 10), (31, 2, 20000, 120, 250, 100000)):
+        wins = np.sort(rng.choice(n_win, size=max(1, n_win // 3), replace=False)).astype(np.int32)
+        n_out = len(wins)
+        primers = np.array([1, 2, 4, 8], np.uint8)[rng.integers(0, 4, size=(n_out, k))]
+        primers[rng.random((n_out, k)) < 0.1] = 15
+        x_window = np.sort(rng.integers(0, n_win, size=n)).astype(np.int32)
+        x_row = rng.integers(0, row0 + n_rows + 500, size=n).astype(np.int64)
+        xc = rng.integers(0, 16, size=(n, k)).astype(np.uint8)
+        xc[rng.random((n, k)) < 0.9] = 1
+        sF, sR = 0b101, 0b11 << (k - 2)
+        slot_of = np.full(n_win, -1, np.int32)
+        slot_of[wins] = np.arange(n_out, dtype=np.int32)
+        cand, row, which, value = host.exception_assignments(x_window, x_row, xc, slot_of, row0, n_rows, primers, v, sF, sR)
+        mask_i = slot_of[x_window].astype(np.int64)
+        r_loc = x_row - row0
+        sel = (mask_i >= 0) & (r_loc >= 0) & (r_loc < n_rows)
+        m = int(sel.sum())
+        assert len(cand) == 2 * m
+        if m == 0:
+            continue
+        bad = host.exception_verdicts(xc[sel], mask_i[sel], primers, v, sF, sR)
+        assert np.array_equal(cand, np.repeat(mask_i[sel], 2)) and np.array_equal(row, np.repeat(r_loc[sel], 2))
+        assert np.array_equal(which, np.tile(np.array([0, 1], np.uint8), m)) and np.array_equal(value, bad.reshape(-1).astype(np.uint8))
+        assert 0 < m < n
+    with pytest.raises(host.MprimeError):
+        host.exception_assignments(x_window + 1000, x_row, xc, slot_of, row0, n_rows, primers, v, sF, sR)
+    with pytest.raises(host.MprimeError):
+        host.exception_assignments(np.zeros(3, np.int32), np.zeros(3, np.int64), np.ones((3, 18), np.uint8), np.array([5], np.int32), 0, 10,
+                                   np.ones((2, 18), np.uint8), 1, 0, 0)

@@ -134,3 +134,50 @@ def test_launches_on_the_second_stream_equal_the_first(hip_lib, oracle_lib, n, k
     finally:
         h.close()
         o.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("seed,n,L,ragged,k,v", [(3, 6000, 120, False, 18, 1), (4, 70000, 80, False, 18, 2), (5, 3000, 150, False, 36, 2), (6, 900, 100, False, 25, 0)])
+def test_exception_records_fetched_on_demand(hip_lib, oracle_lib, seed, n, L, ragged, k, v):
+    """The exception records mp_build_windows leaves on the device (ex_fetch: copied and sorted for whoever asks first) are the oracle's whether
+    the histograms' device gate or mp_get_exceptions asks first, on a context that builds its windows several times; the statistics after
+    the host's extra rows, in two halves and blocking."""
+    data, off, maxlen = fuzz_msa(seed, n, L, ragged, p_iupac=0.004)
+    h, o = both(hip_lib, oracle_lib, data, off)
+    try:
+        W = (int(np.sort(np.diff(off))[n // 4]) if ragged else maxlen) - k - 2
+        for round_ in range(3):
+            ne = h.build_windows(2, W, k, v)
+            assert ne == o.build_windows(2, W, k, v) and ne > 0
+            if round_ == 1:
+                h.set_entropy_gate(3.6)                            # the device gate counts the exception rows per window: the histograms ask first
+                h.window_unique_device()
+                h.set_entropy_gate(0)
+            want_ex = o.get_exceptions(ne)
+            got_ex = h.get_exceptions(ne)
+            for a, b in zip(got_ex, want_ex):
+                assert np.array_equal(a, b)
+            ew, er, ec = got_ex
+            raw = iupac.strings_of(iupac.SYMBOL_LUT[ec])
+            xw, xk = [], []
+            for w_, s in zip(ew.tolist(), raw):
+                if s.count("-") <= v and iupac.degeneracy(s) <= 16:
+                    for e in iupac.expand(s):
+                        xw.append(w_)
+                        xk.append(e)
+            assert xw
+            words = iupac.words_of_kmers(np.frombuffer("".join(xk).encode(), np.uint8).reshape(len(xk), k))
+            for c in (h, o):
+                c.set_extra_rows(np.asarray(xw, np.int32), words)
+            fw, nw_ = o.window_stats()
+            if round_ == 2:
+                f0, n0 = h.window_stats()
+            else:
+                f0, n0 = h.window_stats_begin()
+                h.window_stats_end(f0, n0)
+            assert np.array_equal(f0, fw) and np.array_equal(n0, nw_)
+            f1, n1 = h.window_stats()
+            assert np.array_equal(f1, fw) and np.array_equal(n1, nw_)
+    finally:
+        h.close()
+        o.close()

@@ -374,6 +374,30 @@ def test_expansions_as_window_words_equal_the_code_path():
     assert np.array_equal(src, src2) and np.array_equal(iupac.words_of_codes(exp), words)
 
 
+@pytest.mark.parametrize("k,v", [(18, 1), (18, 0), (25, 3), (40, 2)])
+def test_exception_words_equal_selection_plus_expansion(k, v):
+    """mp_expand_exception_words (rows with more than v gaps dropped, every expansion with its row's window) against the numpy selection
+    around mp_expand_kmer_words that core.py used; a list without a gap; the capacity retry of the wrapper."""
+    rng = np.random.default_rng(k + v)
+    n = 3000
+    codes = np.where(rng.random((n, k)) < 0.9, rng.choice(np.array([1, 2, 4, 8], np.uint8), size=(n, k)), rng.integers(0, 16, size=(n, k))).astype(np.uint8)
+    codes[::7, : v + 1] = 0                                     # rows with more than v gaps
+    x_win = np.sort(rng.integers(0, 200, size=n)).astype(np.int32)
+    for cds in (codes, np.where(codes == 0, 1, codes).astype(np.uint8)):
+        sel = (cds == 0).sum(axis=1) <= v
+        words, src = host.expand_kmer_words(cds[sel])
+        want_win = x_win[sel][src]
+        got_win, got_words = host.expand_exception_words(x_win, cds, v)
+        assert got_words.dtype == words.dtype and np.array_equal(got_words, words) and np.array_equal(got_win, want_win)
+        assert len(got_win) > 0 and (0 < sel.sum() < n or not (cds == 0).any())
+    many = np.full((50, k), 15, np.uint8)                       # 4^k expansions each: beyond any capacity
+    many[:, 6:] = 1
+    win, words = host.expand_exception_words(np.zeros(50, np.int32), many, v)      # 50 x 4096: the first guess (4 n + 1024) is too small
+    assert len(win) == 50 * 4096 and len(words) == len(win)
+    w0, e0 = host.expand_exception_words(np.zeros(0, np.int32), np.zeros((0, k), np.uint8), v)
+    assert len(w0) == 0 and len(e0) == 0
+
+
 def test_fasta_gather_equals_the_rows_array():
     """mp_fasta_gather (the streamed load's source): any byte range of the rows laid end to end, on any number of threads — multi-line
     records, CRLF, repeated ids, empty records."""
