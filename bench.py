@@ -95,6 +95,14 @@ def main():
     ap.add_argument("--share", default=None, metavar="RxG", help="N = 1 experiment: time one rank's share of an R x G job instead of the whole workload")
     ap.add_argument("--bucket", type=int, default=4, help="steps per collective of the bucketed side measurement (N > 1)")
     a = ap.parse_args()
+    import faulthandler
+    faulthandler.enable()           # a fatal signal leaves every thread's Python stack on stderr (the driver keeps stderr)
+    t_main = time.time()
+
+    def progress(block):
+        """MP_BENCH_PROGRESS=1: which block starts when, on stderr."""
+        if os.environ.get("MP_BENCH_PROGRESS"):
+            print("[bench] %7.2f s  %s" % (time.time() - t_main, block), file=sys.stderr, flush=True)
 
     from multiprime_amd._abi import Library, prefer_staged_copies
     prefer_staged_copies()          # a program's decision, before the HIP runtime starts: what the drop-in command lines do (the `pipeline` block times their code path)
@@ -325,12 +333,17 @@ def main():
         if world == 1:
             res["step_form"] = ("rotating: the launch that fills a step's counter block clears the next step's inside its own grid (mp_eval_launch_rotating)"
                                 if rotate else "a fill dispatch in front of every evaluation (mp_eval_launch; MP_BENCH_ROTATE=0)")
+            progress("cpu_baseline")
             blocks = None
             if not a.no_cpu:
                 n_cpu = a.cpu_rows or rows_per_gpu
                 blocks = OracleBlocks(w, w.rows[:n_cpu], a.cpu_threads)
                 res["cpu_baseline"] = cpu_baseline(w, blocks, gpu_counters if n_cpu == rows_per_gpu else None, a.seed)
                 res["parity_checked"] = res["cpu_baseline"].get("parity_checked")
+            # The contract's line as soon as its fields exist (value, roofline, cpu_baseline, parity): should one of the side measurements below take
+            # the process down — a fatal signal cannot be caught — the LAST stdout line is still a complete headline.  The final line replaces it.
+            print(headline({**res, "provisional": True}), flush=True)
+            progress("variants")
             if not a.no_variants:
                 # SURVEY 8d's micro-benchmark at the headline size: C = 1, unrelated C = 8, nested C = 64, each checked against the oracle
                 try:
@@ -342,6 +355,7 @@ def main():
             if blocks is not None:
                 blocks.close()
                 del blocks
+            progress("pipeline")
             if not a.no_pipeline:
                 res["pipeline"] = {"what": "the REAL step: the drop-in class NN_degenerate(...).run() (multiprime_amd/core.py; --no-json, coverage bitsets kept on the "
                                            "device) on the same synthetic rows, median of 5 after one warm-up; `run_ms` is run() alone (the context is kept across repetitions, as the "
@@ -349,6 +363,7 @@ def main():
                                            "(oracle/core_ref.py over the plain-C oracle, tests/golden/synth_pipeline.json)",
                                    f"rows_{rows_per_gpu}": pipeline_block(lib, local, w.rows, a)}
     # N = 1: the shard one GPU holds in the 8-GPU job, timed the same way (with the variant measurements)
+    progress("weak_shard")
     if rank == 0 and world == 1 and not a.no_shard and rows_per_gpu != SHARD_ROWS:
         del sb
         w.ctx = ctx = None
@@ -375,6 +390,7 @@ def main():
                         "kernel for row shards (dist.StepBuckets); north_star asks >= 6"}
         # ... and what the 2-D shards reach (dist.ShardGrid: R row shards x G window groups, the alignment's rows replicated along the window axis,
         # the all-reduce inside a row group only): the share of ONE rank of every shape, on this GPU, in this run, checked against the oracle
+        progress("shard_shapes")
         if not a.no_shapes and rows_per_gpu == FULL_ROWS:
             try:
                 res["shard_shapes"] = shard_shapes(lib, local, torch, a, timed_pair, rows_full, not a.no_cpu)
@@ -388,6 +404,7 @@ def main():
             except Exception as e:              # noqa: BLE001 — as above
                 res["shard_shapes"] = {"error": f"{type(e).__name__}: {e}"}
         # the same rows at other primer lengths (k = 20, 22: BASELINE configs[1]; 36: 64-bit window words)
+        progress("k_sweep")
         if not a.no_ksweep and rows_per_gpu == FULL_ROWS and a.k == 18:
             try:
                 res["k_sweep"] = k_sweep(lib, local, torch, dev, a, rows_full, not a.no_cpu)
@@ -399,6 +416,7 @@ def main():
     if rank == 0 and world == 1 and any(isinstance(p, dict) and p.get("tsv_equal_oracle") is False for p in res.get("pipeline", {}).values()):
         res["parity_checked"] = False
     # N = 1: the steps either side of the core step, each with its checker leg — detail file only
+    progress("side_steps")
     if rank == 0 and world == 1 and not a.no_side:
         try:
             sys.path.insert(0, os.path.join(REPO, "tools"))
@@ -408,6 +426,7 @@ def main():
                 res["parity_checked"] = False
         except Exception as e:                  # noqa: BLE001 — a side measurement must not take the headline line with it
             res["side_steps"] = {"error": f"{type(e).__name__}: {e}"}
+    progress("emit")
     if rank == 0:
         emit(res)
     if world > 1:
@@ -436,7 +455,7 @@ def headline(res):
     the projected scaling ceiling — no notes, no tables, no nested side measurements (those go to bench_detail.json and to an
     earlier, prefixed stdout line).  Always shorter than HEADLINE_LIMIT (tests/test_bench_line.py)."""
     top = ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data",
-           "parity_checked", "ms_per_step_bucketed", "bucket", "steps_in_flight", "ms_per_step_one_stream")
+           "parity_checked", "ms_per_step_bucketed", "bucket", "steps_in_flight", "ms_per_step_one_stream", "provisional")
     out = {key: res[key] for key in top if key in res}
     cfg = res.get("config", {})
     out["config"] = {key: cfg[key] for key in ("workload", "rows_per_gpu", "rows_total", "cols", "k", "variation", "candidates_per_window", "windows",
@@ -498,6 +517,47 @@ def emit(res):
     print(headline(res), flush=True)
 
 
+def supervise(cmd, env=None, out=None, attempts=2):
+    """N = 1: the measuring runs in a CHILD process and this one only relays its stdout.  A fatal signal inside the runtime cannot be caught
+    in the process it hits (round 6: two of 57 runs died in a side measurement, never reproduced in isolation — DESIGN 9.-2); from here it can:
+      * the child's last line is a final headline           -> nothing to add, its exit status is ours (non-zero when parity failed);
+      * the child ended after the PROVISIONAL headline      -> that line again as the last line, `side_measurements` saying what happened, exit 0
+        (the timed region, the roofline, the CPU leg and the parity check of the headline were complete when it was printed);
+      * the child ended before any headline                 -> one more attempt, then its exit status.
+    Nothing is measured here: the timed region is the child's.  `cmd` / `out` exist for tests/test_bench_line.py."""
+    import subprocess
+    out = out or sys.stdout
+    rc = 1
+    for attempt in range(1, attempts + 1):
+        child = subprocess.Popen(cmd, stdout=subprocess.PIPE, env=env, text=True, bufsize=1)
+        last, line = None, "\n"
+        for line in child.stdout:
+            out.write(line)
+            out.flush()
+            if line.startswith("{"):
+                try:
+                    last = json.loads(line)
+                except ValueError:
+                    last = None
+        rc = child.wait()
+        if not line.endswith("\n"):
+            out.write("\n")                         # the child ended in the middle of a line
+        if isinstance(last, dict) and "metric" in last:
+            if not last.get("provisional"):
+                return rc
+            last.pop("provisional")
+            last["side_measurements"] = f"the measuring process ended with status {rc} after the headline was complete; side blocks missing (attempt {attempt})"
+            out.write(json.dumps(last, separators=(",", ":")) + "\n")
+            out.flush()
+            return 0
+        print(f"[bench] attempt {attempt}: the measuring process ended with status {rc} before a headline", file=sys.stderr, flush=True)
+    return rc
+
+
 if __name__ == "__main__":
-    main()
+    profiled = "rocprof" in os.environ.get("LD_PRELOAD", "") or "ROCP_TOOL_LIBRARIES" in os.environ      # rocprofv3: one process, one trace
+    if "RANK" in os.environ or profiled or os.environ.get("MP_BENCH_CHILD") or os.environ.get("MP_BENCH_NO_SUPERVISOR"):
+        main()                      # a rank of torch.distributed.run, a profiled run, or the child below
+    else:
+        sys.exit(supervise([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env={**os.environ, "MP_BENCH_CHILD": "1"}))
 

@@ -1,6 +1,8 @@
 // api.hip — part of libmprime_hip.so: hand-written HIP (gfx950 / MI355X, wave64) behind the C ABI of
 // include/mprime.h.  Context lifetime and bookkeeping.
 #include <sys/mman.h>
+#include <execinfo.h>
+#include <exception>
 #include <algorithm>
 
 #include <thread>
@@ -267,6 +269,15 @@ const char *mp_last_error(const mp_ctx *c) { return c ? c->err : "mp_create fail
 int mp_create(int device, mp_ctx **out) {
     if (!out) return MP_ERR_ARG;
     *out = nullptr;
+    if (getenv("MP_DEBUG_TERMINATE")) {        // debugging: the stack of whoever lets an exception escape (the runtime's threads included)
+        std::set_terminate([] {
+            void *bt[64];
+            const int n = backtrace(bt, 64);
+            fprintf(stderr, "[mprime] std::terminate: %d frames\n", n);
+            backtrace_symbols_fd(bt, n, 2);
+            abort();
+        });
+    }
     int n = 0;
     if (hipGetDeviceCount(&n) != hipSuccess || n <= 0 || device < 0 || device >= n) return MP_ERR_DEVICE;
     if (hipSetDevice(device) != hipSuccess) return MP_ERR_DEVICE;
@@ -293,12 +304,15 @@ void mp_destroy(mp_ctx *c) {
     if (!c) return;
     (void)hipSetDevice(c->dev);
     (void)hipDeviceSynchronize();
-    if (c->alt_stream) (void)hipStreamDestroy(c->alt_stream);
-    if (c->ex_stream) (void)hipStreamDestroy(c->ex_stream);
-    if (c->h_ex) { if (c->h_ex_pinned) (void)hipHostUnregister(c->h_ex); host_unmap(c->h_ex, c->h_ex_bytes); }
     free_comm(c);
     free_msa(c);
     free_seq(c);
+    // The library's own streams go AFTER the stages: free_eval() waits for the second stream before it releases what launches on it read.
+    // [r6] They went first, so that wait named a destroyed stream (freed memory of the runtime).  Found by reading while hunting two of 57
+    // `bench.py` runs that died inside the runtime (std::bad_variant_access / SIGSEGV); 3000 contexts in either order did not reproduce a
+    // crash (profiles/r06_close_stress.txt), so this is a fix of a real fault, not a proven cause: bench.py measures in a child process.
+    if (c->alt_stream) { (void)hipStreamDestroy(c->alt_stream); c->alt_stream = nullptr; }
+    if (c->ex_stream) { (void)hipStreamDestroy(c->ex_stream); c->ex_stream = nullptr; }
     dev_free(c, &c->tmp_out, (size_t)c->tmp_out_n);
     dev_free(c, &c->stats_buf, c->stats_buf_n);
     if (getenv("MP_TRACE")) fprintf(stderr, "[mprime] device blocks: %lld reused, %lld from the runtime, %zu waiting (%.1f MB)\n", c->pool_hits, c->pool_misses,

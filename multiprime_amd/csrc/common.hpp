@@ -143,11 +143,9 @@ struct mp_ctx {
     int *ex_count = nullptr, *err_flag = nullptr;
     std::vector<mp::ExRec> ex_host;          // sorted by (window, row); complete only after ex_fetch()
     // [r6] the records leave the device BESIDE the histogram launch: mp_build_windows only notes how many there are; whoever needs ex_host
-    // first — mp_get_exceptions on the caller's helper thread, the device gate's per-window counts (unique.hip) — copies them into h_ex
-    // (host_map, registered) on ex_stream and sorts: ex_fetch(), one at a time under ex_mu
-    uint8_t *h_ex = nullptr;
-    size_t h_ex_bytes = 0;
-    bool h_ex_pinned = false;
+    // first — mp_get_exceptions on the caller's helper thread, the device gate's per-window counts (unique.hip) — copies them into ex_raw
+    // on ex_stream and sorts: ex_fetch(), one at a time under ex_mu
+    std::vector<mp::ExRec> ex_raw;           // as they come off the device (kept: its pages exist the second time)
     hipStream_t ex_stream = nullptr;
     int ex_pending = 0;                      // records on the device (c->ex), not yet in ex_host
     std::mutex ex_mu;

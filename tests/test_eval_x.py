@@ -181,3 +181,44 @@ def test_exception_records_fetched_on_demand(hip_lib, oracle_lib, seed, n, L, ra
     finally:
         h.close()
         o.close()
+
+
+@pytest.mark.gpu
+def test_contexts_that_used_both_streams_close_and_reopen(hip_lib, oracle_lib):
+    """[r6] mp_destroy released the library's second stream BEFORE the stages whose release waits for that stream (free_eval): a wait on a
+    destroyed stream, one process in fifteen died at a context's close.  Forty short-lived contexts that used both streams (statistics in two
+    halves, evaluations on the second stream), each closed while the next already exists; the last one still equals the oracle."""
+    data, off, maxlen = fuzz_msa(77, 3000, 90, False, p_iupac=0.001)
+    k, v = 18, 1
+    W = maxlen - k - 2
+    rng = np.random.default_rng(1)
+    rows_ascii = data[: 400 * 90].reshape(400, 90)
+    cw, codes = chain_candidates(rng, rows_ascii, 2, W, k, 8)
+    sF, sR = (1 << 2) | (1 << 3), (1 << (k - 2)) | (1 << 2)
+    prev = None
+    for i in range(40):
+        h = hip_lib.context(0)
+        h.load_msa(data, off)
+        h.build_windows(2, W, k, v)
+        h.set_stream(torch.cuda.current_stream().cuda_stream)
+        f0, n0 = h.window_stats_begin()
+        h.window_stats_end(f0, n0)
+        h.eval_upload(cw, codes, sF, sR)
+        blocks = torch.zeros((2, len(cw), 3), dtype=torch.int64, device="cuda")
+        h.eval_launch(blocks[0].data_ptr())
+        h.eval_launch_alt(blocks[1].data_ptr())
+        h.eval_sync()
+        torch.cuda.synchronize()
+        if prev is not None:
+            prev.close()
+        prev = h
+    o = oracle_lib.context(0)
+    try:
+        o.load_msa(data, off)
+        o.build_windows(2, W, k, v)
+        want = o.eval_candidates(cw, codes, sF, sR)
+        got = blocks.cpu().numpy()
+        assert np.array_equal(got[0], want) and np.array_equal(got[1], want)
+    finally:
+        prev.close()
+        o.close()
