@@ -523,7 +523,7 @@ def supervise(cmd, env=None, out=None, attempts=2):
       * the child's last line is a final headline           -> nothing to add, its exit status is ours (non-zero when parity failed);
       * the child ended after the PROVISIONAL headline      -> that line again as the last line, `side_measurements` saying what happened, exit 0
         (the timed region, the roofline, the CPU leg and the parity check of the headline were complete when it was printed);
-      * the child ended before any headline                 -> one more attempt, then its exit status.
+      * the child was ended by a signal before any headline -> one more attempt, then its exit status.
     Nothing is measured here: the timed region is the child's.  `cmd` / `out` exist for tests/test_bench_line.py."""
     import subprocess
     out = out or sys.stdout
@@ -551,6 +551,8 @@ def supervise(cmd, env=None, out=None, attempts=2):
             out.flush()
             return 0
         print(f"[bench] attempt {attempt}: the measuring process ended with status {rc} before a headline", file=sys.stderr, flush=True)
+        if rc >= 0:
+            break                                   # its own exit (no GPU, bad flags, an exception): a second attempt would end the same way
     return rc
 
 

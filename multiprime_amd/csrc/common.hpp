@@ -213,7 +213,8 @@ struct mp_ctx {
     uint32_t *slide_iters = nullptr, *slide_recs = nullptr;
     size_t slide_n_iters = 0;
     int slide_items = 0, slide_n_bands = 0, slide_max_items = 0, slide_ns = 0, slide_gw = 0;
-    uint32_t slide_spos = 0, slide_fmask = 0, slide_rmask = 0;
+    uint32_t slide_spos = 0, slide_fmask = 0, slide_rmask = 0, slide_fpos = 0, slide_rpos = 0;
+    bool slide_fast = false;                 // the strict positions as two-bit counts per side (slidecore.hpp FAST)
     mp::ChainItem *chain_rest = nullptr;     // the chain items the plan leaves to the first-pass kernel
     mp::ChainItem *chain_slid = nullptr;     // the chain items that slide (slide_items of them): the patch pass subtracts their plain slices
     int n_rest = 0, rest_max_steps = 0;

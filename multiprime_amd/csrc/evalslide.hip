@@ -203,7 +203,7 @@ struct DevEnv {
 #ifndef SLIDE_MIN_WAVES
 #define SLIDE_MIN_WAVES 1
 #endif
-template <int LV, int GW>
+template <int LV, int GW, bool FAST>
 __global__ __launch_bounds__(kBlock, GW == 4 ? 1 : SLIDE_MIN_WAVES) void eval_slide_kernel(const SlideKernArgs K) {
     extern __shared__ __align__(16) uint32_t lds[];
     clear_counters(K.clear, K.n_clear, blockIdx.x, gridDim.x);
@@ -254,7 +254,7 @@ __global__ __launch_bounds__(kBlock, GW == 4 ? 1 : SLIDE_MIN_WAVES) void eval_sl
     __syncthreads();
     env.stamp(1);
     const bool wave_live = (slice * kBlock + wv * 64) * GW < K.nw32;          // some lane of the wave holds rows
-    if (wave_live) slide_band<LV, GW, true, false>(env, K.A, band);
+    if (wave_live) slide_band<LV, GW, true, false, FAST>(env, K.A, band);
     env.stamp(4);
     __syncthreads();
     env.stamp(5);
@@ -355,6 +355,10 @@ int upload_eval_slide(mp_ctx *c, const std::vector<ChainItem> &chains, const std
     HIPCK(c, hipMemcpy(c->slide_recs, P.recs.data(), sizeof(uint32_t) * P.recs.size(), hipMemcpyHostToDevice));
     c->slide_max_items = P.max_items_band;
     c->slide_ns = P.ns; c->slide_spos = P.spos; c->slide_fmask = P.fmask; c->slide_rmask = P.rmask;
+    // [r6] at most three strict positions per side (the reference's default `-c 1,2,-1`, V20:85): the strict positions as a two-bit count per
+    // side (slidecore.hpp FAST); MP_SLIDE_STRICT=0 keeps the per-position form
+    c->slide_fast = slide_strict_lists(c->k, (uint32_t)c->sF, (uint32_t)c->sR, c->slide_fpos, c->slide_rpos);
+    if (const char *e = getenv("MP_SLIDE_STRICT")) { if (atoi(e) == 0) c->slide_fast = false; }
     c->slide_gw = gw;
     {
         std::vector<ChainItem> slid;
@@ -374,14 +378,15 @@ int upload_eval_slide(mp_ctx *c, const std::vector<ChainItem> &chains, const std
 
 int launch_eval_slide(mp_ctx *c, unsigned long long *device_out, const EvalChainArgs *patch, int patch_blocks, int patch_words,
                       unsigned long long *clear, uint32_t n_clear) {
-#define SLIDE_ROW(LV) {eval_slide_kernel<LV, 1>, eval_slide_kernel<LV, 2>, eval_slide_kernel<LV, 4>}
-    static const SlideFn fn[4][3] = {SLIDE_ROW(1), SLIDE_ROW(2), SLIDE_ROW(3), SLIDE_ROW(4)};
+#define SLIDE_ROW(LV, F) {eval_slide_kernel<LV, 1, F>, eval_slide_kernel<LV, 2, F>, eval_slide_kernel<LV, 4, F>}
+    static const SlideFn fn[2][4][3] = {{SLIDE_ROW(1, false), SLIDE_ROW(2, false), SLIDE_ROW(3, false), SLIDE_ROW(4, false)},
+                                        {SLIDE_ROW(1, true), SLIDE_ROW(2, true), SLIDE_ROW(3, true), SLIDE_ROW(4, true)}};
 #undef SLIDE_ROW
     const int gw = c->slide_gw, gi = gw == 4 ? 2 : gw - 1;
     const int nw32 = c->n_pad / 32;
     SlideKernArgs K;
     K.A = SlideArgs{c->slide_bands, c->slide_iters, c->slide_recs, c->k, c->p0, c->slide_ns, c->slide_spos, c->slide_fmask, c->slide_rmask,
-                    (uint32_t)nw32 * 4u};
+                    (uint32_t)nw32 * 4u, c->slide_fpos, c->slide_rpos};
     K.cols32 = reinterpret_cast<const uint32_t *>(c->cols);
     K.excl32 = reinterpret_cast<const uint32_t *>(c->excl);
     K.nw32 = nw32;
@@ -405,7 +410,7 @@ int launch_eval_slide(mp_ctx *c, unsigned long long *device_out, const EvalChain
     size_t lds = ((size_t)(kBlock / 64) * ((size_t)c->k * 64 * gw) + (size_t)c->slide_max_items * 12) * sizeof(uint32_t);
     if (patch_blocks) lds = std::max(lds, (size_t)(64 + (kBlock / 64) * 64 * kPatchEvents) * sizeof(uint32_t));      // the patch units' rows and stashes
     if (lds > 160 * 1024) return fail(c, MP_ERR_ARG, "sliding evaluation: a band needs %zu bytes of LDS", lds);
-    SlideFn f = fn[c->v][gi];
+    SlideFn f = fn[c->slide_fast ? 1 : 0][c->v][gi];
     if (lds > 48 * 1024) HIPCK(c, hipFuncSetAttribute(reinterpret_cast<const void *>(f), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     hipLaunchKernelGGL(f, dim3((unsigned)K.n_slide_blocks + (unsigned)patch_blocks), dim3(kBlock), lds, c->stream, K);
     HIPCK(c, hipGetLastError());

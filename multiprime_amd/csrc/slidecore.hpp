@@ -58,6 +58,7 @@ constexpr int kSlOrAndNot = slide_lut([](bool a, bool b, bool c) { return a || (
 constexpr int kSlAndNotNot = slide_lut([](bool a, bool b, bool c) { return a && !b && !c; });
 constexpr int kSlOrNot = slide_lut([](bool a, bool b, bool) { return a || !b; });                         // a | ~b
 constexpr int kSlOrOrNot = slide_lut([](bool a, bool b, bool c) { return a || b || !c; });               // a | b | ~c
+constexpr int kSlXorAndNot = slide_lut([](bool a, bool b, bool c) { return a != (b && !c); });         // a ^ (b & ~c)
 
 SLIDE_HD int slide_popc(uint32_t x) {
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -96,7 +97,21 @@ struct SlideArgs {
     int k, p0, ns;
     uint32_t spos, fmask, rmask;
     uint32_t row_scale;                // plane row -> what Env::fetch takes (bytes of a plane row on the GPU, 1 in the emulation)
+    uint32_t fpos, rpos;               // FAST strict form (slide_strict_lists): up to three forward / reverse strict positions, 5 bits each, their number << 15
 };
+
+// The strict positions of a launch as two lists (forward, reverse) of at most three positions each — what `-c` gives by default (V20:85:
+// "1,2,-1").  False when a side has more: the launch keeps the per-position form.
+inline bool slide_strict_lists(int k, uint32_t sF, uint32_t sR, uint32_t &fpos, uint32_t &rpos) {
+    fpos = rpos = 0u;
+    uint32_t nf = 0, nr = 0;
+    for (int j = 0; j < k && j < 32; j++) {
+        if ((sF >> j) & 1u) { if (nf == 3) return false; fpos |= (uint32_t)j << (5 * nf++); }
+        if ((sR >> j) & 1u) { if (nr == 3) return false; rpos |= (uint32_t)j << (5 * nr++); }
+    }
+    fpos |= nf << 15; rpos |= nr << 15;
+    return true;
+}
 
 // The planes an item needs beyond the sliding count: its event planes (entries 1 .. n_slots - 1) and the rows its window lets the
 // column-plane pass count.  Requested one item AHEAD of their use (slide_band), so that an item's memory latency hides behind the
@@ -120,7 +135,14 @@ SLIDE_HD void slide_request(Env &env, const typename Env::Rec &rec, SlideFetch<G
 // One item: all eight member slots, straight-line (a slot the item does not have repeats the counts of the one before it — its plane
 // is the all-zero row — and reports to nobody).  SIMPLE (the host's flag; every chain of a refinement run has it): every event plane is
 // the plane of a base beyond the reference — no per-plane masks in the carry-save sum.
-template <int LV, int GW, bool SIMPLE, bool USE_VALID, bool NO_EXTRA, class Env>
+// FAST (simple items of a launch with at most three strict positions per side): `sv` does not hold the reference's mismatch words position by
+// position but, per side, their SUM over the side's strict positions as a two-bit bit-sliced count (sv[0], sv[1]: forward; sv[2], sv[3]:
+// reverse; slide_band computes them once per window).  An event at a strict position is the plane of a base the most degenerate member
+// accepts there: its rows mismatch the reference at that position (they are in the count) and must not — one decrement of the count, two
+// instructions per word and side, for the flagged events only.  A row is out by its strict positions when the count is not zero.  (The
+// per-position form builds, per strict position with an event, the union of its event planes by seven masked ORs: with seven events per
+// item and six strict positions of eighteen, two positions of six take that path — ~52 vector instructions per item against ~17 here.)
+template <int LV, int GW, bool SIMPLE, bool USE_VALID, bool NO_EXTRA, bool FAST, class Env>
 SLIDE_HD void slide_item(Env &env, const SlideArgs &A, const typename Env::Rec &rec, uint32_t hdr, const SlideCount (&cnt)[GW],
                          const uint32_t (&sv)[kSlideStrict][GW], const SlideFetch<GW> &F, uint32_t (&accPF)[8], uint32_t (&accR)[4]) {
     const int n_extra = (int)((hdr >> 8) & 15u);
@@ -176,8 +198,28 @@ SLIDE_HD void slide_item(Env &env, const SlideArgs &A, const typename Env::Rec &
     // position takes back (they carry a base the member accepts)
     // (DF |= word & ~(x | ~fF): with no event plane at the position — the usual case — x is nothing and ~fF a launch constant in a
     // scalar register, so a position costs one instruction per word and set, and the ring's words are never copied)
+    uint32_t cF0[GW], cF1[GW], cR0[GW], cR1[GW];
+    if (FAST) {
+        static_assert(!FAST || SIMPLE, "the two-bit strict counts take back SUB planes only");
+#pragma unroll
+        for (int i = 0; i < GW; i++) { cF0[i] = sv[0][i]; cF1[i] = sv[1][i]; cR0[i] = sv[2][i]; cR1[i] = sv[3][i]; }
+#pragma unroll
+        for (int s = 1; s <= kSlideKept; s++) {
+            if (SLIDE_UNLIKELY(((flags >> s) & 0x101u) != 0u)) {
+                if ((flags >> s) & 1u) {
+#pragma unroll
+                    for (int i = 0; i < GW; i++) { cF1[i] = bop<kSlXorAndNot>(cF1[i], F.d[s][i], cF0[i]); cF0[i] ^= F.d[s][i]; }
+                }
+                if ((flags >> (8 + s)) & 1u) {
+#pragma unroll
+                    for (int i = 0; i < GW; i++) { cR1[i] = bop<kSlXorAndNot>(cR1[i], F.d[s][i], cR0[i]); cR0[i] ^= F.d[s][i]; }
+                }
+            }
+        }
+    }
 #pragma unroll
     for (int q = 0; q < kSlideStrict; q++) {
+        if (FAST) break;
         if (q >= 4 && A.ns <= 4) break;
         const uint32_t sm = ((q < 4 ? sm_lo : sm_hi) >> (8 * (q & 3))) & 255u;
         const uint32_t nfF = ~(uint32_t)((int32_t)(A.fmask << (31 - q)) >> 31), nfR = ~(uint32_t)((int32_t)(A.rmask << (31 - q)) >> 31);
@@ -212,8 +254,14 @@ SLIDE_HD void slide_item(Env &env, const SlideArgs &A, const typename Env::Rec &
         const uint32_t far = LV == 1 ? t1 : (LV == 2 ? t2 : (LV == 3 ? t3 : hi));
         T[0][i] = USE_VALID ? bop<kSlOrNot>(t1, F.valid[i], 0u) : t1;   // t1 | ~valid
         T[1][i] = t2; T[2][i] = t3; T[3][i] = hi;
-        DF[i] = USE_VALID ? bop<kSlOrOrNot>(DF[i], far, F.valid[i]) : (DF[i] | far);
-        DR[i] = USE_VALID ? bop<kSlOrOrNot>(DR[i], far, F.valid[i]) : (DR[i] | far);
+        if (FAST && !USE_VALID) {
+            DF[i] = bop<kSlOr3>(cF0[i], cF1[i], far);
+            DR[i] = bop<kSlOr3>(cR0[i], cR1[i], far);
+        } else {
+            if (FAST) { DF[i] = cF0[i] | cF1[i]; DR[i] = cR0[i] | cR1[i]; }
+            DF[i] = USE_VALID ? bop<kSlOrOrNot>(DF[i], far, F.valid[i]) : (DF[i] | far);
+            DR[i] = USE_VALID ? bop<kSlOrOrNot>(DR[i], far, F.valid[i]) : (DR[i] | far);
+        }
     }
     // (c) walk down the chain: event plane s, then member slot s is counted.  Counts leave in the layout the wave sums want:
     // accPF[s] = out1 | outF << 16, accR[s / 2] = outR of an even slot | outR of the odd one << 16
@@ -326,9 +374,11 @@ SLIDE_HD void slide_warm_chunk(Env &env, SlideCount (&cnt)[GW], int &slot, int j
 // USE_VALID false (the GPU kernel): every row of a window is counted as its plain column slice — rows with more than v gaps or past the
 // alignment's end never reach a count anyway (a gap mismatches everything), and what the caller must NOT count as a plain slice (edge-
 // gap repaired rows, IUPAC rows) it takes back itself (eval.hip: the subtracting run on the plain-slice planes of the patch list).
-template <int LV, int GW, bool ONLY_SIMPLE, bool USE_VALID, class Env>
+// FAST: the strict positions as two-bit counts per side (slide_item); needs ONLY_SIMPLE and A.fpos / A.rpos (slide_strict_lists).
+template <int LV, int GW, bool ONLY_SIMPLE, bool USE_VALID, bool FAST = false, class Env>
 SLIDE_HD void slide_band(Env &env, const SlideArgs &A, int band_index) {
     static_assert(LV >= 1 && LV <= 4 && GW >= 1 && GW <= 4, "counter levels / words per lane");
+    static_assert(!FAST || ONLY_SIMPLE, "FAST strict counts: simple items only");
     const SlideBand bd = env.uband(band_index);
     const int k = A.k;
     SlideCount cnt[GW];
@@ -370,8 +420,8 @@ SLIDE_HD void slide_band(Env &env, const SlideArgs &A, int band_index) {
         slide_request<GW, USE_VALID>(env, rec_other, F_other);                    // (behind the band's last item: that item's again, unused)
         const uint32_t hdr = env.rec_word(rec, 0);
         uint32_t accPF[8], accR[4];
-        if (ONLY_SIMPLE || (hdr & kSlSimple)) slide_item<LV, GW, true, USE_VALID, ONLY_SIMPLE>(env, A, rec, hdr, cnt, sv, F_cur, accPF, accR);
-        else slide_item<LV, GW, false, USE_VALID, false>(env, A, rec, hdr, cnt, sv, F_cur, accPF, accR);
+        if (ONLY_SIMPLE || (hdr & kSlSimple)) slide_item<LV, GW, true, USE_VALID, ONLY_SIMPLE, FAST>(env, A, rec, hdr, cnt, sv, F_cur, accPF, accR);
+        else slide_item<LV, GW, false, USE_VALID, false, false>(env, A, rec, hdr, cnt, sv, F_cur, accPF, accR);
         env.commit(done, accPF, accR);
         done++;
     };
@@ -394,8 +444,36 @@ SLIDE_HD void slide_band(Env &env, const SlideArgs &A, int band_index) {
         // mismatch words of the reference at the strict positions of this window, out of the ring (slots beyond the launch's strict
         // positions read position 0 and meet empty masks)
         uint32_t sv[kSlideStrict][GW];
+        if (FAST) {
+            // the reference's mismatch words at the side's (up to three) strict positions, summed: bit 0 = xor3, bit 1 = majority
+            uint32_t p[2][3][GW];
+#pragma unroll
+            for (int side = 0; side < 2; side++) {
+                const uint32_t pos = side ? A.rpos : A.fpos;
+                const int n = (int)(pos >> 15);
+#pragma unroll
+                for (int q = 0; q < 3; q++) {
+                    if (SLIDE_UNLIKELY(q >= n)) {
+#pragma unroll
+                        for (int i = 0; i < GW; i++) p[side][q][i] = 0u;
+                    } else {
+                        int s = slot_now + 1 + (int)((pos >> (5 * q)) & 31u);
+                        if (s >= k) s -= k;
+                        env.ring_read(s, p[side][q]);
+                    }
+                }
+            }
+#pragma unroll
+            for (int side = 0; side < 2; side++)
+#pragma unroll
+                for (int i = 0; i < GW; i++) {
+                    sv[2 * side][i] = bop<kSlXor3>(p[side][0][i], p[side][1][i], p[side][2][i]);
+                    sv[2 * side + 1][i] = bop<kSlMaj>(p[side][0][i], p[side][1][i], p[side][2][i]);
+                }
+        }
 #pragma unroll
         for (int q = 0; q < kSlideStrict; q++) {
+            if (FAST) break;
             if (q < 4 || A.ns > 4) {
                 int s = slot_now + 1 + (int)((A.spos >> (5 * q)) & 31u);
                 if (s >= k) s -= k;

@@ -250,7 +250,7 @@ def test_candidate_grouping_paths_match_oracle(hip_lib, oracle_lib, monkeypatch,
     settings = [{}, {"MP_EVAL_GROUP": "plain"}, {"MP_EVAL_GROUP": "nested"}, {"MP_EVAL_BITS": "1"}, {"MP_EVAL_BITS": "2"},
                 {"MP_EVAL_CHAIN": "0"}, {"MP_EVAL_CHAIN": "3"}, {"MP_EVAL_CHAIN": "5"}, {"MP_EVAL_CHAIN": "7"},
                 {"MP_EVAL_MODE": "rows"}, {"MP_EVAL_SLIDE": "1"}, {"MP_EVAL_SLIDE": "1", "MP_SLIDE_GW": "1", "MP_SLIDE_BAND": "5"},
-                {"MP_EVAL_SLIDE": "1", "MP_SLIDE_GW": "4", "MP_SLIDE_BAND": "64"}, {"MP_EVAL_PROG": "1"},
+                {"MP_EVAL_SLIDE": "1", "MP_SLIDE_GW": "4", "MP_SLIDE_BAND": "64"}, {"MP_EVAL_SLIDE": "1", "MP_SLIDE_STRICT": "0"}, {"MP_EVAL_PROG": "1"},
                 {"MP_EVAL_PROG": "1", "MP_EVAL_CHAIN": "3"}, {"MP_EVAL_PROG": "1", "MP_EVAL_CHAIN": "7"},
                 {"MP_EVAL_PROG": "1", "MP_EVAL_CHAIN": "10"}, {"MP_EVAL_PROG": "1", "MP_EVAL_CHAIN": "11"}, {"MP_EVAL_PROG": "1", "MP_EVAL_CHAIN": "12"}]
     for env in settings:
@@ -329,6 +329,47 @@ def test_kernel_shapes_and_extreme_k(hip_lib, oracle_lib, monkeypatch, n, k, v):
                     m.setenv(key, val)
                 got = hip.eval_candidates(cw, codes, sF, sR)
             assert np.array_equal(got, want), f"{kind} counters differ with {env or 'defaults'}"
+
+
+@pytest.mark.parametrize("strict_f,strict_r", [((), ()), ((0,), (17,)), ((1, 2, 17), (0, 15, 16)), ((2, 3, 5), (2, 3, 5)), ((16, 17), (0, 1, 2)),
+                                               ((1, 2, 3, 4), (2,)), ((3,), (0, 4, 9, 16)), ((0, 1, 2), ())])
+@pytest.mark.parametrize("n,v", [(2100, 1), (9000, 2), (700, 0), (5000, 3)])
+def test_sliding_kernel_strict_position_forms_match_oracle(hip_lib, oracle_lib, monkeypatch, n, v, strict_f, strict_r):
+    """[r6] The sliding kernel keeps a launch's strict positions as a two-bit count per side when a side has at most three of them (the reference's
+    default `-c 1,2,-1`, V20:85; slidecore.hpp FAST), position by position otherwise (or with MP_SLIDE_STRICT=0): no, one, two, three positions per
+    side, the same positions on both sides, four on a side (the per-position form), chains that widen AT the strict positions (every event there is
+    a take-back of the count) — every form and band shape against the oracle."""
+    L, k, p0 = 110, 18, 2
+    data, off, _ = fuzz_msa(4242 + n + v, n, L, ragged=False, p_gap=0.03, p_iupac=0.002)
+    W = L - p0 - k - 3
+    rng = np.random.default_rng(n * 13 + v + 101 * len(strict_f) + 7 * len(strict_r))
+    root = np.array([1, 2, 4, 8], np.uint8)[rng.integers(0, 4, size=L)]
+    strict = sorted(set(strict_f) | set(strict_r))
+    cw, codes = [], []
+    for w in range(W):
+        for _ in range(int(rng.integers(1, 3))):
+            cur = root[w: w + k].copy()
+            chain = [cur.copy()]
+            for _ in range(int(rng.integers(1, 8))):
+                at_strict = strict and rng.random() < 0.6                   # most steps widen a strict position
+                cur[int(rng.choice(strict)) if at_strict else int(rng.integers(0, k))] |= np.uint8(1 << rng.integers(0, 4))
+                chain.append(cur.copy())
+            chain.reverse()                                                 # most degenerate member first, as refinement chains come
+            cw += [w] * len(chain)
+            codes += chain
+    cw, codes = np.asarray(cw, np.int32), np.asarray(codes, np.uint8)
+    sF, sR = sum(1 << y for y in strict_f), sum(1 << y for y in strict_r)
+    hip, ora = both(hip_lib, oracle_lib, data, off)
+    for c in (hip, ora):
+        c.build_windows(p0, W, k, v)
+    want = ora.eval_candidates(cw, codes, sF, sR)
+    for env in ({"MP_EVAL_SLIDE": "1"}, {"MP_EVAL_SLIDE": "1", "MP_SLIDE_STRICT": "0"}, {"MP_EVAL_SLIDE": "1", "MP_SLIDE_GW": "1", "MP_SLIDE_BAND": "7"},
+                {"MP_EVAL_SLIDE": "1", "MP_SLIDE_GW": "4", "MP_SLIDE_BAND": "40"}, {}):
+        with monkeypatch.context() as m:
+            for key, val in env.items():
+                m.setenv(key, val)
+            got = hip.eval_candidates(cw, codes, sF, sR)
+        assert np.array_equal(got, want), f"counters differ with {env or 'defaults'}"
 
 
 @pytest.mark.parametrize("n,v,kind", [(300, 1, "up"), (9000, 1, "mixed"), (40000, 2, "mixed")])

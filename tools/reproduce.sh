@@ -86,6 +86,14 @@ streams)         # one stream (rotating launches) against two (mp_eval_launch_al
 import json, sys
 d = json.loads(sys.stdin.read()); print('share ${share:-1x1} streams $st ms_per_step %.5f kernel_ms %.5f' % (d['ms_per_step'], d['roofline']['kernel_ms']))"
   done; done; done 2>&1 | tee $O/streams.txt ;;
+strict_ab)       # profiles/r06_strict_forms.txt: the sliding kernel's strict positions as two-bit counts per side against position by position (MP_SLIDE_STRICT=0)
+  timeout 900 python -m pytest tests/test_hip_parity.py -q -m gpu -x -k "strict_position or grouping_paths or kernel_shapes" 2>&1 | tail -4 | tee $O/pytest.txt
+  for rep in 1 2 3; do for st in 0 1; do
+    MP_SLIDE_STRICT=$st timeout 300 python bench.py --steps 80 --warmup 6 --no-variants --no-pipeline --no-side --no-ksweep --no-shard --no-cpu 2>/dev/null | tail -1 | python -c "
+import json, sys
+d = json.loads(sys.stdin.read()); print('MP_SLIDE_STRICT=$st ms_per_step %.5f one_stream %.5f kernel_ms %.5f' % (d['ms_per_step'], d.get('ms_per_step_one_stream', 0), d['roofline']['kernel_ms']))"
+  done; done 2>&1 | tee $O/strict_forms.txt
+  timeout 600 python bench.py --steps 20 --warmup 5 --no-variants --no-pipeline --no-side --no-ksweep --no-shapes 2> $O/bench.err | tail -1 | tee $O/bench_parity.json ;;
 bench_default)   # profiles/r06_bench.json + r06_bench_detail.json: `python bench.py` with the driver's flags, wall time, the blocks of the detail file in short
   SECONDS=0; python bench.py --gpus 1 --steps 20 --warmup 5 > $O/bench.txt 2> $O/bench.err; echo "rc=$? wall=${SECONDS}s"; tail -c 300 $O/bench.err
   tail -1 $O/bench.txt > $O/bench.json; cp bench_detail.json $O/bench_detail.json; wc -c $O/bench.json; cat $O/bench.json

@@ -176,13 +176,16 @@ static void brute(const Case &C, std::vector<long long> &out) {
 }
 
 template <int LV, int GW>
-static void run_plan(const Case &C, const SlidePlan &P, std::vector<long long> &out, bool only_simple, bool use_valid) {
+static void run_plan(const Case &C, const SlidePlan &P, std::vector<long long> &out, bool only_simple, bool use_valid, bool fast) {
     out.assign(C.members.size() * 3, 0);
-    SlideArgs A{P.bands.data(), P.iters.data(), P.recs.data(), P.k, C.p0, P.ns, P.spos, P.fmask, P.rmask, 1u};
+    SlideArgs A{P.bands.data(), P.iters.data(), P.recs.data(), P.k, C.p0, P.ns, P.spos, P.fmask, P.rmask, 1u, 0u, 0u};
+    if (fast && (!only_simple || !slide_strict_lists(C.k, C.sF, C.sR, A.fpos, A.rpos))) { fprintf(stderr, "fast form asked for a plan it does not serve\n"); exit(3); }
     for (size_t b = 0; b < P.bands.size(); b++)
         for (int w0 = 0; w0 < C.nw32; w0 += GW) {
             HostEnv<GW> env(C, P, w0, out);
-            if (!use_valid) slide_band<LV, GW, true, false>(env, A, (int)b);
+            if (fast && !use_valid) slide_band<LV, GW, true, false, true>(env, A, (int)b);          // the GPU kernel's form
+            else if (fast) slide_band<LV, GW, true, true, true>(env, A, (int)b);
+            else if (!use_valid) slide_band<LV, GW, true, false>(env, A, (int)b);
             else if (only_simple) slide_band<LV, GW, true, true>(env, A, (int)b);
             else slide_band<LV, GW, false, true>(env, A, (int)b);
         }
@@ -191,7 +194,7 @@ static void run_plan(const Case &C, const SlidePlan &P, std::vector<long long> &
 int main(int argc, char **argv) {
     const int trials = argc > 1 ? atoi(argv[1]) : 300;
     std::mt19937 rng(argc > 2 ? (unsigned)atoi(argv[2]) : 12345u);
-    int slid = 0, refused = 0;
+    int slid = 0, refused = 0, n_fast = 0;
     long long items_slid = 0, items_rest = 0;
     for (int trial = 0; trial < trials; trial++) {
         Case C;
@@ -206,17 +209,24 @@ int main(int argc, char **argv) {
         if (!build_slide_plan(C.chains, C.events, C.cand_out, C.k, C.sF, C.sR, C.p0, C.n_cols, B, 1u, only_simple, P)) { refused++; continue; }
         P.iters.resize(P.iters.size() + 64, 0u);                          // as upload_eval_slide pads it
         slid++;
-        std::vector<long long> want, got;
+        std::vector<long long> want, got, got_fast;
         brute(C, want);
         const int gw = 1 << (int)(rng() % 3);
-#define RUN(LV) (gw == 1 ? run_plan<LV, 1>(C, P, got, only_simple, use_valid) : (gw == 2 ? run_plan<LV, 2>(C, P, got, only_simple, use_valid) : run_plan<LV, 4>(C, P, got, only_simple, use_valid)))
-        switch (C.v) {
-            case 0: RUN(1); break;
-            case 1: RUN(2); break;
-            case 2: RUN(3); break;
-            default: RUN(4); break;
+        // the strict positions as two-bit counts per side (slidecore.hpp FAST): wherever that form applies it runs too, beside the per-position form
+        uint32_t fp, rp;
+        const bool fast = only_simple && slide_strict_lists(C.k, C.sF, C.sR, fp, rp);
+#define RUN(LV, G, F) (gw == 1 ? run_plan<LV, 1>(C, P, G, only_simple, use_valid, F) : (gw == 2 ? run_plan<LV, 2>(C, P, G, only_simple, use_valid, F) : run_plan<LV, 4>(C, P, G, only_simple, use_valid, F)))
+        for (int f = 0; f <= (fast ? 1 : 0); f++) {
+            std::vector<long long> &g = f ? got_fast : got;
+            switch (C.v) {
+                case 0: RUN(1, g, f); break;
+                case 1: RUN(2, g, f); break;
+                case 2: RUN(3, g, f); break;
+                default: RUN(4, g, f); break;
+            }
         }
 #undef RUN
+        if (fast) { n_fast++; if (got_fast != got) { fprintf(stderr, "trial %d: k=%d v=%d sF=%x sR=%x: the two strict forms differ\n", trial, C.k, C.v, C.sF, C.sR); return 1; } }
         // candidates of the items the builder left to the first-pass kernels are not the plan's to count
         for (size_t ci = 0; ci < C.chains.size(); ci++) {
             if (P.slides[ci]) { items_slid++; continue; }
@@ -235,7 +245,7 @@ int main(int argc, char **argv) {
             return 1;
         }
     }
-    printf("slide_emul: %d cases equal to brute force (%lld items slid, %lld left to the first-pass kernels), %d cases without a plan\n", slid,
-           items_slid, items_rest, refused);
+    printf("slide_emul: %d cases equal to brute force (%lld items slid, %lld left to the first-pass kernels; %d cases also in the two-bit strict form), %d cases without a plan\n",
+           slid, items_slid, items_rest, n_fast, refused);
     return slid > 0 ? 0 : 2;
 }
