@@ -267,20 +267,6 @@ def main():
     comm_info = None
     if world > 1:
         comm_info = {"backend": backend, "torch_world": dist.get_world_size()}
-        if backend == "nccl":
-            try:
-                raw = ctx.comm_unique_id() if rank == 0 else bytes(128)
-                box = torch.frombuffer(bytearray(raw), dtype=torch.uint8).to(dev)
-                dist.broadcast(box, src=0)
-                ctx.comm_init(world, rank, bytes(box.cpu().numpy().tobytes()))
-                seen = ctx.comm_describe()
-                one = ctx.comm_sum(np.ones(1, np.int64))
-                comm_info.update({"rccl_ranks_seen": seen[0], "rccl_rank": seen[1], "rccl_library": seen[2],
-                                  "sum_of_ones": int(one[0])})
-                ctx.comm_destroy()
-            except Exception as e:                                      # reported, not fatal: the timed steps above ran on torch's RCCL
-                comm_info["library_communicator_error"] = str(e)
-
     # measured device-copy bandwidth (SURVEY §8d asks for it next to the spec peak): 1 GiB d2d, read + write
     copy_gbs = None
     if rank == 0:
@@ -426,6 +412,30 @@ def main():
                 res["parity_checked"] = False
         except Exception as e:                  # noqa: BLE001 — a side measurement must not take the headline line with it
             res["side_steps"] = {"error": f"{type(e).__name__}: {e}"}
+    # N > 1: what the communicator itself says, through a communicator of the library's own (csrc/comm.hip) — AFTER everything the headline needs
+    # exists, and under a watchdog: this path has only ever run on stand-ins (gloo ranks, the shared-memory stub of librccl), a communicator
+    # that never answers must not take the measured line with it.  After 120 s rank 0 prints the line without it and every rank leaves.
+    if world > 1 and backend == "nccl" and os.environ.get("MP_BENCH_LIBCOMM", "1") != "0":
+        def give_up():
+            if rank == 0:
+                comm_info["library_communicator_error"] = "no answer within 120 s"
+                emit(res)
+            os._exit(0)
+        dog = threading.Timer(120.0, give_up)
+        dog.daemon = True
+        dog.start()
+        try:
+            raw = ctx.comm_unique_id() if rank == 0 else bytes(128)
+            box = torch.frombuffer(bytearray(raw), dtype=torch.uint8).to(dev)
+            dist.broadcast(box, src=0)
+            ctx.comm_init(world, rank, bytes(box.cpu().numpy().tobytes()))
+            seen = ctx.comm_describe()
+            one = ctx.comm_sum(np.ones(1, np.int64))
+            comm_info.update({"rccl_ranks_seen": seen[0], "rccl_rank": seen[1], "rccl_library": seen[2], "sum_of_ones": int(one[0])})
+            ctx.comm_destroy()
+        except Exception as e:                                      # noqa: BLE001 — reported, not fatal: the timed steps ran on torch's RCCL
+            comm_info["library_communicator_error"] = str(e)
+        dog.cancel()
     progress("emit")
     if rank == 0:
         emit(res)

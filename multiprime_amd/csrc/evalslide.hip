@@ -111,7 +111,17 @@ struct DevEnv {
             d[0] = __builtin_amdgcn_raw_buffer_load_b32(rs, voff, soff, 0);
         }
     }
-    __device__ __forceinline__ void fetch(uint32_t row_off, uint32_t (&d)[GW]) const { load(rs_cols, (int)row_off, d); }
+    // SLIDE_EXP_ONE_ROW (experiment builds, tools/build_variant.sh; the results are WRONG, timing only): 1 = every plane fetch reads plane row 0
+    // (cache hits only), 2 = the items' event planes only, 3 = the reference columns only
+#ifndef SLIDE_EXP_ONE_ROW
+#define SLIDE_EXP_ONE_ROW 0
+#endif
+    __device__ __forceinline__ void fetch(uint32_t row_off, uint32_t (&d)[GW]) const {
+        load(rs_cols, SLIDE_EXP_ONE_ROW == 1 || SLIDE_EXP_ONE_ROW == 3 ? 0 : (int)row_off, d);
+    }
+    __device__ __forceinline__ void fetch_event(uint32_t row_off, uint32_t (&d)[GW]) const {
+        load(rs_cols, SLIDE_EXP_ONE_ROW == 1 || SLIDE_EXP_ONE_ROW == 2 ? 0 : (int)row_off, d);
+    }
     __device__ __forceinline__ void valid_of(uint32_t row_off, uint32_t (&v)[GW]) const {
         load(rs_excl, (int)row_off, v);
 #pragma unroll

@@ -129,7 +129,7 @@ template <int GW, bool USE_VALID, class Env>
 SLIDE_HD void slide_request(Env &env, const typename Env::Rec &rec, SlideFetch<GW> &F) {
     if (USE_VALID) env.valid_of(env.rec_word(rec, 29), F.valid);
 #pragma unroll
-    for (int s = 1; s <= kSlideKept; s++) env.fetch(env.rec_word(rec, s), F.d[s]);
+    for (int s = 1; s <= kSlideKept; s++) env.fetch_event(env.rec_word(rec, s), F.d[s]);
 }
 
 // One item: all eight member slots, straight-line (a slot the item does not have repeats the counts of the one before it — its plane
@@ -362,6 +362,7 @@ SLIDE_HD void slide_warm_chunk(Env &env, SlideCount (&cnt)[GW], int &slot, int j
 //   uband(b) -> SlideBand; load_iters(idx) then iter_word(j) = iteration word idx + j, j < 64             wave-uniform values
 //   Rec, load_rec(item) -> Rec, rec_word(rec, q) (q a constant), rec_word_dyn(rec, q)                      an item's record
 //   fetch(plane_row x row_scale, d)    the lane's words of column plane row `plane_row` (= column * 4 + base)
+//   fetch_event(...)                   the same for an item's event planes (one function in every product build)
 //   valid_of(window x row_scale, v)    rows the column-plane pass may count for this window
 //   ring_zero(k); ring_write(slot, in); ring_read(slot, out)
 //   progress(quarter)                  quarters of the band behind the wave (a hint for the issue priority)

@@ -94,6 +94,31 @@ import json, sys
 d = json.loads(sys.stdin.read()); print('MP_SLIDE_STRICT=$st ms_per_step %.5f one_stream %.5f kernel_ms %.5f' % (d['ms_per_step'], d.get('ms_per_step_one_stream', 0), d['roofline']['kernel_ms']))"
   done; done 2>&1 | tee $O/strict_forms.txt
   timeout 600 python bench.py --steps 20 --warmup 5 --no-variants --no-pipeline --no-side --no-ksweep --no-shapes 2> $O/bench.err | tail -1 | tee $O/bench_parity.json ;;
+exp_libs)        # A/B of experiment builds: tools/reproduce.sh exp_libs TAG... (tools/_build/libmprime_hip_TAG.so; `product` = the tree's library), 3 interleaved repetitions
+  for rep in 1 2 3; do for tag in "$@"; do
+    lib=$PWD/tools/_build/libmprime_hip_$tag.so; [ $tag = product ] && lib=$PWD/multiprime_amd/csrc/libmprime_hip.so
+    MPRIME_LIBRARY=$lib MP_HOST_LIB=$lib MP_BENCH_STREAMS=1 timeout 300 python bench.py --steps 80 --warmup 6 --no-variants --no-pipeline --no-side --no-ksweep --no-shard --no-cpu 2>/dev/null | tail -1 | python -c "
+import json, sys
+d = json.loads(sys.stdin.read()); print('$tag ms_per_step %.5f kernel_ms %.5f' % (d['ms_per_step'], d['roofline']['kernel_ms']))"
+  done; done 2>&1 | tee $O/exp_libs.txt
+  timeout 600 python -m pytest tests/test_hip_parity.py -q -m gpu -x -k "strict_position or grouping_paths" 2>&1 | tail -2 | tee -a $O/exp_libs.txt ;;
+exp_rows)        # profiles/r06_exp_one_row.txt: experiment builds of the sliding kernel (tools/build_variant.sh rowN evalslide.hip -DSLIDE_EXP_ONE_ROW=N; wrong results, timing only)
+  for rep in 1 2; do for tag in product row1 row2 row3; do
+    lib=$PWD/tools/_build/libmprime_hip_$tag.so; [ $tag = product ] && lib=$PWD/multiprime_amd/csrc/libmprime_hip.so
+    MPRIME_LIBRARY=$lib MP_HOST_LIB=$lib MP_BENCH_STREAMS=1 timeout 300 python bench.py --steps 80 --warmup 6 --no-variants --no-pipeline --no-side --no-ksweep --no-shard --no-cpu 2>/dev/null | tail -1 | python -c "
+import json, sys
+d = json.loads(sys.stdin.read()); print('$tag ms_per_step %.5f kernel_ms %.5f' % (d['ms_per_step'], d['roofline']['kernel_ms']))"
+  done; done 2>&1 | tee $O/exp_one_row.txt
+  for st in 1 0; do
+    MP_SLIDE_STRICT=$st timeout 900 python tools/collect_counters.py --rows 1048576 --out $O/prof_strict$st > $O/collect_strict$st.log 2>&1
+    python -c "
+import json
+d = json.load(open('$O/prof_strict$st/counters.json'))
+for e in d['entries']:
+    print('MP_SLIDE_STRICT=$st', 'trace', e.get('trace'), 'raw', {k: round(v) for k, v in e.get('raw_counters_per_launch', {}).items()})
+" 2>&1 | tee -a $O/exp_one_row.txt
+    rm -rf $O/prof_strict$st/pmc_* $O/prof_strict$st/cal_* $O/prof_strict$st/trace
+  done ;;
 bench_default)   # profiles/r06_bench.json + r06_bench_detail.json: `python bench.py` with the driver's flags, wall time, the blocks of the detail file in short
   SECONDS=0; python bench.py --gpus 1 --steps 20 --warmup 5 > $O/bench.txt 2> $O/bench.err; echo "rc=$? wall=${SECONDS}s"; tail -c 300 $O/bench.err
   tail -1 $O/bench.txt > $O/bench.json; cp bench_detail.json $O/bench_detail.json; wc -c $O/bench.json; cat $O/bench.json

@@ -44,6 +44,7 @@ struct HostEnv {
     void fetch(uint32_t row, uint32_t (&d)[GW]) const {
         for (int i = 0; i < GW; i++) d[i] = word0 + i < C.nw32 ? C.cols[(size_t)row * C.nw32 + (size_t)(word0 + i)] : 0u;
     }
+    void fetch_event(uint32_t row, uint32_t (&d)[GW]) const { fetch(row, d); }
     void valid_of(uint32_t win, uint32_t (&v)[GW]) const {
         for (int i = 0; i < GW; i++) v[i] = word0 + i < C.nw32 ? C.valid[(size_t)win * C.nw32 + (size_t)(word0 + i)] : 0u;
     }
