@@ -100,15 +100,17 @@ struct DevEnv {
         return q < 8 ? r.w[q] : (q == 24 ? r.sm_lo : (q == 25 ? r.sm_hi : (q == 28 ? r.flags : r.p[q])));
     }
     __device__ __forceinline__ uint32_t rec_word_dyn(const Rec &r, int q) const { return r.p[q]; }
+    // AUX: the load's cache policy bits (gfx940+: 1 = sc0, 2 = nt, 16 = sc1)
+    template <int AUX = 0>
     __device__ __forceinline__ void load(__amdgpu_buffer_rsrc_t rs, int soff, uint32_t (&d)[GW]) const {
         if constexpr (GW == 4) {
-            const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rs, voff, soff, 0);
+            const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rs, voff, soff, AUX);
             d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w;
         } else if constexpr (GW == 2) {
-            const u32x2 v = __builtin_amdgcn_raw_buffer_load_b64(rs, voff, soff, 0);
+            const u32x2 v = __builtin_amdgcn_raw_buffer_load_b64(rs, voff, soff, AUX);
             d[0] = v.x; d[1] = v.y;
         } else {
-            d[0] = __builtin_amdgcn_raw_buffer_load_b32(rs, voff, soff, 0);
+            d[0] = __builtin_amdgcn_raw_buffer_load_b32(rs, voff, soff, AUX);
         }
     }
     // SLIDE_EXP_ONE_ROW (experiment builds, tools/build_variant.sh; the results are WRONG, timing only): 1 = every plane fetch reads plane row 0
@@ -116,11 +118,20 @@ struct DevEnv {
 #ifndef SLIDE_EXP_ONE_ROW
 #define SLIDE_EXP_ONE_ROW 0
 #endif
+    // [r6] the reference columns stream through (every word is used once, two iterations after its request): non-temporal, so that they do not push
+    // the items' event planes — wanted again by a window up to k - 1 columns on — out of the XCD's L2.  Measured (profiles/r06_slide_limits.txt):
+    // columns nt 0.1368 ms against 0.1397; event planes nt 0.1438 (they do live on L2 hits); sc1 on the columns: nothing.
+#ifndef SLIDE_COL_AUX
+#define SLIDE_COL_AUX 2
+#endif
+#ifndef SLIDE_EVT_AUX
+#define SLIDE_EVT_AUX 0
+#endif
     __device__ __forceinline__ void fetch(uint32_t row_off, uint32_t (&d)[GW]) const {
-        load(rs_cols, SLIDE_EXP_ONE_ROW == 1 || SLIDE_EXP_ONE_ROW == 3 ? 0 : (int)row_off, d);
+        load<SLIDE_COL_AUX>(rs_cols, SLIDE_EXP_ONE_ROW == 1 || SLIDE_EXP_ONE_ROW == 3 ? 0 : (int)row_off, d);
     }
     __device__ __forceinline__ void fetch_event(uint32_t row_off, uint32_t (&d)[GW]) const {
-        load(rs_cols, SLIDE_EXP_ONE_ROW == 1 || SLIDE_EXP_ONE_ROW == 2 ? 0 : (int)row_off, d);
+        load<SLIDE_EVT_AUX>(rs_cols, SLIDE_EXP_ONE_ROW == 1 || SLIDE_EXP_ONE_ROW == 2 ? 0 : (int)row_off, d);
     }
     __device__ __forceinline__ void valid_of(uint32_t row_off, uint32_t (&v)[GW]) const {
         load(rs_excl, (int)row_off, v);
@@ -339,19 +350,30 @@ int upload_eval_slide(mp_ctx *c, const std::vector<ChainItem> &chains, const std
     // rings' LDS allow four) = 1024 at a time, so 1024 / slices bands; every workgroup does the same work, a second round would
     // only add warm-up columns (0.184 ms with 16 bands of 60 windows against 0.190 with 32 of 30 at 1 048 576 rows).  More rounds
     // when a band would be longer, never bands shorter than 8 windows.
+    // [r6] ... and "resident" is what the rings' LDS allows: k x 64 x GW words per wave.  k = 18 at two words per lane is the last k with FOUR
+    // workgroups per CU (39.7 KB each); from k = 19 on three fit (two from k = 26), and bands sized for 1024 workgroups at a time then ran in a
+    // round and a third — k = 20 took 1.42 x the time of k = 18 (bench_detail k_sweep, 0.185 ms).  The band length follows the residency the
+    // plan's own LDS need allows; a plan is rebuilt when its longest band's table does not fit the residency it was sized for.
     const int span = chains.back().win - chains.front().win + 1;
-    const int per_round = std::max(1, 1024 / std::max(1, wc_pad));
-    int band = (span + per_round - 1) / per_round;
-    for (int r = 2; band > 96; r++) band = (span + per_round * r - 1) / (per_round * r);
-    band = std::max(8, band);
-    if (const char *e = getenv("MP_SLIDE_BAND")) band = std::max(1, atoi(e));
     std::vector<SlideChainIn> in(chains.size());
     for (size_t i = 0; i < chains.size(); i++) {
         const ChainItem &ch = chains[i];
         in[i] = SlideChainIn{ch.win, ch.cand0, ch.n_steps, ch.ev0, ch.n_ev, {ch.sym[0], ch.sym[1], ch.sym[2], ch.sym[3]}};
     }
+    const size_t ring_bytes = (size_t)(kBlock / 64) * ((size_t)c->k * 64 * gw) * sizeof(uint32_t), lds_cu = 160 * 1024;
+    int resident = (int)std::min<size_t>(4, std::max<size_t>(1, lds_cu / (ring_bytes + 1024)));
+    if (gw == 4) resident = 1;                                           // (launch bounds of the four-word form)
     SlidePlan P;
-    if (!build_slide_plan(in, events, cand_out, c->k, (uint32_t)c->sF, (uint32_t)c->sR, c->p0, n_cols, band, (uint32_t)nw32 * 4u, true, P)) return MP_OK;
+    for (;; resident--) {
+        const int per_round = std::max(1, 256 * resident / std::max(1, wc_pad));
+        int band = (span + per_round - 1) / per_round;
+        for (int r = 2; band > 96; r++) band = (span + per_round * r - 1) / (per_round * r);
+        band = std::max(8, band);
+        if (const char *e = getenv("MP_SLIDE_BAND")) band = std::max(1, atoi(e));
+        if (!build_slide_plan(in, events, cand_out, c->k, (uint32_t)c->sF, (uint32_t)c->sR, c->p0, n_cols, band, (uint32_t)nw32 * 4u, true, P)) return MP_OK;
+        const size_t need = ring_bytes + (size_t)P.max_items_band * 12 * sizeof(uint32_t);
+        if (resident <= 1 || need * (size_t)resident <= lds_cu) break;
+    }
     P.iters.resize(P.iters.size() + 64, 0u);                      // uiter reads 64 words at a time
     int rc;
     if ((rc = dev_alloc(c, &c->slide_bands, P.bands.size()))) return rc;

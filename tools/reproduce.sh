@@ -102,6 +102,13 @@ import json, sys
 d = json.loads(sys.stdin.read()); print('$tag ms_per_step %.5f kernel_ms %.5f' % (d['ms_per_step'], d['roofline']['kernel_ms']))"
   done; done 2>&1 | tee $O/exp_libs.txt
   timeout 600 python -m pytest tests/test_hip_parity.py -q -m gpu -x -k "strict_position or grouping_paths" 2>&1 | tail -2 | tee -a $O/exp_libs.txt ;;
+k_sweep)         # bench.py's k_sweep block alone (the headline workload at k = 20, 22, 36), after the headline
+  timeout 900 python bench.py --steps 20 --warmup 5 --no-variants --no-pipeline --no-side --no-shapes 2> $O/bench.err | tail -1 > $O/bench.json; python -c "
+import json
+d = json.load(open('bench_detail.json'))
+print('k_18', d['ms_per_step'], d['roofline']['kernel_ms'], d['parity_checked'])
+for k, v in d.get('k_sweep', {}).items(): print(k, v if not isinstance(v, dict) else {x: v[x] for x in ('kernel_ms', 'evals_per_s', 'eval_mode', 'compulsory_frac', 'parity_checked') if x in v})
+" | tee $O/k_sweep.txt ;;
 exp_rows)        # profiles/r06_exp_one_row.txt: experiment builds of the sliding kernel (tools/build_variant.sh rowN evalslide.hip -DSLIDE_EXP_ONE_ROW=N; wrong results, timing only)
   for rep in 1 2; do for tag in product row1 row2 row3; do
     lib=$PWD/tools/_build/libmprime_hip_$tag.so; [ $tag = product ] && lib=$PWD/multiprime_amd/csrc/libmprime_hip.so
