@@ -20,7 +20,7 @@ from test_hip_parity import chain_candidates, fuzz_msa  # noqa: E402
 
 ENVS = [{}, {"MP_EVAL_GROUP": "plain"}, {"MP_EVAL_GROUP": "nested"}, {"MP_EVAL_BITS": "1"}, {"MP_EVAL_BITS": "2"},
         {"MP_EVAL_CHAIN": "0"}, {"MP_EVAL_CHAIN": "3"}, {"MP_EVAL_CHAIN": "5"}, {"MP_EVAL_CHAIN": "7"}, {"MP_EVAL_CHAIN": "8"},
-        {"MP_EVAL_MODE": "rows"}, {"MP_EVAL_SLIDE": "1"}, {"MP_EVAL_SLIDE": "1", "MP_SLIDE_GW": "1", "MP_SLIDE_BAND": "6"},
+        {"MP_EVAL_MODE": "rows"}, {"MP_EVAL_SLIDE": "1"}, {"MP_EVAL_SLIDE": "1", "MP_SLIDE_STRICT": "0"}, {"MP_EVAL_SLIDE": "1", "MP_SLIDE_GW": "1", "MP_SLIDE_BAND": "6"},
         {"MP_EVAL_SLIDE": "1", "MP_SLIDE_GW": "4", "MP_SLIDE_BAND": "40"}, {"MP_EVAL_PROG": "1"},
         {"MP_EVAL_PROG": "1", "MP_EVAL_CHAIN": "7"}, {"MP_EVAL_PROG": "1", "MP_EVAL_CHAIN": "3"},
         {"MP_EVAL_PROG": "1", "MP_EVAL_CHAIN": "11"}, {"MP_EVAL_PROG": "1", "MP_EVAL_CHAIN": "10"}, {"MP_EVAL_PROG": "1", "MP_EVAL_CHAIN": "12"},
@@ -102,8 +102,12 @@ def main():
                 os.environ.pop(key, None)
             root = np.array([1, 2, 4, 8], np.uint8)[rng.integers(0, 4, size=maxlen + k)]
             cw, codes = chain_candidates(rng, root, W, k, str(rng.choice(["up", "down", "mixed"])))
-            sF = int(rng.integers(0, 1 << k))
-            sR = int(rng.integers(0, 1 << k))
+            if rng.random() < 0.6:          # few strict positions (the reference's -c lists; the sliding kernel's two strict forms: <= 3 per side, <= 6 in all)
+                sF = sum(1 << int(j) for j in set(rng.integers(0, k, size=int(rng.integers(0, 5))).tolist()))
+                sR = sum(1 << int(j) for j in set(rng.integers(0, k, size=int(rng.integers(0, 5))).tolist()))
+            else:                           # any subset of the positions
+                sF = int(rng.integers(0, 1 << k))
+                sR = int(rng.integers(0, 1 << k))
             want = ctxs[1].eval_candidates(cw, codes, sF, sR)
             for env in (ENVS if k <= 31 and v <= 3 else ENVS_X):
                 for key in KEYS:
