@@ -668,7 +668,8 @@ struct StatsArgs {
     const unsigned long long *cols;    // [n_cols][4][nw]
     const unsigned long long *excl;    // [W][nw]
     int nw, p0, k, v;
-    BlockMap map;                      // items = windows
+    BlockMap map;                      // items = windows (window_stats_kernel) or groups of G windows (window_stats_group_kernel)
+    int n_win;
     unsigned long long *freq;          // [W][4][k]
     unsigned long long *nn;            // [W][k-1][16]
     PatchArgs patch;
@@ -685,14 +686,13 @@ __device__ __forceinline__ void stats_flush(const StatsArgs &A, int win, const u
 }
 
 template <int GW>
-__global__ __launch_bounds__(kBlock) void window_stats_kernel(const StatsArgs A) {
-    __shared__ uint32_t s_cnt[MP_MAX_K][20];           // [position][4 base counts, then 16 pair counts (j, j+1)]
+__device__ __forceinline__ void stats_window_body(const StatsArgs &A, uint32_t (*s_cnt)[20]) {
     const bool on_patch = (int)blockIdx.x < A.patch.n_blocks;
     int slice, win;
     if (on_patch) {
         win = blockIdx.x / A.patch.per_item;
         slice = blockIdx.x % A.patch.per_item;
-        if (win >= A.map.n_items) return;
+        if (win >= A.n_win) return;                   // (A.map counts window GROUPS in window_stats_group_kernel)
     } else if (!map_block(A.map, blockIdx.x - A.patch.n_blocks, slice, win)) {
         return;
     }
@@ -751,6 +751,139 @@ __global__ __launch_bounds__(kBlock) void window_stats_kernel(const StatsArgs A)
     }
     __syncthreads();
     stats_flush(A, win, s_cnt);
+}
+
+template <int GW>
+__global__ __launch_bounds__(kBlock) void window_stats_kernel(const StatsArgs A) {
+    __shared__ uint32_t s_cnt[MP_MAX_K][20];           // [position][4 base counts, then 16 pair counts (j, j+1)]
+    stats_window_body<GW>(A, s_cnt);
+}
+
+// Wave totals of 12 registers, TRANSPOSED (the reduction of evalslide.hip's commit: quad-masked DPP adds across the quads of a row, then
+// inside the quads, then v_permlane16/32_swap across the rows — a step that adds partner lanes also halves the registers): 31 instructions
+// instead of 12 x 6 DPP adds.  Afterwards lane L (L < 48, L % 4 == 0) holds the wave's total of register (L >> 4) * 4 + ((L >> 2) & 3).
+__device__ __forceinline__ uint32_t wave_sum12_transposed(uint32_t x0, uint32_t x1, uint32_t x2, uint32_t x3, uint32_t x4, uint32_t x5, uint32_t x6,
+                                                          uint32_t x7, uint32_t x8, uint32_t x9, uint32_t x10, uint32_t x11) {
+    asm volatile(
+        "s_nop 1\n\t"
+        "v_add_u32_dpp %0, %0, %0 row_ror:4 row_mask:0xf bank_mask:0x5\n\t"
+        "v_add_u32_dpp %2, %2, %2 row_ror:4 row_mask:0xf bank_mask:0x5\n\t"
+        "v_add_u32_dpp %4, %4, %4 row_ror:4 row_mask:0xf bank_mask:0x5\n\t"
+        "v_add_u32_dpp %6, %6, %6 row_ror:4 row_mask:0xf bank_mask:0x5\n\t"
+        "v_add_u32_dpp %8, %8, %8 row_ror:4 row_mask:0xf bank_mask:0x5\n\t"
+        "v_add_u32_dpp %10, %10, %10 row_ror:4 row_mask:0xf bank_mask:0x5\n\t"
+        "v_add_u32_dpp %0, %1, %1 row_ror:4 row_mask:0xf bank_mask:0xa\n\t"
+        "v_add_u32_dpp %2, %3, %3 row_ror:4 row_mask:0xf bank_mask:0xa\n\t"
+        "v_add_u32_dpp %4, %5, %5 row_ror:4 row_mask:0xf bank_mask:0xa\n\t"
+        "v_add_u32_dpp %6, %7, %7 row_ror:4 row_mask:0xf bank_mask:0xa\n\t"
+        "v_add_u32_dpp %8, %9, %9 row_ror:4 row_mask:0xf bank_mask:0xa\n\t"
+        "v_add_u32_dpp %10, %11, %11 row_ror:4 row_mask:0xf bank_mask:0xa\n\t"
+        "v_add_u32_dpp %0, %0, %0 row_ror:8 row_mask:0xf bank_mask:0x3\n\t"
+        "v_add_u32_dpp %4, %4, %4 row_ror:8 row_mask:0xf bank_mask:0x3\n\t"
+        "v_add_u32_dpp %8, %8, %8 row_ror:8 row_mask:0xf bank_mask:0x3\n\t"
+        "v_add_u32_dpp %0, %2, %2 row_ror:8 row_mask:0xf bank_mask:0xc\n\t"
+        "v_add_u32_dpp %4, %6, %6 row_ror:8 row_mask:0xf bank_mask:0xc\n\t"
+        "v_add_u32_dpp %8, %10, %10 row_ror:8 row_mask:0xf bank_mask:0xc\n\t"
+        "v_add_u32_dpp %0, %0, %0 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
+        "v_add_u32_dpp %4, %4, %4 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
+        "v_add_u32_dpp %8, %8, %8 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
+        "v_add_u32_dpp %0, %0, %0 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"
+        "v_add_u32_dpp %4, %4, %4 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"
+        "v_add_u32_dpp %8, %8, %8 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"
+        "s_nop 1"
+        : "+v"(x0), "+v"(x1), "+v"(x2), "+v"(x3), "+v"(x4), "+v"(x5), "+v"(x6), "+v"(x7), "+v"(x8), "+v"(x9), "+v"(x10), "+v"(x11));
+    typedef unsigned int u32pair __attribute__((ext_vector_type(2)));
+    const u32pair s01 = __builtin_amdgcn_permlane16_swap(x0, x4, false, false);
+    const uint32_t a = s01.x + s01.y;
+    const u32pair s22 = __builtin_amdgcn_permlane16_swap(x8, x8, false, false);
+    const uint32_t b = s22.x + s22.y;
+    const u32pair h = __builtin_amdgcn_permlane32_swap(a, b, false, false);
+    return h.x + h.y;
+}
+
+// [r6] The same counts for G CONSECUTIVE windows per workgroup: window w uses column w + j at position j, so G neighbouring windows share all but
+// G - 1 of their k + G - 1 columns — the workgroup walks the columns once, every plane word is loaded once and counted under the validity words
+// of the (up to G) windows it belongs to.  The per-window kernel above re-reads every plane k times through L2 (9.4 GB at 10^6 x 1000, k = 18:
+// 2.27 ms with the vector ALUs 46 % busy); here (k + G - 1) / (G k) of that.  The arithmetic per (window, position) is the same 20 AND + popcount
+// pairs (the pair counts as one v_bitop3 a & b & valid each).  Plain rows only: the patch planes keep the kernel above (its patch blocks).
+template <int GW, int G>
+__global__ __launch_bounds__(kBlock) void window_stats_group_kernel(const StatsArgs A) {
+    // per window of the group and position: 10 words of two 16-bit counts (base counts 0-3, pair counts 4-19; a workgroup covers
+    // kBlock x 32 GW <= 32768 rows, so a field never carries) + 2 words of padding (the reduction works on 12 registers)
+    static_assert(kBlock * 32 * GW <= 32768, "two 16-bit counts per word");
+    __shared__ uint32_t s_grp[G][MP_MAX_K][12];
+    __shared__ uint32_t s_one[MP_MAX_K][20];
+    if ((int)blockIdx.x < A.patch.n_blocks) {                       // the patch planes: per window, as before
+        stats_window_body<GW>(A, s_one);
+        return;
+    }
+    int slice, grp;
+    if (!map_block(A.map, blockIdx.x - (unsigned)A.patch.n_blocks, slice, grp)) return;
+    const int w0 = grp * G, n_here = min(G, A.n_win - w0), k = A.k;
+    const int word0 = (slice * kBlock + (int)threadIdx.x) * GW, lane = (int)(threadIdx.x & 63);
+    const size_t nw32 = (size_t)A.nw * 2;
+    const bool live = word0 < (int)nw32;
+    for (int t = threadIdx.x; t < G * MP_MAX_K * 12; t += kBlock) (&s_grp[0][0][0])[t] = 0;
+    __syncthreads();
+    const uint32_t *Pw = reinterpret_cast<const uint32_t *>(A.cols) + ((size_t)(A.p0 + w0) * 4) * nw32 + word0;
+    const uint32_t *Ex = reinterpret_cast<const uint32_t *>(A.excl) + (size_t)w0 * nw32 + word0;
+    uint32_t valid[G][GW], cur[4][GW], nxt[4][GW];
+#pragma unroll
+    for (int g = 0; g < G; g++)
+#pragma unroll
+        for (int i = 0; i < GW; i++) valid[g][i] = (live && g < n_here) ? ~Ex[(size_t)g * nw32 + i] : 0u;
+#pragma unroll
+    for (int b = 0; b < 4; b++)
+#pragma unroll
+        for (int i = 0; i < GW; i++) cur[b][i] = live ? Pw[b * nw32 + i] : 0u;
+    const int n_col = n_here + k - 1;
+    const bool adder = lane < 48 && (lane & 3) == 0;
+    const int my_word = (lane >> 4) * 4 + ((lane >> 2) & 3);
+#pragma unroll 1
+    for (int c = 0; c < n_col; c++) {
+        const bool more = c + 1 < n_col;
+#pragma unroll
+        for (int b = 0; b < 4; b++)
+#pragma unroll
+            for (int i = 0; i < GW; i++) nxt[b][i] = (live && more) ? Pw[((size_t)(c + 1) * 4 + b) * nw32 + i] : 0u;
+#pragma unroll
+        for (int g = 0; g < G; g++) {
+            const int j = c - g;                                   // the column's position in window w0 + g (wave-uniform)
+            if (g >= n_here || j < 0 || j >= k) continue;
+            uint32_t cnt[20];
+#pragma unroll
+            for (int b = 0; b < 4; b++) {
+                cnt[b] = 0;
+#pragma unroll
+                for (int i = 0; i < GW; i++) cnt[b] += __popc(cur[b][i] & valid[g][i]);
+            }
+            // (at the window's last position nxt is the next window's column or zero: those pair counts are never read — stats_flush_packed)
+#pragma unroll
+            for (int a = 0; a < 4; a++)
+#pragma unroll
+                for (int b = 0; b < 4; b++) {
+                    cnt[4 + a * 4 + b] = 0;
+#pragma unroll
+                    for (int i = 0; i < GW; i++) cnt[4 + a * 4 + b] += __popc(__builtin_amdgcn_bitop3_b32(cur[a][i], nxt[b][i], valid[g][i], 0x80));
+                }
+            const uint32_t tot = wave_sum12_transposed(cnt[0] | (cnt[1] << 16), cnt[2] | (cnt[3] << 16), cnt[4] | (cnt[5] << 16), cnt[6] | (cnt[7] << 16),
+                                                       cnt[8] | (cnt[9] << 16), cnt[10] | (cnt[11] << 16), cnt[12] | (cnt[13] << 16), cnt[14] | (cnt[15] << 16),
+                                                       cnt[16] | (cnt[17] << 16), cnt[18] | (cnt[19] << 16), 0u, 0u);
+            if (adder) atomicAdd(&s_grp[g][j][my_word], tot);
+        }
+#pragma unroll
+        for (int b = 0; b < 4; b++)
+#pragma unroll
+            for (int i = 0; i < GW; i++) cur[b][i] = nxt[b][i];
+    }
+    __syncthreads();
+    for (int t = threadIdx.x; t < n_here * k * 20; t += kBlock) {
+        const int g = t / (k * 20), r = t % (k * 20), j = r / 20, q = r % 20, win = w0 + g;
+        const uint32_t val = (s_grp[g][j][q >> 1] >> (16 * (q & 1))) & 0xFFFFu;
+        if (!val) continue;
+        if (q < 4) atomicAdd(&A.freq[((size_t)win * 4 + q) * k + j], (unsigned long long)val);
+        else if (j + 1 < k) atomicAdd(&A.nn[((size_t)win * (k - 1) + j) * 16 + (q - 4)], (unsigned long long)val);
+    }
 }
 
 // Per-sequence coverage masks (mp_eval_masks): thread = sequence, the wave's 64 "not covered" bits
@@ -1562,7 +1695,23 @@ static int window_stats_launch(mp_ctx *c, size_t &n_f, size_t &n_t) {
     const int bands = m.ny_pad >= 8 ? 1 : 8 / m.ny_pad;
     m.per_band = (c->n_win + bands - 1) / bands;
     const unsigned grid = m.ny_pad >= 8 ? (unsigned)((size_t)c->n_win * m.ny_pad) : (unsigned)(8 * (size_t)m.per_band);
-    StatsArgs sa{c->cols, c->excl, nw, c->p0, c->k, c->v, m, d, d + n_f, patch_args(c, GW, c->n_win, kBlock)};
+    StatsArgs sa{c->cols, c->excl, nw, c->p0, c->k, c->v, m, c->n_win, d, d + n_f, patch_args(c, GW, c->n_win, kBlock)};
+    // [r6] the plain rows of G consecutive windows per workgroup (window_stats_group_kernel) where the alignment is deep enough for the
+    // per-window form to be bound by its L2 re-reads; the patch planes stay with the per-window kernel (its patch blocks only then).
+    // MP_STATS_GROUP=0 keeps the per-window kernel for everything, =4 / 8 picks G.
+    int G = GW == 4 ? 4 : 0;
+    if (const char *e = getenv("MP_STATS_GROUP")) { const int g = atoi(e); G = (g == 4 || g == 8) && GW == 4 ? g : 0; }
+    if (G) {
+        const int n_groups = (c->n_win + G - 1) / G;
+        unsigned ggrid;
+        StatsArgs sg = sa;
+        sg.map = make_block_map(nw, GW, n_groups, ggrid);
+        const dim3 gfull(ggrid + (unsigned)sg.patch.n_blocks);          // (the patch blocks first, as in the per-window launch)
+        if (G == 8) hipLaunchKernelGGL((window_stats_group_kernel<4, 8>), gfull, dim3(kBlock), 0, c->stream, sg);
+        else hipLaunchKernelGGL((window_stats_group_kernel<4, 4>), gfull, dim3(kBlock), 0, c->stream, sg);
+        HIPCK(c, hipGetLastError());
+        return MP_OK;
+    }
     const dim3 full(grid + (unsigned)sa.patch.n_blocks);
     if (GW == 4) hipLaunchKernelGGL(window_stats_kernel<4>, full, dim3(kBlock), 0, c->stream, sa);
     else if (GW == 2) hipLaunchKernelGGL(window_stats_kernel<2>, full, dim3(kBlock), 0, c->stream, sa);

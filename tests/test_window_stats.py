@@ -102,3 +102,31 @@ def test_hip_stats_match_oracle(hip_lib, oracle_lib, seed, n, L, ragged, k, v, p
         got.append(ctx.window_stats())
     assert np.array_equal(got[0][0], got[1][0])
     assert np.array_equal(got[0][1], got[1][1])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("seed,n,L,ragged,k,v,p0", [(21, 33000, 70, False, 18, 1, 2), (22, 40000, 90, True, 18, 2, 0), (23, 70000, 58, False, 28, 1, 1),
+                                                    (24, 36000, 64, False, 3, 0, 0), (25, 50000, 100, False, 40, 2, 3)])
+def test_grouped_stats_kernel_matches_oracle(hip_lib, oracle_lib, monkeypatch, seed, n, L, ragged, k, v, p0):
+    """[r6] From 32768 rows on the plain rows' counts come from window_stats_group_kernel — G consecutive windows per workgroup sharing their
+    column loads (G = 4; MP_STATS_GROUP=8 / 0: eight / the per-window kernel): every form against the oracle, window counts that are no multiple
+    of G, k from 3 to 40, ragged rows and patch planes beside them."""
+    data, off = _msa(seed, n, L, ragged)
+    W = (L // 2 if ragged else L) - p0 - k - 2
+    ctx = oracle_lib.context(0)
+    _prepare(ctx, data, off, p0, W, k, v)
+    want = ctx.window_stats()
+    ctx.close()
+    for group in (None, "8", "0"):
+        with monkeypatch.context() as m:
+            if group is not None:
+                m.setenv("MP_STATS_GROUP", group)
+            h = hip_lib.context(0)
+            _prepare(h, data, off, p0, W, k, v)
+            got = h.window_stats()
+            got2 = h.window_stats_begin()
+            h.window_stats_end(*got2)
+            h.close()
+        for a, b, c2 in zip(got, want, got2):
+            assert np.array_equal(a, b), f"MP_STATS_GROUP={group}"
+            assert np.array_equal(c2, b), f"MP_STATS_GROUP={group} (two halves)"

@@ -73,7 +73,7 @@ if a.json and tdb:
         ("hist", N * L * 3 / 8, "SURVEY 8d (ii): the packed planes once (every window re-reads its 8 plane words: 36 B per row and window through L2)"),
         ("table_sums_kernel", W * slots * 12, "every slot's key and count once"),
         ("compact_kernel", W * 0.45 * slots * 16, "the tables of the windows the gate leaves (~45 %) once"),
-        ("window_stats_kernel", N * L * 0.5 + W * N / 8, "column planes and exclusion words once"),
+        ("window_stats", N * L * 0.5 + W * N / 8, "column planes and exclusion words once (window_stats_group_kernel from 32768 rows on)"),
         # the slow (window, row) pairs — edge-gap repair, ragged end, IUPAC: 0.55 % of the pairs of the synthetic alignment
         ("repair_kernel", N * W * 0.0055 * (32 + 8 + 12 + 4), "per slow pair: its 8 plane words, two prefix counts, 3 window words + row out"),
         ("plain_planes_kernel", N * W * 0.0055 * (32 + 18 * 4 / 8.0), "per slow pair: its 8 plane words in, k x 4 plane bits out"),

@@ -102,6 +102,13 @@ import json, sys
 d = json.loads(sys.stdin.read()); print('$tag ms_per_step %.5f kernel_ms %.5f' % (d['ms_per_step'], d['roofline']['kernel_ms']))"
   done; done 2>&1 | tee $O/exp_libs.txt
   timeout 600 python -m pytest tests/test_hip_parity.py -q -m gpu -x -k "strict_position or grouping_paths" 2>&1 | tail -2 | tee -a $O/exp_libs.txt ;;
+stats_ab)        # window statistics: G consecutive windows per workgroup (MP_STATS_GROUP=4 default, 8) against the per-window kernel (=0): tests, kernel trace, run() laps
+  timeout 900 python -m pytest tests/test_window_stats.py tests/test_core_golden.py -q -m gpu -x 2>&1 | tail -3 | tee $O/pytest.txt
+  for g in 0 4 8; do for rows in 131072 1048576; do
+    echo "# MP_STATS_GROUP=$g rows $rows"
+    MP_STATS_GROUP=$g python tools/profile_pipeline.py --rows $rows --out $O/prof_${g}_$rows 2>&1 | grep "window_stats\|^kernel"
+    MP_STATS_GROUP=$g MP_TRACE_PY=1 python tools/profile_run.py $rows 18 2>&1 | grep "^{" | tail -1 | cut -c1-600
+  done; done 2>&1 | tee $O/stats_ab.txt; rm -rf $O/prof_* ;;
 k_sweep)         # bench.py's k_sweep block alone (the headline workload at k = 20, 22, 36), after the headline
   timeout 900 python bench.py --steps 20 --warmup 5 --no-variants --no-pipeline --no-side --no-shapes 2> $O/bench.err | tail -1 > $O/bench.json; python -c "
 import json
