@@ -540,6 +540,12 @@ def supervise(cmd, env=None, out=None, attempts=2):
     rc = 1
     for attempt in range(1, attempts + 1):
         child = subprocess.Popen(cmd, stdout=subprocess.PIPE, env=env, text=True, bufsize=1)
+        try:                                        # whoever ends this process ends the measuring one with it
+            import signal
+            for sig in (signal.SIGTERM, signal.SIGINT):
+                signal.signal(sig, lambda signum, frame, c=child: (c.terminate(), sys.exit(128 + signum)))
+        except ValueError:                          # (not the main thread: tests)
+            pass
         last, line = None, "\n"
         for line in child.stdout:
             out.write(line)
