@@ -543,7 +543,7 @@ def supervise(cmd, env=None, out=None, attempts=2):
         try:                                        # whoever ends this process ends the measuring one with it
             import signal
             for sig in (signal.SIGTERM, signal.SIGINT):
-                signal.signal(sig, lambda signum, frame, c=child: (c.terminate(), sys.exit(128 + signum)))
+                signal.signal(sig, lambda signum, frame, c=child: (c.terminate(), c.wait(10), sys.exit(128 + signum)))
         except ValueError:                          # (not the main thread: tests)
             pass
         last, line = None, "\n"
