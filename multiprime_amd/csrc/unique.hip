@@ -710,6 +710,8 @@ struct CompactArgs {
     int g_slots, k;
     const int64_t *win_base;      // [W] first entry of the window's segment
     int32_t *win_cursor;          // [W]
+    int parts;                    // [r6] pieces a window's table is walked in (one workgroup each: table_sums_kernel's pieces)
+    const int32_t *part_base;     // [W][parts] occupied slots of the window in front of the piece (from table_sums_kernel's counts)
     uint32_t *b0, *b1, *g;
     int32_t *count, *first;
     long long cap;
@@ -769,18 +771,22 @@ __global__ __launch_bounds__(kBlock) void compact_kernel(const CompactArgs A) {
     constexpr int U = 8, NWV = kBlock / 64;                   // a thread takes U slots per pass: U independent loads in flight, one barrier pair per pass
     __shared__ int s_part[U * NWV];
     __shared__ int s_base;
-    const int w = blockIdx.x;
+    // [r6] one workgroup per PIECE of a window's table (the pieces table_sums_kernel counted: the occupied slots in front of a piece are known),
+    // not per window: at 10^6 rows the ~430 windows the gate leaves were 430 workgroups walking 1 MB each, 32 passes of two barriers — 0.43 ms
+    // for 450 MB at 5 % of the vector ALUs' time
+    const int w = blockIdx.x / A.parts, part = blockIdx.x % A.parts, per = A.g_slots / A.parts;
     if (A.win_base[w] < 0) return;                            // a window the entropy gate rejected on the device: no entries leave it
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    if (threadIdx.x == 0) s_base = 0;
+    if (threadIdx.x == 0) s_base = A.part_base[blockIdx.x];
     __syncthreads();
     const uint32_t kmask = (1u << A.k) - 1u;
-    for (int i0 = 0; i0 < A.g_slots; i0 += U * kBlock) {     // g_slots is a power of two >= kBlock: a pass is whole or the table's only one
+    const int i_end = (part + 1) * per;
+    for (int i0 = part * per; i0 < i_end; i0 += U * kBlock) {     // per is a power of two >= U * kBlock, or the whole table (parts = 1)
         unsigned long long key[U], m[U];
 #pragma unroll
         for (int u = 0; u < U; u++) {
             const int i = i0 + u * kBlock + threadIdx.x;
-            key[u] = i < A.g_slots ? A.g_key[(size_t)w * A.g_slots + i] : kNoKey;
+            key[u] = i < i_end ? A.g_key[(size_t)w * A.g_slots + i] : kNoKey;
         }
 #pragma unroll
         for (int u = 0; u < U; u++) {
@@ -1041,6 +1047,8 @@ int unique_packed(mp_ctx *c, int64_t cap, int32_t want_labels, int64_t *n_entrie
         for (int t = 0; t < T; t++)
             for (size_t w = 0; w < W; w++) extra[w] += part[(size_t)t][w];
     };
+    int parts_used = 1;
+    std::vector<int32_t> piece_used;                          // [W][parts_used] occupied slots per piece of the final tables
     for (int attempt = 0; attempt < 8; attempt++) {
         const size_t n = W * (size_t)slots;
         c->g_slots = slots;
@@ -1122,6 +1130,9 @@ int unique_packed(mp_ctx *c, int64_t cap, int32_t want_labels, int64_t *n_entrie
             used[w] = u; sums[2 * w] = t; sums[2 * w + 1] = sum;
             any_over |= over[w] != 0 || u > slots - slots / 8;
         }
+        parts_used = parts;
+        piece_used.resize(hs.size());
+        for (size_t i = 0; i < hs.size(); i++) piece_used[i] = hs[i].used;
         if (!any_over) break;
         // a window has (nearly) as many distinct k-mers as slots: start over with tables 8x the size (rare: random input)
         dev_free(c, &c->g_key, n); dev_free(c, &c->g_cnt, MP_HIST_CM64 ? 2 * n : n); dev_free(c, &c->g_min, MP_HIST_CM64 ? 1 : n); dev_free(c, &c->g_idx, n); dev_free(c, &c->g_gap, n);
@@ -1171,9 +1182,17 @@ int unique_packed(mp_ctx *c, int64_t cap, int32_t want_labels, int64_t *n_entrie
     if ((rc = dev_alloc(c, &d_cursor, W))) return rc;
     HIPCK(c, hipMemcpyAsync(c->u_wbase, dev_base.data(), sizeof(int64_t) * W, hipMemcpyHostToDevice, c->stream));
     HIPCK(c, hipMemsetAsync(d_cursor, 0, sizeof(int32_t) * W, c->stream));
-    CompactArgs CA{c->g_key, c->g_cnt, c->g_min, c->g_gap, c->g_idx, c->g_slots, c->k, c->u_wbase, d_cursor,
+    std::vector<int32_t> piece_base(piece_used.size());
+    for (size_t w = 0; w < W; w++) {
+        int32_t run = 0;
+        for (int q = 0; q < parts_used; q++) { piece_base[w * (size_t)parts_used + (size_t)q] = run; run += piece_used[w * (size_t)parts_used + (size_t)q]; }
+    }
+    int32_t *d_pbase = nullptr;
+    if ((rc = dev_alloc(c, &d_pbase, piece_base.size()))) return rc;
+    HIPCK(c, hipMemcpyAsync(d_pbase, piece_base.data(), sizeof(int32_t) * piece_base.size(), hipMemcpyHostToDevice, c->stream));
+    CompactArgs CA{c->g_key, c->g_cnt, c->g_min, c->g_gap, c->g_idx, c->g_slots, c->k, c->u_wbase, d_cursor, parts_used, d_pbase,
                    c->u_b0, c->u_b1, c->u_g, c->u_count, c->u_first, (long long)c->u_cap};
-    hipLaunchKernelGGL(compact_kernel, dim3((unsigned)W), dim3(kBlock), 0, c->stream, CA);
+    hipLaunchKernelGGL(compact_kernel, dim3((unsigned)(W * (size_t)parts_used)), dim3(kBlock), 0, c->stream, CA);
     HIPCK(c, hipGetLastError());
     if (want_labels) {
         if ((rc = dev_alloc(c, &c->labels, W * np))) return rc;
@@ -1184,6 +1203,7 @@ int unique_packed(mp_ctx *c, int64_t cap, int32_t want_labels, int64_t *n_entrie
     HIPCK(c, hipStreamSynchronize(c->stream));
     lap("unique: entries alloc+compact");
     dev_free(c, &d_cursor, W);
+    dev_free(c, &d_pbase, piece_base.size());
     c->u_n = total;
     return MP_OK;
 }

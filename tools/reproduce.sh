@@ -109,6 +109,10 @@ stats_ab)        # window statistics: G consecutive windows per workgroup (MP_ST
     MP_STATS_GROUP=$g python tools/profile_pipeline.py --rows $rows --out $O/prof_${g}_$rows 2>&1 | grep "window_stats\|^kernel"
     MP_STATS_GROUP=$g MP_TRACE_PY=1 python tools/profile_run.py $rows 18 2>&1 | grep "^{" | tail -1 | cut -c1-600
   done; done 2>&1 | tee $O/stats_ab.txt; rm -rf $O/prof_* ;;
+compact_ab)      # compact_kernel per piece of a window's table: the suites that read its entries, then the kernel rows of the core step at both depths
+  timeout 1500 python -m pytest tests/test_hist_paths.py tests/test_hip_parity.py tests/test_core_golden.py tests/test_scale_parity.py -x -q -m gpu 2>&1 | tail -3 | tee $O/pytest.txt
+  for rows in 131072 1048576; do python tools/profile_pipeline.py --rows $rows --out $O/prof_$rows 2>&1 | grep "compact\|table_sums\|hist2\|^kernel"; done 2>&1 | tee $O/compact.txt
+  MP_TRACE=1 python tools/profile_run.py 1048576 18 2>&1 | grep "unique:\|^{" | tail -8 | cut -c1-400 | tee -a $O/compact.txt; rm -rf $O/prof_* ;;
 k_sweep)         # bench.py's k_sweep block alone (the headline workload at k = 20, 22, 36), after the headline
   timeout 900 python bench.py --steps 20 --warmup 5 --no-variants --no-pipeline --no-side --no-shapes 2> $O/bench.err | tail -1 > $O/bench.json; python -c "
 import json
