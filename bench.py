@@ -343,6 +343,14 @@ def main():
                 del blocks
             progress("pipeline")
             if not a.no_pipeline:
+                # the headline's context goes first: a process of the drop-in holds ONE context, and the library divides its pool of released
+                # device blocks by the contexts alive on the device — beside the headline's 5 GB context the pipeline's constructor got every
+                # block of its 1 GB alignment from hipMalloc again (0.16 s instead of 0.05 s; tools/construct_probe.py)
+                sb = None
+                if w.ctx is not None:
+                    w.ctx.close()
+                w.ctx = ctx = None
+                torch.cuda.empty_cache()
                 res["pipeline"] = {"what": "the REAL step: the drop-in class NN_degenerate(...).run() (multiprime_amd/core.py; --no-json, coverage bitsets kept on the "
                                            "device) on the same synthetic rows, median of 5 after one warm-up; `run_ms` is run() alone (the context is kept across repetitions, as the "
                                            "--batch workers keep theirs across alignments), `construct_ms` the constructor before it (FASTA parse of a file in /dev/shm + mp_load_msa); TSV compared with the CHECKER's "
@@ -351,7 +359,9 @@ def main():
     # N = 1: the shard one GPU holds in the 8-GPU job, timed the same way (with the variant measurements)
     progress("weak_shard")
     if rank == 0 and world == 1 and not a.no_shard and rows_per_gpu != SHARD_ROWS:
-        del sb
+        sb = None
+        if w.ctx is not None:
+            w.ctx.close()
         w.ctx = ctx = None
         rows_full, w.rows = w.rows, None
         torch.cuda.empty_cache()
