@@ -97,8 +97,8 @@ void free_unique(mp_ctx *c) {
     dev_free(c, &c->labels, W * c->n_pad);
     dev_free(c, &c->u_over, W); dev_free(c, &c->u_wcount, W); dev_free(c, &c->u_wbase, W);
     dev_free(c, &c->u_total, 1);
-    dev_free(c, &c->g_key, W * (size_t)c->g_slots); dev_free(c, &c->g_cnt, W * (size_t)c->g_slots);
-    dev_free(c, &c->g_min, W * (size_t)c->g_slots); dev_free(c, &c->g_idx, W * (size_t)c->g_slots);
+    dev_free(c, &c->g_key, W * (size_t)c->g_slots); dev_free(c, &c->g_cnt, (MP_HIST_CM64 ? 2 : 1) * W * (size_t)c->g_slots);
+    dev_free(c, &c->g_min, MP_HIST_CM64 ? (size_t)1 : W * (size_t)c->g_slots); dev_free(c, &c->g_idx, W * (size_t)c->g_slots);
     dev_free(c, &c->g_gap, W * (size_t)c->g_slots);
     c->g_slots = 0;
     c->u_cap = c->u_n = 0;

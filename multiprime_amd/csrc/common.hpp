@@ -115,6 +115,10 @@ struct Lap {
     }
 };
 
+#ifndef MP_HIST_CM64
+#define MP_HIST_CM64 2                       // (unique.hip; mp_ctx::g_cnt below)
+#endif
+
 struct mp_ctx {
     char err[512] = {0};
     int dev = 0;
@@ -164,6 +168,9 @@ struct mp_ctx {
     bool pp_dirty = true;
     // unique: global hash tables [W][g_slots] (k <= 21) behind the per-workgroup LDS tables
     unsigned long long *g_key = nullptr;
+    // [r6] MP_HIST_CM64 = 2 (default): a slot's count and first row are the two halves of ONE 64-bit word of g_cnt (count << 32 | ~first row; zero =
+    // empty; g_min is a one-element stand-in) — the flush's unreturned add and max land on one line where two arrays cost two (hist2_kernel 5.77 ->
+    // 5.41 ms at 10^6 rows, compact_kernel 0.15 -> 0.125; profiles/r06_hist_experiments.txt).  0: two arrays; 1: one word updated by a CAS loop.
     uint32_t *g_cnt = nullptr, *g_min = nullptr;
     uint32_t *g_gap = nullptr;               // k = 22..31: gap words of the keys that carry a gap (unique.hip)
     int32_t *g_idx = nullptr;                // dense index of a slot's entry inside its window (labels)

@@ -99,17 +99,20 @@ __device__ inline uint32_t g_cas(uint32_t *p, uint32_t expect, uint32_t val) {
     __hip_atomic_compare_exchange_strong(p, &expect, val, __ATOMIC_RELAXED, __ATOMIC_RELAXED, MP_HIST_SCOPE);
     return expect;
 }
-// MP_HIST_CM64 (experiment, tools/build_variant.sh): count and first row of a slot in ONE 64-bit word (count << 32 | ~first row: zero = empty),
-// updated by a compare-and-swap loop — one atomic operation on the table in HBM where add + min are two
-#ifndef MP_HIST_CM64
-#define MP_HIST_CM64 0
-#endif
+// MP_HIST_CM64 (common.hpp; default 2): count and first row of a slot in ONE 64-bit word (count << 32 | ~first row: zero = empty).  2: its halves
+// updated by two unreturned 32-bit atomics (add, max) on one line; 1 (experiment): by a compare-and-swap loop; 0: two arrays, two lines
 __device__ inline void g_count_min(uint32_t *cnt_base, uint32_t *min_base, size_t at, uint32_t cnt, uint32_t row, bool fresh);
 __device__ inline void g_add(uint32_t *p, uint32_t v) { (void)__hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, MP_HIST_SCOPE); }
 __device__ inline void g_min(uint32_t *p, uint32_t v) { (void)__hip_atomic_fetch_min(p, v, __ATOMIC_RELAXED, MP_HIST_SCOPE); }
 
 __device__ inline void g_count_min(uint32_t *cnt_base, uint32_t *min_base, size_t at, uint32_t cnt, uint32_t row, bool fresh) {
-#if MP_HIST_CM64
+#if MP_HIST_CM64 == 2
+    // the two words of the slot's 64-bit (count << 32 | ~first row) by two UNRETURNED 32-bit atomics on ONE line (add on the high word, max on the low)
+    uint32_t *cm = cnt_base + 2 * at;
+    (void)__hip_atomic_fetch_max(cm, ~row, __ATOMIC_RELAXED, MP_HIST_SCOPE);
+    g_add(cm + 1, cnt);
+    (void)min_base; (void)fresh;
+#elif MP_HIST_CM64
     unsigned long long *cm = reinterpret_cast<unsigned long long *>(cnt_base) + at;
     unsigned long long old = fresh ? 0ull : *cm;
     for (;;) {
